@@ -1,0 +1,164 @@
+// ach_platform.h — the only place that knows whether the sources are being compiled by hipcc for gfx950
+// (the product: libachelous_hip.so) or by g++ against tests/hostemu (a CPU emulation used by the
+// `-m "not gpu"` tests to check kernel indexing and the engine plan; never shipped, never a fallback).
+#pragma once
+#include <cstdint>
+#include <cstddef>
+
+#if defined(ACH_HOSTEMU)
+#include "hostemu.h"
+#define ACH_LAUNCH(kern, grid, block, stream, ...) \
+    do { (void)(stream); hostemu::launch((grid), (block), [=]() { kern(__VA_ARGS__); }); } while (0)
+#define ACH_UNROLL
+namespace ach {
+struct f32x4 {
+    float v[4];
+    float& operator[](int i) { return v[i]; }
+    const float& operator[](int i) const { return v[i]; }
+};
+}  // namespace ach
+#else
+#include <hip/hip_runtime.h>
+#define ACH_LAUNCH(kern, grid, block, stream, ...) hipLaunchKernelGGL(kern, (grid), (block), 0, (stream), __VA_ARGS__)
+#define ACH_UNROLL _Pragma("unroll")
+namespace ach {
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+}  // namespace ach
+#endif
+
+namespace ach {
+
+// ---------------------------------------------------------------------------------------- storage types
+struct bf16_t { uint16_t bits; };
+
+__host__ __device__ __forceinline__ float bf16_to_f32(uint16_t b) {
+    union { uint32_t u; float f; } c;
+    c.u = uint32_t(b) << 16;
+    return c.f;
+}
+__host__ __device__ __forceinline__ uint16_t f32_to_bf16(float f) {   // round to nearest even
+    union { uint32_t u; float f; } c;
+    c.f = f;
+    uint32_t u = c.u;
+    if ((u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0;
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return uint16_t(u >> 16);
+}
+
+template <class T> struct Store;
+template <> struct Store<float> {
+    static constexpr int VEC = 4;          // elements per 16 bytes
+    __host__ __device__ static __forceinline__ float ld(const float* p) { return *p; }
+    __host__ __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+    // 4 consecutive elements (16 B aligned)
+    __device__ static __forceinline__ void ld4(const float* p, float (&o)[4]) {
+        const float4 v = *reinterpret_cast<const float4*>(p);
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+    }
+    __device__ static __forceinline__ void st4(float* p, const float (&i)[4]) {
+        *reinterpret_cast<float4*>(p) = make_float4(i[0], i[1], i[2], i[3]);
+    }
+};
+template <> struct Store<bf16_t> {
+    static constexpr int VEC = 8;
+    __host__ __device__ static __forceinline__ float ld(const bf16_t* p) { return bf16_to_f32(p->bits); }
+    __host__ __device__ static __forceinline__ void st(bf16_t* p, float v) { p->bits = f32_to_bf16(v); }
+    // 4 consecutive elements (8 B aligned)
+    __device__ static __forceinline__ void ld4(const bf16_t* p, float (&o)[4]) {
+        const uint2 v = *reinterpret_cast<const uint2*>(p);
+        o[0] = bf16_to_f32(uint16_t(v.x & 0xffffu)); o[1] = bf16_to_f32(uint16_t(v.x >> 16));
+        o[2] = bf16_to_f32(uint16_t(v.y & 0xffffu)); o[3] = bf16_to_f32(uint16_t(v.y >> 16));
+    }
+    __device__ static __forceinline__ void st4(bf16_t* p, const float (&i)[4]) {
+        uint2 v;
+        v.x = uint32_t(f32_to_bf16(i[0])) | (uint32_t(f32_to_bf16(i[1])) << 16);
+        v.y = uint32_t(f32_to_bf16(i[2])) | (uint32_t(f32_to_bf16(i[3])) << 16);
+        *reinterpret_cast<uint2*>(p) = v;
+    }
+};
+
+// unpack one 16-byte fragment (4 f32 or 8 bf16) to floats / pack it back
+template <class T> __device__ __forceinline__ void frag_unpack(const uint4& f, float* o);
+template <> __device__ __forceinline__ void frag_unpack<float>(const uint4& f, float* o) {
+    o[0] = __uint_as_float(f.x); o[1] = __uint_as_float(f.y); o[2] = __uint_as_float(f.z); o[3] = __uint_as_float(f.w);
+}
+template <> __device__ __forceinline__ void frag_unpack<bf16_t>(const uint4& f, float* o) {
+    const uint32_t w[4] = {f.x, f.y, f.z, f.w};
+    ACH_UNROLL
+    for (int i = 0; i < 4; ++i) { o[2 * i] = bf16_to_f32(uint16_t(w[i] & 0xffffu)); o[2 * i + 1] = bf16_to_f32(uint16_t(w[i] >> 16)); }
+}
+template <class T> __device__ __forceinline__ uint4 frag_pack(const float* i);
+template <> __device__ __forceinline__ uint4 frag_pack<float>(const float* i) {
+    return make_uint4(__float_as_uint(i[0]), __float_as_uint(i[1]), __float_as_uint(i[2]), __float_as_uint(i[3]));
+}
+template <> __device__ __forceinline__ uint4 frag_pack<bf16_t>(const float* i) {
+    uint32_t w[4];
+    ACH_UNROLL
+    for (int k = 0; k < 4; ++k) w[k] = uint32_t(f32_to_bf16(i[2 * k])) | (uint32_t(f32_to_bf16(i[2 * k + 1])) << 16);
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// ---------------------------------------------------------------------------------------- MFMA
+// One "k-chunk" of the 16x16 MFMA family: every lane contributes 16 bytes of A and 16 bytes of B.
+//   bf16: v_mfma_f32_16x16x32_bf16 — lane l holds A[i = l&15][k = (l>>4)*8 + j], B[k = (l>>4)*8 + j][n = l&15], j<8
+//   f32 : 4 x v_mfma_f32_16x16x4_f32 — step j uses element j of the lane's float4:  A[i = l&15][k = l>>4]
+//         (any bijection lane-group/element -> k is legal as long as A and B use the same one)
+//   C/D : lane l holds C[row = (l>>4)*4 + r][col = l&15], r<4      (cdna_hip_programming.md §3)
+template <class T> __device__ __forceinline__ void mfma16(const uint4& a, const uint4& b, f32x4& c);
+
+#if defined(ACH_HOSTEMU)
+template <class T> __device__ inline void mfma16(const uint4& a, const uint4& b, f32x4& c) {
+    constexpr int VEC = Store<T>::VEC;
+    struct { uint4 a, b; } mine{a, b};
+    hostemu::wave_deposit(&mine, sizeof(mine));
+    const int lane = hostemu::lane_id();
+    const int col = lane & 15;
+    float add[4] = {0, 0, 0, 0};
+    for (int g = 0; g < 4; ++g) {
+        uint4 fb;
+        std::memcpy(&fb, static_cast<const unsigned char*>(hostemu::wave_slot(g * 16 + col)) + 16, 16);
+        float bv[8];
+        frag_unpack<T>(fb, bv);
+        for (int r = 0; r < 4; ++r) {
+            const int row = (lane >> 4) * 4 + r;
+            uint4 fa;
+            std::memcpy(&fa, hostemu::wave_slot(g * 16 + row), 16);
+            float av[8];
+            frag_unpack<T>(fa, av);
+            for (int j = 0; j < VEC; ++j) add[r] += av[j] * bv[j];
+        }
+    }
+    hostemu::wave_release();
+    for (int r = 0; r < 4; ++r) c[r] += add[r];
+}
+#else
+typedef __bf16 bf16x8_hw __attribute__((ext_vector_type(8)));
+template <> __device__ __forceinline__ void mfma16<bf16_t>(const uint4& a, const uint4& b, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_hw, a), __builtin_bit_cast(bf16x8_hw, b), c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ void mfma16<float>(const uint4& a, const uint4& b, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+}
+#endif
+
+// ---------------------------------------------------------------------------------------- activations
+enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2, ACT_GELU = 3, ACT_SIGMOID = 4 };
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float apply_act(float x, int act) {
+    switch (act) {
+        case ACT_RELU: return x > 0.f ? x : 0.f;
+        case ACT_SILU: return x * sigmoidf_(x);
+        case ACT_GELU: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));   // exact (erf) GELU
+        case ACT_SIGMOID: return sigmoidf_(x);
+        default: return x;
+    }
+}
+
+__host__ __device__ __forceinline__ int cdiv(int a, int b) { return (a + b - 1) / b; }
+__host__ __device__ __forceinline__ long cdivl(long a, long b) { return (a + b - 1) / b; }
+
+}  // namespace ach

@@ -1,0 +1,161 @@
+// api.cpp — the extern "C" boundary of libachelous_hip.so (declared in include/achelous.h).
+// No exception crosses it: every failure becomes a negative code + a message retrievable with ach_last_error().
+#include <cstring>
+#include <string>
+
+#include "engine.h"
+
+struct ach_handle {
+    ach::EngineBase* eng = nullptr;
+    std::string err;
+};
+
+static thread_local std::string g_create_error;
+
+template <class F>
+static int guarded(ach_handle* h, F&& f) {
+    if (!h || !h->eng) return ACH_ERR_INVALID;
+    try {
+        f();
+        return ACH_OK;
+    } catch (const ach::AchError& e) {
+        h->err = e.msg;
+        return e.code;
+    } catch (const std::exception& e) {
+        h->err = e.what();
+        return ACH_ERR_INVALID;
+    } catch (...) {
+        h->err = "unknown error";
+        return ACH_ERR_INVALID;
+    }
+}
+
+extern "C" {
+
+int ach_create(const ach_config* cfg, ach_handle** out) {
+    if (!cfg || !out) return ACH_ERR_INVALID;
+    try {
+        if (cfg->backbone != ACH_BACKBONE_EDGENEXT && cfg->backbone != ACH_BACKBONE_MOBILEVIT)
+            throw ach::AchError{ACH_ERR_UNSUPPORTED, "backbone must be 'en' or 'mv'"};
+        if (cfg->phi < ACH_PHI_S0 || cfg->phi > ACH_PHI_S2) throw ach::AchError{ACH_ERR_UNSUPPORTED, "phi must be S0, S1 or S2"};
+        if (!cfg->nano_head) throw ach::AchError{ACH_ERR_UNSUPPORTED, "only nano_head=True is built"};
+        if (cfg->num_det < 1 || cfg->num_det > 59 || cfg->num_seg < 1 || cfg->pc_classes < 1 || cfg->pc_channels < 3)
+            throw ach::AchError{ACH_ERR_INVALID, "bad class / channel counts"};
+        ach_handle* h = new ach_handle();
+        h->eng = ach::make_engine(*cfg);
+        *out = h;
+        return ACH_OK;
+    } catch (const ach::AchError& e) {
+        g_create_error = e.msg;
+        return e.code;
+    } catch (...) {
+        g_create_error = "allocation failure";
+        return ACH_ERR_NOMEM;
+    }
+}
+
+void ach_destroy(ach_handle* h) {
+    if (!h) return;
+    delete h->eng;
+    delete h;
+}
+
+const char* ach_last_error(const ach_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int ach_load_weights(ach_handle* h, const ach_tensor_desc* tensors, size_t n) {
+    return guarded(h, [&] { h->eng->load(tensors, n); });
+}
+
+int ach_plan(ach_handle* h, int32_t batch) {
+    return guarded(h, [&] { h->eng->plan(batch); });
+}
+
+size_t ach_arena_bytes(const ach_handle* h) { return (h && h->eng) ? h->eng->aarena_used + h->eng->warena_used : 0; }
+
+int ach_forward(ach_handle* h, const void* image, const void* radar, const void* points, void* det3, void* det4, void* det5,
+                void* se_seg, void* lane_seg, void* pc_seg, void* stream) {
+    return guarded(h, [&] {
+        if (h->eng->ops.empty()) throw ach::AchError{ACH_ERR_INVALID, "ach_plan must precede ach_forward"};
+        if (!image || !radar || !points || !det3 || !det4 || !det5 || !se_seg || !lane_seg || !pc_seg)
+            throw ach::AchError{ACH_ERR_INVALID, "null input/output pointer"};
+        ach::IoPtrs& io = h->eng->io;
+        io.image = image; io.radar = radar; io.points = points;
+        io.det[0] = det3; io.det[1] = det4; io.det[2] = det5; io.se = se_seg; io.lane = lane_seg; io.pc = pc_seg;
+        h->eng->run(static_cast<hipStream_t>(stream));
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) throw ach::AchError{ACH_ERR_DEVICE, std::string("kernel launch: ") + hipGetErrorString(e)};
+    });
+}
+
+int ach_decode(ach_handle* h, int32_t batch, const void* det3, const void* det4, const void* det5, float* decoded, void* stream) {
+    return guarded(h, [&] {
+        if (batch <= 0 || !det3 || !det4 || !det5 || !decoded) throw ach::AchError{ACH_ERR_INVALID, "bad decode arguments"};
+        h->eng->decode(batch, det3, det4, det5, decoded, static_cast<hipStream_t>(stream));
+    });
+}
+
+size_t ach_nms_workspace_bytes(const ach_handle* h, int32_t batch) { return (h && h->eng) ? h->eng->nms_workspace_bytes(batch) : 0; }
+
+int ach_nms(ach_handle* h, int32_t batch, const float* decoded, float conf_thres, float nms_thres, int32_t max_det,
+            float* out_rows, int32_t* out_idx, int32_t* out_count, void* workspace, void* stream) {
+    return guarded(h, [&] {
+        if (batch <= 0 || max_det <= 0 || !decoded || !out_rows || !out_idx || !out_count || !workspace)
+            throw ach::AchError{ACH_ERR_INVALID, "bad nms arguments"};
+        h->eng->nms(batch, decoded, conf_thres, nms_thres, max_det, out_rows, out_idx, out_count, workspace, static_cast<hipStream_t>(stream));
+    });
+}
+
+int ach_tap_count(const ach_handle* h) { return (h && h->eng) ? int(h->eng->tap_order.size()) : 0; }
+const char* ach_tap_name(const ach_handle* h, int i) {
+    if (!h || !h->eng || i < 0 || i >= int(h->eng->tap_order.size())) return nullptr;
+    return h->eng->tap_order[size_t(i)].c_str();
+}
+int ach_tap_shape(const ach_handle* hc, const char* name, int64_t shape[4], int32_t* ndim) {
+    ach_handle* h = const_cast<ach_handle*>(hc);
+    return guarded(h, [&] {
+        if (!name || !shape || !ndim) throw ach::AchError{ACH_ERR_INVALID, "bad tap arguments"};
+        std::vector<long> s = h->eng->tap_shape(name);
+        *ndim = int32_t(s.size());
+        for (size_t i = 0; i < s.size() && i < 4; ++i) shape[i] = s[i];
+    });
+}
+int ach_read_tap(ach_handle* h, const char* name, float* host_out, size_t capacity_elems) {
+    return guarded(h, [&] {
+        if (!name || !host_out) throw ach::AchError{ACH_ERR_INVALID, "bad tap arguments"};
+        h->eng->read_tap(name, host_out, capacity_elems);
+    });
+}
+int ach_plan_launches(const ach_handle* h) { return (h && h->eng) ? int(h->eng->ops.size()) : 0; }
+const char* ach_op_name(const ach_handle* h, int i) {
+    if (!h || !h->eng || i < 0 || i >= int(h->eng->ops.size())) return nullptr;
+    return h->eng->ops[size_t(i)].name.c_str();
+}
+double ach_op_bytes(const ach_handle* h, int i) {
+    if (!h || !h->eng || i < 0 || i >= int(h->eng->ops.size())) return 0;
+    return h->eng->ops[size_t(i)].bytes;
+}
+double ach_op_flops(const ach_handle* h, int i) {
+    if (!h || !h->eng || i < 0 || i >= int(h->eng->ops.size())) return 0;
+    return h->eng->ops[size_t(i)].flops;
+}
+int ach_forward_profiled(ach_handle* h, const void* image, const void* radar, const void* points, void* det3, void* det4,
+                         void* det5, void* se_seg, void* lane_seg, void* pc_seg, void* stream, float* op_ms, size_t capacity) {
+    return guarded(h, [&] {
+        if (h->eng->ops.empty()) throw ach::AchError{ACH_ERR_INVALID, "ach_plan must precede ach_forward"};
+        if (!image || !radar || !points || !det3 || !det4 || !det5 || !se_seg || !lane_seg || !pc_seg || !op_ms)
+            throw ach::AchError{ACH_ERR_INVALID, "null pointer"};
+        ach::IoPtrs& io = h->eng->io;
+        io.image = image; io.radar = radar; io.points = points;
+        io.det[0] = det3; io.det[1] = det4; io.det[2] = det5; io.se = se_seg; io.lane = lane_seg; io.pc = pc_seg;
+        h->eng->run_profiled(static_cast<hipStream_t>(stream), op_ms, capacity);
+    });
+}
+int ach_set_probe(ach_handle* h, int op_index) { return guarded(h, [&] { h->eng->set_probe(op_index); }); }
+int ach_read_probe(ach_handle* h, float* avg_ms, int* samples) {
+    return guarded(h, [&] {
+        if (!avg_ms || !samples) throw ach::AchError{ACH_ERR_INVALID, "null pointer"};
+        h->eng->read_probe(avg_ms, samples);
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,900 @@
+// engine.cpp — weight folding / packing and the launch plan of the Achelous forward path.
+//
+// The plan is a flat list of kernel launches over a bump-allocated activation arena (288 GB of HBM: no buffer is
+// reused inside a forward, so any intermediate can be tapped by the parity tests; channel padding lanes are zeroed
+// once at plan time and never written).  Image path: NHWC.  Radar path: planar NCHW.  Point path: [B*N, C] rows.
+// Everything input-independent is folded on the host when the plan is built: eval-mode BatchNorm into the
+// preceding conv, LayerNorm affine into the following linear, layer scale into the preceding linear, the Fourier
+// positional encoding into a constant [HW, C] table.
+#include "engine.h"
+
+#include <cmath>
+#include <cstring>
+
+#include "k_detect.h"
+#include "k_gemm.h"
+#include "k_nhwc.h"
+#include "k_points.h"
+#include "k_radar.h"
+#include "k_xca.h"
+
+namespace ach {
+
+#define ACH_HIP_CHECK(expr)                                                                               \
+    do {                                                                                                  \
+        hipError_t e_ = (expr);                                                                           \
+        if (e_ != hipSuccess) throw AchError{ACH_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)}; \
+    } while (0)
+
+static inline long round_up(long v, long m) { return (v + m - 1) / m * m; }
+
+// ================================================================================================ EngineBase
+EngineBase::~EngineBase() {
+    if (warena) (void)hipFree(warena);
+    if (aarena) (void)hipFree(aarena);
+    for (auto e : probe_ev0) (void)hipEventDestroy(e);
+    for (auto e : probe_ev1) (void)hipEventDestroy(e);
+}
+
+void EngineBase::load(const ach_tensor_desc* t, size_t n) {
+    weights.clear();
+    for (size_t i = 0; i < n; ++i) {
+        if (!t[i].name || !t[i].data || t[i].ndim < 0 || t[i].ndim > 4) throw AchError{ACH_ERR_INVALID, "bad tensor descriptor"};
+        HostTensor h;
+        long numel = 1;
+        for (int d = 0; d < t[i].ndim; ++d) { h.shape.push_back(long(t[i].shape[d])); numel *= long(t[i].shape[d]); }
+        h.data.assign(t[i].data, t[i].data + numel);
+        weights[t[i].name] = std::move(h);
+    }
+}
+
+const HostTensor& EngineBase::W(const std::string& key) const {
+    auto it = weights.find(key);
+    if (it == weights.end()) throw AchError{ACH_ERR_MISSING_KEY, "state_dict key missing: " + key};
+    return it->second;
+}
+
+void* EngineBase::walloc(size_t bytes) {
+    bytes = size_t(round_up(long(bytes), 256));
+    if (measuring) { warena_used += bytes; return reinterpret_cast<void*>(uintptr_t(0x10000)); }
+    if (warena_used + bytes > warena_cap) throw AchError{ACH_ERR_NOMEM, "weight arena exhausted"};
+    void* p = warena + warena_used;
+    warena_used += bytes;
+    return p;
+}
+void* EngineBase::aalloc(size_t bytes) {
+    bytes = size_t(round_up(long(bytes), 256));
+    void* p = measuring ? reinterpret_cast<void*>(uintptr_t(0x10000) + aarena_used) : static_cast<void*>(aarena + aarena_used);
+    if (!measuring && aarena_used + bytes > aarena_cap) throw AchError{ACH_ERR_NOMEM, "activation arena exhausted"};
+    aarena_used += bytes;
+    return p;
+}
+float* EngineBase::up_f32(const std::vector<float>& v) {
+    float* d = static_cast<float*>(walloc(v.size() * sizeof(float)));
+    if (!measuring) ACH_HIP_CHECK(hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+    return d;
+}
+void EngineBase::reset_plan() {
+    probe_op = -1;
+    ops.clear(); taps.clear(); tap_order.clear();
+    warena_used = 0; aarena_used = 0;
+}
+void EngineBase::run(hipStream_t s) {
+    for (size_t i = 0; i < ops.size(); ++i) {
+        if (int(i) == probe_op) {
+            const size_t slot = size_t(probe_count % kProbeEvents);
+            (void)hipEventRecord(probe_ev0[slot], s);
+            ops[i].fn(s);
+            (void)hipEventRecord(probe_ev1[slot], s);
+            ++probe_count;
+        } else {
+            ops[i].fn(s);
+        }
+    }
+}
+void EngineBase::run_profiled(hipStream_t s, float* op_ms, size_t cap) {
+    if (cap < ops.size()) throw AchError{ACH_ERR_INVALID, "profile buffer too small"};
+    std::vector<hipEvent_t> ev(ops.size() + 1);
+    for (auto& e : ev) ACH_HIP_CHECK(hipEventCreate(&e));
+    ACH_HIP_CHECK(hipEventRecord(ev[0], s));
+    for (size_t i = 0; i < ops.size(); ++i) { ops[i].fn(s); ACH_HIP_CHECK(hipEventRecord(ev[i + 1], s)); }
+    ACH_HIP_CHECK(hipEventSynchronize(ev[ops.size()]));
+    for (size_t i = 0; i < ops.size(); ++i) ACH_HIP_CHECK(hipEventElapsedTime(&op_ms[i], ev[i], ev[i + 1]));
+    for (auto& e : ev) (void)hipEventDestroy(e);
+}
+void EngineBase::set_probe(int op_index) {
+    if (op_index >= int(ops.size())) throw AchError{ACH_ERR_INVALID, "probe index out of range"};
+    if (probe_ev0.empty()) {
+        probe_ev0.resize(kProbeEvents); probe_ev1.resize(kProbeEvents);
+        for (int i = 0; i < kProbeEvents; ++i) { ACH_HIP_CHECK(hipEventCreate(&probe_ev0[i])); ACH_HIP_CHECK(hipEventCreate(&probe_ev1[i])); }
+    }
+    probe_op = op_index;
+    probe_count = 0;
+}
+void EngineBase::read_probe(float* avg_ms, int* samples) {
+    const long n = probe_count < kProbeEvents ? probe_count : kProbeEvents;
+    double tot = 0;
+    for (long i = 0; i < n; ++i) {
+        float ms = 0.f;
+        ACH_HIP_CHECK(hipEventSynchronize(probe_ev1[size_t(i)]));
+        ACH_HIP_CHECK(hipEventElapsedTime(&ms, probe_ev0[size_t(i)], probe_ev1[size_t(i)]));
+        tot += ms;
+    }
+    *avg_ms = n ? float(tot / double(n)) : 0.f;
+    *samples = int(n);
+}
+int EngineBase::num_anchors() const {
+    const int r = cfg.resolution;
+    return (r / 8) * (r / 8) + (r / 16) * (r / 16) + (r / 32) * (r / 32);
+}
+size_t EngineBase::nms_workspace_bytes(int B) const { return size_t(B) * num_anchors() * (8 * sizeof(float) + sizeof(int)) + 256; }
+
+void EngineBase::nms(int B, const float* decoded, float conf, float iou, int max_det, float* rows, int* idx, int* count,
+                     void* workspace, hipStream_t s) {
+    const int A = num_anchors();
+    if (A > 2112) throw AchError{ACH_ERR_UNSUPPORTED, "device NMS supports up to 2112 anchors per image (resolution 320)"};
+    NmsParams p;
+    p.dec = decoded;
+    p.scratch = static_cast<float*>(workspace);
+    p.scratch_idx = reinterpret_cast<int*>(static_cast<char*>(workspace) + size_t(round_up(long(B) * A * 8 * long(sizeof(float)), 256)));
+    p.rows = rows; p.kept = idx; p.count = count;
+    p.B = B; p.A = A; p.NC5 = 5 + cfg.num_det; p.num_classes = cfg.num_det; p.max_det = max_det; p.conf = conf; p.iou = iou;
+    ACH_LAUNCH(nms_kernel, dim3(unsigned(B)), dim3(NMS_THREADS), s, p);
+}
+
+std::vector<long> EngineBase::tap_shape(const std::string& name) const {
+    auto it = taps.find(name);
+    if (it == taps.end()) throw AchError{ACH_ERR_INVALID, "unknown tap: " + name};
+    const TapInfo& t = it->second;
+    if (t.kind == 2) return t.add_eye ? std::vector<long>{t.B, t.add_eye, t.add_eye} : std::vector<long>{long(t.B) * t.H * t.W, t.C};
+    return {t.B, t.C, t.H, t.W};
+}
+
+// ================================================================================================ Engine<T>
+template <class T>
+class Engine final : public EngineBase {
+    using S = Store<T>;
+    static constexpr int VEC = S::VEC;
+    static constexpr int KC = 4 * VEC;
+
+public:
+    explicit Engine(const ach_config& c) : EngineBase(c) {}
+
+    struct A {              // NHWC activation view
+        T* p = nullptr; int B = 0, H = 0, W = 0, C = 0; long ld = 0;
+        long rows() const { return long(B) * H * W; }
+        A slice(int c0, int c) const { A s = *this; s.p = p + c0; s.C = c; return s; }
+    };
+    struct Pl {             // planar NCHW tensor (radar branch)
+        T* p = nullptr; int B = 0, C = 0, H = 0, W = 0;
+    };
+    struct Lin { std::vector<float> w, b; int N = 0, K = 0; };      // w[n*K + k]
+
+    // ------------------------------------------------------------------------------------------ helpers
+    A alloc(int B, int H, int W, int C) {
+        A a; a.B = B; a.H = H; a.W = W; a.C = C; a.ld = round_up(C, 8);
+        a.p = static_cast<T*>(aalloc(size_t(a.rows()) * a.ld * sizeof(T)));
+        return a;
+    }
+    Pl alloc_pl(int B, int C, int H, int W) {
+        Pl a; a.B = B; a.C = C; a.H = H; a.W = W;
+        a.p = static_cast<T*>(aalloc(size_t(B) * C * H * W * sizeof(T)));
+        return a;
+    }
+    float* alloc_f32(size_t n) { return static_cast<float*>(aalloc(n * sizeof(float))); }
+
+    T* up_T(const std::vector<float>& v) {
+        T* d = static_cast<T*>(walloc(v.size() * sizeof(T)));
+        if (!measuring) {
+            std::vector<T> h(v.size());
+            for (size_t i = 0; i < v.size(); ++i) S::st(&h[i], v[i]);
+            ACH_HIP_CHECK(hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+        }
+        return d;
+    }
+    void tap(const std::string& name, const A& a) {
+        TapInfo t; t.ptr = a.p; t.kind = 0; t.B = a.B; t.H = a.H; t.W = a.W; t.C = a.C; t.ld = a.ld; add_tap(name, t);
+    }
+    void tap(const std::string& name, const Pl& a) {
+        TapInfo t; t.ptr = a.p; t.kind = 1; t.B = a.B; t.H = a.H; t.W = a.W; t.C = a.C; add_tap(name, t);
+    }
+
+    // ---- linear-layer algebra on the host
+    Lin lin(const std::string& wkey, const std::string& bkey) const {
+        const HostTensor& w = W(wkey);
+        if (w.shape.size() < 2) throw AchError{ACH_ERR_MISSING_KEY, "not a matrix: " + wkey};
+        Lin l; l.N = int(w.shape[0]); l.K = int(w.numel() / w.shape[0]);
+        l.w = w.data;
+        if (!bkey.empty() && hasW(bkey)) { l.b = W(bkey).data; if (int(l.b.size()) != l.N) throw AchError{ACH_ERR_MISSING_KEY, "bias shape: " + bkey}; }
+        else l.b.assign(size_t(l.N), 0.f);
+        return l;
+    }
+    void bn_coeffs(const std::string& pfx, double eps, std::vector<float>& scale, std::vector<float>& shift) const {
+        const auto& g = W(pfx + ".weight").data; const auto& b = W(pfx + ".bias").data;
+        const auto& m = W(pfx + ".running_mean").data; const auto& v = W(pfx + ".running_var").data;
+        scale.resize(g.size()); shift.resize(g.size());
+        for (size_t i = 0; i < g.size(); ++i) {
+            const double s = double(g[i]) / std::sqrt(double(v[i]) + eps);
+            scale[i] = float(s); shift[i] = float(double(b[i]) - double(m[i]) * s);
+        }
+    }
+    void fold_bn(Lin& l, const std::string& pfx, double eps) const {            // y = bn(Wx + b)
+        std::vector<float> sc, sh; bn_coeffs(pfx, eps, sc, sh);
+        if (int(sc.size()) != l.N) throw AchError{ACH_ERR_MISSING_KEY, "BatchNorm width mismatch at " + pfx};
+        for (int n = 0; n < l.N; ++n) {
+            for (int k = 0; k < l.K; ++k) l.w[size_t(n) * l.K + k] *= sc[n];
+            l.b[n] = l.b[n] * sc[n] + sh[n];
+        }
+    }
+    void fold_ln_in(Lin& l, const std::string& pfx) const {                      // y = W(lnw * xhat + lnb) + b
+        const auto& lw = W(pfx + ".weight").data; const auto& lb = W(pfx + ".bias").data;
+        if (int(lw.size()) != l.K) throw AchError{ACH_ERR_MISSING_KEY, "LayerNorm width mismatch at " + pfx};
+        for (int n = 0; n < l.N; ++n) {
+            double acc = l.b[n];
+            for (int k = 0; k < l.K; ++k) { acc += double(l.w[size_t(n) * l.K + k]) * lb[k]; l.w[size_t(n) * l.K + k] *= lw[k]; }
+            l.b[n] = float(acc);
+        }
+    }
+    void fold_scale_out(Lin& l, const std::vector<float>& g) const {             // y = g * (Wx + b)
+        for (int n = 0; n < l.N; ++n) { for (int k = 0; k < l.K; ++k) l.w[size_t(n) * l.K + k] *= g[n]; l.b[n] *= g[n]; }
+    }
+
+    struct Packed { T* w = nullptr; float* b = nullptr; int N = 0, K = 0, NT = 1, nchunks = 0, ksteps = 0; long group_elems = 0; };
+    static int pick_nt(int N) { return N <= 16 ? 1 : (N <= 32 ? 2 : 4); }
+    Packed pack_shape(int N, int K) const {
+        Packed p; p.N = N; p.K = K; p.NT = pick_nt(N);
+        p.nchunks = cdiv(N, 16 * p.NT); p.ksteps = cdiv(K, KC);
+        p.group_elems = long(p.nchunks) * p.ksteps * p.NT * 64 * VEC;
+        return p;
+    }
+    Packed pack(const Lin& l) {
+        Packed p = pack_shape(l.N, l.K);
+        std::vector<float> blob(size_t(p.group_elems), 0.f);
+        if (!measuring)
+            for (int n = 0; n < l.N; ++n)
+                for (int k = 0; k < l.K; ++k) blob[size_t(wfrag_offset(n, k, p.NT, p.ksteps, VEC))] = l.w[size_t(n) * l.K + k];
+        p.w = up_T(blob);
+        p.b = up_f32(l.b);
+        return p;
+    }
+
+    struct GemmOpt {
+        int act = ACT_NONE; bool ln = false; float ln_eps = 0.f;
+        const A* residual = nullptr;
+        int patch = 0; int Hin = 0, Win = 0, Cin = 0;
+        void** ydyn = nullptr; int out_nchw = 0, HW = 0, Ctot = 0, coff = 0;     // NCHW scatter into a user buffer
+        unsigned* colmax = nullptr;
+        int groups = 1; long w_group_stride = 0;
+        const T* w_override = nullptr;                                            // data-dependent packed weights
+    };
+    // rows view: X.p, X.ld, rows = M ; K = pk.K
+    void gemm(const std::string& name, const T* Xp, long ldx, long M, const Packed& pk, T* Yp, long ldy, const GemmOpt& o) {
+        GemmParams g;
+        std::memset(&g, 0, sizeof(g));
+        g.X = Xp; g.ldx = ldx; g.patch = o.patch; g.Hin = o.Hin; g.Win = o.Win; g.Cin = o.Cin;
+        g.W = o.w_override ? o.w_override : pk.w; g.w_group_stride = o.w_group_stride;
+        g.bias = pk.b; g.bias_group_stride = 0;
+        g.Y = Yp; g.ldy = ldy;
+        g.R = o.residual ? o.residual->p : nullptr; g.ldr = o.residual ? o.residual->ld : 0;
+        g.colmax = o.colmax;
+        g.groups = o.groups; g.M_per_group = int(M / o.groups);
+        g.K = pk.K; g.N = pk.N; g.nchunks = pk.nchunks; g.ksteps = pk.ksteps;
+        g.act = o.act; g.ln = o.ln ? 1 : 0; g.ln_eps = o.ln_eps;
+        g.out_nchw = o.out_nchw; g.HW = o.HW; g.Ctot = o.Ctot; g.coff = o.coff;
+        g.vec_store = (ldy % 4 == 0 && (!o.residual || o.residual->ld % 4 == 0)) ? 1 : 0;
+        if (o.patch == 0 && ldx % VEC != 0) throw AchError{ACH_ERR_INVALID, name + ": activation row stride not 16-byte aligned"};
+        if (o.patch > 0 && ((o.patch * o.Cin) % VEC != 0)) throw AchError{ACH_ERR_UNSUPPORTED, name + ": patch segment not 16-byte aligned"};
+        const int P = g.M_per_group >= 4096 ? 4 : (g.M_per_group >= 1024 ? 2 : 1);
+        const int NT = pk.NT;
+        void** ydyn = o.ydyn;
+        const double esz = double(sizeof(T));
+        const double bytes = double(M) * pk.K * esz + (o.colmax ? 0.0 : double(M) * pk.N * esz) + (o.residual ? double(M) * pk.N * esz : 0.0)
+                             + double(pk.group_elems) * esz * (o.w_group_stride ? o.groups : 1);
+        add_op(name, [g, NT, P, ydyn](hipStream_t s) mutable {
+            if (ydyn) g.Y = *ydyn;
+            launch_gemm<T>(g, NT, P, s);
+        }, bytes, 2.0 * double(M) * pk.K * pk.N);
+    }
+    void gemm(const std::string& name, const A& X, const Packed& pk, const A& Y, const GemmOpt& o = GemmOpt()) {
+        gemm(name, X.p, X.ld, X.rows(), pk, Y.p, Y.ld, o);
+    }
+
+    // depthwise conv (+ folded BN) on NHWC views
+    void dwconv(const std::string& name, const A& X, const A* X2, const std::string& wkey, const std::string& bkey,
+                const std::string& bnpfx, double bneps, int ks, int stride, int act, const A& Y) {
+        const HostTensor& w = W(wkey);
+        const int C = X.C;
+        if (w.shape[0] != C || w.numel() != long(C) * ks * ks) throw AchError{ACH_ERR_MISSING_KEY, "depthwise weight shape: " + wkey};
+        if (C % 4) throw AchError{ACH_ERR_UNSUPPORTED, name + ": depthwise channel count must be a multiple of 4"};
+        std::vector<float> wt(size_t(ks) * ks * C), bias(size_t(C), 0.f), sc(size_t(C), 1.f), sh(size_t(C), 0.f);
+        if (!bkey.empty()) bias = W(bkey).data;
+        if (!bnpfx.empty()) bn_coeffs(bnpfx, bneps, sc, sh);
+        for (int c = 0; c < C; ++c) {
+            for (int t = 0; t < ks * ks; ++t) wt[size_t(t) * C + c] = w.data[size_t(c) * ks * ks + t] * sc[c];
+            bias[c] = bias[c] * sc[c] + sh[c];
+        }
+        DwParams p;
+        std::memset(&p, 0, sizeof(p));
+        p.X = X.p; p.ldx = X.ld; p.X2 = X2 ? X2->p : nullptr; p.ldx2 = X2 ? X2->ld : 0;
+        p.W = up_f32(wt); p.bias = up_f32(bias); p.Y = Y.p; p.ldy = Y.ld;
+        p.B = X.B; p.H = X.H; p.Wd = X.W; p.C = C; p.Ho = Y.H; p.Wo = Y.W; p.stride = stride; p.act = act;
+        const double px_in = double(X.B) * X.H * X.W * C * sizeof(T), px_out = double(Y.B) * Y.H * Y.W * C * sizeof(T);
+        add_op(name, [p, ks](hipStream_t s) { launch_dwconv<T>(p, ks, s); }, px_in * (X2 ? 2 : 1) + px_out, 0);
+    }
+
+    template <class K, class Pm>
+    void ew(const std::string& name, K kern, const Pm& p, long total, double bytes = 0) {      // 256-thread element-wise launch
+        const dim3 grid(unsigned(cdivl(total, 256))), block(256);
+        add_op(name, [kern, p, grid, block](hipStream_t s) { ACH_LAUNCH(kern, grid, block, s, p); }, bytes, 0);
+    }
+    void add(const std::string& name, const A& a, const A& b, const A& y) {
+        AddParams p{a.p, a.ld, b.p, b.ld, y.p, y.ld, a.rows(), a.C};
+        ew(name, add_kernel<T>, p, a.rows() * (a.C / 4), 3.0 * a.rows() * a.C * sizeof(T));
+    }
+    void copy(const std::string& name, const A& x, const A& y, const float* posenc = nullptr) {
+        CopyParams p{x.p, x.ld, y.p, y.ld, x.rows(), x.C, posenc, x.H * x.W};
+        ew(name, copy_kernel<T>, p, x.rows() * (x.C / 4), 2.0 * x.rows() * x.C * sizeof(T));
+    }
+    // per-(sample, channel) sums over H*W -> partial [B][S][2][C] ; returns S
+    int stats(const std::string& name, const A& x, float*& partial) {
+        const int HW = x.H * x.W;
+        const int S = HW >= 1024 ? 8 : (HW >= 256 ? 4 : 1);
+        partial = alloc_f32(size_t(x.B) * S * 2 * x.C);
+        StatParams p{x.p, x.ld, partial, HW, x.C, S};
+        const dim3 grid(unsigned(x.B), unsigned(S)), block(256);
+        add_op(name, [p, grid, block](hipStream_t s) { ACH_LAUNCH(chan_stats_kernel<T>, grid, block, s, p); });
+        return S;
+    }
+
+    // ------------------------------------------------------------------------------------------ EdgeNeXt (a2-a5)
+    struct EnCfg { int depths[4]; int dims[4]; int heads; int scales[4]; int ks[4]; };
+    EnCfg en_cfg() const {
+        switch (cfg.phi) {
+            case ACH_PHI_S0: return {{2, 2, 6, 2}, {32, 48, 96, 176}, 4, {2, 2, 3, 4}, {3, 5, 7, 9}};
+            case ACH_PHI_S1: return {{3, 3, 9, 3}, {32, 48, 120, 224}, 4, {2, 2, 3, 4}, {3, 5, 7, 9}};
+            default: return {{3, 3, 9, 3}, {32, 64, 144, 288}, 8, {2, 2, 3, 4}, {3, 5, 7, 9}};
+        }
+    }
+    // constant-folded Fourier positional encoding [HW][C] (edgenext_modules/layers.py:38-59)
+    float* posenc_table(const std::string& pfx, int H, int Wd, int C) {
+        const int hidden = 32;
+        const HostTensor& w = W(pfx + ".token_projection.weight");
+        const HostTensor& b = W(pfx + ".token_projection.bias");
+        std::vector<float> tab(size_t(H) * Wd * C);
+        if (!measuring) {
+            std::vector<float> feat(2 * hidden);
+            for (int y = 0; y < H; ++y)
+                for (int x = 0; x < Wd; ++x) {
+                    const float ye = float(y + 1) / (float(H) + 1e-6f) * float(2.0 * M_PI);
+                    const float xe = float(x + 1) / (float(Wd) + 1e-6f) * float(2.0 * M_PI);
+                    for (int i = 0; i < hidden; ++i) {
+                        const float dim_t = std::pow(10000.0f, float(2 * (i / 2)) / float(hidden));
+                        const float py = ye / dim_t, px = xe / dim_t;
+                        feat[i] = (i % 2 == 0) ? std::sin(py) : std::cos(py);
+                        feat[hidden + i] = (i % 2 == 0) ? std::sin(px) : std::cos(px);
+                    }
+                    for (int c = 0; c < C; ++c) {
+                        double acc = b.data[c];
+                        for (int k = 0; k < 2 * hidden; ++k) acc += double(w.data[size_t(c) * 2 * hidden + k]) * feat[k];
+                        tab[(size_t(y) * Wd + x) * C + c] = float(acc);
+                    }
+                }
+        }
+        return up_f32(tab);
+    }
+
+    A pw_mlp(const std::string& pfx, const A& xin, const A& resid) {     // LN -> Linear -> GELU -> Linear -> gamma -> + resid
+        const int C = xin.C;
+        Lin l1 = lin(pfx + ".pwconv1.weight", pfx + ".pwconv1.bias");
+        fold_ln_in(l1, pfx + ".norm");
+        Lin l2 = lin(pfx + ".pwconv2.weight", pfx + ".pwconv2.bias");
+        fold_scale_out(l2, W(pfx + ".gamma").data);
+        A h = alloc(xin.B, xin.H, xin.W, 4 * C);
+        GemmOpt o1; o1.act = ACT_GELU; o1.ln = true; o1.ln_eps = 1e-6f;
+        gemm(pfx + ".pwconv1", xin, pack(l1), h, o1);
+        A y = alloc(xin.B, xin.H, xin.W, C);
+        GemmOpt o2; o2.residual = &resid;
+        gemm(pfx + ".pwconv2", h, pack(l2), y, o2);
+        return y;
+    }
+    A conv_encoder(const std::string& pfx, const A& x, int ks) {          // conv_encoder.py:19-32
+        A d = alloc(x.B, x.H, x.W, x.C);
+        dwconv(pfx + ".dwconv", x, nullptr, pfx + ".dwconv.weight", pfx + ".dwconv.bias", "", 0, ks, 1, ACT_NONE, d);
+        return pw_mlp(pfx, d, x);
+    }
+    A sdta_encoder(const std::string& pfx, const A& x, int scales, int heads) {   // sdta_encoder.py:39-74
+        const int C = x.C;
+        const int width = std::max((C + scales - 1) / scales, C / scales);
+        const int nums = scales - 1;
+        if ((C / heads) > 48) throw AchError{ACH_ERR_UNSUPPORTED, "XCA head dimension > 48"};
+        if (width % 4) throw AchError{ACH_ERR_UNSUPPORTED, "SDTA split width must be a multiple of 4"};
+        A y = alloc(x.B, x.H, x.W, C);
+        for (int i = 0; i < nums; ++i) {
+            A xi = x.slice(i * width, width), yi = y.slice(i * width, width);
+            A prev = i > 0 ? y.slice((i - 1) * width, width) : A();
+            const std::string c = pfx + ".convs." + std::to_string(i);
+            dwconv(c, xi, i > 0 ? &prev : nullptr, c + ".weight", c + ".bias", "", 0, 3, 1, ACT_NONE, yi);
+        }
+        copy(pfx + ".split_tail", x.slice(nums * width, C - nums * width), y.slice(nums * width, C - nums * width));
+        if (hasW(pfx + ".pos_embd.token_projection.weight"))
+            copy(pfx + ".pos_embd", y, y, posenc_table(pfx + ".pos_embd", x.H, x.W, C));
+        // XCA
+        Lin lq = lin(pfx + ".xca.qkv.weight", pfx + ".xca.qkv.bias");
+        fold_ln_in(lq, pfx + ".norm_xca");
+        A qkv = alloc(x.B, x.H, x.W, 3 * C);
+        GemmOpt oq; oq.ln = true; oq.ln_eps = 1e-6f;
+        gemm(pfx + ".xca.qkv", y, pack(lq), qkv, oq);
+        const int d = C / heads, N = x.H * x.W;
+        float* attn = alloc_f32(size_t(x.B) * heads * d * d);
+        const float* temp = up_f32(W(pfx + ".xca.temperature").data);
+        XcaAttnParams pa{qkv.p, qkv.ld, attn, temp, x.B, N, C, heads};
+        {
+            const dim3 grid(unsigned(x.B * heads)), block(256);
+            add_op(pfx + ".xca.attn", [pa, grid, block](hipStream_t s) { ACH_LAUNCH(xca_attn_kernel<T>, grid, block, s, pa); });
+        }
+        A ao = alloc(x.B, x.H, x.W, C);
+        XcaApplyParams pp{qkv.p, qkv.ld, attn, ao.p, ao.ld, x.B, N, C, heads};
+        ew(pfx + ".xca.apply", xca_apply_kernel<T>, pp, ao.rows() * C);
+        Lin lp = lin(pfx + ".xca.proj.weight", pfx + ".xca.proj.bias");
+        fold_scale_out(lp, W(pfx + ".gamma_xca").data);
+        A t2 = alloc(x.B, x.H, x.W, C);
+        GemmOpt op; op.residual = &y;
+        gemm(pfx + ".xca.proj", ao, pack(lp), t2, op);
+        return pw_mlp(pfx, t2, x);
+    }
+    void edgenext(const std::string& pfx, A feats[4]) {                   // edgenext.py:73-86
+        const EnCfg ec = en_cfg();
+        const int B = batch, R = cfg.resolution;
+        A x;
+        for (int i = 0; i < 4; ++i) {
+            const std::string d = pfx + ".downsample_layers." + std::to_string(i);
+            if (i == 0) {
+                const HostTensor& w = W(d + ".0.weight");
+                if (w.shape.size() != 4 || w.shape[0] != 32 || w.shape[1] != 3 || w.shape[2] != 4) throw AchError{ACH_ERR_UNSUPPORTED, "stem shape"};
+                std::vector<float> wt(48 * 32);
+                for (int o = 0; o < 32; ++o)
+                    for (int k = 0; k < 48; ++k) wt[size_t(k) * 32 + o] = w.data[size_t(o) * 48 + k];
+                x = alloc(B, R / 4, R / 4, 32);
+                StemParams sp{nullptr, x.p, up_f32(wt), up_f32(W(d + ".0.bias").data), up_f32(W(d + ".1.weight").data),
+                              up_f32(W(d + ".1.bias").data), B, R, R, 1e-6f};
+                const dim3 grid(unsigned(cdivl(x.rows(), 256))), block(256);
+                const void** img = &io.image;
+                add_op(d, [sp, grid, block, img](hipStream_t s) mutable { sp.X = *img; ACH_LAUNCH(stem_kernel<T>, grid, block, s, sp); });
+            } else {
+                A t = alloc(x.B, x.H, x.W, x.C);
+                LnParams lp{x.p, x.ld, t.p, t.ld, up_f32(W(d + ".0.weight").data), up_f32(W(d + ".0.bias").data), x.rows(), x.C, 1e-6f};
+                const dim3 grid(unsigned(cdivl(x.rows(), 4))), block(256);
+                add_op(d + ".0", [lp, grid, block](hipStream_t s) { ACH_LAUNCH(layernorm_kernel<T>, grid, block, s, lp); });
+                // conv 2x2 stride 2: k = (dy, dx, c) over two contiguous NHWC segments
+                const HostTensor& w = W(d + ".1.weight");
+                const int Co = int(w.shape[0]), Ci = int(w.shape[1]);
+                if (Ci != x.C || x.ld != x.C) throw AchError{ACH_ERR_UNSUPPORTED, "downsample conv shape"};
+                Lin l; l.N = Co; l.K = 4 * Ci; l.w.resize(size_t(Co) * 4 * Ci); l.b = W(d + ".1.bias").data;
+                for (int o = 0; o < Co; ++o)
+                    for (int c = 0; c < Ci; ++c)
+                        for (int dy = 0; dy < 2; ++dy)
+                            for (int dx = 0; dx < 2; ++dx)
+                                l.w[size_t(o) * 4 * Ci + (dy * 2 + dx) * Ci + c] = w.data[((size_t(o) * Ci + c) * 2 + dy) * 2 + dx];
+                A y = alloc(x.B, x.H / 2, x.W / 2, Co);
+                GemmOpt o; o.patch = 2; o.Hin = x.H; o.Win = x.W; o.Cin = Ci;
+                gemm(d + ".1", t.p, t.ld, y.rows(), pack(l), y.p, y.ld, o);
+                x = y;
+            }
+            for (int j = 0; j < ec.depths[i]; ++j) {
+                const std::string b = pfx + ".stages." + std::to_string(i) + "." + std::to_string(j);
+                if (i > 0 && j == ec.depths[i] - 1) x = sdta_encoder(b, x, ec.scales[i], ec.heads);
+                else x = conv_encoder(b, x, ec.ks[i]);
+                tap("backbone.s" + std::to_string(i) + ".b" + std::to_string(j), x);
+            }
+            feats[i] = x;
+        }
+    }
+
+    // ------------------------------------------------------------------------------------------ neck (a7-a13)
+    Lin conv_bn(const std::string& conv, const std::string& bn, double eps) const { Lin l = lin(conv + ".weight", conv + ".bias"); fold_bn(l, bn, eps); return l; }
+
+    // GhostModule (ghost_conv.py:6-29) on NHWC: primary 1x1 -> channels [0,init), cheap dw3x3 -> [init, 2*init)
+    A ghost(const std::string& pfx, const A& x, int oup, bool relu) {
+        const int init = (oup + 1) / 2;
+        if (init % 4 || oup != 2 * init) throw AchError{ACH_ERR_UNSUPPORTED, pfx + ": NHWC GhostModule needs an even output width divisible by 8"};
+        A y = alloc(x.B, x.H, x.W, oup);
+        GemmOpt o; o.act = relu ? ACT_RELU : ACT_NONE;
+        gemm(pfx + ".primary", x, pack(conv_bn(pfx + ".primary_conv.0", pfx + ".primary_conv.1", 1e-5)), y.slice(0, init), o);
+        dwconv(pfx + ".cheap", y.slice(0, init), nullptr, pfx + ".cheap_operation.0.weight", "", pfx + ".cheap_operation.1", 1e-5, 3, 1,
+               relu ? ACT_RELU : ACT_NONE, y.slice(init, init));
+        return y;
+    }
+    A ghost_bottleneck(const std::string& pfx, const A& x, int out_chs) {       // ghost_conv.py:58-70, stride 1, in != out
+        A g1 = ghost(pfx + ".ghost1", x, x.C, true);
+        A g2 = ghost(pfx + ".ghost2", g1, out_chs, false);
+        A sd = alloc(x.B, x.H, x.W, x.C);
+        dwconv(pfx + ".shortcut.dw", x, nullptr, pfx + ".shortcut.0.weight", "", pfx + ".shortcut.1", 1e-5, 3, 1, ACT_NONE, sd);
+        A y = alloc(x.B, x.H, x.W, out_chs);
+        GemmOpt o; o.residual = &g2;
+        gemm(pfx + ".shortcut.pw", sd, pack(conv_bn(pfx + ".shortcut.2", pfx + ".shortcut.3", 1e-5)), y, o);
+        return y;
+    }
+    // Upsample = BaseConv 1x1 + BN(1e-3) + ReLU, bilinear x2 align_corners (ghostdualfpn.py:28-39); writes into `dst`
+    void upsample(const std::string& pfx, const A& x, const A& dst) {
+        Lin l = conv_bn(pfx + ".upsample.0.conv", pfx + ".upsample.0.bn", 1e-3);
+        A t = alloc(x.B, x.H, x.W, l.N);
+        GemmOpt o; o.act = ACT_RELU;
+        gemm(pfx + ".conv", x, pack(l), t, o);
+        UpParams p{t.p, t.ld, dst.p, dst.ld, x.B, x.H, x.W, l.N};
+        ew(pfx + ".bilinear", upsample2x_kernel<T>, p, long(x.B) * x.H * 2 * x.W * 2 * (l.N / 4), 5.0 * x.rows() * l.N * sizeof(T));
+    }
+    A shuffle_attention(const std::string& pfx, const A& x) {                   // shuffle_attention.py:48-72, G = 4
+        float* partial = nullptr;
+        const int S = stats(pfx + ".stats", x, partial);
+        float* coef = alloc_f32(size_t(x.B) * x.C * 2);
+        SaCoefParams pc{partial, S, coef, up_f32(W(pfx + ".cweight").data), up_f32(W(pfx + ".cbias").data), up_f32(W(pfx + ".sweight").data),
+                        up_f32(W(pfx + ".sbias").data), up_f32(W(pfx + ".gn.weight").data), up_f32(W(pfx + ".gn.bias").data),
+                        x.B, x.C, 4, x.H * x.W, 1e-5f};
+        ew(pfx + ".coef", sa_coef_kernel, pc, long(x.B) * x.C);
+        A y = alloc(x.B, x.H, x.W, x.C);
+        SaApplyParams pa{x.p, x.ld, y.p, y.ld, coef, x.B, x.H * x.W, x.C};
+        ew(pfx + ".apply", sa_apply_kernel<T>, pa, x.rows() * x.C);
+        return y;
+    }
+    // segmentation head = GhostModule whose outputs ARE the network output (NCHW, 2 or num_seg channels)
+    void seg_head(const std::string& pfx, const A& x, int oup, void** out) {
+        const int init = (oup + 1) / 2, HW = x.H * x.W;
+        GemmOpt o; o.act = ACT_RELU; o.ydyn = out; o.out_nchw = 1; o.HW = HW; o.Ctot = oup; o.coff = 0;
+        gemm(pfx + ".primary", x.p, x.ld, x.rows(), pack(conv_bn(pfx + ".primary_conv.0", pfx + ".primary_conv.1", 1e-5)), nullptr, 0, o);
+        const int nch = oup - init;            // cheap-operation channels that survive the [:oup] slice
+        if (nch <= 0) return;
+        const HostTensor& w = W(pfx + ".cheap_operation.0.weight");
+        std::vector<float> sc, sh; bn_coeffs(pfx + ".cheap_operation.1", 1e-5, sc, sh);
+        std::vector<float> wt(size_t(9) * nch), bias(static_cast<size_t>(nch), 0.f);
+        for (int j = 0; j < nch; ++j) { for (int t = 0; t < 9; ++t) wt[size_t(t) * nch + j] = w.data[size_t(j) * 9 + t] * sc[j]; bias[j] = sh[j]; }
+        DwPlaneParams p{nullptr, nullptr, up_f32(wt), up_f32(bias), x.B, x.H, x.W, oup, oup, 0, init, nch, ACT_RELU};
+        const dim3 grid(unsigned(cdivl(long(x.B) * nch * HW, 256))), block(256);
+        add_op(pfx + ".cheap", [p, grid, block, out](hipStream_t s) mutable { p.X = *out; p.Y = *out; ACH_LAUNCH(dwplane3x3_kernel<T>, grid, block, s, p); });
+    }
+
+    void neck(A m[4], A q[3]) {                                                  // ghostdualfpn.py:156-200
+        const std::string f = "image_radar_encoder.fpn";
+        const int* w = widths();
+        A m3 = m[1], m4 = m[2], m5 = m[3];
+        tap("map2", m[0]); tap("map3", m3); tap("map4", m4); tap("map5", m5);
+        // SPP (spp.py:41-67)
+        const int c_ = w[3] / 2;
+        if (c_ % 4) throw AchError{ACH_ERR_UNSUPPORTED, "SPP hidden width must be a multiple of 4"};
+        A cat5 = alloc(m5.B, m5.H, m5.W, 4 * c_);
+        { GemmOpt o; o.act = ACT_SILU; gemm(f + ".spp.cv1", m5, pack(conv_bn(f + ".spp.cv1.conv", f + ".spp.cv1.bn", 1e-3)), cat5.slice(0, c_), o); }
+        SppParams sp{cat5.p, cat5.ld, m5.B, m5.H, m5.W, c_};
+        ew(f + ".spp.pool", spp_pool_kernel<T>, sp, m5.rows() * (c_ / 4));
+        A p5 = alloc(m5.B, m5.H, m5.W, w[3]);
+        { GemmOpt o; o.act = ACT_SILU; gemm(f + ".spp.cv2", cat5, pack(conv_bn(f + ".spp.cv2.conv", f + ".spp.cv2.bn", 1e-3)), p5, o); }
+        tap("spp", p5);
+        // top-down
+        A c4 = alloc(m4.B, m4.H, m4.W, 2 * w[2]);
+        upsample(f + ".upsample_5_to_4", p5, c4.slice(0, w[2]));
+        copy(f + ".cat4", m4, c4.slice(w[2], w[2]));
+        A p4 = ghost_bottleneck(f + ".ghost_5_to_4", c4, w[2]);
+        A c3 = alloc(m3.B, m3.H, m3.W, 2 * w[1]);
+        upsample(f + ".upsample_4_to_3", p4, c3.slice(0, w[1]));
+        copy(f + ".cat3", m3, c3.slice(w[1], w[1]));
+        A p3 = ghost_bottleneck(f + ".ghost_4_to_3", c3, w[1]);
+        tap("fpn4", p4); tap("fpn3", p3);
+        // two segmentation decoders
+        const char* names[2] = {"lane", "se"};
+        const char* sa[2] = {"stage_3_lane_seg", "stage_3_semantic_seg"};
+        const int oups[2] = {2, cfg.num_seg};
+        void** outs[2] = {&io.lane, &io.se};
+        for (int d = 0; d < 2; ++d) {
+            const std::string n = names[d];
+            A y = shuffle_attention(f + "." + sa[d], p3);
+            tap(n + ".sa", y);
+            const char* lv[3] = {"3_to_2", "2_to_1", "1_to_0"};
+            const int cw[3] = {w[1], w[0], w[0]};
+            for (int l = 0; l < 3; ++l) {
+                A u = alloc(y.B, y.H * 2, y.W * 2, cw[l]);
+                upsample(f + "." + n + "_seg_" + lv[l], y, u);
+                y = ghost(f + "." + n + "_seg_ghost_" + lv[l], u, cw[l], true);
+                tap(n + "." + lv[l], y);
+            }
+            seg_head(f + "." + n + "_seg_head", y, oups[d], outs[d]);
+        }
+        // residual FPN outputs (ghostdualfpn.py:200)
+        q[0] = alloc(p3.B, p3.H, p3.W, p3.C); add(f + ".q3", p3, m3, q[0]);
+        q[1] = alloc(p4.B, p4.H, p4.W, p4.C); add(f + ".q4", p4, m4, q[1]);
+        q[2] = alloc(p5.B, p5.H, p5.W, p5.C); add(f + ".q5", p5, m5, q[2]);
+    }
+    const int* widths() const {
+        static const int w0[4] = {32, 48, 96, 176}, w1[4] = {32, 48, 120, 224}, w2[4] = {32, 64, 144, 288};
+        return cfg.phi == ACH_PHI_S0 ? w0 : (cfg.phi == ACH_PHI_S1 ? w1 : w2);
+    }
+
+    // ------------------------------------------------------------------------------------------ radar (a14-a15)
+    void rcnet(Pl outs[3]) {                                                     // RadarEncoder.py:38-109
+        const int* w = widths();
+        const int chans[9] = {3, w[0] / 4, w[0] / 4, w[0] / 4, w[1] / 4, w[1] / 4, w[2] / 4, w[2] / 4, w[3] / 4};
+        const bool down[8] = {true, true, false, true, false, true, false, true};
+        const int B = batch;
+        int H = cfg.resolution;
+        Pl x; x.B = B; x.C = 3; x.H = H; x.W = H; x.p = nullptr;                 // block 0 reads the user's radar map
+        for (int i = 0; i < 8; ++i) {
+            const std::string pfx = "image_radar_encoder.radar_encoder.rc_blocks." + std::to_string(i);
+            const std::string d = pfx + ".radar_conv.deformable_conv";
+            const int C = chans[i], Co = chans[i + 1];
+            // offsets + modulators
+            std::vector<float> wom(size_t(27) * C * 9), bom(27);
+            const HostTensor& wo = W(d + ".offset_conv.weight"); const HostTensor& wm = W(d + ".modulator_conv.weight");
+            if (wo.numel() != 18L * C * 9 || wm.numel() != 9L * C * 9) throw AchError{ACH_ERR_MISSING_KEY, "deformable conv shapes at " + d};
+            std::copy(wo.data.begin(), wo.data.end(), wom.begin());
+            std::copy(wm.data.begin(), wm.data.end(), wom.begin() + 18L * C * 9);
+            std::copy(W(d + ".offset_conv.bias").data.begin(), W(d + ".offset_conv.bias").data.end(), bom.begin());
+            std::copy(W(d + ".modulator_conv.bias").data.begin(), W(d + ".modulator_conv.bias").data.end(), bom.begin() + 18);
+            Pl pooled = alloc_pl(B, C, H, H);
+            float* offmask = alloc_f32(size_t(B) * 27 * H * H);
+            OffMaskParams po{x.p, pooled.p, offmask, up_f32(wom), up_f32(bom), B, C, H, H};
+            const dim3 grid(unsigned(cdivl(long(B) * H * H, 256))), block(256);
+            const void** rin = (i == 0) ? &io.radar : nullptr;
+            add_op(pfx + ".offmask", [po, grid, block, rin](hipStream_t s) mutable { if (rin) po.X = *rin; ACH_LAUNCH(radar_offmask_kernel<T>, grid, block, s, po); });
+            // deformable conv + 1x1 + BN + ReLU + residual
+            std::vector<float> sc, sh; bn_coeffs(pfx + ".norm", 1e-5, sc, sh);
+            const HostTensor& w1 = W(pfx + ".weight_conv1.weight"); const HostTensor& b1 = W(pfx + ".weight_conv1.bias");
+            std::vector<float> w1f(size_t(C) * C), b1f(static_cast<size_t>(C), 0.f);
+            for (int o = 0; o < C; ++o) { for (int c = 0; c < C; ++c) w1f[size_t(o) * C + c] = w1.data[size_t(o) * C + c] * sc[o]; b1f[o] = b1.data[o] * sc[o] + sh[o]; }
+            Pl y = alloc_pl(B, C, H, H);
+            DeformParams pd{pooled.p, offmask, x.p, y.p, up_f32(W(d + ".regular_conv.weight").data), up_f32(w1f), up_f32(b1f), B, H, H};
+            add_op(pfx + ".deform", [pd, C, rin](hipStream_t s) mutable {
+                if (rin) pd.res = *rin;
+                launch_radar_deform<T>(pd, C, s);
+            });
+            if (C != 3 && C != 8 && C != 12 && C != 16 && C != 24 && C != 30 && C != 36) throw AchError{ACH_ERR_UNSUPPORTED, "radar width"};
+            // weight_conv2
+            const int k = down[i] ? 3 : 1, st = down[i] ? 2 : 1;
+            const int Ho = down[i] ? (H + 2 - 3) / 2 + 1 : H;
+            Pl z = alloc_pl(B, Co, Ho, Ho);
+            ConvPlanarParams pc{y.p, z.p, up_f32(W(pfx + ".weight_conv2.weight").data), up_f32(W(pfx + ".weight_conv2.bias").data),
+                                B, C, H, H, Co, Ho, Ho, k, st, ACT_NONE};
+            const dim3 g2(unsigned(cdivl(long(B) * Ho * Ho, 256)), unsigned(cdiv(Co, 8)));
+            add_op(pfx + ".conv2", [pc, g2, block](hipStream_t s) { ACH_LAUNCH((conv_planar_kernel<T, 8>), g2, block, s, pc); });
+            x = z; H = Ho;
+            tap("radar.b" + std::to_string(i), x);
+            if (i == 3) outs[0] = x;
+            if (i == 5) outs[1] = x;
+            if (i == 7) outs[2] = x;
+        }
+        tap("r3", outs[0]); tap("r4", outs[1]); tap("r5", outs[2]);
+    }
+
+    // ------------------------------------------------------------------------------------------ fusion (a16)
+    A fuse(int stage, const A& img, const Pl& rad) {                             // IREncoder.py:79-89
+        const std::string e = "image_radar_encoder";
+        const std::string st = std::to_string(stage);
+        const int Ci = img.C, Cr = rad.C, HW = img.H * img.W;
+        std::vector<float> sc, sh; bn_coeffs(e + ".norm_stage" + st, 1e-5, sc, sh);
+        if (int(sc.size()) != Ci + Cr) throw AchError{ACH_ERR_MISSING_KEY, "fusion norm width"};
+        A y = alloc(img.B, img.H, img.W, Ci + Cr);
+        // image half
+        float* pi = nullptr;
+        const int S = stats(e + ".eca_img" + st + ".stats", img, pi);
+        const HostTensor& wi = W(e + ".channel_attn_stage" + st + ".0.conv.weight");
+        float* sci = alloc_f32(size_t(img.B) * Ci);
+        EcaParams ei{pi, S, up_f32(wi.data), int(wi.numel()), up_f32(std::vector<float>(sc.begin(), sc.begin() + Ci)), sci, img.B, Ci, HW};
+        ew(e + ".eca_img" + st, eca_scale_kernel, ei, long(img.B) * Ci);
+        FuseParams fi{img.p, img.ld, 0, y.p, y.ld, sci, up_f32(std::vector<float>(sh.begin(), sh.begin() + Ci)), img.B, HW, Ci};
+        ew(e + ".fuse_img" + st, fuse_scale_kernel<T>, fi, img.rows() * Ci);
+        // radar half (planar input)
+        float* pr = alloc_f32(size_t(rad.B) * 2 * Cr);
+        StatNchwParams sr{rad.p, pr, HW, Cr};
+        { const dim3 grid(unsigned(rad.B * Cr)), block(256); add_op(e + ".eca_rad" + st + ".stats", [sr, grid, block](hipStream_t s) { ACH_LAUNCH(chan_stats_nchw_kernel<T>, grid, block, s, sr); }); }
+        const HostTensor& wr = W(e + ".channel_attn_stage" + st + ".1.conv.weight");
+        float* scr = alloc_f32(size_t(rad.B) * Cr);
+        EcaParams er{pr, 1, up_f32(wr.data), int(wr.numel()), up_f32(std::vector<float>(sc.begin() + Ci, sc.end())), scr, rad.B, Cr, HW};
+        ew(e + ".eca_rad" + st, eca_scale_kernel, er, long(rad.B) * Cr);
+        A yr = y.slice(Ci, Cr);
+        FuseParams fr{rad.p, 0, 1, yr.p, yr.ld, scr, up_f32(std::vector<float>(sh.begin() + Ci, sh.end())), rad.B, HW, Cr};
+        ew(e + ".fuse_rad" + st, fuse_scale_kernel<T>, fr, long(rad.B) * HW * Cr);
+        tap("p" + st, y);
+        return y;
+    }
+
+    // ------------------------------------------------------------------------------------------ head (a17)
+    void head(A p[3]) {                                                          // decouplehead.py:58-103
+        const int NC5 = 5 + cfg.num_det;
+        for (int k = 0; k < 3; ++k) {
+            const std::string ks = std::to_string(k);
+            const A& x = p[k];
+            const int HW = x.H * x.W;
+            Lin ls = conv_bn("det_head.stems." + ks + ".conv", "det_head.stems." + ks + ".bn", 1e-3);
+            const int base = ls.N;
+            A st = alloc(x.B, x.H, x.W, base);
+            { GemmOpt o; o.act = ACT_RELU; gemm("det_head.stems." + ks, x, pack(ls), st, o); }
+            A feat[2];
+            const char* br[2] = {"cls_convs", "reg_convs"};
+            for (int b = 0; b < 2; ++b) {
+                A cur = st;
+                for (int j = 0; j < 2; ++j) {
+                    const std::string c = std::string("det_head.") + br[b] + "." + ks + "." + std::to_string(j);
+                    A d = alloc(x.B, x.H, x.W, base);
+                    dwconv(c + ".dconv", cur, nullptr, c + ".conv.dconv.weight", "", "", 0, 5, 1, ACT_NONE, d);
+                    A y = alloc(x.B, x.H, x.W, base);
+                    GemmOpt o; o.act = ACT_RELU;
+                    gemm(c + ".pconv", d, pack(conv_bn(c + ".conv.pconv", c + ".bn", 1e-3)), y, o);
+                    cur = y;
+                }
+                feat[b] = cur;
+            }
+            // predictions straight into the NCHW output map: [reg 4 | obj 1 | cls num_det]
+            Lin lr = lin("det_head.reg_preds." + ks + ".weight", "det_head.reg_preds." + ks + ".bias");
+            Lin lo = lin("det_head.obj_preds." + ks + ".weight", "det_head.obj_preds." + ks + ".bias");
+            Lin lro; lro.N = 5; lro.K = lr.K; lro.w = lr.w; lro.w.insert(lro.w.end(), lo.w.begin(), lo.w.end()); lro.b = lr.b; lro.b.push_back(lo.b[0]);
+            GemmOpt o1; o1.ydyn = &io.det[k]; o1.out_nchw = 1; o1.HW = HW; o1.Ctot = NC5; o1.coff = 0;
+            gemm("det_head.regobj_preds." + ks, feat[1].p, feat[1].ld, feat[1].rows(), pack(lro), nullptr, 0, o1);
+            GemmOpt o2 = o1; o2.coff = 5;
+            gemm("det_head.cls_preds." + ks, feat[0].p, feat[0].ld, feat[0].rows(),
+                 pack(lin("det_head.cls_preds." + ks + ".weight", "det_head.cls_preds." + ks + ".bias")), nullptr, 0, o2);
+        }
+    }
+
+    // ------------------------------------------------------------------------------------------ PointNet (a18)
+    struct Rows { T* p = nullptr; long rows = 0; int C = 0; long ld = 0; };
+    Rows alloc_rows(long rows, int C) { Rows r; r.rows = rows; r.C = C; r.ld = round_up(C, 8); r.p = static_cast<T*>(aalloc(size_t(rows) * r.ld * sizeof(T))); return r; }
+    Lin lin_bn1d(const std::string& conv, const std::string& bn) const { Lin l = lin(conv + ".weight", conv + ".bias"); if (!bn.empty()) fold_bn(l, bn, 1e-5); return l; }
+    Rows pc_layer(const std::string& name, const Rows& x, const Lin& l, int act) {
+        Rows y = alloc_rows(x.rows, l.N);
+        GemmOpt o; o.act = act;
+        gemm(name, x.p, x.ld, x.rows, pack(l), y.p, y.ld, o);
+        return y;
+    }
+    // shared MLP + max over the N points of every sample -> [B, C]
+    Rows pc_layer_max(const std::string& name, const Rows& x, const Lin& l, int act, int B) {
+        unsigned* enc = static_cast<unsigned*>(aalloc(size_t(B) * l.N * sizeof(unsigned)));
+        const size_t bytes = size_t(B) * l.N * sizeof(unsigned);
+        add_op(name + ".init", [enc, bytes](hipStream_t s) { (void)hipMemsetAsync(enc, 0, bytes, s); });
+        GemmOpt o; o.act = act; o.colmax = enc; o.groups = B;
+        gemm(name, x.p, x.ld, x.rows, pack(l), nullptr, 0, o);
+        Rows y = alloc_rows(B, l.N);
+        const long total = long(B) * l.N;
+        const int N = l.N; const long ld = y.ld; T* yp = y.p;
+        const dim3 grid(unsigned(cdivl(total, 256))), block(256);
+        add_op(name + ".max", [enc, yp, N, ld, total, grid, block](hipStream_t s) { ACH_LAUNCH(colmax_decode_kernel<T>, grid, block, s, enc, yp, N, ld, total); });
+        return y;
+    }
+    Rows stn(const std::string& pfx, const Rows& x, int B) {                     // pointnet_utils.py:27-45,67-85 (without + I)
+        Rows h = pc_layer(pfx + ".conv1", x, lin_bn1d(pfx + ".conv1", pfx + ".bn1"), ACT_RELU);
+        h = pc_layer(pfx + ".conv2", h, lin_bn1d(pfx + ".conv2", pfx + ".bn2"), ACT_RELU);
+        Rows g = pc_layer_max(pfx + ".conv3", h, lin_bn1d(pfx + ".conv3", pfx + ".bn3"), ACT_RELU, B);
+        g = pc_layer(pfx + ".fc1", g, lin_bn1d(pfx + ".fc1", pfx + ".bn4"), ACT_RELU);
+        g = pc_layer(pfx + ".fc2", g, lin_bn1d(pfx + ".fc2", pfx + ".bn5"), ACT_RELU);
+        return pc_layer(pfx + ".fc3", g, lin_bn1d(pfx + ".fc3", ""), ACT_NONE);
+    }
+    void pointnet() {                                                            // pointnet_sem_seg.py:26-37
+        const std::string p = "pc_seg_model";
+        const int B = batch, N = cfg.num_points, D = cfg.pc_channels;
+        if (N % 16) throw AchError{ACH_ERR_UNSUPPORTED, "num_points must be a multiple of 16"};
+        Rows x0 = alloc_rows(long(B) * N, D);
+        {
+            PcPrepParams pp{nullptr, x0.p, B, D, N, x0.ld};
+            const dim3 grid(unsigned(cdivl(long(B) * N * x0.ld, 256))), block(256);
+            const void** pin = &io.points;
+            add_op(p + ".prep", [pp, grid, block, pin](hipStream_t s) mutable { pp.X = *pin; ACH_LAUNCH(pc_prep_kernel<T>, grid, block, s, pp); });
+        }
+        Rows t9 = stn(p + ".feat.stn", x0, B);
+        { TapInfo t; t.ptr = t9.p; t.kind = 2; t.B = B; t.H = 1; t.W = 1; t.C = 9; t.ld = t9.ld; t.add_eye = 3; add_tap("pc.trans", t); }
+        Rows x1 = alloc_rows(long(B) * N, D);
+        { PcT3Params q{x0.p, x0.ld, t9.p, t9.ld, x1.p, x1.ld, B, N, D}; ew(p + ".feat.apply_t3", pc_apply_t3_kernel<T>, q, long(B) * N); }
+        Rows f1 = pc_layer(p + ".feat.conv1", x1, lin_bn1d(p + ".feat.conv1", p + ".feat.bn1"), ACT_RELU);
+        const int kf = f1.C;                                                     // 32
+        Rows tf = stn(p + ".feat.fstn", f1, B);
+        { TapInfo t; t.ptr = tf.p; t.kind = 2; t.B = B; t.H = 1; t.W = 1; t.C = kf * kf; t.ld = tf.ld; t.add_eye = kf; add_tap("pc.trans_feat", t); }
+        // per-sample kf x kf transform as packed MFMA weights
+        Packed pk = pack_shape(kf, kf);
+        T* wp = static_cast<T*>(aalloc(size_t(B) * pk.group_elems * sizeof(T)));
+        pk.b = up_f32(std::vector<float>(static_cast<size_t>(kf), 0.f));
+        { PcPackParams q{tf.p, tf.ld, wp, pk.group_elems, B, kf, pk.NT, pk.ksteps}; ew(p + ".feat.pack_tf", pc_pack_transform_kernel<T>, q, long(B) * kf * kf); }
+        Rows pf = alloc_rows(long(B) * N, kf);
+        { GemmOpt o; o.groups = B; o.w_group_stride = pk.group_elems; o.w_override = wp; gemm(p + ".feat.bmm_tf", f1.p, f1.ld, f1.rows, pk, pf.p, pf.ld, o); }
+        Rows h = pc_layer(p + ".feat.conv2", pf, lin_bn1d(p + ".feat.conv2", p + ".feat.bn2"), ACT_RELU);
+        Rows g = pc_layer_max(p + ".feat.conv3", h, lin_bn1d(p + ".feat.conv3", p + ".feat.bn3"), ACT_NONE, B);
+        { TapInfo t; t.ptr = g.p; t.kind = 2; t.B = B; t.H = 1; t.W = 1; t.C = g.C; t.ld = g.ld; add_tap("pc.global", t); }
+        Rows cat = alloc_rows(long(B) * N, g.C + kf);
+        { PcConcatParams q{g.p, g.ld, pf.p, pf.ld, cat.p, cat.ld, B, N, g.C, kf}; ew(p + ".concat", pc_concat_kernel<T>, q, long(B) * N * (g.C + kf)); }
+        Rows y = pc_layer(p + ".conv1", cat, lin_bn1d(p + ".conv1", p + ".bn1"), ACT_RELU);
+        y = pc_layer(p + ".conv2", y, lin_bn1d(p + ".conv2", p + ".bn2"), ACT_RELU);
+        y = pc_layer(p + ".conv3", y, lin_bn1d(p + ".conv3", p + ".bn3"), ACT_RELU);
+        y = pc_layer(p + ".conv4", y, lin_bn1d(p + ".conv4", ""), ACT_NONE);
+        {
+            LsmParams q{y.p, y.ld, nullptr, long(B) * N, cfg.pc_classes};
+            const dim3 grid(unsigned(cdivl(long(B) * N, 256))), block(256);
+            void** out = &io.pc;
+            add_op(p + ".log_softmax", [q, grid, block, out](hipStream_t s) mutable { q.Y = *out; ACH_LAUNCH(log_softmax_kernel<T>, grid, block, s, q); });
+        }
+    }
+
+    // ------------------------------------------------------------------------------------------ plan (a1)
+    void build() {
+        if (cfg.backbone != ACH_BACKBONE_EDGENEXT) throw AchError{ACH_ERR_UNSUPPORTED, "MobileViT backbone is not built yet (SURVEY.md §8 a6)"};
+        if (cfg.resolution % 32 || cfg.resolution < 64) throw AchError{ACH_ERR_INVALID, "resolution must be a multiple of 32"};
+        pointnet();
+        A m[4];
+        edgenext("image_radar_encoder.fpn.backbone", m);
+        A q[3];
+        neck(m, q);
+        Pl r[3];
+        rcnet(r);
+        tap("q3", q[0]); tap("q4", q[1]); tap("q5", q[2]);
+        A p[3] = {fuse(3, q[0], r[0]), fuse(4, q[1], r[1]), fuse(5, q[2], r[2])};
+        head(p);
+    }
+
+    void plan(int B) override {
+        if (B <= 0) throw AchError{ACH_ERR_INVALID, "batch must be positive"};
+        if (weights.empty()) throw AchError{ACH_ERR_INVALID, "ach_load_weights must precede ach_plan"};
+        batch = B;
+        reset_plan();
+        measuring = true;
+        build();
+        const size_t wneed = warena_used + (1 << 20), aneed = aarena_used + (1 << 20);
+        measuring = false;
+        if (wneed > warena_cap) { if (warena) (void)hipFree(warena); warena = nullptr; ACH_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&warena), wneed)); warena_cap = wneed; }
+        if (aneed > aarena_cap) { if (aarena) (void)hipFree(aarena); aarena = nullptr; ACH_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&aarena), aneed)); aarena_cap = aneed; }
+        reset_plan();
+        build();
+        ACH_HIP_CHECK(hipMemset(aarena, 0, aarena_used));      // channel padding lanes stay zero for the lifetime of the plan
+        ACH_HIP_CHECK(hipDeviceSynchronize());
+    }
+
+    void decode(int B, const void* d3, const void* d4, const void* d5, float* out, hipStream_t s) override {
+        DecodeParams p;
+        const int r = cfg.resolution;
+        p.det[0] = d3; p.det[1] = d4; p.det[2] = d5;
+        p.h[0] = p.w[0] = r / 8; p.h[1] = p.w[1] = r / 16; p.h[2] = p.w[2] = r / 32;
+        p.out = out; p.B = B; p.NC5 = 5 + cfg.num_det; p.A = num_anchors(); p.in_h = float(r); p.in_w = float(r);
+        ACH_LAUNCH(decode_kernel<T>, dim3(unsigned(cdivl(long(B) * p.A, 256))), dim3(256), s, p);
+    }
+};
+
+// ================================================================================================ taps
+void EngineBase::read_tap(const std::string& name, float* out, size_t cap) {
+    auto it = taps.find(name);
+    if (it == taps.end()) throw AchError{ACH_ERR_INVALID, "unknown tap: " + name};
+    const TapInfo& t = it->second;
+    const bool bf = cfg.dtype == ACH_DTYPE_BF16 && !t.is_f32;
+    const size_t esz = bf ? 2 : 4;
+    ACH_HIP_CHECK(hipDeviceSynchronize());
+    auto fetch = [&](size_t elems) {
+        std::vector<unsigned char> raw(elems * esz);
+        ACH_HIP_CHECK(hipMemcpy(raw.data(), t.ptr, raw.size(), hipMemcpyDeviceToHost));
+        std::vector<float> f(elems);
+        if (bf) for (size_t i = 0; i < elems; ++i) { uint16_t b; std::memcpy(&b, &raw[i * 2], 2); f[i] = bf16_to_f32(b); }
+        else std::memcpy(f.data(), raw.data(), elems * 4);
+        return f;
+    };
+    if (t.kind == 0) {
+        const size_t rows = size_t(t.B) * t.H * t.W, HW = size_t(t.H) * t.W;
+        if (cap < rows * t.C) throw AchError{ACH_ERR_INVALID, "tap buffer too small"};
+        // a view may start inside a wider row: fetch up to the last element it covers
+        std::vector<float> f = fetch((rows - 1) * size_t(t.ld) + t.C);
+        for (size_t b = 0; b < size_t(t.B); ++b)
+            for (size_t p = 0; p < HW; ++p)
+                for (int c = 0; c < t.C; ++c) out[(b * t.C + c) * HW + p] = f[(b * HW + p) * t.ld + c];
+    } else if (t.kind == 1) {
+        const size_t n = size_t(t.B) * t.C * t.H * t.W;
+        if (cap < n) throw AchError{ACH_ERR_INVALID, "tap buffer too small"};
+        std::vector<float> f = fetch(n);
+        std::memcpy(out, f.data(), n * 4);
+    } else if (t.kind == 2) {
+        const size_t rows = size_t(t.B) * t.H * t.W;
+        if (cap < rows * t.C) throw AchError{ACH_ERR_INVALID, "tap buffer too small"};
+        std::vector<float> f = fetch((rows - 1) * size_t(t.ld) + t.C);
+        for (size_t r = 0; r < rows; ++r)
+            for (int c = 0; c < t.C; ++c) {
+                float v = f[r * t.ld + c];
+                if (t.add_eye && (c / t.add_eye) == (c % t.add_eye)) v += 1.0f;
+                out[r * t.C + c] = v;
+            }
+    } else throw AchError{ACH_ERR_INVALID, "tap not readable"};
+}
+
+EngineBase* make_engine(const ach_config& cfg) {
+    if (cfg.dtype == ACH_DTYPE_F32) return new Engine<float>(cfg);
+    if (cfg.dtype == ACH_DTYPE_BF16) return new Engine<bf16_t>(cfg);
+    throw AchError{ACH_ERR_INVALID, "unknown dtype"};
+}
+
+}  // namespace ach

@@ -1,0 +1,100 @@
+// engine.h — host side of the engine: state-dict ingestion, constant folding, weight packing, activation arena
+// and the launch plan.  Compiled by hipcc into libachelous_hip.so (and by g++ against tests/hostemu for the CPU
+// emulation used by the unit tests).  See include/achelous.h for the C ABI and DESIGN.md for the data layout.
+#pragma once
+#include <functional>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/achelous.h"
+#include "ach_platform.h"
+
+namespace ach {
+
+struct AchError {
+    int code;
+    std::string msg;
+};
+
+struct HostTensor {
+    std::vector<float> data;
+    std::vector<long> shape;
+    long numel() const { long n = 1; for (long s : shape) n *= s; return n; }
+};
+
+struct TapInfo {
+    const void* ptr = nullptr;
+    int kind = 0;                 // 0: NHWC activation [B,H,W,C] (ld) -> NCHW ; 1: NCHW dense ; 2: rows [R, C] (ld) ; 3: user output (not readable)
+    int B = 0, H = 0, W = 0, C = 0;
+    long ld = 0;
+    int is_f32 = 0;               // buffer holds fp32 regardless of the engine dtype
+    int add_eye = 0;              // rows kind: add identity of this size (PointNet transforms are stored without +I)
+};
+
+struct Op {
+    std::string name;
+    std::function<void(hipStream_t)> fn;
+    double bytes = 0;             // algorithmic HBM bytes of one launch: inputs read once + outputs written once + weights
+    double flops = 0;             // 2 * MACs of one launch (dense contractions only)
+};
+
+struct IoPtrs {
+    const void* image = nullptr; const void* radar = nullptr; const void* points = nullptr;
+    void* det[3] = {nullptr, nullptr, nullptr};
+    void* se = nullptr; void* lane = nullptr; void* pc = nullptr;
+};
+
+class EngineBase {
+public:
+    explicit EngineBase(const ach_config& c) : cfg(c) {}
+    virtual ~EngineBase();
+    ach_config cfg;
+    std::map<std::string, HostTensor> weights;
+    std::string last_error;
+
+    // device memory owned by the engine
+    char* warena = nullptr; size_t warena_cap = 0, warena_used = 0;      // packed weights / constants
+    char* aarena = nullptr; size_t aarena_cap = 0, aarena_used = 0;      // activations
+    bool measuring = false;
+    int batch = 0;
+    std::vector<Op> ops;
+    std::map<std::string, TapInfo> taps;
+    std::vector<std::string> tap_order;
+    IoPtrs io;
+
+    void load(const ach_tensor_desc* t, size_t n);
+    virtual void plan(int B) = 0;
+    void run(hipStream_t s);
+    void run_profiled(hipStream_t s, float* op_ms, size_t cap);
+    // live probe: HIP events around ONE op of the plan on every run() (bench.py's roofline leg)
+    void set_probe(int op_index);
+    void read_probe(float* avg_ms, int* samples);
+    virtual void decode(int B, const void* d3, const void* d4, const void* d5, float* out, hipStream_t s) = 0;
+    void nms(int B, const float* decoded, float conf, float iou, int max_det, float* rows, int* idx, int* count,
+             void* workspace, hipStream_t s);
+    size_t nms_workspace_bytes(int B) const;
+    int num_anchors() const;
+    void read_tap(const std::string& name, float* out, size_t cap);
+    std::vector<long> tap_shape(const std::string& name) const;
+
+protected:
+    const HostTensor& W(const std::string& key) const;
+    bool hasW(const std::string& key) const { return weights.count(key) != 0; }
+    void* walloc(size_t bytes);
+    void* aalloc(size_t bytes);
+    float* up_f32(const std::vector<float>& v);
+    void add_op(const std::string& name, std::function<void(hipStream_t)> fn, double bytes = 0, double flops = 0) {
+        if (!measuring) ops.push_back(Op{name, std::move(fn), bytes, flops});
+    }
+    int probe_op = -1;
+    static constexpr int kProbeEvents = 512;
+    std::vector<hipEvent_t> probe_ev0, probe_ev1;
+    long probe_count = 0;
+    void add_tap(const std::string& name, const TapInfo& t) { if (!measuring) { if (!taps.count(name)) tap_order.push_back(name); taps[name] = t; } }
+    void reset_plan();
+};
+
+EngineBase* make_engine(const ach_config& cfg);
+
+}  // namespace ach

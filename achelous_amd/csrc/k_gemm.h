@@ -1,0 +1,249 @@
+// k_gemm.h — the pointwise / linear workhorse: Y[m, n] = epilogue( sum_k X[m, k] * W[n, k] ) on MFMA.
+//
+// Serves every 1x1 conv and nn.Linear of the path (EdgeNeXt pw-MLPs and qkv/proj, neck 1x1s, Ghost primary
+// convs, head stems/pw/preds, PointNet shared MLPs and FC stack, MobileViT projections) and the 2x2/s2
+// patchify convs of EdgeNeXt (rows gathered from two contiguous NHWC segments).
+//
+// Shape regime: M = B*H*W is huge (up to 6.5 M rows), K and N are tiny (8..704).  So:
+//   * weights are the MFMA *A* operand, activations the *B* operand: a lane's accumulator registers are then
+//     consecutive OUTPUT CHANNELS of one pixel, i.e. contiguous bytes of the NHWC output row (wide stores);
+//   * weights are pre-packed on the host in exact fragment order (one 1 KiB coalesced read per fragment,
+//     L1/L2 resident, no LDS staging and no barrier in the kernel);
+//   * an activation fragment is 16 B per lane, 4 lane groups reading 64 contiguous bytes of each of 16 rows;
+//     every activation row is consumed by exactly one wave;
+//   * fp32 storage uses v_mfma_f32_16x16x4_f32 (exact fp32, parity path), bf16 storage v_mfma_f32_16x16x32_bf16.
+// Fusions: LayerNorm over K as a prologue (affine folded into W/bias on the host), bias (BatchNorm folded),
+// activation, residual add, NCHW scatter for network outputs, per-group (per-sample) weights, and a
+// column max over the rows of a group (PointNet's max over points) reduced with wavefront shuffles.
+#pragma once
+#include "ach_platform.h"
+
+namespace ach {
+
+// Offset (in elements) of W[n][k] inside one group's packed weight blob.  Shared by the host packer and the
+// device-side packer for data-dependent weights (PointNet feature transform).
+__host__ __device__ __forceinline__ long wfrag_offset(int n, int k, int NT, int ksteps, int VEC) {
+    const int CH = 16 * NT;
+    const int c = n / CH, nn = n % CH;
+    const int gq = nn / (4 * NT), rem = nn % (4 * NT), t = rem >> 2, r = rem & 3;
+    const int i = gq * 4 + r;
+    const int KC = 4 * VEC;
+    const int s = k / KC, kk = k % KC, g = kk / VEC, j = kk % VEC;
+    return ((long(c) * ksteps + s) * NT + t) * (64L * VEC) + long(g * 16 + i) * VEC + j;
+}
+
+struct GemmParams {
+    const void* X; long ldx;            // activations: row m at X + m*ldx (elements), K contiguous channels
+    int patch, Hin, Win, Cin;           // patch>0: rows are outputs of a patch x patch / stride patch conv over NHWC [.,Hin,Win,Cin]
+    const void* W; long w_group_stride; // packed fragments; per-group stride in elements (0: shared)
+    const float* bias; long bias_group_stride;
+    void* Y; long ldy;                  // NHWC: row m at Y + m*ldy ; NCHW: see out_nchw
+    const void* R; long ldr;            // optional residual, NHWC rows
+    unsigned* colmax;                   // optional [groups][N] order-encoded running max (zero-initialised)
+    int M_per_group, groups, K, N;
+    int nchunks, ksteps;
+    int act, ln; float ln_eps;
+    int out_nchw, HW, Ctot, coff;       // NCHW scatter: Y[((b*Ctot + coff + n)*HW + p)], m = b*HW + p
+    int vec_store;                      // Y/R rows and channel offsets are 16-byte compatible
+};
+
+__device__ __forceinline__ unsigned order_encode(float v) {
+    const unsigned u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float order_decode(unsigned e) {
+    return __uint_as_float((e & 0x80000000u) ? (e & 0x7fffffffu) : ~e);
+}
+
+template <class T, int NT, int P>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
+    constexpr int VEC = Store<T>::VEC;
+    constexpr int KC = 4 * VEC;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int px = lane & 15, g = lane >> 4;
+    const int grp = blockIdx.y;
+    const long row0 = long(blockIdx.x) * (64 * P) + wave * (16 * P);   // first row (within the group) of this wave
+    const T* X = static_cast<const T*>(p.X);
+    const uint4* Wf = reinterpret_cast<const uint4*>(static_cast<const T*>(p.W) + long(grp) * p.w_group_stride);
+    const float* bias = p.bias + long(grp) * p.bias_group_stride;
+
+    // per sub-tile: this lane's row, its validity and the element offset of its first channel
+    long xoff[P];
+    bool valid[P];
+    long mrow[P];
+    ACH_UNROLL
+    for (int q = 0; q < P; ++q) {
+        const long mloc = row0 + q * 16 + px;
+        valid[q] = mloc < p.M_per_group;
+        const long m = long(grp) * p.M_per_group + (valid[q] ? mloc : 0);
+        mrow[q] = m;
+        if (p.patch > 0) {
+            const int Wo = p.Win / p.patch, Ho = p.Hin / p.patch;
+            const long b = m / (long(Ho) * Wo);
+            const int rem = int(m - b * long(Ho) * Wo);
+            const int oy = rem / Wo, ox = rem - oy * Wo;
+            xoff[q] = ((b * p.Hin + long(oy) * p.patch) * p.Win + long(ox) * p.patch) * p.Cin;
+        } else {
+            xoff[q] = m * p.ldx;
+        }
+    }
+    const int seg_len = p.patch > 0 ? p.patch * p.Cin : 0x7fffffff;
+    const long seg_stride = long(p.Win) * p.Cin;
+
+    auto load_x = [&](int q, int s) -> uint4 {
+        const int k0 = s * KC + g * VEC;
+        if (!valid[q] || k0 >= p.K) return make_uint4(0u, 0u, 0u, 0u);
+        long off = xoff[q];
+        if (p.patch > 0) { const int sg = k0 / seg_len; off += sg * seg_stride + (k0 - sg * seg_len); }
+        else off += k0;
+        return *reinterpret_cast<const uint4*>(X + off);
+    };
+
+    // ---- optional LayerNorm prologue: two-pass mean / variance over the K channels of each row
+    float mean[P], rstd[P];
+    if (p.ln) {
+        ACH_UNROLL
+        for (int q = 0; q < P; ++q) {
+            float s1 = 0.f;
+            for (int s = 0; s < p.ksteps; ++s) {
+                float v[8];
+                frag_unpack<T>(load_x(q, s), v);
+                ACH_UNROLL
+                for (int j = 0; j < VEC; ++j) s1 += v[j];          // channels >= K load as 0
+            }
+            s1 += __shfl_xor(s1, 16);
+            s1 += __shfl_xor(s1, 32);
+            const float mu = s1 / float(p.K);
+            float s2 = 0.f;
+            for (int s = 0; s < p.ksteps; ++s) {
+                const int k0 = s * KC + g * VEC;
+                float v[8];
+                frag_unpack<T>(load_x(q, s), v);
+                if (k0 < p.K) {
+                    ACH_UNROLL
+                    for (int j = 0; j < VEC; ++j) { const float d = v[j] - mu; s2 += d * d; }
+                }
+            }
+            s2 += __shfl_xor(s2, 16);
+            s2 += __shfl_xor(s2, 32);
+            mean[q] = mu;
+            rstd[q] = 1.0f / sqrtf(s2 / float(p.K) + p.ln_eps);
+        }
+    }
+
+    for (int c = 0; c < p.nchunks; ++c) {
+        f32x4 acc[P][NT];
+        ACH_UNROLL
+        for (int q = 0; q < P; ++q)
+            ACH_UNROLL
+            for (int t = 0; t < NT; ++t) { acc[q][t][0] = 0.f; acc[q][t][1] = 0.f; acc[q][t][2] = 0.f; acc[q][t][3] = 0.f; }
+
+        for (int s = 0; s < p.ksteps; ++s) {
+            uint4 xf[P];
+            ACH_UNROLL
+            for (int q = 0; q < P; ++q) {
+                xf[q] = load_x(q, s);
+                if (p.ln) {
+                    float v[8];
+                    frag_unpack<T>(xf[q], v);
+                    ACH_UNROLL
+                    for (int j = 0; j < VEC; ++j) v[j] = (v[j] - mean[q]) * rstd[q];
+                    xf[q] = frag_pack<T>(v);
+                }
+            }
+            const uint4* wrow = Wf + (long(c) * p.ksteps + s) * NT * 64 + lane;
+            ACH_UNROLL
+            for (int t = 0; t < NT; ++t) {
+                const uint4 wf = wrow[t * 64];
+                ACH_UNROLL
+                for (int q = 0; q < P; ++q) mfma16<T>(wf, xf[q], acc[q][t]);
+            }
+        }
+
+        // ---- epilogue: lane holds channels n0 .. n0+4*NT-1 of pixel px of every sub-tile
+        const int n0 = c * (16 * NT) + g * (4 * NT);
+        float bv[4 * NT];
+        ACH_UNROLL
+        for (int i = 0; i < 4 * NT; ++i) bv[i] = (n0 + i < p.N) ? bias[n0 + i] : 0.f;
+
+        if (p.colmax) {
+            ACH_UNROLL
+            for (int t = 0; t < NT; ++t)
+                ACH_UNROLL
+                for (int r = 0; r < 4; ++r) {
+                    float mx = -3.0e38f;
+                    ACH_UNROLL
+                    for (int q = 0; q < P; ++q) {
+                        const float v = apply_act(acc[q][t][r] + bv[t * 4 + r], p.act);
+                        if (valid[q]) mx = fmaxf(mx, v);
+                    }
+                    mx = fmaxf(mx, __shfl_xor(mx, 1));
+                    mx = fmaxf(mx, __shfl_xor(mx, 2));
+                    mx = fmaxf(mx, __shfl_xor(mx, 4));
+                    mx = fmaxf(mx, __shfl_xor(mx, 8));
+                    const int n = n0 + t * 4 + r;
+                    if (px == 0 && n < p.N) atomicMax(p.colmax + long(grp) * p.N + n, order_encode(mx));
+                }
+            continue;
+        }
+
+        ACH_UNROLL
+        for (int q = 0; q < P; ++q) {
+            if (!valid[q]) continue;
+            float o[4 * NT];
+            ACH_UNROLL
+            for (int t = 0; t < NT; ++t)
+                ACH_UNROLL
+                for (int r = 0; r < 4; ++r) o[t * 4 + r] = apply_act(acc[q][t][r] + bv[t * 4 + r], p.act);
+            const long m = mrow[q];
+            if (p.out_nchw) {
+                T* Y = static_cast<T*>(p.Y);
+                const long b = m / p.HW, pix = m - b * p.HW;
+                ACH_UNROLL
+                for (int i = 0; i < 4 * NT; ++i)
+                    if (n0 + i < p.N) Store<T>::st(Y + ((b * p.Ctot + p.coff + n0 + i) * p.HW + pix), o[i]);
+                continue;
+            }
+            T* yrow = static_cast<T*>(p.Y) + m * p.ldy + n0;
+            const T* rrow = p.R ? static_cast<const T*>(p.R) + m * p.ldr + n0 : nullptr;
+            ACH_UNROLL
+            for (int i4 = 0; i4 < NT; ++i4) {
+                const int nb = n0 + i4 * 4;
+                if (nb >= p.N) break;
+                float v4[4] = {o[i4 * 4], o[i4 * 4 + 1], o[i4 * 4 + 2], o[i4 * 4 + 3]};
+                if (p.vec_store && nb + 4 <= p.N) {
+                    if (rrow) { float r4[4]; Store<T>::ld4(rrow + i4 * 4, r4); v4[0] += r4[0]; v4[1] += r4[1]; v4[2] += r4[2]; v4[3] += r4[3]; }
+                    Store<T>::st4(yrow + i4 * 4, v4);
+                } else {
+                    for (int i = 0; i < 4; ++i)
+                        if (nb + i < p.N) {
+                            float v = v4[i];
+                            if (rrow) v += Store<T>::ld(rrow + i4 * 4 + i);
+                            Store<T>::st(yrow + i4 * 4 + i, v);
+                        }
+                }
+            }
+        }
+    }
+}
+
+// decode the order-encoded column max back to T  ([groups][N] -> rows of width ld)
+template <class T>
+__global__ void colmax_decode_kernel(const unsigned* enc, T* out, int N, long ld, long total) {
+    const long i = long(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const long g = i / N, n = i - g * N;
+    Store<T>::st(out + g * ld + n, order_decode(enc[i]));
+}
+
+template <class T>
+inline void launch_gemm(const GemmParams& p, int NT, int P, hipStream_t stream) {
+    const dim3 grid(unsigned(cdivl(p.M_per_group, 64L * P)), unsigned(p.groups)), block(256);
+#define ACH_GEMM_CASE(nt, pp) if (NT == nt && P == pp) { ACH_LAUNCH((gemm_kernel<T, nt, pp>), grid, block, stream, p); return; }
+    ACH_GEMM_CASE(1, 1) ACH_GEMM_CASE(1, 2) ACH_GEMM_CASE(1, 4)
+    ACH_GEMM_CASE(2, 1) ACH_GEMM_CASE(2, 2) ACH_GEMM_CASE(2, 4)
+    ACH_GEMM_CASE(4, 1) ACH_GEMM_CASE(4, 2) ACH_GEMM_CASE(4, 4)
+#undef ACH_GEMM_CASE
+}
+
+}  // namespace ach

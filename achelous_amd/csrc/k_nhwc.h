@@ -1,0 +1,425 @@
+// k_nhwc.h — the bandwidth-bound NHWC kernels of the image path: depthwise kxk conv, EdgeNeXt stem, channel
+// LayerNorm, bilinear x2 (align_corners), SPP max-pools, per-channel statistics, ShuffleAttention, ECA fusion,
+// element-wise add.  One thread owns 4 consecutive channels of one pixel (8 B bf16 / 16 B fp32), so a wave reads
+// and writes whole contiguous NHWC rows.  All arithmetic in fp32.
+#pragma once
+#include "ach_platform.h"
+
+namespace ach {
+
+// ------------------------------------------------------------------------------------------ depthwise conv
+struct DwParams {
+    const void* X; long ldx;        // input  [B,H,W,(C)] view, channel stride ldx
+    const void* X2; long ldx2;      // optional second input added tap-wise (SDTA cascade: conv(sp_prev + spx_i))
+    const float* W;                 // [KS*KS][C] fp32 (BatchNorm scale folded)
+    const float* bias;              // [C] fp32
+    void* Y; long ldy;              // output [B,Ho,Wo,(C)]
+    int B, H, Wd, C, Ho, Wo, stride, act;
+};
+
+template <class T, int KS>
+__global__ __launch_bounds__(256) void dwconv_kernel(const DwParams p) {
+    const int cq = p.C >> 2;
+    const long total = long(p.B) * p.Ho * p.Wo * cq;
+    const long idx = long(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = int(idx % cq) * 4;
+    long pix = idx / cq;
+    const int ox = int(pix % p.Wo); pix /= p.Wo;
+    const int oy = int(pix % p.Ho);
+    const long b = pix / p.Ho;
+    constexpr int PAD = KS / 2;
+    const T* X = static_cast<const T*>(p.X);
+    const T* X2 = static_cast<const T*>(p.X2);
+    float acc[4] = {p.bias[c], p.bias[c + 1], p.bias[c + 2], p.bias[c + 3]};
+    for (int ky = 0; ky < KS; ++ky) {
+        const int iy = oy * p.stride - PAD + ky;
+        if (iy < 0 || iy >= p.H) continue;
+        for (int kx = 0; kx < KS; ++kx) {
+            const int ix = ox * p.stride - PAD + kx;
+            if (ix < 0 || ix >= p.Wd) continue;
+            const long ip = (b * p.H + iy) * p.Wd + ix;
+            float v[4];
+            Store<T>::ld4(X + ip * p.ldx + c, v);
+            if (X2) { float u[4]; Store<T>::ld4(X2 + ip * p.ldx2 + c, u); v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3]; }
+            const float4 w = *reinterpret_cast<const float4*>(p.W + long(ky * KS + kx) * p.C + c);
+            acc[0] += v[0] * w.x; acc[1] += v[1] * w.y; acc[2] += v[2] * w.z; acc[3] += v[3] * w.w;
+        }
+    }
+    ACH_UNROLL
+    for (int i = 0; i < 4; ++i) acc[i] = apply_act(acc[i], p.act);
+    const long op = (b * p.Ho + oy) * p.Wo + ox;
+    Store<T>::st4(static_cast<T*>(p.Y) + op * p.ldy + c, acc);
+}
+
+template <class T>
+inline void launch_dwconv(const DwParams& p, int ks, hipStream_t s) {
+    const long total = long(p.B) * p.Ho * p.Wo * (p.C / 4);
+    const dim3 grid(unsigned(cdivl(total, 256))), block(256);
+    switch (ks) {
+        case 3: ACH_LAUNCH((dwconv_kernel<T, 3>), grid, block, s, p); break;
+        case 5: ACH_LAUNCH((dwconv_kernel<T, 5>), grid, block, s, p); break;
+        case 7: ACH_LAUNCH((dwconv_kernel<T, 7>), grid, block, s, p); break;
+        case 9: ACH_LAUNCH((dwconv_kernel<T, 9>), grid, block, s, p); break;
+        default: break;
+    }
+}
+
+// 3x3 depthwise on NCHW planes, used only for the "cheap operation" of the two segmentation heads whose
+// channel counts (5 and 1) are the network outputs themselves:  out[:, co+j] = act(w_j * in[:, ci+j] + b_j)
+struct DwPlaneParams {
+    const void* X; void* Y;         // NCHW tensors (may alias: distinct planes)
+    const float* W; const float* bias;   // [9][nch] , [nch]
+    int B, H, Wd, Cx, Cy, ci, co, nch, act;
+};
+template <class T>
+__global__ __launch_bounds__(256) void dwplane3x3_kernel(const DwPlaneParams p) {
+    const long total = long(p.B) * p.nch * p.H * p.Wd;
+    const long idx = long(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int x = int(idx % p.Wd);
+    long r = idx / p.Wd;
+    const int y = int(r % p.H); r /= p.H;
+    const int j = int(r % p.nch);
+    const long b = r / p.nch;
+    const T* in = static_cast<const T*>(p.X) + (b * p.Cx + p.ci + j) * long(p.H) * p.Wd;
+    float acc = p.bias[j];
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = y - 1 + ky;
+        if (iy < 0 || iy >= p.H) continue;
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = x - 1 + kx;
+            if (ix < 0 || ix >= p.Wd) continue;
+            acc += Store<T>::ld(in + long(iy) * p.Wd + ix) * p.W[(ky * 3 + kx) * p.nch + j];
+        }
+    }
+    Store<T>::st(static_cast<T*>(p.Y) + ((b * p.Cy + p.co + j) * long(p.H) + y) * p.Wd + x, apply_act(acc, p.act));
+}
+
+// ------------------------------------------------------------------------------------------ EdgeNeXt stem
+// conv 4x4 stride 4 (3 -> 32, bias) + channels-first LayerNorm(eps) with affine; NCHW image in, NHWC out.
+struct StemParams {
+    const void* X; void* Y;
+    const float* W;      // [48][32]: k = (c*4 + dy)*4 + dx
+    const float* bias; const float* lnw; const float* lnb;
+    int B, H, Wd; float eps;
+};
+template <class T>
+__global__ __launch_bounds__(256) void stem_kernel(const StemParams p) {
+    constexpr int CO = 32;
+    const int Ho = p.H / 4, Wo = p.Wd / 4;
+    const long total = long(p.B) * Ho * Wo;
+    const long idx = long(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int ox = int(idx % Wo);
+    const int oy = int((idx / Wo) % Ho);
+    const long b = idx / (long(Wo) * Ho);
+    const T* X = static_cast<const T*>(p.X);
+    float acc[CO];
+    ACH_UNROLL
+    for (int o = 0; o < CO; ++o) acc[o] = p.bias[o];
+    for (int c = 0; c < 3; ++c)
+        for (int dy = 0; dy < 4; ++dy) {
+            const T* row = X + ((b * 3 + c) * p.H + (oy * 4 + dy)) * long(p.Wd) + ox * 4;
+            ACH_UNROLL
+            for (int dx = 0; dx < 4; ++dx) {
+                const float v = Store<T>::ld(row + dx);
+                const float* w = p.W + ((c * 4 + dy) * 4 + dx) * CO;
+                ACH_UNROLL
+                for (int o = 0; o < CO; ++o) acc[o] += v * w[o];
+            }
+        }
+    float mu = 0.f;
+    ACH_UNROLL
+    for (int o = 0; o < CO; ++o) mu += acc[o];
+    mu *= (1.0f / CO);
+    float var = 0.f;
+    ACH_UNROLL
+    for (int o = 0; o < CO; ++o) { const float d = acc[o] - mu; var += d * d; }
+    const float rs = 1.0f / sqrtf(var * (1.0f / CO) + p.eps);
+    T* y = static_cast<T*>(p.Y) + idx * CO;
+    ACH_UNROLL
+    for (int o = 0; o < CO; o += 4) {
+        float v4[4];
+        ACH_UNROLL
+        for (int i = 0; i < 4; ++i) v4[i] = (acc[o + i] - mu) * rs * p.lnw[o + i] + p.lnb[o + i];
+        Store<T>::st4(y + o, v4);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ LayerNorm over C
+// one wave per pixel; used for the channels-first LayerNorm in front of the three 2x2/s2 down-sampling convs
+struct LnParams { const void* X; long ldx; void* Y; long ldy; const float* w; const float* b; long rows; int C; float eps; };
+template <class T>
+__global__ __launch_bounds__(256) void layernorm_kernel(const LnParams p) {
+    const int lane = threadIdx.x & 63;
+    const long row = long(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    const bool ok = row < p.rows;
+    const T* x = static_cast<const T*>(p.X) + (ok ? row : 0) * p.ldx;
+    const int cq = p.C >> 2;
+    float s1 = 0.f;
+    for (int q = lane; q < cq; q += 64) { float v[4]; Store<T>::ld4(x + q * 4, v); s1 += v[0] + v[1] + v[2] + v[3]; }
+    for (int m = 32; m >= 1; m >>= 1) s1 += __shfl_xor(s1, m);
+    const float mu = s1 / float(p.C);
+    float s2 = 0.f;
+    for (int q = lane; q < cq; q += 64) {
+        float v[4]; Store<T>::ld4(x + q * 4, v);
+        ACH_UNROLL
+        for (int i = 0; i < 4; ++i) { const float d = v[i] - mu; s2 += d * d; }
+    }
+    for (int m = 32; m >= 1; m >>= 1) s2 += __shfl_xor(s2, m);
+    const float rs = 1.0f / sqrtf(s2 / float(p.C) + p.eps);
+    if (!ok) return;
+    T* y = static_cast<T*>(p.Y) + row * p.ldy;
+    for (int q = lane; q < cq; q += 64) {
+        float v[4]; Store<T>::ld4(x + q * 4, v);
+        ACH_UNROLL
+        for (int i = 0; i < 4; ++i) v[i] = (v[i] - mu) * rs * p.w[q * 4 + i] + p.b[q * 4 + i];
+        Store<T>::st4(y + q * 4, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ bilinear x2
+// nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True): src = dst * (in-1)/(out-1)
+struct UpParams { const void* X; long ldx; void* Y; long ldy; int B, H, Wd, C; };
+template <class T>
+__global__ __launch_bounds__(256) void upsample2x_kernel(const UpParams p) {
+    const int Ho = p.H * 2, Wo = p.Wd * 2, cq = p.C >> 2;
+    const long total = long(p.B) * Ho * Wo * cq;
+    const long idx = long(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = int(idx % cq) * 4;
+    long pix = idx / cq;
+    const int ox = int(pix % Wo); pix /= Wo;
+    const int oy = int(pix % Ho);
+    const long b = pix / Ho;
+    const float sy = Ho > 1 ? float(p.H - 1) / float(Ho - 1) : 0.f;
+    const float sx = Wo > 1 ? float(p.Wd - 1) / float(Wo - 1) : 0.f;
+    const float fy = sy * float(oy), fx = sx * float(ox);
+    int y0 = int(fy), x0 = int(fx);
+    if (y0 > p.H - 1) y0 = p.H - 1;
+    if (x0 > p.Wd - 1) x0 = p.Wd - 1;
+    const int y1 = y0 + (y0 < p.H - 1 ? 1 : 0), x1 = x0 + (x0 < p.Wd - 1 ? 1 : 0);
+    const float ly = fy - float(y0), lx = fx - float(x0);
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const T* X = static_cast<const T*>(p.X);
+    float a[4], bq[4], cc[4], d[4], o[4];
+    Store<T>::ld4(X + ((b * p.H + y0) * p.Wd + x0) * p.ldx + c, a);
+    Store<T>::ld4(X + ((b * p.H + y0) * p.Wd + x1) * p.ldx + c, bq);
+    Store<T>::ld4(X + ((b * p.H + y1) * p.Wd + x0) * p.ldx + c, cc);
+    Store<T>::ld4(X + ((b * p.H + y1) * p.Wd + x1) * p.ldx + c, d);
+    ACH_UNROLL
+    for (int i = 0; i < 4; ++i) o[i] = hy * (hx * a[i] + lx * bq[i]) + ly * (hx * cc[i] + lx * d[i]);
+    Store<T>::st4(static_cast<T*>(p.Y) + ((b * Ho + oy) * Wo + ox) * p.ldy + c, o);
+}
+
+// ------------------------------------------------------------------------------------------ SPP max pools
+// reads channels [0,C) of the concat buffer, writes the 5x5 / 9x9 / 13x13 stride-1 max pools (-inf padding)
+// to channels [C,2C) [2C,3C) [3C,4C).  (SPPF's three chained 5x5 pools are the same three windows.)
+struct SppParams { void* buf; long ld; int B, H, Wd, C; };
+template <class T>
+__global__ __launch_bounds__(256) void spp_pool_kernel(const SppParams p) {
+    const int cq = p.C >> 2;
+    const long total = long(p.B) * p.H * p.Wd * cq;
+    const long idx = long(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = int(idx % cq) * 4;
+    long pix = idx / cq;
+    const int x = int(pix % p.Wd); pix /= p.Wd;
+    const int y = int(pix % p.H);
+    const long b = pix / p.H;
+    T* buf = static_cast<T*>(p.buf);
+    float m5[4], m9[4], m13[4];
+    ACH_UNROLL
+    for (int i = 0; i < 4; ++i) m5[i] = m9[i] = m13[i] = -3.0e38f;
+    for (int dy = -6; dy <= 6; ++dy) {
+        const int iy = y + dy;
+        if (iy < 0 || iy >= p.H) continue;
+        for (int dx = -6; dx <= 6; ++dx) {
+            const int ix = x + dx;
+            if (ix < 0 || ix >= p.Wd) continue;
+            float v[4];
+            Store<T>::ld4(buf + ((b * p.H + iy) * p.Wd + ix) * p.ld + c, v);
+            const int r = (dy < 0 ? -dy : dy) > (dx < 0 ? -dx : dx) ? (dy < 0 ? -dy : dy) : (dx < 0 ? -dx : dx);
+            ACH_UNROLL
+            for (int i = 0; i < 4; ++i) {
+                m13[i] = fmaxf(m13[i], v[i]);
+                if (r <= 4) m9[i] = fmaxf(m9[i], v[i]);
+                if (r <= 2) m5[i] = fmaxf(m5[i], v[i]);
+            }
+        }
+    }
+    T* o = buf + ((b * p.H + y) * p.Wd + x) * p.ld + c;
+    Store<T>::st4(o + p.C, m5);
+    Store<T>::st4(o + 2 * p.C, m9);
+    Store<T>::st4(o + 3 * p.C, m13);
+}
+
+// ------------------------------------------------------------------------------------------ element-wise
+struct AddParams { const void* A; long lda; const void* Bp; long ldb; void* Y; long ldy; long rows; int C; };
+template <class T>
+__global__ __launch_bounds__(256) void add_kernel(const AddParams p) {
+    const int cq = p.C >> 2;
+    const long idx = long(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (idx >= p.rows * cq) return;
+    const int c = int(idx % cq) * 4;
+    const long r = idx / cq;
+    float a[4], b[4];
+    Store<T>::ld4(static_cast<const T*>(p.A) + r * p.lda + c, a);
+    Store<T>::ld4(static_cast<const T*>(p.Bp) + r * p.ldb + c, b);
+    ACH_UNROLL
+    for (int i = 0; i < 4; ++i) a[i] += b[i];
+    Store<T>::st4(static_cast<T*>(p.Y) + r * p.ldy + c, a);
+}
+// copy a [rows, C] view (optionally adding a per-position constant [HW][C] fp32: the folded Fourier pos-enc)
+struct CopyParams { const void* X; long ldx; void* Y; long ldy; long rows; int C; const float* posenc; int HW; };
+template <class T>
+__global__ __launch_bounds__(256) void copy_kernel(const CopyParams p) {
+    const int cq = p.C >> 2;
+    const long idx = long(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (idx >= p.rows * cq) return;
+    const int c = int(idx % cq) * 4;
+    const long r = idx / cq;
+    float a[4];
+    Store<T>::ld4(static_cast<const T*>(p.X) + r * p.ldx + c, a);
+    if (p.posenc) {
+        const float* pe = p.posenc + (r % p.HW) * p.C + c;
+        ACH_UNROLL
+        for (int i = 0; i < 4; ++i) a[i] += pe[i];
+    }
+    Store<T>::st4(static_cast<T*>(p.Y) + r * p.ldy + c, a);
+}
+
+// ------------------------------------------------------------------------------------------ channel statistics
+// per (sample, channel) sum and sum of squares over the H*W positions of an NHWC view.
+// grid (B, S): block (b, s) reduces positions s, s+S, ... and writes partial[b][s][2][C]; the consumers add the S partials.
+struct StatParams { const void* X; long ldx; float* partial; int HW, C, S; };
+template <class T>
+__global__ __launch_bounds__(256) void chan_stats_kernel(const StatParams p) {
+    __shared__ float red[2][256];
+    const int b = blockIdx.x, s = blockIdx.y;
+    const int tid = threadIdx.x;
+    const T* X = static_cast<const T*>(p.X) + long(b) * p.HW * p.ldx;
+    float* out = p.partial + (long(b) * p.S + s) * 2 * p.C;
+    // threads = (channel c) x (row lane rl); every thread strides over positions
+    const int tc = p.C < 256 ? p.C : 256;       // channels handled per pass
+    const int rl_n = 256 / tc;                  // row lanes per channel (>= 1)
+    for (int c0 = 0; c0 < p.C; c0 += tc) {
+        const int c = c0 + (tid % tc);
+        const int rl = tid / tc;
+        float s1 = 0.f, s2 = 0.f;
+        if (rl < rl_n && c < p.C)
+            for (int i = s * rl_n + rl; i < p.HW; i += p.S * rl_n) {
+                const float v = Store<T>::ld(X + long(i) * p.ldx + c);
+                s1 += v; s2 += v * v;
+            }
+        red[0][tid] = s1; red[1][tid] = s2;
+        __syncthreads();
+        if (tid < tc && c0 + tid < p.C) {
+            float a = 0.f, q = 0.f;
+            for (int r = 0; r < rl_n; ++r) { a += red[0][r * tc + tid]; q += red[1][r * tc + tid]; }
+            out[c0 + tid] = a;
+            out[p.C + c0 + tid] = q;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------ ShuffleAttention
+// coefficients: out = x * sigmoid(a*x + d) per (sample, channel)
+//   channel-attention half: a = 0, d = cweight*mean + cbias
+//   spatial half (GroupNorm with one channel per group): a = sweight*gnw*rstd, d = sweight*(gnb - gnw*mean*rstd) + sbias
+struct SaCoefParams {
+    const float* partial; int S; float* coef;   // coef [B][C][2]
+    const float* cw; const float* cb; const float* sw; const float* sb; const float* gnw; const float* gnb;
+    int B, C, G, HW; float eps;
+};
+__global__ void sa_coef_kernel(const SaCoefParams p) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= p.B * p.C) return;
+    const int b = idx / p.C, c = idx % p.C;
+    float s1 = 0.f, s2 = 0.f;
+    for (int s = 0; s < p.S; ++s) { const float* q = p.partial + (long(b) * p.S + s) * 2 * p.C; s1 += q[c]; s2 += q[p.C + c]; }
+    const float mean = s1 / float(p.HW);
+    const int cg = p.C / p.G, half = cg / 2;        // channels per group, per half
+    const int j = c % cg;
+    float a, d;
+    if (j < half) { a = 0.f; d = p.cw[j] * mean + p.cb[j]; }
+    else {
+        const int jj = j - half;
+        float var = s2 / float(p.HW) - mean * mean;
+        if (var < 0.f) var = 0.f;
+        const float rstd = 1.0f / sqrtf(var + p.eps);
+        a = p.sw[jj] * p.gnw[jj] * rstd;
+        d = p.sw[jj] * (p.gnb[jj] - p.gnw[jj] * mean * rstd) + p.sb[jj];
+    }
+    p.coef[2 * idx] = a;
+    p.coef[2 * idx + 1] = d;
+}
+// apply + channel_shuffle(groups=2): input channel c -> output channel (c % (C/2)) * 2 + c / (C/2)
+struct SaApplyParams { const void* X; long ldx; void* Y; long ldy; const float* coef; int B, HW, C; };
+template <class T>
+__global__ __launch_bounds__(256) void sa_apply_kernel(const SaApplyParams p) {
+    const long total = long(p.B) * p.HW * p.C;
+    const long idx = long(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int co = int(idx % p.C);
+    const long pix = idx / p.C;
+    const long b = pix / p.HW;
+    const int c = (co & 1) * (p.C / 2) + (co >> 1);          // inverse of the shuffle
+    const float x = Store<T>::ld(static_cast<const T*>(p.X) + pix * p.ldx + c);
+    const float* k = p.coef + (b * p.C + c) * 2;
+    Store<T>::st(static_cast<T*>(p.Y) + pix * p.ldy + co, x * sigmoidf_(k[0] * x + k[1]));
+}
+
+// ------------------------------------------------------------------------------------------ ECA + fusion
+// scale[b][c] = sigmoid(conv1d_k(mean over HW)) * bn_scale[c] ; shift = bn_shift[c]
+struct EcaParams { const float* partial; int S; const float* w; int k; const float* bn_scale; float* scale; int B, C, HW; };
+__global__ void eca_scale_kernel(const EcaParams p) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= p.B * p.C) return;
+    const int b = idx / p.C, c = idx % p.C;
+    float g = 0.f;
+    for (int t = 0; t < p.k; ++t) {
+        const int cc = c + t - (p.k - 1) / 2;
+        if (cc < 0 || cc >= p.C) continue;
+        float s1 = 0.f;
+        for (int s = 0; s < p.S; ++s) s1 += p.partial[(long(b) * p.S + s) * 2 * p.C + cc];
+        g += p.w[t] * (s1 / float(p.HW));
+    }
+    p.scale[idx] = sigmoidf_(g) * p.bn_scale[c];
+}
+// Y[b,pix,c] = relu(X[b,pix,c] * scale[b][c] + shift[c]); X is NHWC (x_nchw = 0) or NCHW (radar branch)
+struct FuseParams { const void* X; long ldx; int x_nchw; void* Y; long ldy; const float* scale; const float* shift; int B, HW, C; };
+template <class T>
+__global__ __launch_bounds__(256) void fuse_scale_kernel(const FuseParams p) {
+    const long total = long(p.B) * p.HW * p.C;
+    const long idx = long(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = int(idx % p.C);
+    const long pix = idx / p.C;
+    const long b = pix / p.HW;
+    const T* X = static_cast<const T*>(p.X);
+    const float x = p.x_nchw ? Store<T>::ld(X + (b * p.C + c) * p.HW + (pix - b * p.HW)) : Store<T>::ld(X + pix * p.ldx + c);
+    const float v = x * p.scale[b * p.C + c] + p.shift[c];
+    Store<T>::st(static_cast<T*>(p.Y) + pix * p.ldy + c, v > 0.f ? v : 0.f);
+}
+// per-channel sums of an NCHW tensor -> partial[b][0][2][C] (S = 1); one block per (b, c)
+struct StatNchwParams { const void* X; float* partial; int HW, C; };
+template <class T>
+__global__ __launch_bounds__(256) void chan_stats_nchw_kernel(const StatNchwParams p) {
+    __shared__ float red[256];
+    const int b = blockIdx.x / p.C, c = blockIdx.x % p.C;
+    const T* X = static_cast<const T*>(p.X) + (long(b) * p.C + c) * p.HW;
+    float s1 = 0.f;
+    for (int i = threadIdx.x; i < p.HW; i += 256) s1 += Store<T>::ld(X + i);
+    red[threadIdx.x] = s1;
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) {
+        if (int(threadIdx.x) < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { p.partial[long(b) * 2 * p.C + c] = red[0]; p.partial[long(b) * 2 * p.C + p.C + c] = 0.f; }
+}
+
+}  // namespace ach

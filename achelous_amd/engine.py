@@ -1,0 +1,219 @@
+"""ctypes binding of the C ABI in include/achelous.h (libachelous_hip.so).
+
+PyTorch is plumbing here: it owns device memory and streams; tensors cross the boundary as raw
+`data_ptr()`s.  The library is built in-tree by `make -C achelous_amd/csrc` (see __graft_entry__.build()).
+There is NO fallback: if the HIP library cannot be loaded, or a tensor is not on a GPU, this raises.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_LIBRARY = os.path.join(_HERE, 'libachelous_hip.so')
+
+DTYPE_F32, DTYPE_BF16 = 0, 1
+BACKBONES = {'en': 0, 'mv': 1}
+PHIS = {'S0': 0, 'S1': 1, 'S2': 2}
+
+_ERRORS = {-1: ValueError, -2: NotImplementedError, -3: KeyError, -4: RuntimeError, -5: MemoryError}
+
+
+class AchConfig(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ('num_det', 'num_seg', 'phi', 'backbone', 'resolution', 'pc_channels',
+                                              'pc_classes', 'num_points', 'nano_head', 'spp', 'dtype')]
+
+
+class AchTensorDesc(ctypes.Structure):
+    _fields_ = [('name', ctypes.c_char_p), ('data', ctypes.c_void_p), ('ndim', ctypes.c_int32),
+                ('shape', ctypes.c_int64 * 4)]
+
+
+class NativeLibrary:
+    """dlopen + prototypes for every symbol declared in include/achelous.h."""
+    SYMBOLS = ('ach_create', 'ach_destroy', 'ach_last_error', 'ach_load_weights', 'ach_plan', 'ach_arena_bytes',
+               'ach_forward', 'ach_decode', 'ach_nms_workspace_bytes', 'ach_nms', 'ach_tap_count', 'ach_tap_name',
+               'ach_tap_shape', 'ach_read_tap', 'ach_plan_launches', 'ach_op_name', 'ach_op_bytes', 'ach_op_flops',
+               'ach_forward_profiled', 'ach_set_probe', 'ach_read_probe')
+
+    def __init__(self, path):
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: build it with `make -C achelous_amd/csrc` "
+                               f"(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        self.path = path
+        self.lib = L = ctypes.CDLL(path)
+        vp, i32, sz, f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_size_t, ctypes.c_float
+        L.ach_create.argtypes = [ctypes.POINTER(AchConfig), ctypes.POINTER(vp)]
+        L.ach_create.restype = ctypes.c_int
+        L.ach_destroy.argtypes = [vp]
+        L.ach_destroy.restype = None
+        L.ach_last_error.argtypes = [vp]
+        L.ach_last_error.restype = ctypes.c_char_p
+        L.ach_load_weights.argtypes = [vp, ctypes.POINTER(AchTensorDesc), sz]
+        L.ach_load_weights.restype = ctypes.c_int
+        L.ach_plan.argtypes = [vp, i32]
+        L.ach_plan.restype = ctypes.c_int
+        L.ach_arena_bytes.argtypes = [vp]
+        L.ach_arena_bytes.restype = sz
+        L.ach_forward.argtypes = [vp] + [vp] * 9 + [vp]
+        L.ach_forward.restype = ctypes.c_int
+        L.ach_decode.argtypes = [vp, i32, vp, vp, vp, vp, vp]
+        L.ach_decode.restype = ctypes.c_int
+        L.ach_nms_workspace_bytes.argtypes = [vp, i32]
+        L.ach_nms_workspace_bytes.restype = sz
+        L.ach_nms.argtypes = [vp, i32, vp, f32, f32, i32, vp, vp, vp, vp, vp]
+        L.ach_nms.restype = ctypes.c_int
+        L.ach_tap_count.argtypes = [vp]
+        L.ach_tap_count.restype = ctypes.c_int
+        L.ach_tap_name.argtypes = [vp, ctypes.c_int]
+        L.ach_tap_name.restype = ctypes.c_char_p
+        L.ach_tap_shape.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(i32)]
+        L.ach_tap_shape.restype = ctypes.c_int
+        L.ach_read_tap.argtypes = [vp, ctypes.c_char_p, vp, sz]
+        L.ach_read_tap.restype = ctypes.c_int
+        L.ach_plan_launches.argtypes = [vp]
+        L.ach_plan_launches.restype = ctypes.c_int
+        L.ach_op_name.argtypes = [vp, ctypes.c_int]
+        L.ach_op_name.restype = ctypes.c_char_p
+        L.ach_op_bytes.argtypes = [vp, ctypes.c_int]
+        L.ach_op_bytes.restype = ctypes.c_double
+        L.ach_op_flops.argtypes = [vp, ctypes.c_int]
+        L.ach_op_flops.restype = ctypes.c_double
+        L.ach_forward_profiled.argtypes = [vp] + [vp] * 9 + [vp, vp, sz]
+        L.ach_forward_profiled.restype = ctypes.c_int
+        L.ach_set_probe.argtypes = [vp, ctypes.c_int]
+        L.ach_set_probe.restype = ctypes.c_int
+        L.ach_read_probe.argtypes = [vp, ctypes.POINTER(f32), ctypes.POINTER(ctypes.c_int)]
+        L.ach_read_probe.restype = ctypes.c_int
+
+
+_hip_library = None
+
+
+def hip_library():
+    """The product library.  Raises (never falls back) when it has not been built."""
+    global _hip_library
+    if _hip_library is None:
+        _hip_library = NativeLibrary(HIP_LIBRARY)
+    return _hip_library
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+class NativeEngine:
+    """One ach_handle: a (config, dtype) specialisation of the forward engine on the current device."""
+
+    def __init__(self, lib, *, num_det, num_seg, phi, backbone, resolution, pc_channels, pc_classes, num_points,
+                 nano_head, spp, dtype):
+        self.lib = lib
+        self.L = lib.lib
+        self.cfg = AchConfig(num_det, num_seg, PHIS[phi], BACKBONES[backbone], resolution, pc_channels, pc_classes,
+                             num_points, int(bool(nano_head)), int(bool(spp)), dtype)
+        self.dtype = dtype
+        self.torch_dtype = torch.float32 if dtype == DTYPE_F32 else torch.bfloat16
+        self.h = ctypes.c_void_p()
+        rc = self.L.ach_create(ctypes.byref(self.cfg), ctypes.byref(self.h))
+        if rc != 0:
+            msg = self.L.ach_last_error(None)
+            raise _ERRORS.get(rc, RuntimeError)((msg or b'ach_create failed').decode())
+        self.batch = 0
+        self.num_det, self.num_seg, self.resolution = num_det, num_seg, resolution
+        self.pc_classes, self.num_points, self.pc_channels = pc_classes, num_points, pc_channels
+
+    def __del__(self):
+        try:
+            if getattr(self, 'h', None) and self.h.value:
+                self.L.ach_destroy(self.h)
+                self.h = ctypes.c_void_p()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            msg = (self.L.ach_last_error(self.h) or b'').decode()
+            raise _ERRORS.get(rc, RuntimeError)(msg)
+
+    # ---------------------------------------------------------------------------------------------------
+    def load_state_dict(self, state_dict):
+        """Reference-keyed state_dict (achelous.py:171) -> folded + packed device weights."""
+        keep, descs = [], []
+        for k, v in state_dict.items():
+            if not torch.is_floating_point(v):
+                continue                                   # BatchNorm num_batches_tracked
+            t = v.detach().to(device='cpu', dtype=torch.float32).contiguous()
+            if t.dim() > 4:
+                raise ValueError(f'{k}: rank {t.dim()} tensor')
+            keep.append((k.encode(), t))
+        arr = (AchTensorDesc * len(keep))()
+        for i, (name, t) in enumerate(keep):
+            arr[i].name = name
+            arr[i].data = t.data_ptr()
+            arr[i].ndim = t.dim()
+            for d in range(t.dim()):
+                arr[i].shape[d] = t.shape[d]
+        self._check(self.L.ach_load_weights(self.h, arr, len(keep)))
+        self.batch = 0
+
+    def plan(self, batch):
+        self._check(self.L.ach_plan(self.h, int(batch)))
+        self.batch = int(batch)
+
+    def arena_bytes(self):
+        return int(self.L.ach_arena_bytes(self.h))
+
+    def launches(self):
+        return int(self.L.ach_plan_launches(self.h))
+
+    def forward(self, image, radar, points, outs, stream=0):
+        det3, det4, det5, se, lane, pc = outs
+        self._check(self.L.ach_forward(self.h, _ptr(image), _ptr(radar), _ptr(points), _ptr(det3), _ptr(det4), _ptr(det5),
+                                       _ptr(se), _ptr(lane), _ptr(pc), ctypes.c_void_p(stream)))
+
+    def op_table(self):
+        """[(name, algorithmic bytes, flops)] of every launch in the plan."""
+        return [(self.L.ach_op_name(self.h, i).decode(), self.L.ach_op_bytes(self.h, i), self.L.ach_op_flops(self.h, i))
+                for i in range(self.launches())]
+
+    def forward_profiled(self, image, radar, points, outs, stream=0):
+        """One forward with every launch bracketed by HIP events -> per-launch milliseconds."""
+        n = self.launches()
+        ms = (ctypes.c_float * n)()
+        det3, det4, det5, se, lane, pc = outs
+        self._check(self.L.ach_forward_profiled(self.h, _ptr(image), _ptr(radar), _ptr(points), _ptr(det3), _ptr(det4),
+                                                _ptr(det5), _ptr(se), _ptr(lane), _ptr(pc), ctypes.c_void_p(stream),
+                                                ctypes.cast(ms, ctypes.c_void_p), n))
+        return list(ms)
+
+    def set_probe(self, op_index):
+        self._check(self.L.ach_set_probe(self.h, int(op_index)))
+
+    def read_probe(self):
+        avg, n = ctypes.c_float(), ctypes.c_int()
+        self._check(self.L.ach_read_probe(self.h, ctypes.byref(avg), ctypes.byref(n)))
+        return float(avg.value), int(n.value)
+
+    def decode(self, batch, det3, det4, det5, decoded, stream=0):
+        self._check(self.L.ach_decode(self.h, int(batch), _ptr(det3), _ptr(det4), _ptr(det5), _ptr(decoded),
+                                      ctypes.c_void_p(stream)))
+
+    def nms_workspace_bytes(self, batch):
+        return int(self.L.ach_nms_workspace_bytes(self.h, int(batch)))
+
+    def nms(self, batch, decoded, conf, iou, max_det, rows, idx, count, workspace, stream=0):
+        self._check(self.L.ach_nms(self.h, int(batch), _ptr(decoded), float(conf), float(iou), int(max_det), _ptr(rows),
+                                   _ptr(idx), _ptr(count), _ptr(workspace), ctypes.c_void_p(stream)))
+
+    # ---------------------------------------------------------------------------------------------------
+    def tap_names(self):
+        return [self.L.ach_tap_name(self.h, i).decode() for i in range(self.L.ach_tap_count(self.h))]
+
+    def read_tap(self, name):
+        shape = (ctypes.c_int64 * 4)()
+        ndim = ctypes.c_int32()
+        self._check(self.L.ach_tap_shape(self.h, name.encode(), shape, ctypes.byref(ndim)))
+        dims = [int(shape[i]) for i in range(ndim.value)]
+        out = torch.empty(dims, dtype=torch.float32)
+        self._check(self.L.ach_read_tap(self.h, name.encode(), ctypes.c_void_p(out.data_ptr()), out.numel()))
+        return out

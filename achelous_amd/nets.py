@@ -1,0 +1,137 @@
+"""Drop-in replacement for the reference's `nets.Achelous.Achelous` (nets/Achelous.py:26-53).
+
+Same constructor arguments, same `forward(x, x_radar, x_point_clouds)` signature, same output structure / shapes /
+dtypes, same state_dict keys (so `load_state_dict(torch.load(path))`, achelous.py:171, works unchanged) — but the
+forward is executed by the MI355X-native engine behind the C ABI in include/achelous.h (hand-written HIP kernels,
+libachelous_hip.so).  There is no PyTorch-op or CPU fallback: without the HIP library, or off-GPU, forward raises.
+
+    det_list[3], se_seg, lane_seg, pc_seg = model(image[B,3,R,R], radar[B,3,R,R], points[B,pc_channels,N])
+
+Eval-mode (inference) only: the engine folds BatchNorm running statistics into the convolutions, which is only
+legal in eval mode; `forward` in training mode raises NotImplementedError.
+"""
+import torch
+import torch.nn as nn
+
+from . import engine as _eng
+from .spec import state_dict_spec
+
+
+def _build_tree(root, spec):
+    """Register parameters / buffers under the reference's dotted names on a tree of plain nn.Modules."""
+    for key, shape, kind in spec:
+        parts = key.split('.')
+        mod = root
+        for p in parts[:-1]:
+            if p not in mod._modules:
+                mod.add_module(p, nn.Module())
+            mod = mod._modules[p]
+        leaf = parts[-1]
+        if kind == 'param':
+            mod.register_parameter(leaf, nn.Parameter(torch.zeros(shape)))
+        elif kind == 'buffer':
+            mod.register_buffer(leaf, torch.ones(shape) if leaf == 'running_var' else torch.zeros(shape))
+        else:
+            mod.register_buffer(leaf, torch.zeros(shape, dtype=torch.long))
+
+
+class Achelous(nn.Module):
+    def __init__(self, num_det, num_seg, phi='S0', image_channels=3, radar_channels=3, resolution=416,
+                 backbone='ef', neck='gdf', pc_seg='pn', pc_channels=6, pc_classes=9, nano_head=False, spp=True):
+        super().__init__()
+        if neck != 'gdf':
+            raise NotImplementedError(f"neck={neck!r}: only the Ghost-Dual-FPN ('gdf') is built (SURVEY.md §2.1 rows 18-19)")
+        if backbone not in ('en', 'mv'):
+            raise NotImplementedError(f"backbone={backbone!r}: only EdgeNeXt ('en') and MobileViT ('mv') are in scope")
+        if pc_seg != 'pn':
+            raise NotImplementedError(
+                f"pc_seg={pc_seg!r}: the reference snapshot contains no PointNet++ implementation "
+                "(nets/Achelous.py:31-32 only builds 'pn'; its own forward raises for anything else)")
+        if phi not in ('S0', 'S1', 'S2'):
+            raise NotImplementedError(f"phi={phi!r}: only S0, S1, S2 exist for the en/mv backbones")
+        if not nano_head:
+            raise NotImplementedError("nano_head=False (256-channel head) is not built")
+        if image_channels != 3 or radar_channels != 3:
+            raise NotImplementedError("image_channels / radar_channels other than 3")
+        self.num_det, self.num_seg, self.resolution = num_det, num_seg, resolution
+        self.phi, self.image_channels, self.radar_channels = phi, image_channels, radar_channels
+        self.backbone, self.neck, self.pc_seg_kind = backbone, neck, pc_seg
+        self.pc_channels, self.pc_classes, self.nano_head, self.spp = pc_channels, pc_classes, nano_head, spp
+        _build_tree(self, state_dict_spec(num_det, num_seg, phi, backbone, pc_channels, pc_classes, nano_head, radar_channels))
+        self._init_like_reference()
+        self._engines = {}          # (device index, dtype) -> [NativeEngine, weight version, num_points]
+
+    # engines hold ctypes handles: never pickle / deepcopy them (utils_fit.py:378 pickles the module, ModelEMA deep-copies it)
+    def __getstate__(self):
+        st = self.__dict__.copy()
+        st['_engines'] = {}
+        return st
+
+    def _init_like_reference(self):
+        """Default values in the spirit of the reference's initialisers (not bit-identical: real use loads a checkpoint)."""
+        g = torch.Generator().manual_seed(0)
+        for name, p in self.named_parameters():
+            leaf = name.rsplit('.', 1)[-1]
+            with torch.no_grad():
+                if leaf in ('gamma', 'gamma_xca'):
+                    p.fill_(1e-6)
+                elif leaf == 'temperature' or leaf in ('cbias', 'sbias'):
+                    p.fill_(1.0)
+                elif leaf in ('cweight', 'sweight'):
+                    p.zero_()
+                elif p.dim() == 1:
+                    p.fill_(1.0 if leaf == 'weight' else 0.0)
+                elif 'offset_conv' in name or 'modulator_conv' in name:
+                    p.zero_()
+                else:
+                    p.copy_(torch.randn(p.shape, generator=g) * 0.02)
+
+    # ---------------------------------------------------------------------------------------------------
+    def _weights_version(self):
+        return sum(t._version for t in self.parameters()) + sum(t._version for t in self.buffers())
+
+    def _engine_for(self, device, dtype, batch, num_points):
+        if dtype == torch.float32:
+            code = _eng.DTYPE_F32
+        elif dtype == torch.bfloat16:
+            code = _eng.DTYPE_BF16
+        else:
+            raise TypeError(f"Achelous forward supports float32 and bfloat16 inputs, got {dtype}")
+        key = (device.index, code)
+        ver = self._weights_version()
+        ent = self._engines.get(key)
+        if ent is None or ent[2] != num_points:
+            eng = _eng.NativeEngine(_eng.hip_library(), num_det=self.num_det, num_seg=self.num_seg, phi=self.phi,
+                                    backbone=self.backbone, resolution=self.resolution, pc_channels=self.pc_channels,
+                                    pc_classes=self.pc_classes, num_points=num_points, nano_head=self.nano_head,
+                                    spp=self.spp, dtype=code)
+            ent = [eng, None, num_points]
+            self._engines[key] = ent
+        if ent[1] != ver:
+            ent[0].load_state_dict(self.state_dict())
+            ent[1] = ver
+        if ent[0].batch != batch:
+            ent[0].plan(batch)
+        return ent[0]
+
+    def forward(self, x, x_radar, x_point_clouds):
+        if self.training:
+            raise NotImplementedError("achelous_amd.Achelous runs eval-mode inference only; call .eval() first")
+        if not (x.is_cuda and x_radar.is_cuda and x_point_clouds.is_cuda):
+            raise RuntimeError("achelous_amd.Achelous.forward needs GPU tensors (MI355X HIP engine; there is no CPU path)")
+        B, R = x.shape[0], self.resolution
+        if tuple(x.shape) != (B, 3, R, R) or tuple(x_radar.shape) != (B, 3, R, R):
+            raise ValueError(f"expected image and radar map of shape [B,3,{R},{R}], got {tuple(x.shape)} / {tuple(x_radar.shape)}")
+        if x_point_clouds.dim() != 3 or x_point_clouds.shape[0] != B or x_point_clouds.shape[1] != self.pc_channels:
+            raise ValueError(f"expected points of shape [B,{self.pc_channels},N], got {tuple(x_point_clouds.shape)}")
+        dt, dev, N = x.dtype, x.device, x_point_clouds.shape[2]
+        with torch.cuda.device(dev):
+            eng = self._engine_for(dev, dt, B, N)
+            x, x_radar, pts = x.contiguous(), x_radar.to(dt).contiguous(), x_point_clouds.to(dt).contiguous()
+            nc5 = 5 + self.num_det
+            det = [torch.empty(B, nc5, R // s, R // s, dtype=dt, device=dev) for s in (8, 16, 32)]
+            se = torch.empty(B, self.num_seg, R, R, dtype=dt, device=dev)
+            lane = torch.empty(B, 2, R, R, dtype=dt, device=dev)
+            pc = torch.empty(B, N, self.pc_classes, dtype=dt, device=dev)
+            eng.forward(x, x_radar, pts, (det[0], det[1], det[2], se, lane, pc), torch.cuda.current_stream(dev).cuda_stream)
+        return det, se, lane, pc

@@ -1,0 +1,93 @@
+"""Device-side counterparts of the reference's utils/utils_bbox.py, same call signatures:
+
+    decode_outputs(outputs, input_shape[, local_rank])                      utils_bbox.py:33-85
+    non_max_suppression(prediction, num_classes, input_shape, image_shape,
+                        letterbox_image, conf_thres=0.5, nms_thres=0.4)     utils_bbox.py:87-181
+
+Both run as HIP kernels through the C ABI (ach_decode / ach_nms); only the final un-letterboxing of the kept boxes
+(`yolo_correct_boxes`, utils_bbox.py:5-30) stays on the host in numpy, as in the reference.  No CPU fallback.
+"""
+import numpy as np
+import torch
+
+from . import engine as _eng
+
+_handles = {}
+
+
+def _handle(num_det, resolution, dtype):
+    code = _eng.DTYPE_BF16 if dtype == torch.bfloat16 else _eng.DTYPE_F32
+    key = (torch.cuda.current_device(), num_det, resolution, code)
+    if key not in _handles:
+        _handles[key] = _eng.NativeEngine(_eng.hip_library(), num_det=num_det, num_seg=1, phi='S0', backbone='en',
+                                          resolution=resolution, pc_channels=3, pc_classes=1, num_points=16, nano_head=True,
+                                          spp=True, dtype=code)
+    return _handles[key]
+
+
+def decode_outputs(outputs, input_shape, local_rank=None):
+    """[B,5+C,h,w] x 3 raw head maps -> [B, A, 5+C] fp32 (cx, cy, w, h normalised; sigmoid obj / cls)."""
+    d3, d4, d5 = [o.contiguous() for o in outputs]
+    if not d3.is_cuda:
+        raise RuntimeError("decode_outputs needs GPU tensors (HIP kernel; no CPU path)")
+    B, nc5 = d3.shape[0], d3.shape[1]
+    R = int(input_shape[0])
+    if d3.shape[-1] * 8 != R or int(input_shape[1]) != R:
+        raise ValueError("decode_outputs: square input whose stride-8 map matches input_shape expected")
+    with torch.cuda.device(d3.device):
+        h = _handle(nc5 - 5, R, d3.dtype)
+        A = sum(o.shape[-1] * o.shape[-2] for o in (d3, d4, d5))
+        out = torch.empty(B, A, nc5, dtype=torch.float32, device=d3.device)
+        h.decode(B, d3, d4, d5, out, torch.cuda.current_stream().cuda_stream)
+    return out
+
+
+def nms_device(prediction, num_classes, conf_thres, nms_thres, max_det=None):
+    """Decoded [B,A,5+C] fp32 -> (rows [B,max_det,7], kept anchor indices [B,max_det] int32, counts [B] int32) on device."""
+    p = prediction.contiguous().float()
+    if not p.is_cuda:
+        raise RuntimeError("non_max_suppression needs a GPU tensor (HIP kernel; no CPU path)")
+    B, A, nc5 = p.shape
+    max_det = int(max_det or A)
+    with torch.cuda.device(p.device):
+        R = {2100: 320}.get(A)
+        if R is None:
+            raise NotImplementedError(f"device NMS is built for 2100 anchors (320x320), got {A}")
+        h = _handle(num_classes, R, torch.float32)
+        rows = torch.zeros(B, max_det, 7, dtype=torch.float32, device=p.device)
+        idx = torch.full((B, max_det), -1, dtype=torch.int32, device=p.device)
+        cnt = torch.zeros(B, dtype=torch.int32, device=p.device)
+        ws = torch.empty(h.nms_workspace_bytes(B), dtype=torch.uint8, device=p.device)
+        h.nms(B, p, conf_thres, nms_thres, max_det, rows, idx, cnt, ws, torch.cuda.current_stream().cuda_stream)
+    return rows, idx, cnt
+
+
+def yolo_correct_boxes(box_xy, box_wh, input_shape, image_shape, letterbox_image):
+    """utils_bbox.py:5-30 (host, numpy): normalised (xy, wh) in the letterboxed input -> (y1,x1,y2,x2) image pixels."""
+    box_yx, box_hw = box_xy[..., ::-1], box_wh[..., ::-1]
+    input_shape = np.array(input_shape, dtype=np.float64)
+    image_shape = np.array(image_shape, dtype=np.float64)
+    if letterbox_image:
+        new_shape = np.round(image_shape * np.min(input_shape / image_shape))
+        offset = (input_shape - new_shape) / 2. / input_shape
+        scale = input_shape / new_shape
+        box_yx = (box_yx - offset) * scale
+        box_hw = box_hw * scale
+    mins, maxes = box_yx - box_hw / 2., box_yx + box_hw / 2.
+    boxes = np.concatenate([mins[..., 0:1], mins[..., 1:2], maxes[..., 0:1], maxes[..., 1:2]], axis=-1)
+    return boxes * np.concatenate([image_shape, image_shape], axis=-1)
+
+
+def non_max_suppression(prediction, num_classes, input_shape, image_shape, letterbox_image, conf_thres=0.5, nms_thres=0.4):
+    """Per image: None or float32 [K,7] = (y1,x1,y2,x2 in image pixels, obj_conf, class_conf, class_id), descending score."""
+    rows, idx, cnt = nms_device(prediction, num_classes, conf_thres, nms_thres)
+    rows, cnt = rows.cpu().numpy(), cnt.cpu().numpy()
+    out = []
+    for b in range(rows.shape[0]):
+        k = int(cnt[b])
+        r = rows[b, :k].copy()
+        if k:
+            xy, wh = (r[:, 0:2] + r[:, 2:4]) / 2, r[:, 2:4] - r[:, 0:2]
+            r[:, :4] = yolo_correct_boxes(xy, wh, input_shape, image_shape, letterbox_image)
+        out.append(r)          # the reference yields an empty selection as a [0,7] array as well
+    return out

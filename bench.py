@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py — whole-node frames/s of the Achelous forward path on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the hot path over one batch of synthetic frames already resident in HBM:
+    Achelous.forward (5 tasks / 4 output groups)  ->  decode_outputs  ->  class-aware NMS (device)
+    [-> RCCL all-gather of the fixed-size detection records when N > 1]
+Workload: BASELINE.json configs[1] = EN-GDF-PN-S0, bf16, batch 64 per GPU, 320x320 image + radar map, 512 points,
+seeded re-conditioned random weights (no checkpoint ships with the reference), synthetic inputs.
+Weak scaling: every rank runs its own 64-frame shard (frames are independent; the only exchange is the all-gather
+of detections).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line (rank 0).  Besides the contract fields:
+  roofline     — for the dominant kernel of the plan: achieved = algorithmic bytes per launch / mean launch duration,
+                 the duration measured LIVE with HIP events on the launch stream around that kernel on every timed step.
+  cpu_baseline — the oracle (CPU port of the reference forward) timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+CONFIGS = {
+    'en_s0': (2, dict(backbone='en', phi='S0')),
+    'en_s2': (5, dict(backbone='en', phi='S2')),
+}
+COMMON = dict(num_det=7, num_seg=9, resolution=320, neck='gdf', pc_seg='pn', pc_channels=5, pc_classes=8, nano_head=True, spp=True)
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=64, help='frames per GPU per step')
+    ap.add_argument('--config', default='en_s0', choices=sorted(CONFIGS))
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--max-det', type=int, default=100)
+    ap.add_argument('--conf', type=float, default=0.35)
+    ap.add_argument('--iou', type=float, default=0.35)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-sample', type=int, default=8, help='frames in the CPU-baseline sample')
+    ap.add_argument('--ops-json', default=None, help='write the per-launch table (ms, algorithmic bytes) here')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU (the HIP engine has no CPU path)')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)   # "nccl" is RCCL on ROCm
+
+    from achelous_amd import Achelous, decode_outputs
+    from achelous_amd import engine as E
+    from achelous_amd.postprocess import nms_device
+    from achelous_amd.synth import condition_state_dict, make_inputs, config_seed
+
+    cid, kw = CONFIGS[args.config]
+    tdt = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+    model = Achelous(**COMMON, **kw).eval()
+    model.load_state_dict(condition_state_dict(model.state_dict(), seed=0))
+    model = model.to(dev)
+    B = args.batch
+    x, xr, xp = make_inputs(B, config_seed(cid) + 1000 * rank, resolution=COMMON['resolution'], pc_channels=COMMON['pc_channels'])
+    x, xr, xp = x.to(dev, tdt), xr.to(dev, tdt), xp.to(dev, tdt)
+    rec_w = args.max_det * 7 + args.max_det + 1
+    gathered = torch.empty(world * B, rec_w, dtype=torch.int32, device=dev) if world > 1 else None
+    ishape = [COMMON['resolution']] * 2
+
+    def step():
+        det, se, lane, pc = model(x, xr, xp)
+        dec = decode_outputs(det, ishape)
+        rows, idx, cnt = nms_device(dec, COMMON['num_det'], args.conf, args.iou, args.max_det)
+        if world > 1:
+            rec = torch.cat([rows.view(B, -1).view(torch.int32), idx, cnt.view(B, 1)], dim=1).contiguous()
+            dist.all_gather_into_tensor(gathered, rec)
+        return det, se, lane, pc, cnt
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    with torch.no_grad():
+        for _ in range(max(args.warmup, 1)):
+            out = step()
+        torch.cuda.synchronize(dev)
+        eng = model._engines[(local, E.DTYPE_BF16 if args.dtype == 'bf16' else E.DTYPE_F32)][0]
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        # one pass with every launch bracketed by HIP events: find the dominant kernel of the plan
+        outs = (out[0][0], out[0][1], out[0][2], out[1], out[2], out[3])
+        prof = [eng.forward_profiled(x, xr, xp, outs, stream) for _ in range(3)][-1]
+        table = eng.op_table()
+        dom = max(range(len(prof)), key=lambda i: prof[i])
+        eng.set_probe(dom)
+
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        fence()
+        t1 = time.perf_counter()
+        probe_ms, probe_n = eng.read_probe()
+        eng.set_probe(-1)
+
+        # forward-only rate (same inputs, no decode / NMS / gather), for the report
+        fence()
+        f0 = time.perf_counter()
+        for _ in range(args.steps):
+            model(x, xr, xp)
+        fence()
+        f1 = time.perf_counter()
+
+    elapsed = torch.tensor([t1 - t0, f1 - f0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed, fwd_elapsed = elapsed.tolist()
+    frames = world * B * args.steps
+    fps = frames / elapsed
+
+    result = None
+    if rank == 0:
+        name, dom_bytes, dom_flops = table[dom]
+        achieved = dom_bytes / (probe_ms * 1e-3) / 1e9 if probe_ms > 0 else 0.0
+        roofline = {'bound': 'hbm', 'kernel': name, 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': None,
+                    'algorithmic_bytes_per_launch': dom_bytes, 'launch_ms': round(probe_ms, 5), 'launches_timed': probe_n,
+                    'share_of_forward': round(prof[dom] / max(sum(prof), 1e-9), 4)}
+        traffic_file = os.path.join(ROOT, 'profiles', 'traffic.json')      # PMC passes are separate rocprofv3 runs
+        if os.path.exists(traffic_file):
+            try:
+                roofline['traffic'] = json.load(open(traffic_file)).get(name)
+            except Exception:
+                pass
+        algo_bytes_frame = (616960 + 1155696) * (2 if args.dtype == 'bf16' else 4)     # inputs + outputs once
+        result = {
+            'metric': 'frames/sec (whole node) EN-GDF-PN-S0 320x320+512pts bs64 @1/2/4/8 GPU' if args.config == 'en_s0'
+                      else f'frames/sec (whole node) {args.config} 320x320+512pts bs{B}',
+            'value': round(fps, 2), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': f'{args.config.upper().replace("_", "-GDF-PN-")} forward + decode + NMS, 320x320 image + radar map, '
+                                   f'512 points, batch {B} per GPU, all 5 heads, seeded random weights',
+                       'global_batch': world * B, 'parallelism': f'batch-sharded x{world}' + (' + RCCL all-gather of detections' if world > 1 else ''),
+                       'launches_per_forward': len(table)},
+            'forward_only_fps': round(frames / fwd_elapsed, 2),
+            'compulsory_hbm_frac': round(algo_bytes_frame * (frames / fwd_elapsed) / world / 1e9 / HBM_PEAK_GBS, 5),
+            'roofline': roofline,
+        }
+        if args.ops_json:
+            rows = [{'op': n, 'ms': round(ms, 5), 'bytes': b, 'flops': f} for (n, b, f), ms in zip(table, prof)]
+            os.makedirs(os.path.dirname(os.path.abspath(args.ops_json)), exist_ok=True)
+            json.dump({'config': args.config, 'dtype': args.dtype, 'batch': B, 'ops': rows}, open(args.ops_json, 'w'), indent=0)
+
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle.achelous_oracle import AchelousOracle
+            n = max(1, min(args.cpu_sample, B))
+            orc = AchelousOracle({k: v.detach().cpu() for k, v in model.state_dict().items()}, **COMMON, **kw)
+            cx, cr, cp = x[:n].float().cpu(), xr[:n].float().cpu(), xp[:n].float().cpu()
+            cores = torch.get_num_threads()
+            orc.forward(cx[:1], cr[:1], cp[:1])
+            c0 = time.perf_counter()
+            reps = 0
+            while reps < 1 or (time.perf_counter() - c0 < 10.0 and reps < 8):
+                orc.forward(cx, cr, cp)
+                reps += 1
+            cdt = (time.perf_counter() - c0) / reps
+            result['cpu_baseline'] = {'value': round(n / cdt, 3), 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
+                                      'sample': f'{reps} x oracle fp32 forward (torch CPU ops, {cores} threads) on {n} of the {B} frames; '
+                                                f'radar branch uses the oracle\'s gather-based deform_conv2d restatement'}
+        else:
+            result['cpu_baseline'] = None
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

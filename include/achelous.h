@@ -1,0 +1,120 @@
+/* achelous.h — C ABI of the MI355X-native Achelous forward engine (libachelous_hip.so).
+ *
+ * The reference (GuanRunwei/Achelous @ 2024-08-07) is 100 % Python: there is no FFI, plugin registry or native
+ * operator table in it.  Its "operator API" for the hot path is one nn.Module and two free functions, and each
+ * entry point below replaces exactly one of them (file:line relative to the reference tree):
+ *
+ *   ach_create / ach_destroy      <- nets/Achelous.py:26-47      Achelous.__init__ (ctor arguments -> ach_config)
+ *   ach_load_weights              <- achelous.py:171             net.load_state_dict(torch.load(path))  (reference key names)
+ *   ach_plan                      <- (implicit in eager PyTorch)  shape specialisation for one batch size
+ *   ach_forward                   <- nets/Achelous.py:49-53      Achelous.forward(x, x_radar, x_point_clouds)
+ *   ach_decode                    <- utils/utils_bbox.py:33-85   decode_outputs(outputs, input_shape)
+ *   ach_nms                       <- utils/utils_bbox.py:87-132  non_max_suppression(...) up to the host-side un-letterbox
+ *   ach_read_tap / ach_tap_*      <- (test hook) intermediate tensors at the SURVEY.md §8(a) boundaries
+ *
+ * Conventions: plain pointers and sizes only (no torch / HIP C++ types in the signatures; `stream` is a
+ * hipStream_t passed as void*).  Every function returns 0 on success and a negative code on failure and never
+ * throws; ach_last_error() returns a message for the most recent failure on that handle (or a global one when the
+ * handle itself could not be created).  The caller owns inputs and outputs (device pointers, dtype = config dtype,
+ * layouts exactly those of the reference: NCHW images / maps, [B, C, N] point clouds, [B, N, classes] point
+ * log-probabilities).  The engine owns its packed weights and activation arena (allocated in ach_load_weights /
+ * ach_plan; nothing is allocated inside ach_forward, which is asynchronous on `stream` and performs no host sync).
+ * One handle per (device, stream); calls on one handle must not overlap.
+ */
+#ifndef ACHELOUS_H_
+#define ACHELOUS_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ach_handle ach_handle;
+
+enum { ACH_DTYPE_F32 = 0, ACH_DTYPE_BF16 = 1 };
+enum { ACH_BACKBONE_EDGENEXT = 0, ACH_BACKBONE_MOBILEVIT = 1 };
+enum { ACH_PHI_S0 = 0, ACH_PHI_S1 = 1, ACH_PHI_S2 = 2 };
+
+enum {
+    ACH_OK = 0,
+    ACH_ERR_INVALID = -1,       /* bad argument / shape / state */
+    ACH_ERR_UNSUPPORTED = -2,   /* configuration outside the built scope (mirrors NotImplementedError) */
+    ACH_ERR_MISSING_KEY = -3,   /* state-dict key absent or of the wrong shape */
+    ACH_ERR_DEVICE = -4,        /* HIP runtime error */
+    ACH_ERR_NOMEM = -5
+};
+
+typedef struct ach_config {
+    int32_t num_det;        /* detection classes           (Achelous.__init__ num_det)      */
+    int32_t num_seg;        /* semantic classes            (num_seg)                        */
+    int32_t phi;            /* ACH_PHI_*                   (phi)                            */
+    int32_t backbone;       /* ACH_BACKBONE_*              (backbone in {'en','mv'})        */
+    int32_t resolution;     /* square input size           (resolution)                     */
+    int32_t pc_channels;    /* point features              (pc_channels)                    */
+    int32_t pc_classes;     /* point classes               (pc_classes)                     */
+    int32_t num_points;     /* points per cloud N                                           */
+    int32_t nano_head;      /* 1: 64-channel head          (nano_head)                      */
+    int32_t spp;            /* 1: SPP, 0: SPPF             (spp)                            */
+    int32_t dtype;          /* ACH_DTYPE_*: storage type of activations, inputs and outputs */
+} ach_config;
+
+/* one entry of a reference-keyed state_dict; `data` is HOST memory, fp32, contiguous, reference shape */
+typedef struct ach_tensor_desc {
+    const char* name;
+    const float* data;
+    int32_t ndim;
+    int64_t shape[4];
+} ach_tensor_desc;
+
+int ach_create(const ach_config* cfg, ach_handle** out);
+void ach_destroy(ach_handle* h);
+const char* ach_last_error(const ach_handle* h);
+
+/* Copies, folds (eval-mode BatchNorm, LayerNorm affine, layer scale, constant positional encoding) and repacks
+ * the weights into kernel-native layouts on the device.  Integer buffers (num_batches_tracked) may be omitted. */
+int ach_load_weights(ach_handle* h, const ach_tensor_desc* tensors, size_t n);
+
+/* Builds the launch plan and the activation arena for batch size B (re-plan to change B). */
+int ach_plan(ach_handle* h, int32_t batch);
+size_t ach_arena_bytes(const ach_handle* h);
+
+/* image [B,3,R,R], radar [B,3,R,R], points [B,pc_channels,N]  ->
+ * det3 [B,5+num_det,R/8,R/8], det4 [..,R/16,R/16], det5 [..,R/32,R/32], se_seg [B,num_seg,R,R],
+ * lane_seg [B,2,R,R], pc_seg [B,N,pc_classes] (log-probabilities).  All device pointers of the config dtype. */
+int ach_forward(ach_handle* h, const void* image, const void* radar, const void* points,
+                void* det3, void* det4, void* det5, void* se_seg, void* lane_seg, void* pc_seg, void* stream);
+
+/* det maps (config dtype) -> decoded [B, A, 5+num_det] fp32, A = (R/8)^2 + (R/16)^2 + (R/32)^2 */
+int ach_decode(ach_handle* h, int32_t batch, const void* det3, const void* det4, const void* det5,
+               float* decoded, void* stream);
+
+/* decoded [B,A,5+num_det] fp32 -> per image: rows [max_det,7] = x1,y1,x2,y2,obj,cls_conf,cls_id (normalised
+ * corners), kept anchor indices [max_det] (descending score), count.  `workspace` >= ach_nms_workspace_bytes(). */
+size_t ach_nms_workspace_bytes(const ach_handle* h, int32_t batch);
+int ach_nms(ach_handle* h, int32_t batch, const float* decoded, float conf_thres, float nms_thres, int32_t max_det,
+            float* out_rows, int32_t* out_idx, int32_t* out_count, void* workspace, void* stream);
+
+/* test hooks: intermediate tensors of the last ach_forward, converted to fp32 NCHW (or [rows, C]) on the host */
+int ach_tap_count(const ach_handle* h);
+const char* ach_tap_name(const ach_handle* h, int i);
+int ach_tap_shape(const ach_handle* h, const char* name, int64_t shape[4], int32_t* ndim);
+int ach_read_tap(ach_handle* h, const char* name, float* host_out, size_t capacity_elems);
+
+/* measurement hooks (bench.py): the plan's launch list with the ALGORITHMIC bytes / flops of each launch, a pass
+ * that brackets every launch with HIP events, and a live probe that brackets ONE launch on every ach_forward. */
+int ach_plan_launches(const ach_handle* h);
+const char* ach_op_name(const ach_handle* h, int i);
+double ach_op_bytes(const ach_handle* h, int i);
+double ach_op_flops(const ach_handle* h, int i);
+int ach_forward_profiled(ach_handle* h, const void* image, const void* radar, const void* points,
+                         void* det3, void* det4, void* det5, void* se_seg, void* lane_seg, void* pc_seg, void* stream,
+                         float* op_ms, size_t capacity);
+int ach_set_probe(ach_handle* h, int op_index);          /* -1 disables */
+int ach_read_probe(ach_handle* h, float* avg_ms, int* samples);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ACHELOUS_H_ */

@@ -39,7 +39,8 @@ class AchelousOracle:
                  pc_channels=5, pc_classes=8, nano_head=True, spp=True, resolution=320):
         if neck != 'gdf' or backbone not in ('en', 'mv') or pc_seg != 'pn':
             raise NotImplementedError("oracle covers backbone in {en,mv}, neck=gdf, pc_seg=pn")
-        self.sd = {k: v.detach().to(torch.float32) if v.is_floating_point() else v for k, v in state_dict.items()}
+        self.sd = {k: (v.detach().to(device='cpu', dtype=torch.float32) if v.is_floating_point() else v.detach().cpu())
+                   for k, v in state_dict.items()}
         self.num_det, self.num_seg, self.phi, self.backbone = num_det, num_seg, phi, backbone
         self.pc_channels, self.pc_classes, self.nano_head, self.spp = pc_channels, pc_classes, nano_head, spp
         self.w = WIDTHS[phi]

@@ -1,0 +1,79 @@
+"""The engine's kernel sources compiled for the host (tests/hostemu: fibers + emulated wavefront collectives / MFMA)
+and run through the SAME C ABI on CPU memory, against the oracle.  This is how kernel indexing, weight folding /
+packing and the launch plan are validated in the build container, which has no GPU.  It says nothing about the
+speed or the hardware-specific behaviour of the HIP build — the `-m gpu` tests do that — and the emulation library is
+test infrastructure that the achelous_amd package cannot load."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from achelous_amd.engine import DTYPE_BF16, DTYPE_F32
+from achelous_amd.synth import condition_state_dict, make_inputs
+from emu_util import alloc_outputs, emu_library, make_engine, rel_err
+from golden_util import GOLDEN_DIR
+from oracle.achelous_oracle import AchelousOracle, decode_outputs as o_decode, non_max_suppression as o_nms
+
+ORACLE_KEYS = ('num_det', 'num_seg', 'phi', 'backbone', 'neck', 'pc_seg', 'pc_channels', 'pc_classes', 'nano_head', 'spp', 'resolution')
+
+
+def _setup(name, res, batch, npts, seed=7):
+    meta = json.load(open(os.path.join(GOLDEN_DIR, name + '.keys.json')))
+    kw = dict(meta['ctor'])
+    kw['resolution'] = res
+    blank = {k: torch.zeros(s, dtype=getattr(torch, dt)) for k, s, dt in meta['keys']}
+    sd = condition_state_dict(blank, seed=0)
+    x, xr, xp = make_inputs(batch, seed, resolution=res, num_points=npts, pc_channels=kw['pc_channels'], radar_cells=40)
+    return kw, sd, (x, xr, xp)
+
+
+@pytest.mark.parametrize('name,res,batch,dtype,tol', [('en_s0', 64, 2, DTYPE_F32, 2e-5), ('en_s2', 64, 1, DTYPE_F32, 2e-5),
+                                                     ('en_s0', 96, 1, DTYPE_BF16, 6e-2)])
+def test_emulated_forward_matches_oracle(name, res, batch, dtype, tol):
+    npts = 48
+    kw, sd, (x, xr, xp) = _setup(name, res, batch, npts)
+    orc = AchelousOracle(sd, **{k: kw[k] for k in ORACLE_KEYS})
+    det, se, lane, pc = orc.forward(x, xr, xp)
+    eng = make_engine(emu_library(), kw, batch, sd, npts, dtype)
+    td = torch.float32 if dtype == DTYPE_F32 else torch.bfloat16
+    outs = alloc_outputs(kw, batch, npts, td, 'cpu')
+    eng.forward(x.to(td), xr.to(td), xp.to(td), outs)
+    for a, b in zip(outs, (det[0], det[1], det[2], se, lane, pc)):
+        assert rel_err(a.float(), b) < tol
+    for tap in eng.tap_names():
+        if tap in orc.taps:
+            assert rel_err(eng.read_tap(tap), orc.taps[tap]) < tol, tap
+    # second forward on the same plan (buffers reused, padding lanes untouched)
+    eng.forward(x.to(td), xr.to(td), xp.to(td), outs)
+    assert rel_err(outs[3].float(), se) < tol
+
+
+def test_emulated_decode_and_nms_match_oracle():
+    kw, sd, _ = _setup('en_s0', 320, 2, 16)
+    eng = make_engine(emu_library(), dict(kw, resolution=320), 1, sd, 16) if False else None
+    from achelous_amd.engine import NativeEngine
+    h = NativeEngine(emu_library(), num_det=7, num_seg=1, phi='S0', backbone='en', resolution=320, pc_channels=3, pc_classes=1,
+                     num_points=16, nano_head=True, spp=True, dtype=DTYPE_F32)
+    g = torch.Generator().manual_seed(11)
+    det = [torch.randn(2, 12, s, s, generator=g) * 1.5 for s in (40, 20, 10)]
+    for d in det:
+        d[:, 4] -= 2.0
+        d[:, 2:4] += 1.5
+    dec = torch.zeros(2, 2100, 12)
+    h.decode(2, det[0], det[1], det[2], dec)
+    ref = o_decode(det, [320, 320])
+    assert rel_err(dec, ref) < 1e-6
+    ws = torch.zeros(h.nms_workspace_bytes(2), dtype=torch.uint8)
+    for conf, iou in ((0.35, 0.35), (0.05, 0.5)):
+        rows = torch.zeros(2, 2100, 7)
+        idx = torch.full((2, 2100), -1, dtype=torch.int32)
+        cnt = torch.zeros(2, dtype=torch.int32)
+        h.nms(2, ref.contiguous(), conf, iou, 2100, rows, idx, cnt, ws)
+        exp = o_nms(ref.clone(), 7, conf, iou)
+        for b in range(2):
+            k = int(cnt[b])
+            assert k == len(exp[b][1]) and k > 0
+            assert np.array_equal(idx[b, :k].numpy().astype(np.int64), exp[b][1])
+            assert np.array_equal(rows[b, :k].numpy(), exp[b][0])
