@@ -8,6 +8,7 @@
 // positional encoding into a constant [HW, C] table.
 #include "engine.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -261,7 +262,7 @@ public:
     struct GemmOpt {
         int act = ACT_NONE; bool ln = false; float ln_eps = 0.f;
         const A* residual = nullptr;
-        int patch = 0; int Hin = 0, Win = 0, Cin = 0;
+        int conv_k = 0, conv_s = 1, conv_p = 0, Hin = 0, Win = 0, Cin = 0, Ho = 0, Wo = 0;   // implicit-GEMM conv over NHWC
         void** ydyn = nullptr; int out_nchw = 0, HW = 0, Ctot = 0, coff = 0;     // NCHW scatter into a user buffer
         unsigned* colmax = nullptr;
         int groups = 1; long w_group_stride = 0;
@@ -271,7 +272,7 @@ public:
     void gemm(const std::string& name, const T* Xp, long ldx, long M, const Packed& pk, T* Yp, long ldy, const GemmOpt& o) {
         GemmParams g;
         std::memset(&g, 0, sizeof(g));
-        g.X = Xp; g.ldx = ldx; g.patch = o.patch; g.Hin = o.Hin; g.Win = o.Win; g.Cin = o.Cin;
+        g.X = Xp; g.ldx = ldx; g.conv_k = o.conv_k; g.conv_s = o.conv_s; g.conv_p = o.conv_p; g.Hin = o.Hin; g.Win = o.Win; g.Cin = o.Cin; g.Ho = o.Ho; g.Wo = o.Wo;
         g.W = o.w_override ? o.w_override : pk.w; g.w_group_stride = o.w_group_stride;
         g.bias = pk.b; g.bias_group_stride = 0;
         g.Y = Yp; g.ldy = ldy;
@@ -282,9 +283,16 @@ public:
         g.act = o.act; g.ln = o.ln ? 1 : 0; g.ln_eps = o.ln_eps;
         g.out_nchw = o.out_nchw; g.HW = o.HW; g.Ctot = o.Ctot; g.coff = o.coff;
         g.vec_store = (ldy % 4 == 0 && (!o.residual || o.residual->ld % 4 == 0)) ? 1 : 0;
-        if (o.patch == 0 && ldx % VEC != 0) throw AchError{ACH_ERR_INVALID, name + ": activation row stride not 16-byte aligned"};
-        if (o.patch > 0 && ((o.patch * o.Cin) % VEC != 0)) throw AchError{ACH_ERR_UNSUPPORTED, name + ": patch segment not 16-byte aligned"};
-        const int P = g.M_per_group >= 4096 ? 4 : (g.M_per_group >= 1024 ? 2 : 1);
+        if (ldx % VEC != 0) throw AchError{ACH_ERR_INVALID, name + ": activation row stride not 16-byte aligned"};
+        if (o.conv_k > 0 && (o.Cin % VEC != 0 || pk.K != o.conv_k * o.conv_k * o.Cin)) throw AchError{ACH_ERR_UNSUPPORTED, name + ": conv channel count not 16-byte aligned"};
+        // launch geometry: >= ~4 workgroups per CU.  Rows first (P sub-tiles of 16 rows per wave), then split the
+        // N-chunks over blockIdx.z when the row count alone cannot fill 256 CUs (10x10 / 20x20 maps, FC layers).
+        const long kTargetBlocks = 1024;
+        int P = 4;
+        while (P > 1 && cdivl(g.M_per_group, 64L * P) * g.groups < kTargetBlocks) P >>= 1;
+        const long row_blocks = cdivl(g.M_per_group, 64L * P) * g.groups;
+        int zsplit = int(std::min<long>(pk.nchunks, std::max<long>(1, cdivl(kTargetBlocks, row_blocks))));
+        g.chunks_per_block = cdiv(pk.nchunks, zsplit);
         const int NT = pk.NT;
         void** ydyn = o.ydyn;
         const double esz = double(sizeof(T));
@@ -476,7 +484,7 @@ public:
                             for (int dx = 0; dx < 2; ++dx)
                                 l.w[size_t(o) * 4 * Ci + (dy * 2 + dx) * Ci + c] = w.data[((size_t(o) * Ci + c) * 2 + dy) * 2 + dx];
                 A y = alloc(x.B, x.H / 2, x.W / 2, Co);
-                GemmOpt o; o.patch = 2; o.Hin = x.H; o.Win = x.W; o.Cin = Ci;
+                GemmOpt o; o.conv_k = 2; o.conv_s = 2; o.conv_p = 0; o.Hin = x.H; o.Win = x.W; o.Cin = Ci; o.Ho = x.H / 2; o.Wo = x.W / 2;
                 gemm(d + ".1", t.p, t.ld, y.rows(), pack(l), y.p, y.ld, o);
                 x = y;
             }
@@ -607,52 +615,92 @@ public:
     }
 
     // ------------------------------------------------------------------------------------------ radar (a14-a15)
-    void rcnet(Pl outs[3]) {                                                     // RadarEncoder.py:38-109
+    // dense k x k conv weight [Co][Ci][k][k] -> implicit-GEMM matrix with K ordered (tap, channel) over Cp channels per tap
+    Lin conv_lin(const std::string& wkey, const std::string& bkey, int Ci, int Cp, int k) const {
+        const HostTensor& w = W(wkey);
+        const int Co = int(w.shape[0]);
+        if (w.numel() != long(Co) * Ci * k * k) throw AchError{ACH_ERR_MISSING_KEY, "conv weight shape: " + wkey};
+        Lin l; l.N = Co; l.K = k * k * Cp; l.w.assign(size_t(Co) * l.K, 0.f);
+        for (int o = 0; o < Co; ++o)
+            for (int c = 0; c < Ci; ++c)
+                for (int t = 0; t < k * k; ++t) l.w[size_t(o) * l.K + size_t(t) * Cp + c] = w.data[(size_t(o) * Ci + c) * k * k + t];
+        if (!bkey.empty() && hasW(bkey)) l.b = W(bkey).data; else l.b.assign(size_t(Co), 0.f);
+        return l;
+    }
+    A conv_gemm(const std::string& name, const A& x, const Lin& l, int k, int stride, int act, const A* residual = nullptr) {
+        const int pad = k / 2;
+        const int Ho = (x.H + 2 * pad - k) / stride + 1, Wo = (x.W + 2 * pad - k) / stride + 1;
+        A y = alloc(x.B, Ho, Wo, l.N);
+        GemmOpt o; o.act = act; o.residual = residual;
+        o.conv_k = k; o.conv_s = stride; o.conv_p = pad; o.Hin = x.H; o.Win = x.W; o.Cin = int(x.ld); o.Ho = Ho; o.Wo = Wo;
+        gemm(name, x.p, x.ld, y.rows(), pack(l), y.p, y.ld, o);
+        return y;
+    }
+    void rcnet(A outs[3]) {                                                      // RadarEncoder.py:38-109
         const int* w = widths();
         const int chans[9] = {3, w[0] / 4, w[0] / 4, w[0] / 4, w[1] / 4, w[1] / 4, w[2] / 4, w[2] / 4, w[3] / 4};
         const bool down[8] = {true, true, false, true, false, true, false, true};
-        const int B = batch;
-        int H = cfg.resolution;
-        Pl x; x.B = B; x.C = 3; x.H = H; x.W = H; x.p = nullptr;                 // block 0 reads the user's radar map
+        const int B = batch, R = cfg.resolution;
+        A x = alloc(B, R, R, 3);
+        {
+            ToNhwcParams tp{nullptr, x.p, B, 3, R, R, x.ld};
+            const dim3 grid(unsigned(cdivl(x.rows(), 256))), block(256);
+            const void** rin = &io.radar;
+            add_op("image_radar_encoder.radar_encoder.to_nhwc", [tp, grid, block, rin](hipStream_t s) mutable { tp.X = *rin; ACH_LAUNCH(nchw_to_nhwc_kernel<T>, grid, block, s, tp); },
+                   double(x.rows()) * (3 + x.ld) * sizeof(T));
+        }
         for (int i = 0; i < 8; ++i) {
             const std::string pfx = "image_radar_encoder.radar_encoder.rc_blocks." + std::to_string(i);
             const std::string d = pfx + ".radar_conv.deformable_conv";
-            const int C = chans[i], Co = chans[i + 1];
-            // offsets + modulators
-            std::vector<float> wom(size_t(27) * C * 9), bom(27);
-            const HostTensor& wo = W(d + ".offset_conv.weight"); const HostTensor& wm = W(d + ".modulator_conv.weight");
-            if (wo.numel() != 18L * C * 9 || wm.numel() != 9L * C * 9) throw AchError{ACH_ERR_MISSING_KEY, "deformable conv shapes at " + d};
-            std::copy(wo.data.begin(), wo.data.end(), wom.begin());
-            std::copy(wm.data.begin(), wm.data.end(), wom.begin() + 18L * C * 9);
-            std::copy(W(d + ".offset_conv.bias").data.begin(), W(d + ".offset_conv.bias").data.end(), bom.begin());
-            std::copy(W(d + ".modulator_conv.bias").data.begin(), W(d + ".modulator_conv.bias").data.end(), bom.begin() + 18);
-            Pl pooled = alloc_pl(B, C, H, H);
-            float* offmask = alloc_f32(size_t(B) * 27 * H * H);
-            OffMaskParams po{x.p, pooled.p, offmask, up_f32(wom), up_f32(bom), B, C, H, H};
-            const dim3 grid(unsigned(cdivl(long(B) * H * H, 256))), block(256);
-            const void** rin = (i == 0) ? &io.radar : nullptr;
-            add_op(pfx + ".offmask", [po, grid, block, rin](hipStream_t s) mutable { if (rin) po.X = *rin; ACH_LAUNCH(radar_offmask_kernel<T>, grid, block, s, po); });
-            // deformable conv + 1x1 + BN + ReLU + residual
+            const int C = chans[i], Cp = int(x.ld);
+            // AvgPool2d(3,1,1)
+            A pooled = alloc(B, x.H, x.W, C);
+            { PoolParams pp{x.p, x.ld, pooled.p, pooled.ld, B, x.H, x.W, C}; ew(pfx + ".avgpool", avgpool3x3_kernel<T>, pp, x.rows() * ((C + 3) / 4), 2.0 * x.rows() * Cp * sizeof(T)); }
+            // offset_conv (18) + modulator_conv (9) as one implicit GEMM
+            Lin lo = conv_lin(d + ".offset_conv.weight", d + ".offset_conv.bias", C, Cp, 3);
+            Lin lm = conv_lin(d + ".modulator_conv.weight", d + ".modulator_conv.bias", C, Cp, 3);
+            if (lo.N != 18 || lm.N != 9) throw AchError{ACH_ERR_MISSING_KEY, "deformable conv shapes at " + d};
+            Lin lom; lom.N = 27; lom.K = lo.K; lom.w = lo.w; lom.w.insert(lom.w.end(), lm.w.begin(), lm.w.end()); lom.b = lo.b; lom.b.insert(lom.b.end(), lm.b.begin(), lm.b.end());
+            A om = conv_gemm(pfx + ".offmask", pooled, lom, 3, 1, ACT_NONE);
+            // regular_conv (no bias) folded with weight_conv1 (bias) and BatchNorm:  Wf[co][k][c] = sum_m W1'[co][m] Wd3[m][c][k]
             std::vector<float> sc, sh; bn_coeffs(pfx + ".norm", 1e-5, sc, sh);
             const HostTensor& w1 = W(pfx + ".weight_conv1.weight"); const HostTensor& b1 = W(pfx + ".weight_conv1.bias");
-            std::vector<float> w1f(size_t(C) * C), b1f(static_cast<size_t>(C), 0.f);
-            for (int o = 0; o < C; ++o) { for (int c = 0; c < C; ++c) w1f[size_t(o) * C + c] = w1.data[size_t(o) * C + c] * sc[o]; b1f[o] = b1.data[o] * sc[o] + sh[o]; }
-            Pl y = alloc_pl(B, C, H, H);
-            DeformParams pd{pooled.p, offmask, x.p, y.p, up_f32(W(d + ".regular_conv.weight").data), up_f32(w1f), up_f32(b1f), B, H, H};
-            add_op(pfx + ".deform", [pd, C, rin](hipStream_t s) mutable {
-                if (rin) pd.res = *rin;
-                launch_radar_deform<T>(pd, C, s);
-            });
-            if (C != 3 && C != 8 && C != 12 && C != 16 && C != 24 && C != 30 && C != 36) throw AchError{ACH_ERR_UNSUPPORTED, "radar width"};
-            // weight_conv2
-            const int k = down[i] ? 3 : 1, st = down[i] ? 2 : 1;
-            const int Ho = down[i] ? (H + 2 - 3) / 2 + 1 : H;
-            Pl z = alloc_pl(B, Co, Ho, Ho);
-            ConvPlanarParams pc{y.p, z.p, up_f32(W(pfx + ".weight_conv2.weight").data), up_f32(W(pfx + ".weight_conv2.bias").data),
-                                B, C, H, H, Co, Ho, Ho, k, st, ACT_NONE};
-            const dim3 g2(unsigned(cdivl(long(B) * Ho * Ho, 256)), unsigned(cdiv(Co, 8)));
-            add_op(pfx + ".conv2", [pc, g2, block](hipStream_t s) { ACH_LAUNCH((conv_planar_kernel<T, 8>), g2, block, s, pc); });
-            x = z; H = Ho;
+            const HostTensor& w3 = W(d + ".regular_conv.weight");
+            if (w3.numel() != long(C) * C * 9 || w1.numel() != long(C) * C) throw AchError{ACH_ERR_MISSING_KEY, "radar block shapes at " + pfx};
+            Lin lf; lf.N = C; lf.K = 9 * Cp; lf.w.assign(size_t(C) * lf.K, 0.f); lf.b.assign(size_t(C), 0.f);
+            for (int co = 0; co < C; ++co) {
+                lf.b[co] = b1.data[co] * sc[co] + sh[co];
+                for (int c = 0; c < C; ++c)
+                    for (int k = 0; k < 9; ++k) {
+                        double acc = 0;
+                        for (int m = 0; m < C; ++m) acc += double(w1.data[size_t(co) * C + m]) * sc[co] * w3.data[(size_t(m) * C + c) * 9 + k];
+                        lf.w[size_t(co) * lf.K + size_t(k) * Cp + c] = float(acc);
+                    }
+            }
+            A y;
+            DeformParams dp;
+            std::memset(&dp, 0, sizeof(dp));
+            dp.pooled = pooled.p; dp.ldp = pooled.ld; dp.om = om.p; dp.ldo = om.ld; dp.res = x.p; dp.ldr = x.ld;
+            dp.B = B; dp.H = x.H; dp.Wd = x.W; dp.Cp = Cp;
+            if (Cp == 8 && (C == 3 || C == 8)) {
+                y = alloc(B, x.H, x.W, C);
+                dp.Y = y.p; dp.ldy = y.ld; dp.Wf = up_f32(lf.w); dp.bf = up_f32(lf.b);
+                const dim3 grid(unsigned(cdivl(x.rows(), 256))), block(256);
+                const double bytes = double(x.rows()) * (3.0 * Cp + 32) * sizeof(T);
+                if (C == 3) add_op(pfx + ".deform", [dp, grid, block](hipStream_t s) { ACH_LAUNCH((deform_fused_kernel<T, 3, 8>), grid, block, s, dp); }, bytes);
+                else add_op(pfx + ".deform", [dp, grid, block](hipStream_t s) { ACH_LAUNCH((deform_fused_kernel<T, 8, 8>), grid, block, s, dp); }, bytes);
+            } else {
+                A col = alloc(B, x.H, x.W, 9 * Cp);
+                dp.Y = col.p; dp.ldy = col.ld;
+                ew(pfx + ".deform.sample", deform_sample_kernel<T>, dp, x.rows() * 9 * (Cp / 4), double(x.rows()) * (10.0 * Cp + 32) * sizeof(T));
+                y = alloc(B, x.H, x.W, C);
+                GemmOpt o; o.act = ACT_RELU; o.residual = &x;            // epilogue order: act, then + residual
+                gemm(pfx + ".deform.contract", col, pack(lf), y, o);
+            }
+            // weight_conv2: 1x1, or 3x3 stride 2
+            const int k = down[i] ? 3 : 1;
+            x = conv_gemm(pfx + ".conv2", y, conv_lin(pfx + ".weight_conv2.weight", pfx + ".weight_conv2.bias", C, int(y.ld), k), k, down[i] ? 2 : 1, ACT_NONE);
+            if (x.C != chans[i + 1]) throw AchError{ACH_ERR_MISSING_KEY, "radar width mismatch at " + pfx};
             tap("radar.b" + std::to_string(i), x);
             if (i == 3) outs[0] = x;
             if (i == 5) outs[1] = x;
@@ -662,33 +710,29 @@ public:
     }
 
     // ------------------------------------------------------------------------------------------ fusion (a16)
-    A fuse(int stage, const A& img, const Pl& rad) {                             // IREncoder.py:79-89
+    A fuse(int stage, const A& img, const A& rad) {                              // IREncoder.py:79-89
         const std::string e = "image_radar_encoder";
         const std::string st = std::to_string(stage);
         const int Ci = img.C, Cr = rad.C, HW = img.H * img.W;
         std::vector<float> sc, sh; bn_coeffs(e + ".norm_stage" + st, 1e-5, sc, sh);
         if (int(sc.size()) != Ci + Cr) throw AchError{ACH_ERR_MISSING_KEY, "fusion norm width"};
         A y = alloc(img.B, img.H, img.W, Ci + Cr);
-        // image half
-        float* pi = nullptr;
-        const int S = stats(e + ".eca_img" + st + ".stats", img, pi);
-        const HostTensor& wi = W(e + ".channel_attn_stage" + st + ".0.conv.weight");
-        float* sci = alloc_f32(size_t(img.B) * Ci);
-        EcaParams ei{pi, S, up_f32(wi.data), int(wi.numel()), up_f32(std::vector<float>(sc.begin(), sc.begin() + Ci)), sci, img.B, Ci, HW};
-        ew(e + ".eca_img" + st, eca_scale_kernel, ei, long(img.B) * Ci);
-        FuseParams fi{img.p, img.ld, 0, y.p, y.ld, sci, up_f32(std::vector<float>(sh.begin(), sh.begin() + Ci)), img.B, HW, Ci};
-        ew(e + ".fuse_img" + st, fuse_scale_kernel<T>, fi, img.rows() * Ci);
-        // radar half (planar input)
-        float* pr = alloc_f32(size_t(rad.B) * 2 * Cr);
-        StatNchwParams sr{rad.p, pr, HW, Cr};
-        { const dim3 grid(unsigned(rad.B * Cr)), block(256); add_op(e + ".eca_rad" + st + ".stats", [sr, grid, block](hipStream_t s) { ACH_LAUNCH(chan_stats_nchw_kernel<T>, grid, block, s, sr); }); }
-        const HostTensor& wr = W(e + ".channel_attn_stage" + st + ".1.conv.weight");
-        float* scr = alloc_f32(size_t(rad.B) * Cr);
-        EcaParams er{pr, 1, up_f32(wr.data), int(wr.numel()), up_f32(std::vector<float>(sc.begin() + Ci, sc.end())), scr, rad.B, Cr, HW};
-        ew(e + ".eca_rad" + st, eca_scale_kernel, er, long(rad.B) * Cr);
-        A yr = y.slice(Ci, Cr);
-        FuseParams fr{rad.p, 0, 1, yr.p, yr.ld, scr, up_f32(std::vector<float>(sh.begin() + Ci, sh.end())), rad.B, HW, Cr};
-        ew(e + ".fuse_rad" + st, fuse_scale_kernel<T>, fr, long(rad.B) * HW * Cr);
+        const A srcs[2] = {img, rad};
+        const char* tag[2] = {"img", "rad"};
+        int coff = 0;
+        for (int h = 0; h < 2; ++h) {
+            const A& x = srcs[h];
+            float* part = nullptr;
+            const int S = stats(e + ".eca_" + tag[h] + st + ".stats", x, part);
+            const HostTensor& wk = W(e + ".channel_attn_stage" + st + "." + std::to_string(h) + ".conv.weight");
+            float* scl = alloc_f32(size_t(x.B) * x.C);
+            EcaParams ep{part, S, up_f32(wk.data), int(wk.numel()), up_f32(std::vector<float>(sc.begin() + coff, sc.begin() + coff + x.C)), scl, x.B, x.C, HW};
+            ew(e + ".eca_" + tag[h] + st, eca_scale_kernel, ep, long(x.B) * x.C);
+            A ys = y.slice(coff, x.C);
+            FuseParams fp{x.p, x.ld, 0, ys.p, ys.ld, scl, up_f32(std::vector<float>(sh.begin() + coff, sh.begin() + coff + x.C)), x.B, HW, x.C};
+            ew(e + ".fuse_" + tag[h] + st, fuse_scale_kernel<T>, fp, x.rows() * x.C, 2.0 * x.rows() * x.C * sizeof(T));
+            coff += x.C;
+        }
         tap("p" + st, y);
         return y;
     }
@@ -815,7 +859,7 @@ public:
         edgenext("image_radar_encoder.fpn.backbone", m);
         A q[3];
         neck(m, q);
-        Pl r[3];
+        A r[3];
         rcnet(r);
         tap("q3", q[0]); tap("q4", q[1]); tap("q5", q[2]);
         A p[3] = {fuse(3, q[0], r[0]), fuse(4, q[1], r[1]), fuse(5, q[2], r[2])};

@@ -34,7 +34,10 @@ __host__ __device__ __forceinline__ long wfrag_offset(int n, int k, int NT, int 
 
 struct GemmParams {
     const void* X; long ldx;            // activations: row m at X + m*ldx (elements), K contiguous channels
-    int patch, Hin, Win, Cin;           // patch>0: rows are outputs of a patch x patch / stride patch conv over NHWC [.,Hin,Win,Cin]
+    // conv_k > 0: implicit-GEMM convolution over an NHWC input [.,Hin,Win,(Cin<=ldx)]: row m is output pixel (b,oy,ox) of a
+    // conv_k x conv_k / stride conv_s / zero-pad conv_p conv, K ordered (tap, channel) with Cin channels per tap
+    // (Cin a multiple of the 16-byte vector).  Covers EdgeNeXt's 2x2/s2 patchify convs and every dense 3x3.
+    int conv_k, conv_s, conv_p, Hin, Win, Cin, Ho, Wo;
     const void* W; long w_group_stride; // packed fragments; per-group stride in elements (0: shared)
     const float* bias; long bias_group_stride;
     void* Y; long ldy;                  // NHWC: row m at Y + m*ldy ; NCHW: see out_nchw
@@ -42,6 +45,7 @@ struct GemmParams {
     unsigned* colmax;                   // optional [groups][N] order-encoded running max (zero-initialised)
     int M_per_group, groups, K, N;
     int nchunks, ksteps;
+    int chunks_per_block;               // blockIdx.z selects a contiguous range of N-chunks (fills the chip when M is small)
     int act, ln; float ln_eps;
     int out_nchw, HW, Ctot, coff;       // NCHW scatter: Y[((b*Ctot + coff + n)*HW + p)], m = b*HW + p
     int vec_store;                      // Y/R rows and channel offsets are 16-byte compatible
@@ -71,31 +75,39 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
     long xoff[P];
     bool valid[P];
     long mrow[P];
+    int iy0[P], ix0[P];                       // conv mode: top-left input coordinate of the receptive field
     ACH_UNROLL
     for (int q = 0; q < P; ++q) {
         const long mloc = row0 + q * 16 + px;
         valid[q] = mloc < p.M_per_group;
         const long m = long(grp) * p.M_per_group + (valid[q] ? mloc : 0);
         mrow[q] = m;
-        if (p.patch > 0) {
-            const int Wo = p.Win / p.patch, Ho = p.Hin / p.patch;
-            const long b = m / (long(Ho) * Wo);
-            const int rem = int(m - b * long(Ho) * Wo);
-            const int oy = rem / Wo, ox = rem - oy * Wo;
-            xoff[q] = ((b * p.Hin + long(oy) * p.patch) * p.Win + long(ox) * p.patch) * p.Cin;
+        iy0[q] = 0; ix0[q] = 0;
+        if (p.conv_k > 0) {
+            const long b = m / (long(p.Ho) * p.Wo);
+            const int rem = int(m - b * long(p.Ho) * p.Wo);
+            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            iy0[q] = oy * p.conv_s - p.conv_p;
+            ix0[q] = ox * p.conv_s - p.conv_p;
+            xoff[q] = b * p.Hin * long(p.Win);            // pixel index of the sample's first input pixel
         } else {
             xoff[q] = m * p.ldx;
         }
     }
-    const int seg_len = p.patch > 0 ? p.patch * p.Cin : 0x7fffffff;
-    const long seg_stride = long(p.Win) * p.Cin;
 
     auto load_x = [&](int q, int s) -> uint4 {
         const int k0 = s * KC + g * VEC;
         if (!valid[q] || k0 >= p.K) return make_uint4(0u, 0u, 0u, 0u);
-        long off = xoff[q];
-        if (p.patch > 0) { const int sg = k0 / seg_len; off += sg * seg_stride + (k0 - sg * seg_len); }
-        else off += k0;
+        long off;
+        if (p.conv_k > 0) {
+            const int tap = k0 / p.Cin, c = k0 - tap * p.Cin;
+            const int ty = tap / p.conv_k;
+            const int iy = iy0[q] + ty, ix = ix0[q] + (tap - ty * p.conv_k);
+            if (iy < 0 || iy >= p.Hin || ix < 0 || ix >= p.Win) return make_uint4(0u, 0u, 0u, 0u);
+            off = (xoff[q] + long(iy) * p.Win + ix) * p.ldx + c;
+        } else {
+            off = xoff[q] + k0;
+        }
         return *reinterpret_cast<const uint4*>(X + off);
     };
 
@@ -131,7 +143,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
         }
     }
 
-    for (int c = 0; c < p.nchunks; ++c) {
+    const int c_begin = blockIdx.z * p.chunks_per_block;
+    const int c_end = (c_begin + p.chunks_per_block < p.nchunks) ? c_begin + p.chunks_per_block : p.nchunks;
+    for (int c = c_begin; c < c_end; ++c) {
         f32x4 acc[P][NT];
         ACH_UNROLL
         for (int q = 0; q < P; ++q)
@@ -238,7 +252,7 @@ __global__ void colmax_decode_kernel(const unsigned* enc, T* out, int N, long ld
 
 template <class T>
 inline void launch_gemm(const GemmParams& p, int NT, int P, hipStream_t stream) {
-    const dim3 grid(unsigned(cdivl(p.M_per_group, 64L * P)), unsigned(p.groups)), block(256);
+    const dim3 grid(unsigned(cdivl(p.M_per_group, 64L * P)), unsigned(p.groups), unsigned(cdiv(p.nchunks, p.chunks_per_block))), block(256);
 #define ACH_GEMM_CASE(nt, pp) if (NT == nt && P == pp) { ACH_LAUNCH((gemm_kernel<T, nt, pp>), grid, block, stream, p); return; }
     ACH_GEMM_CASE(1, 1) ACH_GEMM_CASE(1, 2) ACH_GEMM_CASE(1, 4)
     ACH_GEMM_CASE(2, 1) ACH_GEMM_CASE(2, 2) ACH_GEMM_CASE(2, 4)

@@ -1,196 +1,183 @@
 // k_radar.h — the radar-map branch (RCNet: 8 x RCBlock, backbone/radar/RadarEncoder.py:38-109).
 //
-// Channel counts are tiny (3..72) and the maps are read by gathers, so this branch stays in planar NCHW
-// (coalesced along x for every channel plane) and runs on the VALU with wave-uniform weight loads; no MFMA.
-// Per block:  radar_offmask (AvgPool3x3 + offset conv 3x3 -> 18 + modulator conv 3x3 -> 9, 2*sigmoid)
-//             radar_deform  (modulated deformable 3x3 sampling + contraction + 1x1(bias) + BN + ReLU + residual)
-//             conv_planar   (weight_conv2: 1x1 or 3x3 stride 2)
-// deform_conv2d semantics restated from torchvision 0.12.0 (see oracle/deform_conv.py header).
+// Layout: NHWC with the channel count padded to a multiple of 8 (3 -> 8, 12 -> 16, 44 -> 48; padding lanes stay 0),
+// so that a bilinear corner of the deformable sampling is ONE vector load for all channels and the dense 3x3
+// convolutions (offset/modulator conv, stride-2 weight_conv2) run as implicit GEMMs on MFMA (k_gemm.h conv mode).
+// Per RCBlock:
+//   avgpool3x3        AvgPool2d(3,1,1), count_include_pad                                          (VALU, streaming)
+//   gemm conv3x3      offset_conv (18) + modulator_conv (9) in one 27-wide implicit GEMM          (MFMA)
+//   deform            modulated deformable 3x3 sampling (torchvision 0.12.0 semantics, oracle/deform_conv.py)
+//                     + [regular_conv folded with weight_conv1 and BatchNorm] + ReLU + residual:
+//                       C <= 8 : one fused kernel, contraction on the VALU with wave-uniform weights
+//                       C >= 12: sampling kernel writes the 9*Cp "columns", contraction is an MFMA GEMM
+//   gemm              weight_conv2: 1x1, or 3x3 stride 2 as implicit GEMM                         (MFMA)
 #pragma once
 #include "ach_platform.h"
 
 namespace ach {
 
-struct OffMaskParams {
-    const void* X;            // [B,C,H,W] block input
-    void* pooled;             // [B,C,H,W] AvgPool2d(3,1,1) (count_include_pad) of X
-    float* offmask;           // [B,27,H,W] fp32: 18 offsets (dy,dx interleaved per tap) then 9 masks (2*sigmoid)
-    const float* W;           // [27][C][9]  (offset_conv rows 0..17, modulator_conv rows 18..26)
-    const float* bias;        // [27]
-    int B, C, H, Wd;
-};
-
+// NCHW [B,C,H,W] -> NHWC [B,H,W,ld] (channels C..ld-1 are left untouched = 0)
+struct ToNhwcParams { const void* X; void* Y; int B, C, H, Wd; long ld; };
 template <class T>
-__global__ __launch_bounds__(256) void radar_offmask_kernel(const OffMaskParams p) {
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const ToNhwcParams p) {
     const long total = long(p.B) * p.H * p.Wd;
     const long idx = long(blockIdx.x) * blockDim.x + threadIdx.x;
     if (idx >= total) return;
-    const int x = int(idx % p.Wd);
-    const int y = int((idx / p.Wd) % p.H);
-    const long b = idx / (long(p.Wd) * p.H);
     const long HW = long(p.H) * p.Wd;
-    float acc[27];
+    const long b = idx / HW, pix = idx - b * HW;
+    const T* x = static_cast<const T*>(p.X) + b * p.C * HW + pix;
+    T* y = static_cast<T*>(p.Y) + idx * p.ld;
+    for (int c = 0; c < p.C; ++c) y[c] = x[c * HW];
+}
+
+// AvgPool2d(3, stride 1, pad 1, count_include_pad=True): always divides by 9
+struct PoolParams { const void* X; long ldx; void* Y; long ldy; int B, H, Wd, C; };
+template <class T>
+__global__ __launch_bounds__(256) void avgpool3x3_kernel(const PoolParams p) {
+    const int cq = (p.C + 3) >> 2;
+    const long total = long(p.B) * p.H * p.Wd * cq;
+    const long idx = long(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = int(idx % cq) * 4;
+    long pix = idx / cq;
+    const int x = int(pix % p.Wd); pix /= p.Wd;
+    const int y = int(pix % p.H);
+    const long b = pix / p.H;
+    const T* X = static_cast<const T*>(p.X);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
     ACH_UNROLL
-    for (int o = 0; o < 27; ++o) acc[o] = p.bias[o];
-    for (int c = 0; c < p.C; ++c) {
-        const T* plane = static_cast<const T*>(p.X) + (b * p.C + c) * HW;
-        float win[5][5];
+    for (int dy = -1; dy <= 1; ++dy) {
+        const int iy = y + dy;
+        if (iy < 0 || iy >= p.H) continue;
         ACH_UNROLL
-        for (int dy = 0; dy < 5; ++dy)
-            ACH_UNROLL
-            for (int dx = 0; dx < 5; ++dx) {
-                const int iy = y + dy - 2, ix = x + dx - 2;
-                win[dy][dx] = (iy >= 0 && iy < p.H && ix >= 0 && ix < p.Wd) ? Store<T>::ld(plane + long(iy) * p.Wd + ix) : 0.f;
-            }
-        // pooled value at each of the 3x3 conv taps; a tap outside the map is the conv's zero padding
-        float pl[9];
-        ACH_UNROLL
-        for (int ky = 0; ky < 3; ++ky)
-            ACH_UNROLL
-            for (int kx = 0; kx < 3; ++kx) {
-                const int py = y + ky - 1, px = x + kx - 1;
-                float s = 0.f;
-                ACH_UNROLL
-                for (int a = 0; a < 3; ++a)
-                    ACH_UNROLL
-                    for (int bb = 0; bb < 3; ++bb) s += win[ky + a][kx + bb];
-                pl[ky * 3 + kx] = (py >= 0 && py < p.H && px >= 0 && px < p.Wd) ? s * (1.0f / 9.0f) : 0.f;
-            }
-        Store<T>::st(static_cast<T*>(p.pooled) + (b * p.C + c) * HW + long(y) * p.Wd + x, pl[4]);
-        const float* w = p.W + long(c) * 9;
-        ACH_UNROLL
-        for (int o = 0; o < 27; ++o) {
-            const float* wo = w + long(o) * p.C * 9;
-            float s = 0.f;
-            ACH_UNROLL
-            for (int k = 0; k < 9; ++k) s += wo[k] * pl[k];
-            acc[o] += s;
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int ix = x + dx;
+            if (ix < 0 || ix >= p.Wd) continue;
+            float v[4];
+            Store<T>::ld4(X + ((b * p.H + iy) * p.Wd + ix) * p.ldx + c, v);
+            acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
         }
     }
-    float* om = p.offmask + b * 27 * HW + long(y) * p.Wd + x;
     ACH_UNROLL
-    for (int o = 0; o < 18; ++o) om[o * HW] = acc[o];
-    ACH_UNROLL
-    for (int o = 18; o < 27; ++o) om[o * HW] = 2.0f * sigmoidf_(acc[o]);
+    for (int i = 0; i < 4; ++i) acc[i] *= (1.0f / 9.0f);
+    Store<T>::st4(static_cast<T*>(p.Y) + ((b * p.H + y) * p.Wd + x) * p.ldy + c, acc);
+}
+
+// ---- shared by both deformable kernels: one tap's bilinear footprint (zero outside, torchvision semantics)
+struct BilinearTap {
+    long o00, o01, o10, o11;      // pixel indices of the four corners (clamped into the map)
+    float w00, w01, w10, w11;     // bilinear weights, already 0 for corners outside the map and multiplied by the mask
+};
+__device__ __forceinline__ BilinearTap make_tap(float sy, float sx, float mask, int H, int Wd, long base) {
+    BilinearTap t;
+    const bool inside = sy > -1.f && sy < float(H) && sx > -1.f && sx < float(Wd);
+    const float fy = floorf(sy), fx = floorf(sx);
+    const int y0 = int(fy), x0 = int(fx), y1 = y0 + 1, x1 = x0 + 1;
+    const float ly = sy - fy, lx = sx - fx, hy = 1.f - ly, hx = 1.f - lx;
+    const float m = inside ? mask : 0.f;
+    const bool oy0 = y0 >= 0 && y0 <= H - 1, oy1 = y1 >= 0 && y1 <= H - 1, ox0 = x0 >= 0 && x0 <= Wd - 1, ox1 = x1 >= 0 && x1 <= Wd - 1;
+    t.w00 = (oy0 && ox0) ? hy * hx * m : 0.f;
+    t.w01 = (oy0 && ox1) ? hy * lx * m : 0.f;
+    t.w10 = (oy1 && ox0) ? ly * hx * m : 0.f;
+    t.w11 = (oy1 && ox1) ? ly * lx * m : 0.f;
+    const int cy0 = y0 < 0 ? 0 : (y0 > H - 1 ? H - 1 : y0), cy1 = y1 < 0 ? 0 : (y1 > H - 1 ? H - 1 : y1);
+    const int cx0 = x0 < 0 ? 0 : (x0 > Wd - 1 ? Wd - 1 : x0), cx1 = x1 < 0 ? 0 : (x1 > Wd - 1 ? Wd - 1 : x1);
+    t.o00 = base + long(cy0) * Wd + cx0; t.o01 = base + long(cy0) * Wd + cx1;
+    t.o10 = base + long(cy1) * Wd + cx0; t.o11 = base + long(cy1) * Wd + cx1;
+    return t;
 }
 
 struct DeformParams {
-    const void* pooled;       // [B,C,H,W]  sampled tensor (the block's avg-pooled input)
-    const float* offmask;     // [B,27,H,W]
-    const void* res;          // [B,C,H,W]  block input (residual)
-    void* Y;                  // [B,C,H,W]  relu(bn(conv1x1(dcn))) + res
-    const float* Wd3;         // regular_conv [C][C][9]
-    const float* W1;          // weight_conv1 [C][C] with BN scale folded
-    const float* b1;          // [C] (bias and BN shift folded)
-    int B, H, Wd;
+    const void* pooled; long ldp;     // sampled tensor (avg-pooled block input), NHWC
+    const void* om; long ldo;         // [pixels, 27]: 18 offsets (dy,dx per tap) + 9 modulator logits
+    const void* res; long ldr;        // block input (residual)
+    void* Y; long ldy;                // fused: relu(Wf . col + bf) + res ; sample: the columns [pixels, 9*Cp]
+    const float* Wf;                  // fused: [C][9][CP] folded (weight_conv1 . BN . regular_conv)
+    const float* bf;                  // fused: [C]
+    int B, H, Wd, Cp;
 };
 
-template <class T, int C>
-__global__ __launch_bounds__(256) void radar_deform_kernel(const DeformParams p) {
+// C <= 8: sampling + contraction + ReLU + residual in one pass, one thread per pixel
+template <class T, int C, int CP>
+__global__ __launch_bounds__(256) void deform_fused_kernel(const DeformParams p) {
     const long total = long(p.B) * p.H * p.Wd;
     const long idx = long(blockIdx.x) * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const int x = int(idx % p.Wd);
     const int y = int((idx / p.Wd) % p.H);
     const long b = idx / (long(p.Wd) * p.H);
-    const long HW = long(p.H) * p.Wd;
-    const float* om = p.offmask + b * 27 * HW + long(y) * p.Wd + x;
-    const T* base = static_cast<const T*>(p.pooled) + b * C * HW;
+    const T* om = static_cast<const T*>(p.om) + idx * p.ldo;
+    float o[28];
+    ACH_UNROLL
+    for (int i = 0; i < 7; ++i) { float v[4]; Store<T>::ld4(om + i * 4, v); o[i * 4] = v[0]; o[i * 4 + 1] = v[1]; o[i * 4 + 2] = v[2]; o[i * 4 + 3] = v[3]; }
+    const T* P0 = static_cast<const T*>(p.pooled);
     float acc[C];
     ACH_UNROLL
-    for (int o = 0; o < C; ++o) acc[o] = 0.f;
+    for (int i = 0; i < C; ++i) acc[i] = p.bf[i];
+    ACH_UNROLL
     for (int k = 0; k < 9; ++k) {
-        const float sy = float(y - 1 + k / 3) + om[(2 * k) * HW];
-        const float sx = float(x - 1 + k % 3) + om[(2 * k + 1) * HW];
-        const float mk = om[(18 + k) * HW];
-        if (!(sy > -1.f && sy < float(p.H) && sx > -1.f && sx < float(p.Wd))) continue;   // sample is 0
-        const float fy = floorf(sy), fx = floorf(sx);
-        const int y0 = int(fy), x0 = int(fx), y1 = y0 + 1, x1 = x0 + 1;
-        const float ly = sy - fy, lx = sx - fx, hy = 1.f - ly, hx = 1.f - lx;
-        const bool oky0 = y0 >= 0, oky1 = y1 <= p.H - 1, okx0 = x0 >= 0, okx1 = x1 <= p.Wd - 1;
-        const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
-        const long o00 = long(y0) * p.Wd + x0;
-        for (int c = 0; c < C; ++c) {
-            const T* pl = base + c * HW;
-            const float v1 = (oky0 && okx0) ? Store<T>::ld(pl + o00) : 0.f;
-            const float v2 = (oky0 && okx1) ? Store<T>::ld(pl + o00 + 1) : 0.f;
-            const float v3 = (oky1 && okx0) ? Store<T>::ld(pl + o00 + p.Wd) : 0.f;
-            const float v4 = (oky1 && okx1) ? Store<T>::ld(pl + o00 + p.Wd + 1) : 0.f;
-            const float v = (w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4) * mk;
-            const float* w = p.Wd3 + long(c) * 9 + k;
-            ACH_UNROLL
-            for (int o = 0; o < C; ++o) acc[o] += w[long(o) * C * 9] * v;
-        }
-    }
-    const long pix = long(y) * p.Wd + x;
-    for (int o = 0; o < C; ++o) {
-        float s = p.b1[o];
+        const BilinearTap t = make_tap(float(y - 1 + k / 3) + o[2 * k], float(x - 1 + k % 3) + o[2 * k + 1],
+                                       2.0f * sigmoidf_(o[18 + k]), p.H, p.Wd, b * p.H * long(p.Wd));
+        float v[CP];
         ACH_UNROLL
-        for (int c = 0; c < C; ++c) s += p.W1[o * C + c] * acc[c];
-        s = s > 0.f ? s : 0.f;
-        s += Store<T>::ld(static_cast<const T*>(p.res) + (b * C + o) * HW + pix);
-        Store<T>::st(static_cast<T*>(p.Y) + (b * C + o) * HW + pix, s);
+        for (int c = 0; c < CP; c += 4) {
+            float a[4], bq[4], cc[4], d[4];
+            Store<T>::ld4(P0 + t.o00 * p.ldp + c, a);
+            Store<T>::ld4(P0 + t.o01 * p.ldp + c, bq);
+            Store<T>::ld4(P0 + t.o10 * p.ldp + c, cc);
+            Store<T>::ld4(P0 + t.o11 * p.ldp + c, d);
+            ACH_UNROLL
+            for (int i = 0; i < 4; ++i) v[c + i] = t.w00 * a[i] + t.w01 * bq[i] + t.w10 * cc[i] + t.w11 * d[i];
+        }
+        const float* w = p.Wf + k * CP;
+        ACH_UNROLL
+        for (int co = 0; co < C; ++co)
+            ACH_UNROLL
+            for (int c = 0; c < C; ++c) acc[co] += w[co * 9 * CP + c] * v[c];
+    }
+    float outv[CP];
+    ACH_UNROLL
+    for (int i = 0; i < CP; ++i) outv[i] = 0.f;
+    ACH_UNROLL
+    for (int i = 0; i < C; ++i) outv[i] = acc[i] > 0.f ? acc[i] : 0.f;
+    const T* r = static_cast<const T*>(p.res) + idx * p.ldr;
+    T* yo = static_cast<T*>(p.Y) + idx * p.ldy;
+    ACH_UNROLL
+    for (int c = 0; c < CP; c += 4) {
+        float rr[4], ov[4];
+        Store<T>::ld4(r + c, rr);                 // padding lanes of the residual are zero
+        ACH_UNROLL
+        for (int i = 0; i < 4; ++i) ov[i] = outv[c + i] + rr[i];
+        Store<T>::st4(yo + c, ov);
     }
 }
 
+// generic: one thread per (pixel, tap, 4-channel group) writes the masked bilinear sample into the column buffer
 template <class T>
-inline bool launch_radar_deform(const DeformParams& p, int C, hipStream_t s) {
-    const long total = long(p.B) * p.H * p.Wd;
-    const dim3 grid(unsigned(cdivl(total, 256))), block(256);
-    switch (C) {
-        case 3: ACH_LAUNCH((radar_deform_kernel<T, 3>), grid, block, s, p); return true;
-        case 8: ACH_LAUNCH((radar_deform_kernel<T, 8>), grid, block, s, p); return true;
-        case 12: ACH_LAUNCH((radar_deform_kernel<T, 12>), grid, block, s, p); return true;
-        case 16: ACH_LAUNCH((radar_deform_kernel<T, 16>), grid, block, s, p); return true;
-        case 24: ACH_LAUNCH((radar_deform_kernel<T, 24>), grid, block, s, p); return true;
-        case 30: ACH_LAUNCH((radar_deform_kernel<T, 30>), grid, block, s, p); return true;
-        case 36: ACH_LAUNCH((radar_deform_kernel<T, 36>), grid, block, s, p); return true;
-        default: return false;
-    }
-}
-
-// planar direct convolution (k = 1 or 3, stride 1 or 2, zero padding k/2): CO output channels per thread
-struct ConvPlanarParams {
-    const void* X; void* Y;
-    const float* W;           // [Cout][Cin][k*k]
-    const float* bias;        // [Cout]
-    int B, Cin, H, Wd, Cout, Ho, Wo, k, stride, act;
-};
-template <class T, int CO>
-__global__ __launch_bounds__(256) void conv_planar_kernel(const ConvPlanarParams p) {
-    const long total = long(p.B) * p.Ho * p.Wo;
+__global__ __launch_bounds__(256) void deform_sample_kernel(const DeformParams p) {
+    const int cq = p.Cp >> 2;
+    const long total = long(p.B) * p.H * p.Wd * 9 * cq;
     const long idx = long(blockIdx.x) * blockDim.x + threadIdx.x;
     if (idx >= total) return;
-    const int co0 = blockIdx.y * CO;
-    const int ox = int(idx % p.Wo);
-    const int oy = int((idx / p.Wo) % p.Ho);
-    const long b = idx / (long(p.Wo) * p.Ho);
-    const long HW = long(p.H) * p.Wd;
-    const int pad = p.k / 2, kk = p.k * p.k;
-    float acc[CO];
+    const int c = int(idx % cq) * 4;
+    long r = idx / cq;
+    const int k = int(r % 9);
+    const long pix = r / 9;
+    const int x = int(pix % p.Wd);
+    const int y = int((pix / p.Wd) % p.H);
+    const long b = pix / (long(p.Wd) * p.H);
+    const T* om = static_cast<const T*>(p.om) + pix * p.ldo;
+    const float dy = Store<T>::ld(om + 2 * k), dx = Store<T>::ld(om + 2 * k + 1), ml = Store<T>::ld(om + 18 + k);
+    const BilinearTap t = make_tap(float(y - 1 + k / 3) + dy, float(x - 1 + k % 3) + dx, 2.0f * sigmoidf_(ml), p.H, p.Wd, b * p.H * long(p.Wd));
+    const T* P0 = static_cast<const T*>(p.pooled);
+    float a[4], bq[4], cc[4], d[4], v[4];
+    Store<T>::ld4(P0 + t.o00 * p.ldp + c, a);
+    Store<T>::ld4(P0 + t.o01 * p.ldp + c, bq);
+    Store<T>::ld4(P0 + t.o10 * p.ldp + c, cc);
+    Store<T>::ld4(P0 + t.o11 * p.ldp + c, d);
     ACH_UNROLL
-    for (int o = 0; o < CO; ++o) acc[o] = (co0 + o < p.Cout) ? p.bias[co0 + o] : 0.f;
-    for (int c = 0; c < p.Cin; ++c) {
-        const T* pl = static_cast<const T*>(p.X) + (b * p.Cin + c) * HW;
-        for (int ky = 0; ky < p.k; ++ky) {
-            const int iy = oy * p.stride - pad + ky;
-            if (iy < 0 || iy >= p.H) continue;
-            for (int kx = 0; kx < p.k; ++kx) {
-                const int ix = ox * p.stride - pad + kx;
-                if (ix < 0 || ix >= p.Wd) continue;
-                const float v = Store<T>::ld(pl + long(iy) * p.Wd + ix);
-                const float* w = p.W + (long(co0) * p.Cin + c) * kk + ky * p.k + kx;
-                ACH_UNROLL
-                for (int o = 0; o < CO; ++o)
-                    if (co0 + o < p.Cout) acc[o] += w[long(o) * p.Cin * kk] * v;
-            }
-        }
-    }
-    const long OHW = long(p.Ho) * p.Wo;
-    ACH_UNROLL
-    for (int o = 0; o < CO; ++o)
-        if (co0 + o < p.Cout)
-            Store<T>::st(static_cast<T*>(p.Y) + (b * p.Cout + co0 + o) * OHW + long(oy) * p.Wo + ox, apply_act(acc[o], p.act));
+    for (int i = 0; i < 4; ++i) v[i] = t.w00 * a[i] + t.w01 * bq[i] + t.w10 * cc[i] + t.w11 * d[i];
+    Store<T>::st4(static_cast<T*>(p.Y) + pix * p.ldy + k * p.Cp + c, v);
 }
 
 }  // namespace ach
