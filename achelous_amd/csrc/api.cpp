@@ -150,6 +150,12 @@ int ach_forward_profiled(ach_handle* h, const void* image, const void* radar, co
         h->eng->run_profiled(static_cast<hipStream_t>(stream), op_ms, capacity);
     });
 }
+int ach_bench_gemm(ach_handle* h, int M, int K, int N, int act, int ln, int residual, int P, int iters, void* stream, float* ms) {
+    return guarded(h, [&] {
+        if (M <= 0 || K <= 0 || N <= 0 || iters <= 0 || !ms) throw ach::AchError{ACH_ERR_INVALID, "bad bench arguments"};
+        *ms = h->eng->bench_gemm(M, K, N, act, ln, residual, P, iters, static_cast<hipStream_t>(stream));
+    });
+}
 int ach_set_probe(ach_handle* h, int op_index) { return guarded(h, [&] { h->eng->set_probe(op_index); }); }
 int ach_read_probe(ach_handle* h, float* avg_ms, int* samples) {
     return guarded(h, [&] {

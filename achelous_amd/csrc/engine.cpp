@@ -287,9 +287,10 @@ public:
         if (o.conv_k > 0 && (o.Cin % VEC != 0 || pk.K != o.conv_k * o.conv_k * o.Cin)) throw AchError{ACH_ERR_UNSUPPORTED, name + ": conv channel count not 16-byte aligned"};
         // launch geometry: >= ~4 workgroups per CU.  Rows first (P sub-tiles of 16 rows per wave), then split the
         // N-chunks over blockIdx.z when the row count alone cannot fill 256 CUs (10x10 / 20x20 maps, FC layers).
+        // (measured on MI355X, tests/gpu_gemm_bench.py: one 16-row sub-tile per wave beats 2 or 4 at every shape of this
+        //  network — the kernel is latency/bandwidth bound and lives on occupancy, not on weight-fragment reuse)
         const long kTargetBlocks = 1024;
-        int P = 4;
-        while (P > 1 && cdivl(g.M_per_group, 64L * P) * g.groups < kTargetBlocks) P >>= 1;
+        int P = 1;
         const long row_blocks = cdivl(g.M_per_group, 64L * P) * g.groups;
         int zsplit = int(std::min<long>(pk.nchunks, std::max<long>(1, cdivl(kTargetBlocks, row_blocks))));
         g.chunks_per_block = cdiv(pk.nchunks, zsplit);
@@ -544,20 +545,41 @@ public:
         ew(pfx + ".apply", sa_apply_kernel<T>, pa, x.rows() * x.C);
         return y;
     }
+    // one decoder level: Upsample (1x1+BN+ReLU, bilinear x2) + GhostModule, restructured (see upghost_kernel):
+    // both 1x1 convs at low resolution on MFMA, then one fused full-resolution kernel.
+    A decoder_level(const std::string& up_pfx, const std::string& ghost_pfx, const A& x, int cout) {
+        Lin lu = conv_bn(up_pfx + ".upsample.0.conv", up_pfx + ".upsample.0.bn", 1e-3);
+        Lin lp = conv_bn(ghost_pfx + ".primary_conv.0", ghost_pfx + ".primary_conv.1", 1e-5);
+        const int Cg = lp.N;
+        if (2 * Cg != cout || Cg % 4 || Cg > UPG_CMAX || lp.K != lu.N) throw AchError{ACH_ERR_UNSUPPORTED, ghost_pfx + ": decoder level widths"};
+        A u = alloc(x.B, x.H, x.W, lu.N);
+        { GemmOpt o; o.act = ACT_RELU; gemm(up_pfx + ".conv", x, pack(lu), u, o); }
+        A t = alloc(x.B, x.H, x.W, Cg);
+        gemm(ghost_pfx + ".primary_lowres", u, pack(lp), t);
+        const HostTensor& w = W(ghost_pfx + ".cheap_operation.0.weight");
+        std::vector<float> sc, sh; bn_coeffs(ghost_pfx + ".cheap_operation.1", 1e-5, sc, sh);
+        std::vector<float> wt(size_t(9) * Cg);
+        for (int c = 0; c < Cg; ++c) for (int k = 0; k < 9; ++k) wt[size_t(k) * Cg + c] = w.data[size_t(c) * 9 + k] * sc[c];
+        A y = alloc(x.B, 2 * x.H, 2 * x.W, cout);
+        UpGhostParams p{t.p, t.ld, y.p, y.ld, up_f32(wt), up_f32(sh), x.B, x.H, x.W, Cg};
+        const dim3 grid(unsigned(cdiv(2 * x.W, UPG_TS)), unsigned(cdiv(2 * x.H, UPG_TS)), unsigned(x.B)), block(256);
+        add_op(ghost_pfx + ".upghost", [p, grid, block](hipStream_t s) { ACH_LAUNCH(upghost_kernel<T>, grid, block, s, p); },
+               double(t.rows()) * Cg * sizeof(T) + double(y.rows()) * cout * sizeof(T));
+        return y;
+    }
     // segmentation head = GhostModule whose outputs ARE the network output (NCHW, 2 or num_seg channels)
     void seg_head(const std::string& pfx, const A& x, int oup, void** out) {
-        const int init = (oup + 1) / 2, HW = x.H * x.W;
-        GemmOpt o; o.act = ACT_RELU; o.ydyn = out; o.out_nchw = 1; o.HW = HW; o.Ctot = oup; o.coff = 0;
-        gemm(pfx + ".primary", x.p, x.ld, x.rows(), pack(conv_bn(pfx + ".primary_conv.0", pfx + ".primary_conv.1", 1e-5)), nullptr, 0, o);
-        const int nch = oup - init;            // cheap-operation channels that survive the [:oup] slice
-        if (nch <= 0) return;
+        const int init = (oup + 1) / 2, nch = oup - init;
+        if (init > SEGH_IMAX || x.C % 4) throw AchError{ACH_ERR_UNSUPPORTED, pfx + ": segmentation head width"};
+        Lin lp = conv_bn(pfx + ".primary_conv.0", pfx + ".primary_conv.1", 1e-5);
         const HostTensor& w = W(pfx + ".cheap_operation.0.weight");
         std::vector<float> sc, sh; bn_coeffs(pfx + ".cheap_operation.1", 1e-5, sc, sh);
-        std::vector<float> wt(size_t(9) * nch), bias(static_cast<size_t>(nch), 0.f);
+        std::vector<float> wt(size_t(9) * std::max(nch, 1)), bias(static_cast<size_t>(std::max(nch, 1)), 0.f);
         for (int j = 0; j < nch; ++j) { for (int t = 0; t < 9; ++t) wt[size_t(t) * nch + j] = w.data[size_t(j) * 9 + t] * sc[j]; bias[j] = sh[j]; }
-        DwPlaneParams p{nullptr, nullptr, up_f32(wt), up_f32(bias), x.B, x.H, x.W, oup, oup, 0, init, nch, ACT_RELU};
-        const dim3 grid(unsigned(cdivl(long(x.B) * nch * HW, 256))), block(256);
-        add_op(pfx + ".cheap", [p, grid, block, out](hipStream_t s) mutable { p.X = *out; p.Y = *out; ACH_LAUNCH(dwplane3x3_kernel<T>, grid, block, s, p); });
+        SegHeadParams p{x.p, x.ld, nullptr, up_f32(lp.w), up_f32(lp.b), up_f32(wt), up_f32(bias), x.B, x.H, x.W, x.C, init, nch, oup};
+        const dim3 grid(unsigned(cdiv(x.W, SEGH_TW)), unsigned(cdiv(x.H, SEGH_TH)), unsigned(x.B)), block(256);
+        add_op(pfx, [p, grid, block, out](hipStream_t s) mutable { p.out = *out; ACH_LAUNCH(seg_head_kernel<T>, grid, block, s, p); },
+               double(x.rows()) * (x.C + oup) * sizeof(T));
     }
 
     void neck(A m[4], A q[3]) {                                                  // ghostdualfpn.py:156-200
@@ -597,9 +619,7 @@ public:
             const char* lv[3] = {"3_to_2", "2_to_1", "1_to_0"};
             const int cw[3] = {w[1], w[0], w[0]};
             for (int l = 0; l < 3; ++l) {
-                A u = alloc(y.B, y.H * 2, y.W * 2, cw[l]);
-                upsample(f + "." + n + "_seg_" + lv[l], y, u);
-                y = ghost(f + "." + n + "_seg_ghost_" + lv[l], u, cw[l], true);
+                y = decoder_level(f + "." + n + "_seg_" + lv[l], f + "." + n + "_seg_ghost_" + lv[l], y, cw[l]);
                 tap(n + "." + lv[l], y);
             }
             seg_head(f + "." + n + "_seg_head", y, oups[d], outs[d]);
@@ -881,6 +901,43 @@ public:
         build();
         ACH_HIP_CHECK(hipMemset(aarena, 0, aarena_used));      // channel padding lanes stay zero for the lifetime of the plan
         ACH_HIP_CHECK(hipDeviceSynchronize());
+    }
+
+    float bench_gemm(int M, int K, int N, int act, int ln, int residual, int Pforce, int iters, hipStream_t s) override {
+        Packed pk = pack_shape(N, K);
+        const long ldx = round_up(K, 8), ldy = round_up(N, 8);
+        T *X = nullptr, *Y = nullptr, *R = nullptr, *Wp = nullptr; float* bias = nullptr;
+        ACH_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&X), size_t(M) * ldx * sizeof(T)));
+        ACH_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&Y), size_t(M) * ldy * sizeof(T)));
+        ACH_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&R), size_t(M) * ldy * sizeof(T)));
+        ACH_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&Wp), size_t(pk.group_elems) * sizeof(T)));
+        ACH_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&bias), size_t(N) * sizeof(float)));
+        ACH_HIP_CHECK(hipMemset(X, 0x3c, size_t(M) * ldx * sizeof(T)));     // small finite values
+        ACH_HIP_CHECK(hipMemset(R, 0x3c, size_t(M) * ldy * sizeof(T)));
+        ACH_HIP_CHECK(hipMemset(Wp, 0x3c, size_t(pk.group_elems) * sizeof(T)));
+        ACH_HIP_CHECK(hipMemset(bias, 0, size_t(N) * sizeof(float)));
+        GemmParams g;
+        std::memset(&g, 0, sizeof(g));
+        g.X = X; g.ldx = ldx; g.W = Wp; g.bias = bias; g.Y = Y; g.ldy = ldy; g.R = residual ? R : nullptr; g.ldr = ldy;
+        g.groups = 1; g.M_per_group = M; g.K = K; g.N = N; g.nchunks = pk.nchunks; g.ksteps = pk.ksteps;
+        g.act = act; g.ln = ln; g.ln_eps = 1e-6f; g.vec_store = 1;
+        int P = 1;
+        if (Pforce > 0) P = Pforce;
+        const long row_blocks = cdivl(M, 64L * P);
+        const int zsplit = int(std::min<long>(pk.nchunks, std::max<long>(1, cdivl(1024, row_blocks))));
+        g.chunks_per_block = cdiv(pk.nchunks, zsplit);
+        hipEvent_t e0, e1;
+        ACH_HIP_CHECK(hipEventCreate(&e0)); ACH_HIP_CHECK(hipEventCreate(&e1));
+        for (int i = 0; i < 3; ++i) launch_gemm<T>(g, pk.NT, P, s);
+        ACH_HIP_CHECK(hipEventRecord(e0, s));
+        for (int i = 0; i < iters; ++i) launch_gemm<T>(g, pk.NT, P, s);
+        ACH_HIP_CHECK(hipEventRecord(e1, s));
+        ACH_HIP_CHECK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        ACH_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        (void)hipFree(X); (void)hipFree(Y); (void)hipFree(R); (void)hipFree(Wp); (void)hipFree(bias);
+        return ms / float(iters);
     }
 
     void decode(int B, const void* d3, const void* d4, const void* d5, float* out, hipStream_t s) override {

@@ -77,6 +77,8 @@ public:
     int num_anchors() const;
     void read_tap(const std::string& name, float* out, size_t cap);
     std::vector<long> tap_shape(const std::string& name) const;
+    // micro-benchmark hook: time the MFMA GEMM kernel alone on scratch buffers (ms per launch)
+    virtual float bench_gemm(int M, int K, int N, int act, int ln, int residual, int P, int iters, hipStream_t s) = 0;
 
 protected:
     const HostTensor& W(const std::string& key) const;

@@ -423,3 +423,133 @@ __global__ __launch_bounds__(256) void chan_stats_nchw_kernel(const StatNchwPara
 }
 
 }  // namespace ach
+
+namespace ach {
+
+// ------------------------------------------------------------------------------------------ decoder level (fused)
+// One segmentation-decoder level (neck/ghostdualfpn.py:175-197) is
+//     u = relu(bn(conv1x1(x)))  ->  bilinear x2 (align_corners)  ->  x1 = relu(bn(conv1x1(.)))  ->  x2 = relu(bn(dw3x3(x1)))
+// Bilinear interpolation is linear and its weights sum to 1, so it commutes with the Ghost primary 1x1 conv + folded BN:
+//     x1 = relu( bilinear( Wp u + bp ) ).
+// Both 1x1 convs therefore run at LOW resolution (4x fewer pixels, MFMA GEMMs) and the full-resolution work is this
+// kernel: x1 = relu(bilinear(t)), x2 = relu(dw3x3(x1) + b), written side by side as [x1 | x2] — the full-resolution
+// tensor is written exactly once and never re-read by the level itself.  LDS-staged halo tile (16x16 outputs).
+struct UpGhostParams {
+    const void* Tq; long ldt;       // t = Wp u + bp at low resolution, NHWC [B,h,w,Cg]
+    void* Y; long ldy;              // [B,2h,2w,2Cg]
+    const float* Wdw; const float* bdw;   // cheap operation: [9][Cg] (BN folded), [Cg]
+    int B, h, w, Cg;
+};
+constexpr int UPG_TS = 16;
+constexpr int UPG_CMAX = 32;
+template <class T>
+__global__ __launch_bounds__(256) void upghost_kernel(const UpGhostParams p) {
+    constexpr int TS = UPG_TS, HS = TS + 2;
+    __shared__ float x1[HS * HS * UPG_CMAX];
+    const int H = 2 * p.h, Wd = 2 * p.w, cq = p.Cg >> 2, Cg = p.Cg;
+    const int bx = blockIdx.x * TS, by = blockIdx.y * TS;
+    const long b = blockIdx.z;
+    const float sy = H > 1 ? float(p.h - 1) / float(H - 1) : 0.f, sx = Wd > 1 ? float(p.w - 1) / float(Wd - 1) : 0.f;
+    const T* Tq = static_cast<const T*>(p.Tq) + b * p.h * long(p.w) * p.ldt;
+    for (int item = threadIdx.x; item < HS * HS * cq; item += 256) {
+        const int c = (item % cq) * 4, pos = item / cq;
+        const int oy = by + pos / HS - 1, ox = bx + pos % HS - 1;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};                        // outside the map: the dw conv's zero padding
+        if (oy >= 0 && oy < H && ox >= 0 && ox < Wd) {
+            const float fy = sy * float(oy), fx = sx * float(ox);
+            int y0 = int(fy), x0 = int(fx);
+            if (y0 > p.h - 1) y0 = p.h - 1;
+            if (x0 > p.w - 1) x0 = p.w - 1;
+            const int y1 = y0 + (y0 < p.h - 1 ? 1 : 0), x1i = x0 + (x0 < p.w - 1 ? 1 : 0);
+            const float ly = fy - float(y0), lx = fx - float(x0), hy = 1.f - ly, hx = 1.f - lx;
+            float a[4], bq[4], cc[4], d[4];
+            Store<T>::ld4(Tq + (long(y0) * p.w + x0) * p.ldt + c, a);
+            Store<T>::ld4(Tq + (long(y0) * p.w + x1i) * p.ldt + c, bq);
+            Store<T>::ld4(Tq + (long(y1) * p.w + x0) * p.ldt + c, cc);
+            Store<T>::ld4(Tq + (long(y1) * p.w + x1i) * p.ldt + c, d);
+            ACH_UNROLL
+            for (int i = 0; i < 4; ++i) { const float t = hy * (hx * a[i] + lx * bq[i]) + ly * (hx * cc[i] + lx * d[i]); v[i] = t > 0.f ? t : 0.f; }
+        }
+        ACH_UNROLL
+        for (int i = 0; i < 4; ++i) x1[pos * Cg + c + i] = v[i];
+    }
+    __syncthreads();
+    T* Y = static_cast<T*>(p.Y);
+    for (int item = threadIdx.x; item < TS * TS * cq; item += 256) {
+        const int c = (item % cq) * 4, pix = item / cq;
+        const int ty = pix / TS, tx = pix % TS;
+        const int oy = by + ty, ox = bx + tx;
+        if (oy >= H || ox >= Wd) continue;
+        float acc[4] = {p.bdw[c], p.bdw[c + 1], p.bdw[c + 2], p.bdw[c + 3]};
+        ACH_UNROLL
+        for (int k = 0; k < 9; ++k) {
+            const float* s = x1 + ((ty + k / 3) * HS + tx + k % 3) * Cg + c;
+            const float* wk = p.Wdw + k * Cg + c;
+            ACH_UNROLL
+            for (int i = 0; i < 4; ++i) acc[i] += s[i] * wk[i];
+        }
+        const float* ctr = x1 + ((ty + 1) * HS + tx + 1) * Cg + c;
+        float o1[4] = {ctr[0], ctr[1], ctr[2], ctr[3]};
+        ACH_UNROLL
+        for (int i = 0; i < 4; ++i) acc[i] = acc[i] > 0.f ? acc[i] : 0.f;
+        T* yo = Y + ((b * H + oy) * long(Wd) + ox) * p.ldy;
+        Store<T>::st4(yo + c, o1);
+        Store<T>::st4(yo + Cg + c, acc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ segmentation head (fused)
+// GhostModule(Cin -> oup) whose result IS a network output (NCHW): x1 = relu(bn(conv1x1(f))) (init = ceil(oup/2) channels),
+// x2 = relu(bn(dw3x3(x1))), out = cat(x1, x2)[:oup].  One workgroup = 30x6 outputs + 1-pixel halo = 32x8 threads: every thread
+// computes x1 of its halo pixel (64 B of f, weights wave-uniform), interior threads then take the 3x3 from LDS.
+struct SegHeadParams {
+    const void* F; long ldf; void* out;      // f NHWC [B,H,W,Cin] ; out NCHW [B,oup,H,W]
+    const float* Wp; const float* bp;        // [init][Cin] (BN folded), [init]
+    const float* Wdw; const float* bdw;      // [9][nch], [nch]   (nch = oup - init)
+    int B, H, Wd, Cin, init, nch, oup;
+};
+constexpr int SEGH_TW = 30, SEGH_TH = 6, SEGH_IMAX = 8;
+template <class T>
+__global__ __launch_bounds__(256) void seg_head_kernel(const SegHeadParams p) {
+    constexpr int HW_ = SEGH_TW + 2;
+    __shared__ float x1[(SEGH_TH + 2) * HW_][SEGH_IMAX];
+    const int lx = threadIdx.x % HW_, ly = threadIdx.x / HW_;
+    const int ox = blockIdx.x * SEGH_TW + lx - 1, oy = blockIdx.y * SEGH_TH + ly - 1;
+    const long b = blockIdx.z;
+    const bool inside = ox >= 0 && ox < p.Wd && oy >= 0 && oy < p.H;
+    float v[SEGH_IMAX];
+    ACH_UNROLL
+    for (int j = 0; j < SEGH_IMAX; ++j) v[j] = 0.f;
+    if (inside) {
+        const T* f = static_cast<const T*>(p.F) + ((b * p.H + oy) * long(p.Wd) + ox) * p.ldf;
+        ACH_UNROLL
+        for (int j = 0; j < SEGH_IMAX; ++j) v[j] = j < p.init ? p.bp[j] : 0.f;
+        for (int c = 0; c < p.Cin; c += 4) {
+            float x[4];
+            Store<T>::ld4(f + c, x);
+            ACH_UNROLL
+            for (int j = 0; j < SEGH_IMAX; ++j)
+                if (j < p.init) {
+                    const float* w = p.Wp + j * p.Cin + c;
+                    v[j] += w[0] * x[0] + w[1] * x[1] + w[2] * x[2] + w[3] * x[3];
+                }
+        }
+        ACH_UNROLL
+        for (int j = 0; j < SEGH_IMAX; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
+    }
+    ACH_UNROLL
+    for (int j = 0; j < SEGH_IMAX; ++j) x1[threadIdx.x][j] = v[j];
+    __syncthreads();
+    if (!inside || lx == 0 || lx == HW_ - 1 || ly == 0 || ly == SEGH_TH + 1) return;
+    T* out = static_cast<T*>(p.out) + b * p.oup * long(p.H) * p.Wd + long(oy) * p.Wd + ox;
+    const long HW = long(p.H) * p.Wd;
+    for (int j = 0; j < p.init && j < p.oup; ++j) Store<T>::st(out + j * HW, v[j]);
+    for (int j = 0; j < p.nch; ++j) {
+        float a = p.bdw[j];
+        ACH_UNROLL
+        for (int k = 0; k < 9; ++k) a += x1[(ly - 1 + k / 3) * HW_ + lx - 1 + k % 3][j] * p.Wdw[k * p.nch + j];
+        Store<T>::st(out + (p.init + j) * HW, a > 0.f ? a : 0.f);
+    }
+}
+
+}  // namespace ach

@@ -34,7 +34,7 @@ class NativeLibrary:
     SYMBOLS = ('ach_create', 'ach_destroy', 'ach_last_error', 'ach_load_weights', 'ach_plan', 'ach_arena_bytes',
                'ach_forward', 'ach_decode', 'ach_nms_workspace_bytes', 'ach_nms', 'ach_tap_count', 'ach_tap_name',
                'ach_tap_shape', 'ach_read_tap', 'ach_plan_launches', 'ach_op_name', 'ach_op_bytes', 'ach_op_flops',
-               'ach_forward_profiled', 'ach_set_probe', 'ach_read_probe')
+               'ach_forward_profiled', 'ach_set_probe', 'ach_read_probe', 'ach_bench_gemm')
 
     def __init__(self, path):
         if not os.path.exists(path):
@@ -85,6 +85,8 @@ class NativeLibrary:
         L.ach_set_probe.restype = ctypes.c_int
         L.ach_read_probe.argtypes = [vp, ctypes.POINTER(f32), ctypes.POINTER(ctypes.c_int)]
         L.ach_read_probe.restype = ctypes.c_int
+        L.ach_bench_gemm.argtypes = [vp] + [ctypes.c_int] * 8 + [vp, ctypes.POINTER(f32)]
+        L.ach_bench_gemm.restype = ctypes.c_int
 
 
 _hip_library = None
@@ -185,6 +187,11 @@ class NativeEngine:
                                                 _ptr(det5), _ptr(se), _ptr(lane), _ptr(pc), ctypes.c_void_p(stream),
                                                 ctypes.cast(ms, ctypes.c_void_p), n))
         return list(ms)
+
+    def bench_gemm(self, M, K, N, act=0, ln=0, residual=0, P=0, iters=20, stream=0):
+        ms = ctypes.c_float()
+        self._check(self.L.ach_bench_gemm(self.h, M, K, N, act, ln, residual, P, iters, ctypes.c_void_p(stream), ctypes.byref(ms)))
+        return float(ms.value)
 
     def set_probe(self, op_index):
         self._check(self.L.ach_set_probe(self.h, int(op_index)))

@@ -112,6 +112,8 @@ int ach_forward_profiled(ach_handle* h, const void* image, const void* radar, co
                          void* det3, void* det4, void* det5, void* se_seg, void* lane_seg, void* pc_seg, void* stream,
                          float* op_ms, size_t capacity);
 int ach_set_probe(ach_handle* h, int op_index);          /* -1 disables */
+/* micro-benchmark of the MFMA GEMM kernel alone on scratch buffers: ms per launch of Y[M,N] = epi(X[M,K] W^T) */
+int ach_bench_gemm(ach_handle* h, int M, int K, int N, int act, int ln, int residual, int P, int iters, void* stream, float* ms);
 int ach_read_probe(ach_handle* h, float* avg_ms, int* samples);
 
 #ifdef __cplusplus
