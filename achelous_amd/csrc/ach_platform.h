@@ -144,6 +144,26 @@ template <> __device__ __forceinline__ void mfma16<float>(const uint4& a, const 
 }
 #endif
 
+// max over each row of 16 lanes (all 16 lanes receive it): four DPP VALU ops instead of four LDS-routed shuffles.
+// quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror pair up lanes / quads / halves of the row.
+#if defined(ACH_HOSTEMU)
+__device__ inline float row16_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 1)); v = fmaxf(v, __shfl_xor(v, 2)); v = fmaxf(v, __shfl_xor(v, 4)); v = fmaxf(v, __shfl_xor(v, 8));
+    return v;
+}
+#else
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_mov<0xB1>(v));
+    v = fmaxf(v, dpp_mov<0x4E>(v));
+    v = fmaxf(v, dpp_mov<0x141>(v));
+    v = fmaxf(v, dpp_mov<0x140>(v));
+    return v;
+}
+#endif
+
 // ---------------------------------------------------------------------------------------- activations
 enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2, ACT_GELU = 3, ACT_SIGMOID = 4 };
 

@@ -434,21 +434,34 @@ public:
         GemmOpt oq; oq.ln = true; oq.ln_eps = 1e-6f;
         gemm(pfx + ".xca.qkv", y, pack(lq), qkv, oq);
         const int d = C / heads, N = x.H * x.W;
-        float* attn = alloc_f32(size_t(x.B) * heads * d * d);
-        const float* temp = up_f32(W(pfx + ".xca.temperature").data);
-        XcaAttnParams pa{qkv.p, qkv.ld, attn, temp, x.B, N, C, heads};
+        // Gram matrices over token slices, then softmax + fold into per-sample projection weights (see k_xca.h)
+        const int S = N >= 1024 ? 8 : (N >= 256 ? 4 : 1);
+        float* partial = alloc_f32(size_t(x.B) * heads * S * (d * d + 2 * d));
+        XcaGramParams pg{qkv.p, qkv.ld, partial, x.B, N, C, heads, S};
+        {
+            const dim3 grid(unsigned(x.B * heads), unsigned(S)), block(256);
+            add_op(pfx + ".xca.gram", [pg, grid, block](hipStream_t s) { ACH_LAUNCH(xca_gram_kernel<T>, grid, block, s, pg); },
+                   2.0 * x.rows() * C * sizeof(T));
+        }
+        Packed pe = pack_shape(C, C);
+        T* weff = static_cast<T*>(aalloc(size_t(x.B) * pe.group_elems * sizeof(T)));
+        Lin lp = lin(pfx + ".xca.proj.weight", pfx + ".xca.proj.bias");
+        const std::vector<float>& gx = W(pfx + ".gamma_xca").data;
+        std::vector<float> bproj(static_cast<size_t>(C), 0.f);
+        for (int c = 0; c < C; ++c) bproj[c] = lp.b[c] * gx[c];
+        pe.b = up_f32(bproj);
+        XcaFinalParams pf{partial, S, up_f32(W(pfx + ".xca.temperature").data), up_f32(lp.w), up_f32(gx), nullptr, weff, pe.group_elems,
+                          x.B, C, heads, pe.NT, pe.ksteps};
         {
             const dim3 grid(unsigned(x.B * heads)), block(256);
-            add_op(pfx + ".xca.attn", [pa, grid, block](hipStream_t s) { ACH_LAUNCH(xca_attn_kernel<T>, grid, block, s, pa); });
+            add_op(pfx + ".xca.finalize", [pf, grid, block](hipStream_t s) { ACH_LAUNCH(xca_finalize_kernel<T>, grid, block, s, pf); });
         }
-        A ao = alloc(x.B, x.H, x.W, C);
-        XcaApplyParams pp{qkv.p, qkv.ld, attn, ao.p, ao.ld, x.B, N, C, heads};
-        ew(pfx + ".xca.apply", xca_apply_kernel<T>, pp, ao.rows() * C);
-        Lin lp = lin(pfx + ".xca.proj.weight", pfx + ".xca.proj.bias");
-        fold_scale_out(lp, W(pfx + ".gamma_xca").data);
+        // t2 = y + gamma_xca * proj(attn @ v): one GEMM over v (channel slice [2C,3C) of qkv) with per-sample weights
         A t2 = alloc(x.B, x.H, x.W, C);
-        GemmOpt op; op.residual = &y;
-        gemm(pfx + ".xca.proj", ao, pack(lp), t2, op);
+        {
+            GemmOpt op; op.residual = &y; op.groups = x.B; op.w_group_stride = pe.group_elems; op.w_override = weff;
+            gemm(pfx + ".xca.proj", qkv.p + 2 * C, qkv.ld, qkv.rows(), pe, t2.p, t2.ld, op);
+        }
         return pw_mlp(pfx, t2, x);
     }
     void edgenext(const std::string& pfx, A feats[4]) {                   // edgenext.py:73-86
@@ -471,8 +484,10 @@ public:
                 add_op(d, [sp, grid, block, img](hipStream_t s) mutable { sp.X = *img; ACH_LAUNCH(stem_kernel<T>, grid, block, s, sp); });
             } else {
                 A t = alloc(x.B, x.H, x.W, x.C);
-                LnParams lp{x.p, x.ld, t.p, t.ld, up_f32(W(d + ".0.weight").data), up_f32(W(d + ".0.bias").data), x.rows(), x.C, 1e-6f};
-                const dim3 grid(unsigned(cdivl(x.rows(), 4))), block(256);
+                int G = 1;
+                while (G < x.C / 4 && G < 64) G <<= 1;
+                LnParams lp{x.p, x.ld, t.p, t.ld, up_f32(W(d + ".0.weight").data), up_f32(W(d + ".0.bias").data), x.rows(), x.C, 1e-6f, G};
+                const dim3 grid(unsigned(cdivl(x.rows(), 256 / G))), block(256);
                 add_op(d + ".0", [lp, grid, block](hipStream_t s) { ACH_LAUNCH(layernorm_kernel<T>, grid, block, s, lp); });
                 // conv 2x2 stride 2: k = (dy, dx, c) over two contiguous NHWC segments
                 const HostTensor& w = W(d + ".1.weight");
@@ -562,9 +577,12 @@ public:
         for (int c = 0; c < Cg; ++c) for (int k = 0; k < 9; ++k) wt[size_t(k) * Cg + c] = w.data[size_t(c) * 9 + k] * sc[c];
         A y = alloc(x.B, 2 * x.H, 2 * x.W, cout);
         UpGhostParams p{t.p, t.ld, y.p, y.ld, up_f32(wt), up_f32(sh), x.B, x.H, x.W, Cg};
-        const dim3 grid(unsigned(cdiv(2 * x.W, UPG_TS)), unsigned(cdiv(2 * x.H, UPG_TS)), unsigned(x.B)), block(256);
-        add_op(ghost_pfx + ".upghost", [p, grid, block](hipStream_t s) { ACH_LAUNCH(upghost_kernel<T>, grid, block, s, p); },
-               double(t.rows()) * Cg * sizeof(T) + double(y.rows()) * cout * sizeof(T));
+        const dim3 grid(unsigned(cdiv(2 * x.W, UPG_TS)), unsigned(cdiv(2 * x.H, UPG_TS)), unsigned(x.B)), block(unsigned(16 * Cg));
+        const double bytes = double(t.rows()) * Cg * sizeof(T) + double(y.rows()) * cout * sizeof(T);
+        if (Cg == 16) add_op(ghost_pfx + ".upghost", [p, grid, block](hipStream_t s) { ACH_LAUNCH((upghost_kernel<T, 16>), grid, block, s, p); }, bytes);
+        else if (Cg == 24) add_op(ghost_pfx + ".upghost", [p, grid, block](hipStream_t s) { ACH_LAUNCH((upghost_kernel<T, 24>), grid, block, s, p); }, bytes);
+        else if (Cg == 32) add_op(ghost_pfx + ".upghost", [p, grid, block](hipStream_t s) { ACH_LAUNCH((upghost_kernel<T, 32>), grid, block, s, p); }, bytes);
+        else throw AchError{ACH_ERR_UNSUPPORTED, ghost_pfx + ": Ghost half-width must be 16, 24 or 32"};
         return y;
     }
     // segmentation head = GhostModule whose outputs ARE the network output (NCHW, 2 or num_seg channels)

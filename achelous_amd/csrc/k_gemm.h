@@ -182,10 +182,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
                         const float v = apply_act(acc[q][t][r] + bv[t * 4 + r], p.act);
                         if (valid[q]) mx = fmaxf(mx, v);
                     }
-                    mx = fmaxf(mx, __shfl_xor(mx, 1));
-                    mx = fmaxf(mx, __shfl_xor(mx, 2));
-                    mx = fmaxf(mx, __shfl_xor(mx, 4));
-                    mx = fmaxf(mx, __shfl_xor(mx, 8));
+                    mx = row16_max(mx);
                     const int n = n0 + t * 4 + r;
                     if (px == 0 && n < p.N) atomicMax(p.colmax + long(grp) * p.N + n, order_encode(mx));
                 }

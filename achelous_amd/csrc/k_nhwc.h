@@ -17,6 +17,64 @@ struct DwParams {
     int B, H, Wd, C, Ho, Wo, stride, act;
 };
 
+// stride-1 kernel: one thread = 4 channels x a strip of OW consecutive output pixels of one row.  A row of the receptive
+// field is loaded once (KS + OW - 1 vector loads) and feeds all OW outputs from registers: k^2 -> k (k + OW - 1) / OW loads
+// per output (49 -> 17.5 for the 7x7 of EdgeNeXt stage 2), with the KS weight vectors of the row held in registers.
+template <class T, int KS, int OW>
+__global__ __launch_bounds__(256) void dwconv_strip_kernel(const DwParams p) {
+    const int cq = p.C >> 2;
+    const int strips = (p.Wo + OW - 1) / OW;
+    const long total = long(p.B) * p.Ho * strips * cq;
+    const long idx = long(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = int(idx % cq) * 4;
+    long r = idx / cq;
+    const int ox0 = int(r % strips) * OW; r /= strips;
+    const int oy = int(r % p.Ho);
+    const long b = r / p.Ho;
+    constexpr int PAD = KS / 2;
+    const T* X = static_cast<const T*>(p.X) + b * p.H * long(p.Wd) * p.ldx + c;
+    const T* X2 = p.X2 ? static_cast<const T*>(p.X2) + b * p.H * long(p.Wd) * p.ldx2 + c : nullptr;
+    float acc[OW][4];
+    {
+        const float4 bb = *reinterpret_cast<const float4*>(p.bias + c);
+        ACH_UNROLL
+        for (int o = 0; o < OW; ++o) { acc[o][0] = bb.x; acc[o][1] = bb.y; acc[o][2] = bb.z; acc[o][3] = bb.w; }
+    }
+    for (int ky = 0; ky < KS; ++ky) {
+        const int iy = oy - PAD + ky;
+        if (iy < 0 || iy >= p.H) continue;
+        float4 w[KS];
+        ACH_UNROLL
+        for (int kx = 0; kx < KS; ++kx) w[kx] = *reinterpret_cast<const float4*>(p.W + long(ky * KS + kx) * p.C + c);
+        ACH_UNROLL
+        for (int j = 0; j < KS + OW - 1; ++j) {
+            const int ix = ox0 - PAD + j;
+            const bool ok = ix >= 0 && ix < p.Wd;
+            const long ip = long(iy) * p.Wd + (ok ? ix : 0);
+            float v[4];
+            Store<T>::ld4(X + ip * p.ldx, v);
+            if (X2) { float u[4]; Store<T>::ld4(X2 + ip * p.ldx2, u); v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3]; }
+            if (!ok) { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; v[3] = 0.f; }
+            ACH_UNROLL
+            for (int o = 0; o < OW; ++o) {
+                const int kx = j - o;
+                if (kx >= 0 && kx < KS) { acc[o][0] += v[0] * w[kx].x; acc[o][1] += v[1] * w[kx].y; acc[o][2] += v[2] * w[kx].z; acc[o][3] += v[3] * w[kx].w; }
+            }
+        }
+    }
+    T* Y = static_cast<T*>(p.Y) + ((b * p.Ho + oy) * long(p.Wo) + ox0) * p.ldy + c;
+    ACH_UNROLL
+    for (int o = 0; o < OW; ++o) {
+        if (ox0 + o >= p.Wo) break;
+        float t[4];
+        ACH_UNROLL
+        for (int i = 0; i < 4; ++i) t[i] = apply_act(acc[o][i], p.act);
+        Store<T>::st4(Y + long(o) * p.ldy, t);
+    }
+}
+
+// general kernel (any stride): one thread = 4 channels of one output pixel
 template <class T, int KS>
 __global__ __launch_bounds__(256) void dwconv_kernel(const DwParams p) {
     const int cq = p.C >> 2;
@@ -54,13 +112,25 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const DwParams p) {
 
 template <class T>
 inline void launch_dwconv(const DwParams& p, int ks, hipStream_t s) {
+    const dim3 block(256);
+    if (p.stride == 1) {
+        constexpr int OW = 4;
+        const long total = long(p.B) * p.Ho * cdiv(p.Wo, OW) * (p.C / 4);
+        const dim3 grid(unsigned(cdivl(total, 256)));
+        switch (ks) {
+            case 3: ACH_LAUNCH((dwconv_strip_kernel<T, 3, OW>), grid, block, s, p); break;
+            case 5: ACH_LAUNCH((dwconv_strip_kernel<T, 5, OW>), grid, block, s, p); break;
+            case 7: ACH_LAUNCH((dwconv_strip_kernel<T, 7, OW>), grid, block, s, p); break;
+            case 9: ACH_LAUNCH((dwconv_strip_kernel<T, 9, OW>), grid, block, s, p); break;
+            default: break;
+        }
+        return;
+    }
     const long total = long(p.B) * p.Ho * p.Wo * (p.C / 4);
-    const dim3 grid(unsigned(cdivl(total, 256))), block(256);
+    const dim3 grid(unsigned(cdivl(total, 256)));
     switch (ks) {
         case 3: ACH_LAUNCH((dwconv_kernel<T, 3>), grid, block, s, p); break;
         case 5: ACH_LAUNCH((dwconv_kernel<T, 5>), grid, block, s, p); break;
-        case 7: ACH_LAUNCH((dwconv_kernel<T, 7>), grid, block, s, p); break;
-        case 9: ACH_LAUNCH((dwconv_kernel<T, 9>), grid, block, s, p); break;
         default: break;
     }
 }
@@ -148,30 +218,31 @@ __global__ __launch_bounds__(256) void stem_kernel(const StemParams p) {
 }
 
 // ------------------------------------------------------------------------------------------ LayerNorm over C
-// one wave per pixel; used for the channels-first LayerNorm in front of the three 2x2/s2 down-sampling convs
-struct LnParams { const void* X; long ldx; void* Y; long ldy; const float* w; const float* b; long rows; int C; float eps; };
+// channels-first LayerNorm in front of the three 2x2/s2 down-sampling convs.  A row (pixel) is owned by a group of G lanes
+// (G = power of two >= C/4, <= 64), each lane holding 4 channels per step; reductions are xor-shuffles inside the group.
+struct LnParams { const void* X; long ldx; void* Y; long ldy; const float* w; const float* b; long rows; int C; float eps; int G; };
 template <class T>
 __global__ __launch_bounds__(256) void layernorm_kernel(const LnParams p) {
-    const int lane = threadIdx.x & 63;
-    const long row = long(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    const int G = p.G, rows_per_block = 256 / G;
+    const int gl = threadIdx.x % G;
+    const long row = long(blockIdx.x) * rows_per_block + threadIdx.x / G;
     const bool ok = row < p.rows;
     const T* x = static_cast<const T*>(p.X) + (ok ? row : 0) * p.ldx;
     const int cq = p.C >> 2;
-    float s1 = 0.f;
-    for (int q = lane; q < cq; q += 64) { float v[4]; Store<T>::ld4(x + q * 4, v); s1 += v[0] + v[1] + v[2] + v[3]; }
-    for (int m = 32; m >= 1; m >>= 1) s1 += __shfl_xor(s1, m);
-    const float mu = s1 / float(p.C);
-    float s2 = 0.f;
-    for (int q = lane; q < cq; q += 64) {
+    float s1 = 0.f, s2 = 0.f;
+    for (int q = gl; q < cq; q += G) {
         float v[4]; Store<T>::ld4(x + q * 4, v);
         ACH_UNROLL
-        for (int i = 0; i < 4; ++i) { const float d = v[i] - mu; s2 += d * d; }
+        for (int i = 0; i < 4; ++i) { s1 += v[i]; s2 += v[i] * v[i]; }
     }
-    for (int m = 32; m >= 1; m >>= 1) s2 += __shfl_xor(s2, m);
-    const float rs = 1.0f / sqrtf(s2 / float(p.C) + p.eps);
+    for (int m = G >> 1; m >= 1; m >>= 1) { s1 += __shfl_xor(s1, m); s2 += __shfl_xor(s2, m); }
+    const float mu = s1 / float(p.C);
+    float var = s2 / float(p.C) - mu * mu;
+    var = var > 0.f ? var : 0.f;
+    const float rs = 1.0f / sqrtf(var + p.eps);
     if (!ok) return;
     T* y = static_cast<T*>(p.Y) + row * p.ldy;
-    for (int q = lane; q < cq; q += 64) {
+    for (int q = gl; q < cq; q += G) {
         float v[4]; Store<T>::ld4(x + q * 4, v);
         ACH_UNROLL
         for (int i = 0; i < 4; ++i) v[i] = (v[i] - mu) * rs * p.w[q * 4 + i] + p.b[q * 4 + i];
@@ -442,17 +513,19 @@ struct UpGhostParams {
 };
 constexpr int UPG_TS = 16;
 constexpr int UPG_CMAX = 32;
-template <class T>
-__global__ __launch_bounds__(256) void upghost_kernel(const UpGhostParams p) {
-    constexpr int TS = UPG_TS, HS = TS + 2;
-    __shared__ float x1[HS * HS * UPG_CMAX];
-    const int H = 2 * p.h, Wd = 2 * p.w, cq = p.Cg >> 2, Cg = p.Cg;
+// CG = Ghost half-width (16 / 24 / 32).  64 * CG/4 threads: a thread owns one 4-channel group for the whole tile (its nine
+// depthwise weight vectors live in registers) and walks the tile's pixels 64 at a time.
+template <class T, int CG>
+__global__ __launch_bounds__(16 * CG) void upghost_kernel(const UpGhostParams p) {
+    constexpr int TS = UPG_TS, HS = TS + 2, CQ = CG / 4;
+    __shared__ float x1[HS * HS * CG];
+    const int H = 2 * p.h, Wd = 2 * p.w;
     const int bx = blockIdx.x * TS, by = blockIdx.y * TS;
     const long b = blockIdx.z;
+    const int c = (threadIdx.x % CQ) * 4, slot = threadIdx.x / CQ;
     const float sy = H > 1 ? float(p.h - 1) / float(H - 1) : 0.f, sx = Wd > 1 ? float(p.w - 1) / float(Wd - 1) : 0.f;
-    const T* Tq = static_cast<const T*>(p.Tq) + b * p.h * long(p.w) * p.ldt;
-    for (int item = threadIdx.x; item < HS * HS * cq; item += 256) {
-        const int c = (item % cq) * 4, pos = item / cq;
+    const T* Tq = static_cast<const T*>(p.Tq) + b * p.h * long(p.w) * p.ldt + c;
+    for (int pos = slot; pos < HS * HS; pos += 64) {
         const int oy = by + pos / HS - 1, ox = bx + pos % HS - 1;
         float v[4] = {0.f, 0.f, 0.f, 0.f};                        // outside the map: the dw conv's zero padding
         if (oy >= 0 && oy < H && ox >= 0 && ox < Wd) {
@@ -463,38 +536,39 @@ __global__ __launch_bounds__(256) void upghost_kernel(const UpGhostParams p) {
             const int y1 = y0 + (y0 < p.h - 1 ? 1 : 0), x1i = x0 + (x0 < p.w - 1 ? 1 : 0);
             const float ly = fy - float(y0), lx = fx - float(x0), hy = 1.f - ly, hx = 1.f - lx;
             float a[4], bq[4], cc[4], d[4];
-            Store<T>::ld4(Tq + (long(y0) * p.w + x0) * p.ldt + c, a);
-            Store<T>::ld4(Tq + (long(y0) * p.w + x1i) * p.ldt + c, bq);
-            Store<T>::ld4(Tq + (long(y1) * p.w + x0) * p.ldt + c, cc);
-            Store<T>::ld4(Tq + (long(y1) * p.w + x1i) * p.ldt + c, d);
+            Store<T>::ld4(Tq + (long(y0) * p.w + x0) * p.ldt, a);
+            Store<T>::ld4(Tq + (long(y0) * p.w + x1i) * p.ldt, bq);
+            Store<T>::ld4(Tq + (long(y1) * p.w + x0) * p.ldt, cc);
+            Store<T>::ld4(Tq + (long(y1) * p.w + x1i) * p.ldt, d);
             ACH_UNROLL
             for (int i = 0; i < 4; ++i) { const float t = hy * (hx * a[i] + lx * bq[i]) + ly * (hx * cc[i] + lx * d[i]); v[i] = t > 0.f ? t : 0.f; }
         }
-        ACH_UNROLL
-        for (int i = 0; i < 4; ++i) x1[pos * Cg + c + i] = v[i];
+        *reinterpret_cast<float4*>(x1 + pos * CG + c) = make_float4(v[0], v[1], v[2], v[3]);
     }
+    float wk[9][4];
+    ACH_UNROLL
+    for (int k = 0; k < 9; ++k) { const float4 w = *reinterpret_cast<const float4*>(p.Wdw + k * CG + c); wk[k][0] = w.x; wk[k][1] = w.y; wk[k][2] = w.z; wk[k][3] = w.w; }
+    const float4 bb = *reinterpret_cast<const float4*>(p.bdw + c);
     __syncthreads();
     T* Y = static_cast<T*>(p.Y);
-    for (int item = threadIdx.x; item < TS * TS * cq; item += 256) {
-        const int c = (item % cq) * 4, pix = item / cq;
+    ACH_UNROLL
+    for (int pix = slot; pix < TS * TS; pix += 64) {
         const int ty = pix / TS, tx = pix % TS;
         const int oy = by + ty, ox = bx + tx;
         if (oy >= H || ox >= Wd) continue;
-        float acc[4] = {p.bdw[c], p.bdw[c + 1], p.bdw[c + 2], p.bdw[c + 3]};
+        float acc[4] = {bb.x, bb.y, bb.z, bb.w};
+        float o1[4] = {0.f, 0.f, 0.f, 0.f};
         ACH_UNROLL
         for (int k = 0; k < 9; ++k) {
-            const float* s = x1 + ((ty + k / 3) * HS + tx + k % 3) * Cg + c;
-            const float* wk = p.Wdw + k * Cg + c;
-            ACH_UNROLL
-            for (int i = 0; i < 4; ++i) acc[i] += s[i] * wk[i];
+            const float4 s = *reinterpret_cast<const float4*>(x1 + ((ty + k / 3) * HS + tx + k % 3) * CG + c);
+            acc[0] += s.x * wk[k][0]; acc[1] += s.y * wk[k][1]; acc[2] += s.z * wk[k][2]; acc[3] += s.w * wk[k][3];
+            if (k == 4) { o1[0] = s.x; o1[1] = s.y; o1[2] = s.z; o1[3] = s.w; }
         }
-        const float* ctr = x1 + ((ty + 1) * HS + tx + 1) * Cg + c;
-        float o1[4] = {ctr[0], ctr[1], ctr[2], ctr[3]};
         ACH_UNROLL
         for (int i = 0; i < 4; ++i) acc[i] = acc[i] > 0.f ? acc[i] : 0.f;
-        T* yo = Y + ((b * H + oy) * long(Wd) + ox) * p.ldy;
-        Store<T>::st4(yo + c, o1);
-        Store<T>::st4(yo + Cg + c, acc);
+        T* yo = Y + ((b * H + oy) * long(Wd) + ox) * p.ldy + c;
+        Store<T>::st4(yo, o1);
+        Store<T>::st4(yo + CG, acc);
     }
 }
 

@@ -1,44 +1,49 @@
 // k_xca.h — EdgeNeXt cross-covariance attention (XCA, edgenext_modules/sdta_encoder.py:162-185).
 //
-// Attention is over CHANNELS: per (sample, head) a d x d matrix, d = C/heads in {8..44}; the token axis N
-// (<= 1600) is only reduced over.  Two small kernels:
-//   xca_attn : A[b,h] = softmax_j( (q_i . k_j) / (max(|q_i|,eps) max(|k_j|,eps)) * temperature_h )
-//              (F.normalize over the N tokens folded into the Gram matrix)
-//   xca_apply: out[b,n,h*d+i] = sum_j A[b,h,i,j] * v[b,n,h*d+j]
-// qkv comes from the MFMA GEMM (LayerNorm fused as its prologue); the projection (+ layer scale + residual)
-// is another MFMA GEMM.
+// Attention is over CHANNELS: per (sample, head) a d x d matrix, d = C/heads in {8..44}; the token axis N (<= 1600) is only
+// reduced over.  Because the attention matrix multiplies v from the left and the projection from the right,
+//     proj(attn @ v)[n, co] = sum_k v[n, k] * Weff[b][co][k],   Weff[b][co][h*d+j] = gamma[co] * sum_i A[b,h,i,j] * Wproj[co][h*d+i]
+// the whole "attn @ v -> proj -> layer scale -> + residual" tail is ONE MFMA GEMM with per-sample weights.  So:
+//   xca_gram    : partial Gram matrices q.k^T and squared norms over a slice of the tokens  (grid: B*heads x S, LDS staged)
+//   xca_finalize: sum the partials, F.normalize over tokens folded in, temperature, row softmax, then write Weff of this
+//                 (sample, head) straight into MFMA fragment order (k_gemm.h wfrag_offset)
+// qkv comes from the MFMA GEMM with the LayerNorm prologue; v is a channel slice of that buffer.
 #pragma once
 #include "ach_platform.h"
+#include "k_gemm.h"
 
 namespace ach {
 
-struct XcaAttnParams { const void* qkv; long ld; float* attn; const float* temperature; int B, N, C, heads; };
+constexpr int XCA_DMAX = 48;
 
+struct XcaGramParams { const void* qkv; long ld; float* partial; int B, N, C, heads, S; };
+
+// partial layout per (b, h, s): [d*d gram | d sum q^2 | d sum k^2]
 template <class T>
-__global__ __launch_bounds__(256) void xca_attn_kernel(const XcaAttnParams p) {
-    constexpr int TOK = 16;                 // tokens staged per step
-    constexpr int DMAX = 48;
-    __shared__ float qs[TOK][DMAX];
-    __shared__ float ks[TOK][DMAX];
-    __shared__ float gram[DMAX][DMAX + 1];
-    __shared__ float nq[DMAX], nk[DMAX];
-    const int b = blockIdx.x / p.heads, h = blockIdx.x % p.heads;
+__global__ __launch_bounds__(256) void xca_gram_kernel(const XcaGramParams p) {
+    constexpr int TOK = 16;
+    __shared__ float qs[TOK][XCA_DMAX];
+    __shared__ float ks[TOK][XCA_DMAX];
+    const int bh = blockIdx.x, sp = blockIdx.y;
+    const int b = bh / p.heads, h = bh % p.heads;
     const int d = p.C / p.heads;
     const int tid = threadIdx.x;
+    const int per = (p.N + p.S - 1) / p.S;
+    const int n_lo = sp * per, n_hi = (n_lo + per < p.N) ? n_lo + per : p.N;
     const T* base = static_cast<const T*>(p.qkv) + long(b) * p.N * p.ld;
     const int npair = d * d;
-    constexpr int PP = (DMAX * DMAX + 255) / 256;      // (i,j) pairs per thread
+    constexpr int PP = (XCA_DMAX * XCA_DMAX + 255) / 256;
     float acc[PP];
     ACH_UNROLL
     for (int e = 0; e < PP; ++e) acc[e] = 0.f;
-    float nacc = 0.f;                                   // threads < d: |q_i|^2 ; d <= threads < 2d: |k_j|^2
-    for (int n0 = 0; n0 < p.N; n0 += TOK) {
+    float nacc = 0.f;
+    for (int n0 = n_lo; n0 < n_hi; n0 += TOK) {
         for (int e = tid; e < TOK * d * 2; e += 256) {
             const int which = e / (TOK * d);
             const int r = e - which * TOK * d;
             const int t = r / d, i = r - t * d;
             const int n = n0 + t;
-            const float v = n < p.N ? Store<T>::ld(base + long(n) * p.ld + which * p.C + h * d + i) : 0.f;
+            const float v = n < n_hi ? Store<T>::ld(base + long(n) * p.ld + which * p.C + h * d + i) : 0.f;
             if (which == 0) qs[t][i] = v; else ks[t][i] = v;
         }
         __syncthreads();
@@ -60,42 +65,63 @@ __global__ __launch_bounds__(256) void xca_attn_kernel(const XcaAttnParams p) {
         }
         __syncthreads();
     }
-    if (tid < d) nq[tid] = fmaxf(sqrtf(nacc), 1e-12f);
-    else if (tid < 2 * d) nk[tid - d] = fmaxf(sqrtf(nacc), 1e-12f);
-    __syncthreads();
-    const float temp = p.temperature[h];
+    float* out = p.partial + (long(bh) * p.S + sp) * (npair + 2 * d);
     ACH_UNROLL
     for (int e = 0; e < PP; ++e) {
         const int pr = tid + e * 256;
-        if (pr < npair) { const int i = pr / d, j = pr - i * d; gram[i][j] = acc[e] / (nq[i] * nk[j]) * temp; }
+        if (pr < npair) out[pr] = acc[e];
     }
-    __syncthreads();
-    if (tid < d) {                                       // row softmax
-        float mx = -3.0e38f;
-        for (int j = 0; j < d; ++j) mx = fmaxf(mx, gram[tid][j]);
-        float sum = 0.f;
-        for (int j = 0; j < d; ++j) { const float e = expf(gram[tid][j] - mx); gram[tid][j] = e; sum += e; }
-        const float inv = 1.0f / sum;
-        float* out = p.attn + ((long(b) * p.heads + h) * d + tid) * d;
-        for (int j = 0; j < d; ++j) out[j] = gram[tid][j] * inv;
-    }
+    if (tid < 2 * d) out[npair + tid] = nacc;
 }
 
-struct XcaApplyParams { const void* qkv; long ld; const float* attn; void* Y; long ldy; int B, N, C, heads; };
+struct XcaFinalParams {
+    const float* partial; int S;
+    const float* temperature;     // [heads]
+    const float* Wproj;           // [C][C] fp32
+    const float* gamma;           // [C] layer scale
+    float* attn;                  // optional [B][heads][d][d] (tap) or nullptr
+    void* Weff; long group_stride;   // packed per-sample weights (elements of T)
+    int B, C, heads, NT, ksteps;
+};
+
 template <class T>
-__global__ __launch_bounds__(256) void xca_apply_kernel(const XcaApplyParams p) {
-    const long total = long(p.B) * p.N * p.C;
-    const long idx = long(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    const int c = int(idx % p.C);
-    const long row = idx / p.C;               // b*N + n
-    const long b = row / p.N;
-    const int d = p.C / p.heads, h = c / d, i = c - h * d;
-    const T* v = static_cast<const T*>(p.qkv) + row * p.ld + 2 * p.C + h * d;
-    const float* a = p.attn + ((b * p.heads + h) * d + i) * d;
-    float s = 0.f;
-    for (int j = 0; j < d; ++j) s += a[j] * Store<T>::ld(v + j);
-    Store<T>::st(static_cast<T*>(p.Y) + row * p.ldy + c, s);
+__global__ __launch_bounds__(256) void xca_finalize_kernel(const XcaFinalParams p) {
+    __shared__ float A[XCA_DMAX][XCA_DMAX + 1];
+    __shared__ float nq[XCA_DMAX], nk[XCA_DMAX];
+    const int bh = blockIdx.x;
+    const int b = bh / p.heads, h = bh % p.heads;
+    const int d = p.C / p.heads, npair = d * d;
+    const int tid = threadIdx.x;
+    const float* part = p.partial + long(bh) * p.S * (npair + 2 * d);
+    for (int e = tid; e < npair + 2 * d; e += 256) {
+        float s = 0.f;
+        for (int sp = 0; sp < p.S; ++sp) s += part[long(sp) * (npair + 2 * d) + e];
+        if (e < npair) A[e / d][e % d] = s;
+        else if (e < npair + d) nq[e - npair] = fmaxf(sqrtf(s), 1e-12f);
+        else nk[e - npair - d] = fmaxf(sqrtf(s), 1e-12f);
+    }
+    __syncthreads();
+    const float temp = p.temperature[h];
+    for (int e = tid; e < npair; e += 256) { const int i = e / d, j = e % d; A[i][j] = A[i][j] / (nq[i] * nk[j]) * temp; }
+    __syncthreads();
+    if (tid < d) {
+        float mx = -3.0e38f;
+        for (int j = 0; j < d; ++j) mx = fmaxf(mx, A[tid][j]);
+        float sum = 0.f;
+        for (int j = 0; j < d; ++j) { const float e = expf(A[tid][j] - mx); A[tid][j] = e; sum += e; }
+        const float inv = 1.0f / sum;
+        for (int j = 0; j < d; ++j) A[tid][j] *= inv;
+    }
+    __syncthreads();
+    if (p.attn) for (int e = tid; e < npair; e += 256) p.attn[long(bh) * npair + e] = A[e / d][e % d];
+    T* W = static_cast<T*>(p.Weff) + long(b) * p.group_stride;
+    for (int e = tid; e < p.C * d; e += 256) {
+        const int co = e / d, j = e - co * d;
+        const float* wp = p.Wproj + long(co) * p.C + h * d;
+        float s = 0.f;
+        for (int i = 0; i < d; ++i) s += A[i][j] * wp[i];
+        Store<T>::st(W + wfrag_offset(co, h * d + j, p.NT, p.ksteps, Store<T>::VEC), s * p.gamma[co]);
+    }
 }
 
 }  // namespace ach
