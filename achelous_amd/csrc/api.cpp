@@ -66,6 +66,14 @@ int ach_load_weights(ach_handle* h, const ach_tensor_desc* tensors, size_t n) {
     return guarded(h, [&] { h->eng->load(tensors, n); });
 }
 
+int ach_set_option(ach_handle* h, const char* key, int32_t value) {
+    return guarded(h, [&] {
+        if (!key) throw ach::AchError{ACH_ERR_INVALID, "null option"};
+        if (std::string(key) == "full_taps") h->eng->full_taps = value != 0;
+        else throw ach::AchError{ACH_ERR_INVALID, std::string("unknown option: ") + key};
+    });
+}
+
 int ach_plan(ach_handle* h, int32_t batch) {
     return guarded(h, [&] { h->eng->plan(batch); });
 }

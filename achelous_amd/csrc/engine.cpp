@@ -264,7 +264,6 @@ public:
         const A* residual = nullptr;
         int conv_k = 0, conv_s = 1, conv_p = 0, Hin = 0, Win = 0, Cin = 0, Ho = 0, Wo = 0;   // implicit-GEMM conv over NHWC
         void** ydyn = nullptr; int out_nchw = 0, HW = 0, Ctot = 0, coff = 0;     // NCHW scatter into a user buffer
-        unsigned* colmax = nullptr;
         int groups = 1; long w_group_stride = 0;
         const T* w_override = nullptr;                                            // data-dependent packed weights
     };
@@ -277,12 +276,11 @@ public:
         g.bias = pk.b; g.bias_group_stride = 0;
         g.Y = Yp; g.ldy = ldy;
         g.R = o.residual ? o.residual->p : nullptr; g.ldr = o.residual ? o.residual->ld : 0;
-        g.colmax = o.colmax;
         g.groups = o.groups; g.M_per_group = int(M / o.groups);
         g.K = pk.K; g.N = pk.N; g.nchunks = pk.nchunks; g.ksteps = pk.ksteps;
         g.act = o.act; g.ln = o.ln ? 1 : 0; g.ln_eps = o.ln_eps;
         g.out_nchw = o.out_nchw; g.HW = o.HW; g.Ctot = o.Ctot; g.coff = o.coff;
-        g.vec_store = (ldy % 4 == 0 && (!o.residual || o.residual->ld % 4 == 0)) ? 1 : 0;
+        g.vec_store = (ldy % 8 == 0 && (!o.residual || o.residual->ld % 8 == 0)) ? 1 : 0;
         if (ldx % VEC != 0) throw AchError{ACH_ERR_INVALID, name + ": activation row stride not 16-byte aligned"};
         if (o.conv_k > 0 && (o.Cin % VEC != 0 || pk.K != o.conv_k * o.conv_k * o.Cin)) throw AchError{ACH_ERR_UNSUPPORTED, name + ": conv channel count not 16-byte aligned"};
         // launch geometry: >= ~4 workgroups per CU.  Rows first (P sub-tiles of 16 rows per wave), then split the
@@ -297,7 +295,7 @@ public:
         const int NT = pk.NT;
         void** ydyn = o.ydyn;
         const double esz = double(sizeof(T));
-        const double bytes = double(M) * pk.K * esz + (o.colmax ? 0.0 : double(M) * pk.N * esz) + (o.residual ? double(M) * pk.N * esz : 0.0)
+        const double bytes = double(M) * pk.K * esz + double(M) * pk.N * esz + (o.residual ? double(M) * pk.N * esz : 0.0)
                              + double(pk.group_elems) * esz * (o.w_group_stride ? o.groups : 1);
         add_op(name, [g, NT, P, ydyn](hipStream_t s) mutable {
             if (ydyn) g.Y = *ydyn;
@@ -600,6 +598,36 @@ public:
                double(x.rows()) * (x.C + oup) * sizeof(T));
     }
 
+    // last decoder level (1_to_0) + segmentation head in one full-resolution kernel (upghost_head_kernel)
+    void decoder_last_level(const std::string& up_pfx, const std::string& ghost_pfx, const std::string& head_pfx, const std::string& tap_name,
+                            const A& x, int cout, int oup, void** out) {
+        Lin lu = conv_bn(up_pfx + ".upsample.0.conv", up_pfx + ".upsample.0.bn", 1e-3);
+        Lin lp = conv_bn(ghost_pfx + ".primary_conv.0", ghost_pfx + ".primary_conv.1", 1e-5);
+        const int Cg = lp.N, init = (oup + 1) / 2, nch = oup - init;
+        Lin lh = conv_bn(head_pfx + ".primary_conv.0", head_pfx + ".primary_conv.1", 1e-5);
+        if (Cg != UGH_CG || 2 * Cg != cout || lh.K != cout || lh.N != init || init > UGH_IMAX) throw AchError{ACH_ERR_UNSUPPORTED, head_pfx + ": fused last level expects 16+16 channels"};
+        A u = alloc(x.B, x.H, x.W, lu.N);
+        { GemmOpt o; o.act = ACT_RELU; gemm(up_pfx + ".conv", x, pack(lu), u, o); }
+        A t = alloc(x.B, x.H, x.W, Cg);
+        gemm(ghost_pfx + ".primary_lowres", u, pack(lp), t);
+        auto dw_fold = [&](const std::string& pfx, int n, std::vector<float>& wt, std::vector<float>& bias) {
+            const HostTensor& w = W(pfx + ".cheap_operation.0.weight");
+            std::vector<float> sc, sh; bn_coeffs(pfx + ".cheap_operation.1", 1e-5, sc, sh);
+            wt.assign(size_t(9) * std::max(n, 1), 0.f); bias.assign(static_cast<size_t>(std::max(n, 1)), 0.f);
+            for (int c = 0; c < n; ++c) { for (int k = 0; k < 9; ++k) wt[size_t(k) * n + c] = w.data[size_t(c) * 9 + k] * sc[c]; bias[c] = sh[c]; }
+        };
+        std::vector<float> wl, bl, wh2, bh2;
+        dw_fold(ghost_pfx, Cg, wl, bl);
+        dw_fold(head_pfx, nch, wh2, bh2);
+        A f;
+        if (full_taps) { f = alloc(x.B, 2 * x.H, 2 * x.W, cout); tap(tap_name, f); }
+        UpGhostHeadParams p{t.p, t.ld, full_taps ? f.p : nullptr, full_taps ? f.ld : 0, nullptr, up_f32(wl), up_f32(bl), up_f32(lh.w), up_f32(lh.b),
+                            up_f32(wh2), up_f32(bh2), x.B, x.H, x.W, init, nch, oup};
+        const dim3 grid(unsigned(cdiv(2 * x.W, UGH_TW)), unsigned(cdiv(2 * x.H, UGH_TH)), unsigned(x.B)), block(256);
+        const double bytes = double(t.rows()) * Cg * sizeof(T) + 4.0 * double(t.rows()) * oup * sizeof(T);
+        add_op(head_pfx + ".upghost_head", [p, grid, block, out](hipStream_t s) mutable { p.out = *out; ACH_LAUNCH(upghost_head_kernel<T>, grid, block, s, p); }, bytes);
+    }
+
     void neck(A m[4], A q[3]) {                                                  // ghostdualfpn.py:156-200
         const std::string f = "image_radar_encoder.fpn";
         const int* w = widths();
@@ -636,11 +664,11 @@ public:
             tap(n + ".sa", y);
             const char* lv[3] = {"3_to_2", "2_to_1", "1_to_0"};
             const int cw[3] = {w[1], w[0], w[0]};
-            for (int l = 0; l < 3; ++l) {
+            for (int l = 0; l < 2; ++l) {
                 y = decoder_level(f + "." + n + "_seg_" + lv[l], f + "." + n + "_seg_ghost_" + lv[l], y, cw[l]);
                 tap(n + "." + lv[l], y);
             }
-            seg_head(f + "." + n + "_seg_head", y, oups[d], outs[d]);
+            decoder_last_level(f + "." + n + "_seg_" + lv[2], f + "." + n + "_seg_ghost_" + lv[2], f + "." + n + "_seg_head", n + "." + lv[2], y, cw[2], oups[d], outs[d]);
         }
         // residual FPN outputs (ghostdualfpn.py:200)
         q[0] = alloc(p3.B, p3.H, p3.W, p3.C); add(f + ".q3", p3, m3, q[0]);
@@ -823,18 +851,19 @@ public:
         gemm(name, x.p, x.ld, x.rows, pack(l), y.p, y.ld, o);
         return y;
     }
-    // shared MLP + max over the N points of every sample -> [B, C]
+    // shared MLP + max over the N points of every sample -> [B, C]   (gemm_colmax_kernel: no atomics, nothing materialised)
     Rows pc_layer_max(const std::string& name, const Rows& x, const Lin& l, int act, int B) {
-        unsigned* enc = static_cast<unsigned*>(aalloc(size_t(B) * l.N * sizeof(unsigned)));
-        const size_t bytes = size_t(B) * l.N * sizeof(unsigned);
-        add_op(name + ".init", [enc, bytes](hipStream_t s) { (void)hipMemsetAsync(enc, 0, bytes, s); });
-        GemmOpt o; o.act = act; o.colmax = enc; o.groups = B;
-        gemm(name, x.p, x.ld, x.rows, pack(l), nullptr, 0, o);
+        Packed pk = pack(l);
         Rows y = alloc_rows(B, l.N);
-        const long total = long(B) * l.N;
-        const int N = l.N; const long ld = y.ld; T* yp = y.p;
-        const dim3 grid(unsigned(cdivl(total, 256))), block(256);
-        add_op(name + ".max", [enc, yp, N, ld, total, grid, block](hipStream_t s) { ACH_LAUNCH(colmax_decode_kernel<T>, grid, block, s, enc, yp, N, ld, total); });
+        GemmMaxParams g{x.p, x.ld, pk.w, pk.b, y.p, y.ld, int(x.rows / B), B, pk.K, pk.N, pk.nchunks, pk.ksteps, act};
+        const dim3 grid(unsigned(pk.nchunks), unsigned(B)), block(256);
+        const int NT = pk.NT;
+        const double bytes = double(x.rows) * pk.K * sizeof(T) + double(pk.group_elems) * sizeof(T) + double(B) * pk.N * sizeof(T);
+        add_op(name, [g, grid, block, NT](hipStream_t s) {
+            if (NT == 1) ACH_LAUNCH((gemm_colmax_kernel<T, 1>), grid, block, s, g);
+            else if (NT == 2) ACH_LAUNCH((gemm_colmax_kernel<T, 2>), grid, block, s, g);
+            else ACH_LAUNCH((gemm_colmax_kernel<T, 4>), grid, block, s, g);
+        }, bytes, 2.0 * double(x.rows) * pk.K * pk.N);
         return y;
     }
     Rows stn(const std::string& pfx, const Rows& x, int B) {                     // pointnet_utils.py:27-45,67-85 (without + I)

@@ -57,6 +57,7 @@ public:
     char* warena = nullptr; size_t warena_cap = 0, warena_used = 0;      // packed weights / constants
     char* aarena = nullptr; size_t aarena_cap = 0, aarena_used = 0;      // activations
     bool measuring = false;
+    bool full_taps = false;           // option "full_taps": also materialise boundaries that production plans keep on-chip
     int batch = 0;
     std::vector<Op> ops;
     std::map<std::string, TapInfo> taps;

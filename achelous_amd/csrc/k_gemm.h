@@ -22,14 +22,23 @@ namespace ach {
 
 // Offset (in elements) of W[n][k] inside one group's packed weight blob.  Shared by the host packer and the
 // device-side packer for data-dependent weights (PointNet feature transform).
+// Output-channel order inside a chunk of 16*NT channels is chosen for the STORES: lane group g = lane>>4 of the MFMA
+// result owns, per pair of 16-row tiles (t = 2j, 2j+1), the 8 consecutive channels  j*32 + g*8 .. +7  — so one 16-byte
+// (bf16) / two 16-byte (fp32) stores per lane, and the 4 lane groups of a pixel write 64 / 128 contiguous bytes.
+// (NT = 1: 4 consecutive channels g*4 .. +3.)
+__host__ __device__ __forceinline__ int chunk_channel(int NT, int t, int g, int r) {
+    return NT == 1 ? g * 4 + r : (t >> 1) * 32 + g * 8 + (t & 1) * 4 + r;
+}
 __host__ __device__ __forceinline__ long wfrag_offset(int n, int k, int NT, int ksteps, int VEC) {
     const int CH = 16 * NT;
     const int c = n / CH, nn = n % CH;
-    const int gq = nn / (4 * NT), rem = nn % (4 * NT), t = rem >> 2, r = rem & 3;
-    const int i = gq * 4 + r;
+    int g, t, r;
+    if (NT == 1) { g = nn >> 2; t = 0; r = nn & 3; }
+    else { const int j = nn >> 5, w = nn & 31; g = w >> 3; t = j * 2 + ((w & 7) >> 2); r = w & 3; }
+    const int i = g * 4 + r;
     const int KC = 4 * VEC;
-    const int s = k / KC, kk = k % KC, g = kk / VEC, j = kk % VEC;
-    return ((long(c) * ksteps + s) * NT + t) * (64L * VEC) + long(g * 16 + i) * VEC + j;
+    const int s = k / KC, kk = k % KC, kg = kk / VEC, kj = kk % VEC;
+    return ((long(c) * ksteps + s) * NT + t) * (64L * VEC) + long(kg * 16 + i) * VEC + kj;
 }
 
 struct GemmParams {
@@ -42,7 +51,6 @@ struct GemmParams {
     const float* bias; long bias_group_stride;
     void* Y; long ldy;                  // NHWC: row m at Y + m*ldy ; NCHW: see out_nchw
     const void* R; long ldr;            // optional residual, NHWC rows
-    unsigned* colmax;                   // optional [groups][N] order-encoded running max (zero-initialised)
     int M_per_group, groups, K, N;
     int nchunks, ksteps;
     int chunks_per_block;               // blockIdx.z selects a contiguous range of N-chunks (fills the chip when M is small)
@@ -165,29 +173,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
             }
         }
 
-        // ---- epilogue: lane holds channels n0 .. n0+4*NT-1 of pixel px of every sub-tile
-        const int n0 = c * (16 * NT) + g * (4 * NT);
+        // ---- epilogue: lane holds, for pixel px of every sub-tile, the channels chunk_channel(NT, t, g, r) of this chunk
+        const int cbase = c * (16 * NT);
         float bv[4 * NT];
         ACH_UNROLL
-        for (int i = 0; i < 4 * NT; ++i) bv[i] = (n0 + i < p.N) ? bias[n0 + i] : 0.f;
-
-        if (p.colmax) {
+        for (int t = 0; t < NT; ++t)
             ACH_UNROLL
-            for (int t = 0; t < NT; ++t)
-                ACH_UNROLL
-                for (int r = 0; r < 4; ++r) {
-                    float mx = -3.0e38f;
-                    ACH_UNROLL
-                    for (int q = 0; q < P; ++q) {
-                        const float v = apply_act(acc[q][t][r] + bv[t * 4 + r], p.act);
-                        if (valid[q]) mx = fmaxf(mx, v);
-                    }
-                    mx = row16_max(mx);
-                    const int n = n0 + t * 4 + r;
-                    if (px == 0 && n < p.N) atomicMax(p.colmax + long(grp) * p.N + n, order_encode(mx));
-                }
-            continue;
-        }
+            for (int r = 0; r < 4; ++r) { const int n = cbase + chunk_channel(NT, t, g, r); bv[t * 4 + r] = n < p.N ? bias[n] : 0.f; }
 
         ACH_UNROLL
         for (int q = 0; q < P; ++q) {
@@ -202,40 +194,116 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
                 T* Y = static_cast<T*>(p.Y);
                 const long b = m / p.HW, pix = m - b * p.HW;
                 ACH_UNROLL
-                for (int i = 0; i < 4 * NT; ++i)
-                    if (n0 + i < p.N) Store<T>::st(Y + ((b * p.Ctot + p.coff + n0 + i) * p.HW + pix), o[i]);
+                for (int t = 0; t < NT; ++t)
+                    ACH_UNROLL
+                    for (int r = 0; r < 4; ++r) {
+                        const int n = cbase + chunk_channel(NT, t, g, r);
+                        if (n < p.N) Store<T>::st(Y + ((b * p.Ctot + p.coff + n) * p.HW + pix), o[t * 4 + r]);
+                    }
                 continue;
             }
-            T* yrow = static_cast<T*>(p.Y) + m * p.ldy + n0;
-            const T* rrow = p.R ? static_cast<const T*>(p.R) + m * p.ldr + n0 : nullptr;
-            ACH_UNROLL
-            for (int i4 = 0; i4 < NT; ++i4) {
-                const int nb = n0 + i4 * 4;
-                if (nb >= p.N) break;
-                float v4[4] = {o[i4 * 4], o[i4 * 4 + 1], o[i4 * 4 + 2], o[i4 * 4 + 3]};
-                if (p.vec_store && nb + 4 <= p.N) {
-                    if (rrow) { float r4[4]; Store<T>::ld4(rrow + i4 * 4, r4); v4[0] += r4[0]; v4[1] += r4[1]; v4[2] += r4[2]; v4[3] += r4[3]; }
-                    Store<T>::st4(yrow + i4 * 4, v4);
-                } else {
-                    for (int i = 0; i < 4; ++i)
-                        if (nb + i < p.N) {
-                            float v = v4[i];
-                            if (rrow) v += Store<T>::ld(rrow + i4 * 4 + i);
-                            Store<T>::st(yrow + i4 * 4 + i, v);
-                        }
+            T* yrow = static_cast<T*>(p.Y) + m * p.ldy;
+            const T* rrow = p.R ? static_cast<const T*>(p.R) + m * p.ldr : nullptr;
+            if (NT >= 2) {
+                ACH_UNROLL
+                for (int j = 0; j < NT / 2; ++j) {
+                    const int nb = cbase + j * 32 + g * 8;                  // 8 consecutive channels nb .. nb+7
+                    if (nb >= p.N) continue;
+                    float v8[8];
+                    ACH_UNROLL
+                    for (int i = 0; i < 8; ++i) v8[i] = o[j * 8 + i];       // tiles 2j (first 4) and 2j+1 (last 4)
+                    if (p.vec_store && nb + 8 <= p.N) {
+                        if (rrow) { float r8[8]; Store<T>::ld8(rrow + nb, r8); ACH_UNROLL for (int i = 0; i < 8; ++i) v8[i] += r8[i]; }
+                        Store<T>::st8(yrow + nb, v8);
+                    } else {
+                        for (int i = 0; i < 8; ++i)
+                            if (nb + i < p.N) {
+                                float v = v8[i];
+                                if (rrow) v += Store<T>::ld(rrow + nb + i);
+                                Store<T>::st(yrow + nb + i, v);
+                            }
+                    }
+                }
+            } else {
+                const int nb = cbase + g * 4;                               // 4 consecutive channels
+                if (nb < p.N) {
+                    float v4[4] = {o[0], o[1], o[2], o[3]};
+                    if (p.vec_store && nb + 4 <= p.N) {
+                        if (rrow) { float r4[4]; Store<T>::ld4(rrow + nb, r4); v4[0] += r4[0]; v4[1] += r4[1]; v4[2] += r4[2]; v4[3] += r4[3]; }
+                        Store<T>::st4(yrow + nb, v4);
+                    } else {
+                        for (int i = 0; i < 4; ++i)
+                            if (nb + i < p.N) {
+                                float v = v4[i];
+                                if (rrow) v += Store<T>::ld(rrow + nb + i);
+                                Store<T>::st(yrow + nb + i, v);
+                            }
+                    }
                 }
             }
         }
     }
 }
 
-// decode the order-encoded column max back to T  ([groups][N] -> rows of width ld)
-template <class T>
-__global__ void colmax_decode_kernel(const unsigned* enc, T* out, int N, long ld, long total) {
-    const long i = long(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const long g = i / N, n = i - g * N;
-    Store<T>::st(out + g * ld + n, order_decode(enc[i]));
+// ---- shared MLP + max over the rows of a group (PointNet: conv1d -> BN -> [ReLU] -> max over the N points).
+// One workgroup owns (group, chunk of 16*NT output channels): it sweeps ALL rows of the group, 64 at a time (4 waves x 16),
+// keeps the running maxima in registers, reduces the 16 pixels of a wave with DPP row operations and the 4 waves through
+// LDS, and writes the result once — no atomics, no initialisation pass, no decode pass.  The [rows, N] activation (134 MB
+// in fp32 for the 128->1024 STN layers at batch 64) is never materialised.
+struct GemmMaxParams {
+    const void* X; long ldx;
+    const void* W; const float* bias;
+    void* Y; long ldy;                  // [groups, N]
+    int M_per_group, groups, K, N, nchunks, ksteps, act;
+};
+template <class T, int NT>
+__global__ __launch_bounds__(256) void gemm_colmax_kernel(const GemmMaxParams p) {
+    constexpr int VEC = Store<T>::VEC;
+    constexpr int KC = 4 * VEC;
+    __shared__ float red[4][16 * NT];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int px = lane & 15, g = lane >> 4;
+    const int c = blockIdx.x, grp = blockIdx.y;
+    const T* X = static_cast<const T*>(p.X) + long(grp) * p.M_per_group * p.ldx;
+    const uint4* Wf = reinterpret_cast<const uint4*>(p.W) + long(c) * p.ksteps * NT * 64 + lane;
+    float bv[4 * NT], cm[4 * NT];
+    ACH_UNROLL
+    for (int t = 0; t < NT; ++t)
+        ACH_UNROLL
+        for (int r = 0; r < 4; ++r) { const int n = c * (16 * NT) + chunk_channel(NT, t, g, r); bv[t * 4 + r] = n < p.N ? p.bias[n] : 0.f; cm[t * 4 + r] = -3.0e38f; }
+    for (int r0 = wave * 16; r0 < p.M_per_group; r0 += 64) {
+        const int row = r0 + px;
+        const bool valid = row < p.M_per_group;
+        f32x4 acc[NT];
+        ACH_UNROLL
+        for (int t = 0; t < NT; ++t) { acc[t][0] = 0.f; acc[t][1] = 0.f; acc[t][2] = 0.f; acc[t][3] = 0.f; }
+        for (int s = 0; s < p.ksteps; ++s) {
+            const int k0 = s * KC + g * VEC;
+            uint4 xf = make_uint4(0u, 0u, 0u, 0u);
+            if (valid && k0 < p.K) xf = *reinterpret_cast<const uint4*>(X + long(row) * p.ldx + k0);
+            ACH_UNROLL
+            for (int t = 0; t < NT; ++t) mfma16<T>(Wf[(s * NT + t) * 64], xf, acc[t]);
+        }
+        if (valid) {
+            ACH_UNROLL
+            for (int t = 0; t < NT; ++t)
+                ACH_UNROLL
+                for (int r = 0; r < 4; ++r) cm[t * 4 + r] = fmaxf(cm[t * 4 + r], apply_act(acc[t][r] + bv[t * 4 + r], p.act));
+        }
+    }
+    ACH_UNROLL
+    for (int t = 0; t < NT; ++t)
+        ACH_UNROLL
+        for (int r = 0; r < 4; ++r) {
+            const float m = row16_max(cm[t * 4 + r]);
+            if (px == 0) red[wave][chunk_channel(NT, t, g, r)] = m;
+        }
+    __syncthreads();
+    if (threadIdx.x < 16 * NT) {
+        const int n = c * (16 * NT) + threadIdx.x;
+        const float m = fmaxf(fmaxf(red[0][threadIdx.x], red[1][threadIdx.x]), fmaxf(red[2][threadIdx.x], red[3][threadIdx.x]));
+        if (n < p.N) Store<T>::st(static_cast<T*>(p.Y) + long(grp) * p.ldy + n, m);
+    }
 }
 
 template <class T>

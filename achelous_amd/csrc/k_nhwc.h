@@ -627,3 +627,120 @@ __global__ __launch_bounds__(256) void seg_head_kernel(const SegHeadParams p) {
 }
 
 }  // namespace ach
+
+namespace ach {
+
+// ------------------------------------------------------------------------------------------ last decoder level + head (fused)
+// upghost (above) followed by the Ghost segmentation head, in one kernel: the 32-channel full-resolution tensor — the
+// single largest activation of the network (6.5 MB per frame per decoder in bf16) — is never written to HBM.
+//   x1  = relu(bilinear(t))                 on the tile + 2-pixel halo   (LDS)
+//   f   = [x1 | relu(dw3x3(x1) + b)]        on the tile + 1-pixel halo   (registers)
+//   h1  = relu(Wh f + bh)   (init channels) on the tile + 1-pixel halo   (LDS)
+//   out = [h1 | relu(dw3x3(h1) + b')][:oup] on the tile, scattered to NCHW
+// Tile 32x8 outputs, 256 threads.  `F` (optional) receives f for the parity tests that tap this boundary.
+struct UpGhostHeadParams {
+    const void* Tq; long ldt;                 // t at low resolution [B,h,w,16]
+    void* F; long ldf;                        // optional [B,2h,2w,32] tap (nullptr in production plans)
+    void* out;                                // NCHW [B,oup,2h,2w]
+    const float* Wdw; const float* bdw;       // level cheap op: [9][16], [16]
+    const float* Wh; const float* bh;         // head primary: [init][32], [init]
+    const float* Wdh; const float* bdh;       // head cheap op: [9][nch], [nch]
+    int B, h, w, init, nch, oup;
+};
+constexpr int UGH_TW = 32, UGH_TH = 8, UGH_CG = 16, UGH_IMAX = 8;
+template <class T>
+__global__ __launch_bounds__(256) void upghost_head_kernel(const UpGhostHeadParams p) {
+    constexpr int TW = UGH_TW, TH = UGH_TH, CG = UGH_CG;
+    constexpr int W2 = TW + 4, H2 = TH + 4, W1 = TW + 2, H1 = TH + 2;
+    __shared__ float x1s[H2 * W2 * CG];
+    __shared__ float hs[H1 * W1][UGH_IMAX];
+    const int H = 2 * p.h, Wd = 2 * p.w;
+    const int bx = blockIdx.x * TW, by = blockIdx.y * TH;
+    const long b = blockIdx.z;
+    const int tid = threadIdx.x;
+    {   // ---- x1 on the 2-halo tile
+        const int c = (tid & 3) * 4, slot = tid >> 2;
+        const float sy = H > 1 ? float(p.h - 1) / float(H - 1) : 0.f, sx = Wd > 1 ? float(p.w - 1) / float(Wd - 1) : 0.f;
+        const T* Tq = static_cast<const T*>(p.Tq) + b * p.h * long(p.w) * p.ldt + c;
+        for (int pos = slot; pos < H2 * W2; pos += 64) {
+            const int oy = by + pos / W2 - 2, ox = bx + pos % W2 - 2;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (oy >= 0 && oy < H && ox >= 0 && ox < Wd) {
+                const float fy = sy * float(oy), fx = sx * float(ox);
+                int y0 = int(fy), x0 = int(fx);
+                if (y0 > p.h - 1) y0 = p.h - 1;
+                if (x0 > p.w - 1) x0 = p.w - 1;
+                const int y1 = y0 + (y0 < p.h - 1 ? 1 : 0), x1i = x0 + (x0 < p.w - 1 ? 1 : 0);
+                const float ly = fy - float(y0), lx = fx - float(x0), hy = 1.f - ly, hx = 1.f - lx;
+                float a[4], bq[4], cc[4], d[4];
+                Store<T>::ld4(Tq + (long(y0) * p.w + x0) * p.ldt, a);
+                Store<T>::ld4(Tq + (long(y0) * p.w + x1i) * p.ldt, bq);
+                Store<T>::ld4(Tq + (long(y1) * p.w + x0) * p.ldt, cc);
+                Store<T>::ld4(Tq + (long(y1) * p.w + x1i) * p.ldt, d);
+                ACH_UNROLL
+                for (int i = 0; i < 4; ++i) { const float t = hy * (hx * a[i] + lx * bq[i]) + ly * (hx * cc[i] + lx * d[i]); v[i] = t > 0.f ? t : 0.f; }
+            }
+            *reinterpret_cast<float4*>(x1s + pos * CG + c) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+    __syncthreads();
+    // ---- f and h1 on the 1-halo tile: one position per thread per round
+    for (int pos = tid; pos < H1 * W1; pos += 256) {
+        const int ly_ = pos / W1, lx_ = pos % W1;
+        const int oy = by + ly_ - 1, ox = bx + lx_ - 1;
+        float hv[UGH_IMAX];
+        ACH_UNROLL
+        for (int j = 0; j < UGH_IMAX; ++j) hv[j] = 0.f;
+        if (oy >= 0 && oy < H && ox >= 0 && ox < Wd) {
+            float f[2 * CG];
+            ACH_UNROLL
+            for (int c = 0; c < CG; ++c) f[CG + c] = p.bdw[c];
+            ACH_UNROLL
+            for (int k = 0; k < 9; ++k) {
+                const float* s = x1s + ((ly_ + k / 3) * W2 + lx_ + k % 3) * CG;     // 2-halo coords = 1-halo coords + 1, minus the tap's 1
+                ACH_UNROLL
+                for (int c4 = 0; c4 < CG; c4 += 4) {
+                    const float4 sv = *reinterpret_cast<const float4*>(s + c4);
+                    const float* wk = p.Wdw + k * CG + c4;
+                    f[CG + c4] += sv.x * wk[0]; f[CG + c4 + 1] += sv.y * wk[1]; f[CG + c4 + 2] += sv.z * wk[2]; f[CG + c4 + 3] += sv.w * wk[3];
+                    if (k == 4) { f[c4] = sv.x; f[c4 + 1] = sv.y; f[c4 + 2] = sv.z; f[c4 + 3] = sv.w; }
+                }
+            }
+            ACH_UNROLL
+            for (int c = 0; c < CG; ++c) f[CG + c] = f[CG + c] > 0.f ? f[CG + c] : 0.f;
+            if (p.F && ly_ >= 1 && ly_ <= TH && lx_ >= 1 && lx_ <= TW) {
+                T* fo = static_cast<T*>(p.F) + ((b * H + oy) * long(Wd) + ox) * p.ldf;
+                ACH_UNROLL
+                for (int c4 = 0; c4 < 2 * CG; c4 += 4) { const float v4[4] = {f[c4], f[c4 + 1], f[c4 + 2], f[c4 + 3]}; Store<T>::st4(fo + c4, v4); }
+            }
+            ACH_UNROLL
+            for (int j = 0; j < UGH_IMAX; ++j)
+                if (j < p.init) {
+                    const float* w = p.Wh + j * 2 * CG;
+                    float a = p.bh[j];
+                    ACH_UNROLL
+                    for (int c = 0; c < 2 * CG; ++c) a += w[c] * f[c];
+                    hv[j] = a > 0.f ? a : 0.f;
+                }
+        }
+        ACH_UNROLL
+        for (int j = 0; j < UGH_IMAX; ++j) hs[pos][j] = hv[j];
+    }
+    __syncthreads();
+    // ---- outputs: one pixel per thread
+    const int tx = tid % TW, ty = tid / TW;
+    const int oy = by + ty, ox = bx + tx;
+    if (oy >= H || ox >= Wd) return;
+    const long HW = long(H) * Wd;
+    T* out = static_cast<T*>(p.out) + b * p.oup * HW + long(oy) * Wd + ox;
+    const int ctr = (ty + 1) * W1 + tx + 1;
+    for (int j = 0; j < p.init && j < p.oup; ++j) Store<T>::st(out + j * HW, hs[ctr][j]);
+    for (int j = 0; j < p.nch; ++j) {
+        float a = p.bdh[j];
+        ACH_UNROLL
+        for (int k = 0; k < 9; ++k) a += hs[(ty + k / 3) * W1 + tx + k % 3][j] * p.Wdh[k * p.nch + j];
+        Store<T>::st(out + (p.init + j) * HW, a > 0.f ? a : 0.f);
+    }
+}
+
+}  // namespace ach

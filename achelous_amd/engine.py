@@ -34,7 +34,7 @@ class NativeLibrary:
     SYMBOLS = ('ach_create', 'ach_destroy', 'ach_last_error', 'ach_load_weights', 'ach_plan', 'ach_arena_bytes',
                'ach_forward', 'ach_decode', 'ach_nms_workspace_bytes', 'ach_nms', 'ach_tap_count', 'ach_tap_name',
                'ach_tap_shape', 'ach_read_tap', 'ach_plan_launches', 'ach_op_name', 'ach_op_bytes', 'ach_op_flops',
-               'ach_forward_profiled', 'ach_set_probe', 'ach_read_probe', 'ach_bench_gemm')
+               'ach_forward_profiled', 'ach_set_probe', 'ach_read_probe', 'ach_bench_gemm', 'ach_set_option')
 
     def __init__(self, path):
         if not os.path.exists(path):
@@ -51,6 +51,8 @@ class NativeLibrary:
         L.ach_last_error.restype = ctypes.c_char_p
         L.ach_load_weights.argtypes = [vp, ctypes.POINTER(AchTensorDesc), sz]
         L.ach_load_weights.restype = ctypes.c_int
+        L.ach_set_option.argtypes = [vp, ctypes.c_char_p, i32]
+        L.ach_set_option.restype = ctypes.c_int
         L.ach_plan.argtypes = [vp, i32]
         L.ach_plan.restype = ctypes.c_int
         L.ach_arena_bytes.argtypes = [vp]
@@ -156,6 +158,10 @@ class NativeEngine:
             for d in range(t.dim()):
                 arr[i].shape[d] = t.shape[d]
         self._check(self.L.ach_load_weights(self.h, arr, len(keep)))
+        self.batch = 0
+
+    def set_option(self, key, value):
+        self._check(self.L.ach_set_option(self.h, key.encode(), int(value)))
         self.batch = 0
 
     def plan(self, batch):

@@ -60,6 +60,7 @@ class Achelous(nn.Module):
         _build_tree(self, state_dict_spec(num_det, num_seg, phi, backbone, pc_channels, pc_classes, nano_head, radar_channels))
         self._init_like_reference()
         self._engines = {}          # (device index, dtype) -> [NativeEngine, weight version, num_points]
+        self.debug_taps = False     # True: the engine also materialises every SURVEY §8(a) boundary (parity tests)
 
     # engines hold ctypes handles: never pickle / deepcopy them (utils_fit.py:378 pickles the module, ModelEMA deep-copies it)
     def __getstate__(self):
@@ -105,6 +106,7 @@ class Achelous(nn.Module):
                                     backbone=self.backbone, resolution=self.resolution, pc_channels=self.pc_channels,
                                     pc_classes=self.pc_classes, num_points=num_points, nano_head=self.nano_head,
                                     spp=self.spp, dtype=code)
+            eng.set_option('full_taps', 1 if self.debug_taps else 0)
             ent = [eng, None, num_points]
             self._engines[key] = ent
         if ent[1] != ver:

@@ -76,6 +76,10 @@ const char* ach_last_error(const ach_handle* h);
  * the weights into kernel-native layouts on the device.  Integer buffers (num_batches_tracked) may be omitted. */
 int ach_load_weights(ach_handle* h, const ach_tensor_desc* tensors, size_t n);
 
+/* Options, set before ach_plan.  "full_taps" = 1: also write to HBM the SURVEY §8(a) boundaries that production plans keep
+ * on-chip (the 32-channel full-resolution decoder tensors), so that parity tests can read them back. */
+int ach_set_option(ach_handle* h, const char* key, int32_t value);
+
 /* Builds the launch plan and the activation arena for batch size B (re-plan to change B). */
 int ach_plan(ach_handle* h, int32_t batch);
 size_t ach_arena_bytes(const ach_handle* h);

@@ -20,9 +20,10 @@ pytestmark = pytest.mark.gpu
 F32_TOL, BF16_TOL = 1e-3, 6e-2
 
 
-def _model(meta, device='cuda'):
+def _model(meta, device='cuda', debug_taps=False):
     kw = ctor_kwargs(meta)
     m = Achelous(**kw).eval()
+    m.debug_taps = debug_taps
     m.load_state_dict(condition_state_dict(m.state_dict(), seed=meta['weight_seed']), strict=True)
     return m.to(device), kw
 
@@ -47,7 +48,7 @@ def test_native_library_is_loaded():
 @pytest.mark.parametrize('name', ['en_s0', 'en_s2'])
 def test_forward_fp32_matches_reference_fixtures(name):
     g = Golden(name)
-    m, kw = _model(g.meta)
+    m, kw = _model(g.meta, debug_taps=True)
     x, xr, xp = make_inputs(g.meta['batch'], g.meta['input_seed'], resolution=kw['resolution'], pc_channels=kw['pc_channels'])
     with torch.no_grad():
         det, se, lane, pc = m(x.cuda(), xr.cuda(), xp.cuda())
@@ -71,7 +72,7 @@ def test_forward_fp32_matches_reference_fixtures(name):
 
 def test_forward_fp32_matches_oracle_full_tensors():
     g = Golden('en_s0')
-    m, kw = _model(g.meta)
+    m, kw = _model(g.meta, debug_taps=True)
     x, xr, xp = make_inputs(3, 77, resolution=kw['resolution'], pc_channels=kw['pc_channels'], dense_radar=True)
     with torch.no_grad():
         det, se, lane, pc = m(x.cuda(), xr.cuda(), xp.cuda())
