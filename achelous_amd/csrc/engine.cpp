@@ -14,6 +14,7 @@
 
 #include "k_detect.h"
 #include "k_gemm.h"
+#include "k_mvit.h"
 #include "k_nhwc.h"
 #include "k_points.h"
 #include "k_radar.h"
@@ -295,7 +296,8 @@ public:
         const int NT = pk.NT;
         void** ydyn = o.ydyn;
         const double esz = double(sizeof(T));
-        const double bytes = double(M) * pk.K * esz + double(M) * pk.N * esz + (o.residual ? double(M) * pk.N * esz : 0.0)
+        const double in_bytes = o.conv_k > 0 ? double(M) / (double(o.Ho) * o.Wo) * o.Hin * o.Win * o.Cin * esz : double(M) * pk.K * esz;   // inputs read ONCE
+        const double bytes = in_bytes + double(M) * pk.N * esz + (o.residual ? double(M) * pk.N * esz : 0.0)
                              + double(pk.group_elems) * esz * (o.w_group_stride ? o.groups : 1);
         add_op(name, [g, NT, P, ydyn](hipStream_t s) mutable {
             if (ydyn) g.Y = *ydyn;
@@ -510,6 +512,99 @@ public:
             }
             feats[i] = x;
         }
+    }
+
+    // ------------------------------------------------------------------------------------------ MobileViT (a6)
+    struct MvCfg { int dims[3]; int ch[11]; int exp; };
+    MvCfg mv_cfg() const {
+        switch (cfg.phi) {
+            case ACH_PHI_S0: return {{64, 80, 96}, {16, 16, 32, 32, 48, 48, 96, 96, 96, 96, 176}, 2};
+            case ACH_PHI_S1: return {{96, 120, 144}, {16, 32, 32, 32, 48, 48, 120, 120, 120, 120, 224}, 4};
+            default: return {{144, 192, 240}, {16, 32, 32, 32, 64, 64, 144, 144, 144, 144, 288}, 4};
+        }
+    }
+    // nn.Sequential(conv kxk (no bias), BatchNorm(1e-5), SiLU) as an (implicit-)GEMM   (mobilevit.py:6-19)
+    A mv_conv(const std::string& pfx, const A& x, int k, int stride) {
+        const HostTensor& w = W(pfx + ".0.weight");
+        Lin l = (k == 1) ? lin(pfx + ".0.weight", "") : conv_lin(pfx + ".0.weight", "", int(w.shape[1]), int(x.ld), k);
+        if (k == 1 && l.K != x.C) throw AchError{ACH_ERR_MISSING_KEY, "conv width at " + pfx};
+        fold_bn(l, pfx + ".1", 1e-5);
+        if (k == 1) { A y = alloc(x.B, x.H, x.W, l.N); GemmOpt o; o.act = ACT_SILU; gemm(pfx, x, pack(l), y, o); return y; }
+        return conv_gemm(pfx, x, l, k, stride, ACT_SILU);
+    }
+    A mv2block(const std::string& pfx, const A& x, int stride, int oup) {         // mobilevit.py:93-131 (expansion != 1)
+        Lin l1 = lin(pfx + ".conv.0.weight", ""); fold_bn(l1, pfx + ".conv.1", 1e-5);
+        A hdn = alloc(x.B, x.H, x.W, l1.N);
+        { GemmOpt o; o.act = ACT_SILU; gemm(pfx + ".pw1", x, pack(l1), hdn, o); }
+        const int Ho = (x.H + 2 - 3) / stride + 1, Wo = (x.W + 2 - 3) / stride + 1;
+        A d = alloc(x.B, Ho, Wo, l1.N);
+        dwconv(pfx + ".dw", hdn, nullptr, pfx + ".conv.3.weight", "", pfx + ".conv.4", 1e-5, 3, stride, ACT_SILU, d);
+        Lin l2 = lin(pfx + ".conv.6.weight", ""); fold_bn(l2, pfx + ".conv.7", 1e-5);
+        if (l2.N != oup) throw AchError{ACH_ERR_MISSING_KEY, "MV2 width at " + pfx};
+        A y = alloc(x.B, Ho, Wo, oup);
+        GemmOpt o; if (stride == 1 && x.C == oup) o.residual = &x;
+        gemm(pfx + ".pw2", d, pack(l2), y, o);
+        return y;
+    }
+    A mvit_block(const std::string& pfx, const A& x, int depth) {                   // mobilevit.py:147-165
+        if ((x.H & 1) || (x.W & 1) || (x.H / 2) * (x.W / 2) > MVIT_NMAX) throw AchError{ACH_ERR_UNSUPPORTED, "MobileViT token count"};
+        A t = mv_conv(pfx + ".conv1", x, 3, 1);
+        t = mv_conv(pfx + ".conv2", t, 1, 1);
+        const int D = t.C;
+        for (int l = 0; l < depth; ++l) {
+            const std::string a = pfx + ".transformer.layers." + std::to_string(l) + ".0", f = pfx + ".transformer.layers." + std::to_string(l) + ".1";
+            Lin lq = lin(a + ".fn.to_qkv.weight", ""); fold_ln_in(lq, a + ".norm");
+            if (lq.N != 96) throw AchError{ACH_ERR_UNSUPPORTED, "MobileViT attention is built for 4 heads x 8"};
+            A qkv = alloc(t.B, t.H, t.W, 96);
+            { GemmOpt o; o.ln = true; o.ln_eps = 1e-5f; gemm(a + ".qkv", t, pack(lq), qkv, o); }
+            A ao = alloc(t.B, t.H, t.W, 32);
+            MvitAttnParams ap{qkv.p, qkv.ld, ao.p, ao.ld, t.B, t.H, t.W, 4, 0.35355339059327373f};
+            const int N = (t.H / 2) * (t.W / 2);
+            const dim3 grid(unsigned(t.B * 4 * 4), unsigned(cdiv(N, 256))), block(256);
+            add_op(a + ".attn", [ap, grid, block](hipStream_t s) { ACH_LAUNCH(mvit_attn_kernel<T>, grid, block, s, ap); }, double(t.rows()) * 128 * sizeof(T));
+            A t1 = alloc(t.B, t.H, t.W, D);
+            { GemmOpt o; o.residual = &t; gemm(a + ".to_out", ao, pack(lin(a + ".fn.to_out.0.weight", a + ".fn.to_out.0.bias")), t1, o); }
+            Lin l1 = lin(f + ".fn.net.0.weight", f + ".fn.net.0.bias"); fold_ln_in(l1, f + ".norm");
+            A hdn = alloc(t.B, t.H, t.W, l1.N);
+            { GemmOpt o; o.ln = true; o.ln_eps = 1e-5f; o.act = ACT_SILU; gemm(f + ".ff1", t1, pack(l1), hdn, o); }
+            A t2 = alloc(t.B, t.H, t.W, D);
+            { GemmOpt o; o.residual = &t1; gemm(f + ".ff2", hdn, pack(lin(f + ".fn.net.3.weight", f + ".fn.net.3.bias")), t2, o); }
+            t = t2;
+        }
+        // conv3 (1x1 D->C) written next to the block input: cat((conv3(x), y), 1) -> conv4 3x3
+        Lin l3 = lin(pfx + ".conv3.0.weight", ""); fold_bn(l3, pfx + ".conv3.1", 1e-5);
+        if (l3.N != x.C) throw AchError{ACH_ERR_MISSING_KEY, "MobileViT conv3 width at " + pfx};
+        A cat = alloc(x.B, x.H, x.W, 2 * x.C);
+        { GemmOpt o; o.act = ACT_SILU; gemm(pfx + ".conv3", t, pack(l3), cat.slice(0, x.C), o); }
+        copy(pfx + ".cat", x, cat.slice(x.C, x.C));
+        return mv_conv(pfx + ".conv4", cat, 3, 1);
+    }
+    void mobilevit(const std::string& pfx, A feats[4]) {                            // mobilevit.py:198-222
+        const MvCfg mc = mv_cfg();
+        const int B = batch, R = cfg.resolution;
+        A img = alloc(B, R, R, 3);
+        {
+            ToNhwcParams tp{nullptr, img.p, B, 3, R, R, img.ld};
+            const dim3 grid(unsigned(cdivl(img.rows(), 256))), block(256);
+            const void** in = &io.image;
+            add_op(pfx + ".to_nhwc", [tp, grid, block, in](hipStream_t s) mutable { tp.X = *in; ACH_LAUNCH(nchw_to_nhwc_kernel<T>, grid, block, s, tp); },
+                   double(img.rows()) * (3 + img.ld) * sizeof(T));
+        }
+        A x = mv_conv(pfx + ".conv1", img, 3, 2);
+        x = mv2block(pfx + ".mv2.0", x, 1, mc.ch[1]);
+        x = mv2block(pfx + ".mv2.1", x, 2, mc.ch[2]);
+        x = mv2block(pfx + ".mv2.2", x, 1, mc.ch[3]);
+        x = mv2block(pfx + ".mv2.3", x, 1, mc.ch[3]);
+        feats[0] = x;
+        x = mv2block(pfx + ".mv2.4", x, 2, mc.ch[4]);
+        x = mvit_block(pfx + ".mvit.0", x, 2);
+        feats[1] = x;
+        x = mv2block(pfx + ".mv2.5", x, 2, mc.ch[6]);
+        x = mvit_block(pfx + ".mvit.1", x, 4);
+        feats[2] = x;
+        x = mv2block(pfx + ".mv2.6", x, 2, mc.ch[8]);
+        x = mvit_block(pfx + ".mvit.2", x, 3);
+        feats[3] = mv_conv(pfx + ".conv2", x, 1, 1);
     }
 
     // ------------------------------------------------------------------------------------------ neck (a7-a13)
@@ -919,11 +1014,11 @@ public:
 
     // ------------------------------------------------------------------------------------------ plan (a1)
     void build() {
-        if (cfg.backbone != ACH_BACKBONE_EDGENEXT) throw AchError{ACH_ERR_UNSUPPORTED, "MobileViT backbone is not built yet (SURVEY.md §8 a6)"};
         if (cfg.resolution % 32 || cfg.resolution < 64) throw AchError{ACH_ERR_INVALID, "resolution must be a multiple of 32"};
         pointnet();
         A m[4];
-        edgenext("image_radar_encoder.fpn.backbone", m);
+        if (cfg.backbone == ACH_BACKBONE_EDGENEXT) edgenext("image_radar_encoder.fpn.backbone", m);
+        else mobilevit("image_radar_encoder.fpn.backbone", m);
         A q[3];
         neck(m, q);
         A r[3];

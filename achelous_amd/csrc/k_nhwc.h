@@ -647,13 +647,17 @@ struct UpGhostHeadParams {
     const float* Wdh; const float* bdh;       // head cheap op: [9][nch], [nch]
     int B, h, w, init, nch, oup;
 };
-constexpr int UGH_TW = 32, UGH_TH = 8, UGH_CG = 16, UGH_IMAX = 8;
+constexpr int UGH_TW = 30, UGH_TH = 6, UGH_CG = 16, UGH_IMAX = 8;
+// Tile 30x6 outputs: its 1-pixel halo is exactly 32x8 = 256 positions = one per thread.  LDS layouts are chosen for the
+// access patterns: x1 rows padded to 20 floats (thread = position reads 16 consecutive floats: stride 20 dwords is
+// conflict-free for ds_read_b128), h1 stored planar [channel][position] (thread = pixel reads one channel at a time).
 template <class T>
 __global__ __launch_bounds__(256) void upghost_head_kernel(const UpGhostHeadParams p) {
-    constexpr int TW = UGH_TW, TH = UGH_TH, CG = UGH_CG;
+    constexpr int TW = UGH_TW, TH = UGH_TH, CG = UGH_CG, CS = CG + 4;
     constexpr int W2 = TW + 4, H2 = TH + 4, W1 = TW + 2, H1 = TH + 2;
-    __shared__ float x1s[H2 * W2 * CG];
-    __shared__ float hs[H1 * W1][UGH_IMAX];
+    static_assert(W1 * H1 == 256, "one halo position per thread");
+    __shared__ float x1s[H2 * W2 * CS];
+    __shared__ float hs[UGH_IMAX][H1 * W1];
     const int H = 2 * p.h, Wd = 2 * p.w;
     const int bx = blockIdx.x * TW, by = blockIdx.y * TH;
     const long b = blockIdx.z;
@@ -680,24 +684,25 @@ __global__ __launch_bounds__(256) void upghost_head_kernel(const UpGhostHeadPara
                 ACH_UNROLL
                 for (int i = 0; i < 4; ++i) { const float t = hy * (hx * a[i] + lx * bq[i]) + ly * (hx * cc[i] + lx * d[i]); v[i] = t > 0.f ? t : 0.f; }
             }
-            *reinterpret_cast<float4*>(x1s + pos * CG + c) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(x1s + pos * CS + c) = make_float4(v[0], v[1], v[2], v[3]);
         }
     }
     __syncthreads();
-    // ---- f and h1 on the 1-halo tile: one position per thread per round
-    for (int pos = tid; pos < H1 * W1; pos += 256) {
-        const int ly_ = pos / W1, lx_ = pos % W1;
-        const int oy = by + ly_ - 1, ox = bx + lx_ - 1;
+    // ---- f and h1 on the 1-halo tile: thread = position
+    const int ly_ = tid / W1, lx_ = tid % W1;
+    const int oy = by + ly_ - 1, ox = bx + lx_ - 1;
+    const bool inside = oy >= 0 && oy < H && ox >= 0 && ox < Wd;
+    {
         float hv[UGH_IMAX];
         ACH_UNROLL
         for (int j = 0; j < UGH_IMAX; ++j) hv[j] = 0.f;
-        if (oy >= 0 && oy < H && ox >= 0 && ox < Wd) {
+        if (inside) {
             float f[2 * CG];
             ACH_UNROLL
             for (int c = 0; c < CG; ++c) f[CG + c] = p.bdw[c];
             ACH_UNROLL
             for (int k = 0; k < 9; ++k) {
-                const float* s = x1s + ((ly_ + k / 3) * W2 + lx_ + k % 3) * CG;     // 2-halo coords = 1-halo coords + 1, minus the tap's 1
+                const float* s = x1s + ((ly_ + k / 3) * W2 + lx_ + k % 3) * CS;     // 2-halo coords of the tap
                 ACH_UNROLL
                 for (int c4 = 0; c4 < CG; c4 += 4) {
                     const float4 sv = *reinterpret_cast<const float4*>(s + c4);
@@ -724,21 +729,18 @@ __global__ __launch_bounds__(256) void upghost_head_kernel(const UpGhostHeadPara
                 }
         }
         ACH_UNROLL
-        for (int j = 0; j < UGH_IMAX; ++j) hs[pos][j] = hv[j];
+        for (int j = 0; j < UGH_IMAX; ++j) hs[j][tid] = hv[j];
     }
     __syncthreads();
-    // ---- outputs: one pixel per thread
-    const int tx = tid % TW, ty = tid / TW;
-    const int oy = by + ty, ox = bx + tx;
-    if (oy >= H || ox >= Wd) return;
+    // ---- outputs: the interior positions
+    if (!inside || ly_ < 1 || ly_ > TH || lx_ < 1 || lx_ > TW) return;
     const long HW = long(H) * Wd;
     T* out = static_cast<T*>(p.out) + b * p.oup * HW + long(oy) * Wd + ox;
-    const int ctr = (ty + 1) * W1 + tx + 1;
-    for (int j = 0; j < p.init && j < p.oup; ++j) Store<T>::st(out + j * HW, hs[ctr][j]);
+    for (int j = 0; j < p.init && j < p.oup; ++j) Store<T>::st(out + j * HW, hs[j][tid]);
     for (int j = 0; j < p.nch; ++j) {
         float a = p.bdh[j];
         ACH_UNROLL
-        for (int k = 0; k < 9; ++k) a += hs[(ty + k / 3) * W1 + tx + k % 3][j] * p.Wdh[k * p.nch + j];
+        for (int k = 0; k < 9; ++k) a += hs[j][(ly_ - 1 + k / 3) * W1 + lx_ - 1 + k % 3] * p.Wdh[k * p.nch + j];
         Store<T>::st(out + (p.init + j) * HW, a > 0.f ? a : 0.f);
     }
 }

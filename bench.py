@@ -32,6 +32,7 @@ import torch.distributed as dist  # noqa: E402
 CONFIGS = {
     'en_s0': (2, dict(backbone='en', phi='S0')),
     'en_s2': (5, dict(backbone='en', phi='S2')),
+    'mv_s2': (3, dict(backbone='mv', phi='S2')),
 }
 COMMON = dict(num_det=7, num_seg=9, resolution=320, neck='gdf', pc_seg='pn', pc_channels=5, pc_classes=8, nano_head=True, spp=True)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
