@@ -70,6 +70,7 @@ int ach_set_option(ach_handle* h, const char* key, int32_t value) {
     return guarded(h, [&] {
         if (!key) throw ach::AchError{ACH_ERR_INVALID, "null option"};
         if (std::string(key) == "full_taps") h->eng->full_taps = value != 0;
+        else if (std::string(key) == "streams") h->eng->multi_stream = value != 0;
         else throw ach::AchError{ACH_ERR_INVALID, std::string("unknown option: ") + key};
     });
 }

@@ -34,6 +34,11 @@ static inline long round_up(long v, long m) { return (v + m - 1) / m * m; }
 EngineBase::~EngineBase() {
     if (warena) (void)hipFree(warena);
     if (aarena) (void)hipFree(aarena);
+    if (streams_ready) {
+        for (int k = 0; k < kSideStreams; ++k) { (void)hipStreamDestroy(side_stream[k]); (void)hipEventDestroy(ev_end[k]); }
+        (void)hipEventDestroy(ev_fork);
+        for (int k = 0; k < kJoinEvents; ++k) (void)hipEventDestroy(ev_join[k]);
+    }
     for (auto e : probe_ev0) (void)hipEventDestroy(e);
     for (auto e : probe_ev1) (void)hipEventDestroy(e);
 }
@@ -78,21 +83,50 @@ float* EngineBase::up_f32(const std::vector<float>& v) {
 }
 void EngineBase::reset_plan() {
     probe_op = -1;
+    cur_stream = 0; pending_wait = -1;
     ops.clear(); taps.clear(); tap_order.clear();
     warena_used = 0; aarena_used = 0;
 }
+void EngineBase::ensure_streams() {
+    if (streams_ready) return;
+    for (int k = 0; k < kSideStreams; ++k) {
+        ACH_HIP_CHECK(hipStreamCreateWithFlags(&side_stream[k], hipStreamNonBlocking));
+        ACH_HIP_CHECK(hipEventCreate(&ev_end[k]));
+    }
+    ACH_HIP_CHECK(hipEventCreate(&ev_fork));
+    for (int k = 0; k < kJoinEvents; ++k) ACH_HIP_CHECK(hipEventCreate(&ev_join[k]));
+    streams_ready = true;
+}
+// The radar and point branches do not depend on the image path until the fusion stage, and most of their kernels are
+// latency-bound on small maps: they run on two engine-owned side streams, forked from and joined back into the caller's
+// stream with events, so their launches fill the CUs the image path leaves idle.
 void EngineBase::run(hipStream_t s) {
+    bool used[kSideStreams] = {false, false};
+    const bool multi = multi_stream;
+    if (multi) {
+        ensure_streams();
+        (void)hipEventRecord(ev_fork, s);
+        for (int k = 0; k < kSideStreams; ++k) (void)hipStreamWaitEvent(side_stream[k], ev_fork, 0);
+    }
     for (size_t i = 0; i < ops.size(); ++i) {
+        Op& op = ops[i];
+        hipStream_t st = s;
+        if (multi && op.stream > 0) { st = side_stream[op.stream - 1]; used[op.stream - 1] = true; }
+        if (multi && op.wait_ev >= 0) (void)hipStreamWaitEvent(st, ev_join[op.wait_ev], 0);
         if (int(i) == probe_op) {
             const size_t slot = size_t(probe_count % kProbeEvents);
-            (void)hipEventRecord(probe_ev0[slot], s);
-            ops[i].fn(s);
-            (void)hipEventRecord(probe_ev1[slot], s);
+            (void)hipEventRecord(probe_ev0[slot], st);
+            op.fn(st);
+            (void)hipEventRecord(probe_ev1[slot], st);
             ++probe_count;
         } else {
-            ops[i].fn(s);
+            op.fn(st);
         }
+        if (multi && op.signal_ev >= 0) (void)hipEventRecord(ev_join[op.signal_ev], st);
     }
+    if (multi)
+        for (int k = 0; k < kSideStreams; ++k)
+            if (used[k]) { (void)hipEventRecord(ev_end[k], side_stream[k]); (void)hipStreamWaitEvent(s, ev_end[k], 0); }
 }
 void EngineBase::run_profiled(hipStream_t s, float* op_ms, size_t cap) {
     if (cap < ops.size()) throw AchError{ACH_ERR_INVALID, "profile buffer too small"};
@@ -678,21 +712,6 @@ public:
         else throw AchError{ACH_ERR_UNSUPPORTED, ghost_pfx + ": Ghost half-width must be 16, 24 or 32"};
         return y;
     }
-    // segmentation head = GhostModule whose outputs ARE the network output (NCHW, 2 or num_seg channels)
-    void seg_head(const std::string& pfx, const A& x, int oup, void** out) {
-        const int init = (oup + 1) / 2, nch = oup - init;
-        if (init > SEGH_IMAX || x.C % 4) throw AchError{ACH_ERR_UNSUPPORTED, pfx + ": segmentation head width"};
-        Lin lp = conv_bn(pfx + ".primary_conv.0", pfx + ".primary_conv.1", 1e-5);
-        const HostTensor& w = W(pfx + ".cheap_operation.0.weight");
-        std::vector<float> sc, sh; bn_coeffs(pfx + ".cheap_operation.1", 1e-5, sc, sh);
-        std::vector<float> wt(size_t(9) * std::max(nch, 1)), bias(static_cast<size_t>(std::max(nch, 1)), 0.f);
-        for (int j = 0; j < nch; ++j) { for (int t = 0; t < 9; ++t) wt[size_t(t) * nch + j] = w.data[size_t(j) * 9 + t] * sc[j]; bias[j] = sh[j]; }
-        SegHeadParams p{x.p, x.ld, nullptr, up_f32(lp.w), up_f32(lp.b), up_f32(wt), up_f32(bias), x.B, x.H, x.W, x.C, init, nch, oup};
-        const dim3 grid(unsigned(cdiv(x.W, SEGH_TW)), unsigned(cdiv(x.H, SEGH_TH)), unsigned(x.B)), block(256);
-        add_op(pfx, [p, grid, block, out](hipStream_t s) mutable { p.out = *out; ACH_LAUNCH(seg_head_kernel<T>, grid, block, s, p); },
-               double(x.rows()) * (x.C + oup) * sizeof(T));
-    }
-
     // last decoder level (1_to_0) + segmentation head in one full-resolution kernel (upghost_head_kernel)
     void decoder_last_level(const std::string& up_pfx, const std::string& ghost_pfx, const std::string& head_pfx, const std::string& tap_name,
                             const A& x, int cout, int oup, void** out) {
@@ -848,7 +867,7 @@ public:
                 dp.Y = y.p; dp.ldy = y.ld; dp.Wf = up_f32(lf.w); dp.bf = up_f32(lf.b);
                 const dim3 grid(unsigned(cdivl(x.rows(), 256))), block(256);
                 const double bytes = double(x.rows()) * (3.0 * Cp + 32) * sizeof(T);
-                if (C == 3) add_op(pfx + ".deform", [dp, grid, block](hipStream_t s) { ACH_LAUNCH((deform_fused_kernel<T, 3, 8>), grid, block, s, dp); }, bytes);
+                if (C == 3) add_op(pfx + ".deform", [dp, grid, block](hipStream_t s) { ACH_LAUNCH((deform_fused_kernel<T, 3, 4>), grid, block, s, dp); }, bytes);   // 3 channels: one 4-vector per corner
                 else add_op(pfx + ".deform", [dp, grid, block](hipStream_t s) { ACH_LAUNCH((deform_fused_kernel<T, 8, 8>), grid, block, s, dp); }, bytes);
             } else {
                 A col = alloc(B, x.H, x.W, 9 * Cp);
@@ -965,6 +984,8 @@ public:
         Rows h = pc_layer(pfx + ".conv1", x, lin_bn1d(pfx + ".conv1", pfx + ".bn1"), ACT_RELU);
         h = pc_layer(pfx + ".conv2", h, lin_bn1d(pfx + ".conv2", pfx + ".bn2"), ACT_RELU);
         Rows g = pc_layer_max(pfx + ".conv3", h, lin_bn1d(pfx + ".conv3", pfx + ".bn3"), ACT_RELU, B);
+        // (a one-workgroup-per-sample fusion of the three FC layers was measured 4-6x SLOWER than three small GEMM launches:
+        //  64 workgroups cannot hide the weight-row latency; the N-chunk split of the GEMM spreads each layer over the chip)
         g = pc_layer(pfx + ".fc1", g, lin_bn1d(pfx + ".fc1", pfx + ".bn4"), ACT_RELU);
         g = pc_layer(pfx + ".fc2", g, lin_bn1d(pfx + ".fc2", pfx + ".bn5"), ACT_RELU);
         return pc_layer(pfx + ".fc3", g, lin_bn1d(pfx + ".fc3", ""), ACT_NONE);
@@ -1015,15 +1036,22 @@ public:
     // ------------------------------------------------------------------------------------------ plan (a1)
     void build() {
         if (cfg.resolution % 32 || cfg.resolution < 64) throw AchError{ACH_ERR_INVALID, "resolution must be a multiple of 32"};
+        // enqueue order = plan order: the two side branches first, so they are already running while the (longest) image
+        // path is being enqueued on the caller's stream
+        A r[3];
+        cur_stream = 1;
+        rcnet(r);
+        signal_after_last(0);
+        cur_stream = 2;
         pointnet();
+        cur_stream = 0;
         A m[4];
         if (cfg.backbone == ACH_BACKBONE_EDGENEXT) edgenext("image_radar_encoder.fpn.backbone", m);
         else mobilevit("image_radar_encoder.fpn.backbone", m);
         A q[3];
         neck(m, q);
-        A r[3];
-        rcnet(r);
         tap("q3", q[0]); tap("q4", q[1]); tap("q5", q[2]);
+        wait_before_next(0);                      // fusion needs the radar taps
         A p[3] = {fuse(3, q[0], r[0]), fuse(4, q[1], r[1]), fuse(5, q[2], r[2])};
         head(p);
     }

@@ -37,6 +37,9 @@ struct Op {
     std::function<void(hipStream_t)> fn;
     double bytes = 0;             // algorithmic HBM bytes of one launch: inputs read once + outputs written once + weights
     double flops = 0;             // 2 * MACs of one launch (dense contractions only)
+    int stream = 0;               // 0: caller's stream (image path) ; 1, 2: engine-owned side streams (radar / point branches)
+    int wait_ev = -1;             // join: wait for this event before the launch
+    int signal_ev = -1;           // record this event after the launch
 };
 
 struct IoPtrs {
@@ -57,6 +60,7 @@ public:
     char* warena = nullptr; size_t warena_cap = 0, warena_used = 0;      // packed weights / constants
     char* aarena = nullptr; size_t aarena_cap = 0, aarena_used = 0;      // activations
     bool measuring = false;
+    bool multi_stream = true;         // option "streams": run the independent radar / point branches on side streams
     bool full_taps = false;           // option "full_taps": also materialise boundaries that production plans keep on-chip
     int batch = 0;
     std::vector<Op> ops;
@@ -88,8 +92,22 @@ protected:
     void* aalloc(size_t bytes);
     float* up_f32(const std::vector<float>& v);
     void add_op(const std::string& name, std::function<void(hipStream_t)> fn, double bytes = 0, double flops = 0) {
-        if (!measuring) ops.push_back(Op{name, std::move(fn), bytes, flops});
+        if (measuring) return;
+        Op op{name, std::move(fn), bytes, flops};
+        op.stream = cur_stream;
+        op.wait_ev = pending_wait;
+        pending_wait = -1;
+        ops.push_back(std::move(op));
     }
+    // branch bookkeeping while the plan is built
+    int cur_stream = 0, pending_wait = -1;
+    void signal_after_last(int ev) { if (!measuring && !ops.empty()) ops.back().signal_ev = ev; }
+    void wait_before_next(int ev) { pending_wait = ev; }
+    static constexpr int kSideStreams = 2, kJoinEvents = 4;
+    hipStream_t side_stream[kSideStreams] = {nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[kJoinEvents] = {nullptr, nullptr, nullptr, nullptr}, ev_end[kSideStreams] = {nullptr, nullptr};
+    bool streams_ready = false;
+    void ensure_streams();
     int probe_op = -1;
     static constexpr int kProbeEvents = 512;
     std::vector<hipEvent_t> probe_ev0, probe_ev1;

@@ -41,6 +41,8 @@ __global__ __launch_bounds__(256) void dwconv_strip_kernel(const DwParams p) {
         ACH_UNROLL
         for (int o = 0; o < OW; ++o) { acc[o][0] = bb.x; acc[o][1] = bb.y; acc[o][2] = bb.z; acc[o][3] = bb.w; }
     }
+    // (measured: unrolling the row loop with clamped, always-issued loads is 2-3x SLOWER here — the extra live registers cost
+    //  more occupancy than the batched loads gain; rows outside the map are skipped instead)
     for (int ky = 0; ky < KS; ++ky) {
         const int iy = oy - PAD + ky;
         if (iy < 0 || iy >= p.H) continue;
@@ -133,37 +135,6 @@ inline void launch_dwconv(const DwParams& p, int ks, hipStream_t s) {
         case 5: ACH_LAUNCH((dwconv_kernel<T, 5>), grid, block, s, p); break;
         default: break;
     }
-}
-
-// 3x3 depthwise on NCHW planes, used only for the "cheap operation" of the two segmentation heads whose
-// channel counts (5 and 1) are the network outputs themselves:  out[:, co+j] = act(w_j * in[:, ci+j] + b_j)
-struct DwPlaneParams {
-    const void* X; void* Y;         // NCHW tensors (may alias: distinct planes)
-    const float* W; const float* bias;   // [9][nch] , [nch]
-    int B, H, Wd, Cx, Cy, ci, co, nch, act;
-};
-template <class T>
-__global__ __launch_bounds__(256) void dwplane3x3_kernel(const DwPlaneParams p) {
-    const long total = long(p.B) * p.nch * p.H * p.Wd;
-    const long idx = long(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    const int x = int(idx % p.Wd);
-    long r = idx / p.Wd;
-    const int y = int(r % p.H); r /= p.H;
-    const int j = int(r % p.nch);
-    const long b = r / p.nch;
-    const T* in = static_cast<const T*>(p.X) + (b * p.Cx + p.ci + j) * long(p.H) * p.Wd;
-    float acc = p.bias[j];
-    for (int ky = 0; ky < 3; ++ky) {
-        const int iy = y - 1 + ky;
-        if (iy < 0 || iy >= p.H) continue;
-        for (int kx = 0; kx < 3; ++kx) {
-            const int ix = x - 1 + kx;
-            if (ix < 0 || ix >= p.Wd) continue;
-            acc += Store<T>::ld(in + long(iy) * p.Wd + ix) * p.W[(ky * 3 + kx) * p.nch + j];
-        }
-    }
-    Store<T>::st(static_cast<T*>(p.Y) + ((b * p.Cy + p.co + j) * long(p.H) + y) * p.Wd + x, apply_act(acc, p.act));
 }
 
 // ------------------------------------------------------------------------------------------ EdgeNeXt stem
@@ -525,25 +496,28 @@ __global__ __launch_bounds__(16 * CG) void upghost_kernel(const UpGhostParams p)
     const int c = (threadIdx.x % CQ) * 4, slot = threadIdx.x / CQ;
     const float sy = H > 1 ? float(p.h - 1) / float(H - 1) : 0.f, sx = Wd > 1 ? float(p.w - 1) / float(Wd - 1) : 0.f;
     const T* Tq = static_cast<const T*>(p.Tq) + b * p.h * long(p.w) * p.ldt + c;
-    for (int pos = slot; pos < HS * HS; pos += 64) {
+    constexpr int ROUNDS = (HS * HS + 63) / 64;
+    ACH_UNROLL
+    for (int r = 0; r < ROUNDS; ++r) {                             // unconditional clamped loads: all rounds in flight together
+        const int pos_raw = slot + r * 64;
+        const int pos = pos_raw < HS * HS ? pos_raw : HS * HS - 1;
         const int oy = by + pos / HS - 1, ox = bx + pos % HS - 1;
-        float v[4] = {0.f, 0.f, 0.f, 0.f};                        // outside the map: the dw conv's zero padding
-        if (oy >= 0 && oy < H && ox >= 0 && ox < Wd) {
-            const float fy = sy * float(oy), fx = sx * float(ox);
-            int y0 = int(fy), x0 = int(fx);
-            if (y0 > p.h - 1) y0 = p.h - 1;
-            if (x0 > p.w - 1) x0 = p.w - 1;
-            const int y1 = y0 + (y0 < p.h - 1 ? 1 : 0), x1i = x0 + (x0 < p.w - 1 ? 1 : 0);
-            const float ly = fy - float(y0), lx = fx - float(x0), hy = 1.f - ly, hx = 1.f - lx;
-            float a[4], bq[4], cc[4], d[4];
-            Store<T>::ld4(Tq + (long(y0) * p.w + x0) * p.ldt, a);
-            Store<T>::ld4(Tq + (long(y0) * p.w + x1i) * p.ldt, bq);
-            Store<T>::ld4(Tq + (long(y1) * p.w + x0) * p.ldt, cc);
-            Store<T>::ld4(Tq + (long(y1) * p.w + x1i) * p.ldt, d);
-            ACH_UNROLL
-            for (int i = 0; i < 4; ++i) { const float t = hy * (hx * a[i] + lx * bq[i]) + ly * (hx * cc[i] + lx * d[i]); v[i] = t > 0.f ? t : 0.f; }
-        }
-        *reinterpret_cast<float4*>(x1 + pos * CG + c) = make_float4(v[0], v[1], v[2], v[3]);
+        const bool ok = oy >= 0 && oy < H && ox >= 0 && ox < Wd;  // outside the map: the dw conv's zero padding
+        const int cy = oy < 0 ? 0 : (oy >= H ? H - 1 : oy), cx = ox < 0 ? 0 : (ox >= Wd ? Wd - 1 : ox);
+        const float fy = sy * float(cy), fx = sx * float(cx);
+        int y0 = int(fy), x0 = int(fx);
+        if (y0 > p.h - 1) y0 = p.h - 1;
+        if (x0 > p.w - 1) x0 = p.w - 1;
+        const int y1 = y0 + (y0 < p.h - 1 ? 1 : 0), x1i = x0 + (x0 < p.w - 1 ? 1 : 0);
+        const float ly = fy - float(y0), lx = fx - float(x0), hy = 1.f - ly, hx = 1.f - lx;
+        float a[4], bq[4], cc[4], d[4], v[4];
+        Store<T>::ld4(Tq + (long(y0) * p.w + x0) * p.ldt, a);
+        Store<T>::ld4(Tq + (long(y0) * p.w + x1i) * p.ldt, bq);
+        Store<T>::ld4(Tq + (long(y1) * p.w + x0) * p.ldt, cc);
+        Store<T>::ld4(Tq + (long(y1) * p.w + x1i) * p.ldt, d);
+        ACH_UNROLL
+        for (int i = 0; i < 4; ++i) { const float t = hy * (hx * a[i] + lx * bq[i]) + ly * (hx * cc[i] + lx * d[i]); v[i] = (ok && t > 0.f) ? t : 0.f; }
+        if (pos_raw < HS * HS) *reinterpret_cast<float4*>(x1 + pos * CG + c) = make_float4(v[0], v[1], v[2], v[3]);
     }
     float wk[9][4];
     ACH_UNROLL
@@ -569,60 +543,6 @@ __global__ __launch_bounds__(16 * CG) void upghost_kernel(const UpGhostParams p)
         T* yo = Y + ((b * H + oy) * long(Wd) + ox) * p.ldy + c;
         Store<T>::st4(yo, o1);
         Store<T>::st4(yo + CG, acc);
-    }
-}
-
-// ------------------------------------------------------------------------------------------ segmentation head (fused)
-// GhostModule(Cin -> oup) whose result IS a network output (NCHW): x1 = relu(bn(conv1x1(f))) (init = ceil(oup/2) channels),
-// x2 = relu(bn(dw3x3(x1))), out = cat(x1, x2)[:oup].  One workgroup = 30x6 outputs + 1-pixel halo = 32x8 threads: every thread
-// computes x1 of its halo pixel (64 B of f, weights wave-uniform), interior threads then take the 3x3 from LDS.
-struct SegHeadParams {
-    const void* F; long ldf; void* out;      // f NHWC [B,H,W,Cin] ; out NCHW [B,oup,H,W]
-    const float* Wp; const float* bp;        // [init][Cin] (BN folded), [init]
-    const float* Wdw; const float* bdw;      // [9][nch], [nch]   (nch = oup - init)
-    int B, H, Wd, Cin, init, nch, oup;
-};
-constexpr int SEGH_TW = 30, SEGH_TH = 6, SEGH_IMAX = 8;
-template <class T>
-__global__ __launch_bounds__(256) void seg_head_kernel(const SegHeadParams p) {
-    constexpr int HW_ = SEGH_TW + 2;
-    __shared__ float x1[(SEGH_TH + 2) * HW_][SEGH_IMAX];
-    const int lx = threadIdx.x % HW_, ly = threadIdx.x / HW_;
-    const int ox = blockIdx.x * SEGH_TW + lx - 1, oy = blockIdx.y * SEGH_TH + ly - 1;
-    const long b = blockIdx.z;
-    const bool inside = ox >= 0 && ox < p.Wd && oy >= 0 && oy < p.H;
-    float v[SEGH_IMAX];
-    ACH_UNROLL
-    for (int j = 0; j < SEGH_IMAX; ++j) v[j] = 0.f;
-    if (inside) {
-        const T* f = static_cast<const T*>(p.F) + ((b * p.H + oy) * long(p.Wd) + ox) * p.ldf;
-        ACH_UNROLL
-        for (int j = 0; j < SEGH_IMAX; ++j) v[j] = j < p.init ? p.bp[j] : 0.f;
-        for (int c = 0; c < p.Cin; c += 4) {
-            float x[4];
-            Store<T>::ld4(f + c, x);
-            ACH_UNROLL
-            for (int j = 0; j < SEGH_IMAX; ++j)
-                if (j < p.init) {
-                    const float* w = p.Wp + j * p.Cin + c;
-                    v[j] += w[0] * x[0] + w[1] * x[1] + w[2] * x[2] + w[3] * x[3];
-                }
-        }
-        ACH_UNROLL
-        for (int j = 0; j < SEGH_IMAX; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
-    }
-    ACH_UNROLL
-    for (int j = 0; j < SEGH_IMAX; ++j) x1[threadIdx.x][j] = v[j];
-    __syncthreads();
-    if (!inside || lx == 0 || lx == HW_ - 1 || ly == 0 || ly == SEGH_TH + 1) return;
-    T* out = static_cast<T*>(p.out) + b * p.oup * long(p.H) * p.Wd + long(oy) * p.Wd + ox;
-    const long HW = long(p.H) * p.Wd;
-    for (int j = 0; j < p.init && j < p.oup; ++j) Store<T>::st(out + j * HW, v[j]);
-    for (int j = 0; j < p.nch; ++j) {
-        float a = p.bdw[j];
-        ACH_UNROLL
-        for (int k = 0; k < 9; ++k) a += x1[(ly - 1 + k / 3) * HW_ + lx - 1 + k % 3][j] * p.Wdw[k * p.nch + j];
-        Store<T>::st(out + (p.init + j) * HW, a > 0.f ? a : 0.f);
     }
 }
 
@@ -666,25 +586,30 @@ __global__ __launch_bounds__(256) void upghost_head_kernel(const UpGhostHeadPara
         const int c = (tid & 3) * 4, slot = tid >> 2;
         const float sy = H > 1 ? float(p.h - 1) / float(H - 1) : 0.f, sx = Wd > 1 ? float(p.w - 1) / float(Wd - 1) : 0.f;
         const T* Tq = static_cast<const T*>(p.Tq) + b * p.h * long(p.w) * p.ldt + c;
-        for (int pos = slot; pos < H2 * W2; pos += 64) {
+        // every round issues its four corner loads unconditionally from clamped coordinates, so the loads of all rounds can
+        // be in flight together (positions outside the map / past the tile are zeroed after the fact)
+        constexpr int ROUNDS = (H2 * W2 + 63) / 64;
+        ACH_UNROLL
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int pos_raw = slot + r * 64;
+            const int pos = pos_raw < H2 * W2 ? pos_raw : H2 * W2 - 1;
             const int oy = by + pos / W2 - 2, ox = bx + pos % W2 - 2;
-            float v[4] = {0.f, 0.f, 0.f, 0.f};
-            if (oy >= 0 && oy < H && ox >= 0 && ox < Wd) {
-                const float fy = sy * float(oy), fx = sx * float(ox);
-                int y0 = int(fy), x0 = int(fx);
-                if (y0 > p.h - 1) y0 = p.h - 1;
-                if (x0 > p.w - 1) x0 = p.w - 1;
-                const int y1 = y0 + (y0 < p.h - 1 ? 1 : 0), x1i = x0 + (x0 < p.w - 1 ? 1 : 0);
-                const float ly = fy - float(y0), lx = fx - float(x0), hy = 1.f - ly, hx = 1.f - lx;
-                float a[4], bq[4], cc[4], d[4];
-                Store<T>::ld4(Tq + (long(y0) * p.w + x0) * p.ldt, a);
-                Store<T>::ld4(Tq + (long(y0) * p.w + x1i) * p.ldt, bq);
-                Store<T>::ld4(Tq + (long(y1) * p.w + x0) * p.ldt, cc);
-                Store<T>::ld4(Tq + (long(y1) * p.w + x1i) * p.ldt, d);
-                ACH_UNROLL
-                for (int i = 0; i < 4; ++i) { const float t = hy * (hx * a[i] + lx * bq[i]) + ly * (hx * cc[i] + lx * d[i]); v[i] = t > 0.f ? t : 0.f; }
-            }
-            *reinterpret_cast<float4*>(x1s + pos * CS + c) = make_float4(v[0], v[1], v[2], v[3]);
+            const bool ok = oy >= 0 && oy < H && ox >= 0 && ox < Wd;
+            const int cy = oy < 0 ? 0 : (oy >= H ? H - 1 : oy), cx = ox < 0 ? 0 : (ox >= Wd ? Wd - 1 : ox);
+            const float fy = sy * float(cy), fx = sx * float(cx);
+            int y0 = int(fy), x0 = int(fx);
+            if (y0 > p.h - 1) y0 = p.h - 1;
+            if (x0 > p.w - 1) x0 = p.w - 1;
+            const int y1 = y0 + (y0 < p.h - 1 ? 1 : 0), x1i = x0 + (x0 < p.w - 1 ? 1 : 0);
+            const float ly = fy - float(y0), lx = fx - float(x0), hy = 1.f - ly, hx = 1.f - lx;
+            float a[4], bq[4], cc[4], d[4], v[4];
+            Store<T>::ld4(Tq + (long(y0) * p.w + x0) * p.ldt, a);
+            Store<T>::ld4(Tq + (long(y0) * p.w + x1i) * p.ldt, bq);
+            Store<T>::ld4(Tq + (long(y1) * p.w + x0) * p.ldt, cc);
+            Store<T>::ld4(Tq + (long(y1) * p.w + x1i) * p.ldt, d);
+            ACH_UNROLL
+            for (int i = 0; i < 4; ++i) { const float t = hy * (hx * a[i] + lx * bq[i]) + ly * (hx * cc[i] + lx * d[i]); v[i] = (ok && t > 0.f) ? t : 0.f; }
+            if (pos_raw < H2 * W2) *reinterpret_cast<float4*>(x1s + pos * CS + c) = make_float4(v[0], v[1], v[2], v[3]);
         }
     }
     __syncthreads();

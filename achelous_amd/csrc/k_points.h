@@ -87,3 +87,4 @@ __global__ void log_softmax_kernel(const LsmParams p) {
 }
 
 }  // namespace ach
+

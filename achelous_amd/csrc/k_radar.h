@@ -45,18 +45,19 @@ __global__ __launch_bounds__(256) void avgpool3x3_kernel(const PoolParams p) {
     const long b = pix / p.H;
     const T* X = static_cast<const T*>(p.X);
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    // nine unconditional loads from clamped addresses (all in flight together); taps outside the map are zeroed afterwards
+    float v[9][4];
     ACH_UNROLL
-    for (int dy = -1; dy <= 1; ++dy) {
-        const int iy = y + dy;
-        if (iy < 0 || iy >= p.H) continue;
-        ACH_UNROLL
-        for (int dx = -1; dx <= 1; ++dx) {
-            const int ix = x + dx;
-            if (ix < 0 || ix >= p.Wd) continue;
-            float v[4];
-            Store<T>::ld4(X + ((b * p.H + iy) * p.Wd + ix) * p.ldx + c, v);
-            acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
-        }
+    for (int k = 0; k < 9; ++k) {
+        const int iy = y + k / 3 - 1, ix = x + k % 3 - 1;
+        const int cy = iy < 0 ? 0 : (iy >= p.H ? p.H - 1 : iy), cx = ix < 0 ? 0 : (ix >= p.Wd ? p.Wd - 1 : ix);
+        Store<T>::ld4(X + ((b * p.H + cy) * p.Wd + cx) * p.ldx + c, v[k]);
+    }
+    ACH_UNROLL
+    for (int k = 0; k < 9; ++k) {
+        const int iy = y + k / 3 - 1, ix = x + k % 3 - 1;
+        const float ok = (iy >= 0 && iy < p.H && ix >= 0 && ix < p.Wd) ? 1.f : 0.f;
+        acc[0] += v[k][0] * ok; acc[1] += v[k][1] * ok; acc[2] += v[k][2] * ok; acc[3] += v[k][3] * ok;
     }
     ACH_UNROLL
     for (int i = 0; i < 4; ++i) acc[i] *= (1.0f / 9.0f);
@@ -92,7 +93,7 @@ struct DeformParams {
     const void* om; long ldo;         // [pixels, 27]: 18 offsets (dy,dx per tap) + 9 modulator logits
     const void* res; long ldr;        // block input (residual)
     void* Y; long ldy;                // fused: relu(Wf . col + bf) + res ; sample: the columns [pixels, 9*Cp]
-    const float* Wf;                  // fused: [C][9][CP] folded (weight_conv1 . BN . regular_conv)
+    const float* Wf;                  // fused: [C][9][Cp] folded (weight_conv1 . BN . regular_conv)
     const float* bf;                  // fused: [C]
     int B, H, Wd, Cp;
 };
@@ -129,11 +130,11 @@ __global__ __launch_bounds__(256) void deform_fused_kernel(const DeformParams p)
             ACH_UNROLL
             for (int i = 0; i < 4; ++i) v[c + i] = t.w00 * a[i] + t.w01 * bq[i] + t.w10 * cc[i] + t.w11 * d[i];
         }
-        const float* w = p.Wf + k * CP;
+        const float* w = p.Wf + k * p.Cp;                         // host layout [C][9][Cp], Cp = channel stride of the buffers
         ACH_UNROLL
         for (int co = 0; co < C; ++co)
             ACH_UNROLL
-            for (int c = 0; c < C; ++c) acc[co] += w[co * 9 * CP + c] * v[c];
+            for (int c = 0; c < C; ++c) acc[co] += w[co * 9 * p.Cp + c] * v[c];
     }
     float outv[CP];
     ACH_UNROLL

@@ -77,7 +77,9 @@ const char* ach_last_error(const ach_handle* h);
 int ach_load_weights(ach_handle* h, const ach_tensor_desc* tensors, size_t n);
 
 /* Options, set before ach_plan.  "full_taps" = 1: also write to HBM the SURVEY §8(a) boundaries that production plans keep
- * on-chip (the 32-channel full-resolution decoder tensors), so that parity tests can read them back. */
+ * on-chip (the 32-channel full-resolution decoder tensors), so that parity tests can read them back.
+ * "streams" = 0: launch everything on the caller's stream (default 1: the independent radar and point branches run on two
+ * engine-owned side streams, forked from / joined into the caller's stream with events). */
 int ach_set_option(ach_handle* h, const char* key, int32_t value);
 
 /* Builds the launch plan and the activation arena for batch size B (re-plan to change B). */
