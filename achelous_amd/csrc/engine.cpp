@@ -918,6 +918,11 @@ public:
     }
 
     // ------------------------------------------------------------------------------------------ head (a17)
+    // The cls and reg branches (2 x [dw5x5 -> pw1x1+BN+ReLU]) read the same stem output and never interact, so they are run as
+    // ONE 128-channel branch: depthwise filters of both banks side by side (the first over the shared 64-channel input), the
+    // pointwise convs as block-diagonal 128x128 GEMMs, and the three prediction convs as one 12 x 128 GEMM scattered straight
+    // into the NCHW output map [reg 4 | obj 1 | cls num_det].  6 launches per level instead of 11, twice the work per launch on
+    // the small maps where the head is latency-bound.
     void head(A p[3]) {                                                          // decouplehead.py:58-103
         const int NC5 = 5 + cfg.num_det;
         for (int k = 0; k < 3; ++k) {
@@ -926,32 +931,46 @@ public:
             const int HW = x.H * x.W;
             Lin ls = conv_bn("det_head.stems." + ks + ".conv", "det_head.stems." + ks + ".bn", 1e-3);
             const int base = ls.N;
-            A st = alloc(x.B, x.H, x.W, base);
-            { GemmOpt o; o.act = ACT_RELU; gemm("det_head.stems." + ks, x, pack(ls), st, o); }
-            A feat[2];
-            const char* br[2] = {"cls_convs", "reg_convs"};
-            for (int b = 0; b < 2; ++b) {
-                A cur = st;
-                for (int j = 0; j < 2; ++j) {
-                    const std::string c = std::string("det_head.") + br[b] + "." + ks + "." + std::to_string(j);
-                    A d = alloc(x.B, x.H, x.W, base);
-                    dwconv(c + ".dconv", cur, nullptr, c + ".conv.dconv.weight", "", "", 0, 5, 1, ACT_NONE, d);
-                    A y = alloc(x.B, x.H, x.W, base);
-                    GemmOpt o; o.act = ACT_RELU;
-                    gemm(c + ".pconv", d, pack(conv_bn(c + ".conv.pconv", c + ".bn", 1e-3)), y, o);
-                    cur = y;
-                }
-                feat[b] = cur;
+            A cur = alloc(x.B, x.H, x.W, base);
+            { GemmOpt o; o.act = ACT_RELU; gemm("det_head.stems." + ks, x, pack(ls), cur, o); }
+            for (int j = 0; j < 2; ++j) {
+                const std::string js = std::to_string(j);
+                const std::string c = "det_head.cls_convs." + ks + "." + js, r = "det_head.reg_convs." + ks + "." + js;
+                // depthwise 5x5, both banks: out[0:base] = cls filters, out[base:2base] = reg filters
+                const HostTensor& wc = W(c + ".conv.dconv.weight"); const HostTensor& wr = W(r + ".conv.dconv.weight");
+                if (wc.numel() != long(base) * 25 || wr.numel() != long(base) * 25) throw AchError{ACH_ERR_MISSING_KEY, "head depthwise shape"};
+                std::vector<float> wt(size_t(25) * 2 * base), bias(size_t(2) * base, 0.f);
+                for (int ch = 0; ch < base; ++ch)
+                    for (int t = 0; t < 25; ++t) { wt[size_t(t) * 2 * base + ch] = wc.data[size_t(ch) * 25 + t]; wt[size_t(t) * 2 * base + base + ch] = wr.data[size_t(ch) * 25 + t]; }
+                A d = alloc(x.B, x.H, x.W, 2 * base);
+                DwParams dp;
+                std::memset(&dp, 0, sizeof(dp));
+                dp.X = cur.p; dp.ldx = cur.ld; dp.W = up_f32(wt); dp.bias = up_f32(bias); dp.Y = d.p; dp.ldy = d.ld;
+                dp.B = x.B; dp.H = x.H; dp.Wd = x.W; dp.C = 2 * base; dp.Ho = x.H; dp.Wo = x.W; dp.stride = 1; dp.act = ACT_NONE;
+                dp.cin_mod = (j == 0) ? base : 0;
+                add_op("det_head.convs." + ks + "." + js + ".dconv", [dp](hipStream_t s) { launch_dwconv<T>(dp, 5, s); },
+                       double(cur.rows()) * cur.C * sizeof(T) + double(d.rows()) * d.C * sizeof(T));
+                // pointwise, block diagonal
+                Lin lc = conv_bn(c + ".conv.pconv", c + ".bn", 1e-3), lr = conv_bn(r + ".conv.pconv", r + ".bn", 1e-3);
+                Lin lb; lb.N = 2 * base; lb.K = 2 * base; lb.w.assign(size_t(lb.N) * lb.K, 0.f); lb.b = lc.b; lb.b.insert(lb.b.end(), lr.b.begin(), lr.b.end());
+                for (int n = 0; n < base; ++n)
+                    for (int kk = 0; kk < base; ++kk) { lb.w[size_t(n) * lb.K + kk] = lc.w[size_t(n) * base + kk]; lb.w[size_t(base + n) * lb.K + base + kk] = lr.w[size_t(n) * base + kk]; }
+                A y = alloc(x.B, x.H, x.W, 2 * base);
+                GemmOpt o; o.act = ACT_RELU;
+                gemm("det_head.convs." + ks + "." + js + ".pconv", d, pack(lb), y, o);
+                cur = y;
             }
-            // predictions straight into the NCHW output map: [reg 4 | obj 1 | cls num_det]
-            Lin lr = lin("det_head.reg_preds." + ks + ".weight", "det_head.reg_preds." + ks + ".bias");
-            Lin lo = lin("det_head.obj_preds." + ks + ".weight", "det_head.obj_preds." + ks + ".bias");
-            Lin lro; lro.N = 5; lro.K = lr.K; lro.w = lr.w; lro.w.insert(lro.w.end(), lo.w.begin(), lo.w.end()); lro.b = lr.b; lro.b.push_back(lo.b[0]);
+            // predictions: rows [reg 4 | obj 1] read the reg half, rows [cls] read the cls half
+            Lin lreg = lin("det_head.reg_preds." + ks + ".weight", "det_head.reg_preds." + ks + ".bias");
+            Lin lobj = lin("det_head.obj_preds." + ks + ".weight", "det_head.obj_preds." + ks + ".bias");
+            Lin lcls = lin("det_head.cls_preds." + ks + ".weight", "det_head.cls_preds." + ks + ".bias");
+            Lin lp; lp.N = NC5; lp.K = 2 * base; lp.w.assign(size_t(NC5) * lp.K, 0.f); lp.b.assign(size_t(NC5), 0.f);
+            for (int n = 0; n < 4; ++n) { lp.b[n] = lreg.b[n]; for (int kk = 0; kk < base; ++kk) lp.w[size_t(n) * lp.K + base + kk] = lreg.w[size_t(n) * base + kk]; }
+            lp.b[4] = lobj.b[0];
+            for (int kk = 0; kk < base; ++kk) lp.w[size_t(4) * lp.K + base + kk] = lobj.w[kk];
+            for (int n = 0; n < cfg.num_det; ++n) { lp.b[5 + n] = lcls.b[n]; for (int kk = 0; kk < base; ++kk) lp.w[size_t(5 + n) * lp.K + kk] = lcls.w[size_t(n) * base + kk]; }
             GemmOpt o1; o1.ydyn = &io.det[k]; o1.out_nchw = 1; o1.HW = HW; o1.Ctot = NC5; o1.coff = 0;
-            gemm("det_head.regobj_preds." + ks, feat[1].p, feat[1].ld, feat[1].rows(), pack(lro), nullptr, 0, o1);
-            GemmOpt o2 = o1; o2.coff = 5;
-            gemm("det_head.cls_preds." + ks, feat[0].p, feat[0].ld, feat[0].rows(),
-                 pack(lin("det_head.cls_preds." + ks + ".weight", "det_head.cls_preds." + ks + ".bias")), nullptr, 0, o2);
+            gemm("det_head.preds." + ks, cur.p, cur.ld, cur.rows(), pack(lp), nullptr, 0, o1);
         }
     }
 

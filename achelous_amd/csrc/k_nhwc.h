@@ -15,6 +15,7 @@ struct DwParams {
     const float* bias;              // [C] fp32
     void* Y; long ldy;              // output [B,Ho,Wo,(C)]
     int B, H, Wd, C, Ho, Wo, stride, act;
+    int cin_mod;                    // > 0: output channel c reads input channel c % cin_mod (two filter banks over one input)
 };
 
 // stride-1 kernel: one thread = 4 channels x a strip of OW consecutive output pixels of one row.  A row of the receptive
@@ -33,8 +34,9 @@ __global__ __launch_bounds__(256) void dwconv_strip_kernel(const DwParams p) {
     const int oy = int(r % p.Ho);
     const long b = r / p.Ho;
     constexpr int PAD = KS / 2;
-    const T* X = static_cast<const T*>(p.X) + b * p.H * long(p.Wd) * p.ldx + c;
-    const T* X2 = p.X2 ? static_cast<const T*>(p.X2) + b * p.H * long(p.Wd) * p.ldx2 + c : nullptr;
+    const int ci = p.cin_mod > 0 ? c % p.cin_mod : c;
+    const T* X = static_cast<const T*>(p.X) + b * p.H * long(p.Wd) * p.ldx + ci;
+    const T* X2 = p.X2 ? static_cast<const T*>(p.X2) + b * p.H * long(p.Wd) * p.ldx2 + ci : nullptr;
     float acc[OW][4];
     {
         const float4 bb = *reinterpret_cast<const float4*>(p.bias + c);
