@@ -216,6 +216,12 @@ __device__ __forceinline__ float apply_act(float x, int act) {
     }
 }
 
+// XCD-aware workgroup order for kernels whose neighbouring workgroups share input lines (3x3 halos, bilinear corners):
+// workgroup w is observed to run on XCD w % 8, each XCD with its own L2.  Re-numbering w -> (w % 8) * (n / 8) + w / 8 hands
+// every XCD one contiguous run of tiles, so shared lines are fetched from HBM once instead of once per XCD.  Speed only:
+// results never depend on placement.  (Measured with rocprofv3 FETCH_SIZE: 2.0x -> 1.0x algorithmic bytes on the decoder kernel.)
+__device__ __forceinline__ unsigned xcd_block(unsigned w, unsigned n) { return (n % 8 == 0) ? (w % 8) * (n / 8) + w / 8 : w; }
+
 __host__ __device__ __forceinline__ int cdiv(int a, int b) { return (a + b - 1) / b; }
 __host__ __device__ __forceinline__ long cdivl(long a, long b) { return (a + b - 1) / b; }
 

@@ -71,6 +71,7 @@ int ach_set_option(ach_handle* h, const char* key, int32_t value) {
         if (!key) throw ach::AchError{ACH_ERR_INVALID, "null option"};
         if (std::string(key) == "full_taps") h->eng->full_taps = value != 0;
         else if (std::string(key) == "streams") h->eng->multi_stream = value != 0;
+        else if (std::string(key) == "graph") h->eng->use_graph = value != 0;
         else throw ach::AchError{ACH_ERR_INVALID, std::string("unknown option: ") + key};
     });
 }
@@ -111,6 +112,31 @@ int ach_nms(ach_handle* h, int32_t batch, const float* decoded, float conf_thres
         if (batch <= 0 || max_det <= 0 || !decoded || !out_rows || !out_idx || !out_count || !workspace)
             throw ach::AchError{ACH_ERR_INVALID, "bad nms arguments"};
         h->eng->nms(batch, decoded, conf_thres, nms_thres, max_det, out_rows, out_idx, out_count, workspace, static_cast<hipStream_t>(stream));
+    });
+}
+
+int ach_preprocess_radar(ach_handle* h, int32_t batch, int32_t channels, const float* in, void* out, void* stream) {
+    return guarded(h, [&] {
+        if (batch <= 0 || channels <= 0 || !in || !out) throw ach::AchError{ACH_ERR_INVALID, "bad preprocess_radar arguments"};
+        h->eng->preprocess_radar(batch, channels, in, out, static_cast<hipStream_t>(stream));
+    });
+}
+int ach_normalize_points(ach_handle* h, int32_t batch, int32_t n, int32_t d, const float* in, void* out, void* stream) {
+    return guarded(h, [&] {
+        if (batch <= 0 || n <= 0 || d <= 0 || !in || !out) throw ach::AchError{ACH_ERR_INVALID, "bad normalize_points arguments"};
+        h->eng->normalize_points(batch, n, d, in, out, static_cast<hipStream_t>(stream));
+    });
+}
+int ach_preprocess_image(ach_handle* h, int32_t batch, const uint8_t* in, void* out, void* stream) {
+    return guarded(h, [&] {
+        if (batch <= 0 || !in || !out) throw ach::AchError{ACH_ERR_INVALID, "bad preprocess_image arguments"};
+        h->eng->preprocess_image(batch, in, out, static_cast<hipStream_t>(stream));
+    });
+}
+int ach_seg_argmax(ach_handle* h, int32_t batch, int32_t channels, const void* seg, uint8_t* out, void* stream) {
+    return guarded(h, [&] {
+        if (batch <= 0 || channels <= 0 || channels > 255 || !seg || !out) throw ach::AchError{ACH_ERR_INVALID, "bad seg_argmax arguments"};
+        h->eng->seg_argmax(batch, channels, seg, out, static_cast<hipStream_t>(stream));
     });
 }
 

@@ -17,6 +17,7 @@
 #include "k_mvit.h"
 #include "k_nhwc.h"
 #include "k_points.h"
+#include "k_prepost.h"
 #include "k_radar.h"
 #include "k_xca.h"
 
@@ -34,6 +35,11 @@ static inline long round_up(long v, long m) { return (v + m - 1) / m * m; }
 EngineBase::~EngineBase() {
     if (warena) (void)hipFree(warena);
     if (aarena) (void)hipFree(aarena);
+    if (prepost_scratch) (void)hipFree(prepost_scratch);
+#if !defined(ACH_HOSTEMU)
+    drop_graphs();
+    if (capture_stream) (void)hipStreamDestroy(capture_stream);
+#endif
     if (streams_ready) {
         for (int k = 0; k < kSideStreams; ++k) { (void)hipStreamDestroy(side_stream[k]); (void)hipEventDestroy(ev_end[k]); }
         (void)hipEventDestroy(ev_fork);
@@ -82,6 +88,9 @@ float* EngineBase::up_f32(const std::vector<float>& v) {
     return d;
 }
 void EngineBase::reset_plan() {
+#if !defined(ACH_HOSTEMU)
+    drop_graphs();
+#endif
     probe_op = -1;
     cur_stream = 0; pending_wait = -1;
     ops.clear(); taps.clear(); tap_order.clear();
@@ -100,7 +109,7 @@ void EngineBase::ensure_streams() {
 // The radar and point branches do not depend on the image path until the fusion stage, and most of their kernels are
 // latency-bound on small maps: they run on two engine-owned side streams, forked from and joined back into the caller's
 // stream with events, so their launches fill the CUs the image path leaves idle.
-void EngineBase::run(hipStream_t s) {
+void EngineBase::run_eager(hipStream_t s) {
     bool used[kSideStreams] = {false, false};
     const bool multi = multi_stream;
     if (multi) {
@@ -128,6 +137,48 @@ void EngineBase::run(hipStream_t s) {
         for (int k = 0; k < kSideStreams; ++k)
             if (used[k]) { (void)hipEventRecord(ev_end[k], side_stream[k]); (void)hipStreamWaitEvent(s, ev_end[k], 0); }
 }
+#if defined(ACH_HOSTEMU)
+void EngineBase::run(hipStream_t s) { run_eager(s); }
+#else
+static bool same_io(const IoPtrs& a, const IoPtrs& b) {
+    return a.image == b.image && a.radar == b.radar && a.points == b.points && a.det[0] == b.det[0] && a.det[1] == b.det[1] &&
+           a.det[2] == b.det[2] && a.se == b.se && a.lane == b.lane && a.pc == b.pc;
+}
+void EngineBase::drop_graphs() {
+    for (auto& g : graphs) (void)hipGraphExecDestroy(g.exec);
+    graphs.clear();
+}
+// The plan is ~200 launches; at small batch the forward is bound by host launch cost, not by the kernels.  The whole plan
+// (including the fork / join of the side streams) is therefore captured once per distinct set of I/O pointers into a hipGraph
+// and replayed with one hipGraphLaunch on the caller's stream.  Capture happens on an engine-owned stream (the caller's may be
+// the legacy default stream, which cannot be captured).  Any failure falls back to eager launches of the SAME kernels.
+void EngineBase::run(hipStream_t s) {
+    if (!use_graph || graph_failed || probe_op >= 0) { run_eager(s); return; }
+    for (auto& g : graphs)
+        if (same_io(g.io, io)) {
+            g.stamp = ++graph_clock;
+            if (hipGraphLaunch(g.exec, s) == hipSuccess) return;
+            graph_failed = true; run_eager(s); return;
+        }
+    if (!capture_stream && hipStreamCreateWithFlags(&capture_stream, hipStreamNonBlocking) != hipSuccess) { graph_failed = true; run_eager(s); return; }
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    if (hipStreamBeginCapture(capture_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { graph_failed = true; run_eager(s); return; }
+    run_eager(capture_stream);
+    if (hipStreamEndCapture(capture_stream, &graph) != hipSuccess || !graph) { (void)hipGetLastError(); graph_failed = true; run_eager(s); return; }
+    const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ie != hipSuccess || !exec) { (void)hipGetLastError(); graph_failed = true; run_eager(s); return; }
+    if (graphs.size() >= 8) {                                  // evict the least recently used
+        size_t lru = 0;
+        for (size_t i = 1; i < graphs.size(); ++i) if (graphs[i].stamp < graphs[lru].stamp) lru = i;
+        (void)hipGraphExecDestroy(graphs[lru].exec);
+        graphs.erase(graphs.begin() + long(lru));
+    }
+    graphs.push_back(GraphEntry{io, exec, ++graph_clock});
+    if (hipGraphLaunch(exec, s) != hipSuccess) { graph_failed = true; run_eager(s); }
+}
+#endif
 void EngineBase::run_profiled(hipStream_t s, float* op_ms, size_t cap) {
     if (cap < ops.size()) throw AchError{ACH_ERR_INVALID, "profile buffer too small"};
     std::vector<hipEvent_t> ev(ops.size() + 1);
@@ -704,7 +755,7 @@ public:
         for (int c = 0; c < Cg; ++c) for (int k = 0; k < 9; ++k) wt[size_t(k) * Cg + c] = w.data[size_t(c) * 9 + k] * sc[c];
         A y = alloc(x.B, 2 * x.H, 2 * x.W, cout);
         UpGhostParams p{t.p, t.ld, y.p, y.ld, up_f32(wt), up_f32(sh), x.B, x.H, x.W, Cg};
-        const dim3 grid(unsigned(cdiv(2 * x.W, UPG_TS)), unsigned(cdiv(2 * x.H, UPG_TS)), unsigned(x.B)), block(unsigned(16 * Cg));
+        const dim3 grid(unsigned(cdiv(2 * x.W, UPG_TS)) * unsigned(cdiv(2 * x.H, UPG_TS)) * unsigned(x.B)), block(unsigned(16 * Cg));
         const double bytes = double(t.rows()) * Cg * sizeof(T) + double(y.rows()) * cout * sizeof(T);
         if (Cg == 16) add_op(ghost_pfx + ".upghost", [p, grid, block](hipStream_t s) { ACH_LAUNCH((upghost_kernel<T, 16>), grid, block, s, p); }, bytes);
         else if (Cg == 24) add_op(ghost_pfx + ".upghost", [p, grid, block](hipStream_t s) { ACH_LAUNCH((upghost_kernel<T, 24>), grid, block, s, p); }, bytes);
@@ -737,7 +788,7 @@ public:
         if (full_taps) { f = alloc(x.B, 2 * x.H, 2 * x.W, cout); tap(tap_name, f); }
         UpGhostHeadParams p{t.p, t.ld, full_taps ? f.p : nullptr, full_taps ? f.ld : 0, nullptr, up_f32(wl), up_f32(bl), up_f32(lh.w), up_f32(lh.b),
                             up_f32(wh2), up_f32(bh2), x.B, x.H, x.W, init, nch, oup};
-        const dim3 grid(unsigned(cdiv(2 * x.W, UGH_TW)), unsigned(cdiv(2 * x.H, UGH_TH)), unsigned(x.B)), block(256);
+        const dim3 grid(unsigned(cdiv(2 * x.W, UGH_TW)) * unsigned(cdiv(2 * x.H, UGH_TH)) * unsigned(x.B)), block(256);
         const double bytes = double(t.rows()) * Cg * sizeof(T) + 4.0 * double(t.rows()) * oup * sizeof(T);
         add_op(head_pfx + ".upghost_head", [p, grid, block, out](hipStream_t s) mutable { p.out = *out; ACH_LAUNCH(upghost_head_kernel<T>, grid, block, s, p); }, bytes);
     }
@@ -1090,6 +1141,34 @@ public:
         build();
         ACH_HIP_CHECK(hipMemset(aarena, 0, aarena_used));      // channel padding lanes stay zero for the lifetime of the plan
         ACH_HIP_CHECK(hipDeviceSynchronize());
+    }
+
+    // ---- pre / post-processing
+    void preprocess_radar(int B, int C, const float* in, void* out, hipStream_t s) override {
+        const int S = 64;
+        const size_t need = size_t(B) * S * 2 * sizeof(float);
+        if (need > prepost_scratch_bytes) {
+            if (prepost_scratch) (void)hipFree(prepost_scratch);
+            ACH_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&prepost_scratch), need));
+            prepost_scratch_bytes = need;
+        }
+        const long per = long(C) * cfg.resolution * cfg.resolution;
+        MinMaxParams pm{in, prepost_scratch, per, S};
+        ACH_LAUNCH(frame_minmax_kernel, dim3(unsigned(B), unsigned(S)), dim3(256), s, pm);
+        RadarScaleParams ps{in, prepost_scratch, out, per, S, B};
+        ACH_LAUNCH(radar_scale_kernel<T>, dim3(unsigned(cdivl(per * B, 256))), dim3(256), s, ps);
+    }
+    void normalize_points(int B, int N, int D, const float* in, void* out, hipStream_t s) override {
+        PointNormParams pp{in, out, B, N, D};
+        ACH_LAUNCH(point_norm_kernel<T>, dim3(unsigned(B * D)), dim3(256), s, pp);
+    }
+    void preprocess_image(int B, const unsigned char* in, void* out, hipStream_t s) override {
+        ImagePrepParams pp{in, out, B, cfg.resolution, cfg.resolution};
+        ACH_LAUNCH(image_prep_kernel<T>, dim3(unsigned(cdivl(long(B) * cfg.resolution * cfg.resolution, 256))), dim3(256), s, pp);
+    }
+    void seg_argmax(int B, int C, const void* seg, unsigned char* out, hipStream_t s) override {
+        SegArgmaxParams pp{seg, out, B, C, long(cfg.resolution) * cfg.resolution};
+        ACH_LAUNCH(seg_argmax_kernel<T>, dim3(unsigned(cdivl(pp.HW * B, 256))), dim3(256), s, pp);
     }
 
     float bench_gemm(int M, int K, int N, int act, int ln, int residual, int Pforce, int iters, hipStream_t s) override {

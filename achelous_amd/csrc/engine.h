@@ -60,6 +60,7 @@ public:
     char* warena = nullptr; size_t warena_cap = 0, warena_used = 0;      // packed weights / constants
     char* aarena = nullptr; size_t aarena_cap = 0, aarena_used = 0;      // activations
     bool measuring = false;
+    bool use_graph = true;            // option "graph": replay the plan as a hipGraph (captured per distinct set of I/O pointers)
     bool multi_stream = true;         // option "streams": run the independent radar / point branches on side streams
     bool full_taps = false;           // option "full_taps": also materialise boundaries that production plans keep on-chip
     int batch = 0;
@@ -70,7 +71,8 @@ public:
 
     void load(const ach_tensor_desc* t, size_t n);
     virtual void plan(int B) = 0;
-    void run(hipStream_t s);
+    void run(hipStream_t s);            // graph replay when possible, else eager launches
+    void run_eager(hipStream_t s);
     void run_profiled(hipStream_t s, float* op_ms, size_t cap);
     // live probe: HIP events around ONE op of the plan on every run() (bench.py's roofline leg)
     void set_probe(int op_index);
@@ -82,6 +84,12 @@ public:
     int num_anchors() const;
     void read_tap(const std::string& name, float* out, size_t cap);
     std::vector<long> tap_shape(const std::string& name) const;
+    // pre / post-processing around the forward (k_prepost.h)
+    virtual void preprocess_radar(int B, int C, const float* in, void* out, hipStream_t s) = 0;
+    virtual void normalize_points(int B, int N, int D, const float* in, void* out, hipStream_t s) = 0;
+    virtual void preprocess_image(int B, const unsigned char* in, void* out, hipStream_t s) = 0;
+    virtual void seg_argmax(int B, int C, const void* seg, unsigned char* out, hipStream_t s) = 0;
+    float* prepost_scratch = nullptr; size_t prepost_scratch_bytes = 0;
     // micro-benchmark hook: time the MFMA GEMM kernel alone on scratch buffers (ms per launch)
     virtual float bench_gemm(int M, int K, int N, int act, int ln, int residual, int P, int iters, hipStream_t s) = 0;
 
@@ -108,6 +116,14 @@ protected:
     hipEvent_t ev_fork = nullptr, ev_join[kJoinEvents] = {nullptr, nullptr, nullptr, nullptr}, ev_end[kSideStreams] = {nullptr, nullptr};
     bool streams_ready = false;
     void ensure_streams();
+#if !defined(ACH_HOSTEMU)
+    struct GraphEntry { IoPtrs io; hipGraphExec_t exec; unsigned long stamp; };
+    std::vector<GraphEntry> graphs;
+    hipStream_t capture_stream = nullptr;
+    unsigned long graph_clock = 0;
+    bool graph_failed = false;
+    void drop_graphs();
+#endif
     int probe_op = -1;
     static constexpr int kProbeEvents = 512;
     std::vector<hipEvent_t> probe_ev0, probe_ev1;

@@ -74,7 +74,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int px = lane & 15, g = lane >> 4;
     const int grp = blockIdx.y;
-    const long row0 = long(blockIdx.x) * (64 * P) + wave * (16 * P);   // first row (within the group) of this wave
+    // implicit-GEMM convs re-read halo rows across row tiles: XCD-aware tile order keeps those re-reads inside one L2
+    const unsigned rt = p.conv_k > 1 ? xcd_block(blockIdx.x, gridDim.x) : blockIdx.x;
+    const long row0 = long(rt) * (64 * P) + wave * (16 * P);           // first row (within the group) of this wave
     const T* X = static_cast<const T*>(p.X);
     const uint4* Wf = reinterpret_cast<const uint4*>(static_cast<const T*>(p.W) + long(grp) * p.w_group_stride);
     const float* bias = p.bias + long(grp) * p.bias_group_stride;

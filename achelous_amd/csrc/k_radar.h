@@ -36,7 +36,7 @@ template <class T>
 __global__ __launch_bounds__(256) void avgpool3x3_kernel(const PoolParams p) {
     const int cq = (p.C + 3) >> 2;
     const long total = long(p.B) * p.H * p.Wd * cq;
-    const long idx = long(blockIdx.x) * blockDim.x + threadIdx.x;
+    const long idx = long(xcd_block(blockIdx.x, gridDim.x)) * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const int c = int(idx % cq) * 4;
     long pix = idx / cq;
@@ -102,7 +102,7 @@ struct DeformParams {
 template <class T, int C, int CP>
 __global__ __launch_bounds__(256) void deform_fused_kernel(const DeformParams p) {
     const long total = long(p.B) * p.H * p.Wd;
-    const long idx = long(blockIdx.x) * blockDim.x + threadIdx.x;
+    const long idx = long(xcd_block(blockIdx.x, gridDim.x)) * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const int x = int(idx % p.Wd);
     const int y = int((idx / p.Wd) % p.H);
@@ -158,7 +158,7 @@ template <class T>
 __global__ __launch_bounds__(256) void deform_sample_kernel(const DeformParams p) {
     const int cq = p.Cp >> 2;
     const long total = long(p.B) * p.H * p.Wd * 9 * cq;
-    const long idx = long(blockIdx.x) * blockDim.x + threadIdx.x;
+    const long idx = long(xcd_block(blockIdx.x, gridDim.x)) * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const int c = int(idx % cq) * 4;
     long r = idx / cq;

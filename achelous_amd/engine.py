@@ -34,7 +34,8 @@ class NativeLibrary:
     SYMBOLS = ('ach_create', 'ach_destroy', 'ach_last_error', 'ach_load_weights', 'ach_plan', 'ach_arena_bytes',
                'ach_forward', 'ach_decode', 'ach_nms_workspace_bytes', 'ach_nms', 'ach_tap_count', 'ach_tap_name',
                'ach_tap_shape', 'ach_read_tap', 'ach_plan_launches', 'ach_op_name', 'ach_op_bytes', 'ach_op_flops',
-               'ach_forward_profiled', 'ach_set_probe', 'ach_read_probe', 'ach_bench_gemm', 'ach_set_option')
+               'ach_forward_profiled', 'ach_set_probe', 'ach_read_probe', 'ach_bench_gemm', 'ach_set_option', 'ach_preprocess_radar',
+               'ach_normalize_points', 'ach_preprocess_image', 'ach_seg_argmax')
 
     def __init__(self, path):
         if not os.path.exists(path):
@@ -65,6 +66,14 @@ class NativeLibrary:
         L.ach_nms_workspace_bytes.restype = sz
         L.ach_nms.argtypes = [vp, i32, vp, f32, f32, i32, vp, vp, vp, vp, vp]
         L.ach_nms.restype = ctypes.c_int
+        L.ach_preprocess_radar.argtypes = [vp, i32, i32, vp, vp, vp]
+        L.ach_preprocess_radar.restype = ctypes.c_int
+        L.ach_normalize_points.argtypes = [vp, i32, i32, i32, vp, vp, vp]
+        L.ach_normalize_points.restype = ctypes.c_int
+        L.ach_preprocess_image.argtypes = [vp, i32, vp, vp, vp]
+        L.ach_preprocess_image.restype = ctypes.c_int
+        L.ach_seg_argmax.argtypes = [vp, i32, i32, vp, vp, vp]
+        L.ach_seg_argmax.restype = ctypes.c_int
         L.ach_tap_count.argtypes = [vp]
         L.ach_tap_count.restype = ctypes.c_int
         L.ach_tap_name.argtypes = [vp, ctypes.c_int]
@@ -217,6 +226,19 @@ class NativeEngine:
     def nms(self, batch, decoded, conf, iou, max_det, rows, idx, count, workspace, stream=0):
         self._check(self.L.ach_nms(self.h, int(batch), _ptr(decoded), float(conf), float(iou), int(max_det), _ptr(rows),
                                    _ptr(idx), _ptr(count), _ptr(workspace), ctypes.c_void_p(stream)))
+
+    # ---- pre / post-processing
+    def preprocess_radar(self, batch, channels, src, dst, stream=0):
+        self._check(self.L.ach_preprocess_radar(self.h, int(batch), int(channels), _ptr(src), _ptr(dst), ctypes.c_void_p(stream)))
+
+    def normalize_points(self, batch, n, d, src, dst, stream=0):
+        self._check(self.L.ach_normalize_points(self.h, int(batch), int(n), int(d), _ptr(src), _ptr(dst), ctypes.c_void_p(stream)))
+
+    def preprocess_image(self, batch, src, dst, stream=0):
+        self._check(self.L.ach_preprocess_image(self.h, int(batch), _ptr(src), _ptr(dst), ctypes.c_void_p(stream)))
+
+    def seg_argmax(self, batch, channels, src, dst, stream=0):
+        self._check(self.L.ach_seg_argmax(self.h, int(batch), int(channels), _ptr(src), _ptr(dst), ctypes.c_void_p(stream)))
 
     # ---------------------------------------------------------------------------------------------------
     def tap_names(self):

@@ -61,6 +61,7 @@ class Achelous(nn.Module):
         self._init_like_reference()
         self._engines = {}          # (device index, dtype) -> [NativeEngine, weight version, num_points]
         self.debug_taps = False     # True: the engine also materialises every SURVEY §8(a) boundary (parity tests)
+        self.static_weights = False  # True: skip the per-call check for in-place weight changes (serving loops)
 
     # engines hold ctypes handles: never pickle / deepcopy them (utils_fit.py:378 pickles the module, ModelEMA deep-copies it)
     def __getstate__(self):
@@ -99,7 +100,8 @@ class Achelous(nn.Module):
         else:
             raise TypeError(f"Achelous forward supports float32 and bfloat16 inputs, got {dtype}")
         key = (device.index, code)
-        ver = self._weights_version()
+        ent0 = self._engines.get(key)
+        ver = ent0[1] if (self.static_weights and ent0 is not None and ent0[1] is not None) else self._weights_version()
         ent = self._engines.get(key)
         if ent is None or ent[2] != num_points:
             eng = _eng.NativeEngine(_eng.hip_library(), num_det=self.num_det, num_seg=self.num_seg, phi=self.phi,

@@ -76,6 +76,7 @@ def main():
     model = Achelous(**COMMON, **kw).eval()
     model.load_state_dict(condition_state_dict(model.state_dict(), seed=0))
     model = model.to(dev)
+    model.static_weights = True          # serving loop: weights do not change between steps
     B = args.batch
     x, xr, xp = make_inputs(B, config_seed(cid) + 1000 * rank, resolution=COMMON['resolution'], pc_channels=COMMON['pc_channels'])
     x, xr, xp = x.to(dev, tdt), xr.to(dev, tdt), xp.to(dev, tdt)

@@ -79,7 +79,8 @@ int ach_load_weights(ach_handle* h, const ach_tensor_desc* tensors, size_t n);
 /* Options, set before ach_plan.  "full_taps" = 1: also write to HBM the SURVEY §8(a) boundaries that production plans keep
  * on-chip (the 32-channel full-resolution decoder tensors), so that parity tests can read them back.
  * "streams" = 0: launch everything on the caller's stream (default 1: the independent radar and point branches run on two
- * engine-owned side streams, forked from / joined into the caller's stream with events). */
+ * engine-owned side streams, forked from / joined into the caller's stream with events).
+ * "graph" = 0: eager launches (default 1: the plan is captured into a hipGraph per distinct set of I/O pointers and replayed). */
 int ach_set_option(ach_handle* h, const char* key, int32_t value);
 
 /* Builds the launch plan and the activation arena for batch size B (re-plan to change B). */
@@ -101,6 +102,18 @@ int ach_decode(ach_handle* h, int32_t batch, const void* det3, const void* det4,
 size_t ach_nms_workspace_bytes(const ach_handle* h, int32_t batch);
 int ach_nms(ach_handle* h, int32_t batch, const float* decoded, float conf_thres, float nms_thres, int32_t max_det,
             float* out_rows, int32_t* out_idx, int32_t* out_count, void* workspace, void* stream);
+
+/* Pre / post-processing either side of the forward (the reference does these per frame on the host):
+ *   ach_preprocess_radar  <- utils/utils.py:51-54   preprocess_input_radar: (x - min) / (max - min) + 1e-13, min/max per frame;
+ *                                                   in fp32 [B,C,R,R] -> out [B,C,R,R] (config dtype)
+ *   ach_normalize_points  <- achelous.py:240-243    sklearn normalize(X[N,D], axis=0) + permute; in fp32 [B,N,D] -> out [B,D,N]
+ *   ach_preprocess_image  <- utils/utils.py:44-48   preprocess_input + HWC->CHW (achelous.py:205); in uint8 [B,R,R,3] (already
+ *                                                   letterboxed) -> out [B,3,R,R]
+ *   ach_seg_argmax        <- achelous.py:283-318    per-pixel class at network resolution; in [B,C,R,R] -> out uint8 [B,R,R] */
+int ach_preprocess_radar(ach_handle* h, int32_t batch, int32_t channels, const float* in, void* out, void* stream);
+int ach_normalize_points(ach_handle* h, int32_t batch, int32_t n, int32_t d, const float* in, void* out, void* stream);
+int ach_preprocess_image(ach_handle* h, int32_t batch, const uint8_t* in, void* out, void* stream);
+int ach_seg_argmax(ach_handle* h, int32_t batch, int32_t channels, const void* seg, uint8_t* out, void* stream);
 
 /* test hooks: intermediate tensors of the last ach_forward, converted to fp32 NCHW (or [rows, C]) on the host */
 int ach_tap_count(const ach_handle* h);
