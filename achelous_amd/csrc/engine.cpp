@@ -818,6 +818,12 @@ public:
         copy(f + ".cat3", m3, c3.slice(w[1], w[1]));
         A p3 = ghost_bottleneck(f + ".ghost_4_to_3", c3, w[1]);
         tap("fpn4", p4); tap("fpn3", p3);
+        // residual FPN outputs (ghostdualfpn.py:200) — computed BEFORE the decoders so that the detection branch (fusion + head,
+        // on the radar stream) can start while the two heavy decoders still run on this stream
+        q[0] = alloc(p3.B, p3.H, p3.W, p3.C); add(f + ".q3", p3, m3, q[0]);
+        q[1] = alloc(p4.B, p4.H, p4.W, p4.C); add(f + ".q4", p4, m4, q[1]);
+        q[2] = alloc(p5.B, p5.H, p5.W, p5.C); add(f + ".q5", p5, m5, q[2]);
+        signal_after_last(1);
         // two segmentation decoders
         const char* names[2] = {"lane", "se"};
         const char* sa[2] = {"stage_3_lane_seg", "stage_3_semantic_seg"};
@@ -835,10 +841,6 @@ public:
             }
             decoder_last_level(f + "." + n + "_seg_" + lv[2], f + "." + n + "_seg_ghost_" + lv[2], f + "." + n + "_seg_head", n + "." + lv[2], y, cw[2], oups[d], outs[d]);
         }
-        // residual FPN outputs (ghostdualfpn.py:200)
-        q[0] = alloc(p3.B, p3.H, p3.W, p3.C); add(f + ".q3", p3, m3, q[0]);
-        q[1] = alloc(p4.B, p4.H, p4.W, p4.C); add(f + ".q4", p4, m4, q[1]);
-        q[2] = alloc(p5.B, p5.H, p5.W, p5.C); add(f + ".q5", p5, m5, q[2]);
     }
     const int* widths() const {
         static const int w0[4] = {32, 48, 96, 176}, w1[4] = {32, 48, 120, 224}, w2[4] = {32, 64, 144, 288};
@@ -1111,7 +1113,6 @@ public:
         A r[3];
         cur_stream = 1;
         rcnet(r);
-        signal_after_last(0);
         cur_stream = 2;
         pointnet();
         cur_stream = 0;
@@ -1121,9 +1122,13 @@ public:
         A q[3];
         neck(m, q);
         tap("q3", q[0]); tap("q4", q[1]); tap("q5", q[2]);
-        wait_before_next(0);                      // fusion needs the radar taps
+        // detection branch: fusion + head continue on the RADAR stream (in order after the radar taps), gated only on the FPN
+        // outputs (event 1) — they overlap with the segmentation decoders that keep the caller's stream busy
+        cur_stream = 1;
+        wait_before_next(1);
         A p[3] = {fuse(3, q[0], r[0]), fuse(4, q[1], r[1]), fuse(5, q[2], r[2])};
         head(p);
+        cur_stream = 0;
     }
 
     void plan(int B) override {

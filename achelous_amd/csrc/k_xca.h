@@ -15,6 +15,7 @@
 namespace ach {
 
 constexpr int XCA_DMAX = 48;
+constexpr int XCA_CT = 128;      // output-channel tile of xca_finalize
 
 struct XcaGramParams { const void* qkv; long ld; float* partial; int B, N, C, heads, S; };
 
@@ -88,6 +89,7 @@ template <class T>
 __global__ __launch_bounds__(256) void xca_finalize_kernel(const XcaFinalParams p) {
     __shared__ float A[XCA_DMAX][XCA_DMAX + 1];
     __shared__ float nq[XCA_DMAX], nk[XCA_DMAX];
+    __shared__ float wps[XCA_CT][XCA_DMAX + 1];
     const int bh = blockIdx.x;
     const int b = bh / p.heads, h = bh % p.heads;
     const int d = p.C / p.heads, npair = d * d;
@@ -114,13 +116,26 @@ __global__ __launch_bounds__(256) void xca_finalize_kernel(const XcaFinalParams 
     }
     __syncthreads();
     if (p.attn) for (int e = tid; e < npair; e += 256) p.attn[long(bh) * npair + e] = A[e / d][e % d];
+    // Weff rows in tiles of XCA_CT output channels: the Wproj slice [tile][d] of this head is staged in LDS with coalesced loads
+    // first (a thread-private walk over Wproj rows is a chain of dependent L1/L2 latencies: 67 us for a 2 us job).
     T* W = static_cast<T*>(p.Weff) + long(b) * p.group_stride;
-    for (int e = tid; e < p.C * d; e += 256) {
-        const int co = e / d, j = e - co * d;
-        const float* wp = p.Wproj + long(co) * p.C + h * d;
-        float s = 0.f;
-        for (int i = 0; i < d; ++i) s += A[i][j] * wp[i];
-        Store<T>::st(W + wfrag_offset(co, h * d + j, p.NT, p.ksteps, Store<T>::VEC), s * p.gamma[co]);
+    for (int c0 = 0; c0 < p.C; c0 += XCA_CT) {
+        const int rows = (p.C - c0 < XCA_CT) ? p.C - c0 : XCA_CT;
+        __syncthreads();
+        for (int e = tid; e < rows * d; e += 256) { const int r = e / d, i = e - r * d; wps[r][i] = p.Wproj[long(c0 + r) * p.C + h * d + i]; }
+        __syncthreads();
+        for (int e = tid; e < rows * d; e += 256) {
+            const int r = e / d, j = e - r * d;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;          // 4 independent chains: LDS reads of a group are all in flight
+            int i = 0;
+            for (; i + 4 <= d; i += 4) {
+                s0 += A[i][j] * wps[r][i]; s1 += A[i + 1][j] * wps[r][i + 1]; s2 += A[i + 2][j] * wps[r][i + 2]; s3 += A[i + 3][j] * wps[r][i + 3];
+            }
+            for (; i < d; ++i) s0 += A[i][j] * wps[r][i];
+            const float s = (s0 + s1) + (s2 + s3);
+            const int co = c0 + r;
+            Store<T>::st(W + wfrag_offset(co, h * d + j, p.NT, p.ksteps, Store<T>::VEC), s * p.gamma[co]);
+        }
     }
 }
 
