@@ -1129,6 +1129,36 @@ public:
         A p[3] = {fuse(3, q[0], r[0]), fuse(4, q[1], r[1]), fuse(5, q[2], r[2])};
         head(p);
         cur_stream = 0;
+        interleave_streams();
+    }
+
+    // Host enqueue order = plan order.  Built branch by branch, the plan would enqueue all ~65 radar launches before the first
+    // image-path launch, delaying the critical path by the host cost of those launches (measured: the image path started 1.5 ms
+    // late under rocprofv3).  Merge the per-stream sequences proportionally instead, keeping each stream's own order and never
+    // placing a wait before the launch that signals its event.
+    void interleave_streams() {
+        if (measuring || ops.size() < 2) return;
+        std::vector<std::vector<Op>> seq(1 + kSideStreams);
+        for (auto& op : ops) seq[size_t(op.stream)].push_back(std::move(op));
+        const size_t total = ops.size();
+        ops.clear();
+        std::vector<size_t> pos(seq.size(), 0);
+        bool signalled[kJoinEvents] = {false, false, false, false};
+        while (ops.size() < total) {
+            // pick the stream that is furthest behind its proportional share and whose next launch is not blocked
+            int best = -1; double best_lag = -1e30;
+            for (size_t k = 0; k < seq.size(); ++k) {
+                if (pos[k] >= seq[k].size()) continue;
+                const Op& nx = seq[k][pos[k]];
+                if (nx.wait_ev >= 0 && !signalled[nx.wait_ev]) continue;
+                const double lag = double(ops.size() + 1) * double(seq[k].size()) / double(total) - double(pos[k]);
+                if (lag > best_lag) { best_lag = lag; best = int(k); }
+            }
+            if (best < 0) throw AchError{ACH_ERR_INVALID, "plan interleave: unsatisfiable event order"};
+            Op& op = seq[size_t(best)][pos[size_t(best)]++];
+            if (op.signal_ev >= 0) signalled[op.signal_ev] = true;
+            ops.push_back(std::move(op));
+        }
     }
 
     void plan(int B) override {
