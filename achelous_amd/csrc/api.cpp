@@ -72,6 +72,8 @@ int ach_set_option(ach_handle* h, const char* key, int32_t value) {
         if (std::string(key) == "full_taps") h->eng->full_taps = value != 0;
         else if (std::string(key) == "streams") h->eng->multi_stream = value != 0;
         else if (std::string(key) == "graph") h->eng->use_graph = value != 0;
+        else if (std::string(key) == "fused_mlp") h->eng->fuse_mlp = value != 0;
+        else if (std::string(key) == "mlp_split") h->eng->mlp_split = value;
         else throw ach::AchError{ACH_ERR_INVALID, std::string("unknown option: ") + key};
     });
 }

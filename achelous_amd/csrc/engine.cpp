@@ -14,6 +14,7 @@
 
 #include "k_detect.h"
 #include "k_gemm.h"
+#include "k_mlp.h"
 #include "k_mvit.h"
 #include "k_nhwc.h"
 #include "k_points.h"
@@ -491,7 +492,60 @@ public:
         gemm(pfx + ".pwconv2", h, pack(l2), y, o2);
         return y;
     }
+    // One launch for [depthwise kxk ->] LN -> Linear -> act -> Linear -> scale -> + resid (k_mlp.h).  Returns false when the
+    // width is outside the kernel's instantiations (the caller then runs the layer-wise path).
+    bool fused_mlp(const std::string& pfx, const A& xin, const A& resid, int dw_ks, A& y) {
+        if (!fuse_mlp) return false;
+        const int C = xin.C, DT = mlp_pick_dt(C);
+        if (DT == 0 || (dw_ks != 0 && dw_ks != 3 && dw_ks != 5 && dw_ks != 7 && dw_ks != 9)) return false;
+        Lin l1 = lin(pfx + ".pwconv1.weight", pfx + ".pwconv1.bias");
+        fold_ln_in(l1, pfx + ".norm");
+        Lin l2 = lin(pfx + ".pwconv2.weight", pfx + ".pwconv2.bias");
+        fold_scale_out(l2, W(pfx + ".gamma").data);
+        const int hidden = l1.N, k1 = cdiv(C, KC), J = cdiv(hidden, 32), hstep = 8 / VEC, ks2 = J * hstep;
+        if (l1.K != C || l2.N != C || l2.K != hidden) throw AchError{ACH_ERR_MISSING_KEY, "MLP shapes at " + pfx};
+        std::vector<float> w1(size_t(J) * k1 * 2 * 64 * VEC, 0.f), b1(size_t(J) * 32, 0.f);
+        std::vector<float> w2(size_t(ks2) * DT * 64 * VEC, 0.f), b2(size_t(DT) * 16, 0.f);
+        if (!measuring) {
+            for (int n = 0; n < hidden; ++n) {
+                b1[n] = l1.b[n];
+                for (int k = 0; k < C; ++k) w1[size_t(wfrag_offset(n, k, 2, k1, VEC))] = l1.w[size_t(n) * C + k];
+            }
+            for (int n = 0; n < C; ++n) {
+                b2[n] = l2.b[n];
+                for (int kap = 0; kap < 32 * J; ++kap) {
+                    const int ch = mlp_hidden_channel(kap, VEC);
+                    if (ch < hidden) w2[size_t(wfrag_offset(n, kap, DT, ks2, VEC))] = l2.w[size_t(n) * hidden + ch];
+                }
+            }
+        }
+        MlpParams mp;
+        std::memset(&mp, 0, sizeof(mp));
+        mp.X = xin.p; mp.ldx = xin.ld; mp.R = resid.p; mp.ldr = resid.ld;
+        y = alloc(xin.B, xin.H, xin.W, C);
+        mp.Y = y.p; mp.ldy = y.ld;
+        mp.dw_k = dw_ks; mp.H = xin.H; mp.W = xin.W;
+        if (dw_ks) {
+            const HostTensor& w = W(pfx + ".dwconv.weight");
+            const std::vector<float>& b = W(pfx + ".dwconv.bias").data;
+            const int ldc = k1 * KC, kk = dw_ks * dw_ks;
+            if (size_t(w.numel()) != size_t(C) * size_t(kk)) throw AchError{ACH_ERR_MISSING_KEY, "depthwise shape at " + pfx};
+            std::vector<float> wt(size_t(kk) * ldc, 0.f), bt(size_t(ldc), 0.f);
+            for (int c = 0; c < C; ++c) { bt[c] = b[c]; for (int t = 0; t < kk; ++t) wt[size_t(t) * ldc + c] = w.data[size_t(c) * kk + t]; }
+            mp.Wdw = up_f32(wt); mp.bdw = up_f32(bt);
+        }
+        mp.W1 = up_T(w1); mp.b1 = up_f32(b1); mp.W2 = up_T(w2); mp.b2 = up_f32(b2);
+        mp.M = xin.rows(); mp.C = C; mp.k1 = k1; mp.J = J; mp.act = ACT_GELU; mp.ln_eps = 1e-6f;
+        // per-sample map size, not batch, decides the geometry: a frame's result must not depend on the batch it is in
+        const bool split = mlp_split < 0 ? xin.H * xin.W <= 1024 : mlp_split != 0;
+        const double bytes = double(mp.M) * C * sizeof(T) * (xin.p == resid.p ? 2.0 : 3.0);
+        const double flops = 4.0 * double(mp.M) * C * hidden + (dw_ks ? 2.0 * double(mp.M) * C * dw_ks * dw_ks : 0.0);
+        add_op(pfx + (dw_ks ? ".block" : ".mlp"), [mp, DT, split](hipStream_t s) { launch_mlp<T>(mp, DT, split, s); }, bytes, flops);
+        return true;
+    }
     A conv_encoder(const std::string& pfx, const A& x, int ks) {          // conv_encoder.py:19-32
+        A fy;
+        if (fused_mlp(pfx, x, x, ks, fy)) return fy;
         A d = alloc(x.B, x.H, x.W, x.C);
         dwconv(pfx + ".dwconv", x, nullptr, pfx + ".dwconv.weight", pfx + ".dwconv.bias", "", 0, ks, 1, ACT_NONE, d);
         return pw_mlp(pfx, d, x);
@@ -547,6 +601,8 @@ public:
             GemmOpt op; op.residual = &y; op.groups = x.B; op.w_group_stride = pe.group_elems; op.w_override = weff;
             gemm(pfx + ".xca.proj", qkv.p + 2 * C, qkv.ld, qkv.rows(), pe, t2.p, t2.ld, op);
         }
+        A fy;
+        if (fused_mlp(pfx, t2, x, 0, fy)) return fy;
         return pw_mlp(pfx, t2, x);
     }
     void edgenext(const std::string& pfx, A feats[4]) {                   // edgenext.py:73-86
@@ -790,7 +846,7 @@ public:
                             up_f32(wh2), up_f32(bh2), x.B, x.H, x.W, init, nch, oup};
         const dim3 grid(unsigned(cdiv(2 * x.W, UGH_TW)) * unsigned(cdiv(2 * x.H, UGH_TH)) * unsigned(x.B)), block(256);
         const double bytes = double(t.rows()) * Cg * sizeof(T) + 4.0 * double(t.rows()) * oup * sizeof(T);
-        add_op(head_pfx + ".upghost_head", [p, grid, block, out](hipStream_t s) mutable { p.out = *out; ACH_LAUNCH(upghost_head_kernel<T>, grid, block, s, p); }, bytes);
+        add_op(head_pfx + ".upghost_head", [p, grid, block, out](hipStream_t s) mutable { p.out = *out; ACH_LAUNCH(upghost_head_kernel<T>, grid, block, s, p, p.Wdw, p.bdw, p.Wh, p.bh, p.Wdh, p.bdh); }, bytes);
     }
 
     void neck(A m[4], A q[3]) {                                                  // ghostdualfpn.py:156-200

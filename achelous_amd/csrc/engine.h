@@ -65,6 +65,8 @@ public:
     // (1.36 ms vs 1.66 ms): HIP's graph executor serialises more of the three-branch DAG than the streams do.
     bool use_graph = false;
     bool multi_stream = true;         // option "streams": run the independent radar / point branches on side streams
+    bool fuse_mlp = true;             // option "fused_mlp": EdgeNeXt blocks as one kernel (k_mlp.h) instead of dw / pw1 / pw2 launches
+    int mlp_split = -1;               // option "mlp_split": -1 auto (by tile count), 0 one tile per wave, 1 four waves per tile
     bool full_taps = false;           // option "full_taps": also materialise boundaries that production plans keep on-chip
     int batch = 0;
     std::vector<Op> ops;

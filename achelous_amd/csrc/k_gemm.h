@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
             ACH_UNROLL
             for (int t = 0; t < NT; ++t)
                 ACH_UNROLL
-                for (int r = 0; r < 4; ++r) o[t * 4 + r] = apply_act(acc[q][t][r] + bv[t * 4 + r], p.act);
+                for (int r = 0; r < 4; ++r) o[t * 4 + r] = apply_act_t<T>(acc[q][t][r] + bv[t * 4 + r], p.act);
             const long m = mrow[q];
             if (p.out_nchw) {
                 T* Y = static_cast<T*>(p.Y);

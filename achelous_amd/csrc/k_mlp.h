@@ -1,0 +1,292 @@
+// k_mlp.h — one kernel for the whole pointwise half of an EdgeNeXt block:
+//
+//     y = r + W2 · act( W1 · LN( dw_kxk(x) + b_dw ) + b1 ) + b2
+//
+// (ConvEncoder, edgenext_modules/conv_encoder.py:19-32: depthwise conv -> LayerNorm -> Linear(d,4d) -> GELU ->
+//  Linear(4d,d) -> layer scale -> + input;  the MLP tail of SDTAEncoder, sdta_encoder.py:68-74, is the same thing
+//  without the depthwise conv and with a residual taken from a different tensor.)
+// LayerNorm affine is folded into W1/b1 and the layer scale into W2/b2 on the host.
+//
+// Layer by layer this was three launches and a round trip of the 4d-wide hidden tensor through HBM (the largest
+// activation of the backbone).  Here the hidden activations never leave registers: with weights as the MFMA *A* operand
+// a lane's accumulators of one PAIR of 16-channel output tiles are, after the channel permutation chosen for the wide
+// stores (chunk_channel in k_gemm.h), exactly the 8 consecutive hidden channels  j*32 + g*8 .. +7  of pixel (lane & 15)
+// — which is the *B* operand fragment of k-step j of the second GEMM.  So GEMM1 -> bias -> GELU -> GEMM2 chains through
+// registers with no LDS shuffle.  (fp32 storage: the same 8 values form two 4-wide k-steps; the host packs W2 with the
+// matching order of hidden channels, see mlp_hidden_channel.)
+//
+// A wave owns 16 pixels.  Large maps (SPLIT = false): the 4 waves of a workgroup take 4 different pixel tiles.  Small
+// maps (SPLIT = true; 20x20 and 10x10 at batch 64 are only 1600 / 400 tiles): the 4 waves share ONE tile — each computes
+// the depthwise conv for a quarter of the channel k-steps and a quarter of the hidden chunks, inputs are exchanged and
+// the partial outputs summed through LDS — four times the parallelism, a quarter of the dependent-latency chain.
+#pragma once
+#include "ach_platform.h"
+#include "k_gemm.h"
+
+namespace ach {
+
+// Hidden channel that k index `kappa` of the second GEMM refers to.  bf16 (VEC 8): identity.  fp32 (VEC 4): the 8 values a
+// lane group g holds for hidden chunk j (channels j*32 + g*8 + e) are consumed as two k-steps of 16: step 2j takes e = 0..3,
+// step 2j+1 takes e = 4..7, and inside a step lane group g / element kj is k index g*4 + kj.
+__host__ __device__ __forceinline__ int mlp_hidden_channel(int kappa, int VEC) {
+    if (VEC == 8) return kappa;
+    const int j = kappa >> 5, rem = kappa & 31, half = rem >> 4, g = (rem & 15) >> 2, kj = rem & 3;
+    return j * 32 + g * 8 + half * 4 + kj;
+}
+
+struct MlpParams {
+    const void* X; long ldx;              // LayerNorm input rows, or the depthwise conv's input map when dw_k > 0 (NHWC)
+    const void* R; long ldr;              // residual rows
+    void* Y; long ldy;
+    const float* Wdw; const float* bdw;   // depthwise weights [dw_k*dw_k][ldc] (fp32, zero padded), bias [ldc]; ldc = k1 * 4 * VEC
+    int dw_k, H, W;
+    const void* W1; const float* b1;      // [hidden][C] packed in NT = 2 chunks with k1 k-steps ; bias padded to 32 * J
+    const void* W2; const float* b2;      // [C][hidden] packed as ONE chunk of DT tiles with J * (8 / VEC) k-steps ; bias padded to 16 * DT
+    long M; int C, k1, J, act; float ln_eps;
+};
+
+constexpr int MLP_RED_TILES = 8;          // output tiles reduced per LDS round in SPLIT mode
+
+// depthwise k x k conv (zero padding k/2) of this lane's VEC channels at its pixel; up to 5 taps of a row in flight at a time.
+// Loads are unconditional from clamped columns (no divergent branches), out-of-map taps are zeroed afterwards; the weights are
+// kept in fp32 so that only the activations need unpacking (this loop is VALU-issue bound).
+template <class T, int KS>
+__device__ __forceinline__ void mlp_dw(const MlpParams& p, const T* img, int oy, int ox, int k0, float* acc) {
+    constexpr int VEC = Store<T>::VEC;
+    constexpr int TG = KS <= 5 ? KS : (KS + 1) / 2;
+    const int ldc = p.k1 * 4 * VEC;
+    const float* wdw = p.Wdw + k0;
+    for (int ty = 0; ty < KS; ++ty) {
+        const int iy = oy + ty - KS / 2;
+        if (iy < 0 || iy >= p.H) continue;
+        const T* row = img + long(iy) * p.W * p.ldx + k0;
+        const float* wrow = wdw + long(ty * KS) * ldc;
+        ACH_UNROLL
+        for (int tx0 = 0; tx0 < KS; tx0 += TG) {
+            uint4 xv[TG];
+            f32x4 wv[TG][VEC / 4];
+            ACH_UNROLL
+            for (int i = 0; i < TG; ++i) {
+                const int tx = tx0 + i;
+                if (tx >= KS) continue;
+                const int ix = ox + tx - KS / 2;
+                const int cx = ix < 0 ? 0 : (ix >= p.W ? p.W - 1 : ix);
+                xv[i] = *reinterpret_cast<const uint4*>(row + long(cx) * p.ldx);
+                ACH_UNROLL
+                for (int q = 0; q < VEC / 4; ++q) wv[i][q] = *reinterpret_cast<const f32x4*>(wrow + long(tx) * ldc + q * 4);
+            }
+            ACH_UNROLL
+            for (int i = 0; i < TG; ++i) {
+                const int tx = tx0 + i;
+                if (tx >= KS) continue;
+                const int ix = ox + tx - KS / 2;
+                const bool live = ix >= 0 && ix < p.W;
+                const uint4 xz = make_uint4(live ? xv[i].x : 0u, live ? xv[i].y : 0u, live ? xv[i].z : 0u, live ? xv[i].w : 0u);
+                float xf[8];
+                frag_unpack<T>(xz, xf);
+                ACH_UNROLL
+                for (int e = 0; e < VEC; ++e) acc[e] += xf[e] * wv[i][e >> 2][e & 3];
+            }
+        }
+    }
+}
+
+// Step 1 of mlp_kernel: this wave's input fragments and its partial LayerNorm sums.  KS = 0: plain rows; KS = 3/5/7/9: depthwise conv.
+// SPLIT: wave w produces k-steps w, w+4, ... straight into LDS (`xs`); otherwise all k-steps into `xf`.
+template <class T, int K1MAX, bool SPLIT, int KS>
+__device__ __forceinline__ void mlp_inputs(const MlpParams& p, long m, bool valid, int g, int wave, int lane, uint4* xs, uint4* xf, float& s1, float& s2) {
+    constexpr int VEC = Store<T>::VEC;
+    constexpr int KC = 4 * VEC;
+    const T* X = static_cast<const T*>(p.X);
+    int oy = 0, ox = 0;
+    const T* img = X;
+    if (KS > 0) {
+        const long hw = long(p.H) * p.W;
+        const long b = m / hw;
+        const int rem = int(m - b * hw);
+        oy = rem / p.W; ox = rem - oy * p.W;
+        img = X + b * hw * p.ldx;
+    }
+    constexpr int NS = SPLIT ? (K1MAX + 3) / 4 : K1MAX;
+    ACH_UNROLL
+    for (int si = 0; si < NS; ++si) {
+        const int s = SPLIT ? wave + 4 * si : si;
+        if (s >= p.k1) continue;
+        const int k0 = s * KC + g * VEC;
+        uint4 frag = make_uint4(0u, 0u, 0u, 0u);
+        if (valid && k0 < p.C) {
+            if (KS == 0) {
+                frag = *reinterpret_cast<const uint4*>(X + m * p.ldx + k0);
+                float v[8];
+                frag_unpack<T>(frag, v);
+                ACH_UNROLL
+                for (int i = 0; i < VEC; ++i) { s1 += v[i]; s2 += v[i] * v[i]; }
+            } else {
+                float acc[8];
+                ACH_UNROLL
+                for (int i = 0; i < VEC; ++i) acc[i] = p.bdw[k0 + i];
+                mlp_dw<T, (KS > 0 ? KS : 3)>(p, img, oy, ox, k0, acc);
+                ACH_UNROLL
+                for (int i = 0; i < VEC; ++i) { s1 += acc[i]; s2 += acc[i] * acc[i]; }     // channels >= C: zero weights, zero bias
+                frag = frag_pack<T>(acc);
+            }
+        }
+        if (SPLIT) xs[s * 64 + lane] = frag; else xf[si] = frag;
+    }
+}
+
+template <int DT> struct MlpOcc { static constexpr int blocks = DT <= 8 ? 4 : (DT <= 12 ? 3 : 2); };
+
+template <class T, int DT, bool SPLIT>
+__global__ __launch_bounds__(256, MlpOcc<DT>::blocks) void mlp_kernel(const MlpParams p) {
+    constexpr int VEC = Store<T>::VEC;
+    constexpr int KC = 4 * VEC;
+    constexpr int K1MAX = (16 * DT + KC - 1) / KC;
+    constexpr int HSTEP = 8 / VEC;                       // k-steps of the second GEMM per hidden chunk of 32
+    constexpr int RT = DT < MLP_RED_TILES ? DT : MLP_RED_TILES;
+    __shared__ uint4 xs[SPLIT ? K1MAX * 64 : 1];         // SPLIT: exchanged input fragments
+    __shared__ float st[SPLIT ? 4 * 16 * 2 : 1];         //        per-wave partial LayerNorm sums
+    __shared__ float red[SPLIT ? 4 * RT * 4 * 64 : 1];   //        partial outputs, RT tiles per round
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int px = lane & 15, g = lane >> 4;
+    const long tile = SPLIT ? long(blockIdx.x) : long(blockIdx.x) * 4 + wave;
+    const long mraw = tile * 16 + px;
+    const bool valid = mraw < p.M;
+    const long m = valid ? mraw : 0;
+
+    // ---- 1. input fragments and LayerNorm sums
+    uint4 xf[K1MAX];
+    ACH_UNROLL
+    for (int s = 0; s < K1MAX; ++s) xf[s] = make_uint4(0u, 0u, 0u, 0u);
+    float s1 = 0.f, s2 = 0.f;
+    switch (p.dw_k) {
+        case 0: mlp_inputs<T, K1MAX, SPLIT, 0>(p, m, valid, g, wave, lane, xs, xf, s1, s2); break;
+        case 3: mlp_inputs<T, K1MAX, SPLIT, 3>(p, m, valid, g, wave, lane, xs, xf, s1, s2); break;
+        case 5: mlp_inputs<T, K1MAX, SPLIT, 5>(p, m, valid, g, wave, lane, xs, xf, s1, s2); break;
+        case 7: mlp_inputs<T, K1MAX, SPLIT, 7>(p, m, valid, g, wave, lane, xs, xf, s1, s2); break;
+        default: mlp_inputs<T, K1MAX, SPLIT, 9>(p, m, valid, g, wave, lane, xs, xf, s1, s2); break;
+    }
+    s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+    s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+    if (SPLIT) {
+        if (g == 0) { st[(wave * 16 + px) * 2] = s1; st[(wave * 16 + px) * 2 + 1] = s2; }
+        __syncthreads();
+        ACH_UNROLL
+        for (int s = 0; s < K1MAX; ++s)
+            if (s < p.k1) xf[s] = xs[s * 64 + lane];
+        s1 = 0.f; s2 = 0.f;
+        ACH_UNROLL
+        for (int w = 0; w < 4; ++w) { s1 += st[(w * 16 + px) * 2]; s2 += st[(w * 16 + px) * 2 + 1]; }
+    }
+    // ---- 2. LayerNorm (affine folded into W1 / b1)
+    {
+        const float mu = s1 / float(p.C);
+        float var = s2 / float(p.C) - mu * mu;
+        var = var > 0.f ? var : 0.f;
+        const float rstd = 1.0f / sqrtf(var + p.ln_eps);
+        ACH_UNROLL
+        for (int s = 0; s < K1MAX; ++s) {
+            if (s >= p.k1) continue;
+            const int k0 = s * KC + g * VEC;
+            float v[8];
+            frag_unpack<T>(xf[s], v);
+            ACH_UNROLL
+            for (int i = 0; i < VEC; ++i) v[i] = (k0 + i < p.C) ? (v[i] - mu) * rstd : 0.f;
+            xf[s] = frag_pack<T>(v);
+        }
+    }
+    // ---- 3. hidden chunks of 32 channels: GEMM1 (2 tiles) -> bias, activation -> GEMM2 accumulation
+    f32x4 acc2[DT];
+    ACH_UNROLL
+    for (int t = 0; t < DT; ++t) { acc2[t][0] = 0.f; acc2[t][1] = 0.f; acc2[t][2] = 0.f; acc2[t][3] = 0.f; }
+    const uint4* W1f = static_cast<const uint4*>(p.W1) + lane;
+    const uint4* W2f = static_cast<const uint4*>(p.W2) + lane;
+    for (int j = SPLIT ? wave : 0; j < p.J; j += (SPLIT ? 4 : 1)) {
+        f32x4 a0, a1;
+        a0[0] = a0[1] = a0[2] = a0[3] = 0.f;
+        a1[0] = a1[1] = a1[2] = a1[3] = 0.f;
+        const uint4* w1 = W1f + long(j) * p.k1 * 2 * 64;
+        ACH_UNROLL
+        for (int s = 0; s < K1MAX; ++s) {
+            if (s >= p.k1) continue;
+            const uint4 wa = w1[(s * 2) * 64], wb = w1[(s * 2 + 1) * 64];
+            mfma16<T>(wa, xf[s], a0);
+            mfma16<T>(wb, xf[s], a1);
+        }
+        float h[8];
+        const float* b1 = p.b1 + j * 32 + g * 8;
+        ACH_UNROLL
+        for (int r = 0; r < 4; ++r) { h[r] = apply_act_t<T>(a0[r] + b1[r], p.act); h[4 + r] = apply_act_t<T>(a1[r] + b1[4 + r], p.act); }
+        ACH_UNROLL
+        for (int hh = 0; hh < HSTEP; ++hh) {
+            const uint4 hf = frag_pack<T>(h + hh * VEC);
+            const uint4* w2 = W2f + long(j * HSTEP + hh) * DT * 64;
+            ACH_UNROLL
+            for (int t = 0; t < DT; ++t) mfma16<T>(w2[t * 64], hf, acc2[t]);
+        }
+    }
+    // ---- 4. + bias + residual, 8 consecutive channels per lane per tile pair
+    auto finish = [&](int pair, const float* v8) {
+        const int nb = pair * 32 + g * 8;
+        if (!valid || nb >= p.C) return;
+        float o[8], r8[8];
+        Store<T>::ld8(static_cast<const T*>(p.R) + m * p.ldr + nb, r8);
+        ACH_UNROLL
+        for (int i = 0; i < 8; ++i) o[i] = v8[i] + p.b2[nb + i] + r8[i];
+        Store<T>::st8(static_cast<T*>(p.Y) + m * p.ldy + nb, o);
+    };
+    if (!SPLIT) {
+        ACH_UNROLL
+        for (int pair = 0; pair < DT / 2; ++pair) {
+            float v8[8];
+            ACH_UNROLL
+            for (int r = 0; r < 4; ++r) { v8[r] = acc2[2 * pair][r]; v8[4 + r] = acc2[2 * pair + 1][r]; }
+            finish(pair, v8);
+        }
+    } else {
+        ACH_UNROLL
+        for (int t0 = 0; t0 < DT; t0 += RT) {
+            if (t0 > 0) __syncthreads();
+            ACH_UNROLL
+            for (int t = 0; t < RT; ++t) {
+                if (t0 + t >= DT) continue;
+                ACH_UNROLL
+                for (int r = 0; r < 4; ++r) red[((wave * RT + t) * 4 + r) * 64 + lane] = acc2[t0 + t][r];
+            }
+            __syncthreads();
+            ACH_UNROLL
+            for (int q = 0; q < RT / 2; ++q) {                      // pair q of this round belongs to wave q % 4
+                if ((q & 3) != wave || t0 + 2 * q >= DT) continue;
+                float v8[8];
+                ACH_UNROLL
+                for (int i = 0; i < 8; ++i) {
+                    const int t = 2 * q + (i >> 2), r = i & 3;
+                    float a = 0.f;
+                    ACH_UNROLL
+                    for (int w = 0; w < 4; ++w) a += red[((w * RT + t) * 4 + r) * 64 + lane];
+                    v8[i] = a;
+                }
+                finish((t0 >> 1) + q, v8);
+            }
+        }
+    }
+}
+
+template <class T>
+inline bool launch_mlp(const MlpParams& p, int DT, bool split, hipStream_t stream) {
+    const long tiles = (p.M + 15) / 16;
+    const dim3 grid(unsigned(split ? tiles : (tiles + 3) / 4)), block(256);
+#define ACH_MLP_CASE(dt) \
+    if (DT == dt) { if (split) ACH_LAUNCH((mlp_kernel<T, dt, true>), grid, block, stream, p); else ACH_LAUNCH((mlp_kernel<T, dt, false>), grid, block, stream, p); return true; }
+    ACH_MLP_CASE(2) ACH_MLP_CASE(4) ACH_MLP_CASE(8) ACH_MLP_CASE(12) ACH_MLP_CASE(20)
+#undef ACH_MLP_CASE
+    return false;
+}
+inline int mlp_pick_dt(int C) {
+    const int need = 2 * ((C + 31) / 32);
+    for (int dt : {2, 4, 8, 12, 20}) if (dt >= need) return dt;
+    return 0;
+}
+
+}  // namespace ach

@@ -577,7 +577,9 @@ constexpr int UGH_TW = 30, UGH_TH = 6, UGH_CG = 16, UGH_IMAX = 8;
 // access patterns: x1 rows padded to 20 floats (thread = position reads 16 consecutive floats: stride 20 dwords is
 // conflict-free for ds_read_b128), h1 stored planar [channel][position] (thread = pixel reads one channel at a time).
 template <class T>
-__global__ __launch_bounds__(256) void upghost_head_kernel(const UpGhostHeadParams p) {
+__global__ __launch_bounds__(256) void upghost_head_kernel(const UpGhostHeadParams p, const float* __restrict__ Wdw, const float* __restrict__ bdw,
+                                                           const float* __restrict__ Wh, const float* __restrict__ bh,
+                                                           const float* __restrict__ Wdh, const float* __restrict__ bdh) {
     constexpr int TW = UGH_TW, TH = UGH_TH, CG = UGH_CG, CS = CG + 4;
     constexpr int W2 = TW + 4, H2 = TH + 4, W1 = TW + 2, H1 = TH + 2;
     static_assert(W1 * H1 == 256, "one halo position per thread");
@@ -635,14 +637,14 @@ __global__ __launch_bounds__(256) void upghost_head_kernel(const UpGhostHeadPara
         if (inside) {
             float f[2 * CG];
             ACH_UNROLL
-            for (int c = 0; c < CG; ++c) f[CG + c] = p.bdw[c];
+            for (int c = 0; c < CG; ++c) f[CG + c] = bdw[c];
             ACH_UNROLL
             for (int k = 0; k < 9; ++k) {
                 const float* s = x1s + ((ly_ + k / 3) * W2 + lx_ + k % 3) * CS;     // 2-halo coords of the tap
                 ACH_UNROLL
                 for (int c4 = 0; c4 < CG; c4 += 4) {
                     const float4 sv = *reinterpret_cast<const float4*>(s + c4);
-                    const float* wk = p.Wdw + k * CG + c4;
+                    const float* wk = Wdw + k * CG + c4;
                     f[CG + c4] += sv.x * wk[0]; f[CG + c4 + 1] += sv.y * wk[1]; f[CG + c4 + 2] += sv.z * wk[2]; f[CG + c4 + 3] += sv.w * wk[3];
                     if (k == 4) { f[c4] = sv.x; f[c4 + 1] = sv.y; f[c4 + 2] = sv.z; f[c4 + 3] = sv.w; }
                 }
@@ -656,12 +658,13 @@ __global__ __launch_bounds__(256) void upghost_head_kernel(const UpGhostHeadPara
             }
             ACH_UNROLL
             for (int j = 0; j < UGH_IMAX; ++j)
-                if (j < p.init) {
-                    const float* w = p.Wh + j * 2 * CG;
-                    float a = p.bh[j];
+                if (j < p.init) {                                   // two packed partial sums per output channel (v_pk_fma_f32)
+                    const float* w = Wh + j * 2 * CG;
+                    f32x2 a = {bh[j], 0.f};
                     ACH_UNROLL
-                    for (int c = 0; c < 2 * CG; ++c) a += w[c] * f[c];
-                    hv[j] = a > 0.f ? a : 0.f;
+                    for (int c = 0; c < 2 * CG; c += 2) { const f32x2 wv = {w[c], w[c + 1]}, fv = {f[c], f[c + 1]}; a += wv * fv; }
+                    const float r = a[0] + a[1];
+                    hv[j] = r > 0.f ? r : 0.f;
                 }
         }
         ACH_UNROLL
@@ -674,9 +677,9 @@ __global__ __launch_bounds__(256) void upghost_head_kernel(const UpGhostHeadPara
     T* out = static_cast<T*>(p.out) + b * p.oup * HW + long(oy) * Wd + ox;
     for (int j = 0; j < p.init && j < p.oup; ++j) Store<T>::st(out + j * HW, hs[j][tid]);
     for (int j = 0; j < p.nch; ++j) {
-        float a = p.bdh[j];
+        float a = bdh[j];
         ACH_UNROLL
-        for (int k = 0; k < 9; ++k) a += hs[j][(ly_ - 1 + k / 3) * W1 + lx_ - 1 + k % 3] * p.Wdh[k * p.nch + j];
+        for (int k = 0; k < 9; ++k) a += hs[j][(ly_ - 1 + k / 3) * W1 + lx_ - 1 + k % 3] * Wdh[k * p.nch + j];
         Store<T>::st(out + (p.init + j) * HW, a > 0.f ? a : 0.f);
     }
 }

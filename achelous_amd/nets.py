@@ -62,6 +62,7 @@ class Achelous(nn.Module):
         self._engines = {}          # (device index, dtype) -> [NativeEngine, weight version, num_points]
         self.debug_taps = False     # True: the engine also materialises every SURVEY §8(a) boundary (parity tests)
         self.static_weights = False  # True: skip the per-call check for in-place weight changes (serving loops)
+        self.engine_options = {}    # ach_set_option(key, value) pairs applied when an engine is created (include/achelous.h)
 
     # engines hold ctypes handles: never pickle / deepcopy them (utils_fit.py:378 pickles the module, ModelEMA deep-copies it)
     def __getstate__(self):
@@ -109,6 +110,8 @@ class Achelous(nn.Module):
                                     pc_classes=self.pc_classes, num_points=num_points, nano_head=self.nano_head,
                                     spp=self.spp, dtype=code)
             eng.set_option('full_taps', 1 if self.debug_taps else 0)
+            for k, v in self.engine_options.items():
+                eng.set_option(k, int(v))
             ent = [eng, None, num_points]
             self._engines[key] = ent
         if ent[1] != ver:

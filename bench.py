@@ -52,6 +52,7 @@ def main():
     ap.add_argument('--iou', type=float, default=0.35)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=8, help='frames in the CPU-baseline sample')
+    ap.add_argument('--opt', action='append', default=[], help='engine option key=value (ach_set_option), repeatable')
     ap.add_argument('--ops-json', default=None, help='write the per-launch table (ms, algorithmic bytes) here')
     args = ap.parse_args()
 
@@ -77,6 +78,7 @@ def main():
     model.load_state_dict(condition_state_dict(model.state_dict(), seed=0))
     model = model.to(dev)
     model.static_weights = True          # serving loop: weights do not change between steps
+    model.engine_options = {kv.split('=')[0]: int(kv.split('=')[1]) for kv in args.opt}
     B = args.batch
     x, xr, xp = make_inputs(B, config_seed(cid) + 1000 * rank, resolution=COMMON['resolution'], pc_channels=COMMON['pc_channels'])
     x, xr, xp = x.to(dev, tdt), xr.to(dev, tdt), xp.to(dev, tdt)
