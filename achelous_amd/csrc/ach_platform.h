@@ -39,7 +39,10 @@ __host__ __device__ __forceinline__ float bf16_to_f32(uint16_t b) {
     c.u = uint32_t(b) << 16;
     return c.f;
 }
-__host__ __device__ __forceinline__ uint16_t f32_to_bf16(float f) {   // round to nearest even
+// round to nearest even.  On the device this is gfx950's v_cvt_pk_bf16_f32 (one instruction per PAIR of values; the integer
+// sequence below costs five per value and bf16 packing sits in every kernel's epilogue); the host packers and the CPU
+// emulation of the kernels use the integer form, which rounds identically.
+__host__ __device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
     union { uint32_t u; float f; } c;
     c.f = f;
     uint32_t u = c.u;
@@ -47,6 +50,20 @@ __host__ __device__ __forceinline__ uint16_t f32_to_bf16(float f) {   // round t
     u += 0x7fffu + ((u >> 16) & 1u);
     return uint16_t(u >> 16);
 }
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __bf16 bf16x2_hw __attribute__((ext_vector_type(2)));
+typedef float f32x2_hw __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    const f32x2_hw v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_hw));
+}
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) { return __builtin_bit_cast(uint16_t, static_cast<__bf16>(f)); }
+#else
+__host__ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return uint32_t(f32_to_bf16_bits(lo)) | (uint32_t(f32_to_bf16_bits(hi)) << 16);
+}
+__host__ __device__ __forceinline__ uint16_t f32_to_bf16(float f) { return f32_to_bf16_bits(f); }
+#endif
 
 template <class T> struct Store;
 template <> struct Store<float> {
@@ -83,8 +100,8 @@ template <> struct Store<bf16_t> {
     }
     __device__ static __forceinline__ void st4(bf16_t* p, const float (&i)[4]) {
         uint2 v;
-        v.x = uint32_t(f32_to_bf16(i[0])) | (uint32_t(f32_to_bf16(i[1])) << 16);
-        v.y = uint32_t(f32_to_bf16(i[2])) | (uint32_t(f32_to_bf16(i[3])) << 16);
+        v.x = pack_bf16x2(i[0], i[1]);
+        v.y = pack_bf16x2(i[2], i[3]);
         *reinterpret_cast<uint2*>(p) = v;
     }
     // 8 consecutive elements (16 B aligned)
@@ -95,7 +112,7 @@ template <> struct Store<bf16_t> {
     }
     __device__ static __forceinline__ void st8(bf16_t* p, const float (&i)[8]) {
         uint32_t w[4];
-        for (int k = 0; k < 4; ++k) w[k] = uint32_t(f32_to_bf16(i[2 * k])) | (uint32_t(f32_to_bf16(i[2 * k + 1])) << 16);
+        for (int k = 0; k < 4; ++k) w[k] = pack_bf16x2(i[2 * k], i[2 * k + 1]);
         *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
     }
 };
@@ -117,7 +134,7 @@ template <> __device__ __forceinline__ uint4 frag_pack<float>(const float* i) {
 template <> __device__ __forceinline__ uint4 frag_pack<bf16_t>(const float* i) {
     uint32_t w[4];
     ACH_UNROLL
-    for (int k = 0; k < 4; ++k) w[k] = uint32_t(f32_to_bf16(i[2 * k])) | (uint32_t(f32_to_bf16(i[2 * k + 1])) << 16);
+    for (int k = 0; k < 4; ++k) w[k] = pack_bf16x2(i[2 * k], i[2 * k + 1]);
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
