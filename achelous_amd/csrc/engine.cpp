@@ -13,6 +13,7 @@
 #include <cstring>
 
 #include "k_detect.h"
+#include "k_conv3.h"
 #include "k_gemm.h"
 #include "k_mlp.h"
 #include "k_mvit.h"
@@ -920,6 +921,21 @@ public:
         const int pad = k / 2;
         const int Ho = (x.H + 2 * pad - k) / stride + 1, Wo = (x.W + 2 * pad - k) / stride + 1;
         A y = alloc(x.B, Ho, Wo, l.N);
+        // narrow 3x3 / s1 convs with 25..32 outputs (the offset + modulator convs): row-walking kernel, k_conv3.h
+        {
+            const int cv = int(x.ld) / VEC, ks = cdiv(9 * cv, 4);
+            if (row_conv && k == 3 && stride == 1 && !residual && l.N > 24 && l.N <= 32 && y.ld == 32 && x.ld % VEC == 0 && (ks == 3 || ks == 5 || ks == 9)) {
+                Packed pk = pack(l);
+                if (pk.NT == 2 && pk.nchunks == 1 && pk.ksteps == ks) {
+                    std::vector<float> b32(32, 0.f);
+                    for (int n = 0; n < l.N; ++n) b32[n] = l.b[n];
+                    Conv3Params cp{x.p, x.ld, y.p, y.ld, pk.w, up_f32(b32), x.B, x.H, x.W, cv, act};
+                    const double bytes = double(x.rows()) * x.ld * sizeof(T) + double(y.rows()) * y.ld * sizeof(T);
+                    add_op(name, [cp, ks](hipStream_t s) { launch_conv3<T>(cp, ks, s); }, bytes, 2.0 * double(y.rows()) * l.K * l.N);
+                    return y;
+                }
+            }
+        }
         GemmOpt o; o.act = act; o.residual = residual;
         o.conv_k = k; o.conv_s = stride; o.conv_p = pad; o.Hin = x.H; o.Win = x.W; o.Cin = int(x.ld); o.Ho = Ho; o.Wo = Wo;
         gemm(name, x.p, x.ld, y.rows(), pack(l), y.p, y.ld, o);
