@@ -921,24 +921,38 @@ public:
         const int pad = k / 2;
         const int Ho = (x.H + 2 * pad - k) / stride + 1, Wo = (x.W + 2 * pad - k) / stride + 1;
         A y = alloc(x.B, Ho, Wo, l.N);
-        // narrow 3x3 / s1 convs with 25..32 outputs (the offset + modulator convs): row-walking kernel, k_conv3.h
-        {
-            const int cv = int(x.ld) / VEC, ks = cdiv(9 * cv, 4);
-            if (row_conv && k == 3 && stride == 1 && !residual && l.N > 24 && l.N <= 32 && y.ld == 32 && x.ld % VEC == 0 && (ks == 3 || ks == 5 || ks == 9)) {
-                Packed pk = pack(l);
-                if (pk.NT == 2 && pk.nchunks == 1 && pk.ksteps == ks) {
-                    std::vector<float> b32(32, 0.f);
-                    for (int n = 0; n < l.N; ++n) b32[n] = l.b[n];
-                    Conv3Params cp{x.p, x.ld, y.p, y.ld, pk.w, up_f32(b32), x.B, x.H, x.W, cv, act};
-                    const double bytes = double(x.rows()) * x.ld * sizeof(T) + double(y.rows()) * y.ld * sizeof(T);
-                    add_op(name, [cp, ks](hipStream_t s) { launch_conv3<T>(cp, ks, s); }, bytes, 2.0 * double(y.rows()) * l.K * l.N);
-                    return y;
-                }
-            }
-        }
         GemmOpt o; o.act = act; o.residual = residual;
         o.conv_k = k; o.conv_s = stride; o.conv_p = pad; o.Hin = x.H; o.Win = x.W; o.Cin = int(x.ld); o.Ho = Ho; o.Wo = Wo;
         gemm(name, x.p, x.ld, y.rows(), pack(l), y.p, y.ld, o);
+        return y;
+    }
+    // NHWC tensor with a one-pixel zero border around every sample (the arena is zeroed when the plan is built and the border is
+    // never written): p0 = pixel (0,0) of sample 0
+    struct Bordered { T* p0 = nullptr; T* base = nullptr; int B = 0, H = 0, W = 0, C = 0; long ld = 0, row = 0, img = 0; };
+    Bordered alloc_bordered(int B, int H, int W, int C) {
+        Bordered t; t.B = B; t.H = H; t.W = W; t.C = C; t.ld = round_up(C, 8);
+        t.row = long(W + 2) * t.ld; t.img = long(H + 2) * t.row;
+        t.base = static_cast<T*>(aalloc(size_t(B) * t.img * sizeof(T)));
+        t.p0 = t.base + t.row + t.ld;
+        return t;
+    }
+    // 3x3 / stride 1 / pad 1 conv of a bordered tensor with 25..32 outputs (the offset + modulator convs of the RCBlocks)
+    A conv3_bordered(const std::string& name, const Bordered& x, const Lin& l, int act) {
+        A y = alloc(x.B, x.H, x.W, l.N);
+        const int cv = int(x.ld) / VEC, ks = cdiv(9 * cv, 4);
+        Packed pk = pack(l);
+        const double bytes = double(x.B) * x.H * x.W * x.ld * sizeof(T) + double(y.rows()) * y.ld * sizeof(T);
+        if (row_conv && l.N > 24 && l.N <= 32 && y.ld == 32 && (ks == 3 || ks == 5 || ks == 9) && pk.NT == 2 && pk.nchunks == 1 && pk.ksteps == ks) {
+            std::vector<float> b32(32, 0.f);
+            for (int n = 0; n < l.N; ++n) b32[n] = l.b[n];
+            Conv3Params cp{x.p0, x.ld, x.row, x.img, y.p, y.ld, pk.w, up_f32(b32), x.B, x.H, x.W, cv, act};
+            add_op(name, [cp, ks](hipStream_t s) { launch_conv3<T>(cp, ks, s); }, bytes, 2.0 * double(y.rows()) * l.K * l.N);
+            return y;
+        }
+        // generic implicit GEMM: the bordered buffer is a dense [B, H+2, W+2, ld] tensor convolved without padding
+        GemmOpt o; o.act = act;
+        o.conv_k = 3; o.conv_s = 1; o.conv_p = 0; o.Hin = x.H + 2; o.Win = x.W + 2; o.Cin = int(x.ld); o.Ho = x.H; o.Wo = x.W;
+        gemm(name, x.base, x.ld, y.rows(), pk, y.p, y.ld, o);
         return y;
     }
     void rcnet(A outs[3]) {                                                      // RadarEncoder.py:38-109
@@ -959,14 +973,14 @@ public:
             const std::string d = pfx + ".radar_conv.deformable_conv";
             const int C = chans[i], Cp = int(x.ld);
             // AvgPool2d(3,1,1)
-            A pooled = alloc(B, x.H, x.W, C);
-            { PoolParams pp{x.p, x.ld, pooled.p, pooled.ld, B, x.H, x.W, C}; ew(pfx + ".avgpool", avgpool3x3_kernel<T>, pp, x.rows() * ((C + 3) / 4), 2.0 * x.rows() * Cp * sizeof(T)); }
+            Bordered pooled = alloc_bordered(B, x.H, x.W, C);
+            { PoolParams pp{x.p, x.ld, pooled.p0, pooled.ld, B, x.H, x.W, C, pooled.row, pooled.img}; ew(pfx + ".avgpool", avgpool3x3_kernel<T>, pp, x.rows() * ((C + 3) / 4), 2.0 * x.rows() * Cp * sizeof(T)); }
             // offset_conv (18) + modulator_conv (9) as one implicit GEMM
             Lin lo = conv_lin(d + ".offset_conv.weight", d + ".offset_conv.bias", C, Cp, 3);
             Lin lm = conv_lin(d + ".modulator_conv.weight", d + ".modulator_conv.bias", C, Cp, 3);
             if (lo.N != 18 || lm.N != 9) throw AchError{ACH_ERR_MISSING_KEY, "deformable conv shapes at " + d};
             Lin lom; lom.N = 27; lom.K = lo.K; lom.w = lo.w; lom.w.insert(lom.w.end(), lm.w.begin(), lm.w.end()); lom.b = lo.b; lom.b.insert(lom.b.end(), lm.b.begin(), lm.b.end());
-            A om = conv_gemm(pfx + ".offmask", pooled, lom, 3, 1, ACT_NONE);
+            A om = conv3_bordered(pfx + ".offmask", pooled, lom, ACT_NONE);
             // regular_conv (no bias) folded with weight_conv1 (bias) and BatchNorm:  Wf[co][k][c] = sum_m W1'[co][m] Wd3[m][c][k]
             std::vector<float> sc, sh; bn_coeffs(pfx + ".norm", 1e-5, sc, sh);
             const HostTensor& w1 = W(pfx + ".weight_conv1.weight"); const HostTensor& b1 = W(pfx + ".weight_conv1.bias");
@@ -985,15 +999,15 @@ public:
             A y;
             DeformParams dp;
             std::memset(&dp, 0, sizeof(dp));
-            dp.pooled = pooled.p; dp.ldp = pooled.ld; dp.om = om.p; dp.ldo = om.ld; dp.res = x.p; dp.ldr = x.ld;
+            dp.pooled = pooled.p0; dp.ldp = pooled.ld; dp.prow = pooled.row; dp.pimg = pooled.img; dp.om = om.p; dp.ldo = om.ld; dp.res = x.p; dp.ldr = x.ld;
             dp.B = B; dp.H = x.H; dp.Wd = x.W; dp.Cp = Cp;
             if (Cp == 8 && (C == 3 || C == 8)) {
                 y = alloc(B, x.H, x.W, C);
                 dp.Y = y.p; dp.ldy = y.ld; dp.Wf = up_f32(lf.w); dp.bf = up_f32(lf.b);
                 const dim3 grid(unsigned(cdivl(x.rows(), 256))), block(256);
                 const double bytes = double(x.rows()) * (3.0 * Cp + 32) * sizeof(T);
-                if (C == 3) add_op(pfx + ".deform", [dp, grid, block](hipStream_t s) { ACH_LAUNCH((deform_fused_kernel<T, 3, 4>), grid, block, s, dp); }, bytes);   // 3 channels: one 4-vector per corner
-                else add_op(pfx + ".deform", [dp, grid, block](hipStream_t s) { ACH_LAUNCH((deform_fused_kernel<T, 8, 8>), grid, block, s, dp); }, bytes);
+                if (C == 3) add_op(pfx + ".deform", [dp, grid, block](hipStream_t s) { ACH_LAUNCH((deform_fused_kernel<T, 3, 4>), grid, block, s, dp, dp.Wf, dp.bf); }, bytes);   // 3 channels: one 4-vector per corner
+                else add_op(pfx + ".deform", [dp, grid, block](hipStream_t s) { ACH_LAUNCH((deform_fused_kernel<T, 8, 8>), grid, block, s, dp, dp.Wf, dp.bf); }, bytes);
             } else {
                 A col = alloc(B, x.H, x.W, 9 * Cp);
                 dp.Y = col.p; dp.ldy = col.ld;

@@ -6,7 +6,8 @@
 // (64-bit divisions to recover (b, y, x) from the row index, tap decoding per k-step, weight fragment loads) for six MFMAs:
 // rocprofv3 showed it VALU-issue bound at 1.4 TB/s.  Here a workgroup owns one output ROW: (b, y) come from the workgroup id
 // (scalar), the tap geometry of a lane's k-slots is computed once, the weight fragments stay in registers, and each wave
-// walks the row 16 pixels at a time — per tile only the loads, MFMAs and one wide store remain.
+// walks the row 16 pixels at a time — per tile only the loads, MFMAs and one wide store remain.  The input carries a
+// one-pixel zero border in memory (its producer, avgpool3x3, writes into such a buffer), so there is no bounds logic either.
 // K is ordered (tap, channel vector) exactly as conv_lin packs it, so the weights are the ones gemm_kernel would use.
 #pragma once
 #include "ach_platform.h"
@@ -15,7 +16,8 @@
 namespace ach {
 
 struct Conv3Params {
-    const void* X; long ldx;        // NHWC input [B,H,W,ldx], ldx = cv * VEC
+    const void* X; long ldx;        // NHWC input, ldx = cv * VEC, with a one-pixel ZERO BORDER around every sample: X is pixel (0,0) of
+    long xpr, xpi;                  //   sample 0, xpr / xpi the row / image pitches in elements — the conv's zero padding is in memory
     void* Y; long ldy;              // NHWC output [B,H,W,ldy], ldy >= 32
     const void* W; const float* bias;   // packed NT = 2, one chunk, KS k-steps ; bias[32]
     int B, H, Wd, cv, act;
@@ -30,17 +32,15 @@ __global__ __launch_bounds__(256) void conv3x3_rows_kernel(const Conv3Params p) 
     const int b = int(wg / unsigned(p.H)), oy = int(wg - unsigned(b) * unsigned(p.H));
     const int ldx = int(p.ldx);
 
-    int off[KS], dx[KS];
-    bool rowok[KS];
+    int off[KS];
+    bool live[KS];
     ACH_UNROLL
     for (int s = 0; s < KS; ++s) {
         const int q = 4 * s + g;
         const int tap = q / p.cv, c = q - tap * p.cv;
         const int ty = tap / 3, tx = tap - 3 * ty;
-        const int iy = oy + ty - 1;
-        rowok[s] = tap < 9 && iy >= 0 && iy < p.H;
-        dx[s] = tx - 1;
-        off[s] = ((ty - 1) * p.Wd + (tx - 1)) * ldx + c * VEC;
+        live[s] = tap < 9;                                             // k-slots past the ninth tap: zero weights, but keep the address in bounds
+        off[s] = live[s] ? (ty - 1) * int(p.xpr) + (tx - 1) * ldx + c * VEC : 0;
     }
     const uint4* Wf = static_cast<const uint4*>(p.W) + lane;
     uint4 wf[KS][2];
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void conv3x3_rows_kernel(const Conv3Params p) 
     ACH_UNROLL
     for (int i = 0; i < 8; ++i) bv[i] = p.bias[g * 8 + i];
 
-    const T* xrow = static_cast<const T*>(p.X) + (long(b) * p.H + oy) * p.Wd * p.ldx;
+    const T* xrow = static_cast<const T*>(p.X) + long(b) * p.xpi + long(oy) * p.xpr;
     T* yrow = static_cast<T*>(p.Y) + (long(b) * p.H + oy) * p.Wd * p.ldy + g * 8;
     for (int tile = wave; tile * 16 < p.Wd; tile += 4) {
         const int xr = tile * 16 + px;
@@ -59,12 +59,7 @@ __global__ __launch_bounds__(256) void conv3x3_rows_kernel(const Conv3Params p) 
         const T* xp = xrow + long(x) * ldx;
         uint4 xf[KS];
         ACH_UNROLL
-        for (int s = 0; s < KS; ++s) {
-            const int ix = x + dx[s];
-            const bool ok = valid && rowok[s] && ix >= 0 && ix < p.Wd;
-            const uint4 v = *reinterpret_cast<const uint4*>(ok ? xp + off[s] : xp);    // always an in-bounds address
-            xf[s] = make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
-        }
+        for (int s = 0; s < KS; ++s) xf[s] = *reinterpret_cast<const uint4*>(xp + off[s]);
         f32x4 a0, a1;
         a0[0] = a0[1] = a0[2] = a0[3] = 0.f;
         a1[0] = a1[1] = a1[2] = a1[3] = 0.f;

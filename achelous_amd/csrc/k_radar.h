@@ -31,7 +31,9 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const ToNhwcParams p)
 }
 
 // AvgPool2d(3, stride 1, pad 1, count_include_pad=True): always divides by 9
-struct PoolParams { const void* X; long ldx; void* Y; long ldy; int B, H, Wd, C; };
+// The output goes to a buffer with a one-pixel ZERO BORDER around every sample (Y points at pixel (0,0) of sample 0, ypr / ypi are
+// its row / image pitches in elements): the 3x3 conv and the deformable sampling that read it need no bounds logic at all.
+struct PoolParams { const void* X; long ldx; void* Y; long ldy; int B, H, Wd, C; long ypr, ypi; };
 template <class T>
 __global__ __launch_bounds__(256) void avgpool3x3_kernel(const PoolParams p) {
     const int cq = (p.C + 3) >> 2;
@@ -61,35 +63,33 @@ __global__ __launch_bounds__(256) void avgpool3x3_kernel(const PoolParams p) {
     }
     ACH_UNROLL
     for (int i = 0; i < 4; ++i) acc[i] *= (1.0f / 9.0f);
-    Store<T>::st4(static_cast<T*>(p.Y) + ((b * p.H + y) * p.Wd + x) * p.ldy + c, acc);
+    Store<T>::st4(static_cast<T*>(p.Y) + b * p.ypi + y * p.ypr + x * p.ldy + c, acc);
 }
 
-// ---- shared by both deformable kernels: one tap's bilinear footprint (zero outside, torchvision semantics)
+// ---- shared by both deformable kernels: one tap's bilinear footprint (torchvision 0.12.0 deform_conv2d semantics:
+// a sample at or beyond -1 / H (W) is 0, corners outside the map contribute 0).  The sampled tensor carries a one-pixel zero
+// border, so clamping the coordinate to [-1, H] and the top-left corner to [-1, H-1] reproduces exactly that with no
+// validity logic: out-of-range samples land on border pixels and/or get weight 0.
 struct BilinearTap {
-    long o00, o01, o10, o11;      // pixel indices of the four corners (clamped into the map)
-    float w00, w01, w10, w11;     // bilinear weights, already 0 for corners outside the map and multiplied by the mask
+    int o0, o1;                   // element offsets (relative to the sample's pixel (0,0)) of the top-left / bottom-left corners
+    float w00, w01, w10, w11;     // bilinear weights multiplied by the modulation mask
 };
-__device__ __forceinline__ BilinearTap make_tap(float sy, float sx, float mask, int H, int Wd, long base) {
+__device__ __forceinline__ BilinearTap make_tap(float sy, float sx, float mask, int H, int Wd, int prow, int ld) {
     BilinearTap t;
-    const bool inside = sy > -1.f && sy < float(H) && sx > -1.f && sx < float(Wd);
-    const float fy = floorf(sy), fx = floorf(sx);
-    const int y0 = int(fy), x0 = int(fx), y1 = y0 + 1, x1 = x0 + 1;
-    const float ly = sy - fy, lx = sx - fx, hy = 1.f - ly, hx = 1.f - lx;
-    const float m = inside ? mask : 0.f;
-    const bool oy0 = y0 >= 0 && y0 <= H - 1, oy1 = y1 >= 0 && y1 <= H - 1, ox0 = x0 >= 0 && x0 <= Wd - 1, ox1 = x1 >= 0 && x1 <= Wd - 1;
-    t.w00 = (oy0 && ox0) ? hy * hx * m : 0.f;
-    t.w01 = (oy0 && ox1) ? hy * lx * m : 0.f;
-    t.w10 = (oy1 && ox0) ? ly * hx * m : 0.f;
-    t.w11 = (oy1 && ox1) ? ly * lx * m : 0.f;
-    const int cy0 = y0 < 0 ? 0 : (y0 > H - 1 ? H - 1 : y0), cy1 = y1 < 0 ? 0 : (y1 > H - 1 ? H - 1 : y1);
-    const int cx0 = x0 < 0 ? 0 : (x0 > Wd - 1 ? Wd - 1 : x0), cx1 = x1 < 0 ? 0 : (x1 > Wd - 1 ? Wd - 1 : x1);
-    t.o00 = base + long(cy0) * Wd + cx0; t.o01 = base + long(cy0) * Wd + cx1;
-    t.o10 = base + long(cy1) * Wd + cx0; t.o11 = base + long(cy1) * Wd + cx1;
+    const float cy = fminf(fmaxf(sy, -1.f), float(H)), cx = fminf(fmaxf(sx, -1.f), float(Wd));
+    const float fy = fminf(floorf(cy), float(H - 1)), fx = fminf(floorf(cx), float(Wd - 1));
+    const float ly = cy - fy, lx = cx - fx;
+    const float hym = (1.f - ly) * mask, lym = ly * mask, hx = 1.f - lx;
+    t.w00 = hym * hx; t.w01 = hym * lx; t.w10 = lym * hx; t.w11 = lym * lx;
+    t.o0 = int(fy) * prow + int(fx) * ld;
+    t.o1 = t.o0 + prow;
     return t;
 }
+__device__ __forceinline__ float modulation(float logit) { return 2.0f * fast_rcp(1.0f + fast_exp2(-1.44269504f * logit)); }   // 2 sigmoid
 
 struct DeformParams {
-    const void* pooled; long ldp;     // sampled tensor (avg-pooled block input), NHWC
+    const void* pooled; long ldp;     // sampled tensor (avg-pooled block input), NHWC with a zero border: pixel (0,0) of sample 0,
+    long prow, pimg;                  //   row / image pitches in elements
     const void* om; long ldo;         // [pixels, 27]: 18 offsets (dy,dx per tap) + 9 modulator logits
     const void* res; long ldr;        // block input (residual)
     void* Y; long ldy;                // fused: relu(Wf . col + bf) + res ; sample: the columns [pixels, 9*Cp]
@@ -98,9 +98,10 @@ struct DeformParams {
     int B, H, Wd, Cp;
 };
 
-// C <= 8: sampling + contraction + ReLU + residual in one pass, one thread per pixel
+// C <= 8: sampling + contraction + ReLU + residual in one pass, one thread per pixel.  CP = channels fetched per corner (4 or 8).
+// The folded weights are wave-uniform: passed as __restrict__ kernel arguments so they are fetched with scalar loads.
 template <class T, int C, int CP>
-__global__ __launch_bounds__(256) void deform_fused_kernel(const DeformParams p) {
+__global__ __launch_bounds__(256) void deform_fused_kernel(const DeformParams p, const float* __restrict__ Wf, const float* __restrict__ bf) {
     const long total = long(p.B) * p.H * p.Wd;
     const long idx = long(xcd_block(blockIdx.x, gridDim.x)) * blockDim.x + threadIdx.x;
     if (idx >= total) return;
@@ -108,39 +109,49 @@ __global__ __launch_bounds__(256) void deform_fused_kernel(const DeformParams p)
     const int y = int((idx / p.Wd) % p.H);
     const long b = idx / (long(p.Wd) * p.H);
     const T* om = static_cast<const T*>(p.om) + idx * p.ldo;
-    float o[28];
+    float o[32];
     ACH_UNROLL
-    for (int i = 0; i < 7; ++i) { float v[4]; Store<T>::ld4(om + i * 4, v); o[i * 4] = v[0]; o[i * 4 + 1] = v[1]; o[i * 4 + 2] = v[2]; o[i * 4 + 3] = v[3]; }
-    const T* P0 = static_cast<const T*>(p.pooled);
-    float acc[C];
+    for (int i = 0; i < 4; ++i) {
+        float v[8];
+        Store<T>::ld8(om + i * 8, v);                 // row stride 32: offsets 0..17, logits 18..26, padding
+        ACH_UNROLL
+        for (int j = 0; j < 8; ++j) o[i * 8 + j] = v[j];
+    }
+    const T* P = static_cast<const T*>(p.pooled) + b * p.pimg;
+    const int prow = int(p.prow), ld = int(p.ldp);
+    f32x2 acc[C];
     ACH_UNROLL
-    for (int i = 0; i < C; ++i) acc[i] = p.bf[i];
+    for (int i = 0; i < C; ++i) { acc[i][0] = bf[i]; acc[i][1] = 0.f; }
     ACH_UNROLL
     for (int k = 0; k < 9; ++k) {
-        const BilinearTap t = make_tap(float(y - 1 + k / 3) + o[2 * k], float(x - 1 + k % 3) + o[2 * k + 1],
-                                       2.0f * sigmoidf_(o[18 + k]), p.H, p.Wd, b * p.H * long(p.Wd));
-        float v[CP];
-        ACH_UNROLL
-        for (int c = 0; c < CP; c += 4) {
-            float a[4], bq[4], cc[4], d[4];
-            Store<T>::ld4(P0 + t.o00 * p.ldp + c, a);
-            Store<T>::ld4(P0 + t.o01 * p.ldp + c, bq);
-            Store<T>::ld4(P0 + t.o10 * p.ldp + c, cc);
-            Store<T>::ld4(P0 + t.o11 * p.ldp + c, d);
-            ACH_UNROLL
-            for (int i = 0; i < 4; ++i) v[c + i] = t.w00 * a[i] + t.w01 * bq[i] + t.w10 * cc[i] + t.w11 * d[i];
+        const BilinearTap t = make_tap(float(y - 1 + k / 3) + o[2 * k], float(x - 1 + k % 3) + o[2 * k + 1], modulation(o[18 + k]),
+                                       p.H, p.Wd, prow, ld);
+        float a[CP], bq[CP], cc[CP], d[CP];
+        if constexpr (CP == 8) {
+            Store<T>::ld8(P + t.o0, a);  Store<T>::ld8(P + t.o0 + ld, bq);
+            Store<T>::ld8(P + t.o1, cc); Store<T>::ld8(P + t.o1 + ld, d);
+        } else {
+            Store<T>::ld4(P + t.o0, a);  Store<T>::ld4(P + t.o0 + ld, bq);
+            Store<T>::ld4(P + t.o1, cc); Store<T>::ld4(P + t.o1 + ld, d);
         }
-        const float* w = p.Wf + k * p.Cp;                         // host layout [C][9][Cp], Cp = channel stride of the buffers
+        f32x2 v[CP / 2];
+        const f32x2 w00 = {t.w00, t.w00}, w01 = {t.w01, t.w01}, w10 = {t.w10, t.w10}, w11 = {t.w11, t.w11};
+        ACH_UNROLL
+        for (int c = 0; c < CP / 2; ++c) {
+            const f32x2 av = {a[2 * c], a[2 * c + 1]}, bv = {bq[2 * c], bq[2 * c + 1]}, cv = {cc[2 * c], cc[2 * c + 1]}, dv = {d[2 * c], d[2 * c + 1]};
+            v[c] = w00 * av + w01 * bv + w10 * cv + w11 * dv;
+        }
+        const float* w = Wf + k * p.Cp;                           // host layout [C][9][Cp], Cp = channel stride of the buffers (zero beyond C)
         ACH_UNROLL
         for (int co = 0; co < C; ++co)
             ACH_UNROLL
-            for (int c = 0; c < C; ++c) acc[co] += w[co * 9 * p.Cp + c] * v[c];
+            for (int c = 0; c < CP / 2; ++c) { const f32x2 wv = {w[co * 9 * p.Cp + 2 * c], w[co * 9 * p.Cp + 2 * c + 1]}; acc[co] += wv * v[c]; }
     }
     float outv[CP];
     ACH_UNROLL
     for (int i = 0; i < CP; ++i) outv[i] = 0.f;
     ACH_UNROLL
-    for (int i = 0; i < C; ++i) outv[i] = acc[i] > 0.f ? acc[i] : 0.f;
+    for (int i = 0; i < C; ++i) { const float r = acc[i][0] + acc[i][1]; outv[i] = r > 0.f ? r : 0.f; }
     const T* r = static_cast<const T*>(p.res) + idx * p.ldr;
     T* yo = static_cast<T*>(p.Y) + idx * p.ldy;
     ACH_UNROLL
@@ -169,13 +180,14 @@ __global__ __launch_bounds__(256) void deform_sample_kernel(const DeformParams p
     const long b = pix / (long(p.Wd) * p.H);
     const T* om = static_cast<const T*>(p.om) + pix * p.ldo;
     const float dy = Store<T>::ld(om + 2 * k), dx = Store<T>::ld(om + 2 * k + 1), ml = Store<T>::ld(om + 18 + k);
-    const BilinearTap t = make_tap(float(y - 1 + k / 3) + dy, float(x - 1 + k % 3) + dx, 2.0f * sigmoidf_(ml), p.H, p.Wd, b * p.H * long(p.Wd));
-    const T* P0 = static_cast<const T*>(p.pooled);
+    const int ld = int(p.ldp);
+    const BilinearTap t = make_tap(float(y - 1 + k / 3) + dy, float(x - 1 + k % 3) + dx, modulation(ml), p.H, p.Wd, int(p.prow), ld);
+    const T* P = static_cast<const T*>(p.pooled) + b * p.pimg + c;
     float a[4], bq[4], cc[4], d[4], v[4];
-    Store<T>::ld4(P0 + t.o00 * p.ldp + c, a);
-    Store<T>::ld4(P0 + t.o01 * p.ldp + c, bq);
-    Store<T>::ld4(P0 + t.o10 * p.ldp + c, cc);
-    Store<T>::ld4(P0 + t.o11 * p.ldp + c, d);
+    Store<T>::ld4(P + t.o0, a);
+    Store<T>::ld4(P + t.o0 + ld, bq);
+    Store<T>::ld4(P + t.o1, cc);
+    Store<T>::ld4(P + t.o1 + ld, d);
     ACH_UNROLL
     for (int i = 0; i < 4; ++i) v[i] = t.w00 * a[i] + t.w01 * bq[i] + t.w10 * cc[i] + t.w11 * d[i];
     Store<T>::st4(static_cast<T*>(p.Y) + pix * p.ldy + k * p.Cp + c, v);
