@@ -184,6 +184,25 @@ template <> __device__ __forceinline__ void mfma16<float>(const uint4& a, const 
 }
 #endif
 
+// wave-level helpers for 64-bit masks (the CPU emulation goes through its shuffle)
+#if defined(ACH_HOSTEMU)
+__device__ inline unsigned long long wave_read64(unsigned long long v, int lane) { return __shfl(v, lane); }
+__device__ inline unsigned long long wave_ballot64(bool pred) {
+    unsigned long long bits = 0;
+    const int mine = pred ? 1 : 0;
+    for (int l = 0; l < 64; ++l) bits |= (unsigned long long)(__shfl(mine, l)) << l;
+    return bits;
+}
+__device__ inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+__device__ inline int __ffsll(long long v) { return __builtin_ffsll(v); }
+#else
+__device__ __forceinline__ unsigned long long wave_read64(unsigned long long v, int lane) {
+    const unsigned lo = __builtin_amdgcn_readlane(unsigned(v), lane), hi = __builtin_amdgcn_readlane(unsigned(v >> 32), lane);
+    return (unsigned long long)(hi) << 32 | lo;
+}
+__device__ __forceinline__ unsigned long long wave_ballot64(bool pred) { return __ballot(pred); }
+#endif
+
 // max over each row of 16 lanes (all 16 lanes receive it): four DPP VALU ops instead of four LDS-routed shuffles.
 // quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror pair up lanes / quads / halves of the row.
 #if defined(ACH_HOSTEMU)

@@ -54,6 +54,18 @@ struct NmsParams {
     int B, A, NC5, num_classes, max_det; float conf, iou;
 };
 
+// IoU(bi, bj) > thr with bi the earlier (higher-score) box; every operation is a single correctly rounded fp32 op in the
+// oracle's order (oracle/nms.py), so the kept-index sequence is bit-exact
+__device__ __forceinline__ bool nms_overlaps(const float4& bi, float ai, const float4& bj, float thr) {
+    const float xx1 = fmaxf(bi.x, bj.x), yy1 = fmaxf(bi.y, bj.y);
+    const float xx2 = fminf(bi.z, bj.z), yy2 = fminf(bi.w, bj.w);
+    const float w = fmaxf(0.f, __fsub_rn(xx2, xx1)), h = fmaxf(0.f, __fsub_rn(yy2, yy1));
+    const float inter = __fmul_rn(w, h);
+    const float aj = __fmul_rn(__fsub_rn(bj.z, bj.x), __fsub_rn(bj.w, bj.y));
+    const float ovr = __fdiv_rn(inter, __fsub_rn(__fadd_rn(ai, aj), inter));
+    return ovr > thr;
+}
+
 constexpr int NMS_THREADS = 1024;
 constexpr int NMS_MAXA = 4096;
 
@@ -148,13 +160,47 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsParams p) {
         sbox[i] = make_float4(q[0], q[1], q[2], q[3]);
     }
     __syncthreads();
-    // ---- 5. greedy suppression in sorted order
-    if (tid == 0) s_n = 0;
-    __syncthreads();
-    for (int i = 0; i < n; ++i) {
-        if (supp[i] == 0) {                       // uniform: written before the previous barrier
-            if (tid == 0) {
-                const int slot = s_n;
+    // ---- 5. greedy suppression in sorted order, 64 candidates per round (three barriers per round instead of one per candidate):
+    //   a. all threads: the 64x64 "row suppresses column" bits inside the chunk (4 pairs per thread)
+    //   b. wave 0: lane l assembles row l's mask; the greedy pass over the chunk runs in registers (masks read lane by lane);
+    //      kept candidates write their output rows
+    //   c. all threads: every later, still-alive candidate is tested against the boxes the chunk kept
+    // A candidate is kept iff no EARLIER KEPT candidate overlaps it by more than the threshold — exactly the sequential rule.
+    __shared__ unsigned char pm[64][16];            // 4 pair bits per entry
+    __shared__ unsigned long long s_keep;
+    int kept_total = 0;                             // same value in every thread
+    for (int c0 = 0; c0 < n && kept_total < p.max_det; c0 += 64) {
+        {   // a.
+            const int row = tid >> 4, cb = (tid & 15) * 4;
+            const int i = c0 + row;
+            unsigned bits = 0;
+            if (i < n && supp[i] == 0) {
+                const float4 bi = sbox[i];
+                const float ai = __fmul_rn(__fsub_rn(bi.z, bi.x), __fsub_rn(bi.w, bi.y));
+                ACH_UNROLL
+                for (int e = 0; e < 4; ++e) {
+                    const int col = cb + e, j = c0 + col;
+                    if (col > row && j < n && nms_overlaps(bi, ai, sbox[j], p.iou)) bits |= 1u << e;
+                }
+            }
+            pm[row][tid & 15] = (unsigned char)bits;
+        }
+        __syncthreads();
+        if (tid < 64) {   // b.
+            const int i = c0 + tid;
+            const bool alive = i < n && supp[i] == 0;
+            unsigned long long m = 0;
+            ACH_UNROLL
+            for (int q = 0; q < 16; ++q) m |= (unsigned long long)(pm[tid][q]) << (4 * q);
+            const unsigned long long alive_bits = wave_ballot64(alive);
+            unsigned long long removed = ~alive_bits, keep = 0;
+            for (int l = 0; l < 64; ++l) {
+                const unsigned long long ml = wave_read64(m, l);
+                if (!((removed >> l) & 1ull)) { keep |= 1ull << l; removed |= ml; }
+            }
+            if (tid == 0) s_keep = keep;
+            if ((keep >> tid) & 1ull) {
+                const int slot = kept_total + __popcll(keep & ((1ull << tid) - 1ull));
                 if (slot < p.max_det) {
                     const int cand = order[i];
                     const float* q = sc + long(cand) * 8;
@@ -167,24 +213,27 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsParams p) {
                     r[4] = q[6]; r[5] = q[5]; r[6] = q[7];
                     p.kept[long(b) * p.max_det + slot] = a;
                 }
-                s_n = slot + 1;
             }
-            const float4 bi = sbox[i];
-            const float ai = __fmul_rn(__fsub_rn(bi.z, bi.x), __fsub_rn(bi.w, bi.y));
-            for (int j = i + 1 + tid; j < n; j += NMS_THREADS) {
-                if (supp[j]) continue;
-                const float4 bj = sbox[j];
-                const float xx1 = fmaxf(bi.x, bj.x), yy1 = fmaxf(bi.y, bj.y);
-                const float xx2 = fminf(bi.z, bj.z), yy2 = fminf(bi.w, bj.w);
-                const float w = fmaxf(0.f, __fsub_rn(xx2, xx1)), h = fmaxf(0.f, __fsub_rn(yy2, yy1));
-                const float inter = __fmul_rn(w, h);
-                const float aj = __fmul_rn(__fsub_rn(bj.z, bj.x), __fsub_rn(bj.w, bj.y));
-                const float ovr = __fdiv_rn(inter, __fsub_rn(__fadd_rn(ai, aj), inter));
-                if (ovr > p.iou) supp[j] = 1;
+        }
+        __syncthreads();
+        const unsigned long long keep = s_keep;
+        kept_total += __popcll(keep);
+        for (int j = c0 + 64 + tid; j < n; j += NMS_THREADS) {   // c.
+            if (supp[j]) continue;
+            const float4 bj = sbox[j];
+            unsigned long long k = keep;
+            while (k) {
+                const int l = __ffsll((long long)k) - 1;
+                k &= k - 1ull;
+                const float4 bi = sbox[c0 + l];
+                const float ai = __fmul_rn(__fsub_rn(bi.z, bi.x), __fsub_rn(bi.w, bi.y));
+                if (nms_overlaps(bi, ai, bj, p.iou)) { supp[j] = 1; break; }
             }
         }
         __syncthreads();
     }
+    if (tid == 0) s_n = kept_total;
+    __syncthreads();
     if (tid == 0) p.count[b] = s_n < p.max_det ? s_n : p.max_det;
 }
 

@@ -77,3 +77,12 @@ def test_emulated_decode_and_nms_match_oracle():
             assert k == len(exp[b][1]) and k > 0
             assert np.array_equal(idx[b, :k].numpy().astype(np.int64), exp[b][1])
             assert np.array_equal(rows[b, :k].numpy(), exp[b][0])
+        # truncated output (serving configuration): the first max_det kept detections, count clamped
+        rows = torch.zeros(2, 100, 7)
+        idx = torch.full((2, 100), -1, dtype=torch.int32)
+        h.nms(2, ref.contiguous(), conf, iou, 100, rows, idx, cnt, ws)
+        for b in range(2):
+            k = min(len(exp[b][1]), 100)
+            assert int(cnt[b]) == k
+            assert np.array_equal(idx[b, :k].numpy().astype(np.int64), exp[b][1][:k])
+            assert np.array_equal(rows[b, :k].numpy(), exp[b][0][:k])
