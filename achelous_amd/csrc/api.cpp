@@ -100,6 +100,31 @@ int ach_forward(ach_handle* h, const void* image, const void* radar, const void*
     });
 }
 
+int ach_forward_detect(ach_handle* h, const void* image, const void* radar, const void* points, void* det3, void* det4, void* det5,
+                       void* se_seg, void* lane_seg, void* pc_seg, float* decoded, float conf_thres, float nms_thres, int32_t max_det,
+                       float* out_rows, int32_t* out_idx, int32_t* out_count, void* workspace, void* stream) {
+    return guarded(h, [&] {
+        if (h->eng->ops.empty()) throw ach::AchError{ACH_ERR_INVALID, "ach_plan must precede ach_forward_detect"};
+        if (!image || !radar || !points || !det3 || !det4 || !det5 || !se_seg || !lane_seg || !pc_seg)
+            throw ach::AchError{ACH_ERR_INVALID, "null input/output pointer"};
+        if (max_det <= 0 || !decoded || !out_rows || !out_idx || !out_count || !workspace)
+            throw ach::AchError{ACH_ERR_INVALID, "bad detect arguments"};
+        ach::IoPtrs& io = h->eng->io;
+        io.image = image; io.radar = radar; io.points = points;
+        io.det[0] = det3; io.det[1] = det4; io.det[2] = det5; io.se = se_seg; io.lane = lane_seg; io.pc = pc_seg;
+        ach::EngineBase* e = h->eng;
+        const int B = e->batch;
+        e->detect_tail = [=](hipStream_t st) {
+            e->decode(B, det3, det4, det5, decoded, st);
+            e->nms(B, decoded, conf_thres, nms_thres, max_det, out_rows, out_idx, out_count, workspace, st);
+        };
+        struct Clear { ach::EngineBase* e; ~Clear() { e->detect_tail = nullptr; } } clear{e};
+        e->run_eager(static_cast<hipStream_t>(stream));          // the tail carries per-call arguments: never replayed from a graph
+        hipError_t err = hipGetLastError();
+        if (err != hipSuccess) throw ach::AchError{ACH_ERR_DEVICE, std::string("kernel launch: ") + hipGetErrorString(err)};
+    });
+}
+
 int ach_decode(ach_handle* h, int32_t batch, const void* det3, const void* det4, const void* det5, float* decoded, void* stream) {
     return guarded(h, [&] {
         if (batch <= 0 || !det3 || !det4 || !det5 || !decoded) throw ach::AchError{ACH_ERR_INVALID, "bad decode arguments"};

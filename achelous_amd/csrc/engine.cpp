@@ -135,6 +135,7 @@ void EngineBase::run_eager(hipStream_t s) {
         }
         if (multi && op.signal_ev >= 0) (void)hipEventRecord(ev_join[op.signal_ev], st);
     }
+    if (detect_tail) detect_tail((multi && used[0]) ? side_stream[0] : s);       // det maps are final on that stream at this point
     if (multi)
         for (int k = 0; k < kSideStreams; ++k)
             if (used[k]) { (void)hipEventRecord(ev_end[k], side_stream[k]); (void)hipStreamWaitEvent(s, ev_end[k], 0); }

@@ -79,6 +79,8 @@ public:
     virtual void plan(int B) = 0;
     void run(hipStream_t s);            // graph replay when possible, else eager launches
     void run_eager(hipStream_t s);
+    // transient: extra launches enqueued behind the last op of the detection branch (stream 1) by ach_forward_detect
+    std::function<void(hipStream_t)> detect_tail;
     void run_profiled(hipStream_t s, float* op_ms, size_t cap);
     // live probe: HIP events around ONE op of the plan on every run() (bench.py's roofline leg)
     void set_probe(int op_index);

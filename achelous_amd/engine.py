@@ -32,7 +32,7 @@ class AchTensorDesc(ctypes.Structure):
 class NativeLibrary:
     """dlopen + prototypes for every symbol declared in include/achelous.h."""
     SYMBOLS = ('ach_create', 'ach_destroy', 'ach_last_error', 'ach_load_weights', 'ach_plan', 'ach_arena_bytes',
-               'ach_forward', 'ach_decode', 'ach_nms_workspace_bytes', 'ach_nms', 'ach_tap_count', 'ach_tap_name',
+               'ach_forward', 'ach_forward_detect', 'ach_decode', 'ach_nms_workspace_bytes', 'ach_nms', 'ach_tap_count', 'ach_tap_name',
                'ach_tap_shape', 'ach_read_tap', 'ach_plan_launches', 'ach_op_name', 'ach_op_bytes', 'ach_op_flops',
                'ach_forward_profiled', 'ach_set_probe', 'ach_read_probe', 'ach_bench_gemm', 'ach_set_option', 'ach_preprocess_radar',
                'ach_normalize_points', 'ach_preprocess_image', 'ach_seg_argmax')
@@ -60,6 +60,8 @@ class NativeLibrary:
         L.ach_arena_bytes.restype = sz
         L.ach_forward.argtypes = [vp] + [vp] * 9 + [vp]
         L.ach_forward.restype = ctypes.c_int
+        L.ach_forward_detect.argtypes = [vp] + [vp] * 9 + [vp, f32, f32, i32, vp, vp, vp, vp, vp]
+        L.ach_forward_detect.restype = ctypes.c_int
         L.ach_decode.argtypes = [vp, i32, vp, vp, vp, vp, vp]
         L.ach_decode.restype = ctypes.c_int
         L.ach_nms_workspace_bytes.argtypes = [vp, i32]
@@ -187,6 +189,13 @@ class NativeEngine:
         det3, det4, det5, se, lane, pc = outs
         self._check(self.L.ach_forward(self.h, _ptr(image), _ptr(radar), _ptr(points), _ptr(det3), _ptr(det4), _ptr(det5),
                                        _ptr(se), _ptr(lane), _ptr(pc), ctypes.c_void_p(stream)))
+
+    def forward_detect(self, image, radar, points, outs, decoded, conf, iou, max_det, rows, idx, count, workspace, stream=0):
+        """forward + decode + NMS; decode / NMS ride the detection-branch stream behind the head (include/achelous.h)."""
+        det3, det4, det5, se, lane, pc = outs
+        self._check(self.L.ach_forward_detect(self.h, _ptr(image), _ptr(radar), _ptr(points), _ptr(det3), _ptr(det4), _ptr(det5),
+                                              _ptr(se), _ptr(lane), _ptr(pc), _ptr(decoded), float(conf), float(iou), int(max_det),
+                                              _ptr(rows), _ptr(idx), _ptr(count), _ptr(workspace), ctypes.c_void_p(stream)))
 
     def op_table(self):
         """[(name, algorithmic bytes, flops)] of every launch in the plan."""

@@ -3,6 +3,8 @@
 
 One "step" = one pass of the hot path over one batch of synthetic frames already resident in HBM:
     Achelous.forward (5 tasks / 4 output groups)  ->  decode_outputs  ->  class-aware NMS (device)
+    (issued as ONE engine call, Achelous.forward_detect: identical results, decode + NMS overlap the segmentation decoders;
+     --separate-calls issues the three reference-shaped calls instead)
     [-> RCCL all-gather of the fixed-size detection records when N > 1]
 Workload: BASELINE.json configs[1] = EN-GDF-PN-S0, bf16, batch 64 per GPU, 320x320 image + radar map, 512 points,
 seeded re-conditioned random weights (no checkpoint ships with the reference), synthetic inputs.
@@ -52,6 +54,7 @@ def main():
     ap.add_argument('--iou', type=float, default=0.35)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=8, help='frames in the CPU-baseline sample')
+    ap.add_argument('--separate-calls', action='store_true', help='forward, decode_outputs and NMS as three calls instead of forward_detect')
     ap.add_argument('--opt', action='append', default=[], help='engine option key=value (ach_set_option), repeatable')
     ap.add_argument('--ops-json', default=None, help='write the per-launch table (ms, algorithmic bytes) here')
     args = ap.parse_args()
@@ -87,9 +90,12 @@ def main():
     ishape = [COMMON['resolution']] * 2
 
     def step():
-        det, se, lane, pc = model(x, xr, xp)
-        dec = decode_outputs(det, ishape)
-        rows, idx, cnt = nms_device(dec, COMMON['num_det'], args.conf, args.iou, args.max_det)
+        if args.separate_calls:
+            det, se, lane, pc = model(x, xr, xp)
+            dec = decode_outputs(det, ishape)
+            rows, idx, cnt = nms_device(dec, COMMON['num_det'], args.conf, args.iou, args.max_det)
+        else:                              # same three stages as one engine call (decode + NMS overlap the segmentation decoders)
+            (det, se, lane, pc), (rows, idx, cnt) = model.forward_detect(x, xr, xp, args.conf, args.iou, args.max_det)
         if world > 1:
             rec = torch.cat([rows.view(B, -1).view(torch.int32), idx, cnt.view(B, 1)], dim=1).contiguous()
             dist.all_gather_into_tensor(gathered, rec)

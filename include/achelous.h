@@ -10,6 +10,7 @@
  *   ach_forward                   <- nets/Achelous.py:49-53      Achelous.forward(x, x_radar, x_point_clouds)
  *   ach_decode                    <- utils/utils_bbox.py:33-85   decode_outputs(outputs, input_shape)
  *   ach_nms                       <- utils/utils_bbox.py:87-132  non_max_suppression(...) up to the host-side un-letterbox
+ *   ach_forward_detect            <- achelous.py:196-262         the three calls above as the reference's detect_image chains them
  *   ach_read_tap / ach_tap_*      <- (test hook) intermediate tensors at the SURVEY.md §8(a) boundaries
  *
  * Conventions: plain pointers and sizes only (no torch / HIP C++ types in the signatures; `stream` is a
@@ -93,6 +94,16 @@ size_t ach_arena_bytes(const ach_handle* h);
  * lane_seg [B,2,R,R], pc_seg [B,N,pc_classes] (log-probabilities).  All device pointers of the config dtype. */
 int ach_forward(ach_handle* h, const void* image, const void* radar, const void* points,
                 void* det3, void* det4, void* det5, void* se_seg, void* lane_seg, void* pc_seg, void* stream);
+
+/* ach_forward + ach_decode + ach_nms in one call (achelous.py:246-262 runs net -> decode_outputs -> non_max_suppression back to
+ * back).  Same outputs as the three separate calls, bit for bit; the difference is scheduling: decode and NMS are enqueued on the
+ * engine's detection-branch stream right behind the detection head, so they overlap with the segmentation decoders instead of
+ * running alone at the end of the step.  `decoded` [B,A,5+num_det] fp32 and `workspace` (>= ach_nms_workspace_bytes) are scratch
+ * owned by the caller. */
+int ach_forward_detect(ach_handle* h, const void* image, const void* radar, const void* points,
+                       void* det3, void* det4, void* det5, void* se_seg, void* lane_seg, void* pc_seg,
+                       float* decoded, float conf_thres, float nms_thres, int32_t max_det,
+                       float* out_rows, int32_t* out_idx, int32_t* out_count, void* workspace, void* stream);
 
 /* det maps (config dtype) -> decoded [B, A, 5+num_det] fp32, A = (R/8)^2 + (R/16)^2 + (R/32)^2 */
 int ach_decode(ach_handle* h, int32_t batch, const void* det3, const void* det4, const void* det5,

@@ -86,3 +86,24 @@ def test_emulated_decode_and_nms_match_oracle():
             assert int(cnt[b]) == k
             assert np.array_equal(idx[b, :k].numpy().astype(np.int64), exp[b][1][:k])
             assert np.array_equal(rows[b, :k].numpy(), exp[b][0][:k])
+
+
+def test_emulated_forward_detect_equals_the_three_calls():
+    """The one-call detect path of the C ABI (ach_forward_detect) against forward + decode + nms on the same engine."""
+    kw, sd, (x, xr, xp) = _setup('en_s0', 320, 1, 16)
+    eng = make_engine(emu_library(), kw, 1, sd, 16, full_taps=False)
+    outs = alloc_outputs(kw, 1, 16, torch.float32, 'cpu')
+    eng.forward(x, xr, xp, outs)
+    A, nc5 = 2100, 5 + kw['num_det']
+    dec = torch.zeros(1, A, nc5)
+    eng.decode(1, outs[0], outs[1], outs[2], dec)
+    ws = torch.zeros(eng.nms_workspace_bytes(1), dtype=torch.uint8)
+    rows, idx, cnt = torch.zeros(1, 50, 7), torch.full((1, 50), -1, dtype=torch.int32), torch.zeros(1, dtype=torch.int32)
+    eng.nms(1, dec, 0.05, 0.5, 50, rows, idx, cnt, ws)
+    outs2 = alloc_outputs(kw, 1, 16, torch.float32, 'cpu')
+    dec2 = torch.zeros(1, A, nc5)
+    rows2, idx2, cnt2 = torch.zeros(1, 50, 7), torch.full((1, 50), -1, dtype=torch.int32), torch.zeros(1, dtype=torch.int32)
+    eng.forward_detect(x, xr, xp, outs2, dec2, 0.05, 0.5, 50, rows2, idx2, cnt2, ws)
+    for a, b in zip((*outs, dec, rows, idx, cnt), (*outs2, dec2, rows2, idx2, cnt2)):
+        assert torch.equal(a, b)
+    assert int(cnt[0]) > 0

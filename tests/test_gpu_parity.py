@@ -213,3 +213,22 @@ def test_launch_modes_agree():
     for o in outs:
         for a, b in zip((o[0][0], o[0][1], o[0][2], o[1], o[2], o[3]), (ref[0][0], ref[0][1], ref[0][2], ref[1], ref[2], ref[3])):
             assert torch.equal(a, b)
+
+
+def test_forward_detect_equals_the_three_calls():
+    """ach_forward_detect (decode + NMS behind the detection head on its stream) == forward -> decode_outputs -> NMS, bit for bit."""
+    g = Golden('en_s0')
+    m, kw = _model(g.meta)
+    x, xr, xp = make_inputs(8, 99, resolution=kw['resolution'], pc_channels=kw['pc_channels'])
+    for dt in (torch.float32, torch.bfloat16):
+        xs, rs, ps = x.cuda().to(dt), xr.cuda().to(dt), xp.cuda().to(dt)
+        with torch.no_grad():
+            det, se, lane, pc = m(xs, rs, ps)
+            dec = decode_outputs(det, [kw['resolution']] * 2)
+            for conf, iou, md in ((0.35, 0.35, 100), (0.05, 0.5, None)):
+                rows, idx, cnt = nms_device(dec, kw['num_det'], conf, iou, md)
+                (det2, se2, lane2, pc2), (rows2, idx2, cnt2) = m.forward_detect(xs, rs, ps, conf, iou, md)
+                torch.cuda.synchronize()
+                for a, b in zip((*det, se, lane, pc, rows, idx, cnt), (*det2, se2, lane2, pc2, rows2, idx2, cnt2)):
+                    assert torch.equal(a, b)
+                assert int(cnt.max()) > 0
