@@ -112,7 +112,7 @@ void EngineBase::ensure_streams() {
 // latency-bound on small maps: they run on two engine-owned side streams, forked from and joined back into the caller's
 // stream with events, so their launches fill the CUs the image path leaves idle.
 void EngineBase::run_eager(hipStream_t s) {
-    bool used[kSideStreams] = {false, false};
+    bool used[kSideStreams] = {false, false, false};
     const bool multi = multi_stream;
     if (multi) {
         ensure_streams();
@@ -537,12 +537,44 @@ public:
             mp.Wdw = up_f32(wt); mp.bdw = up_f32(bt);
         }
         mp.W1 = up_T(w1); mp.b1 = up_f32(b1); mp.W2 = up_T(w2); mp.b2 = up_f32(b2);
-        mp.M = xin.rows(); mp.C = C; mp.k1 = k1; mp.J = J; mp.act = ACT_GELU; mp.ln_eps = 1e-6f;
+        mp.M = xin.rows(); mp.C = C; mp.k1 = k1; mp.J = J; mp.act = ACT_GELU; mp.ln_eps = 1e-6f; mp.ln = 1; mp.Cout = C;
         // per-sample map size, not batch, decides the geometry: a frame's result must not depend on the batch it is in
         const bool split = mlp_split < 0 ? xin.H * xin.W <= 1024 : mlp_split != 0;
         const double bytes = double(mp.M) * C * sizeof(T) * (xin.p == resid.p ? 2.0 : 3.0);
         const double flops = 4.0 * double(mp.M) * C * hidden + (dw_ks ? 2.0 * double(mp.M) * C * dw_ks * dw_ks : 0.0);
         add_op(pfx + (dw_ks ? ".block" : ".mlp"), [mp, DT, split](hipStream_t s) { launch_mlp<T>(mp, DT, split, s); }, bytes, flops);
+        return true;
+    }
+    // y = l2(act(l1(x))) as one launch (k_mlp.h without LayerNorm / residual); false when the widths are not instantiated
+    bool chain2(const std::string& name, const A& x, const Lin& l1, int act, const Lin& l2, A& y) {
+        if (!fuse_mlp) return false;
+        const int Cin = x.C, hidden = l1.N, Cout = l2.N, DT = mlp_pick_dt(std::max(Cin, Cout));
+        if (DT == 0 || l1.K != Cin || l2.K != hidden) return false;
+        const int k1 = cdiv(Cin, KC), J = cdiv(hidden, 32), hstep = 8 / VEC, ks2 = J * hstep;
+        std::vector<float> w1(size_t(J) * k1 * 2 * 64 * VEC, 0.f), b1(size_t(J) * 32, 0.f);
+        std::vector<float> w2(size_t(ks2) * DT * 64 * VEC, 0.f), b2(size_t(DT) * 16, 0.f);
+        if (!measuring) {
+            for (int n = 0; n < hidden; ++n) {
+                b1[n] = l1.b[n];
+                for (int k = 0; k < Cin; ++k) w1[size_t(wfrag_offset(n, k, 2, k1, VEC))] = l1.w[size_t(n) * Cin + k];
+            }
+            for (int n = 0; n < Cout; ++n) {
+                b2[n] = l2.b[n];
+                for (int kap = 0; kap < 32 * J; ++kap) {
+                    const int ch = mlp_hidden_channel(kap, VEC);
+                    if (ch < hidden) w2[size_t(wfrag_offset(n, kap, DT, ks2, VEC))] = l2.w[size_t(n) * hidden + ch];
+                }
+            }
+        }
+        y = alloc(x.B, x.H, x.W, Cout);
+        MlpParams mp;
+        std::memset(&mp, 0, sizeof(mp));
+        mp.X = x.p; mp.ldx = x.ld; mp.Y = y.p; mp.ldy = y.ld;
+        mp.W1 = up_T(w1); mp.b1 = up_f32(b1); mp.W2 = up_T(w2); mp.b2 = up_f32(b2);
+        mp.M = x.rows(); mp.C = Cin; mp.k1 = k1; mp.J = J; mp.act = act; mp.ln = 0; mp.Cout = Cout;
+        const bool split = mlp_split < 0 ? x.H * x.W <= 1024 : mlp_split != 0;
+        add_op(name, [mp, DT, split](hipStream_t s) { launch_mlp<T>(mp, DT, split, s); },
+               double(mp.M) * (Cin + Cout) * sizeof(T), 2.0 * double(mp.M) * hidden * (Cin + Cout));
         return true;
     }
     A conv_encoder(const std::string& pfx, const A& x, int ks) {          // conv_encoder.py:19-32
@@ -803,10 +835,13 @@ public:
         Lin lp = conv_bn(ghost_pfx + ".primary_conv.0", ghost_pfx + ".primary_conv.1", 1e-5);
         const int Cg = lp.N;
         if (2 * Cg != cout || Cg % 4 || Cg > UPG_CMAX || lp.K != lu.N) throw AchError{ACH_ERR_UNSUPPORTED, ghost_pfx + ": decoder level widths"};
-        A u = alloc(x.B, x.H, x.W, lu.N);
-        { GemmOpt o; o.act = ACT_RELU; gemm(up_pfx + ".conv", x, pack(lu), u, o); }
-        A t = alloc(x.B, x.H, x.W, Cg);
-        gemm(ghost_pfx + ".primary_lowres", u, pack(lp), t);
+        A t;
+        if (!chain2(ghost_pfx + ".lowres_pair", x, lu, ACT_RELU, lp, t)) {
+            A u = alloc(x.B, x.H, x.W, lu.N);
+            { GemmOpt o; o.act = ACT_RELU; gemm(up_pfx + ".conv", x, pack(lu), u, o); }
+            t = alloc(x.B, x.H, x.W, Cg);
+            gemm(ghost_pfx + ".primary_lowres", u, pack(lp), t);
+        }
         const HostTensor& w = W(ghost_pfx + ".cheap_operation.0.weight");
         std::vector<float> sc, sh; bn_coeffs(ghost_pfx + ".cheap_operation.1", 1e-5, sc, sh);
         std::vector<float> wt(size_t(9) * Cg);
@@ -829,10 +864,13 @@ public:
         const int Cg = lp.N, init = (oup + 1) / 2, nch = oup - init;
         Lin lh = conv_bn(head_pfx + ".primary_conv.0", head_pfx + ".primary_conv.1", 1e-5);
         if (Cg != UGH_CG || 2 * Cg != cout || lh.K != cout || lh.N != init || init > UGH_IMAX) throw AchError{ACH_ERR_UNSUPPORTED, head_pfx + ": fused last level expects 16+16 channels"};
-        A u = alloc(x.B, x.H, x.W, lu.N);
-        { GemmOpt o; o.act = ACT_RELU; gemm(up_pfx + ".conv", x, pack(lu), u, o); }
-        A t = alloc(x.B, x.H, x.W, Cg);
-        gemm(ghost_pfx + ".primary_lowres", u, pack(lp), t);
+        A t;
+        if (!chain2(ghost_pfx + ".lowres_pair", x, lu, ACT_RELU, lp, t)) {
+            A u = alloc(x.B, x.H, x.W, lu.N);
+            { GemmOpt o; o.act = ACT_RELU; gemm(up_pfx + ".conv", x, pack(lu), u, o); }
+            t = alloc(x.B, x.H, x.W, Cg);
+            gemm(ghost_pfx + ".primary_lowres", u, pack(lp), t);
+        }
         auto dw_fold = [&](const std::string& pfx, int n, std::vector<float>& wt, std::vector<float>& bias) {
             const HostTensor& w = W(pfx + ".cheap_operation.0.weight");
             std::vector<float> sc, sh; bn_coeffs(pfx + ".cheap_operation.1", 1e-5, sc, sh);
@@ -876,6 +914,7 @@ public:
         copy(f + ".cat3", m3, c3.slice(w[1], w[1]));
         A p3 = ghost_bottleneck(f + ".ghost_4_to_3", c3, w[1]);
         tap("fpn4", p4); tap("fpn3", p3);
+        if (split_decoders) signal_after_last(2);   // p3 ready: the semantic decoder may start on its own stream
         // residual FPN outputs (ghostdualfpn.py:200) — computed BEFORE the decoders so that the detection branch (fusion + head,
         // on the radar stream) can start while the two heavy decoders still run on this stream
         q[0] = alloc(p3.B, p3.H, p3.W, p3.C); add(f + ".q3", p3, m3, q[0]);
@@ -888,6 +927,8 @@ public:
         const int oups[2] = {2, cfg.num_seg};
         void** outs[2] = {&io.lane, &io.se};
         for (int d = 0; d < 2; ++d) {
+            // the two decoders only share their input: water-line decoder on the caller's stream, semantic decoder on stream 3
+            if (d == 1 && split_decoders) { cur_stream = 3; wait_before_next(2); }
             const std::string n = names[d];
             A y = shuffle_attention(f + "." + sa[d], p3);
             tap(n + ".sa", y);
@@ -899,6 +940,7 @@ public:
             }
             decoder_last_level(f + "." + n + "_seg_" + lv[2], f + "." + n + "_seg_ghost_" + lv[2], f + "." + n + "_seg_head", n + "." + lv[2], y, cw[2], oups[d], outs[d]);
         }
+        cur_stream = 0;
     }
     const int* widths() const {
         static const int w0[4] = {32, 48, 96, 176}, w1[4] = {32, 48, 120, 224}, w2[4] = {32, 64, 144, 288};

@@ -66,6 +66,7 @@ public:
     bool use_graph = false;
     bool multi_stream = true;         // option "streams": run the independent radar / point branches on side streams
     bool fuse_mlp = true;             // option "fused_mlp": EdgeNeXt blocks as one kernel (k_mlp.h) instead of dw / pw1 / pw2 launches
+    bool split_decoders = true;       // option "split_decoders": semantic decoder on its own stream
     bool row_conv = true;             // option "row_conv": narrow 3x3 convs through k_conv3.h instead of the generic implicit GEMM
     int mlp_split = -1;               // option "mlp_split": -1 auto (by tile count), 0 one tile per wave, 1 four waves per tile
     bool full_taps = false;           // option "full_taps": also materialise boundaries that production plans keep on-chip
@@ -119,9 +120,9 @@ protected:
     int cur_stream = 0, pending_wait = -1;
     void signal_after_last(int ev) { if (!measuring && !ops.empty()) ops.back().signal_ev = ev; }
     void wait_before_next(int ev) { pending_wait = ev; }
-    static constexpr int kSideStreams = 2, kJoinEvents = 4;
-    hipStream_t side_stream[kSideStreams] = {nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join[kJoinEvents] = {nullptr, nullptr, nullptr, nullptr}, ev_end[kSideStreams] = {nullptr, nullptr};
+    static constexpr int kSideStreams = 3, kJoinEvents = 4;
+    hipStream_t side_stream[kSideStreams] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[kJoinEvents] = {nullptr, nullptr, nullptr, nullptr}, ev_end[kSideStreams] = {nullptr, nullptr, nullptr};
     bool streams_ready = false;
     void ensure_streams();
 #if !defined(ACH_HOSTEMU)

@@ -5,7 +5,9 @@
 // (ConvEncoder, edgenext_modules/conv_encoder.py:19-32: depthwise conv -> LayerNorm -> Linear(d,4d) -> GELU ->
 //  Linear(4d,d) -> layer scale -> + input;  the MLP tail of SDTAEncoder, sdta_encoder.py:68-74, is the same thing
 //  without the depthwise conv and with a residual taken from a different tensor.)
-// LayerNorm affine is folded into W1/b1 and the layer scale into W2/b2 on the host.
+// LayerNorm affine is folded into W1/b1 and the layer scale into W2/b2 on the host.  With ln = 0 and no residual the same
+// kernel is a plain two-layer 1x1 chain  y = W2 · act(W1 x + b1) + b2  (the low-resolution pair of every decoder level:
+// upsample conv + BN + ReLU followed by the Ghost primary conv + BN, neck/ghostdualfpn.py:175-197).
 //
 // Layer by layer this was three launches and a round trip of the 4d-wide hidden tensor through HBM (the largest
 // activation of the backbone).  Here the hidden activations never leave registers: with weights as the MFMA *A* operand
@@ -43,6 +45,7 @@ struct MlpParams {
     const void* W1; const float* b1;      // [hidden][C] packed in NT = 2 chunks with k1 k-steps ; bias padded to 32 * J
     const void* W2; const float* b2;      // [C][hidden] packed as ONE chunk of DT tiles with J * (8 / VEC) k-steps ; bias padded to 16 * DT
     long M; int C, k1, J, act; float ln_eps;
+    int ln, Cout;                         // ln = 0: no normalisation (plain two-layer chain); Cout: output width (R may be null)
 };
 
 constexpr int MLP_RED_TILES = 8;          // output tiles reduced per LDS round in SPLIT mode
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(256, MlpOcc<DT>::blocks) void mlp_kernel(const MlpP
         for (int w = 0; w < 4; ++w) { s1 += st[(w * 16 + px) * 2]; s2 += st[(w * 16 + px) * 2 + 1]; }
     }
     // ---- 2. LayerNorm (affine folded into W1 / b1)
-    {
+    if (p.ln) {
         const float mu = s1 / float(p.C);
         float var = s2 / float(p.C) - mu * mu;
         var = var > 0.f ? var : 0.f;
@@ -229,9 +232,9 @@ __global__ __launch_bounds__(256, MlpOcc<DT>::blocks) void mlp_kernel(const MlpP
     // ---- 4. + bias + residual, 8 consecutive channels per lane per tile pair
     auto finish = [&](int pair, const float* v8) {
         const int nb = pair * 32 + g * 8;
-        if (!valid || nb >= p.C) return;
-        float o[8], r8[8];
-        Store<T>::ld8(static_cast<const T*>(p.R) + m * p.ldr + nb, r8);
+        if (!valid || nb >= p.Cout) return;
+        float o[8], r8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (p.R) Store<T>::ld8(static_cast<const T*>(p.R) + m * p.ldr + nb, r8);
         ACH_UNROLL
         for (int i = 0; i < 8; ++i) o[i] = v8[i] + p.b2[nb + i] + r8[i];
         Store<T>::st8(static_cast<T*>(p.Y) + m * p.ldy + nb, o);
