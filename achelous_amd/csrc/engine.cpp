@@ -914,7 +914,8 @@ public:
         copy(f + ".cat3", m3, c3.slice(w[1], w[1]));
         A p3 = ghost_bottleneck(f + ".ghost_4_to_3", c3, w[1]);
         tap("fpn4", p4); tap("fpn3", p3);
-        if (split_decoders) signal_after_last(2);   // p3 ready: the semantic decoder may start on its own stream
+        const bool split_dec = split_decoders < 0 ? batch <= 16 : split_decoders != 0;
+        if (split_dec) signal_after_last(2);   // p3 ready: the semantic decoder may start on its own stream
         // residual FPN outputs (ghostdualfpn.py:200) — computed BEFORE the decoders so that the detection branch (fusion + head,
         // on the radar stream) can start while the two heavy decoders still run on this stream
         q[0] = alloc(p3.B, p3.H, p3.W, p3.C); add(f + ".q3", p3, m3, q[0]);
@@ -928,7 +929,7 @@ public:
         void** outs[2] = {&io.lane, &io.se};
         for (int d = 0; d < 2; ++d) {
             // the two decoders only share their input: water-line decoder on the caller's stream, semantic decoder on stream 3
-            if (d == 1 && split_decoders) { cur_stream = 3; wait_before_next(2); }
+            if (d == 1 && split_dec) { cur_stream = 3; wait_before_next(2); }
             const std::string n = names[d];
             A y = shuffle_attention(f + "." + sa[d], p3);
             tap(n + ".sa", y);

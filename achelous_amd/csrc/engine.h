@@ -66,7 +66,8 @@ public:
     bool use_graph = false;
     bool multi_stream = true;         // option "streams": run the independent radar / point branches on side streams
     bool fuse_mlp = true;             // option "fused_mlp": EdgeNeXt blocks as one kernel (k_mlp.h) instead of dw / pw1 / pw2 launches
-    bool split_decoders = true;       // option "split_decoders": semantic decoder on its own stream
+    int split_decoders = -1;          // option "split_decoders": semantic decoder on its own stream (-1: only when batch <= 16, where the
+                                      // step is launch-bound; at batch 64 the two decoders saturate the chip one after the other)
     bool row_conv = true;             // option "row_conv": narrow 3x3 convs through k_conv3.h instead of the generic implicit GEMM
     int mlp_split = -1;               // option "mlp_split": -1 auto (by tile count), 0 one tile per wave, 1 four waves per tile
     bool full_taps = false;           // option "full_taps": also materialise boundaries that production plans keep on-chip

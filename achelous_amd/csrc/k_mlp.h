@@ -153,7 +153,9 @@ __global__ __launch_bounds__(256, MlpOcc<DT>::blocks) void mlp_kernel(const MlpP
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int px = lane & 15, g = lane >> 4;
-    const long tile = SPLIT ? long(blockIdx.x) : long(blockIdx.x) * 4 + wave;
+    // depthwise mode re-reads halo rows across tiles: XCD-aware order keeps those re-reads inside one L2 (ach_platform.h)
+    const unsigned wgid = p.dw_k > 0 ? xcd_block(blockIdx.x, gridDim.x) : blockIdx.x;
+    const long tile = SPLIT ? long(wgid) : long(wgid) * 4 + wave;
     const long mraw = tile * 16 + px;
     const bool valid = mraw < p.M;
     const long m = valid ? mraw : 0;

@@ -82,7 +82,11 @@ int ach_load_weights(ach_handle* h, const ach_tensor_desc* tensors, size_t n);
  * "streams" = 0: launch everything on the caller's stream (default 1: the independent radar and point branches run on two
  * engine-owned side streams, forked from / joined into the caller's stream with events).
  * "graph" = 1: capture the plan into a hipGraph per distinct set of I/O pointers and replay it (default 0: measured no faster
- * than the interleaved eager launches on three streams). */
+ * than the interleaved eager launches on the side streams).
+ * Kernel-selection switches, all default 1, kept so that each fused kernel can be A/B-measured against the layer-wise path it
+ * replaced (results agree to rounding): "fused_mlp" (EdgeNeXt blocks and decoder conv pairs through k_mlp.h), "mlp_split"
+ * (-1 auto / 0 / 1: four waves per pixel tile in k_mlp.h), "row_conv" (offset/modulator convs through k_conv3.h),
+ * "split_decoders" (-1 auto / 0 / 1: semantic decoder on its own stream; auto = only at batch <= 16). */
 int ach_set_option(ach_handle* h, const char* key, int32_t value);
 
 /* Builds the launch plan and the activation arena for batch size B (re-plan to change B). */

@@ -64,21 +64,47 @@ def main():
                 'traffic_bytes': round(f_kib * 1024 * factor + w_kib * 1024)}
     # ---- op-name keyed entries that bench.py looks up (dominant kernels of the EN-GDF-PN-S0 plan)
     ops = {}
+    def avg_bytes(kname, pick=lambda v: v):
+        f = pick(sorted(fetch[kname])); w = pick(sorted(write.get(kname, [])))
+        if not f or not w:
+            return None
+        return round(sum(x[1] for x in f) / len(f) * 2048 + sum(x[1] for x in w) / len(w) * 1024)
+
+    def largest_grid(v):
+        g = max(x[2] for x in v) if v else 0
+        return [x for x in v if x[2] == g]
+
     for kname in fetch:
-        if 'upghost_head_kernel' in kname:       # two launches per forward, in plan order: lane decoder, then semantic decoder
-            f = sorted(fetch[kname]); w = sorted(write.get(kname, []))
-            for parity, op in ((0, 'image_radar_encoder.fpn.lane_seg_head.upghost_head'), (1, 'image_radar_encoder.fpn.se_seg_head.upghost_head')):
-                fk = [x[1] for i, x in enumerate(f) if i % 2 == parity]; wk = [x[1] for i, x in enumerate(w) if i % 2 == parity]
-                if fk and wk:
-                    ops[op] = round(sum(fk) / len(fk) * 1024 * 2.0 + sum(wk) / len(wk) * 1024)
-        if 'gemm_kernel<ach::bf16_t, 2, 1>' in kname:
-            big = [x for x in fetch[kname] if x[2] == max(y[2] for y in fetch[kname])]
-            bw = [x for x in write.get(kname, []) if x[2] == max(y[2] for y in write[kname])]
-            if big and bw:
-                ops['image_radar_encoder.radar_encoder.rc_blocks.0.offmask'] = round(sum(x[1] for x in big) / len(big) * 2048 + sum(x[1] for x in bw) / len(bw) * 1024)
+        if 'upghost_head_kernel' in kname and 'bf16' in kname:
+            # two launches per forward in a fixed plan order; the semantic decoder (9 output planes) is the one that writes more
+            w = sorted(write.get(kname, []))
+            even = [x[1] for i, x in enumerate(w) if i % 2 == 0]; odd = [x[1] for i, x in enumerate(w) if i % 2 == 1]
+            if even and odd:
+                se_parity = 0 if sum(even) / len(even) > sum(odd) / len(odd) else 1
+                for parity, op in ((se_parity, 'image_radar_encoder.fpn.se_seg_head.upghost_head'),
+                                   (1 - se_parity, 'image_radar_encoder.fpn.lane_seg_head.upghost_head')):
+                    v = avg_bytes(kname, lambda v, q=parity: [x for i, x in enumerate(v) if i % 2 == q])
+                    if v:
+                        ops[op] = v
+        if 'conv3x3_rows_kernel<ach::bf16_t, 3>' in kname:
+            v = avg_bytes(kname, largest_grid)
+            if v:
+                ops['image_radar_encoder.radar_encoder.rc_blocks.0.offmask'] = v
         if 'deform_fused_kernel<ach::bf16_t, 3' in kname:
-            ops['image_radar_encoder.radar_encoder.rc_blocks.0.deform'] = round(sum(x[1] for x in fetch[kname]) / len(fetch[kname]) * 2048 +
-                                                                              sum(x[1] for x in write[kname]) / len(write[kname]) * 1024)
+            v = avg_bytes(kname)
+            if v:
+                ops['image_radar_encoder.radar_encoder.rc_blocks.0.deform'] = v
+        if 'mlp_kernel<ach::bf16_t, 2, false>' in kname:
+            # batch 64: the two stage-0 EdgeNeXt blocks are the launches with 409600 rows = 6400 workgroups = 1638400 threads;
+            # the largest grid of this instantiation is the 160x160 conv pair of a decoder
+            v = avg_bytes(kname, lambda v: [x for x in v if x[2] == 1638400])
+            if v:
+                ops['image_radar_encoder.fpn.backbone.stages.0.0.block'] = v
+                ops['image_radar_encoder.fpn.backbone.stages.0.1.block'] = v
+            v = avg_bytes(kname, largest_grid)
+            if v:
+                ops['image_radar_encoder.fpn.se_seg_ghost_1_to_0.lowres_pair'] = v
+                ops['image_radar_encoder.fpn.lane_seg_ghost_1_to_0.lowres_pair'] = v
     report['ops'] = ops
     report.update(ops)            # flat keys for bench.py
     json.dump(report, open(out, 'w'), indent=1)
