@@ -899,8 +899,14 @@ public:
         if (c_ % 4) throw AchError{ACH_ERR_UNSUPPORTED, "SPP hidden width must be a multiple of 4"};
         A cat5 = alloc(m5.B, m5.H, m5.W, 4 * c_);
         { GemmOpt o; o.act = ACT_SILU; gemm(f + ".spp.cv1", m5, pack(conv_bn(f + ".spp.cv1.conv", f + ".spp.cv1.bn", 1e-3)), cat5.slice(0, c_), o); }
-        SppParams sp{cat5.p, cat5.ld, m5.B, m5.H, m5.W, c_};
-        ew(f + ".spp.pool", spp_pool_kernel<T>, sp, m5.rows() * (c_ / 4));
+        {
+            const int hw = m5.H * m5.W, cq = c_ / 4;
+            if (hw > SPP_TILE) throw AchError{ACH_ERR_UNSUPPORTED, "SPP map larger than the pooling tile"};
+            const int cqb = std::max(1, std::min(cq, SPP_TILE / hw));
+            SppParams sp{cat5.p, cat5.ld, m5.B, m5.H, m5.W, c_, cqb};
+            const dim3 grid(unsigned(m5.B) * unsigned(cdiv(cq, cqb))), block(256);
+            add_op(f + ".spp.pool", [sp, grid, block](hipStream_t s) { ACH_LAUNCH(spp_pool_kernel<T>, grid, block, s, sp); }, 5.0 * double(m5.rows()) * c_ * sizeof(T));
+        }
         A p5 = alloc(m5.B, m5.H, m5.W, w[3]);
         { GemmOpt o; o.act = ACT_SILU; gemm(f + ".spp.cv2", cat5, pack(conv_bn(f + ".spp.cv2.conv", f + ".spp.cv2.bn", 1e-3)), p5, o); }
         tap("spp", p5);

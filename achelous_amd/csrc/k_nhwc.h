@@ -260,43 +260,51 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const UpParams p) {
 // ------------------------------------------------------------------------------------------ SPP max pools
 // reads channels [0,C) of the concat buffer, writes the 5x5 / 9x9 / 13x13 stride-1 max pools (-inf padding)
 // to channels [C,2C) [2C,3C) [3C,4C).  (SPPF's three chained 5x5 pools are the same three windows.)
-struct SppParams { void* buf; long ld; int B, H, Wd, C; };
+struct SppParams { void* buf; long ld; int B, H, Wd, C, cqb; };
+// One workgroup = one sample x `cqb` channel quads: the map slice is staged in LDS once and the three square windows are
+// computed separably (row maxima of radius 2 / 4 / 6, then column maxima) — 2 x 13 LDS reads per output instead of 169
+// global loads.  H * W * cqb <= SPP_TILE.
+constexpr int SPP_TILE = 768;
 template <class T>
 __global__ __launch_bounds__(256) void spp_pool_kernel(const SppParams p) {
-    const int cq = p.C >> 2;
-    const long total = long(p.B) * p.H * p.Wd * cq;
-    const long idx = long(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    const int c = int(idx % cq) * 4;
-    long pix = idx / cq;
-    const int x = int(pix % p.Wd); pix /= p.Wd;
-    const int y = int(pix % p.H);
-    const long b = pix / p.H;
-    T* buf = static_cast<T*>(p.buf);
-    float m5[4], m9[4], m13[4];
-    ACH_UNROLL
-    for (int i = 0; i < 4; ++i) m5[i] = m9[i] = m13[i] = -3.0e38f;
-    for (int dy = -6; dy <= 6; ++dy) {
-        const int iy = y + dy;
-        if (iy < 0 || iy >= p.H) continue;
-        for (int dx = -6; dx <= 6; ++dx) {
-            const int ix = x + dx;
-            if (ix < 0 || ix >= p.Wd) continue;
-            float v[4];
-            Store<T>::ld4(buf + ((b * p.H + iy) * p.Wd + ix) * p.ld + c, v);
-            const int r = (dy < 0 ? -dy : dy) > (dx < 0 ? -dx : dx) ? (dy < 0 ? -dy : dy) : (dx < 0 ? -dx : dx);
-            ACH_UNROLL
-            for (int i = 0; i < 4; ++i) {
-                m13[i] = fmaxf(m13[i], v[i]);
-                if (r <= 4) m9[i] = fmaxf(m9[i], v[i]);
-                if (r <= 2) m5[i] = fmaxf(m5[i], v[i]);
-            }
-        }
+    __shared__ float4 src[SPP_TILE], r5[SPP_TILE], r9[SPP_TILE], r13[SPP_TILE];
+    const int cq = p.C >> 2, groups = (cq + p.cqb - 1) / p.cqb;
+    const int b = blockIdx.x / groups, q0 = (blockIdx.x % groups) * p.cqb;
+    const int nq = (cq - q0) < p.cqb ? (cq - q0) : p.cqb;
+    const int HW = p.H * p.Wd, n = HW * nq;
+    T* buf = static_cast<T*>(p.buf) + long(b) * HW * p.ld;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int pix = i / nq, q = i - pix * nq;
+        float v[4];
+        Store<T>::ld4(buf + long(pix) * p.ld + (q0 + q) * 4, v);
+        src[i] = make_float4(v[0], v[1], v[2], v[3]);
     }
-    T* o = buf + ((b * p.H + y) * p.Wd + x) * p.ld + c;
-    Store<T>::st4(o + p.C, m5);
-    Store<T>::st4(o + 2 * p.C, m9);
-    Store<T>::st4(o + 3 * p.C, m13);
+    __syncthreads();
+    auto mx = [](float4 a, const float4& c) { a.x = fmaxf(a.x, c.x); a.y = fmaxf(a.y, c.y); a.z = fmaxf(a.z, c.z); a.w = fmaxf(a.w, c.w); return a; };
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int pix = i / nq, q = i - pix * nq, y = pix / p.Wd, x = pix - y * p.Wd;
+        float4 m5 = src[i], m9, m13;
+        for (int d = 1; d <= 2; ++d) { if (x - d >= 0) m5 = mx(m5, src[(pix - d) * nq + q]); if (x + d < p.Wd) m5 = mx(m5, src[(pix + d) * nq + q]); }
+        m9 = m5;
+        for (int d = 3; d <= 4; ++d) { if (x - d >= 0) m9 = mx(m9, src[(pix - d) * nq + q]); if (x + d < p.Wd) m9 = mx(m9, src[(pix + d) * nq + q]); }
+        m13 = m9;
+        for (int d = 5; d <= 6; ++d) { if (x - d >= 0) m13 = mx(m13, src[(pix - d) * nq + q]); if (x + d < p.Wd) m13 = mx(m13, src[(pix + d) * nq + q]); }
+        r5[i] = m5; r9[i] = m9; r13[i] = m13;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int pix = i / nq, q = i - pix * nq, y = pix / p.Wd;
+        float4 m5 = r5[i], m9 = r9[i], m13 = r13[i];
+        for (int d = 1; d <= 6; ++d) {
+            if (y - d >= 0) { const int j = (pix - d * p.Wd) * nq + q; if (d <= 2) m5 = mx(m5, r5[j]); if (d <= 4) m9 = mx(m9, r9[j]); m13 = mx(m13, r13[j]); }
+            if (y + d < p.H) { const int j = (pix + d * p.Wd) * nq + q; if (d <= 2) m5 = mx(m5, r5[j]); if (d <= 4) m9 = mx(m9, r9[j]); m13 = mx(m13, r13[j]); }
+        }
+        T* o = buf + long(pix) * p.ld + (q0 + q) * 4;
+        const float a5[4] = {m5.x, m5.y, m5.z, m5.w}, a9[4] = {m9.x, m9.y, m9.z, m9.w}, a13[4] = {m13.x, m13.y, m13.z, m13.w};
+        Store<T>::st4(o + p.C, a5);
+        Store<T>::st4(o + 2 * p.C, a9);
+        Store<T>::st4(o + 3 * p.C, a13);
+    }
 }
 
 // ------------------------------------------------------------------------------------------ element-wise
@@ -595,34 +603,42 @@ __global__ __launch_bounds__(256) void upghost_head_kernel(const UpGhostHeadPara
     const int bx = int(wg % tiles_x) * TW, by = int((wg / tiles_x) % tiles_y) * TH;
     const long b = wg / (unsigned(tiles_x) * tiles_y);
     const int tid = threadIdx.x;
-    {   // ---- x1 on the 2-halo tile
-        const int c = (tid & 3) * 4, slot = tid >> 2;
+    {   // ---- x1 on the 2-halo tile: thread = position (all 16 channels), so the bilinear geometry is computed once per position;
+        // loads are unconditional from clamped coordinates (positions outside the map / past the tile are zeroed afterwards)
         const float sy = H > 1 ? float(p.h - 1) / float(H - 1) : 0.f, sx = Wd > 1 ? float(p.w - 1) / float(Wd - 1) : 0.f;
-        const T* Tq = static_cast<const T*>(p.Tq) + b * p.h * long(p.w) * p.ldt + c;
-        // every round issues its four corner loads unconditionally from clamped coordinates, so the loads of all rounds can
-        // be in flight together (positions outside the map / past the tile are zeroed after the fact)
-        constexpr int ROUNDS = (H2 * W2 + 63) / 64;
+        const T* Tq = static_cast<const T*>(p.Tq) + b * p.h * long(p.w) * p.ldt;
+        const int ldt = int(p.ldt);
+        constexpr int ROUNDS = (H2 * W2 + 255) / 256;
         ACH_UNROLL
         for (int r = 0; r < ROUNDS; ++r) {
-            const int pos_raw = slot + r * 64;
+            const int pos_raw = tid + r * 256;
             const int pos = pos_raw < H2 * W2 ? pos_raw : H2 * W2 - 1;
-            const int oy = by + pos / W2 - 2, ox = bx + pos % W2 - 2;
+            const int py = pos / W2, oy = by + py - 2, ox = bx + (pos - py * W2) - 2;
             const bool ok = oy >= 0 && oy < H && ox >= 0 && ox < Wd;
             const int cy = oy < 0 ? 0 : (oy >= H ? H - 1 : oy), cx = ox < 0 ? 0 : (ox >= Wd ? Wd - 1 : ox);
             const float fy = sy * float(cy), fx = sx * float(cx);
             int y0 = int(fy), x0 = int(fx);
             if (y0 > p.h - 1) y0 = p.h - 1;
             if (x0 > p.w - 1) x0 = p.w - 1;
-            const int y1 = y0 + (y0 < p.h - 1 ? 1 : 0), x1i = x0 + (x0 < p.w - 1 ? 1 : 0);
+            const int dy = y0 < p.h - 1 ? p.w * ldt : 0, dx = x0 < p.w - 1 ? ldt : 0;
             const float ly = fy - float(y0), lx = fx - float(x0), hy = 1.f - ly, hx = 1.f - lx;
-            float a[4], bq[4], cc[4], d[4], v[4];
-            Store<T>::ld4(Tq + (long(y0) * p.w + x0) * p.ldt, a);
-            Store<T>::ld4(Tq + (long(y0) * p.w + x1i) * p.ldt, bq);
-            Store<T>::ld4(Tq + (long(y1) * p.w + x0) * p.ldt, cc);
-            Store<T>::ld4(Tq + (long(y1) * p.w + x1i) * p.ldt, d);
+            const float w00 = ok ? hy * hx : 0.f, w01 = ok ? hy * lx : 0.f, w10 = ok ? ly * hx : 0.f, w11 = ok ? ly * lx : 0.f;
+            const T* t0 = Tq + (y0 * p.w + x0) * ldt;
             ACH_UNROLL
-            for (int i = 0; i < 4; ++i) { const float t = hy * (hx * a[i] + lx * bq[i]) + ly * (hx * cc[i] + lx * d[i]); v[i] = (ok && t > 0.f) ? t : 0.f; }
-            if (pos_raw < H2 * W2) *reinterpret_cast<float4*>(x1s + pos * CS + c) = make_float4(v[0], v[1], v[2], v[3]);
+            for (int c8 = 0; c8 < CG; c8 += 8) {
+                float a[8], bq[8], cc[8], d[8];
+                Store<T>::ld8(t0 + c8, a);
+                Store<T>::ld8(t0 + dx + c8, bq);
+                Store<T>::ld8(t0 + dy + c8, cc);
+                Store<T>::ld8(t0 + dy + dx + c8, d);
+                float v[8];
+                ACH_UNROLL
+                for (int i = 0; i < 8; ++i) { const float t = w00 * a[i] + w01 * bq[i] + w10 * cc[i] + w11 * d[i]; v[i] = t > 0.f ? t : 0.f; }
+                if (pos_raw < H2 * W2) {
+                    *reinterpret_cast<float4*>(x1s + pos * CS + c8) = make_float4(v[0], v[1], v[2], v[3]);
+                    *reinterpret_cast<float4*>(x1s + pos * CS + c8 + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                }
+            }
         }
     }
     __syncthreads();
