@@ -203,6 +203,18 @@ __device__ __forceinline__ unsigned long long wave_read64(unsigned long long v, 
 __device__ __forceinline__ unsigned long long wave_ballot64(bool pred) { return __ballot(pred); }
 #endif
 
+// orders a wave's LDS writes before its own later LDS reads of other lanes' data (a wave's LDS operations execute in order; this
+// only stops the compiler from moving them).  The CPU emulation needs a real rendezvous of the 64 fibers.
+#if defined(ACH_HOSTEMU)
+__device__ inline void wave_sync() { (void)__shfl(0, 0); }
+#else
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+#endif
+
 // max over each row of 16 lanes (all 16 lanes receive it): four DPP VALU ops instead of four LDS-routed shuffles.
 // quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror pair up lanes / quads / halves of the row.
 #if defined(ACH_HOSTEMU)

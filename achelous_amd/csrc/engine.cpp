@@ -1030,7 +1030,10 @@ public:
             Lin lm = conv_lin(d + ".modulator_conv.weight", d + ".modulator_conv.bias", C, Cp, 3);
             if (lo.N != 18 || lm.N != 9) throw AchError{ACH_ERR_MISSING_KEY, "deformable conv shapes at " + d};
             Lin lom; lom.N = 27; lom.K = lo.K; lom.w = lo.w; lom.w.insert(lom.w.end(), lm.w.begin(), lm.w.end()); lom.b = lo.b; lom.b.insert(lom.b.end(), lm.b.begin(), lm.b.end());
-            A om = conv3_bordered(pfx + ".offmask", pooled, lom, ACT_NONE);
+            const int cvp = int(pooled.ld) / VEC, ksp = cdiv(9 * cvp, 4);
+            const bool fused_front = fuse_rc && C <= 16 && (ksp == 3 || ksp == 5 || ksp == 9);
+            A om;
+            if (!fused_front) om = conv3_bordered(pfx + ".offmask", pooled, lom, ACT_NONE);
             // regular_conv (no bias) folded with weight_conv1 (bias) and BatchNorm:  Wf[co][k][c] = sum_m W1'[co][m] Wd3[m][c][k]
             std::vector<float> sc, sh; bn_coeffs(pfx + ".norm", 1e-5, sc, sh);
             const HostTensor& w1 = W(pfx + ".weight_conv1.weight"); const HostTensor& b1 = W(pfx + ".weight_conv1.bias");
@@ -1047,6 +1050,20 @@ public:
                     }
             }
             A y;
+            if (fused_front) {           // conv + sampling + folded contraction + ReLU + residual as one launch (k_conv3.h)
+                Packed pkom = pack(lom), pkf = pack(lf);
+                if (pkom.NT != 2 || pkom.nchunks != 1 || pkom.ksteps != ksp || pkf.NT != 1 || pkf.nchunks != 1 || pkf.ksteps != ksp)
+                    throw AchError{ACH_ERR_UNSUPPORTED, "radar block packing at " + pfx};
+                std::vector<float> b32(32, 0.f), b16(16, 0.f);
+                for (int n = 0; n < 27; ++n) b32[n] = lom.b[n];
+                for (int n = 0; n < C; ++n) b16[n] = lf.b[n];
+                y = alloc(B, x.H, x.W, C);
+                RcFrontParams rp{pooled.p0, pooled.ld, pooled.row, pooled.img, pkom.w, up_f32(b32), pkf.w, up_f32(b16), x.p, x.ld, y.p, y.ld,
+                                 B, x.H, x.W, cvp, C};
+                const double bytes = double(x.rows()) * (pooled.ld + x.ld + y.ld) * sizeof(T);
+                add_op(pfx + ".front", [rp, ksp](hipStream_t s) { launch_rc_front<T>(rp, ksp, s); }, bytes,
+                       2.0 * double(x.rows()) * 9.0 * Cp * (27 + C));
+            } else {
             DeformParams dp;
             std::memset(&dp, 0, sizeof(dp));
             dp.pooled = pooled.p0; dp.ldp = pooled.ld; dp.prow = pooled.row; dp.pimg = pooled.img; dp.om = om.p; dp.ldo = om.ld; dp.res = x.p; dp.ldr = x.ld;
@@ -1065,6 +1082,7 @@ public:
                 y = alloc(B, x.H, x.W, C);
                 GemmOpt o; o.act = ACT_RELU; o.residual = &x;            // epilogue order: act, then + residual
                 gemm(pfx + ".deform.contract", col, pack(lf), y, o);
+            }
             }
             // weight_conv2: 1x1, or 3x3 stride 2
             const int k = down[i] ? 3 : 1;

@@ -12,6 +12,7 @@
 #pragma once
 #include "ach_platform.h"
 #include "k_gemm.h"
+#include "k_radar.h"
 
 namespace ach {
 
@@ -78,6 +79,148 @@ inline bool launch_conv3(const Conv3Params& p, int ksteps, hipStream_t stream) {
     if (ksteps == 3) { ACH_LAUNCH((conv3x3_rows_kernel<T, 3>), grid, block, stream, p); return true; }
     if (ksteps == 5) { ACH_LAUNCH((conv3x3_rows_kernel<T, 5>), grid, block, stream, p); return true; }
     if (ksteps == 9) { ACH_LAUNCH((conv3x3_rows_kernel<T, 9>), grid, block, stream, p); return true; }
+    return false;
+}
+
+}  // namespace ach
+
+namespace ach {
+
+// ------------------------------------------------------------------------------------------ RCBlock front half, fused
+// offset/modulator conv (above) + modulated deformable 3x3 sampling + [regular_conv . weight_conv1 . BN] + ReLU + residual
+// (radar_models/dcn.py:49-63, RadarEncoder.py:80-92) for blocks of up to 16 channels, in ONE kernel: the 27-channel
+// offset/mask tensor — 64 B per pixel, the dominant HBM traffic of both separate kernels at 320x320 and 160x160 — never leaves
+// the chip.  Per 16-pixel tile of an output row:
+//   1. conv: 2 x KS MFMAs -> the 27 offset/mask values of each pixel, parked in a 2 KB per-wave LDS tile;
+//   2. lane (pixel, g) owns k-slots 4s+g = (tap, channel vector): it reads that tap's (dy, dx, logit) from LDS, forms the
+//      bilinear footprint on the zero-bordered map (no validity logic), gathers 4 corners (16 B each), blends, and the packed
+//      result IS the B fragment of k-step s;
+//   3. KS MFMAs against the folded weights -> output channels, + bias, ReLU, + residual, one 8/16-byte store per lane.
+struct RcFrontParams {
+    const void* P; long ldp, prow, pimg;      // avg-pooled input with a zero border: pixel (0,0) of sample 0, row / image pitches
+    const void* Wom; const float* bom;        // offset + modulator conv: packed NT = 2, KS k-steps; bias[32]
+    const void* Wf; const float* bf;          // folded deformable weights [C][9*ldp]: packed NT = 1, KS k-steps; bias[16]
+    const void* R; long ldr;                  // block input (residual)
+    void* Y; long ldy;
+    int B, H, Wd, cv, C;
+};
+
+// NARROW: the block has at most 4 channels (the first RCBlock: 3) — only the first 4 channels of a corner are fetched and blended.
+template <class T, int KS, bool NARROW>
+__global__ __launch_bounds__(256, KS == 3 ? 3 : 1) void rc_front_kernel(const RcFrontParams p) {
+    constexpr int VEC = Store<T>::VEC;
+    __shared__ float oml[4][16][36];                               // per wave: [pixel][27 values], row padded against bank conflicts
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int px = lane & 15, g = lane >> 4;
+    const unsigned wg = xcd_block(blockIdx.x, gridDim.x);
+    const int b = int(wg / unsigned(p.H)), oy = int(wg - unsigned(b) * unsigned(p.H));
+    const int ldp = int(p.ldp), prow = int(p.prow);
+
+    int off[KS], tapi[KS], cofs[KS];
+    float ybase[KS], xbase[KS];
+    ACH_UNROLL
+    for (int s = 0; s < KS; ++s) {
+        const int q = 4 * s + g;
+        const int tap = q / p.cv, c = q - tap * p.cv;
+        const int ty = tap / 3, tx = tap - 3 * ty;
+        const bool live = tap < 9;
+        tapi[s] = live ? tap : -1;
+        cofs[s] = c * VEC;
+        off[s] = live ? (ty - 1) * prow + (tx - 1) * ldp + c * VEC : 0;
+        ybase[s] = float(oy + ty - 1);
+        xbase[s] = float(tx - 1);
+    }
+    const uint4* Wom = static_cast<const uint4*>(p.Wom) + lane;
+    const uint4* Wfp = static_cast<const uint4*>(p.Wf) + lane;
+    uint4 wom[KS][2], wfd[KS];
+    ACH_UNROLL
+    for (int s = 0; s < KS; ++s) { wom[s][0] = Wom[(s * 2) * 64]; wom[s][1] = Wom[(s * 2 + 1) * 64]; wfd[s] = Wfp[s * 64]; }
+    float bv[8], bo[4];
+    ACH_UNROLL
+    for (int i = 0; i < 8; ++i) bv[i] = p.bom[g * 8 + i];
+    ACH_UNROLL
+    for (int i = 0; i < 4; ++i) bo[i] = p.bf[g * 4 + i];
+
+    const T* Pimg = static_cast<const T*>(p.P) + long(b) * p.pimg;
+    const T* xrow = Pimg + long(oy) * p.prow;
+    const long rowpix = (long(b) * p.H + oy) * p.Wd;
+    const int ntiles = (p.Wd + 15) / 16;
+    // the conv inputs of the NEXT tile are fetched while the current tile is being sampled (one memory round trip hidden)
+    uint4 xf[KS];
+    auto fetch = [&](int tile) {
+        const int xr = tile * 16 + px;
+        const int x = xr < p.Wd ? xr : p.Wd - 1;
+        const T* xp = xrow + long(x) * ldp;
+        ACH_UNROLL
+        for (int s = 0; s < KS; ++s) xf[s] = *reinterpret_cast<const uint4*>(xp + off[s]);
+    };
+    if (wave < ntiles) fetch(wave);
+    for (int tile = wave; tile < ntiles; tile += 4) {
+        const int xr = tile * 16 + px;
+        const bool valid = xr < p.Wd;
+        const int x = valid ? xr : p.Wd - 1;
+        {   // 1. offsets + modulator logits of the tile
+            f32x4 a0, a1;
+            a0[0] = a0[1] = a0[2] = a0[3] = 0.f;
+            a1[0] = a1[1] = a1[2] = a1[3] = 0.f;
+            ACH_UNROLL
+            for (int s = 0; s < KS; ++s) { mfma16<T>(wom[s][0], xf[s], a0); mfma16<T>(wom[s][1], xf[s], a1); }
+            float* o = &oml[wave][px][g * 8];
+            *reinterpret_cast<float4*>(o) = make_float4(a0[0] + bv[0], a0[1] + bv[1], a0[2] + bv[2], a0[3] + bv[3]);
+            *reinterpret_cast<float4*>(o + 4) = make_float4(a1[0] + bv[4], a1[1] + bv[5], a1[2] + bv[6], a1[3] + bv[7]);
+        }
+        if (tile + 4 < ntiles) fetch(tile + 4);
+        wave_sync();
+        f32x4 acc;
+        acc[0] = acc[1] = acc[2] = acc[3] = 0.f;
+        ACH_UNROLL
+        for (int s = 0; s < KS; ++s) {   // 2. + 3.
+            const int tap = tapi[s] < 0 ? 0 : tapi[s];
+            const float* om = &oml[wave][px][0];
+            const float dy = om[2 * tap], dx = om[2 * tap + 1], ml = om[18 + tap];
+            const BilinearTap t = make_tap(ybase[s] + dy, float(x) + xbase[s] + dx, modulation(ml), p.H, p.Wd, prow, ldp);
+            const T* P0 = Pimg + cofs[s];
+            const float live = tapi[s] < 0 ? 0.f : 1.f;
+            const float w00 = t.w00 * live, w01 = t.w01 * live, w10 = t.w10 * live, w11 = t.w11 * live;
+            float v[8];
+            if constexpr (NARROW && VEC == 8) {
+                float a[4], bq[4], cc[4], d[4];
+                Store<T>::ld4(P0 + t.o0, a); Store<T>::ld4(P0 + t.o0 + ldp, bq); Store<T>::ld4(P0 + t.o1, cc); Store<T>::ld4(P0 + t.o1 + ldp, d);
+                ACH_UNROLL
+                for (int i = 0; i < 4; ++i) { v[i] = w00 * a[i] + w01 * bq[i] + w10 * cc[i] + w11 * d[i]; v[4 + i] = 0.f; }
+            } else {
+                float a[8], bq[8], cc[8], d[8];
+                frag_unpack<T>(*reinterpret_cast<const uint4*>(P0 + t.o0), a);
+                frag_unpack<T>(*reinterpret_cast<const uint4*>(P0 + t.o0 + ldp), bq);
+                frag_unpack<T>(*reinterpret_cast<const uint4*>(P0 + t.o1), cc);
+                frag_unpack<T>(*reinterpret_cast<const uint4*>(P0 + t.o1 + ldp), d);
+                ACH_UNROLL
+                for (int i = 0; i < VEC; ++i) v[i] = w00 * a[i] + w01 * bq[i] + w10 * cc[i] + w11 * d[i];
+            }
+            mfma16<T>(wfd[s], frag_pack<T>(v), acc);
+        }
+        wave_sync();                                                // the LDS tile is rewritten by the next iteration
+        const int ch = g * 4;
+        if (valid && ch < int(p.ldy)) {
+            float rr[4], ov[4];
+            Store<T>::ld4(static_cast<const T*>(p.R) + (rowpix + x) * p.ldr + ch, rr);
+            ACH_UNROLL
+            for (int i = 0; i < 4; ++i) { const float r = acc[i] + bo[i]; ov[i] = (r > 0.f ? r : 0.f) + rr[i]; }
+            Store<T>::st4(static_cast<T*>(p.Y) + (rowpix + x) * p.ldy + ch, ov);
+        }
+    }
+}
+
+template <class T>
+inline bool launch_rc_front(const RcFrontParams& p, int ksteps, hipStream_t stream) {
+    const dim3 grid(unsigned(p.B) * unsigned(p.H)), block(256);
+    const bool narrow = p.C <= 4 && Store<T>::VEC == 8;
+    if (ksteps == 3) {
+        if (narrow) ACH_LAUNCH((rc_front_kernel<T, 3, true>), grid, block, stream, p); else ACH_LAUNCH((rc_front_kernel<T, 3, false>), grid, block, stream, p);
+        return true;
+    }
+    if (ksteps == 5) { ACH_LAUNCH((rc_front_kernel<T, 5, false>), grid, block, stream, p); return true; }
+    if (ksteps == 9) { ACH_LAUNCH((rc_front_kernel<T, 9, false>), grid, block, stream, p); return true; }
     return false;
 }
 
