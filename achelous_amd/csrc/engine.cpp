@@ -548,9 +548,13 @@ public:
     // y = l2(act(l1(x))) as one launch (k_mlp.h without LayerNorm / residual); false when the widths are not instantiated
     bool chain2(const std::string& name, const A& x, const Lin& l1, int act, const Lin& l2, A& y) {
         if (!fuse_mlp) return false;
-        const int Cin = x.C, hidden = l1.N, Cout = l2.N, DT = mlp_pick_dt(std::max(Cin, Cout));
-        if (DT == 0 || l1.K != Cin || l2.K != hidden) return false;
+        const int Cin = x.C, hidden = l1.N, Cout = l2.N;
         const int k1 = cdiv(Cin, KC), J = cdiv(hidden, 32), hstep = 8 / VEC, ks2 = J * hstep;
+        const bool split = mlp_split < 0 ? x.H * x.W <= 1024 : mlp_split != 0;
+        // narrow layers on maps that are not latency-bound: every weight fragment in registers, several tiles per wave (chain_kernel)
+        const bool small = Cout <= 32 && k1 <= 3 && J <= 2 && !split;
+        const int DT = small ? 2 : mlp_pick_dt(std::max(Cin, Cout));
+        if (DT == 0 || l1.K != Cin || l2.K != hidden) return false;
         std::vector<float> w1(size_t(J) * k1 * 2 * 64 * VEC, 0.f), b1(size_t(J) * 32, 0.f);
         std::vector<float> w2(size_t(ks2) * DT * 64 * VEC, 0.f), b2(size_t(DT) * 16, 0.f);
         if (!measuring) {
@@ -572,8 +576,7 @@ public:
         mp.X = x.p; mp.ldx = x.ld; mp.Y = y.p; mp.ldy = y.ld;
         mp.W1 = up_T(w1); mp.b1 = up_f32(b1); mp.W2 = up_T(w2); mp.b2 = up_f32(b2);
         mp.M = x.rows(); mp.C = Cin; mp.k1 = k1; mp.J = J; mp.act = act; mp.ln = 0; mp.Cout = Cout;
-        const bool split = mlp_split < 0 ? x.H * x.W <= 1024 : mlp_split != 0;
-        add_op(name, [mp, DT, split](hipStream_t s) { launch_mlp<T>(mp, DT, split, s); },
+        add_op(name, [mp, DT, split, small](hipStream_t s) { if (small) launch_chain<T>(mp, s); else launch_mlp<T>(mp, DT, split, s); },
                double(mp.M) * (Cin + Cout) * sizeof(T), 2.0 * double(mp.M) * hidden * (Cin + Cout));
         return true;
     }

@@ -295,3 +295,101 @@ inline int mlp_pick_dt(int C) {
 }
 
 }  // namespace ach
+
+namespace ach {
+
+// ------------------------------------------------------------------------------------------ small two-layer chain
+// y = W2 · act(W1 x + b1) + b2 for narrow layers (<= 48 inputs, <= 64 hidden, <= 32 outputs: the low-resolution conv pair of
+// every decoder level, up to 1.6 M pixels).  Same register chaining as mlp_kernel, but everything is compile-time sized so
+// that ALL weight fragments live in registers, and a wave walks several 16-pixel tiles with the next tile's rows prefetched:
+// per tile only the row load, 2 K1 J + J HSTEP 2 MFMAs, the activation and one 16-byte store remain — the kernel is then a
+// plain stream over x and y (HBM-bound).  Weight layouts are mlp_kernel's with DT = 2.
+constexpr int CHAIN_TILES_PER_WAVE = 4;
+template <class T, int K1, int J>
+__global__ __launch_bounds__(256) void chain_kernel(const MlpParams p) {
+    constexpr int VEC = Store<T>::VEC;
+    constexpr int KC = 4 * VEC;
+    constexpr int HSTEP = 8 / VEC;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int px = lane & 15, g = lane >> 4;
+    const uint4* W1f = static_cast<const uint4*>(p.W1) + lane;
+    const uint4* W2f = static_cast<const uint4*>(p.W2) + lane;
+    uint4 w1[J][K1][2], w2[J][HSTEP][2];
+    ACH_UNROLL
+    for (int j = 0; j < J; ++j) {
+        ACH_UNROLL
+        for (int s = 0; s < K1; ++s) { w1[j][s][0] = W1f[((j * K1 + s) * 2) * 64]; w1[j][s][1] = W1f[((j * K1 + s) * 2 + 1) * 64]; }
+        ACH_UNROLL
+        for (int hh = 0; hh < HSTEP; ++hh) { w2[j][hh][0] = W2f[((j * HSTEP + hh) * 2) * 64]; w2[j][hh][1] = W2f[((j * HSTEP + hh) * 2 + 1) * 64]; }
+    }
+    float b1[J][8], b2[8];
+    ACH_UNROLL
+    for (int j = 0; j < J; ++j)
+        ACH_UNROLL
+        for (int i = 0; i < 8; ++i) b1[j][i] = p.b1[j * 32 + g * 8 + i];
+    ACH_UNROLL
+    for (int i = 0; i < 8; ++i) b2[i] = p.b2[g * 8 + i];
+
+    const T* X = static_cast<const T*>(p.X);
+    const long tile0 = (long(blockIdx.x) * 4 + wave) * CHAIN_TILES_PER_WAVE;
+    uint4 xf[K1];
+    auto fetch = [&](long tile) {
+        const long mr = tile * 16 + px;
+        const long m = mr < p.M ? mr : p.M - 1;
+        ACH_UNROLL
+        for (int s = 0; s < K1; ++s) {
+            const int k0 = s * KC + g * VEC;
+            xf[s] = k0 < p.C ? *reinterpret_cast<const uint4*>(X + m * p.ldx + k0) : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    if (tile0 * 16 < p.M) fetch(tile0);
+    ACH_UNROLL
+    for (int t = 0; t < CHAIN_TILES_PER_WAVE; ++t) {
+        const long tile = tile0 + t;
+        if (tile * 16 >= p.M) break;
+        f32x4 acc[2];
+        acc[0][0] = acc[0][1] = acc[0][2] = acc[0][3] = 0.f;
+        acc[1][0] = acc[1][1] = acc[1][2] = acc[1][3] = 0.f;
+        f32x4 h0[J], h1[J];
+        ACH_UNROLL
+        for (int j = 0; j < J; ++j) {
+            h0[j][0] = h0[j][1] = h0[j][2] = h0[j][3] = 0.f;
+            h1[j][0] = h1[j][1] = h1[j][2] = h1[j][3] = 0.f;
+            ACH_UNROLL
+            for (int s = 0; s < K1; ++s) { mfma16<T>(w1[j][s][0], xf[s], h0[j]); mfma16<T>(w1[j][s][1], xf[s], h1[j]); }
+        }
+        const long mr = tile * 16 + px;
+        if (t + 1 < CHAIN_TILES_PER_WAVE && (tile + 1) * 16 < p.M) fetch(tile + 1);      // xf is free: all first-layer MFMAs are issued
+        ACH_UNROLL
+        for (int j = 0; j < J; ++j) {
+            float h[8];
+            ACH_UNROLL
+            for (int r = 0; r < 4; ++r) { h[r] = apply_act_t<T>(h0[j][r] + b1[j][r], p.act); h[4 + r] = apply_act_t<T>(h1[j][r] + b1[j][4 + r], p.act); }
+            ACH_UNROLL
+            for (int hh = 0; hh < HSTEP; ++hh) {
+                const uint4 hf = frag_pack<T>(h + hh * VEC);
+                mfma16<T>(w2[j][hh][0], hf, acc[0]);
+                mfma16<T>(w2[j][hh][1], hf, acc[1]);
+            }
+        }
+        const int nb = g * 8;
+        if (mr < p.M && nb < p.Cout) {
+            float o[8];
+            ACH_UNROLL
+            for (int r = 0; r < 4; ++r) { o[r] = acc[0][r] + b2[r]; o[4 + r] = acc[1][r] + b2[4 + r]; }
+            Store<T>::st8(static_cast<T*>(p.Y) + mr * p.ldy + nb, o);
+        }
+    }
+}
+
+template <class T>
+inline bool launch_chain(const MlpParams& p, hipStream_t stream) {
+    const long tiles = (p.M + 15) / 16;
+    const dim3 grid(unsigned((tiles + 4 * CHAIN_TILES_PER_WAVE - 1) / (4 * CHAIN_TILES_PER_WAVE))), block(256);
+#define ACH_CHAIN_CASE(KK, JJ) if (p.k1 == KK && p.J == JJ) { ACH_LAUNCH((chain_kernel<T, KK, JJ>), grid, block, stream, p); return true; }
+    ACH_CHAIN_CASE(1, 1) ACH_CHAIN_CASE(2, 1) ACH_CHAIN_CASE(3, 1) ACH_CHAIN_CASE(1, 2) ACH_CHAIN_CASE(2, 2) ACH_CHAIN_CASE(3, 2)
+#undef ACH_CHAIN_CASE
+    return false;
+}
+
+}  // namespace ach
