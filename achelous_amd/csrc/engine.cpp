@@ -818,18 +818,23 @@ public:
         UpParams p{t.p, t.ld, dst.p, dst.ld, x.B, x.H, x.W, l.N};
         ew(pfx + ".bilinear", upsample2x_kernel<T>, p, long(x.B) * x.H * 2 * x.W * 2 * (l.N / 4), 5.0 * x.rows() * l.N * sizeof(T));
     }
-    A shuffle_attention(const std::string& pfx, const A& x) {                   // shuffle_attention.py:48-72, G = 4
+    // the two ShuffleAttention modules that open the decoders, on their common input (shuffle_attention.py:48-72, G = 4)
+    void shuffle_attention_pair(const std::string& pfx0, const std::string& pfx1, const A& x, A& y0, A& y1) {
         float* partial = nullptr;
-        const int S = stats(pfx + ".stats", x, partial);
-        float* coef = alloc_f32(size_t(x.B) * x.C * 2);
-        SaCoefParams pc{partial, S, coef, up_f32(W(pfx + ".cweight").data), up_f32(W(pfx + ".cbias").data), up_f32(W(pfx + ".sweight").data),
-                        up_f32(W(pfx + ".sbias").data), up_f32(W(pfx + ".gn.weight").data), up_f32(W(pfx + ".gn.bias").data),
-                        x.B, x.C, 4, x.H * x.W, 1e-5f};
-        ew(pfx + ".coef", sa_coef_kernel, pc, long(x.B) * x.C);
-        A y = alloc(x.B, x.H, x.W, x.C);
-        SaApplyParams pa{x.p, x.ld, y.p, y.ld, coef, x.B, x.H * x.W, x.C};
-        ew(pfx + ".apply", sa_apply_kernel<T>, pa, x.rows() * x.C);
-        return y;
+        const int S = stats(pfx0 + ".stats", x, partial);
+        float* coef = alloc_f32(size_t(2) * x.B * x.C * 2);
+        SaCoefParams pc;
+        std::memset(&pc, 0, sizeof(pc));
+        pc.partial = partial; pc.S = S; pc.coef = coef; pc.B = x.B; pc.C = x.C; pc.G = 4; pc.HW = x.H * x.W; pc.eps = 1e-5f;
+        const std::string* pf[2] = {&pfx0, &pfx1};
+        for (int m = 0; m < 2; ++m)
+            pc.w[m] = SaWeights{up_f32(W(*pf[m] + ".cweight").data), up_f32(W(*pf[m] + ".cbias").data), up_f32(W(*pf[m] + ".sweight").data),
+                                up_f32(W(*pf[m] + ".sbias").data), up_f32(W(*pf[m] + ".gn.weight").data), up_f32(W(*pf[m] + ".gn.bias").data)};
+        ew(pfx0 + ".coef", sa_coef_kernel, pc, long(2) * x.B * x.C);
+        y0 = alloc(x.B, x.H, x.W, x.C);
+        y1 = alloc(x.B, x.H, x.W, x.C);
+        SaApplyParams pa{x.p, x.ld, y0.p, y1.p, y0.ld, coef, x.B, x.H * x.W, x.C};
+        ew(pfx0 + ".apply", sa_apply_kernel<T>, pa, x.rows() * x.C, 3.0 * x.rows() * x.C * sizeof(T));
     }
     // one decoder level: Upsample (1x1+BN+ReLU, bilinear x2) + GhostModule, restructured (see upghost_kernel):
     // both 1x1 convs at low resolution on MFMA, then one fused full-resolution kernel.
@@ -924,7 +929,6 @@ public:
         A p3 = ghost_bottleneck(f + ".ghost_4_to_3", c3, w[1]);
         tap("fpn4", p4); tap("fpn3", p3);
         const bool split_dec = split_decoders < 0 ? batch <= 16 : split_decoders != 0;
-        if (split_dec) signal_after_last(2);   // p3 ready: the semantic decoder may start on its own stream
         // residual FPN outputs (ghostdualfpn.py:200) — computed BEFORE the decoders so that the detection branch (fusion + head,
         // on the radar stream) can start while the two heavy decoders still run on this stream
         q[0] = alloc(p3.B, p3.H, p3.W, p3.C); add(f + ".q3", p3, m3, q[0]);
@@ -936,11 +940,15 @@ public:
         const char* sa[2] = {"stage_3_lane_seg", "stage_3_semantic_seg"};
         const int oups[2] = {2, cfg.num_seg};
         void** outs[2] = {&io.lane, &io.se};
+        A ysa[2];
+        shuffle_attention_pair(f + "." + sa[0], f + "." + sa[1], p3, ysa[0], ysa[1]);
+        if (split_dec) signal_after_last(2);   // the semantic decoder may start on its own stream
         for (int d = 0; d < 2; ++d) {
-            // the two decoders only share their input: water-line decoder on the caller's stream, semantic decoder on stream 3
+            // past the shared attention stage the two decoders are independent: water-line decoder on the caller's stream, semantic
+            // decoder on stream 3 when the option is on
             if (d == 1 && split_dec) { cur_stream = 3; wait_before_next(2); }
             const std::string n = names[d];
-            A y = shuffle_attention(f + "." + sa[d], p3);
+            A y = ysa[d];
             tap(n + ".sa", y);
             const char* lv[3] = {"3_to_2", "2_to_1", "1_to_0"};
             const int cw[3] = {w[1], w[0], w[0]};

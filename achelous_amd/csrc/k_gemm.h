@@ -153,12 +153,32 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
             ACH_UNROLL
             for (int t = 0; t < NT; ++t) { acc[q][t][0] = 0.f; acc[q][t][1] = 0.f; acc[q][t][2] = 0.f; acc[q][t][3] = 0.f; }
 
-        for (int s = 0; s < p.ksteps; ++s) {
-            uint4 xf[P];
+        // k-loop with the operands of step s+1 requested before the MFMAs of step s are issued: on the small maps a wave's
+        // lifetime is a chain of dependent L2 round trips, and this halves the chain
+        uint4 xn[P], wn[NT];
+        ACH_UNROLL
+        for (int q = 0; q < P; ++q) xn[q] = load_x(q, 0);
+        {
+            const uint4* wrow = Wf + (long(c) * p.ksteps) * NT * 64 + lane;
             ACH_UNROLL
-            for (int q = 0; q < P; ++q) {
-                xf[q] = load_x(q, s);
-                if (p.ln) {
+            for (int t = 0; t < NT; ++t) wn[t] = wrow[t * 64];
+        }
+        for (int s = 0; s < p.ksteps; ++s) {
+            uint4 xf[P], wf[NT];
+            ACH_UNROLL
+            for (int q = 0; q < P; ++q) xf[q] = xn[q];
+            ACH_UNROLL
+            for (int t = 0; t < NT; ++t) wf[t] = wn[t];
+            if (s + 1 < p.ksteps) {
+                ACH_UNROLL
+                for (int q = 0; q < P; ++q) xn[q] = load_x(q, s + 1);
+                const uint4* wrow = Wf + (long(c) * p.ksteps + s + 1) * NT * 64 + lane;
+                ACH_UNROLL
+                for (int t = 0; t < NT; ++t) wn[t] = wrow[t * 64];
+            }
+            if (p.ln) {
+                ACH_UNROLL
+                for (int q = 0; q < P; ++q) {
                     float v[8];
                     frag_unpack<T>(xf[q], v);
                     ACH_UNROLL
@@ -166,13 +186,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
                     xf[q] = frag_pack<T>(v);
                 }
             }
-            const uint4* wrow = Wf + (long(c) * p.ksteps + s) * NT * 64 + lane;
             ACH_UNROLL
-            for (int t = 0; t < NT; ++t) {
-                const uint4 wf = wrow[t * 64];
+            for (int t = 0; t < NT; ++t)
                 ACH_UNROLL
-                for (int q = 0; q < P; ++q) mfma16<T>(wf, xf[q], acc[q][t]);
-            }
+                for (int q = 0; q < P; ++q) mfma16<T>(wf[t], xf[q], acc[q][t]);
         }
 
         // ---- epilogue: lane holds, for pixel px of every sub-tile, the channels chunk_channel(NT, t, g, r) of this chunk

@@ -381,14 +381,20 @@ __global__ __launch_bounds__(256) void chan_stats_kernel(const StatParams p) {
 // coefficients: out = x * sigmoid(a*x + d) per (sample, channel)
 //   channel-attention half: a = 0, d = cweight*mean + cbias
 //   spatial half (GroupNorm with one channel per group): a = sweight*gnw*rstd, d = sweight*(gnb - gnw*mean*rstd) + sbias
+// Both decoders start with a ShuffleAttention of the SAME tensor (ghostdualfpn.py:175,187): the channel statistics are
+// computed once and the two modules (weight sets w[0], w[1]) share one coefficient launch and one apply launch that reads the
+// input once and writes both outputs.
+struct SaWeights { const float* cw; const float* cb; const float* sw; const float* sb; const float* gnw; const float* gnb; };
 struct SaCoefParams {
-    const float* partial; int S; float* coef;   // coef [B][C][2]
-    const float* cw; const float* cb; const float* sw; const float* sb; const float* gnw; const float* gnb;
+    const float* partial; int S; float* coef;   // coef [2][B][C][2]
+    SaWeights w[2];
     int B, C, G, HW; float eps;
 };
 __global__ void sa_coef_kernel(const SaCoefParams p) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= p.B * p.C) return;
+    const int gidx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gidx >= 2 * p.B * p.C) return;
+    const int m = gidx / (p.B * p.C), idx = gidx - m * p.B * p.C;
+    const SaWeights& w = p.w[m];
     const int b = idx / p.C, c = idx % p.C;
     float s1 = 0.f, s2 = 0.f;
     for (int s = 0; s < p.S; ++s) { const float* q = p.partial + (long(b) * p.S + s) * 2 * p.C; s1 += q[c]; s2 += q[p.C + c]; }
@@ -396,20 +402,20 @@ __global__ void sa_coef_kernel(const SaCoefParams p) {
     const int cg = p.C / p.G, half = cg / 2;        // channels per group, per half
     const int j = c % cg;
     float a, d;
-    if (j < half) { a = 0.f; d = p.cw[j] * mean + p.cb[j]; }
+    if (j < half) { a = 0.f; d = w.cw[j] * mean + w.cb[j]; }
     else {
         const int jj = j - half;
         float var = s2 / float(p.HW) - mean * mean;
         if (var < 0.f) var = 0.f;
         const float rstd = 1.0f / sqrtf(var + p.eps);
-        a = p.sw[jj] * p.gnw[jj] * rstd;
-        d = p.sw[jj] * (p.gnb[jj] - p.gnw[jj] * mean * rstd) + p.sb[jj];
+        a = w.sw[jj] * w.gnw[jj] * rstd;
+        d = w.sw[jj] * (w.gnb[jj] - w.gnw[jj] * mean * rstd) + w.sb[jj];
     }
-    p.coef[2 * idx] = a;
-    p.coef[2 * idx + 1] = d;
+    p.coef[2 * gidx] = a;
+    p.coef[2 * gidx + 1] = d;
 }
 // apply + channel_shuffle(groups=2): input channel c -> output channel (c % (C/2)) * 2 + c / (C/2)
-struct SaApplyParams { const void* X; long ldx; void* Y; long ldy; const float* coef; int B, HW, C; };
+struct SaApplyParams { const void* X; long ldx; void* Y0; void* Y1; long ldy; const float* coef; int B, HW, C; };
 template <class T>
 __global__ __launch_bounds__(256) void sa_apply_kernel(const SaApplyParams p) {
     const long total = long(p.B) * p.HW * p.C;
@@ -420,8 +426,10 @@ __global__ __launch_bounds__(256) void sa_apply_kernel(const SaApplyParams p) {
     const long b = pix / p.HW;
     const int c = (co & 1) * (p.C / 2) + (co >> 1);          // inverse of the shuffle
     const float x = Store<T>::ld(static_cast<const T*>(p.X) + pix * p.ldx + c);
-    const float* k = p.coef + (b * p.C + c) * 2;
-    Store<T>::st(static_cast<T*>(p.Y) + pix * p.ldy + co, x * sigmoidf_(k[0] * x + k[1]));
+    const float* k0 = p.coef + (b * p.C + c) * 2;
+    const float* k1 = k0 + long(p.B) * p.C * 2;
+    Store<T>::st(static_cast<T*>(p.Y0) + pix * p.ldy + co, x * sigmoidf_(k0[0] * x + k0[1]));
+    Store<T>::st(static_cast<T*>(p.Y1) + pix * p.ldy + co, x * sigmoidf_(k1[0] * x + k1[1]));
 }
 
 // ------------------------------------------------------------------------------------------ ECA + fusion
