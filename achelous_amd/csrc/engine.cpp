@@ -415,6 +415,7 @@ public:
         p.X = X.p; p.ldx = X.ld; p.X2 = X2 ? X2->p : nullptr; p.ldx2 = X2 ? X2->ld : 0;
         p.W = up_f32(wt); p.bias = up_f32(bias); p.Y = Y.p; p.ldy = Y.ld;
         p.B = X.B; p.H = X.H; p.Wd = X.W; p.C = C; p.Ho = Y.H; p.Wo = Y.W; p.stride = stride; p.act = act;
+        p.tile = (dw_tile && X.H * X.W <= 144) ? 1 : 0;      // measured: wins on 10x10 maps (2x), loses from 20x20 up (LDS issue bound)
         const double px_in = double(X.B) * X.H * X.W * C * sizeof(T), px_out = double(Y.B) * Y.H * Y.W * C * sizeof(T);
         add_op(name, [p, ks](hipStream_t s) { launch_dwconv<T>(p, ks, s); }, px_in * (X2 ? 2 : 1) + px_out, 0);
     }
@@ -1166,6 +1167,7 @@ public:
                 dp.X = cur.p; dp.ldx = cur.ld; dp.W = up_f32(wt); dp.bias = up_f32(bias); dp.Y = d.p; dp.ldy = d.ld;
                 dp.B = x.B; dp.H = x.H; dp.Wd = x.W; dp.C = 2 * base; dp.Ho = x.H; dp.Wo = x.W; dp.stride = 1; dp.act = ACT_NONE;
                 dp.cin_mod = (j == 0) ? base : 0;
+                dp.tile = (dw_tile && x.H * x.W <= 144) ? 1 : 0;
                 add_op("det_head.convs." + ks + "." + js + ".dconv", [dp](hipStream_t s) { launch_dwconv<T>(dp, 5, s); },
                        double(cur.rows()) * cur.C * sizeof(T) + double(d.rows()) * d.C * sizeof(T));
                 // pointwise, block diagonal

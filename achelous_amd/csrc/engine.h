@@ -68,6 +68,7 @@ public:
     bool fuse_mlp = true;             // option "fused_mlp": EdgeNeXt blocks as one kernel (k_mlp.h) instead of dw / pw1 / pw2 launches
     int split_decoders = -1;          // option "split_decoders": semantic decoder on its own stream (-1: only when batch <= 16, where the
                                       // step is launch-bound; at batch 64 the two decoders saturate the chip one after the other)
+    bool dw_tile = true;              // option "dw_tile": LDS-tiled depthwise kernel on the 10x10 maps
     bool fuse_rc = true;              // option "fused_rc": RCBlock conv + deformable sampling + contraction as one launch (k_conv3.h)
     bool row_conv = true;             // option "row_conv": narrow 3x3 convs through k_conv3.h instead of the generic implicit GEMM
     int mlp_split = -1;               // option "mlp_split": -1 auto (by tile count), 0 one tile per wave, 1 four waves per tile

@@ -16,6 +16,7 @@ struct DwParams {
     void* Y; long ldy;              // output [B,Ho,Wo,(C)]
     int B, H, Wd, C, Ho, Wo, stride, act;
     int cin_mod;                    // > 0: output channel c reads input channel c % cin_mod (two filter banks over one input)
+    int tile;                       // 1: LDS-tiled kernel (10x10 maps; measured slower than the strip kernel from 20x20 up), 0: strip kernel
 };
 
 // stride-1 kernel: one thread = 4 channels x a strip of OW consecutive output pixels of one row.  A row of the receptive
@@ -114,9 +115,75 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const DwParams p) {
     Store<T>::st4(static_cast<T*>(p.Y) + op * p.ldy + c, acc);
 }
 
+// stride-1 kernel for the smallest maps (10x10), where the strip kernel above is a chain of dependent global
+// loads (rocprofv3: waves 65 % waiting, 2.8 waves per SIMD): a workgroup stages an 8x8 output tile + halo of 16 channels in LDS
+// with every global load in flight at once (unpacked to fp32), plus the KS*KS weight vectors, and the taps then run from LDS:
+// two ds_read_b128 + two packed FMAs per tap per thread (thread = 4 channels x 1 output).
+constexpr int DWT_TS = 8;
+template <class T, int KS>
+__global__ __launch_bounds__(256) void dwconv_tile_kernel(const DwParams p) {
+    constexpr int TS = DWT_TS, HS = TS + KS - 1, PAD = KS / 2;
+    __shared__ float4 xs[HS * HS * 4];
+    __shared__ float4 ws[KS * KS * 4];
+    const int cq = p.C >> 2, cgroups = (cq + 3) >> 2;
+    const int tiles_x = (p.Wo + TS - 1) / TS, tiles_y = (p.Ho + TS - 1) / TS;
+    unsigned wg = blockIdx.x;
+    const int cg = int(wg % unsigned(cgroups)); wg /= unsigned(cgroups);
+    const int bx = int(wg % unsigned(tiles_x)) * TS; wg /= unsigned(tiles_x);
+    const int by = int(wg % unsigned(tiles_y)) * TS;
+    const long b = wg / unsigned(tiles_y);
+    const int q = threadIdx.x & 3, pos = threadIdx.x >> 2;
+    const int c = (cg * 4 + q) * 4;
+    const bool cok = c < p.C;
+    const int ci = p.cin_mod > 0 ? c % p.cin_mod : c;
+    const T* X = static_cast<const T*>(p.X) + b * p.H * long(p.Wd) * p.ldx + ci;
+    const T* X2 = p.X2 ? static_cast<const T*>(p.X2) + b * p.H * long(p.Wd) * p.ldx2 + ci : nullptr;
+    for (int i = pos; i < HS * HS; i += 64) {
+        const int hy = i / HS, hx = i - hy * HS;
+        const int iy = by + hy - PAD, ix = bx + hx - PAD;
+        const bool ok = cok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.Wd;
+        const long ip = long(ok ? iy : 0) * p.Wd + (ok ? ix : 0);
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (cok) {
+            Store<T>::ld4(X + ip * p.ldx, v);
+            if (X2) { float u[4]; Store<T>::ld4(X2 + ip * p.ldx2, u); v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3]; }
+        }
+        xs[i * 4 + q] = ok ? make_float4(v[0], v[1], v[2], v[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int i = pos; i < KS * KS; i += 64)
+        ws[i * 4 + q] = cok ? *reinterpret_cast<const float4*>(p.W + long(i) * p.C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    const int ty = pos / TS, tx = pos - ty * TS;
+    const int oy = by + ty, ox = bx + tx;
+    if (!cok || oy >= p.Ho || ox >= p.Wo) return;
+    const float4 bb = *reinterpret_cast<const float4*>(p.bias + c);
+    f32x2 a0 = {bb.x, bb.y}, a1 = {bb.z, bb.w};
+    ACH_UNROLL
+    for (int ky = 0; ky < KS; ++ky)
+        ACH_UNROLL
+        for (int kx = 0; kx < KS; ++kx) {
+            const float4 v = xs[((ty + ky) * HS + tx + kx) * 4 + q];
+            const float4 w = ws[(ky * KS + kx) * 4 + q];
+            const f32x2 v0 = {v.x, v.y}, v1 = {v.z, v.w}, w0 = {w.x, w.y}, w1 = {w.z, w.w};
+            a0 += v0 * w0; a1 += v1 * w1;
+        }
+    float t[4] = {apply_act(a0[0], p.act), apply_act(a0[1], p.act), apply_act(a1[0], p.act), apply_act(a1[1], p.act)};
+    Store<T>::st4(static_cast<T*>(p.Y) + ((b * p.Ho + oy) * long(p.Wo) + ox) * p.ldy + c, t);
+}
+
 template <class T>
 inline void launch_dwconv(const DwParams& p, int ks, hipStream_t s) {
     const dim3 block(256);
+    if (p.stride == 1 && p.tile && p.Ho == p.H && p.Wo == p.Wd) {
+        const dim3 grid(unsigned(p.B) * unsigned(cdiv(p.Ho, DWT_TS)) * unsigned(cdiv(p.Wo, DWT_TS)) * unsigned((p.C / 4 + 3) / 4));
+        switch (ks) {
+            case 3: ACH_LAUNCH((dwconv_tile_kernel<T, 3>), grid, block, s, p); return;
+            case 5: ACH_LAUNCH((dwconv_tile_kernel<T, 5>), grid, block, s, p); return;
+            case 7: ACH_LAUNCH((dwconv_tile_kernel<T, 7>), grid, block, s, p); return;
+            case 9: ACH_LAUNCH((dwconv_tile_kernel<T, 9>), grid, block, s, p); return;
+            default: break;
+        }
+    }
     if (p.stride == 1) {
         constexpr int OW = 4;
         const long total = long(p.B) * p.Ho * cdiv(p.Wo, OW) * (p.C / 4);
