@@ -498,13 +498,19 @@ public:
     // One launch for [depthwise kxk ->] LN -> Linear -> act -> Linear -> scale -> + resid (k_mlp.h).  Returns false when the
     // width is outside the kernel's instantiations (the caller then runs the layer-wise path).
     bool fused_mlp(const std::string& pfx, const A& xin, const A& resid, int dw_ks, A& y) {
-        if (!fuse_mlp) return false;
-        const int C = xin.C, DT = mlp_pick_dt(C);
-        if (DT == 0 || (dw_ks != 0 && dw_ks != 3 && dw_ks != 5 && dw_ks != 7 && dw_ks != 9)) return false;
+        if (!fuse_mlp || mlp_pick_dt(xin.C) == 0) return false;
         Lin l1 = lin(pfx + ".pwconv1.weight", pfx + ".pwconv1.bias");
         fold_ln_in(l1, pfx + ".norm");
         Lin l2 = lin(pfx + ".pwconv2.weight", pfx + ".pwconv2.bias");
         fold_scale_out(l2, W(pfx + ".gamma").data);
+        return fused_mlp_lin(pfx + (dw_ks ? ".block" : ".mlp"), pfx, xin, resid, dw_ks, l1, l2, ACT_GELU, 1e-6f, y);
+    }
+    // generic form: l1 has the LayerNorm affine folded in, l2 any output scale; `pfx`.dwconv.{weight,bias} when dw_ks > 0
+    bool fused_mlp_lin(const std::string& name, const std::string& pfx, const A& xin, const A& resid, int dw_ks, const Lin& l1, const Lin& l2,
+                       int act, float ln_eps, A& y) {
+        if (!fuse_mlp) return false;
+        const int C = xin.C, DT = mlp_pick_dt(C);
+        if (DT == 0 || (dw_ks != 0 && dw_ks != 3 && dw_ks != 5 && dw_ks != 7 && dw_ks != 9)) return false;
         const int hidden = l1.N, k1 = cdiv(C, KC), J = cdiv(hidden, 32), hstep = 8 / VEC, ks2 = J * hstep;
         if (l1.K != C || l2.N != C || l2.K != hidden) throw AchError{ACH_ERR_MISSING_KEY, "MLP shapes at " + pfx};
         std::vector<float> w1(size_t(J) * k1 * 2 * 64 * VEC, 0.f), b1(size_t(J) * 32, 0.f);
@@ -538,12 +544,12 @@ public:
             mp.Wdw = up_f32(wt); mp.bdw = up_f32(bt);
         }
         mp.W1 = up_T(w1); mp.b1 = up_f32(b1); mp.W2 = up_T(w2); mp.b2 = up_f32(b2);
-        mp.M = xin.rows(); mp.C = C; mp.k1 = k1; mp.J = J; mp.act = ACT_GELU; mp.ln_eps = 1e-6f; mp.ln = 1; mp.Cout = C;
+        mp.M = xin.rows(); mp.C = C; mp.k1 = k1; mp.J = J; mp.act = act; mp.ln_eps = ln_eps; mp.ln = 1; mp.Cout = C;
         // per-sample map size, not batch, decides the geometry: a frame's result must not depend on the batch it is in
         const bool split = mlp_split < 0 ? xin.H * xin.W <= 1024 : mlp_split != 0;
         const double bytes = double(mp.M) * C * sizeof(T) * (xin.p == resid.p ? 2.0 : 3.0);
         const double flops = 4.0 * double(mp.M) * C * hidden + (dw_ks ? 2.0 * double(mp.M) * C * dw_ks * dw_ks : 0.0);
-        add_op(pfx + (dw_ks ? ".block" : ".mlp"), [mp, DT, split](hipStream_t s) { launch_mlp<T>(mp, DT, split, s); }, bytes, flops);
+        add_op(name, [mp, DT, split](hipStream_t s) { launch_mlp<T>(mp, DT, split, s); }, bytes, flops);
         return true;
     }
     // y = l2(act(l1(x))) as one launch (k_mlp.h without LayerNorm / residual); false when the widths are not instantiated
@@ -744,10 +750,14 @@ public:
             A t1 = alloc(t.B, t.H, t.W, D);
             { GemmOpt o; o.residual = &t; gemm(a + ".to_out", ao, pack(lin(a + ".fn.to_out.0.weight", a + ".fn.to_out.0.bias")), t1, o); }
             Lin l1 = lin(f + ".fn.net.0.weight", f + ".fn.net.0.bias"); fold_ln_in(l1, f + ".norm");
-            A hdn = alloc(t.B, t.H, t.W, l1.N);
-            { GemmOpt o; o.ln = true; o.ln_eps = 1e-5f; o.act = ACT_SILU; gemm(f + ".ff1", t1, pack(l1), hdn, o); }
-            A t2 = alloc(t.B, t.H, t.W, D);
-            { GemmOpt o; o.residual = &t1; gemm(f + ".ff2", hdn, pack(lin(f + ".fn.net.3.weight", f + ".fn.net.3.bias")), t2, o); }
+            Lin l2 = lin(f + ".fn.net.3.weight", f + ".fn.net.3.bias");
+            A t2;
+            if (!fused_mlp_lin(f + ".ffn", f, t1, t1, 0, l1, l2, ACT_SILU, 1e-5f, t2)) {      // LN -> fc1 -> SiLU -> fc2 -> + input (k_mlp.h)
+                A hdn = alloc(t.B, t.H, t.W, l1.N);
+                { GemmOpt o; o.ln = true; o.ln_eps = 1e-5f; o.act = ACT_SILU; gemm(f + ".ff1", t1, pack(l1), hdn, o); }
+                t2 = alloc(t.B, t.H, t.W, D);
+                { GemmOpt o; o.residual = &t1; gemm(f + ".ff2", hdn, pack(l2), t2, o); }
+            }
             t = t2;
         }
         // conv3 (1x1 D->C) written next to the block input: cat((conv3(x), y), 1) -> conv4 3x3
