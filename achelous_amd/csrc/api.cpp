@@ -77,6 +77,7 @@ int ach_set_option(ach_handle* h, const char* key, int32_t value) {
         else if (std::string(key) == "row_conv") h->eng->row_conv = value != 0;
         else if (std::string(key) == "fused_rc") h->eng->fuse_rc = value != 0;
         else if (std::string(key) == "dw_tile") h->eng->dw_tile = value != 0;
+        else if (std::string(key) == "head_batch") h->eng->head_batch = value != 0;
         else if (std::string(key) == "split_decoders") h->eng->split_decoders = value;
         else throw ach::AchError{ACH_ERR_INVALID, std::string("unknown option: ") + key};
     });

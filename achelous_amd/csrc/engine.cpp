@@ -387,10 +387,73 @@ public:
         const double in_bytes = o.conv_k > 0 ? double(M) / (double(o.Ho) * o.Wo) * o.Hin * o.Win * o.Cin * esz : double(M) * pk.K * esz;   // inputs read ONCE
         const double bytes = in_bytes + double(M) * pk.N * esz + (o.residual ? double(M) * pk.N * esz : 0.0)
                              + double(pk.group_elems) * esz * (o.w_group_stride ? o.groups : 1);
+        if (batching) {           // collected now, emitted by flush_batch() as one launch per layer across the pyramid levels
+            if (g.groups != 1 || P != 1) throw AchError{ACH_ERR_INVALID, name + ": batched GEMMs must be ungrouped"};
+            BatchJob j; j.kind = 0; j.name = name; j.g = g; j.NT = NT; j.ydyn = ydyn; j.bytes = bytes; j.flops = 2.0 * double(M) * pk.K * pk.N;
+            batch_jobs.push_back(j);
+            return;
+        }
         add_op(name, [g, NT, P, ydyn](hipStream_t s) mutable {
             if (ydyn) g.Y = *ydyn;
             launch_gemm<T>(g, NT, P, s);
         }, bytes, 2.0 * double(M) * pk.K * pk.N);
+    }
+    // ---- batching of the same layer over the detection head's pyramid levels
+    struct BatchJob { int kind = 0; std::string name; GemmParams g; int NT = 1; void** ydyn = nullptr; DwParams d; int ks = 0; double bytes = 0, flops = 0; };
+    bool batching = false;
+    std::vector<BatchJob> batch_jobs;
+    // `levels` chains of `per_level` jobs each were recorded level by level; emit stage s of all levels as one launch
+    void flush_batch(int levels, int per_level) {
+        batching = false;
+        if (int(batch_jobs.size()) != levels * per_level || levels > 3) throw AchError{ACH_ERR_INVALID, "head batching: unexpected job count"};
+        for (int st = 0; st < per_level; ++st) {
+            const BatchJob& j0 = batch_jobs[size_t(st)];
+            double bytes = 0, flops = 0;
+            const std::string name = j0.name + "+levels";
+            if (j0.kind == 0) {
+                GemmJobs m;
+                std::memset(&m, 0, sizeof(m));
+                m.n = levels;
+                unsigned gx = 1, gz = 1;
+                void** yd[3] = {nullptr, nullptr, nullptr};
+                for (int l = 0; l < levels; ++l) {
+                    const BatchJob& j = batch_jobs[size_t(l * per_level + st)];
+                    if (j.kind != 0 || j.NT != j0.NT) throw AchError{ACH_ERR_INVALID, "head batching: layer shapes differ across levels"};
+                    m.p[l] = j.g;
+                    m.nbx[l] = unsigned(cdivl(j.g.M_per_group, 64L));
+                    m.nbz[l] = unsigned(cdiv(j.g.nchunks, j.g.chunks_per_block));
+                    gx = std::max(gx, m.nbx[l]); gz = std::max(gz, m.nbz[l]);
+                    yd[l] = j.ydyn; bytes += j.bytes; flops += j.flops;
+                }
+                const dim3 grid(gx, unsigned(levels), gz), block(256);
+                const int NT = j0.NT;
+                void** y0 = yd[0]; void** y1 = yd[1]; void** y2 = yd[2];
+                add_op(name, [m, grid, block, NT, y0, y1, y2](hipStream_t s) mutable {
+                    if (y0) m.p[0].Y = *y0;
+                    if (y1) m.p[1].Y = *y1;
+                    if (y2) m.p[2].Y = *y2;
+                    if (NT == 1) ACH_LAUNCH((gemm_multi_kernel<T, 1>), grid, block, s, m);
+                    else if (NT == 2) ACH_LAUNCH((gemm_multi_kernel<T, 2>), grid, block, s, m);
+                    else ACH_LAUNCH((gemm_multi_kernel<T, 4>), grid, block, s, m);
+                }, bytes, flops);
+            } else {
+                DwJobs m;
+                std::memset(&m, 0, sizeof(m));
+                m.n = levels;
+                unsigned gx = 1;
+                for (int l = 0; l < levels; ++l) {
+                    const BatchJob& j = batch_jobs[size_t(l * per_level + st)];
+                    if (j.kind != 1 || j.ks != 5 || j.d.stride != 1) throw AchError{ACH_ERR_INVALID, "head batching: depthwise shapes differ across levels"};
+                    m.p[l] = j.d;
+                    m.nbx[l] = unsigned(cdivl(long(j.d.B) * j.d.Ho * cdiv(j.d.Wo, 4) * (j.d.C / 4), 256));
+                    gx = std::max(gx, m.nbx[l]);
+                    bytes += j.bytes;
+                }
+                const dim3 grid(gx, unsigned(levels)), block(256);
+                add_op(name, [m, grid, block](hipStream_t s) { ACH_LAUNCH((dwconv_strip_multi_kernel<T, 5, 4>), grid, block, s, m); }, bytes, 0);
+            }
+        }
+        batch_jobs.clear();
     }
     void gemm(const std::string& name, const A& X, const Packed& pk, const A& Y, const GemmOpt& o = GemmOpt()) {
         gemm(name, X.p, X.ld, X.rows(), pk, Y.p, Y.ld, o);
@@ -1119,31 +1182,55 @@ public:
     }
 
     // ------------------------------------------------------------------------------------------ fusion (a16)
-    A fuse(int stage, const A& img, const A& rad) {                              // IREncoder.py:79-89
+    // ECA channel attention + BatchNorm + ReLU on cat(image level, radar level) for the three pyramid levels (IREncoder.py:79-89).
+    // The six (level, source) jobs are independent: three launches in total — statistics, ECA scales, scaled write — each
+    // covering all six (Multi6 in k_nhwc.h), instead of eighteen small ones.
+    void fuse_all(const A img[3], const A rad[3], A out[3]) {
         const std::string e = "image_radar_encoder";
-        const std::string st = std::to_string(stage);
-        const int Ci = img.C, Cr = rad.C, HW = img.H * img.W;
-        std::vector<float> sc, sh; bn_coeffs(e + ".norm_stage" + st, 1e-5, sc, sh);
-        if (int(sc.size()) != Ci + Cr) throw AchError{ACH_ERR_MISSING_KEY, "fusion norm width"};
-        A y = alloc(img.B, img.H, img.W, Ci + Cr);
-        const A srcs[2] = {img, rad};
-        const char* tag[2] = {"img", "rad"};
-        int coff = 0;
-        for (int h = 0; h < 2; ++h) {
-            const A& x = srcs[h];
-            float* part = nullptr;
-            const int S = stats(e + ".eca_" + tag[h] + st + ".stats", x, part);
-            const HostTensor& wk = W(e + ".channel_attn_stage" + st + "." + std::to_string(h) + ".conv.weight");
-            float* scl = alloc_f32(size_t(x.B) * x.C);
-            EcaParams ep{part, S, up_f32(wk.data), int(wk.numel()), up_f32(std::vector<float>(sc.begin() + coff, sc.begin() + coff + x.C)), scl, x.B, x.C, HW};
-            ew(e + ".eca_" + tag[h] + st, eca_scale_kernel, ep, long(x.B) * x.C);
-            A ys = y.slice(coff, x.C);
-            FuseParams fp{x.p, x.ld, 0, ys.p, ys.ld, scl, up_f32(std::vector<float>(sh.begin() + coff, sh.begin() + coff + x.C)), x.B, HW, x.C};
-            ew(e + ".fuse_" + tag[h] + st, fuse_scale_kernel<T>, fp, x.rows() * x.C, 2.0 * x.rows() * x.C * sizeof(T));
-            coff += x.C;
+        Multi6<StatParams> ms; Multi6<EcaParams> me; Multi6<FuseParams> mf;
+        std::memset(&ms, 0, sizeof(ms)); std::memset(&me, 0, sizeof(me)); std::memset(&mf, 0, sizeof(mf));
+        int n = 0, smax = 1;
+        long eca_max = 0, fuse_max = 0;
+        double bytes = 0;
+        for (int l = 0; l < 3; ++l) {
+            const std::string st = std::to_string(3 + l);
+            const int Ci = img[l].C, Cr = rad[l].C, HW = img[l].H * img[l].W;
+            std::vector<float> sc, sh; bn_coeffs(e + ".norm_stage" + st, 1e-5, sc, sh);
+            if (int(sc.size()) != Ci + Cr) throw AchError{ACH_ERR_MISSING_KEY, "fusion norm width"};
+            out[l] = alloc(img[l].B, img[l].H, img[l].W, Ci + Cr);
+            const A srcs[2] = {img[l], rad[l]};
+            int coff = 0;
+            for (int h = 0; h < 2; ++h, ++n) {
+                const A& x = srcs[h];
+                const int S = HW >= 1024 ? 8 : (HW >= 256 ? 4 : 1);
+                float* part = alloc_f32(size_t(x.B) * S * 2 * x.C);
+                ms.j[n] = StatParams{x.p, x.ld, part, HW, x.C, S};
+                smax = std::max(smax, S);
+                const HostTensor& wk = W(e + ".channel_attn_stage" + st + "." + std::to_string(h) + ".conv.weight");
+                float* scl = alloc_f32(size_t(x.B) * x.C);
+                me.j[n] = EcaParams{part, S, up_f32(wk.data), int(wk.numel()), up_f32(std::vector<float>(sc.begin() + coff, sc.begin() + coff + x.C)), scl, x.B, x.C, HW};
+                eca_max = std::max(eca_max, long(x.B) * x.C);
+                A ys = out[l].slice(coff, x.C);
+                mf.j[n] = FuseParams{x.p, x.ld, 0, ys.p, ys.ld, scl, up_f32(std::vector<float>(sh.begin() + coff, sh.begin() + coff + x.C)), x.B, HW, x.C};
+                fuse_max = std::max(fuse_max, x.rows() * x.C);
+                bytes += 2.0 * x.rows() * x.C * sizeof(T);
+                coff += x.C;
+            }
+            tap("p" + st, out[l]);
         }
-        tap("p" + st, y);
-        return y;
+        ms.n = me.n = mf.n = n;
+        {
+            const dim3 grid(unsigned(img[0].B), unsigned(smax), unsigned(n)), block(256);
+            add_op(e + ".fusion.stats", [ms, grid, block](hipStream_t s) { ACH_LAUNCH(chan_stats_multi_kernel<T>, grid, block, s, ms); }, bytes / 2);
+        }
+        {
+            const dim3 grid(unsigned(cdivl(eca_max, 256)), unsigned(n)), block(256);
+            add_op(e + ".fusion.eca", [me, grid, block](hipStream_t s) { ACH_LAUNCH(eca_scale_multi_kernel, grid, block, s, me); });
+        }
+        {
+            const dim3 grid(unsigned(cdivl(fuse_max, 256)), unsigned(n)), block(256);
+            add_op(e + ".fusion.apply", [mf, grid, block](hipStream_t s) { ACH_LAUNCH(fuse_scale_multi_kernel<T>, grid, block, s, mf); }, bytes);
+        }
     }
 
     // ------------------------------------------------------------------------------------------ head (a17)
@@ -1154,6 +1241,8 @@ public:
     // the small maps where the head is latency-bound.
     void head(A p[3]) {                                                          // decouplehead.py:58-103
         const int NC5 = 5 + cfg.num_det;
+        batching = head_batch;          // the same six layers on three maps: one launch per layer for all levels (flush_batch)
+        batch_jobs.clear();
         for (int k = 0; k < 3; ++k) {
             const std::string ks = std::to_string(k);
             const A& x = p[k];
@@ -1178,6 +1267,11 @@ public:
                 dp.B = x.B; dp.H = x.H; dp.Wd = x.W; dp.C = 2 * base; dp.Ho = x.H; dp.Wo = x.W; dp.stride = 1; dp.act = ACT_NONE;
                 dp.cin_mod = (j == 0) ? base : 0;
                 dp.tile = (dw_tile && x.H * x.W <= 144) ? 1 : 0;
+                if (batching) {
+                    BatchJob bj; bj.kind = 1; bj.name = "det_head.convs." + ks + "." + js + ".dconv"; bj.d = dp; bj.ks = 5;
+                    bj.bytes = double(cur.rows()) * cur.C * sizeof(T) + double(d.rows()) * d.C * sizeof(T);
+                    batch_jobs.push_back(bj);
+                } else
                 add_op("det_head.convs." + ks + "." + js + ".dconv", [dp](hipStream_t s) { launch_dwconv<T>(dp, 5, s); },
                        double(cur.rows()) * cur.C * sizeof(T) + double(d.rows()) * d.C * sizeof(T));
                 // pointwise, block diagonal
@@ -1202,6 +1296,7 @@ public:
             GemmOpt o1; o1.ydyn = &io.det[k]; o1.out_nchw = 1; o1.HW = HW; o1.Ctot = NC5; o1.coff = 0;
             gemm("det_head.preds." + ks, cur.p, cur.ld, cur.rows(), pack(lp), nullptr, 0, o1);
         }
+        if (batching) flush_batch(3, 6);
     }
 
     // ------------------------------------------------------------------------------------------ PointNet (a18)
@@ -1303,7 +1398,8 @@ public:
         // outputs (event 1) — they overlap with the segmentation decoders that keep the caller's stream busy
         cur_stream = 1;
         wait_before_next(1);
-        A p[3] = {fuse(3, q[0], r[0]), fuse(4, q[1], r[1]), fuse(5, q[2], r[2])};
+        A p[3];
+        fuse_all(q, r, p);
         head(p);
         cur_stream = 0;
         interleave_streams();

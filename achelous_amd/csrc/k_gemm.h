@@ -68,14 +68,14 @@ __device__ __forceinline__ float order_decode(unsigned e) {
 }
 
 template <class T, int NT, int P>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
+__device__ __forceinline__ void gemm_body(const GemmParams& p, unsigned bx, unsigned nbx, unsigned by, unsigned bz) {
     constexpr int VEC = Store<T>::VEC;
     constexpr int KC = 4 * VEC;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int px = lane & 15, g = lane >> 4;
-    const int grp = blockIdx.y;
+    const int grp = by;
     // implicit-GEMM convs re-read halo rows across row tiles: XCD-aware tile order keeps those re-reads inside one L2
-    const unsigned rt = p.conv_k > 1 ? xcd_block(blockIdx.x, gridDim.x) : blockIdx.x;
+    const unsigned rt = p.conv_k > 1 ? xcd_block(bx, nbx) : bx;
     const long row0 = long(rt) * (64 * P) + wave * (16 * P);           // first row (within the group) of this wave
     const T* X = static_cast<const T*>(p.X);
     const uint4* Wf = reinterpret_cast<const uint4*>(static_cast<const T*>(p.W) + long(grp) * p.w_group_stride);
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
         }
     }
 
-    const int c_begin = blockIdx.z * p.chunks_per_block;
+    const int c_begin = int(bz) * p.chunks_per_block;
     const int c_end = (c_begin + p.chunks_per_block < p.nchunks) ? c_begin + p.chunks_per_block : p.nchunks;
     for (int c = c_begin; c < c_end; ++c) {
         f32x4 acc[P][NT];
@@ -262,6 +262,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
             }
         }
     }
+}
+
+template <class T, int NT, int P>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) { gemm_body<T, NT, P>(p, blockIdx.x, gridDim.x, blockIdx.y, blockIdx.z); }
+
+// Up to three independent GEMMs of the same tile shape in one launch (blockIdx.y = job): the three pyramid levels of the
+// detection head run the same layer on maps of 1600 / 400 / 100 pixels — the small levels ride in the big level's launch
+// instead of costing a latency-bound launch each.  Jobs have groups == 1.
+struct GemmJobs { GemmParams p[3]; unsigned nbx[3], nbz[3]; int n; };
+template <class T, int NT>
+__global__ __launch_bounds__(256) void gemm_multi_kernel(const GemmJobs m) {
+    const unsigned j = blockIdx.y;
+    if (blockIdx.x >= m.nbx[j] || blockIdx.z >= m.nbz[j]) return;
+    gemm_body<T, NT, 1>(m.p[j], blockIdx.x, m.nbx[j], 0u, blockIdx.z);
 }
 
 // ---- shared MLP + max over the rows of a group (PointNet: conv1d -> BN -> [ReLU] -> max over the N points).

@@ -23,11 +23,11 @@ struct DwParams {
 // field is loaded once (KS + OW - 1 vector loads) and feeds all OW outputs from registers: k^2 -> k (k + OW - 1) / OW loads
 // per output (49 -> 17.5 for the 7x7 of EdgeNeXt stage 2), with the KS weight vectors of the row held in registers.
 template <class T, int KS, int OW>
-__global__ __launch_bounds__(256) void dwconv_strip_kernel(const DwParams p) {
+__device__ __forceinline__ void dwconv_strip_body(const DwParams& p, unsigned bx, unsigned nbx) {
     const int cq = p.C >> 2;
     const int strips = (p.Wo + OW - 1) / OW;
     const long total = long(p.B) * p.Ho * strips * cq;
-    const long idx = long(xcd_block(blockIdx.x, gridDim.x)) * blockDim.x + threadIdx.x;
+    const long idx = long(xcd_block(bx, nbx)) * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const int c = int(idx % cq) * 4;
     long r = idx / cq;
@@ -77,6 +77,17 @@ __global__ __launch_bounds__(256) void dwconv_strip_kernel(const DwParams p) {
         for (int i = 0; i < 4; ++i) t[i] = apply_act(acc[o][i], p.act);
         Store<T>::st4(Y + long(o) * p.ldy, t);
     }
+}
+
+template <class T, int KS, int OW>
+__global__ __launch_bounds__(256) void dwconv_strip_kernel(const DwParams p) { dwconv_strip_body<T, KS, OW>(p, blockIdx.x, gridDim.x); }
+// up to three independent maps in one launch (blockIdx.y = job; the detection head's three pyramid levels)
+struct DwJobs { DwParams p[3]; unsigned nbx[3]; int n; };
+template <class T, int KS, int OW>
+__global__ __launch_bounds__(256) void dwconv_strip_multi_kernel(const DwJobs m) {
+    const unsigned j = blockIdx.y;
+    if (blockIdx.x >= m.nbx[j]) return;
+    dwconv_strip_body<T, KS, OW>(m.p[j], blockIdx.x, m.nbx[j]);
 }
 
 // general kernel (any stride): one thread = 4 channels of one output pixel
@@ -414,9 +425,8 @@ __global__ __launch_bounds__(256) void copy_kernel(const CopyParams p) {
 // grid (B, S): block (b, s) reduces positions s, s+S, ... and writes partial[b][s][2][C]; the consumers add the S partials.
 struct StatParams { const void* X; long ldx; float* partial; int HW, C, S; };
 template <class T>
-__global__ __launch_bounds__(256) void chan_stats_kernel(const StatParams p) {
+__device__ __forceinline__ void chan_stats_body(const StatParams& p, int b, int s) {
     __shared__ float red[2][256];
-    const int b = blockIdx.x, s = blockIdx.y;
     const int tid = threadIdx.x;
     const T* X = static_cast<const T*>(p.X) + long(b) * p.HW * p.ldx;
     float* out = p.partial + (long(b) * p.S + s) * 2 * p.C;
@@ -442,6 +452,16 @@ __global__ __launch_bounds__(256) void chan_stats_kernel(const StatParams p) {
         }
         __syncthreads();
     }
+}
+template <class T>
+__global__ __launch_bounds__(256) void chan_stats_kernel(const StatParams p) { chan_stats_body<T>(p, blockIdx.x, blockIdx.y); }
+// up to 6 independent jobs in one launch (the six ECA inputs of the fusion stage): blockIdx.z = job
+template <class P> struct Multi6 { P j[6]; int n; };
+template <class T>
+__global__ __launch_bounds__(256) void chan_stats_multi_kernel(const Multi6<StatParams> m) {
+    const StatParams& p = m.j[blockIdx.z];
+    if (int(blockIdx.y) >= p.S) return;
+    chan_stats_body<T>(p, blockIdx.x, blockIdx.y);
 }
 
 // ------------------------------------------------------------------------------------------ ShuffleAttention
@@ -502,8 +522,7 @@ __global__ __launch_bounds__(256) void sa_apply_kernel(const SaApplyParams p) {
 // ------------------------------------------------------------------------------------------ ECA + fusion
 // scale[b][c] = sigmoid(conv1d_k(mean over HW)) * bn_scale[c] ; shift = bn_shift[c]
 struct EcaParams { const float* partial; int S; const float* w; int k; const float* bn_scale; float* scale; int B, C, HW; };
-__global__ void eca_scale_kernel(const EcaParams p) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void eca_scale_body(const EcaParams& p, int idx) {
     if (idx >= p.B * p.C) return;
     const int b = idx / p.C, c = idx % p.C;
     float g = 0.f;
@@ -516,12 +535,13 @@ __global__ void eca_scale_kernel(const EcaParams p) {
     }
     p.scale[idx] = sigmoidf_(g) * p.bn_scale[c];
 }
+__global__ void eca_scale_kernel(const EcaParams p) { eca_scale_body(p, blockIdx.x * blockDim.x + threadIdx.x); }
+__global__ void eca_scale_multi_kernel(const Multi6<EcaParams> m) { eca_scale_body(m.j[blockIdx.y], blockIdx.x * blockDim.x + threadIdx.x); }
 // Y[b,pix,c] = relu(X[b,pix,c] * scale[b][c] + shift[c]); X is NHWC (x_nchw = 0) or NCHW (radar branch)
 struct FuseParams { const void* X; long ldx; int x_nchw; void* Y; long ldy; const float* scale; const float* shift; int B, HW, C; };
 template <class T>
-__global__ __launch_bounds__(256) void fuse_scale_kernel(const FuseParams p) {
+__device__ __forceinline__ void fuse_scale_body(const FuseParams& p, long idx) {
     const long total = long(p.B) * p.HW * p.C;
-    const long idx = long(blockIdx.x) * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const int c = int(idx % p.C);
     const long pix = idx / p.C;
@@ -531,6 +551,10 @@ __global__ __launch_bounds__(256) void fuse_scale_kernel(const FuseParams p) {
     const float v = x * p.scale[b * p.C + c] + p.shift[c];
     Store<T>::st(static_cast<T*>(p.Y) + pix * p.ldy + c, v > 0.f ? v : 0.f);
 }
+template <class T>
+__global__ __launch_bounds__(256) void fuse_scale_kernel(const FuseParams p) { fuse_scale_body<T>(p, long(blockIdx.x) * blockDim.x + threadIdx.x); }
+template <class T>
+__global__ __launch_bounds__(256) void fuse_scale_multi_kernel(const Multi6<FuseParams> m) { fuse_scale_body<T>(m.j[blockIdx.y], long(blockIdx.x) * blockDim.x + threadIdx.x); }
 // per-channel sums of an NCHW tensor -> partial[b][0][2][C] (S = 1); one block per (b, c)
 struct StatNchwParams { const void* X; float* partial; int HW, C; };
 template <class T>
