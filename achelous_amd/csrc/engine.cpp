@@ -1002,7 +1002,7 @@ public:
         copy(f + ".cat3", m3, c3.slice(w[1], w[1]));
         A p3 = ghost_bottleneck(f + ".ghost_4_to_3", c3, w[1]);
         tap("fpn4", p4); tap("fpn3", p3);
-        const bool split_dec = split_decoders < 0 ? batch <= 16 : split_decoders != 0;
+        const bool split_dec = split_decoders != 0;
         // residual FPN outputs (ghostdualfpn.py:200) — computed BEFORE the decoders so that the detection branch (fusion + head,
         // on the radar stream) can start while the two heavy decoders still run on this stream
         q[0] = alloc(p3.B, p3.H, p3.W, p3.C); add(f + ".q3", p3, m3, q[0]);
