@@ -1318,9 +1318,11 @@ public:
         const int NT = pk.NT;
         const double bytes = double(x.rows) * pk.K * sizeof(T) + double(pk.group_elems) * sizeof(T) + double(B) * pk.N * sizeof(T);
         add_op(name, [g, grid, block, NT](hipStream_t s) {
-            if (NT == 1) ACH_LAUNCH((gemm_colmax_kernel<T, 1>), grid, block, s, g);
-            else if (NT == 2) ACH_LAUNCH((gemm_colmax_kernel<T, 2>), grid, block, s, g);
-            else ACH_LAUNCH((gemm_colmax_kernel<T, 4>), grid, block, s, g);
+            if (NT == 1) ACH_LAUNCH((gemm_colmax_kernel<T, 1, 0>), grid, block, s, g);
+            else if (NT == 2) ACH_LAUNCH((gemm_colmax_kernel<T, 2, 0>), grid, block, s, g);
+            else if (g.ksteps == 4) ACH_LAUNCH((gemm_colmax_kernel<T, 4, 4>), grid, block, s, g);     // weights register-resident
+            else if (g.ksteps == 8) ACH_LAUNCH((gemm_colmax_kernel<T, 4, 8>), grid, block, s, g);
+            else ACH_LAUNCH((gemm_colmax_kernel<T, 4, 0>), grid, block, s, g);
         }, bytes, 2.0 * double(x.rows) * pk.K * pk.N);
         return y;
     }

@@ -289,7 +289,10 @@ struct GemmMaxParams {
     void* Y; long ldy;                  // [groups, N]
     int M_per_group, groups, K, N, nchunks, ksteps, act;
 };
-template <class T, int NT>
+// KH > 0: the chunk's KH x NT weight fragments are loaded once and stay in registers for all the row tiles a wave walks
+// (K <= 128: the 128 -> 1024 convs of the PointNet transforms, where re-reading 16 fragments per 16 rows made the kernel
+// L1-bound at 190 TFLOP/s).
+template <class T, int NT, int KH>
 __global__ __launch_bounds__(256) void gemm_colmax_kernel(const GemmMaxParams p) {
     constexpr int VEC = Store<T>::VEC;
     constexpr int KC = 4 * VEC;
@@ -304,12 +307,39 @@ __global__ __launch_bounds__(256) void gemm_colmax_kernel(const GemmMaxParams p)
     for (int t = 0; t < NT; ++t)
         ACH_UNROLL
         for (int r = 0; r < 4; ++r) { const int n = c * (16 * NT) + chunk_channel(NT, t, g, r); bv[t * 4 + r] = n < p.N ? p.bias[n] : 0.f; cm[t * 4 + r] = -3.0e38f; }
+    uint4 wh[KH > 0 ? KH : 1][NT];
+    if (KH > 0) {
+        ACH_UNROLL
+        for (int s = 0; s < KH; ++s)
+            ACH_UNROLL
+            for (int t = 0; t < NT; ++t) wh[s][t] = Wf[(s * NT + t) * 64];
+    }
+    uint4 xn[KH > 0 ? KH : 1];                                    // KH > 0: rows of the NEXT tile, requested one tile ahead
+    auto fetch = [&](int r0) {
+        const int row = r0 + px;
+        ACH_UNROLL
+        for (int s = 0; s < (KH > 0 ? KH : 1); ++s) {
+            const int k0 = s * KC + g * VEC;
+            xn[s] = (row < p.M_per_group && k0 < p.K) ? *reinterpret_cast<const uint4*>(X + long(row) * p.ldx + k0) : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    if (KH > 0 && wave * 16 < p.M_per_group) fetch(wave * 16);
     for (int r0 = wave * 16; r0 < p.M_per_group; r0 += 64) {
         const int row = r0 + px;
         const bool valid = row < p.M_per_group;
         f32x4 acc[NT];
         ACH_UNROLL
         for (int t = 0; t < NT; ++t) { acc[t][0] = 0.f; acc[t][1] = 0.f; acc[t][2] = 0.f; acc[t][3] = 0.f; }
+        if (KH > 0) {
+            uint4 xf[KH > 0 ? KH : 1];
+            ACH_UNROLL
+            for (int s = 0; s < KH; ++s) xf[s] = xn[s];
+            if (r0 + 64 < p.M_per_group) fetch(r0 + 64);
+            ACH_UNROLL
+            for (int s = 0; s < KH; ++s)
+                ACH_UNROLL
+                for (int t = 0; t < NT; ++t) mfma16<T>(wh[s][t], xf[s], acc[t]);
+        } else
         for (int s = 0; s < p.ksteps; ++s) {
             const int k0 = s * KC + g * VEC;
             uint4 xf = make_uint4(0u, 0u, 0u, 0u);
