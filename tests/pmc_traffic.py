@@ -86,6 +86,14 @@ def main():
                     v = avg_bytes(kname, lambda v, q=parity: [x for i, x in enumerate(v) if i % 2 == q])
                     if v:
                         ops[op] = v
+        if 'rc_front_kernel<ach::bf16_t, 3, true>' in kname:      # first RCBlock (3 channels, 320x320): fused conv + sampling + contraction
+            v = avg_bytes(kname, largest_grid)
+            if v:
+                ops['image_radar_encoder.radar_encoder.rc_blocks.0.front'] = v
+        if 'rc_front_kernel<ach::bf16_t, 3, false>' in kname:
+            v = avg_bytes(kname, largest_grid)
+            if v:
+                ops['image_radar_encoder.radar_encoder.rc_blocks.1.front'] = v
         if 'conv3x3_rows_kernel<ach::bf16_t, 3>' in kname:
             v = avg_bytes(kname, largest_grid)
             if v:
@@ -95,16 +103,11 @@ def main():
             if v:
                 ops['image_radar_encoder.radar_encoder.rc_blocks.0.deform'] = v
         if 'mlp_kernel<ach::bf16_t, 2, false>' in kname:
-            # batch 64: the two stage-0 EdgeNeXt blocks are the launches with 409600 rows = 6400 workgroups = 1638400 threads;
-            # the largest grid of this instantiation is the 160x160 conv pair of a decoder
+            # batch 64: the two stage-0 EdgeNeXt blocks are the launches with 409600 rows = 6400 workgroups = 1638400 threads
             v = avg_bytes(kname, lambda v: [x for x in v if x[2] == 1638400])
             if v:
                 ops['image_radar_encoder.fpn.backbone.stages.0.0.block'] = v
                 ops['image_radar_encoder.fpn.backbone.stages.0.1.block'] = v
-            v = avg_bytes(kname, largest_grid)
-            if v:
-                ops['image_radar_encoder.fpn.se_seg_ghost_1_to_0.lowres_pair'] = v
-                ops['image_radar_encoder.fpn.lane_seg_ghost_1_to_0.lowres_pair'] = v
     report['ops'] = ops
     report.update(ops)            # flat keys for bench.py
     json.dump(report, open(out, 'w'), indent=1)
