@@ -107,3 +107,23 @@ def test_emulated_forward_detect_equals_the_three_calls():
     for a, b in zip((*outs, dec, rows, idx, cnt), (*outs2, dec2, rows2, idx2, cnt2)):
         assert torch.equal(a, b)
     assert int(cnt[0]) > 0
+
+
+@pytest.mark.parametrize('option', ['fused_mlp', 'row_conv', 'fused_rc', 'dw_tile', 'head_batch', 'split_decoders', 'streams'])
+def test_emulated_kernel_switches_agree(option):
+    """Each fused / batched kernel against the layer-wise launches it replaced, through the C ABI on the CPU emulation (fp32)."""
+    kw, sd, (x, xr, xp) = _setup('en_s0', 64, 1, 16)
+    outs = []
+    for v in (1, 0):
+        from achelous_amd.engine import NativeEngine
+        eng = NativeEngine(emu_library(), num_det=kw['num_det'], num_seg=kw['num_seg'], phi=kw['phi'], backbone=kw['backbone'],
+                           resolution=kw['resolution'], pc_channels=kw['pc_channels'], pc_classes=kw['pc_classes'],
+                           num_points=16, nano_head=kw['nano_head'], spp=kw['spp'], dtype=DTYPE_F32)
+        eng.set_option(option, v)
+        eng.load_state_dict(sd)
+        eng.plan(1)
+        o = alloc_outputs(kw, 1, 16, torch.float32, 'cpu')
+        eng.forward(x, xr, xp, o)
+        outs.append(o)
+    for a, b in zip(*outs):
+        assert rel_err(a, b) < 2e-5, option

@@ -232,3 +232,26 @@ def test_forward_detect_equals_the_three_calls():
                 for a, b in zip((*det, se, lane, pc, rows, idx, cnt), (*det2, se2, lane2, pc2, rows2, idx2, cnt2)):
                     assert torch.equal(a, b)
                 assert int(cnt.max()) > 0
+
+
+@pytest.mark.parametrize('option', ['fused_mlp', 'row_conv', 'fused_rc', 'dw_tile', 'head_batch', 'split_decoders'])
+def test_fused_kernels_agree_with_the_layerwise_path(option):
+    """Every fused / batched kernel has a switch back to the layer-wise launches it replaced (include/achelous.h): the two plans
+    must agree — to fp32 rounding in the fp32 engine (different summation order), and within the bf16 tolerance in the bf16
+    engine (intermediates that the fused kernels keep in fp32 registers are rounded to bf16 on the layer-wise path)."""
+    g = Golden('en_s0')
+    m, kw = _model(g.meta)
+    x, xr, xp = make_inputs(2, 17, resolution=kw['resolution'], pc_channels=kw['pc_channels'])
+    for dt, tol in ((torch.float32, 2e-5), (torch.bfloat16, BF16_TOL)):
+        xs, rs, ps = x.cuda().to(dt), xr.cuda().to(dt), xp.cuda().to(dt)
+        with torch.no_grad():
+            ref = m(xs, rs, ps)
+            e = _engine_of(m, dt)
+            e.set_option(option, 0)
+            e.plan(2)
+            alt = m(xs, rs, ps)
+            torch.cuda.synchronize()
+            e.set_option(option, -1 if option == 'split_decoders' else 1)
+            e.plan(2)
+        for a, b in zip((*alt[0], alt[1], alt[2], alt[3]), (*ref[0], ref[1], ref[2], ref[3])):
+            assert _rel(a.float(), b.float()) <= tol, option
