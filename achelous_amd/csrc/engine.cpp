@@ -809,7 +809,9 @@ public:
             MvitAttnParams ap{qkv.p, qkv.ld, ao.p, ao.ld, t.B, t.H, t.W, 4, 0.35355339059327373f};
             const int N = (t.H / 2) * (t.W / 2);
             const dim3 grid(unsigned(t.B * 4 * 4), unsigned(cdiv(N, 256))), block(256);
-            add_op(a + ".attn", [ap, grid, block](hipStream_t s) { ACH_LAUNCH(mvit_attn_kernel<T>, grid, block, s, ap); }, double(t.rows()) * 128 * sizeof(T));
+            if (N > MVIT_NMAX) throw AchError{ACH_ERR_UNSUPPORTED, "MobileViT attention: more than 1600 tokens per group"};
+            if (N <= 400) add_op(a + ".attn", [ap, grid, block](hipStream_t s) { ACH_LAUNCH((mvit_attn_kernel<T, 400>), grid, block, s, ap); }, double(t.rows()) * 128 * sizeof(T));
+            else add_op(a + ".attn", [ap, grid, block](hipStream_t s) { ACH_LAUNCH((mvit_attn_kernel<T, MVIT_NMAX>), grid, block, s, ap); }, double(t.rows()) * 128 * sizeof(T));
             A t1 = alloc(t.B, t.H, t.W, D);
             { GemmOpt o; o.residual = &t; gemm(a + ".to_out", ao, pack(lin(a + ".fn.to_out.0.weight", a + ".fn.to_out.0.bias")), t1, o); }
             Lin l1 = lin(f + ".fn.net.0.weight", f + ".fn.net.0.bias"); fold_ln_in(l1, f + ".norm");

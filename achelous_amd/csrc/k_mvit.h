@@ -16,10 +16,12 @@ struct MvitAttnParams { const void* qkv; long ld; void* Y; long ldy; int B, H, W
 constexpr int MVIT_DH = 8;
 constexpr int MVIT_NMAX = 1600;
 
-template <class T>
+// NMAX sizes the LDS staging: 400 tokens (a 40x40 map: 25 KB, six workgroups per CU) or 1600 (100 KB, one workgroup per CU —
+// with the large instantiation on a 40x40 map the kernel ran at one wave per SIMD and 2.5x slower)
+template <class T, int NMAX>
 __global__ __launch_bounds__(256) void mvit_attn_kernel(const MvitAttnParams p) {
-    __shared__ float ks[MVIT_NMAX * MVIT_DH];
-    __shared__ float vs[MVIT_NMAX * MVIT_DH];
+    __shared__ float ks[NMAX * MVIT_DH];
+    __shared__ float vs[NMAX * MVIT_DH];
     const int h2 = p.H / 2, w2 = p.Wd / 2, N = h2 * w2;
     int id = blockIdx.x;
     const int head = id % p.heads; id /= p.heads;
@@ -47,23 +49,42 @@ __global__ __launch_bounds__(256) void mvit_attn_kernel(const MvitAttnParams p) 
         float a[4], c[4];
         Store<T>::ld4(src, a);
         Store<T>::ld4(src + 4, c);
+        // softmax in base 2: log2(e) is folded into the query scale, so every exponential is one v_exp_f32
+        const float sc = p.scale * 1.44269504088896341f;
         ACH_UNROLL
-        for (int i = 0; i < 4; ++i) { q[i] = a[i] * p.scale; q[4 + i] = c[i] * p.scale; }
+        for (int i = 0; i < 4; ++i) { q[i] = a[i] * sc; q[4 + i] = c[i] * sc; }
     }
     float m = -3.0e38f, l = 0.f, acc[MVIT_DH];
     ACH_UNROLL
     for (int i = 0; i < MVIT_DH; ++i) acc[i] = 0.f;
-    for (int j = 0; j < N; ++j) {
-        const float* kk = ks + j * MVIT_DH;
-        float s = 0.f;
+    // online softmax over chunks of 8 keys: one running-max correction per chunk instead of per key
+    for (int j0 = 0; j0 < N; j0 += 8) {
+        float sj[8];
+        float cm = -3.0e38f;
         ACH_UNROLL
-        for (int i = 0; i < MVIT_DH; ++i) s += q[i] * kk[i];
-        const float mn = fmaxf(m, s);
-        const float corr = expf(m - mn), pj = expf(s - mn);
-        const float* vv = vs + j * MVIT_DH;
-        l = l * corr + pj;
+        for (int u = 0; u < 8; ++u) {
+            const int j = j0 + u;
+            const float4 k0 = *reinterpret_cast<const float4*>(ks + (j < N ? j : 0) * MVIT_DH);
+            const float4 k1 = *reinterpret_cast<const float4*>(ks + (j < N ? j : 0) * MVIT_DH + 4);
+            float d = q[0] * k0.x + q[1] * k0.y + q[2] * k0.z + q[3] * k0.w + q[4] * k1.x + q[5] * k1.y + q[6] * k1.z + q[7] * k1.w;
+            sj[u] = j < N ? d : -3.0e38f;
+            cm = fmaxf(cm, sj[u]);
+        }
+        const float mn = fmaxf(m, cm);
+        const float corr = fast_exp2(m - mn);
+        l *= corr;
         ACH_UNROLL
-        for (int i = 0; i < MVIT_DH; ++i) acc[i] = acc[i] * corr + pj * vv[i];
+        for (int i = 0; i < MVIT_DH; ++i) acc[i] *= corr;
+        ACH_UNROLL
+        for (int u = 0; u < 8; ++u) {
+            const int j = j0 + u;
+            const float pj = fast_exp2(sj[u] - mn);                 // padded keys: exp2(-huge) = 0
+            const float4 v0 = *reinterpret_cast<const float4*>(vs + (j < N ? j : 0) * MVIT_DH);
+            const float4 v1 = *reinterpret_cast<const float4*>(vs + (j < N ? j : 0) * MVIT_DH + 4);
+            l += pj;
+            acc[0] += pj * v0.x; acc[1] += pj * v0.y; acc[2] += pj * v0.z; acc[3] += pj * v0.w;
+            acc[4] += pj * v1.x; acc[5] += pj * v1.y; acc[6] += pj * v1.z; acc[7] += pj * v1.w;
+        }
         m = mn;
     }
     const float inv = 1.0f / l;
