@@ -48,7 +48,7 @@ struct MlpParams {
     int ln, Cout;                         // ln = 0: no normalisation (plain two-layer chain); Cout: output width (R may be null)
 };
 
-constexpr int MLP_RED_TILES = 8;          // output tiles reduced per LDS round in SPLIT mode
+constexpr int MLP_RED_TILES = 4;          // output tiles reduced per LDS round in SPLIT mode
 
 // depthwise k x k conv (zero padding k/2) of this lane's VEC channels at its pixel; up to 5 taps of a row in flight at a time.
 // Loads are unconditional from clamped columns (no divergent branches), out-of-map taps are zeroed afterwards; the weights are
@@ -138,7 +138,7 @@ __device__ __forceinline__ void mlp_inputs(const MlpParams& p, long m, bool vali
     }
 }
 
-template <int DT> struct MlpOcc { static constexpr int blocks = DT <= 6 ? 5 : (DT <= 8 ? 4 : (DT <= 12 ? 3 : 2)); };
+template <int DT> struct MlpOcc { static constexpr int blocks = DT <= 6 ? 6 : (DT <= 8 ? 4 : (DT <= 12 ? 3 : 2)); };
 
 template <class T, int DT, bool SPLIT>
 __global__ __launch_bounds__(256, MlpOcc<DT>::blocks) void mlp_kernel(const MlpParams p) {
