@@ -138,7 +138,7 @@ __device__ __forceinline__ void mlp_inputs(const MlpParams& p, long m, bool vali
     }
 }
 
-template <int DT> struct MlpOcc { static constexpr int blocks = DT <= 6 ? 6 : (DT <= 8 ? 4 : (DT <= 12 ? 3 : 2)); };
+template <int DT> struct MlpOcc { static constexpr int blocks = DT <= 6 ? 6 : (DT <= 10 ? 4 : (DT <= 12 ? 3 : 2)); };
 
 template <class T, int DT, bool SPLIT>
 __global__ __launch_bounds__(256, MlpOcc<DT>::blocks) void mlp_kernel(const MlpParams p) {
@@ -284,13 +284,13 @@ inline bool launch_mlp(const MlpParams& p, int DT, bool split, hipStream_t strea
     const dim3 grid(unsigned(split ? tiles : (tiles + 3) / 4)), block(256);
 #define ACH_MLP_CASE(dt) \
     if (DT == dt) { if (split) ACH_LAUNCH((mlp_kernel<T, dt, true>), grid, block, stream, p); else ACH_LAUNCH((mlp_kernel<T, dt, false>), grid, block, stream, p); return true; }
-    ACH_MLP_CASE(2) ACH_MLP_CASE(4) ACH_MLP_CASE(6) ACH_MLP_CASE(8) ACH_MLP_CASE(12) ACH_MLP_CASE(20)
+    ACH_MLP_CASE(2) ACH_MLP_CASE(4) ACH_MLP_CASE(6) ACH_MLP_CASE(8) ACH_MLP_CASE(10) ACH_MLP_CASE(12) ACH_MLP_CASE(18) ACH_MLP_CASE(20)
 #undef ACH_MLP_CASE
     return false;
 }
 inline int mlp_pick_dt(int C) {
     const int need = 2 * ((C + 31) / 32);
-    for (int dt : {2, 4, 6, 8, 12, 20}) if (dt >= need) return dt;
+    for (int dt : {2, 4, 6, 8, 10, 12, 18, 20}) if (dt >= need) return dt;
     return 0;
 }
 
