@@ -1073,22 +1073,26 @@ public:
         t.p0 = t.base + t.row + t.ld;
         return t;
     }
-    // 3x3 / stride 1 / pad 1 conv of a bordered tensor with 25..32 outputs (the offset + modulator convs of the RCBlocks)
-    A conv3_bordered(const std::string& name, const Bordered& x, const Lin& l, int act) {
-        A y = alloc(x.B, x.H, x.W, l.N);
+    // 3x3 / pad 1 conv (stride 1 or 2) of a bordered tensor with up to 32 outputs: the offset + modulator convs and the
+    // stride-2 weight_conv2 of the RCBlocks (k_conv3.h); anything else goes to the generic implicit GEMM
+    A conv3_bordered(const std::string& name, const Bordered& x, const Lin& l, int act, int stride = 1) {
+        const int Ho = (x.H - 1) / stride + 1, Wo = (x.W - 1) / stride + 1;
+        A y = alloc(x.B, Ho, Wo, l.N);
         const int cv = int(x.ld) / VEC, ks = cdiv(9 * cv, 4);
         Packed pk = pack(l);
         const double bytes = double(x.B) * x.H * x.W * x.ld * sizeof(T) + double(y.rows()) * y.ld * sizeof(T);
-        if (row_conv && l.N > 24 && l.N <= 32 && y.ld == 32 && (ks == 3 || ks == 5 || ks == 9) && pk.NT == 2 && pk.nchunks == 1 && pk.ksteps == ks) {
+        const bool shape_ok = (pk.NT == 2 && y.ld == 32) || (pk.NT == 1 && stride == 2 && y.ld <= 16);
+        if (row_conv && shape_ok && (ks == 3 || ks == 5 || ks == 9) && pk.nchunks == 1 && pk.ksteps == ks) {
             std::vector<float> b32(32, 0.f);
             for (int n = 0; n < l.N; ++n) b32[n] = l.b[n];
-            Conv3Params cp{x.p0, x.ld, x.row, x.img, y.p, y.ld, pk.w, up_f32(b32), x.B, x.H, x.W, cv, act};
-            add_op(name, [cp, ks](hipStream_t s) { launch_conv3<T>(cp, ks, s); }, bytes, 2.0 * double(y.rows()) * l.K * l.N);
+            Conv3Params cp{x.p0, x.ld, x.row, x.img, y.p, y.ld, pk.w, up_f32(b32), x.B, Ho, Wo, cv, act};
+            const int NT = pk.NT;
+            add_op(name, [cp, ks, NT, stride](hipStream_t s) { launch_conv3<T>(cp, ks, NT, stride, s); }, bytes, 2.0 * double(y.rows()) * l.K * l.N);
             return y;
         }
         // generic implicit GEMM: the bordered buffer is a dense [B, H+2, W+2, ld] tensor convolved without padding
         GemmOpt o; o.act = act;
-        o.conv_k = 3; o.conv_s = 1; o.conv_p = 0; o.Hin = x.H + 2; o.Win = x.W + 2; o.Cin = int(x.ld); o.Ho = x.H; o.Wo = x.W;
+        o.conv_k = 3; o.conv_s = stride; o.conv_p = 0; o.Hin = x.H + 2; o.Win = x.W + 2; o.Cin = int(x.ld); o.Ho = Ho; o.Wo = Wo;
         gemm(name, x.base, x.ld, y.rows(), pk, y.p, y.ld, o);
         return y;
     }
@@ -1137,6 +1141,8 @@ public:
                     }
             }
             A y;
+            Bordered yb;
+            bool y_bordered = false;
             if (fused_front) {           // conv + sampling + folded contraction + ReLU + residual as one launch (k_conv3.h)
                 Packed pkom = pack(lom), pkf = pack(lf);
                 if (pkom.NT != 2 || pkom.nchunks != 1 || pkom.ksteps != ksp || pkf.NT != 1 || pkf.nchunks != 1 || pkf.ksteps != ksp)
@@ -1144,10 +1150,17 @@ public:
                 std::vector<float> b32(32, 0.f), b16(16, 0.f);
                 for (int n = 0; n < 27; ++n) b32[n] = lom.b[n];
                 for (int n = 0; n < C; ++n) b16[n] = lf.b[n];
-                y = alloc(B, x.H, x.W, C);
-                RcFrontParams rp{pooled.p0, pooled.ld, pooled.row, pooled.img, pkom.w, up_f32(b32), pkf.w, up_f32(b16), x.p, x.ld, y.p, y.ld,
+                if (down[i] && row_conv) {            // the stride-2 weight_conv2 reads it through the row-walking kernel: zero border
+                    yb = alloc_bordered(B, x.H, x.W, C);
+                    y_bordered = true;
+                } else {
+                    y = alloc(B, x.H, x.W, C);
+                }
+                const long yld = y_bordered ? yb.ld : y.ld;
+                RcFrontParams rp{pooled.p0, pooled.ld, pooled.row, pooled.img, pkom.w, up_f32(b32), pkf.w, up_f32(b16), x.p, x.ld,
+                                 y_bordered ? yb.p0 : y.p, yld, y_bordered ? yb.row : long(x.W) * y.ld, y_bordered ? yb.img : long(x.H) * x.W * y.ld,
                                  B, x.H, x.W, cvp, C};
-                const double bytes = double(x.rows()) * (pooled.ld + x.ld + y.ld) * sizeof(T);
+                const double bytes = double(x.rows()) * (pooled.ld + x.ld + yld) * sizeof(T);
                 add_op(pfx + ".front", [rp, ksp](hipStream_t s) { launch_rc_front<T>(rp, ksp, s); }, bytes,
                        2.0 * double(x.rows()) * 9.0 * Cp * (27 + C));
             } else {
@@ -1173,7 +1186,8 @@ public:
             }
             // weight_conv2: 1x1, or 3x3 stride 2
             const int k = down[i] ? 3 : 1;
-            x = conv_gemm(pfx + ".conv2", y, conv_lin(pfx + ".weight_conv2.weight", pfx + ".weight_conv2.bias", C, int(y.ld), k), k, down[i] ? 2 : 1, ACT_NONE);
+            if (y_bordered) x = conv3_bordered(pfx + ".conv2", yb, conv_lin(pfx + ".weight_conv2.weight", pfx + ".weight_conv2.bias", C, int(yb.ld), 3), ACT_NONE, 2);
+            else x = conv_gemm(pfx + ".conv2", y, conv_lin(pfx + ".weight_conv2.weight", pfx + ".weight_conv2.bias", C, int(y.ld), k), k, down[i] ? 2 : 1, ACT_NONE);
             if (x.C != chans[i + 1]) throw AchError{ACH_ERR_MISSING_KEY, "radar width mismatch at " + pfx};
             tap("radar.b" + std::to_string(i), x);
             if (i == 3) outs[0] = x;

@@ -24,7 +24,9 @@ struct Conv3Params {
     int B, H, Wd, cv, act;
 };
 
-template <class T, int KS>
+// NT = 1: up to 16 outputs (one 8-byte store per lane); NT = 2: up to 32.  STRIDE 1 or 2 (H, Wd are the OUTPUT map; the input is
+// the bordered map of (H - 1) * STRIDE + 1 .. rows, pad 1).
+template <class T, int KS, int NT, int STRIDE>
 __global__ __launch_bounds__(256) void conv3x3_rows_kernel(const Conv3Params p) {
     constexpr int VEC = Store<T>::VEC;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -34,51 +36,65 @@ __global__ __launch_bounds__(256) void conv3x3_rows_kernel(const Conv3Params p) 
     const int ldx = int(p.ldx);
 
     int off[KS];
-    bool live[KS];
     ACH_UNROLL
     for (int s = 0; s < KS; ++s) {
         const int q = 4 * s + g;
         const int tap = q / p.cv, c = q - tap * p.cv;
         const int ty = tap / 3, tx = tap - 3 * ty;
-        live[s] = tap < 9;                                             // k-slots past the ninth tap: zero weights, but keep the address in bounds
-        off[s] = live[s] ? (ty - 1) * int(p.xpr) + (tx - 1) * ldx + c * VEC : 0;
+        // k-slots past the ninth tap: zero weights, but keep the address in bounds
+        off[s] = tap < 9 ? (ty - 1) * int(p.xpr) + (tx - 1) * ldx + c * VEC : 0;
     }
     const uint4* Wf = static_cast<const uint4*>(p.W) + lane;
-    uint4 wf[KS][2];
+    uint4 wf[KS][NT];
     ACH_UNROLL
-    for (int s = 0; s < KS; ++s) { wf[s][0] = Wf[(s * 2) * 64]; wf[s][1] = Wf[(s * 2 + 1) * 64]; }
-    float bv[8];
+    for (int s = 0; s < KS; ++s)
+        ACH_UNROLL
+        for (int t = 0; t < NT; ++t) wf[s][t] = Wf[(s * NT + t) * 64];
+    float bv[4 * NT];
     ACH_UNROLL
-    for (int i = 0; i < 8; ++i) bv[i] = p.bias[g * 8 + i];
+    for (int i = 0; i < 4 * NT; ++i) bv[i] = p.bias[g * 4 * NT + i];
 
-    const T* xrow = static_cast<const T*>(p.X) + long(b) * p.xpi + long(oy) * p.xpr;
-    T* yrow = static_cast<T*>(p.Y) + (long(b) * p.H + oy) * p.Wd * p.ldy + g * 8;
+    const T* xrow = static_cast<const T*>(p.X) + long(b) * p.xpi + long(oy) * STRIDE * p.xpr;
+    T* yrow = static_cast<T*>(p.Y) + (long(b) * p.H + oy) * p.Wd * p.ldy + g * 4 * NT;
+    const bool chan_ok = g * 4 * NT < int(p.ldy);
     for (int tile = wave; tile * 16 < p.Wd; tile += 4) {
         const int xr = tile * 16 + px;
         const bool valid = xr < p.Wd;
         const int x = valid ? xr : p.Wd - 1;
-        const T* xp = xrow + long(x) * ldx;
+        const T* xp = xrow + long(x) * STRIDE * ldx;
         uint4 xf[KS];
         ACH_UNROLL
         for (int s = 0; s < KS; ++s) xf[s] = *reinterpret_cast<const uint4*>(xp + off[s]);
-        f32x4 a0, a1;
-        a0[0] = a0[1] = a0[2] = a0[3] = 0.f;
-        a1[0] = a1[1] = a1[2] = a1[3] = 0.f;
+        f32x4 acc[NT];
         ACH_UNROLL
-        for (int s = 0; s < KS; ++s) { mfma16<T>(wf[s][0], xf[s], a0); mfma16<T>(wf[s][1], xf[s], a1); }
-        float o[8];
+        for (int t = 0; t < NT; ++t) { acc[t][0] = 0.f; acc[t][1] = 0.f; acc[t][2] = 0.f; acc[t][3] = 0.f; }
         ACH_UNROLL
-        for (int r = 0; r < 4; ++r) { o[r] = apply_act_t<T>(a0[r] + bv[r], p.act); o[4 + r] = apply_act_t<T>(a1[r] + bv[4 + r], p.act); }
-        if (valid) Store<T>::st8(yrow + long(x) * p.ldy, o);
+        for (int s = 0; s < KS; ++s)
+            ACH_UNROLL
+            for (int t = 0; t < NT; ++t) mfma16<T>(wf[s][t], xf[s], acc[t]);
+        if (!valid || !chan_ok) continue;
+        if (NT == 2) {
+            float o[8];
+            ACH_UNROLL
+            for (int r = 0; r < 4; ++r) { o[r] = apply_act_t<T>(acc[0][r] + bv[r], p.act); o[4 + r] = apply_act_t<T>(acc[NT - 1][r] + bv[4 * (NT - 1) + r], p.act); }
+            Store<T>::st8(yrow + long(x) * p.ldy, o);
+        } else {
+            float o[4];
+            ACH_UNROLL
+            for (int r = 0; r < 4; ++r) o[r] = apply_act_t<T>(acc[0][r] + bv[r], p.act);
+            Store<T>::st4(yrow + long(x) * p.ldy, o);
+        }
     }
 }
 
 template <class T>
-inline bool launch_conv3(const Conv3Params& p, int ksteps, hipStream_t stream) {
+inline bool launch_conv3(const Conv3Params& p, int ksteps, int NT, int stride, hipStream_t stream) {
     const dim3 grid(unsigned(p.B) * unsigned(p.H)), block(256);
-    if (ksteps == 3) { ACH_LAUNCH((conv3x3_rows_kernel<T, 3>), grid, block, stream, p); return true; }
-    if (ksteps == 5) { ACH_LAUNCH((conv3x3_rows_kernel<T, 5>), grid, block, stream, p); return true; }
-    if (ksteps == 9) { ACH_LAUNCH((conv3x3_rows_kernel<T, 9>), grid, block, stream, p); return true; }
+#define ACH_C3_CASE(ks, nt, st) if (ksteps == ks && NT == nt && stride == st) { ACH_LAUNCH((conv3x3_rows_kernel<T, ks, nt, st>), grid, block, stream, p); return true; }
+    ACH_C3_CASE(3, 2, 1) ACH_C3_CASE(5, 2, 1) ACH_C3_CASE(9, 2, 1)
+    ACH_C3_CASE(3, 1, 2) ACH_C3_CASE(5, 1, 2) ACH_C3_CASE(9, 1, 2)
+    ACH_C3_CASE(3, 2, 2) ACH_C3_CASE(5, 2, 2) ACH_C3_CASE(9, 2, 2)
+#undef ACH_C3_CASE
     return false;
 }
 
@@ -101,7 +117,7 @@ struct RcFrontParams {
     const void* Wom; const float* bom;        // offset + modulator conv: packed NT = 2, KS k-steps; bias[32]
     const void* Wf; const float* bf;          // folded deformable weights [C][9*ldp]: packed NT = 1, KS k-steps; bias[16]
     const void* R; long ldr;                  // block input (residual)
-    void* Y; long ldy;
+    void* Y; long ldy, ypr, ypi;              // output: pixel (0,0) of sample 0 and row / image pitches (dense or zero-bordered)
     int B, H, Wd, cv, C;
 };
 
@@ -206,7 +222,7 @@ __global__ __launch_bounds__(256, KS == 3 ? 3 : 1) void rc_front_kernel(const Rc
             Store<T>::ld4(static_cast<const T*>(p.R) + (rowpix + x) * p.ldr + ch, rr);
             ACH_UNROLL
             for (int i = 0; i < 4; ++i) { const float r = acc[i] + bo[i]; ov[i] = (r > 0.f ? r : 0.f) + rr[i]; }
-            Store<T>::st4(static_cast<T*>(p.Y) + (rowpix + x) * p.ldy + ch, ov);
+            Store<T>::st4(static_cast<T*>(p.Y) + long(b) * p.ypi + long(oy) * p.ypr + long(x) * p.ldy + ch, ov);
         }
     }
 }
