@@ -553,7 +553,7 @@ public:
         A h = alloc(xin.B, xin.H, xin.W, 4 * C);
         GemmOpt o1; o1.act = ACT_GELU; o1.ln = true; o1.ln_eps = 1e-6f;
         gemm(pfx + ".pwconv1", xin, pack(l1), h, o1);
-        A y = alloc(xin.B, xin.H, xin.W, C);
+        A y = block_out(xin);
         GemmOpt o2; o2.residual = &resid;
         gemm(pfx + ".pwconv2", h, pack(l2), y, o2);
         return y;
@@ -569,6 +569,18 @@ public:
         return fused_mlp_lin(pfx + (dw_ks ? ".block" : ".mlp"), pfx, xin, resid, dw_ks, l1, l2, ACT_GELU, 1e-6f, y);
     }
     // generic form: l1 has the LayerNorm affine folded in, l2 any output scale; `pfx`.dwconv.{weight,bias} when dw_ks > 0
+    // When set, the next block output is written there instead of a fresh allocation (a channel slice of a concat buffer of the
+    // neck: torch.cat((upsampled, backbone feature), 1) then needs no copy).  Consumed by the first block that produces an output.
+    A preset_out; bool has_preset = false;
+    A block_out(const A& like) {
+        if (has_preset) {
+            has_preset = false;
+            if (preset_out.B != like.B || preset_out.H != like.H || preset_out.W != like.W || preset_out.C != like.C)
+                throw AchError{ACH_ERR_INVALID, "preset block output does not match the block"};
+            return preset_out;
+        }
+        return alloc(like.B, like.H, like.W, like.C);
+    }
     bool fused_mlp_lin(const std::string& name, const std::string& pfx, const A& xin, const A& resid, int dw_ks, const Lin& l1, const Lin& l2,
                        int act, float ln_eps, A& y) {
         if (!fuse_mlp) return false;
@@ -594,7 +606,7 @@ public:
         MlpParams mp;
         std::memset(&mp, 0, sizeof(mp));
         mp.X = xin.p; mp.ldx = xin.ld; mp.R = resid.p; mp.ldr = resid.ld;
-        y = alloc(xin.B, xin.H, xin.W, C);
+        y = block_out(xin);
         mp.Y = y.p; mp.ldy = y.ld;
         mp.dw_k = dw_ks; mp.H = xin.H; mp.W = xin.W;
         if (dw_ks) {
@@ -712,7 +724,8 @@ public:
         if (fused_mlp(pfx, t2, x, 0, fy)) return fy;
         return pw_mlp(pfx, t2, x);
     }
-    void edgenext(const std::string& pfx, A feats[4]) {                   // edgenext.py:73-86
+    // `dst[i]` (optional, may be null): where the output of stage i is to be written
+    void edgenext(const std::string& pfx, A feats[4], const A* const dst[4]) {                   // edgenext.py:73-86
         const EnCfg ec = en_cfg();
         const int B = batch, R = cfg.resolution;
         A x;
@@ -740,7 +753,7 @@ public:
                 // conv 2x2 stride 2: k = (dy, dx, c) over two contiguous NHWC segments
                 const HostTensor& w = W(d + ".1.weight");
                 const int Co = int(w.shape[0]), Ci = int(w.shape[1]);
-                if (Ci != x.C || x.ld != x.C) throw AchError{ACH_ERR_UNSUPPORTED, "downsample conv shape"};
+                if (Ci != x.C || t.ld != t.C) throw AchError{ACH_ERR_UNSUPPORTED, "downsample conv shape"};
                 Lin l; l.N = Co; l.K = 4 * Ci; l.w.resize(size_t(Co) * 4 * Ci); l.b = W(d + ".1.bias").data;
                 for (int o = 0; o < Co; ++o)
                     for (int c = 0; c < Ci; ++c)
@@ -754,10 +767,12 @@ public:
             }
             for (int j = 0; j < ec.depths[i]; ++j) {
                 const std::string b = pfx + ".stages." + std::to_string(i) + "." + std::to_string(j);
+                if (j == ec.depths[i] - 1 && dst && dst[i]) { preset_out = *dst[i]; has_preset = true; }
                 if (i > 0 && j == ec.depths[i] - 1) x = sdta_encoder(b, x, ec.scales[i], ec.heads);
                 else x = conv_encoder(b, x, ec.ks[i]);
                 tap("backbone.s" + std::to_string(i) + ".b" + std::to_string(j), x);
             }
+            if (has_preset) throw AchError{ACH_ERR_INVALID, "stage output destination was not consumed"};
             feats[i] = x;
         }
     }
@@ -973,6 +988,7 @@ public:
         add_op(head_pfx + ".upghost_head", [p, grid, block, out](hipStream_t s) mutable { p.out = *out; ACH_LAUNCH(upghost_head_kernel<T>, grid, block, s, p, p.Wdw, p.bdw, p.Wh, p.bh, p.Wdh, p.bdh); }, bytes);
     }
 
+    A cat_buf[2];                     // concat buffers of the top-down path when the backbone writes its features into them
     void neck(A m[4], A q[3]) {                                                  // ghostdualfpn.py:156-200
         const std::string f = "image_radar_encoder.fpn";
         const int* w = widths();
@@ -995,13 +1011,13 @@ public:
         { GemmOpt o; o.act = ACT_SILU; gemm(f + ".spp.cv2", cat5, pack(conv_bn(f + ".spp.cv2.conv", f + ".spp.cv2.bn", 1e-3)), p5, o); }
         tap("spp", p5);
         // top-down
-        A c4 = alloc(m4.B, m4.H, m4.W, 2 * w[2]);
+        A c4 = cat_buf[1].p ? cat_buf[1] : alloc(m4.B, m4.H, m4.W, 2 * w[2]);
         upsample(f + ".upsample_5_to_4", p5, c4.slice(0, w[2]));
-        copy(f + ".cat4", m4, c4.slice(w[2], w[2]));
+        if (m4.p != c4.slice(w[2], w[2]).p) copy(f + ".cat4", m4, c4.slice(w[2], w[2]));      // else: the backbone wrote it in place
         A p4 = ghost_bottleneck(f + ".ghost_5_to_4", c4, w[2]);
-        A c3 = alloc(m3.B, m3.H, m3.W, 2 * w[1]);
+        A c3 = cat_buf[0].p ? cat_buf[0] : alloc(m3.B, m3.H, m3.W, 2 * w[1]);
         upsample(f + ".upsample_4_to_3", p4, c3.slice(0, w[1]));
-        copy(f + ".cat3", m3, c3.slice(w[1], w[1]));
+        if (m3.p != c3.slice(w[1], w[1]).p) copy(f + ".cat3", m3, c3.slice(w[1], w[1]));
         A p3 = ghost_bottleneck(f + ".ghost_4_to_3", c3, w[1]);
         tap("fpn4", p4); tap("fpn3", p3);
         const bool split_dec = split_decoders != 0;
@@ -1407,7 +1423,17 @@ public:
         pointnet();
         cur_stream = 0;
         A m[4];
-        if (cfg.backbone == ACH_BACKBONE_EDGENEXT) edgenext("image_radar_encoder.fpn.backbone", m);
+        cat_buf[0] = A(); cat_buf[1] = A();
+        if (cfg.backbone == ACH_BACKBONE_EDGENEXT) {
+            // stage 1 / stage 2 outputs go straight into the second half of the neck's concat buffers (no cat copy)
+            const int* wd = widths();
+            const int R = cfg.resolution;
+            cat_buf[0] = alloc(batch, R / 8, R / 8, 2 * wd[1]);
+            cat_buf[1] = alloc(batch, R / 16, R / 16, 2 * wd[2]);
+            const A d1 = cat_buf[0].slice(wd[1], wd[1]), d2 = cat_buf[1].slice(wd[2], wd[2]);
+            const A* dst[4] = {nullptr, &d1, &d2, nullptr};
+            edgenext("image_radar_encoder.fpn.backbone", m, dst);
+        }
         else mobilevit("image_radar_encoder.fpn.backbone", m);
         A q[3];
         neck(m, q);
