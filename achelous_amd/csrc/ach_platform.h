@@ -240,10 +240,12 @@ __device__ __forceinline__ float row16_max(float v) {
 // in the epilogue of bandwidth-bound kernels (measured: +28 us on a 47 us GEMM for GELU with the exact forms)
 #if defined(ACH_HOSTEMU)
 __device__ inline float fast_rcp(float x) { return 1.0f / x; }
+__device__ inline float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 __device__ inline float fast_exp(float x) { return expf(x); }
 __device__ inline float fast_exp2(float x) { return exp2f(x); }
 #else
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float clampf(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }      // v_med3_f32
 __device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 #endif

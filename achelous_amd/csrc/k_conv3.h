@@ -195,21 +195,27 @@ __global__ __launch_bounds__(256, KS == 3 ? 3 : 1) void rc_front_kernel(const Rc
             const float* om = &oml[wave][px][0];
             const float dy = om[2 * tap], dx = om[2 * tap + 1], ml = om[18 + tap];
             const BilinearTap t = make_tap(ybase[s] + dy, float(x) + xbase[s] + dx, modulation(ml), p.H, p.Wd, prow, ldp);
-            const T* P0 = Pimg + cofs[s];
+            // 32-bit element offsets from the (wave-uniform) image base: scalar base + vector offset addressing
+            // wave-uniform base (top-left border pixel of the sample) + 32-bit BYTE offsets >= 0: scalar-base addressing, no 64-bit math
+            const char* Pb = reinterpret_cast<const char*>(Pimg - (prow + ldp));
+            const unsigned esz = unsigned(sizeof(T));
+            const unsigned q0 = unsigned(prow + ldp + t.o0 + cofs[s]) * esz, q1 = unsigned(prow + ldp + t.o1 + cofs[s]) * esz;
+            const unsigned q0b = q0 + unsigned(ldp) * esz, q1b = q1 + unsigned(ldp) * esz;
             const float live = tapi[s] < 0 ? 0.f : 1.f;
             const float w00 = t.w00 * live, w01 = t.w01 * live, w10 = t.w10 * live, w11 = t.w11 * live;
             float v[8];
             if constexpr (NARROW && VEC == 8) {
                 float a[4], bq[4], cc[4], d[4];
-                Store<T>::ld4(P0 + t.o0, a); Store<T>::ld4(P0 + t.o0 + ldp, bq); Store<T>::ld4(P0 + t.o1, cc); Store<T>::ld4(P0 + t.o1 + ldp, d);
+                Store<T>::ld4(reinterpret_cast<const T*>(Pb + q0), a); Store<T>::ld4(reinterpret_cast<const T*>(Pb + q0b), bq);
+                Store<T>::ld4(reinterpret_cast<const T*>(Pb + q1), cc); Store<T>::ld4(reinterpret_cast<const T*>(Pb + q1b), d);
                 ACH_UNROLL
                 for (int i = 0; i < 4; ++i) { v[i] = w00 * a[i] + w01 * bq[i] + w10 * cc[i] + w11 * d[i]; v[4 + i] = 0.f; }
             } else {
                 float a[8], bq[8], cc[8], d[8];
-                frag_unpack<T>(*reinterpret_cast<const uint4*>(P0 + t.o0), a);
-                frag_unpack<T>(*reinterpret_cast<const uint4*>(P0 + t.o0 + ldp), bq);
-                frag_unpack<T>(*reinterpret_cast<const uint4*>(P0 + t.o1), cc);
-                frag_unpack<T>(*reinterpret_cast<const uint4*>(P0 + t.o1 + ldp), d);
+                frag_unpack<T>(*reinterpret_cast<const uint4*>(Pb + q0), a);
+                frag_unpack<T>(*reinterpret_cast<const uint4*>(Pb + q0b), bq);
+                frag_unpack<T>(*reinterpret_cast<const uint4*>(Pb + q1), cc);
+                frag_unpack<T>(*reinterpret_cast<const uint4*>(Pb + q1b), d);
                 ACH_UNROLL
                 for (int i = 0; i < VEC; ++i) v[i] = w00 * a[i] + w01 * bq[i] + w10 * cc[i] + w11 * d[i];
             }

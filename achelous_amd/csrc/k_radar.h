@@ -76,7 +76,7 @@ struct BilinearTap {
 };
 __device__ __forceinline__ BilinearTap make_tap(float sy, float sx, float mask, int H, int Wd, int prow, int ld) {
     BilinearTap t;
-    const float cy = fminf(fmaxf(sy, -1.f), float(H)), cx = fminf(fmaxf(sx, -1.f), float(Wd));
+    const float cy = clampf(sy, -1.f, float(H)), cx = clampf(sx, -1.f, float(Wd));
     const float fy = fminf(floorf(cy), float(H - 1)), fx = fminf(floorf(cx), float(Wd - 1));
     const float ly = cy - fy, lx = cx - fx;
     const float hym = (1.f - ly) * mask, lym = ly * mask, hx = 1.f - lx;
