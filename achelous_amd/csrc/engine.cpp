@@ -1244,7 +1244,7 @@ public:
                 eca_max = std::max(eca_max, long(x.B) * x.C);
                 A ys = out[l].slice(coff, x.C);
                 mf.j[n] = FuseParams{x.p, x.ld, 0, ys.p, ys.ld, scl, up_f32(std::vector<float>(sh.begin() + coff, sh.begin() + coff + x.C)), x.B, HW, x.C};
-                fuse_max = std::max(fuse_max, x.rows() * x.C);
+                fuse_max = std::max(fuse_max, cdivl(x.rows() * x.C, 4));        // 4 channels per thread
                 bytes += 2.0 * x.rows() * x.C * sizeof(T);
                 coff += x.C;
             }

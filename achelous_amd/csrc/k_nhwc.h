@@ -539,17 +539,35 @@ __global__ void eca_scale_kernel(const EcaParams p) { eca_scale_body(p, blockIdx
 __global__ void eca_scale_multi_kernel(const Multi6<EcaParams> m) { eca_scale_body(m.j[blockIdx.y], blockIdx.x * blockDim.x + threadIdx.x); }
 // Y[b,pix,c] = relu(X[b,pix,c] * scale[b][c] + shift[c]); X is NHWC (x_nchw = 0) or NCHW (radar branch)
 struct FuseParams { const void* X; long ldx; int x_nchw; void* Y; long ldy; const float* scale; const float* shift; int B, HW, C; };
+// one thread = 4 consecutive channels of one pixel (C % 4 == 0 for NHWC inputs; the NCHW input form stays scalar)
 template <class T>
 __device__ __forceinline__ void fuse_scale_body(const FuseParams& p, long idx) {
-    const long total = long(p.B) * p.HW * p.C;
-    if (idx >= total) return;
-    const int c = int(idx % p.C);
-    const long pix = idx / p.C;
-    const long b = pix / p.HW;
     const T* X = static_cast<const T*>(p.X);
-    const float x = p.x_nchw ? Store<T>::ld(X + (b * p.C + c) * p.HW + (pix - b * p.HW)) : Store<T>::ld(X + pix * p.ldx + c);
-    const float v = x * p.scale[b * p.C + c] + p.shift[c];
-    Store<T>::st(static_cast<T*>(p.Y) + pix * p.ldy + c, v > 0.f ? v : 0.f);
+    if (p.x_nchw || (p.C & 3)) {
+        const long total = long(p.B) * p.HW * p.C;
+        for (int e = 0; e < 4; ++e) {
+            const long i = idx * 4 + e;
+            if (i >= total) return;
+            const int c = int(i % p.C);
+            const long pix = i / p.C;
+            const long b = pix / p.HW;
+            const float x = p.x_nchw ? Store<T>::ld(X + (b * p.C + c) * p.HW + (pix - b * p.HW)) : Store<T>::ld(X + pix * p.ldx + c);
+            const float v = x * p.scale[b * p.C + c] + p.shift[c];
+            Store<T>::st(static_cast<T*>(p.Y) + pix * p.ldy + c, v > 0.f ? v : 0.f);
+        }
+        return;
+    }
+    const int cq = p.C >> 2;
+    const long total = long(p.B) * p.HW * cq;
+    if (idx >= total) return;
+    const int c = int(idx % cq) * 4;
+    const long pix = idx / cq;
+    const long b = pix / p.HW;
+    float x[4], o[4];
+    Store<T>::ld4(X + pix * p.ldx + c, x);
+    const float4 sc = *reinterpret_cast<const float4*>(p.scale + b * p.C + c), sh = *reinterpret_cast<const float4*>(p.shift + c);
+    o[0] = fmaxf(x[0] * sc.x + sh.x, 0.f); o[1] = fmaxf(x[1] * sc.y + sh.y, 0.f); o[2] = fmaxf(x[2] * sc.z + sh.z, 0.f); o[3] = fmaxf(x[3] * sc.w + sh.w, 0.f);
+    Store<T>::st4(static_cast<T*>(p.Y) + pix * p.ldy + c, o);
 }
 template <class T>
 __global__ __launch_bounds__(256) void fuse_scale_kernel(const FuseParams p) { fuse_scale_body<T>(p, long(blockIdx.x) * blockDim.x + threadIdx.x); }
