@@ -711,7 +711,7 @@ public:
         XcaFinalParams pf{partial, S, up_f32(W(pfx + ".xca.temperature").data), up_f32(lp.w), up_f32(gx), nullptr, weff, pe.group_elems,
                           x.B, C, heads, pe.NT, pe.ksteps};
         {
-            const dim3 grid(unsigned(x.B * heads)), block(256);
+            const dim3 grid(unsigned(x.B * heads), unsigned(cdiv(C, XCA_CT))), block(256);
             add_op(pfx + ".xca.finalize", [pf, grid, block](hipStream_t s) { ACH_LAUNCH(xca_finalize_kernel<T>, grid, block, s, pf); });
         }
         // t2 = y + gamma_xca * proj(attn @ v): one GEMM over v (channel slice [2C,3C) of qkv) with per-sample weights

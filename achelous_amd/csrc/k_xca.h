@@ -15,7 +15,8 @@
 namespace ach {
 
 constexpr int XCA_DMAX = 48;
-constexpr int XCA_CT = 128;      // output-channel tile of xca_finalize
+constexpr int XCA_CT = 32;       // output-channel tile of xca_finalize: one workgroup per (sample, head, tile) — the softmax is recomputed
+                                 // per tile (d x d, cheap) so that the fold runs on 4-6x more workgroups instead of a serial loop
 
 struct XcaGramParams { const void* qkv; long ld; float* partial; int B, N, C, heads, S; };
 
@@ -115,11 +116,12 @@ __global__ __launch_bounds__(256) void xca_finalize_kernel(const XcaFinalParams 
         for (int j = 0; j < d; ++j) A[tid][j] *= inv;
     }
     __syncthreads();
-    if (p.attn) for (int e = tid; e < npair; e += 256) p.attn[long(bh) * npair + e] = A[e / d][e % d];
+    if (p.attn && blockIdx.y == 0) for (int e = tid; e < npair; e += 256) p.attn[long(bh) * npair + e] = A[e / d][e % d];
     // Weff rows in tiles of XCA_CT output channels: the Wproj slice [tile][d] of this head is staged in LDS with coalesced loads
     // first (a thread-private walk over Wproj rows is a chain of dependent L1/L2 latencies: 67 us for a 2 us job).
     T* W = static_cast<T*>(p.Weff) + long(b) * p.group_stride;
-    for (int c0 = 0; c0 < p.C; c0 += XCA_CT) {
+    {
+        const int c0 = blockIdx.y * XCA_CT;
         const int rows = (p.C - c0 < XCA_CT) ? p.C - c0 : XCA_CT;
         __syncthreads();
         for (int e = tid; e < rows * d; e += 256) { const int r = e / d, i = e - r * d; wps[r][i] = p.Wproj[long(c0 + r) * p.C + h * d + i]; }
