@@ -1,0 +1,1361 @@
+// engine_impl.h — Engine<T>: the launch plan of the whole path for one storage type (see engine.h).  Included by
+// engine_f32.cpp and engine_bf16.cpp, which instantiate it once each so that the two halves compile in parallel.
+#pragma once
+#include "engine.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "k_detect.h"
+#include "k_conv3.h"
+#include "k_gemm.h"
+#include "k_mlp.h"
+#include "k_mvit.h"
+#include "k_nhwc.h"
+#include "k_points.h"
+#include "k_prepost.h"
+#include "k_radar.h"
+#include "k_xca.h"
+
+namespace ach {
+
+#define ACH_HIP_CHECK(expr)                                                                               \
+    do {                                                                                                  \
+        hipError_t e_ = (expr);                                                                           \
+        if (e_ != hipSuccess) throw AchError{ACH_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)}; \
+    } while (0)
+
+static inline long round_up(long v, long m) { return (v + m - 1) / m * m; }
+
+// ================================================================================================ Engine<T>
+template <class T>
+class Engine final : public EngineBase {
+    using S = Store<T>;
+    static constexpr int VEC = S::VEC;
+    static constexpr int KC = 4 * VEC;
+
+public:
+    explicit Engine(const ach_config& c) : EngineBase(c) {}
+
+    struct A {              // NHWC activation view
+        T* p = nullptr; int B = 0, H = 0, W = 0, C = 0; long ld = 0;
+        long rows() const { return long(B) * H * W; }
+        A slice(int c0, int c) const { A s = *this; s.p = p + c0; s.C = c; return s; }
+    };
+    struct Pl {             // planar NCHW tensor (radar branch)
+        T* p = nullptr; int B = 0, C = 0, H = 0, W = 0;
+    };
+    struct Lin { std::vector<float> w, b; int N = 0, K = 0; };      // w[n*K + k]
+
+    // ------------------------------------------------------------------------------------------ helpers
+    A alloc(int B, int H, int W, int C) {
+        A a; a.B = B; a.H = H; a.W = W; a.C = C; a.ld = round_up(C, 8);
+        a.p = static_cast<T*>(aalloc(size_t(a.rows()) * a.ld * sizeof(T)));
+        return a;
+    }
+    Pl alloc_pl(int B, int C, int H, int W) {
+        Pl a; a.B = B; a.C = C; a.H = H; a.W = W;
+        a.p = static_cast<T*>(aalloc(size_t(B) * C * H * W * sizeof(T)));
+        return a;
+    }
+    float* alloc_f32(size_t n) { return static_cast<float*>(aalloc(n * sizeof(float))); }
+
+    T* up_T(const std::vector<float>& v) {
+        T* d = static_cast<T*>(walloc(v.size() * sizeof(T)));
+        if (!measuring) {
+            std::vector<T> h(v.size());
+            for (size_t i = 0; i < v.size(); ++i) S::st(&h[i], v[i]);
+            ACH_HIP_CHECK(hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+        }
+        return d;
+    }
+    void tap(const std::string& name, const A& a) {
+        TapInfo t; t.ptr = a.p; t.kind = 0; t.B = a.B; t.H = a.H; t.W = a.W; t.C = a.C; t.ld = a.ld; add_tap(name, t);
+    }
+    void tap(const std::string& name, const Pl& a) {
+        TapInfo t; t.ptr = a.p; t.kind = 1; t.B = a.B; t.H = a.H; t.W = a.W; t.C = a.C; add_tap(name, t);
+    }
+
+    // ---- linear-layer algebra on the host
+    Lin lin(const std::string& wkey, const std::string& bkey) const {
+        const HostTensor& w = W(wkey);
+        if (w.shape.size() < 2) throw AchError{ACH_ERR_MISSING_KEY, "not a matrix: " + wkey};
+        Lin l; l.N = int(w.shape[0]); l.K = int(w.numel() / w.shape[0]);
+        l.w = w.data;
+        if (!bkey.empty() && hasW(bkey)) { l.b = W(bkey).data; if (int(l.b.size()) != l.N) throw AchError{ACH_ERR_MISSING_KEY, "bias shape: " + bkey}; }
+        else l.b.assign(size_t(l.N), 0.f);
+        return l;
+    }
+    void bn_coeffs(const std::string& pfx, double eps, std::vector<float>& scale, std::vector<float>& shift) const {
+        const auto& g = W(pfx + ".weight").data; const auto& b = W(pfx + ".bias").data;
+        const auto& m = W(pfx + ".running_mean").data; const auto& v = W(pfx + ".running_var").data;
+        scale.resize(g.size()); shift.resize(g.size());
+        for (size_t i = 0; i < g.size(); ++i) {
+            const double s = double(g[i]) / std::sqrt(double(v[i]) + eps);
+            scale[i] = float(s); shift[i] = float(double(b[i]) - double(m[i]) * s);
+        }
+    }
+    void fold_bn(Lin& l, const std::string& pfx, double eps) const {            // y = bn(Wx + b)
+        std::vector<float> sc, sh; bn_coeffs(pfx, eps, sc, sh);
+        if (int(sc.size()) != l.N) throw AchError{ACH_ERR_MISSING_KEY, "BatchNorm width mismatch at " + pfx};
+        for (int n = 0; n < l.N; ++n) {
+            for (int k = 0; k < l.K; ++k) l.w[size_t(n) * l.K + k] *= sc[n];
+            l.b[n] = l.b[n] * sc[n] + sh[n];
+        }
+    }
+    void fold_ln_in(Lin& l, const std::string& pfx) const {                      // y = W(lnw * xhat + lnb) + b
+        const auto& lw = W(pfx + ".weight").data; const auto& lb = W(pfx + ".bias").data;
+        if (int(lw.size()) != l.K) throw AchError{ACH_ERR_MISSING_KEY, "LayerNorm width mismatch at " + pfx};
+        for (int n = 0; n < l.N; ++n) {
+            double acc = l.b[n];
+            for (int k = 0; k < l.K; ++k) { acc += double(l.w[size_t(n) * l.K + k]) * lb[k]; l.w[size_t(n) * l.K + k] *= lw[k]; }
+            l.b[n] = float(acc);
+        }
+    }
+    void fold_scale_out(Lin& l, const std::vector<float>& g) const {             // y = g * (Wx + b)
+        for (int n = 0; n < l.N; ++n) { for (int k = 0; k < l.K; ++k) l.w[size_t(n) * l.K + k] *= g[n]; l.b[n] *= g[n]; }
+    }
+
+    struct Packed { T* w = nullptr; float* b = nullptr; int N = 0, K = 0, NT = 1, nchunks = 0, ksteps = 0; long group_elems = 0; };
+    static int pick_nt(int N) { return N <= 16 ? 1 : (N <= 32 ? 2 : 4); }
+    Packed pack_shape(int N, int K) const {
+        Packed p; p.N = N; p.K = K; p.NT = pick_nt(N);
+        p.nchunks = cdiv(N, 16 * p.NT); p.ksteps = cdiv(K, KC);
+        p.group_elems = long(p.nchunks) * p.ksteps * p.NT * 64 * VEC;
+        return p;
+    }
+    Packed pack(const Lin& l) {
+        Packed p = pack_shape(l.N, l.K);
+        std::vector<float> blob(size_t(p.group_elems), 0.f);
+        if (!measuring)
+            for (int n = 0; n < l.N; ++n)
+                for (int k = 0; k < l.K; ++k) blob[size_t(wfrag_offset(n, k, p.NT, p.ksteps, VEC))] = l.w[size_t(n) * l.K + k];
+        p.w = up_T(blob);
+        p.b = up_f32(l.b);
+        return p;
+    }
+
+    struct GemmOpt {
+        int act = ACT_NONE; bool ln = false; float ln_eps = 0.f;
+        const A* residual = nullptr;
+        int conv_k = 0, conv_s = 1, conv_p = 0, Hin = 0, Win = 0, Cin = 0, Ho = 0, Wo = 0;   // implicit-GEMM conv over NHWC
+        void** ydyn = nullptr; int out_nchw = 0, HW = 0, Ctot = 0, coff = 0;     // NCHW scatter into a user buffer
+        int groups = 1; long w_group_stride = 0;
+        const T* w_override = nullptr;                                            // data-dependent packed weights
+    };
+    // rows view: X.p, X.ld, rows = M ; K = pk.K
+    void gemm(const std::string& name, const T* Xp, long ldx, long M, const Packed& pk, T* Yp, long ldy, const GemmOpt& o) {
+        GemmParams g;
+        std::memset(&g, 0, sizeof(g));
+        g.X = Xp; g.ldx = ldx; g.conv_k = o.conv_k; g.conv_s = o.conv_s; g.conv_p = o.conv_p; g.Hin = o.Hin; g.Win = o.Win; g.Cin = o.Cin; g.Ho = o.Ho; g.Wo = o.Wo;
+        g.W = o.w_override ? o.w_override : pk.w; g.w_group_stride = o.w_group_stride;
+        g.bias = pk.b; g.bias_group_stride = 0;
+        g.Y = Yp; g.ldy = ldy;
+        g.R = o.residual ? o.residual->p : nullptr; g.ldr = o.residual ? o.residual->ld : 0;
+        g.groups = o.groups; g.M_per_group = int(M / o.groups);
+        g.K = pk.K; g.N = pk.N; g.nchunks = pk.nchunks; g.ksteps = pk.ksteps;
+        g.act = o.act; g.ln = o.ln ? 1 : 0; g.ln_eps = o.ln_eps;
+        g.out_nchw = o.out_nchw; g.HW = o.HW; g.Ctot = o.Ctot; g.coff = o.coff;
+        g.vec_store = (ldy % 8 == 0 && (!o.residual || o.residual->ld % 8 == 0)) ? 1 : 0;
+        if (ldx % VEC != 0) throw AchError{ACH_ERR_INVALID, name + ": activation row stride not 16-byte aligned"};
+        if (o.conv_k > 0 && (o.Cin % VEC != 0 || pk.K != o.conv_k * o.conv_k * o.Cin)) throw AchError{ACH_ERR_UNSUPPORTED, name + ": conv channel count not 16-byte aligned"};
+        // launch geometry: >= ~4 workgroups per CU.  Rows first (P sub-tiles of 16 rows per wave), then split the
+        // N-chunks over blockIdx.z when the row count alone cannot fill 256 CUs (10x10 / 20x20 maps, FC layers).
+        // (measured on MI355X, tests/gpu_gemm_bench.py: one 16-row sub-tile per wave beats 2 or 4 at every shape of this
+        //  network — the kernel is latency/bandwidth bound and lives on occupancy, not on weight-fragment reuse)
+        const long kTargetBlocks = 1024;
+        int P = 1;
+        const long row_blocks = cdivl(g.M_per_group, 64L * P) * g.groups;
+        int zsplit = int(std::min<long>(pk.nchunks, std::max<long>(1, cdivl(kTargetBlocks, row_blocks))));
+        g.chunks_per_block = cdiv(pk.nchunks, zsplit);
+        const int NT = pk.NT;
+        void** ydyn = o.ydyn;
+        const double esz = double(sizeof(T));
+        const double in_bytes = o.conv_k > 0 ? double(M) / (double(o.Ho) * o.Wo) * o.Hin * o.Win * o.Cin * esz : double(M) * pk.K * esz;   // inputs read ONCE
+        const double bytes = in_bytes + double(M) * pk.N * esz + (o.residual ? double(M) * pk.N * esz : 0.0)
+                             + double(pk.group_elems) * esz * (o.w_group_stride ? o.groups : 1);
+        if (batching) {           // collected now, emitted by flush_batch() as one launch per layer across the pyramid levels
+            if (g.groups != 1 || P != 1) throw AchError{ACH_ERR_INVALID, name + ": batched GEMMs must be ungrouped"};
+            BatchJob j; j.kind = 0; j.name = name; j.g = g; j.NT = NT; j.ydyn = ydyn; j.bytes = bytes; j.flops = 2.0 * double(M) * pk.K * pk.N;
+            batch_jobs.push_back(j);
+            return;
+        }
+        add_op(name, [g, NT, P, ydyn](hipStream_t s) mutable {
+            if (ydyn) g.Y = *ydyn;
+            launch_gemm<T>(g, NT, P, s);
+        }, bytes, 2.0 * double(M) * pk.K * pk.N);
+    }
+    // ---- batching of the same layer over the detection head's pyramid levels
+    struct BatchJob { int kind = 0; std::string name; GemmParams g; int NT = 1; void** ydyn = nullptr; DwParams d; int ks = 0; double bytes = 0, flops = 0; };
+    bool batching = false;
+    std::vector<BatchJob> batch_jobs;
+    // `levels` chains of `per_level` jobs each were recorded level by level; emit stage s of all levels as one launch
+    void flush_batch(int levels, int per_level) {
+        batching = false;
+        if (int(batch_jobs.size()) != levels * per_level || levels > 3) throw AchError{ACH_ERR_INVALID, "head batching: unexpected job count"};
+        for (int st = 0; st < per_level; ++st) {
+            const BatchJob& j0 = batch_jobs[size_t(st)];
+            double bytes = 0, flops = 0;
+            const std::string name = j0.name + "+levels";
+            if (j0.kind == 0) {
+                GemmJobs m;
+                std::memset(&m, 0, sizeof(m));
+                m.n = levels;
+                unsigned gx = 1, gz = 1;
+                void** yd[3] = {nullptr, nullptr, nullptr};
+                for (int l = 0; l < levels; ++l) {
+                    const BatchJob& j = batch_jobs[size_t(l * per_level + st)];
+                    if (j.kind != 0 || j.NT != j0.NT) throw AchError{ACH_ERR_INVALID, "head batching: layer shapes differ across levels"};
+                    m.p[l] = j.g;
+                    m.nbx[l] = unsigned(cdivl(j.g.M_per_group, 64L));
+                    m.nbz[l] = unsigned(cdiv(j.g.nchunks, j.g.chunks_per_block));
+                    gx = std::max(gx, m.nbx[l]); gz = std::max(gz, m.nbz[l]);
+                    yd[l] = j.ydyn; bytes += j.bytes; flops += j.flops;
+                }
+                const dim3 grid(gx, unsigned(levels), gz), block(256);
+                const int NT = j0.NT;
+                void** y0 = yd[0]; void** y1 = yd[1]; void** y2 = yd[2];
+                add_op(name, [m, grid, block, NT, y0, y1, y2](hipStream_t s) mutable {
+                    if (y0) m.p[0].Y = *y0;
+                    if (y1) m.p[1].Y = *y1;
+                    if (y2) m.p[2].Y = *y2;
+                    if (NT == 1) ACH_LAUNCH((gemm_multi_kernel<T, 1>), grid, block, s, m);
+                    else if (NT == 2) ACH_LAUNCH((gemm_multi_kernel<T, 2>), grid, block, s, m);
+                    else ACH_LAUNCH((gemm_multi_kernel<T, 4>), grid, block, s, m);
+                }, bytes, flops);
+            } else {
+                DwJobs m;
+                std::memset(&m, 0, sizeof(m));
+                m.n = levels;
+                unsigned gx = 1;
+                for (int l = 0; l < levels; ++l) {
+                    const BatchJob& j = batch_jobs[size_t(l * per_level + st)];
+                    if (j.kind != 1 || j.ks != 5 || j.d.stride != 1) throw AchError{ACH_ERR_INVALID, "head batching: depthwise shapes differ across levels"};
+                    m.p[l] = j.d;
+                    m.nbx[l] = unsigned(cdivl(long(j.d.B) * j.d.Ho * cdiv(j.d.Wo, 4) * (j.d.C / 4), 256));
+                    gx = std::max(gx, m.nbx[l]);
+                    bytes += j.bytes;
+                }
+                const dim3 grid(gx, unsigned(levels)), block(256);
+                add_op(name, [m, grid, block](hipStream_t s) { ACH_LAUNCH((dwconv_strip_multi_kernel<T, 5, 4>), grid, block, s, m); }, bytes, 0);
+            }
+        }
+        batch_jobs.clear();
+    }
+    void gemm(const std::string& name, const A& X, const Packed& pk, const A& Y, const GemmOpt& o = GemmOpt()) {
+        gemm(name, X.p, X.ld, X.rows(), pk, Y.p, Y.ld, o);
+    }
+
+    // depthwise conv (+ folded BN) on NHWC views
+    void dwconv(const std::string& name, const A& X, const A* X2, const std::string& wkey, const std::string& bkey,
+                const std::string& bnpfx, double bneps, int ks, int stride, int act, const A& Y) {
+        const HostTensor& w = W(wkey);
+        const int C = X.C;
+        if (w.shape[0] != C || w.numel() != long(C) * ks * ks) throw AchError{ACH_ERR_MISSING_KEY, "depthwise weight shape: " + wkey};
+        if (C % 4) throw AchError{ACH_ERR_UNSUPPORTED, name + ": depthwise channel count must be a multiple of 4"};
+        std::vector<float> wt(size_t(ks) * ks * C), bias(size_t(C), 0.f), sc(size_t(C), 1.f), sh(size_t(C), 0.f);
+        if (!bkey.empty()) bias = W(bkey).data;
+        if (!bnpfx.empty()) bn_coeffs(bnpfx, bneps, sc, sh);
+        for (int c = 0; c < C; ++c) {
+            for (int t = 0; t < ks * ks; ++t) wt[size_t(t) * C + c] = w.data[size_t(c) * ks * ks + t] * sc[c];
+            bias[c] = bias[c] * sc[c] + sh[c];
+        }
+        DwParams p;
+        std::memset(&p, 0, sizeof(p));
+        p.X = X.p; p.ldx = X.ld; p.X2 = X2 ? X2->p : nullptr; p.ldx2 = X2 ? X2->ld : 0;
+        p.W = up_f32(wt); p.bias = up_f32(bias); p.Y = Y.p; p.ldy = Y.ld;
+        p.B = X.B; p.H = X.H; p.Wd = X.W; p.C = C; p.Ho = Y.H; p.Wo = Y.W; p.stride = stride; p.act = act;
+        p.tile = (dw_tile && X.H * X.W <= 144) ? 1 : 0;      // measured: wins on 10x10 maps (2x), loses from 20x20 up (LDS issue bound)
+        const double px_in = double(X.B) * X.H * X.W * C * sizeof(T), px_out = double(Y.B) * Y.H * Y.W * C * sizeof(T);
+        add_op(name, [p, ks](hipStream_t s) { launch_dwconv<T>(p, ks, s); }, px_in * (X2 ? 2 : 1) + px_out, 0);
+    }
+
+    template <class K, class Pm>
+    void ew(const std::string& name, K kern, const Pm& p, long total, double bytes = 0) {      // 256-thread element-wise launch
+        const dim3 grid(unsigned(cdivl(total, 256))), block(256);
+        add_op(name, [kern, p, grid, block](hipStream_t s) { ACH_LAUNCH(kern, grid, block, s, p); }, bytes, 0);
+    }
+    void add(const std::string& name, const A& a, const A& b, const A& y) {
+        AddParams p{a.p, a.ld, b.p, b.ld, y.p, y.ld, a.rows(), a.C};
+        ew(name, add_kernel<T>, p, a.rows() * (a.C / 4), 3.0 * a.rows() * a.C * sizeof(T));
+    }
+    void copy(const std::string& name, const A& x, const A& y, const float* posenc = nullptr) {
+        CopyParams p{x.p, x.ld, y.p, y.ld, x.rows(), x.C, posenc, x.H * x.W};
+        ew(name, copy_kernel<T>, p, x.rows() * (x.C / 4), 2.0 * x.rows() * x.C * sizeof(T));
+    }
+    // per-(sample, channel) sums over H*W -> partial [B][S][2][C] ; returns S
+    int stats(const std::string& name, const A& x, float*& partial) {
+        const int HW = x.H * x.W;
+        const int S = HW >= 1024 ? 8 : (HW >= 256 ? 4 : 1);
+        partial = alloc_f32(size_t(x.B) * S * 2 * x.C);
+        StatParams p{x.p, x.ld, partial, HW, x.C, S};
+        const dim3 grid(unsigned(x.B), unsigned(S)), block(256);
+        add_op(name, [p, grid, block](hipStream_t s) { ACH_LAUNCH(chan_stats_kernel<T>, grid, block, s, p); });
+        return S;
+    }
+
+    // ------------------------------------------------------------------------------------------ EdgeNeXt (a2-a5)
+    struct EnCfg { int depths[4]; int dims[4]; int heads; int scales[4]; int ks[4]; };
+    EnCfg en_cfg() const {
+        switch (cfg.phi) {
+            case ACH_PHI_S0: return {{2, 2, 6, 2}, {32, 48, 96, 176}, 4, {2, 2, 3, 4}, {3, 5, 7, 9}};
+            case ACH_PHI_S1: return {{3, 3, 9, 3}, {32, 48, 120, 224}, 4, {2, 2, 3, 4}, {3, 5, 7, 9}};
+            default: return {{3, 3, 9, 3}, {32, 64, 144, 288}, 8, {2, 2, 3, 4}, {3, 5, 7, 9}};
+        }
+    }
+    // constant-folded Fourier positional encoding [HW][C] (edgenext_modules/layers.py:38-59)
+    float* posenc_table(const std::string& pfx, int H, int Wd, int C) {
+        const int hidden = 32;
+        const HostTensor& w = W(pfx + ".token_projection.weight");
+        const HostTensor& b = W(pfx + ".token_projection.bias");
+        std::vector<float> tab(size_t(H) * Wd * C);
+        if (!measuring) {
+            std::vector<float> feat(2 * hidden);
+            for (int y = 0; y < H; ++y)
+                for (int x = 0; x < Wd; ++x) {
+                    const float ye = float(y + 1) / (float(H) + 1e-6f) * float(2.0 * M_PI);
+                    const float xe = float(x + 1) / (float(Wd) + 1e-6f) * float(2.0 * M_PI);
+                    for (int i = 0; i < hidden; ++i) {
+                        const float dim_t = std::pow(10000.0f, float(2 * (i / 2)) / float(hidden));
+                        const float py = ye / dim_t, px = xe / dim_t;
+                        feat[i] = (i % 2 == 0) ? std::sin(py) : std::cos(py);
+                        feat[hidden + i] = (i % 2 == 0) ? std::sin(px) : std::cos(px);
+                    }
+                    for (int c = 0; c < C; ++c) {
+                        double acc = b.data[c];
+                        for (int k = 0; k < 2 * hidden; ++k) acc += double(w.data[size_t(c) * 2 * hidden + k]) * feat[k];
+                        tab[(size_t(y) * Wd + x) * C + c] = float(acc);
+                    }
+                }
+        }
+        return up_f32(tab);
+    }
+
+    A pw_mlp(const std::string& pfx, const A& xin, const A& resid) {     // LN -> Linear -> GELU -> Linear -> gamma -> + resid
+        const int C = xin.C;
+        Lin l1 = lin(pfx + ".pwconv1.weight", pfx + ".pwconv1.bias");
+        fold_ln_in(l1, pfx + ".norm");
+        Lin l2 = lin(pfx + ".pwconv2.weight", pfx + ".pwconv2.bias");
+        fold_scale_out(l2, W(pfx + ".gamma").data);
+        A h = alloc(xin.B, xin.H, xin.W, 4 * C);
+        GemmOpt o1; o1.act = ACT_GELU; o1.ln = true; o1.ln_eps = 1e-6f;
+        gemm(pfx + ".pwconv1", xin, pack(l1), h, o1);
+        A y = block_out(xin);
+        GemmOpt o2; o2.residual = &resid;
+        gemm(pfx + ".pwconv2", h, pack(l2), y, o2);
+        return y;
+    }
+    // One launch for [depthwise kxk ->] LN -> Linear -> act -> Linear -> scale -> + resid (k_mlp.h).  Returns false when the
+    // width is outside the kernel's instantiations (the caller then runs the layer-wise path).
+    bool fused_mlp(const std::string& pfx, const A& xin, const A& resid, int dw_ks, A& y) {
+        if (!fuse_mlp || mlp_pick_dt(xin.C) == 0) return false;
+        Lin l1 = lin(pfx + ".pwconv1.weight", pfx + ".pwconv1.bias");
+        fold_ln_in(l1, pfx + ".norm");
+        Lin l2 = lin(pfx + ".pwconv2.weight", pfx + ".pwconv2.bias");
+        fold_scale_out(l2, W(pfx + ".gamma").data);
+        return fused_mlp_lin(pfx + (dw_ks ? ".block" : ".mlp"), pfx, xin, resid, dw_ks, l1, l2, ACT_GELU, 1e-6f, y);
+    }
+    // generic form: l1 has the LayerNorm affine folded in, l2 any output scale; `pfx`.dwconv.{weight,bias} when dw_ks > 0
+    // When set, the next block output is written there instead of a fresh allocation (a channel slice of a concat buffer of the
+    // neck: torch.cat((upsampled, backbone feature), 1) then needs no copy).  Consumed by the first block that produces an output.
+    A preset_out; bool has_preset = false;
+    A block_out(const A& like) {
+        if (has_preset) {
+            has_preset = false;
+            if (preset_out.B != like.B || preset_out.H != like.H || preset_out.W != like.W || preset_out.C != like.C)
+                throw AchError{ACH_ERR_INVALID, "preset block output does not match the block"};
+            return preset_out;
+        }
+        return alloc(like.B, like.H, like.W, like.C);
+    }
+    bool fused_mlp_lin(const std::string& name, const std::string& pfx, const A& xin, const A& resid, int dw_ks, const Lin& l1, const Lin& l2,
+                       int act, float ln_eps, A& y) {
+        if (!fuse_mlp) return false;
+        const int C = xin.C, DT = mlp_pick_dt(C);
+        if (DT == 0 || (dw_ks != 0 && dw_ks != 3 && dw_ks != 5 && dw_ks != 7 && dw_ks != 9)) return false;
+        const int hidden = l1.N, k1 = cdiv(C, KC), J = cdiv(hidden, 32), hstep = 8 / VEC, ks2 = J * hstep;
+        if (l1.K != C || l2.N != C || l2.K != hidden) throw AchError{ACH_ERR_MISSING_KEY, "MLP shapes at " + pfx};
+        std::vector<float> w1(size_t(J) * k1 * 2 * 64 * VEC, 0.f), b1(size_t(J) * 32, 0.f);
+        std::vector<float> w2(size_t(ks2) * DT * 64 * VEC, 0.f), b2(size_t(DT) * 16, 0.f);
+        if (!measuring) {
+            for (int n = 0; n < hidden; ++n) {
+                b1[n] = l1.b[n];
+                for (int k = 0; k < C; ++k) w1[size_t(wfrag_offset(n, k, 2, k1, VEC))] = l1.w[size_t(n) * C + k];
+            }
+            for (int n = 0; n < C; ++n) {
+                b2[n] = l2.b[n];
+                for (int kap = 0; kap < 32 * J; ++kap) {
+                    const int ch = mlp_hidden_channel(kap, VEC);
+                    if (ch < hidden) w2[size_t(wfrag_offset(n, kap, DT, ks2, VEC))] = l2.w[size_t(n) * hidden + ch];
+                }
+            }
+        }
+        MlpParams mp;
+        std::memset(&mp, 0, sizeof(mp));
+        mp.X = xin.p; mp.ldx = xin.ld; mp.R = resid.p; mp.ldr = resid.ld;
+        y = block_out(xin);
+        mp.Y = y.p; mp.ldy = y.ld;
+        mp.dw_k = dw_ks; mp.H = xin.H; mp.W = xin.W;
+        if (dw_ks) {
+            const HostTensor& w = W(pfx + ".dwconv.weight");
+            const std::vector<float>& b = W(pfx + ".dwconv.bias").data;
+            const int ldc = k1 * KC, kk = dw_ks * dw_ks;
+            if (size_t(w.numel()) != size_t(C) * size_t(kk)) throw AchError{ACH_ERR_MISSING_KEY, "depthwise shape at " + pfx};
+            std::vector<float> wt(size_t(kk) * ldc, 0.f), bt(size_t(ldc), 0.f);
+            for (int c = 0; c < C; ++c) { bt[c] = b[c]; for (int t = 0; t < kk; ++t) wt[size_t(t) * ldc + c] = w.data[size_t(c) * kk + t]; }
+            mp.Wdw = up_f32(wt); mp.bdw = up_f32(bt);
+        }
+        mp.W1 = up_T(w1); mp.b1 = up_f32(b1); mp.W2 = up_T(w2); mp.b2 = up_f32(b2);
+        mp.M = xin.rows(); mp.C = C; mp.k1 = k1; mp.J = J; mp.act = act; mp.ln_eps = ln_eps; mp.ln = 1; mp.Cout = C;
+        // per-sample map size, not batch, decides the geometry: a frame's result must not depend on the batch it is in
+        const bool split = mlp_split < 0 ? xin.H * xin.W <= 1024 : mlp_split != 0;
+        const double bytes = double(mp.M) * C * sizeof(T) * (xin.p == resid.p ? 2.0 : 3.0);
+        const double flops = 4.0 * double(mp.M) * C * hidden + (dw_ks ? 2.0 * double(mp.M) * C * dw_ks * dw_ks : 0.0);
+        add_op(name, [mp, DT, split](hipStream_t s) { launch_mlp<T>(mp, DT, split, s); }, bytes, flops);
+        return true;
+    }
+    // y = l2(act(l1(x))) as one launch (k_mlp.h without LayerNorm / residual); false when the widths are not instantiated
+    bool chain2(const std::string& name, const A& x, const Lin& l1, int act, const Lin& l2, A& y) {
+        if (!fuse_mlp) return false;
+        const int Cin = x.C, hidden = l1.N, Cout = l2.N;
+        const int k1 = cdiv(Cin, KC), J = cdiv(hidden, 32), hstep = 8 / VEC, ks2 = J * hstep;
+        const bool split = mlp_split < 0 ? x.H * x.W <= 1024 : mlp_split != 0;
+        // narrow layers on maps that are not latency-bound: every weight fragment in registers, several tiles per wave (chain_kernel)
+        const bool small = Cout <= 32 && k1 <= 3 && J <= 2 && !split;
+        const int DT = small ? 2 : mlp_pick_dt(std::max(Cin, Cout));
+        if (DT == 0 || l1.K != Cin || l2.K != hidden) return false;
+        std::vector<float> w1(size_t(J) * k1 * 2 * 64 * VEC, 0.f), b1(size_t(J) * 32, 0.f);
+        std::vector<float> w2(size_t(ks2) * DT * 64 * VEC, 0.f), b2(size_t(DT) * 16, 0.f);
+        if (!measuring) {
+            for (int n = 0; n < hidden; ++n) {
+                b1[n] = l1.b[n];
+                for (int k = 0; k < Cin; ++k) w1[size_t(wfrag_offset(n, k, 2, k1, VEC))] = l1.w[size_t(n) * Cin + k];
+            }
+            for (int n = 0; n < Cout; ++n) {
+                b2[n] = l2.b[n];
+                for (int kap = 0; kap < 32 * J; ++kap) {
+                    const int ch = mlp_hidden_channel(kap, VEC);
+                    if (ch < hidden) w2[size_t(wfrag_offset(n, kap, DT, ks2, VEC))] = l2.w[size_t(n) * hidden + ch];
+                }
+            }
+        }
+        y = alloc(x.B, x.H, x.W, Cout);
+        MlpParams mp;
+        std::memset(&mp, 0, sizeof(mp));
+        mp.X = x.p; mp.ldx = x.ld; mp.Y = y.p; mp.ldy = y.ld;
+        mp.W1 = up_T(w1); mp.b1 = up_f32(b1); mp.W2 = up_T(w2); mp.b2 = up_f32(b2);
+        mp.M = x.rows(); mp.C = Cin; mp.k1 = k1; mp.J = J; mp.act = act; mp.ln = 0; mp.Cout = Cout;
+        add_op(name, [mp, DT, split, small](hipStream_t s) { if (small) launch_chain<T>(mp, s); else launch_mlp<T>(mp, DT, split, s); },
+               double(mp.M) * (Cin + Cout) * sizeof(T), 2.0 * double(mp.M) * hidden * (Cin + Cout));
+        return true;
+    }
+    A conv_encoder(const std::string& pfx, const A& x, int ks) {          // conv_encoder.py:19-32
+        A fy;
+        if (fused_mlp(pfx, x, x, ks, fy)) return fy;
+        A d = alloc(x.B, x.H, x.W, x.C);
+        dwconv(pfx + ".dwconv", x, nullptr, pfx + ".dwconv.weight", pfx + ".dwconv.bias", "", 0, ks, 1, ACT_NONE, d);
+        return pw_mlp(pfx, d, x);
+    }
+    A sdta_encoder(const std::string& pfx, const A& x, int scales, int heads) {   // sdta_encoder.py:39-74
+        const int C = x.C;
+        const int width = std::max((C + scales - 1) / scales, C / scales);
+        const int nums = scales - 1;
+        if ((C / heads) > 48) throw AchError{ACH_ERR_UNSUPPORTED, "XCA head dimension > 48"};
+        if (width % 4) throw AchError{ACH_ERR_UNSUPPORTED, "SDTA split width must be a multiple of 4"};
+        A y = alloc(x.B, x.H, x.W, C);
+        for (int i = 0; i < nums; ++i) {
+            A xi = x.slice(i * width, width), yi = y.slice(i * width, width);
+            A prev = i > 0 ? y.slice((i - 1) * width, width) : A();
+            const std::string c = pfx + ".convs." + std::to_string(i);
+            dwconv(c, xi, i > 0 ? &prev : nullptr, c + ".weight", c + ".bias", "", 0, 3, 1, ACT_NONE, yi);
+        }
+        copy(pfx + ".split_tail", x.slice(nums * width, C - nums * width), y.slice(nums * width, C - nums * width));
+        if (hasW(pfx + ".pos_embd.token_projection.weight"))
+            copy(pfx + ".pos_embd", y, y, posenc_table(pfx + ".pos_embd", x.H, x.W, C));
+        // XCA
+        Lin lq = lin(pfx + ".xca.qkv.weight", pfx + ".xca.qkv.bias");
+        fold_ln_in(lq, pfx + ".norm_xca");
+        A qkv = alloc(x.B, x.H, x.W, 3 * C);
+        GemmOpt oq; oq.ln = true; oq.ln_eps = 1e-6f;
+        gemm(pfx + ".xca.qkv", y, pack(lq), qkv, oq);
+        const int d = C / heads, N = x.H * x.W;
+        // Gram matrices over token slices, then softmax + fold into per-sample projection weights (see k_xca.h)
+        const int S = N >= 1024 ? 8 : (N >= 256 ? 4 : 1);
+        float* partial = alloc_f32(size_t(x.B) * heads * S * (d * d + 2 * d));
+        XcaGramParams pg{qkv.p, qkv.ld, partial, x.B, N, C, heads, S};
+        {
+            const dim3 grid(unsigned(x.B * heads), unsigned(S)), block(256);
+            add_op(pfx + ".xca.gram", [pg, grid, block](hipStream_t s) { ACH_LAUNCH(xca_gram_kernel<T>, grid, block, s, pg); },
+                   2.0 * x.rows() * C * sizeof(T));
+        }
+        Packed pe = pack_shape(C, C);
+        T* weff = static_cast<T*>(aalloc(size_t(x.B) * pe.group_elems * sizeof(T)));
+        Lin lp = lin(pfx + ".xca.proj.weight", pfx + ".xca.proj.bias");
+        const std::vector<float>& gx = W(pfx + ".gamma_xca").data;
+        std::vector<float> bproj(static_cast<size_t>(C), 0.f);
+        for (int c = 0; c < C; ++c) bproj[c] = lp.b[c] * gx[c];
+        pe.b = up_f32(bproj);
+        XcaFinalParams pf{partial, S, up_f32(W(pfx + ".xca.temperature").data), up_f32(lp.w), up_f32(gx), nullptr, weff, pe.group_elems,
+                          x.B, C, heads, pe.NT, pe.ksteps};
+        {
+            const dim3 grid(unsigned(x.B * heads), unsigned(cdiv(C, XCA_CT))), block(256);
+            add_op(pfx + ".xca.finalize", [pf, grid, block](hipStream_t s) { ACH_LAUNCH(xca_finalize_kernel<T>, grid, block, s, pf); });
+        }
+        // t2 = y + gamma_xca * proj(attn @ v): one GEMM over v (channel slice [2C,3C) of qkv) with per-sample weights
+        A t2 = alloc(x.B, x.H, x.W, C);
+        {
+            GemmOpt op; op.residual = &y; op.groups = x.B; op.w_group_stride = pe.group_elems; op.w_override = weff;
+            gemm(pfx + ".xca.proj", qkv.p + 2 * C, qkv.ld, qkv.rows(), pe, t2.p, t2.ld, op);
+        }
+        A fy;
+        if (fused_mlp(pfx, t2, x, 0, fy)) return fy;
+        return pw_mlp(pfx, t2, x);
+    }
+    // `dst[i]` (optional, may be null): where the output of stage i is to be written
+    void edgenext(const std::string& pfx, A feats[4], const A* const dst[4]) {                   // edgenext.py:73-86
+        const EnCfg ec = en_cfg();
+        const int B = batch, R = cfg.resolution;
+        A x;
+        for (int i = 0; i < 4; ++i) {
+            const std::string d = pfx + ".downsample_layers." + std::to_string(i);
+            if (i == 0) {
+                const HostTensor& w = W(d + ".0.weight");
+                if (w.shape.size() != 4 || w.shape[0] != 32 || w.shape[1] != 3 || w.shape[2] != 4) throw AchError{ACH_ERR_UNSUPPORTED, "stem shape"};
+                std::vector<float> wt(48 * 32);
+                for (int o = 0; o < 32; ++o)
+                    for (int k = 0; k < 48; ++k) wt[size_t(k) * 32 + o] = w.data[size_t(o) * 48 + k];
+                x = alloc(B, R / 4, R / 4, 32);
+                StemParams sp{nullptr, x.p, up_f32(wt), up_f32(W(d + ".0.bias").data), up_f32(W(d + ".1.weight").data),
+                              up_f32(W(d + ".1.bias").data), B, R, R, 1e-6f};
+                const dim3 grid(unsigned(cdivl(x.rows(), 256))), block(256);
+                const void** img = &io.image;
+                add_op(d, [sp, grid, block, img](hipStream_t s) mutable { sp.X = *img; ACH_LAUNCH(stem_kernel<T>, grid, block, s, sp); });
+            } else {
+                A t = alloc(x.B, x.H, x.W, x.C);
+                int G = 1;
+                while (G < x.C / 4 && G < 64) G <<= 1;
+                LnParams lp{x.p, x.ld, t.p, t.ld, up_f32(W(d + ".0.weight").data), up_f32(W(d + ".0.bias").data), x.rows(), x.C, 1e-6f, G};
+                const dim3 grid(unsigned(cdivl(x.rows(), 256 / G))), block(256);
+                add_op(d + ".0", [lp, grid, block](hipStream_t s) { ACH_LAUNCH(layernorm_kernel<T>, grid, block, s, lp); });
+                // conv 2x2 stride 2: k = (dy, dx, c) over two contiguous NHWC segments
+                const HostTensor& w = W(d + ".1.weight");
+                const int Co = int(w.shape[0]), Ci = int(w.shape[1]);
+                if (Ci != x.C || t.ld != t.C) throw AchError{ACH_ERR_UNSUPPORTED, "downsample conv shape"};
+                Lin l; l.N = Co; l.K = 4 * Ci; l.w.resize(size_t(Co) * 4 * Ci); l.b = W(d + ".1.bias").data;
+                for (int o = 0; o < Co; ++o)
+                    for (int c = 0; c < Ci; ++c)
+                        for (int dy = 0; dy < 2; ++dy)
+                            for (int dx = 0; dx < 2; ++dx)
+                                l.w[size_t(o) * 4 * Ci + (dy * 2 + dx) * Ci + c] = w.data[((size_t(o) * Ci + c) * 2 + dy) * 2 + dx];
+                A y = alloc(x.B, x.H / 2, x.W / 2, Co);
+                GemmOpt o; o.conv_k = 2; o.conv_s = 2; o.conv_p = 0; o.Hin = x.H; o.Win = x.W; o.Cin = Ci; o.Ho = x.H / 2; o.Wo = x.W / 2;
+                gemm(d + ".1", t.p, t.ld, y.rows(), pack(l), y.p, y.ld, o);
+                x = y;
+            }
+            for (int j = 0; j < ec.depths[i]; ++j) {
+                const std::string b = pfx + ".stages." + std::to_string(i) + "." + std::to_string(j);
+                if (j == ec.depths[i] - 1 && dst && dst[i]) { preset_out = *dst[i]; has_preset = true; }
+                if (i > 0 && j == ec.depths[i] - 1) x = sdta_encoder(b, x, ec.scales[i], ec.heads);
+                else x = conv_encoder(b, x, ec.ks[i]);
+                tap("backbone.s" + std::to_string(i) + ".b" + std::to_string(j), x);
+            }
+            if (has_preset) throw AchError{ACH_ERR_INVALID, "stage output destination was not consumed"};
+            feats[i] = x;
+        }
+    }
+
+    // ------------------------------------------------------------------------------------------ MobileViT (a6)
+    struct MvCfg { int dims[3]; int ch[11]; int exp; };
+    MvCfg mv_cfg() const {
+        switch (cfg.phi) {
+            case ACH_PHI_S0: return {{64, 80, 96}, {16, 16, 32, 32, 48, 48, 96, 96, 96, 96, 176}, 2};
+            case ACH_PHI_S1: return {{96, 120, 144}, {16, 32, 32, 32, 48, 48, 120, 120, 120, 120, 224}, 4};
+            default: return {{144, 192, 240}, {16, 32, 32, 32, 64, 64, 144, 144, 144, 144, 288}, 4};
+        }
+    }
+    // nn.Sequential(conv kxk (no bias), BatchNorm(1e-5), SiLU) as an (implicit-)GEMM   (mobilevit.py:6-19)
+    A mv_conv(const std::string& pfx, const A& x, int k, int stride) {
+        const HostTensor& w = W(pfx + ".0.weight");
+        Lin l = (k == 1) ? lin(pfx + ".0.weight", "") : conv_lin(pfx + ".0.weight", "", int(w.shape[1]), int(x.ld), k);
+        if (k == 1 && l.K != x.C) throw AchError{ACH_ERR_MISSING_KEY, "conv width at " + pfx};
+        fold_bn(l, pfx + ".1", 1e-5);
+        if (k == 1) { A y = alloc(x.B, x.H, x.W, l.N); GemmOpt o; o.act = ACT_SILU; gemm(pfx, x, pack(l), y, o); return y; }
+        return conv_gemm(pfx, x, l, k, stride, ACT_SILU);
+    }
+    A mv2block(const std::string& pfx, const A& x, int stride, int oup) {         // mobilevit.py:93-131 (expansion != 1)
+        Lin l1 = lin(pfx + ".conv.0.weight", ""); fold_bn(l1, pfx + ".conv.1", 1e-5);
+        A hdn = alloc(x.B, x.H, x.W, l1.N);
+        { GemmOpt o; o.act = ACT_SILU; gemm(pfx + ".pw1", x, pack(l1), hdn, o); }
+        const int Ho = (x.H + 2 - 3) / stride + 1, Wo = (x.W + 2 - 3) / stride + 1;
+        A d = alloc(x.B, Ho, Wo, l1.N);
+        dwconv(pfx + ".dw", hdn, nullptr, pfx + ".conv.3.weight", "", pfx + ".conv.4", 1e-5, 3, stride, ACT_SILU, d);
+        Lin l2 = lin(pfx + ".conv.6.weight", ""); fold_bn(l2, pfx + ".conv.7", 1e-5);
+        if (l2.N != oup) throw AchError{ACH_ERR_MISSING_KEY, "MV2 width at " + pfx};
+        A y = alloc(x.B, Ho, Wo, oup);
+        GemmOpt o; if (stride == 1 && x.C == oup) o.residual = &x;
+        gemm(pfx + ".pw2", d, pack(l2), y, o);
+        return y;
+    }
+    A mvit_block(const std::string& pfx, const A& x, int depth) {                   // mobilevit.py:147-165
+        if ((x.H & 1) || (x.W & 1) || (x.H / 2) * (x.W / 2) > MVIT_NMAX) throw AchError{ACH_ERR_UNSUPPORTED, "MobileViT token count"};
+        A t = mv_conv(pfx + ".conv1", x, 3, 1);
+        t = mv_conv(pfx + ".conv2", t, 1, 1);
+        const int D = t.C;
+        for (int l = 0; l < depth; ++l) {
+            const std::string a = pfx + ".transformer.layers." + std::to_string(l) + ".0", f = pfx + ".transformer.layers." + std::to_string(l) + ".1";
+            Lin lq = lin(a + ".fn.to_qkv.weight", ""); fold_ln_in(lq, a + ".norm");
+            if (lq.N != 96) throw AchError{ACH_ERR_UNSUPPORTED, "MobileViT attention is built for 4 heads x 8"};
+            A qkv = alloc(t.B, t.H, t.W, 96);
+            { GemmOpt o; o.ln = true; o.ln_eps = 1e-5f; gemm(a + ".qkv", t, pack(lq), qkv, o); }
+            A ao = alloc(t.B, t.H, t.W, 32);
+            MvitAttnParams ap{qkv.p, qkv.ld, ao.p, ao.ld, t.B, t.H, t.W, 4, 0.35355339059327373f};
+            const int N = (t.H / 2) * (t.W / 2);
+            const dim3 grid(unsigned(t.B * 4 * 4), unsigned(cdiv(N, 256))), block(256);
+            if (N > MVIT_NMAX) throw AchError{ACH_ERR_UNSUPPORTED, "MobileViT attention: more than 1600 tokens per group"};
+            if (N <= 400) add_op(a + ".attn", [ap, grid, block](hipStream_t s) { ACH_LAUNCH((mvit_attn_kernel<T, 400>), grid, block, s, ap); }, double(t.rows()) * 128 * sizeof(T));
+            else add_op(a + ".attn", [ap, grid, block](hipStream_t s) { ACH_LAUNCH((mvit_attn_kernel<T, MVIT_NMAX>), grid, block, s, ap); }, double(t.rows()) * 128 * sizeof(T));
+            A t1 = alloc(t.B, t.H, t.W, D);
+            { GemmOpt o; o.residual = &t; gemm(a + ".to_out", ao, pack(lin(a + ".fn.to_out.0.weight", a + ".fn.to_out.0.bias")), t1, o); }
+            Lin l1 = lin(f + ".fn.net.0.weight", f + ".fn.net.0.bias"); fold_ln_in(l1, f + ".norm");
+            Lin l2 = lin(f + ".fn.net.3.weight", f + ".fn.net.3.bias");
+            A t2;
+            if (!fused_mlp_lin(f + ".ffn", f, t1, t1, 0, l1, l2, ACT_SILU, 1e-5f, t2)) {      // LN -> fc1 -> SiLU -> fc2 -> + input (k_mlp.h)
+                A hdn = alloc(t.B, t.H, t.W, l1.N);
+                { GemmOpt o; o.ln = true; o.ln_eps = 1e-5f; o.act = ACT_SILU; gemm(f + ".ff1", t1, pack(l1), hdn, o); }
+                t2 = alloc(t.B, t.H, t.W, D);
+                { GemmOpt o; o.residual = &t1; gemm(f + ".ff2", hdn, pack(l2), t2, o); }
+            }
+            t = t2;
+        }
+        // conv3 (1x1 D->C) written next to the block input: cat((conv3(x), y), 1) -> conv4 3x3
+        Lin l3 = lin(pfx + ".conv3.0.weight", ""); fold_bn(l3, pfx + ".conv3.1", 1e-5);
+        if (l3.N != x.C) throw AchError{ACH_ERR_MISSING_KEY, "MobileViT conv3 width at " + pfx};
+        A cat = alloc(x.B, x.H, x.W, 2 * x.C);
+        { GemmOpt o; o.act = ACT_SILU; gemm(pfx + ".conv3", t, pack(l3), cat.slice(0, x.C), o); }
+        copy(pfx + ".cat", x, cat.slice(x.C, x.C));
+        return mv_conv(pfx + ".conv4", cat, 3, 1);
+    }
+    void mobilevit(const std::string& pfx, A feats[4]) {                            // mobilevit.py:198-222
+        const MvCfg mc = mv_cfg();
+        const int B = batch, R = cfg.resolution;
+        A img = alloc(B, R, R, 3);
+        {
+            ToNhwcParams tp{nullptr, img.p, B, 3, R, R, img.ld};
+            const dim3 grid(unsigned(cdivl(img.rows(), 256))), block(256);
+            const void** in = &io.image;
+            add_op(pfx + ".to_nhwc", [tp, grid, block, in](hipStream_t s) mutable { tp.X = *in; ACH_LAUNCH(nchw_to_nhwc_kernel<T>, grid, block, s, tp); },
+                   double(img.rows()) * (3 + img.ld) * sizeof(T));
+        }
+        A x = mv_conv(pfx + ".conv1", img, 3, 2);
+        x = mv2block(pfx + ".mv2.0", x, 1, mc.ch[1]);
+        x = mv2block(pfx + ".mv2.1", x, 2, mc.ch[2]);
+        x = mv2block(pfx + ".mv2.2", x, 1, mc.ch[3]);
+        x = mv2block(pfx + ".mv2.3", x, 1, mc.ch[3]);
+        feats[0] = x;
+        x = mv2block(pfx + ".mv2.4", x, 2, mc.ch[4]);
+        x = mvit_block(pfx + ".mvit.0", x, 2);
+        feats[1] = x;
+        x = mv2block(pfx + ".mv2.5", x, 2, mc.ch[6]);
+        x = mvit_block(pfx + ".mvit.1", x, 4);
+        feats[2] = x;
+        x = mv2block(pfx + ".mv2.6", x, 2, mc.ch[8]);
+        x = mvit_block(pfx + ".mvit.2", x, 3);
+        feats[3] = mv_conv(pfx + ".conv2", x, 1, 1);
+    }
+
+    // ------------------------------------------------------------------------------------------ neck (a7-a13)
+    Lin conv_bn(const std::string& conv, const std::string& bn, double eps) const { Lin l = lin(conv + ".weight", conv + ".bias"); fold_bn(l, bn, eps); return l; }
+
+    // GhostModule (ghost_conv.py:6-29) on NHWC: primary 1x1 -> channels [0,init), cheap dw3x3 -> [init, 2*init)
+    A ghost(const std::string& pfx, const A& x, int oup, bool relu) {
+        const int init = (oup + 1) / 2;
+        if (init % 4 || oup != 2 * init) throw AchError{ACH_ERR_UNSUPPORTED, pfx + ": NHWC GhostModule needs an even output width divisible by 8"};
+        A y = alloc(x.B, x.H, x.W, oup);
+        GemmOpt o; o.act = relu ? ACT_RELU : ACT_NONE;
+        gemm(pfx + ".primary", x, pack(conv_bn(pfx + ".primary_conv.0", pfx + ".primary_conv.1", 1e-5)), y.slice(0, init), o);
+        dwconv(pfx + ".cheap", y.slice(0, init), nullptr, pfx + ".cheap_operation.0.weight", "", pfx + ".cheap_operation.1", 1e-5, 3, 1,
+               relu ? ACT_RELU : ACT_NONE, y.slice(init, init));
+        return y;
+    }
+    A ghost_bottleneck(const std::string& pfx, const A& x, int out_chs) {       // ghost_conv.py:58-70, stride 1, in != out
+        A g1 = ghost(pfx + ".ghost1", x, x.C, true);
+        A g2 = ghost(pfx + ".ghost2", g1, out_chs, false);
+        A sd = alloc(x.B, x.H, x.W, x.C);
+        dwconv(pfx + ".shortcut.dw", x, nullptr, pfx + ".shortcut.0.weight", "", pfx + ".shortcut.1", 1e-5, 3, 1, ACT_NONE, sd);
+        A y = alloc(x.B, x.H, x.W, out_chs);
+        GemmOpt o; o.residual = &g2;
+        gemm(pfx + ".shortcut.pw", sd, pack(conv_bn(pfx + ".shortcut.2", pfx + ".shortcut.3", 1e-5)), y, o);
+        return y;
+    }
+    // Upsample = BaseConv 1x1 + BN(1e-3) + ReLU, bilinear x2 align_corners (ghostdualfpn.py:28-39); writes into `dst`
+    void upsample(const std::string& pfx, const A& x, const A& dst) {
+        Lin l = conv_bn(pfx + ".upsample.0.conv", pfx + ".upsample.0.bn", 1e-3);
+        A t = alloc(x.B, x.H, x.W, l.N);
+        GemmOpt o; o.act = ACT_RELU;
+        gemm(pfx + ".conv", x, pack(l), t, o);
+        UpParams p{t.p, t.ld, dst.p, dst.ld, x.B, x.H, x.W, l.N};
+        ew(pfx + ".bilinear", upsample2x_kernel<T>, p, long(x.B) * x.H * 2 * x.W * 2 * (l.N / 4), 5.0 * x.rows() * l.N * sizeof(T));
+    }
+    // the two ShuffleAttention modules that open the decoders, on their common input (shuffle_attention.py:48-72, G = 4)
+    void shuffle_attention_pair(const std::string& pfx0, const std::string& pfx1, const A& x, A& y0, A& y1) {
+        float* partial = nullptr;
+        const int S = stats(pfx0 + ".stats", x, partial);
+        float* coef = alloc_f32(size_t(2) * x.B * x.C * 2);
+        SaCoefParams pc;
+        std::memset(&pc, 0, sizeof(pc));
+        pc.partial = partial; pc.S = S; pc.coef = coef; pc.B = x.B; pc.C = x.C; pc.G = 4; pc.HW = x.H * x.W; pc.eps = 1e-5f;
+        const std::string* pf[2] = {&pfx0, &pfx1};
+        for (int m = 0; m < 2; ++m)
+            pc.w[m] = SaWeights{up_f32(W(*pf[m] + ".cweight").data), up_f32(W(*pf[m] + ".cbias").data), up_f32(W(*pf[m] + ".sweight").data),
+                                up_f32(W(*pf[m] + ".sbias").data), up_f32(W(*pf[m] + ".gn.weight").data), up_f32(W(*pf[m] + ".gn.bias").data)};
+        ew(pfx0 + ".coef", sa_coef_kernel, pc, long(2) * x.B * x.C);
+        y0 = alloc(x.B, x.H, x.W, x.C);
+        y1 = alloc(x.B, x.H, x.W, x.C);
+        SaApplyParams pa{x.p, x.ld, y0.p, y1.p, y0.ld, coef, x.B, x.H * x.W, x.C};
+        ew(pfx0 + ".apply", sa_apply_kernel<T>, pa, x.rows() * x.C, 3.0 * x.rows() * x.C * sizeof(T));
+    }
+    // one decoder level: Upsample (1x1+BN+ReLU, bilinear x2) + GhostModule, restructured (see upghost_kernel):
+    // both 1x1 convs at low resolution on MFMA, then one fused full-resolution kernel.
+    A decoder_level(const std::string& up_pfx, const std::string& ghost_pfx, const A& x, int cout) {
+        Lin lu = conv_bn(up_pfx + ".upsample.0.conv", up_pfx + ".upsample.0.bn", 1e-3);
+        Lin lp = conv_bn(ghost_pfx + ".primary_conv.0", ghost_pfx + ".primary_conv.1", 1e-5);
+        const int Cg = lp.N;
+        if (2 * Cg != cout || Cg % 4 || Cg > UPG_CMAX || lp.K != lu.N) throw AchError{ACH_ERR_UNSUPPORTED, ghost_pfx + ": decoder level widths"};
+        A t;
+        if (!chain2(ghost_pfx + ".lowres_pair", x, lu, ACT_RELU, lp, t)) {
+            A u = alloc(x.B, x.H, x.W, lu.N);
+            { GemmOpt o; o.act = ACT_RELU; gemm(up_pfx + ".conv", x, pack(lu), u, o); }
+            t = alloc(x.B, x.H, x.W, Cg);
+            gemm(ghost_pfx + ".primary_lowres", u, pack(lp), t);
+        }
+        const HostTensor& w = W(ghost_pfx + ".cheap_operation.0.weight");
+        std::vector<float> sc, sh; bn_coeffs(ghost_pfx + ".cheap_operation.1", 1e-5, sc, sh);
+        std::vector<float> wt(size_t(9) * Cg);
+        for (int c = 0; c < Cg; ++c) for (int k = 0; k < 9; ++k) wt[size_t(k) * Cg + c] = w.data[size_t(c) * 9 + k] * sc[c];
+        A y = alloc(x.B, 2 * x.H, 2 * x.W, cout);
+        UpGhostParams p{t.p, t.ld, y.p, y.ld, up_f32(wt), up_f32(sh), x.B, x.H, x.W, Cg};
+        const dim3 grid(unsigned(cdiv(2 * x.W, UPG_TS)) * unsigned(cdiv(2 * x.H, UPG_TS)) * unsigned(x.B)), block(unsigned(16 * Cg));
+        const double bytes = double(t.rows()) * Cg * sizeof(T) + double(y.rows()) * cout * sizeof(T);
+        if (Cg == 16) add_op(ghost_pfx + ".upghost", [p, grid, block](hipStream_t s) { ACH_LAUNCH((upghost_kernel<T, 16>), grid, block, s, p); }, bytes);
+        else if (Cg == 24) add_op(ghost_pfx + ".upghost", [p, grid, block](hipStream_t s) { ACH_LAUNCH((upghost_kernel<T, 24>), grid, block, s, p); }, bytes);
+        else if (Cg == 32) add_op(ghost_pfx + ".upghost", [p, grid, block](hipStream_t s) { ACH_LAUNCH((upghost_kernel<T, 32>), grid, block, s, p); }, bytes);
+        else throw AchError{ACH_ERR_UNSUPPORTED, ghost_pfx + ": Ghost half-width must be 16, 24 or 32"};
+        return y;
+    }
+    // last decoder level (1_to_0) + segmentation head in one full-resolution kernel (upghost_head_kernel)
+    void decoder_last_level(const std::string& up_pfx, const std::string& ghost_pfx, const std::string& head_pfx, const std::string& tap_name,
+                            const A& x, int cout, int oup, void** out) {
+        Lin lu = conv_bn(up_pfx + ".upsample.0.conv", up_pfx + ".upsample.0.bn", 1e-3);
+        Lin lp = conv_bn(ghost_pfx + ".primary_conv.0", ghost_pfx + ".primary_conv.1", 1e-5);
+        const int Cg = lp.N, init = (oup + 1) / 2, nch = oup - init;
+        Lin lh = conv_bn(head_pfx + ".primary_conv.0", head_pfx + ".primary_conv.1", 1e-5);
+        if (Cg != UGH_CG || 2 * Cg != cout || lh.K != cout || lh.N != init || init > UGH_IMAX) throw AchError{ACH_ERR_UNSUPPORTED, head_pfx + ": fused last level expects 16+16 channels"};
+        A t;
+        if (!chain2(ghost_pfx + ".lowres_pair", x, lu, ACT_RELU, lp, t)) {
+            A u = alloc(x.B, x.H, x.W, lu.N);
+            { GemmOpt o; o.act = ACT_RELU; gemm(up_pfx + ".conv", x, pack(lu), u, o); }
+            t = alloc(x.B, x.H, x.W, Cg);
+            gemm(ghost_pfx + ".primary_lowres", u, pack(lp), t);
+        }
+        auto dw_fold = [&](const std::string& pfx, int n, std::vector<float>& wt, std::vector<float>& bias) {
+            const HostTensor& w = W(pfx + ".cheap_operation.0.weight");
+            std::vector<float> sc, sh; bn_coeffs(pfx + ".cheap_operation.1", 1e-5, sc, sh);
+            wt.assign(size_t(9) * std::max(n, 1), 0.f); bias.assign(static_cast<size_t>(std::max(n, 1)), 0.f);
+            for (int c = 0; c < n; ++c) { for (int k = 0; k < 9; ++k) wt[size_t(k) * n + c] = w.data[size_t(c) * 9 + k] * sc[c]; bias[c] = sh[c]; }
+        };
+        std::vector<float> wl, bl, wh2, bh2;
+        dw_fold(ghost_pfx, Cg, wl, bl);
+        dw_fold(head_pfx, nch, wh2, bh2);
+        A f;
+        if (full_taps) { f = alloc(x.B, 2 * x.H, 2 * x.W, cout); tap(tap_name, f); }
+        UpGhostHeadParams p{t.p, t.ld, full_taps ? f.p : nullptr, full_taps ? f.ld : 0, nullptr, up_f32(wl), up_f32(bl), up_f32(lh.w), up_f32(lh.b),
+                            up_f32(wh2), up_f32(bh2), x.B, x.H, x.W, init, nch, oup};
+        const dim3 grid(unsigned(cdiv(2 * x.W, UGH_TW)) * unsigned(cdiv(2 * x.H, UGH_TH)) * unsigned(x.B)), block(256);
+        const double bytes = double(t.rows()) * Cg * sizeof(T) + 4.0 * double(t.rows()) * oup * sizeof(T);
+        add_op(head_pfx + ".upghost_head", [p, grid, block, out](hipStream_t s) mutable { p.out = *out; ACH_LAUNCH(upghost_head_kernel<T>, grid, block, s, p, p.Wdw, p.bdw, p.Wh, p.bh, p.Wdh, p.bdh); }, bytes);
+    }
+
+    A cat_buf[2];                     // concat buffers of the top-down path when the backbone writes its features into them
+    void neck(A m[4], A q[3]) {                                                  // ghostdualfpn.py:156-200
+        const std::string f = "image_radar_encoder.fpn";
+        const int* w = widths();
+        A m3 = m[1], m4 = m[2], m5 = m[3];
+        tap("map2", m[0]); tap("map3", m3); tap("map4", m4); tap("map5", m5);
+        // SPP (spp.py:41-67)
+        const int c_ = w[3] / 2;
+        if (c_ % 4) throw AchError{ACH_ERR_UNSUPPORTED, "SPP hidden width must be a multiple of 4"};
+        A cat5 = alloc(m5.B, m5.H, m5.W, 4 * c_);
+        { GemmOpt o; o.act = ACT_SILU; gemm(f + ".spp.cv1", m5, pack(conv_bn(f + ".spp.cv1.conv", f + ".spp.cv1.bn", 1e-3)), cat5.slice(0, c_), o); }
+        {
+            const int hw = m5.H * m5.W, cq = c_ / 4;
+            if (hw > SPP_TILE) throw AchError{ACH_ERR_UNSUPPORTED, "SPP map larger than the pooling tile"};
+            const int cqb = std::max(1, std::min(cq, SPP_TILE / hw));
+            SppParams sp{cat5.p, cat5.ld, m5.B, m5.H, m5.W, c_, cqb};
+            const dim3 grid(unsigned(m5.B) * unsigned(cdiv(cq, cqb))), block(256);
+            add_op(f + ".spp.pool", [sp, grid, block](hipStream_t s) { ACH_LAUNCH(spp_pool_kernel<T>, grid, block, s, sp); }, 5.0 * double(m5.rows()) * c_ * sizeof(T));
+        }
+        A p5 = alloc(m5.B, m5.H, m5.W, w[3]);
+        { GemmOpt o; o.act = ACT_SILU; gemm(f + ".spp.cv2", cat5, pack(conv_bn(f + ".spp.cv2.conv", f + ".spp.cv2.bn", 1e-3)), p5, o); }
+        tap("spp", p5);
+        // top-down
+        A c4 = cat_buf[1].p ? cat_buf[1] : alloc(m4.B, m4.H, m4.W, 2 * w[2]);
+        upsample(f + ".upsample_5_to_4", p5, c4.slice(0, w[2]));
+        if (m4.p != c4.slice(w[2], w[2]).p) copy(f + ".cat4", m4, c4.slice(w[2], w[2]));      // else: the backbone wrote it in place
+        A p4 = ghost_bottleneck(f + ".ghost_5_to_4", c4, w[2]);
+        A c3 = cat_buf[0].p ? cat_buf[0] : alloc(m3.B, m3.H, m3.W, 2 * w[1]);
+        upsample(f + ".upsample_4_to_3", p4, c3.slice(0, w[1]));
+        if (m3.p != c3.slice(w[1], w[1]).p) copy(f + ".cat3", m3, c3.slice(w[1], w[1]));
+        A p3 = ghost_bottleneck(f + ".ghost_4_to_3", c3, w[1]);
+        tap("fpn4", p4); tap("fpn3", p3);
+        const bool split_dec = split_decoders != 0;
+        // residual FPN outputs (ghostdualfpn.py:200) — computed BEFORE the decoders so that the detection branch (fusion + head,
+        // on the radar stream) can start while the two heavy decoders still run on this stream
+        q[0] = alloc(p3.B, p3.H, p3.W, p3.C); add(f + ".q3", p3, m3, q[0]);
+        q[1] = alloc(p4.B, p4.H, p4.W, p4.C); add(f + ".q4", p4, m4, q[1]);
+        q[2] = alloc(p5.B, p5.H, p5.W, p5.C); add(f + ".q5", p5, m5, q[2]);
+        signal_after_last(1);
+        // two segmentation decoders
+        const char* names[2] = {"lane", "se"};
+        const char* sa[2] = {"stage_3_lane_seg", "stage_3_semantic_seg"};
+        const int oups[2] = {2, cfg.num_seg};
+        void** outs[2] = {&io.lane, &io.se};
+        A ysa[2];
+        shuffle_attention_pair(f + "." + sa[0], f + "." + sa[1], p3, ysa[0], ysa[1]);
+        if (split_dec) signal_after_last(2);   // the semantic decoder may start on its own stream
+        for (int d = 0; d < 2; ++d) {
+            // past the shared attention stage the two decoders are independent: water-line decoder on the caller's stream, semantic
+            // decoder on stream 3 when the option is on
+            if (d == 1 && split_dec) { cur_stream = 3; wait_before_next(2); }
+            const std::string n = names[d];
+            A y = ysa[d];
+            tap(n + ".sa", y);
+            const char* lv[3] = {"3_to_2", "2_to_1", "1_to_0"};
+            const int cw[3] = {w[1], w[0], w[0]};
+            for (int l = 0; l < 2; ++l) {
+                y = decoder_level(f + "." + n + "_seg_" + lv[l], f + "." + n + "_seg_ghost_" + lv[l], y, cw[l]);
+                tap(n + "." + lv[l], y);
+            }
+            decoder_last_level(f + "." + n + "_seg_" + lv[2], f + "." + n + "_seg_ghost_" + lv[2], f + "." + n + "_seg_head", n + "." + lv[2], y, cw[2], oups[d], outs[d]);
+        }
+        cur_stream = 0;
+    }
+    const int* widths() const {
+        static const int w0[4] = {32, 48, 96, 176}, w1[4] = {32, 48, 120, 224}, w2[4] = {32, 64, 144, 288};
+        return cfg.phi == ACH_PHI_S0 ? w0 : (cfg.phi == ACH_PHI_S1 ? w1 : w2);
+    }
+
+    // ------------------------------------------------------------------------------------------ radar (a14-a15)
+    // dense k x k conv weight [Co][Ci][k][k] -> implicit-GEMM matrix with K ordered (tap, channel) over Cp channels per tap
+    Lin conv_lin(const std::string& wkey, const std::string& bkey, int Ci, int Cp, int k) const {
+        const HostTensor& w = W(wkey);
+        const int Co = int(w.shape[0]);
+        if (w.numel() != long(Co) * Ci * k * k) throw AchError{ACH_ERR_MISSING_KEY, "conv weight shape: " + wkey};
+        Lin l; l.N = Co; l.K = k * k * Cp; l.w.assign(size_t(Co) * l.K, 0.f);
+        for (int o = 0; o < Co; ++o)
+            for (int c = 0; c < Ci; ++c)
+                for (int t = 0; t < k * k; ++t) l.w[size_t(o) * l.K + size_t(t) * Cp + c] = w.data[(size_t(o) * Ci + c) * k * k + t];
+        if (!bkey.empty() && hasW(bkey)) l.b = W(bkey).data; else l.b.assign(size_t(Co), 0.f);
+        return l;
+    }
+    A conv_gemm(const std::string& name, const A& x, const Lin& l, int k, int stride, int act, const A* residual = nullptr) {
+        const int pad = k / 2;
+        const int Ho = (x.H + 2 * pad - k) / stride + 1, Wo = (x.W + 2 * pad - k) / stride + 1;
+        A y = alloc(x.B, Ho, Wo, l.N);
+        GemmOpt o; o.act = act; o.residual = residual;
+        o.conv_k = k; o.conv_s = stride; o.conv_p = pad; o.Hin = x.H; o.Win = x.W; o.Cin = int(x.ld); o.Ho = Ho; o.Wo = Wo;
+        gemm(name, x.p, x.ld, y.rows(), pack(l), y.p, y.ld, o);
+        return y;
+    }
+    // NHWC tensor with a one-pixel zero border around every sample (the arena is zeroed when the plan is built and the border is
+    // never written): p0 = pixel (0,0) of sample 0
+    struct Bordered { T* p0 = nullptr; T* base = nullptr; int B = 0, H = 0, W = 0, C = 0; long ld = 0, row = 0, img = 0; };
+    Bordered alloc_bordered(int B, int H, int W, int C) {
+        Bordered t; t.B = B; t.H = H; t.W = W; t.C = C; t.ld = round_up(C, 8);
+        t.row = long(W + 2) * t.ld; t.img = long(H + 2) * t.row;
+        t.base = static_cast<T*>(aalloc(size_t(B) * t.img * sizeof(T)));
+        t.p0 = t.base + t.row + t.ld;
+        return t;
+    }
+    // 3x3 / pad 1 conv (stride 1 or 2) of a bordered tensor with up to 32 outputs: the offset + modulator convs and the
+    // stride-2 weight_conv2 of the RCBlocks (k_conv3.h); anything else goes to the generic implicit GEMM
+    A conv3_bordered(const std::string& name, const Bordered& x, const Lin& l, int act, int stride = 1) {
+        const int Ho = (x.H - 1) / stride + 1, Wo = (x.W - 1) / stride + 1;
+        A y = alloc(x.B, Ho, Wo, l.N);
+        const int cv = int(x.ld) / VEC, ks = cdiv(9 * cv, 4);
+        Packed pk = pack(l);
+        const double bytes = double(x.B) * x.H * x.W * x.ld * sizeof(T) + double(y.rows()) * y.ld * sizeof(T);
+        const bool shape_ok = (pk.NT == 2 && y.ld == 32) || (pk.NT == 1 && stride == 2 && y.ld <= 16);
+        if (row_conv && shape_ok && (ks == 3 || ks == 5 || ks == 9) && pk.nchunks == 1 && pk.ksteps == ks) {
+            std::vector<float> b32(32, 0.f);
+            for (int n = 0; n < l.N; ++n) b32[n] = l.b[n];
+            Conv3Params cp{x.p0, x.ld, x.row, x.img, y.p, y.ld, pk.w, up_f32(b32), x.B, Ho, Wo, cv, act};
+            const int NT = pk.NT;
+            add_op(name, [cp, ks, NT, stride](hipStream_t s) { launch_conv3<T>(cp, ks, NT, stride, s); }, bytes, 2.0 * double(y.rows()) * l.K * l.N);
+            return y;
+        }
+        // generic implicit GEMM: the bordered buffer is a dense [B, H+2, W+2, ld] tensor convolved without padding
+        GemmOpt o; o.act = act;
+        o.conv_k = 3; o.conv_s = stride; o.conv_p = 0; o.Hin = x.H + 2; o.Win = x.W + 2; o.Cin = int(x.ld); o.Ho = Ho; o.Wo = Wo;
+        gemm(name, x.base, x.ld, y.rows(), pk, y.p, y.ld, o);
+        return y;
+    }
+    void rcnet(A outs[3]) {                                                      // RadarEncoder.py:38-109
+        const int* w = widths();
+        const int chans[9] = {3, w[0] / 4, w[0] / 4, w[0] / 4, w[1] / 4, w[1] / 4, w[2] / 4, w[2] / 4, w[3] / 4};
+        const bool down[8] = {true, true, false, true, false, true, false, true};
+        const int B = batch, R = cfg.resolution;
+        A x = alloc(B, R, R, 3);
+        {
+            ToNhwcParams tp{nullptr, x.p, B, 3, R, R, x.ld};
+            const dim3 grid(unsigned(cdivl(x.rows(), 256))), block(256);
+            const void** rin = &io.radar;
+            add_op("image_radar_encoder.radar_encoder.to_nhwc", [tp, grid, block, rin](hipStream_t s) mutable { tp.X = *rin; ACH_LAUNCH(nchw_to_nhwc_kernel<T>, grid, block, s, tp); },
+                   double(x.rows()) * (3 + x.ld) * sizeof(T));
+        }
+        for (int i = 0; i < 8; ++i) {
+            const std::string pfx = "image_radar_encoder.radar_encoder.rc_blocks." + std::to_string(i);
+            const std::string d = pfx + ".radar_conv.deformable_conv";
+            const int C = chans[i], Cp = int(x.ld);
+            // AvgPool2d(3,1,1)
+            Bordered pooled = alloc_bordered(B, x.H, x.W, C);
+            { PoolParams pp{x.p, x.ld, pooled.p0, pooled.ld, B, x.H, x.W, C, pooled.row, pooled.img}; ew(pfx + ".avgpool", avgpool3x3_kernel<T>, pp, x.rows() * ((C + 3) / 4), 2.0 * x.rows() * Cp * sizeof(T)); }
+            // offset_conv (18) + modulator_conv (9) as one implicit GEMM
+            Lin lo = conv_lin(d + ".offset_conv.weight", d + ".offset_conv.bias", C, Cp, 3);
+            Lin lm = conv_lin(d + ".modulator_conv.weight", d + ".modulator_conv.bias", C, Cp, 3);
+            if (lo.N != 18 || lm.N != 9) throw AchError{ACH_ERR_MISSING_KEY, "deformable conv shapes at " + d};
+            Lin lom; lom.N = 27; lom.K = lo.K; lom.w = lo.w; lom.w.insert(lom.w.end(), lm.w.begin(), lm.w.end()); lom.b = lo.b; lom.b.insert(lom.b.end(), lm.b.begin(), lm.b.end());
+            const int cvp = int(pooled.ld) / VEC, ksp = cdiv(9 * cvp, 4);
+            const bool fused_front = fuse_rc && C <= 16 && (ksp == 3 || ksp == 5 || ksp == 9);
+            A om;
+            if (!fused_front) om = conv3_bordered(pfx + ".offmask", pooled, lom, ACT_NONE);
+            // regular_conv (no bias) folded with weight_conv1 (bias) and BatchNorm:  Wf[co][k][c] = sum_m W1'[co][m] Wd3[m][c][k]
+            std::vector<float> sc, sh; bn_coeffs(pfx + ".norm", 1e-5, sc, sh);
+            const HostTensor& w1 = W(pfx + ".weight_conv1.weight"); const HostTensor& b1 = W(pfx + ".weight_conv1.bias");
+            const HostTensor& w3 = W(d + ".regular_conv.weight");
+            if (w3.numel() != long(C) * C * 9 || w1.numel() != long(C) * C) throw AchError{ACH_ERR_MISSING_KEY, "radar block shapes at " + pfx};
+            Lin lf; lf.N = C; lf.K = 9 * Cp; lf.w.assign(size_t(C) * lf.K, 0.f); lf.b.assign(size_t(C), 0.f);
+            for (int co = 0; co < C; ++co) {
+                lf.b[co] = b1.data[co] * sc[co] + sh[co];
+                for (int c = 0; c < C; ++c)
+                    for (int k = 0; k < 9; ++k) {
+                        double acc = 0;
+                        for (int m = 0; m < C; ++m) acc += double(w1.data[size_t(co) * C + m]) * sc[co] * w3.data[(size_t(m) * C + c) * 9 + k];
+                        lf.w[size_t(co) * lf.K + size_t(k) * Cp + c] = float(acc);
+                    }
+            }
+            A y;
+            Bordered yb;
+            bool y_bordered = false;
+            if (fused_front) {           // conv + sampling + folded contraction + ReLU + residual as one launch (k_conv3.h)
+                Packed pkom = pack(lom), pkf = pack(lf);
+                if (pkom.NT != 2 || pkom.nchunks != 1 || pkom.ksteps != ksp || pkf.NT != 1 || pkf.nchunks != 1 || pkf.ksteps != ksp)
+                    throw AchError{ACH_ERR_UNSUPPORTED, "radar block packing at " + pfx};
+                std::vector<float> b32(32, 0.f), b16(16, 0.f);
+                for (int n = 0; n < 27; ++n) b32[n] = lom.b[n];
+                for (int n = 0; n < C; ++n) b16[n] = lf.b[n];
+                if (down[i] && row_conv) {            // the stride-2 weight_conv2 reads it through the row-walking kernel: zero border
+                    yb = alloc_bordered(B, x.H, x.W, C);
+                    y_bordered = true;
+                } else {
+                    y = alloc(B, x.H, x.W, C);
+                }
+                const long yld = y_bordered ? yb.ld : y.ld;
+                RcFrontParams rp{pooled.p0, pooled.ld, pooled.row, pooled.img, pkom.w, up_f32(b32), pkf.w, up_f32(b16), x.p, x.ld,
+                                 y_bordered ? yb.p0 : y.p, yld, y_bordered ? yb.row : long(x.W) * y.ld, y_bordered ? yb.img : long(x.H) * x.W * y.ld,
+                                 B, x.H, x.W, cvp, C};
+                const double bytes = double(x.rows()) * (pooled.ld + x.ld + yld) * sizeof(T);
+                add_op(pfx + ".front", [rp, ksp](hipStream_t s) { launch_rc_front<T>(rp, ksp, s); }, bytes,
+                       2.0 * double(x.rows()) * 9.0 * Cp * (27 + C));
+            } else {
+            DeformParams dp;
+            std::memset(&dp, 0, sizeof(dp));
+            dp.pooled = pooled.p0; dp.ldp = pooled.ld; dp.prow = pooled.row; dp.pimg = pooled.img; dp.om = om.p; dp.ldo = om.ld; dp.res = x.p; dp.ldr = x.ld;
+            dp.B = B; dp.H = x.H; dp.Wd = x.W; dp.Cp = Cp;
+            if (Cp == 8 && (C == 3 || C == 8)) {
+                y = alloc(B, x.H, x.W, C);
+                dp.Y = y.p; dp.ldy = y.ld; dp.Wf = up_f32(lf.w); dp.bf = up_f32(lf.b);
+                const dim3 grid(unsigned(cdivl(x.rows(), 256))), block(256);
+                const double bytes = double(x.rows()) * (3.0 * Cp + 32) * sizeof(T);
+                if (C == 3) add_op(pfx + ".deform", [dp, grid, block](hipStream_t s) { ACH_LAUNCH((deform_fused_kernel<T, 3, 4>), grid, block, s, dp, dp.Wf, dp.bf); }, bytes);   // 3 channels: one 4-vector per corner
+                else add_op(pfx + ".deform", [dp, grid, block](hipStream_t s) { ACH_LAUNCH((deform_fused_kernel<T, 8, 8>), grid, block, s, dp, dp.Wf, dp.bf); }, bytes);
+            } else {
+                A col = alloc(B, x.H, x.W, 9 * Cp);
+                dp.Y = col.p; dp.ldy = col.ld;
+                ew(pfx + ".deform.sample", deform_sample_kernel<T>, dp, x.rows() * 9 * (Cp / 4), double(x.rows()) * (10.0 * Cp + 32) * sizeof(T));
+                y = alloc(B, x.H, x.W, C);
+                GemmOpt o; o.act = ACT_RELU; o.residual = &x;            // epilogue order: act, then + residual
+                gemm(pfx + ".deform.contract", col, pack(lf), y, o);
+            }
+            }
+            // weight_conv2: 1x1, or 3x3 stride 2
+            const int k = down[i] ? 3 : 1;
+            if (y_bordered) x = conv3_bordered(pfx + ".conv2", yb, conv_lin(pfx + ".weight_conv2.weight", pfx + ".weight_conv2.bias", C, int(yb.ld), 3), ACT_NONE, 2);
+            else x = conv_gemm(pfx + ".conv2", y, conv_lin(pfx + ".weight_conv2.weight", pfx + ".weight_conv2.bias", C, int(y.ld), k), k, down[i] ? 2 : 1, ACT_NONE);
+            if (x.C != chans[i + 1]) throw AchError{ACH_ERR_MISSING_KEY, "radar width mismatch at " + pfx};
+            tap("radar.b" + std::to_string(i), x);
+            if (i == 3) outs[0] = x;
+            if (i == 5) outs[1] = x;
+            if (i == 7) outs[2] = x;
+        }
+        tap("r3", outs[0]); tap("r4", outs[1]); tap("r5", outs[2]);
+    }
+
+    // ------------------------------------------------------------------------------------------ fusion (a16)
+    // ECA channel attention + BatchNorm + ReLU on cat(image level, radar level) for the three pyramid levels (IREncoder.py:79-89).
+    // The six (level, source) jobs are independent: three launches in total — statistics, ECA scales, scaled write — each
+    // covering all six (Multi6 in k_nhwc.h), instead of eighteen small ones.
+    void fuse_all(const A img[3], const A rad[3], A out[3]) {
+        const std::string e = "image_radar_encoder";
+        Multi6<StatParams> ms; Multi6<EcaParams> me; Multi6<FuseParams> mf;
+        std::memset(&ms, 0, sizeof(ms)); std::memset(&me, 0, sizeof(me)); std::memset(&mf, 0, sizeof(mf));
+        int n = 0, smax = 1;
+        long eca_max = 0, fuse_max = 0;
+        double bytes = 0;
+        for (int l = 0; l < 3; ++l) {
+            const std::string st = std::to_string(3 + l);
+            const int Ci = img[l].C, Cr = rad[l].C, HW = img[l].H * img[l].W;
+            std::vector<float> sc, sh; bn_coeffs(e + ".norm_stage" + st, 1e-5, sc, sh);
+            if (int(sc.size()) != Ci + Cr) throw AchError{ACH_ERR_MISSING_KEY, "fusion norm width"};
+            out[l] = alloc(img[l].B, img[l].H, img[l].W, Ci + Cr);
+            const A srcs[2] = {img[l], rad[l]};
+            int coff = 0;
+            for (int h = 0; h < 2; ++h, ++n) {
+                const A& x = srcs[h];
+                const int S = HW >= 1024 ? 8 : (HW >= 256 ? 4 : 1);
+                float* part = alloc_f32(size_t(x.B) * S * 2 * x.C);
+                ms.j[n] = StatParams{x.p, x.ld, part, HW, x.C, S};
+                smax = std::max(smax, S);
+                const HostTensor& wk = W(e + ".channel_attn_stage" + st + "." + std::to_string(h) + ".conv.weight");
+                float* scl = alloc_f32(size_t(x.B) * x.C);
+                me.j[n] = EcaParams{part, S, up_f32(wk.data), int(wk.numel()), up_f32(std::vector<float>(sc.begin() + coff, sc.begin() + coff + x.C)), scl, x.B, x.C, HW};
+                eca_max = std::max(eca_max, long(x.B) * x.C);
+                A ys = out[l].slice(coff, x.C);
+                mf.j[n] = FuseParams{x.p, x.ld, 0, ys.p, ys.ld, scl, up_f32(std::vector<float>(sh.begin() + coff, sh.begin() + coff + x.C)), x.B, HW, x.C};
+                fuse_max = std::max(fuse_max, cdivl(x.rows() * x.C, 4));        // 4 channels per thread
+                bytes += 2.0 * x.rows() * x.C * sizeof(T);
+                coff += x.C;
+            }
+            tap("p" + st, out[l]);
+        }
+        ms.n = me.n = mf.n = n;
+        {
+            const dim3 grid(unsigned(img[0].B), unsigned(smax), unsigned(n)), block(256);
+            add_op(e + ".fusion.stats", [ms, grid, block](hipStream_t s) { ACH_LAUNCH(chan_stats_multi_kernel<T>, grid, block, s, ms); }, bytes / 2);
+        }
+        {
+            const dim3 grid(unsigned(cdivl(eca_max, 256)), unsigned(n)), block(256);
+            add_op(e + ".fusion.eca", [me, grid, block](hipStream_t s) { ACH_LAUNCH(eca_scale_multi_kernel, grid, block, s, me); });
+        }
+        {
+            const dim3 grid(unsigned(cdivl(fuse_max, 256)), unsigned(n)), block(256);
+            add_op(e + ".fusion.apply", [mf, grid, block](hipStream_t s) { ACH_LAUNCH(fuse_scale_multi_kernel<T>, grid, block, s, mf); }, bytes);
+        }
+    }
+
+    // ------------------------------------------------------------------------------------------ head (a17)
+    // The cls and reg branches (2 x [dw5x5 -> pw1x1+BN+ReLU]) read the same stem output and never interact, so they are run as
+    // ONE 128-channel branch: depthwise filters of both banks side by side (the first over the shared 64-channel input), the
+    // pointwise convs as block-diagonal 128x128 GEMMs, and the three prediction convs as one 12 x 128 GEMM scattered straight
+    // into the NCHW output map [reg 4 | obj 1 | cls num_det].  6 launches per level instead of 11, twice the work per launch on
+    // the small maps where the head is latency-bound.
+    void head(A p[3]) {                                                          // decouplehead.py:58-103
+        const int NC5 = 5 + cfg.num_det;
+        batching = head_batch;          // the same six layers on three maps: one launch per layer for all levels (flush_batch)
+        batch_jobs.clear();
+        for (int k = 0; k < 3; ++k) {
+            const std::string ks = std::to_string(k);
+            const A& x = p[k];
+            const int HW = x.H * x.W;
+            Lin ls = conv_bn("det_head.stems." + ks + ".conv", "det_head.stems." + ks + ".bn", 1e-3);
+            const int base = ls.N;
+            A cur = alloc(x.B, x.H, x.W, base);
+            { GemmOpt o; o.act = ACT_RELU; gemm("det_head.stems." + ks, x, pack(ls), cur, o); }
+            for (int j = 0; j < 2; ++j) {
+                const std::string js = std::to_string(j);
+                const std::string c = "det_head.cls_convs." + ks + "." + js, r = "det_head.reg_convs." + ks + "." + js;
+                // depthwise 5x5, both banks: out[0:base] = cls filters, out[base:2base] = reg filters
+                const HostTensor& wc = W(c + ".conv.dconv.weight"); const HostTensor& wr = W(r + ".conv.dconv.weight");
+                if (wc.numel() != long(base) * 25 || wr.numel() != long(base) * 25) throw AchError{ACH_ERR_MISSING_KEY, "head depthwise shape"};
+                std::vector<float> wt(size_t(25) * 2 * base), bias(size_t(2) * base, 0.f);
+                for (int ch = 0; ch < base; ++ch)
+                    for (int t = 0; t < 25; ++t) { wt[size_t(t) * 2 * base + ch] = wc.data[size_t(ch) * 25 + t]; wt[size_t(t) * 2 * base + base + ch] = wr.data[size_t(ch) * 25 + t]; }
+                A d = alloc(x.B, x.H, x.W, 2 * base);
+                DwParams dp;
+                std::memset(&dp, 0, sizeof(dp));
+                dp.X = cur.p; dp.ldx = cur.ld; dp.W = up_f32(wt); dp.bias = up_f32(bias); dp.Y = d.p; dp.ldy = d.ld;
+                dp.B = x.B; dp.H = x.H; dp.Wd = x.W; dp.C = 2 * base; dp.Ho = x.H; dp.Wo = x.W; dp.stride = 1; dp.act = ACT_NONE;
+                dp.cin_mod = (j == 0) ? base : 0;
+                dp.tile = (dw_tile && x.H * x.W <= 144) ? 1 : 0;
+                if (batching) {
+                    BatchJob bj; bj.kind = 1; bj.name = "det_head.convs." + ks + "." + js + ".dconv"; bj.d = dp; bj.ks = 5;
+                    bj.bytes = double(cur.rows()) * cur.C * sizeof(T) + double(d.rows()) * d.C * sizeof(T);
+                    batch_jobs.push_back(bj);
+                } else
+                add_op("det_head.convs." + ks + "." + js + ".dconv", [dp](hipStream_t s) { launch_dwconv<T>(dp, 5, s); },
+                       double(cur.rows()) * cur.C * sizeof(T) + double(d.rows()) * d.C * sizeof(T));
+                // pointwise, block diagonal
+                Lin lc = conv_bn(c + ".conv.pconv", c + ".bn", 1e-3), lr = conv_bn(r + ".conv.pconv", r + ".bn", 1e-3);
+                Lin lb; lb.N = 2 * base; lb.K = 2 * base; lb.w.assign(size_t(lb.N) * lb.K, 0.f); lb.b = lc.b; lb.b.insert(lb.b.end(), lr.b.begin(), lr.b.end());
+                for (int n = 0; n < base; ++n)
+                    for (int kk = 0; kk < base; ++kk) { lb.w[size_t(n) * lb.K + kk] = lc.w[size_t(n) * base + kk]; lb.w[size_t(base + n) * lb.K + base + kk] = lr.w[size_t(n) * base + kk]; }
+                A y = alloc(x.B, x.H, x.W, 2 * base);
+                GemmOpt o; o.act = ACT_RELU;
+                gemm("det_head.convs." + ks + "." + js + ".pconv", d, pack(lb), y, o);
+                cur = y;
+            }
+            // predictions: rows [reg 4 | obj 1] read the reg half, rows [cls] read the cls half
+            Lin lreg = lin("det_head.reg_preds." + ks + ".weight", "det_head.reg_preds." + ks + ".bias");
+            Lin lobj = lin("det_head.obj_preds." + ks + ".weight", "det_head.obj_preds." + ks + ".bias");
+            Lin lcls = lin("det_head.cls_preds." + ks + ".weight", "det_head.cls_preds." + ks + ".bias");
+            Lin lp; lp.N = NC5; lp.K = 2 * base; lp.w.assign(size_t(NC5) * lp.K, 0.f); lp.b.assign(size_t(NC5), 0.f);
+            for (int n = 0; n < 4; ++n) { lp.b[n] = lreg.b[n]; for (int kk = 0; kk < base; ++kk) lp.w[size_t(n) * lp.K + base + kk] = lreg.w[size_t(n) * base + kk]; }
+            lp.b[4] = lobj.b[0];
+            for (int kk = 0; kk < base; ++kk) lp.w[size_t(4) * lp.K + base + kk] = lobj.w[kk];
+            for (int n = 0; n < cfg.num_det; ++n) { lp.b[5 + n] = lcls.b[n]; for (int kk = 0; kk < base; ++kk) lp.w[size_t(5 + n) * lp.K + kk] = lcls.w[size_t(n) * base + kk]; }
+            GemmOpt o1; o1.ydyn = &io.det[k]; o1.out_nchw = 1; o1.HW = HW; o1.Ctot = NC5; o1.coff = 0;
+            gemm("det_head.preds." + ks, cur.p, cur.ld, cur.rows(), pack(lp), nullptr, 0, o1);
+        }
+        if (batching) flush_batch(3, 6);
+    }
+
+    // ------------------------------------------------------------------------------------------ PointNet (a18)
+    struct Rows { T* p = nullptr; long rows = 0; int C = 0; long ld = 0; };
+    Rows alloc_rows(long rows, int C) { Rows r; r.rows = rows; r.C = C; r.ld = round_up(C, 8); r.p = static_cast<T*>(aalloc(size_t(rows) * r.ld * sizeof(T))); return r; }
+    Lin lin_bn1d(const std::string& conv, const std::string& bn) const { Lin l = lin(conv + ".weight", conv + ".bias"); if (!bn.empty()) fold_bn(l, bn, 1e-5); return l; }
+    Rows pc_layer(const std::string& name, const Rows& x, const Lin& l, int act) {
+        Rows y = alloc_rows(x.rows, l.N);
+        GemmOpt o; o.act = act;
+        gemm(name, x.p, x.ld, x.rows, pack(l), y.p, y.ld, o);
+        return y;
+    }
+    // shared MLP + max over the N points of every sample -> [B, C]   (gemm_colmax_kernel: no atomics, nothing materialised)
+    Rows pc_layer_max(const std::string& name, const Rows& x, const Lin& l, int act, int B) {
+        Packed pk = pack(l);
+        Rows y = alloc_rows(B, l.N);
+        GemmMaxParams g{x.p, x.ld, pk.w, pk.b, y.p, y.ld, int(x.rows / B), B, pk.K, pk.N, pk.nchunks, pk.ksteps, act};
+        const dim3 grid(unsigned(pk.nchunks), unsigned(B)), block(256);
+        const int NT = pk.NT;
+        const double bytes = double(x.rows) * pk.K * sizeof(T) + double(pk.group_elems) * sizeof(T) + double(B) * pk.N * sizeof(T);
+        add_op(name, [g, grid, block, NT](hipStream_t s) {
+            if (NT == 1) ACH_LAUNCH((gemm_colmax_kernel<T, 1, 0>), grid, block, s, g);
+            else if (NT == 2) ACH_LAUNCH((gemm_colmax_kernel<T, 2, 0>), grid, block, s, g);
+            else if (g.ksteps == 4) ACH_LAUNCH((gemm_colmax_kernel<T, 4, 4>), grid, block, s, g);     // weights register-resident
+            else if (g.ksteps == 8) ACH_LAUNCH((gemm_colmax_kernel<T, 4, 8>), grid, block, s, g);
+            else ACH_LAUNCH((gemm_colmax_kernel<T, 4, 0>), grid, block, s, g);
+        }, bytes, 2.0 * double(x.rows) * pk.K * pk.N);
+        return y;
+    }
+    Rows stn(const std::string& pfx, const Rows& x, int B) {                     // pointnet_utils.py:27-45,67-85 (without + I)
+        Rows h = pc_layer(pfx + ".conv1", x, lin_bn1d(pfx + ".conv1", pfx + ".bn1"), ACT_RELU);
+        h = pc_layer(pfx + ".conv2", h, lin_bn1d(pfx + ".conv2", pfx + ".bn2"), ACT_RELU);
+        Rows g = pc_layer_max(pfx + ".conv3", h, lin_bn1d(pfx + ".conv3", pfx + ".bn3"), ACT_RELU, B);
+        // (a one-workgroup-per-sample fusion of the three FC layers was measured 4-6x SLOWER than three small GEMM launches:
+        //  64 workgroups cannot hide the weight-row latency; the N-chunk split of the GEMM spreads each layer over the chip)
+        g = pc_layer(pfx + ".fc1", g, lin_bn1d(pfx + ".fc1", pfx + ".bn4"), ACT_RELU);
+        g = pc_layer(pfx + ".fc2", g, lin_bn1d(pfx + ".fc2", pfx + ".bn5"), ACT_RELU);
+        return pc_layer(pfx + ".fc3", g, lin_bn1d(pfx + ".fc3", ""), ACT_NONE);
+    }
+    void pointnet() {                                                            // pointnet_sem_seg.py:26-37
+        const std::string p = "pc_seg_model";
+        const int B = batch, N = cfg.num_points, D = cfg.pc_channels;
+        if (N % 16) throw AchError{ACH_ERR_UNSUPPORTED, "num_points must be a multiple of 16"};
+        Rows x0 = alloc_rows(long(B) * N, D);
+        {
+            PcPrepParams pp{nullptr, x0.p, B, D, N, x0.ld};
+            const dim3 grid(unsigned(cdivl(long(B) * N * x0.ld, 256))), block(256);
+            const void** pin = &io.points;
+            add_op(p + ".prep", [pp, grid, block, pin](hipStream_t s) mutable { pp.X = *pin; ACH_LAUNCH(pc_prep_kernel<T>, grid, block, s, pp); });
+        }
+        Rows t9 = stn(p + ".feat.stn", x0, B);
+        { TapInfo t; t.ptr = t9.p; t.kind = 2; t.B = B; t.H = 1; t.W = 1; t.C = 9; t.ld = t9.ld; t.add_eye = 3; add_tap("pc.trans", t); }
+        Rows x1 = alloc_rows(long(B) * N, D);
+        { PcT3Params q{x0.p, x0.ld, t9.p, t9.ld, x1.p, x1.ld, B, N, D}; ew(p + ".feat.apply_t3", pc_apply_t3_kernel<T>, q, long(B) * N); }
+        Rows f1 = pc_layer(p + ".feat.conv1", x1, lin_bn1d(p + ".feat.conv1", p + ".feat.bn1"), ACT_RELU);
+        const int kf = f1.C;                                                     // 32
+        Rows tf = stn(p + ".feat.fstn", f1, B);
+        { TapInfo t; t.ptr = tf.p; t.kind = 2; t.B = B; t.H = 1; t.W = 1; t.C = kf * kf; t.ld = tf.ld; t.add_eye = kf; add_tap("pc.trans_feat", t); }
+        // per-sample kf x kf transform as packed MFMA weights
+        Packed pk = pack_shape(kf, kf);
+        T* wp = static_cast<T*>(aalloc(size_t(B) * pk.group_elems * sizeof(T)));
+        pk.b = up_f32(std::vector<float>(static_cast<size_t>(kf), 0.f));
+        { PcPackParams q{tf.p, tf.ld, wp, pk.group_elems, B, kf, pk.NT, pk.ksteps}; ew(p + ".feat.pack_tf", pc_pack_transform_kernel<T>, q, long(B) * kf * kf); }
+        Rows pf = alloc_rows(long(B) * N, kf);
+        { GemmOpt o; o.groups = B; o.w_group_stride = pk.group_elems; o.w_override = wp; gemm(p + ".feat.bmm_tf", f1.p, f1.ld, f1.rows, pk, pf.p, pf.ld, o); }
+        Rows h = pc_layer(p + ".feat.conv2", pf, lin_bn1d(p + ".feat.conv2", p + ".feat.bn2"), ACT_RELU);
+        Rows g = pc_layer_max(p + ".feat.conv3", h, lin_bn1d(p + ".feat.conv3", p + ".feat.bn3"), ACT_NONE, B);
+        { TapInfo t; t.ptr = g.p; t.kind = 2; t.B = B; t.H = 1; t.W = 1; t.C = g.C; t.ld = g.ld; add_tap("pc.global", t); }
+        Rows cat = alloc_rows(long(B) * N, g.C + kf);
+        { PcConcatParams q{g.p, g.ld, pf.p, pf.ld, cat.p, cat.ld, B, N, g.C, kf}; ew(p + ".concat", pc_concat_kernel<T>, q, long(B) * N * (g.C + kf)); }
+        Rows y = pc_layer(p + ".conv1", cat, lin_bn1d(p + ".conv1", p + ".bn1"), ACT_RELU);
+        y = pc_layer(p + ".conv2", y, lin_bn1d(p + ".conv2", p + ".bn2"), ACT_RELU);
+        y = pc_layer(p + ".conv3", y, lin_bn1d(p + ".conv3", p + ".bn3"), ACT_RELU);
+        y = pc_layer(p + ".conv4", y, lin_bn1d(p + ".conv4", ""), ACT_NONE);
+        {
+            LsmParams q{y.p, y.ld, nullptr, long(B) * N, cfg.pc_classes};
+            const dim3 grid(unsigned(cdivl(long(B) * N, 256))), block(256);
+            void** out = &io.pc;
+            add_op(p + ".log_softmax", [q, grid, block, out](hipStream_t s) mutable { q.Y = *out; ACH_LAUNCH(log_softmax_kernel<T>, grid, block, s, q); });
+        }
+    }
+
+    // ------------------------------------------------------------------------------------------ plan (a1)
+    void build() {
+        if (cfg.resolution % 32 || cfg.resolution < 64) throw AchError{ACH_ERR_INVALID, "resolution must be a multiple of 32"};
+        // enqueue order = plan order: the two side branches first, so they are already running while the (longest) image
+        // path is being enqueued on the caller's stream
+        A r[3];
+        cur_stream = 1;
+        rcnet(r);
+        cur_stream = 2;
+        pointnet();
+        cur_stream = 0;
+        A m[4];
+        cat_buf[0] = A(); cat_buf[1] = A();
+        if (cfg.backbone == ACH_BACKBONE_EDGENEXT) {
+            // stage 1 / stage 2 outputs go straight into the second half of the neck's concat buffers (no cat copy)
+            const int* wd = widths();
+            const int R = cfg.resolution;
+            cat_buf[0] = alloc(batch, R / 8, R / 8, 2 * wd[1]);
+            cat_buf[1] = alloc(batch, R / 16, R / 16, 2 * wd[2]);
+            const A d1 = cat_buf[0].slice(wd[1], wd[1]), d2 = cat_buf[1].slice(wd[2], wd[2]);
+            const A* dst[4] = {nullptr, &d1, &d2, nullptr};
+            edgenext("image_radar_encoder.fpn.backbone", m, dst);
+        }
+        else mobilevit("image_radar_encoder.fpn.backbone", m);
+        A q[3];
+        neck(m, q);
+        tap("q3", q[0]); tap("q4", q[1]); tap("q5", q[2]);
+        // detection branch: fusion + head continue on the RADAR stream (in order after the radar taps), gated only on the FPN
+        // outputs (event 1) — they overlap with the segmentation decoders that keep the caller's stream busy
+        cur_stream = 1;
+        wait_before_next(1);
+        A p[3];
+        fuse_all(q, r, p);
+        head(p);
+        cur_stream = 0;
+        interleave_streams();
+    }
+
+    // Host enqueue order = plan order.  Built branch by branch, the plan would enqueue all ~65 radar launches before the first
+    // image-path launch, delaying the critical path by the host cost of those launches (measured: the image path started 1.5 ms
+    // late under rocprofv3).  Merge the per-stream sequences proportionally instead, keeping each stream's own order and never
+    // placing a wait before the launch that signals its event.
+    void interleave_streams() {
+        if (measuring || ops.size() < 2) return;
+        std::vector<std::vector<Op>> seq(1 + kSideStreams);
+        for (auto& op : ops) seq[size_t(op.stream)].push_back(std::move(op));
+        const size_t total = ops.size();
+        ops.clear();
+        std::vector<size_t> pos(seq.size(), 0);
+        bool signalled[kJoinEvents] = {false, false, false, false};
+        while (ops.size() < total) {
+            // pick the stream that is furthest behind its proportional share and whose next launch is not blocked
+            int best = -1; double best_lag = -1e30;
+            for (size_t k = 0; k < seq.size(); ++k) {
+                if (pos[k] >= seq[k].size()) continue;
+                const Op& nx = seq[k][pos[k]];
+                if (nx.wait_ev >= 0 && !signalled[nx.wait_ev]) continue;
+                const double lag = double(ops.size() + 1) * double(seq[k].size()) / double(total) - double(pos[k]);
+                if (lag > best_lag) { best_lag = lag; best = int(k); }
+            }
+            if (best < 0) throw AchError{ACH_ERR_INVALID, "plan interleave: unsatisfiable event order"};
+            Op& op = seq[size_t(best)][pos[size_t(best)]++];
+            if (op.signal_ev >= 0) signalled[op.signal_ev] = true;
+            ops.push_back(std::move(op));
+        }
+    }
+
+    void plan(int B) override {
+        if (B <= 0) throw AchError{ACH_ERR_INVALID, "batch must be positive"};
+        if (weights.empty()) throw AchError{ACH_ERR_INVALID, "ach_load_weights must precede ach_plan"};
+        batch = B;
+        reset_plan();
+        measuring = true;
+        build();
+        const size_t wneed = warena_used + (1 << 20), aneed = aarena_used + (1 << 20);
+        measuring = false;
+        if (wneed > warena_cap) { if (warena) (void)hipFree(warena); warena = nullptr; ACH_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&warena), wneed)); warena_cap = wneed; }
+        if (aneed > aarena_cap) { if (aarena) (void)hipFree(aarena); aarena = nullptr; ACH_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&aarena), aneed)); aarena_cap = aneed; }
+        reset_plan();
+        build();
+        ACH_HIP_CHECK(hipMemset(aarena, 0, aarena_used));      // channel padding lanes stay zero for the lifetime of the plan
+        ACH_HIP_CHECK(hipDeviceSynchronize());
+    }
+
+    // ---- pre / post-processing
+    void preprocess_radar(int B, int C, const float* in, void* out, hipStream_t s) override {
+        const int S = 64;
+        const size_t need = size_t(B) * S * 2 * sizeof(float);
+        if (need > prepost_scratch_bytes) {
+            if (prepost_scratch) (void)hipFree(prepost_scratch);
+            ACH_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&prepost_scratch), need));
+            prepost_scratch_bytes = need;
+        }
+        const long per = long(C) * cfg.resolution * cfg.resolution;
+        MinMaxParams pm{in, prepost_scratch, per, S};
+        ACH_LAUNCH(frame_minmax_kernel, dim3(unsigned(B), unsigned(S)), dim3(256), s, pm);
+        RadarScaleParams ps{in, prepost_scratch, out, per, S, B};
+        ACH_LAUNCH(radar_scale_kernel<T>, dim3(unsigned(cdivl(per * B, 256))), dim3(256), s, ps);
+    }
+    void normalize_points(int B, int N, int D, const float* in, void* out, hipStream_t s) override {
+        PointNormParams pp{in, out, B, N, D};
+        ACH_LAUNCH(point_norm_kernel<T>, dim3(unsigned(B * D)), dim3(256), s, pp);
+    }
+    void preprocess_image(int B, const unsigned char* in, void* out, hipStream_t s) override {
+        ImagePrepParams pp{in, out, B, cfg.resolution, cfg.resolution};
+        ACH_LAUNCH(image_prep_kernel<T>, dim3(unsigned(cdivl(long(B) * cfg.resolution * cfg.resolution, 256))), dim3(256), s, pp);
+    }
+    void seg_argmax(int B, int C, const void* seg, unsigned char* out, hipStream_t s) override {
+        SegArgmaxParams pp{seg, out, B, C, long(cfg.resolution) * cfg.resolution};
+        ACH_LAUNCH(seg_argmax_kernel<T>, dim3(unsigned(cdivl(pp.HW * B, 256))), dim3(256), s, pp);
+    }
+
+    float bench_gemm(int M, int K, int N, int act, int ln, int residual, int Pforce, int iters, hipStream_t s) override {
+        Packed pk = pack_shape(N, K);
+        const long ldx = round_up(K, 8), ldy = round_up(N, 8);
+        T *X = nullptr, *Y = nullptr, *R = nullptr, *Wp = nullptr; float* bias = nullptr;
+        ACH_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&X), size_t(M) * ldx * sizeof(T)));
+        ACH_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&Y), size_t(M) * ldy * sizeof(T)));
+        ACH_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&R), size_t(M) * ldy * sizeof(T)));
+        ACH_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&Wp), size_t(pk.group_elems) * sizeof(T)));
+        ACH_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&bias), size_t(N) * sizeof(float)));
+        ACH_HIP_CHECK(hipMemset(X, 0x3c, size_t(M) * ldx * sizeof(T)));     // small finite values
+        ACH_HIP_CHECK(hipMemset(R, 0x3c, size_t(M) * ldy * sizeof(T)));
+        ACH_HIP_CHECK(hipMemset(Wp, 0x3c, size_t(pk.group_elems) * sizeof(T)));
+        ACH_HIP_CHECK(hipMemset(bias, 0, size_t(N) * sizeof(float)));
+        GemmParams g;
+        std::memset(&g, 0, sizeof(g));
+        g.X = X; g.ldx = ldx; g.W = Wp; g.bias = bias; g.Y = Y; g.ldy = ldy; g.R = residual ? R : nullptr; g.ldr = ldy;
+        g.groups = 1; g.M_per_group = M; g.K = K; g.N = N; g.nchunks = pk.nchunks; g.ksteps = pk.ksteps;
+        g.act = act; g.ln = ln; g.ln_eps = 1e-6f; g.vec_store = 1;
+        int P = 1;
+        if (Pforce > 0) P = Pforce;
+        const long row_blocks = cdivl(M, 64L * P);
+        const int zsplit = int(std::min<long>(pk.nchunks, std::max<long>(1, cdivl(1024, row_blocks))));
+        g.chunks_per_block = cdiv(pk.nchunks, zsplit);
+        hipEvent_t e0, e1;
+        ACH_HIP_CHECK(hipEventCreate(&e0)); ACH_HIP_CHECK(hipEventCreate(&e1));
+        for (int i = 0; i < 3; ++i) launch_gemm<T>(g, pk.NT, P, s);
+        ACH_HIP_CHECK(hipEventRecord(e0, s));
+        for (int i = 0; i < iters; ++i) launch_gemm<T>(g, pk.NT, P, s);
+        ACH_HIP_CHECK(hipEventRecord(e1, s));
+        ACH_HIP_CHECK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        ACH_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        (void)hipFree(X); (void)hipFree(Y); (void)hipFree(R); (void)hipFree(Wp); (void)hipFree(bias);
+        return ms / float(iters);
+    }
+
+    void decode(int B, const void* d3, const void* d4, const void* d5, float* out, hipStream_t s) override {
+        DecodeParams p;
+        const int r = cfg.resolution;
+        p.det[0] = d3; p.det[1] = d4; p.det[2] = d5;
+        p.h[0] = p.w[0] = r / 8; p.h[1] = p.w[1] = r / 16; p.h[2] = p.w[2] = r / 32;
+        p.out = out; p.B = B; p.NC5 = 5 + cfg.num_det; p.A = num_anchors(); p.in_h = float(r); p.in_w = float(r);
+        ACH_LAUNCH(decode_kernel<T>, dim3(unsigned(cdivl(long(B) * p.A, 256))), dim3(256), s, p);
+    }
+};
+
+}  // namespace ach

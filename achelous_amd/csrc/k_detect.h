@@ -69,7 +69,7 @@ __device__ __forceinline__ bool nms_overlaps(const float4& bi, float ai, const f
 constexpr int NMS_THREADS = 1024;
 constexpr int NMS_MAXA = 4096;
 
-__global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsParams p) {
+static __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsParams p) {
     __shared__ unsigned long long keybuf[NMS_MAXA + 128];       // sort keys, later aliased by the sorted boxes (float4[A])
     __shared__ unsigned short order[NMS_MAXA];
     __shared__ unsigned char supp[NMS_MAXA];

@@ -477,7 +477,7 @@ struct SaCoefParams {
     SaWeights w[2];
     int B, C, G, HW; float eps;
 };
-__global__ void sa_coef_kernel(const SaCoefParams p) {
+static __global__ void sa_coef_kernel(const SaCoefParams p) {
     const int gidx = blockIdx.x * blockDim.x + threadIdx.x;
     if (gidx >= 2 * p.B * p.C) return;
     const int m = gidx / (p.B * p.C), idx = gidx - m * p.B * p.C;
@@ -535,8 +535,8 @@ __device__ __forceinline__ void eca_scale_body(const EcaParams& p, int idx) {
     }
     p.scale[idx] = sigmoidf_(g) * p.bn_scale[c];
 }
-__global__ void eca_scale_kernel(const EcaParams p) { eca_scale_body(p, blockIdx.x * blockDim.x + threadIdx.x); }
-__global__ void eca_scale_multi_kernel(const Multi6<EcaParams> m) { eca_scale_body(m.j[blockIdx.y], blockIdx.x * blockDim.x + threadIdx.x); }
+static __global__ void eca_scale_kernel(const EcaParams p) { eca_scale_body(p, blockIdx.x * blockDim.x + threadIdx.x); }
+static __global__ void eca_scale_multi_kernel(const Multi6<EcaParams> m) { eca_scale_body(m.j[blockIdx.y], blockIdx.x * blockDim.x + threadIdx.x); }
 // Y[b,pix,c] = relu(X[b,pix,c] * scale[b][c] + shift[c]); X is NHWC (x_nchw = 0) or NCHW (radar branch)
 struct FuseParams { const void* X; long ldx; int x_nchw; void* Y; long ldy; const float* scale; const float* shift; int B, HW, C; };
 // one thread = 4 consecutive channels of one pixel (C % 4 == 0 for NHWC inputs; the NCHW input form stays scalar)

@@ -9,7 +9,7 @@ namespace ach {
 
 // ---- radar map: (x - min) / (max - min) + 1e-13 with min / max over the WHOLE frame (all channels)
 struct MinMaxParams { const float* X; float* partial; long per_frame; int S; };     // partial [B][S][2]
-__global__ __launch_bounds__(256) void frame_minmax_kernel(const MinMaxParams p) {
+static __global__ __launch_bounds__(256) void frame_minmax_kernel(const MinMaxParams p) {
     __shared__ float smin[256], smax[256];
     const long b = blockIdx.x;
     const int s = blockIdx.y;
