@@ -92,7 +92,12 @@ void EngineBase::reset_plan() {
 void EngineBase::ensure_streams() {
     if (streams_ready) return;
     for (int k = 0; k < kSideStreams; ++k) {
-        ACH_HIP_CHECK(hipStreamCreateWithFlags(&side_stream[k], hipStreamNonBlocking));
+        // side branches have slack, the caller's stream carries the critical path (backbone -> neck -> decoder): when the option is
+        // on they are created at the lowest priority so that the dispatcher favours the caller's stream under contention
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if ((side_low_priority >> k) & 1) ACH_HIP_CHECK(hipStreamCreateWithPriority(&side_stream[k], hipStreamNonBlocking, lo));
+        else ACH_HIP_CHECK(hipStreamCreateWithFlags(&side_stream[k], hipStreamNonBlocking));
         ACH_HIP_CHECK(hipEventCreate(&ev_end[k]));
     }
     ACH_HIP_CHECK(hipEventCreate(&ev_fork));

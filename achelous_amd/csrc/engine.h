@@ -68,6 +68,9 @@ public:
     bool fuse_mlp = true;             // option "fused_mlp": EdgeNeXt blocks as one kernel (k_mlp.h) instead of dw / pw1 / pw2 launches
     int split_decoders = -1;          // option "split_decoders": semantic decoder on its own stream (-1 / 1: on, 0: off).  With the main
                                       // stream as the critical path this is +1.3 % at batch 64 and +6 % at batch 1 (A/B on one box)
+    int side_low_priority = 3;        // option "side_priority": bit k set = side stream k+1 is created at the lowest stream priority.
+                                      // Default: the radar/detection and point branches (they have slack); the decoders stay at the
+                                      // caller's priority.  Measured +1.3 % at batch 64 (A/B over the 8 masks on one box).
     bool head_batch = true;           // option "head_batch": each detection-head layer as one launch for the three pyramid levels
     bool dw_tile = true;              // option "dw_tile": LDS-tiled depthwise kernel on the 10x10 maps
     bool fuse_rc = true;              // option "fused_rc": RCBlock conv + deformable sampling + contraction as one launch (k_conv3.h)
