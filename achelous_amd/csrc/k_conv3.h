@@ -123,7 +123,7 @@ struct RcFrontParams {
 
 // NARROW: the block has at most 4 channels (the first RCBlock: 3) — only the first 4 channels of a corner are fetched and blended.
 template <class T, int KS, bool NARROW>
-__global__ __launch_bounds__(256, KS == 3 ? 3 : 1) void rc_front_kernel(const RcFrontParams p) {
+__global__ __launch_bounds__(256, KS == 3 ? 4 : 1) void rc_front_kernel(const RcFrontParams p) {
     constexpr int VEC = Store<T>::VEC;
     __shared__ float oml[4][16][36];                               // per wave: [pixel][27 values], row padded against bank conflicts
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -148,9 +148,21 @@ __global__ __launch_bounds__(256, KS == 3 ? 3 : 1) void rc_front_kernel(const Rc
     }
     const uint4* Wom = static_cast<const uint4*>(p.Wom) + lane;
     const uint4* Wfp = static_cast<const uint4*>(p.Wf) + lane;
-    uint4 wom[KS][2], wfd[KS];
-    ACH_UNROLL
-    for (int s = 0; s < KS; ++s) { wom[s][0] = Wom[(s * 2) * 64]; wom[s][1] = Wom[(s * 2 + 1) * 64]; wfd[s] = Wfp[s * 64]; }
+    // WLDS: the 3 KS weight fragments live in LDS (one copy per workgroup) instead of 12 KS registers per lane — for the small
+    // instantiations this is what lets four waves per SIMD fit without spills
+    constexpr bool WLDS = KS <= 3;
+    __shared__ uint4 wsh[WLDS ? KS * 3 * 64 : 1];
+    uint4 wom[WLDS ? 1 : KS][2], wfd[WLDS ? 1 : KS];
+    if (WLDS) {
+        for (int i = threadIdx.x; i < KS * 3 * 64; i += 256) {
+            const int f = i >> 6, l = i & 63;                       // fragment f: 0 .. 2KS-1 conv, 2KS .. 3KS-1 folded contraction
+            wsh[i] = f < 2 * KS ? static_cast<const uint4*>(p.Wom)[f * 64 + l] : static_cast<const uint4*>(p.Wf)[(f - 2 * KS) * 64 + l];
+        }
+        __syncthreads();
+    } else {
+        ACH_UNROLL
+        for (int s = 0; s < KS; ++s) { wom[s][0] = Wom[(s * 2) * 64]; wom[s][1] = Wom[(s * 2 + 1) * 64]; wfd[s] = Wfp[s * 64]; }
+    }
     float bv[8], bo[4];
     ACH_UNROLL
     for (int i = 0; i < 8; ++i) bv[i] = p.bom[g * 8 + i];
@@ -180,7 +192,11 @@ __global__ __launch_bounds__(256, KS == 3 ? 3 : 1) void rc_front_kernel(const Rc
             a0[0] = a0[1] = a0[2] = a0[3] = 0.f;
             a1[0] = a1[1] = a1[2] = a1[3] = 0.f;
             ACH_UNROLL
-            for (int s = 0; s < KS; ++s) { mfma16<T>(wom[s][0], xf[s], a0); mfma16<T>(wom[s][1], xf[s], a1); }
+            for (int s = 0; s < KS; ++s) {
+                const uint4 w0 = WLDS ? wsh[(s * 2) * 64 + lane] : wom[WLDS ? 0 : s][0], w1 = WLDS ? wsh[(s * 2 + 1) * 64 + lane] : wom[WLDS ? 0 : s][1];
+                mfma16<T>(w0, xf[s], a0);
+                mfma16<T>(w1, xf[s], a1);
+            }
             float* o = &oml[wave][px][g * 8];
             *reinterpret_cast<float4*>(o) = make_float4(a0[0] + bv[0], a0[1] + bv[1], a0[2] + bv[2], a0[3] + bv[3]);
             *reinterpret_cast<float4*>(o + 4) = make_float4(a1[0] + bv[4], a1[1] + bv[5], a1[2] + bv[6], a1[3] + bv[7]);
@@ -219,7 +235,7 @@ __global__ __launch_bounds__(256, KS == 3 ? 3 : 1) void rc_front_kernel(const Rc
                 ACH_UNROLL
                 for (int i = 0; i < VEC; ++i) v[i] = w00 * a[i] + w01 * bq[i] + w10 * cc[i] + w11 * d[i];
             }
-            mfma16<T>(wfd[s], frag_pack<T>(v), acc);
+            mfma16<T>(WLDS ? wsh[(2 * KS + s) * 64 + lane] : wfd[WLDS ? 0 : s], frag_pack<T>(v), acc);
         }
         wave_sync();                                                // the LDS tile is rewritten by the next iteration
         const int ch = g * 4;
