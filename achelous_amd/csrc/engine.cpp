@@ -85,7 +85,7 @@ void EngineBase::reset_plan() {
     drop_graphs();
 #endif
     probe_op = -1;
-    cur_stream = 0; pending_wait = -1;
+    cur_stream = 0; pending_wait = -1; pending_wait2 = -1;
     ops.clear(); taps.clear(); tap_order.clear();
     warena_used = 0; aarena_used = 0;
 }
@@ -96,7 +96,7 @@ void EngineBase::ensure_streams() {
         // on they are created at the lowest priority so that the dispatcher favours the caller's stream under contention
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        if ((side_low_priority >> k) & 1) ACH_HIP_CHECK(hipStreamCreateWithPriority(&side_stream[k], hipStreamNonBlocking, lo));
+        if (((head_stream ? 1 : side_low_priority) >> k) & 1) ACH_HIP_CHECK(hipStreamCreateWithPriority(&side_stream[k], hipStreamNonBlocking, lo));
         else ACH_HIP_CHECK(hipStreamCreateWithFlags(&side_stream[k], hipStreamNonBlocking));
         ACH_HIP_CHECK(hipEventCreate(&ev_end[k]));
     }
@@ -120,6 +120,7 @@ void EngineBase::run_eager(hipStream_t s) {
         hipStream_t st = s;
         if (multi && op.stream > 0) { st = side_stream[op.stream - 1]; used[op.stream - 1] = true; }
         if (multi && op.wait_ev >= 0) (void)hipStreamWaitEvent(st, ev_join[op.wait_ev], 0);
+        if (multi && op.wait_ev2 >= 0) (void)hipStreamWaitEvent(st, ev_join[op.wait_ev2], 0);
         if (int(i) == probe_op) {
             const size_t slot = size_t(probe_count % kProbeEvents);
             (void)hipEventRecord(probe_ev0[slot], st);
@@ -131,7 +132,7 @@ void EngineBase::run_eager(hipStream_t s) {
         }
         if (multi && op.signal_ev >= 0) (void)hipEventRecord(ev_join[op.signal_ev], st);
     }
-    if (detect_tail) detect_tail((multi && used[0]) ? side_stream[0] : s);       // det maps are final on that stream at this point
+    if (detect_tail) detect_tail((multi && detect_stream > 0 && used[detect_stream - 1]) ? side_stream[detect_stream - 1] : s);   // det maps are final on that stream
     if (multi)
         for (int k = 0; k < kSideStreams; ++k)
             if (used[k]) { (void)hipEventRecord(ev_end[k], side_stream[k]); (void)hipStreamWaitEvent(s, ev_end[k], 0); }

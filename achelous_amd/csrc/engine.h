@@ -38,7 +38,7 @@ struct Op {
     double bytes = 0;             // algorithmic HBM bytes of one launch: inputs read once + outputs written once + weights
     double flops = 0;             // 2 * MACs of one launch (dense contractions only)
     int stream = 0;               // 0: caller's stream (image path) ; 1, 2: engine-owned side streams (radar / point branches)
-    int wait_ev = -1;             // join: wait for this event before the launch
+    int wait_ev = -1, wait_ev2 = -1;   // join: wait for these events before the launch
     int signal_ev = -1;           // record this event after the launch
 };
 
@@ -68,6 +68,9 @@ public:
     bool fuse_mlp = true;             // option "fused_mlp": EdgeNeXt blocks as one kernel (k_mlp.h) instead of dw / pw1 / pw2 launches
     int split_decoders = -1;          // option "split_decoders": semantic decoder on its own stream (-1 / 1: on, 0: off).  With the main
                                       // stream as the critical path this is +1.3 % at batch 64 and +6 % at batch 1 (A/B on one box)
+    bool head_stream = true;          // option "head_stream": radar and point branches share low-priority stream 1; fusion + detection head
+                                      // (+ decode + NMS) get stream 2 at the caller's priority: they are on the critical tail once the
+                                      // neck is done.  (A fifth stream is not an option: the runtime has four hardware queues.)
     int side_low_priority = 3;        // option "side_priority": bit k set = side stream k+1 is created at the lowest stream priority.
                                       // Default: the radar/detection and point branches (they have slack); the decoders stay at the
                                       // caller's priority.  Measured +1.3 % at batch 64 (A/B over the 8 masks on one box).
@@ -119,14 +122,16 @@ protected:
         if (measuring) return;
         Op op{name, std::move(fn), bytes, flops};
         op.stream = cur_stream;
-        op.wait_ev = pending_wait;
-        pending_wait = -1;
+        op.wait_ev = pending_wait; op.wait_ev2 = pending_wait2;
+        pending_wait = -1; pending_wait2 = -1;
         ops.push_back(std::move(op));
     }
     // branch bookkeeping while the plan is built
-    int cur_stream = 0, pending_wait = -1;
+    int cur_stream = 0, pending_wait = -1, pending_wait2 = -1;
+    int detect_stream = 1;            // the stream the detection head ends on (decode + NMS of ach_forward_detect follow it there)
     void signal_after_last(int ev) { if (!measuring && !ops.empty()) ops.back().signal_ev = ev; }
     void wait_before_next(int ev) { pending_wait = ev; }
+    void wait_before_next2(int ev) { pending_wait2 = ev; }
     static constexpr int kSideStreams = 3, kJoinEvents = 4;
     hipStream_t side_stream[kSideStreams] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[kJoinEvents] = {nullptr, nullptr, nullptr, nullptr}, ev_end[kSideStreams] = {nullptr, nullptr, nullptr};

@@ -1207,7 +1207,8 @@ public:
         A r[3];
         cur_stream = 1;
         rcnet(r);
-        cur_stream = 2;
+        signal_after_last(3);             // radar pyramid ready
+        cur_stream = head_stream ? 1 : 2; // "head_stream": the point branch queues behind the radar branch on the low-priority stream
         pointnet();
         cur_stream = 0;
         A m[4];
@@ -1228,8 +1229,11 @@ public:
         tap("q3", q[0]); tap("q4", q[1]); tap("q5", q[2]);
         // detection branch: fusion + head continue on the RADAR stream (in order after the radar taps), gated only on the FPN
         // outputs (event 1) — they overlap with the segmentation decoders that keep the caller's stream busy
-        cur_stream = 1;
+        // ("head_stream": on stream 2 at the caller's priority, gated on both the FPN outputs and the radar pyramid)
+        cur_stream = head_stream ? 2 : 1;
+        detect_stream = cur_stream;
         wait_before_next(1);
+        if (head_stream) wait_before_next2(3);
         A p[3];
         fuse_all(q, r, p);
         head(p);
@@ -1256,6 +1260,7 @@ public:
                 if (pos[k] >= seq[k].size()) continue;
                 const Op& nx = seq[k][pos[k]];
                 if (nx.wait_ev >= 0 && !signalled[nx.wait_ev]) continue;
+                if (nx.wait_ev2 >= 0 && !signalled[nx.wait_ev2]) continue;
                 const double lag = double(ops.size() + 1) * double(seq[k].size()) / double(total) - double(pos[k]);
                 if (lag > best_lag) { best_lag = lag; best = int(k); }
             }
