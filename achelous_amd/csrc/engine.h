@@ -66,14 +66,14 @@ public:
     bool use_graph = false;
     bool multi_stream = true;         // option "streams": run the independent radar / point branches on side streams
     bool fuse_mlp = true;             // option "fused_mlp": EdgeNeXt blocks as one kernel (k_mlp.h) instead of dw / pw1 / pw2 launches
-    int split_decoders = -1;          // option "split_decoders": semantic decoder on its own stream (-1 / 1: on, 0: off).  With the main
-                                      // stream as the critical path this is +1.3 % at batch 64 and +6 % at batch 1 (A/B on one box)
+    int split_decoders = 0;           // option "split_decoders": semantic decoder on side stream 3.  OFF: with the other branches at low
+                                      // priority it no longer pays (23.8 k vs 22.9 k frames/s), and the process must stay at <= 4 ACTIVE
+                                      // streams — caller + 2 here leaves one for a collective (RCCL) stream; a fifth costs 28 %
     bool head_stream = true;          // option "head_stream": radar and point branches share low-priority stream 1; fusion + detection head
                                       // (+ decode + NMS) get stream 2 at the caller's priority: they are on the critical tail once the
-                                      // neck is done.  (A fifth stream is not an option: the runtime has four hardware queues.)
-    int side_low_priority = 3;        // option "side_priority": bit k set = side stream k+1 is created at the lowest stream priority.
-                                      // Default: the radar/detection and point branches (they have slack); the decoders stay at the
-                                      // caller's priority.  Measured +1.3 % at batch 64 (A/B over the 8 masks on one box).
+                                      // neck is done
+    int side_low_priority = 3;        // option "side_priority" (with head_stream = 0): bit k set = side stream k+1 is created at the
+                                      // lowest stream priority
     bool head_batch = true;           // option "head_batch": each detection-head layer as one launch for the three pyramid levels
     bool dw_tile = true;              // option "dw_tile": LDS-tiled depthwise kernel on the 10x10 maps
     bool fuse_rc = true;              // option "fused_rc": RCBlock conv + deformable sampling + contraction as one launch (k_conv3.h)

@@ -55,6 +55,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=8, help='frames in the CPU-baseline sample')
     ap.add_argument('--separate-calls', action='store_true', help='forward, decode_outputs and NMS as three calls instead of forward_detect')
+    ap.add_argument('--extra-stream', action='store_true', help='diagnostic: also launch a tiny copy on a separate stream every step (stands in for a collective stream)')
     ap.add_argument('--opt', action='append', default=[], help='engine option key=value (ach_set_option), repeatable')
     ap.add_argument('--ops-json', default=None, help='write the per-launch table (ms, algorithmic bytes) here')
     args = ap.parse_args()
@@ -89,7 +90,15 @@ def main():
     gathered = torch.empty(world * B, rec_w, dtype=torch.int32, device=dev) if world > 1 else None
     ishape = [COMMON['resolution']] * 2
 
+    extra = torch.cuda.Stream(dev) if args.extra_stream else None
+    scratch = torch.zeros(1024, device=dev) if args.extra_stream else None
+
     def step():
+        if extra is not None:
+            extra.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(extra):
+                scratch.add_(1.0)
+            torch.cuda.current_stream(dev).wait_stream(extra)
         if args.separate_calls:
             det, se, lane, pc = model(x, xr, xp)
             dec = decode_outputs(det, ishape)

@@ -234,7 +234,7 @@ def test_forward_detect_equals_the_three_calls():
                 assert int(cnt.max()) > 0
 
 
-@pytest.mark.parametrize('option', ['fused_mlp', 'row_conv', 'fused_rc', 'dw_tile', 'head_batch', 'split_decoders'])
+@pytest.mark.parametrize('option', ['fused_mlp', 'row_conv', 'fused_rc', 'dw_tile', 'head_batch', 'split_decoders', 'head_stream'])
 def test_fused_kernels_agree_with_the_layerwise_path(option):
     """Every fused / batched kernel has a switch back to the layer-wise launches it replaced (include/achelous.h): the two plans
     must agree — to fp32 rounding in the fp32 engine (different summation order), and within the bf16 tolerance in the bf16
@@ -247,11 +247,12 @@ def test_fused_kernels_agree_with_the_layerwise_path(option):
         with torch.no_grad():
             ref = m(xs, rs, ps)
             e = _engine_of(m, dt)
-            e.set_option(option, 0)
+            default = 0 if option == 'split_decoders' else 1
+            e.set_option(option, 1 - default)
             e.plan(2)
             alt = m(xs, rs, ps)
             torch.cuda.synchronize()
-            e.set_option(option, -1 if option == 'split_decoders' else 1)
+            e.set_option(option, default)
             e.plan(2)
         for a, b in zip((*alt[0], alt[1], alt[2], alt[3]), (*ref[0], ref[1], ref[2], ref[3])):
             assert _rel(a.float(), b.float()) <= tol, option
