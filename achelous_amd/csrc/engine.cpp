@@ -218,16 +218,17 @@ int EngineBase::num_anchors() const {
     const int r = cfg.resolution;
     return (r / 8) * (r / 8) + (r / 16) * (r / 16) + (r / 32) * (r / 32);
 }
-size_t EngineBase::nms_workspace_bytes(int B) const { return size_t(B) * num_anchors() * (8 * sizeof(float) + sizeof(int)) + 256; }
+size_t EngineBase::nms_workspace_bytes(int B) const { return size_t(B) * num_anchors() * (8 * sizeof(float) + sizeof(int) + 4 * sizeof(float)) + 512; }
 
 void EngineBase::nms(int B, const float* decoded, float conf, float iou, int max_det, float* rows, int* idx, int* count,
                      void* workspace, hipStream_t s) {
     const int A = num_anchors();
-    if (A > 2112) throw AchError{ACH_ERR_UNSUPPORTED, "device NMS supports up to 2112 anchors per image (resolution 320)"};
+    if (A > NMS_MAXA) throw AchError{ACH_ERR_UNSUPPORTED, "device NMS supports up to 4096 anchors per image (resolution <= 416)"};
     NmsParams p;
     p.dec = decoded;
     p.scratch = static_cast<float*>(workspace);
     p.scratch_idx = reinterpret_cast<int*>(static_cast<char*>(workspace) + size_t(round_up(long(B) * A * 8 * long(sizeof(float)), 256)));
+    p.scratch_boxes = reinterpret_cast<float*>(reinterpret_cast<char*>(p.scratch_idx) + size_t(round_up(long(B) * A * long(sizeof(int)), 256)));
     p.rows = rows; p.kept = idx; p.count = count;
     p.B = B; p.A = A; p.NC5 = 5 + cfg.num_det; p.num_classes = cfg.num_det; p.max_det = max_det; p.conf = conf; p.iou = iou;
     ACH_LAUNCH(nms_kernel, dim3(unsigned(B)), dim3(NMS_THREADS), s, p);

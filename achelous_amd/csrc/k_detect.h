@@ -50,6 +50,7 @@ struct NmsParams {
     const float* dec;           // [B, A, NC5] decoded predictions (cx, cy, w, h, obj, cls...)
     float* scratch;             // [B, A, 8] workspace: candidate (x1,y1,x2,y2 offset boxes, score, cls_conf, obj, cls_id)
     int* scratch_idx;           // [B, A] candidate -> anchor index
+    float* scratch_boxes;       // [B, A, 4] sorted candidate boxes, used instead of LDS when more than NMS_LDS_BOXES pass the filter
     float* rows; int* kept; int* count;   // [B, max_det, 7], [B, max_det], [B]
     int B, A, NC5, num_classes, max_det; float conf, iou;
 };
@@ -68,6 +69,7 @@ __device__ __forceinline__ bool nms_overlaps(const float4& bi, float ai, const f
 
 constexpr int NMS_THREADS = 1024;
 constexpr int NMS_MAXA = 4096;
+constexpr int NMS_LDS_BOXES = 2112;      // sorted boxes that fit in the LDS space of the (consumed) sort keys
 
 static __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsParams p) {
     __shared__ unsigned long long keybuf[NMS_MAXA + 128];       // sort keys, later aliased by the sorted boxes (float4[A])
@@ -153,7 +155,8 @@ static __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsParams
     for (int i = tid; i < n; i += NMS_THREADS) order[i] = (unsigned short)(keybuf[i] & 0xffffull);
     __syncthreads();
     // ---- 4. sorted boxes into LDS (aliasing the key buffer; every key has been consumed above)
-    float4* sbox = reinterpret_cast<float4*>(keybuf);
+    // (more candidates than that — only possible above 320x320 — go through a global scratch copy instead; same arithmetic)
+    float4* sbox = n <= NMS_LDS_BOXES ? reinterpret_cast<float4*>(keybuf) : reinterpret_cast<float4*>(p.scratch_boxes) + long(b) * p.A;
     for (int i = tid; i < n; i += NMS_THREADS) {
         const float* q = sc + long(order[i]) * 8;
         supp[i] = 0;

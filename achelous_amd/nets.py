@@ -157,8 +157,8 @@ class Achelous(nn.Module):
                 return det, se, lane, pc
             conf, iou, max_det = detect
             A = sum((R // s) ** 2 for s in (8, 16, 32))
-            if A > 2112:
-                raise NotImplementedError(f"device NMS handles up to 2112 anchors (320x320), got {A}")
+            if A > 4096:
+                raise NotImplementedError(f"device NMS handles up to 4096 anchors (resolution <= 416), got {A}")
             max_det = int(max_det or A)
             decoded = torch.empty(B, A, nc5, dtype=torch.float32, device=dev)
             rows = torch.zeros(B, max_det, 7, dtype=torch.float32, device=dev)

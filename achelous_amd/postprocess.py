@@ -50,9 +50,11 @@ def nms_device(prediction, num_classes, conf_thres, nms_thres, max_det=None):
     B, A, nc5 = p.shape
     max_det = int(max_det or A)
     with torch.cuda.device(p.device):
-        R = {2100: 320}.get(A)
-        if R is None:
-            raise NotImplementedError(f"device NMS is built for 2100 anchors (320x320), got {A}")
+        # A = (R/8)^2 + (R/16)^2 + (R/32)^2 = 21 (R/32)^2 for the square inputs the reference uses
+        g = int(round((A / 21.0) ** 0.5))
+        if 21 * g * g != A or A > 4096:
+            raise NotImplementedError(f"device NMS handles square inputs up to 416x416 (3549 anchors), got {A} anchors")
+        R = 32 * g
         h = _handle(num_classes, R, torch.float32)
         rows = torch.zeros(B, max_det, 7, dtype=torch.float32, device=p.device)
         idx = torch.full((B, max_det), -1, dtype=torch.int32, device=p.device)

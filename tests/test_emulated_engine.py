@@ -127,3 +127,27 @@ def test_emulated_kernel_switches_agree(option):
         outs.append(o)
     for a, b in zip(*outs):
         assert rel_err(a, b) < 2e-5, option
+
+
+def test_emulated_nms_more_candidates_than_fit_in_lds():
+    """416x416 (3549 anchors, the reference's default resolution): when more than 2112 candidates pass the confidence filter the
+    sorted boxes live in global scratch instead of LDS — same kept-index sequence as the oracle, bit for bit."""
+    from achelous_amd.engine import NativeEngine
+    h = NativeEngine(emu_library(), num_det=7, num_seg=1, phi='S0', backbone='en', resolution=416, pc_channels=3, pc_classes=1,
+                     num_points=16, nano_head=True, spp=True, dtype=DTYPE_F32)
+    rng = np.random.default_rng(3)
+    A, C = 3549, 7
+    dec = np.zeros((1, A, 5 + C), np.float32)
+    dec[..., 0:2] = rng.uniform(0.05, 0.95, (1, A, 2))
+    dec[..., 2:4] = rng.uniform(0.01, 0.08, (1, A, 2))
+    dec[..., 4] = rng.uniform(0.5, 1, (1, A))
+    dec[..., 5:] = rng.uniform(0.5, 1, (1, A, C))
+    t = torch.from_numpy(dec)
+    ws = torch.zeros(h.nms_workspace_bytes(1), dtype=torch.uint8)
+    rows, idx, cnt = torch.zeros(1, A, 7), torch.full((1, A), -1, dtype=torch.int32), torch.zeros(1, dtype=torch.int32)
+    h.nms(1, t, 0.2, 0.45, A, rows, idx, cnt, ws)
+    exp = o_nms(t.clone(), C, 0.2, 0.45)
+    k = int(cnt[0])
+    assert k == len(exp[0][1]) and k > 2112
+    assert np.array_equal(idx[0, :k].numpy().astype(np.int64), exp[0][1])
+    assert np.array_equal(rows[0, :k].numpy(), exp[0][0])

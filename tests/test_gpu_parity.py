@@ -256,3 +256,30 @@ def test_fused_kernels_agree_with_the_layerwise_path(option):
             e.plan(2)
         for a, b in zip((*alt[0], alt[1], alt[2], alt[3]), (*ref[0], ref[1], ref[2], ref[3])):
             assert _rel(a.float(), b.float()) <= tol, option
+
+
+def test_reference_default_resolution_416():
+    """The reference constructor defaults to 416x416 (nets/Achelous.py:27): 3549 anchors, 13x13 coarsest map, the NMS path with
+    more candidates than its LDS tile holds.  fp32 forward against the oracle, decode + NMS bit-exact against the oracle's."""
+    g = Golden('en_s0')
+    kw = dict(ctor_kwargs(g.meta), resolution=416)
+    m = Achelous(**kw).eval()
+    sd = condition_state_dict(m.state_dict(), seed=g.meta['weight_seed'])
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda()
+    x, xr, xp = make_inputs(1, 5, resolution=416, pc_channels=kw['pc_channels'])
+    with torch.no_grad():
+        det, se, lane, pc = m(x.cuda(), xr.cuda(), xp.cuda())
+        okw = {k: kw[k] for k in ('num_det', 'num_seg', 'phi', 'backbone', 'neck', 'pc_seg', 'pc_channels', 'pc_classes', 'nano_head', 'spp', 'resolution')}
+        ref = AchelousOracle({k: v.cpu() for k, v in sd.items()}, **okw).forward(x, xr, xp)
+        for a, b in zip((*det, se, lane, pc), (*ref[0], ref[1], ref[2], ref[3])):
+            assert _rel(a.float(), b.float()) <= F32_TOL
+        dec = o_decode([d.cpu() for d in ref[0]], [416, 416])
+        assert _rel(decode_outputs(det, [416, 416]), dec) <= 1e-5
+        for conf, iou in ((0.35, 0.35), (0.0, 0.6)):                      # conf 0: all 3549 anchors are candidates
+            rows, idx, cnt = nms_device(dec.cuda(), kw['num_det'], conf, iou)
+            exp = o_nms(dec.clone(), kw['num_det'], conf, iou)
+            k = int(cnt[0])
+            assert k == len(exp[0][1])
+            assert np.array_equal(idx[0, :k].cpu().numpy().astype(np.int64), exp[0][1])
+            assert np.array_equal(rows[0, :k].cpu().numpy(), exp[0][0])
