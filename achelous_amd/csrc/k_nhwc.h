@@ -535,7 +535,6 @@ __device__ __forceinline__ void eca_scale_body(const EcaParams& p, int idx) {
     }
     p.scale[idx] = sigmoidf_(g) * p.bn_scale[c];
 }
-static __global__ void eca_scale_kernel(const EcaParams p) { eca_scale_body(p, blockIdx.x * blockDim.x + threadIdx.x); }
 static __global__ void eca_scale_multi_kernel(const Multi6<EcaParams> m) { eca_scale_body(m.j[blockIdx.y], blockIdx.x * blockDim.x + threadIdx.x); }
 // Y[b,pix,c] = relu(X[b,pix,c] * scale[b][c] + shift[c]); X is NHWC (x_nchw = 0) or NCHW (radar branch)
 struct FuseParams { const void* X; long ldx; int x_nchw; void* Y; long ldy; const float* scale; const float* shift; int B, HW, C; };
@@ -570,26 +569,7 @@ __device__ __forceinline__ void fuse_scale_body(const FuseParams& p, long idx) {
     Store<T>::st4(static_cast<T*>(p.Y) + pix * p.ldy + c, o);
 }
 template <class T>
-__global__ __launch_bounds__(256) void fuse_scale_kernel(const FuseParams p) { fuse_scale_body<T>(p, long(blockIdx.x) * blockDim.x + threadIdx.x); }
-template <class T>
 __global__ __launch_bounds__(256) void fuse_scale_multi_kernel(const Multi6<FuseParams> m) { fuse_scale_body<T>(m.j[blockIdx.y], long(blockIdx.x) * blockDim.x + threadIdx.x); }
-// per-channel sums of an NCHW tensor -> partial[b][0][2][C] (S = 1); one block per (b, c)
-struct StatNchwParams { const void* X; float* partial; int HW, C; };
-template <class T>
-__global__ __launch_bounds__(256) void chan_stats_nchw_kernel(const StatNchwParams p) {
-    __shared__ float red[256];
-    const int b = blockIdx.x / p.C, c = blockIdx.x % p.C;
-    const T* X = static_cast<const T*>(p.X) + (long(b) * p.C + c) * p.HW;
-    float s1 = 0.f;
-    for (int i = threadIdx.x; i < p.HW; i += 256) s1 += Store<T>::ld(X + i);
-    red[threadIdx.x] = s1;
-    __syncthreads();
-    for (int st = 128; st >= 1; st >>= 1) {
-        if (int(threadIdx.x) < st) red[threadIdx.x] += red[threadIdx.x + st];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) { p.partial[long(b) * 2 * p.C + c] = red[0]; p.partial[long(b) * 2 * p.C + p.C + c] = 0.f; }
-}
 
 }  // namespace ach
 
