@@ -688,6 +688,44 @@ public:
         gemm(pfx + ".shortcut.pw", sd, pack(conv_bn(pfx + ".shortcut.2", pfx + ".shortcut.3", 1e-5)), y, o);
         return y;
     }
+    // ---- CSP-Dual-FPN blocks (neck/cspdualfpn.py:42-78; BaseConv = conv + BN(1e-3) + act, normal_conv.py:36-47)
+    Lin base_conv3(const std::string& pfx, int Ci, int Cp) const {                // 3x3 BaseConv as an implicit-GEMM matrix, BN folded
+        Lin l = conv_lin(pfx + ".conv.weight", "", Ci, Cp, 3);
+        fold_bn(l, pfx + ".bn", 1e-3);
+        return l;
+    }
+    // Bottleneck: 1x1 (SiLU) -> 3x3 (ReLU, BaseConv's default act) [+ x when in == out].  Writes into `dst` (may be a channel slice, may
+    // alias x for the in-place use inside CSPLayer) or, with `user_out`, scatters to the caller's NCHW buffer.
+    void csp_bottleneck(const std::string& pfx, const A& x, int cout, const A* dst, void** user_out) {
+        Lin l1 = conv_bn(pfx + ".conv1.conv", pfx + ".conv1.bn", 1e-3);
+        A t = alloc(x.B, x.H, x.W, l1.N);
+        { GemmOpt o; o.act = ACT_SILU; gemm(pfx + ".conv1", x, pack(l1), t, o); }
+        Lin l2 = base_conv3(pfx + ".conv2", l1.N, int(t.ld));
+        if (l2.N != cout) throw AchError{ACH_ERR_MISSING_KEY, "bottleneck width at " + pfx};
+        GemmOpt o; o.act = ACT_RELU; o.residual = (x.C == cout) ? &x : nullptr;
+        o.conv_k = 3; o.conv_s = 1; o.conv_p = 1; o.Hin = x.H; o.Win = x.W; o.Cin = int(t.ld); o.Ho = x.H; o.Wo = x.W;
+        if (user_out) {
+            o.ydyn = user_out; o.out_nchw = 1; o.HW = x.H * x.W; o.Ctot = cout; o.coff = 0;
+            gemm(pfx + ".conv2", t.p, t.ld, t.rows(), pack(l2), nullptr, 0, o);
+        } else {
+            gemm(pfx + ".conv2", t.p, t.ld, t.rows(), pack(l2), dst->p, dst->ld, o);
+        }
+    }
+    // CSPLayer, n = 1: conv1 and conv2 share their input -> one GEMM writes [x1 | x2]; the bottleneck rewrites x1 in place; conv3
+    A csp_layer(const std::string& pfx, const A& x, int cout) {
+        Lin l1 = conv_bn(pfx + ".conv1.conv", pfx + ".conv1.bn", 1e-3), l2 = conv_bn(pfx + ".conv2.conv", pfx + ".conv2.bn", 1e-3);
+        const int hidden = l1.N;
+        if (l2.N != hidden || l1.K != x.C || hidden % 8) throw AchError{ACH_ERR_UNSUPPORTED, pfx + ": CSPLayer widths"};
+        Lin l12; l12.N = 2 * hidden; l12.K = l1.K; l12.w = l1.w; l12.w.insert(l12.w.end(), l2.w.begin(), l2.w.end());
+        l12.b = l1.b; l12.b.insert(l12.b.end(), l2.b.begin(), l2.b.end());
+        A cat = alloc(x.B, x.H, x.W, 2 * hidden);
+        { GemmOpt o; o.act = ACT_SILU; gemm(pfx + ".conv12", x, pack(l12), cat, o); }
+        const A x1 = cat.slice(0, hidden);
+        csp_bottleneck(pfx + ".m.0", x1, hidden, &x1, nullptr);
+        A y = alloc(x.B, x.H, x.W, cout);
+        { GemmOpt o; o.act = ACT_SILU; gemm(pfx + ".conv3", cat, pack(conv_bn(pfx + ".conv3.conv", pfx + ".conv3.bn", 1e-3)), y, o); }
+        return y;
+    }
     // Upsample = BaseConv 1x1 + BN(1e-3) + ReLU, bilinear x2 align_corners (ghostdualfpn.py:28-39); writes into `dst`
     void upsample(const std::string& pfx, const A& x, const A& dst) {
         Lin l = conv_bn(pfx + ".upsample.0.conv", pfx + ".upsample.0.bn", 1e-3);
@@ -802,11 +840,12 @@ public:
         A c4 = cat_buf[1].p ? cat_buf[1] : alloc(m4.B, m4.H, m4.W, 2 * w[2]);
         upsample(f + ".upsample_5_to_4", p5, c4.slice(0, w[2]));
         if (m4.p != c4.slice(w[2], w[2]).p) copy(f + ".cat4", m4, c4.slice(w[2], w[2]));      // else: the backbone wrote it in place
-        A p4 = ghost_bottleneck(f + ".ghost_5_to_4", c4, w[2]);
+        const bool csp = cfg.neck == ACH_NECK_CDF;                              // cspdualfpn.py:193-237: same graph, CSP blocks
+        A p4 = csp ? csp_layer(f + ".ghost_5_to_4", c4, w[2]) : ghost_bottleneck(f + ".ghost_5_to_4", c4, w[2]);
         A c3 = cat_buf[0].p ? cat_buf[0] : alloc(m3.B, m3.H, m3.W, 2 * w[1]);
         upsample(f + ".upsample_4_to_3", p4, c3.slice(0, w[1]));
         if (m3.p != c3.slice(w[1], w[1]).p) copy(f + ".cat3", m3, c3.slice(w[1], w[1]));
-        A p3 = ghost_bottleneck(f + ".ghost_4_to_3", c3, w[1]);
+        A p3 = csp ? csp_layer(f + ".ghost_4_to_3", c3, w[1]) : ghost_bottleneck(f + ".ghost_4_to_3", c3, w[1]);
         tap("fpn4", p4); tap("fpn3", p3);
         const bool split_dec = split_decoders != 0;
         // residual FPN outputs (ghostdualfpn.py:200) — computed BEFORE the decoders so that the detection branch (fusion + head,
@@ -832,6 +871,18 @@ public:
             tap(n + ".sa", y);
             const char* lv[3] = {"3_to_2", "2_to_1", "1_to_0"};
             const int cw[3] = {w[1], w[0], w[0]};
+            if (csp) {          // Upsample + Bottleneck per level, Bottleneck head (layer-wise on the generic kernels)
+                for (int l = 0; l < 3; ++l) {
+                    A u = alloc(y.B, 2 * y.H, 2 * y.W, cw[l]);
+                    upsample(f + "." + n + "_seg_" + lv[l], y, u);
+                    A v = alloc(u.B, u.H, u.W, cw[l]);
+                    csp_bottleneck(f + "." + n + "_seg_ghost_" + lv[l], u, cw[l], &v, nullptr);
+                    tap(n + "." + lv[l], v);
+                    y = v;
+                }
+                csp_bottleneck(f + "." + n + "_seg_head", y, oups[d], nullptr, outs[d]);
+                continue;
+            }
             for (int l = 0; l < 2; ++l) {
                 y = decoder_level(f + "." + n + "_seg_" + lv[l], f + "." + n + "_seg_ghost_" + lv[l], y, cw[l]);
                 tap(n + "." + lv[l], y);

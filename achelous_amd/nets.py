@@ -39,8 +39,8 @@ class Achelous(nn.Module):
     def __init__(self, num_det, num_seg, phi='S0', image_channels=3, radar_channels=3, resolution=416,
                  backbone='ef', neck='gdf', pc_seg='pn', pc_channels=6, pc_classes=9, nano_head=False, spp=True):
         super().__init__()
-        if neck != 'gdf':
-            raise NotImplementedError(f"neck={neck!r}: only the Ghost-Dual-FPN ('gdf') is built (SURVEY.md §2.1 rows 18-19)")
+        if neck not in ('gdf', 'cdf'):
+            raise NotImplementedError(f"neck={neck!r}: the Ghost-Dual-FPN ('gdf') and CSP-Dual-FPN ('cdf') are built (SURVEY.md §2.1 rows 18-19)")
         if backbone not in ('en', 'mv'):
             raise NotImplementedError(f"backbone={backbone!r}: only EdgeNeXt ('en') and MobileViT ('mv') are in scope")
         if pc_seg != 'pn':
@@ -57,7 +57,7 @@ class Achelous(nn.Module):
         self.phi, self.image_channels, self.radar_channels = phi, image_channels, radar_channels
         self.backbone, self.neck, self.pc_seg_kind = backbone, neck, pc_seg
         self.pc_channels, self.pc_classes, self.nano_head, self.spp = pc_channels, pc_classes, nano_head, spp
-        _build_tree(self, state_dict_spec(num_det, num_seg, phi, backbone, pc_channels, pc_classes, nano_head, radar_channels))
+        _build_tree(self, state_dict_spec(num_det, num_seg, phi, backbone, pc_channels, pc_classes, nano_head, radar_channels, neck))
         self._init_like_reference()
         self._engines = {}          # (device index, dtype) -> [NativeEngine, weight version, num_points]
         self.debug_taps = False     # True: the engine also materialises every SURVEY §8(a) boundary (parity tests)
@@ -108,7 +108,7 @@ class Achelous(nn.Module):
             eng = _eng.NativeEngine(_eng.hip_library(), num_det=self.num_det, num_seg=self.num_seg, phi=self.phi,
                                     backbone=self.backbone, resolution=self.resolution, pc_channels=self.pc_channels,
                                     pc_classes=self.pc_classes, num_points=num_points, nano_head=self.nano_head,
-                                    spp=self.spp, dtype=code)
+                                    spp=self.spp, dtype=code, neck=self.neck)
             eng.set_option('full_taps', 1 if self.debug_taps else 0)
             for k, v in self.engine_options.items():
                 eng.set_option(k, int(v))

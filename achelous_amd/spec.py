@@ -169,6 +169,46 @@ def _baseconv(s, pfx, cin, cout, k=1):          # normal_conv.py:36-47
     s.bn(pfx + '.bn', cout)
 
 
+def _csp_bottleneck(s, pfx, cin, cout, expansion=0.5):              # cspdualfpn.py:42-57
+    hidden = int(cout * expansion)
+    _baseconv(s, pfx + '.conv1', cin, hidden)
+    _baseconv(s, pfx + '.conv2', hidden, cout, 3)
+
+
+def _csp_layer(s, pfx, cin, cout):                                  # cspdualfpn.py:60-78, n = 1
+    hidden = int(cout * 0.5)
+    _baseconv(s, pfx + '.conv1', cin, hidden)
+    _baseconv(s, pfx + '.conv2', cin, hidden)
+    _baseconv(s, pfx + '.conv3', 2 * hidden, cout)
+    _csp_bottleneck(s, pfx + '.m.0', hidden, hidden, 1.0)
+
+
+def _neck_csp(s, phi, backbone, num_seg):       # cspdualfpn.py:81-191
+    f = 'image_radar_encoder.fpn'
+    w = WIDTHS[phi]
+    if backbone == 'en':
+        _edgenext(s, f + '.backbone', phi)
+    else:
+        _mobilevit(s, f + '.backbone', phi)
+    c_ = w[3] // 2
+    _baseconv(s, f + '.spp.cv1', w[3], c_)
+    _baseconv(s, f + '.spp.cv2', 4 * c_, w[3])
+    _baseconv(s, f + '.upsample_5_to_4.upsample.0', w[3], w[2])
+    _csp_layer(s, f + '.ghost_5_to_4', 2 * w[2], w[2])
+    _baseconv(s, f + '.upsample_4_to_3.upsample.0', w[2], w[1])
+    _csp_layer(s, f + '.ghost_4_to_3', 2 * w[1], w[1])
+    for sa in ('stage_3_lane_seg', 'stage_3_semantic_seg'):
+        c = w[1] // 8
+        for nm in ('cweight', 'cbias', 'sweight', 'sbias'):
+            s.p(f'{f}.{sa}.{nm}', 1, c, 1, 1)
+        s.ln(f'{f}.{sa}.gn', c)
+    for name, oup in (('lane', 2), ('se', num_seg)):
+        for lvl, cin, cout in (('3_to_2', w[1], w[1]), ('2_to_1', w[1], w[0]), ('1_to_0', w[0], w[0])):
+            _baseconv(s, f'{f}.{name}_seg_{lvl}.upsample.0', cin, cout)
+            _csp_bottleneck(s, f'{f}.{name}_seg_ghost_{lvl}', cout, cout)
+        _csp_bottleneck(s, f'{f}.{name}_seg_head', w[0], oup)
+
+
 def _neck(s, phi, backbone, num_seg):           # ghostdualfpn.py:42-152
     f = 'image_radar_encoder.fpn'
     w = WIDTHS[phi]
@@ -253,13 +293,13 @@ def _head(s, phi, num_det, nano_head):          # decouplehead.py:16-56
 
 
 def state_dict_spec(num_det, num_seg, phi='S0', backbone='en', pc_channels=6, pc_classes=9, nano_head=True,
-                    radar_channels=3):
-    """Ordered [(key, shape, kind)] of the reference state_dict for neck='gdf', pc_seg='pn'."""
-    if phi not in WIDTHS or backbone not in ('en', 'mv'):
-        raise NotImplementedError(f"backbone={backbone!r}, phi={phi!r}: only 'en'/'mv' with S0/S1/S2 are built")
+                    radar_channels=3, neck='gdf'):
+    """Ordered [(key, shape, kind)] of the reference state_dict for neck in {'gdf', 'cdf'}, pc_seg='pn'."""
+    if phi not in WIDTHS or backbone not in ('en', 'mv') or neck not in ('gdf', 'cdf'):
+        raise NotImplementedError(f"backbone={backbone!r}, phi={phi!r}, neck={neck!r}: only 'en'/'mv' with S0/S1/S2 and gdf/cdf are built")
     s = _Spec()
     _pointnet(s, pc_channels, pc_classes)
-    _neck(s, phi, backbone, num_seg)
+    (_neck if neck == 'gdf' else _neck_csp)(s, phi, backbone, num_seg)
     _radar(s, phi, radar_channels)
     _fusion(s, phi)
     _head(s, phi, num_det, nano_head)

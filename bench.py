@@ -35,6 +35,7 @@ CONFIGS = {
     'en_s0': (2, dict(backbone='en', phi='S0')),
     'en_s2': (5, dict(backbone='en', phi='S2')),
     'mv_s2': (3, dict(backbone='mv', phi='S2')),
+    'en_s0_cdf': (6, dict(backbone='en', phi='S0', neck='cdf')),      # SURVEY §8(f) rank 3 (not a BASELINE config)
 }
 COMMON = dict(num_det=7, num_seg=9, resolution=320, neck='gdf', pc_seg='pn', pc_channels=5, pc_classes=8, nano_head=True, spp=True)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
@@ -78,7 +79,7 @@ def main():
 
     cid, kw = CONFIGS[args.config]
     tdt = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
-    model = Achelous(**COMMON, **kw).eval()
+    model = Achelous(**dict(COMMON, **kw)).eval()
     model.load_state_dict(condition_state_dict(model.state_dict(), seed=0))
     model = model.to(dev)
     model.static_weights = True          # serving loop: weights do not change between steps
@@ -190,7 +191,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             from oracle.achelous_oracle import AchelousOracle
             n = max(1, min(args.cpu_sample, B))
-            orc = AchelousOracle({k: v.detach().cpu() for k, v in model.state_dict().items()}, **COMMON, **kw)
+            orc = AchelousOracle({k: v.detach().cpu() for k, v in model.state_dict().items()}, **dict(COMMON, **kw))
             cx, cr, cp = x[:n].float().cpu(), xr[:n].float().cpu(), xp[:n].float().cpu()
             cores = torch.get_num_threads()
             orc.forward(cx[:1], cr[:1], cp[:1])

@@ -47,6 +47,8 @@ enum {
     ACH_ERR_NOMEM = -5
 };
 
+enum { ACH_NECK_GDF = 0, ACH_NECK_CDF = 1 };     /* Ghost-Dual-FPN (neck/ghostdualfpn.py) / CSP-Dual-FPN (neck/cspdualfpn.py) */
+
 typedef struct ach_config {
     int32_t num_det;        /* detection classes           (Achelous.__init__ num_det)      */
     int32_t num_seg;        /* semantic classes            (num_seg)                        */
@@ -59,6 +61,7 @@ typedef struct ach_config {
     int32_t nano_head;      /* 1: 64-channel head          (nano_head)                      */
     int32_t spp;            /* 1: SPP, 0: SPPF             (spp)                            */
     int32_t dtype;          /* ACH_DTYPE_*: storage type of activations, inputs and outputs */
+    int32_t neck;           /* ACH_NECK_*                  (neck in {'gdf','cdf'})           */
 } ach_config;
 
 /* one entry of a reference-keyed state_dict; `data` is HOST memory, fp32, contiguous, reference shape */

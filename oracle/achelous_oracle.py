@@ -37,8 +37,9 @@ MOBILEVIT = {  # backbone/vision/mobilevit_modules/mobilevit.py:225-240
 class AchelousOracle:
     def __init__(self, state_dict, num_det=7, num_seg=9, phi='S0', backbone='en', neck='gdf', pc_seg='pn',
                  pc_channels=5, pc_classes=8, nano_head=True, spp=True, resolution=320):
-        if neck != 'gdf' or backbone not in ('en', 'mv') or pc_seg != 'pn':
-            raise NotImplementedError("oracle covers backbone in {en,mv}, neck=gdf, pc_seg=pn")
+        if neck not in ('gdf', 'cdf') or backbone not in ('en', 'mv') or pc_seg != 'pn':
+            raise NotImplementedError("oracle covers backbone in {en,mv}, neck in {gdf,cdf}, pc_seg=pn")
+        self.neck = neck
         self.sd = {k: (v.detach().to(device='cpu', dtype=torch.float32) if v.is_floating_point() else v.detach().cpu())
                    for k, v in state_dict.items()}
         self.num_det, self.num_seg, self.phi, self.backbone = num_det, num_seg, phi, backbone
@@ -327,6 +328,47 @@ class AchelousOracle:
             outs[name] = self.ghost(y, f'{f}.{name}_seg_head', oup)
         return outs['se'], outs['lane'], (p5 + m5, p4 + m4, p3 + m3)
 
+    # ------------------------------------------------------------------ CSP neck
+    def base_conv_act(self, x, pfx, act, k=1):
+        """BaseConv = conv(k, pad (k-1)//2, no bias) + BN(eps 1e-3) + act (backbone/conv_utils/normal_conv.py:36-47)."""
+        y = self.bn(self.conv(x, pfx + '.conv', pad=(k - 1) // 2), pfx + '.bn', 1e-3)
+        return y * torch.sigmoid(y) if act == 'silu' else F.relu(y)
+
+    def csp_bottleneck(self, x, pfx, cout):
+        """Bottleneck (neck/cspdualfpn.py:42-57): 1x1 (SiLU) -> 3x3 (BaseConv default act = ReLU), + x when in == out."""
+        y = self.base_conv_act(self.base_conv_act(x, pfx + '.conv1', 'silu'), pfx + '.conv2', 'relu', 3)
+        return y + x if x.shape[1] == cout else y
+
+    def csp_layer(self, x, pfx):
+        """CSPLayer, n = 1 (neck/cspdualfpn.py:60-78)."""
+        x1 = self.base_conv_act(x, pfx + '.conv1', 'silu')
+        x2 = self.base_conv_act(x, pfx + '.conv2', 'silu')
+        x1 = self.csp_bottleneck(x1, pfx + '.m.0', x1.shape[1])
+        return self.base_conv_act(torch.cat((x1, x2), 1), pfx + '.conv3', 'silu')
+
+    def csp_dual_fpn(self, x):
+        """CSPDualFPN.forward (neck/cspdualfpn.py:193-237): the GDF graph with CSPLayer / Bottleneck blocks."""
+        f = 'image_radar_encoder.fpn'
+        feats = self.edgenext(x, f + '.backbone') if self.backbone == 'en' else self.mobilevit(x, f + '.backbone')
+        m2, m3, m4, m5 = feats
+        self.taps.update({'map2': m2, 'map3': m3, 'map4': m4, 'map5': m5})
+        p5 = self.spp_block(m5, f + '.spp')
+        self.taps['spp'] = p5
+        p4 = self.csp_layer(torch.cat([self.upsample(p5, f + '.upsample_5_to_4'), m4], 1), f + '.ghost_5_to_4')
+        p3 = self.csp_layer(torch.cat([self.upsample(p4, f + '.upsample_4_to_3'), m3], 1), f + '.ghost_4_to_3')
+        self.taps.update({'fpn4': p4, 'fpn3': p3})
+        outs = {}
+        w = self.w
+        for name, sa, oup in (('lane', 'stage_3_lane_seg', 2), ('se', 'stage_3_semantic_seg', self.num_seg)):
+            y = self.shuffle_attention(p3, f'{f}.{sa}')
+            self.taps[f'{name}.sa'] = y
+            for lvl, c in (('3_to_2', w[1]), ('2_to_1', w[0]), ('1_to_0', w[0])):
+                y = self.upsample(y, f'{f}.{name}_seg_{lvl}')
+                y = self.csp_bottleneck(y, f'{f}.{name}_seg_ghost_{lvl}', c)
+                self.taps[f'{name}.{lvl}'] = y
+            outs[name] = self.csp_bottleneck(y, f'{f}.{name}_seg_head', oup)
+        return outs['se'], outs['lane'], (p5 + m5, p4 + m4, p3 + m3)
+
     # ------------------------------------------------------------------ radar branch (a14-a15)
     def rc_block(self, x, pfx, down):
         """RCBlock / RadarConv / DeformableConv2d (backbone/radar/RadarEncoder.py:38-74, conv_utils/dcn.py:49-63)."""
@@ -418,7 +460,7 @@ class AchelousOracle:
         """Achelous.forward (nets/Achelous.py:49-53)."""
         self.taps = {}
         pc = self.pointnet(x_pc.float())
-        se, lane, (q5, q4, q3) = self.ghost_dual_fpn(x.float())
+        se, lane, (q5, q4, q3) = self.ghost_dual_fpn(x.float()) if self.neck == 'gdf' else self.csp_dual_fpn(x.float())
         r3, r4, r5 = self.rcnet(x_radar.float())
         self.taps.update({'q5': q5, 'q4': q4, 'q3': q3, 'r3': r3, 'r4': r4, 'r5': r5})
         p3, p4, p5 = self.fuse(q3, r3, 3), self.fuse(q4, r4, 4), self.fuse(q5, r5, 5)

@@ -16,7 +16,7 @@ copied and never travel to the GPU box.  For each BASELINE.json model config it
   6. writes `<config>.npz` (full tensors when small, otherwise seeded index samples + checksums) and
      `<config>.keys.json` (state-dict key list + shapes — the drop-in contract).
 
-Usage:  python tests/golden/gen_golden.py [en_s0 en_s2 mv_s2]
+Usage:  python tests/golden/gen_golden.py [en_s0 en_s2 mv_s2 en_s0_cdf]
 """
 import json
 import os
@@ -37,6 +37,7 @@ CONFIGS = {   # name -> (config id in BASELINE.json, ctor kwargs)
     'en_s0': (2, dict(backbone='en', phi='S0')),
     'en_s2': (5, dict(backbone='en', phi='S2')),
     'mv_s2': (3, dict(backbone='mv', phi='S2')),
+    'en_s0_cdf': (6, dict(backbone='en', phi='S0', neck='cdf')),     # CSP-Dual-FPN neck (not a BASELINE config)
 }
 COMMON = dict(num_det=7, num_seg=9, resolution=320, neck='gdf', pc_seg='pn', pc_channels=5, pc_classes=8,
               nano_head=True, spp=True)
@@ -92,7 +93,7 @@ def run_config(name):
     from nets.Achelous import Achelous            # the reference (never copied)
     import utils.utils_bbox as ref_bbox
     torch.manual_seed(0)
-    model = Achelous(**COMMON, **kw).eval()
+    model = Achelous(**dict(COMMON, **kw)).eval()
     sd0 = model.state_dict()
     sd = condition_state_dict(sd0, seed=WEIGHT_SEED)
     model.load_state_dict(sd, strict=True)
@@ -120,7 +121,7 @@ def run_config(name):
                      'lane_seg': lane.contiguous(), 'pc_seg': pc})
 
     # ---- pin the oracle against the reference -------------------------------------------------------
-    orc = AchelousOracle(sd, **COMMON, **kw)
+    orc = AchelousOracle(sd, **dict(COMMON, **kw))
     odet, ose, olane, opc = orc.forward(x, xr, xp)
     otaps = dict(orc.taps)
     otaps.update({'det0': odet[0], 'det1': odet[1], 'det2': odet[2], 'se_seg': ose, 'lane_seg': olane, 'pc_seg': opc})

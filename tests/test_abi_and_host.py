@@ -40,11 +40,11 @@ def test_hip_library_exports_every_declared_symbol():
                              num_points=512, nano_head=False, spp=True, dtype=0)
 
 
-@pytest.mark.parametrize('name', ['en_s0', 'en_s2', 'mv_s2'])
+@pytest.mark.parametrize('name', ['en_s0', 'en_s2', 'mv_s2', 'en_s0_cdf'])
 def test_state_dict_contract(name):
     meta = json.load(open(os.path.join(REPO, 'tests', 'golden', name + '.keys.json')))
     c = meta['ctor']
-    spec = state_dict_spec(c['num_det'], c['num_seg'], c['phi'], c['backbone'], c['pc_channels'], c['pc_classes'], c['nano_head'])
+    spec = state_dict_spec(c['num_det'], c['num_seg'], c['phi'], c['backbone'], c['pc_channels'], c['pc_classes'], c['nano_head'], 3, c['neck'])
     assert [(k, list(s)) for k, s, _ in spec] == [(k, s) for k, s, _ in meta['keys']]
     m = achelous_amd.Achelous(**{k: c[k] for k in ('num_det', 'num_seg', 'phi', 'resolution', 'backbone', 'neck', 'pc_seg',
                                                    'pc_channels', 'pc_classes', 'nano_head', 'spp')})
@@ -65,7 +65,7 @@ def test_drop_in_module_protocols():
         child.deploy = True
     with pytest.raises(RuntimeError):           # no CPU path
         m(torch.zeros(1, 3, 320, 320), torch.zeros(1, 3, 320, 320), torch.zeros(1, 5, 512))
-    for bad in (dict(neck='cdf'), dict(backbone='ef'), dict(pc_seg='pn2'), dict(phi='L'), dict(nano_head=False)):
+    for bad in (dict(neck='rdf'), dict(backbone='ef'), dict(pc_seg='pn2'), dict(phi='L'), dict(nano_head=False)):
         kw = dict(num_det=7, num_seg=9, phi='S0', resolution=320, backbone='en', neck='gdf', pc_seg='pn', pc_channels=5,
                   pc_classes=8, nano_head=True)
         kw.update(bad)

@@ -30,7 +30,8 @@ def _setup(name, res, batch, npts, seed=7):
 
 
 @pytest.mark.parametrize('name,res,batch,dtype,tol', [('en_s0', 64, 2, DTYPE_F32, 2e-5), ('en_s2', 64, 1, DTYPE_F32, 2e-5),
-                                                     ('en_s0', 96, 1, DTYPE_BF16, 6e-2), ('mv_s2', 64, 1, DTYPE_F32, 2e-5)])
+                                                     ('en_s0', 96, 1, DTYPE_BF16, 6e-2), ('mv_s2', 64, 1, DTYPE_F32, 2e-5),
+                                                     ('en_s0_cdf', 64, 1, DTYPE_F32, 2e-5), ('en_s0_cdf', 96, 1, DTYPE_BF16, 6e-2)])
 def test_emulated_forward_matches_oracle(name, res, batch, dtype, tol):
     npts = 48
     kw, sd, (x, xr, xp) = _setup(name, res, batch, npts)

@@ -45,7 +45,7 @@ def test_native_library_is_loaded():
         assert 'libachelous_hip.so' in f.read()
 
 
-@pytest.mark.parametrize('name', ['en_s0', 'en_s2', 'mv_s2'])
+@pytest.mark.parametrize('name', ['en_s0', 'en_s2', 'mv_s2', 'en_s0_cdf'])
 def test_forward_fp32_matches_reference_fixtures(name):
     g = Golden(name)
     m, kw = _model(g.meta, debug_taps=True)
@@ -87,7 +87,7 @@ def test_forward_fp32_matches_oracle_full_tensors():
             assert _rel(e.read_tap(tap), orc.taps[tap]) < F32_TOL, tap
 
 
-@pytest.mark.parametrize('name', ['en_s0', 'mv_s2'])
+@pytest.mark.parametrize('name', ['en_s0', 'mv_s2', 'en_s0_cdf'])
 def test_forward_bf16_matches_reference_fixtures(name):
     g = Golden(name)
     m, kw = _model(g.meta)
