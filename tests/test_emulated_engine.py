@@ -152,3 +152,17 @@ def test_emulated_nms_more_candidates_than_fit_in_lds():
     assert k == len(exp[0][1]) and k > 2112
     assert np.array_equal(idx[0, :k].numpy().astype(np.int64), exp[0][1])
     assert np.array_equal(rows[0, :k].numpy(), exp[0][0])
+
+
+def test_emulated_sppf_variant():
+    """spp=False builds SPPF (neck/spp.py:55-67): three chained 5x5 max pools = the 5 / 9 / 13 windows of the SPP kernel.  The oracle
+    restates the chained form (checked once against the imported reference, 1e-6); the engine must agree with it."""
+    kw, sd, (x, xr, xp) = _setup('en_s0', 160, 1, 16)
+    kw = dict(kw, spp=False)
+    orc = AchelousOracle(sd, **{k: kw[k] for k in ORACLE_KEYS})
+    det, se, lane, pc = orc.forward(x, xr, xp)
+    eng = make_engine(emu_library(), kw, 1, sd, 16, DTYPE_F32, full_taps=False)
+    outs = alloc_outputs(kw, 1, 16, torch.float32, 'cpu')
+    eng.forward(x, xr, xp, outs)
+    for a, b in zip(outs, (*det, se, lane, pc)):
+        assert rel_err(a, b) < 2e-5
