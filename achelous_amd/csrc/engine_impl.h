@@ -702,6 +702,22 @@ public:
         { GemmOpt o; o.act = ACT_SILU; gemm(pfx + ".conv1", x, pack(l1), t, o); }
         Lin l2 = base_conv3(pfx + ".conv2", l1.N, int(t.ld));
         if (l2.N != cout) throw AchError{ACH_ERR_MISSING_KEY, "bottleneck width at " + pfx};
+        // 25..32 outputs from <= 32 inputs (the full-resolution decoder levels): row-walking kernel on the dense map (k_conv3.h)
+        {
+            const int cv = int(t.ld) / VEC, ks = cdiv(9 * cv, 4);
+            Packed pk = pack(l2);
+            if (row_conv && !user_out && dst && dst->ld == 32 && t.ld % VEC == 0 && (ks == 3 || ks == 5 || ks == 9) && pk.NT == 2 && pk.nchunks == 1 && pk.ksteps == ks &&
+                (x.C != cout || x.ld % 8 == 0)) {
+                std::vector<float> b32(32, 0.f);
+                for (int n = 0; n < l2.N; ++n) b32[n] = l2.b[n];
+                const bool res = x.C == cout;
+                Conv3Params cp{t.p, t.ld, long(t.W) * t.ld, long(t.H) * t.W * t.ld, dst->p, dst->ld, pk.w, up_f32(b32), t.B, t.H, t.W, cv, ACT_RELU, 1,
+                               res ? x.p : nullptr, res ? x.ld : 0};
+                const double bytes = double(t.rows()) * (t.ld + dst->ld * (res ? 2 : 1)) * sizeof(T);
+                add_op(pfx + ".conv2", [cp, ks](hipStream_t s) { launch_conv3<T>(cp, ks, 2, 1, s); }, bytes, 2.0 * double(t.rows()) * l2.K * l2.N);
+                return;
+            }
+        }
         GemmOpt o; o.act = ACT_RELU; o.residual = (x.C == cout) ? &x : nullptr;
         o.conv_k = 3; o.conv_s = 1; o.conv_p = 1; o.Hin = x.H; o.Win = x.W; o.Cin = int(t.ld); o.Ho = x.H; o.Wo = x.W;
         if (user_out) {
@@ -940,7 +956,7 @@ public:
         if (row_conv && shape_ok && (ks == 3 || ks == 5 || ks == 9) && pk.nchunks == 1 && pk.ksteps == ks) {
             std::vector<float> b32(32, 0.f);
             for (int n = 0; n < l.N; ++n) b32[n] = l.b[n];
-            Conv3Params cp{x.p0, x.ld, x.row, x.img, y.p, y.ld, pk.w, up_f32(b32), x.B, Ho, Wo, cv, act};
+            Conv3Params cp{x.p0, x.ld, x.row, x.img, y.p, y.ld, pk.w, up_f32(b32), x.B, Ho, Wo, cv, act, 0, nullptr, 0};
             const int NT = pk.NT;
             add_op(name, [cp, ks, NT, stride](hipStream_t s) { launch_conv3<T>(cp, ks, NT, stride, s); }, bytes, 2.0 * double(y.rows()) * l.K * l.N);
             return y;

@@ -22,6 +22,8 @@ struct Conv3Params {
     void* Y; long ldy;              // NHWC output [B,H,W,ldy], ldy >= 32
     const void* W; const float* bias;   // packed NT = 2, one chunk, KS k-steps ; bias[32]
     int B, H, Wd, cv, act;
+    int dense;                      // 1: X is a plain dense NHWC map (no border): taps outside the map are masked instead (stride 1 only)
+    const void* R; long ldr;        // optional residual added after the activation, same pixel layout as Y (nullptr: none)
 };
 
 // NT = 1: up to 16 outputs (one 8-byte store per lane); NT = 2: up to 32.  STRIDE 1 or 2 (H, Wd are the OUTPUT map; the input is
@@ -35,7 +37,8 @@ __global__ __launch_bounds__(256) void conv3x3_rows_kernel(const Conv3Params p) 
     const int b = int(wg / unsigned(p.H)), oy = int(wg - unsigned(b) * unsigned(p.H));
     const int ldx = int(p.ldx);
 
-    int off[KS];
+    int off[KS], dxs[KS];
+    bool rowok[KS];
     ACH_UNROLL
     for (int s = 0; s < KS; ++s) {
         const int q = 4 * s + g;
@@ -43,6 +46,9 @@ __global__ __launch_bounds__(256) void conv3x3_rows_kernel(const Conv3Params p) 
         const int ty = tap / 3, tx = tap - 3 * ty;
         // k-slots past the ninth tap: zero weights, but keep the address in bounds
         off[s] = tap < 9 ? (ty - 1) * int(p.xpr) + (tx - 1) * ldx + c * VEC : 0;
+        dxs[s] = tap < 9 ? tx - 1 : 0;
+        const int iy = oy + ty - 1;
+        rowok[s] = tap >= 9 || (iy >= 0 && iy < p.H);                 // dense input only
     }
     const uint4* Wf = static_cast<const uint4*>(p.W) + lane;
     uint4 wf[KS][NT];
@@ -64,7 +70,16 @@ __global__ __launch_bounds__(256) void conv3x3_rows_kernel(const Conv3Params p) 
         const T* xp = xrow + long(x) * STRIDE * ldx;
         uint4 xf[KS];
         ACH_UNROLL
-        for (int s = 0; s < KS; ++s) xf[s] = *reinterpret_cast<const uint4*>(xp + off[s]);
+        for (int s = 0; s < KS; ++s) {
+            if (p.dense) {                                             // masked taps read the centre pixel (in bounds) and are zeroed
+                const int ix = x + dxs[s];
+                const bool ok = rowok[s] && ix >= 0 && ix < p.Wd;
+                const uint4 v = *reinterpret_cast<const uint4*>(ok ? xp + off[s] : xp);
+                xf[s] = make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
+            } else {
+                xf[s] = *reinterpret_cast<const uint4*>(xp + off[s]);
+            }
+        }
         f32x4 acc[NT];
         ACH_UNROLL
         for (int t = 0; t < NT; ++t) { acc[t][0] = 0.f; acc[t][1] = 0.f; acc[t][2] = 0.f; acc[t][3] = 0.f; }
@@ -77,6 +92,12 @@ __global__ __launch_bounds__(256) void conv3x3_rows_kernel(const Conv3Params p) 
             float o[8];
             ACH_UNROLL
             for (int r = 0; r < 4; ++r) { o[r] = apply_act_t<T>(acc[0][r] + bv[r], p.act); o[4 + r] = apply_act_t<T>(acc[NT - 1][r] + bv[4 * (NT - 1) + r], p.act); }
+            if (p.R) {
+                float r8[8];
+                Store<T>::ld8(static_cast<const T*>(p.R) + ((long(b) * p.H + oy) * p.Wd + x) * p.ldr + g * 8, r8);
+                ACH_UNROLL
+                for (int i = 0; i < 8; ++i) o[i] += r8[i];
+            }
             Store<T>::st8(yrow + long(x) * p.ldy, o);
         } else {
             float o[4];
