@@ -235,6 +235,20 @@ __device__ __forceinline__ float row16_max(float v) {
 }
 #endif
 
+// wave-uniform max of a float / broadcast of one lane's float (lane must be wave-uniform)
+#if defined(ACH_HOSTEMU)
+__device__ inline float wave_max_f32(float v) { v = row16_max(v); v = fmaxf(v, __shfl_xor(v, 16)); return fmaxf(v, __shfl_xor(v, 32)); }
+__device__ inline float wave_lane_f32(float v, int lane) { return __shfl(v, lane); }
+#else
+__device__ __forceinline__ float wave_lane_f32(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), __builtin_amdgcn_readfirstlane(lane)));
+}
+__device__ __forceinline__ float wave_max_f32(float v) {
+    v = row16_max(v);
+    return fmaxf(fmaxf(wave_lane_f32(v, 0), wave_lane_f32(v, 16)), fmaxf(wave_lane_f32(v, 32), wave_lane_f32(v, 48)));
+}
+#endif
+
 // ---------------------------------------------------------------------------------------- activations
 // v_rcp_f32 / v_exp_f32 based (1 ulp): the IEEE-exact division and expf expansions cost ~10 VALU instructions each and sit
 // in the epilogue of bandwidth-bound kernels (measured: +28 us on a 47 us GEMM for GELU with the exact forms)

@@ -39,6 +39,7 @@ int ach_create(const ach_config* cfg, ach_handle** out) {
             throw ach::AchError{ACH_ERR_UNSUPPORTED, "backbone must be 'en' or 'mv'"};
         if (cfg->phi < ACH_PHI_S0 || cfg->phi > ACH_PHI_S2) throw ach::AchError{ACH_ERR_UNSUPPORTED, "phi must be S0, S1 or S2"};
         if (cfg->neck != ACH_NECK_GDF && cfg->neck != ACH_NECK_CDF) throw ach::AchError{ACH_ERR_UNSUPPORTED, "neck must be 'gdf' or 'cdf'"};
+        if (cfg->pc_seg != ACH_PCSEG_PN && cfg->pc_seg != ACH_PCSEG_PN2) throw ach::AchError{ACH_ERR_UNSUPPORTED, "pc_seg must be 'pn' or 'pn2'"};
         if (!cfg->nano_head) throw ach::AchError{ACH_ERR_UNSUPPORTED, "only nano_head=True is built"};
         if (cfg->num_det < 1 || cfg->num_det > 59 || cfg->num_seg < 1 || cfg->pc_classes < 1 || cfg->pc_channels < 3)
             throw ach::AchError{ACH_ERR_INVALID, "bad class / channel counts"};

@@ -248,7 +248,7 @@ void EngineBase::read_tap(const std::string& name, float* out, size_t cap) {
     auto it = taps.find(name);
     if (it == taps.end()) throw AchError{ACH_ERR_INVALID, "unknown tap: " + name};
     const TapInfo& t = it->second;
-    const bool bf = cfg.dtype == ACH_DTYPE_BF16 && !t.is_f32;
+    const bool bf = cfg.dtype == ACH_DTYPE_BF16 && !t.is_f32 && !t.is_i32;
     const size_t esz = bf ? 2 : 4;
     ACH_HIP_CHECK(hipDeviceSynchronize());
     auto fetch = [&](size_t elems) {
@@ -256,6 +256,7 @@ void EngineBase::read_tap(const std::string& name, float* out, size_t cap) {
         ACH_HIP_CHECK(hipMemcpy(raw.data(), t.ptr, raw.size(), hipMemcpyDeviceToHost));
         std::vector<float> f(elems);
         if (bf) for (size_t i = 0; i < elems; ++i) { uint16_t b; std::memcpy(&b, &raw[i * 2], 2); f[i] = bf16_to_f32(b); }
+        else if (t.is_i32) for (size_t i = 0; i < elems; ++i) { int32_t v; std::memcpy(&v, &raw[i * 4], 4); f[i] = float(v); }
         else std::memcpy(f.data(), raw.data(), elems * 4);
         return f;
     };

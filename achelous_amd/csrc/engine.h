@@ -29,6 +29,7 @@ struct TapInfo {
     int B = 0, H = 0, W = 0, C = 0;
     long ld = 0;
     int is_f32 = 0;               // buffer holds fp32 regardless of the engine dtype
+    int is_i32 = 0;               // buffer holds int32 (index selections); read back as exact floats
     int add_eye = 0;              // rows kind: add identity of this size (PointNet transforms are stored without +I)
 };
 

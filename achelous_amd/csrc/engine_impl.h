@@ -14,6 +14,7 @@
 #include "k_mvit.h"
 #include "k_nhwc.h"
 #include "k_points.h"
+#include "k_pn2.h"
 #include "k_prepost.h"
 #include "k_radar.h"
 #include "k_xca.h"
@@ -1201,7 +1202,7 @@ public:
         Packed pk = pack(l);
         Rows y = alloc_rows(B, l.N);
         GemmMaxParams g{x.p, x.ld, pk.w, pk.b, y.p, y.ld, int(x.rows / B), B, pk.K, pk.N, pk.nchunks, pk.ksteps, act};
-        const dim3 grid(unsigned(pk.nchunks), unsigned(B)), block(256);
+        const dim3 grid(unsigned(pk.nchunks) * unsigned(B)), block(256);
         const int NT = pk.NT;
         const double bytes = double(x.rows) * pk.K * sizeof(T) + double(pk.group_elems) * sizeof(T) + double(B) * pk.N * sizeof(T);
         add_op(name, [g, grid, block, NT](hipStream_t s) {
@@ -1266,6 +1267,92 @@ public:
         }
     }
 
+    // ------------------------------------------------------------------------------------------ PointNet++ (config 4)
+    // OUR OWN specification (spec.py::PN2): the reference snapshot has no PointNet++ code.  Geometry in
+    // k_pn2.h (fp32 coordinates, bit-exact index selection); every shared MLP on the MFMA GEMM with (centroid, sample) pairs or
+    // points as rows; the max over a ball in the last layer's epilogue.
+    struct Pn2Level { float* xyz = nullptr; int n = 0; Rows f; };
+    void pointnet2() {
+        const std::string p = "pc_seg_model";
+        const int B = batch, N = cfg.num_points, D = cfg.pc_channels;
+        static const int kDiv[4] = {2, 8, 32, 128};
+        static const double kRadius[4] = {0.03, 0.06, 0.12, 0.24};
+        static const int kNs = 32;
+        static const int kFpLayers[4] = {2, 2, 2, 3};                             // fp4, fp3, fp2, fp1
+        if (N % 128 || N > 64 * PN2_FPS_MAX_PPT) throw AchError{ACH_ERR_UNSUPPORTED, "pn2: num_points must be a multiple of 128, at most 1024"};
+        if (D < 3) throw AchError{ACH_ERR_UNSUPPORTED, "pn2: pc_channels must be at least 3 (xyz first)"};
+        Pn2Level lv[5];
+        lv[0].n = N; lv[0].f = alloc_rows(long(B) * N, D);
+        {
+            PcPrepParams pp{nullptr, lv[0].f.p, B, D, N, lv[0].f.ld};
+            const dim3 grid(unsigned(cdivl(long(B) * N * lv[0].f.ld, 256))), block(256);
+            const void** pin = &io.points;
+            add_op(p + ".prep", [pp, grid, block, pin](hipStream_t s) mutable { pp.X = *pin; ACH_LAUNCH(pc_prep_kernel<T>, grid, block, s, pp); });
+        }
+        lv[0].xyz = static_cast<float*>(aalloc(size_t(B) * N * 3 * sizeof(float)));
+        { Pn2XyzParams q{lv[0].f.p, lv[0].f.ld, lv[0].xyz, long(B) * N}; ew(p + ".xyz", pn2_xyz_kernel<T>, q, long(B) * N * 3); }
+        for (int k = 0; k < 4; ++k) {
+            const std::string sa = p + ".sa" + std::to_string(k + 1);
+            const Pn2Level& src = lv[k];
+            Pn2Level& dst = lv[k + 1];
+            const int S = N / kDiv[k];
+            dst.n = S;
+            dst.xyz = static_cast<float*>(aalloc(size_t(B) * S * 3 * sizeof(float)));
+            int* fidx = static_cast<int*>(aalloc(size_t(B) * S * sizeof(int)));
+            {
+                FpsParams q{src.xyz, src.n, S, fidx, dst.xyz};
+                add_op(sa + ".fps", [q, B](hipStream_t s) { launch_pn2_fps(q, B, s); },
+                       double(B) * (src.n + S) * 12.0);
+            }
+            { TapInfo t; t.ptr = dst.xyz; t.kind = 2; t.is_f32 = 1; t.B = B * S; t.H = 1; t.W = 1; t.C = 3; t.ld = 3; add_tap("pc.sa" + std::to_string(k + 1) + ".xyz", t); }
+            { TapInfo t; t.ptr = fidx; t.kind = 2; t.is_i32 = 1; t.B = B; t.H = 1; t.W = 1; t.C = S; t.ld = S; add_tap("pc.sa" + std::to_string(k + 1) + ".fps", t); }
+            Rows g = alloc_rows(long(B) * S * kNs, 3 + src.f.C);
+            int* gidx = nullptr;
+            if (full_taps) {                                                      // parity hook: the ball-query selections themselves
+                gidx = static_cast<int*>(aalloc(size_t(B) * S * kNs * sizeof(int)));
+                TapInfo t; t.ptr = gidx; t.kind = 2; t.is_i32 = 1; t.B = B * S; t.H = 1; t.W = 1; t.C = kNs; t.ld = kNs; add_tap("pc.sa" + std::to_string(k + 1) + ".group_idx", t);
+            }
+            {
+                GroupParams q{src.xyz, dst.xyz, src.f.p, src.f.ld, src.f.C, g.p, g.ld, gidx, B, src.n, S, kNs, float(kRadius[k] * kRadius[k])};
+                const dim3 grid(unsigned(cdivl(long(B) * S, 4))), block(256);
+                add_op(sa + ".group", [q, grid, block](hipStream_t s) { ACH_LAUNCH(pn2_group_kernel<T>, grid, block, s, q); },
+                       double(g.rows) * g.C * sizeof(T) * 2.0);
+            }
+            Rows h = pc_layer(sa + ".mlp.0", g, lin_bn1d(sa + ".mlp_convs.0", sa + ".mlp_bns.0"), ACT_RELU);
+            h = pc_layer(sa + ".mlp.1", h, lin_bn1d(sa + ".mlp_convs.1", sa + ".mlp_bns.1"), ACT_RELU);
+            dst.f = pc_layer_max(sa + ".mlp.2", h, lin_bn1d(sa + ".mlp_convs.2", sa + ".mlp_bns.2"), ACT_RELU, B * S);
+            { TapInfo t; t.ptr = dst.f.p; t.kind = 2; t.B = B * S; t.H = 1; t.W = 1; t.C = dst.f.C; t.ld = dst.f.ld; add_tap("pc.sa" + std::to_string(k + 1) + ".feat", t); }
+        }
+        Rows cur = lv[4].f;
+        for (int j = 0; j < 4; ++j) {
+            const int lvl = 3 - j;                                                // dense level
+            const std::string fp = p + ".fp" + std::to_string(lvl + 1);
+            const Pn2Level& dn = lv[lvl];
+            const Pn2Level& sp = lv[lvl + 1];
+            if (sp.n < 3 || sp.n > 64 * PN2_INTERP_SPL) throw AchError{ACH_ERR_UNSUPPORTED, "pn2: level size outside the interpolation kernel's range"};
+            const int C1 = lvl > 0 ? dn.f.C : 0;
+            Rows cat = alloc_rows(long(B) * dn.n, C1 + cur.C);
+            {
+                InterpParams q{dn.xyz, sp.xyz, dn.f.p, dn.f.ld, C1, cur.p, cur.ld, cur.C, cat.p, cat.ld, B, dn.n, sp.n};
+                const dim3 grid(unsigned(cdivl(long(B) * dn.n, 4))), block(256);
+                add_op(fp + ".interp", [q, grid, block](hipStream_t s) { ACH_LAUNCH(pn2_interp_kernel<T>, grid, block, s, q); },
+                       double(cat.rows) * cat.C * sizeof(T) * 2.0);
+            }
+            cur = cat;
+            for (int i = 0; i < kFpLayers[j]; ++i)
+                cur = pc_layer(fp + ".mlp." + std::to_string(i), cur, lin_bn1d(fp + ".mlp_convs." + std::to_string(i), fp + ".mlp_bns." + std::to_string(i)), ACT_RELU);
+            { TapInfo t; t.ptr = cur.p; t.kind = 2; t.B = B * dn.n; t.H = 1; t.W = 1; t.C = cur.C; t.ld = cur.ld; add_tap("pc.fp" + std::to_string(lvl + 1), t); }
+        }
+        Rows y = pc_layer(p + ".conv1", cur, lin_bn1d(p + ".conv1", p + ".bn1"), ACT_RELU);
+        y = pc_layer(p + ".conv2", y, lin_bn1d(p + ".conv2", ""), ACT_NONE);
+        {
+            LsmParams q{y.p, y.ld, nullptr, long(B) * N, cfg.pc_classes};
+            const dim3 grid(unsigned(cdivl(long(B) * N, 256))), block(256);
+            void** out = &io.pc;
+            add_op(p + ".log_softmax", [q, grid, block, out](hipStream_t s) mutable { q.Y = *out; ACH_LAUNCH(log_softmax_kernel<T>, grid, block, s, q); });
+        }
+    }
+
     // ------------------------------------------------------------------------------------------ plan (a1)
     void build() {
         if (cfg.resolution % 32 || cfg.resolution < 64) throw AchError{ACH_ERR_INVALID, "resolution must be a multiple of 32"};
@@ -1276,7 +1363,7 @@ public:
         rcnet(r);
         signal_after_last(3);             // radar pyramid ready
         cur_stream = head_stream ? 1 : 2; // "head_stream": the point branch queues behind the radar branch on the low-priority stream
-        pointnet();
+        if (cfg.pc_seg == ACH_PCSEG_PN2) pointnet2(); else pointnet();
         cur_stream = 0;
         A m[4];
         cat_buf[0] = A(); cat_buf[1] = A();

@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256) void gemm_colmax_kernel(const GemmMaxParams p)
     __shared__ float red[4][16 * NT];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int px = lane & 15, g = lane >> 4;
-    const int c = blockIdx.x, grp = blockIdx.y;
+    const int c = int(blockIdx.x % unsigned(p.nchunks)), grp = int(blockIdx.x / unsigned(p.nchunks));      // flat grid: groups can exceed 65535
     const T* X = static_cast<const T*>(p.X) + long(grp) * p.M_per_group * p.ldx;
     const uint4* Wf = reinterpret_cast<const uint4*>(p.W) + long(c) * p.ksteps * NT * 64 + lane;
     float bv[4 * NT], cm[4 * NT];

@@ -16,13 +16,14 @@ DTYPE_F32, DTYPE_BF16 = 0, 1
 BACKBONES = {'en': 0, 'mv': 1}
 PHIS = {'S0': 0, 'S1': 1, 'S2': 2}
 NECKS = {'gdf': 0, 'cdf': 1}
+PC_SEGS = {'pn': 0, 'pn2': 1}
 
 _ERRORS = {-1: ValueError, -2: NotImplementedError, -3: KeyError, -4: RuntimeError, -5: MemoryError}
 
 
 class AchConfig(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in ('num_det', 'num_seg', 'phi', 'backbone', 'resolution', 'pc_channels',
-                                              'pc_classes', 'num_points', 'nano_head', 'spp', 'dtype', 'neck')]
+                                              'pc_classes', 'num_points', 'nano_head', 'spp', 'dtype', 'neck', 'pc_seg')]
 
 
 class AchTensorDesc(ctypes.Structure):
@@ -122,11 +123,11 @@ class NativeEngine:
     """One ach_handle: a (config, dtype) specialisation of the forward engine on the current device."""
 
     def __init__(self, lib, *, num_det, num_seg, phi, backbone, resolution, pc_channels, pc_classes, num_points,
-                 nano_head, spp, dtype, neck='gdf'):
+                 nano_head, spp, dtype, neck='gdf', pc_seg='pn'):
         self.lib = lib
         self.L = lib.lib
         self.cfg = AchConfig(num_det, num_seg, PHIS[phi], BACKBONES[backbone], resolution, pc_channels, pc_classes,
-                             num_points, int(bool(nano_head)), int(bool(spp)), dtype, NECKS[neck])
+                             num_points, int(bool(nano_head)), int(bool(spp)), dtype, NECKS[neck], PC_SEGS[pc_seg])
         self.dtype = dtype
         self.torch_dtype = torch.float32 if dtype == DTYPE_F32 else torch.bfloat16
         self.h = ctypes.c_void_p()

@@ -43,10 +43,10 @@ class Achelous(nn.Module):
             raise NotImplementedError(f"neck={neck!r}: the Ghost-Dual-FPN ('gdf') and CSP-Dual-FPN ('cdf') are built (SURVEY.md §2.1 rows 18-19)")
         if backbone not in ('en', 'mv'):
             raise NotImplementedError(f"backbone={backbone!r}: only EdgeNeXt ('en') and MobileViT ('mv') are in scope")
-        if pc_seg != 'pn':
-            raise NotImplementedError(
-                f"pc_seg={pc_seg!r}: the reference snapshot contains no PointNet++ implementation "
-                "(nets/Achelous.py:31-32 only builds 'pn'; its own forward raises for anything else)")
+        if pc_seg not in ('pn', 'pn2'):
+            raise NotImplementedError(f"pc_seg={pc_seg!r}: 'pn' and 'pn2' are built")
+        # 'pn2': the reference snapshot contains no PointNet++ implementation (nets/Achelous.py:31-32 only builds 'pn'; its own
+        # forward raises for anything else).  Ours follows our own specification of that branch: achelous_amd/spec.py::PN2.
         if phi not in ('S0', 'S1', 'S2'):
             raise NotImplementedError(f"phi={phi!r}: only S0, S1, S2 exist for the en/mv backbones")
         if not nano_head:
@@ -57,7 +57,7 @@ class Achelous(nn.Module):
         self.phi, self.image_channels, self.radar_channels = phi, image_channels, radar_channels
         self.backbone, self.neck, self.pc_seg_kind = backbone, neck, pc_seg
         self.pc_channels, self.pc_classes, self.nano_head, self.spp = pc_channels, pc_classes, nano_head, spp
-        _build_tree(self, state_dict_spec(num_det, num_seg, phi, backbone, pc_channels, pc_classes, nano_head, radar_channels, neck))
+        _build_tree(self, state_dict_spec(num_det, num_seg, phi, backbone, pc_channels, pc_classes, nano_head, radar_channels, neck, pc_seg))
         self._init_like_reference()
         self._engines = {}          # (device index, dtype) -> [NativeEngine, weight version, num_points]
         self.debug_taps = False     # True: the engine also materialises every SURVEY §8(a) boundary (parity tests)
@@ -108,7 +108,7 @@ class Achelous(nn.Module):
             eng = _eng.NativeEngine(_eng.hip_library(), num_det=self.num_det, num_seg=self.num_seg, phi=self.phi,
                                     backbone=self.backbone, resolution=self.resolution, pc_channels=self.pc_channels,
                                     pc_classes=self.pc_classes, num_points=num_points, nano_head=self.nano_head,
-                                    spp=self.spp, dtype=code, neck=self.neck)
+                                    spp=self.spp, dtype=code, neck=self.neck, pc_seg=self.pc_seg_kind)
             eng.set_option('full_taps', 1 if self.debug_taps else 0)
             for k, v in self.engine_options.items():
                 eng.set_option(k, int(v))

@@ -72,6 +72,47 @@ def _pointnet(s, pc_channels, pc_classes):      # pointnet_sem_seg.py:13-24, poi
         s.bn(f'{p}.bn{i}', c)
 
 
+# PointNet++ branch (`pc_seg='pn2'`): OUR OWN specification - the reference snapshot has no PointNet++ code (SURVEY.md top;
+# nets/Achelous.py:31-32 builds only 'pn').  Structure and key names follow the published single-scale-grouping semantic
+# segmentation model of the public Pointnet_Pointnet2_pytorch project (sa1-4 / fp4-1 / conv1 / bn1 / conv2, with its channel
+# widths), re-sized to the 512-point clouds of this path: level k keeps N / div points, 32 samples per ball, radii in the units
+# of the column-normalised cloud (achelous.py:240).  Geometry rules (FPS start, distance form, tie-breaks): DESIGN.md section 9.
+PN2 = dict(
+    sa=[dict(div=2, radius=0.03, nsample=32, mlp=[32, 32, 64]),
+        dict(div=8, radius=0.06, nsample=32, mlp=[64, 64, 128]),
+        dict(div=32, radius=0.12, nsample=32, mlp=[128, 128, 256]),
+        dict(div=128, radius=0.24, nsample=32, mlp=[256, 256, 512])],
+    fp=[[256, 256], [256, 256], [256, 128], [128, 128, 128]],          # fp4, fp3, fp2, fp1
+    head=128,
+)
+
+
+def _pointnet2(s, pc_channels, pc_classes):
+    p = 'pc_seg_model'
+    feat = [pc_channels] + [lvl['mlp'][-1] for lvl in PN2['sa']]        # feature width at l0 .. l4
+    for k, lvl in enumerate(PN2['sa']):
+        cin = feat[k] + 3
+        for i, c in enumerate(lvl['mlp']):
+            s.wb(f'{p}.sa{k + 1}.mlp_convs.{i}', (c, cin, 1, 1))
+            cin = c
+        for i, c in enumerate(lvl['mlp']):
+            s.bn(f'{p}.sa{k + 1}.mlp_bns.{i}', c)
+    cur = feat[-1]
+    L = len(PN2['sa'])
+    for j, widths in enumerate(PN2['fp']):
+        lvl = L - 1 - j                                                  # dense level of this propagation
+        cin = cur + (feat[lvl] if lvl > 0 else 0)
+        for i, c in enumerate(widths):
+            s.wb(f'{p}.fp{lvl + 1}.mlp_convs.{i}', (c, cin, 1))
+            cin = c
+        for i, c in enumerate(widths):
+            s.bn(f'{p}.fp{lvl + 1}.mlp_bns.{i}', c)
+        cur = widths[-1]
+    s.wb(p + '.conv1', (PN2['head'], cur, 1))
+    s.bn(p + '.bn1', PN2['head'])
+    s.wb(p + '.conv2', (pc_classes, PN2['head'], 1))
+
+
 def _edgenext(s, pfx, phi):                     # edgenext.py:9-62
     cfg = EDGENEXT[phi]
     dims = cfg['dims']
@@ -293,12 +334,15 @@ def _head(s, phi, num_det, nano_head):          # decouplehead.py:16-56
 
 
 def state_dict_spec(num_det, num_seg, phi='S0', backbone='en', pc_channels=6, pc_classes=9, nano_head=True,
-                    radar_channels=3, neck='gdf'):
-    """Ordered [(key, shape, kind)] of the reference state_dict for neck in {'gdf', 'cdf'}, pc_seg='pn'."""
+                    radar_channels=3, neck='gdf', pc_seg='pn'):
+    """Ordered [(key, shape, kind)] of the reference state_dict for neck in {'gdf', 'cdf'}, pc_seg='pn'; with pc_seg='pn2' the
+    `pc_seg_model.*` keys are those of our own PointNet++ specification (PN2 above)."""
+    if pc_seg not in ('pn', 'pn2'):
+        raise NotImplementedError(f"pc_seg={pc_seg!r}: 'pn' (reference) and 'pn2' (own specification) are built")
     if phi not in WIDTHS or backbone not in ('en', 'mv') or neck not in ('gdf', 'cdf'):
         raise NotImplementedError(f"backbone={backbone!r}, phi={phi!r}, neck={neck!r}: only 'en'/'mv' with S0/S1/S2 and gdf/cdf are built")
     s = _Spec()
-    _pointnet(s, pc_channels, pc_classes)
+    (_pointnet if pc_seg == 'pn' else _pointnet2)(s, pc_channels, pc_classes)
     (_neck if neck == 'gdf' else _neck_csp)(s, phi, backbone, num_seg)
     _radar(s, phi, radar_channels)
     _fusion(s, phi)

@@ -48,6 +48,11 @@ enum {
 };
 
 enum { ACH_NECK_GDF = 0, ACH_NECK_CDF = 1 };     /* Ghost-Dual-FPN (neck/ghostdualfpn.py) / CSP-Dual-FPN (neck/cspdualfpn.py) */
+/* point-cloud branch: PointNet (nets/pointcloudseg/pointnet2/pointnet_sem_seg.py) / PointNet++.  The reference snapshot has no
+ * PointNet++ code (nets/Achelous.py:31-32 builds only 'pn'): ACH_PCSEG_PN2 runs OUR OWN specification of that branch
+ * (state-dict keys pc_seg_model.sa{1-4} / fp{4-1} / conv1 / bn1 / conv2); num_points must be a multiple
+ * of 128 and at most 1024. */
+enum { ACH_PCSEG_PN = 0, ACH_PCSEG_PN2 = 1 };
 
 typedef struct ach_config {
     int32_t num_det;        /* detection classes           (Achelous.__init__ num_det)      */
@@ -62,6 +67,7 @@ typedef struct ach_config {
     int32_t spp;            /* 1: SPP, 0: SPPF             (spp)                            */
     int32_t dtype;          /* ACH_DTYPE_*: storage type of activations, inputs and outputs */
     int32_t neck;           /* ACH_NECK_*                  (neck in {'gdf','cdf'})           */
+    int32_t pc_seg;         /* ACH_PCSEG_*                 (pc_seg in {'pn','pn2'})          */
 } ach_config;
 
 /* one entry of a reference-keyed state_dict; `data` is HOST memory, fp32, contiguous, reference shape */

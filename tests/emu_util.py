@@ -25,7 +25,7 @@ def emu_library():
 def make_engine(lib, kw, batch, state_dict, num_points, dtype=DTYPE_F32, full_taps=True):
     eng = NativeEngine(lib, num_det=kw['num_det'], num_seg=kw['num_seg'], phi=kw['phi'], backbone=kw['backbone'],
                        resolution=kw['resolution'], pc_channels=kw['pc_channels'], pc_classes=kw['pc_classes'],
-                       num_points=num_points, nano_head=kw['nano_head'], spp=kw['spp'], dtype=dtype, neck=kw.get('neck', 'gdf'))
+                       num_points=num_points, nano_head=kw['nano_head'], spp=kw['spp'], dtype=dtype, neck=kw.get('neck', 'gdf'), pc_seg=kw.get('pc_seg', 'pn'))
     eng.set_option('full_taps', 1 if full_taps else 0)
     eng.load_state_dict(state_dict)
     eng.plan(batch)

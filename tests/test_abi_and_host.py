@@ -65,7 +65,7 @@ def test_drop_in_module_protocols():
         child.deploy = True
     with pytest.raises(RuntimeError):           # no CPU path
         m(torch.zeros(1, 3, 320, 320), torch.zeros(1, 3, 320, 320), torch.zeros(1, 5, 512))
-    for bad in (dict(neck='rdf'), dict(backbone='ef'), dict(pc_seg='pn2'), dict(phi='L'), dict(nano_head=False)):
+    for bad in (dict(neck='rdf'), dict(backbone='ef'), dict(pc_seg='pn3'), dict(phi='L'), dict(nano_head=False)):
         kw = dict(num_det=7, num_seg=9, phi='S0', resolution=320, backbone='en', neck='gdf', pc_seg='pn', pc_channels=5,
                   pc_classes=8, nano_head=True)
         kw.update(bad)

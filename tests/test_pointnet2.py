@@ -1,0 +1,199 @@
+"""PointNet++ branch (`pc_seg='pn2'`, BASELINE.json config 4).  The reference snapshot has no PointNet++ code, so there is no
+fixture to pin anything against: the branch follows OUR OWN specification (achelous_amd/spec.py::PN2) and
+these tests compare the engine with the self-oracle (oracle/pointnet2_oracle.py) - parity UNPINNED, and labelled so.  Index
+selection (farthest-point sampling, ball query) is compared bit-exactly, features within the fp32 / bf16 tolerances of the rest
+of the path.  CPU tests run the kernel sources under the host emulator; the `gpu` tests run the HIP build through the module API."""
+import numpy as np
+import pytest
+import torch
+
+import achelous_amd
+from achelous_amd import spec
+from achelous_amd.engine import DTYPE_BF16, DTYPE_F32
+from achelous_amd.synth import condition_state_dict, make_inputs
+from oracle import pointnet2_oracle as po
+from oracle.achelous_oracle import AchelousOracle
+
+KW = dict(num_det=7, num_seg=9, phi='S0', backbone='en', neck='gdf', pc_seg='pn2', pc_channels=5, pc_classes=8, nano_head=True,
+          spp=True, resolution=64)
+
+
+def _state_dict(seed=0):
+    blank = {k: torch.zeros(s, dtype=torch.int64 if kind == 'buffer_i64' else torch.float32)
+             for k, s, kind in spec.state_dict_spec(7, 9, 'S0', 'en', 5, 8, True, 3, 'gdf', 'pn2')}
+    return condition_state_dict(blank, seed=seed)
+
+
+def _rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-6)).item()
+
+
+# ------------------------------------------------------------------------------------------------ specification / oracle
+def test_oracle_constants_equal_the_specification():
+    assert po.PN2 == spec.PN2
+
+
+def test_state_dict_keys_of_the_specification():
+    keys = [(k, s) for k, s, _ in spec.state_dict_spec(7, 9, 'S0', 'en', 5, 8, True, 3, 'gdf', 'pn2') if k.startswith('pc_seg_model.')]
+    d = dict(keys)
+    assert len(keys) == 156
+    assert d['pc_seg_model.sa1.mlp_convs.0.weight'] == (32, 8, 1, 1)          # 3 relative coordinates + 5 point features
+    assert d['pc_seg_model.sa4.mlp_convs.2.weight'] == (512, 256, 1, 1)
+    assert d['pc_seg_model.fp4.mlp_convs.0.weight'] == (256, 768, 1)          # skip 256 + interpolated 512
+    assert d['pc_seg_model.fp1.mlp_convs.0.weight'] == (128, 128, 1)          # no skip features at the input level
+    assert d['pc_seg_model.conv2.weight'] == (8, 128, 1)
+    # everything else is the reference's own state dict
+    ref = [k for k, _, _ in spec.state_dict_spec(7, 9, 'S0', 'en', 5, 8, True, 3, 'gdf', 'pn') if not k.startswith('pc_seg_model.')]
+    own = [k for k, _, _ in spec.state_dict_spec(7, 9, 'S0', 'en', 5, 8, True, 3, 'gdf', 'pn2') if not k.startswith('pc_seg_model.')]
+    assert ref == own
+
+
+def _fps_loops(xyz, npoint):
+    """Scalar restatement of the sampling rule (pure Python, small cases only)."""
+    f = np.float32
+    n = len(xyz)
+    dist = [f(1e10)] * n
+    out, far = [], 0
+    for _ in range(npoint):
+        out.append(far)
+        c = xyz[far]
+        best, besti = f(-1), -1
+        for i in range(n):
+            dx, dy, dz = f(xyz[i][0] - c[0]), f(xyz[i][1] - c[1]), f(xyz[i][2] - c[2])
+            d = f(f(f(dx * dx) + f(dy * dy)) + f(dz * dz))
+            dist[i] = min(dist[i], d)
+            if dist[i] > best:
+                best, besti = dist[i], i
+        far = besti
+    return out
+
+
+def test_oracle_geometry_rules():
+    g = np.random.default_rng(3)
+    xyz = (g.standard_normal((96, 3)) * 0.044).astype(np.float32)
+    xyz[40] = xyz[7]                                                         # a duplicate point: ties must go to the lowest index
+    fps = po.farthest_point_sample(xyz, 24)
+    assert fps[0] == 0 and len(set(fps.tolist())) == 24
+    assert fps.tolist() == _fps_loops(xyz, 24)
+    new = xyz[fps]
+    idx = po.ball_query(0.05, 8, xyz, new)
+    d = po.sqdist(new, xyz)
+    for s in range(24):
+        inside = np.nonzero(d[s] <= np.float32(0.05 * 0.05))[0]
+        assert fps[s] in inside                                              # a centroid is in its own ball
+        k = min(len(inside), 8)
+        assert idx[s, :k].tolist() == inside[:k].tolist() and (idx[s, k:] == inside[0]).all()
+    nn, w = po.three_nn_weights(xyz, new)
+    assert np.allclose(w.sum(1), 1.0, atol=1e-6)
+    assert (nn[fps, 0] == np.arange(24)).all() or xyz[40].tolist() == xyz[7].tolist()   # a sampled point's nearest centroid is itself
+    assert (w[fps, 0] > 0.999).all()
+    order = np.argsort(d.T, axis=1, kind='stable')[:, :3]
+    assert np.array_equal(nn, order)
+
+
+def test_oracle_is_permutation_consistent_for_the_untouched_samples():
+    """Batch independence: sample b's output does not depend on what else is in the batch."""
+    sd = _state_dict()
+    o = po.PointNet2Oracle(sd)
+    _, _, xp = make_inputs(3, 5, resolution=64, num_points=512, pc_channels=5, radar_cells=40)
+    full = o.forward(xp)
+    one = o.forward(xp[1:2])
+    assert np.array_equal(full[1], one[0])
+    assert full.shape == (3, 512, 8) and np.allclose(np.exp(full).sum(-1), 1.0, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------ drop-in module contract
+def test_module_accepts_pn2_and_declares_the_specified_parameters():
+    m = achelous_amd.Achelous(**{**KW, 'resolution': 320})
+    assert list(m.state_dict().keys()) == [k for k, _, _ in spec.state_dict_spec(7, 9, 'S0', 'en', 5, 8, True, 3, 'gdf', 'pn2')]
+    with pytest.raises(NotImplementedError):
+        achelous_amd.Achelous(**{**KW, 'pc_seg': 'pn3'})
+
+
+# ------------------------------------------------------------------------------------------------ engine under emulation
+@pytest.mark.parametrize('dtype,tol', [(DTYPE_F32, 2e-5), (DTYPE_BF16, 6e-2)])
+def test_emulated_pn2_matches_the_self_oracle(dtype, tol):
+    from emu_util import alloc_outputs, emu_library, make_engine
+    sd = _state_dict()
+    B, npts = 2, 512
+    td = torch.float32 if dtype == DTYPE_F32 else torch.bfloat16
+    x, xr, xp = make_inputs(B, 7, resolution=64, num_points=npts, pc_channels=5, radar_cells=40)
+    xp = xp.to(td)                                    # the oracle sees exactly the coordinates the engine sees
+    orc = AchelousOracle(sd, **KW)
+    _, _, _, pc = orc.forward(x, xr, xp.float())
+    eng = make_engine(emu_library(), KW, B, sd, npts, dtype)
+    outs = alloc_outputs(KW, B, npts, td, 'cpu')
+    eng.forward(x.to(td), xr.to(td), xp, outs)
+    assert _rel(outs[5].float(), pc) < tol
+    seen = 0
+    for tap in eng.tap_names():
+        if not tap.startswith('pc.'):
+            continue
+        a, b = eng.read_tap(tap), orc.taps[tap]
+        a = a.reshape(b.shape)
+        if tap.endswith(('.fps', '.group_idx', '.xyz')):
+            assert torch.equal(a, b.float()), tap      # index selection: bit-exact
+        else:
+            assert _rel(a, b.float()) < tol, tap
+        seen += 1
+    assert seen == 4 * 4 + 4
+
+
+def test_emulated_pn2_rejects_unsupported_point_counts():
+    from emu_util import emu_library, make_engine
+    with pytest.raises(NotImplementedError):
+        make_engine(emu_library(), KW, 1, _state_dict(), 200, DTYPE_F32)
+
+
+# ------------------------------------------------------------------------------------------------ HIP build (MI355X)
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype,tol', [(torch.float32, 1e-3), (torch.bfloat16, 6e-2)])
+def test_gpu_pn2_matches_the_self_oracle(dtype, tol):
+    kw = {**KW, 'resolution': 320}
+    m = achelous_amd.Achelous(**kw).eval()
+    m.debug_taps = True
+    sd = condition_state_dict(m.state_dict(), seed=0)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda()
+    B = 4
+    x, xr, xp = make_inputs(B, 11, resolution=320, num_points=512, pc_channels=5)
+    xp = xp.to(dtype)
+    with torch.no_grad():
+        det, se, lane, pc = m(x.cuda().to(dtype), xr.cuda().to(dtype), xp.cuda())
+    orc = AchelousOracle({k: v.cpu() for k, v in sd.items()}, **kw)
+    rdet, rse, rlane, rpc = orc.forward(x, xr, xp.float())
+    assert pc.shape == (B, 512, 8)
+    for a, b in zip((*det, se, lane, pc), (*rdet, rse, rlane, rpc)):
+        assert _rel(a.float(), b.float()) <= tol
+    from achelous_amd import engine as eng_mod
+    e = m._engines[(torch.cuda.current_device(), eng_mod.DTYPE_BF16 if dtype == torch.bfloat16 else eng_mod.DTYPE_F32)][0]
+    checked = 0
+    for tap in e.tap_names():
+        if tap.startswith('pc.'):
+            a, b = e.read_tap(tap), orc.taps[tap]
+            a = a.reshape(b.shape)
+            if tap.endswith(('.fps', '.group_idx', '.xyz')):
+                assert torch.equal(a.cpu(), b.float()), tap
+            else:
+                assert _rel(a, b.float()) <= tol, tap
+            checked += 1
+    assert checked == 20
+
+
+@pytest.mark.gpu
+def test_gpu_pn2_batch_64_is_batch_independent():
+    """BASELINE.json config 4 at its full size: bf16, batch 64 - every sample's point output equals the one it gets alone-ish
+    (in a batch of 2), i.e. the sharded-batch property the multi-GPU path relies on; index selections identical."""
+    kw = {**KW, 'resolution': 320}
+    m = achelous_amd.Achelous(**kw).eval()
+    m.load_state_dict(condition_state_dict(m.state_dict(), seed=0), strict=True)
+    m = m.cuda()
+    x, xr, xp = make_inputs(64, 21, resolution=320, num_points=512, pc_channels=5)
+    x, xr, xp = (t.cuda().to(torch.bfloat16) for t in (x, xr, xp))
+    with torch.no_grad():
+        full = m(x, xr, xp)[3].float().cpu()
+        part = m(x[62:64], xr[62:64], xp[62:64])[3].float().cpu()
+    assert torch.isfinite(full).all()
+    assert torch.allclose(torch.exp(full).sum(-1), torch.ones(64, 512), atol=3e-2)
+    assert _rel(full[62:64], part) < 2e-2
