@@ -1268,7 +1268,7 @@ public:
     }
 
     // ------------------------------------------------------------------------------------------ PointNet++ (config 4)
-    // OUR OWN specification (DESIGN.md section 9, spec.py::PN2): the reference snapshot has no PointNet++ code.  Geometry in
+    // OUR OWN specification (DESIGN.md section 5b, spec.py::PN2): the reference snapshot has no PointNet++ code.  Geometry in
     // k_pn2.h (fp32 coordinates, bit-exact index selection); every shared MLP on the MFMA GEMM with (centroid, sample) pairs or
     // points as rows; the max over a ball in the last layer's epilogue.
     struct Pn2Level { float* xyz = nullptr; int n = 0; Rows f; };

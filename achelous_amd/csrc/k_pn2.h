@@ -1,7 +1,7 @@
 // k_pn2.h — geometry kernels of the PointNet++ branch (`pc_seg='pn2'`, BASELINE.json config 4).
 //
 // The reference snapshot has no PointNet++ code (nets/Achelous.py:31-32 builds only 'pn'; SURVEY.md top): these kernels
-// implement OUR OWN specification of that branch (DESIGN.md section 9, achelous_amd/spec.py::PN2), whose checker is
+// implement OUR OWN specification of that branch (DESIGN.md section 5b, achelous_amd/spec.py::PN2), whose checker is
 // oracle/pointnet2_oracle.py.  All index selection is integer work and is bit-exact against that checker, which is why every
 // squared distance below is ((dx*dx + dy*dy) + dz*dz) in fp32 with contraction switched off: one rounding per operation, as
 // numpy evaluates it.  The shared MLPs of the set-abstraction / feature-propagation levels are plain rows x channels GEMMs and

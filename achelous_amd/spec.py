@@ -76,7 +76,7 @@ def _pointnet(s, pc_channels, pc_classes):      # pointnet_sem_seg.py:13-24, poi
 # nets/Achelous.py:31-32 builds only 'pn').  Structure and key names follow the published single-scale-grouping semantic
 # segmentation model of the public Pointnet_Pointnet2_pytorch project (sa1-4 / fp4-1 / conv1 / bn1 / conv2, with its channel
 # widths), re-sized to the 512-point clouds of this path: level k keeps N / div points, 32 samples per ball, radii in the units
-# of the column-normalised cloud (achelous.py:240).  Geometry rules (FPS start, distance form, tie-breaks): DESIGN.md section 9.
+# of the column-normalised cloud (achelous.py:240).  Geometry rules (FPS start, distance form, tie-breaks): DESIGN.md section 5b.
 PN2 = dict(
     sa=[dict(div=2, radius=0.03, nsample=32, mlp=[32, 32, 64]),
         dict(div=8, radius=0.06, nsample=32, mlp=[64, 64, 128]),

@@ -50,7 +50,7 @@ enum {
 enum { ACH_NECK_GDF = 0, ACH_NECK_CDF = 1 };     /* Ghost-Dual-FPN (neck/ghostdualfpn.py) / CSP-Dual-FPN (neck/cspdualfpn.py) */
 /* point-cloud branch: PointNet (nets/pointcloudseg/pointnet2/pointnet_sem_seg.py) / PointNet++.  The reference snapshot has no
  * PointNet++ code (nets/Achelous.py:31-32 builds only 'pn'): ACH_PCSEG_PN2 runs OUR OWN specification of that branch
- * (DESIGN.md section 9; state-dict keys pc_seg_model.sa{1-4} / fp{4-1} / conv1 / bn1 / conv2); num_points must be a multiple
+ * (DESIGN.md section 5b; state-dict keys pc_seg_model.sa{1-4} / fp{4-1} / conv1 / bn1 / conv2); num_points must be a multiple
  * of 128 and at most 1024. */
 enum { ACH_PCSEG_PN = 0, ACH_PCSEG_PN2 = 1 };
 

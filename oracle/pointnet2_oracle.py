@@ -5,7 +5,7 @@ TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
 PARITY UNPINNED - SELF-ORACLE.  The reference snapshot contains no PointNet++ code: `nets/Achelous.py:31-32` builds
 `self.pc_seg_model` only for `pc_seg == 'pn'`, and a search of the tree for ball-query / farthest-point / set-abstraction
 code returns nothing (SURVEY.md top, section 8c).  There is therefore no reference file to follow and no reference output
-to pin this file against.  What it restates is OUR OWN specification (DESIGN.md section 9, `achelous_amd/spec.py::PN2`),
+to pin this file against.  What it restates is OUR OWN specification (DESIGN.md section 5b, `achelous_amd/spec.py::PN2`),
 whose structure follows the published single-scale-grouping semantic-segmentation PointNet++ of the public
 `Pointnet_Pointnet2_pytorch` project (the project the snapshot's `pointnet_utils.py` / `pointnet_sem_seg.py` come from:
 set abstraction = farthest-point sampling + ball query + shared MLP + max; feature propagation = inverse-distance

@@ -1,5 +1,5 @@
 """PointNet++ branch (`pc_seg='pn2'`, BASELINE.json config 4).  The reference snapshot has no PointNet++ code, so there is no
-fixture to pin anything against: the branch follows OUR OWN specification (achelous_amd/spec.py::PN2, DESIGN.md section 9) and
+fixture to pin anything against: the branch follows OUR OWN specification (achelous_amd/spec.py::PN2, DESIGN.md section 5b) and
 these tests compare the engine with the self-oracle (oracle/pointnet2_oracle.py) - parity UNPINNED, and labelled so.  Index
 selection (farthest-point sampling, ball query) is compared bit-exactly, features within the fp32 / bf16 tolerances of the rest
 of the path.  CPU tests run the kernel sources under the host emulator; the `gpu` tests run the HIP build through the module API."""
