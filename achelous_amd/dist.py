@@ -49,17 +49,48 @@ def all_gather_detections(rows, idx, cnt, group=None):
     return unpack_records(out, rows.shape[1])
 
 
+class PendingDetections:
+    """Handle of an all-gather in flight.  `wait()` makes the CURRENT stream wait for the collective (no host block on GPU
+    backends) and returns the gathered (rows, idx, cnt).  The collective runs on the backend's own stream, so whatever the caller
+    enqueues between the submit and the wait - normally the next batch's forward - overlaps with it."""
+
+    def __init__(self, work, rec, out, max_det, local):
+        self._work, self._rec, self._out, self._max_det, self._local = work, rec, out, max_det, local
+
+    def wait(self):
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+            self._local = unpack_records(self._out, self._max_det)
+        return self._local
+
+
+def all_gather_detections_async(rows, idx, cnt, group=None, out=None, force=False):
+    """As all_gather_detections, but returns a PendingDetections immediately; `out` (optional, [world * B, record_width] int32)
+    lets a serving loop reuse its receive buffers (two of them, alternating, when one step's gather is waited for in the next)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1 and not (force and dist.is_initialized()):      # `force`: diagnostic, run the collective even on one rank
+        return PendingDetections(None, None, None, rows.shape[1], (rows, idx, cnt))
+    rec = pack_records(rows, idx, cnt)
+    if out is None:
+        out = torch.empty(world * rec.shape[0], rec.shape[1], dtype=torch.int32, device=rec.device)
+    work = dist.all_gather_into_tensor(out, rec, group=group, async_op=True)
+    return PendingDetections(work, rec, out, rows.shape[1], None)
+
+
 class ShardedDetector:
-    """model -> decode -> NMS on the local shard, then the all-gather.  `model` is an achelous_amd.Achelous on this rank's GPU."""
+    """forward + decode + NMS on the local shard (one engine call, Achelous.forward_detect), then the all-gather.  `model` is an
+    achelous_amd.Achelous on this rank's GPU.  `__call__` returns the gathered detections; `submit` returns a PendingDetections so
+    that a serving loop can wait for batch k's detections after it has enqueued batch k+1."""
 
     def __init__(self, model, conf_thres=0.35, nms_thres=0.35, max_det=100, group=None):
         self.model, self.conf, self.iou, self.max_det, self.group = model, conf_thres, nms_thres, max_det, group
 
     @torch.no_grad()
+    def submit(self, x, x_radar, x_points, out=None):
+        (det, se, lane, pc), (rows, idx, cnt) = self.model.forward_detect(x, x_radar, x_points, self.conf, self.iou, self.max_det)
+        return all_gather_detections_async(rows, idx, cnt, self.group, out), (se, lane, pc)
+
     def __call__(self, x, x_radar, x_points):
-        from .postprocess import decode_outputs, nms_device
-        det, se, lane, pc = self.model(x, x_radar, x_points)
-        dec = decode_outputs(det, [self.model.resolution] * 2)
-        rows, idx, cnt = nms_device(dec, self.model.num_det, self.conf, self.iou, self.max_det)
-        g_rows, g_idx, g_cnt = all_gather_detections(rows, idx, cnt, self.group)
-        return (g_rows, g_idx, g_cnt), (se, lane, pc)        # segmentation outputs stay sharded on their rank
+        pending, seg = self.submit(x, x_radar, x_points)
+        return pending.wait(), seg                            # segmentation outputs stay sharded on their rank

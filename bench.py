@@ -59,6 +59,7 @@ def main():
     ap.add_argument('--separate-calls', action='store_true', help='forward, decode_outputs and NMS as three calls instead of forward_detect')
     ap.add_argument('--extra-stream', action='store_true', help='diagnostic: also launch a tiny copy on a separate stream every step (stands in for a collective stream)')
     ap.add_argument('--opt', action='append', default=[], help='engine option key=value (ach_set_option), repeatable')
+    ap.add_argument('--force-collective', action='store_true', help='diagnostic: run the RCCL all-gather of the detection records even at world size 1')
     ap.add_argument('--ops-json', default=None, help='write the per-launch table (ms, algorithmic bytes) here')
     args = ap.parse_args()
 
@@ -69,13 +70,18 @@ def main():
         raise SystemExit('bench.py needs a GPU (the HIP engine has no CPU path)')
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    if world > 1:
+    collective = world > 1 or args.force_collective
+    if collective:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group('nccl', device_id=dev)   # "nccl" is RCCL on ROCm
 
     from achelous_amd import Achelous, decode_outputs
     from achelous_amd import engine as E
     from achelous_amd.postprocess import nms_device
+    from achelous_amd.dist import all_gather_detections_async
     from achelous_amd.synth import condition_state_dict, make_inputs, config_seed
 
     cid, kw = CONFIGS[args.config]
@@ -89,7 +95,8 @@ def main():
     x, xr, xp = make_inputs(B, config_seed(cid) + 1000 * rank, resolution=COMMON['resolution'], pc_channels=COMMON['pc_channels'])
     x, xr, xp = x.to(dev, tdt), xr.to(dev, tdt), xp.to(dev, tdt)
     rec_w = args.max_det * 7 + args.max_det + 1
-    gathered = torch.empty(world * B, rec_w, dtype=torch.int32, device=dev) if world > 1 else None
+    gathered = [torch.empty(world * B, rec_w, dtype=torch.int32, device=dev) for _ in range(2)] if collective else None
+    state = {'k': 0, 'pending': None}
     ishape = [COMMON['resolution']] * 2
 
     extra = torch.cuda.Stream(dev) if args.extra_stream else None
@@ -107,14 +114,22 @@ def main():
             rows, idx, cnt = nms_device(dec, COMMON['num_det'], args.conf, args.iou, args.max_det)
         else:                              # same three stages as one engine call (decode + NMS overlap the segmentation decoders)
             (det, se, lane, pc), (rows, idx, cnt) = model.forward_detect(x, xr, xp, args.conf, args.iou, args.max_det)
-        if world > 1:
-            rec = torch.cat([rows.view(B, -1).view(torch.int32), idx, cnt.view(B, 1)], dim=1).contiguous()
-            dist.all_gather_into_tensor(gathered, rec)
+        if collective:
+            # pipelined: this step's gather runs on RCCL's stream under the next step's forward; its result is waited for one
+            # step late (alternating receive buffers).  fence() waits for the last one, so all K gathers finish inside the timing.
+            nxt = all_gather_detections_async(rows, idx, cnt, out=gathered[state['k'] & 1], force=args.force_collective)
+            state['k'] += 1
+            if state['pending'] is not None:
+                state['pending'].wait()
+            state['pending'] = nxt
         return det, se, lane, pc, cnt
 
     def fence():
+        if state['pending'] is not None:
+            state['pending'].wait()
+            state['pending'] = None
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if collective:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -149,7 +164,7 @@ def main():
         f1 = time.perf_counter()
 
     elapsed = torch.tensor([t1 - t0, f1 - f0], dtype=torch.float64, device=dev)
-    if world > 1:
+    if collective:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed, fwd_elapsed = elapsed.tolist()
     frames = world * B * args.steps
@@ -208,7 +223,7 @@ def main():
         else:
             result['cpu_baseline'] = None
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if collective:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from achelous_amd.dist import all_gather_detections, pack_records, record_width, shard_bounds, unpack_records
+from achelous_amd.dist import all_gather_detections, all_gather_detections_async, pack_records, record_width, shard_bounds, unpack_records
 
 
 def _fake_shard(rank, B, max_det):
@@ -32,6 +32,20 @@ def _worker(rank, world, port, B, max_det, q):
         sl = slice(r * B, (r + 1) * B)
         ok &= torch.equal(g_rows[sl].view(torch.int32), er.view(torch.int32))
         ok &= torch.equal(g_idx[sl], ei) and torch.equal(g_cnt[sl], ec)
+    # the pipelined form: two gathers in flight into alternating receive buffers, waited for one step late
+    bufs = [torch.empty(world * B, max_det * 8 + 1, dtype=torch.int32) for _ in range(2)]
+    pend = None
+    for step in range(3):
+        r2, i2, c2 = _fake_shard(rank + 10 * step, B, max_det)
+        nxt = all_gather_detections_async(r2, i2, c2, out=bufs[step & 1])
+        if pend is not None:
+            pr, pi, pc = pend[0].wait()
+            for r in range(world):
+                er, ei, ec = _fake_shard(r + 10 * pend[1], B, max_det)
+                sl = slice(r * B, (r + 1) * B)
+                ok &= torch.equal(pr[sl].view(torch.int32), er.view(torch.int32)) and torch.equal(pi[sl], ei) and torch.equal(pc[sl], ec)
+        pend = (nxt, step)
+    pend[0].wait()
     q.put((rank, bool(ok), tuple(g_rows.shape)))
     dist.barrier()
     dist.destroy_process_group()
