@@ -138,10 +138,16 @@ __device__ __forceinline__ void mlp_inputs(const MlpParams& p, long m, bool vali
     }
 }
 
-template <int DT> struct MlpOcc { static constexpr int blocks = DT <= 6 ? 6 : (DT <= 10 ? 4 : (DT <= 12 ? 3 : 2)); };
+// Workgroups per CU the register budget is sized for.  SPLIT kernels run on the small maps: few workgroups, one latency chain per
+// tile — what matters there is that a wave can have a whole hidden chunk's weight fragments (2 k1 + DT loads) in flight at once.
+// With the non-SPLIT budgets the compiler had 4 fragment registers to cycle through and every second MFMA waited for a fresh L2
+// round trip (measured: 7 us per hidden chunk on the 10x10 maps).
+template <int DT, bool SPLIT> struct MlpOcc {
+    static constexpr int blocks = (SPLIT && DT > 6) ? 2 : (DT <= 6 ? 6 : (DT <= 10 ? 4 : (DT <= 12 ? 3 : 2)));
+};
 
 template <class T, int DT, bool SPLIT>
-__global__ __launch_bounds__(256, MlpOcc<DT>::blocks) void mlp_kernel(const MlpParams p) {
+__global__ __launch_bounds__(256, (MlpOcc<DT, SPLIT>::blocks)) void mlp_kernel(const MlpParams p) {
     constexpr int VEC = Store<T>::VEC;
     constexpr int KC = 4 * VEC;
     constexpr int K1MAX = (16 * DT + KC - 1) / KC;
@@ -207,10 +213,38 @@ __global__ __launch_bounds__(256, MlpOcc<DT>::blocks) void mlp_kernel(const MlpP
     for (int t = 0; t < DT; ++t) { acc2[t][0] = 0.f; acc2[t][1] = 0.f; acc2[t][2] = 0.f; acc2[t][3] = 0.f; }
     const uint4* W1f = static_cast<const uint4*>(p.W1) + lane;
     const uint4* W2f = static_cast<const uint4*>(p.W2) + lane;
+    // SPLIT: branch-free and software-pipelined — all of a chunk's W1 fragments are requested together one chunk ahead, its W2
+    // fragments before the activation (k-steps beyond k1 re-read the last fragment against a zero input instead of branching:
+    // with a branch per k-step every pair of MFMAs waited for its own L2 round trip).
+    // DT <= 6 keeps the small register budget (more workgroups per CU next to the side streams: measured better end to end);
+    // DT > 12: branch-free, but the next chunk's fragments are not requested ahead (they would spill).
+    constexpr bool PIPE = SPLIT && DT > 6;
+    constexpr bool AHEAD = PIPE && DT <= 12;
+    uint4 wn[PIPE ? K1MAX : 1][2];
+    auto load_w1 = [&](int j) {
+        const uint4* w1 = W1f + long(j) * p.k1 * 2 * 64;
+        ACH_UNROLL
+        for (int s = 0; s < K1MAX; ++s) {
+            const int sc = s < p.k1 ? s : p.k1 - 1;
+            wn[s][0] = w1[(sc * 2) * 64]; wn[s][1] = w1[(sc * 2 + 1) * 64];
+        }
+    };
+    if (AHEAD && wave < p.J) load_w1(wave);
     for (int j = SPLIT ? wave : 0; j < p.J; j += (SPLIT ? 4 : 1)) {
         f32x4 a0, a1;
         a0[0] = a0[1] = a0[2] = a0[3] = 0.f;
         a1[0] = a1[1] = a1[2] = a1[3] = 0.f;
+        uint4 w2r[PIPE ? HSTEP : 1][PIPE ? DT : 1];
+        if (PIPE) {
+            if (!AHEAD) load_w1(j);
+            ACH_UNROLL
+            for (int s = 0; s < K1MAX; ++s) { mfma16<T>(wn[s][0], xf[s], a0); mfma16<T>(wn[s][1], xf[s], a1); }
+            ACH_UNROLL
+            for (int hh = 0; hh < HSTEP; ++hh)
+                ACH_UNROLL
+                for (int t = 0; t < DT; ++t) w2r[hh][t] = W2f[(long(j * HSTEP + hh) * DT + t) * 64];
+            if (AHEAD && j + 4 < p.J) load_w1(j + 4);
+        } else {
         const uint4* w1 = W1f + long(j) * p.k1 * 2 * 64;
         ACH_UNROLL
         for (int s = 0; s < K1MAX; ++s) {
@@ -218,6 +252,7 @@ __global__ __launch_bounds__(256, MlpOcc<DT>::blocks) void mlp_kernel(const MlpP
             const uint4 wa = w1[(s * 2) * 64], wb = w1[(s * 2 + 1) * 64];
             mfma16<T>(wa, xf[s], a0);
             mfma16<T>(wb, xf[s], a1);
+        }
         }
         float h[8];
         const float* b1 = p.b1 + j * 32 + g * 8;
@@ -228,7 +263,7 @@ __global__ __launch_bounds__(256, MlpOcc<DT>::blocks) void mlp_kernel(const MlpP
             const uint4 hf = frag_pack<T>(h + hh * VEC);
             const uint4* w2 = W2f + long(j * HSTEP + hh) * DT * 64;
             ACH_UNROLL
-            for (int t = 0; t < DT; ++t) mfma16<T>(w2[t * 64], hf, acc2[t]);
+            for (int t = 0; t < DT; ++t) mfma16<T>(PIPE ? w2r[hh][t] : w2[t * 64], hf, acc2[t]);
         }
     }
     // ---- 4. + bias + residual, 8 consecutive channels per lane per tile pair
