@@ -76,6 +76,7 @@ public:
     int side_low_priority = 3;        // option "side_priority" (with head_stream = 0): bit k set = side stream k+1 is created at the
                                       // lowest stream priority
     bool head_batch = true;           // option "head_batch": each detection-head layer as one launch for the three pyramid levels
+    int point_on_head_stream = -1;    // option "point_stream2" (-1 auto / 0 / 1): the point branch opens stream 2 (ahead of fusion + head) instead of queueing behind the radar branch
     bool dw_tile = true;              // option "dw_tile": LDS-tiled depthwise kernel on the 10x10 maps
     bool fuse_rc = true;              // option "fused_rc": RCBlock conv + deformable sampling + contraction as one launch (k_conv3.h)
     bool row_conv = true;             // option "row_conv": narrow 3x3 convs through k_conv3.h instead of the generic implicit GEMM

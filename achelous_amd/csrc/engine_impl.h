@@ -1362,7 +1362,10 @@ public:
         cur_stream = 1;
         rcnet(r);
         signal_after_last(3);             // radar pyramid ready
-        cur_stream = head_stream ? 1 : 2; // "head_stream": the point branch queues behind the radar branch on the low-priority stream
+        // "head_stream": PointNet queues behind the radar branch on the low-priority stream; the (four times longer) PointNet++
+        // branch opens stream 2 instead, ahead of fusion + head, which only start once the neck is done (measured +4.8 %; PointNet: neutral)
+        const bool point2 = point_on_head_stream < 0 ? cfg.pc_seg == ACH_PCSEG_PN2 : point_on_head_stream != 0;
+        cur_stream = (head_stream && !point2) ? 1 : 2;
         if (cfg.pc_seg == ACH_PCSEG_PN2) pointnet2(); else pointnet();
         cur_stream = 0;
         A m[4];
