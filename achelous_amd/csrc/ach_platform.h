@@ -235,6 +235,30 @@ __device__ __forceinline__ float row16_max(float v) {
 }
 #endif
 
+// Range-checked 16-byte loads through a buffer resource: an offset at or beyond the end of the buffer returns zeros in hardware
+// (MUBUF, raw buffer, stride 0), which is how convolution taps that fall outside the map are handled without clamps or masks:
+// the tap's byte offset is simply made huge.  `bytes` must be below 2^31 so that "in-range base + 0x80000000" never wraps.
+#if defined(ACH_HOSTEMU)
+struct BufRsrc { const char* base; unsigned bytes; };
+inline BufRsrc make_buf(const void* p, unsigned bytes) { return BufRsrc{static_cast<const char*>(p), bytes}; }
+inline uint4 buf_load16(const BufRsrc& r, unsigned off) {
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (r.bytes >= 16u && off <= r.bytes - 16u) std::memcpy(&v, r.base + off, 16);
+    return v;
+}
+#else
+typedef __amdgpu_buffer_rsrc_t BufRsrc;
+typedef unsigned int buf_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ BufRsrc make_buf(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, int(bytes), 0x00020000);      // gfx9 raw buffer, 32-bit data format
+}
+__device__ __forceinline__ uint4 buf_load16(BufRsrc r, unsigned off) {
+    const buf_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, int(off), 0, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+#endif
+constexpr unsigned BUF_OOB = 0x80000000u;
+
 // wave-uniform max of a float / broadcast of one lane's float (lane must be wave-uniform)
 #if defined(ACH_HOSTEMU)
 __device__ inline float wave_max_f32(float v) { v = row16_max(v); v = fmaxf(v, __shfl_xor(v, 16)); return fmaxf(v, __shfl_xor(v, 32)); }

@@ -399,6 +399,11 @@ public:
         mp.Y = y.p; mp.ldy = y.ld;
         mp.dw_k = dw_ks; mp.H = xin.H; mp.W = xin.W;
         if (dw_ks) {
+            const double xb = double(xin.rows()) * double(xin.ld) * sizeof(T);
+            if (xb >= 2147483648.0) throw AchError{ACH_ERR_UNSUPPORTED, "depthwise input of 2 GiB or more (batch too large for one plan)"};
+            mp.xbytes = unsigned(xb);
+        }
+        if (dw_ks) {
             const HostTensor& w = W(pfx + ".dwconv.weight");
             const std::vector<float>& b = W(pfx + ".dwconv.bias").data;
             const int ldc = k1 * KC, kk = dw_ks * dw_ks;

@@ -42,6 +42,7 @@ struct MlpParams {
     void* Y; long ldy;
     const float* Wdw; const float* bdw;   // depthwise weights [dw_k*dw_k][ldc] (fp32, zero padded), bias [ldc]; ldc = k1 * 4 * VEC
     int dw_k, H, W;
+    unsigned xbytes;                      // dw_k > 0: bytes of the whole input tensor (< 2^31), for the range-checked tap loads
     const void* W1; const float* b1;      // [hidden][C] packed in NT = 2 chunks with k1 k-steps ; bias padded to 32 * J
     const void* W2; const float* b2;      // [C][hidden] packed as ONE chunk of DT tiles with J * (8 / VEC) k-steps ; bias padded to 16 * DT
     long M; int C, k1, J, act; float ln_eps;
@@ -51,18 +52,29 @@ struct MlpParams {
 constexpr int MLP_RED_TILES = 4;          // output tiles reduced per LDS round in SPLIT mode
 
 // depthwise k x k conv (zero padding k/2) of this lane's VEC channels at its pixel; up to 5 taps of a row in flight at a time.
-// Loads are unconditional from clamped columns (no divergent branches), out-of-map taps are zeroed afterwards; the weights are
-// kept in fp32 so that only the activations need unpacking (this loop is VALU-issue bound).
+// Taps are fetched through a range-checked buffer resource over the whole activation tensor (ach_platform.h): a column outside
+// the map gets an out-of-range offset and comes back as zeros, so a tap costs one add and one load — no clamps, no 64-bit
+// address arithmetic, no masking of the packed data (this loop is VALU-issue bound: 25 -> 15 instructions per tap).  Rows outside
+// the map are skipped.  The weights are kept in fp32 so that only the activations need unpacking.
 template <class T, int KS>
-__device__ __forceinline__ void mlp_dw(const MlpParams& p, const T* img, int oy, int ox, int k0, float* acc) {
+__device__ __forceinline__ void mlp_dw(const MlpParams& p, const BufRsrc& xb, long pix0, int oy, int ox, int k0, float* acc) {
     constexpr int VEC = Store<T>::VEC;
     constexpr int TG = KS <= 5 ? KS : (KS + 1) / 2;
+    constexpr unsigned ESZ = sizeof(T);
     const int ldc = p.k1 * 4 * VEC;
     const float* wdw = p.Wdw + k0;
+    const unsigned pitch = unsigned(p.ldx) * ESZ, rowpitch = unsigned(p.W) * pitch;
+    const unsigned base = unsigned(pix0) * pitch + unsigned(k0) * ESZ;
+    unsigned coff[KS];
+    ACH_UNROLL
+    for (int tx = 0; tx < KS; ++tx) {
+        const int ix = ox + tx - KS / 2;
+        coff[tx] = (ix >= 0 && ix < p.W) ? unsigned(ix) * pitch : BUF_OOB;
+    }
     for (int ty = 0; ty < KS; ++ty) {
         const int iy = oy + ty - KS / 2;
         if (iy < 0 || iy >= p.H) continue;
-        const T* row = img + long(iy) * p.W * p.ldx + k0;
+        const unsigned rowb = base + unsigned(iy) * rowpitch;
         const float* wrow = wdw + long(ty * KS) * ldc;
         ACH_UNROLL
         for (int tx0 = 0; tx0 < KS; tx0 += TG) {
@@ -72,9 +84,7 @@ __device__ __forceinline__ void mlp_dw(const MlpParams& p, const T* img, int oy,
             for (int i = 0; i < TG; ++i) {
                 const int tx = tx0 + i;
                 if (tx >= KS) continue;
-                const int ix = ox + tx - KS / 2;
-                const int cx = ix < 0 ? 0 : (ix >= p.W ? p.W - 1 : ix);
-                xv[i] = *reinterpret_cast<const uint4*>(row + long(cx) * p.ldx);
+                xv[i] = buf_load16(xb, rowb + coff[tx]);
                 ACH_UNROLL
                 for (int q = 0; q < VEC / 4; ++q) wv[i][q] = *reinterpret_cast<const f32x4*>(wrow + long(tx) * ldc + q * 4);
             }
@@ -82,11 +92,8 @@ __device__ __forceinline__ void mlp_dw(const MlpParams& p, const T* img, int oy,
             for (int i = 0; i < TG; ++i) {
                 const int tx = tx0 + i;
                 if (tx >= KS) continue;
-                const int ix = ox + tx - KS / 2;
-                const bool live = ix >= 0 && ix < p.W;
-                const uint4 xz = make_uint4(live ? xv[i].x : 0u, live ? xv[i].y : 0u, live ? xv[i].z : 0u, live ? xv[i].w : 0u);
                 float xf[8];
-                frag_unpack<T>(xz, xf);
+                frag_unpack<T>(xv[i], xf);
                 ACH_UNROLL
                 for (int e = 0; e < VEC; ++e) acc[e] += xf[e] * wv[i][e >> 2][e & 3];
             }
@@ -102,13 +109,14 @@ __device__ __forceinline__ void mlp_inputs(const MlpParams& p, long m, bool vali
     constexpr int KC = 4 * VEC;
     const T* X = static_cast<const T*>(p.X);
     int oy = 0, ox = 0;
-    const T* img = X;
+    long pix0 = 0;
+    const BufRsrc xb = make_buf(p.X, KS > 0 ? p.xbytes : 0u);
     if (KS > 0) {
         const long hw = long(p.H) * p.W;
         const long b = m / hw;
         const int rem = int(m - b * hw);
         oy = rem / p.W; ox = rem - oy * p.W;
-        img = X + b * hw * p.ldx;
+        pix0 = b * hw;
     }
     constexpr int NS = SPLIT ? (K1MAX + 3) / 4 : K1MAX;
     ACH_UNROLL
@@ -128,7 +136,7 @@ __device__ __forceinline__ void mlp_inputs(const MlpParams& p, long m, bool vali
                 float acc[8];
                 ACH_UNROLL
                 for (int i = 0; i < VEC; ++i) acc[i] = p.bdw[k0 + i];
-                mlp_dw<T, (KS > 0 ? KS : 3)>(p, img, oy, ox, k0, acc);
+                mlp_dw<T, (KS > 0 ? KS : 3)>(p, xb, pix0, oy, ox, k0, acc);
                 ACH_UNROLL
                 for (int i = 0; i < VEC; ++i) { s1 += acc[i]; s2 += acc[i] * acc[i]; }     // channels >= C: zero weights, zero bias
                 frag = frag_pack<T>(acc);
