@@ -258,6 +258,31 @@ __device__ __forceinline__ uint4 buf_load16(BufRsrc r, unsigned off) {
 }
 #endif
 constexpr unsigned BUF_OOB = 0x80000000u;
+// four consecutive elements of the storage type through a buffer resource (8 bytes of bf16 / 16 bytes of fp32), as floats
+#if defined(ACH_HOSTEMU)
+inline void buf_load_raw(const BufRsrc& r, unsigned off, void* dst, unsigned n) {
+    std::memset(dst, 0, n);
+    if (r.bytes >= n && off <= r.bytes - n) std::memcpy(dst, r.base + off, n);
+}
+template <class T> inline void buf_ld4(const BufRsrc& r, unsigned off, float (&o)[4]);
+template <> inline void buf_ld4<float>(const BufRsrc& r, unsigned off, float (&o)[4]) { buf_load_raw(r, off, o, 16); }
+template <> inline void buf_ld4<bf16_t>(const BufRsrc& r, unsigned off, float (&o)[4]) {
+    uint16_t h[4]; buf_load_raw(r, off, h, 8);
+    for (int i = 0; i < 4; ++i) o[i] = bf16_to_f32(h[i]);
+}
+#else
+typedef unsigned int buf_u32x2 __attribute__((ext_vector_type(2)));
+template <class T> __device__ __forceinline__ void buf_ld4(BufRsrc r, unsigned off, float (&o)[4]);
+template <> __device__ __forceinline__ void buf_ld4<float>(BufRsrc r, unsigned off, float (&o)[4]) {
+    const buf_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, int(off), 0, 0);
+    o[0] = __uint_as_float(v.x); o[1] = __uint_as_float(v.y); o[2] = __uint_as_float(v.z); o[3] = __uint_as_float(v.w);
+}
+template <> __device__ __forceinline__ void buf_ld4<bf16_t>(BufRsrc r, unsigned off, float (&o)[4]) {
+    const buf_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, int(off), 0, 0);
+    o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+    o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+}
+#endif
 
 // wave-uniform max of a float / broadcast of one lane's float (lane must be wave-uniform)
 #if defined(ACH_HOSTEMU)

@@ -262,6 +262,8 @@ public:
             for (int t = 0; t < ks * ks; ++t) wt[size_t(t) * C + c] = w.data[size_t(c) * ks * ks + t] * sc[c];
             bias[c] = bias[c] * sc[c] + sh[c];
         }
+        if (double(X.rows()) * double(std::max(X.ld, X2 ? X2->ld : 0L)) * sizeof(T) >= 2147483648.0)
+            throw AchError{ACH_ERR_UNSUPPORTED, name + ": depthwise input of 2 GiB or more (batch too large for one plan)"};
         DwParams p;
         std::memset(&p, 0, sizeof(p));
         p.X = X.p; p.ldx = X.ld; p.X2 = X2 ? X2->p : nullptr; p.ldx2 = X2 ? X2->ld : 0;

@@ -36,8 +36,23 @@ __device__ __forceinline__ void dwconv_strip_body(const DwParams& p, unsigned bx
     const long b = r / p.Ho;
     constexpr int PAD = KS / 2;
     const int ci = p.cin_mod > 0 ? c % p.cin_mod : c;
-    const T* X = static_cast<const T*>(p.X) + b * p.H * long(p.Wd) * p.ldx + ci;
-    const T* X2 = p.X2 ? static_cast<const T*>(p.X2) + b * p.H * long(p.Wd) * p.ldx2 + ci : nullptr;
+    // taps through range-checked buffer resources (ach_platform.h): a column outside the map gets an out-of-range offset and
+    // reads zeros — one add + one load per fetched pixel instead of a clamp, 64-bit address arithmetic and four selects
+    constexpr unsigned ESZ = sizeof(T);
+    const unsigned npix = unsigned(p.B) * unsigned(p.H) * unsigned(p.Wd);
+    const BufRsrc xb = make_buf(p.X, npix * unsigned(p.ldx) * ESZ);
+    const BufRsrc xb2 = make_buf(p.X2 ? p.X2 : p.X, p.X2 ? npix * unsigned(p.ldx2) * ESZ : 0u);
+    const unsigned pitch = unsigned(p.ldx) * ESZ, pitch2 = unsigned(p.ldx2) * ESZ;
+    const unsigned pix0 = unsigned(b) * unsigned(p.H) * unsigned(p.Wd);
+    const unsigned base = pix0 * pitch + unsigned(ci) * ESZ, base2 = pix0 * pitch2 + unsigned(ci) * ESZ;
+    unsigned coff[KS + OW - 1], coff2[KS + OW - 1];
+    ACH_UNROLL
+    for (int j = 0; j < KS + OW - 1; ++j) {
+        const int ix = ox0 - PAD + j;
+        const bool ok = ix >= 0 && ix < p.Wd;
+        coff[j] = ok ? unsigned(ix) * pitch : BUF_OOB;
+        coff2[j] = ok ? unsigned(ix) * pitch2 : BUF_OOB;           // dead (and removed) when there is no second input
+    }
     float acc[OW][4];
     {
         const float4 bb = *reinterpret_cast<const float4*>(p.bias + c);
@@ -52,15 +67,12 @@ __device__ __forceinline__ void dwconv_strip_body(const DwParams& p, unsigned bx
         float4 w[KS];
         ACH_UNROLL
         for (int kx = 0; kx < KS; ++kx) w[kx] = *reinterpret_cast<const float4*>(p.W + long(ky * KS + kx) * p.C + c);
+        const unsigned rowb = base + unsigned(iy) * unsigned(p.Wd) * pitch, rowb2 = base2 + unsigned(iy) * unsigned(p.Wd) * pitch2;
         ACH_UNROLL
         for (int j = 0; j < KS + OW - 1; ++j) {
-            const int ix = ox0 - PAD + j;
-            const bool ok = ix >= 0 && ix < p.Wd;
-            const long ip = long(iy) * p.Wd + (ok ? ix : 0);
             float v[4];
-            Store<T>::ld4(X + ip * p.ldx, v);
-            if (X2) { float u[4]; Store<T>::ld4(X2 + ip * p.ldx2, u); v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3]; }
-            if (!ok) { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; v[3] = 0.f; }
+            buf_ld4<T>(xb, rowb + coff[j], v);
+            if (p.X2) { float u[4]; buf_ld4<T>(xb2, rowb2 + coff2[j], u); v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3]; }
             ACH_UNROLL
             for (int o = 0; o < OW; ++o) {
                 const int kx = j - o;
