@@ -115,19 +115,26 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const DwParams p) {
     const int oy = int(pix % p.Ho);
     const long b = pix / p.Ho;
     constexpr int PAD = KS / 2;
-    const T* X = static_cast<const T*>(p.X);
-    const T* X2 = static_cast<const T*>(p.X2);
+    // branch-free: every tap is fetched through a range-checked buffer resource (ach_platform.h), taps outside the map read zeros
+    constexpr unsigned ESZ = sizeof(T);
+    const unsigned npix = unsigned(p.B) * unsigned(p.H) * unsigned(p.Wd);
+    const BufRsrc xb = make_buf(p.X, npix * unsigned(p.ldx) * ESZ);
+    const BufRsrc xb2 = make_buf(p.X2 ? p.X2 : p.X, p.X2 ? npix * unsigned(p.ldx2) * ESZ : 0u);
+    const unsigned pitch = unsigned(p.ldx) * ESZ, pitch2 = unsigned(p.ldx2) * ESZ;
+    const unsigned pix0 = unsigned(b) * unsigned(p.H) * unsigned(p.Wd);
     float acc[4] = {p.bias[c], p.bias[c + 1], p.bias[c + 2], p.bias[c + 3]};
+    ACH_UNROLL
     for (int ky = 0; ky < KS; ++ky) {
         const int iy = oy * p.stride - PAD + ky;
-        if (iy < 0 || iy >= p.H) continue;
+        const bool rok = iy >= 0 && iy < p.H;
+        ACH_UNROLL
         for (int kx = 0; kx < KS; ++kx) {
             const int ix = ox * p.stride - PAD + kx;
-            if (ix < 0 || ix >= p.Wd) continue;
-            const long ip = (b * p.H + iy) * p.Wd + ix;
+            const bool ok = rok && ix >= 0 && ix < p.Wd;
+            const unsigned pix = pix0 + unsigned(iy) * unsigned(p.Wd) + unsigned(ix);
             float v[4];
-            Store<T>::ld4(X + ip * p.ldx + c, v);
-            if (X2) { float u[4]; Store<T>::ld4(X2 + ip * p.ldx2 + c, u); v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3]; }
+            buf_ld4<T>(xb, ok ? pix * pitch + unsigned(c) * ESZ : BUF_OOB, v);
+            if (p.X2) { float u[4]; buf_ld4<T>(xb2, ok ? pix * pitch2 + unsigned(c) * ESZ : BUF_OOB, u); v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3]; }
             const float4 w = *reinterpret_cast<const float4*>(p.W + long(ky * KS + kx) * p.C + c);
             acc[0] += v[0] * w.x; acc[1] += v[1] * w.y; acc[2] += v[2] * w.z; acc[3] += v[3] * w.w;
         }
