@@ -38,6 +38,8 @@ CONFIGS = {
     'en_s0_cdf': (6, dict(backbone='en', phi='S0', neck='cdf')),      # SURVEY §8(f) rank 3 (not a BASELINE config)
     'en_s0_pn2': (4, dict(backbone='en', phi='S0', pc_seg='pn2')),    # BASELINE config 4: PointNet++ per our own specification
 }
+WORKLOAD_NAMES = {'en_s0': 'EN-GDF-PN-S0', 'en_s2': 'EN-GDF-PN-S2', 'mv_s2': 'MV-GDF-PN-S2', 'en_s0_cdf': 'EN-CDF-PN-S0',
+                  'en_s0_pn2': 'EN-GDF-PN2-S0 (PointNet++ per our own specification)'}
 COMMON = dict(num_det=7, num_seg=9, resolution=320, neck='gdf', pc_seg='pn', pc_channels=5, pc_classes=8, nano_head=True, spp=True)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}
@@ -191,7 +193,7 @@ def main():
             'value': round(fps, 2), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
-            'config': {'workload': f'{args.config.upper().replace("_", "-GDF-PN-")} forward + decode + NMS, 320x320 image + radar map, '
+            'config': {'workload': f'{WORKLOAD_NAMES[args.config]} forward + decode + NMS, 320x320 image + radar map, '
                                    f'512 points, batch {B} per GPU, all 5 heads, seeded random weights',
                        'global_batch': world * B, 'parallelism': f'batch-sharded x{world}' + (' + RCCL all-gather of detections' if world > 1 else ''),
                        'launches_per_forward': len(table)},
