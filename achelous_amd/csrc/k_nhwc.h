@@ -261,9 +261,11 @@ __global__ __launch_bounds__(256) void stem_kernel(const StemParams p) {
     for (int c = 0; c < 3; ++c)
         for (int dy = 0; dy < 4; ++dy) {
             const T* row = X + ((b * 3 + c) * p.H + (oy * 4 + dy)) * long(p.Wd) + ox * 4;
+            float v4[4];
+            Store<T>::ld4(row, v4);                               // the patch row: one 8 / 16-byte load (W is a multiple of 4)
             ACH_UNROLL
             for (int dx = 0; dx < 4; ++dx) {
-                const float v = Store<T>::ld(row + dx);
+                const float v = v4[dx];
                 const float* w = p.W + ((c * 4 + dy) * 4 + dx) * CO;
                 ACH_UNROLL
                 for (int o = 0; o < CO; ++o) acc[o] += v * w[o];

@@ -45,22 +45,23 @@ __global__ __launch_bounds__(256) void avgpool3x3_kernel(const PoolParams p) {
     const int x = int(pix % p.Wd); pix /= p.Wd;
     const int y = int(pix % p.H);
     const long b = pix / p.H;
-    const T* X = static_cast<const T*>(p.X);
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    // nine unconditional loads from clamped addresses (all in flight together); taps outside the map are zeroed afterwards
+    // nine unconditional loads, all in flight together, through a range-checked buffer resource (ach_platform.h): taps outside the
+    // map get an out-of-range offset and read zeros
+    constexpr unsigned ESZ = sizeof(T);
+    const unsigned pitch = unsigned(p.ldx) * ESZ;
+    const BufRsrc xb = make_buf(p.X, unsigned(p.B) * unsigned(p.H) * unsigned(p.Wd) * pitch);
+    const unsigned pix0 = (unsigned(b) * unsigned(p.H) + unsigned(y)) * unsigned(p.Wd) + unsigned(x);
     float v[9][4];
     ACH_UNROLL
     for (int k = 0; k < 9; ++k) {
-        const int iy = y + k / 3 - 1, ix = x + k % 3 - 1;
-        const int cy = iy < 0 ? 0 : (iy >= p.H ? p.H - 1 : iy), cx = ix < 0 ? 0 : (ix >= p.Wd ? p.Wd - 1 : ix);
-        Store<T>::ld4(X + ((b * p.H + cy) * p.Wd + cx) * p.ldx + c, v[k]);
+        const int dy = k / 3 - 1, dx = k % 3 - 1;
+        const int iy = y + dy, ix = x + dx;
+        const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.Wd;
+        buf_ld4<T>(xb, ok ? unsigned(int(pix0) + dy * p.Wd + dx) * pitch + unsigned(c) * ESZ : BUF_OOB, v[k]);
     }
     ACH_UNROLL
-    for (int k = 0; k < 9; ++k) {
-        const int iy = y + k / 3 - 1, ix = x + k % 3 - 1;
-        const float ok = (iy >= 0 && iy < p.H && ix >= 0 && ix < p.Wd) ? 1.f : 0.f;
-        acc[0] += v[k][0] * ok; acc[1] += v[k][1] * ok; acc[2] += v[k][2] * ok; acc[3] += v[k][3] * ok;
-    }
+    for (int k = 0; k < 9; ++k) { acc[0] += v[k][0]; acc[1] += v[k][1]; acc[2] += v[k][2]; acc[3] += v[k][3]; }
     ACH_UNROLL
     for (int i = 0; i < 4; ++i) acc[i] *= (1.0f / 9.0f);
     Store<T>::st4(static_cast<T*>(p.Y) + b * p.ypi + y * p.ypr + x * p.ldy + c, acc);
