@@ -79,6 +79,7 @@ int ach_set_option(ach_handle* h, const char* key, int32_t value) {
         else if (std::string(key) == "row_conv") h->eng->row_conv = value != 0;
         else if (std::string(key) == "fused_rc") h->eng->fuse_rc = value != 0;
         else if (std::string(key) == "dw_tile") h->eng->dw_tile = value != 0;
+        else if (std::string(key) == "stem_mfma") h->eng->stem_mfma = value != 0;
         else if (std::string(key) == "point_stream2") h->eng->point_on_head_stream = value;
         else if (std::string(key) == "head_batch") h->eng->head_batch = value != 0;
         else if (std::string(key) == "side_priority") h->eng->side_low_priority = value;

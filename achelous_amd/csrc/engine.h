@@ -77,6 +77,7 @@ public:
                                       // lowest stream priority
     bool head_batch = true;           // option "head_batch": each detection-head layer as one launch for the three pyramid levels
     int point_on_head_stream = -1;    // option "point_stream2" (-1 auto / 0 / 1): the point branch opens stream 2 (ahead of fusion + head) instead of queueing behind the radar branch
+    bool stem_mfma = true;            // option "stem_mfma": the 4x4/s4 stem conv as an MFMA GEMM gathered from the NCHW image
     bool dw_tile = true;              // option "dw_tile": LDS-tiled depthwise kernel on the 10x10 maps
     bool fuse_rc = true;              // option "fused_rc": RCBlock conv + deformable sampling + contraction as one launch (k_conv3.h)
     bool row_conv = true;             // option "row_conv": narrow 3x3 convs through k_conv3.h instead of the generic implicit GEMM

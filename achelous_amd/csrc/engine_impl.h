@@ -534,11 +534,20 @@ public:
                 for (int o = 0; o < 32; ++o)
                     for (int k = 0; k < 48; ++k) wt[size_t(k) * 32 + o] = w.data[size_t(o) * 48 + k];
                 x = alloc(B, R / 4, R / 4, 32);
-                StemParams sp{nullptr, x.p, up_f32(wt), up_f32(W(d + ".0.bias").data), up_f32(W(d + ".1.weight").data),
-                              up_f32(W(d + ".1.bias").data), B, R, R, 1e-6f};
-                const dim3 grid(unsigned(cdivl(x.rows(), 256))), block(256);
                 const void** img = &io.image;
-                add_op(d, [sp, grid, block, img](hipStream_t s) mutable { sp.X = *img; ACH_LAUNCH(stem_kernel<T>, grid, block, s, sp); });
+                Lin ls; ls.N = 32; ls.K = 48; ls.w = w.data; ls.b = W(d + ".0.bias").data;            // k = c*16 + dy*4 + dx: the conv weight's own order
+                Packed pk = pack(ls);
+                if (stem_mfma && pk.NT == 2 && pk.nchunks == 1 && x.ld == 32) {
+                    StemMfmaParams sp{nullptr, x.p, pk.w, pk.b, up_f32(W(d + ".1.weight").data), up_f32(W(d + ".1.bias").data), B, R, R, pk.ksteps, 1e-6f};
+                    const dim3 grid(unsigned(cdivl(x.rows(), 64))), block(256);
+                    add_op(d, [sp, grid, block, img](hipStream_t s) mutable { sp.X = *img; ACH_LAUNCH(stem_mfma_kernel<T>, grid, block, s, sp); },
+                           double(B) * 3 * R * R * sizeof(T) + double(x.rows()) * 32 * sizeof(T), 2.0 * double(x.rows()) * 48 * 32);
+                } else {
+                    StemParams sp{nullptr, x.p, up_f32(wt), up_f32(W(d + ".0.bias").data), up_f32(W(d + ".1.weight").data),
+                                  up_f32(W(d + ".1.bias").data), B, R, R, 1e-6f};
+                    const dim3 grid(unsigned(cdivl(x.rows(), 256))), block(256);
+                    add_op(d, [sp, grid, block, img](hipStream_t s) mutable { sp.X = *img; ACH_LAUNCH(stem_kernel<T>, grid, block, s, sp); });
+                }
             } else {
                 A t = alloc(x.B, x.H, x.W, x.C);
                 int G = 1;

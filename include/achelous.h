@@ -99,7 +99,8 @@ int ach_load_weights(ach_handle* h, const ach_tensor_desc* tensors, size_t n);
  * kernel), "dw_tile" (LDS-tiled depthwise kernel on 10x10 maps), "head_batch" (detection-head layers batched over the levels),
  * "head_stream" (radar + point branches share low-priority stream 1, fusion + head + NMS run on stream 2 at the caller's priority),
  * "side_priority" (with head_stream = 0: bit mask of the side streams created at the lowest stream priority),
- * "point_stream2" (-1 auto / 0 / 1: the point branch opens stream 2 ahead of fusion + head; auto = PointNet++ only). */
+ * "point_stream2" (-1 auto / 0 / 1: the point branch opens stream 2 ahead of fusion + head; auto = PointNet++ only),
+ * "stem_mfma" (the 4x4/s4 stem conv as an MFMA GEMM gathered from the NCHW image; 0: scalar-FMA kernel). */
 int ach_set_option(ach_handle* h, const char* key, int32_t value);
 
 /* Builds the launch plan and the activation arena for batch size B (re-plan to change B). */
