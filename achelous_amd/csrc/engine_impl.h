@@ -1447,6 +1447,10 @@ public:
     void plan(int B) override {
         if (B <= 0) throw AchError{ACH_ERR_INVALID, "batch must be positive"};
         if (weights.empty()) throw AchError{ACH_ERR_INVALID, "ach_load_weights must precede ach_plan"};
+        // several kernels address an activation tensor with 32-bit byte offsets (range-checked buffer resources): the largest NHWC
+        // tensor of a plan (full resolution x 32 channels) must stay below 2 GiB — 327 frames at 320x320 in bf16
+        if (double(B) * cfg.resolution * cfg.resolution * 32.0 * sizeof(T) >= 2147483648.0)
+            throw AchError{ACH_ERR_UNSUPPORTED, "batch too large for one plan (activation tensors of 2 GiB or more): split the batch"};
         batch = B;
         reset_plan();
         measuring = true;

@@ -166,3 +166,17 @@ def test_emulated_sppf_variant():
     eng.forward(x, xr, xp, outs)
     for a, b in zip(outs, (*det, se, lane, pc)):
         assert rel_err(a, b) < 2e-5
+
+
+def test_plan_refuses_batches_whose_activations_exceed_32_bit_offsets():
+    """Kernels that fetch taps through range-checked buffer resources address a tensor with 32-bit byte offsets: a plan whose
+    largest activation (full resolution x 32 channels) would reach 2 GiB is refused up front (ACH_ERR_UNSUPPORTED), before any
+    allocation; the caller shards the batch instead."""
+    from achelous_amd.engine import NativeEngine
+    kw, sd, _ = _setup('en_s0', 320, 1, 16)
+    eng = NativeEngine(emu_library(), num_det=kw['num_det'], num_seg=kw['num_seg'], phi=kw['phi'], backbone=kw['backbone'],
+                       resolution=320, pc_channels=kw['pc_channels'], pc_classes=kw['pc_classes'], num_points=16,
+                       nano_head=kw['nano_head'], spp=kw['spp'], dtype=DTYPE_BF16)
+    eng.load_state_dict(sd)
+    with pytest.raises(NotImplementedError):
+        eng.plan(328)
