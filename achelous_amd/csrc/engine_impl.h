@@ -1003,7 +1003,8 @@ public:
             const int C = chans[i], Cp = int(x.ld);
             // AvgPool2d(3,1,1)
             Bordered pooled = alloc_bordered(B, x.H, x.W, C);
-            { PoolParams pp{x.p, x.ld, pooled.p0, pooled.ld, B, x.H, x.W, C, pooled.row, pooled.img}; ew(pfx + ".avgpool", avgpool3x3_kernel<T>, pp, x.rows() * ((C + 3) / 4), 2.0 * x.rows() * Cp * sizeof(T)); }
+            { PoolParams pp{x.p, x.ld, pooled.p0, pooled.ld, B, x.H, x.W, C, pooled.row, pooled.img}; if (C >= 16) ew(pfx + ".avgpool", avgpool3x3_kernel<T, 4>, pp, long(B) * x.H * cdiv(x.W, 4) * ((C + 3) / 4), 2.0 * x.rows() * Cp * sizeof(T));
+              else ew(pfx + ".avgpool", avgpool3x3_kernel<T, 1>, pp, x.rows() * ((C + 3) / 4), 2.0 * x.rows() * Cp * sizeof(T)); }
             // offset_conv (18) + modulator_conv (9) as one implicit GEMM
             Lin lo = conv_lin(d + ".offset_conv.weight", d + ".offset_conv.bias", C, Cp, 3);
             Lin lm = conv_lin(d + ".modulator_conv.weight", d + ".modulator_conv.bias", C, Cp, 3);
@@ -1270,7 +1271,7 @@ public:
         Rows g = pc_layer_max(p + ".feat.conv3", h, lin_bn1d(p + ".feat.conv3", p + ".feat.bn3"), ACT_NONE, B);
         { TapInfo t; t.ptr = g.p; t.kind = 2; t.B = B; t.H = 1; t.W = 1; t.C = g.C; t.ld = g.ld; add_tap("pc.global", t); }
         Rows cat = alloc_rows(long(B) * N, g.C + kf);
-        { PcConcatParams q{g.p, g.ld, pf.p, pf.ld, cat.p, cat.ld, B, N, g.C, kf}; ew(p + ".concat", pc_concat_kernel<T>, q, long(B) * N * (g.C + kf)); }
+        { PcConcatParams q{g.p, g.ld, pf.p, pf.ld, cat.p, cat.ld, B, N, g.C, kf}; if ((g.C | kf) & 3) throw AchError{ACH_ERR_UNSUPPORTED, "PointNet feature widths must be multiples of 4"}; ew(p + ".concat", pc_concat_kernel<T>, q, long(B) * N * ((g.C + kf) / 4)); }
         Rows y = pc_layer(p + ".conv1", cat, lin_bn1d(p + ".conv1", p + ".bn1"), ACT_RELU);
         y = pc_layer(p + ".conv2", y, lin_bn1d(p + ".conv2", p + ".bn2"), ACT_RELU);
         y = pc_layer(p + ".conv3", y, lin_bn1d(p + ".conv3", p + ".bn3"), ACT_RELU);

@@ -60,15 +60,16 @@ __global__ void pc_pack_transform_kernel(const PcPackParams p) {
 struct PcConcatParams { const void* g; long ldg; const void* f; long ldf; void* Y; long ldy; int B, N, G, F; };
 template <class T>
 __global__ void pc_concat_kernel(const PcConcatParams p) {
-    const int C = p.G + p.F;
+    const int C4 = (p.G + p.F) >> 2;                       // one thread = 4 channels (G and F are multiples of 4: 128 + 32)
     const long idx = long(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (idx >= long(p.B) * p.N * C) return;
-    const int c = int(idx % C);
-    const long row = idx / C;
+    if (idx >= long(p.B) * p.N * C4) return;
+    const int c = int(idx % C4) * 4;
+    const long row = idx / C4;
     const long b = row / p.N;
-    const float v = c < p.G ? Store<T>::ld(static_cast<const T*>(p.g) + b * p.ldg + c)
-                            : Store<T>::ld(static_cast<const T*>(p.f) + row * p.ldf + (c - p.G));
-    Store<T>::st(static_cast<T*>(p.Y) + row * p.ldy + c, v);
+    float v[4];
+    if (c < p.G) Store<T>::ld4(static_cast<const T*>(p.g) + b * p.ldg + c, v);
+    else Store<T>::ld4(static_cast<const T*>(p.f) + row * p.ldf + (c - p.G), v);
+    Store<T>::st4(static_cast<T*>(p.Y) + row * p.ldy + c, v);
 }
 
 // log_softmax over the class axis; output dense [rows, K]

@@ -34,37 +34,57 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const ToNhwcParams p)
 // The output goes to a buffer with a one-pixel ZERO BORDER around every sample (Y points at pixel (0,0) of sample 0, ypr / ypi are
 // its row / image pitches in elements): the 3x3 conv and the deformable sampling that read it need no bounds logic at all.
 struct PoolParams { const void* X; long ldx; void* Y; long ldy; int B, H, Wd, C; long ypr, ypi; };
-template <class T>
+// One thread = 4 channels x a strip of AVG_OW consecutive output pixels of one row: the 3 x (AVG_OW + 2) window is fetched once
+// (18 loads for 4 outputs instead of 36), summed by columns first and then across three columns — the kernel was VALU-issue bound
+// (SQ counters: 239 VALU instructions per wave against a 46 us launch at 320x320, exactly the VALU floor), and per output this
+// is 4.5 loads, 20 adds and a quarter of the index arithmetic instead of 9, 36 and all of it.
+// (AVG_OW = 1 for maps with fewer than 16 channels: with one or two channel groups per pixel a strip per lane spreads a wave's
+// loads over 4x more cache lines and the texture path becomes the limit — measured 47 -> 55 us on the 3-channel 320x320 map.)
+template <class T, int AVG_OW>
 __global__ __launch_bounds__(256) void avgpool3x3_kernel(const PoolParams p) {
     const int cq = (p.C + 3) >> 2;
-    const long total = long(p.B) * p.H * p.Wd * cq;
+    const int strips = (p.Wd + AVG_OW - 1) / AVG_OW;
+    const long total = long(p.B) * p.H * strips * cq;
     const long idx = long(xcd_block(blockIdx.x, gridDim.x)) * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const int c = int(idx % cq) * 4;
-    long pix = idx / cq;
-    const int x = int(pix % p.Wd); pix /= p.Wd;
-    const int y = int(pix % p.H);
-    const long b = pix / p.H;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    // nine unconditional loads, all in flight together, through a range-checked buffer resource (ach_platform.h): taps outside the
-    // map get an out-of-range offset and read zeros
+    long r = idx / cq;
+    const int x0 = int(r % strips) * AVG_OW; r /= strips;
+    const int y = int(r % p.H);
+    const long b = r / p.H;
+    // taps through a range-checked buffer resource (ach_platform.h): outside the map -> out-of-range offset -> zeros
     constexpr unsigned ESZ = sizeof(T);
     const unsigned pitch = unsigned(p.ldx) * ESZ;
     const BufRsrc xb = make_buf(p.X, unsigned(p.B) * unsigned(p.H) * unsigned(p.Wd) * pitch);
-    const unsigned pix0 = (unsigned(b) * unsigned(p.H) + unsigned(y)) * unsigned(p.Wd) + unsigned(x);
-    float v[9][4];
+    unsigned coff[AVG_OW + 2];
     ACH_UNROLL
-    for (int k = 0; k < 9; ++k) {
-        const int dy = k / 3 - 1, dx = k % 3 - 1;
-        const int iy = y + dy, ix = x + dx;
-        const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.Wd;
-        buf_ld4<T>(xb, ok ? unsigned(int(pix0) + dy * p.Wd + dx) * pitch + unsigned(c) * ESZ : BUF_OOB, v[k]);
+    for (int j = 0; j < AVG_OW + 2; ++j) {
+        const int ix = x0 - 1 + j;
+        coff[j] = (ix >= 0 && ix < p.Wd) ? unsigned(ix) * pitch + unsigned(c) * ESZ : BUF_OOB / 2;     // + row offset: >= 2^30, out of range (radar maps are < 1 GiB, see plan())
     }
+    float col[AVG_OW + 2][4];
     ACH_UNROLL
-    for (int k = 0; k < 9; ++k) { acc[0] += v[k][0]; acc[1] += v[k][1]; acc[2] += v[k][2]; acc[3] += v[k][3]; }
+    for (int j = 0; j < AVG_OW + 2; ++j) { col[j][0] = 0.f; col[j][1] = 0.f; col[j][2] = 0.f; col[j][3] = 0.f; }
     ACH_UNROLL
-    for (int i = 0; i < 4; ++i) acc[i] *= (1.0f / 9.0f);
-    Store<T>::st4(static_cast<T*>(p.Y) + b * p.ypi + y * p.ypr + x * p.ldy + c, acc);
+    for (int dy = -1; dy <= 1; ++dy) {
+        const int iy = y + dy;
+        const unsigned rowb = (iy >= 0 && iy < p.H) ? (unsigned(b) * unsigned(p.H) + unsigned(iy)) * unsigned(p.Wd) * pitch : BUF_OOB;
+        ACH_UNROLL
+        for (int j = 0; j < AVG_OW + 2; ++j) {
+            float v[4];
+            buf_ld4<T>(xb, rowb + coff[j], v);                  // 2^31 + 2^30 at most: no wrap
+            col[j][0] += v[0]; col[j][1] += v[1]; col[j][2] += v[2]; col[j][3] += v[3];
+        }
+    }
+    T* yrow = static_cast<T*>(p.Y) + b * p.ypi + y * p.ypr + c;
+    ACH_UNROLL
+    for (int o = 0; o < AVG_OW; ++o) {
+        if (x0 + o >= p.Wd) break;
+        float acc[4];
+        ACH_UNROLL
+        for (int i = 0; i < 4; ++i) acc[i] = ((col[o][i] + col[o + 1][i]) + col[o + 2][i]) * (1.0f / 9.0f);
+        Store<T>::st4(yrow + long(x0 + o) * p.ldy, acc);
+    }
 }
 
 // ---- shared by both deformable kernels: one tap's bilinear footprint (torchvision 0.12.0 deform_conv2d semantics:
