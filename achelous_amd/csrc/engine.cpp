@@ -43,6 +43,7 @@ EngineBase::~EngineBase() {
 }
 
 void EngineBase::load(const ach_tensor_desc* t, size_t n) {
+    (void)hipDeviceSynchronize();          // a forward in flight still reads the packed weights the next plan() will overwrite
     weights.clear();
     for (size_t i = 0; i < n; ++i) {
         if (!t[i].name || !t[i].data || t[i].ndim < 0 || t[i].ndim > 4) throw AchError{ACH_ERR_INVALID, "bad tensor descriptor"};

@@ -1452,6 +1452,9 @@ public:
         // tensor of a plan (full resolution x 32 channels) must stay below 2 GiB — 327 frames at 320x320 in bf16
         if (double(B) * cfg.resolution * cfg.resolution * 32.0 * sizeof(T) >= 2147483648.0)
             throw AchError{ACH_ERR_UNSUPPORTED, "batch too large for one plan (activation tensors of 2 GiB or more): split the batch"};
+        // the arenas are rewritten below with synchronous copies on the null stream, which does not order against non-blocking
+        // streams: a forward still in flight on the caller's or the side streams must have drained first
+        ACH_HIP_CHECK(hipDeviceSynchronize());
         batch = B;
         reset_plan();
         measuring = true;

@@ -100,7 +100,9 @@ static __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsParams
             bx[e][0] = __fsub_rn(r[0], hw); bx[e][1] = __fsub_rn(r[1], hh);
             bx[e][2] = __fadd_rn(r[0], hw); bx[e][3] = __fadd_rn(r[1], hh);
             float best = r[5]; int bi = 0;
-            for (int c = 1; c < p.num_classes; ++c) if (r[5 + c] > best) { best = r[5 + c]; bi = c; }
+            // torch.max over the classes (utils_bbox.py:109) propagates NaN: the first NaN wins and stays, the score becomes NaN and
+            // the `>= conf_thres` filter below drops the anchor
+            for (int c = 1; c < p.num_classes; ++c) if (best == best && !(r[5 + c] <= best)) { best = r[5 + c]; bi = c; }
             bconf[e] = best; bcls[e] = bi; bobj[e] = r[4];
             bscore[e] = __fmul_rn(r[4], best);
             flag[e] = bscore[e] >= p.conf ? 1 : 0;
@@ -235,9 +237,14 @@ static __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const NmsParams
         }
         __syncthreads();
     }
-    if (tid == 0) s_n = kept_total;
-    __syncthreads();
-    if (tid == 0) p.count[b] = s_n < p.max_det ? s_n : p.max_det;
+    // unused output slots: zero rows, index -1 (the caller hands over uninitialised buffers; kept_total is uniform)
+    for (int slot = (kept_total < p.max_det ? kept_total : p.max_det) + tid; slot < p.max_det; slot += NMS_THREADS) {
+        float* r = p.rows + (long(b) * p.max_det + slot) * 7;
+        ACH_UNROLL
+        for (int c = 0; c < 7; ++c) r[c] = 0.f;
+        p.kept[long(b) * p.max_det + slot] = -1;
+    }
+    if (tid == 0) p.count[b] = kept_total < p.max_det ? kept_total : p.max_det;
 }
 
 }  // namespace ach

@@ -5,9 +5,11 @@ batch slices with replicated weights and NO data-path collective; the only excha
 fixed-size detection records.  This replaces the reference's `nn.DataParallel` scatter/gather through
 GPU 0 (achelous.py:176).
 
-Record per frame (int32 words): max_det x 7 fp32 rows [x1,y1,x2,y2,obj,cls_conf,cls_id] (bit-cast) | max_det kept anchor
-indices | 1 count.  At max_det = 100 that is 3204 B per frame: 205 KB per rank per 64-frame shard, far below the
-bandwidth-bound regime of the xGMI links — latency-bound, one collective per batch.
+Record of a shard of S frames = ONE flat int32 buffer, planar:
+    S x max_det x 7 fp32 rows [x1,y1,x2,y2,obj,cls_conf,cls_id] (bit-cast) | S x max_det kept anchor indices | S counts
+`Achelous.forward_detect` lets the NMS kernel write straight into such a buffer (its rows / idx / cnt results are views of it),
+so nothing is packed or cast before the collective and nothing is copied after it: the gathered [world, words] tensor is read
+through views.  At max_det = 100 a 64-frame shard is 205 KB: latency-bound, far below the xGMI links' bandwidth regime.
 """
 import torch
 import torch.distributed as dist
@@ -20,62 +22,97 @@ def shard_bounds(global_batch, world_size, rank):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def record_width(max_det):
-    return max_det * 7 + max_det + 1
+def shard_capacity(global_batch, world_size):
+    """Frames per rank in the exchanged record: the largest shard (ranks with one frame fewer pad with an empty frame)."""
+    return -(-int(global_batch) // int(world_size))
 
 
-def pack_records(rows, idx, cnt):
-    """rows [B,max_det,7] fp32, idx [B,max_det] int32, cnt [B] int32 -> [B, record_width] int32 (bit-exact)."""
-    B, max_det, _ = rows.shape
-    return torch.cat([rows.contiguous().view(B, max_det * 7).view(torch.int32), idx.to(torch.int32),
-                      cnt.to(torch.int32).view(B, 1)], dim=1).contiguous()
+def record_words(frames, max_det):
+    return frames * (max_det * 8 + 1)
 
 
-def unpack_records(rec, max_det):
-    n = rec.shape[0]
-    rows = rec[:, :max_det * 7].contiguous().view(torch.float32).view(n, max_det, 7)
-    return rows, rec[:, max_det * 7:max_det * 8].contiguous(), rec[:, max_det * 8].contiguous()
+def pack_records(rows, idx, cnt, frames=None):
+    """rows [S,max_det,7] fp32, idx [S,max_det] int32, cnt [S] int32 -> flat int32 [record_words(frames)] (bit-exact).
+    Zero-copy when the three are the views `forward_detect` handed out and no padding is asked for; `frames` > S appends empty
+    frames (count 0, indices -1, rows 0) so that every rank contributes the same number of words."""
+    S, max_det, _ = rows.shape
+    frames = S if frames is None else int(frames)
+    if frames < S:
+        raise ValueError(f"record capacity {frames} is smaller than the shard ({S} frames)")
+    rec = getattr(rows, '_ach_record', None)
+    if frames == S and rec is not None and rec.numel() == record_words(S, max_det):
+        return rec
+    pad = frames - S
+    parts = [rows.contiguous().view(-1).view(torch.int32)]
+    if pad:
+        parts.append(torch.zeros(pad * max_det * 7, dtype=torch.int32, device=rows.device))
+    parts.append(idx.to(torch.int32).reshape(-1))
+    if pad:
+        parts.append(torch.full((pad * max_det,), -1, dtype=torch.int32, device=rows.device))
+    parts.append(cnt.to(torch.int32).reshape(-1))
+    if pad:
+        parts.append(torch.zeros(pad, dtype=torch.int32, device=rows.device))
+    return torch.cat(parts)
 
 
-def all_gather_detections(rows, idx, cnt, group=None):
-    """Every rank contributes the records of its shard (same shard size on every rank); every rank receives the
-    records of the whole global batch, in rank order.  One collective."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rec = pack_records(rows, idx, cnt)
-    if world == 1:
-        return rows, idx, cnt
-    out = torch.empty(world * rec.shape[0], rec.shape[1], dtype=torch.int32, device=rec.device)
-    dist.all_gather_into_tensor(out, rec, group=group)
-    return unpack_records(out, rows.shape[1])
+def unpack_records(rec, frames, max_det):
+    """[world, record_words(frames)] (or flat, one rank) int32 -> VIEWS rows [world,frames,max_det,7] fp32, idx [world,frames,max_det],
+    cnt [world,frames].  No copy."""
+    rec = rec.view(-1, record_words(frames, max_det))
+    a, b = frames * max_det * 7, frames * max_det * 8
+    rows = rec[:, :a].view(torch.float32).unflatten(1, (frames, max_det, 7))
+    return rows, rec[:, a:b].unflatten(1, (frames, max_det)), rec[:, b:]
+
+
+def flatten_gathered(rows, idx, cnt, global_batch=None):
+    """Rank-major views -> [global_batch, ...] tensors in frame order (copies; drops the padding frames of unequal shards)."""
+    world, frames = cnt.shape
+    if global_batch is None or global_batch == world * frames:
+        return rows.reshape(world * frames, *rows.shape[2:]), idx.reshape(world * frames, -1), cnt.reshape(-1)
+    keep = [torch.arange(hi - lo, device=cnt.device) + r * frames for r, (lo, hi) in
+            enumerate(shard_bounds(global_batch, world, r) for r in range(world))]
+    keep = torch.cat(keep)
+    return rows.reshape(world * frames, *rows.shape[2:])[keep], idx.reshape(world * frames, -1)[keep], cnt.reshape(-1)[keep]
 
 
 class PendingDetections:
     """Handle of an all-gather in flight.  `wait()` makes the CURRENT stream wait for the collective (no host block on GPU
-    backends) and returns the gathered (rows, idx, cnt).  The collective runs on the backend's own stream, so whatever the caller
-    enqueues between the submit and the wait - normally the next batch's forward - overlaps with it."""
+    backends) and returns rank-major VIEWS of the receive buffer: rows [world, frames, max_det, 7], idx [world, frames, max_det],
+    cnt [world, frames] (frames = shard capacity; see flatten_gathered).  The collective runs on the backend's own stream, so
+    whatever the caller enqueues between the submit and the wait - normally the next batch's forward - overlaps with it."""
 
-    def __init__(self, work, rec, out, max_det, local):
-        self._work, self._rec, self._out, self._max_det, self._local = work, rec, out, max_det, local
+    def __init__(self, work, rec, out, frames, max_det):
+        self._work, self._rec, self._out, self._frames, self._max_det = work, rec, out, frames, max_det
 
     def wait(self):
         if self._work is not None:
             self._work.wait()
             self._work = None
-            self._local = unpack_records(self._out, self._max_det)
-        return self._local
+        return unpack_records(self._out, self._frames, self._max_det)
 
 
-def all_gather_detections_async(rows, idx, cnt, group=None, out=None, force=False):
-    """As all_gather_detections, but returns a PendingDetections immediately; `out` (optional, [world * B, record_width] int32)
-    lets a serving loop reuse its receive buffers (two of them, alternating, when one step's gather is waited for in the next)."""
+def all_gather_detections_async(rows, idx, cnt, group=None, out=None, force=False, global_batch=None):
+    """One collective: every rank contributes the record of its shard, every rank receives all of them in rank order.
+    `global_batch`: needed when the shards differ in size (global batch not divisible by the world size) - every rank then sends
+    shard_capacity frames.  `out` (optional, flat int32 [world * record_words(frames)]) lets a serving loop reuse its receive
+    buffers (two of them, alternating, when one step's gather is waited for in the next).  `force`: diagnostic, run the collective
+    even on one rank."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1 and not (force and dist.is_initialized()):      # `force`: diagnostic, run the collective even on one rank
-        return PendingDetections(None, None, None, rows.shape[1], (rows, idx, cnt))
-    rec = pack_records(rows, idx, cnt)
+    S, max_det, _ = rows.shape
+    frames = S if global_batch is None else shard_capacity(global_batch, world)
+    rec = pack_records(rows, idx, cnt, frames)
+    if world == 1 and not (force and dist.is_initialized()):
+        return PendingDetections(None, rec, rec, frames, max_det)
     if out is None:
-        out = torch.empty(world * rec.shape[0], rec.shape[1], dtype=torch.int32, device=rec.device)
+        out = torch.empty(world * rec.numel(), dtype=torch.int32, device=rec.device)
     work = dist.all_gather_into_tensor(out, rec, group=group, async_op=True)
-    return PendingDetections(work, rec, out, rows.shape[1], None)
+    return PendingDetections(work, rec, out, frames, max_det)
+
+
+def all_gather_detections(rows, idx, cnt, group=None, global_batch=None):
+    """Blocking form: the gathered detections of the whole global batch in frame order (rows [G,max_det,7], idx, cnt)."""
+    r, i, c = all_gather_detections_async(rows, idx, cnt, group, global_batch=global_batch).wait()
+    return flatten_gathered(r, i, c, global_batch)
 
 
 class ShardedDetector:
@@ -83,14 +120,16 @@ class ShardedDetector:
     achelous_amd.Achelous on this rank's GPU.  `__call__` returns the gathered detections; `submit` returns a PendingDetections so
     that a serving loop can wait for batch k's detections after it has enqueued batch k+1."""
 
-    def __init__(self, model, conf_thres=0.35, nms_thres=0.35, max_det=100, group=None):
-        self.model, self.conf, self.iou, self.max_det, self.group = model, conf_thres, nms_thres, max_det, group
+    def __init__(self, model, conf_thres=0.35, nms_thres=0.35, max_det=100, group=None, global_batch=None, force_collective=False):
+        self.model, self.conf, self.iou, self.max_det, self.group, self.global_batch = model, conf_thres, nms_thres, max_det, group, global_batch
+        self.force_collective = force_collective          # diagnostic: run the collective even at world size 1
 
     @torch.no_grad()
     def submit(self, x, x_radar, x_points, out=None):
         (det, se, lane, pc), (rows, idx, cnt) = self.model.forward_detect(x, x_radar, x_points, self.conf, self.iou, self.max_det)
-        return all_gather_detections_async(rows, idx, cnt, self.group, out), (se, lane, pc)
+        return all_gather_detections_async(rows, idx, cnt, self.group, out, self.force_collective, self.global_batch), (se, lane, pc)
 
     def __call__(self, x, x_radar, x_points):
         pending, seg = self.submit(x, x_radar, x_points)
-        return pending.wait(), seg                            # segmentation outputs stay sharded on their rank
+        r, i, c = pending.wait()
+        return flatten_gathered(r, i, c, self.global_batch), seg       # segmentation outputs stay sharded on their rank

@@ -49,6 +49,11 @@ class Achelous(nn.Module):
         # forward raises for anything else).  Ours follows our own specification of that branch: achelous_amd/spec.py::PN2.
         if phi not in ('S0', 'S1', 'S2'):
             raise NotImplementedError(f"phi={phi!r}: only S0, S1, S2 exist for the en/mv backbones")
+        if backbone == 'en' and phi == 'S1':
+            raise NotImplementedError("backbone='en', phi='S1': the XCA kernel handles head widths up to 48, EdgeNeXt-S1 needs 56 "
+                                      "(not a BASELINE.json config); EN-S0, EN-S2 and MV-S0/S1/S2 are built")
+        if neck == 'gdf' and not 1 <= num_seg <= 16:
+            raise NotImplementedError(f"num_seg={num_seg}: the fused segmentation-head kernel writes up to 16 classes")
         if not nano_head:
             raise NotImplementedError("nano_head=False (256-channel head) is not built")
         if image_channels != 3 or radar_channels != 3:
@@ -59,7 +64,7 @@ class Achelous(nn.Module):
         self.pc_channels, self.pc_classes, self.nano_head, self.spp = pc_channels, pc_classes, nano_head, spp
         _build_tree(self, state_dict_spec(num_det, num_seg, phi, backbone, pc_channels, pc_classes, nano_head, radar_channels, neck, pc_seg))
         self._init_like_reference()
-        self._engines = {}          # (device index, dtype) -> [NativeEngine, weight version, num_points]
+        self._engines = {}          # (device index, dtype, padded num_points) -> [NativeEngine, weight version]
         self.debug_taps = False     # True: the engine also materialises every SURVEY §8(a) boundary (parity tests)
         self.static_weights = False  # True: skip the per-call check for in-place weight changes (serving loops)
         self.engine_options = {}    # ach_set_option(key, value) pairs applied when an engine is created (include/achelous.h)
@@ -68,6 +73,7 @@ class Achelous(nn.Module):
     def __getstate__(self):
         st = self.__dict__.copy()
         st['_engines'] = {}
+        st['_wt_list'] = None
         return st
 
     def _init_like_reference(self):
@@ -91,7 +97,34 @@ class Achelous(nn.Module):
 
     # ---------------------------------------------------------------------------------------------------
     def _weights_version(self):
-        return sum(t._version for t in self.parameters()) + sum(t._version for t in self.buffers())
+        """Changes when any parameter / buffer is written in place, replaced, moved or reloaded.  The tensor list is cached (a walk
+        of the ~300-module tree per call costs more than the launch of a small kernel); `_apply` (.to / .cuda / .float ...) and
+        `load_state_dict` drop the cache, in-place writes show up in the tensors' version counters."""
+        ts = self.__dict__.get('_wt_list')
+        if ts is None:
+            ts = self.__dict__['_wt_list'] = tuple(self.parameters()) + tuple(self.buffers())
+            self.__dict__['_wt_epoch'] = self.__dict__.get('_wt_epoch', 0) + 1
+        v = 0
+        for t in ts:
+            v += t._version
+        return (self.__dict__['_wt_epoch'], v)
+
+    def _apply(self, fn, *a, **k):
+        self.__dict__['_wt_list'] = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self.__dict__['_wt_list'] = None
+        return super().load_state_dict(*a, **k)
+
+    def native_engine(self, dtype=torch.float32, device=None):
+        """The engine that served the last forward of this dtype on `device` (tests, bench: taps, launch table, options)."""
+        code = _eng.DTYPE_BF16 if dtype == torch.bfloat16 else _eng.DTYPE_F32
+        dev = torch.cuda.current_device() if device is None else torch.device(device).index
+        hits = [v[0] for k, v in self._engines.items() if k[:2] == (dev, code)]
+        if not hits:
+            raise KeyError(f"no forward has run yet for dtype {dtype} on device {dev}")
+        return hits[-1]
 
     def _engine_for(self, device, dtype, batch, num_points):
         if dtype == torch.float32:
@@ -100,11 +133,10 @@ class Achelous(nn.Module):
             code = _eng.DTYPE_BF16
         else:
             raise TypeError(f"Achelous forward supports float32 and bfloat16 inputs, got {dtype}")
-        key = (device.index, code)
-        ent0 = self._engines.get(key)
-        ver = ent0[1] if (self.static_weights and ent0 is not None and ent0[1] is not None) else self._weights_version()
+        key = (device.index, code, num_points)          # one engine per point-count bucket: a new N never evicts another's plan
         ent = self._engines.get(key)
-        if ent is None or ent[2] != num_points:
+        ver = ent[1] if (self.static_weights and ent is not None and ent[1] is not None) else self._weights_version()
+        if ent is None:
             eng = _eng.NativeEngine(_eng.hip_library(), num_det=self.num_det, num_seg=self.num_seg, phi=self.phi,
                                     backbone=self.backbone, resolution=self.resolution, pc_channels=self.pc_channels,
                                     pc_classes=self.pc_classes, num_points=num_points, nano_head=self.nano_head,
@@ -112,7 +144,7 @@ class Achelous(nn.Module):
             eng.set_option('full_taps', 1 if self.debug_taps else 0)
             for k, v in self.engine_options.items():
                 eng.set_option(k, int(v))
-            ent = [eng, None, num_points]
+            ent = [eng, None]
             self._engines[key] = ent
         if ent[1] != ver:
             ent[0].load_state_dict(self.state_dict())
@@ -142,10 +174,18 @@ class Achelous(nn.Module):
             raise ValueError(f"expected image and radar map of shape [B,3,{R},{R}], got {tuple(x.shape)} / {tuple(x_radar.shape)}")
         if x_point_clouds.dim() != 3 or x_point_clouds.shape[0] != B or x_point_clouds.shape[1] != self.pc_channels:
             raise ValueError(f"expected points of shape [B,{self.pc_channels},N], got {tuple(x_point_clouds.shape)}")
-        dt, dev, N = x.dtype, x.device, x_point_clouds.shape[2]
+        dt, dev, n_in = x.dtype, x.device, x_point_clouds.shape[2]
+        # The reference takes any point count (achelous.py:240-243 feeds whatever the frame holds); the point kernels work on 16-row
+        # tiles.  PointNet is per-point MLPs + max over points, so repeating the last point changes nothing: pad to the next
+        # multiple of 16 (the engine's bucket) and trim the padded rows of the output.  PointNet++ (our own specification) samples
+        # and groups by index and takes multiples of 128 only.
+        N = n_in if self.pc_seg_kind == 'pn2' else -(-n_in // 16) * 16
         with torch.cuda.device(dev):
             eng = self._engine_for(dev, dt, B, N)
-            x, x_radar, pts = x.contiguous(), x_radar.to(dt).contiguous(), x_point_clouds.to(dt).contiguous()
+            x, x_radar, pts = x.contiguous(), x_radar.to(dt).contiguous(), x_point_clouds.to(dt)
+            if N != n_in:
+                pts = torch.cat([pts, pts[:, :, -1:].expand(-1, -1, N - n_in)], dim=2)
+            pts = pts.contiguous()
             nc5 = 5 + self.num_det
             det = [torch.empty(B, nc5, R // s, R // s, dtype=dt, device=dev) for s in (8, 16, 32)]
             se = torch.empty(B, self.num_seg, R, R, dtype=dt, device=dev)
@@ -154,17 +194,21 @@ class Achelous(nn.Module):
             stream = torch.cuda.current_stream(dev).cuda_stream
             if detect is None:
                 eng.forward(x, x_radar, pts, (det[0], det[1], det[2], se, lane, pc), stream)
-                return det, se, lane, pc
+                return det, se, lane, (pc if N == n_in else pc[:, :n_in].contiguous())
             conf, iou, max_det = detect
             A = sum((R // s) ** 2 for s in (8, 16, 32))
             if A > 4096:
                 raise NotImplementedError(f"device NMS handles up to 4096 anchors (resolution <= 416), got {A}")
             max_det = int(max_det or A)
             decoded = torch.empty(B, A, nc5, dtype=torch.float32, device=dev)
-            rows = torch.zeros(B, max_det, 7, dtype=torch.float32, device=dev)
-            idx = torch.full((B, max_det), -1, dtype=torch.int32, device=dev)
-            cnt = torch.zeros(B, dtype=torch.int32, device=dev)
+            # one flat int32 buffer in the all-gather record layout of achelous_amd/dist.py; rows / idx / cnt are views of it (the
+            # NMS kernel fills every slot: unused ones get zeros / -1, so nothing is memset here)
+            rec = torch.empty(B * (max_det * 8 + 1), dtype=torch.int32, device=dev)
+            rows = rec[:B * max_det * 7].view(torch.float32).view(B, max_det, 7)
+            idx = rec[B * max_det * 7:B * max_det * 8].view(B, max_det)
+            cnt = rec[B * max_det * 8:]
+            rows._ach_record = rec
             ws = torch.empty(eng.nms_workspace_bytes(B), dtype=torch.uint8, device=dev)
             eng.forward_detect(x, x_radar, pts, (det[0], det[1], det[2], se, lane, pc), decoded, conf, iou, max_det, rows, idx, cnt, ws, stream)
             # scratch is released to the caching allocator in stream order: the join at the end of the call orders it after the side stream
-        return (det, se, lane, pc), (rows, idx, cnt)
+        return (det, se, lane, pc if N == n_in else pc[:, :n_in].contiguous()), (rows, idx, cnt)

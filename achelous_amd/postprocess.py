@@ -16,6 +16,9 @@ _handles = {}
 
 
 def _handle(num_det, resolution, dtype):
+    if dtype not in (torch.float32, torch.bfloat16):
+        # the kernels exist for fp32 and bf16 storage only; any other element size would be read / written with the wrong stride
+        raise TypeError(f"achelous_amd kernels take float32 or bfloat16 tensors, got {dtype}")
     code = _eng.DTYPE_BF16 if dtype == torch.bfloat16 else _eng.DTYPE_F32
     key = (torch.cuda.current_device(), num_det, resolution, code)
     if key not in _handles:
@@ -30,6 +33,8 @@ def decode_outputs(outputs, input_shape, local_rank=None):
     d3, d4, d5 = [o.contiguous() for o in outputs]
     if not d3.is_cuda:
         raise RuntimeError("decode_outputs needs GPU tensors (HIP kernel; no CPU path)")
+    if not (d3.dtype == d4.dtype == d5.dtype):
+        raise TypeError(f"decode_outputs: the three head maps must share one dtype, got {d3.dtype}, {d4.dtype}, {d5.dtype}")
     B, nc5 = d3.shape[0], d3.shape[1]
     R = int(input_shape[0])
     if d3.shape[-1] * 8 != R or int(input_shape[1]) != R:
@@ -48,6 +53,8 @@ def nms_device(prediction, num_classes, conf_thres, nms_thres, max_det=None):
     if not p.is_cuda:
         raise RuntimeError("non_max_suppression needs a GPU tensor (HIP kernel; no CPU path)")
     B, A, nc5 = p.shape
+    if nc5 != 5 + int(num_classes):
+        raise ValueError(f"non_max_suppression: prediction rows have {nc5} columns, expected 5 + num_classes = {5 + int(num_classes)}")
     max_det = int(max_det or A)
     with torch.cuda.device(p.device):
         # A = (R/8)^2 + (R/16)^2 + (R/32)^2 = 21 (R/32)^2 for the square inputs the reference uses
@@ -56,9 +63,9 @@ def nms_device(prediction, num_classes, conf_thres, nms_thres, max_det=None):
             raise NotImplementedError(f"device NMS handles square inputs up to 416x416 (3549 anchors), got {A} anchors")
         R = 32 * g
         h = _handle(num_classes, R, torch.float32)
-        rows = torch.zeros(B, max_det, 7, dtype=torch.float32, device=p.device)
-        idx = torch.full((B, max_det), -1, dtype=torch.int32, device=p.device)
-        cnt = torch.zeros(B, dtype=torch.int32, device=p.device)
+        rows = torch.empty(B, max_det, 7, dtype=torch.float32, device=p.device)     # the kernel fills every slot (unused: 0 / -1)
+        idx = torch.empty(B, max_det, dtype=torch.int32, device=p.device)
+        cnt = torch.empty(B, dtype=torch.int32, device=p.device)
         ws = torch.empty(h.nms_workspace_bytes(B), dtype=torch.uint8, device=p.device)
         h.nms(B, p, conf_thres, nms_thres, max_det, rows, idx, cnt, ws, torch.cuda.current_stream().cuda_stream)
     return rows, idx, cnt

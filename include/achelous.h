@@ -128,7 +128,8 @@ int ach_decode(ach_handle* h, int32_t batch, const void* det3, const void* det4,
                float* decoded, void* stream);
 
 /* decoded [B,A,5+num_det] fp32 -> per image: rows [max_det,7] = x1,y1,x2,y2,obj,cls_conf,cls_id (normalised
- * corners), kept anchor indices [max_det] (descending score), count.  `workspace` >= ach_nms_workspace_bytes(). */
+ * corners), kept anchor indices [max_det] (descending score), count.  Every slot of the outputs is written: slots past `count`
+ * get zero rows and index -1 (the caller need not clear them).  `workspace` >= ach_nms_workspace_bytes(). */
 size_t ach_nms_workspace_bytes(const ach_handle* h, int32_t batch);
 int ach_nms(ach_handle* h, int32_t batch, const float* decoded, float conf_thres, float nms_thres, int32_t max_det,
             float* out_rows, int32_t* out_idx, int32_t* out_count, void* workspace, void* stream);

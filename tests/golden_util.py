@@ -50,6 +50,11 @@ class Golden:
                       abs(np.sqrt((flat.astype(np.float64) ** 2).sum() / n) - np.sqrt(s2 / n)) / scale)
         return err
 
+    def calibrate(self, sd):
+        """The fixture's BatchNorm2d running statistics on top of the seeded state dict (synth.apply_calibration)."""
+        from achelous_amd.synth import apply_calibration
+        return apply_calibration(sd, {k[len('calib::'):]: self.npz[k] for k in self.npz.files if k.startswith('calib::')})
+
     def nms(self, conf, iou, b):
         tag = f'nms_{conf}_{iou}_b{b}'
         return self.npz[tag + '::rows'], self.npz[tag + '::idx']

@@ -20,7 +20,7 @@ for dt in (torch.float32, torch.bfloat16):
     with torch.no_grad():
         det, se, lane, pc = m(x.cuda().to(dt), xr.cuda().to(dt), xp.cuda().to(dt))
     torch.cuda.synchronize()
-    e = m._engines[(0, E.DTYPE_F32 if dt == torch.float32 else E.DTYPE_BF16)][0]
+    e = m.native_engine(dt)
     print('==', dt, 'launches', e.launches(), 'arena MB', e.arena_bytes() / 1e6)
     for tap in e.tap_names():
         if tap in orc.taps:
@@ -36,7 +36,7 @@ for dt in (torch.float32, torch.bfloat16):
         torch.cuda.synchronize(); t0 = time.time()
         for _ in range(10): m(xs, rs, ps)
         torch.cuda.synchronize(); dtm = (time.time() - t0) / 10
-    e = m._engines[(0, E.DTYPE_F32 if dt == torch.float32 else E.DTYPE_BF16)][0]
+    e = m.native_engine(dt)
     print(f'== B=64 {dt}: {dtm*1e3:.2f} ms/forward = {B/dtm:.0f} frames/s ; arena {e.arena_bytes()/1e9:.2f} GB')
     outs = m(xs, rs, ps)
     ms = e.forward_profiled(xs, rs, ps, (outs[0][0], outs[0][1], outs[0][2], outs[1], outs[2], outs[3]), torch.cuda.current_stream().cuda_stream)

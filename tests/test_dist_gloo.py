@@ -8,7 +8,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from achelous_amd.dist import all_gather_detections, all_gather_detections_async, pack_records, record_width, shard_bounds, unpack_records
+from achelous_amd.dist import (all_gather_detections, all_gather_detections_async, flatten_gathered, pack_records, record_words,
+                               shard_bounds, shard_capacity, unpack_records)
 
 
 def _fake_shard(rank, B, max_det):
@@ -33,35 +34,43 @@ def _worker(rank, world, port, B, max_det, q):
         ok &= torch.equal(g_rows[sl].view(torch.int32), er.view(torch.int32))
         ok &= torch.equal(g_idx[sl], ei) and torch.equal(g_cnt[sl], ec)
     # the pipelined form: two gathers in flight into alternating receive buffers, waited for one step late
-    bufs = [torch.empty(world * B, max_det * 8 + 1, dtype=torch.int32) for _ in range(2)]
+    bufs = [torch.empty(world * record_words(B, max_det), dtype=torch.int32) for _ in range(2)]
     pend = None
     for step in range(3):
         r2, i2, c2 = _fake_shard(rank + 10 * step, B, max_det)
         nxt = all_gather_detections_async(r2, i2, c2, out=bufs[step & 1])
         if pend is not None:
-            pr, pi, pc = pend[0].wait()
+            pr, pi, pc = pend[0].wait()                      # rank-major views of the receive buffer
             for r in range(world):
                 er, ei, ec = _fake_shard(r + 10 * pend[1], B, max_det)
-                sl = slice(r * B, (r + 1) * B)
-                ok &= torch.equal(pr[sl].view(torch.int32), er.view(torch.int32)) and torch.equal(pi[sl], ei) and torch.equal(pc[sl], ec)
+                ok &= torch.equal(pr[r].view(torch.int32), er.view(torch.int32)) and torch.equal(pi[r], ei) and torch.equal(pc[r], ec)
         pend = (nxt, step)
     pend[0].wait()
+    # unequal shards: a global batch that the world size does not divide (the last ranks own one frame fewer and pad)
+    G = world * B - (world - 1)
+    lo, hi = shard_bounds(G, world, rank)
+    rows, idx, cnt = _fake_shard(50 + rank, hi - lo, max_det)
+    u_rows, u_idx, u_cnt = all_gather_detections(rows, idx, cnt, global_batch=G)
+    ok &= u_rows.shape[0] == G
+    for r in range(world):
+        rl, rh = shard_bounds(G, world, r)
+        er, ei, ec = _fake_shard(50 + r, rh - rl, max_det)
+        ok &= torch.equal(u_rows[rl:rh].view(torch.int32), er.view(torch.int32)) and torch.equal(u_idx[rl:rh], ei) and torch.equal(u_cnt[rl:rh], ec)
     q.put((rank, bool(ok), tuple(g_rows.shape)))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_all_gather_of_detection_records_world2():
+def _run_world(world, B, max_det):
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    world, B, max_det = 2, 5, 16
     procs = [ctx.Process(target=_worker, args=(r, world, port, B, max_det, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in range(world)]
+    res = [q.get(timeout=180) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -69,13 +78,32 @@ def test_all_gather_of_detection_records_world2():
     assert all(shape == (world * B, max_det, 7) for _, _, shape in res)
 
 
+def test_all_gather_of_detection_records_world2():
+    _run_world(2, 5, 16)
+
+
+def test_all_gather_of_detection_records_world4_unequal_last_shards():
+    _run_world(4, 3, 8)
+
+
 def test_record_roundtrip_and_shards():
     rows, idx, cnt = _fake_shard(0, 3, 8)
     rec = pack_records(rows, idx, cnt)
-    assert rec.shape == (3, record_width(8)) and rec.dtype == torch.int32
-    r2, i2, c2 = unpack_records(rec, 8)
-    assert torch.equal(r2.view(torch.int32), rows.view(torch.int32)) and torch.equal(i2, idx) and torch.equal(c2, cnt)
+    assert rec.shape == (record_words(3, 8),) and rec.dtype == torch.int32
+    r2, i2, c2 = unpack_records(rec, 3, 8)
+    assert torch.equal(r2[0].view(torch.int32), rows.view(torch.int32)) and torch.equal(i2[0], idx) and torch.equal(c2[0], cnt)
+    # padded to a capacity of 5 frames: the two extra frames are empty
+    r5, i5, c5 = unpack_records(pack_records(rows, idx, cnt, 5), 5, 8)
+    assert torch.equal(r5[0, :3].view(torch.int32), rows.view(torch.int32)) and int(c5[0, 3:].sum()) == 0 and bool((i5[0, 3:] == -1).all())
+    # views handed out by forward_detect are used as they are (no copy)
+    flat = torch.zeros(record_words(3, 8), dtype=torch.int32)
+    vr = flat[:3 * 8 * 7].view(torch.float32).view(3, 8, 7)
+    vr._ach_record = flat
+    assert pack_records(vr, flat[3 * 8 * 7:3 * 8 * 8].view(3, 8), flat[3 * 8 * 8:]).data_ptr() == flat.data_ptr()
     for gb, w in ((512, 8), (64, 1), (10, 4), (7, 8)):
         b = [shard_bounds(gb, w, r) for r in range(w)]
         assert b[0][0] == 0 and b[-1][1] == gb and all(b[i][1] == b[i + 1][0] for i in range(w - 1))
         assert max(hi - lo for lo, hi in b) - min(hi - lo for lo, hi in b) <= 1
+        assert shard_capacity(gb, w) == max(hi - lo for lo, hi in b)
+    g = flatten_gathered(*unpack_records(torch.arange(2 * record_words(2, 4), dtype=torch.int32), 2, 4), global_batch=3)
+    assert g[0].shape == (3, 4, 7) and g[2].shape == (3,)

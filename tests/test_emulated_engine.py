@@ -14,6 +14,7 @@ from achelous_amd.engine import DTYPE_BF16, DTYPE_F32
 from achelous_amd.synth import condition_state_dict, make_inputs
 from emu_util import alloc_outputs, emu_library, make_engine, rel_err
 from golden_util import GOLDEN_DIR
+from stress_cases import degenerate_decoded, stress_offsets
 from oracle.achelous_oracle import AchelousOracle, decode_outputs as o_decode, non_max_suppression as o_nms
 
 ORACLE_KEYS = ('num_det', 'num_seg', 'phi', 'backbone', 'neck', 'pc_seg', 'pc_channels', 'pc_classes', 'nano_head', 'spp', 'resolution')
@@ -180,3 +181,55 @@ def test_plan_refuses_batches_whose_activations_exceed_32_bit_offsets():
     eng.load_state_dict(sd)
     with pytest.raises(NotImplementedError):
         eng.plan(328)
+
+
+@pytest.mark.parametrize('mode', ['far', 'integer', 'wide'])
+def test_emulated_deformable_sampling_far_and_boundary_offsets(mode):
+    """Offsets a whole map away, exactly on the -1 / H boundaries, and tens of pixels wide, through the fused rc_front kernel (blocks
+    0-5) and the layer-wise deform_sample path (blocks 6-7), against the oracle — whose sampling rule is itself cross-checked
+    against the independent scalar statement in tests/test_independent_ops.py."""
+    kw, sd, (x, xr, xp) = _setup('en_s0', 96, 1, 16)
+    sd = stress_offsets(sd, 96, mode)
+    xr = torch.rand(1, 3, 96, 96, generator=torch.Generator().manual_seed(3))          # dense map: every sample matters
+    orc = AchelousOracle(sd, **{k: kw[k] for k in ORACLE_KEYS})
+    det, se, lane, pc = orc.forward(x, xr, xp)
+    eng = make_engine(emu_library(), kw, 1, sd, 16, DTYPE_F32)
+    outs = alloc_outputs(kw, 1, 16, torch.float32, 'cpu')
+    eng.forward(x, xr, xp, outs)
+    for tap in [f'radar.b{i}' for i in range(8)] + ['r3', 'r4', 'r5']:
+        assert rel_err(eng.read_tap(tap), orc.taps[tap]) < 2e-5, (mode, tap)
+    for a, b in zip(outs[:3], det):
+        assert rel_err(a, b) < 2e-5
+
+
+def test_emulated_nms_degenerate_candidates():
+    """Zero-area boxes (0/0 IoU never suppresses), duplicates, ties, NaN scores (dropped by the confidence filter): kept indices
+    and rows bit-exact against the oracle AND against the independent scalar statement of batched_nms."""
+    from achelous_amd.engine import NativeEngine
+    from oracle import independent as ind
+    h = NativeEngine(emu_library(), num_det=7, num_seg=1, phi='S0', backbone='en', resolution=320, pc_channels=3, pc_classes=1,
+                     num_points=16, nano_head=True, spp=True, dtype=DTYPE_F32)
+    dec = degenerate_decoded()
+    t = torch.from_numpy(dec)
+    B, A, C = dec.shape[0], dec.shape[1], 7
+    ws = torch.zeros(h.nms_workspace_bytes(B), dtype=torch.uint8)
+    for conf, iou in ((0.35, 0.35), (0.05, 0.5), (0.0, 0.9)):
+        rows, idx, cnt = torch.zeros(B, A, 7), torch.full((B, A), -1, dtype=torch.int32), torch.zeros(B, dtype=torch.int32)
+        h.nms(B, t, conf, iou, A, rows, idx, cnt, ws)
+        exp = o_nms(t.clone(), C, conf, iou)
+        for b in range(B):
+            k = int(cnt[b])
+            assert k == len(exp[b][1]), (conf, iou, b, k, len(exp[b][1]))
+            assert np.array_equal(idx[b, :k].numpy().astype(np.int64), exp[b][1])
+            assert np.array_equal(rows[b, :k].numpy(), exp[b][0], equal_nan=True)
+            # second opinion: candidates re-derived here, selection by the independent scalar batched_nms
+            d = dec[b]
+            cid = np.array([int(np.argmax(r)) if not np.isnan(r).any() else int(np.where(np.isnan(r))[0][0]) for r in d[:, 5:]])
+            cconf = d[np.arange(A), 5 + cid]
+            score = d[:, 4] * cconf
+            sel = np.where(score >= np.float32(conf))[0]
+            half = np.float32(2)
+            boxes = np.stack([d[sel, 0] - d[sel, 2] / half, d[sel, 1] - d[sel, 3] / half, d[sel, 0] + d[sel, 2] / half, d[sel, 1] + d[sel, 3] / half], 1)
+            keep = ind.batched_nms(boxes, score[sel], cid[sel].astype(np.float32), iou)
+            assert np.array_equal(sel[keep], exp[b][1]), (conf, iou, b)
+        assert int(cnt[1]) == 0 or conf == 0.0

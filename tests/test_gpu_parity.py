@@ -2,8 +2,8 @@
 would call `Achelous.forward` / `decode_outputs` / `non_max_suppression`, against
   (1) the golden fixtures captured from the imported reference (tests/golden/*.npz), and
   (2) the CPU oracle (oracle/) on the same seeded inputs and weights.
-Tolerances (SURVEY.md §8c): fp32 path  max|a-b| / (max|b| + 1e-6) <= 1e-3 per tensor (measured ~1e-6);
-bf16 path <= 6e-2 per tensor (bf16 storage through ~60 layers; measured 1-3e-2); NMS kept indices bit-exact.
+Tolerances (SURVEY.md §8c): fp32 path  max|a-b| / (max|b| + 1e-6) <= 1e-3 per tensor (measured 1e-6 .. 1e-4);
+NMS kept indices bit-exact; bf16 path: PER-TENSOR bounds, see bf16_bound().
 """
 import numpy as np
 import pytest
@@ -14,17 +14,37 @@ from achelous_amd import engine as eng_mod
 from achelous_amd.postprocess import nms_device
 from achelous_amd.synth import condition_state_dict, make_inputs
 from golden_util import Golden, ctor_kwargs
+from stress_cases import degenerate_decoded, stress_offsets
 from oracle.achelous_oracle import AchelousOracle, decode_outputs as o_decode, non_max_suppression as o_nms
 
 pytestmark = pytest.mark.gpu
-F32_TOL, BF16_TOL = 1e-3, 6e-2
+F32_TOL = 1e-3
+BF16_FUSED_VS_LAYERWISE = 6e-2     # only for test_fused_kernels_agree_with_the_layerwise_path: two bf16 plans against EACH OTHER
+                                   # (both carry bf16 rounding, in different places)
+OUTPUTS = ('det0', 'det1', 'det2', 'se_seg', 'lane_seg', 'pc_seg')
 
 
-def _model(meta, device='cuda', debug_taps=False):
-    kw = ctor_kwargs(meta)
+def bf16_bound(g, tap):
+    """Per-tensor bound for the bf16 engine against the reference's fp32 fixture, same metric as fp32.
+
+    SURVEY §8c's target is 2e-2.  Whether a tensor can meet it is a property of the network + weights, not of the engine: every
+    fixture records how far the REFERENCE ITSELF moves on each tensor when it is evaluated under bf16 autocast — the way its own
+    training loop evaluates it, utils/utils_fit.py:37 — instead of fp32 (`bf16_autocast_reference_err`, written by
+    tests/golden/gen_golden.py on exactly the stored elements).  The six network outputs must be within max(2e-2, 2 x that figure):
+    an engine that stores activations in bf16 is held to the survey's target wherever the layer-wise bf16 reference gets within
+    half of it, and to twice the reference's own deviation elsewhere (the max-norm over 10^5..10^6 elements of two independent
+    rounding patterns differs by such factors from run to run).  Internal boundaries (debug taps) get max(4e-2, 3 x): the fused
+    kernels round at different places than the layers whose outputs these taps are."""
+    ref = g.meta['bf16_autocast_reference_err'].get(tap, 0.0)
+    return max(2e-2, 2.0 * ref) if tap in OUTPUTS else max(4e-2, 3.0 * ref)
+
+
+def _model(g, device='cuda', debug_taps=False):
+    """The drop-in module with the fixture's weights: seeded draw + the fixture's calibrated BatchNorm statistics."""
+    kw = ctor_kwargs(g.meta)
     m = Achelous(**kw).eval()
     m.debug_taps = debug_taps
-    m.load_state_dict(condition_state_dict(m.state_dict(), seed=meta['weight_seed']), strict=True)
+    m.load_state_dict(g.calibrate(condition_state_dict(m.state_dict(), seed=g.meta['weight_seed'])), strict=True)
     return m.to(device), kw
 
 
@@ -34,8 +54,7 @@ def _rel(a, b):
 
 
 def _engine_of(m, dtype):
-    code = eng_mod.DTYPE_BF16 if dtype == torch.bfloat16 else eng_mod.DTYPE_F32
-    return m._engines[(torch.cuda.current_device(), code)][0]
+    return m.native_engine(dtype)
 
 
 def test_native_library_is_loaded():
@@ -48,7 +67,7 @@ def test_native_library_is_loaded():
 @pytest.mark.parametrize('name', ['en_s0', 'en_s2', 'mv_s2', 'en_s0_cdf'])
 def test_forward_fp32_matches_reference_fixtures(name):
     g = Golden(name)
-    m, kw = _model(g.meta, debug_taps=True)
+    m, kw = _model(g, debug_taps=True)
     x, xr, xp = make_inputs(g.meta['batch'], g.meta['input_seed'], resolution=kw['resolution'], pc_channels=kw['pc_channels'])
     with torch.no_grad():
         det, se, lane, pc = m(x.cuda(), xr.cuda(), xp.cuda())
@@ -72,7 +91,7 @@ def test_forward_fp32_matches_reference_fixtures(name):
 
 def test_forward_fp32_matches_oracle_full_tensors():
     g = Golden('en_s0')
-    m, kw = _model(g.meta, debug_taps=True)
+    m, kw = _model(g, debug_taps=True)
     x, xr, xp = make_inputs(3, 77, resolution=kw['resolution'], pc_channels=kw['pc_channels'], dense_radar=True)
     with torch.no_grad():
         det, se, lane, pc = m(x.cuda(), xr.cuda(), xp.cuda())
@@ -87,18 +106,27 @@ def test_forward_fp32_matches_oracle_full_tensors():
             assert _rel(e.read_tap(tap), orc.taps[tap]) < F32_TOL, tap
 
 
-@pytest.mark.parametrize('name', ['en_s0', 'mv_s2', 'en_s0_cdf'])
+@pytest.mark.parametrize('name', ['en_s0', 'en_s2', 'mv_s2', 'en_s0_cdf'])
 def test_forward_bf16_matches_reference_fixtures(name):
     g = Golden(name)
-    m, kw = _model(g.meta)
+    m, kw = _model(g, debug_taps=True)
     x, xr, xp = make_inputs(g.meta['batch'], g.meta['input_seed'], resolution=kw['resolution'], pc_channels=kw['pc_channels'])
     with torch.no_grad():
         det, se, lane, pc = m(x.cuda().bfloat16(), xr.cuda().bfloat16(), xp.cuda().bfloat16())
+    torch.cuda.synchronize()
     assert se.dtype == torch.bfloat16
     outs = {'det0': det[0], 'det1': det[1], 'det2': det[2], 'se_seg': se, 'lane_seg': lane, 'pc_seg': pc}
-    worst = {k: g.rel_err(k, v.float(), check_sums=False) for k, v in outs.items()}
-    print('bf16 rel err', {k: round(v, 4) for k, v in worst.items()})
-    assert max(worst.values()) < BF16_TOL, worst
+    e = _engine_of(m, torch.bfloat16)
+    errs = {}
+    for tap in g.taps:
+        if tap == 'decoded':
+            continue
+        t = outs[tap].float() if tap in outs else e.read_tap(tap)
+        errs[tap] = g.rel_err(tap, t, check_sums=False)
+    print(f'{name}: bf16 rel err per tensor (bound):',
+          {k: f'{v:.1e} ({bf16_bound(g, k):.1e})' for k, v in sorted(errs.items(), key=lambda kv: -kv[1] / bf16_bound(g, kv[0]))})
+    bad = {k: (v, bf16_bound(g, k)) for k, v in errs.items() if not v < bf16_bound(g, k)}
+    assert not bad, bad
 
 
 def test_nms_bit_exact_on_reference_decoded():
@@ -116,17 +144,12 @@ def test_nms_bit_exact_on_reference_decoded():
 
 
 def test_nms_edge_cases_match_oracle():
-    rng = np.random.default_rng(5)
-    B, A, C = 4, 2100, 7
-    dec = np.zeros((B, A, 5 + C), np.float32)
-    dec[..., 0:2] = rng.uniform(0.1, 0.9, (B, A, 2))
-    dec[..., 2:4] = rng.uniform(0.05, 0.4, (B, A, 2))
-    dec[..., 4] = rng.uniform(0, 1, (B, A))
-    dec[..., 5:] = rng.uniform(0, 1, (B, A, C))
-    dec[1, :, 4] = 0.0                                   # image 1: nothing passes the confidence filter
-    dec[2, :, 4] = np.round(dec[2, :, 4], 1)             # image 2: heavy score ties
-    dec[2, :, 5:] = np.round(dec[2, :, 5:], 1)
-    dec[3, 100:, :] = dec[3, :2000, :].copy()            # image 3: duplicated boxes (IoU == 1)
+    """Nothing passes / heavy ties / duplicated boxes (IoU == 1) / zero-area boxes (0/0 IoU never suppresses) / NaN objectness and
+    class scores (torch.max propagates NaN, the `>= conf` filter drops the anchor): kept indices and rows bit-exact against the
+    oracle, and the selection re-derived with the independent scalar statement of batched_nms (oracle/independent)."""
+    from oracle import independent as ind
+    dec = degenerate_decoded()
+    B, A, C = dec.shape[0], dec.shape[1], 7
     t = torch.from_numpy(dec)
     for conf, iou in ((0.35, 0.35), (0.05, 0.5), (0.0, 0.9)):
         ref = o_nms(t.clone(), C, conf, iou)
@@ -135,16 +158,66 @@ def test_nms_edge_cases_match_oracle():
             k = int(cnt[b])
             assert k == len(ref[b][1]), (conf, iou, b)
             assert np.array_equal(idx[b, :k].cpu().numpy().astype(np.int64), ref[b][1])
-            assert np.array_equal(rows[b, :k].cpu().numpy(), ref[b][0])
+            assert np.array_equal(rows[b, :k].cpu().numpy(), ref[b][0], equal_nan=True)
+            d = dec[b]
+            cid = np.array([int(np.argmax(r)) if not np.isnan(r).any() else int(np.where(np.isnan(r))[0][0]) for r in d[:, 5:]])
+            score = d[:, 4] * d[np.arange(A), 5 + cid]
+            sel = np.where(score >= np.float32(conf))[0]
+            half = np.float32(2)
+            boxes = np.stack([d[sel, 0] - d[sel, 2] / half, d[sel, 1] - d[sel, 3] / half, d[sel, 0] + d[sel, 2] / half, d[sel, 1] + d[sel, 3] / half], 1)
+            keep = ind.batched_nms(boxes, score[sel], cid[sel].astype(np.float32), iou)
+            assert np.array_equal(idx[b, :k].cpu().numpy().astype(np.int64), sel[keep]), (conf, iou, b)
+
+
+@pytest.mark.parametrize('mode', ['far', 'integer', 'wide'])
+def test_deformable_sampling_far_and_boundary_offsets(mode):
+    """DCNv2 on the HIP path with offsets a whole map away (+-H, +-1e4), landing exactly on the -1 / H "outside" boundaries and on
+    integer coordinates, and tens of pixels wide — dense radar map, full resolution, every RCBlock boundary against the oracle
+    (whose sampling rule is cross-checked against the independent scalar statement, tests/test_independent_ops.py).  fp32 <= 1e-3;
+    bf16: the radar taps within 4e-2 (offsets are exact in both; only the stored activations are rounded)."""
+    g = Golden('en_s0')
+    kw = ctor_kwargs(g.meta)
+    m = Achelous(**kw).eval()
+    m.debug_taps = True
+    sd = stress_offsets(g.calibrate(condition_state_dict(m.state_dict(), seed=g.meta['weight_seed'])), kw['resolution'], mode)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda()
+    x, xr, xp = make_inputs(2, 55, resolution=kw['resolution'], pc_channels=kw['pc_channels'], dense_radar=True)
+    orc = AchelousOracle(sd, **kw)
+    odet, _, _, _ = orc.forward(x, xr, xp)
+    taps = [f'radar.b{i}' for i in range(8)] + ['r3', 'r4', 'r5']
+    for dt, tol in ((torch.float32, F32_TOL), (torch.bfloat16, 4e-2)):
+        with torch.no_grad():
+            det, _, _, _ = m(x.cuda().to(dt), xr.cuda().to(dt), xp.cuda().to(dt))
+        torch.cuda.synchronize()
+        e = _engine_of(m, dt)
+        errs = {tap: _rel(e.read_tap(tap), orc.taps[tap]) for tap in taps}
+        errs.update({f'det{i}': _rel(det[i].float(), odet[i]) for i in range(3)})
+        print(mode, dt, {k: f'{v:.1e}' for k, v in errs.items()})
+        assert max(errs.values()) < tol, (mode, dt, errs)
 
 
 def test_full_batch_64_properties():
-    """BASELINE.json size (B=64): size-independent properties instead of a full oracle run:
-    frames are independent (a frame's outputs do not depend on its batch position or neighbours), outputs finite,
+    """BASELINE.json size (B=64).  (1) Frames 0, 21, 42, 63 of a 64-batch of DISTINCT frames against the oracle run on those four
+    frames (fp32 <= 1e-3; bf16 within the per-tensor bound of the en_s0 fixture, whose weights these are).  (2) Size-independent
+    properties over the whole batch: a frame's outputs do not depend on its batch position or neighbours, outputs finite,
     segmentation outputs non-negative (post-ReLU), point log-probabilities normalised."""
     g = Golden('en_s0')
-    m, kw = _model(g.meta)
-    x, xr, xp = make_inputs(4, 4242, resolution=kw['resolution'], pc_channels=kw['pc_channels'])
+    m, kw = _model(g)
+    x64, r64, p64 = make_inputs(64, 6464, resolution=kw['resolution'], pc_channels=kw['pc_channels'])
+    pick = [0, 21, 42, 63]
+    orc = AchelousOracle({k: v.cpu() for k, v in m.state_dict().items()}, **kw)
+    odet, ose, olane, opc = orc.forward(x64[pick], r64[pick], p64[pick])
+    want = dict(zip(OUTPUTS, (*odet, ose, olane, opc)))
+    for dt in (torch.float32, torch.bfloat16):
+        with torch.no_grad():
+            det, se, lane, pc = m(x64.cuda().to(dt), r64.cuda().to(dt), p64.cuda().to(dt))
+        got = dict(zip(OUTPUTS, (*det, se, lane, pc)))
+        errs = {k: _rel(got[k][pick].float(), want[k]) for k in OUTPUTS}
+        print(f'B=64 frames {pick} vs oracle, {dt}:', {k: f'{v:.1e}' for k, v in errs.items()})
+        for k, v in errs.items():
+            assert v < (F32_TOL if dt == torch.float32 else bf16_bound(g, k)), (dt, k, v)
+    x, xr, xp = x64[:4], r64[:4], p64[:4]
     rep = torch.arange(64) % 4
     perm = torch.randperm(64, generator=torch.Generator().manual_seed(1))
     for dt, tol in ((torch.float32, 1e-6), (torch.bfloat16, 1e-6)):
@@ -162,7 +235,7 @@ def test_full_batch_64_properties():
 
 def test_point_branch_is_permutation_equivariant():
     g = Golden('en_s0')
-    m, kw = _model(g.meta)
+    m, kw = _model(g)
     x, xr, xp = make_inputs(2, 9, resolution=kw['resolution'], pc_channels=kw['pc_channels'])
     perm = torch.randperm(512, generator=torch.Generator().manual_seed(3))
     with torch.no_grad():
@@ -173,7 +246,7 @@ def test_point_branch_is_permutation_equivariant():
 
 def test_module_is_a_drop_in():
     g = Golden('en_s0')
-    m, kw = _model(g.meta)
+    m, kw = _model(g)
     assert [k for k, _, _ in g.meta['keys']] == list(m.state_dict().keys())
     m.train()
     with pytest.raises(NotImplementedError):
@@ -193,7 +266,7 @@ def test_module_is_a_drop_in():
 def test_launch_modes_agree():
     """Three side streams (default), single stream, and hipGraph replay run the SAME kernels: outputs must be bit-identical."""
     g = Golden('en_s0')
-    m, kw = _model(g.meta)
+    m, kw = _model(g)
     x, xr, xp = make_inputs(2, 31, resolution=kw['resolution'], pc_channels=kw['pc_channels'])
     xs, rs, ps = x.cuda(), xr.cuda(), xp.cuda()
     with torch.no_grad():
@@ -218,7 +291,7 @@ def test_launch_modes_agree():
 def test_forward_detect_equals_the_three_calls():
     """ach_forward_detect (decode + NMS behind the detection head on its stream) == forward -> decode_outputs -> NMS, bit for bit."""
     g = Golden('en_s0')
-    m, kw = _model(g.meta)
+    m, kw = _model(g)
     x, xr, xp = make_inputs(8, 99, resolution=kw['resolution'], pc_channels=kw['pc_channels'])
     for dt in (torch.float32, torch.bfloat16):
         xs, rs, ps = x.cuda().to(dt), xr.cuda().to(dt), xp.cuda().to(dt)
@@ -240,9 +313,9 @@ def test_fused_kernels_agree_with_the_layerwise_path(option):
     must agree — to fp32 rounding in the fp32 engine (different summation order), and within the bf16 tolerance in the bf16
     engine (intermediates that the fused kernels keep in fp32 registers are rounded to bf16 on the layer-wise path)."""
     g = Golden('en_s0')
-    m, kw = _model(g.meta)
+    m, kw = _model(g)
     x, xr, xp = make_inputs(2, 17, resolution=kw['resolution'], pc_channels=kw['pc_channels'])
-    for dt, tol in ((torch.float32, 2e-5), (torch.bfloat16, BF16_TOL)):
+    for dt, tol in ((torch.float32, 2e-5), (torch.bfloat16, BF16_FUSED_VS_LAYERWISE)):
         xs, rs, ps = x.cuda().to(dt), xr.cuda().to(dt), xp.cuda().to(dt)
         with torch.no_grad():
             ref = m(xs, rs, ps)
@@ -264,7 +337,7 @@ def test_reference_default_resolution_416():
     g = Golden('en_s0')
     kw = dict(ctor_kwargs(g.meta), resolution=416)
     m = Achelous(**kw).eval()
-    sd = condition_state_dict(m.state_dict(), seed=g.meta['weight_seed'])
+    sd = g.calibrate(condition_state_dict(m.state_dict(), seed=g.meta['weight_seed']))
     m.load_state_dict(sd, strict=True)
     m = m.cuda()
     x, xr, xp = make_inputs(1, 5, resolution=416, pc_channels=kw['pc_channels'])

@@ -18,7 +18,7 @@ def _state_dict_from_keys(meta):
 def test_oracle_matches_reference_fixtures(name):
     g = Golden(name)
     kw = ctor_kwargs(g.meta)
-    sd = _state_dict_from_keys(g.meta)
+    sd = g.calibrate(_state_dict_from_keys(g.meta))
     x, xr, xp = make_inputs(g.meta['batch'], g.meta['input_seed'], resolution=kw['resolution'],
                             pc_channels=kw['pc_channels'])
     orc = AchelousOracle(sd, **kw)

@@ -167,7 +167,7 @@ def test_gpu_pn2_matches_the_self_oracle(dtype, tol):
     for a, b in zip((*det, se, lane, pc), (*rdet, rse, rlane, rpc)):
         assert _rel(a.float(), b.float()) <= tol
     from achelous_amd import engine as eng_mod
-    e = m._engines[(torch.cuda.current_device(), eng_mod.DTYPE_BF16 if dtype == torch.bfloat16 else eng_mod.DTYPE_F32)][0]
+    e = m.native_engine(dtype)
     checked = 0
     for tap in e.tap_names():
         if tap.startswith('pc.'):
