@@ -174,7 +174,7 @@ def test_deformable_sampling_far_and_boundary_offsets(mode):
     """DCNv2 on the HIP path with offsets a whole map away (+-H, +-1e4), landing exactly on the -1 / H "outside" boundaries and on
     integer coordinates, and tens of pixels wide — dense radar map, full resolution, every RCBlock boundary against the oracle
     (whose sampling rule is cross-checked against the independent scalar statement, tests/test_independent_ops.py).  fp32 <= 1e-3;
-    bf16: the radar taps within 4e-2 (offsets are exact in both; only the stored activations are rounded)."""
+    bf16 ('far', 'integer'): the radar taps within 4e-2 (offsets are exact in both; only the stored activations are rounded)."""
     g = Golden('en_s0')
     kw = ctor_kwargs(g.meta)
     m = Achelous(**kw).eval()
@@ -186,7 +186,9 @@ def test_deformable_sampling_far_and_boundary_offsets(mode):
     orc = AchelousOracle(sd, **kw)
     odet, _, _, _ = orc.forward(x, xr, xp)
     taps = [f'radar.b{i}' for i in range(8)] + ['r3', 'r4', 'r5']
-    for dt, tol in ((torch.float32, F32_TOL), (torch.bfloat16, 4e-2)):
+    # 'wide' multiplies the offset conv by 12: a bf16 rounding of its input moves every sample point by 12x as much, so only the
+    # exact (fp32) engine can be compared there; 'far' / 'integer' offsets are constants, identical in both engines
+    for dt, tol in ((torch.float32, F32_TOL), (torch.bfloat16, 4e-2))[:1 if mode == 'wide' else 2]:
         with torch.no_grad():
             det, _, _, _ = m(x.cuda().to(dt), xr.cuda().to(dt), xp.cuda().to(dt))
         torch.cuda.synchronize()
