@@ -579,6 +579,7 @@ public:
             }
             if (has_preset) throw AchError{ACH_ERR_INVALID, "stage output destination was not consumed"};
             feats[i] = x;
+            if (i == radar_start) signal_after_last(0);
         }
     }
 
@@ -670,12 +671,15 @@ public:
         x = mv2block(pfx + ".mv2.2", x, 1, mc.ch[3]);
         x = mv2block(pfx + ".mv2.3", x, 1, mc.ch[3]);
         feats[0] = x;
+        if (radar_start == 0) signal_after_last(0);
         x = mv2block(pfx + ".mv2.4", x, 2, mc.ch[4]);
         x = mvit_block(pfx + ".mvit.0", x, 2);
         feats[1] = x;
+        if (radar_start == 1) signal_after_last(0);
         x = mv2block(pfx + ".mv2.5", x, 2, mc.ch[6]);
         x = mvit_block(pfx + ".mvit.1", x, 4);
         feats[2] = x;
+        if (radar_start >= 2) signal_after_last(0);
         x = mv2block(pfx + ".mv2.6", x, 2, mc.ch[8]);
         x = mvit_block(pfx + ".mvit.2", x, 3);
         feats[3] = mv_conv(pfx + ".conv2", x, 1, 1);
@@ -1376,14 +1380,17 @@ public:
         // enqueue order = plan order: the two side branches first, so they are already running while the (longest) image
         // path is being enqueued on the caller's stream
         A r[3];
-        cur_stream = 1;
-        rcnet(r);
-        signal_after_last(3);             // radar pyramid ready
         // "head_stream": PointNet queues behind the radar branch on the low-priority stream; the (four times longer) PointNet++
         // branch opens stream 2 instead, ahead of fusion + head, which only start once the neck is done (measured +4.8 %; PointNet: neutral)
         const bool point2 = point_on_head_stream < 0 ? cfg.pc_seg == ACH_PCSEG_PN2 : point_on_head_stream != 0;
-        cur_stream = (head_stream && !point2) ? 1 : 2;
-        if (cfg.pc_seg == ACH_PCSEG_PN2) pointnet2(); else pointnet();
+        const bool radar_late = radar_start >= 0 && multi_stream;
+        auto points = [&] { cur_stream = (head_stream && !point2) ? 1 : 2; if (cfg.pc_seg == ACH_PCSEG_PN2) pointnet2(); else pointnet(); };
+        if (radar_late) points();         // the point branch (small launches) fills the window before the radar branch is released
+        cur_stream = 1;
+        if (radar_late) wait_before_next(0);
+        rcnet(r);
+        signal_after_last(3);             // radar pyramid ready
+        if (!radar_late) points();
         cur_stream = 0;
         A m[4];
         cat_buf[0] = A(); cat_buf[1] = A();

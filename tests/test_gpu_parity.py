@@ -201,7 +201,7 @@ def test_deformable_sampling_far_and_boundary_offsets(mode):
 
 def test_full_batch_64_properties():
     """BASELINE.json size (B=64).  (1) Frames 0, 21, 42, 63 of a 64-batch of DISTINCT frames against the oracle run on those four
-    frames (fp32 <= 1e-3; bf16 within the per-tensor bound of the en_s0 fixture, whose weights these are).  (2) Size-independent
+    frames (fp32 <= 1e-3; bf16 within max(2e-2, 2 x the deviation of the oracle's own bf16-autocast evaluation of these frames)).  (2) Size-independent
     properties over the whole batch: a frame's outputs do not depend on its batch position or neighbours, outputs finite,
     segmentation outputs non-negative (post-ReLU), point log-probabilities normalised."""
     g = Golden('en_s0')
@@ -211,14 +211,19 @@ def test_full_batch_64_properties():
     orc = AchelousOracle({k: v.cpu() for k, v in m.state_dict().items()}, **kw)
     odet, ose, olane, opc = orc.forward(x64[pick], r64[pick], p64[pick])
     want = dict(zip(OUTPUTS, (*odet, ose, olane, opc)))
+    # the bf16 yardstick of bf16_bound(), re-measured on THESE frames and on whole tensors (the fixture's figures are for its own two
+    # frames and its stored samples): the oracle evaluated under bf16 autocast against its fp32 self
+    with torch.autocast('cpu', dtype=torch.bfloat16):
+        adet, ase, alane, apc = AchelousOracle({k: v.cpu() for k, v in m.state_dict().items()}, **kw).forward(x64[pick], r64[pick], p64[pick])
+    amp = {k: _rel(a.float(), want[k]) for k, a in zip(OUTPUTS, (*adet, ase, alane, apc))}
     for dt in (torch.float32, torch.bfloat16):
         with torch.no_grad():
             det, se, lane, pc = m(x64.cuda().to(dt), r64.cuda().to(dt), p64.cuda().to(dt))
         got = dict(zip(OUTPUTS, (*det, se, lane, pc)))
         errs = {k: _rel(got[k][pick].float(), want[k]) for k in OUTPUTS}
-        print(f'B=64 frames {pick} vs oracle, {dt}:', {k: f'{v:.1e}' for k, v in errs.items()})
+        print(f'B=64 frames {pick} vs oracle, {dt}:', {k: f'{v:.1e}' for k, v in errs.items()}, '| oracle under bf16 autocast:', {k: f'{v:.1e}' for k, v in amp.items()})
         for k, v in errs.items():
-            assert v < (F32_TOL if dt == torch.float32 else bf16_bound(g, k)), (dt, k, v)
+            assert v < (F32_TOL if dt == torch.float32 else max(2e-2, 2.0 * amp[k])), (dt, k, v, amp[k])
     x, xr, xp = x64[:4], r64[:4], p64[:4]
     rep = torch.arange(64) % 4
     perm = torch.randperm(64, generator=torch.Generator().manual_seed(1))
