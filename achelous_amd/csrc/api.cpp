@@ -208,6 +208,14 @@ double ach_op_bytes(const ach_handle* h, int i) {
     if (!h || !h->eng || i < 0 || i >= int(h->eng->ops.size())) return 0;
     return h->eng->ops[size_t(i)].bytes;
 }
+double ach_op_layout_bytes(const ach_handle* h, int i) {
+    if (!h || !h->eng || i < 0 || i >= int(h->eng->ops.size())) return 0;
+    return h->eng->ops[size_t(i)].layout_bytes;
+}
+int ach_op_stream(const ach_handle* h, int i) {
+    if (!h || !h->eng || i < 0 || i >= int(h->eng->ops.size())) return -1;
+    return h->eng->ops[size_t(i)].stream;
+}
 double ach_op_flops(const ach_handle* h, int i) {
     if (!h || !h->eng || i < 0 || i >= int(h->eng->ops.size())) return 0;
     return h->eng->ops[size_t(i)].flops;

@@ -36,7 +36,8 @@ struct TapInfo {
 struct Op {
     std::string name;
     std::function<void(hipStream_t)> fn;
-    double bytes = 0;             // algorithmic HBM bytes of one launch: inputs read once + outputs written once + weights
+    double bytes = 0;             // algorithmic HBM bytes of one launch: inputs read once + outputs written once + weights, REAL channels
+    double layout_bytes = 0;      // the same count over the pixel pitches actually stored (channel padding included): what the launch must move
     double flops = 0;             // 2 * MACs of one launch (dense contractions only)
     int stream = 0;               // 0: caller's stream (image path) ; 1, 2: engine-owned side streams (radar / point branches)
     int wait_ev = -1, wait_ev2 = -1;   // join: wait for these events before the launch
@@ -124,9 +125,9 @@ protected:
     void* walloc(size_t bytes);
     void* aalloc(size_t bytes);
     float* up_f32(const std::vector<float>& v);
-    void add_op(const std::string& name, std::function<void(hipStream_t)> fn, double bytes = 0, double flops = 0) {
+    void add_op(const std::string& name, std::function<void(hipStream_t)> fn, double bytes = 0, double flops = 0, double layout_bytes = -1) {
         if (measuring) return;
-        Op op{name, std::move(fn), bytes, flops};
+        Op op{name, std::move(fn), bytes, layout_bytes < 0 ? bytes : layout_bytes, flops};
         op.stream = cur_stream;
         op.wait_ev = pending_wait; op.wait_ev2 = pending_wait2;
         pending_wait = -1; pending_wait2 = -1;

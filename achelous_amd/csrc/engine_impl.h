@@ -55,6 +55,11 @@ public:
         a.p = static_cast<T*>(aalloc(size_t(a.rows()) * a.ld * sizeof(T)));
         return a;
     }
+    A alloc_ld(int B, int H, int W, int C, long ld) {          // explicit pixel pitch (the 4-channel maps of the first RCBlock)
+        A a; a.B = B; a.H = H; a.W = W; a.C = C; a.ld = ld;
+        a.p = static_cast<T*>(aalloc(size_t(a.rows()) * a.ld * sizeof(T)));
+        return a;
+    }
     Pl alloc_pl(int B, int C, int H, int W) {
         Pl a; a.B = B; a.C = C; a.H = H; a.W = W;
         a.p = static_cast<T*>(aalloc(size_t(B) * C * H * W * sizeof(T)));
@@ -275,9 +280,9 @@ public:
     }
 
     template <class K, class Pm>
-    void ew(const std::string& name, K kern, const Pm& p, long total, double bytes = 0) {      // 256-thread element-wise launch
+    void ew(const std::string& name, K kern, const Pm& p, long total, double bytes = 0, double layout_bytes = -1) {      // 256-thread element-wise launch
         const dim3 grid(unsigned(cdivl(total, 256))), block(256);
-        add_op(name, [kern, p, grid, block](hipStream_t s) { ACH_LAUNCH(kern, grid, block, s, p); }, bytes, 0);
+        add_op(name, [kern, p, grid, block](hipStream_t s) { ACH_LAUNCH(kern, grid, block, s, p); }, bytes, 0, layout_bytes);
     }
     void add(const std::string& name, const A& a, const A& b, const A& y) {
         AddParams p{a.p, a.ld, b.p, b.ld, y.p, y.ld, a.rows(), a.C};
@@ -958,8 +963,8 @@ public:
     // NHWC tensor with a one-pixel zero border around every sample (the arena is zeroed when the plan is built and the border is
     // never written): p0 = pixel (0,0) of sample 0
     struct Bordered { T* p0 = nullptr; T* base = nullptr; int B = 0, H = 0, W = 0, C = 0; long ld = 0, row = 0, img = 0; };
-    Bordered alloc_bordered(int B, int H, int W, int C) {
-        Bordered t; t.B = B; t.H = H; t.W = W; t.C = C; t.ld = round_up(C, 8);
+    Bordered alloc_bordered(int B, int H, int W, int C, long ld = 0) {
+        Bordered t; t.B = B; t.H = H; t.W = W; t.C = C; t.ld = ld ? ld : round_up(C, 8);
         t.row = long(W + 2) * t.ld; t.img = long(H + 2) * t.row;
         t.base = static_cast<T*>(aalloc(size_t(B) * t.img * sizeof(T)));
         t.p0 = t.base + t.row + t.ld;
@@ -970,18 +975,21 @@ public:
     A conv3_bordered(const std::string& name, const Bordered& x, const Lin& l, int act, int stride = 1) {
         const int Ho = (x.H - 1) / stride + 1, Wo = (x.W - 1) / stride + 1;
         A y = alloc(x.B, Ho, Wo, l.N);
-        const int cv = int(x.ld) / VEC, ks = cdiv(9 * cv, 4);
+        const bool half = 2 * x.ld == VEC;                       // 8-byte pixels: one k-slot per tap, its upper half zero (k_conv3.h)
+        const int cv = half ? 1 : int(x.ld) / VEC, ks = cdiv(9 * cv, 4);
         Packed pk = pack(l);
-        const double bytes = double(x.B) * x.H * x.W * x.ld * sizeof(T) + double(y.rows()) * y.ld * sizeof(T);
-        const bool shape_ok = (pk.NT == 2 && y.ld == 32) || (pk.NT == 1 && stride == 2 && y.ld <= 16);
+        const double bytes = double(x.B) * x.H * x.W * x.C * sizeof(T) + double(y.rows()) * y.C * sizeof(T);
+        const double lbytes = double(x.B) * x.H * x.W * x.ld * sizeof(T) + double(y.rows()) * y.ld * sizeof(T);
+        const bool shape_ok = (pk.NT == 2 && y.ld == 32 && !half) || (pk.NT == 1 && stride == 2 && y.ld <= 16);
         if (row_conv && shape_ok && (ks == 3 || ks == 5 || ks == 9) && pk.nchunks == 1 && pk.ksteps == ks) {
             std::vector<float> b32(32, 0.f);
             for (int n = 0; n < l.N; ++n) b32[n] = l.b[n];
             Conv3Params cp{x.p0, x.ld, x.row, x.img, y.p, y.ld, pk.w, up_f32(b32), x.B, Ho, Wo, cv, act, 0, nullptr, 0};
             const int NT = pk.NT;
-            add_op(name, [cp, ks, NT, stride](hipStream_t s) { launch_conv3<T>(cp, ks, NT, stride, s); }, bytes, 2.0 * double(y.rows()) * l.K * l.N);
+            add_op(name, [cp, ks, NT, stride, half](hipStream_t s) { launch_conv3<T>(cp, ks, NT, stride, s, half); }, bytes, 2.0 * double(y.rows()) * l.K * l.N, lbytes);
             return y;
         }
+        if (half) throw AchError{ACH_ERR_INVALID, name + ": 8-byte pixels are only read by the row-walking conv"};
         // generic implicit GEMM: the bordered buffer is a dense [B, H+2, W+2, ld] tensor convolved without padding
         GemmOpt o; o.act = act;
         o.conv_k = 3; o.conv_s = stride; o.conv_p = 0; o.Hin = x.H + 2; o.Win = x.W + 2; o.Cin = int(x.ld); o.Ho = Ho; o.Wo = Wo;
@@ -993,28 +1001,41 @@ public:
         const int chans[9] = {3, w[0] / 4, w[0] / 4, w[0] / 4, w[1] / 4, w[1] / 4, w[2] / 4, w[2] / 4, w[3] / 4};
         const bool down[8] = {true, true, false, true, false, true, false, true};
         const int B = batch, R = cfg.resolution;
-        A x = alloc(B, R, R, 3);
+        // The 3-channel maps of the first RCBlock (network input, pooled map, block output: 6.5 M pixels each at batch 64) are carried
+        // as 4-channel pixels — 8 B in bf16, 16 B in fp32 — instead of the 8-channel padding of the generic NHWC layout: they were 2.7x
+        // their real bytes in HBM traffic.  Only the fused front + row-walking conv read that layout; the layer-wise fallback keeps 8.
+        const bool narrow0 = fuse_rc && row_conv && chans[0] <= 4 && (R * R) % 4 == 0;
+        A x = narrow0 ? alloc_ld(B, R, R, 3, 4) : alloc(B, R, R, 3);
         {
             ToNhwcParams tp{nullptr, x.p, B, 3, R, R, x.ld};
-            const dim3 grid(unsigned(cdivl(x.rows(), 256))), block(256);
             const void** rin = &io.radar;
-            add_op("image_radar_encoder.radar_encoder.to_nhwc", [tp, grid, block, rin](hipStream_t s) mutable { tp.X = *rin; ACH_LAUNCH(nchw_to_nhwc_kernel<T>, grid, block, s, tp); },
-                   double(x.rows()) * (3 + x.ld) * sizeof(T));
+            const double bytes = double(x.rows()) * (3 + 3) * sizeof(T), lbytes = double(x.rows()) * (3 + x.ld) * sizeof(T);
+            if (narrow0) {
+                const dim3 grid(unsigned(cdivl(x.rows() / 4, 256))), block(256);
+                add_op("image_radar_encoder.radar_encoder.to_nhwc", [tp, grid, block, rin](hipStream_t s) mutable { tp.X = *rin; ACH_LAUNCH(nchw3_to_nhwc4_kernel<T>, grid, block, s, tp); }, bytes, 0, lbytes);
+            } else {
+                const dim3 grid(unsigned(cdivl(x.rows(), 256))), block(256);
+                add_op("image_radar_encoder.radar_encoder.to_nhwc", [tp, grid, block, rin](hipStream_t s) mutable { tp.X = *rin; ACH_LAUNCH(nchw_to_nhwc_kernel<T>, grid, block, s, tp); }, bytes, 0, lbytes);
+            }
         }
         for (int i = 0; i < 8; ++i) {
             const std::string pfx = "image_radar_encoder.radar_encoder.rc_blocks." + std::to_string(i);
             const std::string d = pfx + ".radar_conv.deformable_conv";
-            const int C = chans[i], Cp = int(x.ld);
+            const bool narrow = i == 0 && narrow0;
+            const bool half = narrow && 2 * x.ld == VEC;             // 8-byte pixels (bf16): a k-slot is one tap x [4 channels | 4 zeros]
+            const int C = chans[i], Cp = half ? VEC : int(x.ld);     // k-elements per tap in the packed conv matrices
             // AvgPool2d(3,1,1)
-            Bordered pooled = alloc_bordered(B, x.H, x.W, C);
-            { PoolParams pp{x.p, x.ld, pooled.p0, pooled.ld, B, x.H, x.W, C, pooled.row, pooled.img}; if (C >= 16) ew(pfx + ".avgpool", avgpool3x3_kernel<T, 4>, pp, long(B) * x.H * cdiv(x.W, 4) * ((C + 3) / 4), 2.0 * x.rows() * Cp * sizeof(T));
-              else ew(pfx + ".avgpool", avgpool3x3_kernel<T, 1>, pp, x.rows() * ((C + 3) / 4), 2.0 * x.rows() * Cp * sizeof(T)); }
+            Bordered pooled = alloc_bordered(B, x.H, x.W, C, narrow ? 4 : 0);
+            { PoolParams pp{x.p, x.ld, pooled.p0, pooled.ld, B, x.H, x.W, C, pooled.row, pooled.img};
+              const double bytes = 2.0 * x.rows() * C * sizeof(T), lbytes = double(x.rows()) * (x.ld + pooled.ld) * sizeof(T);
+              if (C >= 16) ew(pfx + ".avgpool", avgpool3x3_kernel<T, 4>, pp, long(B) * x.H * cdiv(x.W, 4) * ((C + 3) / 4), bytes, lbytes);
+              else ew(pfx + ".avgpool", avgpool3x3_kernel<T, 1>, pp, x.rows() * ((C + 3) / 4), bytes, lbytes); }
             // offset_conv (18) + modulator_conv (9) as one implicit GEMM
             Lin lo = conv_lin(d + ".offset_conv.weight", d + ".offset_conv.bias", C, Cp, 3);
             Lin lm = conv_lin(d + ".modulator_conv.weight", d + ".modulator_conv.bias", C, Cp, 3);
             if (lo.N != 18 || lm.N != 9) throw AchError{ACH_ERR_MISSING_KEY, "deformable conv shapes at " + d};
             Lin lom; lom.N = 27; lom.K = lo.K; lom.w = lo.w; lom.w.insert(lom.w.end(), lm.w.begin(), lm.w.end()); lom.b = lo.b; lom.b.insert(lom.b.end(), lm.b.begin(), lm.b.end());
-            const int cvp = int(pooled.ld) / VEC, ksp = cdiv(9 * cvp, 4);
+            const int cvp = half ? 1 : int(pooled.ld) / VEC, ksp = cdiv(9 * cvp, 4);
             const bool fused_front = fuse_rc && C <= 16 && (ksp == 3 || ksp == 5 || ksp == 9);
             A om;
             if (!fused_front) om = conv3_bordered(pfx + ".offmask", pooled, lom, ACT_NONE);
@@ -1044,7 +1065,7 @@ public:
                 for (int n = 0; n < 27; ++n) b32[n] = lom.b[n];
                 for (int n = 0; n < C; ++n) b16[n] = lf.b[n];
                 if (down[i] && row_conv) {            // the stride-2 weight_conv2 reads it through the row-walking kernel: zero border
-                    yb = alloc_bordered(B, x.H, x.W, C);
+                    yb = alloc_bordered(B, x.H, x.W, C, narrow ? 4 : 0);
                     y_bordered = true;
                 } else {
                     y = alloc(B, x.H, x.W, C);
@@ -1053,9 +1074,11 @@ public:
                 RcFrontParams rp{pooled.p0, pooled.ld, pooled.row, pooled.img, pkom.w, up_f32(b32), pkf.w, up_f32(b16), x.p, x.ld,
                                  y_bordered ? yb.p0 : y.p, yld, y_bordered ? yb.row : long(x.W) * y.ld, y_bordered ? yb.img : long(x.H) * x.W * y.ld,
                                  B, x.H, x.W, cvp, C};
-                const double bytes = double(x.rows()) * (pooled.ld + x.ld + yld) * sizeof(T);
+                // algorithmic bytes: pooled map + residual read once, output written once, REAL channels; the layout figure
+                // counts the pixel pitches the kernel actually moves
+                const double bytes = double(x.rows()) * 3.0 * C * sizeof(T), lbytes = double(x.rows()) * (pooled.ld + x.ld + yld) * sizeof(T);
                 add_op(pfx + ".front", [rp, ksp](hipStream_t s) { launch_rc_front<T>(rp, ksp, s); }, bytes,
-                       2.0 * double(x.rows()) * 9.0 * Cp * (27 + C));
+                       2.0 * double(x.rows()) * 9.0 * C * (27 + C), lbytes);
             } else {
             DeformParams dp;
             std::memset(&dp, 0, sizeof(dp));
@@ -1079,7 +1102,7 @@ public:
             }
             // weight_conv2: 1x1, or 3x3 stride 2
             const int k = down[i] ? 3 : 1;
-            if (y_bordered) x = conv3_bordered(pfx + ".conv2", yb, conv_lin(pfx + ".weight_conv2.weight", pfx + ".weight_conv2.bias", C, int(yb.ld), 3), ACT_NONE, 2);
+            if (y_bordered) x = conv3_bordered(pfx + ".conv2", yb, conv_lin(pfx + ".weight_conv2.weight", pfx + ".weight_conv2.bias", C, half ? VEC : int(yb.ld), 3), ACT_NONE, 2);
             else x = conv_gemm(pfx + ".conv2", y, conv_lin(pfx + ".weight_conv2.weight", pfx + ".weight_conv2.bias", C, int(y.ld), k), k, down[i] ? 2 : 1, ACT_NONE);
             if (x.C != chans[i + 1]) throw AchError{ACH_ERR_MISSING_KEY, "radar width mismatch at " + pfx};
             tap("radar.b" + std::to_string(i), x);

@@ -28,7 +28,9 @@ struct Conv3Params {
 
 // NT = 1: up to 16 outputs (one 8-byte store per lane); NT = 2: up to 32.  STRIDE 1 or 2 (H, Wd are the OUTPUT map; the input is
 // the bordered map of (H - 1) * STRIDE + 1 .. rows, pad 1).
-template <class T, int KS, int NT, int STRIDE>
+// HALF: the input pixel is HALF a 16-byte vector (4 bf16 channels = 8 B: the 3-channel maps of the first RCBlock, ldx = 4, cv = 1):
+// a k-slot is still one tap x 8 k-elements, its upper four elements are zero (zero weights there), and a tap is one 8-byte load.
+template <class T, int KS, int NT, int STRIDE, bool HALF = false>
 __global__ __launch_bounds__(256) void conv3x3_rows_kernel(const Conv3Params p) {
     constexpr int VEC = Store<T>::VEC;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -76,6 +78,9 @@ __global__ __launch_bounds__(256) void conv3x3_rows_kernel(const Conv3Params p) 
                 const bool ok = rowok[s] && ix >= 0 && ix < p.Wd;
                 const uint4 v = *reinterpret_cast<const uint4*>(ok ? xp + off[s] : xp);
                 xf[s] = make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
+            } else if (HALF) {
+                const uint2 v = *reinterpret_cast<const uint2*>(xp + off[s]);
+                xf[s] = make_uint4(v.x, v.y, 0u, 0u);
             } else {
                 xf[s] = *reinterpret_cast<const uint4*>(xp + off[s]);
             }
@@ -109,8 +114,13 @@ __global__ __launch_bounds__(256) void conv3x3_rows_kernel(const Conv3Params p) 
 }
 
 template <class T>
-inline bool launch_conv3(const Conv3Params& p, int ksteps, int NT, int stride, hipStream_t stream) {
+inline bool launch_conv3(const Conv3Params& p, int ksteps, int NT, int stride, hipStream_t stream, bool half = false) {
     const dim3 grid(unsigned(p.B) * unsigned(p.H)), block(256);
+    if (half) {
+        if (Store<T>::VEC != 8 || ksteps != 3 || NT != 1 || stride != 2 || p.dense) return false;
+        ACH_LAUNCH((conv3x3_rows_kernel<T, 3, 1, 2, true>), grid, block, stream, p);
+        return true;
+    }
 #define ACH_C3_CASE(ks, nt, st) if (ksteps == ks && NT == nt && stride == st) { ACH_LAUNCH((conv3x3_rows_kernel<T, ks, nt, st>), grid, block, stream, p); return true; }
     ACH_C3_CASE(3, 2, 1) ACH_C3_CASE(5, 2, 1) ACH_C3_CASE(9, 2, 1)
     ACH_C3_CASE(3, 1, 2) ACH_C3_CASE(5, 1, 2) ACH_C3_CASE(9, 1, 2)
@@ -142,7 +152,8 @@ struct RcFrontParams {
     int B, H, Wd, cv, C;
 };
 
-// NARROW: the block has at most 4 channels (the first RCBlock: 3) — only the first 4 channels of a corner are fetched and blended.
+// NARROW (bf16 storage, the first RCBlock: 3 channels): the maps are carried as 4-channel = 8-BYTE pixels (ldp = ldr = ldy = 4, cv = 1).
+// A corner of the sampling and a tap of the conv are one 8-byte load each; a k-slot is one tap x [4 channels | 4 zeros].
 template <class T, int KS, bool NARROW>
 __global__ __launch_bounds__(256, KS == 3 ? 4 : 1) void rc_front_kernel(const RcFrontParams p) {
     constexpr int VEC = Store<T>::VEC;
@@ -201,7 +212,10 @@ __global__ __launch_bounds__(256, KS == 3 ? 4 : 1) void rc_front_kernel(const Rc
         const int x = xr < p.Wd ? xr : p.Wd - 1;
         const T* xp = xrow + long(x) * ldp;
         ACH_UNROLL
-        for (int s = 0; s < KS; ++s) xf[s] = *reinterpret_cast<const uint4*>(xp + off[s]);
+        for (int s = 0; s < KS; ++s) {
+            if constexpr (NARROW) { const uint2 v = *reinterpret_cast<const uint2*>(xp + off[s]); xf[s] = make_uint4(v.x, v.y, 0u, 0u); }
+            else xf[s] = *reinterpret_cast<const uint4*>(xp + off[s]);
+        }
     };
     if (wave < ntiles) fetch(wave);
     for (int tile = wave; tile < ntiles; tile += 4) {
@@ -273,7 +287,7 @@ __global__ __launch_bounds__(256, KS == 3 ? 4 : 1) void rc_front_kernel(const Rc
 template <class T>
 inline bool launch_rc_front(const RcFrontParams& p, int ksteps, hipStream_t stream) {
     const dim3 grid(unsigned(p.B) * unsigned(p.H)), block(256);
-    const bool narrow = p.C <= 4 && Store<T>::VEC == 8;
+    const bool narrow = p.ldp == 4 && Store<T>::VEC == 8;          // 8-byte pixels (engine: radar block 0 in bf16)
     if (ksteps == 3) {
         if (narrow) ACH_LAUNCH((rc_front_kernel<T, 3, true>), grid, block, stream, p); else ACH_LAUNCH((rc_front_kernel<T, 3, false>), grid, block, stream, p);
         return true;

@@ -35,7 +35,7 @@ class NativeLibrary:
     """dlopen + prototypes for every symbol declared in include/achelous.h."""
     SYMBOLS = ('ach_create', 'ach_destroy', 'ach_last_error', 'ach_load_weights', 'ach_plan', 'ach_arena_bytes',
                'ach_forward', 'ach_forward_detect', 'ach_decode', 'ach_nms_workspace_bytes', 'ach_nms', 'ach_tap_count', 'ach_tap_name',
-               'ach_tap_shape', 'ach_read_tap', 'ach_plan_launches', 'ach_op_name', 'ach_op_bytes', 'ach_op_flops',
+               'ach_tap_shape', 'ach_read_tap', 'ach_plan_launches', 'ach_op_name', 'ach_op_bytes', 'ach_op_layout_bytes', 'ach_op_flops', 'ach_op_stream',
                'ach_forward_profiled', 'ach_set_probe', 'ach_read_probe', 'ach_bench_gemm', 'ach_set_option', 'ach_preprocess_radar',
                'ach_normalize_points', 'ach_preprocess_image', 'ach_seg_argmax')
 
@@ -94,6 +94,10 @@ class NativeLibrary:
         L.ach_op_bytes.restype = ctypes.c_double
         L.ach_op_flops.argtypes = [vp, ctypes.c_int]
         L.ach_op_flops.restype = ctypes.c_double
+        L.ach_op_layout_bytes.argtypes = [vp, ctypes.c_int]
+        L.ach_op_layout_bytes.restype = ctypes.c_double
+        L.ach_op_stream.argtypes = [vp, ctypes.c_int]
+        L.ach_op_stream.restype = ctypes.c_int
         L.ach_forward_profiled.argtypes = [vp] + [vp] * 9 + [vp, vp, sz]
         L.ach_forward_profiled.restype = ctypes.c_int
         L.ach_set_probe.argtypes = [vp, ctypes.c_int]
@@ -203,6 +207,12 @@ class NativeEngine:
         """[(name, algorithmic bytes, flops)] of every launch in the plan."""
         return [(self.L.ach_op_name(self.h, i).decode(), self.L.ach_op_bytes(self.h, i), self.L.ach_op_flops(self.h, i))
                 for i in range(self.launches())]
+
+    def op_table_full(self):
+        """[{name, bytes (real channels), layout_bytes (stored pitches), flops, stream}] of every launch in the plan."""
+        return [dict(op=self.L.ach_op_name(self.h, i).decode(), bytes=self.L.ach_op_bytes(self.h, i),
+                     layout_bytes=self.L.ach_op_layout_bytes(self.h, i), flops=self.L.ach_op_flops(self.h, i),
+                     stream=self.L.ach_op_stream(self.h, i)) for i in range(self.launches())]
 
     def forward_profiled(self, image, radar, points, outs, stream=0):
         """One forward with every launch bracketed by HIP events -> per-launch milliseconds."""

@@ -156,8 +156,10 @@ int ach_read_tap(ach_handle* h, const char* name, float* host_out, size_t capaci
  * that brackets every launch with HIP events, and a live probe that brackets ONE launch on every ach_forward. */
 int ach_plan_launches(const ach_handle* h);
 const char* ach_op_name(const ach_handle* h, int i);
-double ach_op_bytes(const ach_handle* h, int i);
-double ach_op_flops(const ach_handle* h, int i);
+double ach_op_bytes(const ach_handle* h, int i);          /* inputs read once + outputs written once + weights, REAL channel counts */
+double ach_op_layout_bytes(const ach_handle* h, int i);   /* the same over the stored pixel pitches (channel padding included) */
+double ach_op_flops(const ach_handle* h, int i);          /* 2 x MACs of the dense contractions of the launch */
+int ach_op_stream(const ach_handle* h, int i);            /* 0: caller's stream, 1..: engine side streams */
 int ach_forward_profiled(ach_handle* h, const void* image, const void* radar, const void* points,
                          void* det3, void* det4, void* det5, void* se_seg, void* lane_seg, void* pc_seg, void* stream,
                          float* op_ms, size_t capacity);

@@ -19,8 +19,6 @@ from oracle.achelous_oracle import AchelousOracle, decode_outputs as o_decode, n
 
 pytestmark = pytest.mark.gpu
 F32_TOL = 1e-3
-BF16_FUSED_VS_LAYERWISE = 6e-2     # only for test_fused_kernels_agree_with_the_layerwise_path: two bf16 plans against EACH OTHER
-                                   # (both carry bf16 rounding, in different places)
 OUTPUTS = ('det0', 'det1', 'det2', 'se_seg', 'lane_seg', 'pc_seg')
 
 
@@ -314,7 +312,7 @@ def test_forward_detect_equals_the_three_calls():
                 assert int(cnt.max()) > 0
 
 
-@pytest.mark.parametrize('option', ['fused_mlp', 'row_conv', 'fused_rc', 'dw_tile', 'head_batch', 'split_decoders', 'head_stream', 'stem_mfma'])
+@pytest.mark.parametrize('option', ['fused_mlp', 'row_conv', 'fused_rc', 'dw_tile', 'head_batch', 'split_decoders', 'head_stream', 'stem_mfma', 'radar_start'])
 def test_fused_kernels_agree_with_the_layerwise_path(option):
     """Every fused / batched kernel has a switch back to the layer-wise launches it replaced (include/achelous.h): the two plans
     must agree — to fp32 rounding in the fp32 engine (different summation order), and within the bf16 tolerance in the bf16
@@ -322,7 +320,7 @@ def test_fused_kernels_agree_with_the_layerwise_path(option):
     g = Golden('en_s0')
     m, kw = _model(g)
     x, xr, xp = make_inputs(2, 17, resolution=kw['resolution'], pc_channels=kw['pc_channels'])
-    for dt, tol in ((torch.float32, 2e-5), (torch.bfloat16, BF16_FUSED_VS_LAYERWISE)):
+    for dt in (torch.float32, torch.bfloat16):
         xs, rs, ps = x.cuda().to(dt), xr.cuda().to(dt), xp.cuda().to(dt)
         with torch.no_grad():
             ref = m(xs, rs, ps)
@@ -334,8 +332,10 @@ def test_fused_kernels_agree_with_the_layerwise_path(option):
             torch.cuda.synchronize()
             e.set_option(option, default)
             e.plan(2)
-        for a, b in zip((*alt[0], alt[1], alt[2], alt[3]), (*ref[0], ref[1], ref[2], ref[3])):
-            assert _rel(a.float(), b.float()) <= tol, option
+        for k, a, b in zip(OUTPUTS, (*alt[0], alt[1], alt[2], alt[3]), (*ref[0], ref[1], ref[2], ref[3])):
+            # two bf16 plans that are each within bf16_bound of the fp32 truth may differ from each other by twice that
+            tol = 1e-4 if dt == torch.float32 else 2.0 * bf16_bound(g, k)
+            assert _rel(a.float(), b.float()) <= tol, (option, dt, k, _rel(a.float(), b.float()), tol)
 
 
 def test_reference_default_resolution_416():
