@@ -76,7 +76,7 @@ public:
                                       // neck is done
     int side_low_priority = 3;        // option "side_priority" (with head_stream = 0): bit k set = side stream k+1 is created at the
                                       // lowest stream priority
-    int radar_start = -1;             // option "radar_start": -1 = the radar branch starts with the forward; k = 0..2: only once backbone stage k is done
+    int radar_start = 1;              // option "radar_start" (default 1, measured +1 %, the block-0 front kernel 0.58 -> 0.38 ms in-step): -1 = the radar branch starts with the forward; k = 0..2: only once backbone stage k is done
                                       // (event 0), with the point branch ahead of it on the same stream — the first RCBlocks are
                                       // throughput-bound like backbone stages 0 / 1 and halve each other's speed when they overlap
     bool head_batch = true;           // option "head_batch": each detection-head layer as one launch for the three pyramid levels

@@ -1058,7 +1058,9 @@ public:
             Bordered yb;
             bool y_bordered = false;
             if (fused_front) {           // conv + sampling + folded contraction + ReLU + residual as one launch (k_conv3.h)
-                Packed pkom = pack(lom), pkf = pack(lf);
+                Lin lf2 = lf;            // the kernel multiplies the samples by sigmoid(logit); the factor 2 of the modulation (dcn.py:59) is exact here
+                for (float& v : lf2.w) v *= 2.0f;
+                Packed pkom = pack(lom), pkf = pack(lf2);
                 if (pkom.NT != 2 || pkom.nchunks != 1 || pkom.ksteps != ksp || pkf.NT != 1 || pkf.nchunks != 1 || pkf.ksteps != ksp)
                     throw AchError{ACH_ERR_UNSUPPORTED, "radar block packing at " + pfx};
                 std::vector<float> b32(32, 0.f), b16(16, 0.f);

@@ -203,6 +203,7 @@ __global__ __launch_bounds__(256, KS == 3 ? 4 : 1) void rc_front_kernel(const Rc
 
     const T* Pimg = static_cast<const T*>(p.P) + long(b) * p.pimg;
     const T* xrow = Pimg + long(oy) * p.prow;
+    const float prow_b = float(prow) * float(sizeof(T)), ld_b = float(ldp) * float(sizeof(T));
     const long rowpix = (long(b) * p.H + oy) * p.Wd;
     const int ntiles = (p.Wd + 15) / 16;
     // the conv inputs of the NEXT tile are fetched while the current tile is being sampled (one memory round trip hidden)
@@ -245,12 +246,11 @@ __global__ __launch_bounds__(256, KS == 3 ? 4 : 1) void rc_front_kernel(const Rc
             const int tap = tapi[s] < 0 ? 0 : tapi[s];
             const float* om = &oml[wave][px][0];
             const float dy = om[2 * tap], dx = om[2 * tap + 1], ml = om[18 + tap];
-            const BilinearTap t = make_tap(ybase[s] + dy, float(x) + xbase[s] + dx, modulation(ml), p.H, p.Wd, prow, ldp);
-            // 32-bit element offsets from the (wave-uniform) image base: scalar base + vector offset addressing
-            // wave-uniform base (top-left border pixel of the sample) + 32-bit BYTE offsets >= 0: scalar-base addressing, no 64-bit math
+            // wave-uniform base (top-left BORDER pixel of the sample) + 32-bit byte offsets >= 0: scalar-base addressing, no 64-bit math
             const char* Pb = reinterpret_cast<const char*>(Pimg - (prow + ldp));
-            const unsigned esz = unsigned(sizeof(T));
-            const unsigned q0 = unsigned(prow + ldp + t.o0 + cofs[s]) * esz, q1 = unsigned(prow + ldp + t.o1 + cofs[s]) * esz;
+            constexpr unsigned esz = unsigned(sizeof(T));
+            const BilinearTapB t = make_tap_bytes(ybase[s] + dy, float(x) + xbase[s] + dx, sigmoid_mod(ml), p.H, p.Wd, prow_b, ld_b, float(cofs[s]) * float(esz));
+            const unsigned q0 = t.q0, q1 = q0 + unsigned(prow) * esz;
             const unsigned q0b = q0 + unsigned(ldp) * esz, q1b = q1 + unsigned(ldp) * esz;
             const float live = tapi[s] < 0 ? 0.f : 1.f;
             const float w00 = t.w00 * live, w01 = t.w01 * live, w10 = t.w10 * live, w11 = t.w11 * live;

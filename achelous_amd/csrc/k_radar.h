@@ -123,6 +123,25 @@ __device__ __forceinline__ BilinearTap make_tap(float sy, float sx, float mask, 
     return t;
 }
 __device__ __forceinline__ float modulation(float logit) { return 2.0f * fast_rcp(1.0f + fast_exp2(-1.44269504f * logit)); }   // 2 sigmoid
+// The same footprint for the fused front kernel: the corner address as a BYTE offset from the sample's top-left BORDER pixel,
+// formed in fp32 — (fy + 1) * row pitch + (fx + 1) * pixel pitch is an integer below 2^24 for every map of the path (a bordered
+// 320x320 sample of 16-byte pixels is 1.7 MB), so two FMAs and one conversion replace two conversions, a 32-bit multiply and a
+// 64-bit multiply-add (both quarter rate) per tap of a VALU-bound kernel.
+struct BilinearTapB {
+    unsigned q0;                  // byte offset of the top-left corner (>= 0: the border pixel row / column is offset 0)
+    float w00, w01, w10, w11;
+};
+__device__ __forceinline__ BilinearTapB make_tap_bytes(float sy, float sx, float mask, int H, int Wd, float prow_b, float ld_b, float chan_b) {
+    BilinearTapB t;
+    const float cy = clampf(sy, -1.f, float(H)), cx = clampf(sx, -1.f, float(Wd));
+    const float fy = fminf(floorf(cy), float(H - 1)), fx = fminf(floorf(cx), float(Wd - 1));
+    const float ly = cy - fy, lx = cx - fx;
+    const float hym = (1.f - ly) * mask, lym = ly * mask, hx = 1.f - lx;
+    t.w00 = hym * hx; t.w01 = hym * lx; t.w10 = lym * hx; t.w11 = lym * lx;
+    t.q0 = unsigned(fmaf(fy + 1.f, prow_b, fmaf(fx + 1.f, ld_b, chan_b)));
+    return t;
+}
+__device__ __forceinline__ float sigmoid_mod(float logit) { return fast_rcp(1.0f + fast_exp2(-1.44269504f * logit)); }        // the factor 2 of the modulation lives in the folded weights
 
 struct DeformParams {
     const void* pooled; long ldp;     // sampled tensor (avg-pooled block input), NHWC with a zero border: pixel (0,0) of sample 0,
