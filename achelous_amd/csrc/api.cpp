@@ -239,6 +239,13 @@ int ach_bench_gemm(ach_handle* h, int M, int K, int N, int act, int ln, int resi
     });
 }
 int ach_set_probe(ach_handle* h, int op_index) { return guarded(h, [&] { h->eng->set_probe(op_index); }); }
+int ach_set_probe_range(ach_handle* h, int slot, int first, int last) { return guarded(h, [&] { h->eng->set_probe_range(slot, first, last); }); }
+int ach_read_probe_slot(ach_handle* h, int slot, float* avg_ms, int* samples) {
+    return guarded(h, [&] {
+        if (!avg_ms || !samples) throw ach::AchError{ACH_ERR_INVALID, "null probe outputs"};
+        h->eng->read_probe_slot(slot, avg_ms, samples);
+    });
+}
 int ach_read_probe(ach_handle* h, float* avg_ms, int* samples) {
     return guarded(h, [&] {
         if (!avg_ms || !samples) throw ach::AchError{ACH_ERR_INVALID, "null pointer"};

@@ -38,8 +38,7 @@ EngineBase::~EngineBase() {
         (void)hipEventDestroy(ev_fork);
         for (int k = 0; k < kJoinEvents; ++k) (void)hipEventDestroy(ev_join[k]);
     }
-    for (auto e : probe_ev0) (void)hipEventDestroy(e);
-    for (auto e : probe_ev1) (void)hipEventDestroy(e);
+    for (auto& pr : probes) { for (auto e : pr.ev0) (void)hipEventDestroy(e); for (auto e : pr.ev1) (void)hipEventDestroy(e); }
 }
 
 void EngineBase::load(const ach_tensor_desc* t, size_t n) {
@@ -85,7 +84,7 @@ void EngineBase::reset_plan() {
 #if !defined(ACH_HOSTEMU)
     drop_graphs();
 #endif
-    probe_op = -1;
+    for (auto& pr : probes) pr.first = pr.last = -1;
     cur_stream = 0; pending_wait = -1; pending_wait2 = -1;
     ops.clear(); taps.clear(); tap_order.clear();
     warena_used = 0; aarena_used = 0;
@@ -126,15 +125,9 @@ void EngineBase::run_eager(hipStream_t s) {
         if (multi && op.stream > 0) { st = side_stream[op.stream - 1]; used[op.stream - 1] = true; }
         if (multi && op.wait_ev >= 0) (void)hipStreamWaitEvent(st, ev_join[op.wait_ev], 0);
         if (multi && op.wait_ev2 >= 0) (void)hipStreamWaitEvent(st, ev_join[op.wait_ev2], 0);
-        if (int(i) == probe_op) {
-            const size_t slot = size_t(probe_count % kProbeEvents);
-            (void)hipEventRecord(probe_ev0[slot], st);
-            op.fn(st);
-            (void)hipEventRecord(probe_ev1[slot], st);
-            ++probe_count;
-        } else {
-            op.fn(st);
-        }
+        for (auto& pr : probes) if (int(i) == pr.first) (void)hipEventRecord(pr.ev0[size_t(pr.count % kProbeEvents)], st);
+        op.fn(st);
+        for (auto& pr : probes) if (int(i) == pr.last) { (void)hipEventRecord(pr.ev1[size_t(pr.count % kProbeEvents)], st); ++pr.count; }
         if (multi && op.signal_ev >= 0) (void)hipEventRecord(ev_join[op.signal_ev], st);
     }
     if (detect_tail) detect_tail((multi && detect_stream > 0 && used[detect_stream - 1]) ? side_stream[detect_stream - 1] : s);   // det maps are final on that stream
@@ -158,7 +151,7 @@ void EngineBase::drop_graphs() {
 // and replayed with one hipGraphLaunch on the caller's stream.  Capture happens on an engine-owned stream (the caller's may be
 // the legacy default stream, which cannot be captured).  Any failure falls back to eager launches of the SAME kernels.
 void EngineBase::run(hipStream_t s) {
-    if (!use_graph || graph_failed || probe_op >= 0) { run_eager(s); return; }
+    if (!use_graph || graph_failed || probing()) { run_eager(s); return; }
     for (auto& g : graphs)
         if (same_io(g.io, io)) {
             g.stamp = ++graph_clock;
@@ -194,22 +187,27 @@ void EngineBase::run_profiled(hipStream_t s, float* op_ms, size_t cap) {
     for (size_t i = 0; i < ops.size(); ++i) ACH_HIP_CHECK(hipEventElapsedTime(&op_ms[i], ev[i], ev[i + 1]));
     for (auto& e : ev) (void)hipEventDestroy(e);
 }
-void EngineBase::set_probe(int op_index) {
-    if (op_index >= int(ops.size())) throw AchError{ACH_ERR_INVALID, "probe index out of range"};
-    if (probe_ev0.empty()) {
-        probe_ev0.resize(kProbeEvents); probe_ev1.resize(kProbeEvents);
-        for (int i = 0; i < kProbeEvents; ++i) { ACH_HIP_CHECK(hipEventCreate(&probe_ev0[i])); ACH_HIP_CHECK(hipEventCreate(&probe_ev1[i])); }
+void EngineBase::set_probe_range(int slot, int first, int last) {
+    if (slot < 0 || slot >= kProbeSlots) throw AchError{ACH_ERR_INVALID, "probe slot out of range"};
+    if (first >= int(ops.size()) || last >= int(ops.size()) || (first >= 0 && last < first)) throw AchError{ACH_ERR_INVALID, "probe index out of range"};
+    if (first >= 0 && ops[size_t(first)].stream != ops[size_t(last)].stream) throw AchError{ACH_ERR_INVALID, "probe range must start and end on one stream"};
+    Probe& pr = probes[slot];
+    if (pr.ev0.empty()) {
+        pr.ev0.resize(kProbeEvents); pr.ev1.resize(kProbeEvents);
+        for (int i = 0; i < kProbeEvents; ++i) { ACH_HIP_CHECK(hipEventCreate(&pr.ev0[size_t(i)])); ACH_HIP_CHECK(hipEventCreate(&pr.ev1[size_t(i)])); }
     }
-    probe_op = op_index;
-    probe_count = 0;
+    pr.first = first < 0 ? -1 : first; pr.last = first < 0 ? -1 : last;
+    pr.count = 0;
 }
-void EngineBase::read_probe(float* avg_ms, int* samples) {
-    const long n = probe_count < kProbeEvents ? probe_count : kProbeEvents;
+void EngineBase::read_probe_slot(int slot, float* avg_ms, int* samples) {
+    if (slot < 0 || slot >= kProbeSlots) throw AchError{ACH_ERR_INVALID, "probe slot out of range"};
+    Probe& pr = probes[slot];
+    const long n = pr.count < kProbeEvents ? pr.count : kProbeEvents;
     double tot = 0;
     for (long i = 0; i < n; ++i) {
         float ms = 0.f;
-        ACH_HIP_CHECK(hipEventSynchronize(probe_ev1[size_t(i)]));
-        ACH_HIP_CHECK(hipEventElapsedTime(&ms, probe_ev0[size_t(i)], probe_ev1[size_t(i)]));
+        ACH_HIP_CHECK(hipEventSynchronize(pr.ev1[size_t(i)]));
+        ACH_HIP_CHECK(hipEventElapsedTime(&ms, pr.ev0[size_t(i)], pr.ev1[size_t(i)]));
         tot += ms;
     }
     *avg_ms = n ? float(tot / double(n)) : 0.f;

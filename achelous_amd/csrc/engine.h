@@ -100,9 +100,12 @@ public:
     // transient: extra launches enqueued behind the last op of the detection branch (stream 1) by ach_forward_detect
     std::function<void(hipStream_t)> detect_tail;
     void run_profiled(hipStream_t s, float* op_ms, size_t cap);
-    // live probe: HIP events around ONE op of the plan on every run() (bench.py's roofline leg)
-    void set_probe(int op_index);
-    void read_probe(float* avg_ms, int* samples);
+    // live probes: HIP events around ONE op of the plan (slot 0: set_probe) or around a RUN of ops first..last that sit on one stream
+    // (slot 1: set_probe_range — the neck + decoder sub-path of the caller's stream) on every run() (bench.py's roofline leg)
+    void set_probe(int op_index) { set_probe_range(0, op_index, op_index); }
+    void read_probe(float* avg_ms, int* samples) { read_probe_slot(0, avg_ms, samples); }
+    void set_probe_range(int slot, int first, int last);
+    void read_probe_slot(int slot, float* avg_ms, int* samples);
     virtual void decode(int B, const void* d3, const void* d4, const void* d5, float* out, hipStream_t s) = 0;
     void nms(int B, const float* decoded, float conf, float iou, int max_det, float* rows, int* idx, int* count,
              void* workspace, hipStream_t s);
@@ -152,10 +155,10 @@ protected:
     bool graph_failed = false;
     void drop_graphs();
 #endif
-    int probe_op = -1;
-    static constexpr int kProbeEvents = 512;
-    std::vector<hipEvent_t> probe_ev0, probe_ev1;
-    long probe_count = 0;
+    static constexpr int kProbeEvents = 512, kProbeSlots = 2;
+    struct Probe { int first = -1, last = -1; std::vector<hipEvent_t> ev0, ev1; long count = 0; };
+    Probe probes[kProbeSlots];
+    bool probing() const { return probes[0].first >= 0 || probes[1].first >= 0; }
     void add_tap(const std::string& name, const TapInfo& t) { if (!measuring) { if (!taps.count(name)) tap_order.push_back(name); taps[name] = t; } }
     void reset_plan();
 };

@@ -146,6 +146,7 @@ public:
         int act = ACT_NONE; bool ln = false; float ln_eps = 0.f;
         const A* residual = nullptr;
         int conv_k = 0, conv_s = 1, conv_p = 0, Hin = 0, Win = 0, Cin = 0, Ho = 0, Wo = 0;   // implicit-GEMM conv over NHWC
+        int Creal = 0;                                                            // conv mode: real channels per pixel (Cin is the stored pitch) for the byte accounting
         void** ydyn = nullptr; int out_nchw = 0, HW = 0, Ctot = 0, coff = 0;     // NCHW scatter into a user buffer
         int groups = 1; long w_group_stride = 0;
         const T* w_override = nullptr;                                            // data-dependent packed weights
@@ -178,19 +179,22 @@ public:
         const int NT = pk.NT;
         void** ydyn = o.ydyn;
         const double esz = double(sizeof(T));
-        const double in_bytes = o.conv_k > 0 ? double(M) / (double(o.Ho) * o.Wo) * o.Hin * o.Win * o.Cin * esz : double(M) * pk.K * esz;   // inputs read ONCE
-        const double bytes = in_bytes + double(M) * pk.N * esz + (o.residual ? double(M) * pk.N * esz : 0.0)
-                             + double(pk.group_elems) * esz * (o.w_group_stride ? o.groups : 1);
+        const double px_in = o.conv_k > 0 ? double(M) / (double(o.Ho) * o.Wo) * o.Hin * o.Win : 0.0;
+        const double in_bytes = o.conv_k > 0 ? px_in * (o.Creal ? o.Creal : o.Cin) * esz : double(M) * pk.K * esz;   // inputs read ONCE, real channels
+        const double rest = double(M) * pk.N * esz + (o.residual ? double(M) * pk.N * esz : 0.0)
+                            + double(pk.group_elems) * esz * (o.w_group_stride ? o.groups : 1);
+        const double bytes = in_bytes + rest;
+        const double lbytes = (o.conv_k > 0 ? px_in * o.Cin * esz : in_bytes) + rest;
         if (batching) {           // collected now, emitted by flush_batch() as one launch per layer across the pyramid levels
             if (g.groups != 1 || P != 1) throw AchError{ACH_ERR_INVALID, name + ": batched GEMMs must be ungrouped"};
-            BatchJob j; j.kind = 0; j.name = name; j.g = g; j.NT = NT; j.ydyn = ydyn; j.bytes = bytes; j.flops = 2.0 * double(M) * pk.K * pk.N;
+            BatchJob j; j.kind = 0; j.name = name; j.g = g; j.NT = NT; j.ydyn = ydyn; j.bytes = bytes; j.flops = 2.0 * double(M) * (o.conv_k > 0 && o.Creal ? double(o.conv_k * o.conv_k * o.Creal) : double(pk.K)) * pk.N;
             batch_jobs.push_back(j);
             return;
         }
         add_op(name, [g, NT, P, ydyn](hipStream_t s) mutable {
             if (ydyn) g.Y = *ydyn;
             launch_gemm<T>(g, NT, P, s);
-        }, bytes, 2.0 * double(M) * pk.K * pk.N);
+        }, bytes, 2.0 * double(M) * (o.conv_k > 0 && o.Creal ? double(o.conv_k * o.conv_k * o.Creal) : double(pk.K)) * pk.N, lbytes);
     }
     // ---- batching of the same layer over the detection head's pyramid levels
     struct BatchJob { int kind = 0; std::string name; GemmParams g; int NT = 1; void** ydyn = nullptr; DwParams d; int ks = 0; double bytes = 0, flops = 0; };
@@ -668,7 +672,7 @@ public:
             const dim3 grid(unsigned(cdivl(img.rows(), 256))), block(256);
             const void** in = &io.image;
             add_op(pfx + ".to_nhwc", [tp, grid, block, in](hipStream_t s) mutable { tp.X = *in; ACH_LAUNCH(nchw_to_nhwc_kernel<T>, grid, block, s, tp); },
-                   double(img.rows()) * (3 + img.ld) * sizeof(T));
+                   double(img.rows()) * (3 + 3) * sizeof(T), 0, double(img.rows()) * (3 + img.ld) * sizeof(T));
         }
         A x = mv_conv(pfx + ".conv1", img, 3, 2);
         x = mv2block(pfx + ".mv2.0", x, 1, mc.ch[1]);
@@ -956,7 +960,7 @@ public:
         const int Ho = (x.H + 2 * pad - k) / stride + 1, Wo = (x.W + 2 * pad - k) / stride + 1;
         A y = alloc(x.B, Ho, Wo, l.N);
         GemmOpt o; o.act = act; o.residual = residual;
-        o.conv_k = k; o.conv_s = stride; o.conv_p = pad; o.Hin = x.H; o.Win = x.W; o.Cin = int(x.ld); o.Ho = Ho; o.Wo = Wo;
+        o.conv_k = k; o.conv_s = stride; o.conv_p = pad; o.Hin = x.H; o.Win = x.W; o.Cin = int(x.ld); o.Creal = x.C; o.Ho = Ho; o.Wo = Wo;
         gemm(name, x.p, x.ld, y.rows(), pack(l), y.p, y.ld, o);
         return y;
     }
@@ -992,7 +996,7 @@ public:
         if (half) throw AchError{ACH_ERR_INVALID, name + ": 8-byte pixels are only read by the row-walking conv"};
         // generic implicit GEMM: the bordered buffer is a dense [B, H+2, W+2, ld] tensor convolved without padding
         GemmOpt o; o.act = act;
-        o.conv_k = 3; o.conv_s = stride; o.conv_p = 0; o.Hin = x.H + 2; o.Win = x.W + 2; o.Cin = int(x.ld); o.Ho = Ho; o.Wo = Wo;
+        o.conv_k = 3; o.conv_s = stride; o.conv_p = 0; o.Hin = x.H + 2; o.Win = x.W + 2; o.Cin = int(x.ld); o.Creal = x.C; o.Ho = Ho; o.Wo = Wo;
         gemm(name, x.base, x.ld, y.rows(), pk, y.p, y.ld, o);
         return y;
     }
@@ -1090,13 +1094,13 @@ public:
                 y = alloc(B, x.H, x.W, C);
                 dp.Y = y.p; dp.ldy = y.ld; dp.Wf = up_f32(lf.w); dp.bf = up_f32(lf.b);
                 const dim3 grid(unsigned(cdivl(x.rows(), 256))), block(256);
-                const double bytes = double(x.rows()) * (3.0 * Cp + 32) * sizeof(T);
-                if (C == 3) add_op(pfx + ".deform", [dp, grid, block](hipStream_t s) { ACH_LAUNCH((deform_fused_kernel<T, 3, 4>), grid, block, s, dp, dp.Wf, dp.bf); }, bytes);   // 3 channels: one 4-vector per corner
-                else add_op(pfx + ".deform", [dp, grid, block](hipStream_t s) { ACH_LAUNCH((deform_fused_kernel<T, 8, 8>), grid, block, s, dp, dp.Wf, dp.bf); }, bytes);
+                const double bytes = double(x.rows()) * (3.0 * C + 27) * sizeof(T), lbytes = double(x.rows()) * (3.0 * Cp + 32) * sizeof(T);
+                if (C == 3) add_op(pfx + ".deform", [dp, grid, block](hipStream_t s) { ACH_LAUNCH((deform_fused_kernel<T, 3, 4>), grid, block, s, dp, dp.Wf, dp.bf); }, bytes, 0, lbytes);   // 3 channels: one 4-vector per corner
+                else add_op(pfx + ".deform", [dp, grid, block](hipStream_t s) { ACH_LAUNCH((deform_fused_kernel<T, 8, 8>), grid, block, s, dp, dp.Wf, dp.bf); }, bytes, 0, lbytes);
             } else {
                 A col = alloc(B, x.H, x.W, 9 * Cp);
                 dp.Y = col.p; dp.ldy = col.ld;
-                ew(pfx + ".deform.sample", deform_sample_kernel<T>, dp, x.rows() * 9 * (Cp / 4), double(x.rows()) * (10.0 * Cp + 32) * sizeof(T));
+                ew(pfx + ".deform.sample", deform_sample_kernel<T>, dp, x.rows() * 9 * (Cp / 4), double(x.rows()) * (10.0 * C + 27) * sizeof(T), double(x.rows()) * (10.0 * Cp + 32) * sizeof(T));
                 y = alloc(B, x.H, x.W, C);
                 GemmOpt o; o.act = ACT_RELU; o.residual = &x;            // epilogue order: act, then + residual
                 gemm(pfx + ".deform.contract", col, pack(lf), y, o);

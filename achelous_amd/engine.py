@@ -36,7 +36,7 @@ class NativeLibrary:
     SYMBOLS = ('ach_create', 'ach_destroy', 'ach_last_error', 'ach_load_weights', 'ach_plan', 'ach_arena_bytes',
                'ach_forward', 'ach_forward_detect', 'ach_decode', 'ach_nms_workspace_bytes', 'ach_nms', 'ach_tap_count', 'ach_tap_name',
                'ach_tap_shape', 'ach_read_tap', 'ach_plan_launches', 'ach_op_name', 'ach_op_bytes', 'ach_op_layout_bytes', 'ach_op_flops', 'ach_op_stream',
-               'ach_forward_profiled', 'ach_set_probe', 'ach_read_probe', 'ach_bench_gemm', 'ach_set_option', 'ach_preprocess_radar',
+               'ach_forward_profiled', 'ach_set_probe', 'ach_read_probe', 'ach_set_probe_range', 'ach_read_probe_slot', 'ach_bench_gemm', 'ach_set_option', 'ach_preprocess_radar',
                'ach_normalize_points', 'ach_preprocess_image', 'ach_seg_argmax')
 
     def __init__(self, path):
@@ -104,6 +104,10 @@ class NativeLibrary:
         L.ach_set_probe.restype = ctypes.c_int
         L.ach_read_probe.argtypes = [vp, ctypes.POINTER(f32), ctypes.POINTER(ctypes.c_int)]
         L.ach_read_probe.restype = ctypes.c_int
+        L.ach_set_probe_range.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        L.ach_set_probe_range.restype = ctypes.c_int
+        L.ach_read_probe_slot.argtypes = [vp, ctypes.c_int, ctypes.POINTER(f32), ctypes.POINTER(ctypes.c_int)]
+        L.ach_read_probe_slot.restype = ctypes.c_int
         L.ach_bench_gemm.argtypes = [vp] + [ctypes.c_int] * 8 + [vp, ctypes.POINTER(f32)]
         L.ach_bench_gemm.restype = ctypes.c_int
 
@@ -235,6 +239,14 @@ class NativeEngine:
     def read_probe(self):
         avg, n = ctypes.c_float(), ctypes.c_int()
         self._check(self.L.ach_read_probe(self.h, ctypes.byref(avg), ctypes.byref(n)))
+        return float(avg.value), int(n.value)
+
+    def set_probe_range(self, slot, first, last):
+        self._check(self.L.ach_set_probe_range(self.h, int(slot), int(first), int(last)))
+
+    def read_probe_slot(self, slot):
+        avg, n = ctypes.c_float(), ctypes.c_int()
+        self._check(self.L.ach_read_probe_slot(self.h, int(slot), ctypes.byref(avg), ctypes.byref(n)))
         return float(avg.value), int(n.value)
 
     def decode(self, batch, det3, det4, det5, decoded, stream=0):

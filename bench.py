@@ -15,9 +15,16 @@ of detections).
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Prints ONE JSON line (rank 0).  Besides the contract fields:
-  roofline     — for the dominant kernel of the plan: achieved = algorithmic bytes per launch / mean launch duration,
-                 the duration measured LIVE with HIP events on the launch stream around that kernel on every timed step.
-  cpu_baseline — the oracle (CPU port of the reference forward) timed on this box's host cores on a bounded sample.
+  roofline     — for the dominant kernel of the plan: achieved = algorithmic bytes per launch (inputs read once + outputs written
+                 once, REAL channel counts; the stored-pitch figure is given beside it) / mean launch duration, the duration measured
+                 LIVE with HIP events on the launch stream around that kernel on every timed step.  `traffic` = PMC bytes of that launch
+                 (profiles/r02_traffic_<config>.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes).
+                 roofline.subpath — the north-star sub-path (Ghost-Dual-FPN neck + both segmentation decoders, a contiguous run of the
+                 caller's stream): live in-step time (range probe), isolated time (per-launch pass), SURVEY 8(d) compulsory bytes and
+                 the sum of the launches' own algorithmic bytes, each as a fraction of the 8 TB/s HBM peak.
+  mfma         — sum of the dense launches' flops x steps/s against the 2.5 PFLOP/s dense bf16 MFMA peak.
+  cpu_baseline — the oracle (OUR CPU port of the reference forward: torch CPU ops, not the reference's own code) timed on this box's
+                 host cores at batch 1 and on a bounded multi-frame sample, thread count chosen by a short sweep, CPU model stated.
 """
 import argparse
 import json
@@ -43,6 +50,49 @@ WORKLOAD_NAMES = {'en_s0': 'EN-GDF-PN-S0', 'en_s2': 'EN-GDF-PN-S2', 'mv_s2': 'MV
 COMMON = dict(num_det=7, num_seg=9, resolution=320, neck='gdf', pc_seg='pn', pc_channels=5, pc_classes=8, nano_head=True, spp=True)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}
+
+
+def cpu_baseline(model, ctor, x, xr, xp, sample):
+    """The oracle — OUR fp32 CPU port of the reference forward (oracle/achelous_oracle.py: torch CPU ops; the radar branch through
+    the oracle's gather-based deform_conv2d restatement, torchvision's C++ kernel not being installable here) — on this box's host
+    cores: a batch-1 leg and a `sample`-frame leg, each at the best thread count of a short sweep.  It is a reported baseline, not
+    the reference's own code and not a target: SURVEY 6 measured the imported reference itself at 4.05 frames/s (batch 64, 8 cores)
+    in the build container, where it exists."""
+    from oracle.achelous_oracle import AchelousOracle
+    cores = os.cpu_count() or 1
+    model_name = 'unknown'
+    try:
+        model_name = next(l.split(':', 1)[1].strip() for l in open('/proc/cpuinfo') if l.startswith('model name'))
+    except Exception:
+        pass
+    orc = AchelousOracle({k: v.detach().cpu() for k, v in model.state_dict().items()}, **ctor)
+    n = max(1, min(sample, x.shape[0]))
+    cx, cr, cp = x[:n].float().cpu(), xr[:n].float().cpu(), xp[:n].float().cpu()
+    prev = torch.get_num_threads()
+
+    def leg(frames, thread_options, budget_s):
+        best, tried = None, {}
+        for th in thread_options:
+            torch.set_num_threads(th)
+            orc.forward(cx[:1], cr[:1], cp[:1])                      # warm-up at this thread count
+            t0 = time.perf_counter()
+            reps = 0
+            while reps < 1 or (time.perf_counter() - t0 < budget_s and reps < 5):
+                orc.forward(cx[:frames], cr[:frames], cp[:frames])
+                reps += 1
+            fps_ = frames * reps / (time.perf_counter() - t0)
+            tried[th] = round(fps_, 3)
+            if best is None or fps_ > best[0]:
+                best = (fps_, th, reps)
+        return best, tried
+    opts = sorted({min(cores, t) for t in (8, 16, 32, 64, cores)})
+    b1, tried1 = leg(1, opts, 1.5)
+    bn, triedn = leg(n, [t for t in opts if t >= 16] or opts, 4.0)
+    torch.set_num_threads(prev)
+    return {'value': round(bn[0], 3), 'unit': 'frames/s', 'cores': bn[1], 'kind': 'port',
+            'sample': f'oracle (our fp32 CPU port, torch CPU ops) on {n} of the batch frames, {bn[2]} passes at {bn[1]} threads (best of {triedn}); '
+                      f'batch 1: {round(b1[0], 3)} frames/s at {b1[1]} threads (best of {tried1})',
+            'batch1_fps': round(b1[0], 3), 'batch1_threads': b1[1], 'host_cores': cores, 'cpu_model': model_name}
 
 
 def main():
@@ -143,9 +193,17 @@ def main():
         # one pass with every launch bracketed by HIP events: find the dominant kernel of the plan
         outs = (out[0][0], out[0][1], out[0][2], out[1], out[2], out[3])
         prof = [eng.forward_profiled(x, xr, xp, outs, stream) for _ in range(3)][-1]
-        table = eng.op_table()
+        full = eng.op_table_full()
+        table = [(o['op'], o['bytes'], o['flops']) for o in full]
         dom = max(range(len(prof)), key=lambda i: prof[i])
         eng.set_probe(dom)
+        # the north-star sub-path: neck (SPP .. FPN outputs) + ShuffleAttention + both decoders = one run of the caller's stream
+        sub_first = next((i for i, o in enumerate(full) if o['op'].endswith('.fpn.spp.cv1')), None)
+        sub_last = max((i for i, o in enumerate(full) if o['stream'] == 0 and '_seg_head' in o['op']), default=None)
+        sub_ops = []
+        if sub_first is not None and sub_last is not None and full[sub_first]['stream'] == 0:
+            sub_ops = [i for i in range(sub_first, sub_last + 1) if full[i]['stream'] == 0]
+            eng.set_probe_range(1, sub_first, sub_last)
 
         fence()
         t0 = time.perf_counter()
@@ -154,7 +212,9 @@ def main():
         fence()
         t1 = time.perf_counter()
         probe_ms, probe_n = eng.read_probe()
+        sub_ms, sub_n = eng.read_probe_slot(1) if sub_ops else (0.0, 0)
         eng.set_probe(-1)
+        eng.set_probe_range(1, -1, -1)
 
         # forward-only rate (same inputs, no decode / NMS / gather), for the report
         fence()
@@ -174,18 +234,36 @@ def main():
     result = None
     if rank == 0:
         name, dom_bytes, dom_flops = table[dom]
+        esz = 2 if args.dtype == 'bf16' else 4
         achieved = dom_bytes / (probe_ms * 1e-3) / 1e9 if probe_ms > 0 else 0.0
         roofline = {'bound': 'hbm', 'kernel': name, 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                     'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': None,
-                    'algorithmic_bytes_per_launch': dom_bytes, 'launch_ms': round(probe_ms, 5), 'launches_timed': probe_n,
+                    'algorithmic_bytes_per_launch': dom_bytes, 'layout_bytes_per_launch': full[dom]['layout_bytes'],
+                    'launch_ms': round(probe_ms, 5), 'launches_timed': probe_n, 'launch_ms_isolated': round(prof[dom], 5),
+                    'frac_isolated': round(dom_bytes / (prof[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if prof[dom] > 0 else None,
                     'share_of_forward': round(prof[dom] / max(sum(prof), 1e-9), 4)}
-        traffic_file = os.path.join(ROOT, 'profiles', 'traffic.json')      # PMC passes are separate rocprofv3 runs
-        if os.path.exists(traffic_file):
+        traffic_file = os.path.join(ROOT, 'profiles', f'r02_traffic_{args.config}.json')      # PMC passes are separate rocprofv3 runs
+        if os.path.exists(traffic_file) and args.dtype == 'bf16' and B == 64:
             try:
-                roofline['traffic'] = json.load(open(traffic_file)).get(name)
+                roofline['traffic'] = json.load(open(traffic_file))['ops'].get(name, {}).get('traffic_bytes')
             except Exception:
                 pass
-        algo_bytes_frame = (616960 + 1155696) * (2 if args.dtype == 'bf16' else 4)     # inputs + outputs once
+        if sub_ops:
+            # inputs P3/P4/P5 read once + se, lane and the three FPN maps written once (elements per frame)
+            comp_elems = {'S0': 1392000, 'S2': 1504000}.get(kw.get('phi'), None)
+            sub_bytes = sum(full[i]['bytes'] for i in sub_ops)
+            sub_iso = sum(prof[i] for i in sub_ops)
+            comp = comp_elems * esz * B if comp_elems else None
+            fr = lambda by, ms: round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if (by and ms > 0) else None
+            roofline['subpath'] = {
+                'what': f"{full[sub_first]['op']} .. {full[sub_last]['op']} on the caller's stream (neck + ShuffleAttention + both seg decoders)",
+                'launches': len(sub_ops), 'in_step_ms': round(sub_ms, 5), 'steps_timed': sub_n, 'isolated_ms': round(sub_iso, 5),
+                'compulsory_bytes': comp, 'launch_bytes': sub_bytes,
+                'frac_compulsory_in_step': fr(comp, sub_ms), 'frac_compulsory_isolated': fr(comp, sub_iso),
+                'frac_launch_bytes_in_step': fr(sub_bytes, sub_ms), 'frac_launch_bytes_isolated': fr(sub_bytes, sub_iso)}
+        algo_bytes_frame = (616960 + 1155696) * esz     # inputs + outputs once
+        flops_step = sum(o['flops'] for o in full)
+        mfma_peak = MFMA_PEAK_TFLOPS[args.dtype]
         result = {
             'metric': 'frames/sec (whole node) EN-GDF-PN-S0 320x320+512pts bs64 @1/2/4/8 GPU' if args.config == 'en_s0'
                       else f'frames/sec (whole node) {args.config} 320x320+512pts bs{B}',
@@ -199,28 +277,17 @@ def main():
             'forward_only_fps': round(frames / fwd_elapsed, 2),
             'compulsory_hbm_frac': round(algo_bytes_frame * (frames / fwd_elapsed) / world / 1e9 / HBM_PEAK_GBS, 5),
             'roofline': roofline,
+            'mfma': {'flops_per_step': flops_step, 'achieved': round(flops_step * (fps / (world * B)) / 1e12, 2), 'peak': mfma_peak, 'unit': 'TFLOP/s',
+                     'frac': round(flops_step * (fps / (world * B)) / 1e12 / mfma_peak, 5),
+                     'note': '2 x MACs of the dense launches (1x1 / dense convs, linears, attention products) x steps/s per GPU; depthwise convs, the deformable gather and element-wise work are not MFMA work and are excluded'},
         }
         if args.ops_json:
-            rows = [{'op': n, 'ms': round(ms, 5), 'bytes': b, 'flops': f} for (n, b, f), ms in zip(table, prof)]
+            rows = [dict(o, ms=round(ms, 5)) for o, ms in zip(full, prof)]
             os.makedirs(os.path.dirname(os.path.abspath(args.ops_json)), exist_ok=True)
             json.dump({'config': args.config, 'dtype': args.dtype, 'batch': B, 'ops': rows}, open(args.ops_json, 'w'), indent=0)
 
         if world == 1 and not args.no_cpu_baseline:
-            from oracle.achelous_oracle import AchelousOracle
-            n = max(1, min(args.cpu_sample, B))
-            orc = AchelousOracle({k: v.detach().cpu() for k, v in model.state_dict().items()}, **dict(COMMON, **kw))
-            cx, cr, cp = x[:n].float().cpu(), xr[:n].float().cpu(), xp[:n].float().cpu()
-            cores = torch.get_num_threads()
-            orc.forward(cx[:1], cr[:1], cp[:1])
-            c0 = time.perf_counter()
-            reps = 0
-            while reps < 1 or (time.perf_counter() - c0 < 10.0 and reps < 8):
-                orc.forward(cx, cr, cp)
-                reps += 1
-            cdt = (time.perf_counter() - c0) / reps
-            result['cpu_baseline'] = {'value': round(n / cdt, 3), 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
-                                      'sample': f'{reps} x oracle fp32 forward (torch CPU ops, {cores} threads) on {n} of the {B} frames; '
-                                                f'radar branch uses the oracle\'s gather-based deform_conv2d restatement'}
+            result['cpu_baseline'] = cpu_baseline(model, dict(COMMON, **kw), x, xr, xp, args.cpu_sample)
         else:
             result['cpu_baseline'] = None
         print(json.dumps(result), flush=True)

@@ -167,6 +167,10 @@ int ach_set_probe(ach_handle* h, int op_index);          /* -1 disables */
 /* micro-benchmark of the MFMA GEMM kernel alone on scratch buffers: ms per launch of Y[M,N] = epi(X[M,K] W^T) */
 int ach_bench_gemm(ach_handle* h, int M, int K, int N, int act, int ln, int residual, int P, int iters, void* stream, float* ms);
 int ach_read_probe(ach_handle* h, float* avg_ms, int* samples);
+/* second probe form: events before launch `first` and after launch `last` of the plan (both on the same stream: a run of the
+ * caller's stream such as the neck + decoder sub-path), slot 0 or 1 (ach_set_probe uses slot 0); first = -1 disables */
+int ach_set_probe_range(ach_handle* h, int slot, int first, int last);
+int ach_read_probe_slot(ach_handle* h, int slot, float* avg_ms, int* samples);
 
 #ifdef __cplusplus
 }
