@@ -85,9 +85,10 @@ def cpu_baseline(model, ctor, x, xr, xp, sample):
             if best is None or fps_ > best[0]:
                 best = (fps_, th, reps)
         return best, tried
-    opts = sorted({min(cores, t) for t in (8, 16, 32, 64, cores)})
+    # (more threads than ~32 only oversubscribe these small per-layer tensors: measured 7.8 frames/s at 16 threads, 3.6 at 64, 0.04 at 256)
+    opts = sorted({min(cores, t) for t in (8, 16, 32)})
     b1, tried1 = leg(1, opts, 1.5)
-    bn, triedn = leg(n, [t for t in opts if t >= 16] or opts, 4.0)
+    bn, triedn = leg(n, opts, 4.0)
     torch.set_num_threads(prev)
     return {'value': round(bn[0], 3), 'unit': 'frames/s', 'cores': bn[1], 'kind': 'port',
             'sample': f'oracle (our fp32 CPU port, torch CPU ops) on {n} of the batch frames, {bn[2]} passes at {bn[1]} threads (best of {triedn}); '
