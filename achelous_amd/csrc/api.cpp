@@ -86,6 +86,7 @@ int ach_set_option(ach_handle* h, const char* key, int32_t value) {
         else if (std::string(key) == "head_stream") h->eng->head_stream = value != 0;
         else if (std::string(key) == "split_decoders") h->eng->split_decoders = value;
         else if (std::string(key) == "radar_start") h->eng->radar_start = value;
+        else if (std::string(key) == "pipeline") h->eng->pipeline = value != 0;
         else throw ach::AchError{ACH_ERR_INVALID, std::string("unknown option: ") + key};
     });
 }
@@ -135,6 +136,9 @@ int ach_forward_detect(ach_handle* h, const void* image, const void* radar, cons
         if (err != hipSuccess) throw ach::AchError{ACH_ERR_DEVICE, std::string("kernel launch: ") + hipGetErrorString(err)};
     });
 }
+
+int ach_join(ach_handle* h, void* stream) { return guarded(h, [&] { h->eng->join(static_cast<hipStream_t>(stream)); }); }
+int ach_forwards_in_flight(const ach_handle* h) { return (h && h->eng) ? int(h->eng->forwards_in_flight()) : 0; }
 
 int ach_decode(ach_handle* h, int32_t batch, const void* det3, const void* det4, const void* det5, float* decoded, void* stream) {
     return guarded(h, [&] {

@@ -37,6 +37,7 @@ EngineBase::~EngineBase() {
         for (int k = 0; k < kSideStreams; ++k) { (void)hipStreamDestroy(side_stream[k]); (void)hipEventDestroy(ev_end[k]); }
         (void)hipEventDestroy(ev_fork);
         for (int k = 0; k < kJoinEvents; ++k) (void)hipEventDestroy(ev_join[k]);
+        for (int q = 0; q < 2; ++q) { (void)hipEventDestroy(ev_x[q]); for (int k = 0; k < kSideStreams; ++k) (void)hipEventDestroy(ev_done[k][q]); }
     }
     for (auto& pr : probes) { for (auto e : pr.ev0) (void)hipEventDestroy(e); for (auto e : pr.ev1) (void)hipEventDestroy(e); }
 }
@@ -102,14 +103,37 @@ void EngineBase::ensure_streams() {
     }
     ACH_HIP_CHECK(hipEventCreate(&ev_fork));
     for (int k = 0; k < kJoinEvents; ++k) ACH_HIP_CHECK(hipEventCreate(&ev_join[k]));
+    for (int q = 0; q < 2; ++q) {
+        ACH_HIP_CHECK(hipEventCreate(&ev_x[q]));
+        for (int k = 0; k < kSideStreams; ++k) ACH_HIP_CHECK(hipEventCreate(&ev_done[k][q]));
+    }
     streams_ready = true;
 }
 // The radar and point branches do not depend on the image path until the fusion stage, and most of their kernels are
 // latency-bound on small maps: they run on two engine-owned side streams, forked from and joined back into the caller's
 // stream with events, so their launches fill the CUs the image path leaves idle.
+//
+// Pipelined mode (option "pipeline"): the end-of-forward join is left to join(), so that the caller can enqueue forward k+1 before
+// forward k's side streams have finished — the caller's stream is free after the neck and starts the next backbone while stream 2
+// still runs forward k's decoders, fusion, head, decode and NMS.  Buffers are NOT double-buffered; the two places where forward k+1
+// overwrites something forward k's stream 2 still reads are ordered by a cross-forward event instead: the FPN outputs / attention
+// maps (written by the neck on the caller's stream) and the radar pyramid (written by stream 1) are last read by the fusion launch
+// of forward k (`xsignal`), and the first neck launch / first radar launch of forward k+1 (`xwait`) wait for it.  Everything else a
+// stream rewrites is only read by itself (in order) or by launches that the in-forward join events already order.
+// At most two forwards may be un-joined: the third call joins the oldest on its own stream first.
+void EngineBase::join(hipStream_t s) {
+    if (joined >= issued) return;
+    const int q = int(joined & 1);
+    for (int k = 0; k < kSideStreams; ++k) if (done_used[q][k]) (void)hipStreamWaitEvent(s, ev_done[k][q], 0);
+    ++joined;
+}
 void EngineBase::run_eager(hipStream_t s) {
     bool used[kSideStreams] = {false, false, false};
     const bool multi = multi_stream;
+    const bool piped = pipeline && multi;
+    if (piped) { ensure_streams(); while (issued - joined >= 2) join(s); }
+    else while (joined < issued) join(s);                        // a plain forward after pipelined ones: drain them first
+    const int par = int(issued & 1);
     if (multi) {
         ensure_streams();
         (void)hipEventRecord(ev_fork, s);
@@ -125,13 +149,18 @@ void EngineBase::run_eager(hipStream_t s) {
         if (multi && op.stream > 0) { st = side_stream[op.stream - 1]; used[op.stream - 1] = true; }
         if (multi && op.wait_ev >= 0) (void)hipStreamWaitEvent(st, ev_join[op.wait_ev], 0);
         if (multi && op.wait_ev2 >= 0) (void)hipStreamWaitEvent(st, ev_join[op.wait_ev2], 0);
+        if (piped && op.xwait && issued > 0) (void)hipStreamWaitEvent(st, ev_x[par ^ 1], 0);
         for (auto& pr : probes) if (int(i) == pr.first) (void)hipEventRecord(pr.ev0[size_t(pr.count % kProbeEvents)], st);
         op.fn(st);
         for (auto& pr : probes) if (int(i) == pr.last) { (void)hipEventRecord(pr.ev1[size_t(pr.count % kProbeEvents)], st); ++pr.count; }
         if (multi && op.signal_ev >= 0) (void)hipEventRecord(ev_join[op.signal_ev], st);
+        if (piped && op.xsignal) (void)hipEventRecord(ev_x[par], st);
     }
     if (detect_tail) detect_tail((multi && detect_stream > 0 && used[detect_stream - 1]) ? side_stream[detect_stream - 1] : s);   // det maps are final on that stream
-    if (multi)
+    if (piped) {
+        for (int k = 0; k < kSideStreams; ++k) { done_used[par][k] = used[k]; if (used[k]) (void)hipEventRecord(ev_done[k][par], side_stream[k]); }
+        ++issued;
+    } else if (multi)
         for (int k = 0; k < kSideStreams; ++k)
             if (used[k]) { (void)hipEventRecord(ev_end[k], side_stream[k]); (void)hipStreamWaitEvent(s, ev_end[k], 0); }
 }
@@ -151,7 +180,7 @@ void EngineBase::drop_graphs() {
 // and replayed with one hipGraphLaunch on the caller's stream.  Capture happens on an engine-owned stream (the caller's may be
 // the legacy default stream, which cannot be captured).  Any failure falls back to eager launches of the SAME kernels.
 void EngineBase::run(hipStream_t s) {
-    if (!use_graph || graph_failed || probing()) { run_eager(s); return; }
+    if (!use_graph || graph_failed || probing() || pipeline) { run_eager(s); return; }
     for (auto& g : graphs)
         if (same_io(g.io, io)) {
             g.stamp = ++graph_clock;

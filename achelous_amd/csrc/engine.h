@@ -42,6 +42,9 @@ struct Op {
     int stream = 0;               // 0: caller's stream (image path) ; 1, 2: engine-owned side streams (radar / point branches)
     int wait_ev = -1, wait_ev2 = -1;   // join: wait for these events before the launch
     int signal_ev = -1;           // record this event after the launch
+    bool xwait = false;           // pipelined forwards: first launch of its stream to overwrite buffers that the PREVIOUS forward's
+                                  //   detection stream still reads -> waits for that forward's `xsignal` launch
+    bool xsignal = false;         // pipelined forwards: last launch that reads buffers another stream rewrites in the next forward
 };
 
 struct IoPtrs {
@@ -76,6 +79,10 @@ public:
                                       // neck is done
     int side_low_priority = 3;        // option "side_priority" (with head_stream = 0): bit k set = side stream k+1 is created at the
                                       // lowest stream priority
+    bool pipeline = false;            // option "pipeline": consecutive forwards overlap.  The segmentation decoders move from the caller's stream
+                                      // to side stream 2 (ahead of fusion + head), the caller's stream is done after the neck, and NOTHING is
+                                      // joined at the end of ach_forward: the caller enqueues the next forward first and then calls ach_join
+                                      // (at most two forwards in flight; see run_eager).  Results are identical; only the schedule differs.
     int radar_start = 1;              // option "radar_start" (default 1, measured +1 %, the block-0 front kernel 0.58 -> 0.38 ms in-step): -1 = the radar branch starts with the forward; k = 0..2: only once backbone stage k is done
                                       // (event 0), with the point branch ahead of it on the same stream — the first RCBlocks are
                                       // throughput-bound like backbone stages 0 / 1 and halve each other's speed when they overlap
@@ -97,6 +104,8 @@ public:
     virtual void plan(int B) = 0;
     void run(hipStream_t s);            // graph replay when possible, else eager launches
     void run_eager(hipStream_t s);
+    void join(hipStream_t s);           // pipelined mode: `s` waits for the oldest forward that has not been joined yet (no-op when none)
+    long forwards_in_flight() const { return issued - joined; }
     // transient: extra launches enqueued behind the last op of the detection branch (stream 1) by ach_forward_detect
     std::function<void(hipStream_t)> detect_tail;
     void run_profiled(hipStream_t s, float* op_ms, size_t cap);
@@ -134,6 +143,7 @@ protected:
         op.stream = cur_stream;
         op.wait_ev = pending_wait; op.wait_ev2 = pending_wait2;
         pending_wait = -1; pending_wait2 = -1;
+        op.xwait = pending_xwait; pending_xwait = false;
         ops.push_back(std::move(op));
     }
     // branch bookkeeping while the plan is built
@@ -147,6 +157,13 @@ protected:
     hipEvent_t ev_fork = nullptr, ev_join[kJoinEvents] = {nullptr, nullptr, nullptr, nullptr}, ev_end[kSideStreams] = {nullptr, nullptr, nullptr};
     bool streams_ready = false;
     void ensure_streams();
+    // pipelined mode: two alternating event sets (forward k uses set k & 1)
+    hipEvent_t ev_x[2] = {nullptr, nullptr}, ev_done[kSideStreams][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
+    bool done_used[2][kSideStreams] = {{false, false, false}, {false, false, false}};
+    long issued = 0, joined = 0;
+    void mark_xwait_next() { pending_xwait = true; }
+    void mark_xsignal_last() { if (!measuring && !ops.empty()) ops.back().xsignal = true; }
+    bool pending_xwait = false;
 #if !defined(ACH_HOSTEMU)
     struct GraphEntry { IoPtrs io; hipGraphExec_t exec; unsigned long stamp; };
     std::vector<GraphEntry> graphs;
@@ -155,10 +172,10 @@ protected:
     bool graph_failed = false;
     void drop_graphs();
 #endif
-    static constexpr int kProbeEvents = 512, kProbeSlots = 2;
+    static constexpr int kProbeEvents = 512, kProbeSlots = 3;
     struct Probe { int first = -1, last = -1; std::vector<hipEvent_t> ev0, ev1; long count = 0; };
     Probe probes[kProbeSlots];
-    bool probing() const { return probes[0].first >= 0 || probes[1].first >= 0; }
+    bool probing() const { for (const auto& pr : probes) if (pr.first >= 0) return true; return false; }
     void add_tap(const std::string& name, const TapInfo& t) { if (!measuring) { if (!taps.count(name)) tap_order.push_back(name); taps[name] = t; } }
     void reset_plan();
 };

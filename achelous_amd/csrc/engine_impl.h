@@ -870,6 +870,7 @@ public:
         const int c_ = w[3] / 2;
         if (c_ % 4) throw AchError{ACH_ERR_UNSUPPORTED, "SPP hidden width must be a multiple of 4"};
         A cat5 = alloc(m5.B, m5.H, m5.W, 4 * c_);
+        mark_xwait_next();               // pipelined forwards: the neck rewrites what the previous forward's stream 2 reads (engine.cpp)
         { GemmOpt o; o.act = ACT_SILU; gemm(f + ".spp.cv1", m5, pack(conv_bn(f + ".spp.cv1.conv", f + ".spp.cv1.bn", 1e-3)), cat5.slice(0, c_), o); }
         {
             const int hw = m5.H * m5.W, cq = c_ / 4;
@@ -907,6 +908,8 @@ public:
         void** outs[2] = {&io.lane, &io.se};
         A ysa[2];
         shuffle_attention_pair(f + "." + sa[0], f + "." + sa[1], p3, ysa[0], ysa[1]);
+        const bool piped = pipeline && multi_stream && !split_dec;
+        if (piped) { signal_after_last(2); cur_stream = 2; wait_before_next(2); }     // both decoders leave the caller's stream
         if (split_dec) signal_after_last(2);   // the semantic decoder may start on its own stream
         for (int d = 0; d < 2; ++d) {
             // past the shared attention stage the two decoders are independent: water-line decoder on the caller's stream, semantic
@@ -1013,6 +1016,7 @@ public:
         {
             ToNhwcParams tp{nullptr, x.p, B, 3, R, R, x.ld};
             const void** rin = &io.radar;
+            mark_xwait_next();           // pipelined forwards: this branch rewrites the radar pyramid the previous forward's fusion reads
             const double bytes = double(x.rows()) * (3 + 3) * sizeof(T), lbytes = double(x.rows()) * (3 + x.ld) * sizeof(T);
             if (narrow0) {
                 const dim3 grid(unsigned(cdivl(x.rows() / 4, 256))), block(256);
@@ -1168,6 +1172,7 @@ public:
         {
             const dim3 grid(unsigned(cdivl(fuse_max, 256)), unsigned(n)), block(256);
             add_op(e + ".fusion.apply", [mf, grid, block](hipStream_t s) { ACH_LAUNCH(fuse_scale_multi_kernel<T>, grid, block, s, mf); }, bytes);
+            mark_xsignal_last();         // last reader of the FPN outputs / radar pyramid (and, in stream order, after the decoders' reads)
         }
     }
 

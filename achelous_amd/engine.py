@@ -34,7 +34,7 @@ class AchTensorDesc(ctypes.Structure):
 class NativeLibrary:
     """dlopen + prototypes for every symbol declared in include/achelous.h."""
     SYMBOLS = ('ach_create', 'ach_destroy', 'ach_last_error', 'ach_load_weights', 'ach_plan', 'ach_arena_bytes',
-               'ach_forward', 'ach_forward_detect', 'ach_decode', 'ach_nms_workspace_bytes', 'ach_nms', 'ach_tap_count', 'ach_tap_name',
+               'ach_forward', 'ach_forward_detect', 'ach_join', 'ach_forwards_in_flight', 'ach_decode', 'ach_nms_workspace_bytes', 'ach_nms', 'ach_tap_count', 'ach_tap_name',
                'ach_tap_shape', 'ach_read_tap', 'ach_plan_launches', 'ach_op_name', 'ach_op_bytes', 'ach_op_layout_bytes', 'ach_op_flops', 'ach_op_stream',
                'ach_forward_profiled', 'ach_set_probe', 'ach_read_probe', 'ach_set_probe_range', 'ach_read_probe_slot', 'ach_bench_gemm', 'ach_set_option', 'ach_preprocess_radar',
                'ach_normalize_points', 'ach_preprocess_image', 'ach_seg_argmax')
@@ -64,6 +64,10 @@ class NativeLibrary:
         L.ach_forward.restype = ctypes.c_int
         L.ach_forward_detect.argtypes = [vp] + [vp] * 9 + [vp, f32, f32, i32, vp, vp, vp, vp, vp]
         L.ach_forward_detect.restype = ctypes.c_int
+        L.ach_join.argtypes = [vp, vp]
+        L.ach_join.restype = ctypes.c_int
+        L.ach_forwards_in_flight.argtypes = [vp]
+        L.ach_forwards_in_flight.restype = ctypes.c_int
         L.ach_decode.argtypes = [vp, i32, vp, vp, vp, vp, vp]
         L.ach_decode.restype = ctypes.c_int
         L.ach_nms_workspace_bytes.argtypes = [vp, i32]
@@ -206,6 +210,13 @@ class NativeEngine:
         self._check(self.L.ach_forward_detect(self.h, _ptr(image), _ptr(radar), _ptr(points), _ptr(det3), _ptr(det4), _ptr(det5),
                                               _ptr(se), _ptr(lane), _ptr(pc), _ptr(decoded), float(conf), float(iou), int(max_det),
                                               _ptr(rows), _ptr(idx), _ptr(count), _ptr(workspace), ctypes.c_void_p(stream)))
+
+    def join(self, stream=0):
+        """Pipelined mode: make `stream` wait for the oldest forward that has not been joined yet."""
+        self._check(self.L.ach_join(self.h, ctypes.c_void_p(stream)))
+
+    def forwards_in_flight(self):
+        return int(self.L.ach_forwards_in_flight(self.h))
 
     def op_table(self):
         """[(name, algorithmic bytes, flops)] of every launch in the plan."""

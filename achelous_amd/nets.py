@@ -35,6 +35,38 @@ def _build_tree(root, spec):
             mod.register_buffer(leaf, torch.zeros(shape, dtype=torch.long))
 
 
+class PendingForward:
+    """A forward submitted in pipelined mode.  Holds the tensors the engine's side streams still use (inputs, scratch, outputs) so
+    that the caching allocator cannot hand their memory to anyone else before `wait()` has ordered the current stream after them."""
+    _order = {}                                    # engine id -> [submitted, waited]: forwards are joined oldest first
+
+    def __init__(self, eng, device, keep, result):
+        self._eng, self._device, self._keep, self._result = eng, device, keep, result
+        c = PendingForward._order.setdefault(id(eng), [0, 0])
+        c[0] += 1
+        self._ticket = c[0]
+
+    def wait(self):
+        """Makes the CURRENT stream wait for this forward (and any older un-waited one); returns its outputs."""
+        if self._eng is not None:
+            c = PendingForward._order[id(self._eng)]
+            s = torch.cuda.current_stream(self._device).cuda_stream
+            with torch.cuda.device(self._device):
+                while c[1] < self._ticket:
+                    if self._eng.forwards_in_flight() > 0:
+                        self._eng.join(s)
+                    c[1] += 1
+            self._eng, self._keep = None, None
+        return self._result()
+
+    def __del__(self):
+        try:
+            if self._eng is not None:
+                self.wait()
+        except Exception:
+            pass
+
+
 class Achelous(nn.Module):
     def __init__(self, num_det, num_seg, phi='S0', image_channels=3, radar_channels=3, resolution=416,
                  backbone='ef', neck='gdf', pc_seg='pn', pc_channels=6, pc_classes=9, nano_head=False, spp=True):
@@ -122,18 +154,19 @@ class Achelous(nn.Module):
         code = _eng.DTYPE_BF16 if dtype == torch.bfloat16 else _eng.DTYPE_F32
         dev = torch.cuda.current_device() if device is None else torch.device(device).index
         hits = [v[0] for k, v in self._engines.items() if k[:2] == (dev, code)]
+        hits.sort(key=lambda e: getattr(e, '_last_use', 0))
         if not hits:
             raise KeyError(f"no forward has run yet for dtype {dtype} on device {dev}")
         return hits[-1]
 
-    def _engine_for(self, device, dtype, batch, num_points):
+    def _engine_for(self, device, dtype, batch, num_points, pipelined=False):
         if dtype == torch.float32:
             code = _eng.DTYPE_F32
         elif dtype == torch.bfloat16:
             code = _eng.DTYPE_BF16
         else:
             raise TypeError(f"Achelous forward supports float32 and bfloat16 inputs, got {dtype}")
-        key = (device.index, code, num_points)          # one engine per point-count bucket: a new N never evicts another's plan
+        key = (device.index, code, num_points, bool(pipelined))   # one engine per point-count bucket (and schedule): a new N never evicts another's plan
         ent = self._engines.get(key)
         ver = ent[1] if (self.static_weights and ent is not None and ent[1] is not None) else self._weights_version()
         if ent is None:
@@ -144,6 +177,8 @@ class Achelous(nn.Module):
             eng.set_option('full_taps', 1 if self.debug_taps else 0)
             for k, v in self.engine_options.items():
                 eng.set_option(k, int(v))
+            if pipelined:
+                eng.set_option('pipeline', 1)
             ent = [eng, None]
             self._engines[key] = ent
         if ent[1] != ver:
@@ -151,6 +186,7 @@ class Achelous(nn.Module):
             ent[1] = ver
         if ent[0].batch != batch:
             ent[0].plan(batch)
+        self.__dict__['_use_clock'] = ent[0]._last_use = self.__dict__.get('_use_clock', 0) + 1
         return ent[0]
 
     def forward(self, x, x_radar, x_point_clouds):
@@ -164,7 +200,17 @@ class Achelous(nn.Module):
         enqueued behind the detection head on its own stream, so they overlap with the segmentation decoders."""
         return self._run(x, x_radar, x_point_clouds, (float(conf_thres), float(nms_thres), max_det))
 
-    def _run(self, x, x_radar, x_point_clouds, detect):
+    def submit(self, x, x_radar, x_point_clouds):
+        """Pipelined serving form of forward(): returns a PendingForward at once; `.wait()` returns forward()'s outputs.  Submit the
+        NEXT batch before waiting for this one — the engine then overlaps this batch's decoders / detection branch with the next
+        batch's backbone (include/achelous.h, ach_join).  At most two submissions may be un-waited."""
+        return self._run(x, x_radar, x_point_clouds, None, pipelined=True)
+
+    def submit_detect(self, x, x_radar, x_point_clouds, conf_thres=0.5, nms_thres=0.4, max_det=None):
+        """Pipelined form of forward_detect()."""
+        return self._run(x, x_radar, x_point_clouds, (float(conf_thres), float(nms_thres), max_det), pipelined=True)
+
+    def _run(self, x, x_radar, x_point_clouds, detect, pipelined=False):
         if self.training:
             raise NotImplementedError("achelous_amd.Achelous runs eval-mode inference only; call .eval() first")
         if not (x.is_cuda and x_radar.is_cuda and x_point_clouds.is_cuda):
@@ -181,7 +227,7 @@ class Achelous(nn.Module):
         # and groups by index and takes multiples of 128 only.
         N = n_in if self.pc_seg_kind == 'pn2' else -(-n_in // 16) * 16
         with torch.cuda.device(dev):
-            eng = self._engine_for(dev, dt, B, N)
+            eng = self._engine_for(dev, dt, B, N, pipelined)
             x, x_radar, pts = x.contiguous(), x_radar.to(dt).contiguous(), x_point_clouds.to(dt)
             if N != n_in:
                 pts = torch.cat([pts, pts[:, :, -1:].expand(-1, -1, N - n_in)], dim=2)
@@ -194,6 +240,8 @@ class Achelous(nn.Module):
             stream = torch.cuda.current_stream(dev).cuda_stream
             if detect is None:
                 eng.forward(x, x_radar, pts, (det[0], det[1], det[2], se, lane, pc), stream)
+                if pipelined:
+                    return PendingForward(eng, dev, (x, x_radar, pts), lambda: (det, se, lane, pc if N == n_in else pc[:, :n_in].contiguous()))
                 return det, se, lane, (pc if N == n_in else pc[:, :n_in].contiguous())
             conf, iou, max_det = detect
             A = sum((R // s) ** 2 for s in (8, 16, 32))
@@ -211,4 +259,7 @@ class Achelous(nn.Module):
             ws = torch.empty(eng.nms_workspace_bytes(B), dtype=torch.uint8, device=dev)
             eng.forward_detect(x, x_radar, pts, (det[0], det[1], det[2], se, lane, pc), decoded, conf, iou, max_det, rows, idx, cnt, ws, stream)
             # scratch is released to the caching allocator in stream order: the join at the end of the call orders it after the side stream
+        if pipelined:
+            return PendingForward(eng, dev, (x, x_radar, pts, decoded, ws),
+                                  lambda: ((det, se, lane, pc if N == n_in else pc[:, :n_in].contiguous()), (rows, idx, cnt)))
         return (det, se, lane, pc if N == n_in else pc[:, :n_in].contiguous()), (rows, idx, cnt)

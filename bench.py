@@ -110,6 +110,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=8, help='frames in the CPU-baseline sample')
     ap.add_argument('--separate-calls', action='store_true', help='forward, decode_outputs and NMS as three calls instead of forward_detect')
+    ap.add_argument('--no-pipeline', action='store_true', help='plain forward_detect per step (every step joined before the next is enqueued) instead of submit / wait')
     ap.add_argument('--extra-stream', action='store_true', help='diagnostic: also launch a tiny copy on a separate stream every step (stands in for a collective stream)')
     ap.add_argument('--opt', action='append', default=[], help='engine option key=value (ach_set_option), repeatable')
     ap.add_argument('--force-collective', action='store_true', help='diagnostic: run the RCCL all-gather of the detection records even at world size 1')
@@ -148,11 +149,25 @@ def main():
     x, xr, xp = make_inputs(B, config_seed(cid) + 1000 * rank, resolution=COMMON['resolution'], pc_channels=COMMON['pc_channels'])
     x, xr, xp = x.to(dev, tdt), xr.to(dev, tdt), xp.to(dev, tdt)
     gathered = [torch.empty(world * B * (args.max_det * 8 + 1), dtype=torch.int32, device=dev) for _ in range(2)] if collective else None
-    state = {'k': 0, 'pending': None}
+    state = {'k': 0, 'pending': None, 'inflight': None, 'last': None}
     ishape = [COMMON['resolution']] * 2
 
     extra = torch.cuda.Stream(dev) if args.extra_stream else None
     scratch = torch.zeros(1024, device=dev) if args.extra_stream else None
+
+    pipelined = not (args.no_pipeline or args.separate_calls)
+
+    def finish(res):
+        (det, se, lane, pc), (rows, idx, cnt) = res
+        if collective:
+            # pipelined: this step's gather runs on RCCL's stream under the next step's forward; its result is waited for one
+            # step late (alternating receive buffers).  fence() waits for the last one, so all K gathers finish inside the timing.
+            nxt = all_gather_detections_async(rows, idx, cnt, out=gathered[state['k'] & 1], force=args.force_collective)
+            state['k'] += 1
+            if state['pending'] is not None:
+                state['pending'].wait()
+            state['pending'] = nxt
+        state['last'] = (det, se, lane, pc, cnt)
 
     def step():
         if extra is not None:
@@ -163,20 +178,22 @@ def main():
         if args.separate_calls:
             det, se, lane, pc = model(x, xr, xp)
             dec = decode_outputs(det, ishape)
-            rows, idx, cnt = nms_device(dec, COMMON['num_det'], args.conf, args.iou, args.max_det)
-        else:                              # same three stages as one engine call (decode + NMS overlap the segmentation decoders)
-            (det, se, lane, pc), (rows, idx, cnt) = model.forward_detect(x, xr, xp, args.conf, args.iou, args.max_det)
-        if collective:
-            # pipelined: this step's gather runs on RCCL's stream under the next step's forward; its result is waited for one
-            # step late (alternating receive buffers).  fence() waits for the last one, so all K gathers finish inside the timing.
-            nxt = all_gather_detections_async(rows, idx, cnt, out=gathered[state['k'] & 1], force=args.force_collective)
-            state['k'] += 1
-            if state['pending'] is not None:
-                state['pending'].wait()
-            state['pending'] = nxt
-        return det, se, lane, pc, cnt
+            finish(((det, se, lane, pc), nms_device(dec, COMMON['num_det'], args.conf, args.iou, args.max_det)))
+        elif not pipelined:                # the three stages as one engine call (decode + NMS overlap the segmentation decoders)
+            finish(model.forward_detect(x, xr, xp, args.conf, args.iou, args.max_det))
+        else:
+            # serving loop: batch k+1 is enqueued BEFORE batch k is waited for, so the engine overlaps batch k's decoders and
+            # detection branch with batch k+1's backbone (Achelous.submit_detect; fence() drains the last one inside the timing)
+            nxt = model.submit_detect(x, xr, xp, args.conf, args.iou, args.max_det)
+            if state['inflight'] is not None:
+                finish(state['inflight'].wait())
+            state['inflight'] = nxt
+        return state['last']
 
     def fence():
+        if state['inflight'] is not None:
+            finish(state['inflight'].wait())
+            state['inflight'] = None
         if state['pending'] is not None:
             state['pending'].wait()
             state['pending'] = None
@@ -187,8 +204,9 @@ def main():
 
     with torch.no_grad():
         for _ in range(max(args.warmup, 1)):
-            out = step()
-        torch.cuda.synchronize(dev)
+            step()
+        fence()
+        out = state['last']
         eng = model.native_engine(tdt, dev)
         stream = torch.cuda.current_stream(dev).cuda_stream
         # one pass with every launch bracketed by HIP events: find the dominant kernel of the plan
@@ -198,13 +216,19 @@ def main():
         table = [(o['op'], o['bytes'], o['flops']) for o in full]
         dom = max(range(len(prof)), key=lambda i: prof[i])
         eng.set_probe(dom)
-        # the north-star sub-path: neck (SPP .. FPN outputs) + ShuffleAttention + both decoders = one run of the caller's stream
-        sub_first = next((i for i, o in enumerate(full) if o['op'].endswith('.fpn.spp.cv1')), None)
-        sub_last = max((i for i, o in enumerate(full) if o['stream'] == 0 and '_seg_head' in o['op']), default=None)
-        sub_ops = []
-        if sub_first is not None and sub_last is not None and full[sub_first]['stream'] == 0:
-            sub_ops = [i for i in range(sub_first, sub_last + 1) if full[i]['stream'] == 0]
-            eng.set_probe_range(1, sub_first, sub_last)
+        # the north-star sub-path: neck (SPP .. FPN outputs) + ShuffleAttention + both decoders.  One contiguous run of launches per
+        # stream (all on the caller's stream in the plain plan; the decoders on side stream 2 in the pipelined plan): one range probe each
+        sub_ops = [i for i, o in enumerate(full) if '.fpn.' in o['op'] and '.backbone.' not in o['op']]
+        sub_ranges = []
+        for st in sorted({full[i]['stream'] for i in sub_ops}):
+            mine = [i for i in sub_ops if full[i]['stream'] == st]
+            between = [i for i in range(mine[0], mine[-1] + 1) if full[i]['stream'] == st]
+            if between == mine and len(sub_ranges) < 2:                  # contiguous on its stream
+                sub_ranges.append((mine[0], mine[-1]))
+        if len(sub_ranges) != len({full[i]['stream'] for i in sub_ops}):
+            sub_ranges = []
+        for k, (a, b) in enumerate(sub_ranges):
+            eng.set_probe_range(1 + k, a, b)
 
         fence()
         t0 = time.perf_counter()
@@ -213,9 +237,19 @@ def main():
         fence()
         t1 = time.perf_counter()
         probe_ms, probe_n = eng.read_probe()
-        sub_ms, sub_n = eng.read_probe_slot(1) if sub_ops else (0.0, 0)
+        sub_parts = [eng.read_probe_slot(1 + k) for k in range(len(sub_ranges))]
+        sub_ms, sub_n = sum(p[0] for p in sub_parts), min([p[1] for p in sub_parts] or [0])
         eng.set_probe(-1)
-        eng.set_probe_range(1, -1, -1)
+        for k in range(len(sub_ranges)):
+            eng.set_probe_range(1 + k, -1, -1)
+        plain = None
+        if pipelined:                      # the same K steps through the plain call (each step joined before the next is enqueued)
+            fence()
+            p0 = time.perf_counter()
+            for _ in range(args.steps):
+                model.forward_detect(x, xr, xp, args.conf, args.iou, args.max_det)
+            fence()
+            plain = time.perf_counter() - p0
 
         # forward-only rate (same inputs, no decode / NMS / gather), for the report
         fence()
@@ -249,7 +283,7 @@ def main():
                 roofline['traffic'] = json.load(open(traffic_file))['ops'].get(name, {}).get('traffic_bytes')
             except Exception:
                 pass
-        if sub_ops:
+        if sub_ranges:
             # inputs P3/P4/P5 read once + se, lane and the three FPN maps written once (elements per frame)
             comp_elems = {'S0': 1392000, 'S2': 1504000}.get(kw.get('phi'), None)
             sub_bytes = sum(full[i]['bytes'] for i in sub_ops)
@@ -257,7 +291,8 @@ def main():
             comp = comp_elems * esz * B if comp_elems else None
             fr = lambda by, ms: round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if (by and ms > 0) else None
             roofline['subpath'] = {
-                'what': f"{full[sub_first]['op']} .. {full[sub_last]['op']} on the caller's stream (neck + ShuffleAttention + both seg decoders)",
+                'what': f"{full[sub_ops[0]]['op']} .. {full[sub_ops[-1]]['op']}: neck + ShuffleAttention + both seg decoders (in-step = sum of the live range "
+                        f"probes of its {len(sub_ranges)} stream run(s))",
                 'launches': len(sub_ops), 'in_step_ms': round(sub_ms, 5), 'steps_timed': sub_n, 'isolated_ms': round(sub_iso, 5),
                 'compulsory_bytes': comp, 'launch_bytes': sub_bytes,
                 'frac_compulsory_in_step': fr(comp, sub_ms), 'frac_compulsory_isolated': fr(comp, sub_iso),
@@ -276,6 +311,8 @@ def main():
                        'global_batch': world * B, 'parallelism': f'batch-sharded x{world}' + (' + RCCL all-gather of detections' if world > 1 else ''),
                        'launches_per_forward': len(table)},
             'forward_only_fps': round(frames / fwd_elapsed, 2),
+            'schedule': 'pipelined submit/wait (batch k+1 enqueued before batch k is joined)' if pipelined else 'plain (every step joined before the next)',
+            'plain_forward_detect_fps': round(B * args.steps / plain, 2) if plain else None,
             'compulsory_hbm_frac': round(algo_bytes_frame * (frames / fwd_elapsed) / world / 1e9 / HBM_PEAK_GBS, 5),
             'roofline': roofline,
             'mfma': {'flops_per_step': flops_step, 'achieved': round(flops_step * (fps / (world * B)) / 1e12, 2), 'peak': mfma_peak, 'unit': 'TFLOP/s',

@@ -123,6 +123,15 @@ int ach_forward_detect(ach_handle* h, const void* image, const void* radar, cons
                        float* decoded, float conf_thres, float nms_thres, int32_t max_det,
                        float* out_rows, int32_t* out_idx, int32_t* out_count, void* workspace, void* stream);
 
+/* Pipelined serving (ach_set_option(h, "pipeline", 1) before ach_plan): ach_forward / ach_forward_detect return with the work of
+ * the engine's side streams NOT yet joined into `stream`, so that the caller can enqueue the next forward first; ach_join makes
+ * `stream` wait for the oldest un-joined forward (its outputs are complete in stream order after that).  At most two forwards may
+ * be un-joined (a third call joins the oldest itself); inputs, outputs and the detect workspace of a forward must stay allocated
+ * and untouched until it has been joined.  Results are bit-identical to the plain mode.  The reference's counterpart is the
+ * python loop around `net(...)` in achelous.py:246-262 / utils/callbacks.py:184, which serialises frames. */
+int ach_join(ach_handle* h, void* stream);
+int ach_forwards_in_flight(const ach_handle* h);
+
 /* det maps (config dtype) -> decoded [B, A, 5+num_det] fp32, A = (R/8)^2 + (R/16)^2 + (R/32)^2 */
 int ach_decode(ach_handle* h, int32_t batch, const void* det3, const void* det4, const void* det5,
                float* decoded, void* stream);
@@ -168,7 +177,7 @@ int ach_set_probe(ach_handle* h, int op_index);          /* -1 disables */
 int ach_bench_gemm(ach_handle* h, int M, int K, int N, int act, int ln, int residual, int P, int iters, void* stream, float* ms);
 int ach_read_probe(ach_handle* h, float* avg_ms, int* samples);
 /* second probe form: events before launch `first` and after launch `last` of the plan (both on the same stream: a run of the
- * caller's stream such as the neck + decoder sub-path), slot 0 or 1 (ach_set_probe uses slot 0); first = -1 disables */
+ * caller's stream such as the neck + decoder sub-path), slot 0, 1 or 2 (ach_set_probe uses slot 0); first = -1 disables */
 int ach_set_probe_range(ach_handle* h, int slot, int first, int last);
 int ach_read_probe_slot(ach_handle* h, int slot, float* avg_ms, int* samples);
 

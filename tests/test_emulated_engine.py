@@ -233,3 +233,40 @@ def test_emulated_nms_degenerate_candidates():
             keep = ind.batched_nms(boxes, score[sel], cid[sel].astype(np.float32), iou)
             assert np.array_equal(sel[keep], exp[b][1]), (conf, iou, b)
         assert int(cnt[1]) == 0 or conf == 0.0
+
+
+def test_emulated_pipelined_forwards_match_plain():
+    """Option "pipeline" (include/achelous.h, ach_join): decoders on side stream 2, no join at the end of ach_forward, cross-forward
+    events.  On the CPU emulation launches are synchronous, so this checks the plumbing: same outputs as the plain plan for three
+    forwards in flight (the third joins the oldest itself), the in-flight counter, and a plain forward after pipelined ones."""
+    kw, sd, _ = _setup('en_s0', 64, 1, 16)
+    plain = make_engine(emu_library(), kw, 1, sd, 16, DTYPE_F32, full_taps=False)
+    from achelous_amd.engine import NativeEngine
+    piped = NativeEngine(emu_library(), num_det=kw['num_det'], num_seg=kw['num_seg'], phi=kw['phi'], backbone=kw['backbone'],
+                         resolution=kw['resolution'], pc_channels=kw['pc_channels'], pc_classes=kw['pc_classes'], num_points=16,
+                         nano_head=kw['nano_head'], spp=kw['spp'], dtype=DTYPE_F32)
+    piped.set_option('pipeline', 1)
+    piped.load_state_dict(sd)
+    piped.plan(1)
+    streams = {o['stream'] for o in piped.op_table_full() if '_seg_head' in o['op']}
+    assert streams == {2}, streams                                   # the decoders left the caller's stream
+    assert {o['stream'] for o in plain.op_table_full() if '_seg_head' in o['op']} == {0}
+    ins = [make_inputs(1, 40 + i, resolution=64, num_points=16, pc_channels=kw['pc_channels'], radar_cells=40) for i in range(3)]
+    want = []
+    for x, xr, xp in ins:
+        o = alloc_outputs(kw, 1, 16, torch.float32, 'cpu')
+        plain.forward(x, xr, xp, o)
+        want.append(o)
+    got = []
+    for i, (x, xr, xp) in enumerate(ins):
+        o = alloc_outputs(kw, 1, 16, torch.float32, 'cpu')
+        piped.forward(x, xr, xp, o)
+        got.append(o)
+        assert piped.forwards_in_flight() == min(i + 1, 2)
+    piped.join()
+    piped.join()
+    piped.join()                                                     # nothing left: no-op
+    assert piped.forwards_in_flight() == 0
+    for a, b in zip(got, want):
+        for u, v in zip(a, b):
+            assert torch.equal(u, v)
