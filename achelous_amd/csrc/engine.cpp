@@ -9,8 +9,10 @@
 #include "engine.h"
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstring>
+#include <mutex>
 
 #include "k_detect.h"
 
@@ -34,7 +36,7 @@ EngineBase::~EngineBase() {
     if (capture_stream) (void)hipStreamDestroy(capture_stream);
 #endif
     if (streams_ready) {
-        for (int k = 0; k < kSideStreams; ++k) { (void)hipStreamDestroy(side_stream[k]); (void)hipEventDestroy(ev_end[k]); }
+        for (int k = 0; k < kSideStreams; ++k) (void)hipEventDestroy(ev_end[k]);          // (the streams belong to the process-wide pool)
         (void)hipEventDestroy(ev_fork);
         for (int k = 0; k < kJoinEvents; ++k) (void)hipEventDestroy(ev_join[k]);
         for (int q = 0; q < 2; ++q) { (void)hipEventDestroy(ev_x[q]); for (int k = 0; k < kSideStreams; ++k) (void)hipEventDestroy(ev_done[k][q]); }
@@ -90,17 +92,35 @@ void EngineBase::reset_plan() {
     ops.clear(); taps.clear(); tap_order.clear();
     warena_used = 0; aarena_used = 0;
 }
+// Side streams are shared by every engine of the process on a device (one set per priority pattern) and live as long as the process:
+// the runtime maps streams onto a handful of hardware queues, and a process with more than four ACTIVE streams loses a quarter of its
+// throughput — a module that holds an fp32 and a bf16 engine, or a plain and a pipelined one, must not multiply them.
+// Sharing is safe: a stream is an in-order queue, and every forward joins (or, pipelined, is joined by its caller) before reuse.
+static std::mutex g_pool_mutex;
+static std::map<std::pair<int, int>, std::array<hipStream_t, 3>> g_stream_pool;
 void EngineBase::ensure_streams() {
     if (streams_ready) return;
-    for (int k = 0; k < kSideStreams; ++k) {
-        // side branches have slack, the caller's stream carries the critical path (backbone -> neck -> decoder): when the option is
-        // on they are created at the lowest priority so that the dispatcher favours the caller's stream under contention
-        int lo = 0, hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        if (((head_stream ? 1 : side_low_priority) >> k) & 1) ACH_HIP_CHECK(hipStreamCreateWithPriority(&side_stream[k], hipStreamNonBlocking, lo));
-        else ACH_HIP_CHECK(hipStreamCreateWithFlags(&side_stream[k], hipStreamNonBlocking));
-        ACH_HIP_CHECK(hipEventCreate(&ev_end[k]));
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const int mask = head_stream ? 1 : side_low_priority;
+        auto it = g_stream_pool.find({dev, mask});
+        if (it == g_stream_pool.end()) {
+            std::array<hipStream_t, 3> st{};
+            // side branches have slack, the caller's stream carries the critical path (backbone -> neck -> decoder): the masked ones
+            // are created at the lowest priority so that the dispatcher favours the caller's stream under contention
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+            for (int k = 0; k < kSideStreams; ++k) {
+                if ((mask >> k) & 1) ACH_HIP_CHECK(hipStreamCreateWithPriority(&st[size_t(k)], hipStreamNonBlocking, lo));
+                else ACH_HIP_CHECK(hipStreamCreateWithFlags(&st[size_t(k)], hipStreamNonBlocking));
+            }
+            it = g_stream_pool.emplace(std::make_pair(dev, mask), st).first;
+        }
+        for (int k = 0; k < kSideStreams; ++k) side_stream[k] = it->second[size_t(k)];
     }
+    for (int k = 0; k < kSideStreams; ++k) ACH_HIP_CHECK(hipEventCreate(&ev_end[k]));
     ACH_HIP_CHECK(hipEventCreate(&ev_fork));
     for (int k = 0; k < kJoinEvents; ++k) ACH_HIP_CHECK(hipEventCreate(&ev_join[k]));
     for (int q = 0; q < 2; ++q) {

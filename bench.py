@@ -110,7 +110,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=8, help='frames in the CPU-baseline sample')
     ap.add_argument('--separate-calls', action='store_true', help='forward, decode_outputs and NMS as three calls instead of forward_detect')
-    ap.add_argument('--no-pipeline', action='store_true', help='plain forward_detect per step (every step joined before the next is enqueued) instead of submit / wait')
+    ap.add_argument('--pipeline', action='store_true', help='submit / wait serving loop (batch k+1 enqueued before batch k is joined; engine option "pipeline") instead of one plain forward_detect per step.  Measured no faster (2.54 vs 2.48 ms): the chip is work-bound, DESIGN 4.10')
     ap.add_argument('--extra-stream', action='store_true', help='diagnostic: also launch a tiny copy on a separate stream every step (stands in for a collective stream)')
     ap.add_argument('--opt', action='append', default=[], help='engine option key=value (ach_set_option), repeatable')
     ap.add_argument('--force-collective', action='store_true', help='diagnostic: run the RCCL all-gather of the detection records even at world size 1')
@@ -155,7 +155,7 @@ def main():
     extra = torch.cuda.Stream(dev) if args.extra_stream else None
     scratch = torch.zeros(1024, device=dev) if args.extra_stream else None
 
-    pipelined = not (args.no_pipeline or args.separate_calls)
+    pipelined = args.pipeline and not args.separate_calls
 
     def finish(res):
         (det, se, lane, pc), (rows, idx, cnt) = res
@@ -234,6 +234,7 @@ def main():
         t0 = time.perf_counter()
         for _ in range(args.steps):
             out = step()
+        th = time.perf_counter()           # the host has enqueued every step; the GPU is (normally) still running
         fence()
         t1 = time.perf_counter()
         probe_ms, probe_n = eng.read_probe()
@@ -310,6 +311,7 @@ def main():
                                    f'512 points, batch {B} per GPU, all 5 heads, seeded random weights',
                        'global_batch': world * B, 'parallelism': f'batch-sharded x{world}' + (' + RCCL all-gather of detections' if world > 1 else ''),
                        'launches_per_forward': len(table)},
+            'host_enqueue_ms_per_step': round((th - t0) / args.steps * 1e3, 4),
             'forward_only_fps': round(frames / fwd_elapsed, 2),
             'schedule': 'pipelined submit/wait (batch k+1 enqueued before batch k is joined)' if pipelined else 'plain (every step joined before the next)',
             'plain_forward_detect_fps': round(B * args.steps / plain, 2) if plain else None,

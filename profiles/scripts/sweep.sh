@@ -11,6 +11,6 @@ for v in "$@"; do
   echo "{\"variant\": \"$v\", \"rep\": $rep, \"result\": $line}" >> gpurun_out/$tag.txt
   python - "$v" "$line" <<'PY'
 import json,sys
-d=json.loads(sys.argv[2]); print(f"{sys.argv[1]!r:40s} {d['value']:9.1f} fps  {d['ms_per_step']:.4f} ms  fwd {d['forward_only_fps']:9.1f}  probe {d['roofline']['kernel'].split('.')[-2:]} {d['roofline']['launch_ms']}")
+d=json.loads(sys.argv[2]); print(f"{sys.argv[1]!r:40s} {d['value']:9.1f} fps  {d['ms_per_step']:.4f} ms  host {d.get('host_enqueue_ms_per_step')}  plain {d.get('plain_forward_detect_fps')}  fwd {d['forward_only_fps']:9.1f}  probe {d['roofline']['kernel'].split('.')[-2:]} {d['roofline']['launch_ms']}")
 PY
 done; done

@@ -136,6 +136,7 @@ typedef void* hipEvent_t;
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return 0; }
 static inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { *s = nullptr; return 0; }
 static inline hipError_t hipDeviceGetStreamPriorityRange(int* lo, int* hi) { *lo = 0; *hi = 0; return 0; }
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return 0; }
 static inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
 static inline hipError_t hipStreamWaitEvent(hipStream_t, void*, unsigned) { return 0; }
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return 0; }
