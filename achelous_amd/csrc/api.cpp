@@ -183,6 +183,22 @@ int ach_seg_argmax(ach_handle* h, int32_t batch, int32_t channels, const void* s
     });
 }
 
+int ach_seg_resize_argmax(ach_handle* h, int32_t batch, int32_t channels, const void* seg, int32_t out_h, int32_t out_w, float* prob_workspace,
+                          uint8_t* out, void* stream) {
+    return guarded(h, [&] {
+        if (batch <= 0 || channels <= 0 || channels > 255 || out_h <= 0 || out_w <= 0 || !seg || !prob_workspace || !out)
+            throw ach::AchError{ACH_ERR_INVALID, "bad seg_resize_argmax arguments"};
+        h->eng->seg_resize_argmax(batch, channels, seg, out_h, out_w, prob_workspace, out, static_cast<hipStream_t>(stream));
+    });
+}
+int ach_correct_boxes(ach_handle* h, int32_t batch, int32_t max_det, const float* rows, const int32_t* count, int32_t image_h, int32_t image_w,
+                      int32_t letterbox, float* out_rows, void* stream) {
+    return guarded(h, [&] {
+        if (batch <= 0 || max_det <= 0 || image_h <= 0 || image_w <= 0 || !rows || !count || !out_rows) throw ach::AchError{ACH_ERR_INVALID, "bad correct_boxes arguments"};
+        h->eng->correct_boxes(batch, max_det, rows, count, image_h, image_w, letterbox, out_rows, static_cast<hipStream_t>(stream));
+    });
+}
+
 int ach_tap_count(const ach_handle* h) { return (h && h->eng) ? int(h->eng->tap_order.size()) : 0; }
 const char* ach_tap_name(const ach_handle* h, int i) {
     if (!h || !h->eng || i < 0 || i >= int(h->eng->tap_order.size())) return nullptr;

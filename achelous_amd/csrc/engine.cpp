@@ -15,6 +15,7 @@
 #include <mutex>
 
 #include "k_detect.h"
+#include "k_prepost.h"
 
 namespace ach {
 
@@ -280,6 +281,11 @@ void EngineBase::nms(int B, const float* decoded, float conf, float iou, int max
     p.rows = rows; p.kept = idx; p.count = count;
     p.B = B; p.A = A; p.NC5 = 5 + cfg.num_det; p.num_classes = cfg.num_det; p.max_det = max_det; p.conf = conf; p.iou = iou;
     ACH_LAUNCH(nms_kernel, dim3(unsigned(B)), dim3(NMS_THREADS), s, p);
+}
+
+void EngineBase::correct_boxes(int B, int max_det, const float* rows, const int* count, int img_h, int img_w, int letterbox, float* out, hipStream_t s) {
+    BoxCorrectParams p{rows, count, out, B, max_det, double(cfg.resolution), double(cfg.resolution), double(img_h), double(img_w), letterbox};
+    ACH_LAUNCH(correct_boxes_kernel, dim3(unsigned(cdivl(long(B) * max_det, 256))), dim3(256), s, p);
 }
 
 std::vector<long> EngineBase::tap_shape(const std::string& name) const {

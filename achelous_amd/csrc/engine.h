@@ -127,6 +127,8 @@ public:
     virtual void normalize_points(int B, int N, int D, const float* in, void* out, hipStream_t s) = 0;
     virtual void preprocess_image(int B, const unsigned char* in, void* out, hipStream_t s) = 0;
     virtual void seg_argmax(int B, int C, const void* seg, unsigned char* out, hipStream_t s) = 0;
+    virtual void seg_resize_argmax(int B, int C, const void* seg, int out_h, int out_w, float* prob_ws, unsigned char* out, hipStream_t s) = 0;
+    void correct_boxes(int B, int max_det, const float* rows, const int* count, int img_h, int img_w, int letterbox, float* out, hipStream_t s);
     float* prepost_scratch = nullptr; size_t prepost_scratch_bytes = 0;
     // micro-benchmark hook: time the MFMA GEMM kernel alone on scratch buffers (ms per launch)
     virtual float bench_gemm(int M, int K, int N, int act, int ln, int residual, int P, int iters, hipStream_t s) = 0;

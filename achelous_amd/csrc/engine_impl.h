@@ -855,7 +855,7 @@ public:
         if (full_taps) { f = alloc(x.B, 2 * x.H, 2 * x.W, cout); tap(tap_name, f); }
         UpGhostHeadParams p{t.p, t.ld, full_taps ? f.p : nullptr, full_taps ? f.ld : 0, nullptr, up_f32(wl), up_f32(bl), up_f32(lh.w), up_f32(lh.b),
                             up_f32(wh2), up_f32(bh2), x.B, x.H, x.W, init, nch, oup};
-        const dim3 grid(unsigned(cdiv(2 * x.W, UGH_TW)) * unsigned(cdiv(2 * x.H, UGH_TH)) * unsigned(x.B)), block(256);
+        const dim3 grid(unsigned(cdiv(2 * x.W, UGH_TW)) * unsigned(cdiv(2 * x.H, UGH_TH)) * unsigned(x.B)), block(UGH_THREADS);
         const double bytes = double(t.rows()) * Cg * sizeof(T) + 4.0 * double(t.rows()) * oup * sizeof(T);
         add_op(head_pfx + ".upghost_head", [p, grid, block, out](hipStream_t s) mutable { p.out = *out; ACH_LAUNCH(upghost_head_kernel<T>, grid, block, s, p, p.Wdw, p.bdw, p.Wh, p.bh, p.Wdh, p.bdh); }, bytes);
     }
@@ -1536,6 +1536,19 @@ public:
     void seg_argmax(int B, int C, const void* seg, unsigned char* out, hipStream_t s) override {
         SegArgmaxParams pp{seg, out, B, C, long(cfg.resolution) * cfg.resolution};
         ACH_LAUNCH(seg_argmax_kernel<T>, dim3(unsigned(cdivl(pp.HW * B, 256))), dim3(256), s, pp);
+    }
+
+    // achelous.py:283-318: softmax -> crop the letterbox bars -> INTER_LINEAR resize to the original size -> argmax (k_prepost.h)
+    void seg_resize_argmax(int B, int C, const void* seg, int out_h, int out_w, float* prob_ws, unsigned char* out, hipStream_t s) override {
+        const int R = cfg.resolution;
+        const long HW = long(R) * R;
+        SegSoftmaxParams sp{seg, prob_ws, B, C, HW};
+        ACH_LAUNCH(seg_softmax_kernel<T>, dim3(unsigned(cdivl(HW * B, 256))), dim3(256), s, sp);
+        // utils_seg/utils.py:19-31 (resize_image): scale = min(w / iw, h / ih), nw = int(iw * scale), nh = int(ih * scale), centred
+        const double scale = std::min(double(R) / double(out_w), double(R) / double(out_h));
+        const int nw = std::max(1, int(double(out_w) * scale)), nh = std::max(1, int(double(out_h) * scale));
+        SegResizeParams rp{prob_ws, out, B, C, R, (R - nh) / 2, (R - nw) / 2, nh, nw, out_h, out_w, double(nh) / double(out_h), double(nw) / double(out_w)};
+        ACH_LAUNCH(seg_resize_argmax_kernel, dim3(unsigned(cdivl(long(out_h) * out_w * B, 256))), dim3(256), s, rp);
     }
 
     float bench_gemm(int M, int K, int N, int act, int ln, int residual, int Pforce, int iters, hipStream_t s) override {

@@ -82,4 +82,95 @@ __global__ __launch_bounds__(256) void seg_argmax_kernel(const SegArgmaxParams p
     p.Y[idx] = (unsigned char)bi;
 }
 
+// ---- segmentation output -> class map at the ORIGINAL image size, as the reference's detect_image does it (achelous.py:283-318):
+// softmax over the classes at network resolution, crop the letterbox's grey bars, cv2.resize(..., INTER_LINEAR) to the original size,
+// argmax.  (Interpolating probabilities and THEN taking the argmax is not the argmax of the network-resolution map.)
+// Step 1: probabilities [B, C, R, R] fp32 into a workspace; step 2: one thread per output pixel blends the four source pixels of
+// every class and keeps the first maximum.  INTER_LINEAR for float images, restated from OpenCV's resize (imgproc/src/resize.cpp:
+// half-pixel centres, fx = (dx + 0.5) * (src / dst) - 0.5, sx = floor(fx); sx < 0 -> (0, weight 0); sx >= src - 1 -> (src - 1,
+// weight 0); rows blended horizontally first, then vertically, in fp32).  OpenCV is not installable in this image: parity unpinned.
+struct SegSoftmaxParams { const void* X; float* P; int B, C; long HW; };
+template <class T>
+__global__ __launch_bounds__(256) void seg_softmax_kernel(const SegSoftmaxParams p) {
+    const long idx = long(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (idx >= p.HW * p.B) return;
+    const long b = idx / p.HW, pix = idx - b * p.HW;
+    const T* x = static_cast<const T*>(p.X) + b * p.C * p.HW + pix;
+    float* o = p.P + b * p.C * p.HW + pix;
+    float mx = Store<T>::ld(x);
+    for (int c = 1; c < p.C; ++c) mx = fmaxf(mx, Store<T>::ld(x + c * p.HW));
+    float sum = 0.f;
+    for (int c = 0; c < p.C; ++c) { const float e = expf(Store<T>::ld(x + c * p.HW) - mx); o[c * p.HW] = e; sum += e; }
+    for (int c = 0; c < p.C; ++c) o[c * p.HW] = o[c * p.HW] / sum;
+}
+struct SegResizeParams {
+    const float* P; unsigned char* Y;
+    int B, C, R;                  // probabilities [B, C, R, R]
+    int y0, x0, nh, nw;           // the cropped (un-letterboxed) window of the network-resolution map
+    int oh, ow;                   // output size
+    double sy, sx;                // nh / oh, nw / ow
+};
+static __global__ __launch_bounds__(256) void seg_resize_argmax_kernel(const SegResizeParams p) {
+    const long per = long(p.oh) * p.ow;
+    const long idx = long(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (idx >= per * p.B) return;
+    const long b = idx / per;
+    const int dy = int((idx - b * per) / p.ow), dx = int((idx - b * per) % p.ow);
+    float fy = float((double(dy) + 0.5) * p.sy - 0.5), fx = float((double(dx) + 0.5) * p.sx - 0.5);
+    int iy = int(floorf(fy)), ix = int(floorf(fx));
+    fy -= float(iy); fx -= float(ix);
+    if (iy < 0) { iy = 0; fy = 0.f; }
+    if (iy >= p.nh - 1) { iy = p.nh - 1; fy = 0.f; }
+    if (ix < 0) { ix = 0; fx = 0.f; }
+    if (ix >= p.nw - 1) { ix = p.nw - 1; fx = 0.f; }
+    const int iy1 = iy + 1 < p.nh ? iy + 1 : iy, ix1 = ix + 1 < p.nw ? ix + 1 : ix;
+    const long HW = long(p.R) * p.R;
+    const float* base = p.P + b * p.C * HW;
+    const long r0 = long(p.y0 + iy) * p.R + p.x0, r1 = long(p.y0 + iy1) * p.R + p.x0;
+    const float ax0 = 1.f - fx, ay0 = 1.f - fy;
+    float best = -1.f;
+    int bi = 0;
+    for (int c = 0; c < p.C; ++c) {
+        const float* q = base + c * HW;
+        const float top = __fadd_rn(__fmul_rn(q[r0 + ix], ax0), __fmul_rn(q[r0 + ix1], fx));
+        const float bot = __fadd_rn(__fmul_rn(q[r1 + ix], ax0), __fmul_rn(q[r1 + ix1], fx));
+        const float v = __fadd_rn(__fmul_rn(top, ay0), __fmul_rn(bot, fy));
+        if (v > best) { best = v; bi = c; }
+    }
+    p.Y[idx] = (unsigned char)bi;
+}
+
+// ---- kept boxes -> image pixels: yolo_correct_boxes (utils/utils_bbox.py:5-30, called from non_max_suppression :177-180).
+// rows [B, max_det, 7] = x1, y1, x2, y2 (normalised corners in the letterboxed network input), obj, cls_conf, cls_id  ->
+// out  [B, max_det, 7] = y1, x1, y2, x2 in pixels of the ORIGINAL image, other columns copied.  The reference does this in numpy
+// with float64 intermediates (a float32 array combined with float64 shape arrays) and stores float32: same here, in double.
+struct BoxCorrectParams { const float* rows; const int* count; float* out; int B, max_det; double in_h, in_w, img_h, img_w; int letterbox; };
+static __global__ __launch_bounds__(256) void correct_boxes_kernel(const BoxCorrectParams p) {
+    const long idx = long(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (idx >= long(p.B) * p.max_det) return;
+    const int b = int(idx / p.max_det), k = int(idx % p.max_det);
+    const float* r = p.rows + idx * 7;
+    float* o = p.out + idx * 7;
+    if (k >= p.count[b]) { for (int c = 0; c < 7; ++c) o[c] = 0.f; return; }
+    // box_xy = (x1y1 + x2y2) / 2, box_wh = x2y2 - x1y1 in float32 (utils_bbox.py:178), then reversed to (y, x)
+    const float cx = __fdiv_rn(__fadd_rn(r[0], r[2]), 2.f), cy = __fdiv_rn(__fadd_rn(r[1], r[3]), 2.f);
+    float bw = __fsub_rn(r[2], r[0]), bh = __fsub_rn(r[3], r[1]);
+    double yy = double(cy), xx = double(cx);
+    if (p.letterbox) {
+        const double m = fmin(p.in_h / p.img_h, p.in_w / p.img_w);
+        const double nh = rint(p.img_h * m), nw = rint(p.img_w * m);                  // np.round: half to even, as rint
+        const double off_y = (p.in_h - nh) / 2. / p.in_h, off_x = (p.in_w - nw) / 2. / p.in_w;
+        const double sc_y = p.in_h / nh, sc_x = p.in_w / nw;
+        yy = (yy - off_y) * sc_y; xx = (xx - off_x) * sc_x;
+        bh = float(double(bh) * sc_y); bw = float(double(bw) * sc_x);                 // `box_hw *= scale` is an in-place float32 update
+    }
+    const float hy = __fdiv_rn(bh, 2.f), hx = __fdiv_rn(bw, 2.f);                    // float32 array / python float stays float32
+    double y_lo, x_lo, y_hi, x_hi;
+    if (p.letterbox) { y_lo = yy - double(hy); x_lo = xx - double(hx); y_hi = yy + double(hy); x_hi = xx + double(hx); }   // float64 - float32
+    else { y_lo = double(__fsub_rn(cy, hy)); x_lo = double(__fsub_rn(cx, hx)); y_hi = double(__fadd_rn(cy, hy)); x_hi = double(__fadd_rn(cx, hx)); }   // all float32
+    o[0] = float(y_lo * p.img_h); o[1] = float(x_lo * p.img_w);                        // `boxes *= image_shape`: computed in float64, stored float32
+    o[2] = float(y_hi * p.img_h); o[3] = float(x_hi * p.img_w);
+    o[4] = r[4]; o[5] = r[5]; o[6] = r[6];
+}
+
 }  // namespace ach

@@ -37,7 +37,7 @@ class NativeLibrary:
                'ach_forward', 'ach_forward_detect', 'ach_join', 'ach_forwards_in_flight', 'ach_decode', 'ach_nms_workspace_bytes', 'ach_nms', 'ach_tap_count', 'ach_tap_name',
                'ach_tap_shape', 'ach_read_tap', 'ach_plan_launches', 'ach_op_name', 'ach_op_bytes', 'ach_op_layout_bytes', 'ach_op_flops', 'ach_op_stream',
                'ach_forward_profiled', 'ach_set_probe', 'ach_read_probe', 'ach_set_probe_range', 'ach_read_probe_slot', 'ach_bench_gemm', 'ach_set_option', 'ach_preprocess_radar',
-               'ach_normalize_points', 'ach_preprocess_image', 'ach_seg_argmax')
+               'ach_normalize_points', 'ach_preprocess_image', 'ach_seg_argmax', 'ach_seg_resize_argmax', 'ach_correct_boxes')
 
     def __init__(self, path):
         if not os.path.exists(path):
@@ -82,6 +82,10 @@ class NativeLibrary:
         L.ach_preprocess_image.restype = ctypes.c_int
         L.ach_seg_argmax.argtypes = [vp, i32, i32, vp, vp, vp]
         L.ach_seg_argmax.restype = ctypes.c_int
+        L.ach_seg_resize_argmax.argtypes = [vp, i32, i32, vp, i32, i32, vp, vp, vp]
+        L.ach_seg_resize_argmax.restype = ctypes.c_int
+        L.ach_correct_boxes.argtypes = [vp, i32, i32, vp, vp, i32, i32, i32, vp, vp]
+        L.ach_correct_boxes.restype = ctypes.c_int
         L.ach_tap_count.argtypes = [vp]
         L.ach_tap_count.restype = ctypes.c_int
         L.ach_tap_name.argtypes = [vp, ctypes.c_int]
@@ -283,6 +287,14 @@ class NativeEngine:
 
     def seg_argmax(self, batch, channels, src, dst, stream=0):
         self._check(self.L.ach_seg_argmax(self.h, int(batch), int(channels), _ptr(src), _ptr(dst), ctypes.c_void_p(stream)))
+
+    def seg_resize_argmax(self, batch, channels, src, out_h, out_w, prob_ws, dst, stream=0):
+        self._check(self.L.ach_seg_resize_argmax(self.h, int(batch), int(channels), _ptr(src), int(out_h), int(out_w), _ptr(prob_ws), _ptr(dst),
+                                                 ctypes.c_void_p(stream)))
+
+    def correct_boxes(self, batch, max_det, rows, count, image_h, image_w, letterbox, out, stream=0):
+        self._check(self.L.ach_correct_boxes(self.h, int(batch), int(max_det), _ptr(rows), _ptr(count), int(image_h), int(image_w),
+                                             int(bool(letterbox)), _ptr(out), ctypes.c_void_p(stream)))
 
     # ---------------------------------------------------------------------------------------------------
     def tap_names(self):

@@ -4,10 +4,9 @@
     non_max_suppression(prediction, num_classes, input_shape, image_shape,
                         letterbox_image, conf_thres=0.5, nms_thres=0.4)     utils_bbox.py:87-181
 
-Both run as HIP kernels through the C ABI (ach_decode / ach_nms); only the final un-letterboxing of the kept boxes
-(`yolo_correct_boxes`, utils_bbox.py:5-30) stays on the host in numpy, as in the reference.  No CPU fallback.
+All of it runs as HIP kernels through the C ABI (ach_decode / ach_nms / ach_correct_boxes — the un-letterboxing of the kept boxes,
+`yolo_correct_boxes`, utils_bbox.py:5-30, included).  No CPU fallback.
 """
-import numpy as np
 import torch
 
 from . import engine as _eng
@@ -71,32 +70,27 @@ def nms_device(prediction, num_classes, conf_thres, nms_thres, max_det=None):
     return rows, idx, cnt
 
 
-def yolo_correct_boxes(box_xy, box_wh, input_shape, image_shape, letterbox_image):
-    """utils_bbox.py:5-30 (host, numpy): normalised (xy, wh) in the letterboxed input -> (y1,x1,y2,x2) image pixels."""
-    box_yx, box_hw = box_xy[..., ::-1], box_wh[..., ::-1]
-    input_shape = np.array(input_shape, dtype=np.float64)
-    image_shape = np.array(image_shape, dtype=np.float64)
-    if letterbox_image:
-        new_shape = np.round(image_shape * np.min(input_shape / image_shape))
-        offset = (input_shape - new_shape) / 2. / input_shape
-        scale = input_shape / new_shape
-        box_yx = (box_yx - offset) * scale
-        box_hw = box_hw * scale
-    mins, maxes = box_yx - box_hw / 2., box_yx + box_hw / 2.
-    boxes = np.concatenate([mins[..., 0:1], mins[..., 1:2], maxes[..., 0:1], maxes[..., 1:2]], axis=-1)
-    return boxes * np.concatenate([image_shape, image_shape], axis=-1)
-
-
-def non_max_suppression(prediction, num_classes, input_shape, image_shape, letterbox_image, conf_thres=0.5, nms_thres=0.4):
-    """Per image: None or float32 [K,7] = (y1,x1,y2,x2 in image pixels, obj_conf, class_conf, class_id), descending score."""
-    rows, idx, cnt = nms_device(prediction, num_classes, conf_thres, nms_thres)
-    rows, cnt = rows.cpu().numpy(), cnt.cpu().numpy()
-    out = []
-    for b in range(rows.shape[0]):
-        k = int(cnt[b])
-        r = rows[b, :k].copy()
-        if k:
-            xy, wh = (r[:, 0:2] + r[:, 2:4]) / 2, r[:, 2:4] - r[:, 0:2]
-            r[:, :4] = yolo_correct_boxes(xy, wh, input_shape, image_shape, letterbox_image)
-        out.append(r)          # the reference yields an empty selection as a [0,7] array as well
+def correct_boxes_device(rows, cnt, input_shape, image_shape, letterbox_image):
+    """utils_bbox.py:5-30,177-180 on the device: kept rows [B,max_det,7] (normalised x1,y1,x2,y2 in the network input) ->
+    (y1,x1,y2,x2) in pixels of the original image; rows past cnt[b] are zero.  float64 intermediates, as numpy's promotion gives the
+    reference."""
+    R = int(input_shape[0])
+    if int(input_shape[1]) != R:
+        raise ValueError("square network input expected")
+    rows = rows.contiguous()
+    B, max_det, _ = rows.shape
+    with torch.cuda.device(rows.device):
+        out = torch.empty_like(rows)
+        _handle(1, R, torch.float32).correct_boxes(B, max_det, rows, cnt.contiguous(), int(image_shape[0]), int(image_shape[1]), letterbox_image,
+                                                   out, torch.cuda.current_stream().cuda_stream)
     return out
+
+
+def non_max_suppression(prediction, num_classes, input_shape, image_shape, letterbox_image, conf_thres=0.5, nms_thres=0.4, max_det=None):
+    """Per image: float32 [K,7] = (y1,x1,y2,x2 in image pixels, obj_conf, class_conf, class_id), descending score (the reference's
+    return value for a non-empty selection; an empty one is a [0,7] array here, None there).  `max_det` = 100 gives the evaluation
+    path's "top 100 by confidence" (utils/callbacks.py:202-205): the rows already come in descending obj * class confidence."""
+    rows, idx, cnt = nms_device(prediction, num_classes, conf_thres, nms_thres, max_det)
+    rows = correct_boxes_device(rows, cnt, input_shape, image_shape, letterbox_image).cpu().numpy()
+    cnt = cnt.cpu().numpy()
+    return [rows[b, :int(cnt[b])].copy() for b in range(rows.shape[0])]

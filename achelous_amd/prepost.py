@@ -4,6 +4,7 @@
     normalize_points(points[B,N,D] fp32)             achelous.py:240-243    -> [B,D,N]   dtype
     preprocess_input(images[B,R,R,3] uint8)          utils/utils.py:44-48   -> [B,3,R,R] dtype   (letterboxing stays on the host)
     seg_class_map(seg[B,C,R,R])                      achelous.py:283-296    -> uint8 [B,R,R]     (network resolution)
+    seg_class_map_original(seg[B,C,R,R], (h, w))     achelous.py:283-318    -> uint8 [B,h,w]     softmax -> crop bars -> INTER_LINEAR -> argmax
 HIP kernels through the C ABI; no CPU fallback.
 """
 import torch
@@ -56,4 +57,19 @@ def seg_class_map(seg):
     with torch.cuda.device(s.device):
         out = torch.empty(B, R, R, dtype=torch.uint8, device=s.device)
         _handle(1, R, s.dtype).seg_argmax(B, C, s, out, torch.cuda.current_stream().cuda_stream)
+    return out
+
+
+def seg_class_map_original(seg, image_shape):
+    """The class map at the ORIGINAL image size exactly as the reference's detect_image builds it (achelous.py:283-318): softmax over
+    the classes, the letterbox's grey bars cropped (utils_seg/utils.py:19-31), cv2.resize(..., INTER_LINEAR) to `image_shape` = (h, w),
+    argmax.  All frames of the batch share `image_shape`."""
+    _need_gpu(seg, 'seg_class_map_original')
+    s = seg.contiguous()
+    B, C, R, _ = s.shape
+    oh, ow = int(image_shape[0]), int(image_shape[1])
+    with torch.cuda.device(s.device):
+        ws = torch.empty(B * C * R * R, dtype=torch.float32, device=s.device)
+        out = torch.empty(B, oh, ow, dtype=torch.uint8, device=s.device)
+        _handle(1, R, s.dtype).seg_resize_argmax(B, C, s, oh, ow, ws, out, torch.cuda.current_stream().cuda_stream)
     return out

@@ -154,6 +154,16 @@ int ach_preprocess_radar(ach_handle* h, int32_t batch, int32_t channels, const f
 int ach_normalize_points(ach_handle* h, int32_t batch, int32_t n, int32_t d, const float* in, void* out, void* stream);
 int ach_preprocess_image(ach_handle* h, int32_t batch, const uint8_t* in, void* out, void* stream);
 int ach_seg_argmax(ach_handle* h, int32_t batch, int32_t channels, const void* seg, uint8_t* out, void* stream);
+/*   ach_seg_resize_argmax <- achelous.py:283-318    the class map at the ORIGINAL image size as detect_image produces it: softmax ->
+ *                                                   crop the letterbox bars (utils_seg/utils.py:19-31) -> cv2.resize INTER_LINEAR ->
+ *                                                   argmax; seg [B,C,R,R] (config dtype) -> out uint8 [B,out_h,out_w];
+ *                                                   prob_workspace: batch * channels * R * R floats
+ *   ach_correct_boxes     <- utils_bbox.py:5-30,177-180  kept rows (normalised x1,y1,x2,y2 in the network input) -> (y1,x1,y2,x2) in pixels
+ *                                                   of the original image (letterbox undone), rows past count[b] zeroed; fp64 as numpy */
+int ach_seg_resize_argmax(ach_handle* h, int32_t batch, int32_t channels, const void* seg, int32_t out_h, int32_t out_w,
+                          float* prob_workspace, uint8_t* out, void* stream);
+int ach_correct_boxes(ach_handle* h, int32_t batch, int32_t max_det, const float* rows, const int32_t* count, int32_t image_h, int32_t image_w,
+                      int32_t letterbox, float* out_rows, void* stream);
 
 /* test hooks: intermediate tensors of the last ach_forward, converted to fp32 NCHW (or [rows, C]) on the host */
 int ach_tap_count(const ach_handle* h);

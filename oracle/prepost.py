@@ -34,3 +34,65 @@ def seg_class_map(seg_chw):
     x = np.asarray(seg_chw, dtype=np.float32).transpose(1, 2, 0)
     e = np.exp(x - x.max(-1, keepdims=True))
     return (e / e.sum(-1, keepdims=True)).argmax(axis=-1).astype(np.uint8)
+
+
+def letterbox_window(out_h, out_w, R):
+    """utils_seg/utils.py:19-31 (resize_image): the un-padded window of the R x R network input for an image of (out_h, out_w)."""
+    scale = min(R / out_w, R / out_h)
+    nw, nh = max(1, int(out_w * scale)), max(1, int(out_h * scale))
+    return (R - nh) // 2, (R - nw) // 2, nh, nw
+
+
+def resize_linear(img_hwc, out_h, out_w):
+    """cv2.resize(img, (out_w, out_h), interpolation=cv2.INTER_LINEAR) for a float32 HxWxC image, restated from OpenCV's
+    imgproc/src/resize.cpp (float path): half-pixel centres fx = (dx + 0.5) * (src / dst) - 0.5, sx = floor(fx); sx < 0 -> sx = 0 with
+    weight 0; sx >= src - 1 -> sx = src - 1 with weight 0; rows are interpolated horizontally first, then vertically, in float32.
+    PARITY UNPINNED: OpenCV is not installed (nor installable) in this image."""
+    src = np.asarray(img_hwc, dtype=np.float32)
+    H, W = src.shape[:2]
+
+    def axis(n_dst, n_src):
+        f = ((np.arange(n_dst, dtype=np.float64) + 0.5) * (n_src / n_dst) - 0.5).astype(np.float32)
+        i = np.floor(f).astype(np.int64)
+        f = (f - i.astype(np.float32)).astype(np.float32)
+        lo, hi = i < 0, i >= n_src - 1
+        i = np.where(lo, 0, np.where(hi, n_src - 1, i))
+        f = np.where(lo | hi, np.float32(0), f).astype(np.float32)
+        return i, np.minimum(i + 1, n_src - 1), f
+    iy, iy1, fy = axis(out_h, H)
+    ix, ix1, fx = axis(out_w, W)
+    fxc, fyc = fx[None, :, None], fy[:, None, None]
+    top = src[iy][:, ix] * (np.float32(1) - fxc) + src[iy][:, ix1] * fxc
+    bot = src[iy1][:, ix] * (np.float32(1) - fxc) + src[iy1][:, ix1] * fxc
+    return (top * (np.float32(1) - fyc) + bot * fyc).astype(np.float32)
+
+
+def seg_class_map_original(seg_chw, out_h, out_w):
+    """achelous.py:283-296 / 305-318: softmax over the classes, crop the letterbox bars, INTER_LINEAR resize to the original image
+    size, argmax (first maximum)."""
+    x = np.asarray(seg_chw, dtype=np.float32).transpose(1, 2, 0)
+    R = x.shape[0]
+    e = np.exp(x - x.max(-1, keepdims=True))
+    p = (e / e.sum(-1, keepdims=True)).astype(np.float32)
+    y0, x0, nh, nw = letterbox_window(out_h, out_w, R)
+    return resize_linear(p[y0:y0 + nh, x0:x0 + nw], out_h, out_w).argmax(axis=-1).astype(np.uint8)
+
+
+def correct_boxes(rows_k7, input_shape, image_shape, letterbox_image):
+    """utils_bbox.py:177-180 + yolo_correct_boxes :5-30 on kept rows (x1,y1,x2,y2 normalised, float32): -> (y1,x1,y2,x2) in image
+    pixels, numpy dtype promotion as in the reference (float32 rows, float64 shape arrays)."""
+    r = np.array(rows_k7, dtype=np.float32, copy=True)
+    box_xy, box_wh = (r[:, 0:2] + r[:, 2:4]) / 2, r[:, 2:4] - r[:, 0:2]
+    box_yx, box_hw = box_xy[..., ::-1], box_wh[..., ::-1]
+    input_shape, image_shape = np.array(input_shape), np.array(image_shape)
+    if letterbox_image:
+        new_shape = np.round(image_shape * np.min(input_shape / image_shape))
+        offset = (input_shape - new_shape) / 2. / input_shape
+        scale = input_shape / new_shape
+        box_yx = (box_yx - offset) * scale
+        box_hw *= scale
+    mins, maxes = box_yx - (box_hw / 2.), box_yx + (box_hw / 2.)
+    boxes = np.concatenate([mins[..., 0:1], mins[..., 1:2], maxes[..., 0:1], maxes[..., 1:2]], axis=-1)
+    boxes *= np.concatenate([image_shape, image_shape], axis=-1)
+    r[:, :4] = boxes
+    return r

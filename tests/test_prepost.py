@@ -22,6 +22,36 @@ def test_oracle_matches_reference_vectors():
     assert np.allclose(O.preprocess_input(g['img']), g['ref_img'], rtol=1e-6, atol=1e-6)
 
 
+BOX_CASES = (('lb_1080x1920', 320, (1080, 1920), True), ('lb_720x405', 320, (720, 405), True), ('plain_1080x1920', 320, (1080, 1920), False),
+             ('lb_square', 416, (416, 416), True))
+
+
+def test_oracle_box_correction_matches_reference_vectors():
+    g = _golden()
+    for tag, R, imshape, lb in BOX_CASES:
+        assert np.array_equal(O.correct_boxes(g['boxes'], [R, R], imshape, lb), g['boxes_' + tag]), tag
+
+
+def test_resize_linear_restatement_properties():
+    """cv2 is not installable here (parity unpinned): the restatement of INTER_LINEAR is checked on what the published algorithm
+    guarantees: identity at equal size, exact reproduction of an affine ramp away from the clamped border, x2 up-sampling phases
+    (0.25 / 0.75), constant images stay constant, and the class map of a one-hot image survives."""
+    rng = np.random.default_rng(1)
+    a = rng.normal(0, 1, (7, 9, 3)).astype(np.float32)
+    assert np.array_equal(O.resize_linear(a, 7, 9), a)
+    yy, xx = np.mgrid[0:12, 0:10].astype(np.float32)
+    ramp = (2 * yy + 3 * xx)[..., None]
+    up = O.resize_linear(ramp, 24, 20)[..., 0]
+    Y, X = np.mgrid[0:24, 0:20]
+    want = 2 * ((Y + 0.5) / 2 - 0.5) + 3 * ((X + 0.5) / 2 - 0.5)
+    assert np.allclose(up[1:-1, 1:-1], want[1:-1, 1:-1], atol=1e-4)
+    assert np.allclose(O.resize_linear(np.full((5, 6, 2), 0.37, np.float32), 11, 13), 0.37, atol=1e-6)
+    row = np.array([[0.0], [1.0]], np.float32).reshape(1, 2, 1)
+    assert np.allclose(O.resize_linear(row, 1, 4)[0, :, 0], [0.0, 0.25, 0.75, 1.0])
+    y0, x0, nh, nw = O.letterbox_window(1080, 1920, 320)
+    assert (nh, nw, y0, x0) == (180, 320, 70, 0)
+
+
 def _inputs(res, B=3, N=96, D=5, C=9, seed=3):
     rng = np.random.default_rng(seed)
     radar = np.zeros((B, 3, res, res), np.float32)
@@ -52,6 +82,28 @@ def _check(h, dev, res):
     out = torch.empty(B, res, res, dtype=torch.uint8, device=dev)
     h.seg_argmax(B, seg.shape[1], t(seg), out)
     assert np.array_equal(out.cpu().numpy(), np.stack([O.seg_class_map(s) for s in seg]))
+    # class map at the original image size (softmax -> crop -> INTER_LINEAR -> argmax), landscape / portrait / down-sampling
+    for oh, ow in ((3 * res + 60, 6 * res), (2 * res + 7, res + 3), (res // 2, res // 2 + 5)):
+        ws = torch.empty(B * seg.shape[1] * res * res, device=dev)
+        out = torch.empty(B, oh, ow, dtype=torch.uint8, device=dev)
+        h.seg_resize_argmax(B, seg.shape[1], t(seg), oh, ow, ws, out)
+        want = np.stack([O.seg_class_map_original(s, oh, ow) for s in seg])
+        got = out.cpu().numpy()
+        # exp / division differ by an ulp between libm and the device: a class may flip only where two probabilities tie to ~1e-6
+        assert (got != want).mean() < 2e-4, ((oh, ow), (got != want).mean())
+    # kept boxes -> image pixels, against the vectors captured from the reference's yolo_correct_boxes (bit-exact)
+    if h.resolution in (320, 416):
+        g = _golden()
+        for tag, R, imshape, lb in BOX_CASES:
+            if R != h.resolution:
+                continue
+            rows = np.zeros((2, 80, 7), np.float32)
+            rows[0, :64], rows[1, :10] = g['boxes'], g['boxes'][:10]
+            cnt = torch.tensor([64, 10], dtype=torch.int32)
+            out = torch.empty(2, 80, 7, device=dev)
+            h.correct_boxes(2, 80, t(rows), cnt.to(dev), imshape[0], imshape[1], lb, out)
+            o = out.cpu().numpy()
+            assert np.array_equal(o[0, :64], g['boxes_' + tag]) and np.array_equal(o[1, :10], g['boxes_' + tag][:10]) and not o[0, 64:].any() and not o[1, 10:].any(), tag
 
 
 def test_emulated_prepost_kernels_match_oracle():
@@ -59,6 +111,18 @@ def test_emulated_prepost_kernels_match_oracle():
     h = NativeEngine(emu_library(), num_det=1, num_seg=1, phi='S0', backbone='en', resolution=32, pc_channels=3, pc_classes=1,
                      num_points=16, nano_head=True, spp=True, dtype=DTYPE_F32)
     _check(h, 'cpu', 32)
+    for R in (320, 416):                                  # the box-correction vectors are for 320 / 416 network inputs
+        hb = NativeEngine(emu_library(), num_det=1, num_seg=1, phi='S0', backbone='en', resolution=R, pc_channels=3, pc_classes=1,
+                          num_points=16, nano_head=True, spp=True, dtype=DTYPE_F32)
+        g = _golden()
+        for tag, RR, imshape, lb in BOX_CASES:
+            if RR != R:
+                continue
+            rows = np.zeros((1, 64, 7), np.float32)
+            rows[0] = g['boxes']
+            out = torch.empty(1, 64, 7)
+            hb.correct_boxes(1, 64, torch.from_numpy(rows), torch.tensor([64], dtype=torch.int32), imshape[0], imshape[1], lb, out)
+            assert np.array_equal(out.numpy()[0], g['boxes_' + tag]), tag
 
 
 @pytest.mark.gpu
@@ -74,3 +138,18 @@ def test_gpu_prepost_kernels_match_oracle():
     assert np.array_equal(prepost.seg_class_map(torch.from_numpy(seg).cuda()).cpu().numpy(), np.stack([O.seg_class_map(s) for s in seg]))
     assert np.allclose(prepost.normalize_points(torch.from_numpy(pts).cuda()).cpu().numpy(), np.stack([O.normalize_points(p) for p in pts]), atol=1e-6)
     assert np.allclose(prepost.preprocess_input(torch.from_numpy(img).cuda()).cpu().numpy(), np.stack([O.preprocess_input(i) for i in img]), rtol=1e-5, atol=1e-6)
+    # the reference-shaped calls: class map at 1080x1920 and non_max_suppression with un-letterboxing + top-100 on the device
+    cm = prepost.seg_class_map_original(torch.from_numpy(seg).cuda(), (1080, 1920)).cpu().numpy()
+    want = np.stack([O.seg_class_map_original(s, 1080, 1920) for s in seg])
+    assert cm.shape == (3, 1080, 1920) and (cm != want).mean() < 2e-4
+    from achelous_amd import non_max_suppression
+    from oracle.achelous_oracle import non_max_suppression as o_nms
+    rng = np.random.default_rng(8)
+    dec = np.zeros((2, 2100, 12), np.float32)
+    dec[..., 0:2] = rng.uniform(0.1, 0.9, (2, 2100, 2)); dec[..., 2:4] = rng.uniform(0.05, 0.3, (2, 2100, 2))
+    dec[..., 4] = rng.uniform(0, 1, (2, 2100)); dec[..., 5:] = rng.uniform(0, 1, (2, 2100, 7))
+    got = non_max_suppression(torch.from_numpy(dec).cuda(), 7, [320, 320], (1080, 1920), True, conf_thres=0.3, nms_thres=0.4, max_det=100)
+    ref = o_nms(torch.from_numpy(dec), 7, 0.3, 0.4)
+    for b in range(2):
+        want_rows = O.correct_boxes(ref[b][0][:100], [320, 320], (1080, 1920), True)
+        assert got[b].shape == want_rows.shape and np.array_equal(got[b], want_rows)
