@@ -765,19 +765,20 @@ struct UpGhostHeadParams {
     const float* Wdh; const float* bdh;       // head cheap op: [9][nch], [nch]
     int B, h, w, init, nch, oup;
 };
-constexpr int UGH_TW = 28, UGH_TH = 12, UGH_CG = 16, UGH_IMAX = 8, UGH_THREADS = 512;
-// Tile 28x12 outputs, 512 threads: its 2-pixel halo is exactly 32x16 = 512 positions = one per thread for the bilinear phase (the
-// round-1 tile, 30x6 outputs on 256 threads, spent two rounds of 256 on 340 halo positions: 2.8 thread-slots of the most expensive
-// phase per output pixel, 1.5 here; the 1-halo phase goes from 1.42 to 1.52).  LDS layouts are chosen for the access patterns: x1 rows
-// padded to 20 floats (thread = position reads 16 consecutive floats: stride 20 dwords is conflict-free for ds_read_b128), h1 stored
-// planar [channel][position] (thread = pixel reads one channel at a time).  54 KB per workgroup: two workgroups = 16 waves per CU.
+constexpr int UGH_TW = 30, UGH_TH = 6, UGH_CG = 16, UGH_IMAX = 8, UGH_THREADS = 256;
+// Tile 30x6 outputs: its 1-pixel halo is exactly 32x8 = 256 positions = one per thread.  LDS layouts are chosen for the
+// access patterns: x1 rows padded to 20 floats (thread = position reads 16 consecutive floats: stride 20 dwords is
+// conflict-free for ds_read_b128), h1 stored planar [channel][position] (thread = pixel reads one channel at a time).
+// (Measured and rejected in round 2: a 28x12 tile on 512 threads, whose 2-halo is exactly one position per thread — 1.5 instead of
+//  2.8 thread-slots of the bilinear phase per output pixel, 25 % fewer VALU instructions per output in total — ran SLOWER, 160 -> 166 us
+//  (lane) and 215 -> 233 us (semantic): the kernel is not bound by its instruction count)
 template <class T>
 __global__ __launch_bounds__(UGH_THREADS) void upghost_head_kernel(const UpGhostHeadParams p, const float* __restrict__ Wdw, const float* __restrict__ bdw,
                                                            const float* __restrict__ Wh, const float* __restrict__ bh,
                                                            const float* __restrict__ Wdh, const float* __restrict__ bdh) {
     constexpr int TW = UGH_TW, TH = UGH_TH, CG = UGH_CG, CS = CG + 4;
     constexpr int W2 = TW + 4, H2 = TH + 4, W1 = TW + 2, H1 = TH + 2;
-    static_assert(W2 * H2 == UGH_THREADS, "one 2-halo position per thread");
+    static_assert(W1 * H1 == UGH_THREADS, "one halo position per thread");
     __shared__ float x1s[H2 * W2 * CS];
     __shared__ float hs[UGH_IMAX][H1 * W1];
     const int H = 2 * p.h, Wd = 2 * p.w;
@@ -795,9 +796,11 @@ __global__ __launch_bounds__(UGH_THREADS) void upghost_head_kernel(const UpGhost
         const float sy = H > 1 ? float(p.h - 1) / float(H - 1) : 0.f, sx = Wd > 1 ? float(p.w - 1) / float(Wd - 1) : 0.f;
         const T* Tq = static_cast<const T*>(p.Tq) + b * p.h * long(p.w) * p.ldt;
         const int ldt = int(p.ldt);
-        {
-            const int pos_raw = tid;
-            const int pos = tid;
+        constexpr int ROUNDS = (H2 * W2 + 255) / 256;
+        ACH_UNROLL
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int pos_raw = tid + r * 256;
+            const int pos = pos_raw < H2 * W2 ? pos_raw : H2 * W2 - 1;
             const int py = pos / W2, oy = by + py - 2, ox = bx + (pos - py * W2) - 2;
             const bool ok = oy >= 0 && oy < H && ox >= 0 && ox < Wd;
             const int cy = oy < 0 ? 0 : (oy >= H ? H - 1 : oy), cx = ox < 0 ? 0 : (ox >= Wd ? Wd - 1 : ox);
@@ -827,12 +830,11 @@ __global__ __launch_bounds__(UGH_THREADS) void upghost_head_kernel(const UpGhost
         }
     }
     __syncthreads();
-    // ---- f and h1 on the 1-halo tile: thread = position (H1 * W1 = 420 of the 512 threads)
-    const bool has_pos = tid < H1 * W1;
-    const int ly_ = has_pos ? tid / W1 : 0, lx_ = has_pos ? tid % W1 : 0;
+    // ---- f and h1 on the 1-halo tile: thread = position
+    const int ly_ = tid / W1, lx_ = tid % W1;
     const int oy = by + ly_ - 1, ox = bx + lx_ - 1;
-    const bool inside = has_pos && oy >= 0 && oy < H && ox >= 0 && ox < Wd;
-    if (has_pos) {
+    const bool inside = oy >= 0 && oy < H && ox >= 0 && ox < Wd;
+    {
         float hv[UGH_IMAX];
         ACH_UNROLL
         for (int j = 0; j < UGH_IMAX; ++j) hv[j] = 0.f;
