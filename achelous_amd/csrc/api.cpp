@@ -87,6 +87,7 @@ int ach_set_option(ach_handle* h, const char* key, int32_t value) {
         else if (std::string(key) == "split_decoders") h->eng->split_decoders = value;
         else if (std::string(key) == "radar_start") h->eng->radar_start = value;
         else if (std::string(key) == "pipeline") h->eng->pipeline = value != 0;
+        else if (std::string(key) == "pool_strip") h->eng->pool_strip = value;
         else throw ach::AchError{ACH_ERR_INVALID, std::string("unknown option: ") + key};
     });
 }

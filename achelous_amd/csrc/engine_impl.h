@@ -1036,7 +1036,10 @@ public:
             Bordered pooled = alloc_bordered(B, x.H, x.W, C, narrow ? 4 : 0);
             { PoolParams pp{x.p, x.ld, pooled.p0, pooled.ld, B, x.H, x.W, C, pooled.row, pooled.img};
               const double bytes = 2.0 * x.rows() * C * sizeof(T), lbytes = double(x.rows()) * (x.ld + pooled.ld) * sizeof(T);
-              if (C >= 16) ew(pfx + ".avgpool", avgpool3x3_kernel<T, 4>, pp, long(B) * x.H * cdiv(x.W, 4) * ((C + 3) / 4), bytes, lbytes);
+              // strips of 4 output pixels per thread where a strip is contiguous enough for the loads to coalesce: >= 16 channels, or
+              // the 4-channel pixels of block 0 (option "pool_strip": 0 never, 1 as described, 2 also the 8-channel blocks)
+              const bool strip = pool_strip > 0 && (C >= 16 || narrow || (pool_strip > 1 && C >= 8));
+              if (strip) ew(pfx + ".avgpool", avgpool3x3_kernel<T, 4>, pp, long(B) * x.H * cdiv(x.W, 4) * ((C + 3) / 4), bytes, lbytes);
               else ew(pfx + ".avgpool", avgpool3x3_kernel<T, 1>, pp, x.rows() * ((C + 3) / 4), bytes, lbytes); }
             // offset_conv (18) + modulator_conv (9) as one implicit GEMM
             Lin lo = conv_lin(d + ".offset_conv.weight", d + ".offset_conv.bias", C, Cp, 3);
