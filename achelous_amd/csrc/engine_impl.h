@@ -11,6 +11,7 @@
 #include "k_conv3.h"
 #include "k_gemm.h"
 #include "k_mlp.h"
+#include "k_mv2.h"
 #include "k_mvit.h"
 #include "k_nhwc.h"
 #include "k_points.h"
@@ -610,8 +611,38 @@ public:
         if (k == 1) { A y = alloc(x.B, x.H, x.W, l.N); GemmOpt o; o.act = ACT_SILU; gemm(pfx, x, pack(l), y, o); return y; }
         return conv_gemm(pfx, x, l, k, stride, ACT_SILU);
     }
+    // the whole block as one launch (k_mv2.h): hidden widths 64 / 128 (the 160x160 .. 40x40 blocks, where the expanded map is the traffic)
+    bool fused_mv2(const std::string& pfx, const A& x, int stride, int oup, const Lin& l1, const Lin& l2, A& y) {
+        const int hid = l1.N, Cin = x.C, k1 = cdiv(Cin, KC);
+        if (!fuse_mv2 || !mv2_supported(stride, hid, oup) || x.ld % VEC != 0 || l1.K != Cin || l2.K != hid) return false;
+        const HostTensor& wd = W(pfx + ".conv.3.weight");
+        if (wd.numel() != long(hid) * 9) return false;
+        std::vector<float> sc, sh; bn_coeffs(pfx + ".conv.4", 1e-5, sc, sh);
+        const int ks2 = hid / KC, nt1 = hid / 16, nt2 = cdiv(oup, 16);
+        std::vector<float> w1(size_t(nt1) * k1 * 64 * VEC, 0.f), w2(size_t(nt2) * ks2 * 64 * VEC, 0.f), wdw(size_t(9) * hid), bdw(static_cast<size_t>(hid)), b2(size_t(nt2) * 16, 0.f);
+        if (!measuring) {
+            for (int n = 0; n < hid; ++n) for (int k = 0; k < Cin; ++k) w1[size_t(mv2_frag_offset(n, k, k1, VEC))] = l1.w[size_t(n) * Cin + k];
+            for (int n = 0; n < oup; ++n) { b2[n] = l2.b[n]; for (int k = 0; k < hid; ++k) w2[size_t(mv2_frag_offset(n, k, ks2, VEC))] = l2.w[size_t(n) * hid + k]; }
+            for (int c = 0; c < hid; ++c) { bdw[c] = sh[c]; for (int t = 0; t < 9; ++t) wdw[size_t(t) * hid + c] = wd.data[size_t(c) * 9 + t] * sc[c]; }
+        }
+        const int Ho = (x.H + 2 - 3) / stride + 1, Wo = (x.W + 2 - 3) / stride + 1;
+        y = alloc(x.B, Ho, Wo, oup);
+        const bool res = stride == 1 && x.C == oup;
+        Mv2Params mp{x.p, x.ld, y.p, y.ld, up_T(w1), up_f32(l1.b), up_f32(wdw), up_f32(bdw), up_T(w2), up_f32(b2), res ? x.p : nullptr, res ? x.ld : 0,
+                     x.B, x.H, x.W, Ho, Wo, hid, oup, k1};
+        const double bytes = (double(x.rows()) * Cin * (res ? 2 : 1) + double(y.rows()) * oup) * sizeof(T);
+        const double flops = 2.0 * double(x.rows()) * Cin * hid + 2.0 * double(y.rows()) * hid * (9.0 + oup);
+        add_op(pfx + ".block", [mp, stride](hipStream_t s) { launch_mv2<T>(mp, stride, s); }, bytes, flops);
+        return true;
+    }
     A mv2block(const std::string& pfx, const A& x, int stride, int oup) {         // mobilevit.py:93-131 (expansion != 1)
         Lin l1 = lin(pfx + ".conv.0.weight", ""); fold_bn(l1, pfx + ".conv.1", 1e-5);
+        {
+            Lin l2f = lin(pfx + ".conv.6.weight", ""); fold_bn(l2f, pfx + ".conv.7", 1e-5);
+            if (l2f.N != oup) throw AchError{ACH_ERR_MISSING_KEY, "MV2 width at " + pfx};
+            A fy;
+            if (fused_mv2(pfx, x, stride, oup, l1, l2f, fy)) return fy;
+        }
         A hdn = alloc(x.B, x.H, x.W, l1.N);
         { GemmOpt o; o.act = ACT_SILU; gemm(pfx + ".pw1", x, pack(l1), hdn, o); }
         const int Ho = (x.H + 2 - 3) / stride + 1, Wo = (x.W + 2 - 3) / stride + 1;

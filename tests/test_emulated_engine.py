@@ -32,7 +32,7 @@ def _setup(name, res, batch, npts, seed=7):
 
 @pytest.mark.parametrize('name,res,batch,dtype,tol', [('en_s0', 64, 2, DTYPE_F32, 2e-5), ('en_s2', 64, 1, DTYPE_F32, 2e-5),
                                                      ('en_s0', 96, 1, DTYPE_BF16, 6e-2), ('mv_s2', 64, 1, DTYPE_F32, 2e-5),
-                                                     ('en_s0_cdf', 64, 1, DTYPE_F32, 2e-5), ('en_s0_cdf', 96, 1, DTYPE_BF16, 6e-2)])
+                                                     ('en_s0_cdf', 64, 1, DTYPE_F32, 2e-5), ('en_s0_cdf', 96, 1, DTYPE_BF16, 6e-2), ('mv_s2', 128, 1, DTYPE_BF16, 6e-2)])
 def test_emulated_forward_matches_oracle(name, res, batch, dtype, tol):
     npts = 48
     kw, sd, (x, xr, xp) = _setup(name, res, batch, npts)
@@ -270,3 +270,28 @@ def test_emulated_pipelined_forwards_match_plain():
     for a, b in zip(got, want):
         for u, v in zip(a, b):
             assert torch.equal(u, v)
+
+
+@pytest.mark.parametrize('dtype,tol', [(DTYPE_F32, 2e-5), (DTYPE_BF16, 6e-2)])
+def test_emulated_fused_mv2_blocks_agree_with_the_three_launches(dtype, tol):
+    """k_mv2.h (1x1 -> depthwise 3x3 -> 1x1 of a MobileViT MV2 block in one launch, hidden map in LDS) against the layer-wise
+    launches it replaces, stride 1 (with and without residual) and stride 2, 128x128 input (64x64 .. 16x16 maps: tiles cut by the border)."""
+    from achelous_amd.engine import NativeEngine
+    kw, sd, (x, xr, xp) = _setup('mv_s2', 128, 2, 16)
+    td = torch.float32 if dtype == DTYPE_F32 else torch.bfloat16
+    outs = []
+    for v in (1, 0):
+        eng = NativeEngine(emu_library(), num_det=kw['num_det'], num_seg=kw['num_seg'], phi=kw['phi'], backbone=kw['backbone'],
+                           resolution=kw['resolution'], pc_channels=kw['pc_channels'], pc_classes=kw['pc_classes'],
+                           num_points=16, nano_head=kw['nano_head'], spp=kw['spp'], dtype=dtype)
+        eng.set_option('fused_mv2', v)
+        eng.set_option('full_taps', 1)
+        eng.load_state_dict(sd)
+        eng.plan(2)
+        names = [o['op'] for o in eng.op_table_full()]
+        assert any(n.endswith('mv2.1.block') for n in names) == bool(v)
+        o = alloc_outputs(kw, 2, 16, td, 'cpu')
+        eng.forward(x.to(td), xr.to(td), xp.to(td), o)
+        outs.append([t.float() for t in o] + [eng.read_tap('map2'), eng.read_tap('map3')])
+    for a, b in zip(*outs):
+        assert rel_err(a, b) < tol
