@@ -10,6 +10,7 @@
 #define ACH_LAUNCH(kern, grid, block, stream, ...) \
     do { (void)(stream); hostemu::launch((grid), (block), [=]() { kern(__VA_ARGS__); }); } while (0)
 #define ACH_UNROLL
+#define ACH_NO_UNROLL
 namespace ach {
 struct f32x4 {
     float v[4];
@@ -21,6 +22,7 @@ struct f32x4 {
 #include <hip/hip_runtime.h>
 #define ACH_LAUNCH(kern, grid, block, stream, ...) hipLaunchKernelGGL(kern, (grid), (block), 0, (stream), __VA_ARGS__)
 #define ACH_UNROLL _Pragma("unroll")
+#define ACH_NO_UNROLL _Pragma("unroll 1")
 namespace ach {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 }  // namespace ach

@@ -42,7 +42,7 @@ template <> struct Mv2Tile<2, 4> { static constexpr int TW = 8, TH = 2; };      
 
 // HID: hidden width (64 | 128); NT2 = Cout / 16 (1 | 2 | 4).  Static LDS: region pixels x (HID elements + 16 B of padding).
 template <class T, int STRIDE, int HID, int NT2>
-__global__ __launch_bounds__(256) void mv2_kernel(const Mv2Params p) {
+__global__ __launch_bounds__(256, STRIDE == 2 ? 3 : 1) void mv2_kernel(const Mv2Params p) {
     constexpr int VEC = Store<T>::VEC, KC = 4 * VEC;
     constexpr int TW = Mv2Tile<STRIDE, int(sizeof(T))>::TW, TH = Mv2Tile<STRIDE, int(sizeof(T))>::TH;
     constexpr int RW = TW * STRIDE + (STRIDE == 1 ? 2 : 1), RH = TH * STRIDE + (STRIDE == 1 ? 2 : 1), RP = RW * RH;
@@ -94,20 +94,26 @@ __global__ __launch_bounds__(256) void mv2_kernel(const Mv2Params p) {
 
     // ---- phase 2: depthwise 3x3 + SiLU from LDS -> B fragments -> projection
     constexpr int PT = TW * TH / 16;                               // 16-pixel tiles of the output tile
-    constexpr int PPW = (PT + 3) / 4;                              // per wave
+    // four or more pixel tiles: a wave owns tiles wave, wave + 4, .. and runs every k-step.  Fewer (the stride-2 tiles): the waves
+    // split the K-STEPS of a tile between them as well, and the partial sums meet in LDS — otherwise half the workgroup idles here
+    constexpr int KSPLIT = PT >= 4 ? 1 : 4 / PT, KPER = KS2 / KSPLIT;
+    static_assert(KS2 % KSPLIT == 0, "k-steps must split evenly over the waves");
+    constexpr int PPW = KSPLIT == 1 ? (PT + 3) / 4 : 1;           // pixel tiles per wave
+    const int tile0 = KSPLIT == 1 ? wave : wave % PT, kpart = KSPLIT == 1 ? 0 : wave / PT;
     f32x4 acc[PPW][NT2];
     int rbase[PPW];                                                // LDS byte offset of the top-left tap of this lane's pixel
     ACH_UNROLL
     for (int q = 0; q < PPW; ++q) {
         ACH_UNROLL
         for (int t = 0; t < NT2; ++t) { acc[q][t][0] = acc[q][t][1] = acc[q][t][2] = acc[q][t][3] = 0.f; }
-        const int pt = wave + 4 * q, o = pt * 16 + px;
+        const int pt = tile0 + 4 * q, o = pt * 16 + px;
         const int oy = o / TW, ox = o - oy * TW;
         rbase[q] = ((oy * STRIDE) * RW + ox * STRIDE) * PITCH;
     }
     const uint4* W2 = static_cast<const uint4*>(p.W2) + lane;
-    ACH_UNROLL
-    for (int s = 0; s < KS2; ++s) {
+    ACH_NO_UNROLL                                                  // one k-step's 9 x VEC depthwise weights live at a time (register budget)
+    for (int si = 0; si < KPER; ++si) {
+        const int s = kpart * KPER + si;
         const int ch = s * KC + g * VEC;
         float wd[9][VEC], bd[VEC];
         ACH_UNROLL
@@ -124,7 +130,7 @@ __global__ __launch_bounds__(256) void mv2_kernel(const Mv2Params p) {
         for (int t = 0; t < NT2; ++t) wf[t] = W2[(t * KS2 + s) * 64];
         ACH_UNROLL
         for (int q = 0; q < PPW; ++q) {
-            if (wave + 4 * q >= PT) continue;
+            if (tile0 + 4 * q >= PT) continue;
             float a[VEC];
             ACH_UNROLL
             for (int j = 0; j < VEC; ++j) a[j] = bd[j];
@@ -143,10 +149,27 @@ __global__ __launch_bounds__(256) void mv2_kernel(const Mv2Params p) {
             for (int t = 0; t < NT2; ++t) mfma16<T>(wf[t], bf, acc[q][t]);
         }
     }
+    if (KSPLIT > 1) {                                              // partial sums of the k-step groups -> wave group 0, through the (now free) LDS tile
+        __syncthreads();
+        f32x4* part = reinterpret_cast<f32x4*>(hs);
+        if (kpart > 0) {
+            ACH_UNROLL
+            for (int t = 0; t < NT2; ++t) part[(((kpart - 1) * PT + tile0) * NT2 + t) * 64 + lane] = acc[0][t];
+        }
+        __syncthreads();
+        if (kpart > 0) return;
+        ACH_UNROLL
+        for (int kp = 1; kp < KSPLIT; ++kp)
+            ACH_UNROLL
+            for (int t = 0; t < NT2; ++t) {
+                const f32x4 v = part[(((kp - 1) * PT + tile0) * NT2 + t) * 64 + lane];
+                acc[0][t][0] += v[0]; acc[0][t][1] += v[1]; acc[0][t][2] += v[2]; acc[0][t][3] += v[3];
+            }
+    }
     // ---- epilogue: + bias [+ residual], one 4-channel store per 16-channel tile
     ACH_UNROLL
     for (int q = 0; q < PPW; ++q) {
-        const int pt = wave + 4 * q;
+        const int pt = tile0 + 4 * q;
         if (pt >= PT) continue;
         const int o = pt * 16 + px, oyl = o / TW, oxl = o - oyl * TW;
         const int oy = by + oyl, ox = bx + oxl;
