@@ -70,6 +70,7 @@ public:
     // (1.36 ms vs 1.66 ms): HIP's graph executor serialises more of the three-branch DAG than the streams do.
     bool use_graph = false;
     bool multi_stream = true;         // option "streams": run the independent radar / point branches on side streams
+    bool attn_mfma = true;            // option "attn_mfma": MobileViT attention scores / P.V on MFMA (k_mvit.h) instead of one query per thread
     bool fuse_mv2 = true;             // option "fused_mv2": MobileViT's MV2 blocks (1x1 -> dw3x3 -> 1x1) as one launch (k_mv2.h)
     bool fuse_mlp = true;             // option "fused_mlp": EdgeNeXt blocks as one kernel (k_mlp.h) instead of dw / pw1 / pw2 launches
     int split_decoders = 0;           // option "split_decoders": semantic decoder on side stream 3.  OFF: with the other branches at low

@@ -671,6 +671,10 @@ public:
             const int N = (t.H / 2) * (t.W / 2);
             const dim3 grid(unsigned(t.B * 4 * 4), unsigned(cdiv(N, 256))), block(256);
             if (N > MVIT_NMAX) throw AchError{ACH_ERR_UNSUPPORTED, "MobileViT attention: more than 1600 tokens per group"};
+            if (N <= 400 && attn_mfma) {                    // scores and P.V on the matrix cores (k_mvit.h), up to 256 queries per workgroup
+                add_op(a + ".attn", [ap, grid, block](hipStream_t s) { ACH_LAUNCH((mvit_attn_mfma_kernel<T, 400>), grid, block, s, ap); },
+                       double(t.rows()) * 128 * sizeof(T), 4.0 * double(t.rows()) * N * 8);
+            } else
             if (N <= 400) add_op(a + ".attn", [ap, grid, block](hipStream_t s) { ACH_LAUNCH((mvit_attn_kernel<T, 400>), grid, block, s, ap); }, double(t.rows()) * 128 * sizeof(T));
             else add_op(a + ".attn", [ap, grid, block](hipStream_t s) { ACH_LAUNCH((mvit_attn_kernel<T, MVIT_NMAX>), grid, block, s, ap); }, double(t.rows()) * 128 * sizeof(T));
             A t1 = alloc(t.B, t.H, t.W, D);

@@ -96,4 +96,102 @@ __global__ __launch_bounds__(256) void mvit_attn_kernel(const MvitAttnParams p) 
     Store<T>::st4(dst + 4, o1);
 }
 
+// ------------------------------------------------------------------------------------------ the same attention on the matrix cores
+// One workgroup = one (sample, patch group, head) and up to 256 queries; a wave takes 16 queries at a time.
+//   S^T = K Q^T   per 16 keys: A = the keys (16 x d), B = Q^T (d x 16 queries).  The accumulator layout puts a lane's four values on
+//                 four KEYS of one query, so exp2(S^T - max) of one (bf16: two) key tile(s), packed, IS the B fragment of
+//   O^T = V^T P^T : A = V^T (d x keys of the chunk), staged in LDS in exactly the key order the lanes hold.
+// The softmax is two-pass over the 400 (<= NMAX) keys — pass 1 recomputes nothing but the maxima (MFMA + max), pass 2 recomputes
+// the scores, exponentiates and accumulates — which costs 2 x 25 extra MFMAs per 16 queries and saves the online rescaling's
+// cross-lane traffic per chunk; the two reductions across the four lanes that share a query (max, sum) are two xor-shuffles each.
+// log2(e) is folded into the query scale (one v_exp_f32 per score).  Head width 8 uses a quarter (bf16) / half (fp32) of the MFMA's
+// k-range; the kernel is bound by the exponentials, not by the matrix cores.  Replaces one-query-per-thread VALU dot products:
+// 165 us -> see DESIGN (MV-GDF-PN-S2, 40x40 map, batch 64).
+template <class T, int NMAX>
+__global__ __launch_bounds__(256) void mvit_attn_mfma_kernel(const MvitAttnParams p) {
+    constexpr int VEC = Store<T>::VEC, CH = 4 * VEC;              // keys per P.V chunk: 32 (bf16) / 16 (fp32)
+    constexpr int NT = (NMAX + 15) / 16, NC = (NMAX + CH - 1) / CH;
+    __shared__ __attribute__((aligned(16))) T ks[NT * 16 * MVIT_DH];                 // [key][d]
+    __shared__ __attribute__((aligned(16))) T vt[NC * MVIT_DH * 4 * VEC];           // [chunk][d][g][j]: key(chunk, g, j) as the lanes hold them
+    const int h2 = p.H / 2, w2 = p.Wd / 2, N = h2 * w2;
+    int id = blockIdx.x;
+    const int head = id % p.heads; id /= p.heads;
+    const int grp = id % 4;
+    const long b = id / 4;
+    const int ph = grp >> 1, pw = grp & 1;
+    const int inner = p.heads * MVIT_DH;
+    const T* base = static_cast<const T*>(p.qkv) + b * p.H * long(p.Wd) * p.ld;
+    auto pixel = [&](int n) { return long(2 * (n / w2) + ph) * p.Wd + 2 * (n % w2) + pw; };
+    // key held by slot (g, j) of chunk c:  bf16: j < 4 -> tile 2c, row 4g + j ; j >= 4 -> tile 2c + 1, row 4g + j - 4.  fp32: tile c, row 4g + j
+    auto slot_key = [&](int c, int g, int j) { return VEC == 8 ? 32 * c + (j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4)) : 16 * c + 4 * g + j; };
+    const int ntiles = (N + 15) / 16, nchunks = (N + CH - 1) / CH;
+    for (int e = threadIdx.x; e < ntiles * 16; e += 256) {                            // keys (zero rows past N)
+        float a[4] = {0.f, 0.f, 0.f, 0.f}, c[4] = {0.f, 0.f, 0.f, 0.f};
+        if (e < N) { const T* src = base + pixel(e) * p.ld + inner + head * MVIT_DH; Store<T>::ld4(src, a); Store<T>::ld4(src + 4, c); }
+        Store<T>::st4(ks + e * MVIT_DH, a);
+        Store<T>::st4(ks + e * MVIT_DH + 4, c);
+    }
+    for (int e = threadIdx.x; e < nchunks * 4 * VEC; e += 256) {                      // values, transposed into the chunk's slot order
+        const int c = e / (4 * VEC), gj = e % (4 * VEC), g = gj / VEC, j = gj % VEC;
+        const int key = slot_key(c, g, j);
+        float a[4] = {0.f, 0.f, 0.f, 0.f}, d[4] = {0.f, 0.f, 0.f, 0.f};
+        if (key < N) { const T* src = base + pixel(key) * p.ld + 2 * inner + head * MVIT_DH; Store<T>::ld4(src, a); Store<T>::ld4(src + 4, d); }
+        ACH_UNROLL
+        for (int dv = 0; dv < 4; ++dv) { Store<T>::st(vt + ((c * MVIT_DH + dv) * 4 + g) * VEC + j, a[dv]); Store<T>::st(vt + ((c * MVIT_DH + 4 + dv) * 4 + g) * VEC + j, d[dv]); }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 15, g = lane >> 4;
+    const float sc = p.scale * 1.44269504088896341f;
+    const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
+    // the lane's share of a K fragment (A operand: row = key, k = d): bf16: g == 0 holds d 0..7 ; fp32: g < 2 hold d 4g .. 4g+3
+    auto kfrag = [&](int t) -> uint4 {
+        if (VEC == 8) return g == 0 ? *reinterpret_cast<const uint4*>(ks + (t * 16 + col) * MVIT_DH) : zero;
+        return g < 2 ? *reinterpret_cast<const uint4*>(ks + (t * 16 + col) * MVIT_DH + 4 * g) : zero;
+    };
+    for (int qt = blockIdx.y * 16 + wave; qt < ntiles && qt < int(blockIdx.y + 1) * 16; qt += 4) {
+        const int n = qt * 16 + col, nq = n < N ? n : N - 1;
+        uint4 qf = zero;                                                              // B operand: k = d, column = query
+        {
+            const T* src = base + pixel(nq) * p.ld + head * MVIT_DH;
+            float q8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (VEC == 8) { if (g == 0) { float a[4], c[4]; Store<T>::ld4(src, a); Store<T>::ld4(src + 4, c); for (int i = 0; i < 4; ++i) { q8[i] = a[i] * sc; q8[4 + i] = c[i] * sc; } qf = frag_pack<T>(q8); } }
+            else if (g < 2) { float a[4]; Store<T>::ld4(src + 4 * g, a); for (int i = 0; i < 4; ++i) q8[i] = a[i] * sc; qf = frag_pack<T>(q8); }
+        }
+        // pass 1: the query's maximum score
+        float m = -3.0e38f;
+        for (int t = 0; t < ntiles; ++t) {
+            f32x4 s4; s4[0] = s4[1] = s4[2] = s4[3] = 0.f;
+            mfma16<T>(kfrag(t), qf, s4);
+            ACH_UNROLL
+            for (int r = 0; r < 4; ++r) if (t * 16 + g * 4 + r < N) m = fmaxf(m, s4[r]);
+        }
+        m = fmaxf(m, __shfl_xor(m, 16));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        // pass 2: P^T = exp2(S^T - m) chunk by chunk, O^T += V^T P^T
+        float l = 0.f;
+        f32x4 o4; o4[0] = o4[1] = o4[2] = o4[3] = 0.f;
+        for (int c = 0; c < nchunks; ++c) {
+            float pj[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            ACH_UNROLL
+            for (int u = 0; u < VEC / 4; ++u) {
+                const int t = c * (VEC / 4) + u;
+                f32x4 s4; s4[0] = s4[1] = s4[2] = s4[3] = 0.f;
+                if (t < ntiles) mfma16<T>(kfrag(t), qf, s4);
+                ACH_UNROLL
+                for (int r = 0; r < 4; ++r) { const float e = (t * 16 + g * 4 + r < N) ? fast_exp2(s4[r] - m) : 0.f; pj[4 * u + r] = e; l += e; }
+            }
+            const uint4 vf = col < MVIT_DH ? *reinterpret_cast<const uint4*>(vt + ((c * MVIT_DH + col) * 4 + g) * VEC) : zero;      // A: row = d, k = slot
+            mfma16<T>(vf, frag_pack<T>(pj), o4);
+        }
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        if (n < N && g < 2) {                                                          // rows (d) 4g .. 4g+3 of this query's column
+            const float inv = 1.0f / l;
+            const float o[4] = {o4[0] * inv, o4[1] * inv, o4[2] * inv, o4[3] * inv};
+            Store<T>::st4(static_cast<T*>(p.Y) + (b * p.H * long(p.Wd) + pixel(n)) * p.ldy + head * MVIT_DH + 4 * g, o);
+        }
+    }
+}
+
 }  // namespace ach

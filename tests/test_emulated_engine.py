@@ -273,6 +273,29 @@ def test_emulated_pipelined_forwards_match_plain():
 
 
 @pytest.mark.parametrize('dtype,tol', [(DTYPE_F32, 2e-5), (DTYPE_BF16, 6e-2)])
+def test_emulated_mfma_attention_agrees_with_the_per_thread_kernel(dtype, tol):
+    """MobileViT attention on the matrix cores (S^T = K Q^T, softmax output used as the B operand of V^T P^T, two-pass softmax) against
+    the one-query-per-thread online-softmax kernel, 128x128 input: 64 / 16 / 4 tokens per group (partial key tiles and chunks)."""
+    from achelous_amd.engine import NativeEngine
+    kw, sd, (x, xr, xp) = _setup('mv_s2', 128, 1, 16)
+    td = torch.float32 if dtype == DTYPE_F32 else torch.bfloat16
+    outs = []
+    for v in (1, 0):
+        eng = NativeEngine(emu_library(), num_det=kw['num_det'], num_seg=kw['num_seg'], phi=kw['phi'], backbone=kw['backbone'],
+                           resolution=kw['resolution'], pc_channels=kw['pc_channels'], pc_classes=kw['pc_classes'],
+                           num_points=16, nano_head=kw['nano_head'], spp=kw['spp'], dtype=dtype)
+        eng.set_option('attn_mfma', v)
+        eng.set_option('full_taps', 1)
+        eng.load_state_dict(sd)
+        eng.plan(1)
+        o = alloc_outputs(kw, 1, 16, td, 'cpu')
+        eng.forward(x.to(td), xr.to(td), xp.to(td), o)
+        outs.append([t.float() for t in o] + [eng.read_tap('map3'), eng.read_tap('map4'), eng.read_tap('map5')])
+    for a, b in zip(*outs):
+        assert rel_err(a, b) < tol
+
+
+@pytest.mark.parametrize('dtype,tol', [(DTYPE_F32, 2e-5), (DTYPE_BF16, 6e-2)])
 def test_emulated_fused_mv2_blocks_agree_with_the_three_launches(dtype, tol):
     """k_mv2.h (1x1 -> depthwise 3x3 -> 1x1 of a MobileViT MV2 block in one launch, hidden map in LDS) against the layer-wise
     launches it replaces, stride 1 (with and without residual) and stride 2, 128x128 input (64x64 .. 16x16 maps: tiles cut by the border)."""
