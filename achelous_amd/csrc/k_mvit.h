@@ -158,20 +158,39 @@ __global__ __launch_bounds__(256) void mvit_attn_mfma_kernel(const MvitAttnParam
             if (VEC == 8) { if (g == 0) { float a[4], c[4]; Store<T>::ld4(src, a); Store<T>::ld4(src + 4, c); for (int i = 0; i < 4; ++i) { q8[i] = a[i] * sc; q8[4 + i] = c[i] * sc; } qf = frag_pack<T>(q8); } }
             else if (g < 2) { float a[4]; Store<T>::ld4(src + 4 * g, a); for (int i = 0; i < 4; ++i) q8[i] = a[i] * sc; qf = frag_pack<T>(q8); }
         }
-        // pass 1: the query's maximum score
+        // pass 1: the query's maximum score (full key tiles need no mask; a last partial tile is masked)
+        const int full_tiles = N / 16;
         float m = -3.0e38f;
-        for (int t = 0; t < ntiles; ++t) {
+        for (int t = 0; t < full_tiles; ++t) {
             f32x4 s4; s4[0] = s4[1] = s4[2] = s4[3] = 0.f;
             mfma16<T>(kfrag(t), qf, s4);
+            m = fmaxf(fmaxf(m, fmaxf(s4[0], s4[1])), fmaxf(s4[2], s4[3]));
+        }
+        if (full_tiles < ntiles) {
+            f32x4 s4; s4[0] = s4[1] = s4[2] = s4[3] = 0.f;
+            mfma16<T>(kfrag(full_tiles), qf, s4);
             ACH_UNROLL
-            for (int r = 0; r < 4; ++r) if (t * 16 + g * 4 + r < N) m = fmaxf(m, s4[r]);
+            for (int r = 0; r < 4; ++r) if (full_tiles * 16 + g * 4 + r < N) m = fmaxf(m, s4[r]);
         }
         m = fmaxf(m, __shfl_xor(m, 16));
         m = fmaxf(m, __shfl_xor(m, 32));
         // pass 2: P^T = exp2(S^T - m) chunk by chunk, O^T += V^T P^T
         float l = 0.f;
         f32x4 o4; o4[0] = o4[1] = o4[2] = o4[3] = 0.f;
-        for (int c = 0; c < nchunks; ++c) {
+        const int full_chunks = N / CH;
+        for (int c = 0; c < full_chunks; ++c) {
+            float pj[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            ACH_UNROLL
+            for (int u = 0; u < VEC / 4; ++u) {
+                f32x4 s4; s4[0] = s4[1] = s4[2] = s4[3] = 0.f;
+                mfma16<T>(kfrag(c * (VEC / 4) + u), qf, s4);
+                ACH_UNROLL
+                for (int r = 0; r < 4; ++r) { const float e = fast_exp2(s4[r] - m); pj[4 * u + r] = e; l += e; }
+            }
+            const uint4 vf = col < MVIT_DH ? *reinterpret_cast<const uint4*>(vt + ((c * MVIT_DH + col) * 4 + g) * VEC) : zero;      // A: row = d, k = slot
+            mfma16<T>(vf, frag_pack<T>(pj), o4);
+        }
+        for (int c = full_chunks; c < nchunks; ++c) {                                  // the last, partial chunk
             float pj[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             ACH_UNROLL
             for (int u = 0; u < VEC / 4; ++u) {
@@ -181,7 +200,7 @@ __global__ __launch_bounds__(256) void mvit_attn_mfma_kernel(const MvitAttnParam
                 ACH_UNROLL
                 for (int r = 0; r < 4; ++r) { const float e = (t * 16 + g * 4 + r < N) ? fast_exp2(s4[r] - m) : 0.f; pj[4 * u + r] = e; l += e; }
             }
-            const uint4 vf = col < MVIT_DH ? *reinterpret_cast<const uint4*>(vt + ((c * MVIT_DH + col) * 4 + g) * VEC) : zero;      // A: row = d, k = slot
+            const uint4 vf = col < MVIT_DH ? *reinterpret_cast<const uint4*>(vt + ((c * MVIT_DH + col) * 4 + g) * VEC) : zero;
             mfma16<T>(vf, frag_pack<T>(pj), o4);
         }
         l += __shfl_xor(l, 16);
