@@ -1,9 +1,11 @@
 // api.cpp — the extern "C" boundary of libachelous_hip.so (declared in include/achelous.h).
 // No exception crosses it: every failure becomes a negative code + a message retrievable with ach_last_error().
 #include <cstring>
+#include <functional>
 #include <string>
 
 #include "engine.h"
+#include "k_train.h"
 
 struct ach_handle {
     ach::EngineBase* eng = nullptr;
@@ -199,6 +201,47 @@ int ach_correct_boxes(ach_handle* h, int32_t batch, int32_t max_det, const float
     return guarded(h, [&] {
         if (batch <= 0 || max_det <= 0 || image_h <= 0 || image_w <= 0 || !rows || !count || !out_rows) throw ach::AchError{ACH_ERR_INVALID, "bad correct_boxes arguments"};
         h->eng->correct_boxes(batch, max_det, rows, count, image_h, image_w, letterbox, out_rows, static_cast<hipStream_t>(stream));
+    });
+}
+
+// ---- training-mode kernels (k_train.h): stateless, fp32, no handle
+static int train_guard(const std::function<void()>& fn) {
+    try { fn(); hipError_t e = hipGetLastError(); if (e != hipSuccess) { g_create_error = std::string("kernel launch: ") + hipGetErrorString(e); return ACH_ERR_DEVICE; } return ACH_OK; }
+    catch (const ach::AchError& e) { g_create_error = e.msg; return e.code; }
+    catch (const std::exception& e) { g_create_error = e.what(); return ACH_ERR_INVALID; }
+}
+int ach_train_gemm(const float* A, const float* B, float* C, const float* bias, int32_t M, int32_t N, int32_t K, int64_t lda, int64_t ldb, int64_t ldc,
+                   int64_t stride_a, int64_t stride_b, int64_t stride_c, int32_t trans_a, int32_t trans_b, int32_t batch, int32_t reduce_batch,
+                   int32_t accumulate, void* stream) {
+    return train_guard([&] {
+        if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0) throw ach::AchError{ACH_ERR_INVALID, "bad train_gemm arguments"};
+        ach::TrainGemmParams p{A, B, C, bias, M, N, K, long(lda), long(ldb), long(ldc), long(stride_a), long(stride_b), long(stride_c), trans_a, trans_b, batch, reduce_batch, accumulate};
+        const dim3 grid(unsigned((N + 63) / 64), unsigned((M + 63) / 64), unsigned(reduce_batch ? 1 : batch));
+        ACH_LAUNCH(ach::train_gemm_kernel, grid, dim3(256), static_cast<hipStream_t>(stream), p);
+    });
+}
+int ach_train_bn_stats(const float* z, float* mean, float* var, int32_t B, int32_t C, int32_t N, void* stream) {
+    return train_guard([&] {
+        if (!z || !mean || !var || B <= 0 || C <= 0 || N <= 0) throw ach::AchError{ACH_ERR_INVALID, "bad train_bn_stats arguments"};
+        ach::BnStatsParams p{z, mean, var, B, C, N};
+        ACH_LAUNCH(ach::train_bn_stats_kernel, dim3(unsigned(C)), dim3(256), static_cast<hipStream_t>(stream), p);
+    });
+}
+int ach_train_bn_relu_fwd(const float* z, const float* mean, const float* var, const float* gamma, const float* beta, float* y, int32_t B, int32_t C,
+                          int32_t N, float eps, int32_t relu, void* stream) {
+    return train_guard([&] {
+        if (!z || !mean || !var || !gamma || !beta || !y || B <= 0 || C <= 0 || N <= 0) throw ach::AchError{ACH_ERR_INVALID, "bad train_bn_relu_fwd arguments"};
+        ach::BnReluFwdParams p{z, mean, var, gamma, beta, y, B, C, N, eps, relu};
+        ACH_LAUNCH(ach::train_bn_relu_fwd_kernel, dim3(unsigned(ach::cdivl(long(B) * C * N, 256))), dim3(256), static_cast<hipStream_t>(stream), p);
+    });
+}
+int ach_train_bn_relu_bwd(const float* z, const float* y, const float* dy, const float* mean, const float* var, const float* gamma, float* dgamma,
+                          float* dbeta, float* dz, int32_t B, int32_t C, int32_t N, float eps, int32_t relu, void* stream) {
+    return train_guard([&] {
+        if (!z || !y || !dy || !mean || !var || !gamma || !dgamma || !dbeta || !dz || B <= 0 || C <= 0 || N <= 0) throw ach::AchError{ACH_ERR_INVALID, "bad train_bn_relu_bwd arguments"};
+        ach::BnReluBwdParams p{z, y, dy, mean, var, gamma, dgamma, dbeta, dz, B, C, N, eps, relu};
+        ACH_LAUNCH(ach::train_bn_relu_bwd_reduce_kernel, dim3(unsigned(C)), dim3(256), static_cast<hipStream_t>(stream), p);
+        ACH_LAUNCH(ach::train_bn_relu_bwd_apply_kernel, dim3(unsigned(ach::cdivl(long(B) * C * N, 256))), dim3(256), static_cast<hipStream_t>(stream), p);
     });
 }
 

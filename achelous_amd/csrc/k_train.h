@@ -1,0 +1,160 @@
+// k_train.h — first training-mode kernels: the PointNet "shared MLP" layer
+//     y = relu(BatchNorm1d(Conv1d_k1(x)))        x [B, Cin, N] -> y [B, Cout, N]      (pointnet_utils.py:29-31, 69-71, 124-127;
+// pointnet_sem_seg.py:31-33) in TRAINING mode — batch statistics over (B, N), running statistics updated — forward and backward.
+// The reference trains it through ATen autograd (utils/utils_fit.py:37-166); here the same arithmetic is four kernels in fp32:
+//   train_gemm      C[b] (+)= op(A[b]) op(B[b]) on fp32 MFMA (v_mfma_f32_16x16x4_f32), LDS-staged 64 x 64 x 16 tiles, any transposition,
+//                   optional reduction over the batch (the weight gradient sums over samples) and row bias
+//   bn_stats        per channel mean / biased variance over (B, N), two passes (mean, then centred squares)
+//   bn_relu_fwd     y = [relu](gamma * (z - mean) * rstd + beta)
+//   bn_relu_bwd_*   g = dy * (y > 0); dbeta = sum g, dgamma = sum g * xhat;  dz = gamma * rstd * (g - dbeta / M - xhat * dgamma / M)
+// Inference keeps its own folded / fused path; these exist so that `.train()` can be built block by block.
+#pragma once
+#include "ach_platform.h"
+
+namespace ach {
+
+struct TrainGemmParams {
+    const float* A; const float* B; float* C; const float* bias;   // bias: per ROW of C (output channel) or nullptr
+    int M, N, K;                      // C is M x N
+    long lda, ldb, ldc;               // leading dimensions of the STORED matrices (row-major)
+    long sA, sB, sC;                  // batch strides (0: shared)
+    int transA, transB;               // stored A is K x M / stored B is N x K
+    int batch, reduce_batch;          // reduce_batch: C = sum_b op(A[b]) op(B[b])  (one output, grid.z = 1)
+    int accumulate;                   // C += instead of C =
+};
+
+// 256 threads = 4 waves; wave w owns the 32 x 32 quadrant (w >> 1, w & 1) of the 64 x 64 block tile: 2 x 2 MFMA tiles.
+static __global__ __launch_bounds__(256) void train_gemm_kernel(const TrainGemmParams p) {
+    constexpr int TM = 64, TN = 64, TK = 16, PAD = 4;
+    __shared__ float As[TK][TM + PAD];
+    __shared__ float Bs[TK][TN + PAD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    const int li = lane & 15, lk = lane >> 4;
+    f32x4 acc[2][2];
+    ACH_UNROLL
+    for (int i = 0; i < 2; ++i)
+        ACH_UNROLL
+        for (int j = 0; j < 2; ++j) { acc[i][j][0] = acc[i][j][1] = acc[i][j][2] = acc[i][j][3] = 0.f; }
+    const int b_lo = p.reduce_batch ? 0 : int(blockIdx.z), b_hi = p.reduce_batch ? p.batch : int(blockIdx.z) + 1;
+    for (int b = b_lo; b < b_hi; ++b) {
+        const float* A = p.A + long(b) * p.sA;
+        const float* B = p.B + long(b) * p.sB;
+        for (int k0 = 0; k0 < p.K; k0 += TK) {
+            // stage the two tiles k-major; each thread moves 4 elements of A and 4 of B (64 x 16 = 1024 each)
+            ACH_UNROLL
+            for (int e = 0; e < 4; ++e) {
+                const int idx = tid + e * 256;
+                {   // A: element (m, k)
+                    const int m = p.transA ? idx % TM : idx / TK, k = p.transA ? idx / TM : idx % TK;      // walk the contiguous index of the stored matrix fastest
+                    const int gm = m0 + m, gk = k0 + k;
+                    float v = 0.f;
+                    if (gm < p.M && gk < p.K) v = p.transA ? A[long(gk) * p.lda + gm] : A[long(gm) * p.lda + gk];
+                    As[k][m] = v;
+                }
+                {   // B: element (k, n)
+                    const int n = p.transB ? idx / TK : idx % TN, k = p.transB ? idx % TK : idx / TN;
+                    const int gn = n0 + n, gk = k0 + k;
+                    float v = 0.f;
+                    if (gn < p.N && gk < p.K) v = p.transB ? B[long(gn) * p.ldb + gk] : B[long(gk) * p.ldb + gn];
+                    Bs[k][n] = v;
+                }
+            }
+            __syncthreads();
+            ACH_UNROLL
+            for (int i = 0; i < 2; ++i) {
+                const uint4 a = make_uint4(__float_as_uint(As[lk][wm + 16 * i + li]), __float_as_uint(As[4 + lk][wm + 16 * i + li]),
+                                           __float_as_uint(As[8 + lk][wm + 16 * i + li]), __float_as_uint(As[12 + lk][wm + 16 * i + li]));
+                ACH_UNROLL
+                for (int j = 0; j < 2; ++j) {
+                    const uint4 bb = make_uint4(__float_as_uint(Bs[lk][wn + 16 * j + li]), __float_as_uint(Bs[4 + lk][wn + 16 * j + li]),
+                                                __float_as_uint(Bs[8 + lk][wn + 16 * j + li]), __float_as_uint(Bs[12 + lk][wn + 16 * j + li]));
+                    mfma16<float>(a, bb, acc[i][j]);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    float* C = p.C + (p.reduce_batch ? 0L : long(blockIdx.z) * p.sC);
+    ACH_UNROLL
+    for (int i = 0; i < 2; ++i)
+        ACH_UNROLL
+        for (int j = 0; j < 2; ++j)
+            ACH_UNROLL
+            for (int r = 0; r < 4; ++r) {
+                const int gm = m0 + wm + 16 * i + lk * 4 + r, gn = n0 + wn + 16 * j + li;
+                if (gm < p.M && gn < p.N) {
+                    float v = acc[i][j][r] + (p.bias ? p.bias[gm] : 0.f);
+                    float* c = C + long(gm) * p.ldc + gn;
+                    *c = p.accumulate ? *c + v : v;
+                }
+            }
+}
+
+// ---- BatchNorm over (B, N) of z [B, C, N]: one workgroup per channel
+struct BnStatsParams { const float* Z; float* mean; float* var; int B, C, N; };        // var: biased
+static __global__ __launch_bounds__(256) void train_bn_stats_kernel(const BnStatsParams p) {
+    __shared__ float red[256];
+    __shared__ float s_mean;
+    const int c = blockIdx.x;
+    const long total = long(p.B) * p.N;
+    float s = 0.f;
+    for (long i = threadIdx.x; i < total; i += 256) s += p.Z[((i / p.N) * p.C + c) * p.N + i % p.N];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) { if (int(threadIdx.x) < st) red[threadIdx.x] += red[threadIdx.x + st]; __syncthreads(); }
+    if (threadIdx.x == 0) s_mean = red[0] / float(total);
+    __syncthreads();
+    const float mean = s_mean;
+    float q = 0.f;
+    for (long i = threadIdx.x; i < total; i += 256) { const float d = p.Z[((i / p.N) * p.C + c) * p.N + i % p.N] - mean; q += d * d; }
+    __syncthreads();
+    red[threadIdx.x] = q;
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) { if (int(threadIdx.x) < st) red[threadIdx.x] += red[threadIdx.x + st]; __syncthreads(); }
+    if (threadIdx.x == 0) { p.mean[c] = mean; p.var[c] = red[0] / float(total); }
+}
+
+struct BnReluFwdParams { const float* Z; const float* mean; const float* var; const float* gamma; const float* beta; float* Y; int B, C, N; float eps; int relu; };
+static __global__ __launch_bounds__(256) void train_bn_relu_fwd_kernel(const BnReluFwdParams p) {
+    const long idx = long(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (idx >= long(p.B) * p.C * p.N) return;
+    const int c = int((idx / p.N) % p.C);
+    const float v = p.gamma[c] * ((p.Z[idx] - p.mean[c]) * (1.0f / sqrtf(p.var[c] + p.eps))) + p.beta[c];
+    p.Y[idx] = (p.relu && v < 0.f) ? 0.f : v;
+}
+
+// backward, step 1: per channel  dbeta = sum g,  dgamma = sum g * xhat   with g = dy * (y > 0 | no relu)
+struct BnReluBwdParams {
+    const float* Z; const float* Y; const float* dY; const float* mean; const float* var; const float* gamma;
+    float* dgamma; float* dbeta; float* dZ; int B, C, N; float eps; int relu;
+};
+static __global__ __launch_bounds__(256) void train_bn_relu_bwd_reduce_kernel(const BnReluBwdParams p) {
+    __shared__ float r0[256], r1[256];
+    const int c = blockIdx.x;
+    const long total = long(p.B) * p.N;
+    const float mean = p.mean[c], rstd = 1.0f / sqrtf(p.var[c] + p.eps);
+    float sb = 0.f, sg = 0.f;
+    for (long i = threadIdx.x; i < total; i += 256) {
+        const long o = ((i / p.N) * p.C + c) * p.N + i % p.N;
+        const float g = (p.relu && !(p.Y[o] > 0.f)) ? 0.f : p.dY[o];
+        sb += g; sg += g * ((p.Z[o] - mean) * rstd);
+    }
+    r0[threadIdx.x] = sb; r1[threadIdx.x] = sg;
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) { if (int(threadIdx.x) < st) { r0[threadIdx.x] += r0[threadIdx.x + st]; r1[threadIdx.x] += r1[threadIdx.x + st]; } __syncthreads(); }
+    if (threadIdx.x == 0) { p.dbeta[c] = r0[0]; p.dgamma[c] = r1[0]; }
+}
+// step 2: dz = gamma * rstd * (g - dbeta / M - xhat * dgamma / M)
+static __global__ __launch_bounds__(256) void train_bn_relu_bwd_apply_kernel(const BnReluBwdParams p) {
+    const long idx = long(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (idx >= long(p.B) * p.C * p.N) return;
+    const int c = int((idx / p.N) % p.C);
+    const float rstd = 1.0f / sqrtf(p.var[c] + p.eps), xhat = (p.Z[idx] - p.mean[c]) * rstd;
+    const float g = (p.relu && !(p.Y[idx] > 0.f)) ? 0.f : p.dY[idx];
+    const float invM = 1.0f / float(long(p.B) * p.N);
+    p.dZ[idx] = p.gamma[c] * rstd * (g - p.dbeta[c] * invM - xhat * p.dgamma[c] * invM);
+}
+
+}  // namespace ach

@@ -191,6 +191,23 @@ int ach_read_probe(ach_handle* h, float* avg_ms, int* samples);
 int ach_set_probe_range(ach_handle* h, int slot, int first, int last);
 int ach_read_probe_slot(ach_handle* h, int slot, float* avg_ms, int* samples);
 
+/* ---- training mode, first block (utils/utils_fit.py:37-166 trains through ATen autograd).
+ * Stateless fp32 kernels (no handle; errors through ach_last_error(NULL)) for the PointNet shared-MLP layer
+ * relu(BatchNorm1d(Conv1d_k1(x))) on [B, C, N] tensors in TRAINING mode — batch statistics — forward and backward:
+ *   ach_train_gemm         C[b] (+)= op(A[b]) op(B[b]) [+ bias per row]: row-major, leading dimensions and batch strides in elements,
+ *                          trans_x = the stored matrix is the transpose; reduce_batch sums the products over the batch into ONE C
+ *   ach_train_bn_stats     mean / biased variance per channel over (B, N)
+ *   ach_train_bn_relu_fwd  y = [relu](gamma * (z - mean) / sqrt(var + eps) + beta)
+ *   ach_train_bn_relu_bwd  dgamma, dbeta and dz from dy (z, y, mean, var of the forward) */
+int ach_train_gemm(const float* A, const float* B, float* C, const float* bias, int32_t M, int32_t N, int32_t K, int64_t lda, int64_t ldb, int64_t ldc,
+                   int64_t stride_a, int64_t stride_b, int64_t stride_c, int32_t trans_a, int32_t trans_b, int32_t batch, int32_t reduce_batch,
+                   int32_t accumulate, void* stream);
+int ach_train_bn_stats(const float* z, float* mean, float* var, int32_t B, int32_t C, int32_t N, void* stream);
+int ach_train_bn_relu_fwd(const float* z, const float* mean, const float* var, const float* gamma, const float* beta, float* y, int32_t B, int32_t C,
+                          int32_t N, float eps, int32_t relu, void* stream);
+int ach_train_bn_relu_bwd(const float* z, const float* y, const float* dy, const float* mean, const float* var, const float* gamma, float* dgamma,
+                          float* dbeta, float* dz, int32_t B, int32_t C, int32_t N, float eps, int32_t relu, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
