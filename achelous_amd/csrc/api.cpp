@@ -245,6 +245,21 @@ int ach_train_bn_relu_bwd(const float* z, const float* y, const float* dy, const
     });
 }
 
+int ach_train_dw3x3(const float* x, const float* w, float* y, int32_t B, int32_t C, int32_t H, int32_t W, int32_t flip, void* stream) {
+    return train_guard([&] {
+        if (!x || !w || !y || B <= 0 || C <= 0 || H <= 0 || W <= 0) throw ach::AchError{ACH_ERR_INVALID, "bad train_dw3x3 arguments"};
+        ach::DwTrainParams p{x, w, y, B, C, H, W, flip};
+        ACH_LAUNCH(ach::train_dw3x3_kernel, dim3(unsigned(ach::cdivl(long(B) * C * H * W, 256))), dim3(256), static_cast<hipStream_t>(stream), p);
+    });
+}
+int ach_train_dw3x3_wgrad(const float* x, const float* dz, float* dw, int32_t B, int32_t C, int32_t H, int32_t W, void* stream) {
+    return train_guard([&] {
+        if (!x || !dz || !dw || B <= 0 || C <= 0 || H <= 0 || W <= 0) throw ach::AchError{ACH_ERR_INVALID, "bad train_dw3x3_wgrad arguments"};
+        ach::DwWgradParams p{x, dz, dw, B, C, H, W};
+        ACH_LAUNCH(ach::train_dw3x3_wgrad_kernel, dim3(unsigned(C)), dim3(256), static_cast<hipStream_t>(stream), p);
+    });
+}
+
 int ach_tap_count(const ach_handle* h) { return (h && h->eng) ? int(h->eng->tap_order.size()) : 0; }
 const char* ach_tap_name(const ach_handle* h, int i) {
     if (!h || !h->eng || i < 0 || i >= int(h->eng->tap_order.size())) return nullptr;

@@ -157,4 +157,51 @@ static __global__ __launch_bounds__(256) void train_bn_relu_bwd_apply_kernel(con
     p.dZ[idx] = p.gamma[c] * rstd * (g - p.dbeta[c] * invM - xhat * p.dgamma[c] * invM);
 }
 
+// ---- depthwise 3x3, stride 1, pad 1 on [B, C, H, W] (GhostModule's cheap operation, the GhostBottleneck shortcut: ghost_conv.py:19-23,47-56)
+//   forward            y = w (*) x                      (flip = 0)
+//   input gradient     dx = flipped(w) (*) dz           (flip = 1: the same kernel on the gradient with the taps mirrored)
+//   weight gradient    dw[c][t] = sum_{b,y,x} dz[b,c,y,x] * x[b,c,y+ty-1,x+tx-1]    one workgroup per channel
+struct DwTrainParams { const float* X; const float* W; float* Y; int B, C, H, Wd, flip; };
+static __global__ __launch_bounds__(256) void train_dw3x3_kernel(const DwTrainParams p) {
+    const long idx = long(blockIdx.x) * blockDim.x + threadIdx.x;
+    const long HW = long(p.H) * p.Wd;
+    if (idx >= long(p.B) * p.C * HW) return;
+    const int x = int(idx % p.Wd), y = int((idx / p.Wd) % p.H), c = int((idx / HW) % p.C);
+    const float* plane = p.X + (idx / HW) * HW;
+    const float* w = p.W + c * 9;
+    float acc = 0.f;
+    ACH_UNROLL
+    for (int t = 0; t < 9; ++t) {
+        const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
+        if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.Wd) acc += w[p.flip ? 8 - t : t] * plane[long(iy) * p.Wd + ix];
+    }
+    p.Y[idx] = acc;
+}
+struct DwWgradParams { const float* X; const float* dZ; float* dW; int B, C, H, Wd; };
+static __global__ __launch_bounds__(256) void train_dw3x3_wgrad_kernel(const DwWgradParams p) {
+    __shared__ float red[9][256];
+    const int c = blockIdx.x;
+    const long HW = long(p.H) * p.Wd, total = long(p.B) * HW;
+    float acc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (long i = threadIdx.x; i < total; i += 256) {
+        const long b = i / HW, pix = i % HW;
+        const int y = int(pix / p.Wd), x = int(pix % p.Wd);
+        const float g = p.dZ[(b * p.C + c) * HW + pix];
+        const float* plane = p.X + (b * p.C + c) * HW;
+        ACH_UNROLL
+        for (int t = 0; t < 9; ++t) {
+            const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
+            if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.Wd) acc[t] += g * plane[long(iy) * p.Wd + ix];
+        }
+    }
+    ACH_UNROLL
+    for (int t = 0; t < 9; ++t) red[t][threadIdx.x] = acc[t];
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) {
+        if (int(threadIdx.x) < st) { ACH_UNROLL for (int t = 0; t < 9; ++t) red[t][threadIdx.x] += red[t][threadIdx.x + st]; }
+        __syncthreads();
+    }
+    if (threadIdx.x < 9) p.dW[c * 9 + threadIdx.x] = red[threadIdx.x][0];
+}
+
 }  // namespace ach

@@ -7,7 +7,13 @@ the unfolded arithmetic, batch statistics and gradients.  This module starts tha
     SharedMLP1d(cin, cout, relu=True)(x)  ==  relu(BatchNorm1d(cout)(Conv1d(cin, cout, 1)(x)))        x [B, cin, N]
     (pointnet_utils.py:29-31, 69-71, 124-127; pointnet_sem_seg.py:31-33 — twelve of PointNet's layers; 1.9 M of the model's 3.6 M parameters)
 
-as a `torch.autograd.Function` over the kernels of csrc/k_train.h (fp32 MFMA GEMMs for z = W x, dx = W^T dz, dW = sum_b dz x^T;
+and the Ghost blocks of the neck and decoders (backbone/conv_utils/ghost_conv.py: `GhostModule` :6-29, `GhostBottleneck` :32-70, stride 1)
+
+    GhostModule(inp, oup, relu)(x), GhostBottleneck(in_chs, mid_chs, out_chs)(x)                       x [B, inp, H, W]
+
+built from two native layers: 1x1 conv + BatchNorm2d [+ ReLU] (the same Function as the shared MLP, on [B, C, H*W]) and depthwise 3x3
++ BatchNorm2d [+ ReLU]; `torch.cat`, the channel slice and the residual add between them are tensor views / adds whose gradients
+autograd routes.  All of it as `torch.autograd.Function`s over the kernels of csrc/k_train.h (fp32 MFMA GEMMs for z = W x, dx = W^T dz, dW = sum_b dz x^T;
 batch statistics; normalise + ReLU; their backward).  In training mode it normalises with the batch statistics and updates
 `running_mean` / `running_var` exactly as `nn.BatchNorm1d` does (momentum 0.1, unbiased variance into the running estimate); in eval
 mode it uses the running statistics.  Parameter names (`conv.weight [cout,cin,1]`, `conv.bias`, `bn.weight`, ...) are those of the
@@ -114,3 +120,120 @@ class SharedMLP1d(nn.Module):
             bn.num_batches_tracked += 1
         return _SharedMLP1dFn.apply(x, self.conv.weight, self.conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                     self.training, bn.momentum, bn.eps, self.relu)
+
+
+def _bn_train_fwd(lib, L, s, z3, gamma, beta, running_mean, running_var, training, momentum, eps, relu):
+    """Shared tail of the conv + BatchNorm [+ ReLU] Functions on z3 [B, C, N]: statistics, running update, normalise."""
+    B, C, N = z3.shape
+    mean = torch.empty(C, dtype=torch.float32, device=z3.device)
+    var = torch.empty(C, dtype=torch.float32, device=z3.device)
+    if training:
+        _check(lib, L.ach_train_bn_stats(_p(z3), _p(mean), _p(var), B, C, N, s))
+        if running_mean is not None:
+            with torch.no_grad():
+                m = B * N
+                running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
+                running_var.mul_(1 - momentum).add_(var, alpha=momentum * m / max(m - 1, 1))
+    else:
+        mean.copy_(running_mean)
+        var.copy_(running_var)
+    y = torch.empty_like(z3)
+    _check(lib, L.ach_train_bn_relu_fwd(_p(z3), _p(mean), _p(var), _p(gamma), _p(beta), _p(y), B, C, N, float(eps), int(relu), s))
+    return y, mean, var
+
+
+class _DWConvBNFn(torch.autograd.Function):
+    """depthwise 3x3 (stride 1, pad 1, no bias) + BatchNorm2d [+ ReLU] on [B, C, H, W]"""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, training, momentum, eps, relu):
+        if x.dtype != torch.float32:
+            raise TypeError("DWConvBN2d trains in float32")
+        x = x.contiguous()
+        B, C, H, W = x.shape
+        if tuple(weight.shape) != (C, 1, 3, 3):
+            raise ValueError(f"depthwise 3x3 weight of shape [{C},1,3,3] expected, got {tuple(weight.shape)}")
+        w2 = weight.detach().reshape(C, 9).contiguous()
+        lib = _lib(x)
+        L, s = lib.lib, _stream(x)
+        z = torch.empty_like(x)
+        _check(lib, L.ach_train_dw3x3(_p(x), _p(w2), _p(z), B, C, H, W, 0, s))
+        g = gamma.detach().contiguous()
+        y, mean, var = _bn_train_fwd(lib, L, s, z.view(B, C, H * W), g, beta.detach().contiguous(), running_mean, running_var, training, momentum, eps, relu)
+        ctx.save_for_backward(x, w2, z, y, mean, var, g)
+        ctx.cfg = (training, float(eps), int(relu))
+        return y.view(B, C, H, W)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w2, z, y, mean, var, gamma = ctx.saved_tensors
+        training, eps, relu = ctx.cfg
+        if not training:
+            raise NotImplementedError("DWConvBN2d backward is built for training mode (batch statistics)")
+        B, C, H, W = x.shape
+        lib = _lib(x)
+        L, s = lib.lib, _stream(x)
+        dy = dy.contiguous()
+        dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+        dz = torch.empty_like(z)
+        _check(lib, L.ach_train_bn_relu_bwd(_p(z), _p(y), _p(dy), _p(mean), _p(var), _p(gamma), _p(dgamma), _p(dbeta), _p(dz), B, C, H * W, eps, relu, s))
+        dx = torch.empty_like(x)
+        _check(lib, L.ach_train_dw3x3(_p(dz), _p(w2), _p(dx), B, C, H, W, 1, s))                    # mirrored taps
+        dw = torch.empty(C, 9, dtype=torch.float32, device=x.device)
+        _check(lib, L.ach_train_dw3x3_wgrad(_p(x), _p(dz), _p(dw), B, C, H, W, s))
+        return dx, dw.view(C, 1, 3, 3), dgamma, dbeta, None, None, None, None, None, None
+
+
+def _conv1x1_bn(x, conv, bn, relu, training):
+    """1x1 Conv2d + BatchNorm2d [+ ReLU] on [B, C, H, W] through the shared-MLP Function ([B, C, H*W] is the same memory)."""
+    B, C, H, W = x.shape
+    if training and bn.track_running_stats:
+        bn.num_batches_tracked += 1
+    y = _SharedMLP1dFn.apply(x.reshape(B, C, H * W), conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                             training, bn.momentum, bn.eps, relu)
+    return y.view(B, -1, H, W)
+
+
+def _dw3x3_bn(x, conv, bn, relu, training):
+    if training and bn.track_running_stats:
+        bn.num_batches_tracked += 1
+    return _DWConvBNFn.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.momentum, bn.eps, relu)
+
+
+class GhostModule(nn.Module):
+    """backbone/conv_utils/ghost_conv.py:6-29 (kernel_size 1, ratio 2, dw_size 3, stride 1) with the reference's parameter names
+    (`primary_conv.0/.1`, `cheap_operation.0/.1`); forward / backward run on the native kernels."""
+
+    def __init__(self, inp, oup, relu=True):
+        super().__init__()
+        self.oup, self.relu = oup, relu
+        init = (oup + 1) // 2
+        self.primary_conv = nn.Sequential(nn.Conv2d(inp, init, 1, 1, 0, bias=False), nn.BatchNorm2d(init), nn.ReLU(inplace=True) if relu else nn.Sequential())
+        self.cheap_operation = nn.Sequential(nn.Conv2d(init, init, 3, 1, 1, groups=init, bias=False), nn.BatchNorm2d(init),
+                                             nn.ReLU(inplace=True) if relu else nn.Sequential())
+
+    def forward(self, x):
+        x1 = _conv1x1_bn(x, self.primary_conv[0], self.primary_conv[1], self.relu, self.training)
+        x2 = _dw3x3_bn(x1, self.cheap_operation[0], self.cheap_operation[1], self.relu, self.training)
+        return torch.cat([x1, x2], dim=1)[:, :self.oup]
+
+
+class GhostBottleneck(nn.Module):
+    """ghost_conv.py:32-70, stride 1 (the only form the Ghost-Dual-FPN uses, neck/ghostdualfpn.py:108-112)."""
+
+    def __init__(self, in_chs, mid_chs, out_chs):
+        super().__init__()
+        self.ghost1 = GhostModule(in_chs, mid_chs, relu=True)
+        self.ghost2 = GhostModule(mid_chs, out_chs, relu=False)
+        self.identity = in_chs == out_chs
+        self.shortcut = nn.Sequential() if self.identity else nn.Sequential(
+            nn.Conv2d(in_chs, in_chs, 3, 1, 1, groups=in_chs, bias=False), nn.BatchNorm2d(in_chs),
+            nn.Conv2d(in_chs, out_chs, 1, 1, 0, bias=False), nn.BatchNorm2d(out_chs))
+
+    def forward(self, x):
+        y = self.ghost2(self.ghost1(x))
+        if self.identity:
+            return y + x
+        s = _dw3x3_bn(x, self.shortcut[0], self.shortcut[1], False, self.training)
+        return y + _conv1x1_bn(s, self.shortcut[2], self.shortcut[3], False, self.training)

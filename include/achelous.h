@@ -207,6 +207,10 @@ int ach_train_bn_relu_fwd(const float* z, const float* mean, const float* var, c
                           int32_t N, float eps, int32_t relu, void* stream);
 int ach_train_bn_relu_bwd(const float* z, const float* y, const float* dy, const float* mean, const float* var, const float* gamma, float* dgamma,
                           float* dbeta, float* dz, int32_t B, int32_t C, int32_t N, float eps, int32_t relu, void* stream);
+/*   ach_train_dw3x3        depthwise 3x3 / stride 1 / pad 1 on [B,C,H,W], w [C,9]; flip = 1 mirrors the taps (the input gradient)
+ *   ach_train_dw3x3_wgrad  its weight gradient dw [C,9] = sum over (B,H,W) of dz x shifted x   (GhostModule cheap operation, ghost_conv.py:19-23) */
+int ach_train_dw3x3(const float* x, const float* w, float* y, int32_t B, int32_t C, int32_t H, int32_t W, int32_t flip, void* stream);
+int ach_train_dw3x3_wgrad(const float* x, const float* dz, float* dw, int32_t B, int32_t C, int32_t H, int32_t W, void* stream);
 
 #ifdef __cplusplus
 }

@@ -84,3 +84,83 @@ def test_gpu_shared_mlp_trains():
     ref[3].load_state_dict(net[1].conv.state_dict()); ref[4].load_state_dict(net[1].bn.state_dict())
     with torch.no_grad():
         assert torch.allclose(net(x), ref(x), rtol=1e-4, atol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------- Ghost blocks (neck / decoders)
+def _torch_ghost(inp, oup, relu):
+    init = (oup + 1) // 2
+    class G(nn.Module):                                       # ghost_conv.py:6-29 stated with torch layers (the checker)
+        def __init__(self):
+            super().__init__()
+            self.oup = oup
+            self.primary_conv = nn.Sequential(nn.Conv2d(inp, init, 1, 1, 0, bias=False), nn.BatchNorm2d(init), nn.ReLU() if relu else nn.Sequential())
+            self.cheap_operation = nn.Sequential(nn.Conv2d(init, init, 3, 1, 1, groups=init, bias=False), nn.BatchNorm2d(init), nn.ReLU() if relu else nn.Sequential())
+        def forward(self, x):
+            x1 = self.primary_conv(x)
+            return torch.cat([x1, self.cheap_operation(x1)], 1)[:, :self.oup]
+    return G()
+
+
+def _torch_bottleneck(i, m, o):
+    class Bk(nn.Module):                                      # ghost_conv.py:32-70, stride 1
+        def __init__(self):
+            super().__init__()
+            self.ghost1, self.ghost2 = _torch_ghost(i, m, True), _torch_ghost(m, o, False)
+            self.shortcut = nn.Sequential() if i == o else nn.Sequential(nn.Conv2d(i, i, 3, 1, 1, groups=i, bias=False), nn.BatchNorm2d(i), nn.Conv2d(i, o, 1, bias=False), nn.BatchNorm2d(o))
+        def forward(self, x):
+            return self.ghost2(self.ghost1(x)) + self.shortcut(x)
+    return Bk()
+
+
+def _run_module(dev, native, ref, xshape, seed=0):
+    torch.manual_seed(seed)
+    with torch.no_grad():
+        for p_ in ref.parameters():
+            p_.copy_(torch.randn_like(p_) * (0.3 if p_.dim() > 1 else 0.2) + (1.0 if p_.dim() == 1 else 0.0))
+    native.load_state_dict(ref.state_dict(), strict=True)      # same parameter names as the torch statement of the reference block
+    native = native.to(dev).train(); ref.train()
+    x = torch.randn(*xshape)
+    xr = x.clone().requires_grad_(True); xn = x.clone().to(dev).requires_grad_(True)
+    yr = ref(xr); yn = native(xn)
+    dy = torch.randn_like(yr)
+    yr.backward(dy); yn.backward(dy.to(dev))
+    # (+1e-4 absolute: a BatchNorm shift that feeds a linear layer + another training-mode BatchNorm — shortcut.1.bias — has a true
+    #  gradient of zero, and both implementations return rounding noise there)
+    rel = lambda a, b: \
+        max(0.0, ((a.detach().cpu().double() - b.detach().double()).abs().max().item() - 1e-4)) / (b.detach().double().abs().max().item() + 1e-12)
+    errs = {'y': rel(yn, yr), 'dx': rel(xn.grad, xr.grad)}
+    refp = dict(ref.named_parameters())
+    for k, v in native.named_parameters():
+        errs['d' + k] = rel(v.grad, refp[k].grad)
+    refb = dict(ref.named_buffers())
+    for k, v in native.named_buffers():
+        if 'running' in k:
+            errs[k] = rel(v, refb[k])
+    assert max(errs.values()) < 5e-4, errs
+    return errs
+
+
+GHOST_CASES = [('module', (48, 48, True), (2, 48, 12, 10)), ('module', (32, 9, True), (2, 32, 9, 16)), ('module', (96, 48, False), (1, 96, 8, 8)),
+               ('bottleneck', (96, 96, 48), (2, 96, 10, 10)), ('bottleneck', (32, 32, 32), (2, 32, 6, 7))]
+
+
+def _ghost_pair(kind, args):
+    if kind == 'module':
+        return train_ops.GhostModule(*args), _torch_ghost(*args)
+    return train_ops.GhostBottleneck(*args), _torch_bottleneck(*args)
+
+
+@pytest.mark.parametrize('kind,args,xshape', GHOST_CASES)
+def test_emulated_ghost_blocks_forward_backward_match_autograd(kind, args, xshape):
+    from emu_util import emu_library
+    train_ops._lib.test_library = emu_library()
+    try:
+        _run_module('cpu', *_ghost_pair(kind, args), xshape)
+    finally:
+        train_ops._lib.test_library = None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kind,args,xshape', GHOST_CASES + [('bottleneck', (192, 192, 96), (64, 192, 20, 20)), ('module', (32, 9, True), (8, 32, 320, 320))])
+def test_gpu_ghost_blocks_forward_backward_match_autograd(kind, args, xshape):
+    print(_run_module('cuda', *_ghost_pair(kind, args), xshape))
