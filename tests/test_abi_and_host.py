@@ -19,7 +19,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared_symbols():
     src = open(os.path.join(REPO, 'include', 'achelous.h')).read()
     src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
-    return sorted(set(re.findall(r'\b(ach_[a-z_]+)\s*\(', src)))
+    return sorted(set(re.findall(r'\b(ach_[a-z_0-9]+)\s*\(', src)))
 
 
 def test_header_and_binding_agree():
