@@ -124,14 +124,17 @@ def _run_module(dev, native, ref, xshape, seed=0):
     yr = ref(xr); yn = native(xn)
     dy = torch.randn_like(yr)
     yr.backward(dy); yn.backward(dy.to(dev))
-    # (+1e-4 absolute: a BatchNorm shift that feeds a linear layer + another training-mode BatchNorm — shortcut.1.bias — has a true
-    #  gradient of zero, and both implementations return rounding noise there)
-    rel = lambda a, b: \
-        max(0.0, ((a.detach().cpu().double() - b.detach().double()).abs().max().item() - 1e-4)) / (b.detach().double().abs().max().item() + 1e-12)
-    errs = {'y': rel(yn, yr), 'dx': rel(xn.grad, xr.grad)}
+    # A BatchNorm shift that feeds a linear layer + another training-mode BatchNorm (shortcut.1.bias) has a true gradient of ZERO:
+    # both implementations return rounding noise there.  Errors are therefore measured against max(|reference|, 1e-3 x the largest
+    # parameter gradient of the block) — noise in a vanishing gradient is judged on the scale of the gradients around it.
     refp = dict(ref.named_parameters())
+    gscale = max(float(p_.grad.abs().max()) for p_ in refp.values())
+    def rel(a, b, floor=0.0):
+        a, b = a.detach().cpu().double(), b.detach().double()
+        return ((a - b).abs().max() / max(float(b.abs().max()), floor, 1e-12)).item()
+    errs = {'y': rel(yn, yr), 'dx': rel(xn.grad, xr.grad)}
     for k, v in native.named_parameters():
-        errs['d' + k] = rel(v.grad, refp[k].grad)
+        errs['d' + k] = rel(v.grad, refp[k].grad, 1e-3 * gscale)
     refb = dict(ref.named_buffers())
     for k, v in native.named_buffers():
         if 'running' in k:
