@@ -260,6 +260,30 @@ int ach_train_dw3x3_wgrad(const float* x, const float* dz, float* dw, int32_t B,
     });
 }
 
+int ach_train_max_points(const float* x, float* y, int32_t* idx, const float* dy, float* dx, int64_t rows, int32_t N, void* stream) {
+    return train_guard([&] {                                 /* forward when dy == NULL, backward otherwise */
+        if (rows <= 0 || N <= 0 || !idx) throw ach::AchError{ACH_ERR_INVALID, "bad train_max_points arguments"};
+        if (!dy) {
+            if (!x || !y) throw ach::AchError{ACH_ERR_INVALID, "bad train_max_points arguments"};
+            ach::MaxPtsParams p{x, y, idx, long(rows), N};
+            ACH_LAUNCH(ach::train_max_points_fwd_kernel, dim3(unsigned(ach::cdivl(long(rows), 4))), dim3(256), static_cast<hipStream_t>(stream), p);
+        } else {
+            if (!dx) throw ach::AchError{ACH_ERR_INVALID, "bad train_max_points arguments"};
+            ach::MaxPtsBwdParams p{dy, idx, dx, long(rows), N};
+            ACH_LAUNCH(ach::train_max_points_bwd_kernel, dim3(unsigned(ach::cdivl(long(rows) * N, 256))), dim3(256), static_cast<hipStream_t>(stream), p);
+        }
+    });
+}
+int ach_train_log_softmax(const float* z, float* y, const float* dy, float* dz, int32_t B, int32_t K, int32_t N, void* stream) {
+    return train_guard([&] {                                 /* forward when dy == NULL (z -> y [B,N,K]); backward: y, dy -> dz [B,K,N] */
+        if (B <= 0 || K <= 0 || N <= 0 || !y) throw ach::AchError{ACH_ERR_INVALID, "bad train_log_softmax arguments"};
+        ach::LsmTrainParams p{z, y, dy, dz, B, K, N};
+        const dim3 grid(unsigned(ach::cdivl(long(B) * N, 256)));
+        if (!dy) { if (!z) throw ach::AchError{ACH_ERR_INVALID, "bad train_log_softmax arguments"}; ACH_LAUNCH(ach::train_log_softmax_fwd_kernel, grid, dim3(256), static_cast<hipStream_t>(stream), p); }
+        else { if (!dz) throw ach::AchError{ACH_ERR_INVALID, "bad train_log_softmax arguments"}; ACH_LAUNCH(ach::train_log_softmax_bwd_kernel, grid, dim3(256), static_cast<hipStream_t>(stream), p); }
+    });
+}
+
 int ach_tap_count(const ach_handle* h) { return (h && h->eng) ? int(h->eng->tap_order.size()) : 0; }
 const char* ach_tap_name(const ach_handle* h, int i) {
     if (!h || !h->eng || i < 0 || i >= int(h->eng->tap_order.size())) return nullptr;

@@ -204,4 +204,52 @@ static __global__ __launch_bounds__(256) void train_dw3x3_wgrad_kernel(const DwW
     if (threadIdx.x < 9) p.dW[c * 9 + threadIdx.x] = red[threadIdx.x][0];
 }
 
+// ---- PointNet glue in training mode (pointnet_utils.py:32, 127; pointnet_sem_seg.py:34-37)
+// max over the N points of [B, C, N] with the arg-max kept for the backward (ties: lowest index, as torch.max)
+struct MaxPtsParams { const float* X; float* Y; int* idx; long rows; int N; };          // rows = B * C
+static __global__ __launch_bounds__(256) void train_max_points_fwd_kernel(const MaxPtsParams p) {
+    const int lane = threadIdx.x & 63;
+    const long row = long(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (row >= p.rows) return;
+    const float* x = p.X + row * p.N;
+    float best = -3.0e38f; int bi = 0x7fffffff;
+    for (int n = lane; n < p.N; n += 64) { const float v = x[n]; if (v > best) { best = v; bi = n; } }
+    ACH_UNROLL
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float ob = __shfl_xor(best, off); const int oi = __shfl_xor(bi, off);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (lane == 0) { p.Y[row] = best; p.idx[row] = bi; }
+}
+struct MaxPtsBwdParams { const float* dY; const int* idx; float* dX; long rows; int N; };
+static __global__ __launch_bounds__(256) void train_max_points_bwd_kernel(const MaxPtsBwdParams p) {
+    const long i = long(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= p.rows * p.N) return;
+    const long row = i / p.N;
+    p.dX[i] = (int(i - row * p.N) == p.idx[row]) ? p.dY[row] : 0.f;
+}
+// log_softmax over the classes of z [B, K, N] written as y [B, N, K] (the transpose + view of pointnet_sem_seg.py:34-36), and its
+// backward  dz[b,k,n] = dy[b,n,k] - exp(y[b,n,k]) * sum_k' dy[b,n,k']
+struct LsmTrainParams { const float* Z; float* Y; const float* dY; float* dZ; int B, K, N; };
+static __global__ __launch_bounds__(256) void train_log_softmax_fwd_kernel(const LsmTrainParams p) {
+    const long i = long(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= long(p.B) * p.N) return;
+    const long b = i / p.N; const int n = int(i - b * p.N);
+    const float* z = p.Z + b * p.K * p.N + n;
+    float m = z[0];
+    for (int k = 1; k < p.K; ++k) m = fmaxf(m, z[long(k) * p.N]);
+    float s = 0.f;
+    for (int k = 0; k < p.K; ++k) s += expf(z[long(k) * p.N] - m);
+    const float lse = m + logf(s);
+    for (int k = 0; k < p.K; ++k) p.Y[i * p.K + k] = z[long(k) * p.N] - lse;
+}
+static __global__ __launch_bounds__(256) void train_log_softmax_bwd_kernel(const LsmTrainParams p) {
+    const long i = long(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= long(p.B) * p.N) return;
+    const long b = i / p.N; const int n = int(i - b * p.N);
+    float s = 0.f;
+    for (int k = 0; k < p.K; ++k) s += p.dY[i * p.K + k];
+    for (int k = 0; k < p.K; ++k) p.dZ[(b * p.K + k) * p.N + n] = p.dY[i * p.K + k] - expf(p.Y[i * p.K + k]) * s;
+}
+
 }  // namespace ach

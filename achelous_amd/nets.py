@@ -106,6 +106,7 @@ class Achelous(nn.Module):
         st = self.__dict__.copy()
         st['_engines'] = {}
         st['_wt_list'] = None
+        st['_op_token'] = None
         return st
 
     def _init_like_reference(self):
@@ -190,6 +191,13 @@ class Achelous(nn.Module):
         return ent[0]
 
     def forward(self, x, x_radar, x_point_clouds):
+        if torch.jit.is_tracing() or torch.compiler.is_compiling():
+            # one `achelous_amd::forward` node for torch.jit.trace (TensorBoard add_graph) / torch.compile / torch.export (torch_op.py)
+            from . import torch_op
+            if self.__dict__.get('_op_token') is None:
+                self.__dict__['_op_token'] = torch_op.register_module(self)
+            o = torch.ops.achelous_amd.forward(x, x_radar, x_point_clouds, self.__dict__['_op_token'])
+            return [o[0], o[1], o[2]], o[3], o[4], o[5]
         return self._run(x, x_radar, x_point_clouds, None)
 
     def forward_detect(self, x, x_radar, x_point_clouds, conf_thres=0.5, nms_thres=0.4, max_det=None):

@@ -237,3 +237,207 @@ class GhostBottleneck(nn.Module):
             return y + x
         s = _dw3x3_bn(x, self.shortcut[0], self.shortcut[1], False, self.training)
         return y + _conv1x1_bn(s, self.shortcut[2], self.shortcut[3], False, self.training)
+
+
+# ---------------------------------------------------------------------------------------------- PointNet branch, trainable end to end
+class _LinearFn(torch.autograd.Function):
+    """z = W x + b on [B, Cin, N] (a Conv1d of kernel 1 / a Linear with N = 1) without normalisation: fc3 of the STNs, conv4 of the head."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = x.contiguous()
+        B, cin, N = x.shape
+        cout = weight.shape[0]
+        w2 = weight.detach().reshape(cout, cin).contiguous()
+        lib = _lib(x)
+        L, s = lib.lib, _stream(x)
+        z = torch.empty(B, cout, N, dtype=torch.float32, device=x.device)
+        _check(lib, L.ach_train_gemm(_p(w2), _p(x), _p(z), _p(bias.detach().contiguous()) if bias is not None else ctypes.c_void_p(), cout, N, cin,
+                                     cin, N, N, 0, cin * N, cout * N, 0, 0, B, 0, 0, s))
+        ctx.save_for_backward(x, w2)
+        ctx.cfg = (bias is not None, tuple(weight.shape))
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, w2 = ctx.saved_tensors
+        has_bias, wshape = ctx.cfg
+        B, cin, N = x.shape
+        cout = w2.shape[0]
+        lib = _lib(x)
+        L, s = lib.lib, _stream(x)
+        dz = dz.contiguous()
+        dx = torch.empty_like(x)
+        _check(lib, L.ach_train_gemm(_p(w2), _p(dz), _p(dx), ctypes.c_void_p(), cin, N, cout, cin, N, N, 0, cout * N, cin * N, 1, 0, B, 0, 0, s))
+        dw = torch.empty(cout, cin, dtype=torch.float32, device=x.device)
+        _check(lib, L.ach_train_gemm(_p(dz), _p(x), _p(dw), ctypes.c_void_p(), cout, cin, N, N, N, cin, cout * N, cin * N, 0, 0, 1, B, 1, 0, s))
+        db = None
+        if has_bias:                      # db[c] = sum over (B, N) of dz = B N x the per-channel mean the statistics kernel returns
+            db = torch.empty(cout, dtype=torch.float32, device=x.device)
+            scratch = torch.empty(cout, dtype=torch.float32, device=x.device)
+            _check(lib, L.ach_train_bn_stats(_p(dz), _p(db), _p(scratch), B, cout, N, s))
+            db = db * float(B * N)
+        return dx, dw.reshape(wshape), db
+
+
+class _BmmPointsFn(torch.autograd.Function):
+    """y[b] = T[b]^T x[b]  for x [B, K, N], T [B, K, K]  — `torch.bmm(x.transpose(2, 1), trans).transpose(2, 1)` (pointnet_utils.py:110, 118-120)."""
+
+    @staticmethod
+    def forward(ctx, x, T):
+        x, T = x.contiguous(), T.contiguous()
+        B, K, N = x.shape
+        lib = _lib(x)
+        L, s = lib.lib, _stream(x)
+        y = torch.empty_like(x)
+        _check(lib, L.ach_train_gemm(_p(T), _p(x), _p(y), ctypes.c_void_p(), K, N, K, K, N, N, K * K, K * N, K * N, 1, 0, B, 0, 0, s))
+        ctx.save_for_backward(x, T)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, T = ctx.saved_tensors
+        B, K, N = x.shape
+        lib = _lib(x)
+        L, s = lib.lib, _stream(x)
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)                                   # dx[b] = T[b] dy[b]
+        _check(lib, L.ach_train_gemm(_p(T), _p(dy), _p(dx), ctypes.c_void_p(), K, N, K, K, N, N, K * K, K * N, K * N, 0, 0, B, 0, 0, s))
+        dT = torch.empty_like(T)                                   # dT[b] = x[b] dy[b]^T
+        _check(lib, L.ach_train_gemm(_p(x), _p(dy), _p(dT), ctypes.c_void_p(), K, K, N, N, N, K, K * N, K * N, K * K, 0, 1, B, 0, 0, s))
+        return dx, dT
+
+
+class _MaxPointsFn(torch.autograd.Function):
+    """[B, C, N] -> [B, C]: `torch.max(x, 2)[0]` with the arg-max kept for the backward."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        B, C, N = x.shape
+        lib = _lib(x)
+        y = torch.empty(B, C, dtype=torch.float32, device=x.device)
+        idx = torch.empty(B, C, dtype=torch.int32, device=x.device)
+        _check(lib, lib.lib.ach_train_max_points(_p(x), _p(y), _p(idx), ctypes.c_void_p(), ctypes.c_void_p(), B * C, N, _stream(x)))
+        ctx.save_for_backward(idx)
+        ctx.shape = (B, C, N)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        B, C, N = ctx.shape
+        lib = _lib(dy)
+        dy = dy.contiguous()
+        dx = torch.empty(B, C, N, dtype=torch.float32, device=dy.device)
+        _check(lib, lib.lib.ach_train_max_points(ctypes.c_void_p(), ctypes.c_void_p(), _p(idx), _p(dy), _p(dx), B * C, N, _stream(dy)))
+        return dx
+
+
+class _LogSoftmaxPointsFn(torch.autograd.Function):
+    """z [B, K, N] -> log_softmax over K written as [B, N, K] (pointnet_sem_seg.py:34-37)."""
+
+    @staticmethod
+    def forward(ctx, z):
+        z = z.contiguous()
+        B, K, N = z.shape
+        lib = _lib(z)
+        y = torch.empty(B, N, K, dtype=torch.float32, device=z.device)
+        _check(lib, lib.lib.ach_train_log_softmax(_p(z), _p(y), ctypes.c_void_p(), ctypes.c_void_p(), B, K, N, _stream(z)))
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        B, N, K = y.shape
+        lib = _lib(y)
+        dy = dy.contiguous()
+        dz = torch.empty(B, K, N, dtype=torch.float32, device=y.device)
+        _check(lib, lib.lib.ach_train_log_softmax(ctypes.c_void_p(), _p(y), _p(dy), _p(dz), B, K, N, _stream(y)))
+        return dz
+
+
+def _conv_bn(x, conv, bn, relu, training):
+    if training and bn.track_running_stats:
+        bn.num_batches_tracked += 1
+    return _SharedMLP1dFn.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.momentum, bn.eps, relu)
+
+
+def _fc_bn(x, fc, bn, relu, training):
+    """Linear + BatchNorm1d [+ ReLU] on [B, C]: the batch is the axis the statistics run over, i.e. the layer on [1, C, B]."""
+    y = _conv_bn(x.t().contiguous().unsqueeze(0), fc, bn, relu, training)
+    return y.squeeze(0).t()
+
+
+class _STN(nn.Module):
+    """STN3d / STNkd (pointnet_utils.py:10-85): the same trunk, output k x k plus the identity."""
+
+    def __init__(self, channel, k):
+        super().__init__()
+        self.k = k
+        self.conv1, self.conv2, self.conv3 = nn.Conv1d(channel, 64, 1), nn.Conv1d(64, 128, 1), nn.Conv1d(128, 1024, 1)
+        self.fc1, self.fc2, self.fc3 = nn.Linear(1024, 512), nn.Linear(512, 256), nn.Linear(256, k * k)
+        self.relu = nn.ReLU()
+        self.bn1, self.bn2, self.bn3, self.bn4, self.bn5 = (nn.BatchNorm1d(c) for c in (64, 128, 1024, 512, 256))
+
+    def forward(self, x):
+        t = self.training
+        x = _conv_bn(x, self.conv1, self.bn1, True, t)
+        x = _conv_bn(x, self.conv2, self.bn2, True, t)
+        x = _conv_bn(x, self.conv3, self.bn3, True, t)
+        x = _MaxPointsFn.apply(x)
+        x = _fc_bn(x, self.fc1, self.bn4, True, t)
+        x = _fc_bn(x, self.fc2, self.bn5, True, t)
+        x = _LinearFn.apply(x.t().contiguous().unsqueeze(0), self.fc3.weight, self.fc3.bias).squeeze(0).t()
+        return (x + torch.eye(self.k, dtype=x.dtype, device=x.device).reshape(1, self.k * self.k)).view(-1, self.k, self.k)
+
+
+class _Encoder(nn.Module):
+    """PointNetEncoder(global_feat=False, feature_transform=True) (pointnet_utils.py:88-133)."""
+
+    def __init__(self, channel):
+        super().__init__()
+        self.stn = _STN(channel, 3)
+        self.conv1, self.conv2, self.conv3 = nn.Conv1d(channel, 32, 1), nn.Conv1d(32, 64, 1), nn.Conv1d(64, 128, 1)
+        self.bn1, self.bn2, self.bn3 = nn.BatchNorm1d(32), nn.BatchNorm1d(64), nn.BatchNorm1d(128)
+        self.fstn = _STN(32, 32)
+
+    def forward(self, x):
+        t = self.training
+        B, D, N = x.shape
+        trans = self.stn(x)
+        xyz = _BmmPointsFn.apply(x[:, :3].contiguous(), trans)              # only x, y, z are transformed; the other features pass through
+        x = torch.cat([xyz, x[:, 3:]], dim=1) if D > 3 else xyz
+        x = _conv_bn(x, self.conv1, self.bn1, True, t)
+        trans_feat = self.fstn(x)
+        x = _BmmPointsFn.apply(x, trans_feat)
+        pointfeat = x
+        x = _conv_bn(x, self.conv2, self.bn2, True, t)
+        x = _conv_bn(x, self.conv3, self.bn3, False, t)
+        g = _MaxPointsFn.apply(x)
+        return torch.cat([g.unsqueeze(2).expand(-1, -1, N), pointfeat], dim=1), trans, trans_feat
+
+
+class PointNetSeg(nn.Module):
+    """`PointNet_SEG` (nets/pointcloudseg/pointnet2/pointnet_sem_seg.py:13-37) — the `pc_seg_model` of Achelous, 1.9 M of its 3.6 M
+    parameters — with the reference's state-dict keys, trainable END TO END on the native kernels: every conv / linear (+ BatchNorm
+    in batch-statistics mode + ReLU), the two max-over-points, the two per-sample transforms and the log-softmax run hand-written
+    forward and backward kernels; what torch does in between is tensor plumbing (slices, cat / expand, the + identity) whose
+    gradients autograd routes.  x [B, channels, N] fp32 -> log-probabilities [B, N, num_class]."""
+
+    def __init__(self, num_class, point_cloud_channels):
+        super().__init__()
+        self.k = num_class
+        self.feat = _Encoder(point_cloud_channels)
+        self.conv1, self.conv2, self.conv3, self.conv4 = nn.Conv1d(160, 128, 1), nn.Conv1d(128, 100, 1), nn.Conv1d(100, 64, 1), nn.Conv1d(64, num_class, 1)
+        self.bn1, self.bn2, self.bn3 = nn.BatchNorm1d(128), nn.BatchNorm1d(100), nn.BatchNorm1d(64)
+
+    def forward(self, x):
+        t = self.training
+        x, trans, trans_feat = self.feat(x)
+        x = _conv_bn(x, self.conv1, self.bn1, True, t)
+        x = _conv_bn(x, self.conv2, self.bn2, True, t)
+        x = _conv_bn(x, self.conv3, self.bn3, True, t)
+        x = _LinearFn.apply(x, self.conv4.weight, self.conv4.bias)
+        return _LogSoftmaxPointsFn.apply(x)

@@ -211,6 +211,11 @@ int ach_train_bn_relu_bwd(const float* z, const float* y, const float* dy, const
  *   ach_train_dw3x3_wgrad  its weight gradient dw [C,9] = sum over (B,H,W) of dz x shifted x   (GhostModule cheap operation, ghost_conv.py:19-23) */
 int ach_train_dw3x3(const float* x, const float* w, float* y, int32_t B, int32_t C, int32_t H, int32_t W, int32_t flip, void* stream);
 int ach_train_dw3x3_wgrad(const float* x, const float* dz, float* dw, int32_t B, int32_t C, int32_t H, int32_t W, void* stream);
+/*   ach_train_max_points   max over the N points of rows = B*C rows with the arg-max (dy == NULL: forward x -> y, idx; else backward dy, idx -> dx)
+ *   ach_train_log_softmax  log-softmax over the classes of z [B,K,N] written as [B,N,K] (dy == NULL: forward; else y, dy -> dz [B,K,N])
+ *                          (pointnet_utils.py:32,127; pointnet_sem_seg.py:34-37) */
+int ach_train_max_points(const float* x, float* y, int32_t* idx, const float* dy, float* dx, int64_t rows, int32_t N, void* stream);
+int ach_train_log_softmax(const float* z, float* y, const float* dy, float* dz, int32_t B, int32_t K, int32_t N, void* stream);
 
 #ifdef __cplusplus
 }

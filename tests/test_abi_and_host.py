@@ -71,3 +71,17 @@ def test_drop_in_module_protocols():
         kw.update(bad)
         with pytest.raises(NotImplementedError):
             achelous_amd.Achelous(**kw)
+
+
+def test_forward_is_registered_as_a_torch_library_op():
+    """`torch.ops.achelous_amd.forward` exists, and its fake implementation gives tracing / export the reference's output shapes
+    without touching a GPU (nets/Achelous.py:49-53)."""
+    import torch
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    from achelous_amd import Achelous, torch_op
+    m = Achelous(num_det=7, num_seg=9, phi='S0', resolution=320, backbone='en', neck='gdf', pc_seg='pn', pc_channels=5, pc_classes=8, nano_head=True)
+    tok = torch_op.register_module(m)
+    with FakeTensorMode():
+        outs = torch.ops.achelous_amd.forward(torch.empty(4, 3, 320, 320), torch.empty(4, 3, 320, 320), torch.empty(4, 5, 512), tok)
+    assert [tuple(o.shape) for o in outs] == [(4, 12, 40, 40), (4, 12, 20, 20), (4, 12, 10, 10), (4, 9, 320, 320), (4, 2, 320, 320), (4, 512, 8)]
+    assert 'achelous_amd::forward' in str(torch.ops.achelous_amd.forward.default._schema)

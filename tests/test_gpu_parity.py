@@ -268,6 +268,23 @@ def test_module_is_a_drop_in():
     assert (b - a).abs().max() > 0.1
 
 
+def test_jit_trace_records_one_achelous_op():
+    """torch.jit.trace (what TensorBoard's add_graph runs, utils/callbacks.py:31-34) sees the module as ONE `achelous_amd::forward`
+    node, and the traced module reproduces the eager outputs."""
+    g = Golden('en_s0')
+    m, kw = _model(g)
+    x, xr, xp = make_inputs(2, 12, resolution=kw['resolution'], pc_channels=kw['pc_channels'])
+    xs, rs, ps = x.cuda(), xr.cuda(), xp.cuda()
+    with torch.no_grad():
+        ref = m(xs, rs, ps)
+        traced = torch.jit.trace(m, (xs, rs, ps), check_trace=False, strict=False)
+        assert 'achelous_amd::forward' in str(traced.graph)
+        out = traced(xs, rs, ps)
+    torch.cuda.synchronize()
+    for a, b in zip((*out[0], out[1], out[2], out[3]), (*ref[0], ref[1], ref[2], ref[3])):
+        assert torch.equal(a, b)
+
+
 def test_launch_modes_agree():
     """Three side streams (default), single stream, and hipGraph replay run the SAME kernels: outputs must be bit-identical."""
     g = Golden('en_s0')
