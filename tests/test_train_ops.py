@@ -284,3 +284,15 @@ def test_emulated_pointnet_branch_trains_natively_end_to_end():
 @pytest.mark.gpu
 def test_gpu_pointnet_branch_trains_natively_end_to_end():
     print(_run_pointnet('cuda', 16, 512))
+
+
+def test_pointnet_seg_state_dict_is_the_reference_pc_seg_model():
+    """`train_ops.PointNetSeg` registers exactly the `pc_seg_model.*` entries (names, shapes, order) captured from the imported
+    reference (tests/golden/en_s0.keys.json): a reference checkpoint's point branch loads into it unchanged."""
+    import json
+    import os
+    from golden_util import GOLDEN_DIR
+    meta = json.load(open(os.path.join(GOLDEN_DIR, 'en_s0.keys.json')))
+    ref = [(k[len('pc_seg_model.'):], tuple(s)) for k, s, _ in meta['keys'] if k.startswith('pc_seg_model.')]
+    mine = [(k, tuple(v.shape)) for k, v in train_ops.PointNetSeg(8, 5).state_dict().items()]
+    assert len(ref) == 118 and ref == mine
