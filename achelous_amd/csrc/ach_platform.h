@@ -248,6 +248,7 @@ inline uint4 buf_load16(const BufRsrc& r, unsigned off) {
     if (r.bytes >= 16u && off <= r.bytes - 16u) std::memcpy(&v, r.base + off, 16);
     return v;
 }
+inline uint4 buf_load16s(const BufRsrc& r, unsigned voff, unsigned soff) { return buf_load16(r, voff + soff); }
 #else
 typedef __amdgpu_buffer_rsrc_t BufRsrc;
 typedef unsigned int buf_u32x4 __attribute__((ext_vector_type(4)));
@@ -256,6 +257,11 @@ __device__ __forceinline__ BufRsrc make_buf(const void* p, unsigned bytes) {
 }
 __device__ __forceinline__ uint4 buf_load16(BufRsrc r, unsigned off) {
     const buf_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, int(off), 0, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+// per-lane offset + wave-uniform offset (the MUBUF soffset operand: no VALU add); the range check applies to their sum
+__device__ __forceinline__ uint4 buf_load16s(BufRsrc r, unsigned voff, unsigned soff) {
+    const buf_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, int(voff), int(soff), 0);
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 #endif
@@ -284,6 +290,21 @@ template <> __device__ __forceinline__ void buf_ld4<bf16_t>(BufRsrc r, unsigned 
     o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
     o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
 }
+#endif
+
+// tell the compiler that a value is the same in every lane of the wave (threadIdx.x >> 6 and what is derived from it): branches on it
+// become scalar branches and the arithmetic moves to the scalar unit
+#if defined(ACH_HOSTEMU)
+__device__ inline int wave_uniform(int v) { return v; }
+#else
+__device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+#endif
+
+// value of lane `lane` (a compile-time or wave-uniform index) as a scalar
+#if defined(ACH_HOSTEMU)
+__device__ inline int wave_lane_i32(int v, int lane) { return __shfl(v, lane); }
+#else
+__device__ __forceinline__ int wave_lane_i32(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 #endif
 
 // wave-uniform max of a float / broadcast of one lane's float (lane must be wave-uniform)

@@ -70,6 +70,10 @@ public:
     // (1.36 ms vs 1.66 ms): HIP's graph executor serialises more of the three-branch DAG than the streams do.
     bool use_graph = false;
     bool multi_stream = true;         // option "streams": run the independent radar / point branches on side streams
+    bool radar_skip = true;           // option "radar_skip": first RCBlock — closed-form shortcut on 16-pixel segments whose neighbourhood of the radar map is empty (k_conv3.h)
+    bool head_mfma = false;           // option "head_mfma": bf16 — bilinear phase of the fused last decoder level on MFMA over a channel-planar t (k_nhwc.h)
+    int head_grid = 0;                // option "head_grid": persistent workgroups of the MFMA head kernel (0 = UGM_GRID)
+    int head_debug = 0;               // option "head_debug": timing experiments on the fused last decoder level (skips phases: results are wrong)
     bool attn_mfma = true;            // option "attn_mfma": MobileViT attention scores / P.V on MFMA (k_mvit.h) instead of one query per thread
     bool fuse_mv2 = true;             // option "fused_mv2": MobileViT's MV2 blocks (1x1 -> dw3x3 -> 1x1) as one launch (k_mv2.h)
     bool fuse_mlp = true;             // option "fused_mlp": EdgeNeXt blocks as one kernel (k_mlp.h) instead of dw / pw1 / pw2 launches

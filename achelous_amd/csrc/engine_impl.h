@@ -434,7 +434,7 @@ public:
         return true;
     }
     // y = l2(act(l1(x))) as one launch (k_mlp.h without LayerNorm / residual); false when the widths are not instantiated
-    bool chain2(const std::string& name, const A& x, const Lin& l1, int act, const Lin& l2, A& y) {
+    bool chain2(const std::string& name, const A& x, const Lin& l1, int act, const Lin& l2, A& y, bool* planar = nullptr) {
         if (!fuse_mlp) return false;
         const int Cin = x.C, hidden = l1.N, Cout = l2.N;
         const int k1 = cdiv(Cin, KC), J = cdiv(hidden, 32), hstep = 8 / VEC, ks2 = J * hstep;
@@ -464,6 +464,10 @@ public:
         mp.X = x.p; mp.ldx = x.ld; mp.Y = y.p; mp.ldy = y.ld;
         mp.W1 = up_T(w1); mp.b1 = up_f32(b1); mp.W2 = up_T(w2); mp.b2 = up_f32(b2);
         mp.M = x.rows(); mp.C = Cin; mp.k1 = k1; mp.J = J; mp.act = act; mp.ln = 0; mp.Cout = Cout;
+        if (planar) {                            // channel-planar rows for the MFMA bilinear phase of the fused last decoder level
+            *planar = *planar && small && Cout == 16;
+            if (*planar) mp.planar_w = x.W;
+        }
         add_op(name, [mp, DT, split, small](hipStream_t s) { if (small) launch_chain<T>(mp, s); else launch_mlp<T>(mp, DT, split, s); },
                double(mp.M) * (Cin + Cout) * sizeof(T), 2.0 * double(mp.M) * hidden * (Cin + Cout));
         return true;
@@ -871,12 +875,16 @@ public:
         Lin lh = conv_bn(head_pfx + ".primary_conv.0", head_pfx + ".primary_conv.1", 1e-5);
         if (Cg != UGH_CG || 2 * Cg != cout || lh.K != cout || lh.N != init || init > UGH_IMAX) throw AchError{ACH_ERR_UNSUPPORTED, head_pfx + ": fused last level expects 16+16 channels"};
         A t;
-        if (!chain2(ghost_pfx + ".lowres_pair", x, lu, ACT_RELU, lp, t)) {
+        // bf16: bilinear phase on the matrix cores, t channel-planar (upghost_head_mfma_kernel)
+        bool planar = head_mfma && std::is_same<T, bf16_t>::value && x.W % 4 == 0 && size_t(x.B) * x.H * x.W * Cg * sizeof(T) < (size_t(1) << 31);
+        if (!chain2(ghost_pfx + ".lowres_pair", x, lu, ACT_RELU, lp, t, &planar)) {
+            planar = false;
             A u = alloc(x.B, x.H, x.W, lu.N);
             { GemmOpt o; o.act = ACT_RELU; gemm(up_pfx + ".conv", x, pack(lu), u, o); }
             t = alloc(x.B, x.H, x.W, Cg);
             gemm(ghost_pfx + ".primary_lowres", u, pack(lp), t);
         }
+        if (planar) aalloc(256);                  // the MFMA head's 16-byte window loads may start in the last row's last 16 bytes
         auto dw_fold = [&](const std::string& pfx, int n, std::vector<float>& wt, std::vector<float>& bias) {
             const HostTensor& w = W(pfx + ".cheap_operation.0.weight");
             std::vector<float> sc, sh; bn_coeffs(pfx + ".cheap_operation.1", 1e-5, sc, sh);
@@ -889,10 +897,41 @@ public:
         A f;
         if (full_taps) { f = alloc(x.B, 2 * x.H, 2 * x.W, cout); tap(tap_name, f); }
         UpGhostHeadParams p{t.p, t.ld, full_taps ? f.p : nullptr, full_taps ? f.ld : 0, nullptr, up_f32(wl), up_f32(bl), up_f32(lh.w), up_f32(lh.b),
-                            up_f32(wh2), up_f32(bh2), x.B, x.H, x.W, init, nch, oup};
-        const dim3 grid(unsigned(cdiv(2 * x.W, UGH_TW)) * unsigned(cdiv(2 * x.H, UGH_TH)) * unsigned(x.B)), block(UGH_THREADS);
+                            up_f32(wh2), up_f32(bh2), x.B, x.H, x.W, init, nch, oup,
+                            x.H > 0 ? float(x.H - 1) / float(2 * x.H - 1) : 0.f, x.W > 0 ? float(x.W - 1) / float(2 * x.W - 1) : 0.f};
         const double bytes = double(t.rows()) * Cg * sizeof(T) + 4.0 * double(t.rows()) * oup * sizeof(T);
-        add_op(head_pfx + ".upghost_head", [p, grid, block, out](hipStream_t s) mutable { p.out = *out; ACH_LAUNCH(upghost_head_kernel<T>, grid, block, s, p, p.Wdw, p.bdw, p.Wh, p.bh, p.Wdh, p.bdh); }, bytes);
+        const dim3 block(UGH_THREADS);
+        if (planar) {
+            const int tw = 16 * UGM_NSEG - 4;
+            const unsigned tiles = unsigned(cdiv(2 * x.W, tw)) * unsigned(cdiv(2 * x.H, UGM_TH)) * unsigned(x.B);
+            const unsigned cap = head_grid > 0 ? unsigned(head_grid) : (UGM_GRID > 0 ? unsigned(UGM_GRID) : tiles);
+            const dim3 grid(tiles < cap ? tiles : cap);
+            const int dbg = head_debug;
+            add_op(head_pfx + ".upghost_head", [p, grid, block, out, dbg, tiles](hipStream_t s) mutable {
+                p.out = *out;
+#define ACH_UGM_CASE(D) case D: if (grid.x < tiles) ACH_LAUNCH((upghost_head_mfma_kernel<UGM_NSEG, UGM_TH, true, D>), grid, block, s, p, p.Wdw, p.bdw, p.Wh, p.bh, p.Wdh, p.bdh); \
+                             else ACH_LAUNCH((upghost_head_mfma_kernel<UGM_NSEG, UGM_TH, false, D>), grid, block, s, p, p.Wdw, p.bdw, p.Wh, p.bh, p.Wdh, p.bdh); break;
+#if defined(ACH_HEAD_DEBUG)
+                switch (dbg) { ACH_UGM_CASE(1) ACH_UGM_CASE(3) ACH_UGM_CASE(7) ACH_UGM_CASE(14) ACH_UGM_CASE(15) default: ACH_UGM_CASE(0) }
+#else
+                switch (dbg) { default: ACH_UGM_CASE(0) }
+#endif
+#undef ACH_UGM_CASE
+            }, bytes);
+            return;
+        }
+        const dim3 grid(unsigned(cdiv(2 * x.W, UGH_TW)) * unsigned(cdiv(2 * x.H, UGH_TH)) * unsigned(x.B));
+        const int dbg = head_debug;
+        add_op(head_pfx + ".upghost_head", [p, grid, block, out, dbg](hipStream_t s) mutable {
+            p.out = *out;
+#define ACH_UGH_CASE(D) case D: ACH_LAUNCH((upghost_head_kernel<T, D>), grid, block, s, p, p.Wdw, p.bdw, p.Wh, p.bh, p.Wdh, p.bdh); break;
+#if defined(ACH_HEAD_DEBUG)
+            switch (dbg) { ACH_UGH_CASE(1) ACH_UGH_CASE(3) ACH_UGH_CASE(7) ACH_UGH_CASE(14) ACH_UGH_CASE(15) default: ACH_UGH_CASE(0) }
+#else
+            switch (dbg) { default: ACH_UGH_CASE(0) }
+#endif
+#undef ACH_UGH_CASE
+        }, bytes);
     }
 
     A cat_buf[2];                     // concat buffers of the top-down path when the backbone writes its features into them
@@ -1069,7 +1108,19 @@ public:
             const int C = chans[i], Cp = half ? VEC : int(x.ld);     // k-elements per tap in the packed conv matrices
             // AvgPool2d(3,1,1)
             Bordered pooled = alloc_bordered(B, x.H, x.W, C, narrow ? 4 : 0);
-            { PoolParams pp{x.p, x.ld, pooled.p0, pooled.ld, B, x.H, x.W, C, pooled.row, pooled.img};
+            // block 0 reads the raw radar map (> 99 % zeros): occupancy masks (one bit per column) per 16-pixel row segment of the pooled map let rc_front
+            // take its closed-form shortcut on empty segments (k_conv3.h); the reach follows from the offset conv's bias
+            unsigned short* occ = nullptr;
+            int occ_r = 0;
+            const bool strip0 = pool_strip > 0 && (C >= 16 || narrow || (pool_strip > 1 && C >= 8));
+            if (i == 0 && radar_skip && fuse_rc && strip0 && C <= 4 && x.W % 16 == 0 && x.W / 16 <= 32) {
+                const HostTensor& ob = W(d + ".offset_conv.bias");
+                float mx = 0.f;
+                bool finite = true;
+                for (float v : ob.data) { finite = finite && std::isfinite(v); mx = std::max(mx, std::fabs(v)); }
+                if (finite && mx <= 13.f) { occ_r = 2 + int(std::ceil(mx)); occ = static_cast<unsigned short*>(aalloc(size_t(B) * x.H * (x.W / 16) * sizeof(unsigned short))); }
+            }
+            { PoolParams pp{x.p, x.ld, pooled.p0, pooled.ld, B, x.H, x.W, C, pooled.row, pooled.img, occ};
               const double bytes = 2.0 * x.rows() * C * sizeof(T), lbytes = double(x.rows()) * (x.ld + pooled.ld) * sizeof(T);
               // strips of 4 output pixels per thread where a strip is contiguous enough for the loads to coalesce: >= 16 channels, or
               // the 4-channel pixels of block 0 (option "pool_strip": 0 never, 1 as described, 2 also the 8-channel blocks)
@@ -1121,7 +1172,7 @@ public:
                 const long yld = y_bordered ? yb.ld : y.ld;
                 RcFrontParams rp{pooled.p0, pooled.ld, pooled.row, pooled.img, pkom.w, up_f32(b32), pkf.w, up_f32(b16), x.p, x.ld,
                                  y_bordered ? yb.p0 : y.p, yld, y_bordered ? yb.row : long(x.W) * y.ld, y_bordered ? yb.img : long(x.H) * x.W * y.ld,
-                                 B, x.H, x.W, cvp, C};
+                                 B, x.H, x.W, cvp, C, occ, occ_r};
                 // algorithmic bytes: pooled map + residual read once, output written once, REAL channels; the layout figure
                 // counts the pixel pitches the kernel actually moves
                 const double bytes = double(x.rows()) * 3.0 * C * sizeof(T), lbytes = double(x.rows()) * (pooled.ld + x.ld + yld) * sizeof(T);

@@ -150,7 +150,16 @@ struct RcFrontParams {
     const void* R; long ldr;                  // block input (residual)
     void* Y; long ldy, ypr, ypi;              // output: pixel (0,0) of sample 0 and row / image pitches (dense or zero-bordered)
     int B, H, Wd, cv, C;
+    const unsigned short* occ; int occ_r;     // optional occupancy of P per 16-pixel row segment [B][H][Wd/16], one bit per column (avgpool3x3), and the reach of a pixel, see below
 };
+
+// Empty segments (first RCBlock only: its input is the raw radar map, > 99 % zeros — radar_feature_map_generate.ipynb).  If P is
+// exactly zero within `occ_r` rows / columns of a 16-pixel segment — occ_r = 2 + ceil(max |offset-conv bias|): the 3x3 conv window, plus
+// the constant offset the conv then produces, plus the bilinear footprint — then the offsets are the bias, every sampled corner is 0, the
+// contraction accumulates +0 and the output is relu(bias) + residual: the segment takes that shortcut, which evaluates the SAME final
+// expression (bit-identical to the full path).  Dense maps only pay the mask test.  occ_r <= 15: horizontally a segment sees the last occ_r
+// columns of its left neighbour and the first occ_r of its right one (column masks: with whole-segment flags 66 % of the segments of a
+// 256-cells-per-frame map stayed active, with column masks 36 %).
 
 // NARROW (bf16 storage, the first RCBlock: 3 channels): the maps are carried as 4-channel = 8-BYTE pixels (ldp = ldr = ldy = 4, cv = 1).
 // A corner of the sampling and a tap of the conv are one 8-byte load each; a k-slot is one tap x [4 channels | 4 zeros].
@@ -218,8 +227,63 @@ __global__ __launch_bounds__(256, KS == 3 ? 4 : 1) void rc_front_kernel(const Rc
             else xf[s] = *reinterpret_cast<const uint4*>(xp + off[s]);
         }
     };
-    if (wave < ntiles) fetch(wave);
-    for (int tile = wave; tile < ntiles; tile += 4) {
+    unsigned active = 0xffffffffu;                                  // bit t: segment t of this row needs the full path
+    if (p.occ) {                                                    // ntiles <= 32 (engine)
+        unsigned cols = 0;                                          // lane t: columns of segment t occupied in rows oy - occ_r .. oy + occ_r
+        if (lane < ntiles) {                                        // fixed trip count (rows clamped into the map: duplicates do not change an OR)
+            const unsigned short* f = p.occ + long(b) * p.H * ntiles + lane;
+#pragma unroll 8
+            for (int dy = -p.occ_r; dy <= p.occ_r; ++dy) {
+                const int y = oy + dy < 0 ? 0 : (oy + dy > p.H - 1 ? p.H - 1 : oy + dy);
+                cols |= f[y * ntiles];
+            }
+        }
+        const unsigned own = unsigned(wave_ballot64(cols != 0));
+        const unsigned to_right = unsigned(wave_ballot64((cols >> (16 - p.occ_r)) != 0));           // its last occ_r columns reach segment t + 1
+        const unsigned to_left = unsigned(wave_ballot64((cols & ((1u << p.occ_r) - 1u)) != 0));     // its first occ_r columns reach segment t - 1
+        active = own | (to_right << 1) | (to_left >> 1);
+    }
+    const int ch = g * 4;
+    auto finish = [&](int x, bool valid, const f32x4& acc) {        // bias, ReLU, residual, one store
+        if (valid && ch < int(p.ldy)) {
+            float rr[4], ov[4];
+            Store<T>::ld4(static_cast<const T*>(p.R) + (rowpix + x) * p.ldr + ch, rr);
+            ACH_UNROLL
+            for (int i = 0; i < 4; ++i) { const float r = acc[i] + bo[i]; ov[i] = (r > 0.f ? r : 0.f) + rr[i]; }
+            Store<T>::st4(static_cast<T*>(p.Y) + long(b) * p.ypi + long(oy) * p.ypr + long(x) * p.ldy + ch, ov);
+        }
+    };
+    // Segments are dealt to the four waves by RANK among the active (and among the empty) ones, not by position: occupied cells come
+    // in clusters, and position-strided waves would leave one wave with a row's whole cluster.
+    const int wv = wave_uniform(wave);
+    const unsigned tmask = ntiles >= 32 ? 0xffffffffu : ((1u << ntiles) - 1u);
+    unsigned rem = active & tmask;
+    int rank = 0;
+    auto take = [&]() -> int {                                      // this wave's next segment of `rem` (consumed), or -1
+        while (rem) {
+            const int t = __ffsll(static_cast<long long>(rem)) - 1;
+            rem &= rem - 1u;
+            if ((rank++ & 3) == wv) return t;
+        }
+        return -1;
+    };
+    int tile = take();
+    if (tile >= 0) fetch(tile);
+    if (p.occ) {                                                    // empty neighbourhoods: the full path would accumulate +0
+        unsigned rem_e = ~active & tmask;
+        int rank_e = 0;
+        while (rem_e) {
+            const int t = __ffsll(static_cast<long long>(rem_e)) - 1;
+            rem_e &= rem_e - 1u;
+            if ((rank_e++ & 3) != wv) continue;
+            f32x4 zero;
+            zero[0] = zero[1] = zero[2] = zero[3] = 0.f;
+            const int xr = t * 16 + px;
+            finish(xr < p.Wd ? xr : p.Wd - 1, xr < p.Wd, zero);
+        }
+    }
+    while (tile >= 0) {
+        const int next = take();
         const int xr = tile * 16 + px;
         const bool valid = xr < p.Wd;
         const int x = valid ? xr : p.Wd - 1;
@@ -237,7 +301,7 @@ __global__ __launch_bounds__(256, KS == 3 ? 4 : 1) void rc_front_kernel(const Rc
             *reinterpret_cast<float4*>(o) = make_float4(a0[0] + bv[0], a0[1] + bv[1], a0[2] + bv[2], a0[3] + bv[3]);
             *reinterpret_cast<float4*>(o + 4) = make_float4(a1[0] + bv[4], a1[1] + bv[5], a1[2] + bv[6], a1[3] + bv[7]);
         }
-        if (tile + 4 < ntiles) fetch(tile + 4);
+        if (next >= 0) fetch(next);
         wave_sync();
         f32x4 acc;
         acc[0] = acc[1] = acc[2] = acc[3] = 0.f;
@@ -273,14 +337,8 @@ __global__ __launch_bounds__(256, KS == 3 ? 4 : 1) void rc_front_kernel(const Rc
             mfma16<T>(WLDS ? wsh[(2 * KS + s) * 64 + lane] : wfd[WLDS ? 0 : s], frag_pack<T>(v), acc);
         }
         wave_sync();                                                // the LDS tile is rewritten by the next iteration
-        const int ch = g * 4;
-        if (valid && ch < int(p.ldy)) {
-            float rr[4], ov[4];
-            Store<T>::ld4(static_cast<const T*>(p.R) + (rowpix + x) * p.ldr + ch, rr);
-            ACH_UNROLL
-            for (int i = 0; i < 4; ++i) { const float r = acc[i] + bo[i]; ov[i] = (r > 0.f ? r : 0.f) + rr[i]; }
-            Store<T>::st4(static_cast<T*>(p.Y) + long(b) * p.ypi + long(oy) * p.ypr + long(x) * p.ldy + ch, ov);
-        }
+        finish(x, valid, acc);
+        tile = next;
     }
 }
 

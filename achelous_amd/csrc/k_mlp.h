@@ -47,6 +47,7 @@ struct MlpParams {
     const void* W2; const float* b2;      // [C][hidden] packed as ONE chunk of DT tiles with J * (8 / VEC) k-steps ; bias padded to 16 * DT
     long M; int C, k1, J, act; float ln_eps;
     int ln, Cout;                         // ln = 0: no normalisation (plain two-layer chain); Cout: output width (R may be null)
+    int planar_w;                         // chain_kernel only, > 0: Y is written channel-planar per map row, [M / planar_w][Cout][planar_w]
 };
 
 constexpr int MLP_RED_TILES = 4;          // output tiles reduced per LDS round in SPLIT mode
@@ -420,7 +421,14 @@ __global__ __launch_bounds__(256) void chain_kernel(const MlpParams p) {
             float o[8];
             ACH_UNROLL
             for (int r = 0; r < 4; ++r) { o[r] = acc[0][r] + b2[r]; o[4 + r] = acc[1][r] + b2[4 + r]; }
-            Store<T>::st8(static_cast<T*>(p.Y) + mr * p.ldy + nb, o);
+            if (p.planar_w > 0) {                       // [row][channel][x]: the layout upghost_head_mfma_kernel's A operand wants
+                const long row = mr / p.planar_w;
+                T* yo = static_cast<T*>(p.Y) + (row * p.Cout + nb) * p.planar_w + (mr - row * p.planar_w);
+                ACH_UNROLL
+                for (int i = 0; i < 8; ++i) Store<T>::st(yo + long(i) * p.planar_w, o[i]);
+            } else {
+                Store<T>::st8(static_cast<T*>(p.Y) + mr * p.ldy + nb, o);
+            }
         }
     }
 }

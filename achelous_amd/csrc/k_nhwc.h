@@ -764,23 +764,101 @@ struct UpGhostHeadParams {
     const float* Wh; const float* bh;         // head primary: [init][32], [init]
     const float* Wdh; const float* bdh;       // head cheap op: [9][nch], [nch]
     int B, h, w, init, nch, oup;
+    float sy, sx;                             // (h-1)/(2h-1), (w-1)/(2w-1): align_corners source scale (computed on the host, same float division)
 };
 constexpr int UGH_TW = 30, UGH_TH = 6, UGH_CG = 16, UGH_IMAX = 8, UGH_THREADS = 256;
+
+// Phases 2 and 3 of the fused last level, shared by both variants below: thread = position of the 1-halo tile (W1 x H1 <= 256).
+//   x1s: relu(bilinear(t)) on the 2-halo tile, [position][CS] floats (zero outside the map)
+//   hs : head init channels on the 1-halo tile, planar [channel][position]
+// DBG (timing experiments only, engine option head_debug; results are wrong): bit 0 skip phase 1, 1 skip the level's depthwise taps,
+// 2 skip the head 1x1, 3 skip the head's depthwise conv and the stores.
+template <class T, int TW, int TH, int DBG = 0>
+__device__ __forceinline__ void upghost_head_tail(const UpGhostHeadParams& p, const float* x1s, float (*hs)[UGH_THREADS], long b, int bx, int by, int H, int Wd,
+                                                  const float* __restrict__ Wdw, const float* __restrict__ bdw, const float* __restrict__ Wh,
+                                                  const float* __restrict__ bh, const float* __restrict__ Wdh, const float* __restrict__ bdh) {
+    constexpr int CG = UGH_CG, CS = CG + 4, W2 = TW + 4, W1 = TW + 2, H1 = TH + 2;
+    // a row of positions starts on a multiple of 16 threads: the 16 lanes that share an LDS access cycle then read 16 consecutive positions of
+    // ONE row — stride CS = 20 dwords, conflict-free — instead of straddling two rows whose pitch may be a multiple of the 64 banks
+    // (measured on a 30-wide row packed densely: the depthwise taps 52 -> 78 us)
+    constexpr int W1P = (W1 + 15) / 16 * 16;
+    static_assert(W1P * H1 <= UGH_THREADS, "one halo position per thread");
+    const int tid = threadIdx.x;
+    const bool live = tid % W1P < W1 && tid / W1P < H1;
+    const int ly_ = live ? tid / W1P : 0, lx_ = live ? tid % W1P : 0;
+    const int oy = by + ly_ - 1, ox = bx + lx_ - 1;
+    const bool inside = live && oy >= 0 && oy < H && ox >= 0 && ox < Wd;
+    {
+        float hv[UGH_IMAX];
+        ACH_UNROLL
+        for (int j = 0; j < UGH_IMAX; ++j) hv[j] = 0.f;
+        if (inside) {
+            float f[2 * CG];
+            ACH_UNROLL
+            for (int c = 0; c < CG; ++c) f[CG + c] = bdw[c];
+            if (!(DBG & 2))
+            ACH_UNROLL
+            for (int k = 0; k < 9; ++k) {
+                const float* s = x1s + ((ly_ + k / 3) * W2 + lx_ + k % 3) * CS;     // 2-halo coords of the tap
+                ACH_UNROLL
+                for (int c4 = 0; c4 < CG; c4 += 4) {
+                    const float4 sv = *reinterpret_cast<const float4*>(s + c4);
+                    const float* wk = Wdw + k * CG + c4;
+                    f[CG + c4] += sv.x * wk[0]; f[CG + c4 + 1] += sv.y * wk[1]; f[CG + c4 + 2] += sv.z * wk[2]; f[CG + c4 + 3] += sv.w * wk[3];
+                    if (k == 4) { f[c4] = sv.x; f[c4 + 1] = sv.y; f[c4 + 2] = sv.z; f[c4 + 3] = sv.w; }
+                }
+            }
+            ACH_UNROLL
+            for (int c = 0; c < CG; ++c) f[CG + c] = f[CG + c] > 0.f ? f[CG + c] : 0.f;
+            if (p.F && ly_ >= 1 && ly_ <= TH && lx_ >= 1 && lx_ <= TW) {
+                T* fo = static_cast<T*>(p.F) + ((b * H + oy) * long(Wd) + ox) * p.ldf;
+                ACH_UNROLL
+                for (int c4 = 0; c4 < 2 * CG; c4 += 4) { const float v4[4] = {f[c4], f[c4 + 1], f[c4 + 2], f[c4 + 3]}; Store<T>::st4(fo + c4, v4); }
+            }
+            if (!(DBG & 4))
+            ACH_UNROLL
+            for (int j = 0; j < UGH_IMAX; ++j)
+                if (j < p.init) {                                   // two packed partial sums per output channel (v_pk_fma_f32)
+                    const float* w = Wh + j * 2 * CG;
+                    f32x2 a = {bh[j], 0.f};
+                    ACH_UNROLL
+                    for (int c = 0; c < 2 * CG; c += 2) { const f32x2 wv = {w[c], w[c + 1]}, fv = {f[c], f[c + 1]}; a += wv * fv; }
+                    const float r = a[0] + a[1];
+                    hv[j] = r > 0.f ? r : 0.f;
+                }
+        }
+        ACH_UNROLL
+        for (int j = 0; j < UGH_IMAX; ++j) hs[j][tid] = hv[j];
+    }
+    __syncthreads();
+    // ---- outputs: the interior positions
+    if (inside && ly_ >= 1 && ly_ <= TH && lx_ >= 1 && lx_ <= TW && !(DBG & 8)) {
+        const long HW = long(H) * Wd;
+        T* out = static_cast<T*>(p.out) + b * p.oup * HW + long(oy) * Wd + ox;
+        for (int j = 0; j < p.init && j < p.oup; ++j) Store<T>::st(out + j * HW, hs[j][tid]);
+        for (int j = 0; j < p.nch; ++j) {
+            float a = bdh[j];
+            ACH_UNROLL
+            for (int k = 0; k < 9; ++k) a += hs[j][(ly_ - 1 + k / 3) * W1P + lx_ - 1 + k % 3] * Wdh[k * p.nch + j];
+            Store<T>::st(out + (p.init + j) * HW, a > 0.f ? a : 0.f);
+        }
+    }
+}
+
 // Tile 30x6 outputs: its 1-pixel halo is exactly 32x8 = 256 positions = one per thread.  LDS layouts are chosen for the
 // access patterns: x1 rows padded to 20 floats (thread = position reads 16 consecutive floats: stride 20 dwords is
 // conflict-free for ds_read_b128), h1 stored planar [channel][position] (thread = pixel reads one channel at a time).
 // (Measured and rejected in round 2: a 28x12 tile on 512 threads, whose 2-halo is exactly one position per thread — 1.5 instead of
 //  2.8 thread-slots of the bilinear phase per output pixel, 25 % fewer VALU instructions per output in total — ran SLOWER, 160 -> 166 us
 //  (lane) and 215 -> 233 us (semantic): the kernel is not bound by its instruction count)
-template <class T>
+template <class T, int DBG = 0>
 __global__ __launch_bounds__(UGH_THREADS) void upghost_head_kernel(const UpGhostHeadParams p, const float* __restrict__ Wdw, const float* __restrict__ bdw,
                                                            const float* __restrict__ Wh, const float* __restrict__ bh,
                                                            const float* __restrict__ Wdh, const float* __restrict__ bdh) {
     constexpr int TW = UGH_TW, TH = UGH_TH, CG = UGH_CG, CS = CG + 4;
-    constexpr int W2 = TW + 4, H2 = TH + 4, W1 = TW + 2, H1 = TH + 2;
-    static_assert(W1 * H1 == UGH_THREADS, "one halo position per thread");
+    constexpr int W2 = TW + 4, H2 = TH + 4;
     __shared__ float x1s[H2 * W2 * CS];
-    __shared__ float hs[UGH_IMAX][H1 * W1];
+    __shared__ float hs[UGH_IMAX][UGH_THREADS];
     const int H = 2 * p.h, Wd = 2 * p.w;
     // XCD-aware tile order: workgroup w runs on XCD w % 8 (observed dispatch order; a speed assumption only).  Give every XCD
     // a contiguous run of tiles, i.e. whole samples, so the halo re-reads of t and the partial-line NCHW writes of neighbouring
@@ -791,9 +869,10 @@ __global__ __launch_bounds__(UGH_THREADS) void upghost_head_kernel(const UpGhost
     const int bx = int(wg % tiles_x) * TW, by = int((wg / tiles_x) % tiles_y) * TH;
     const long b = wg / (unsigned(tiles_x) * tiles_y);
     const int tid = threadIdx.x;
+    if (!(DBG & 1))
     {   // ---- x1 on the 2-halo tile: thread = position (all 16 channels), so the bilinear geometry is computed once per position;
         // loads are unconditional from clamped coordinates (positions outside the map / past the tile are zeroed afterwards)
-        const float sy = H > 1 ? float(p.h - 1) / float(H - 1) : 0.f, sx = Wd > 1 ? float(p.w - 1) / float(Wd - 1) : 0.f;
+        const float sy = p.sy, sx = p.sx;
         const T* Tq = static_cast<const T*>(p.Tq) + b * p.h * long(p.w) * p.ldt;
         const int ldt = int(p.ldt);
         constexpr int ROUNDS = (H2 * W2 + 255) / 256;
@@ -830,61 +909,152 @@ __global__ __launch_bounds__(UGH_THREADS) void upghost_head_kernel(const UpGhost
         }
     }
     __syncthreads();
-    // ---- f and h1 on the 1-halo tile: thread = position
-    const int ly_ = tid / W1, lx_ = tid % W1;
-    const int oy = by + ly_ - 1, ox = bx + lx_ - 1;
-    const bool inside = oy >= 0 && oy < H && ox >= 0 && ox < Wd;
-    {
-        float hv[UGH_IMAX];
-        ACH_UNROLL
-        for (int j = 0; j < UGH_IMAX; ++j) hv[j] = 0.f;
-        if (inside) {
-            float f[2 * CG];
-            ACH_UNROLL
-            for (int c = 0; c < CG; ++c) f[CG + c] = bdw[c];
-            ACH_UNROLL
-            for (int k = 0; k < 9; ++k) {
-                const float* s = x1s + ((ly_ + k / 3) * W2 + lx_ + k % 3) * CS;     // 2-halo coords of the tap
-                ACH_UNROLL
-                for (int c4 = 0; c4 < CG; c4 += 4) {
-                    const float4 sv = *reinterpret_cast<const float4*>(s + c4);
-                    const float* wk = Wdw + k * CG + c4;
-                    f[CG + c4] += sv.x * wk[0]; f[CG + c4 + 1] += sv.y * wk[1]; f[CG + c4 + 2] += sv.z * wk[2]; f[CG + c4 + 3] += sv.w * wk[3];
-                    if (k == 4) { f[c4] = sv.x; f[c4 + 1] = sv.y; f[c4 + 2] = sv.z; f[c4 + 3] = sv.w; }
-                }
-            }
-            ACH_UNROLL
-            for (int c = 0; c < CG; ++c) f[CG + c] = f[CG + c] > 0.f ? f[CG + c] : 0.f;
-            if (p.F && ly_ >= 1 && ly_ <= TH && lx_ >= 1 && lx_ <= TW) {
-                T* fo = static_cast<T*>(p.F) + ((b * H + oy) * long(Wd) + ox) * p.ldf;
-                ACH_UNROLL
-                for (int c4 = 0; c4 < 2 * CG; c4 += 4) { const float v4[4] = {f[c4], f[c4 + 1], f[c4 + 2], f[c4 + 3]}; Store<T>::st4(fo + c4, v4); }
-            }
-            ACH_UNROLL
-            for (int j = 0; j < UGH_IMAX; ++j)
-                if (j < p.init) {                                   // two packed partial sums per output channel (v_pk_fma_f32)
-                    const float* w = Wh + j * 2 * CG;
-                    f32x2 a = {bh[j], 0.f};
-                    ACH_UNROLL
-                    for (int c = 0; c < 2 * CG; c += 2) { const f32x2 wv = {w[c], w[c + 1]}, fv = {f[c], f[c + 1]}; a += wv * fv; }
-                    const float r = a[0] + a[1];
-                    hv[j] = r > 0.f ? r : 0.f;
-                }
-        }
-        ACH_UNROLL
-        for (int j = 0; j < UGH_IMAX; ++j) hs[j][tid] = hv[j];
+    upghost_head_tail<T, TW, TH, DBG>(p, x1s, hs, b, bx, by, H, Wd, Wdw, bdw, Wh, bh, Wdh, bdh);
+}
+
+// The same fused level with the bilinear phase on the matrix cores (bf16 storage).  x2 bilinear interpolation is separable:
+//   v[i][x][c]  = sum_j Ax[x][j] t[i][j][c]            along x: a 16-pixel segment needs <= 10 source columns -> ONE MFMA per (source row,
+//                                                      segment), K = 16 columns x {hi, lo}: the fp32 interpolation weight is split into two bf16
+//                                                      halves so that the product is exact to 2^-17 (plain bf16 weights would cost 2^-9)
+//   x1[y][x][c] = relu(hy v[y0][x][c] + ly v[y0+1][x][c])   along y on the VALU, fp32: 2 FMA per value instead of 4, no bf16 unpacking,
+//                                                      one 16-byte load per (source row, channel, segment) instead of four corner gathers per position
+// For the MFMA's A operand (16 channels x K source columns, 8 consecutive k per lane) t must be CHANNEL-PLANAR per row, [B*h][16][w]:
+// its producer (chain_kernel, planar_w) writes it that way.  The weights are the B operand, built once per wave; the product lands as
+// lane (pixel, 4 channels) and goes to LDS in the [position][CS] layout of the tail phases.  Requires w % 4 == 0 (8-byte aligned window).
+// NSEG segments of 16 columns x H2 rows, split over the four waves as (segment, RPW consecutive rows); RPW = 5 -> 4 source rows per wave.
+constexpr int UGM_NSEG = 2, UGM_TH = 6;       // 28 x 6 outputs per tile
+constexpr int UGM_GRID = 0;                   // > 0: that many persistent workgroups walk the tiles (option head_grid); 0: one tile per workgroup
+// Instruction budget of phase 1 (the kernel is VALU-issue bound at ~80 % busy, so its time is its instruction count): everything that is
+// the same for the whole wave stays off the vector pipe — the per-row geometry (y0, weights) is computed ONCE by lanes 0..RPW-1 and read
+// back with v_readlane, the row select is a scalar branch, the load addresses are a constant per-lane offset + a scalar offset (MUBUF
+// soffset), the past-the-row mask is a scalar branch taken only by the right-most tiles.
+// UGM_PREFETCH (persistent form only): request the next tile's source fragments before the current tile's tail phases
+template <int NSEG, int TH, bool UGM_PREFETCH, int DBG = 0>
+__global__ __launch_bounds__(UGH_THREADS, 4) void upghost_head_mfma_kernel(const UpGhostHeadParams p, const float* __restrict__ Wdw, const float* __restrict__ bdw,
+                                                                const float* __restrict__ Wh, const float* __restrict__ bh,
+                                                                const float* __restrict__ Wdh, const float* __restrict__ bdh) {
+    typedef bf16_t T;
+    constexpr int TW = 16 * NSEG - 4, CG = UGH_CG, CS = CG + 4;
+    constexpr int W2 = TW + 4, H2 = TH + 4;
+    constexpr int RPW = H2 * NSEG / 4, NSRC = (RPW - 1) / 2 + 2;
+    static_assert(RPW * 4 == H2 * NSEG && (NSEG == 1 || NSEG == 2 || NSEG == 4), "rows split evenly over the four waves");
+    static_assert(NSRC <= 4, "source rows per wave");
+    __shared__ float x1s[H2 * W2 * CS];
+    __shared__ float hs[UGH_IMAX][UGH_THREADS];
+    const int H = 2 * p.h, Wd = 2 * p.w;
+    const int tiles_x = (Wd + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const unsigned per_frame = unsigned(tiles_x) * tiles_y, ntiles = per_frame * unsigned(p.B);
+    // tiles of this workgroup: workgroup w runs on XCD w % 8; every XCD takes one contiguous eighth of the tiles (whole frames: halo
+    // re-reads of t and the partial-line NCHW writes of neighbouring tiles meet in one L2), its workgroups interleaved over that run
+    unsigned t_begin, t_end, t_step;
+    if (gridDim.x % 8 == 0) {
+        const unsigned xcd = blockIdx.x & 7u, li = blockIdx.x >> 3, per = gridDim.x >> 3;
+        const unsigned lo = unsigned((unsigned long long)(ntiles) * xcd / 8), hi = unsigned((unsigned long long)(ntiles) * (xcd + 1) / 8);
+        t_begin = lo + li; t_end = hi; t_step = per;
+    } else {
+        t_begin = blockIdx.x; t_end = ntiles; t_step = gridDim.x;
     }
-    __syncthreads();
-    // ---- outputs: the interior positions
-    if (!inside || ly_ < 1 || ly_ > TH || lx_ < 1 || lx_ > TW) return;
-    const long HW = long(H) * Wd;
-    T* out = static_cast<T*>(p.out) + b * p.oup * HW + long(oy) * Wd + ox;
-    for (int j = 0; j < p.init && j < p.oup; ++j) Store<T>::st(out + j * HW, hs[j][tid]);
-    for (int j = 0; j < p.nch; ++j) {
-        float a = bdh[j];
+    const int lane = threadIdx.x & 63, wave = wave_uniform(int(threadIdx.x >> 6));
+    const int px = lane & 15, g = lane >> 4;
+    const int seg = wave % NSEG, r0 = (wave / NSEG) * RPW;
+    const float sy = p.sy, sx = p.sx;
+    auto clampi = [](int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); };
+    // the engine keeps 16 readable bytes behind t: the window of the last row's last channel may start in its final 16 bytes
+    const BufRsrc tb = make_buf(p.Tq, unsigned(size_t(p.B) * p.h * CG * p.w * sizeof(T)) + 16u);
+    const unsigned voff = unsigned((px * p.w + (g & 1) * 8) * int(sizeof(T)));          // channel px, window columns (g & 1) * 8 ..
+    struct Geo { int bx, by, win0, ymin, k0; float wa, wb; long b; };
+    auto geometry = [&](unsigned t) {
+        Geo q;
+        q.b = t / per_frame;
+        const unsigned rem = t - unsigned(q.b) * per_frame;
+        q.by = int(rem / unsigned(tiles_x)) * TH; q.bx = int(rem % unsigned(tiles_x)) * TW;
+        // source window of this wave's segment: 16 columns from a multiple of 4 at or below the first pixel's left neighbour
+        int xfirst = wave_uniform(int(sx * float(clampi(q.bx - 2 + seg * 16, Wd - 1))));
+        if (xfirst > p.w - 1) xfirst = p.w - 1;
+        q.win0 = xfirst & ~3;
+        // row geometry: lane r < RPW holds output row r0 + r of this wave (other lanes compute a copy of the last row: harmless)
+        const int oy = q.by - 2 + r0 + (lane < RPW ? lane : RPW - 1);
+        const bool oky = oy >= 0 && oy < H;
+        const float fy = sy * float(clampi(oy, H - 1));
+        int y0 = int(fy);
+        if (y0 > p.h - 1) y0 = p.h - 1;
+        const float ly = oky ? fy - float(y0) : 0.f, hy = oky ? 1.f - (fy - float(y0)) : 0.f;
+        const bool last = y0 >= p.h - 1;                            // bottom row: both taps are row y0
+        q.wa = last ? hy + ly : hy; q.wb = last ? 0.f : ly;
+        q.ymin = wave_lane_i32(y0, 0);
+        q.k0 = y0 - q.ymin;                                         // 0 .. NSRC-2 (RPW rows span < RPW/2 source rows)
+        return q;
+    };
+    uint4 tf[NSRC];
+    auto request = [&](const Geo& q) {          // A operand fragments of source rows ymin .. ymin + NSRC - 1
         ACH_UNROLL
-        for (int k = 0; k < 9; ++k) a += hs[j][(ly_ - 1 + k / 3) * W1 + lx_ - 1 + k % 3] * Wdh[k * p.nch + j];
-        Store<T>::st(out + (p.init + j) * HW, a > 0.f ? a : 0.f);
+        for (int k = 0; k < NSRC; ++k) {
+            const int sr = q.ymin + k < p.h ? q.ymin + k : p.h - 1;
+            const unsigned soff = unsigned(((q.b * p.h + sr) * CG) * long(p.w) + q.win0) * unsigned(sizeof(T));
+            tf[k] = buf_load16s(tb, voff, soff);
+        }
+    };
+    Geo q = geometry(t_begin < t_end ? t_begin : 0u);
+    if (t_begin < t_end && !(DBG & 1)) request(q);
+    for (unsigned t = t_begin; t < t_end; t += t_step) {
+        const int bx = q.bx, by = q.by;
+        const long b = q.b;
+        if (!(DBG & 1)) {
+            uint4 wfrag;
+            {   // B operand: this lane's pixel, k = g*8 + i -> window column (g&1)*8 + i, hi half (g < 2) or lo half of the weight
+                const int ox = bx - 2 + seg * 16 + px;
+                const bool okx = ox >= 0 && ox < Wd;
+                const float fx = sx * float(clampi(ox, Wd - 1));
+                int x0 = int(fx);
+                if (x0 > p.w - 1) x0 = p.w - 1;
+                const bool edge = x0 >= p.w - 1;                    // right column: both taps are column x0
+                const float lx = edge ? 0.f : fx - float(x0), hx = edge ? 1.f : 1.f - (fx - float(x0));
+                const float hxh = bf16_to_f32(f32_to_bf16(hx)), lxh = bf16_to_f32(f32_to_bf16(lx));
+                const float wa = okx ? (g < 2 ? hxh : hx - hxh) : 0.f, wb = okx ? (g < 2 ? lxh : lx - lxh) : 0.f;
+                const int rel = x0 - q.win0 - (g & 1) * 8;          // slot of the left tap in this lane's 8 columns (may be outside 0..7)
+                float wv[8];
+                ACH_UNROLL
+                for (int i = 0; i < 8; ++i) wv[i] = (i == rel ? wa : 0.f) + (i == rel + 1 ? wb : 0.f);
+                wfrag = frag_pack<T>(wv);
+            }
+            if (q.win0 + 16 > p.w) {            // right-most tiles: the window runs past the row (another channel's data, or the guard bytes): zero it
+                const int colb = q.win0 + (g & 1) * 8;
+                const bool keep_lo = colb + 4 <= p.w, keep_hi = colb + 8 <= p.w;
+                ACH_UNROLL
+                for (int k = 0; k < NSRC; ++k) {
+                    tf[k].x = keep_lo ? tf[k].x : 0u; tf[k].y = keep_lo ? tf[k].y : 0u; tf[k].z = keep_hi ? tf[k].z : 0u; tf[k].w = keep_hi ? tf[k].w : 0u;
+                }
+            }
+            f32x4 v[NSRC];
+            ACH_UNROLL
+            for (int k = 0; k < NSRC; ++k) {
+                v[k][0] = v[k][1] = v[k][2] = v[k][3] = 0.f;
+                mfma16<T>(tf[k], wfrag, v[k]);
+            }
+            const Geo cur = q;
+            if (UGM_PREFETCH && t + t_step < t_end) { q = geometry(t + t_step); request(q); }     // in flight during this tile's tail
+            ACH_UNROLL
+            for (int r = 0; r < RPW; ++r) {
+                const int k0 = wave_lane_i32(cur.k0, r);
+                const float wa = wave_lane_f32(cur.wa, r), wb = wave_lane_f32(cur.wb, r);
+                f32x4 o = {0.f, 0.f, 0.f, 0.f};
+                ACH_UNROLL
+                for (int kk = 0; kk < NSRC - 1; ++kk)
+                    if (kk == k0) {
+                        ACH_UNROLL
+                        for (int c = 0; c < 4; ++c) { const float s = wa * v[kk][c] + wb * v[kk + 1][c]; o[c] = s > 0.f ? s : 0.f; }
+                    }
+                const int pos = (r0 + r) * W2 + seg * 16 + px;
+                *reinterpret_cast<float4*>(x1s + pos * CS + g * 4) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+            if (!UGM_PREFETCH && t + t_step < t_end) { q = geometry(t + t_step); }
+        } else if (t + t_step < t_end) {
+            q = geometry(t + t_step);
+        }
+        __syncthreads();
+        upghost_head_tail<T, TW, TH, DBG>(p, x1s, hs, b, bx, by, H, Wd, Wdw, bdw, Wh, bh, Wdh, bdh);
+        // the next tile's phase 1 writes x1s only; its barrier orders this tile's reads of hs before the next writes to it
+        if (!UGM_PREFETCH && !(DBG & 1) && t + t_step < t_end) request(q);
     }
 }
 

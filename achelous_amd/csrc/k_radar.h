@@ -49,7 +49,8 @@ __global__ __launch_bounds__(256) void nchw3_to_nhwc4_kernel(const ToNhwcParams 
 // AvgPool2d(3, stride 1, pad 1, count_include_pad=True): always divides by 9
 // The output goes to a buffer with a one-pixel ZERO BORDER around every sample (Y points at pixel (0,0) of sample 0, ypr / ypi are
 // its row / image pitches in elements): the 3x3 conv and the deformable sampling that read it need no bounds logic at all.
-struct PoolParams { const void* X; long ldx; void* Y; long ldy; int B, H, Wd, C; long ypr, ypi; };
+struct PoolParams { const void* X; long ldx; void* Y; long ldy; int B, H, Wd, C; long ypr, ypi;
+                    unsigned short* occ; };    // optional [B][H][Wd/16]: bit c set where column c of a 16-pixel row segment of the OUTPUT is non-zero (rc_front's skip test)
 // One thread = 4 channels x a strip of AVG_OW consecutive output pixels of one row: the 3 x (AVG_OW + 2) window is fetched once
 // (18 loads for 4 outputs instead of 36), summed by columns first and then across three columns — the kernel was VALU-issue bound
 // (SQ counters: 239 VALU instructions per wave against a 46 us launch at 320x320, exactly the VALU floor), and per output this
@@ -61,8 +62,10 @@ __global__ __launch_bounds__(256) void avgpool3x3_kernel(const PoolParams p) {
     const int cq = (p.C + 3) >> 2;
     const int strips = (p.Wd + AVG_OW - 1) / AVG_OW;
     const long total = long(p.B) * p.H * strips * cq;
-    const long idx = long(xcd_block(blockIdx.x, gridDim.x)) * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
+    const long idx_raw = long(xcd_block(blockIdx.x, gridDim.x)) * blockDim.x + threadIdx.x;
+    const bool live = idx_raw < total;
+    if (!live && !p.occ) return;                     // with occupancy flags every lane takes part in the ballot below
+    const long idx = live ? idx_raw : total - 1;
     const int c = int(idx % cq) * 4;
     long r = idx / cq;
     const int x0 = int(r % strips) * AVG_OW; r /= strips;
@@ -93,13 +96,22 @@ __global__ __launch_bounds__(256) void avgpool3x3_kernel(const PoolParams p) {
         }
     }
     T* yrow = static_cast<T*>(p.Y) + b * p.ypi + y * p.ypr + c;
+    int nz = 0;                                      // bit o: output pixel x0 + o is non-zero in some channel
     ACH_UNROLL
     for (int o = 0; o < AVG_OW; ++o) {
         if (x0 + o >= p.Wd) break;
         float acc[4];
         ACH_UNROLL
-        for (int i = 0; i < 4; ++i) acc[i] = ((col[o][i] + col[o + 1][i]) + col[o + 2][i]) * (1.0f / 9.0f);
-        Store<T>::st4(yrow + long(x0 + o) * p.ldy, acc);
+        for (int i = 0; i < 4; ++i) { acc[i] = ((col[o][i] + col[o + 1][i]) + col[o + 2][i]) * (1.0f / 9.0f); nz |= !(acc[i] == 0.f) ? 1 << o : 0; }     // NaN counts as occupied
+        if (live) Store<T>::st4(yrow + long(x0 + o) * p.ldy, acc);
+    }
+    if (AVG_OW == 4 && p.occ) {
+        // engine guarantees one channel group per pixel and Wd % 16 == 0: four consecutive lanes (aligned: rows are multiples of 4 strips and
+        // workgroups of 64 strips) hold the four strips of one 16-pixel segment; two butterfly steps gather their 4-bit masks in the first
+        int m = live ? nz : 0;
+        m |= __shfl_xor(m, 1) << 4;                  // valid in even lanes: strips s, s+1
+        m |= __shfl_xor(m, 2) << 8;                  // valid in lanes % 4 == 0: strips s .. s+3
+        if (live && (threadIdx.x & 3) == 0) p.occ[(b * p.H + y) * long(p.Wd >> 4) + (x0 >> 4)] = static_cast<unsigned short>(m & 0xffff);
     }
 }
 

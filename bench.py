@@ -112,6 +112,7 @@ def main():
     ap.add_argument('--separate-calls', action='store_true', help='forward, decode_outputs and NMS as three calls instead of forward_detect')
     ap.add_argument('--pipeline', action='store_true', help='submit / wait serving loop (batch k+1 enqueued before batch k is joined; engine option "pipeline") instead of one plain forward_detect per step.  Measured no faster (2.54 vs 2.48 ms): the chip is work-bound, DESIGN 4.10')
     ap.add_argument('--extra-stream', action='store_true', help='diagnostic: also launch a tiny copy on a separate stream every step (stands in for a collective stream)')
+    ap.add_argument('--dense-radar', action='store_true', help='stress variant: U(0,1) in every cell of the radar map instead of 256 occupied cells per frame (SURVEY 8d); nothing is skipped in the first RCBlock')
     ap.add_argument('--opt', action='append', default=[], help='engine option key=value (ach_set_option), repeatable')
     ap.add_argument('--force-collective', action='store_true', help='diagnostic: run the RCCL all-gather of the detection records even at world size 1')
     ap.add_argument('--ops-json', default=None, help='write the per-launch table (ms, algorithmic bytes) here')
@@ -146,7 +147,7 @@ def main():
     model.static_weights = True          # serving loop: weights do not change between steps
     model.engine_options = {kv.split('=')[0]: int(kv.split('=')[1]) for kv in args.opt}
     B = args.batch
-    x, xr, xp = make_inputs(B, config_seed(cid) + 1000 * rank, resolution=COMMON['resolution'], pc_channels=COMMON['pc_channels'])
+    x, xr, xp = make_inputs(B, config_seed(cid) + 1000 * rank, resolution=COMMON['resolution'], pc_channels=COMMON['pc_channels'], dense_radar=args.dense_radar)
     x, xr, xp = x.to(dev, tdt), xr.to(dev, tdt), xp.to(dev, tdt)
     gathered = [torch.empty(world * B * (args.max_det * 8 + 1), dtype=torch.int32, device=dev) for _ in range(2)] if collective else None
     state = {'k': 0, 'pending': None, 'inflight': None, 'last': None}
@@ -309,6 +310,7 @@ def main():
             'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': f'{WORKLOAD_NAMES[args.config]} forward + decode + NMS, 320x320 image + radar map, '
                                    f'512 points, batch {B} per GPU, all 5 heads, seeded random weights',
+                       'radar_map': 'dense U(0,1) (stress variant)' if args.dense_radar else '256 occupied cells per frame of 102 400 (SURVEY 8d: real maps are > 99 % zeros)',
                        'global_batch': world * B, 'parallelism': f'batch-sharded x{world}' + (' + RCCL all-gather of detections' if world > 1 else ''),
                        'launches_per_forward': len(table)},
             'host_enqueue_ms_per_step': round((th - t0) / args.steps * 1e3, 4),

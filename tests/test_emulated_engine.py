@@ -318,3 +318,60 @@ def test_emulated_fused_mv2_blocks_agree_with_the_three_launches(dtype, tol):
         outs.append([t.float() for t in o] + [eng.read_tap('map2'), eng.read_tap('map3')])
     for a, b in zip(*outs):
         assert rel_err(a, b) < tol
+
+
+@pytest.mark.parametrize('res,batch', [(128, 1), (96, 2)])
+def test_emulated_mfma_bilinear_head_agrees_with_the_per_position_kernel(res, batch):
+    """bf16: the fused last decoder level with its bilinear phase on the matrix cores (upghost_head_mfma_kernel: channel-planar t from
+    chain_kernel, interpolation weights split hi + lo so the product is exact to 2^-17) against the per-position gather kernel.  Both end
+    in the same fp32 tail, so the segmentation outputs and the `lane.1_to_0` / `se.1_to_0` taps may differ by a bf16 rounding flip at most.
+    128: ragged 12x16 tiles in x; 96: ragged in x and y, two frames."""
+    from achelous_amd.engine import NativeEngine
+    kw, sd, (x, xr, xp) = _setup('en_s0', res, batch, 16)
+    td = torch.bfloat16
+    outs = []
+    for v in (1, 0):
+        eng = NativeEngine(emu_library(), num_det=kw['num_det'], num_seg=kw['num_seg'], phi=kw['phi'], backbone=kw['backbone'],
+                           resolution=kw['resolution'], pc_channels=kw['pc_channels'], pc_classes=kw['pc_classes'],
+                           num_points=16, nano_head=kw['nano_head'], spp=kw['spp'], dtype=DTYPE_BF16)
+        eng.set_option('head_mfma', v)
+        eng.set_option('head_grid', 8 if res == 128 else 5)          # persistent workgroups walk several tiles each (XCD split / plain stride)
+        eng.set_option('full_taps', 1)
+        eng.load_state_dict(sd)
+        eng.plan(batch)
+        o = alloc_outputs(kw, batch, 16, td, 'cpu')
+        eng.forward(x.to(td), xr.to(td), xp.to(td), o)
+        outs.append({'se': o[3].float(), 'lane': o[4].float(), 'lane.1_to_0': eng.read_tap('lane.1_to_0'), 'se.1_to_0': eng.read_tap('se.1_to_0')})
+    for k in outs[0]:
+        a, b = outs[0][k], outs[1][k]
+        assert a.shape == b.shape
+        assert rel_err(a, b) < 1e-2, (k, rel_err(a, b))
+        assert float((a != b).float().mean()) < 0.05, (k, float((a != b).float().mean()))
+
+
+@pytest.mark.parametrize('dtype', [DTYPE_F32, DTYPE_BF16])
+@pytest.mark.parametrize('cells', [0, 2, 40, -1])
+def test_emulated_radar_skip_is_bit_identical(dtype, cells):
+    """First RCBlock: segments of 16 pixels whose neighbourhood of the pooled radar map is empty take the closed-form shortcut
+    relu(bias) + residual (k_conv3.h, option radar_skip).  The full path on such a segment accumulates +0, so both plans must agree BIT FOR
+    BIT — on an empty map (every segment skipped), a sparse one, the fixtures' density and a dense map (cells = -1: nothing skipped)."""
+    from achelous_amd.engine import NativeEngine
+    kw, sd, _ = _setup('en_s0', 96, 2, 16)
+    x, xr, xp = make_inputs(2, 11, resolution=96, num_points=16, pc_channels=kw['pc_channels'], radar_cells=max(cells, 1), dense_radar=cells < 0)
+    if cells == 0:
+        xr = torch.zeros_like(xr)
+    td = torch.float32 if dtype == DTYPE_F32 else torch.bfloat16
+    outs = []
+    for v in (1, 0):
+        eng = NativeEngine(emu_library(), num_det=kw['num_det'], num_seg=kw['num_seg'], phi=kw['phi'], backbone=kw['backbone'],
+                           resolution=kw['resolution'], pc_channels=kw['pc_channels'], pc_classes=kw['pc_classes'],
+                           num_points=16, nano_head=kw['nano_head'], spp=kw['spp'], dtype=dtype)
+        eng.set_option('radar_skip', v)
+        eng.set_option('full_taps', 1)
+        eng.load_state_dict(sd)
+        eng.plan(2)
+        o = alloc_outputs(kw, 2, 16, td, 'cpu')
+        eng.forward(x.to(td), xr.to(td), xp.to(td), o)
+        outs.append([t.float() for t in o[:3]] + [eng.read_tap(t) for t in ('radar.b0', 'radar.b1', 'r3', 'r5')])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)

@@ -364,7 +364,7 @@ def test_forward_detect_equals_the_three_calls():
                 assert int(cnt.max()) > 0
 
 
-@pytest.mark.parametrize('option', ['fused_mlp', 'row_conv', 'fused_rc', 'dw_tile', 'head_batch', 'split_decoders', 'head_stream', 'stem_mfma', 'radar_start'])
+@pytest.mark.parametrize('option', ['fused_mlp', 'row_conv', 'fused_rc', 'dw_tile', 'head_batch', 'split_decoders', 'head_stream', 'stem_mfma', 'radar_start', 'head_mfma', 'radar_skip'])
 def test_fused_kernels_agree_with_the_layerwise_path(option):
     """Every fused / batched kernel has a switch back to the layer-wise launches it replaced (include/achelous.h): the two plans
     must agree — to fp32 rounding in the fp32 engine (different summation order), and within the bf16 tolerance in the bf16
@@ -377,7 +377,7 @@ def test_fused_kernels_agree_with_the_layerwise_path(option):
         with torch.no_grad():
             ref = m(xs, rs, ps)
             e = _engine_of(m, dt)
-            default = 0 if option == 'split_decoders' else 1
+            default = 0 if option in ('split_decoders', 'head_mfma') else 1
             e.set_option(option, 1 - default)
             e.plan(2)
             alt = m(xs, rs, ps)
@@ -388,6 +388,59 @@ def test_fused_kernels_agree_with_the_layerwise_path(option):
             # two bf16 plans that are each within bf16_bound of the fp32 truth may differ from each other by twice that
             tol = 1e-4 if dt == torch.float32 else 2.0 * bf16_bound(g, k)
             assert _rel(a.float(), b.float()) <= tol, (option, dt, k, _rel(a.float(), b.float()), tol)
+
+
+@pytest.mark.parametrize('res,batch', [(320, 3), (416, 1), (96, 2)])
+def test_mfma_bilinear_head_matches_the_gather_head(res, batch):
+    """bf16 engine: the fused last decoder level with its bilinear phase on the matrix cores (channel-planar t, interpolation weights split
+    hi + lo: exact to 2^-17; option head_mfma = 1, off by default: measured slower) against the per-position gather kernel.  Both end in the same fp32 tail, so the two
+    segmentation outputs may differ by isolated bf16 rounding flips only.  416 and 96 have ragged 12 x 16 tiles at the right / bottom
+    edges; the last frame's last row exercises the window load that starts in the tensor's final 16 bytes."""
+    g = Golden('en_s0')
+    kw = dict(ctor_kwargs(g.meta), resolution=res)
+    m = Achelous(**kw).eval()
+    m.load_state_dict(g.calibrate(condition_state_dict(m.state_dict(), seed=g.meta['weight_seed'])), strict=True)
+    m = m.cuda()
+    x, xr, xp = make_inputs(batch, 23, resolution=res, pc_channels=kw['pc_channels'])
+    xs, rs, ps = x.cuda().bfloat16(), xr.cuda().bfloat16(), xp.cuda().bfloat16()
+    with torch.no_grad():
+        old = m(xs, rs, ps)
+        e = _engine_of(m, torch.bfloat16)
+        e.set_option('head_mfma', 1)
+        e.plan(batch)
+        new = m(xs, rs, ps)
+        torch.cuda.synchronize()
+        e.set_option('head_mfma', 0)
+        e.plan(batch)
+    for k, a, b in (('se_seg', new[1], old[1]), ('lane_seg', new[2], old[2])):
+        a, b = a.float(), b.float()
+        assert _rel(a, b) <= 1.6e-2, (k, _rel(a, b))                      # one bf16 ulp of the largest value
+        assert float((a != b).float().mean()) < 5e-3, (k, float((a != b).float().mean()))
+
+
+@pytest.mark.parametrize('cells', [0, 8, 256, -1])
+def test_radar_skip_is_bit_identical(cells):
+    """First RCBlock: 16-pixel segments whose neighbourhood of the pooled radar map is empty take the closed-form shortcut
+    relu(bias) + residual (k_conv3.h, option radar_skip, on by default).  The full path accumulates +0 there, so the two plans agree BIT
+    FOR BIT: empty map, a few cells, the bench's density (256 cells per frame) and a dense map (cells = -1: nothing is skipped)."""
+    g = Golden('en_s0')
+    m, kw = _model(g)
+    x, xr, xp = make_inputs(3, 29, resolution=kw['resolution'], pc_channels=kw['pc_channels'], radar_cells=max(cells, 1), dense_radar=cells < 0)
+    if cells == 0:
+        xr = torch.zeros_like(xr)
+    for dt in (torch.float32, torch.bfloat16):
+        xs, rs, ps = x.cuda().to(dt), xr.cuda().to(dt), xp.cuda().to(dt)
+        with torch.no_grad():
+            on = m(xs, rs, ps)
+            e = _engine_of(m, dt)
+            e.set_option('radar_skip', 0)
+            e.plan(3)
+            off = m(xs, rs, ps)
+            torch.cuda.synchronize()
+            e.set_option('radar_skip', 1)
+            e.plan(3)
+        for a, b in zip(on[0], off[0]):
+            assert torch.equal(a, b)
 
 
 def test_reference_default_resolution_416():
