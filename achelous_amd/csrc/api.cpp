@@ -6,6 +6,7 @@
 
 #include "engine.h"
 #include "k_train.h"
+#include "k_train2.h"
 
 struct ach_handle {
     ach::EngineBase* eng = nullptr;
@@ -287,6 +288,149 @@ int ach_train_log_softmax(const float* z, float* y, const float* dy, float* dz, 
         else { if (!dz) throw ach::AchError{ACH_ERR_INVALID, "bad train_log_softmax arguments"}; ACH_LAUNCH(ach::train_log_softmax_bwd_kernel, grid, dim3(256), static_cast<hipStream_t>(stream), p); }
     });
 }
+
+// ---- training-mode primitives of k_train2.h
+#define ACH_TRAIN_1D(kern, p, total) ACH_LAUNCH(kern, dim3(unsigned(ach::cdivl((total), 256))), dim3(256), static_cast<hipStream_t>(stream), p)
+#define ACH_TRAIN_ROWS(kern, p, nblocks) ACH_LAUNCH(kern, dim3(unsigned(nblocks)), dim3(256), static_cast<hipStream_t>(stream), p)
+static void train_need(bool ok, const char* what) { if (!ok) throw ach::AchError{ACH_ERR_INVALID, std::string("bad arguments: ") + what}; }
+int ach_train_act(const float* x, const float* dy, float* out, int64_t n, int32_t kind, void* stream) {
+    return train_guard([&] {
+        train_need(x && out && n > 0 && kind >= 0 && kind <= 3, "ach_train_act");
+        ach::TrainActParams p{x, dy, out, long(n), kind};
+        ACH_TRAIN_1D(ach::train_act_kernel, p, long(n));
+    });
+}
+int ach_train_layernorm(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, int64_t rows, int32_t C, int64_t inner,
+                        float eps, void* stream) {
+    return train_guard([&] {
+        train_need(x && gamma && beta && y && mean && rstd && rows > 0 && C > 0 && inner > 0, "ach_train_layernorm");
+        ach::TrainLnParams p{x, gamma, beta, y, mean, rstd, long(rows), C, long(inner), eps};
+        ACH_TRAIN_1D(ach::train_ln_fwd_kernel, p, long(rows) * inner);
+    });
+}
+int ach_train_layernorm_bwd(const float* x, const float* dy, const float* gamma, const float* mean, const float* rstd, float* dx, float* dgamma, float* dbeta,
+                            int64_t rows, int32_t C, int64_t inner, void* stream) {
+    return train_guard([&] {
+        train_need(x && dy && gamma && mean && rstd && dx && dgamma && dbeta && rows > 0 && C > 0 && inner > 0, "ach_train_layernorm_bwd");
+        ach::TrainLnBwdParams p{x, dy, gamma, mean, rstd, dx, dgamma, dbeta, long(rows), C, long(inner)};
+        ACH_TRAIN_1D(ach::train_ln_bwd_dx_kernel, p, long(rows) * inner);
+        ACH_TRAIN_ROWS(ach::train_ln_bwd_param_kernel, p, C);
+    });
+}
+int ach_train_dwconv(const float* x, const float* w, const float* bias, float* y, int32_t B, int32_t C, int32_t H, int32_t W, int32_t k, int32_t flip, void* stream) {
+    return train_guard([&] {
+        train_need(x && w && y && B > 0 && C > 0 && H > 0 && W > 0 && k > 0 && (k & 1), "ach_train_dwconv");
+        ach::TrainDwParams p{x, w, bias, y, B, C, H, W, k, flip};
+        ACH_TRAIN_1D(ach::train_dwconv_kernel, p, long(B) * C * H * W);
+    });
+}
+int ach_train_dwconv_wgrad(const float* x, const float* dz, float* dw, int32_t B, int32_t C, int32_t H, int32_t W, int32_t k, void* stream) {
+    return train_guard([&] {
+        train_need(x && dz && dw && B > 0 && C > 0 && H > 0 && W > 0 && k > 0 && (k & 1), "ach_train_dwconv_wgrad");
+        ach::TrainDwWgradParams p{x, dz, dw, B, C, H, W, k};
+        ACH_TRAIN_ROWS(ach::train_dwconv_wgrad_kernel, p, long(C) * k * k);
+    });
+}
+int ach_train_im2col(const float* src, float* dst, int32_t B, int32_t C, int32_t H, int32_t W, int32_t kh, int32_t kw, int32_t sh, int32_t sw, int32_t ph, int32_t pw,
+                     int32_t Ho, int32_t Wo, int32_t backward, void* stream) {
+    return train_guard([&] {
+        train_need(src && dst && B > 0 && C > 0 && H > 0 && W > 0 && kh > 0 && kw > 0 && sh > 0 && sw > 0 && Ho > 0 && Wo > 0, "ach_train_im2col");
+        ach::TrainColParams p{src, dst, B, C, H, W, kh, kw, sh, sw, ph, pw, Ho, Wo};
+        if (!backward) ACH_TRAIN_1D(ach::train_im2col_kernel, p, long(B) * C * kh * kw * Ho * Wo);
+        else ACH_TRAIN_1D(ach::train_col2im_kernel, p, long(B) * C * H * W);
+    });
+}
+int ach_train_softmax(const float* x, float* y, const float* dy, float* dx, int64_t rows, int32_t d, void* stream) {
+    return train_guard([&] {
+        train_need(y && rows > 0 && d > 0 && (dy ? dx != nullptr : x != nullptr), "ach_train_softmax");
+        ach::TrainSoftmaxParams p{x, y, dy, dx, long(rows), d};
+        ACH_TRAIN_1D(ach::train_softmax_kernel, p, long(rows));
+    });
+}
+int ach_train_upsample2x(const float* src, float* dst, int64_t planes, int32_t h, int32_t w, int32_t backward, void* stream) {
+    return train_guard([&] {
+        train_need(src && dst && planes > 0 && h > 0 && w > 0, "ach_train_upsample2x");
+        ach::TrainUpParams p{src, dst, long(planes), h, w, h > 1 ? float(h - 1) / float(2 * h - 1) : 0.f, w > 1 ? float(w - 1) / float(2 * w - 1) : 0.f};
+        if (!backward) ACH_TRAIN_1D(ach::train_up2_fwd_kernel, p, long(planes) * 4 * h * w);
+        else ACH_TRAIN_1D(ach::train_up2_bwd_kernel, p, long(planes) * h * w);
+    });
+}
+int ach_train_maxpool(const float* x, float* y, int32_t* idx, const float* dy, float* dx, int64_t planes, int32_t H, int32_t W, int32_t k, void* stream) {
+    return train_guard([&] {
+        train_need(idx && planes > 0 && H > 0 && W > 0 && k > 0 && (k & 1) && (dy ? dx != nullptr : (x && y)), "ach_train_maxpool");
+        ach::TrainPoolParams p{x, y, idx, dy, dx, long(planes), H, W, k};
+        ACH_TRAIN_1D(ach::train_maxpool_kernel, p, long(planes) * H * W);
+    });
+}
+int ach_train_avgpool3(const float* x, float* y, int64_t planes, int32_t H, int32_t W, void* stream) {
+    return train_guard([&] {
+        train_need(x && y && planes > 0 && H > 0 && W > 0, "ach_train_avgpool3");
+        ach::TrainPoolParams p{x, y, nullptr, nullptr, nullptr, long(planes), H, W, 3};
+        ACH_TRAIN_1D(ach::train_avgpool3_kernel, p, long(planes) * H * W);
+    });
+}
+int ach_train_row_reduce(const float* a, const float* b, float* out, int64_t rows, int64_t n, float scale, void* stream) {
+    return train_guard([&] {
+        train_need(a && out && rows > 0 && n > 0, "ach_train_row_reduce");
+        ach::TrainRowParams p{a, b, out, long(rows), long(n), 1, scale};
+        ACH_TRAIN_ROWS(ach::train_row_reduce_kernel, p, rows);
+    });
+}
+int ach_train_row_scale(const float* x, const float* s, float* out, int64_t rows, int64_t n, int64_t period, void* stream) {
+    return train_guard([&] {
+        train_need(s && out && rows > 0 && n > 0 && period > 0, "ach_train_row_scale");
+        ach::TrainRowParams p{x, s, out, long(rows), long(n), long(period), 1.f};
+        ACH_TRAIN_1D(ach::train_row_scale_kernel, p, long(rows) * n);
+    });
+}
+int ach_train_col_reduce(const float* a, const float* b, float* out, int64_t rows, int64_t cols, float scale, void* stream) {
+    return train_guard([&] {
+        train_need(a && out && rows > 0 && cols > 0, "ach_train_col_reduce");
+        ach::TrainRowParams p{a, b, out, long(rows), long(cols), 1, scale};
+        ACH_TRAIN_ROWS(ach::train_col_reduce_kernel, p, cols);
+    });
+}
+int ach_train_col_scale(const float* x, const float* g, float* out, int64_t rows, int64_t cols, void* stream) {
+    return train_guard([&] {
+        train_need(x && g && out && rows > 0 && cols > 0, "ach_train_col_scale");
+        ach::TrainRowParams p{x, g, out, long(rows), long(cols), 1, 1.f};
+        ACH_TRAIN_1D(ach::train_col_scale_kernel, p, long(rows) * cols);
+    });
+}
+int ach_train_instnorm(const float* x, const float* dy, const float* gamma, const float* beta, float* y, float* mean, float* rstd, float* dx, float* dgamma_rows,
+                       float* dbeta_rows, int64_t rows, int64_t n, int32_t C, float eps, void* stream) {
+    return train_guard([&] {
+        train_need(x && gamma && mean && rstd && rows > 0 && n > 0 && C > 0 && (dy ? (dx && dgamma_rows && dbeta_rows) : (y && beta)), "ach_train_instnorm");
+        ach::TrainInParams p{x, dy, gamma, beta, y, mean, rstd, dx, dgamma_rows, dbeta_rows, long(rows), long(n), C, eps};
+        ACH_TRAIN_ROWS(ach::train_instnorm_kernel, p, rows);
+    });
+}
+int ach_train_l2norm(const float* x, float* y, float* norm, const float* dy, float* dx, int64_t rows, int64_t n, float eps, void* stream) {
+    return train_guard([&] {
+        train_need(x && norm && rows > 0 && n > 0 && (dy ? dx != nullptr : y != nullptr), "ach_train_l2norm");
+        ach::TrainL2Params p{x, y, norm, dy, dx, long(rows), long(n), eps};
+        ACH_TRAIN_ROWS(ach::train_l2norm_kernel, p, rows);
+    });
+}
+int ach_train_deform_im2col(const float* x, const float* offset, const float* mask, float* col, int32_t B, int32_t C, int32_t H, int32_t W, int32_t Ho, int32_t Wo,
+                            int32_t stride, int32_t pad, void* stream) {
+    return train_guard([&] {
+        train_need(x && offset && mask && col && B > 0 && C > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && stride > 0, "ach_train_deform_im2col");
+        ach::TrainDeformParams p{x, offset, mask, col, nullptr, nullptr, nullptr, nullptr, B, C, H, W, Ho, Wo, stride, pad};
+        ACH_TRAIN_1D(ach::train_deform_im2col_kernel, p, long(B) * C * 9 * Ho * Wo);
+    });
+}
+int ach_train_deform_bwd(const float* x, const float* offset, const float* mask, const float* dcol, float* dx_zeroed, float* doffset, float* dmask, int32_t B,
+                         int32_t C, int32_t H, int32_t W, int32_t Ho, int32_t Wo, int32_t stride, int32_t pad, void* stream) {
+    return train_guard([&] {
+        train_need(x && offset && mask && dcol && dx_zeroed && doffset && dmask && B > 0 && C > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && stride > 0, "ach_train_deform_bwd");
+        ach::TrainDeformParams p{x, offset, mask, nullptr, dcol, dx_zeroed, doffset, dmask, B, C, H, W, Ho, Wo, stride, pad};
+        ACH_TRAIN_1D(ach::train_deform_bwd_coord_kernel, p, long(B) * 9 * Ho * Wo);
+        ACH_TRAIN_1D(ach::train_deform_bwd_input_kernel, p, long(B) * C * 9 * Ho * Wo);
+    });
+}
+#undef ACH_TRAIN_1D
+#undef ACH_TRAIN_ROWS
 
 int ach_tap_count(const ach_handle* h) { return (h && h->eng) ? int(h->eng->tap_order.size()) : 0; }
 const char* ach_tap_name(const ach_handle* h, int i) {

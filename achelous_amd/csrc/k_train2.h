@@ -1,0 +1,443 @@
+// k_train2.h — the remaining training-mode primitives: with k_train.h (fp32 MFMA GEMM, BatchNorm batch statistics,
+// depthwise 3x3, PointNet glue) these are every arithmetic operation `Achelous.forward` performs in `.train()` — forward AND backward —
+// for the EdgeNeXt / Ghost-Dual-FPN / RCNet / nano-head / PointNet model (utils/utils_fit.py:37-166 runs them through ATen autograd).
+// fp32, NCHW-contiguous tensors as PyTorch lays them out, one thread per output element or one workgroup per reduction: written for
+// correctness first (the measured hot path of this repository is inference).  Every backward is in GATHER form — an output
+// element sums its contributions in a fixed order, so results are run-to-run identical — except the input gradient of the deformable
+// sampling, which scatters with fp32 atomics as torchvision's kernel does.
+#pragma once
+#include "ach_platform.h"
+
+namespace ach {
+
+// ------------------------------------------------------------------------------------------ block reduction helper
+__device__ __forceinline__ float block_sum_256(float v, float* sh) {       // sh: 256 floats of LDS; every thread gets the total
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (int(threadIdx.x) < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+        __syncthreads();
+    }
+    const float r = sh[0];
+    __syncthreads();
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------ activations
+// kind 0 ReLU, 1 SiLU, 2 GELU (erf form, nn.GELU default), 3 sigmoid.  dy == nullptr: out = f(x); else out = dy * f'(x).
+struct TrainActParams { const float* x; const float* dy; float* out; long n; int kind; };
+static __global__ __launch_bounds__(256) void train_act_kernel(const TrainActParams p) {
+    const long i = long(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= p.n) return;
+    const float x = p.x[i];
+    float f, d;
+    if (p.kind == 0) { f = x > 0.f ? x : 0.f; d = x > 0.f ? 1.f : 0.f; }
+    else if (p.kind == 1) { const float s = 1.f / (1.f + expf(-x)); f = x * s; d = s * (1.f + x * (1.f - s)); }
+    else if (p.kind == 2) {
+        const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
+        f = x * cdf; d = cdf + x * 0.3989422804014327f * expf(-0.5f * x * x);
+    } else { const float s = 1.f / (1.f + expf(-x)); f = s; d = s * (1.f - s); }
+    p.out[i] = p.dy ? p.dy[i] * d : f;
+}
+
+// ------------------------------------------------------------------------------------------ LayerNorm over C
+// element (r, c, i) at (r * C + c) * inner + i; one normalisation group per (r, i): channels-last rows (inner = 1, edgenext_modules/layers.py
+// "channels_last") and channels_first maps [B, C, H*W] (inner = H*W).  Biased variance, eps inside the square root.
+struct TrainLnParams { const float* x; const float* gamma; const float* beta; float* y; float* mean; float* rstd; long rows; int C; long inner; float eps; };
+static __global__ __launch_bounds__(256) void train_ln_fwd_kernel(const TrainLnParams p) {
+    const long gidx = long(blockIdx.x) * 256 + threadIdx.x;
+    if (gidx >= p.rows * p.inner) return;
+    const long r = gidx / p.inner, i = gidx - r * p.inner;
+    const float* x = p.x + r * p.C * p.inner + i;
+    float m = 0.f;
+    for (int c = 0; c < p.C; ++c) m += x[c * p.inner];
+    m /= float(p.C);
+    float v = 0.f;
+    for (int c = 0; c < p.C; ++c) { const float d = x[c * p.inner] - m; v += d * d; }
+    const float rs = 1.f / sqrtf(v / float(p.C) + p.eps);
+    float* y = p.y + r * p.C * p.inner + i;
+    for (int c = 0; c < p.C; ++c) y[c * p.inner] = (x[c * p.inner] - m) * rs * p.gamma[c] + p.beta[c];
+    p.mean[gidx] = m; p.rstd[gidx] = rs;
+}
+struct TrainLnBwdParams { const float* x; const float* dy; const float* gamma; const float* mean; const float* rstd; float* dx; float* dgamma; float* dbeta;
+                          long rows; int C; long inner; };
+static __global__ __launch_bounds__(256) void train_ln_bwd_dx_kernel(const TrainLnBwdParams p) {
+    const long gidx = long(blockIdx.x) * 256 + threadIdx.x;
+    if (gidx >= p.rows * p.inner) return;
+    const long r = gidx / p.inner, i = gidx - r * p.inner;
+    const long base = r * p.C * p.inner + i;
+    const float m = p.mean[gidx], rs = p.rstd[gidx];
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = 0; c < p.C; ++c) {
+        const float g = p.dy[base + c * p.inner] * p.gamma[c], xh = (p.x[base + c * p.inner] - m) * rs;
+        s1 += g; s2 += g * xh;
+    }
+    s1 /= float(p.C); s2 /= float(p.C);
+    for (int c = 0; c < p.C; ++c) {
+        const float g = p.dy[base + c * p.inner] * p.gamma[c], xh = (p.x[base + c * p.inner] - m) * rs;
+        p.dx[base + c * p.inner] = rs * (g - s1 - xh * s2);
+    }
+}
+static __global__ __launch_bounds__(256) void train_ln_bwd_param_kernel(const TrainLnBwdParams p) {      // one workgroup per channel
+    __shared__ float sh[256];
+    const int c = blockIdx.x;
+    const long groups = p.rows * p.inner;
+    float a = 0.f, b = 0.f;
+    for (long gidx = threadIdx.x; gidx < groups; gidx += 256) {
+        const long r = gidx / p.inner, i = gidx - r * p.inner;
+        const long e = (r * p.C + c) * p.inner + i;
+        const float dy = p.dy[e];
+        a += dy * (p.x[e] - p.mean[gidx]) * p.rstd[gidx];
+        b += dy;
+    }
+    a = block_sum_256(a, sh); b = block_sum_256(b, sh);
+    if (threadIdx.x == 0) { p.dgamma[c] = a; p.dbeta[c] = b; }
+}
+
+// ------------------------------------------------------------------------------------------ depthwise k x k, stride 1, pad k/2
+// x [B,C,H,W], w [C,k*k]; flip mirrors the taps (the input gradient of the same layer); bias optional
+struct TrainDwParams { const float* x; const float* w; const float* bias; float* y; int B, C, H, W, k, flip; };
+static __global__ __launch_bounds__(256) void train_dwconv_kernel(const TrainDwParams p) {
+    const long i = long(blockIdx.x) * 256 + threadIdx.x;
+    const long total = long(p.B) * p.C * p.H * p.W;
+    if (i >= total) return;
+    const int ox = int(i % p.W), oy = int((i / p.W) % p.H), c = int((i / (long(p.W) * p.H)) % p.C);
+    const float* xp = p.x + (i - long(oy) * p.W - ox);
+    const float* w = p.w + long(c) * p.k * p.k;
+    const int r = p.k / 2;
+    float acc = p.bias ? p.bias[c] : 0.f;
+    for (int ky = 0; ky < p.k; ++ky) {
+        const int iy = oy + ky - r;
+        if (iy < 0 || iy >= p.H) continue;
+        for (int kx = 0; kx < p.k; ++kx) {
+            const int ix = ox + kx - r;
+            if (ix < 0 || ix >= p.W) continue;
+            const int t = p.flip ? (p.k - 1 - ky) * p.k + (p.k - 1 - kx) : ky * p.k + kx;
+            acc += xp[long(iy) * p.W + ix] * w[t];
+        }
+    }
+    p.y[i] = acc;
+}
+struct TrainDwWgradParams { const float* x; const float* dz; float* dw; int B, C, H, W, k; };
+static __global__ __launch_bounds__(256) void train_dwconv_wgrad_kernel(const TrainDwWgradParams p) {      // one workgroup per (channel, tap)
+    __shared__ float sh[256];
+    const int c = blockIdx.x / (p.k * p.k), t = blockIdx.x % (p.k * p.k);
+    const int ky = t / p.k - p.k / 2, kx = t % p.k - p.k / 2;
+    const long hw = long(p.H) * p.W;
+    float a = 0.f;
+    for (long e = threadIdx.x; e < long(p.B) * hw; e += 256) {
+        const long b = e / hw, pix = e - b * hw;
+        const int oy = int(pix / p.W), ox = int(pix - long(oy) * p.W);
+        const int iy = oy + ky, ix = ox + kx;
+        if (iy < 0 || iy >= p.H || ix < 0 || ix >= p.W) continue;
+        const long base = (b * p.C + c) * hw;
+        a += p.dz[base + pix] * p.x[base + long(iy) * p.W + ix];
+    }
+    a = block_sum_256(a, sh);
+    if (threadIdx.x == 0) p.dw[blockIdx.x] = a;
+}
+
+// ------------------------------------------------------------------------------------------ im2col / col2im (dense convolutions through train_gemm)
+// col [B][(ci * kh + ky) * kw + kx][oy * Wo + ox] = x[b][ci][oy * sh - ph + ky][ox * sw - pw + kx]   (0 outside)
+struct TrainColParams { const float* src; float* dst; int B, C, H, W, kh, kw, sh, sw, ph, pw, Ho, Wo; };
+static __global__ __launch_bounds__(256) void train_im2col_kernel(const TrainColParams p) {
+    const long i = long(blockIdx.x) * 256 + threadIdx.x;
+    const long K = long(p.C) * p.kh * p.kw, O = long(p.Ho) * p.Wo;
+    if (i >= long(p.B) * K * O) return;
+    const long o = i % O, kk = (i / O) % K, b = i / (O * K);
+    const int ox = int(o % p.Wo), oy = int(o / p.Wo);
+    const int kx = int(kk % p.kw), ky = int((kk / p.kw) % p.kh), ci = int(kk / (long(p.kw) * p.kh));
+    const int iy = oy * p.sh - p.ph + ky, ix = ox * p.sw - p.pw + kx;
+    p.dst[i] = (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? p.src[((b * p.C + ci) * p.H + iy) * long(p.W) + ix] : 0.f;
+}
+static __global__ __launch_bounds__(256) void train_col2im_kernel(const TrainColParams p) {      // dx[b][ci][iy][ix] = sum of the col entries that read it
+    const long i = long(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= long(p.B) * p.C * p.H * p.W) return;
+    const int ix = int(i % p.W), iy = int((i / p.W) % p.H), ci = int((i / (long(p.W) * p.H)) % p.C);
+    const long b = i / (long(p.W) * p.H * p.C);
+    const long K = long(p.C) * p.kh * p.kw, O = long(p.Ho) * p.Wo;
+    float a = 0.f;
+    for (int ky = 0; ky < p.kh; ++ky) {
+        const int ty = iy + p.ph - ky;
+        if (ty < 0 || ty % p.sh) continue;
+        const int oy = ty / p.sh;
+        if (oy >= p.Ho) continue;
+        for (int kx = 0; kx < p.kw; ++kx) {
+            const int tx = ix + p.pw - kx;
+            if (tx < 0 || tx % p.sw) continue;
+            const int ox = tx / p.sw;
+            if (ox >= p.Wo) continue;
+            a += p.src[(b * K + (long(ci) * p.kh + ky) * p.kw + kx) * O + long(oy) * p.Wo + ox];
+        }
+    }
+    p.dst[i] = a;
+}
+
+// ------------------------------------------------------------------------------------------ softmax over the last dimension
+struct TrainSoftmaxParams { const float* x; float* y; const float* dy; float* dx; long rows; int d; };
+static __global__ __launch_bounds__(256) void train_softmax_kernel(const TrainSoftmaxParams p) {
+    const long r = long(blockIdx.x) * 256 + threadIdx.x;
+    if (r >= p.rows) return;
+    if (!p.dy) {
+        const float* x = p.x + r * p.d;
+        float m = x[0];
+        for (int j = 1; j < p.d; ++j) m = fmaxf(m, x[j]);
+        float s = 0.f;
+        for (int j = 0; j < p.d; ++j) s += expf(x[j] - m);
+        for (int j = 0; j < p.d; ++j) p.y[r * p.d + j] = expf(x[j] - m) / s;
+    } else {
+        const float* y = p.y + r * p.d; const float* dy = p.dy + r * p.d;
+        float s = 0.f;
+        for (int j = 0; j < p.d; ++j) s += dy[j] * y[j];
+        for (int j = 0; j < p.d; ++j) p.dx[r * p.d + j] = y[j] * (dy[j] - s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ bilinear x2, align_corners=True
+__device__ __forceinline__ void up2_src(int o, int n_in, float scale, int& i0, int& i1, float& l) {
+    const float f = scale * float(o);
+    i0 = int(f);
+    if (i0 > n_in - 1) i0 = n_in - 1;
+    i1 = i0 < n_in - 1 ? i0 + 1 : i0;
+    l = f - float(i0);
+}
+struct TrainUpParams { const float* src; float* dst; long planes; int h, w; float sy, sx; };
+static __global__ __launch_bounds__(256) void train_up2_fwd_kernel(const TrainUpParams p) {
+    const int H = 2 * p.h, W = 2 * p.w;
+    const long i = long(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= p.planes * H * W) return;
+    const int ox = int(i % W), oy = int((i / W) % H);
+    const long pl = i / (long(W) * H);
+    int y0, y1, x0, x1; float ly, lx;
+    up2_src(oy, p.h, p.sy, y0, y1, ly); up2_src(ox, p.w, p.sx, x0, x1, lx);
+    const float* s = p.src + pl * p.h * p.w;
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    p.dst[i] = hy * (hx * s[y0 * p.w + x0] + lx * s[y0 * p.w + x1]) + ly * (hx * s[y1 * p.w + x0] + lx * s[y1 * p.w + x1]);
+}
+static __global__ __launch_bounds__(256) void train_up2_bwd_kernel(const TrainUpParams p) {      // src = dy [planes,2h,2w], dst = dx [planes,h,w]
+    const int H = 2 * p.h, W = 2 * p.w;
+    const long i = long(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= p.planes * p.h * p.w) return;
+    const int ix = int(i % p.w), iy = int((i / p.w) % p.h);
+    const long pl = i / (long(p.w) * p.h);
+    const float* dy = p.src + pl * H * W;
+    float a = 0.f;
+    for (int oy = 2 * iy - 2 < 0 ? 0 : 2 * iy - 2; oy <= 2 * iy + 2 && oy < H; ++oy) {
+        int y0, y1; float ly;
+        up2_src(oy, p.h, p.sy, y0, y1, ly);
+        const float wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
+        if (wy == 0.f) continue;
+        for (int ox = 2 * ix - 2 < 0 ? 0 : 2 * ix - 2; ox <= 2 * ix + 2 && ox < W; ++ox) {
+            int x0, x1; float lx;
+            up2_src(ox, p.w, p.sx, x0, x1, lx);
+            const float wx = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
+            a += wy * wx * dy[long(oy) * W + ox];
+        }
+    }
+    p.dst[i] = a;
+}
+
+// ------------------------------------------------------------------------------------------ max pool k x k, stride 1, pad k/2 (SPP) and avg pool 3x3
+struct TrainPoolParams { const float* x; float* y; int* idx; const float* dy; float* dx; long planes; int H, W, k; };
+static __global__ __launch_bounds__(256) void train_maxpool_kernel(const TrainPoolParams p) {
+    const long i = long(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= p.planes * p.H * p.W) return;
+    const int x0 = int(i % p.W), y0 = int((i / p.W) % p.H), r = p.k / 2;
+    const long base = i - long(y0) * p.W - x0;
+    if (!p.dy) {                                   // forward: first maximum in row-major order, NaN wins (ATen's rule)
+        float best = -INFINITY;
+        int bi = (y0 - r < 0 ? 0 : y0 - r) * p.W + (x0 - r < 0 ? 0 : x0 - r);
+        for (int y = y0 - r < 0 ? 0 : y0 - r; y <= y0 + r && y < p.H; ++y)
+            for (int x = x0 - r < 0 ? 0 : x0 - r; x <= x0 + r && x < p.W; ++x) {
+                const float v = p.x[base + long(y) * p.W + x];
+                if (v > best || v != v) { best = v; bi = y * p.W + x; }
+            }
+        p.y[i] = best; p.idx[i] = bi;
+    } else {                                       // backward: this input collects from the windows whose arg-max it is
+        const int me = y0 * p.W + x0;
+        float a = 0.f;
+        for (int y = y0 - r < 0 ? 0 : y0 - r; y <= y0 + r && y < p.H; ++y)
+            for (int x = x0 - r < 0 ? 0 : x0 - r; x <= x0 + r && x < p.W; ++x)
+                if (p.idx[base + long(y) * p.W + x] == me) a += p.dy[base + long(y) * p.W + x];
+        p.dx[i] = a;
+    }
+}
+static __global__ __launch_bounds__(256) void train_avgpool3_kernel(const TrainPoolParams p) {     // count_include_pad: always / 9; self-adjoint
+    const long i = long(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= p.planes * p.H * p.W) return;
+    const int x0 = int(i % p.W), y0 = int((i / p.W) % p.H);
+    const long base = i - long(y0) * p.W - x0;
+    float a = 0.f;
+    for (int y = y0 - 1 < 0 ? 0 : y0 - 1; y <= y0 + 1 && y < p.H; ++y)
+        for (int x = x0 - 1 < 0 ? 0 : x0 - 1; x <= x0 + 1 && x < p.W; ++x) a += p.x[base + long(y) * p.W + x];
+    p.y[i] = a * (1.0f / 9.0f);
+}
+
+// ------------------------------------------------------------------------------------------ row / column reductions and scalings
+// row_reduce: out[r] = scale * sum_i a[r,i] * (b ? b[r,i] : 1)            one workgroup per row
+// row_scale : out[r,i] = (x ? x[r,i] : 1) * s[r % S]
+// col_reduce: out[c] = sum_r a[r,c] * (b ? b[r,c] : 1)                    one workgroup per column
+// col_scale : out[r,c] = x[r,c] * g[c]
+struct TrainRowParams { const float* a; const float* b; float* out; long rows; long N; long S; float scale; };
+static __global__ __launch_bounds__(256) void train_row_reduce_kernel(const TrainRowParams p) {
+    __shared__ float sh[256];
+    const long r = blockIdx.x;
+    float v = 0.f;
+    for (long i = threadIdx.x; i < p.N; i += 256) v += p.a[r * p.N + i] * (p.b ? p.b[r * p.N + i] : 1.f);
+    v = block_sum_256(v, sh);
+    if (threadIdx.x == 0) p.out[r] = v * p.scale;
+}
+static __global__ __launch_bounds__(256) void train_row_scale_kernel(const TrainRowParams p) {
+    const long i = long(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= p.rows * p.N) return;
+    const long r = i / p.N;
+    p.out[i] = (p.a ? p.a[i] : 1.f) * p.b[r % p.S];
+}
+static __global__ __launch_bounds__(256) void train_col_reduce_kernel(const TrainRowParams p) {      // N = number of columns
+    __shared__ float sh[256];
+    const long c = blockIdx.x;
+    float v = 0.f;
+    for (long r = threadIdx.x; r < p.rows; r += 256) v += p.a[r * p.N + c] * (p.b ? p.b[r * p.N + c] : 1.f);
+    v = block_sum_256(v, sh);
+    if (threadIdx.x == 0) p.out[c] = v * p.scale;
+}
+static __global__ __launch_bounds__(256) void train_col_scale_kernel(const TrainRowParams p) {
+    const long i = long(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= p.rows * p.N) return;
+    p.out[i] = p.a[i] * p.b[i % p.N];
+}
+
+// ------------------------------------------------------------------------------------------ per-row normalisations
+// instance norm (GroupNorm with one channel per group, shuffle_attention.py:20): row r = (b, c), statistics over its N elements
+struct TrainInParams { const float* x; const float* dy; const float* gamma; const float* beta; float* y; float* mean; float* rstd; float* dx; float* dg; float* db;
+                       long rows; long N; int C; float eps; };
+static __global__ __launch_bounds__(256) void train_instnorm_kernel(const TrainInParams p) {
+    __shared__ float sh[256];
+    const long r = blockIdx.x;
+    const int c = int(r % p.C);
+    const float* x = p.x + r * p.N;
+    if (!p.dy) {
+        float s = 0.f;
+        for (long i = threadIdx.x; i < p.N; i += 256) s += x[i];
+        const float m = block_sum_256(s, sh) / float(p.N);
+        float v = 0.f;
+        for (long i = threadIdx.x; i < p.N; i += 256) { const float d = x[i] - m; v += d * d; }
+        const float rs = 1.f / sqrtf(block_sum_256(v, sh) / float(p.N) + p.eps);
+        for (long i = threadIdx.x; i < p.N; i += 256) p.y[r * p.N + i] = (x[i] - m) * rs * p.gamma[c] + p.beta[c];
+        if (threadIdx.x == 0) { p.mean[r] = m; p.rstd[r] = rs; }
+    } else {
+        const float m = p.mean[r], rs = p.rstd[r], g = p.gamma[c];
+        const float* dy = p.dy + r * p.N;
+        float s1 = 0.f, s2 = 0.f;
+        for (long i = threadIdx.x; i < p.N; i += 256) { s1 += dy[i]; s2 += dy[i] * (x[i] - m) * rs; }
+        s1 = block_sum_256(s1, sh); s2 = block_sum_256(s2, sh);
+        for (long i = threadIdx.x; i < p.N; i += 256) p.dx[r * p.N + i] = g * rs * (dy[i] - s1 / float(p.N) - (x[i] - m) * rs * s2 / float(p.N));
+        if (threadIdx.x == 0) { p.dg[r] = s2; p.db[r] = s1; }         // per row: the caller sums over the batch
+    }
+}
+// F.normalize(x, dim=-1): y = x / max(||x||, eps)   (xca.py: q, k over the tokens)
+struct TrainL2Params { const float* x; float* y; float* norm; const float* dy; float* dx; long rows; long N; float eps; };
+static __global__ __launch_bounds__(256) void train_l2norm_kernel(const TrainL2Params p) {
+    __shared__ float sh[256];
+    const long r = blockIdx.x;
+    const float* x = p.x + r * p.N;
+    if (!p.dy) {
+        float s = 0.f;
+        for (long i = threadIdx.x; i < p.N; i += 256) s += x[i] * x[i];
+        const float n = sqrtf(block_sum_256(s, sh));
+        const float d = n > p.eps ? n : p.eps;
+        for (long i = threadIdx.x; i < p.N; i += 256) p.y[r * p.N + i] = x[i] / d;
+        if (threadIdx.x == 0) p.norm[r] = n;
+    } else {
+        const float n = p.norm[r];
+        const float* dy = p.dy + r * p.N;
+        if (n > p.eps) {
+            float s = 0.f;
+            for (long i = threadIdx.x; i < p.N; i += 256) s += dy[i] * x[i];
+            s = block_sum_256(s, sh) / (n * n);
+            for (long i = threadIdx.x; i < p.N; i += 256) p.dx[r * p.N + i] = (dy[i] - x[i] * s) / n;
+        } else {
+            for (long i = threadIdx.x; i < p.N; i += 256) p.dx[r * p.N + i] = dy[i] / p.eps;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ modulated deformable 3x3 sampling (DCNv2)
+// torchvision 0.12 deform_conv2d semantics (deformable_im2col / bilinear_interpolate; dcn.py:49-63 calls it with padding 1, one offset
+// group): sample position (oy * s - pad + ky + off_y, ox * s - pad + kx + off_x); a sample at or beyond -1 / H (W) is 0; corners
+// outside the map contribute 0.  offset [B,18,Ho,Wo] = (dy, dx) per tap, mask [B,9,Ho,Wo].
+//   col  [B][(ci*9 + k)][o] = mask * bilinear(x[b,ci], p)
+// backward from dcol = W^T dY:
+//   dmask[b][k][o]   = sum_ci dcol * bilinear
+//   doffset[b][2k+{0,1}][o] = sum_ci dcol * mask * d bilinear / d{py, px}
+//   dx: each sample scatters dcol * mask * corner weight to its four corners (atomicAdd; dx zeroed by the caller)
+struct TrainDeformParams { const float* x; const float* offset; const float* mask; float* col; const float* dcol; float* dx; float* doffset; float* dmask;
+                           int B, C, H, W, Ho, Wo, stride, pad; };
+__device__ __forceinline__ float dcn_corner(const float* img, int H, int W, int y, int x) { return (y >= 0 && y < H && x >= 0 && x < W) ? img[long(y) * W + x] : 0.f; }
+static __global__ __launch_bounds__(256) void train_deform_im2col_kernel(const TrainDeformParams p) {
+    const long O = long(p.Ho) * p.Wo;
+    const long i = long(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= long(p.B) * p.C * 9 * O) return;
+    const long o = i % O; const int k = int((i / O) % 9), ci = int((i / (O * 9)) % p.C); const long b = i / (O * 9 * p.C);
+    const int ox = int(o % p.Wo), oy = int(o / p.Wo);
+    const float py = float(oy * p.stride - p.pad + k / 3) + p.offset[(b * 18 + 2 * k) * O + o];
+    const float px = float(ox * p.stride - p.pad + k % 3) + p.offset[(b * 18 + 2 * k + 1) * O + o];
+    float v = 0.f;
+    if (py > -1.f && px > -1.f && py < float(p.H) && px < float(p.W)) {
+        const float* img = p.x + (b * p.C + ci) * long(p.H) * p.W;
+        const int y0 = int(floorf(py)), x0 = int(floorf(px));
+        const float ly = py - float(y0), lx = px - float(x0), hy = 1.f - ly, hx = 1.f - lx;
+        v = hy * hx * dcn_corner(img, p.H, p.W, y0, x0) + hy * lx * dcn_corner(img, p.H, p.W, y0, x0 + 1) +
+            ly * hx * dcn_corner(img, p.H, p.W, y0 + 1, x0) + ly * lx * dcn_corner(img, p.H, p.W, y0 + 1, x0 + 1);
+    }
+    p.col[i] = v * p.mask[(b * 9 + k) * O + o];
+}
+static __global__ __launch_bounds__(256) void train_deform_bwd_coord_kernel(const TrainDeformParams p) {     // one thread per (b, k, o): doffset, dmask
+    const long O = long(p.Ho) * p.Wo;
+    const long i = long(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= long(p.B) * 9 * O) return;
+    const long o = i % O; const int k = int((i / O) % 9); const long b = i / (O * 9);
+    const int ox = int(o % p.Wo), oy = int(o / p.Wo);
+    const float py = float(oy * p.stride - p.pad + k / 3) + p.offset[(b * 18 + 2 * k) * O + o];
+    const float px = float(ox * p.stride - p.pad + k % 3) + p.offset[(b * 18 + 2 * k + 1) * O + o];
+    const float m = p.mask[(b * 9 + k) * O + o];
+    float gm = 0.f, gy = 0.f, gx = 0.f;
+    if (py > -1.f && px > -1.f && py < float(p.H) && px < float(p.W)) {
+        const int y0 = int(floorf(py)), x0 = int(floorf(px));
+        const float ly = py - float(y0), lx = px - float(x0), hy = 1.f - ly, hx = 1.f - lx;
+        for (int ci = 0; ci < p.C; ++ci) {
+            const float* img = p.x + (b * p.C + ci) * long(p.H) * p.W;
+            const float v00 = dcn_corner(img, p.H, p.W, y0, x0), v01 = dcn_corner(img, p.H, p.W, y0, x0 + 1);
+            const float v10 = dcn_corner(img, p.H, p.W, y0 + 1, x0), v11 = dcn_corner(img, p.H, p.W, y0 + 1, x0 + 1);
+            const float d = p.dcol[((b * p.C + ci) * 9 + k) * O + o];
+            gm += d * (hy * hx * v00 + hy * lx * v01 + ly * hx * v10 + ly * lx * v11);
+            gy += d * m * (hx * (v10 - v00) + lx * (v11 - v01));
+            gx += d * m * (hy * (v01 - v00) + ly * (v11 - v10));
+        }
+    }
+    p.dmask[(b * 9 + k) * O + o] = gm;
+    p.doffset[(b * 18 + 2 * k) * O + o] = gy;
+    p.doffset[(b * 18 + 2 * k + 1) * O + o] = gx;
+}
+static __global__ __launch_bounds__(256) void train_deform_bwd_input_kernel(const TrainDeformParams p) {     // one thread per col element: 4 atomic adds
+    const long O = long(p.Ho) * p.Wo;
+    const long i = long(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= long(p.B) * p.C * 9 * O) return;
+    const long o = i % O; const int k = int((i / O) % 9), ci = int((i / (O * 9)) % p.C); const long b = i / (O * 9 * p.C);
+    const int ox = int(o % p.Wo), oy = int(o / p.Wo);
+    const float py = float(oy * p.stride - p.pad + k / 3) + p.offset[(b * 18 + 2 * k) * O + o];
+    const float px = float(ox * p.stride - p.pad + k % 3) + p.offset[(b * 18 + 2 * k + 1) * O + o];
+    if (!(py > -1.f && px > -1.f && py < float(p.H) && px < float(p.W))) return;
+    const float g = p.dcol[i] * p.mask[(b * 9 + k) * O + o];
+    const int y0 = int(floorf(py)), x0 = int(floorf(px));
+    const float ly = py - float(y0), lx = px - float(x0), hy = 1.f - ly, hx = 1.f - lx;
+    float* dimg = p.dx + (b * p.C + ci) * long(p.H) * p.W;
+    const float wts[4] = {hy * hx, hy * lx, ly * hx, ly * lx};
+    ACH_UNROLL
+    for (int q = 0; q < 4; ++q) {
+        const int y = y0 + (q >> 1), x = x0 + (q & 1);
+        if (y >= 0 && y < p.H && x >= 0 && x < p.W) atomicAdd(dimg + long(y) * p.W + x, g * wts[q]);
+    }
+}
+
+}  // namespace ach

@@ -217,6 +217,47 @@ int ach_train_dw3x3_wgrad(const float* x, const float* dz, float* dw, int32_t B,
 int ach_train_max_points(const float* x, float* y, int32_t* idx, const float* dy, float* dx, int64_t rows, int32_t N, void* stream);
 int ach_train_log_softmax(const float* z, float* y, const float* dy, float* dz, int32_t B, int32_t K, int32_t N, void* stream);
 
+/* Training-mode primitives, second set (achelous_amd/csrc/k_train2.h): with the functions above, every arithmetic operation of
+ * Achelous.forward in .train() — forward and backward (utils/utils_fit.py:37-166 runs them through ATen autograd).  fp32, NCHW-contiguous.
+ * A function with a `dy` argument runs FORWARD when dy == NULL and BACKWARD otherwise.
+ *   ach_train_act            kind 0 ReLU, 1 SiLU, 2 GELU (erf), 3 sigmoid: out = f(x) | dy * f'(x)
+ *   ach_train_layernorm      over C of elements (r, c, i) at (r*C + c)*inner + i (channels-last rows: inner 1; channels_first maps: inner H*W)
+ *   ach_train_dwconv         depthwise k x k, stride 1, pad k/2, w [C,k*k]; flip = 1: the input gradient;  _wgrad: dw [C,k*k]
+ *   ach_train_im2col         col [B][C*kh*kw][Ho*Wo] <- x (backward = 1: dx <- dcol), dense convolutions run through ach_train_gemm
+ *   ach_train_softmax        over the last dimension d of [rows, d]
+ *   ach_train_upsample2x     bilinear x2, align_corners=True: [planes,h,w] -> [planes,2h,2w] (backward = 1: the adjoint)
+ *   ach_train_maxpool        k x k, stride 1, pad k/2 with arg-max;  ach_train_avgpool3: 3x3 / 9 (self-adjoint)
+ *   ach_train_row_reduce     out[r] = scale * sum_i a[r,i] * (b ? b[r,i] : 1);     ach_train_row_scale  out[r,i] = (x ? x[r,i] : 1) * s[r % period]
+ *   ach_train_col_reduce     out[c] = scale * sum_r a[r,c] * (b ? b[r,c] : 1);     ach_train_col_scale  out[r,c] = x[r,c] * g[c]
+ *   ach_train_instnorm       per-row statistics (GroupNorm with one channel per group), gamma / beta index r % C; backward also returns per-row dgamma / dbeta
+ *   ach_train_l2norm         y = x / max(||x||, eps) per row (F.normalize)
+ *   ach_train_deform_im2col  modulated deformable 3x3 sampling (torchvision 0.12 deform_conv2d semantics): col [B][C*9][Ho*Wo]
+ *   ach_train_deform_bwd     from dcol: doffset, dmask, and dx (scattered with fp32 atomics into a buffer the caller zeroed) */
+int ach_train_act(const float* x, const float* dy, float* out, int64_t n, int32_t kind, void* stream);
+int ach_train_layernorm(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, int64_t rows, int32_t C, int64_t inner,
+                        float eps, void* stream);
+int ach_train_layernorm_bwd(const float* x, const float* dy, const float* gamma, const float* mean, const float* rstd, float* dx, float* dgamma, float* dbeta,
+                            int64_t rows, int32_t C, int64_t inner, void* stream);
+int ach_train_dwconv(const float* x, const float* w, const float* bias, float* y, int32_t B, int32_t C, int32_t H, int32_t W, int32_t k, int32_t flip, void* stream);
+int ach_train_dwconv_wgrad(const float* x, const float* dz, float* dw, int32_t B, int32_t C, int32_t H, int32_t W, int32_t k, void* stream);
+int ach_train_im2col(const float* src, float* dst, int32_t B, int32_t C, int32_t H, int32_t W, int32_t kh, int32_t kw, int32_t sh, int32_t sw, int32_t ph, int32_t pw,
+                     int32_t Ho, int32_t Wo, int32_t backward, void* stream);
+int ach_train_softmax(const float* x, float* y, const float* dy, float* dx, int64_t rows, int32_t d, void* stream);
+int ach_train_upsample2x(const float* src, float* dst, int64_t planes, int32_t h, int32_t w, int32_t backward, void* stream);
+int ach_train_maxpool(const float* x, float* y, int32_t* idx, const float* dy, float* dx, int64_t planes, int32_t H, int32_t W, int32_t k, void* stream);
+int ach_train_avgpool3(const float* x, float* y, int64_t planes, int32_t H, int32_t W, void* stream);
+int ach_train_row_reduce(const float* a, const float* b, float* out, int64_t rows, int64_t n, float scale, void* stream);
+int ach_train_row_scale(const float* x, const float* s, float* out, int64_t rows, int64_t n, int64_t period, void* stream);
+int ach_train_col_reduce(const float* a, const float* b, float* out, int64_t rows, int64_t cols, float scale, void* stream);
+int ach_train_col_scale(const float* x, const float* g, float* out, int64_t rows, int64_t cols, void* stream);
+int ach_train_instnorm(const float* x, const float* dy, const float* gamma, const float* beta, float* y, float* mean, float* rstd, float* dx, float* dgamma_rows,
+                       float* dbeta_rows, int64_t rows, int64_t n, int32_t C, float eps, void* stream);
+int ach_train_l2norm(const float* x, float* y, float* norm, const float* dy, float* dx, int64_t rows, int64_t n, float eps, void* stream);
+int ach_train_deform_im2col(const float* x, const float* offset, const float* mask, float* col, int32_t B, int32_t C, int32_t H, int32_t W, int32_t Ho, int32_t Wo,
+                            int32_t stride, int32_t pad, void* stream);
+int ach_train_deform_bwd(const float* x, const float* offset, const float* mask, const float* dcol, float* dx_zeroed, float* doffset, float* dmask, int32_t B,
+                         int32_t C, int32_t H, int32_t W, int32_t Ho, int32_t Wo, int32_t stride, int32_t pad, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
