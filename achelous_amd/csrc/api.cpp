@@ -300,6 +300,13 @@ int ach_train_act(const float* x, const float* dy, float* out, int64_t n, int32_
         ACH_TRAIN_1D(ach::train_act_kernel, p, long(n));
     });
 }
+int ach_train_mul(const float* a, const float* b, float* out, int64_t n, void* stream) {
+    return train_guard([&] {
+        train_need(a && b && out && n > 0, "ach_train_mul");
+        ach::TrainMulParams p{a, b, out, long(n)};
+        ACH_TRAIN_1D(ach::train_mul_kernel, p, long(n));
+    });
+}
 int ach_train_layernorm(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, int64_t rows, int32_t C, int64_t inner,
                         float eps, void* stream) {
     return train_guard([&] {

@@ -40,6 +40,13 @@ static __global__ __launch_bounds__(256) void train_act_kernel(const TrainActPar
     p.out[i] = p.dy ? p.dy[i] * d : f;
 }
 
+// element-wise product (gates that are full tensors: shuffle_attention.py:66); its backward is the same kernel with the other factor
+struct TrainMulParams { const float* a; const float* b; float* out; long n; };
+static __global__ __launch_bounds__(256) void train_mul_kernel(const TrainMulParams p) {
+    const long i = long(blockIdx.x) * 256 + threadIdx.x;
+    if (i < p.n) p.out[i] = p.a[i] * p.b[i];
+}
+
 // ------------------------------------------------------------------------------------------ LayerNorm over C
 // element (r, c, i) at (r * C + c) * inner + i; one normalisation group per (r, i): channels-last rows (inner = 1, edgenext_modules/layers.py
 // "channels_last") and channels_first maps [B, C, H*W] (inner = H*W).  Biased variance, eps inside the square root.

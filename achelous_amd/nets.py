@@ -7,8 +7,9 @@ libachelous_hip.so).  There is no PyTorch-op or CPU fallback: without the HIP li
 
     det_list[3], se_seg, lane_seg, pc_seg = model(image[B,3,R,R], radar[B,3,R,R], points[B,pc_channels,N])
 
-Eval-mode (inference) only: the engine folds BatchNorm running statistics into the convolutions, which is only
-legal in eval mode; `forward` in training mode raises NotImplementedError.
+Eval mode runs the fused inference engine (BatchNorm running statistics folded into the convolutions).  Training mode
+(`.train()`, fp32) runs the unfused network on native forward / backward kernels through autograd (train_graph.py, SURVEY.md §8(f)
+row 4) for the EdgeNeXt / Ghost-Dual-FPN / PointNet family; the other families raise NotImplementedError in training mode.
 """
 import torch
 import torch.nn as nn
@@ -198,7 +199,24 @@ class Achelous(nn.Module):
                 self.__dict__['_op_token'] = torch_op.register_module(self)
             o = torch.ops.achelous_amd.forward(x, x_radar, x_point_clouds, self.__dict__['_op_token'])
             return [o[0], o[1], o[2]], o[3], o[4], o[5]
+        if self.training:
+            return self._train_forward(x, x_radar, x_point_clouds)
         return self._run(x, x_radar, x_point_clouds, None)
+
+    def _train_forward(self, x, x_radar, x_point_clouds):
+        """Training mode (train.py:400-420, utils/utils_fit.py:37-166): the unfused fp32 statement of the network on native forward /
+        backward kernels (train_graph.py) — BatchNorm with batch statistics and running-estimate updates, gradients for every parameter
+        through autograd.  Same output structure as the inference path; the outputs carry `grad_fn`."""
+        from . import train_graph, train_ops
+        if not (x.is_cuda and x_radar.is_cuda and x_point_clouds.is_cuda) and not getattr(train_ops._lib, 'test_library', None):
+            raise RuntimeError("achelous_amd.Achelous.forward needs GPU tensors (HIP training kernels; there is no CPU path)")
+        B, R = x.shape[0], self.resolution
+        if tuple(x.shape) != (B, 3, R, R) or tuple(x_radar.shape) != (B, 3, R, R):
+            raise ValueError(f"expected image and radar map of shape [B,3,{R},{R}], got {tuple(x.shape)} / {tuple(x_radar.shape)}")
+        if x_point_clouds.dim() != 3 or x_point_clouds.shape[0] != B or x_point_clouds.shape[1] != self.pc_channels:
+            raise ValueError(f"expected points of shape [B,{self.pc_channels},N], got {tuple(x_point_clouds.shape)}")
+        det, se, lane, pc = train_graph.TrainGraph(self).forward(x, x_radar, x_point_clouds)
+        return list(det), se, lane, pc
 
     def forward_detect(self, x, x_radar, x_point_clouds, conf_thres=0.5, nms_thres=0.4, max_det=None):
         """forward + decode_outputs + class-aware NMS as one engine call (what achelous.py:246-262 chains per frame).

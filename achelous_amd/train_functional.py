@@ -46,12 +46,40 @@ class _ActFn(torch.autograd.Function):
         (x,) = ctx.saved_tensors
         lib = _lib(x)
         dx = torch.empty_like(x)
-        _check(lib, lib.lib.ach_train_act(_p(x), _p(dy.contiguous()), _p(dx), x.numel(), ctx.kind, _stream(x)))
+        dy = dy.contiguous()              # bound to a name: a temporary would be freed before the kernel reads it
+        _check(lib, lib.lib.ach_train_act(_p(x), _p(dy), _p(dx), x.numel(), ctx.kind, _stream(x)))
         return dx, None
 
 
 def act(x, kind):
     return _ActFn.apply(x, kind)
+
+
+class _MulFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _f32(a, 'mul'), _f32(b, 'mul')
+        if a.shape != b.shape:
+            raise ValueError("mul: equal shapes expected (broadcast gates go through channel_scale)")
+        lib = _lib(a)
+        y = torch.empty_like(a)
+        _check(lib, lib.lib.ach_train_mul(_p(a), _p(b), _p(y), a.numel(), _stream(a)))
+        ctx.save_for_backward(a, b)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, b = ctx.saved_tensors
+        lib = _lib(a)
+        dy = dy.contiguous()
+        da, db = torch.empty_like(a), torch.empty_like(b)
+        _check(lib, lib.lib.ach_train_mul(_p(dy), _p(b), _p(da), a.numel(), _stream(a)))
+        _check(lib, lib.lib.ach_train_mul(_p(dy), _p(a), _p(db), a.numel(), _stream(a)))
+        return da, db
+
+
+def mul(a, b):
+    return _MulFn.apply(a, b)
 
 
 class _RowScaleFn(torch.autograd.Function):
@@ -143,7 +171,8 @@ class _BatchNormFn(torch.autograd.Function):
         B, C, N = x.shape
         lib = _lib(x)
         dg, db, dx = _empty(x, C), _empty(x, C), torch.empty_like(x)
-        _check(lib, lib.lib.ach_train_bn_relu_bwd(_p(x), _p(y), _p(dy.contiguous()), _p(mean), _p(var), _p(g), _p(dg), _p(db), _p(dx), B, C, N, eps, relu, _stream(x)))
+        dy = dy.contiguous()              # bound to a name: a temporary would be freed before the kernel reads it
+        _check(lib, lib.lib.ach_train_bn_relu_bwd(_p(x), _p(y), _p(dy), _p(mean), _p(var), _p(g), _p(dg), _p(db), _p(dx), B, C, N, eps, relu, _stream(x)))
         return dx, dg, db, None, None, None, None, None, None
 
 
@@ -159,7 +188,8 @@ class _LayerNormFn(torch.autograd.Function):
         lib = _lib(x)
         g = gamma.detach().contiguous()
         y, mean, rstd = torch.empty_like(x), _empty(x, rows * inner), _empty(x, rows * inner)
-        _check(lib, lib.lib.ach_train_layernorm(_p(x), _p(g), _p(beta.detach().contiguous()), _p(y), _p(mean), _p(rstd), rows, C, inner, float(eps), _stream(x)))
+        bt = beta.detach().contiguous()
+        _check(lib, lib.lib.ach_train_layernorm(_p(x), _p(g), _p(bt), _p(y), _p(mean), _p(rstd), rows, C, inner, float(eps), _stream(x)))
         ctx.save_for_backward(x, g, mean, rstd)
         ctx.dims = (rows, C, inner)
         return y
@@ -170,7 +200,8 @@ class _LayerNormFn(torch.autograd.Function):
         rows, C, inner = ctx.dims
         lib = _lib(x)
         dx, dg, db = torch.empty_like(x), _empty(x, C), _empty(x, C)
-        _check(lib, lib.lib.ach_train_layernorm_bwd(_p(x), _p(dy.contiguous()), _p(g), _p(mean), _p(rstd), _p(dx), _p(dg), _p(db), rows, C, inner, _stream(x)))
+        dy = dy.contiguous()              # bound to a name: a temporary would be freed before the kernel reads it
+        _check(lib, lib.lib.ach_train_layernorm_bwd(_p(x), _p(dy), _p(g), _p(mean), _p(rstd), _p(dx), _p(dg), _p(db), rows, C, inner, _stream(x)))
         return dx, dg, db, None, None, None, None
 
 
@@ -190,7 +221,8 @@ class _InstNormFn(torch.autograd.Function):
         lib = _lib(x)
         g = gamma.detach().contiguous()
         y, mean, rstd = torch.empty_like(x), _empty(x, B * C), _empty(x, B * C)
-        _check(lib, lib.lib.ach_train_instnorm(_p(x), _NULL, _p(g), _p(beta.detach().contiguous()), _p(y), _p(mean), _p(rstd), _NULL, _NULL, _NULL, B * C, N, C, float(eps), _stream(x)))
+        bt = beta.detach().contiguous()
+        _check(lib, lib.lib.ach_train_instnorm(_p(x), _NULL, _p(g), _p(bt), _p(y), _p(mean), _p(rstd), _NULL, _NULL, _NULL, B * C, N, C, float(eps), _stream(x)))
         ctx.save_for_backward(x, g, mean, rstd)
         ctx.eps = float(eps)
         return y
@@ -201,7 +233,8 @@ class _InstNormFn(torch.autograd.Function):
         B, C, N = x.shape
         lib = _lib(x)
         dx, dgr, dbr = torch.empty_like(x), _empty(x, B * C), _empty(x, B * C)
-        _check(lib, lib.lib.ach_train_instnorm(_p(x), _p(dy.contiguous()), _p(g), _NULL, _NULL, _p(mean), _p(rstd), _p(dx), _p(dgr), _p(dbr), B * C, N, C, ctx.eps, _stream(x)))
+        dy = dy.contiguous()              # bound to a name: a temporary would be freed before the kernel reads it
+        _check(lib, lib.lib.ach_train_instnorm(_p(x), _p(dy), _p(g), _NULL, _NULL, _p(mean), _p(rstd), _p(dx), _p(dgr), _p(dbr), B * C, N, C, ctx.eps, _stream(x)))
         return dx, dgr.view(B, C).sum(0), dbr.view(B, C).sum(0), None
 
 
@@ -227,7 +260,8 @@ class _L2NormFn(torch.autograd.Function):
         rows, n, eps = ctx.dims
         lib = _lib(x)
         dx = torch.empty_like(x)
-        _check(lib, lib.lib.ach_train_l2norm(_p(x), _NULL, _p(norm), _p(dy.contiguous()), _p(dx), rows, n, eps, _stream(x)))
+        dy = dy.contiguous()              # bound to a name: a temporary would be freed before the kernel reads it
+        _check(lib, lib.lib.ach_train_l2norm(_p(x), _NULL, _p(norm), _p(dy), _p(dx), rows, n, eps, _stream(x)))
         return dx, None, None, None
 
 
@@ -253,7 +287,8 @@ class _SoftmaxFn(torch.autograd.Function):
         d = y.shape[-1]
         lib = _lib(y)
         dx = torch.empty_like(y)
-        _check(lib, lib.lib.ach_train_softmax(_NULL, _p(y), _p(dy.contiguous()), _p(dx), y.numel() // d, d, _stream(y)))
+        dy = dy.contiguous()              # bound to a name: a temporary would be freed before the kernel reads it
+        _check(lib, lib.lib.ach_train_softmax(_NULL, _p(y), _p(dy), _p(dx), y.numel() // d, d, _stream(y)))
         return dx
 
 
@@ -352,7 +387,8 @@ class _DWConvFn(torch.autograd.Function):
         lib = _lib(x)
         w2 = weight.detach().reshape(C, k * k).contiguous()
         y = torch.empty_like(x)
-        _check(lib, lib.lib.ach_train_dwconv(_p(x), _p(w2), _p(bias.detach().contiguous()) if bias is not None else _NULL, _p(y), B, C, H, W, k, 0, _stream(x)))
+        bs = bias.detach().contiguous() if bias is not None else None
+        _check(lib, lib.lib.ach_train_dwconv(_p(x), _p(w2), _p(bs) if bs is not None else _NULL, _p(y), B, C, H, W, k, 0, _stream(x)))
         ctx.save_for_backward(x, w2)
         ctx.cfg = (k, bias is not None)
         return y
@@ -440,7 +476,8 @@ class _Up2Fn(torch.autograd.Function):
         B, C, h, w = ctx.shape
         lib = _lib(dy)
         dx = _empty(dy, B, C, h, w)
-        _check(lib, lib.lib.ach_train_upsample2x(_p(dy.contiguous()), _p(dx), B * C, h, w, 1, _stream(dy)))
+        dy = dy.contiguous()              # bound to a name: a temporary would be freed before the kernel reads it
+        _check(lib, lib.lib.ach_train_upsample2x(_p(dy), _p(dx), B * C, h, w, 1, _stream(dy)))
         return dx
 
 
@@ -468,7 +505,8 @@ class _MaxPoolFn(torch.autograd.Function):
         B, C, H, W = idx.shape
         lib = _lib(dy)
         dx = _empty(dy, B, C, H, W)
-        _check(lib, lib.lib.ach_train_maxpool(_NULL, _NULL, _p(idx), _p(dy.contiguous()), _p(dx), B * C, H, W, ctx.k, _stream(dy)))
+        dy = dy.contiguous()              # bound to a name: a temporary would be freed before the kernel reads it
+        _check(lib, lib.lib.ach_train_maxpool(_NULL, _NULL, _p(idx), _p(dy), _p(dx), B * C, H, W, ctx.k, _stream(dy)))
         return dx, None
 
 

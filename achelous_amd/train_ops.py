@@ -60,7 +60,8 @@ class _SharedMLP1dFn(torch.autograd.Function):
         lib = _lib(x)
         L, s = lib.lib, _stream(x)
         z = torch.empty(B, cout, N, dtype=torch.float32, device=x.device)
-        _check(lib, L.ach_train_gemm(_p(w2), _p(x), _p(z), _p(bias.detach().contiguous()) if bias is not None else ctypes.c_void_p(), cout, N, cin,
+        bs = bias.detach().contiguous() if bias is not None else None           # bound to a name: a temporary would be freed before the kernel reads it
+        _check(lib, L.ach_train_gemm(_p(w2), _p(x), _p(z), _p(bs) if bs is not None else ctypes.c_void_p(), cout, N, cin,
                                      cin, N, N, 0, cin * N, cout * N, 0, 0, B, 0, 0, s))
         mean = torch.empty(cout, dtype=torch.float32, device=x.device)
         var = torch.empty(cout, dtype=torch.float32, device=x.device)
@@ -75,7 +76,8 @@ class _SharedMLP1dFn(torch.autograd.Function):
             mean.copy_(running_mean)
             var.copy_(running_var)
         y = torch.empty_like(z)
-        _check(lib, L.ach_train_bn_relu_fwd(_p(z), _p(mean), _p(var), _p(gamma.detach().contiguous()), _p(beta.detach().contiguous()), _p(y),
+        gm, bt = gamma.detach().contiguous(), beta.detach().contiguous()
+        _check(lib, L.ach_train_bn_relu_fwd(_p(z), _p(mean), _p(var), _p(gm), _p(bt), _p(y),
                                             B, cout, N, float(eps), int(relu), s))
         ctx.save_for_backward(x, w2, z, y, mean, var, gamma.detach().contiguous())
         ctx.cfg = (training, float(eps), int(relu), bias is not None, tuple(weight.shape))
@@ -252,7 +254,8 @@ class _LinearFn(torch.autograd.Function):
         lib = _lib(x)
         L, s = lib.lib, _stream(x)
         z = torch.empty(B, cout, N, dtype=torch.float32, device=x.device)
-        _check(lib, L.ach_train_gemm(_p(w2), _p(x), _p(z), _p(bias.detach().contiguous()) if bias is not None else ctypes.c_void_p(), cout, N, cin,
+        bs = bias.detach().contiguous() if bias is not None else None           # bound to a name: a temporary would be freed before the kernel reads it
+        _check(lib, L.ach_train_gemm(_p(w2), _p(x), _p(z), _p(bs) if bs is not None else ctypes.c_void_p(), cout, N, cin,
                                      cin, N, N, 0, cin * N, cout * N, 0, 0, B, 0, 0, s))
         ctx.save_for_backward(x, w2)
         ctx.cfg = (bias is not None, tuple(weight.shape))

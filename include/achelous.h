@@ -234,6 +234,7 @@ int ach_train_log_softmax(const float* z, float* y, const float* dy, float* dz, 
  *   ach_train_deform_im2col  modulated deformable 3x3 sampling (torchvision 0.12 deform_conv2d semantics): col [B][C*9][Ho*Wo]
  *   ach_train_deform_bwd     from dcol: doffset, dmask, and dx (scattered with fp32 atomics into a buffer the caller zeroed) */
 int ach_train_act(const float* x, const float* dy, float* out, int64_t n, int32_t kind, void* stream);
+int ach_train_mul(const float* a, const float* b, float* out, int64_t n, void* stream);      /* out = a * b element-wise */
 int ach_train_layernorm(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, int64_t rows, int32_t C, int64_t inner,
                         float eps, void* stream);
 int ach_train_layernorm_bwd(const float* x, const float* dy, const float* gamma, const float* mean, const float* rstd, float* dx, float* dgamma, float* dbeta,

@@ -68,6 +68,7 @@ def _cases(dev):
     yield 'silu', lambda: _check(lambda x: TF.act(x, TF.ACT_SILU), F.silu, [(_r(3, 7, 5, 6, scale=2), True)], dev)
     yield 'gelu', lambda: _check(lambda x: TF.act(x, TF.ACT_GELU), F.gelu, [(_r(3, 7, 5, 6, scale=2), True)], dev)
     yield 'sigmoid', lambda: _check(lambda x: TF.act(x, TF.ACT_SIGMOID), torch.sigmoid, [(_r(300, scale=3), True)], dev)
+    yield 'mul', lambda: _check(TF.mul, lambda a, b: a * b, [(_r(3, 5, 4, 6), True), (_r(3, 5, 4, 6, seed=1), True)], dev)
     yield 'channel_scale[B,C]', lambda: _check(TF.channel_scale, lambda x, s: x * s[:, :, None, None], [(_r(3, 5, 4, 6), True), (_r(3, 5, seed=1), True)], dev)
     yield 'channel_scale[C]', lambda: _check(TF.channel_scale, lambda x, s: x * s[None, :, None, None], [(_r(3, 5, 4, 6), True), (_r(5, seed=1), True)], dev)
     yield 'global_avg_pool', lambda: _check(TF.global_avg_pool, lambda x: x.mean((2, 3)), [(_r(3, 5, 7, 9), True)], dev)
