@@ -253,9 +253,9 @@ def test_module_is_a_drop_in():
     g = Golden('en_s0')
     m, kw = _model(g)
     assert [k for k, _, _ in g.meta['keys']] == list(m.state_dict().keys())
-    m.train()
-    with pytest.raises(NotImplementedError):
-        m(torch.zeros(1, 3, 320, 320).cuda(), torch.zeros(1, 3, 320, 320).cuda(), torch.zeros(1, 5, 512).cuda())
+    m.train()                       # training mode: the unfused network on the native training kernels (tests/test_train_graph.py); fp32 only
+    with pytest.raises(TypeError):
+        m(torch.zeros(2, 3, 320, 320).cuda().bfloat16(), torch.zeros(2, 3, 320, 320).cuda().bfloat16(), torch.zeros(2, 5, 512).cuda().bfloat16())
     m.eval()
     with pytest.raises(RuntimeError):
         m(torch.zeros(1, 3, 320, 320), torch.zeros(1, 3, 320, 320), torch.zeros(1, 5, 512))
