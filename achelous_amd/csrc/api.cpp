@@ -5,6 +5,8 @@
 #include <string>
 
 #include "engine.h"
+#include <mutex>
+#include <algorithm>
 #include "k_train.h"
 #include "k_train2.h"
 
@@ -215,19 +217,56 @@ static int train_guard(const std::function<void()>& fn) {
     catch (const ach::AchError& e) { g_create_error = e.msg; return e.code; }
     catch (const std::exception& e) { g_create_error = e.what(); return ACH_ERR_INVALID; }
 }
+// scratch for split reductions: one buffer per process, grown on demand.  Its users are ordered on the caller's stream; training runs on one.
+static float* train_workspace(size_t bytes) {
+    static std::mutex mu;
+    static float* buf = nullptr;
+    static size_t cap = 0;
+    std::lock_guard<std::mutex> lock(mu);
+    if (bytes > cap) {
+        if (buf) { (void)hipDeviceSynchronize(); (void)hipFree(buf); buf = nullptr; cap = 0; }
+        const size_t want = std::max(bytes, size_t(8) << 20);
+        if (hipMalloc(reinterpret_cast<void**>(&buf), want) != hipSuccess) { buf = nullptr; throw ach::AchError{ACH_ERR_NOMEM, "training workspace"}; }
+        cap = want;
+    }
+    return buf;
+}
+// slices of a per-channel reduction over `total` values: ~16 K values per workgroup, at most ~2048 workgroups in all
+static int train_slices(long total, int C) {
+    const long want = (total + 16383) / 16384, cap = std::max<long>(1, 2048 / std::max(C, 1));
+    return int(std::max<long>(1, std::min<long>(std::min<long>(want, cap), 64)));
+}
 int ach_train_gemm(const float* A, const float* B, float* C, const float* bias, int32_t M, int32_t N, int32_t K, int64_t lda, int64_t ldb, int64_t ldc,
                    int64_t stride_a, int64_t stride_b, int64_t stride_c, int32_t trans_a, int32_t trans_b, int32_t batch, int32_t reduce_batch,
                    int32_t accumulate, void* stream) {
     return train_guard([&] {
         if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0) throw ach::AchError{ACH_ERR_INVALID, "bad train_gemm arguments"};
-        ach::TrainGemmParams p{A, B, C, bias, M, N, K, long(lda), long(ldb), long(ldc), long(stride_a), long(stride_b), long(stride_c), trans_a, trans_b, batch, reduce_batch, accumulate};
-        const dim3 grid(unsigned((N + 63) / 64), unsigned((M + 63) / 64), unsigned(reduce_batch ? 1 : batch));
+        ach::TrainGemmParams p{A, B, C, bias, M, N, K, long(lda), long(ldb), long(ldc), long(stride_a), long(stride_b), long(stride_c), trans_a, trans_b, batch, reduce_batch, accumulate, 1, nullptr};
+        dim3 grid(unsigned((N + 63) / 64), unsigned((M + 63) / 64), unsigned(reduce_batch ? 1 : batch));
+        if (reduce_batch) {           // few output tiles, long reduction (weight gradients): split it over ~1024 workgroups, partial sums in a workspace
+            const long T = long(batch) * ((K + 15) / 16), tiles = long(grid.x) * grid.y;
+            long split = std::min<long>(std::min<long>(1024 / tiles, T / 8), 512);
+            if (split > 1) {
+                p.ksplit = int(split);
+                p.ws = train_workspace(size_t(split) * M * N * sizeof(float));
+                grid.z = unsigned(split);
+            }
+        }
         ACH_LAUNCH(ach::train_gemm_kernel, grid, dim3(256), static_cast<hipStream_t>(stream), p);
+        if (p.ksplit > 1) ACH_LAUNCH(ach::train_gemm_reduce_kernel, dim3(unsigned(ach::cdivl(long(M) * N, 256))), dim3(256), static_cast<hipStream_t>(stream), p);
     });
 }
 int ach_train_bn_stats(const float* z, float* mean, float* var, int32_t B, int32_t C, int32_t N, void* stream) {
     return train_guard([&] {
         if (!z || !mean || !var || B <= 0 || C <= 0 || N <= 0) throw ach::AchError{ACH_ERR_INVALID, "bad train_bn_stats arguments"};
+        const int S = train_slices(long(B) * N, C);
+        if (S > 1) {
+            ach::BnSliceParams q{z, train_workspace(size_t(2) * C * S * sizeof(float)), mean, var, B, C, N, S};
+            ACH_LAUNCH(ach::train_bn_slice_kernel<0>, dim3(unsigned(C), unsigned(S)), dim3(256), static_cast<hipStream_t>(stream), q);
+            ACH_LAUNCH(ach::train_bn_slice_kernel<1>, dim3(unsigned(C), unsigned(S)), dim3(256), static_cast<hipStream_t>(stream), q);
+            ACH_LAUNCH(ach::train_bn_slice_finalize_kernel, dim3(unsigned((C + 255) / 256)), dim3(256), static_cast<hipStream_t>(stream), q);
+            return;
+        }
         ach::BnStatsParams p{z, mean, var, B, C, N};
         ACH_LAUNCH(ach::train_bn_stats_kernel, dim3(unsigned(C)), dim3(256), static_cast<hipStream_t>(stream), p);
     });
@@ -244,8 +283,11 @@ int ach_train_bn_relu_bwd(const float* z, const float* y, const float* dy, const
                           float* dbeta, float* dz, int32_t B, int32_t C, int32_t N, float eps, int32_t relu, void* stream) {
     return train_guard([&] {
         if (!z || !y || !dy || !mean || !var || !gamma || !dgamma || !dbeta || !dz || B <= 0 || C <= 0 || N <= 0) throw ach::AchError{ACH_ERR_INVALID, "bad train_bn_relu_bwd arguments"};
-        ach::BnReluBwdParams p{z, y, dy, mean, var, gamma, dgamma, dbeta, dz, B, C, N, eps, relu};
-        ACH_LAUNCH(ach::train_bn_relu_bwd_reduce_kernel, dim3(unsigned(C)), dim3(256), static_cast<hipStream_t>(stream), p);
+        ach::BnReluBwdParams p{z, y, dy, mean, var, gamma, dgamma, dbeta, dz, B, C, N, eps, relu, 1, nullptr};
+        p.S = train_slices(long(B) * N, C);
+        if (p.S > 1) p.ws = train_workspace(size_t(2) * C * p.S * sizeof(float));
+        ACH_LAUNCH(ach::train_bn_relu_bwd_reduce_kernel, dim3(unsigned(C), unsigned(p.S)), dim3(256), static_cast<hipStream_t>(stream), p);
+        if (p.S > 1) ACH_LAUNCH(ach::train_bn_relu_bwd_finalize_kernel, dim3(unsigned((C + 255) / 256)), dim3(256), static_cast<hipStream_t>(stream), p);
         ACH_LAUNCH(ach::train_bn_relu_bwd_apply_kernel, dim3(unsigned(ach::cdivl(long(B) * C * N, 256))), dim3(256), static_cast<hipStream_t>(stream), p);
     });
 }

@@ -21,6 +21,10 @@ struct TrainGemmParams {
     int transA, transB;               // stored A is K x M / stored B is N x K
     int batch, reduce_batch;          // reduce_batch: C = sum_b op(A[b]) op(B[b])  (one output, grid.z = 1)
     int accumulate;                   // C += instead of C =
+    int ksplit; float* ws;            // ksplit > 1 (reduce_batch only): workgroup z reduces its share of the (batch, k-tile) range into ws[z][M][N];
+                                      // train_gemm_reduce_kernel then sums the partials in order (deterministic) and applies bias / accumulate.
+                                      // A weight gradient reduces over B x H x W (819 200 at batch 8, 320 x 320) into a 32 x 48 tile: without the split one
+                                      // workgroup did all of it (72 ms per call, 90 % of a training step)
 };
 
 // 256 threads = 4 waves; wave w owns the 32 x 32 quadrant (w >> 1, w & 1) of the 64 x 64 block tile: 2 x 2 MFMA tiles.
@@ -37,11 +41,18 @@ static __global__ __launch_bounds__(256) void train_gemm_kernel(const TrainGemmP
     for (int i = 0; i < 2; ++i)
         ACH_UNROLL
         for (int j = 0; j < 2; ++j) { acc[i][j][0] = acc[i][j][1] = acc[i][j][2] = acc[i][j][3] = 0.f; }
-    const int b_lo = p.reduce_batch ? 0 : int(blockIdx.z), b_hi = p.reduce_batch ? p.batch : int(blockIdx.z) + 1;
-    for (int b = b_lo; b < b_hi; ++b) {
-        const float* A = p.A + long(b) * p.sA;
-        const float* B = p.B + long(b) * p.sB;
-        for (int k0 = 0; k0 < p.K; k0 += TK) {
+    // the reduction range as (batch, k-tile) pairs, linearised: everything for one output of a batched product, the whole batch for a
+    // batch-reduced one, or this workgroup's share of it when split
+    const long ktiles = (p.K + TK - 1) / TK;
+    long t_lo, t_hi;
+    if (!p.reduce_batch) { t_lo = long(blockIdx.z) * ktiles; t_hi = t_lo + ktiles; }
+    else if (p.ksplit > 1) { const long T = long(p.batch) * ktiles, per = (T + p.ksplit - 1) / p.ksplit; t_lo = long(blockIdx.z) * per; t_hi = t_lo + per < T ? t_lo + per : T; }
+    else { t_lo = 0; t_hi = long(p.batch) * ktiles; }
+    {
+        for (long t = t_lo; t < t_hi; ++t) {
+            const int b = int(t / ktiles), k0 = int(t - long(b) * ktiles) * TK;
+            const float* A = p.A + long(b) * p.sA;
+            const float* B = p.B + long(b) * p.sB;
             // stage the two tiles k-major; each thread moves 4 elements of A and 4 of B (64 x 16 = 1024 each)
             ACH_UNROLL
             for (int e = 0; e < 4; ++e) {
@@ -76,7 +87,9 @@ static __global__ __launch_bounds__(256) void train_gemm_kernel(const TrainGemmP
             __syncthreads();
         }
     }
-    float* C = p.C + (p.reduce_batch ? 0L : long(blockIdx.z) * p.sC);
+    const bool partial = p.reduce_batch && p.ksplit > 1;
+    float* C = partial ? p.ws + long(blockIdx.z) * p.M * p.N : p.C + (p.reduce_batch ? 0L : long(blockIdx.z) * p.sC);
+    const long ldc = partial ? long(p.N) : p.ldc;
     ACH_UNROLL
     for (int i = 0; i < 2; ++i)
         ACH_UNROLL
@@ -85,11 +98,22 @@ static __global__ __launch_bounds__(256) void train_gemm_kernel(const TrainGemmP
             for (int r = 0; r < 4; ++r) {
                 const int gm = m0 + wm + 16 * i + lk * 4 + r, gn = n0 + wn + 16 * j + li;
                 if (gm < p.M && gn < p.N) {
-                    float v = acc[i][j][r] + (p.bias ? p.bias[gm] : 0.f);
-                    float* c = C + long(gm) * p.ldc + gn;
+                    float* c = C + long(gm) * ldc + gn;
+                    if (partial) { *c = acc[i][j][r]; continue; }
+                    const float v = acc[i][j][r] + (p.bias ? p.bias[gm] : 0.f);
                     *c = p.accumulate ? *c + v : v;
                 }
             }
+}
+static __global__ __launch_bounds__(256) void train_gemm_reduce_kernel(const TrainGemmParams p) {       // C = [C +] bias + sum_z ws[z], z ascending
+    const long i = long(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= long(p.M) * p.N) return;
+    const int gm = int(i / p.N), gn = int(i - long(gm) * p.N);
+    float v = 0.f;
+    for (int z = 0; z < p.ksplit; ++z) v += p.ws[long(z) * p.M * p.N + i];
+    v += p.bias ? p.bias[gm] : 0.f;
+    float* c = p.C + long(gm) * p.ldc + gn;
+    *c = p.accumulate ? *c + v : v;
 }
 
 // ---- BatchNorm over (B, N) of z [B, C, N]: one workgroup per channel
@@ -116,6 +140,38 @@ static __global__ __launch_bounds__(256) void train_bn_stats_kernel(const BnStat
     if (threadIdx.x == 0) { p.mean[c] = mean; p.var[c] = red[0] / float(total); }
 }
 
+// The same statistics with the (B, N) range of a channel cut into S slices (grid C x S) when it is long — at batch 8 a 320 x 320 map is
+// 819 200 values per channel for one workgroup (2.5 ms per launch; with the backward reduction 2/3 of a training step once the weight
+// gradients were split).  pass 0: partial sums; pass 1: partial centred squares around the mean that every workgroup re-derives from the
+// S partial sums (same order everywhere: deterministic); finalize: mean, biased variance.
+struct BnSliceParams { const float* Z; float* ws; float* mean; float* var; int B, C, N, S; };       // ws: [2][C][S]
+template <int PASS>
+static __global__ __launch_bounds__(256) void train_bn_slice_kernel(const BnSliceParams p) {
+    __shared__ float red[256];
+    const int c = blockIdx.x, sl = blockIdx.y;
+    const long total = long(p.B) * p.N, per = (total + p.S - 1) / p.S;
+    const long lo = long(sl) * per, hi = lo + per < total ? lo + per : total;
+    float mean = 0.f;
+    if (PASS == 1) { for (int j = 0; j < p.S; ++j) mean += p.ws[long(c) * p.S + j]; mean /= float(total); }
+    float a = 0.f;
+    for (long i = lo + threadIdx.x; i < hi; i += 256) {
+        const float v = p.Z[((i / p.N) * p.C + c) * p.N + i % p.N] - mean;
+        a += PASS == 0 ? v : v * v;
+    }
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) { if (int(threadIdx.x) < st) red[threadIdx.x] += red[threadIdx.x + st]; __syncthreads(); }
+    if (threadIdx.x == 0) p.ws[(long(PASS) * p.C + c) * p.S + sl] = red[0];
+}
+static __global__ __launch_bounds__(256) void train_bn_slice_finalize_kernel(const BnSliceParams p) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= p.C) return;
+    const float total = float(long(p.B) * p.N);
+    float m = 0.f, q = 0.f;
+    for (int j = 0; j < p.S; ++j) { m += p.ws[long(c) * p.S + j]; q += p.ws[(long(p.C) + c) * p.S + j]; }
+    p.mean[c] = m / total; p.var[c] = q / total;
+}
+
 struct BnReluFwdParams { const float* Z; const float* mean; const float* var; const float* gamma; const float* beta; float* Y; int B, C, N; float eps; int relu; };
 static __global__ __launch_bounds__(256) void train_bn_relu_fwd_kernel(const BnReluFwdParams p) {
     const long idx = long(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -129,14 +185,16 @@ static __global__ __launch_bounds__(256) void train_bn_relu_fwd_kernel(const BnR
 struct BnReluBwdParams {
     const float* Z; const float* Y; const float* dY; const float* mean; const float* var; const float* gamma;
     float* dgamma; float* dbeta; float* dZ; int B, C, N; float eps; int relu;
+    int S; float* ws;                 // S > 1: grid C x S, slice partials into ws [2][C][S], summed in order by train_bn_relu_bwd_finalize_kernel
 };
 static __global__ __launch_bounds__(256) void train_bn_relu_bwd_reduce_kernel(const BnReluBwdParams p) {
     __shared__ float r0[256], r1[256];
     const int c = blockIdx.x;
     const long total = long(p.B) * p.N;
+    const long per = p.S > 1 ? (total + p.S - 1) / p.S : total, lo = p.S > 1 ? long(blockIdx.y) * per : 0, hi = lo + per < total ? lo + per : total;
     const float mean = p.mean[c], rstd = 1.0f / sqrtf(p.var[c] + p.eps);
     float sb = 0.f, sg = 0.f;
-    for (long i = threadIdx.x; i < total; i += 256) {
+    for (long i = lo + threadIdx.x; i < hi; i += 256) {
         const long o = ((i / p.N) * p.C + c) * p.N + i % p.N;
         const float g = (p.relu && !(p.Y[o] > 0.f)) ? 0.f : p.dY[o];
         sb += g; sg += g * ((p.Z[o] - mean) * rstd);
@@ -144,7 +202,17 @@ static __global__ __launch_bounds__(256) void train_bn_relu_bwd_reduce_kernel(co
     r0[threadIdx.x] = sb; r1[threadIdx.x] = sg;
     __syncthreads();
     for (int st = 128; st >= 1; st >>= 1) { if (int(threadIdx.x) < st) { r0[threadIdx.x] += r0[threadIdx.x + st]; r1[threadIdx.x] += r1[threadIdx.x + st]; } __syncthreads(); }
-    if (threadIdx.x == 0) { p.dbeta[c] = r0[0]; p.dgamma[c] = r1[0]; }
+    if (threadIdx.x == 0) {
+        if (p.S > 1) { p.ws[long(c) * p.S + blockIdx.y] = r0[0]; p.ws[(long(p.C) + c) * p.S + blockIdx.y] = r1[0]; }
+        else { p.dbeta[c] = r0[0]; p.dgamma[c] = r1[0]; }
+    }
+}
+static __global__ __launch_bounds__(256) void train_bn_relu_bwd_finalize_kernel(const BnReluBwdParams p) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= p.C) return;
+    float sb = 0.f, sg = 0.f;
+    for (int j = 0; j < p.S; ++j) { sb += p.ws[long(c) * p.S + j]; sg += p.ws[(long(p.C) + c) * p.S + j]; }
+    p.dbeta[c] = sb; p.dgamma[c] = sg;
 }
 // step 2: dz = gamma * rstd * (g - dbeta / M - xhat * dgamma / M)
 static __global__ __launch_bounds__(256) void train_bn_relu_bwd_apply_kernel(const BnReluBwdParams p) {

@@ -83,6 +83,11 @@ def _cases(dev):
         yield f'conv2d k{k}s{s}', (lambda k=k, s=s, p=p, cin=cin, cout=cout, hw=hw: _check(
             lambda x, w, b: TF.conv2d(x, w, b, s, p), lambda x, w, b: F.conv2d(x, w, b, s, p),
             [(_r(2, cin, *hw), True), (_r(cout, cin, k, k, seed=1, scale=0.3), True), (_r(cout, seed=2), True)], dev))
+    yield 'conv2d long reduction', lambda: _check(lambda x, w, b: TF.conv2d(x, w, b, 1, 1), lambda x, w, b: F.conv2d(x, w, b, 1, 1),      # weight gradient split over 25 workgroups
+                                                 [(_r(2, 3, 40, 40), True), (_r(8, 3, 3, 3, seed=1, scale=0.3), True), (_r(8, seed=2), True)], dev)
+    yield 'batchnorm sliced', lambda: _check(lambda x, g, b: TF.batchnorm(x, g, b, None, None, True, 0.1, 1e-5, True),                      # 3 slices per channel
+                                            lambda x, g, b: torch.relu(F.batch_norm(x, None, None, g, b, True, 0.1, 1e-5)),
+                                            [(_r(2, 4, 130, 130), True), (_r(4, seed=1) + 1, True), (_r(4, seed=2), True)], dev)
     yield 'conv2d (5,1)', lambda: _check(lambda x, w: TF.conv2d(x, w, None, 1, (2, 0)), lambda x, w: F.conv2d(x, w, None, 1, (2, 0)),
                                         [(_r(3, 1, 40, 1), True), (_r(1, 1, 5, 1, seed=1), True)], dev)
     yield 'conv1x1', lambda: _check(TF.conv1x1, lambda x, w, b: F.conv2d(x, w[:, :, None, None], b),
