@@ -101,6 +101,7 @@ class Achelous(nn.Module):
         self.debug_taps = False     # True: the engine also materialises every SURVEY §8(a) boundary (parity tests)
         self.static_weights = False  # True: skip the per-call check for in-place weight changes (serving loops)
         self.engine_options = {}    # ach_set_option(key, value) pairs applied when an engine is created (include/achelous.h)
+        self.max_plan_batch = 256   # larger batches run as near-equal chunks through one plan (_run_chunked)
 
     # engines hold ctypes handles: never pickle / deepcopy them (utils_fit.py:378 pickles the module, ModelEMA deep-copies it)
     def __getstate__(self):
@@ -236,6 +237,30 @@ class Achelous(nn.Module):
         """Pipelined form of forward_detect()."""
         return self._run(x, x_radar, x_point_clouds, (float(conf_thres), float(nms_thres), max_det), pipelined=True)
 
+    def _run_chunked(self, x, x_radar, x_point_clouds, detect):
+        """Batches beyond one plan's reach (an activation tensor must stay below 2 GiB: 327 frames at 320x320 in bf16; 288 GB of HBM hold far
+        more): near-equal chunks of at most `max_plan_batch` frames through ONE plan — the last chunk is padded with copies of the final
+        frame so that the plan is never rebuilt — outputs concatenated and trimmed.  Frames are independent in eval mode, so the result
+        is what a single plan of the whole batch would give."""
+        B = x.shape[0]
+        n = -(-B // self.max_plan_batch)
+        size = -(-B // n)
+        pad = n * size - B
+
+        def padded(t):
+            return torch.cat([t, t[-1:].expand(pad, *t.shape[1:])], 0) if pad else t
+        xs, rs, ps = padded(x), padded(x_radar), padded(x_point_clouds)
+        parts = [self._run(xs[i:i + size], rs[i:i + size], ps[i:i + size], detect) for i in range(0, n * size, size)]
+        if detect is None:
+            outs, recs = parts, None
+        else:
+            outs, recs = [p[0] for p in parts], [p[1] for p in parts]
+        det = [torch.cat([o[0][k] for o in outs], 0)[:B] for k in range(3)]
+        res = (det, torch.cat([o[1] for o in outs], 0)[:B], torch.cat([o[2] for o in outs], 0)[:B], torch.cat([o[3] for o in outs], 0)[:B])
+        if recs is None:
+            return res
+        return res, tuple(torch.cat([r[k] for r in recs], 0)[:B] for k in range(3))
+
     def _run(self, x, x_radar, x_point_clouds, detect, pipelined=False):
         if self.training:
             raise NotImplementedError("achelous_amd.Achelous runs eval-mode inference only; call .eval() first")
@@ -247,6 +272,8 @@ class Achelous(nn.Module):
         if x_point_clouds.dim() != 3 or x_point_clouds.shape[0] != B or x_point_clouds.shape[1] != self.pc_channels:
             raise ValueError(f"expected points of shape [B,{self.pc_channels},N], got {tuple(x_point_clouds.shape)}")
         dt, dev, n_in = x.dtype, x.device, x_point_clouds.shape[2]
+        if B > self.max_plan_batch and not pipelined:
+            return self._run_chunked(x, x_radar, x_point_clouds, detect)
         # The reference takes any point count (achelous.py:240-243 feeds whatever the frame holds); the point kernels work on 16-row
         # tiles.  PointNet is per-point MLPs + max over points, so repeating the last point changes nothing: pad to the next
         # multiple of 16 (the engine's bucket) and trim the padded rows of the output.  PointNet++ (our own specification) samples

@@ -4,7 +4,7 @@
 root="${GRAFT_REPO_ROOT:-/root/repo}"
 cd "$root"; mkdir -p gpurun_out/variants
 for cfg in en_s0 mv_s2 en_s2 en_s0_pn2; do bash profiles/scripts/profile_config.sh $cfg > gpurun_out/profile_$cfg.log 2>&1; done
-b() { name=$1; shift; python bench.py --steps 20 --warmup 5 --no-cpu-baseline "$@" 2>/dev/null | tail -1 > gpurun_out/variants/r02_bench_$name.json; }
+b() { name=$1; shift; python bench.py --steps 20 --warmup 5 --no-cpu-baseline "$@" 2>/dev/null | grep '^{"metric' | tail -1 > gpurun_out/variants/r02_bench_$name.json; }
 b en_s0_dense_radar --dense-radar
 b en_s0_dense_radar_noskip --dense-radar --opt radar_skip=0
 b en_s0_noskip --opt radar_skip=0

@@ -443,6 +443,54 @@ def test_radar_skip_is_bit_identical(cells):
             assert torch.equal(a, b)
 
 
+def test_batches_beyond_one_plan_run_in_chunks():
+    """A plan's activation tensors must stay below 2 GiB (327 frames at 320x320 in bf16); larger batches go through near-equal chunks of
+    one plan with the last chunk padded (nets.py::_run_chunked).  Here with the chunk size lowered to 24: 50 frames = 3 chunks of 17 with
+    one padded frame.  Frames are independent in eval mode: identical to the plain calls on the same frames."""
+    g = Golden('en_s0')
+    m, kw = _model(g)
+    x, xr, xp = make_inputs(50, 31, resolution=kw['resolution'], pc_channels=kw['pc_channels'])
+    xs, rs, ps = x.cuda().bfloat16(), xr.cuda().bfloat16(), xp.cuda().bfloat16()
+    with torch.no_grad():
+        m.max_plan_batch = 24
+        (det, se, lane, pc), (rows, idx, cnt) = m.forward_detect(xs, rs, ps, 0.05, 0.5, 50)
+        plain = m(xs, rs, ps)
+        m.max_plan_batch = 256
+        ref = m.forward_detect(xs[34:50].contiguous(), rs[34:50].contiguous(), ps[34:50].contiguous(), 0.05, 0.5, 50)
+        torch.cuda.synchronize()
+    assert se.shape[0] == 50 and rows.shape[0] == 50 and cnt.shape[0] == 50
+    for a, b in zip((*det, se, lane, pc), (*plain[0], plain[1], plain[2], plain[3])):
+        assert torch.equal(a, b)
+    for a, b in zip((*det, se, lane, pc, rows, idx, cnt), (*ref[0][0], ref[0][1], ref[0][2], ref[0][3], *ref[1])):
+        assert torch.equal(a[34:50], b)
+    assert int(cnt.max()) > 0
+
+
+def test_sppf_neck_matches_oracle():
+    """spp=False builds SPPF (neck/spp.py:55-67: three chained 5x5 max pools = the 5 / 9 / 13 windows of the SPP pool kernel) — on the
+    MI355X, not only under emulation: fp32 against the oracle, bf16 within twice the oracle's own bf16-autocast deviation on these frames."""
+    g = Golden('en_s0')
+    kw = dict(ctor_kwargs(g.meta), spp=False)
+    m = Achelous(**kw).eval()
+    sd = g.calibrate(condition_state_dict(m.state_dict(), seed=g.meta['weight_seed']))
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda()
+    x, xr, xp = make_inputs(2, 6, resolution=kw['resolution'], pc_channels=kw['pc_channels'])
+    okw = {k: kw[k] for k in ('num_det', 'num_seg', 'phi', 'backbone', 'neck', 'pc_seg', 'pc_channels', 'pc_classes', 'nano_head', 'spp', 'resolution')}
+    ref = AchelousOracle({k: v.cpu() for k, v in sd.items()}, **okw).forward(x, xr, xp)
+    with torch.no_grad():
+        det, se, lane, pc = m(x.cuda(), xr.cuda(), xp.cuda())
+        for a, b in zip((*det, se, lane, pc), (*ref[0], ref[1], ref[2], ref[3])):
+            assert _rel(a.float(), b.float()) <= F32_TOL
+        # bf16 yardstick measured on THESE frames and THIS model (the fixture's figures belong to the SPP model's calibration frames):
+        # the oracle under bf16 autocast against its fp32 self
+        with torch.autocast('cpu', dtype=torch.bfloat16):
+            amp = AchelousOracle({k: v.cpu() for k, v in sd.items()}, **okw).forward(x, xr, xp)
+        det, se, lane, pc = m(x.cuda().bfloat16(), xr.cuda().bfloat16(), xp.cuda().bfloat16())
+        for k, a, b, c in zip(OUTPUTS, (*det, se, lane, pc), (*ref[0], ref[1], ref[2], ref[3]), (*amp[0], amp[1], amp[2], amp[3])):
+            assert _rel(a.float(), b.float()) <= max(2e-2, 2.0 * _rel(c.float(), b.float())), k
+
+
 def test_reference_default_resolution_416():
     """The reference constructor defaults to 416x416 (nets/Achelous.py:27): 3549 anchors, 13x13 coarsest map, the NMS path with
     more candidates than its LDS tile holds.  fp32 forward against the oracle, decode + NMS bit-exact against the oracle's."""
