@@ -80,9 +80,11 @@ public:
     int split_decoders = 0;           // option "split_decoders": semantic decoder on side stream 3.  OFF: with the other branches at low
                                       // priority it no longer pays (23.8 k vs 22.9 k frames/s), and the process must stay at <= 4 ACTIVE
                                       // streams — caller + 2 here leaves one for a collective (RCCL) stream; a fifth costs 28 %
-    bool head_stream = true;          // option "head_stream": radar and point branches share low-priority stream 1; fusion + detection head
-                                      // (+ decode + NMS) get stream 2 at the caller's priority: they are on the critical tail once the
-                                      // neck is done
+    bool head_stream = false;         // option "head_stream" = 1: radar and point branches share low-priority stream 1; fusion + detection head
+                                      // (+ decode + NMS) get stream 2 at the caller's priority.  Was the default (+1.1 % in round 1) until the
+                                      // first RCBlock's shortcut shortened the radar branch: with the head queued BEHIND the radar branch on
+                                      // stream 1 the plan is now +1.2 % faster (26.1 k vs 25.8 k frames/s), and — caller + ONE side stream —
+                                      // it leaves room for RCCL's stream: all-gather overhead at world size 1 9 % -> 1.5-4.5 %
     int side_low_priority = 3;        // option "side_priority" (with head_stream = 0): bit k set = side stream k+1 is created at the
                                       // lowest stream priority
     bool pipeline = false;            // option "pipeline": consecutive forwards overlap.  The segmentation decoders move from the caller's stream

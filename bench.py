@@ -131,6 +131,9 @@ def main():
         os.environ.setdefault('MASTER_PORT', '29533')
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
+        # This image exports NCCL_DEBUG=VERSION: RCCL then writes a five-line banner to STDOUT through C stdio, which lands AFTER the JSON
+        # line when stdout is a pipe.  The contract is one JSON line on stdout, so the banner is switched off (ACH_NCCL_DEBUG overrides).
+        os.environ['NCCL_DEBUG'] = os.environ.get('ACH_NCCL_DEBUG', 'NONE')
         dist.init_process_group('nccl', device_id=dev)   # "nccl" is RCCL on ROCm
 
     from achelous_amd import Achelous, decode_outputs
@@ -332,10 +335,12 @@ def main():
             result['cpu_baseline'] = cpu_baseline(model, dict(COMMON, **kw), x, xr, xp, args.cpu_sample)
         else:
             result['cpu_baseline'] = None
-        print(json.dumps(result), flush=True)
+        line = json.dumps(result)
     if collective:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        print(line, flush=True)          # the last thing on stdout
 
 
 if __name__ == '__main__':

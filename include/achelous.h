@@ -97,7 +97,7 @@ int ach_load_weights(ach_handle* h, const ach_tensor_desc* tensors, size_t n);
  * (-1 auto / 0 / 1: four waves per pixel tile in k_mlp.h), "row_conv" (offset/modulator convs through k_conv3.h),
  * "split_decoders" (semantic decoder on its own stream), "fused_rc" (RCBlock conv + deformable sampling + contraction as one
  * kernel), "dw_tile" (LDS-tiled depthwise kernel on 10x10 maps), "head_batch" (detection-head layers batched over the levels),
- * "head_stream" (radar + point branches share low-priority stream 1, fusion + head + NMS run on stream 2 at the caller's priority),
+ * "head_stream" (1: radar + point branches share low-priority stream 1, fusion + head + NMS run on stream 2 at the caller's priority; default 0: they queue behind the radar branch on stream 1),
  * "side_priority" (with head_stream = 0: bit mask of the side streams created at the lowest stream priority),
  * "point_stream2" (-1 auto / 0 / 1: the point branch opens stream 2 ahead of fusion + head; auto = PointNet++ only),
  * "stem_mfma" (the 4x4/s4 stem conv as an MFMA GEMM gathered from the NCHW image; 0: scalar-FMA kernel). */

@@ -7,7 +7,7 @@ mkdir -p gpurun_out
 : > gpurun_out/$tag.txt
 for rep in 1 2; do
 for v in "$@"; do
-  line=$(python bench.py --steps 30 --warmup 5 --no-cpu-baseline $v 2>/dev/null | tail -1)
+  line=$(python bench.py --steps 30 --warmup 5 --no-cpu-baseline $v 2>/dev/null | grep "^{\"metric" | tail -1)
   echo "{\"variant\": \"$v\", \"rep\": $rep, \"result\": $line}" >> gpurun_out/$tag.txt
   python - "$v" "$line" <<'PY'
 import json,sys

@@ -377,7 +377,7 @@ def test_fused_kernels_agree_with_the_layerwise_path(option):
         with torch.no_grad():
             ref = m(xs, rs, ps)
             e = _engine_of(m, dt)
-            default = 0 if option in ('split_decoders', 'head_mfma') else 1
+            default = 0 if option in ('split_decoders', 'head_mfma', 'head_stream') else 1
             e.set_option(option, 1 - default)
             e.plan(2)
             alt = m(xs, rs, ps)
