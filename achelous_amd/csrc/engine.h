@@ -45,6 +45,9 @@ struct Op {
     bool xwait = false;           // pipelined forwards: first launch of its stream to overwrite buffers that the PREVIOUS forward's
                                   //   detection stream still reads -> waits for that forward's `xsignal` launch
     bool xsignal = false;         // pipelined forwards: last launch that reads buffers another stream rewrites in the next forward
+    bool xwait2 = false;          // the same pair for the DECODERS' reads of the attention maps: since fusion + head moved to the radar stream
+    bool xsignal2 = false;        //   (head_stream = 0) the fusion launch no longer follows the decoders in stream order, so `xsignal` alone would
+                                  //   let the next forward's neck overwrite what this forward's decoders still read
 };
 
 struct IoPtrs {
@@ -155,6 +158,7 @@ protected:
         op.wait_ev = pending_wait; op.wait_ev2 = pending_wait2;
         pending_wait = -1; pending_wait2 = -1;
         op.xwait = pending_xwait; pending_xwait = false;
+        op.xwait2 = pending_xwait2; pending_xwait2 = false;
         ops.push_back(std::move(op));
     }
     // branch bookkeeping while the plan is built
@@ -169,12 +173,16 @@ protected:
     bool streams_ready = false;
     void ensure_streams();
     // pipelined mode: two alternating event sets (forward k uses set k & 1)
+    hipEvent_t ev_x2[2] = {nullptr, nullptr};
+    bool x2_recorded[2] = {false, false};
     hipEvent_t ev_x[2] = {nullptr, nullptr}, ev_done[kSideStreams][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
     bool done_used[2][kSideStreams] = {{false, false, false}, {false, false, false}};
     long issued = 0, joined = 0;
     void mark_xwait_next() { pending_xwait = true; }
     void mark_xsignal_last() { if (!measuring && !ops.empty()) ops.back().xsignal = true; }
-    bool pending_xwait = false;
+    bool pending_xwait = false, pending_xwait2 = false;
+    void mark_xwait2_next() { pending_xwait2 = true; }
+    void mark_xsignal2_last() { if (!measuring && !ops.empty()) ops.back().xsignal2 = true; }
 #if !defined(ACH_HOSTEMU)
     struct GraphEntry { IoPtrs io; hipGraphExec_t exec; unsigned long stamp; };
     std::vector<GraphEntry> graphs;

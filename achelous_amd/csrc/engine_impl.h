@@ -945,6 +945,7 @@ public:
         if (c_ % 4) throw AchError{ACH_ERR_UNSUPPORTED, "SPP hidden width must be a multiple of 4"};
         A cat5 = alloc(m5.B, m5.H, m5.W, 4 * c_);
         mark_xwait_next();               // pipelined forwards: the neck rewrites what the previous forward's stream 2 reads (engine.cpp)
+        mark_xwait2_next();              // ... and what its decoders read
         { GemmOpt o; o.act = ACT_SILU; gemm(f + ".spp.cv1", m5, pack(conv_bn(f + ".spp.cv1.conv", f + ".spp.cv1.bn", 1e-3)), cat5.slice(0, c_), o); }
         {
             const int hw = m5.H * m5.W, cq = c_ / 4;
@@ -987,8 +988,10 @@ public:
         if (split_dec) signal_after_last(2);   // the semantic decoder may start on its own stream
         for (int d = 0; d < 2; ++d) {
             // past the shared attention stage the two decoders are independent: water-line decoder on the caller's stream, semantic
-            // decoder on stream 3 when the option is on
-            if (d == 1 && split_dec) { cur_stream = 3; wait_before_next(2); }
+            // decoder on stream 3 when the option is 1; option 2: the (shorter) water-line decoder joins side stream 1 behind the radar
+            // branch instead — no extra stream — and the semantic decoder keeps the caller's
+            if (split_decoders == 1 && d == 1) { cur_stream = 3; wait_before_next(2); }
+            if (split_decoders == 2) { cur_stream = d == 0 ? 1 : 0; if (d == 0) wait_before_next(2); }
             const std::string n = names[d];
             A y = ysa[d];
             tap(n + ".sa", y);
@@ -1012,6 +1015,7 @@ public:
             }
             decoder_last_level(f + "." + n + "_seg_" + lv[2], f + "." + n + "_seg_ghost_" + lv[2], f + "." + n + "_seg_head", n + "." + lv[2], y, cw[2], oups[d], outs[d]);
         }
+        if (piped) mark_xsignal2_last();    // the decoders' last launch: the next forward's neck may rewrite the attention maps after it
         cur_stream = 0;
     }
     const int* widths() const {

@@ -12,7 +12,7 @@ b en_s0_cdf --config en_s0_cdf
 b en_s0_f32 --dtype f32
 b en_s0_b1 --batch 1
 b en_s0_b8 --batch 8
-b en_s0_pipeline --pipeline
+b en_s0_plain --plain
 b en_s0_separate_calls --separate-calls
 b en_s0_force_collective --force-collective
 b en_s0_head_mfma --opt head_mfma=1
