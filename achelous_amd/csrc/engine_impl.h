@@ -428,6 +428,17 @@ public:
         mp.M = xin.rows(); mp.C = C; mp.k1 = k1; mp.J = J; mp.act = act; mp.ln_eps = ln_eps; mp.ln = 1; mp.Cout = C;
         // per-sample map size, not batch, decides the geometry: a frame's result must not depend on the batch it is in
         const bool split = mlp_split < 0 ? xin.H * xin.W <= 1024 : mlp_split != 0;
+        if (split && dw_ks && dw_even && DT == 10) {                      // the instantiated width (launch_mlp)
+            // deal the k1 * k tap rows to the four waves in contiguous shares when that lowers the slowest wave's count and no share spans
+            // more than two k-steps (the exchange buffer holds two slots per wave)
+            const int U = k1 * dw_ks, chunk = cdiv(U, 4);
+            bool ok = chunk < cdiv(k1, 4) * dw_ks;
+            for (int w = 0; w < 4 && ok; ++w) {
+                const int u0 = w * chunk, u1 = std::min(U, u0 + chunk);
+                if (u0 < u1 && (u1 - 1) / dw_ks > u0 / dw_ks + 1) ok = false;
+            }
+            mp.dw_even = ok ? 1 : 0;
+        }
         const double bytes = double(mp.M) * C * sizeof(T) * (xin.p == resid.p ? 2.0 : 3.0);
         const double flops = 4.0 * double(mp.M) * C * hidden + (dw_ks ? 2.0 * double(mp.M) * C * dw_ks * dw_ks : 0.0);
         add_op(name, [mp, DT, split](hipStream_t s) { launch_mlp<T>(mp, DT, split, s); }, bytes, flops);

@@ -48,6 +48,7 @@ struct MlpParams {
     long M; int C, k1, J, act; float ln_eps;
     int ln, Cout;                         // ln = 0: no normalisation (plain two-layer chain); Cout: output width (R may be null)
     int planar_w;                         // chain_kernel only, > 0: Y is written channel-planar per map row, [M / planar_w][Cout][planar_w]
+    int dw_even;                          // SPLIT + depthwise: the k1 * dw_k tap ROWS are dealt evenly to the four waves (mlp_inputs), not whole k-steps
 };
 
 constexpr int MLP_RED_TILES = 4;          // output tiles reduced per LDS round in SPLIT mode
@@ -58,7 +59,7 @@ constexpr int MLP_RED_TILES = 4;          // output tiles reduced per LDS round 
 // address arithmetic, no masking of the packed data (this loop is VALU-issue bound: 25 -> 15 instructions per tap).  Rows outside
 // the map are skipped.  The weights are kept in fp32 so that only the activations need unpacking.
 template <class T, int KS>
-__device__ __forceinline__ void mlp_dw(const MlpParams& p, const BufRsrc& xb, long pix0, int oy, int ox, int k0, float* acc) {
+__device__ __forceinline__ void mlp_dw(const MlpParams& p, const BufRsrc& xb, long pix0, int oy, int ox, int k0, float* acc, int ty0 = 0, int ty1 = KS) {
     constexpr int VEC = Store<T>::VEC;
     constexpr int TG = KS <= 5 ? KS : (KS + 1) / 2;
     constexpr unsigned ESZ = sizeof(T);
@@ -72,7 +73,7 @@ __device__ __forceinline__ void mlp_dw(const MlpParams& p, const BufRsrc& xb, lo
         const int ix = ox + tx - KS / 2;
         coff[tx] = (ix >= 0 && ix < p.W) ? unsigned(ix) * pitch : BUF_OOB;
     }
-    for (int ty = 0; ty < KS; ++ty) {
+    for (int ty = ty0; ty < ty1; ++ty) {
         const int iy = oy + ty - KS / 2;
         if (iy < 0 || iy >= p.H) continue;
         const unsigned rowb = base + unsigned(iy) * rowpitch;
@@ -104,8 +105,12 @@ __device__ __forceinline__ void mlp_dw(const MlpParams& p, const BufRsrc& xb, lo
 
 // Step 1 of mlp_kernel: this wave's input fragments and its partial LayerNorm sums.  KS = 0: plain rows; KS = 3/5/7/9: depthwise conv.
 // SPLIT: wave w produces k-steps w, w+4, ... straight into LDS (`xs`); otherwise all k-steps into `xf`.
-template <class T, int K1MAX, bool SPLIT, int KS>
-__device__ __forceinline__ void mlp_inputs(const MlpParams& p, long m, bool valid, int g, int wave, int lane, uint4* xs, uint4* xf, float& s1, float& s2) {
+// SPLIT + dw_even (host: every wave's share spans at most two k-steps, `part` holds 4 waves x 2 slots x 64 lanes x 8 floats): with whole
+// k-steps per wave, 5 k-steps (d = 144) are 2 / 1 / 1 / 1 and 3 k-steps (d = 96) 1 / 1 / 1 / 0 — the depthwise phase waits for its slowest wave.
+// Dealing the k1 * KS tap ROWS in four contiguous shares makes that 9 / 9 / 9 / 8 rows instead of 14 / 7 / 7 / 7; the owner of a k-step
+// (as before: wave s % 4) then sums the shares in wave order (deterministic), adds the bias and forms the fragment.
+template <class T, int K1MAX, bool SPLIT, int KS, bool EVEN>
+__device__ __forceinline__ void mlp_inputs(const MlpParams& p, long m, bool valid, int g, int wave, int lane, uint4* xs, uint4* xf, float& s1, float& s2, float* part) {
     constexpr int VEC = Store<T>::VEC;
     constexpr int KC = 4 * VEC;
     const T* X = static_cast<const T*>(p.X);
@@ -120,12 +125,49 @@ __device__ __forceinline__ void mlp_inputs(const MlpParams& p, long m, bool vali
         pix0 = b * hw;
     }
     constexpr int NS = SPLIT ? (K1MAX + 3) / 4 : K1MAX;
+    constexpr bool even = SPLIT && KS > 0 && EVEN;     // a compile-time variant: as a run-time branch it cost the plain path 116 bytes of spills at DT = 6
+    const int U = p.k1 * KS, chunk = (U + 3) / 4;
+    if (SPLIT && KS > 0 && even) {
+        const int u0 = wave * chunk, u1 = u0 + chunk < U ? u0 + chunk : U, sa = u0 / KS;
+        ACH_UNROLL
+        for (int slot = 0; slot < 2; ++slot) {
+            const int s = sa + slot, k0 = s * KC + g * VEC;
+            const int r0 = slot == 0 ? u0 - sa * KS : 0, r1 = u1 - s * KS < KS ? u1 - s * KS : KS;
+            float acc[8];
+            ACH_UNROLL
+            for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+            if (u0 < u1 && s < p.k1 && r0 < r1 && valid && k0 < p.C) mlp_dw<T, (KS > 0 ? KS : 3)>(p, xb, pix0, oy, ox, k0, acc, r0, r1);
+            float* dst = part + ((wave * 2 + slot) * 64 + lane) * 8;
+            *reinterpret_cast<float4*>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            *reinterpret_cast<float4*>(dst + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+        }
+        __syncthreads();
+    }
     ACH_UNROLL
     for (int si = 0; si < NS; ++si) {
         const int s = SPLIT ? wave + 4 * si : si;
         if (s >= p.k1) continue;
         const int k0 = s * KC + g * VEC;
         uint4 frag = make_uint4(0u, 0u, 0u, 0u);
+        if (SPLIT && KS > 0 && even) {
+            if (valid && k0 < p.C) {
+                float acc[8];
+                ACH_UNROLL
+                for (int i = 0; i < VEC; ++i) acc[i] = p.bdw[k0 + i];
+                for (int w = 0; w < 4; ++w) {                          // shares of k-step s, in wave order
+                    const int a = (w * chunk) / KS;
+                    if (w * chunk >= U || (a != s && a + 1 != s)) continue;
+                    const float* src = part + ((w * 2 + (s - a)) * 64 + lane) * 8;
+                    ACH_UNROLL
+                    for (int i = 0; i < VEC; ++i) acc[i] += src[i];
+                }
+                ACH_UNROLL
+                for (int i = 0; i < VEC; ++i) { s1 += acc[i]; s2 += acc[i] * acc[i]; }
+                frag = frag_pack<T>(acc);
+            }
+            xs[s * 64 + lane] = frag;
+            continue;
+        }
         if (valid && k0 < p.C) {
             if (KS == 0) {
                 frag = *reinterpret_cast<const uint4*>(X + m * p.ldx + k0);
@@ -155,7 +197,7 @@ template <int DT, bool SPLIT> struct MlpOcc {
     static constexpr int blocks = (SPLIT && DT > 6) ? 2 : (DT <= 6 ? 6 : (DT <= 10 ? 4 : (DT <= 12 ? 3 : 2)));
 };
 
-template <class T, int DT, bool SPLIT>
+template <class T, int DT, bool SPLIT, bool EVEN = false>
 __global__ __launch_bounds__(256, (MlpOcc<DT, SPLIT>::blocks)) void mlp_kernel(const MlpParams p) {
     constexpr int VEC = Store<T>::VEC;
     constexpr int KC = 4 * VEC;
@@ -181,11 +223,11 @@ __global__ __launch_bounds__(256, (MlpOcc<DT, SPLIT>::blocks)) void mlp_kernel(c
     for (int s = 0; s < K1MAX; ++s) xf[s] = make_uint4(0u, 0u, 0u, 0u);
     float s1 = 0.f, s2 = 0.f;
     switch (p.dw_k) {
-        case 0: mlp_inputs<T, K1MAX, SPLIT, 0>(p, m, valid, g, wave, lane, xs, xf, s1, s2); break;
-        case 3: mlp_inputs<T, K1MAX, SPLIT, 3>(p, m, valid, g, wave, lane, xs, xf, s1, s2); break;
-        case 5: mlp_inputs<T, K1MAX, SPLIT, 5>(p, m, valid, g, wave, lane, xs, xf, s1, s2); break;
-        case 7: mlp_inputs<T, K1MAX, SPLIT, 7>(p, m, valid, g, wave, lane, xs, xf, s1, s2); break;
-        default: mlp_inputs<T, K1MAX, SPLIT, 9>(p, m, valid, g, wave, lane, xs, xf, s1, s2); break;
+        case 0: mlp_inputs<T, K1MAX, SPLIT, 0, EVEN>(p, m, valid, g, wave, lane, xs, xf, s1, s2, red); break;
+        case 3: mlp_inputs<T, K1MAX, SPLIT, 3, EVEN>(p, m, valid, g, wave, lane, xs, xf, s1, s2, red); break;
+        case 5: mlp_inputs<T, K1MAX, SPLIT, 5, EVEN>(p, m, valid, g, wave, lane, xs, xf, s1, s2, red); break;
+        case 7: mlp_inputs<T, K1MAX, SPLIT, 7, EVEN>(p, m, valid, g, wave, lane, xs, xf, s1, s2, red); break;
+        default: mlp_inputs<T, K1MAX, SPLIT, 9, EVEN>(p, m, valid, g, wave, lane, xs, xf, s1, s2, red); break;
     }
     s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
     s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
@@ -326,6 +368,9 @@ template <class T>
 inline bool launch_mlp(const MlpParams& p, int DT, bool split, hipStream_t stream) {
     const long tiles = (p.M + 15) / 16;
     const dim3 grid(unsigned(split ? tiles : (tiles + 3) / 4)), block(256);
+    // the even depthwise row split is instantiated where it pays: d = 144 (DT 10; EN-S2 stage 2, +0.7 % frames/s).  At d = 96 (DT 6, the
+    // 80-register budget of six workgroups per CU) the variant spills 80 bytes and EN-S0 loses 0.8 %: not instantiated.
+    if (split && p.dw_even && DT == 10) { ACH_LAUNCH((mlp_kernel<T, 10, true, true>), grid, block, stream, p); return true; }
 #define ACH_MLP_CASE(dt) \
     if (DT == dt) { if (split) ACH_LAUNCH((mlp_kernel<T, dt, true>), grid, block, stream, p); else ACH_LAUNCH((mlp_kernel<T, dt, false>), grid, block, stream, p); return true; }
     ACH_MLP_CASE(2) ACH_MLP_CASE(4) ACH_MLP_CASE(6) ACH_MLP_CASE(8) ACH_MLP_CASE(10) ACH_MLP_CASE(12) ACH_MLP_CASE(18) ACH_MLP_CASE(20)

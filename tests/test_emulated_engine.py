@@ -111,7 +111,7 @@ def test_emulated_forward_detect_equals_the_three_calls():
     assert int(cnt[0]) > 0
 
 
-@pytest.mark.parametrize('option', ['fused_mlp', 'row_conv', 'fused_rc', 'dw_tile', 'head_batch', 'split_decoders', 'head_stream', 'streams', 'stem_mfma', 'radar_start'])
+@pytest.mark.parametrize('option', ['fused_mlp', 'row_conv', 'fused_rc', 'dw_tile', 'head_batch', 'split_decoders', 'head_stream', 'streams', 'stem_mfma', 'radar_start', 'dw_even'])
 def test_emulated_kernel_switches_agree(option):
     """Each fused / batched kernel against the layer-wise launches it replaced, through the C ABI on the CPU emulation (fp32)."""
     kw, sd, (x, xr, xp) = _setup('en_s0', 64, 1, 16)
@@ -375,3 +375,26 @@ def test_emulated_radar_skip_is_bit_identical(dtype, cells):
         outs.append([t.float() for t in o[:3]] + [eng.read_tap(t) for t in ('radar.b0', 'radar.b1', 'r3', 'r5')])
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('name', ['en_s2'])
+def test_emulated_even_depthwise_row_split_bf16(name):
+    """bf16 SPLIT blocks of EN-S2's stage 2 (d = 144: 5 k-steps): the k1 * k depthwise tap rows dealt evenly to the four waves (option dw_even)
+    against whole k-steps per wave.  Different summation order of the taps -> fp32 rounding -> isolated bf16 flips downstream."""
+    from achelous_amd.engine import NativeEngine
+    kw, sd, (x, xr, xp) = _setup(name, 64, 2, 16)
+    td = torch.bfloat16
+    outs = []
+    for v in (1, 0):
+        eng = NativeEngine(emu_library(), num_det=kw['num_det'], num_seg=kw['num_seg'], phi=kw['phi'], backbone=kw['backbone'],
+                           resolution=kw['resolution'], pc_channels=kw['pc_channels'], pc_classes=kw['pc_classes'],
+                           num_points=16, nano_head=kw['nano_head'], spp=kw['spp'], dtype=DTYPE_BF16)
+        eng.set_option('dw_even', v)
+        eng.set_option('full_taps', 1)
+        eng.load_state_dict(sd)
+        eng.plan(2)
+        o = alloc_outputs(kw, 2, 16, td, 'cpu')
+        eng.forward(x.to(td), xr.to(td), xp.to(td), o)
+        outs.append([t.float() for t in o] + [eng.read_tap('map3'), eng.read_tap('map4'), eng.read_tap('map5')])
+    for a, b in zip(*outs):
+        assert rel_err(a, b) < 3e-2
