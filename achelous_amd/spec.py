@@ -3,7 +3,7 @@ generated from the architecture description alone.
 
 This is what makes `achelous_amd.Achelous` a drop-in for `load_state_dict(torch.load(path))` (achelous.py:171):
 the same 771 / 825 / 920 keys as the reference for EN-S0 / EN-S2 / MV-S2, in the same order.  Checked against the
-key lists captured from the imported reference (tests/golden/*.keys.json) by tests/test_dropin_module.py.
+key lists captured from the imported reference (tests/golden/*.keys.json) by tests/test_abi_and_host.py.
 
 Each entry: (key, shape, kind) with kind in {'param', 'buffer', 'buffer_i64'}.
 """
