@@ -9,8 +9,8 @@ arithmetic operation a `torch.autograd.Function` from train_functional.py / trai
 kernels.  What torch does here is tensor plumbing: views, `cat` / `split` / channel shuffles, and the residual / bias additions, whose
 gradients autograd routes.  fp32 on GPU tensors only; there is no PyTorch-op or CPU fallback.
 
-Built for the BASELINE configurations' main family: EdgeNeXt backbone ('en'), Ghost-Dual-FPN ('gdf'), PointNet ('pn'), nano head.  The
-MobileViT backbone, the CSP neck and PointNet++ raise NotImplementedError in training mode.
+Built for every family that has reference code: EdgeNeXt ('en') and MobileViT ('mv') backbones, Ghost-Dual-FPN ('gdf') and CSP-Dual-FPN
+('cdf') necks, PointNet ('pn'), nano head.  PointNet++ (our own specification, no reference) raises NotImplementedError in training mode.
 """
 import math
 
@@ -28,10 +28,17 @@ WIDTHS = {'S0': [32, 48, 96, 176], 'S1': [32, 48, 120, 224], 'S2': [32, 64, 144,
 BN_MOMENTUM = 0.1
 
 
+MOBILEVIT = {  # backbone/vision/mobilevit_modules/mobilevit.py:225-240: channel plan (transformer widths are read from the weights)
+    'S0': [16, 16, 32, 32, 48, 48, 96, 96, 96, 96, 176],
+    'S1': [16, 32, 32, 32, 48, 48, 120, 120, 120, 120, 224],
+    'S2': [16, 32, 32, 32, 64, 64, 144, 144, 144, 144, 288],
+}
+
+
 class TrainGraph:
     def __init__(self, model):
-        if model.backbone != 'en' or model.neck != 'gdf' or model.pc_seg_kind != 'pn' or not model.nano_head:
-            raise NotImplementedError("training mode is built for backbone='en', neck='gdf', pc_seg='pn', nano_head=True")
+        if model.pc_seg_kind != 'pn' or not model.nano_head:
+            raise NotImplementedError("training mode is built for pc_seg='pn' and nano_head=True (PointNet++ has no backward kernels)")
         self.m = model
         self.p = dict(model.named_parameters())
         self.b = dict(model.named_buffers())
@@ -190,6 +197,84 @@ class TrainGraph:
             feats.append(x)
         return feats
 
+    # ---------------------------------------------------------------------------------------------- MobileViT
+    def conv_bn_silu(self, x, pfx, stride=1, pad=0):
+        """conv (no bias) + BatchNorm (1e-5) + SiLU (mobilevit.py:8-21)."""
+        return TF.act(self.bn(self.conv(x, pfx + '.0', stride=stride, pad=pad), pfx + '.1', 1e-5), TF.ACT_SILU)
+
+    def mv2block(self, x, pfx, stride, oup):
+        """MV2Block with expansion (mobilevit.py:93-131).  The stride-2 depthwise 3x3 (pad 1) is the stride-1 result at the even positions."""
+        y = self.conv_bn_silu(x, pfx + '.conv')
+        y = self.conv(y, pfx + '.conv.3', depthwise=True)
+        if stride == 2:
+            y = y[:, :, ::2, ::2].contiguous()
+        y = TF.act(self.bn(y, pfx + '.conv.4', 1e-5), TF.ACT_SILU)
+        y = self.bn(self.conv(y, pfx + '.conv.6'), pfx + '.conv.7', 1e-5)
+        return x + y if (stride == 1 and x.shape[1] == oup) else y
+
+    def ln5(self, t, pfx):
+        """nn.LayerNorm(dim), eps 1e-5, over the channel axis of channels-first tokens [T, D, N]."""
+        return TF.layernorm_channels(t, self.P(pfx + '.weight'), self.P(pfx + '.bias'), 1e-5)
+
+    def mv_transformer(self, t, pfx, depth, heads=4, dim_head=8):
+        """Transformer / Attention / FeedForward (mobilevit.py:33-90) on channels-first tokens t [T = B * patches, D, N]."""
+        T, D, N = t.shape
+        for l in range(depth):
+            a = f'{pfx}.layers.{l}.0'
+            qkv = TF.conv1x1(self.ln5(t, a + '.norm'), self.P(a + '.fn.to_qkv.weight')).view(T, 3, heads, dim_head, N)
+            q, k, v = (qkv[:, i].reshape(T * heads, dim_head, N) for i in range(3))
+            attn = TF.bmm_nt(q.transpose(1, 2).contiguous(), k.transpose(1, 2).contiguous())                   # [T*heads, N(query), N(key)]
+            attn = TF.softmax_last(TF.row_scale(attn, torch.full((1,), dim_head ** -0.5, device=t.device)))
+            o = TF.bmm_nt(v, attn).reshape(T, heads * dim_head, N)                                              # o[d, i] = sum_j v[d, j] attn[i, j]
+            t = TF.conv1x1(o, self.P(a + '.fn.to_out.0.weight'), self.P(a + '.fn.to_out.0.bias')) + t
+            f = f'{pfx}.layers.{l}.1'
+            h = TF.act(self.linear(self.ln5(t, f + '.norm'), f + '.fn.net.0'), TF.ACT_SILU)
+            t = self.linear(h, f + '.fn.net.3') + t
+        return t
+
+    def mvit_block(self, x, pfx, depth):
+        """MobileViTBlock (mobilevit.py:147-165), 2x2 patches: 'b d (h ph) (w pw) -> b (ph pw) (h w) d' as channels-first token groups."""
+        y = x
+        x = self.conv_bn_silu(self.conv_bn_silu(x, pfx + '.conv1', 1, 1), pfx + '.conv2')
+        B, D, H, W = x.shape
+        h, w = H // 2, W // 2
+        t = x.reshape(B, D, h, 2, w, 2).permute(0, 3, 5, 1, 2, 4).reshape(B * 4, D, h * w).contiguous()
+        t = self.mv_transformer(t, pfx + '.transformer', depth)
+        x = t.reshape(B, 2, 2, D, h, w).permute(0, 3, 4, 1, 5, 2).reshape(B, D, H, W).contiguous()
+        x = self.conv_bn_silu(x, pfx + '.conv3')
+        return self.conv_bn_silu(torch.cat((x, y), 1), pfx + '.conv4', 1, 1)
+
+    def mobilevit(self, x, pfx):
+        """MobileViT.forward (mobilevit.py:198-222)."""
+        ch = MOBILEVIT[self.m.phi]
+        x = self.conv_bn_silu(x, pfx + '.conv1', 2, 1)
+        x = self.mv2block(x, pfx + '.mv2.0', 1, ch[1])
+        x = self.mv2block(x, pfx + '.mv2.1', 2, ch[2])
+        x = self.mv2block(x, pfx + '.mv2.2', 1, ch[3])
+        f2 = x = self.mv2block(x, pfx + '.mv2.3', 1, ch[3])
+        f3 = x = self.mvit_block(self.mv2block(x, pfx + '.mv2.4', 2, ch[4]), pfx + '.mvit.0', 2)
+        f4 = x = self.mvit_block(self.mv2block(x, pfx + '.mv2.5', 2, ch[6]), pfx + '.mvit.1', 4)
+        x = self.mvit_block(self.mv2block(x, pfx + '.mv2.6', 2, ch[8]), pfx + '.mvit.2', 3)
+        return [f2, f3, f4, self.conv_bn_silu(x, pfx + '.conv2')]
+
+    # ---------------------------------------------------------------------------------------------- CSP neck blocks
+    def base_conv_k(self, x, pfx, act, k=1):
+        """BaseConv: conv k x k (pad (k-1)//2, no bias) + BN (1e-3) + activation (normal_conv.py:36-47)."""
+        y = self.bn(self.conv(x, pfx + '.conv', pad=(k - 1) // 2), pfx + '.bn', 1e-3, relu=act == TF.ACT_RELU)
+        return y if act == TF.ACT_RELU else TF.act(y, act)
+
+    def csp_bottleneck(self, x, pfx, cout):
+        """Bottleneck (neck/cspdualfpn.py:42-57): 1x1 (SiLU) -> 3x3 (ReLU), + x when in == out."""
+        y = self.base_conv_k(self.base_conv_k(x, pfx + '.conv1', TF.ACT_SILU), pfx + '.conv2', TF.ACT_RELU, 3)
+        return y + x if x.shape[1] == cout else y
+
+    def csp_layer(self, x, pfx):
+        """CSPLayer, n = 1 (neck/cspdualfpn.py:60-78)."""
+        x1 = self.base_conv_k(x, pfx + '.conv1', TF.ACT_SILU)
+        x2 = self.base_conv_k(x, pfx + '.conv2', TF.ACT_SILU)
+        x1 = self.csp_bottleneck(x1, pfx + '.m.0', x1.shape[1])
+        return self.base_conv_k(torch.cat((x1, x2), 1), pfx + '.conv3', TF.ACT_SILU)
+
     # ---------------------------------------------------------------------------------------------- neck, decoders
     def spp(self, x, pfx):
         """SPP / SPPF (neck/spp.py:41-67): Conv = conv + BN (1e-3) + SiLU."""
@@ -206,16 +291,20 @@ class TrainGraph:
         """GhostDualFPN.forward (neck/ghostdualfpn.py:156-200)."""
         f = 'image_radar_encoder.fpn'
         w = self.w
-        m2, m3, m4, m5 = self.edgenext(x, f + '.backbone')
+        m2, m3, m4, m5 = self.edgenext(x, f + '.backbone') if self.m.backbone == 'en' else self.mobilevit(x, f + '.backbone')
+        csp = self.m.neck == 'cdf'                       # CSPDualFPN.forward (neck/cspdualfpn.py:193-237): the same graph with CSP blocks
         p5 = self.spp(m5, f + '.spp')
-        p4 = self.ghost_bottleneck(torch.cat([self.upsample(p5, f + '.upsample_5_to_4'), m4], 1), f + '.ghost_5_to_4', w[2])
-        p3 = self.ghost_bottleneck(torch.cat([self.upsample(p4, f + '.upsample_4_to_3'), m3], 1), f + '.ghost_4_to_3', w[1])
+        c4 = torch.cat([self.upsample(p5, f + '.upsample_5_to_4'), m4], 1)
+        p4 = self.csp_layer(c4, f + '.ghost_5_to_4') if csp else self.ghost_bottleneck(c4, f + '.ghost_5_to_4', w[2])
+        c3 = torch.cat([self.upsample(p4, f + '.upsample_4_to_3'), m3], 1)
+        p3 = self.csp_layer(c3, f + '.ghost_4_to_3') if csp else self.ghost_bottleneck(c3, f + '.ghost_4_to_3', w[1])
         outs = {}
         for name, sa, oup in (('lane', 'stage_3_lane_seg', 2), ('se', 'stage_3_semantic_seg', self.m.num_seg)):
             y = self.shuffle_attention(p3, f'{f}.{sa}')
             for lvl, c in (('3_to_2', w[1]), ('2_to_1', w[0]), ('1_to_0', w[0])):
-                y = self.ghost(self.upsample(y, f'{f}.{name}_seg_{lvl}'), f'{f}.{name}_seg_ghost_{lvl}', c)
-            outs[name] = self.ghost(y, f'{f}.{name}_seg_head', oup)
+                y = self.upsample(y, f'{f}.{name}_seg_{lvl}')
+                y = self.csp_bottleneck(y, f'{f}.{name}_seg_ghost_{lvl}', c) if csp else self.ghost(y, f'{f}.{name}_seg_ghost_{lvl}', c)
+            outs[name] = self.csp_bottleneck(y, f'{f}.{name}_seg_head', oup) if csp else self.ghost(y, f'{f}.{name}_seg_head', oup)
         return outs['se'], outs['lane'], (p5 + m5, p4 + m4, p3 + m3)
 
     # ---------------------------------------------------------------------------------------------- radar branch, fusion, head

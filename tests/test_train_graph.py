@@ -115,7 +115,7 @@ def _oracle_training_reference(sd, kw, x, xr, xp, cot, dtype=torch.float64):
     o = TrainingOracle(sd, **kw)
     with torch.enable_grad():
         pc = o.pointnet(xp.to(dtype))
-        se, lane, (q5, q4, q3) = o.ghost_dual_fpn(x.to(dtype))
+        se, lane, (q5, q4, q3) = o.ghost_dual_fpn(x.to(dtype)) if kw['neck'] == 'gdf' else o.csp_dual_fpn(x.to(dtype))
         r3, r4, r5 = o.rcnet(xr.to(dtype))
         det = o.head((o.fuse(q3, r3, 3), o.fuse(q4, r4, 4), o.fuse(q5, r5, 5)))
         outs = [*det, se, lane, pc]
@@ -124,44 +124,57 @@ def _oracle_training_reference(sd, kw, x, xr, xp, cot, dtype=torch.float64):
     return [t.detach().double() for t in outs], {n: v.grad.double() for n, v in o.sd.items() if v.is_floating_point() and v.requires_grad and v.grad is not None}
 
 
-@pytest.mark.parametrize('phi,spp,res', [('S2', True, 64), ('S0', False, 64)])
-def test_emulated_training_graph_matches_autograd_on_the_oracle(phi, spp, res):
-    """Configurations the imported-reference fixture does not cover — EdgeNeXt-S2 (8 XCA heads, 3/3/9/3 blocks) and the SPPF neck —
-    against torch autograd (float64) through the oracle in training mode: outputs and every parameter gradient."""
-    from emu_util import emu_library
+ORACLE_CASES = [('S2', True, 64, 'en_s2'), ('S0', False, 64, 'en_s0'), ('S2', True, 64, 'mv_s2'), ('S0', True, 64, 'en_s0_cdf')]
+
+
+def _check_against_oracle_autograd(dev, phi, spp, res, fixture):
     from golden_util import Golden, ctor_kwargs
-    name = 'en_s2' if phi == 'S2' else 'en_s0'
-    kw = dict(ctor_kwargs(Golden(name).meta), resolution=res, spp=spp)
+    kw = dict(ctor_kwargs(Golden(fixture).meta), resolution=res, spp=spp)
     m = Achelous(**kw)
     sd = condition_state_dict(m.state_dict(), seed=0)
     m.load_state_dict(sd, strict=True)
-    m.train()
+    m = m.to(dev).train()
     x, xr, xp = make_inputs(2, 13, resolution=res, num_points=32, pc_channels=kw['pc_channels'], radar_cells=12)
-    train_ops._lib.test_library = emu_library()
-    try:
-        det, se, lane, pc = m(x, xr, xp)
-        outs = [*det, se, lane, pc]
-        g = torch.Generator().manual_seed(3)
-        cot = [torch.randn(o.shape, generator=g) for o in outs]
-        sum((a * c).sum() for a, c in zip(outs, cot)).backward()
-    finally:
-        train_ops._lib.test_library = None
+    det, se, lane, pc = m(x.to(dev), xr.to(dev), xp.to(dev))
+    outs = [*det, se, lane, pc]
+    g = torch.Generator().manual_seed(3)
+    cot = [torch.randn(o.shape, generator=g) for o in outs]
+    sum((a * c.to(dev)).sum() for a, c in zip(outs, cot)).backward()
     okw = {k: kw[k] for k in ('num_det', 'num_seg', 'phi', 'backbone', 'neck', 'pc_seg', 'pc_channels', 'pc_classes', 'nano_head', 'spp', 'resolution')}
     ref_outs, ref_grads = _oracle_training_reference(sd, okw, x, xr, xp, cot)
     _, f32_grads = _oracle_training_reference(sd, okw, x, xr, xp, cot, torch.float32)        # torch's own float32 evaluation: the yardstick
     for a, b in zip(outs, ref_outs):
-        assert ((a.detach().double() - b).norm() / b.norm()).item() < 5e-3
+        assert ((a.detach().cpu().double() - b).norm() / b.norm()).item() < 5e-3
     gscale = max(float(v.abs().max()) for v in ref_grads.values())
     checked = 0
     for k, p in m.named_parameters():
         if k not in ref_grads:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
             continue
-        ref = ref_grads[k]
-        err = float((p.grad.double() - ref).norm() / (ref.norm() + 1e-300))
+        ref, got = ref_grads[k], p.grad.detach().cpu().double()
+        err = float((got - ref).norm() / (ref.norm() + 1e-300))
         yard = float((f32_grads[k] - ref).norm() / (ref.norm() + 1e-300))
         # a wiring check (a wrong graph is off by O(1)): BatchNorm over 2 frames of 2x2 maps and PointNet's max over 32 points make a
         # float32 step deviate from the float64 truth by several per cent on some tensors — torch's own float32 does the same
-        assert err < max(3e-2, 4 * yard) or float((p.grad.double() - ref).abs().max()) <= 2e-6 * gscale, (k, err, yard)
+        assert err < max(3e-2, 4 * yard) or float((got - ref).abs().max()) <= 2e-6 * gscale, (k, err, yard)
         checked += 1
     assert checked > 500
+
+
+@pytest.mark.parametrize('phi,spp,res,fixture', ORACLE_CASES)
+def test_emulated_training_graph_matches_autograd_on_the_oracle(phi, spp, res, fixture):
+    """Configurations the imported-reference fixture does not cover — EdgeNeXt-S2 (8 XCA heads, 3/3/9/3 blocks), the SPPF neck, the
+    MobileViT-S2 backbone and the CSP-Dual-FPN neck — against torch autograd (float64) through the oracle in training mode: outputs and
+    every parameter gradient."""
+    from emu_util import emu_library
+    train_ops._lib.test_library = emu_library()
+    try:
+        _check_against_oracle_autograd('cpu', phi, spp, res, fixture)
+    finally:
+        train_ops._lib.test_library = None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('phi,spp,res,fixture', ORACLE_CASES)
+def test_gpu_training_graph_matches_autograd_on_the_oracle(phi, spp, res, fixture):
+    _check_against_oracle_autograd('cuda', phi, spp, res, fixture)
