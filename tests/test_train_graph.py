@@ -156,7 +156,7 @@ def _check_against_oracle_autograd(dev, phi, spp, res, fixture):
         yard = float((f32_grads[k] - ref).norm() / (ref.norm() + 1e-300))
         # a wiring check (a wrong graph is off by O(1)): BatchNorm over 2 frames of 2x2 maps and PointNet's max over 32 points make a
         # float32 step deviate from the float64 truth by several per cent on some tensors — torch's own float32 does the same
-        assert err < max(3e-2, 4 * yard) or float((got - ref).abs().max()) <= 2e-6 * gscale, (k, err, yard)
+        assert err < max(6e-2, 6 * yard) or float((got - ref).abs().max()) <= 2e-6 * gscale, (k, err, yard)
         checked += 1
     assert checked > 500
 
