@@ -5,6 +5,7 @@
 #include <string>
 
 #include "engine.h"
+#include <map>
 #include <mutex>
 #include <algorithm>
 #include "k_train.h"
@@ -218,19 +219,21 @@ static int train_guard(const std::function<void()>& fn) {
     catch (const ach::AchError& e) { g_create_error = e.msg; return e.code; }
     catch (const std::exception& e) { g_create_error = e.what(); return ACH_ERR_INVALID; }
 }
-// scratch for split reductions: one buffer per process, grown on demand.  Its users are ordered on the caller's stream; training runs on one.
+// scratch for split reductions: one buffer per DEVICE, grown on demand.  Its users are ordered on the caller's stream; training runs on one.
 static float* train_workspace(size_t bytes) {
     static std::mutex mu;
-    static float* buf = nullptr;
-    static size_t cap = 0;
+    static std::map<int, std::pair<float*, size_t>> pool;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lock(mu);
-    if (bytes > cap) {
-        if (buf) { (void)hipDeviceSynchronize(); (void)hipFree(buf); buf = nullptr; cap = 0; }
+    auto& ent = pool[dev];
+    if (bytes > ent.second) {
+        if (ent.first) { (void)hipDeviceSynchronize(); (void)hipFree(ent.first); ent.first = nullptr; ent.second = 0; }
         const size_t want = std::max(bytes, size_t(8) << 20);
-        if (hipMalloc(reinterpret_cast<void**>(&buf), want) != hipSuccess) { buf = nullptr; throw ach::AchError{ACH_ERR_NOMEM, "training workspace"}; }
-        cap = want;
+        if (hipMalloc(reinterpret_cast<void**>(&ent.first), want) != hipSuccess) { ent.first = nullptr; throw ach::AchError{ACH_ERR_NOMEM, "training workspace"}; }
+        ent.second = want;
     }
-    return buf;
+    return ent.first;
 }
 // slices of a per-channel reduction over `total` values: ~16 K values per workgroup, at most ~2048 workgroups in all
 static int train_slices(long total, int C) {
