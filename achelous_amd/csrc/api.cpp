@@ -8,6 +8,8 @@
 #include <map>
 #include <mutex>
 #include <algorithm>
+#include "k_detect.h"
+#include "k_prepost.h"
 #include "k_train.h"
 #include "k_train2.h"
 
@@ -211,6 +213,21 @@ int ach_correct_boxes(ach_handle* h, int32_t batch, int32_t max_det, const float
         if (batch <= 0 || max_det <= 0 || image_h <= 0 || image_w <= 0 || !rows || !count || !out_rows) throw ach::AchError{ACH_ERR_INVALID, "bad correct_boxes arguments"};
         h->eng->correct_boxes(batch, max_det, rows, count, image_h, image_w, letterbox, out_rows, static_cast<hipStream_t>(stream));
     });
+}
+
+// ---- one pass of the 8-bit PIL resample (k_prepost.h): stateless
+int ach_resample_pass_u8(const uint8_t* src, uint8_t* dst, const int32_t* bounds, const int32_t* coeffs, int32_t ksize, int32_t h_in, int32_t w_in,
+                         int32_t h_out, int32_t w_out, int32_t channels, int32_t vertical, int64_t src_pitch, int64_t dst_pitch, void* stream) {
+    try {
+        if (!src || !dst || !bounds || !coeffs || ksize <= 0 || h_in <= 0 || w_in <= 0 || h_out <= 0 || w_out <= 0 || channels <= 0 ||
+            (vertical ? w_out != w_in : h_out != h_in))
+            throw ach::AchError{ACH_ERR_INVALID, "bad resample_pass arguments"};
+        ach::ResamplePassParams p{src, dst, bounds, coeffs, ksize, h_in, w_in, h_out, w_out, channels, vertical, long(src_pitch), long(dst_pitch)};
+        ACH_LAUNCH(ach::resample_pass_kernel, dim3(unsigned(ach::cdivl(long(h_out) * w_out * channels, 256))), dim3(256), static_cast<hipStream_t>(stream), p);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { g_create_error = std::string("kernel launch: ") + hipGetErrorString(e); return ACH_ERR_DEVICE; }
+        return ACH_OK;
+    } catch (const ach::AchError& e) { g_create_error = e.msg; return e.code; }
 }
 
 // ---- training-mode kernels (k_train.h): stateless, fp32, no handle

@@ -173,4 +173,33 @@ static __global__ __launch_bounds__(256) void correct_boxes_kernel(const BoxCorr
     o[4] = r[4]; o[5] = r[5]; o[6] = r[6];
 }
 
+// One pass of Pillow's ImagingResample for 8-bit pixels (the reference letterboxes with PIL: utils/utils.py:20-33, Image.BICUBIC): every output
+// sample is an integer dot product of up to `ksize` source samples along ONE axis with 22-bit fixed-point coefficients (computed on the
+// host in double precision exactly as Resample.c's precompute_coeffs / normalize_coeffs_8bpc do), rounded and clipped to 0..255.  A resize is a
+// horizontal pass into an 8-bit intermediate followed by a vertical pass, as in Pillow — the intermediate's rounding is part of the result.
+// Images are HWC (PIL's layout); `dst_pitch` lets the vertical pass write straight into the letterbox canvas.
+struct ResamplePassParams {
+    const uint8_t* src; uint8_t* dst; const int* bounds; const int* kk;      // bounds [n_out][2] = (first source index, count); kk [n_out][ksize]
+    int ksize, H_in, W_in, H_out, W_out, C, vertical;
+    long src_pitch, dst_pitch;                                                // bytes per row
+};
+static __global__ __launch_bounds__(256) void resample_pass_kernel(const ResamplePassParams p) {
+    const long i = long(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= long(p.H_out) * p.W_out * p.C) return;
+    const int c = int(i % p.C), x = int((i / p.C) % p.W_out), y = int(i / (long(p.C) * p.W_out));
+    const int o = p.vertical ? y : x;
+    const int first = p.bounds[2 * o], count = p.bounds[2 * o + 1];
+    const int* k = p.kk + long(o) * p.ksize;
+    int ss = 1 << 21;                                                         // 1 << (PRECISION_BITS - 1), PRECISION_BITS = 32 - 8 - 2
+    if (p.vertical) {
+        const uint8_t* s = p.src + long(first) * p.src_pitch + long(x) * p.C + c;
+        for (int t = 0; t < count; ++t) ss += int(s[long(t) * p.src_pitch]) * k[t];
+    } else {
+        const uint8_t* s = p.src + long(y) * p.src_pitch + long(first) * p.C + c;
+        for (int t = 0; t < count; ++t) ss += int(s[long(t) * p.C]) * k[t];
+    }
+    const int v = ss >> 22;                                                   // arithmetic shift, then clip8
+    p.dst[long(y) * p.dst_pitch + long(x) * p.C + c] = uint8_t(v < 0 ? 0 : (v > 255 ? 255 : v));
+}
+
 }  // namespace ach

@@ -217,6 +217,12 @@ int ach_train_dw3x3_wgrad(const float* x, const float* dz, float* dw, int32_t B,
 int ach_train_max_points(const float* x, float* y, int32_t* idx, const float* dy, float* dx, int64_t rows, int32_t N, void* stream);
 int ach_train_log_softmax(const float* z, float* y, const float* dy, float* dz, int32_t B, int32_t K, int32_t N, void* stream);
 
+/* One pass of Pillow's 8-bit ImagingResample (the reference letterboxes its input with PIL BICUBIC, utils/utils.py:20-33): integer dot products
+ * with 22-bit fixed-point coefficients computed on the host exactly as Resample.c does (achelous_amd/prepost.py).  HWC uint8 images; a resize
+ * is a horizontal pass into an 8-bit intermediate and a vertical pass (dst_pitch lets it write into the letterbox canvas).  Stateless. */
+int ach_resample_pass_u8(const uint8_t* src, uint8_t* dst, const int32_t* bounds, const int32_t* coeffs, int32_t ksize, int32_t h_in, int32_t w_in,
+                         int32_t h_out, int32_t w_out, int32_t channels, int32_t vertical, int64_t src_pitch, int64_t dst_pitch, void* stream);
+
 /* Training-mode primitives, second set (achelous_amd/csrc/k_train2.h): with the functions above, every arithmetic operation of
  * Achelous.forward in .train() — forward and backward (utils/utils_fit.py:37-166 runs them through ATen autograd).  fp32, NCHW-contiguous.
  * A function with a `dy` argument runs FORWARD when dy == NULL and BACKWARD otherwise.

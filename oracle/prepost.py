@@ -1,6 +1,8 @@
 """CPU restatement (numpy) of the reference's host-side pre / post-processing around the forward.  TEST INFRASTRUCTURE
 (see oracle/__init__.py).  Each function follows the cited reference lines; pinned against the imported reference functions by
 tests/golden/gen_prepost_golden.py -> tests/golden/prepost.npz."""
+import math
+
 import numpy as np
 
 
@@ -96,3 +98,73 @@ def correct_boxes(rows_k7, input_shape, image_shape, letterbox_image):
     boxes *= np.concatenate([image_shape, image_shape], axis=-1)
     r[:, :4] = boxes
     return r
+
+
+# ------------------------------------------------------------------------------------------------- PIL BICUBIC letterbox
+def _pil_bicubic(x):
+    """Pillow's bicubic_filter (src/libImaging/Resample.c), a = -0.5."""
+    a = -0.5
+    x = abs(x)
+    if x < 1.0:
+        return ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+    if x < 2.0:
+        return (((x - 5) * x + 8) * x - 4) * a
+    return 0.0
+
+
+def pil_bicubic_coeffs(in_size, out_size):
+    """precompute_coeffs + normalize_coeffs_8bpc of Resample.c for the whole-image box: (bounds [out, 2] = first source index, count;
+    coefficients [out, ksize] as 22-bit fixed point; ksize).  Double-precision arithmetic and C truncation, as in Pillow."""
+    scale = filterscale = in_size / out_size
+    if filterscale < 1.0:
+        filterscale = 1.0
+    support = 2.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), np.int32)
+    kk = np.zeros((out_size, ksize), np.int32)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = max(int(center - support + 0.5), 0)
+        xmax = min(int(center + support + 0.5), in_size) - xmin
+        w = [_pil_bicubic((x + xmin - center + 0.5) * ss) for x in range(xmax)]
+        ww = sum(w)
+        for x in range(xmax):
+            v = w[x] / ww if ww != 0.0 else w[x]
+            kk[xx, x] = int(v * (1 << 22) - 0.5) if v < 0 else int(v * (1 << 22) + 0.5)
+        bounds[xx] = (xmin, xmax)
+    return bounds, kk, ksize
+
+
+def _resample_axis(img, out_size, axis):
+    bounds, kk, _ = pil_bicubic_coeffs(img.shape[axis], out_size)
+    src = np.moveaxis(img.astype(np.int64), axis, 0)
+    out = np.empty((out_size,) + src.shape[1:], np.uint8)
+    for o in range(out_size):
+        first, count = bounds[o]
+        acc = (1 << 21) + np.tensordot(kk[o, :count].astype(np.int64), src[first:first + count], axes=(0, 0))
+        out[o] = np.clip(acc >> 22, 0, 255).astype(np.uint8)
+    return np.moveaxis(out, 0, axis)
+
+
+def pil_resize_bicubic(img, out_h, out_w):
+    """PIL.Image.resize((out_w, out_h), Image.BICUBIC) on an HWC uint8 array: horizontal pass (8-bit intermediate), then vertical; a pass
+    whose size does not change is skipped, as in ImagingResample."""
+    if img.shape[1] != out_w:
+        img = _resample_axis(img, out_w, 1)
+    if img.shape[0] != out_h:
+        img = _resample_axis(img, out_h, 0)
+    return img
+
+
+def resize_image(img, size, letterbox):
+    """utils/utils.py:20-33: size = (w, h); letterbox: aspect-preserving BICUBIC resize pasted centred on a (128, 128, 128) canvas."""
+    ih, iw = img.shape[:2]
+    w, h = size
+    if not letterbox:
+        return pil_resize_bicubic(img, h, w)
+    scale = min(w / iw, h / ih)
+    nw, nh = int(iw * scale), int(ih * scale)
+    out = np.full((h, w, 3), 128, np.uint8)
+    out[(h - nh) // 2:(h - nh) // 2 + nh, (w - nw) // 2:(w - nw) // 2 + nw] = pil_resize_bicubic(img, nh, nw)
+    return out

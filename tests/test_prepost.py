@@ -153,3 +153,53 @@ def test_gpu_prepost_kernels_match_oracle():
     for b in range(2):
         want_rows = O.correct_boxes(ref[b][0][:100], [320, 320], (1080, 1920), True)
         assert got[b].shape == want_rows.shape and np.array_equal(got[b], want_rows)
+
+
+LB_CASES = ['down_lb', 'up_lb', 'tall_lb', 'plain', 'same', 'tiny']
+
+
+@pytest.mark.parametrize('tag', LB_CASES)
+def test_oracle_letterbox_matches_the_reference_resize_image(tag):
+    """oracle/prepost.py::resize_image (a numpy restatement of Pillow's 8-bit BICUBIC resample + the reference's letterbox paste) against the
+    outputs of the reference's own `utils.utils.resize_image` (PIL), bit for bit."""
+    g = _golden()
+    w, h, lb = (int(v) for v in g['lbarg_' + tag])
+    assert np.array_equal(O.resize_image(g['lbin_' + tag], (w, h), bool(lb)), g['lbout_' + tag])
+
+
+def _device_letterbox(dev, tag):
+    from achelous_amd import prepost
+    g = _golden()
+    w, h, lb = (int(v) for v in g['lbarg_' + tag])
+    out = prepost.resize_image(torch.from_numpy(g['lbin_' + tag]).to(dev), (w, h), bool(lb))
+    assert out.dtype == torch.uint8 and tuple(out.shape) == (h, w, 3)
+    assert np.array_equal(out.cpu().numpy(), g['lbout_' + tag]), tag
+
+
+@pytest.mark.parametrize('tag', LB_CASES)
+def test_emulated_letterbox_is_bit_exact_against_pil(tag):
+    from achelous_amd import prepost
+    from emu_util import emu_library
+    prepost._pass_lib.test_library = emu_library()
+    try:
+        _device_letterbox('cpu', tag)
+    finally:
+        prepost._pass_lib.test_library = None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tag', LB_CASES)
+def test_gpu_letterbox_is_bit_exact_against_pil(tag):
+    """achelous_amd.prepost.resize_image on the MI355X against the reference's resize_image (PIL BICUBIC letterbox) — every byte."""
+    _device_letterbox('cuda', tag)
+
+
+@pytest.mark.gpu
+def test_gpu_letterbox_full_hd_frame():
+    """A 1080 x 1920 frame to 320 x 320 (the deployment shape): 6x antialiased down-scale, 25-tap kernels; against the oracle (itself pinned to PIL
+    above), every byte."""
+    from achelous_amd import prepost
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (1080, 1920, 3), dtype=np.uint8)
+    out = prepost.resize_image(torch.from_numpy(img).cuda(), (320, 320), True)
+    assert np.array_equal(out.cpu().numpy(), O.resize_image(img, (320, 320), True))
