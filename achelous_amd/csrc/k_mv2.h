@@ -42,7 +42,7 @@ template <> struct Mv2Tile<2, 4> { static constexpr int TW = 8, TH = 2; };      
 
 // HID: hidden width (64 | 128); NT2 = Cout / 16 (1 | 2 | 4).  Static LDS: region pixels x (HID elements + 16 B of padding).
 template <class T, int STRIDE, int HID, int NT2>
-__global__ __launch_bounds__(256, STRIDE == 2 ? 3 : 1) void mv2_kernel(const Mv2Params p) {
+__global__ __launch_bounds__(256, STRIDE == 2 ? 3 : 4) void mv2_kernel(const Mv2Params p) {
     constexpr int VEC = Store<T>::VEC, KC = 4 * VEC;
     constexpr int TW = Mv2Tile<STRIDE, int(sizeof(T))>::TW, TH = Mv2Tile<STRIDE, int(sizeof(T))>::TH;
     constexpr int RW = TW * STRIDE + (STRIDE == 1 ? 2 : 1), RH = TH * STRIDE + (STRIDE == 1 ? 2 : 1), RP = RW * RH;
@@ -111,39 +111,46 @@ __global__ __launch_bounds__(256, STRIDE == 2 ? 3 : 1) void mv2_kernel(const Mv2
         rbase[q] = ((oy * STRIDE) * RW + ox * STRIDE) * PITCH;
     }
     const uint4* W2 = static_cast<const uint4*>(p.W2) + lane;
-    ACH_NO_UNROLL                                                  // one k-step's 9 x VEC depthwise weights live at a time (register budget)
+    ACH_NO_UNROLL
     for (int si = 0; si < KPER; ++si) {
         const int s = kpart * KPER + si;
         const int ch = s * KC + g * VEC;
-        float wd[9][VEC], bd[VEC];
-        ACH_UNROLL
-        for (int k = 0; k < 9; ++k)
-            ACH_UNROLL
-            for (int j = 0; j < VEC; j += 4) {
-                const float4 w = *reinterpret_cast<const float4*>(p.Wdw + k * HID + ch + j);
-                wd[k][j] = w.x; wd[k][j + 1] = w.y; wd[k][j + 2] = w.z; wd[k][j + 3] = w.w;
-            }
+        float bd[VEC];
         ACH_UNROLL
         for (int j = 0; j < VEC; j += 4) { const float4 w = *reinterpret_cast<const float4*>(p.bdw + ch + j); bd[j] = w.x; bd[j + 1] = w.y; bd[j + 2] = w.z; bd[j + 3] = w.w; }
         uint4 wf[NT2];
         ACH_UNROLL
         for (int t = 0; t < NT2; ++t) wf[t] = W2[(t * KS2 + s) * 64];
+        // taps are the OUTER loop inside a k-step: one tap's VEC weights are live at a time (8 registers instead of 72 for the whole 3x3 —
+        // what kept the stride-1 instantiations at ~200 VGPRs, two waves per SIMD) and serve every pixel tile of the wave
+        float a[PPW][VEC];
         ACH_UNROLL
-        for (int q = 0; q < PPW; ++q) {
-            if (tile0 + 4 * q >= PT) continue;
-            float a[VEC];
+        for (int q = 0; q < PPW; ++q)
             ACH_UNROLL
-            for (int j = 0; j < VEC; ++j) a[j] = bd[j];
+            for (int j = 0; j < VEC; ++j) a[q][j] = bd[j];
+        ACH_UNROLL
+        for (int k = 0; k < 9; ++k) {
+            float wd[VEC];
             ACH_UNROLL
-            for (int k = 0; k < 9; ++k) {
+            for (int j = 0; j < VEC; j += 4) {
+                const float4 w = *reinterpret_cast<const float4*>(p.Wdw + k * HID + ch + j);
+                wd[j] = w.x; wd[j + 1] = w.y; wd[j + 2] = w.z; wd[j + 3] = w.w;
+            }
+            ACH_UNROLL
+            for (int q = 0; q < PPW; ++q) {
+                if (tile0 + 4 * q >= PT) continue;
                 float v[8];
                 frag_unpack<T>(*reinterpret_cast<const uint4*>(hs + rbase[q] + ((k / 3) * RW + (k % 3)) * PITCH + ch * int(sizeof(T))), v);
                 ACH_UNROLL
-                for (int j = 0; j < VEC; ++j) a[j] += v[j] * wd[k][j];
+                for (int j = 0; j < VEC; ++j) a[q][j] += v[j] * wd[j];
             }
+        }
+        ACH_UNROLL
+        for (int q = 0; q < PPW; ++q) {
+            if (tile0 + 4 * q >= PT) continue;
             float h[8];
             ACH_UNROLL
-            for (int j = 0; j < VEC; ++j) h[j] = a[j] * sigmoidf_(a[j]);
+            for (int j = 0; j < VEC; ++j) h[j] = a[q][j] * sigmoidf_(a[q][j]);
             const uint4 bf = frag_pack<T>(h);
             ACH_UNROLL
             for (int t = 0; t < NT2; ++t) mfma16<T>(wf[t], bf, acc[q][t]);
