@@ -193,8 +193,11 @@ __device__ __forceinline__ void mlp_inputs(const MlpParams& p, long m, bool vali
 // tile — what matters there is that a wave can have a whole hidden chunk's weight fragments (2 k1 + DT loads) in flight at once.
 // With the non-SPLIT budgets the compiler had 4 fragment registers to cycle through and every second MFMA waited for a fresh L2
 // round trip (measured: 7 us per hidden chunk on the 10x10 maps).
+#ifndef ACH_MLP_OCC_SMALL
+#define ACH_MLP_OCC_SMALL 6
+#endif
 template <int DT, bool SPLIT> struct MlpOcc {
-    static constexpr int blocks = (SPLIT && DT > 6) ? 2 : (DT <= 6 ? 6 : (DT <= 10 ? 4 : (DT <= 12 ? 3 : 2)));
+    static constexpr int blocks = (SPLIT && DT > 6) ? 2 : (DT <= 6 ? ACH_MLP_OCC_SMALL : (DT <= 10 ? 4 : (DT <= 12 ? 3 : 2)));
 };
 
 template <class T, int DT, bool SPLIT, bool EVEN = false>
