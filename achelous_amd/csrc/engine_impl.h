@@ -1520,9 +1520,11 @@ public:
         A r[3];
         // "head_stream": PointNet queues behind the radar branch on the low-priority stream; the (four times longer) PointNet++
         // branch opens stream 2 instead, ahead of fusion + head, which only start once the neck is done (measured +4.8 %; PointNet: neutral)
-        const bool point2 = point_on_head_stream < 0 ? cfg.pc_seg == ACH_PCSEG_PN2 : point_on_head_stream != 0;
+        // (auto: stream 2 for PointNet++, and in the pipelined plan, where it shares the stream with the decoders: 27.7 k against 26.4 k
+        //  frames/s; the plain plan keeps PointNet on stream 1 ahead of the radar branch — two streams in all: 26.35 k against 25.95 k)
+        const bool point2 = point_on_head_stream < 0 ? (cfg.pc_seg == ACH_PCSEG_PN2 || (!head_stream && pipeline)) : point_on_head_stream != 0;
         const bool radar_late = radar_start >= 0 && multi_stream;
-        auto points = [&] { cur_stream = (head_stream && !point2) ? 1 : 2; if (cfg.pc_seg == ACH_PCSEG_PN2) pointnet2(); else pointnet(); };
+        auto points = [&] { cur_stream = point2 ? 2 : 1; if (cfg.pc_seg == ACH_PCSEG_PN2) pointnet2(); else pointnet(); };
         if (radar_late) points();         // the point branch (small launches) fills the window before the radar branch is released
         cur_stream = 1;
         if (radar_late) wait_before_next(0);
