@@ -178,3 +178,37 @@ def test_emulated_training_graph_matches_autograd_on_the_oracle(phi, spp, res, f
 @pytest.mark.parametrize('phi,spp,res,fixture', ORACLE_CASES)
 def test_gpu_training_graph_matches_autograd_on_the_oracle(phi, spp, res, fixture):
     _check_against_oracle_autograd('cuda', phi, spp, res, fixture)
+
+
+@pytest.mark.gpu
+def test_gpu_train_then_eval_uses_the_updated_weights_and_statistics():
+    """utils/utils_fit.py alternates training steps and evaluation: after `.train()` steps (parameters changed by the optimizer, BatchNorm
+    running statistics by the forward) `.eval()` must run the inference engine on the NEW weights — equal to a fresh module loaded from the
+    trained state dict."""
+    from golden_util import Golden, ctor_kwargs
+    g = Golden('en_s0')
+    kw = dict(ctor_kwargs(g.meta), resolution=96)
+    m = Achelous(**kw)
+    m.load_state_dict(condition_state_dict(m.state_dict(), seed=0))
+    m = m.cuda()
+    x, xr, xp = (t.cuda() for t in make_inputs(2, 41, resolution=96, num_points=32, pc_channels=kw['pc_channels'], radar_cells=10))
+    m.eval()
+    with torch.no_grad():
+        before = [t.clone() for t in (*m(x, xr, xp)[0], m(x, xr, xp)[1])]
+    opt = torch.optim.SGD(m.parameters(), lr=1e-3)
+    m.train()
+    for _ in range(2):
+        det, se, lane, pc = m(x, xr, xp)
+        loss = sum((o ** 2).mean() for o in (*det, se, lane, pc))
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    m.eval()
+    with torch.no_grad():
+        after = m(x, xr, xp)
+        fresh = Achelous(**kw)
+        fresh.load_state_dict(m.state_dict())
+        ref = fresh.cuda().eval()(x, xr, xp)
+    assert any(not torch.equal(a, b) for a, b in zip((*after[0], after[1]), before))            # the step changed something
+    for a, b in zip((*after[0], after[1], after[2], after[3]), (*ref[0], ref[1], ref[2], ref[3])):
+        assert torch.equal(a, b)
