@@ -274,7 +274,7 @@ int ach_train_gemm(const float* A, const float* B, float* C, const float* bias, 
             }
         }
         ACH_LAUNCH(ach::train_gemm_kernel, grid, dim3(256), static_cast<hipStream_t>(stream), p);
-        if (p.ksplit > 1) ACH_LAUNCH(ach::train_gemm_reduce_kernel, dim3(unsigned(ach::cdivl(long(M) * N, 256))), dim3(256), static_cast<hipStream_t>(stream), p);
+        if (p.ksplit > 1) ACH_LAUNCH(ach::train_gemm_reduce_kernel, dim3(unsigned(ach::cdivl(long(M) * N, 16))), dim3(256), static_cast<hipStream_t>(stream), p);
     });
 }
 int ach_train_bn_stats(const float* z, float* mean, float* var, int32_t B, int32_t C, int32_t N, void* stream) {
@@ -397,8 +397,11 @@ int ach_train_dwconv(const float* x, const float* w, const float* bias, float* y
 int ach_train_dwconv_wgrad(const float* x, const float* dz, float* dw, int32_t B, int32_t C, int32_t H, int32_t W, int32_t k, void* stream) {
     return train_guard([&] {
         train_need(x && dz && dw && B > 0 && C > 0 && H > 0 && W > 0 && k > 0 && (k & 1), "ach_train_dwconv_wgrad");
-        ach::TrainDwWgradParams p{x, dz, dw, B, C, H, W, k};
-        ACH_TRAIN_ROWS(ach::train_dwconv_wgrad_kernel, p, long(C) * k * k);
+        ach::TrainDwWgradParams p{x, dz, dw, B, C, H, W, k, 1, nullptr};
+        p.S = train_slices(long(B) * H * W, C * k * k);
+        if (p.S > 1) p.ws = train_workspace(size_t(C) * k * k * p.S * sizeof(float));
+        ACH_LAUNCH(ach::train_dwconv_wgrad_kernel, dim3(unsigned(C * k * k), unsigned(p.S)), dim3(256), static_cast<hipStream_t>(stream), p);
+        if (p.S > 1) ACH_LAUNCH(ach::train_dwconv_wgrad_finalize_kernel, dim3(unsigned((C * k * k + 255) / 256)), dim3(256), static_cast<hipStream_t>(stream), p);
     });
 }
 int ach_train_im2col(const float* src, float* dst, int32_t B, int32_t C, int32_t H, int32_t W, int32_t kh, int32_t kw, int32_t sh, int32_t sw, int32_t ph, int32_t pw,

@@ -125,14 +125,18 @@ static __global__ __launch_bounds__(256) void train_dwconv_kernel(const TrainDwP
     }
     p.y[i] = acc;
 }
-struct TrainDwWgradParams { const float* x; const float* dz; float* dw; int B, C, H, W, k; };
-static __global__ __launch_bounds__(256) void train_dwconv_wgrad_kernel(const TrainDwWgradParams p) {      // one workgroup per (channel, tap)
+// one workgroup per (channel, tap) and SLICE of the (B, H, W) range: a 16-channel 3x3 layer at 320 x 320 is 144 (channel, tap) pairs of
+// 819 200 terms each at batch 8 — 144 workgroups walking 3 200 iterations on a 256-CU chip took 2 ms; S > 1: partials into ws [C*k*k][S],
+// summed in slice order by train_dwconv_wgrad_finalize_kernel
+struct TrainDwWgradParams { const float* x; const float* dz; float* dw; int B, C, H, W, k; int S; float* ws; };
+static __global__ __launch_bounds__(256) void train_dwconv_wgrad_kernel(const TrainDwWgradParams p) {
     __shared__ float sh[256];
     const int c = blockIdx.x / (p.k * p.k), t = blockIdx.x % (p.k * p.k);
     const int ky = t / p.k - p.k / 2, kx = t % p.k - p.k / 2;
-    const long hw = long(p.H) * p.W;
+    const long hw = long(p.H) * p.W, total = long(p.B) * hw;
+    const long per = p.S > 1 ? (total + p.S - 1) / p.S : total, lo = p.S > 1 ? long(blockIdx.y) * per : 0, hi = lo + per < total ? lo + per : total;
     float a = 0.f;
-    for (long e = threadIdx.x; e < long(p.B) * hw; e += 256) {
+    for (long e = lo + threadIdx.x; e < hi; e += 256) {
         const long b = e / hw, pix = e - b * hw;
         const int oy = int(pix / p.W), ox = int(pix - long(oy) * p.W);
         const int iy = oy + ky, ix = ox + kx;
@@ -141,7 +145,14 @@ static __global__ __launch_bounds__(256) void train_dwconv_wgrad_kernel(const Tr
         a += p.dz[base + pix] * p.x[base + long(iy) * p.W + ix];
     }
     a = block_sum_256(a, sh);
-    if (threadIdx.x == 0) p.dw[blockIdx.x] = a;
+    if (threadIdx.x == 0) { if (p.S > 1) p.ws[long(blockIdx.x) * p.S + blockIdx.y] = a; else p.dw[blockIdx.x] = a; }
+}
+static __global__ __launch_bounds__(256) void train_dwconv_wgrad_finalize_kernel(const TrainDwWgradParams p) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= p.C * p.k * p.k) return;
+    float a = 0.f;
+    for (int j = 0; j < p.S; ++j) a += p.ws[long(i) * p.S + j];
+    p.dw[i] = a;
 }
 
 // ------------------------------------------------------------------------------------------ im2col / col2im (dense convolutions through train_gemm)

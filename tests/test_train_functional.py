@@ -95,6 +95,8 @@ def _cases(dev):
     for k in (3, 5, 7, 9):
         yield f'dwconv k{k}', (lambda k=k: _check(TF.dwconv, lambda x, w, b: F.conv2d(x, w, b, 1, k // 2, groups=x.shape[1]),
                                                    [(_r(2, 6, 10, 9), True), (_r(6, 1, k, k, seed=1, scale=0.3), True), (_r(6, seed=2), True)], dev))
+    yield 'dwconv k3 sliced', lambda: _check(TF.dwconv, lambda x, w, b: F.conv2d(x, w, b, 1, 1, groups=x.shape[1]),                  # weight gradient in 2 slices
+                                            [(_r(2, 4, 100, 100), True), (_r(4, 1, 3, 3, seed=1, scale=0.3), True), (_r(4, seed=2), True)], dev)
     yield 'bmm_nt', lambda: _check(TF.bmm_nt, lambda a, b: a @ b.transpose(1, 2), [(_r(5, 12, 70), True), (_r(5, 9, 70, seed=1), True)], dev)
     yield 'bmm_nn', lambda: _check(TF.bmm_nn, lambda a, b: a @ b, [(_r(5, 12, 9), True), (_r(5, 9, 70, seed=1), True)], dev)
     yield 'upsample2x', lambda: _check(TF.upsample2x, lambda x: F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=True), [(_r(2, 3, 5, 7), True)], dev)
