@@ -111,7 +111,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=8, help='frames in the CPU-baseline sample')
     ap.add_argument('--separate-calls', action='store_true', help='forward, decode_outputs and NMS as three calls instead of forward_detect')
-    ap.add_argument('--pipeline', action='store_true', help='(the default since the two-stream plan) submit / wait serving loop: batch k+1 is enqueued before batch k is joined (engine option "pipeline", Achelous.submit_detect): +7 %% on the headline, DESIGN 4.11')
+    ap.add_argument('--pipeline', action='store_true', help='(the default) submit / wait serving loop: batch k+1 is enqueued before batch k is joined (engine option "pipeline", Achelous.submit_detect): +7 %% on the headline, DESIGN 4.11')
     ap.add_argument('--plain', action='store_true', help='one plain forward_detect per step, every step joined before the next is enqueued (what the reference-shaped calls get)')
     ap.add_argument('--extra-stream', action='store_true', help='diagnostic: also launch a tiny copy on a separate stream every step (stands in for a collective stream)')
     ap.add_argument('--dense-radar', action='store_true', help='stress variant: U(0,1) in every cell of the radar map instead of 256 occupied cells per frame (SURVEY 8d); nothing is skipped in the first RCBlock')
