@@ -149,66 +149,88 @@ __global__ __launch_bounds__(256) void mvit_attn_mfma_kernel(const MvitAttnParam
         if (VEC == 8) return g == 0 ? *reinterpret_cast<const uint4*>(ks + (t * 16 + col) * MVIT_DH) : zero;
         return g < 2 ? *reinterpret_cast<const uint4*>(ks + (t * 16 + col) * MVIT_DH + 4 * g) : zero;
     };
-    for (int qt = blockIdx.y * 16 + wave; qt < ntiles && qt < int(blockIdx.y + 1) * 16; qt += 4) {
-        const int n = qt * 16 + col, nq = n < N ? n : N - 1;
-        uint4 qf = zero;                                                              // B operand: k = d, column = query
-        {
+    // TWO query tiles per wave and pass (QT): every score MFMA feeds its exponentials at once, so a single tile is one dependent chain
+    // (MFMA -> exp2 -> pack -> MFMA into the running output); a second, independent tile fills its bubbles (119 -> see DESIGN, 40x40 maps)
+    constexpr int QT = 2;
+    const int full_tiles = N / 16, full_chunks = N / CH;
+    const int q_lo = blockIdx.y * 16, q_hi = (q_lo + 16 < ntiles) ? q_lo + 16 : ntiles;          // this workgroup's query tiles
+    for (int q0 = q_lo + wave * QT; q0 < q_hi; q0 += 4 * QT) {
+        int n[QT];
+        bool live[QT];
+        uint4 qf[QT];
+        ACH_UNROLL
+        for (int u = 0; u < QT; ++u) {
+            live[u] = q0 + u < q_hi;
+            n[u] = (live[u] ? q0 + u : q0) * 16 + col;
+            const int nq = n[u] < N ? n[u] : N - 1;
+            qf[u] = zero;                                                             // B operand: k = d, column = query
             const T* src = base + pixel(nq) * p.ld + head * MVIT_DH;
             float q8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if (VEC == 8) { if (g == 0) { float a[4], c[4]; Store<T>::ld4(src, a); Store<T>::ld4(src + 4, c); for (int i = 0; i < 4; ++i) { q8[i] = a[i] * sc; q8[4 + i] = c[i] * sc; } qf = frag_pack<T>(q8); } }
-            else if (g < 2) { float a[4]; Store<T>::ld4(src + 4 * g, a); for (int i = 0; i < 4; ++i) q8[i] = a[i] * sc; qf = frag_pack<T>(q8); }
+            if (VEC == 8) { if (g == 0) { float a[4], c[4]; Store<T>::ld4(src, a); Store<T>::ld4(src + 4, c); for (int i = 0; i < 4; ++i) { q8[i] = a[i] * sc; q8[4 + i] = c[i] * sc; } qf[u] = frag_pack<T>(q8); } }
+            else if (g < 2) { float a[4]; Store<T>::ld4(src + 4 * g, a); for (int i = 0; i < 4; ++i) q8[i] = a[i] * sc; qf[u] = frag_pack<T>(q8); }
         }
-        // pass 1: the query's maximum score (full key tiles need no mask; a last partial tile is masked)
-        const int full_tiles = N / 16;
-        float m = -3.0e38f;
+        // pass 1: the queries' maximum scores (full key tiles need no mask; a last partial tile is masked)
+        float m[QT];
+        ACH_UNROLL
+        for (int u = 0; u < QT; ++u) m[u] = -3.0e38f;
         for (int t = 0; t < full_tiles; ++t) {
-            f32x4 s4; s4[0] = s4[1] = s4[2] = s4[3] = 0.f;
-            mfma16<T>(kfrag(t), qf, s4);
-            m = fmaxf(fmaxf(m, fmaxf(s4[0], s4[1])), fmaxf(s4[2], s4[3]));
+            const uint4 kf = kfrag(t);
+            ACH_UNROLL
+            for (int u = 0; u < QT; ++u) {
+                f32x4 s4; s4[0] = s4[1] = s4[2] = s4[3] = 0.f;
+                mfma16<T>(kf, qf[u], s4);
+                m[u] = fmaxf(fmaxf(m[u], fmaxf(s4[0], s4[1])), fmaxf(s4[2], s4[3]));
+            }
         }
         if (full_tiles < ntiles) {
-            f32x4 s4; s4[0] = s4[1] = s4[2] = s4[3] = 0.f;
-            mfma16<T>(kfrag(full_tiles), qf, s4);
+            const uint4 kf = kfrag(full_tiles);
             ACH_UNROLL
-            for (int r = 0; r < 4; ++r) if (full_tiles * 16 + g * 4 + r < N) m = fmaxf(m, s4[r]);
+            for (int u = 0; u < QT; ++u) {
+                f32x4 s4; s4[0] = s4[1] = s4[2] = s4[3] = 0.f;
+                mfma16<T>(kf, qf[u], s4);
+                ACH_UNROLL
+                for (int r = 0; r < 4; ++r) if (full_tiles * 16 + g * 4 + r < N) m[u] = fmaxf(m[u], s4[r]);
+            }
         }
-        m = fmaxf(m, __shfl_xor(m, 16));
-        m = fmaxf(m, __shfl_xor(m, 32));
+        ACH_UNROLL
+        for (int u = 0; u < QT; ++u) { m[u] = fmaxf(m[u], __shfl_xor(m[u], 16)); m[u] = fmaxf(m[u], __shfl_xor(m[u], 32)); }
         // pass 2: P^T = exp2(S^T - m) chunk by chunk, O^T += V^T P^T
-        float l = 0.f;
-        f32x4 o4; o4[0] = o4[1] = o4[2] = o4[3] = 0.f;
-        const int full_chunks = N / CH;
-        for (int c = 0; c < full_chunks; ++c) {
-            float pj[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float l[QT];
+        f32x4 o4[QT];
+        ACH_UNROLL
+        for (int u = 0; u < QT; ++u) { l[u] = 0.f; o4[u][0] = o4[u][1] = o4[u][2] = o4[u][3] = 0.f; }
+        for (int c = 0; c < nchunks; ++c) {
+            const bool partial = c >= full_chunks;                                    // the last chunk may hold keys past N
+            uint4 kf[VEC / 4];
             ACH_UNROLL
-            for (int u = 0; u < VEC / 4; ++u) {
-                f32x4 s4; s4[0] = s4[1] = s4[2] = s4[3] = 0.f;
-                mfma16<T>(kfrag(c * (VEC / 4) + u), qf, s4);
-                ACH_UNROLL
-                for (int r = 0; r < 4; ++r) { const float e = fast_exp2(s4[r] - m); pj[4 * u + r] = e; l += e; }
-            }
+            for (int w = 0; w < VEC / 4; ++w) { const int t = c * (VEC / 4) + w; kf[w] = t < ntiles ? kfrag(t) : zero; }
             const uint4 vf = col < MVIT_DH ? *reinterpret_cast<const uint4*>(vt + ((c * MVIT_DH + col) * 4 + g) * VEC) : zero;      // A: row = d, k = slot
-            mfma16<T>(vf, frag_pack<T>(pj), o4);
-        }
-        for (int c = full_chunks; c < nchunks; ++c) {                                  // the last, partial chunk
-            float pj[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             ACH_UNROLL
-            for (int u = 0; u < VEC / 4; ++u) {
-                const int t = c * (VEC / 4) + u;
-                f32x4 s4; s4[0] = s4[1] = s4[2] = s4[3] = 0.f;
-                if (t < ntiles) mfma16<T>(kfrag(t), qf, s4);
+            for (int u = 0; u < QT; ++u) {
+                float pj[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 ACH_UNROLL
-                for (int r = 0; r < 4; ++r) { const float e = (t * 16 + g * 4 + r < N) ? fast_exp2(s4[r] - m) : 0.f; pj[4 * u + r] = e; l += e; }
+                for (int w = 0; w < VEC / 4; ++w) {
+                    const int t = c * (VEC / 4) + w;
+                    f32x4 s4; s4[0] = s4[1] = s4[2] = s4[3] = 0.f;
+                    mfma16<T>(kf[w], qf[u], s4);
+                    ACH_UNROLL
+                    for (int r = 0; r < 4; ++r) {
+                        const float e = (!partial || t * 16 + g * 4 + r < N) ? fast_exp2(s4[r] - m[u]) : 0.f;
+                        pj[4 * w + r] = e; l[u] += e;
+                    }
+                }
+                mfma16<T>(vf, frag_pack<T>(pj), o4[u]);
             }
-            const uint4 vf = col < MVIT_DH ? *reinterpret_cast<const uint4*>(vt + ((c * MVIT_DH + col) * 4 + g) * VEC) : zero;
-            mfma16<T>(vf, frag_pack<T>(pj), o4);
         }
-        l += __shfl_xor(l, 16);
-        l += __shfl_xor(l, 32);
-        if (n < N && g < 2) {                                                          // rows (d) 4g .. 4g+3 of this query's column
-            const float inv = 1.0f / l;
-            const float o[4] = {o4[0] * inv, o4[1] * inv, o4[2] * inv, o4[3] * inv};
-            Store<T>::st4(static_cast<T*>(p.Y) + (b * p.H * long(p.Wd) + pixel(n)) * p.ldy + head * MVIT_DH + 4 * g, o);
+        ACH_UNROLL
+        for (int u = 0; u < QT; ++u) {
+            l[u] += __shfl_xor(l[u], 16);
+            l[u] += __shfl_xor(l[u], 32);
+            if (live[u] && n[u] < N && g < 2) {                                       // rows (d) 4g .. 4g+3 of this query's column
+                const float inv = 1.0f / l[u];
+                const float o[4] = {o4[u][0] * inv, o4[u][1] * inv, o4[u][2] * inv, o4[u][3] * inv};
+                Store<T>::st4(static_cast<T*>(p.Y) + (b * p.H * long(p.Wd) + pixel(n[u])) * p.ldy + head * MVIT_DH + 4 * g, o);
+            }
         }
     }
 }
