@@ -196,8 +196,14 @@ __device__ __forceinline__ void mlp_inputs(const MlpParams& p, long m, bool vali
 #ifndef ACH_MLP_OCC_SMALL
 #define ACH_MLP_OCC_SMALL 6
 #endif
+#ifndef ACH_MLP_OCC_10
+#define ACH_MLP_OCC_10 4
+#endif
+#ifndef ACH_MLP_OCC_12
+#define ACH_MLP_OCC_12 3
+#endif
 template <int DT, bool SPLIT> struct MlpOcc {
-    static constexpr int blocks = (SPLIT && DT > 6) ? 2 : (DT <= 6 ? ACH_MLP_OCC_SMALL : (DT <= 10 ? 4 : (DT <= 12 ? 3 : 2)));
+    static constexpr int blocks = (SPLIT && DT > 6) ? 2 : (DT <= 6 ? ACH_MLP_OCC_SMALL : (DT <= 10 ? ACH_MLP_OCC_10 : (DT <= 12 ? ACH_MLP_OCC_12 : 2)));
 };
 
 template <class T, int DT, bool SPLIT, bool EVEN = false>
