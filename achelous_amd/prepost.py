@@ -169,3 +169,26 @@ def resize_image(image_u8, size, letterbox_image=True):
     y0, x0 = (h - nh) // 2, (w - nw) // 2
     _resample(lib, img, nh, nw, dst=canvas[y0:y0 + nh, x0:x0 + nw])
     return canvas
+
+
+# ------------------------------------------------------------------------------------------------- camera bytes -> results, on the device
+def detect_frame(net, image_u8, radar_map, points, conf_thres=0.5, nms_thres=0.4, letterbox_image=True, max_det=100, dtype=torch.bfloat16):
+    """The arithmetic of the reference's `detect_image` (achelous.py:190-330) for one frame without its file I/O and plotting, every stage a
+    device kernel: letterbox resize (PIL BICUBIC, bit-exact) -> mean / std + HWC -> CHW, radar min-max, point normalisation -> forward +
+    decode + NMS (`forward_detect`) -> boxes back to the original image's pixels, both class maps at the original size (softmax -> crop ->
+    INTER_LINEAR -> argmax), the per-point class.
+
+    image_u8 [H, W, 3] uint8, radar_map [3, R, R] float, points [N, pc_channels] float (rows = points), all on the GPU.
+    Returns dict(boxes [K, 7] = (y1, x1, y2, x2 in image pixels, obj, class conf, class id), semantic [H, W] uint8, waterline [H, W] uint8,
+    point_class [N] int64)."""
+    from .postprocess import correct_boxes_device
+    R = net.resolution
+    H, W = int(image_u8.shape[0]), int(image_u8.shape[1])
+    dt = dtype
+    x = preprocess_input(resize_image(image_u8, (R, R), letterbox_image).unsqueeze(0), dt)
+    xr = preprocess_input_radar(radar_map.unsqueeze(0), dt)
+    xp = normalize_points(points.unsqueeze(0), dt)
+    (det, se, lane, pc), (rows, idx, cnt) = net.forward_detect(x, xr, xp, conf_thres, nms_thres, max_det)
+    boxes = correct_boxes_device(rows, cnt, (R, R), (H, W), letterbox_image)
+    sem, wl = seg_class_map_original(se, (H, W)), seg_class_map_original(lane, (H, W))
+    return {'boxes': boxes[0, :int(cnt[0])], 'semantic': sem[0], 'waterline': wl[0], 'point_class': pc[0].float().argmax(-1)}

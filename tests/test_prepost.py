@@ -203,3 +203,42 @@ def test_gpu_letterbox_full_hd_frame():
     img = rng.integers(0, 256, (1080, 1920, 3), dtype=np.uint8)
     out = prepost.resize_image(torch.from_numpy(img).cuda(), (320, 320), True)
     assert np.array_equal(out.cpu().numpy(), O.resize_image(img, (320, 320), True))
+
+
+@pytest.mark.gpu
+def test_gpu_detect_frame_matches_the_oracle_chain():
+    """prepost.detect_frame — camera bytes to boxes / class maps without leaving the device — against the same chain on the CPU: the oracle's
+    letterbox (pinned to PIL above), pre-processing, forward, decode + NMS, un-letterboxing and original-size class maps (fp32 engine)."""
+    from achelous_amd import Achelous, prepost
+    from achelous_amd.synth import condition_state_dict, make_inputs
+    from golden_util import Golden, ctor_kwargs
+    from oracle.achelous_oracle import AchelousOracle, decode_outputs as o_decode, non_max_suppression as o_nms
+    g = Golden('en_s0')
+    kw = ctor_kwargs(g.meta)
+    m = Achelous(**kw).eval()
+    sd = g.calibrate(condition_state_dict(m.state_dict(), seed=g.meta['weight_seed']))
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda()
+    rng = np.random.default_rng(9)
+    H, W = 270, 480
+    yy, xx = np.mgrid[0:H, 0:W]
+    img = np.clip(127 + 100 * np.sin(xx / 23.0)[..., None] * np.cos(yy[..., None] / 17.0 + np.arange(3)) + rng.normal(0, 25, (H, W, 3)), 0, 255).astype(np.uint8)
+    _, xr, xp = make_inputs(1, 77, resolution=320, pc_channels=kw['pc_channels'])
+    radar = (xr[0] * 30.0 - 3.0).float()                       # un-normalised map: the min-max step has something to do
+    pts = torch.randn(512, kw['pc_channels'], generator=torch.Generator().manual_seed(4)) * 3.0
+    out = prepost.detect_frame(m, torch.from_numpy(img).cuda(), radar.cuda(), pts.cuda(), 0.35, 0.35, True, 100, dtype=torch.float32)
+    # the oracle chain
+    lb = O.resize_image(img, (320, 320), True)
+    x = torch.from_numpy(O.preprocess_input(lb)).unsqueeze(0)
+    r = torch.from_numpy(O.preprocess_input_radar(radar.numpy())).unsqueeze(0)
+    p = torch.from_numpy(O.normalize_points(pts.numpy().astype(np.float64))).unsqueeze(0)
+    okw = {k: kw[k] for k in ('num_det', 'num_seg', 'phi', 'backbone', 'neck', 'pc_seg', 'pc_channels', 'pc_classes', 'nano_head', 'spp', 'resolution')}
+    det, se, lane, pc = AchelousOracle({k: v.cpu() for k, v in sd.items()}, **okw).forward(x, r, p)
+    rows, _ = o_nms(o_decode(det, [320, 320]), kw['num_det'], 0.35, 0.35)[0]
+    want = O.correct_boxes(rows[:100], [320, 320], (H, W), True)
+    got = out['boxes'].cpu().numpy()
+    assert got.shape == want.shape and got.shape[0] > 0
+    assert np.abs(got[:, :4] - want[:, :4]).max() < 0.25 and np.array_equal(got[:, 6], want[:, 6])
+    assert (out['semantic'].cpu().numpy() == O.seg_class_map_original(se[0].numpy(), H, W)).mean() > 0.995
+    assert (out['waterline'].cpu().numpy() == O.seg_class_map_original(lane[0].numpy(), H, W)).mean() > 0.995
+    assert (out['point_class'].cpu() == pc[0].argmax(-1)).float().mean() > 0.99
