@@ -16,6 +16,9 @@ b en_s0_plain --plain
 b en_s0_separate_calls --separate-calls
 b en_s0_force_collective --force-collective
 b en_s0_head_mfma --opt head_mfma=1
+b en_s0_b256 --batch 256
+b en_s2_b256 --config en_s2 --batch 256
+b en_s2_b512_one_gpu --config en_s2 --batch 512 --plain
 PYTHONPATH=. python profiles/scripts/train_step.py --batch 8 --steps 5 > gpurun_out/variants/r02_train_step_b8.json 2>/dev/null
 PYTHONPATH=. python profiles/scripts/train_step.py --batch 32 --steps 3 > gpurun_out/variants/r02_train_step_b32.json 2>/dev/null
 cd /tmp && export TMPDIR=/tmp && cd "$root"
