@@ -151,6 +151,7 @@ struct RcFrontParams {
     void* Y; long ldy, ypr, ypi;              // output: pixel (0,0) of sample 0 and row / image pitches (dense or zero-bordered)
     int B, H, Wd, cv, C;
     const unsigned short* occ; int occ_r;     // optional occupancy of P per 16-pixel row segment [B][H][Wd/16], one bit per column (avgpool3x3), and the reach of a pixel, see below
+    int rows4;                                // 1: a workgroup owns FOUR consecutive rows, one per wave (H % 4 == 0): the weight staging and the tables are paid once per four rows
 };
 
 // Empty segments (first RCBlock only: its input is the raw radar map, > 99 % zeros — radar_feature_map_generate.ipynb).  If P is
@@ -170,7 +171,9 @@ __global__ __launch_bounds__(256, KS == 3 ? 4 : 1) void rc_front_kernel(const Rc
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int px = lane & 15, g = lane >> 4;
     const unsigned wg = xcd_block(blockIdx.x, gridDim.x);
-    const int b = int(wg / unsigned(p.H)), oy = int(wg - unsigned(b) * unsigned(p.H));
+    const int wv = wave_uniform(wave);
+    const unsigned grow = p.rows4 ? wg * 4u + unsigned(wv) : wg;   // global row index (sample * H + row)
+    const int b = int(grow / unsigned(p.H)), oy = int(grow - unsigned(b) * unsigned(p.H));
     const int ldp = int(p.ldp), prow = int(p.prow);
 
     int off[KS], tapi[KS], cofs[KS];
@@ -255,7 +258,6 @@ __global__ __launch_bounds__(256, KS == 3 ? 4 : 1) void rc_front_kernel(const Rc
     };
     // Segments are dealt to the four waves by RANK among the active (and among the empty) ones, not by position: occupied cells come
     // in clusters, and position-strided waves would leave one wave with a row's whole cluster.
-    const int wv = wave_uniform(wave);
     const unsigned tmask = ntiles >= 32 ? 0xffffffffu : ((1u << ntiles) - 1u);
     unsigned rem = active & tmask;
     int rank = 0;
@@ -263,7 +265,7 @@ __global__ __launch_bounds__(256, KS == 3 ? 4 : 1) void rc_front_kernel(const Rc
         while (rem) {
             const int t = __ffsll(static_cast<long long>(rem)) - 1;
             rem &= rem - 1u;
-            if ((rank++ & 3) == wv) return t;
+            if (p.rows4 || (rank++ & 3) == wv) return t;
         }
         return -1;
     };
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(256, KS == 3 ? 4 : 1) void rc_front_kernel(const Rc
         while (rem_e) {
             const int t = __ffsll(static_cast<long long>(rem_e)) - 1;
             rem_e &= rem_e - 1u;
-            if ((rank_e++ & 3) != wv) continue;
+            if (!p.rows4 && (rank_e++ & 3) != wv) continue;
             f32x4 zero;
             zero[0] = zero[1] = zero[2] = zero[3] = 0.f;
             const int xr = t * 16 + px;
@@ -344,7 +346,7 @@ __global__ __launch_bounds__(256, KS == 3 ? 4 : 1) void rc_front_kernel(const Rc
 
 template <class T>
 inline bool launch_rc_front(const RcFrontParams& p, int ksteps, hipStream_t stream) {
-    const dim3 grid(unsigned(p.B) * unsigned(p.H)), block(256);
+    const dim3 grid(unsigned(p.B) * unsigned(p.H) / (p.rows4 ? 4u : 1u)), block(256);
     const bool narrow = p.ldp == 4 && Store<T>::VEC == 8;          // 8-byte pixels (engine: radar block 0 in bf16)
     if (ksteps == 3) {
         if (narrow) ACH_LAUNCH((rc_front_kernel<T, 3, true>), grid, block, stream, p); else ACH_LAUNCH((rc_front_kernel<T, 3, false>), grid, block, stream, p);

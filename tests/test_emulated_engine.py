@@ -362,19 +362,21 @@ def test_emulated_radar_skip_is_bit_identical(dtype, cells):
         xr = torch.zeros_like(xr)
     td = torch.float32 if dtype == DTYPE_F32 else torch.bfloat16
     outs = []
-    for v in (1, 0):
+    for v in (1, 0, 2):
         eng = NativeEngine(emu_library(), num_det=kw['num_det'], num_seg=kw['num_seg'], phi=kw['phi'], backbone=kw['backbone'],
                            resolution=kw['resolution'], pc_channels=kw['pc_channels'], pc_classes=kw['pc_classes'],
                            num_points=16, nano_head=kw['nano_head'], spp=kw['spp'], dtype=dtype)
-        eng.set_option('radar_skip', v)
+        eng.set_option('radar_skip', 1 if v else 0)
+        eng.set_option('radar_rows4', 1 if v == 2 else 0)              # v = 2: four rows per workgroup as well
         eng.set_option('full_taps', 1)
         eng.load_state_dict(sd)
         eng.plan(2)
         o = alloc_outputs(kw, 2, 16, td, 'cpu')
         eng.forward(x.to(td), xr.to(td), xp.to(td), o)
         outs.append([t.float() for t in o[:3]] + [eng.read_tap(t) for t in ('radar.b0', 'radar.b1', 'r3', 'r5')])
-    for a, b in zip(*outs):
-        assert torch.equal(a, b)
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize('name', ['en_s2'])
