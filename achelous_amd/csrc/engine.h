@@ -74,7 +74,8 @@ public:
     bool use_graph = false;
     bool multi_stream = true;         // option "streams": run the independent radar / point branches on side streams
     bool dw_even = true;              // option "dw_even": SPLIT mlp_kernel deals depthwise tap ROWS, not whole k-steps, to its four waves (k_mlp.h)
-    bool radar_rows4 = false;         // option "radar_rows4": with radar_skip, a workgroup of rc_front block 0 owns four rows (one per wave)
+    int radar_rows4 = 2;              // option "radar_rows4": a workgroup of rc_front owns four rows, one per wave (1: block 0 when radar_skip is on; 2: every
+                                      // fused block — 29.1 k against 27.7 k frames/s: the per-workgroup weight staging and tables were a fifth of these kernels)
     bool radar_skip = true;           // option "radar_skip": first RCBlock — closed-form shortcut on 16-pixel segments whose neighbourhood of the radar map is empty (k_conv3.h)
     bool head_mfma = false;           // option "head_mfma": bf16 — bilinear phase of the fused last decoder level on MFMA over a channel-planar t (k_nhwc.h)
     int head_grid = 0;                // option "head_grid": persistent workgroups of the MFMA head kernel (0 = UGM_GRID)

@@ -792,7 +792,7 @@ public:
                 for (int n = 0; n < l2.N; ++n) b32[n] = l2.b[n];
                 const bool res = x.C == cout;
                 Conv3Params cp{t.p, t.ld, long(t.W) * t.ld, long(t.H) * t.W * t.ld, dst->p, dst->ld, pk.w, up_f32(b32), t.B, t.H, t.W, cv, ACT_RELU, 1,
-                               res ? x.p : nullptr, res ? x.ld : 0};
+                               res ? x.p : nullptr, res ? x.ld : 0, (radar_rows4 == 2 && t.H % 4 == 0) ? 1 : 0};
                 const double bytes = double(t.rows()) * (t.ld + dst->ld * (res ? 2 : 1)) * sizeof(T);
                 add_op(pfx + ".conv2", [cp, ks](hipStream_t s) { launch_conv3<T>(cp, ks, 2, 1, s); }, bytes, 2.0 * double(t.rows()) * l2.K * l2.N);
                 return;
@@ -1080,7 +1080,7 @@ public:
         if (row_conv && shape_ok && (ks == 3 || ks == 5 || ks == 9) && pk.nchunks == 1 && pk.ksteps == ks) {
             std::vector<float> b32(32, 0.f);
             for (int n = 0; n < l.N; ++n) b32[n] = l.b[n];
-            Conv3Params cp{x.p0, x.ld, x.row, x.img, y.p, y.ld, pk.w, up_f32(b32), x.B, Ho, Wo, cv, act, 0, nullptr, 0};
+            Conv3Params cp{x.p0, x.ld, x.row, x.img, y.p, y.ld, pk.w, up_f32(b32), x.B, Ho, Wo, cv, act, 0, nullptr, 0, (radar_rows4 == 2 && Ho % 4 == 0) ? 1 : 0};
             const int NT = pk.NT;
             add_op(name, [cp, ks, NT, stride, half](hipStream_t s) { launch_conv3<T>(cp, ks, NT, stride, s, half); }, bytes, 2.0 * double(y.rows()) * l.K * l.N, lbytes);
             return y;
@@ -1187,7 +1187,7 @@ public:
                 const long yld = y_bordered ? yb.ld : y.ld;
                 RcFrontParams rp{pooled.p0, pooled.ld, pooled.row, pooled.img, pkom.w, up_f32(b32), pkf.w, up_f32(b16), x.p, x.ld,
                                  y_bordered ? yb.p0 : y.p, yld, y_bordered ? yb.row : long(x.W) * y.ld, y_bordered ? yb.img : long(x.H) * x.W * y.ld,
-                                 B, x.H, x.W, cvp, C, occ, occ_r, (occ && radar_rows4 && x.H % 4 == 0) ? 1 : 0};
+                                 B, x.H, x.W, cvp, C, occ, occ_r, (((occ && radar_rows4 == 1) || radar_rows4 == 2) && x.H % 4 == 0) ? 1 : 0};
                 // algorithmic bytes: pooled map + residual read once, output written once, REAL channels; the layout figure
                 // counts the pixel pitches the kernel actually moves
                 const double bytes = double(x.rows()) * 3.0 * C * sizeof(T), lbytes = double(x.rows()) * (pooled.ld + x.ld + yld) * sizeof(T);

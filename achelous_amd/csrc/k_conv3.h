@@ -24,6 +24,8 @@ struct Conv3Params {
     int B, H, Wd, cv, act;
     int dense;                      // 1: X is a plain dense NHWC map (no border): taps outside the map are masked instead (stride 1 only)
     const void* R; long ldr;        // optional residual added after the activation, same pixel layout as Y (nullptr: none)
+    int rows4;                      // 1: a workgroup owns four consecutive output rows, one per wave (H % 4 == 0): the weight fragments every lane loads
+                                    //    at the start serve a whole row per wave instead of a quarter of one
 };
 
 // NT = 1: up to 16 outputs (one 8-byte store per lane); NT = 2: up to 32.  STRIDE 1 or 2 (H, Wd are the OUTPUT map; the input is
@@ -36,7 +38,8 @@ __global__ __launch_bounds__(256) void conv3x3_rows_kernel(const Conv3Params p) 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int px = lane & 15, g = lane >> 4;
     const unsigned wg = xcd_block(blockIdx.x, gridDim.x);          // consecutive rows of a sample share an L2 (halo rows)
-    const int b = int(wg / unsigned(p.H)), oy = int(wg - unsigned(b) * unsigned(p.H));
+    const unsigned grow = p.rows4 ? wg * 4u + unsigned(wave_uniform(wave)) : wg;
+    const int b = int(grow / unsigned(p.H)), oy = int(grow - unsigned(b) * unsigned(p.H));
     const int ldx = int(p.ldx);
 
     int off[KS], dxs[KS];
@@ -65,7 +68,7 @@ __global__ __launch_bounds__(256) void conv3x3_rows_kernel(const Conv3Params p) 
     const T* xrow = static_cast<const T*>(p.X) + long(b) * p.xpi + long(oy) * STRIDE * p.xpr;
     T* yrow = static_cast<T*>(p.Y) + (long(b) * p.H + oy) * p.Wd * p.ldy + g * 4 * NT;
     const bool chan_ok = g * 4 * NT < int(p.ldy);
-    for (int tile = wave; tile * 16 < p.Wd; tile += 4) {
+    for (int tile = p.rows4 ? 0 : wave; tile * 16 < p.Wd; tile += p.rows4 ? 1 : 4) {
         const int xr = tile * 16 + px;
         const bool valid = xr < p.Wd;
         const int x = valid ? xr : p.Wd - 1;
@@ -115,7 +118,7 @@ __global__ __launch_bounds__(256) void conv3x3_rows_kernel(const Conv3Params p) 
 
 template <class T>
 inline bool launch_conv3(const Conv3Params& p, int ksteps, int NT, int stride, hipStream_t stream, bool half = false) {
-    const dim3 grid(unsigned(p.B) * unsigned(p.H)), block(256);
+    const dim3 grid(unsigned(p.B) * unsigned(p.H) / (p.rows4 ? 4u : 1u)), block(256);
     if (half) {
         if (Store<T>::VEC != 8 || ksteps != 3 || NT != 1 || stride != 2 || p.dense) return false;
         ACH_LAUNCH((conv3x3_rows_kernel<T, 3, 1, 2, true>), grid, block, stream, p);

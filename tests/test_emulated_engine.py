@@ -111,7 +111,7 @@ def test_emulated_forward_detect_equals_the_three_calls():
     assert int(cnt[0]) > 0
 
 
-@pytest.mark.parametrize('option', ['fused_mlp', 'row_conv', 'fused_rc', 'dw_tile', 'head_batch', 'split_decoders', 'head_stream', 'streams', 'stem_mfma', 'radar_start', 'dw_even'])
+@pytest.mark.parametrize('option', ['fused_mlp', 'row_conv', 'fused_rc', 'dw_tile', 'head_batch', 'split_decoders', 'head_stream', 'streams', 'stem_mfma', 'radar_start', 'dw_even', 'radar_rows4'])
 def test_emulated_kernel_switches_agree(option):
     """Each fused / batched kernel against the layer-wise launches it replaced, through the C ABI on the CPU emulation (fp32)."""
     kw, sd, (x, xr, xp) = _setup('en_s0', 64, 1, 16)
@@ -367,7 +367,7 @@ def test_emulated_radar_skip_is_bit_identical(dtype, cells):
                            resolution=kw['resolution'], pc_channels=kw['pc_channels'], pc_classes=kw['pc_classes'],
                            num_points=16, nano_head=kw['nano_head'], spp=kw['spp'], dtype=dtype)
         eng.set_option('radar_skip', 1 if v else 0)
-        eng.set_option('radar_rows4', 1 if v == 2 else 0)              # v = 2: four rows per workgroup as well
+        eng.set_option('radar_rows4', 2 if v == 2 else 0)              # v = 2: four rows per workgroup as well
         eng.set_option('full_taps', 1)
         eng.load_state_dict(sd)
         eng.plan(2)
