@@ -402,7 +402,10 @@ namespace ach {
 // that ALL weight fragments live in registers, and a wave walks several 16-pixel tiles with the next tile's rows prefetched:
 // per tile only the row load, 2 K1 J + J HSTEP 2 MFMAs, the activation and one 16-byte store remain — the kernel is then a
 // plain stream over x and y (HBM-bound).  Weight layouts are mlp_kernel's with DT = 2.
-constexpr int CHAIN_TILES_PER_WAVE = 4;
+#ifndef ACH_CHAIN_TILES
+#define ACH_CHAIN_TILES 4
+#endif
+constexpr int CHAIN_TILES_PER_WAVE = ACH_CHAIN_TILES;
 template <class T, int K1, int J>
 __global__ __launch_bounds__(256) void chain_kernel(const MlpParams p) {
     constexpr int VEC = Store<T>::VEC;
