@@ -494,7 +494,7 @@ public:
         const int C = x.C;
         const int width = std::max((C + scales - 1) / scales, C / scales);
         const int nums = scales - 1;
-        if ((C / heads) > 48) throw AchError{ACH_ERR_UNSUPPORTED, "XCA head dimension > 48"};
+        if ((C / heads) > 64) throw AchError{ACH_ERR_UNSUPPORTED, "XCA head dimension > 64"};
         if (width % 4) throw AchError{ACH_ERR_UNSUPPORTED, "SDTA split width must be a multiple of 4"};
         A y = alloc(x.B, x.H, x.W, C);
         for (int i = 0; i < nums; ++i) {
@@ -519,7 +519,7 @@ public:
         XcaGramParams pg{qkv.p, qkv.ld, partial, x.B, N, C, heads, S};
         {
             const dim3 grid(unsigned(x.B * heads), unsigned(S)), block(256);
-            add_op(pfx + ".xca.gram", [pg, grid, block](hipStream_t s) { ACH_LAUNCH(xca_gram_kernel<T>, grid, block, s, pg); },
+            add_op(pfx + ".xca.gram", [pg, grid, block, d](hipStream_t s) { if (d <= 48) ACH_LAUNCH((xca_gram_kernel<T, 48>), grid, block, s, pg); else ACH_LAUNCH((xca_gram_kernel<T, 64>), grid, block, s, pg); },
                    2.0 * x.rows() * C * sizeof(T));
         }
         Packed pe = pack_shape(C, C);
@@ -533,7 +533,7 @@ public:
                           x.B, C, heads, pe.NT, pe.ksteps};
         {
             const dim3 grid(unsigned(x.B * heads), unsigned(cdiv(C, XCA_CT))), block(256);
-            add_op(pfx + ".xca.finalize", [pf, grid, block](hipStream_t s) { ACH_LAUNCH(xca_finalize_kernel<T>, grid, block, s, pf); });
+            add_op(pfx + ".xca.finalize", [pf, grid, block, d](hipStream_t s) { if (d <= 48) ACH_LAUNCH((xca_finalize_kernel<T, 48>), grid, block, s, pf); else ACH_LAUNCH((xca_finalize_kernel<T, 64>), grid, block, s, pf); });
         }
         // t2 = y + gamma_xca * proj(attn @ v): one GEMM over v (channel slice [2C,3C) of qkv) with per-sample weights
         A t2 = alloc(x.B, x.H, x.W, C);

@@ -1,7 +1,8 @@
 // k_xca.h — EdgeNeXt cross-covariance attention (XCA, edgenext_modules/sdta_encoder.py:162-185).
 //
-// Attention is over CHANNELS: per (sample, head) a d x d matrix, d = C/heads in {8..44}; the token axis N (<= 1600) is only
-// reduced over.  Because the attention matrix multiplies v from the left and the projection from the right,
+// Attention is over CHANNELS: per (sample, head) a d x d matrix, d = C/heads in {8..72}; the token axis N (<= 1600) is only
+// reduced over.  Both kernels are compiled for d <= 48 (EN-S0: 44, EN-S2 36 at 8 heads) and d <= 64 (EN-S1: 56) — the LDS tiles and the
+// per-thread accumulator count are sized by the template bound.  Because the attention matrix multiplies v from the left and the projection from the right,
 //     proj(attn @ v)[n, co] = sum_k v[n, k] * Weff[b][co][k],   Weff[b][co][h*d+j] = gamma[co] * sum_i A[b,h,i,j] * Wproj[co][h*d+i]
 // the whole "attn @ v -> proj -> layer scale -> + residual" tail is ONE MFMA GEMM with per-sample weights.  So:
 //   xca_gram    : partial Gram matrices q.k^T and squared norms over a slice of the tokens  (grid: B*heads x S, LDS staged)
@@ -14,14 +15,13 @@
 
 namespace ach {
 
-constexpr int XCA_DMAX = 48;
 constexpr int XCA_CT = 32;       // output-channel tile of xca_finalize: one workgroup per (sample, head, tile) — the softmax is recomputed
                                  // per tile (d x d, cheap) so that the fold runs on 4-6x more workgroups instead of a serial loop
 
 struct XcaGramParams { const void* qkv; long ld; float* partial; int B, N, C, heads, S; };
 
 // partial layout per (b, h, s): [d*d gram | d sum q^2 | d sum k^2]
-template <class T>
+template <class T, int XCA_DMAX>
 __global__ __launch_bounds__(256) void xca_gram_kernel(const XcaGramParams p) {
     constexpr int TOK = 16;
     __shared__ float qs[TOK][XCA_DMAX];
@@ -86,7 +86,7 @@ struct XcaFinalParams {
     int B, C, heads, NT, ksteps;
 };
 
-template <class T>
+template <class T, int XCA_DMAX>
 __global__ __launch_bounds__(256) void xca_finalize_kernel(const XcaFinalParams p) {
     __shared__ float A[XCA_DMAX][XCA_DMAX + 1];
     __shared__ float nq[XCA_DMAX], nk[XCA_DMAX];

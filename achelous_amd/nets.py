@@ -82,9 +82,6 @@ class Achelous(nn.Module):
         # forward raises for anything else).  Ours follows our own specification of that branch: achelous_amd/spec.py::PN2.
         if phi not in ('S0', 'S1', 'S2'):
             raise NotImplementedError(f"phi={phi!r}: only S0, S1, S2 exist for the en/mv backbones")
-        if backbone == 'en' and phi == 'S1':
-            raise NotImplementedError("backbone='en', phi='S1': the XCA kernel handles head widths up to 48, EdgeNeXt-S1 needs 56 "
-                                      "(not a BASELINE.json config); EN-S0, EN-S2 and MV-S0/S1/S2 are built")
         if neck == 'gdf' and not 1 <= num_seg <= 16:
             raise NotImplementedError(f"num_seg={num_seg}: the fused segmentation-head kernel writes up to 16 classes")
         if not nano_head:

@@ -18,7 +18,7 @@ copied and never travel to the GPU box.  For each BASELINE.json model config it
   6. writes `<config>.npz` (full tensors when small, otherwise seeded index samples + checksums) and
      `<config>.keys.json` (state-dict key list + shapes — the drop-in contract).
 
-Usage:  python tests/golden/gen_golden.py [en_s0 en_s2 mv_s2 en_s0_cdf]
+Usage:  python tests/golden/gen_golden.py [en_s0 en_s2 mv_s2 en_s0_cdf en_s1]
 """
 import json
 import os
@@ -40,6 +40,7 @@ CONFIGS = {   # name -> (config id in BASELINE.json, ctor kwargs)
     'en_s2': (5, dict(backbone='en', phi='S2')),
     'mv_s2': (3, dict(backbone='mv', phi='S2')),
     'en_s0_cdf': (6, dict(backbone='en', phi='S0', neck='cdf')),     # CSP-Dual-FPN neck (not a BASELINE config)
+    'en_s1': (7, dict(backbone='en', phi='S1')),                     # the middle width of nets/Achelous.py's phi choice (not a BASELINE config): XCA head width 56
 }
 COMMON = dict(num_det=7, num_seg=9, resolution=320, neck='gdf', pc_seg='pn', pc_channels=5, pc_classes=8,
               nano_head=True, spp=True)

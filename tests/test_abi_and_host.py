@@ -40,7 +40,7 @@ def test_hip_library_exports_every_declared_symbol():
                              num_points=512, nano_head=False, spp=True, dtype=0)
 
 
-@pytest.mark.parametrize('name', ['en_s0', 'en_s2', 'mv_s2', 'en_s0_cdf'])
+@pytest.mark.parametrize('name', ['en_s0', 'en_s2', 'mv_s2', 'en_s0_cdf', 'en_s1'])
 def test_state_dict_contract(name):
     meta = json.load(open(os.path.join(REPO, 'tests', 'golden', name + '.keys.json')))
     c = meta['ctor']

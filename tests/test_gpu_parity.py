@@ -62,7 +62,7 @@ def test_native_library_is_loaded():
         assert 'libachelous_hip.so' in f.read()
 
 
-@pytest.mark.parametrize('name', ['en_s0', 'en_s2', 'mv_s2', 'en_s0_cdf'])
+@pytest.mark.parametrize('name', ['en_s0', 'en_s2', 'mv_s2', 'en_s0_cdf', 'en_s1'])
 def test_forward_fp32_matches_reference_fixtures(name):
     g = Golden(name)
     m, kw = _model(g, debug_taps=True)
@@ -104,7 +104,7 @@ def test_forward_fp32_matches_oracle_full_tensors():
             assert _rel(e.read_tap(tap), orc.taps[tap]) < F32_TOL, tap
 
 
-@pytest.mark.parametrize('name', ['en_s0', 'en_s2', 'mv_s2', 'en_s0_cdf'])
+@pytest.mark.parametrize('name', ['en_s0', 'en_s2', 'mv_s2', 'en_s0_cdf', 'en_s1'])
 def test_forward_bf16_matches_reference_fixtures(name):
     g = Golden(name)
     m, kw = _model(g, debug_taps=True)
@@ -516,3 +516,26 @@ def test_reference_default_resolution_416():
             assert k == len(exp[0][1])
             assert np.array_equal(idx[0, :k].cpu().numpy().astype(np.int64), exp[0][1])
             assert np.array_equal(rows[0, :k].cpu().numpy(), exp[0][0])
+
+
+@pytest.mark.parametrize('phi', ['S0', 'S1'])
+def test_mobilevit_other_widths_match_oracle(phi):
+    """MobileViT S0 / S1 (nets/Achelous.py's phi choice; no BASELINE config uses them, so no fixture): the module's own parameter
+    tree with uncalibrated seeded weights, fp32 against the oracle at 320x320; bf16 within twice the oracle's own autocast deviation."""
+    kw = dict(num_det=7, num_seg=9, phi=phi, backbone='mv', neck='gdf', pc_seg='pn', pc_channels=5, pc_classes=8, nano_head=True, spp=True, resolution=320)
+    m = Achelous(**kw).eval()
+    sd = condition_state_dict(m.state_dict(), seed=3)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda()
+    x, xr, xp = make_inputs(2, 9, resolution=320, pc_channels=5)
+    okw = {k: kw[k] for k in ('num_det', 'num_seg', 'phi', 'backbone', 'neck', 'pc_seg', 'pc_channels', 'pc_classes', 'nano_head', 'spp', 'resolution')}
+    ref = AchelousOracle({k: v.cpu() for k, v in sd.items()}, **okw).forward(x, xr, xp)
+    with torch.no_grad():
+        det, se, lane, pc = m(x.cuda(), xr.cuda(), xp.cuda())
+        for k, a, b in zip(OUTPUTS, (*det, se, lane, pc), (*ref[0], ref[1], ref[2], ref[3])):
+            assert _rel(a.float(), b.float()) <= F32_TOL, k
+        with torch.autocast('cpu', dtype=torch.bfloat16):
+            amp = AchelousOracle({k: v.cpu() for k, v in sd.items()}, **okw).forward(x, xr, xp)
+        det, se, lane, pc = m(x.cuda().bfloat16(), xr.cuda().bfloat16(), xp.cuda().bfloat16())
+        for k, a, b, c in zip(OUTPUTS, (*det, se, lane, pc), (*ref[0], ref[1], ref[2], ref[3]), (*amp[0], amp[1], amp[2], amp[3])):
+            assert _rel(a.float(), b.float()) <= max(2e-2, 2.0 * _rel(c.float(), b.float())), k

@@ -14,7 +14,7 @@ def _state_dict_from_keys(meta):
     return condition_state_dict(blank, seed=meta['weight_seed'])
 
 
-@pytest.mark.parametrize('name', ['en_s0', 'en_s2', 'mv_s2', 'en_s0_cdf'])
+@pytest.mark.parametrize('name', ['en_s0', 'en_s2', 'mv_s2', 'en_s0_cdf', 'en_s1'])
 def test_oracle_matches_reference_fixtures(name):
     g = Golden(name)
     kw = ctor_kwargs(g.meta)
