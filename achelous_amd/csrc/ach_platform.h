@@ -367,6 +367,21 @@ __device__ __forceinline__ float gelu_sigmoid(float x) {
 }
 template <class T> __device__ __forceinline__ float apply_act_t(float x, int act) { return apply_act(x, act); }
 template <> __device__ __forceinline__ float apply_act_t<bf16_t>(float x, int act) { return act == ACT_GELU ? gelu_sigmoid(x) : apply_act(x, act); }
+// N values at once with the switch on the (launch-uniform) activation OUTSIDE the element loop.  Per element, the compiler kept a
+// scalar branch ladder around every value: eight serialised (bias load -> wait -> ladder -> exp -> rcp) chains per hidden chunk of
+// mlp_kernel, no two transcendentals ever in flight together.  Same formulas as apply_act_t, so results are bit-identical.
+// ACT >= 0 fixes the activation at compile time (no branch at all: the surrounding loop stays one schedulable block).
+template <class T, int N, int ACT = -1>
+__device__ __forceinline__ void apply_act_n(float* v, int act) {
+    const int a = ACT >= 0 ? ACT : act;
+    switch (a) {
+        case ACT_RELU: ACH_UNROLL for (int i = 0; i < N; ++i) v[i] = apply_act(v[i], ACT_RELU); break;
+        case ACT_SILU: ACH_UNROLL for (int i = 0; i < N; ++i) v[i] = apply_act(v[i], ACT_SILU); break;
+        case ACT_GELU: ACH_UNROLL for (int i = 0; i < N; ++i) v[i] = apply_act_t<T>(v[i], ACT_GELU); break;
+        case ACT_SIGMOID: ACH_UNROLL for (int i = 0; i < N; ++i) v[i] = apply_act(v[i], ACT_SIGMOID); break;
+        default: break;
+    }
+}
 
 // XCD-aware workgroup order for kernels whose neighbouring workgroups share input lines (3x3 halos, bilinear corners):
 // workgroup w is observed to run on XCD w % 8, each XCD with its own L2.  Re-numbering w -> (w % 8) * (n / 8) + w / 8 hands

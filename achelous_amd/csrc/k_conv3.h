@@ -99,7 +99,8 @@ __global__ __launch_bounds__(256) void conv3x3_rows_kernel(const Conv3Params p) 
         if (NT == 2) {
             float o[8];
             ACH_UNROLL
-            for (int r = 0; r < 4; ++r) { o[r] = apply_act_t<T>(acc[0][r] + bv[r], p.act); o[4 + r] = apply_act_t<T>(acc[NT - 1][r] + bv[4 * (NT - 1) + r], p.act); }
+            for (int r = 0; r < 4; ++r) { o[r] = acc[0][r] + bv[r]; o[4 + r] = acc[NT - 1][r] + bv[4 * (NT - 1) + r]; }
+            apply_act_n<T, 8>(o, p.act);
             if (p.R) {
                 float r8[8];
                 Store<T>::ld8(static_cast<const T*>(p.R) + ((long(b) * p.H + oy) * p.Wd + x) * p.ldr + g * 8, r8);
@@ -110,7 +111,8 @@ __global__ __launch_bounds__(256) void conv3x3_rows_kernel(const Conv3Params p) 
         } else {
             float o[4];
             ACH_UNROLL
-            for (int r = 0; r < 4; ++r) o[r] = apply_act_t<T>(acc[0][r] + bv[r], p.act);
+            for (int r = 0; r < 4; ++r) o[r] = acc[0][r] + bv[r];
+            apply_act_n<T, 4>(o, p.act);
             Store<T>::st4(yrow + long(x) * p.ldy, o);
         }
     }

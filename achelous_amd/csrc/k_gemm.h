@@ -207,7 +207,8 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, unsigned bx, unsi
             ACH_UNROLL
             for (int t = 0; t < NT; ++t)
                 ACH_UNROLL
-                for (int r = 0; r < 4; ++r) o[t * 4 + r] = apply_act_t<T>(acc[q][t][r] + bv[t * 4 + r], p.act);
+                for (int r = 0; r < 4; ++r) o[t * 4 + r] = acc[q][t][r] + bv[t * 4 + r];
+            apply_act_n<T, 4 * NT>(o, p.act);
             const long m = mrow[q];
             if (p.out_nchw) {
                 T* Y = static_cast<T*>(p.Y);
@@ -348,10 +349,14 @@ __global__ __launch_bounds__(256) void gemm_colmax_kernel(const GemmMaxParams p)
             for (int t = 0; t < NT; ++t) mfma16<T>(Wf[(s * NT + t) * 64], xf, acc[t]);
         }
         if (valid) {
+            float av[4 * NT];
             ACH_UNROLL
             for (int t = 0; t < NT; ++t)
                 ACH_UNROLL
-                for (int r = 0; r < 4; ++r) cm[t * 4 + r] = fmaxf(cm[t * 4 + r], apply_act(acc[t][r] + bv[t * 4 + r], p.act));
+                for (int r = 0; r < 4; ++r) av[t * 4 + r] = acc[t][r] + bv[t * 4 + r];
+            apply_act_n<float, 4 * NT>(av, p.act);
+            ACH_UNROLL
+            for (int e = 0; e < 4 * NT; ++e) cm[e] = fmaxf(cm[e], av[e]);
         }
     }
     ACH_UNROLL

@@ -22,6 +22,7 @@
 // the depthwise conv for a quarter of the channel k-steps and a quarter of the hidden chunks, inputs are exchanged and
 // the partial outputs summed through LDS — four times the parallelism, a quarter of the dependent-latency chain.
 #pragma once
+#include <type_traits>
 #include "ach_platform.h"
 #include "k_gemm.h"
 
@@ -52,6 +53,9 @@ struct MlpParams {
 };
 
 constexpr int MLP_RED_TILES = 4;          // output tiles reduced per LDS round in SPLIT mode
+#ifndef ACH_MLP_DEBUG
+#define ACH_MLP_DEBUG 0                   // phase timing builds only (profiles/scripts/build_variant.sh): 1 = no depthwise taps, 2 = no hidden chunks, 4 = ReLU for every activation; wrong results
+#endif
 
 // depthwise k x k conv (zero padding k/2) of this lane's VEC channels at its pixel; up to 5 taps of a row in flight at a time.
 // Taps are fetched through a range-checked buffer resource over the whole activation tensor (ach_platform.h): a column outside
@@ -73,6 +77,7 @@ __device__ __forceinline__ void mlp_dw(const MlpParams& p, const BufRsrc& xb, lo
         const int ix = ox + tx - KS / 2;
         coff[tx] = (ix >= 0 && ix < p.W) ? unsigned(ix) * pitch : BUF_OOB;
     }
+    if (ACH_MLP_DEBUG & 1) return;
     for (int ty = ty0; ty < ty1; ++ty) {
         const int iy = oy + ty - KS / 2;
         if (iy < 0 || iy >= p.H) continue;
@@ -193,6 +198,15 @@ __device__ __forceinline__ void mlp_inputs(const MlpParams& p, long m, bool vali
 // tile — what matters there is that a wave can have a whole hidden chunk's weight fragments (2 k1 + DT loads) in flight at once.
 // With the non-SPLIT budgets the compiler had 4 fragment registers to cycle through and every second MFMA waited for a fresh L2
 // round trip (measured: 7 us per hidden chunk on the 10x10 maps).
+#ifndef ACH_MLP_PIPE_SPLIT_DT
+#define ACH_MLP_PIPE_SPLIT_DT 0           // SPLIT kernels wider than this take the branch-free, prefetching chunk loop (all of them: +0.9 % on EN-S0 over > 6)
+#endif
+#ifndef ACH_MLP_PIPE_FLAT_DT
+#define ACH_MLP_PIPE_FLAT_DT 0            // one-tile-per-wave kernels up to this width take it too
+#endif
+#ifndef ACH_MLP_OCC_SPLIT_PIPE
+#define ACH_MLP_OCC_SPLIT_PIPE 4
+#endif
 #ifndef ACH_MLP_OCC_SMALL
 #define ACH_MLP_OCC_SMALL 6
 #endif
@@ -203,7 +217,7 @@ __device__ __forceinline__ void mlp_inputs(const MlpParams& p, long m, bool vali
 #define ACH_MLP_OCC_12 3
 #endif
 template <int DT, bool SPLIT> struct MlpOcc {
-    static constexpr int blocks = (SPLIT && DT > 6) ? 2 : (DT <= 6 ? ACH_MLP_OCC_SMALL : (DT <= 10 ? ACH_MLP_OCC_10 : (DT <= 12 ? ACH_MLP_OCC_12 : 2)));
+    static constexpr int blocks = (SPLIT && DT > 6) ? 2 : (SPLIT && DT > ACH_MLP_PIPE_SPLIT_DT) ? ACH_MLP_OCC_SPLIT_PIPE : (DT <= 6 ? ACH_MLP_OCC_SMALL : (DT <= 10 ? ACH_MLP_OCC_10 : (DT <= 12 ? ACH_MLP_OCC_12 : 2)));
 };
 
 template <class T, int DT, bool SPLIT, bool EVEN = false>
@@ -278,8 +292,10 @@ __global__ __launch_bounds__(256, (MlpOcc<DT, SPLIT>::blocks)) void mlp_kernel(c
     // with a branch per k-step every pair of MFMAs waited for its own L2 round trip).
     // DT <= 6 keeps the small register budget (more workgroups per CU next to the side streams: measured better end to end);
     // DT > 12: branch-free, but the next chunk's fragments are not requested ahead (they would spill).
-    constexpr bool PIPE = SPLIT && DT > 6;
+    constexpr bool PIPE = SPLIT ? DT > ACH_MLP_PIPE_SPLIT_DT : DT <= ACH_MLP_PIPE_FLAT_DT;
     constexpr bool AHEAD = PIPE && DT <= 12;
+    constexpr int JS = SPLIT ? 4 : 1;
+    const int j0 = SPLIT ? wave : 0;
     uint4 wn[PIPE ? K1MAX : 1][2];
     auto load_w1 = [&](int j) {
         const uint4* w1 = W1f + long(j) * p.k1 * 2 * 64;
@@ -289,42 +305,53 @@ __global__ __launch_bounds__(256, (MlpOcc<DT, SPLIT>::blocks)) void mlp_kernel(c
             wn[s][0] = w1[(sc * 2) * 64]; wn[s][1] = w1[(sc * 2 + 1) * 64];
         }
     };
-    if (AHEAD && wave < p.J) load_w1(wave);
-    for (int j = SPLIT ? wave : 0; j < p.J; j += (SPLIT ? 4 : 1)) {
-        f32x4 a0, a1;
-        a0[0] = a0[1] = a0[2] = a0[3] = 0.f;
-        a1[0] = a1[1] = a1[2] = a1[3] = 0.f;
-        uint4 w2r[PIPE ? HSTEP : 1][PIPE ? DT : 1];
-        if (PIPE) {
-            if (!AHEAD) load_w1(j);
-            ACH_UNROLL
-            for (int s = 0; s < K1MAX; ++s) { mfma16<T>(wn[s][0], xf[s], a0); mfma16<T>(wn[s][1], xf[s], a1); }
-            ACH_UNROLL
-            for (int hh = 0; hh < HSTEP; ++hh)
+    // The activation is fixed at compile time inside the loop (GELU: EdgeNeXt, SiLU: MobileViT; anything else through the run-time form):
+    // with `p.act` tested per element the chunk loop was eight serialised load -> wait -> branch ladder -> exp -> rcp chains.
+    auto hidden = [&](auto actc) {
+        constexpr int ACT = decltype(actc)::value;
+        if (AHEAD && j0 < p.J) load_w1(j0);
+        for (int j = j0; j < ((ACH_MLP_DEBUG & 2) ? 0 : p.J); j += JS) {
+            f32x4 a0, a1;
+            a0[0] = a0[1] = a0[2] = a0[3] = 0.f;
+            a1[0] = a1[1] = a1[2] = a1[3] = 0.f;
+            const f32x4 bA = *reinterpret_cast<const f32x4*>(p.b1 + j * 32 + g * 8), bB = *reinterpret_cast<const f32x4*>(p.b1 + j * 32 + g * 8 + 4);
+            uint4 w2r[PIPE ? HSTEP : 1][PIPE ? DT : 1];
+            if (PIPE) {
+                if (!AHEAD) load_w1(j);
                 ACH_UNROLL
-                for (int t = 0; t < DT; ++t) w2r[hh][t] = W2f[(long(j * HSTEP + hh) * DT + t) * 64];
-            if (AHEAD && j + 4 < p.J) load_w1(j + 4);
-        } else {
-        const uint4* w1 = W1f + long(j) * p.k1 * 2 * 64;
-        ACH_UNROLL
-        for (int s = 0; s < K1MAX; ++s) {
-            if (s >= p.k1) continue;
-            const uint4 wa = w1[(s * 2) * 64], wb = w1[(s * 2 + 1) * 64];
-            mfma16<T>(wa, xf[s], a0);
-            mfma16<T>(wb, xf[s], a1);
-        }
-        }
-        float h[8];
-        const float* b1 = p.b1 + j * 32 + g * 8;
-        ACH_UNROLL
-        for (int r = 0; r < 4; ++r) { h[r] = apply_act_t<T>(a0[r] + b1[r], p.act); h[4 + r] = apply_act_t<T>(a1[r] + b1[4 + r], p.act); }
-        ACH_UNROLL
-        for (int hh = 0; hh < HSTEP; ++hh) {
-            const uint4 hf = frag_pack<T>(h + hh * VEC);
-            const uint4* w2 = W2f + long(j * HSTEP + hh) * DT * 64;
+                for (int s = 0; s < K1MAX; ++s) { mfma16<T>(wn[s][0], xf[s], a0); mfma16<T>(wn[s][1], xf[s], a1); }
+                ACH_UNROLL
+                for (int hh = 0; hh < HSTEP; ++hh)
+                    ACH_UNROLL
+                    for (int t = 0; t < DT; ++t) w2r[hh][t] = W2f[(long(j * HSTEP + hh) * DT + t) * 64];
+                if (AHEAD && j + JS < p.J) load_w1(j + JS);
+            } else {
+            const uint4* w1 = W1f + long(j) * p.k1 * 2 * 64;
             ACH_UNROLL
-            for (int t = 0; t < DT; ++t) mfma16<T>(PIPE ? w2r[hh][t] : w2[t * 64], hf, acc2[t]);
+            for (int s = 0; s < K1MAX; ++s) {
+                if (s >= p.k1) continue;
+                const uint4 wa = w1[(s * 2) * 64], wb = w1[(s * 2 + 1) * 64];
+                mfma16<T>(wa, xf[s], a0);
+                mfma16<T>(wb, xf[s], a1);
+            }
+            }
+            float h[8];
+            ACH_UNROLL
+            for (int r = 0; r < 4; ++r) { h[r] = a0[r] + bA[r]; h[4 + r] = a1[r] + bB[r]; }
+            apply_act_n<T, 8, ((ACH_MLP_DEBUG & 4) ? int(ACT_RELU) : ACT)>(h, p.act);
+            ACH_UNROLL
+            for (int hh = 0; hh < HSTEP; ++hh) {
+                const uint4 hf = frag_pack<T>(h + hh * VEC);
+                const uint4* w2 = W2f + long(j * HSTEP + hh) * DT * 64;
+                ACH_UNROLL
+                for (int t = 0; t < DT; ++t) mfma16<T>(PIPE ? w2r[hh][t] : w2[t * 64], hf, acc2[t]);
+            }
         }
+    };
+    switch (p.act) {
+        case ACT_GELU: hidden(std::integral_constant<int, ACT_GELU>{}); break;
+        case ACT_SILU: hidden(std::integral_constant<int, ACT_SILU>{}); break;
+        default: hidden(std::integral_constant<int, -1>{}); break;
     }
     // ---- 4. + bias + residual, 8 consecutive channels per lane per tile pair
     auto finish = [&](int pair, const float* v8) {
@@ -465,7 +492,8 @@ __global__ __launch_bounds__(256) void chain_kernel(const MlpParams p) {
         for (int j = 0; j < J; ++j) {
             float h[8];
             ACH_UNROLL
-            for (int r = 0; r < 4; ++r) { h[r] = apply_act_t<T>(h0[j][r] + b1[j][r], p.act); h[4 + r] = apply_act_t<T>(h1[j][r] + b1[j][4 + r], p.act); }
+            for (int r = 0; r < 4; ++r) { h[r] = h0[j][r] + b1[j][r]; h[4 + r] = h1[j][r] + b1[j][4 + r]; }
+            apply_act_n<T, 8>(h, p.act);
             ACH_UNROLL
             for (int hh = 0; hh < HSTEP; ++hh) {
                 const uint4 hf = frag_pack<T>(h + hh * VEC);

@@ -86,7 +86,8 @@ __device__ __forceinline__ void dwconv_strip_body(const DwParams& p, unsigned bx
         if (ox0 + o >= p.Wo) break;
         float t[4];
         ACH_UNROLL
-        for (int i = 0; i < 4; ++i) t[i] = apply_act(acc[o][i], p.act);
+        for (int i = 0; i < 4; ++i) t[i] = acc[o][i];
+        apply_act_n<float, 4>(t, p.act);
         Store<T>::st4(Y + long(o) * p.ldy, t);
     }
 }
@@ -139,8 +140,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const DwParams p) {
             acc[0] += v[0] * w.x; acc[1] += v[1] * w.y; acc[2] += v[2] * w.z; acc[3] += v[3] * w.w;
         }
     }
-    ACH_UNROLL
-    for (int i = 0; i < 4; ++i) acc[i] = apply_act(acc[i], p.act);
+    apply_act_n<float, 4>(acc, p.act);
     const long op = (b * p.Ho + oy) * p.Wo + ox;
     Store<T>::st4(static_cast<T*>(p.Y) + op * p.ldy + c, acc);
 }
@@ -197,7 +197,8 @@ __global__ __launch_bounds__(256) void dwconv_tile_kernel(const DwParams p) {
             const f32x2 v0 = {v.x, v.y}, v1 = {v.z, v.w}, w0 = {w.x, w.y}, w1 = {w.z, w.w};
             a0 += v0 * w0; a1 += v1 * w1;
         }
-    float t[4] = {apply_act(a0[0], p.act), apply_act(a0[1], p.act), apply_act(a1[0], p.act), apply_act(a1[1], p.act)};
+    float t[4] = {a0[0], a0[1], a1[0], a1[1]};
+    apply_act_n<float, 4>(t, p.act);
     Store<T>::st4(static_cast<T*>(p.Y) + ((b * p.Ho + oy) * long(p.Wo) + ox) * p.ldy + c, t);
 }
 
