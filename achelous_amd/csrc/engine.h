@@ -2,6 +2,7 @@
 // and the launch plan.  Compiled by hipcc into libachelous_hip.so (and by g++ against tests/hostemu for the CPU
 // emulation used by the unit tests).  See include/achelous.h for the C ABI and DESIGN.md for the data layout.
 #pragma once
+#include <cstdlib>
 #include <functional>
 #include <map>
 #include <string>
@@ -73,6 +74,7 @@ public:
     // (1.36 ms vs 1.66 ms): HIP's graph executor serialises more of the three-branch DAG than the streams do.
     bool use_graph = false;
     bool multi_stream = true;         // option "streams": run the independent radar / point branches on side streams
+    bool xca_mfma = true;             // option "xca_mfma": XCA Gram matrices on the matrix cores (xca_gram_mfma_kernel, k_xca.h); 0 = the VALU kernel
     bool dw_even = true;              // option "dw_even": SPLIT mlp_kernel deals depthwise tap ROWS, not whole k-steps, to its four waves (k_mlp.h)
     int radar_rows4 = 2;              // option "radar_rows4": a workgroup of rc_front owns four rows, one per wave (1: block 0 when radar_skip is on; 2: every
                                       // fused block — 29.1 k against 27.7 k frames/s: the per-workgroup weight staging and tables were a fifth of these kernels)
@@ -156,6 +158,16 @@ protected:
     float* up_f32(const std::vector<float>& v);
     void add_op(const std::string& name, std::function<void(hipStream_t)> fn, double bytes = 0, double flops = 0, double layout_bytes = -1) {
         if (measuring) return;
+        // timing experiments only (profiles/scripts/skip_ops.sh): ACH_DEBUG_SKIP="substr,substr" turns the matching launches into no-ops
+        // (events and stream order stay) to read off what a kernel group costs END TO END; the outputs are garbage then.
+        if (const char* skip = std::getenv("ACH_DEBUG_SKIP")) {
+            std::string all(skip);
+            for (size_t a = 0; a < all.size();) {
+                size_t b = all.find(',', a); if (b == std::string::npos) b = all.size();
+                if (b > a && name.find(all.substr(a, b - a)) != std::string::npos) { fn = [](hipStream_t) {}; break; }
+                a = b + 1;
+            }
+        }
         Op op{name, std::move(fn), bytes, layout_bytes < 0 ? bytes : layout_bytes, flops};
         op.stream = cur_stream;
         op.wait_ev = pending_wait; op.wait_ev2 = pending_wait2;

@@ -428,7 +428,7 @@ public:
         mp.M = xin.rows(); mp.C = C; mp.k1 = k1; mp.J = J; mp.act = act; mp.ln_eps = ln_eps; mp.ln = 1; mp.Cout = C;
         // per-sample map size, not batch, decides the geometry: a frame's result must not depend on the batch it is in
         const bool split = mlp_split < 0 ? xin.H * xin.W <= 1024 : mlp_split != 0;
-        if (split && dw_ks && dw_even && DT == 10) {                      // the instantiated width (launch_mlp)
+        if (split && dw_ks && dw_even && mlp_even_dt(DT)) {               // the instantiated widths (launch_mlp)
             // deal the k1 * k tap rows to the four waves in contiguous shares when that lowers the slowest wave's count and no share spans
             // more than two k-steps (the exchange buffer holds two slots per wave)
             const int U = k1 * dw_ks, chunk = cdiv(U, 4);
@@ -516,10 +516,22 @@ public:
         // Gram matrices over token slices, then softmax + fold into per-sample projection weights (see k_xca.h)
         const int S = N >= 1024 ? 8 : (N >= 256 ? 4 : 1);
         float* partial = alloc_f32(size_t(x.B) * heads * S * (d * d + 2 * d));
-        XcaGramParams pg{qkv.p, qkv.ld, partial, x.B, N, C, heads, S};
+        // heads per workgroup of the MFMA Gram kernel: the largest divisor of `heads` whose channels fit the 64-channel staging tile and
+        // whose tiles are at most six per wave (k_xca.h)
+        const int tmx = cdiv(d, 16), per_head = tmx * tmx + 2 * tmx;
+        int hg = 0;
+        for (int c = 1; c <= heads; ++c) if (heads % c == 0 && c * d <= 64 && c * per_head <= 24) hg = c;
+        XcaGramParams pg{qkv.p, qkv.ld, partial, x.B, N, C, heads, S, hg};
         {
             const dim3 grid(unsigned(x.B * heads), unsigned(S)), block(256);
-            add_op(pfx + ".xca.gram", [pg, grid, block, d](hipStream_t s) { if (d <= 48) ACH_LAUNCH((xca_gram_kernel<T, 48>), grid, block, s, pg); else ACH_LAUNCH((xca_gram_kernel<T, 64>), grid, block, s, pg); },
+            // channel pairs are fetched as one 4-byte (bf16) / 8-byte (fp32) load; where a group's channels are not whole 16-byte pieces
+            // (d = 18, 30 in bf16) and the Gram matrix is small, the VALU kernel is faster (measured: EN-S2 stage 2, 30.7 vs 35.4 us)
+            const bool mf = xca_mfma && d % 2 == 0 && hg > 0 && ((hg * d) % VEC == 0 || tmx >= 3);
+            const dim3 gridm(unsigned(x.B * (mf ? heads / hg : 1)), unsigned(S));
+            const bool small = hg * d <= 48;
+            add_op(pfx + ".xca.gram", [pg, grid, gridm, block, d, mf, small](hipStream_t s) {
+                       if (mf) { if (small) ACH_LAUNCH((xca_gram_mfma_kernel<T, 48>), gridm, block, s, pg); else ACH_LAUNCH((xca_gram_mfma_kernel<T, 64>), gridm, block, s, pg); }
+                       else if (d <= 48) ACH_LAUNCH((xca_gram_kernel<T, 48>), grid, block, s, pg); else ACH_LAUNCH((xca_gram_kernel<T, 64>), grid, block, s, pg); },
                    2.0 * x.rows() * C * sizeof(T));
         }
         Packed pe = pack_shape(C, C);

@@ -413,6 +413,7 @@ inline bool launch_mlp(const MlpParams& p, int DT, bool split, hipStream_t strea
 #undef ACH_MLP_CASE
     return false;
 }
+inline bool mlp_even_dt(int DT) { return DT == 10; }      // d = 96 (DT 6) re-measured at the 128-register budget: 45 -> 49 us per block, still not instantiated
 inline int mlp_pick_dt(int C) {
     const int need = 2 * ((C + 31) / 32);
     for (int dt : {2, 4, 6, 8, 10, 12, 18, 20}) if (dt >= need) return dt;

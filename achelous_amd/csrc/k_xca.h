@@ -18,7 +18,7 @@ namespace ach {
 constexpr int XCA_CT = 32;       // output-channel tile of xca_finalize: one workgroup per (sample, head, tile) — the softmax is recomputed
                                  // per tile (d x d, cheap) so that the fold runs on 4-6x more workgroups instead of a serial loop
 
-struct XcaGramParams { const void* qkv; long ld; float* partial; int B, N, C, heads, S; };
+struct XcaGramParams { const void* qkv; long ld; float* partial; int B, N, C, heads, S; int hg; };   // hg: heads per workgroup (xca_gram_mfma_kernel)
 
 // partial layout per (b, h, s): [d*d gram | d sum q^2 | d sum k^2]
 template <class T, int XCA_DMAX>
@@ -74,6 +74,112 @@ __global__ __launch_bounds__(256) void xca_gram_kernel(const XcaGramParams p) {
         if (pr < npair) out[pr] = acc[e];
     }
     if (tid < 2 * d) out[npair + tid] = nacc;
+}
+
+// The same partial sums on the matrix cores (option `xca_mfma`, default): gram = Q^T K is an MFMA with the TOKENS as the k index, so both
+// operands are token-contiguous fragments of one channel — the transpose of how qkv is stored.  A workgroup takes a GROUP of `hg`
+// consecutive heads (hg d <= XCA_DMAX channels: 8 heads of 8, 4 of 12, 2 of 24, one of 36 / 44 / 56) so that a token row contributes one
+// contiguous run of hg d channels, and a round stages 4 k-steps of tokens (128 in bf16, 64 in fp32) of q and k TRANSPOSED into LDS
+// ([channel][token], 4-byte / 8-byte global loads of channel pairs); every fragment is then one 16-byte LDS read.  Work items, dealt to the
+// four waves: per head the ceil(d/16)^2 gram tiles plus, for the squared norms, the 2 ceil(d/16) diagonal tiles of Q^T Q and K^T K (only
+// their diagonals are stored).  A head's tiles start at its first channel, not at a multiple of 16; rows that belong to the next head
+// produce entries that are simply not stored.  Same output layout as xca_gram_kernel; the sums differ from it only in the order of the
+// fp32 additions.  (One head per workgroup was slower than the VALU kernel for d <= 18: 16- / 24-byte pieces of every token row.)
+template <class T, int XCA_DMAX>
+__global__ __launch_bounds__(256) void xca_gram_mfma_kernel(const XcaGramParams p) {
+    constexpr int VEC = Store<T>::VEC, KC = 4 * VEC;        // tokens per MFMA k-step
+    constexpr int CH = 4 * KC;                              // tokens staged per round
+    constexpr int PITCH = CH + VEC;                         // + 16 bytes: rows land on different banks
+    constexpr int ROWS = XCA_DMAX + 16;                     // a head's last tile may reach 15 rows past the group's channels (zeros)
+    constexpr int MAXIT = 6;                                // items per wave: 8 heads x 3, 3 heads x 8, one head of 4 x 4 + 8 -> 24 in all
+    __shared__ __attribute__((aligned(16))) T ts[2][ROWS][PITCH];
+    const int ngroups = (p.heads + p.hg - 1) / p.hg;
+    const int b = blockIdx.x / ngroups, grp = blockIdx.x - b * ngroups, sp = blockIdx.y;
+    const int h0 = grp * p.hg, nh = (h0 + p.hg <= p.heads) ? p.hg : p.heads - h0;
+    const int d = p.C / p.heads, gc2 = (nh * d) >> 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 15, g = lane >> 4;
+    const int per = (p.N + p.S - 1) / p.S;
+    const int n_lo = sp * per, n_hi = (n_lo + per < p.N) ? n_lo + per : p.N;
+    const T* base = static_cast<const T*>(p.qkv) + long(b) * p.N * p.ld + h0 * d;
+    const int tm = (d + 15) >> 4, ngram = tm * tm, per_head = ngram + 2 * tm, nitems = nh * per_head;
+    {   // rows past the group's channels stay zero (16-byte stores; the staged rows are rewritten every round)
+        const int r0 = nh * d, nv = (ROWS - r0) * (PITCH / VEC);
+        for (int e = tid; e < 2 * nv; e += 256) {
+            const int which = e >= nv, k = e - which * nv;
+            reinterpret_cast<uint4*>(&ts[which][r0][0])[k] = make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
+    // a token row's q (or k) channels of this group as 16-byte pieces when everything is 16-byte aligned (12 x 4, 24 x 2, 8 x 8 channels),
+    // else as channel pairs
+    const bool wide = ((h0 * d) % VEC == 0) && ((nh * d) % VEC == 0) && (p.C % VEC == 0) && (p.ld % VEC == 0);
+    const int gv = (nh * d) / VEC;
+    f32x4 acc[MAXIT];
+    ACH_UNROLL
+    for (int it = 0; it < MAXIT; ++it) { acc[it][0] = 0.f; acc[it][1] = 0.f; acc[it][2] = 0.f; acc[it][3] = 0.f; }
+    // this wave's items: (head, operand arrays, first rows) are the same in every round
+    int rowa[MAXIT], rowb[MAXIT];                           // row index + which * ROWS
+    ACH_UNROLL
+    for (int it = 0; it < MAXIT; ++it) {
+        const int item = wave + 4 * it;
+        rowa[it] = rowb[it] = 0;
+        if (item >= nitems) continue;
+        const int hh = item / per_head, k = item - hh * per_head;
+        if (k < ngram) { const int ti = k / tm, tj = k - ti * tm; rowa[it] = hh * d + ti * 16; rowb[it] = ROWS + hh * d + tj * 16; }
+        else { const int w = (k - ngram) / tm, t = (k - ngram) - w * tm; rowa[it] = rowb[it] = w * ROWS + hh * d + t * 16; }
+    }
+    const T* tsf = &ts[0][0][0];
+    for (int n0 = n_lo; n0 < n_hi; n0 += CH) {
+        __syncthreads();
+        if (wide) {
+            for (int e = tid; e < 2 * CH * gv; e += 256) {
+                const int which = e / (CH * gv), r = e - which * CH * gv;
+                const int t = r / gv, cv = r - t * gv, n = n0 + t;
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (n < n_hi) v = *reinterpret_cast<const uint4*>(base + long(n) * p.ld + which * p.C + cv * VEC);
+                T el[VEC];
+                __builtin_memcpy(el, &v, sizeof(v));
+                ACH_UNROLL
+                for (int i = 0; i < VEC; ++i) ts[which][cv * VEC + i][t] = el[i];
+            }
+        } else
+        for (int e = tid; e < 2 * CH * gc2; e += 256) {
+            const int which = e / (CH * gc2), r = e - which * CH * gc2;
+            const int t = r / gc2, cp = r - t * gc2, n = n0 + t;
+            T v0 = T{}, v1 = v0;
+            if (n < n_hi) { const T* src = base + long(n) * p.ld + which * p.C + 2 * cp; v0 = src[0]; v1 = src[1]; }
+            ts[which][2 * cp][t] = v0; ts[which][2 * cp + 1][t] = v1;
+        }
+        __syncthreads();
+        ACH_UNROLL
+        for (int ks = 0; ks < 4; ++ks) {
+            if (n0 + ks * KC >= n_hi) continue;
+            ACH_UNROLL
+            for (int it = 0; it < MAXIT; ++it) {
+                if (wave + 4 * it >= nitems) continue;
+                const uint4 fa = *reinterpret_cast<const uint4*>(tsf + (rowa[it] + col) * PITCH + ks * KC + g * VEC);
+                const uint4 fb = *reinterpret_cast<const uint4*>(tsf + (rowb[it] + col) * PITCH + ks * KC + g * VEC);
+                mfma16<T>(fa, fb, acc[it]);
+            }
+        }
+    }
+    ACH_UNROLL
+    for (int it = 0; it < MAXIT; ++it) {
+        const int item = wave + 4 * it;
+        if (item >= nitems) continue;
+        const int hh = item / per_head, k = item - hh * per_head;
+        float* out = p.partial + ((long(b) * p.heads + h0 + hh) * p.S + sp) * (d * d + 2 * d);
+        if (k < ngram) {                                        // acc[r] = D[4 g + r][col] of the tile
+            const int ti = k / tm, tj = k - ti * tm, j = tj * 16 + col;
+            ACH_UNROLL
+            for (int r = 0; r < 4; ++r) { const int i = ti * 16 + 4 * g + r; if (i < d && j < d) out[i * d + j] = acc[it][r]; }
+        } else {
+            const int w = (k - ngram) / tm, t = (k - ngram) - w * tm, i = t * 16 + col;
+            const int rr = col & 3;
+            const float dv = rr == 0 ? acc[it][0] : (rr == 1 ? acc[it][1] : (rr == 2 ? acc[it][2] : acc[it][3]));
+            if ((col >> 2) == g && i < d) out[d * d + w * d + i] = dv;
+        }
+    }
 }
 
 struct XcaFinalParams {

@@ -132,7 +132,7 @@ def test_emulated_forward_detect_equals_the_three_calls():
     assert int(cnt[0]) > 0
 
 
-@pytest.mark.parametrize('option', ['fused_mlp', 'row_conv', 'fused_rc', 'dw_tile', 'head_batch', 'split_decoders', 'head_stream', 'streams', 'stem_mfma', 'radar_start', 'dw_even', 'radar_rows4'])
+@pytest.mark.parametrize('option', ['fused_mlp', 'row_conv', 'fused_rc', 'dw_tile', 'head_batch', 'split_decoders', 'head_stream', 'streams', 'stem_mfma', 'radar_start', 'dw_even', 'radar_rows4', 'xca_mfma'])
 def test_emulated_kernel_switches_agree(option):
     """Each fused / batched kernel against the layer-wise launches it replaced, through the C ABI on the CPU emulation (fp32)."""
     kw, sd, (x, xr, xp) = _setup('en_s0', 64, 1, 16)
