@@ -194,7 +194,7 @@ struct XcaFinalParams {
 
 template <class T, int XCA_DMAX>
 __global__ __launch_bounds__(256) void xca_finalize_kernel(const XcaFinalParams p) {
-    __shared__ float A[XCA_DMAX][XCA_DMAX + 1];
+    __shared__ __attribute__((aligned(16))) float A[XCA_DMAX][XCA_DMAX + 4];     // rows 16-byte aligned: the fold reads four columns at once
     __shared__ float nq[XCA_DMAX], nk[XCA_DMAX];
     __shared__ float wps[XCA_CT][XCA_DMAX + 1];
     const int bh = blockIdx.x;
@@ -209,17 +209,23 @@ __global__ __launch_bounds__(256) void xca_finalize_kernel(const XcaFinalParams 
         else if (e < npair + d) nq[e - npair] = fmaxf(sqrtf(s), 1e-12f);
         else nk[e - npair - d] = fmaxf(sqrtf(s), 1e-12f);
     }
+    for (int e = tid; e < d * 4; e += 256) A[e >> 2][d + (e & 3)] = 0.f;       // the fold's last column group reads up to three columns past d
     __syncthreads();
     const float temp = p.temperature[h];
     for (int e = tid; e < npair; e += 256) { const int i = e / d, j = e % d; A[i][j] = A[i][j] / (nq[i] * nk[j]) * temp; }
     __syncthreads();
-    if (tid < d) {
+    {   // row softmax, four lanes per row (d <= 64 rows: all 256 threads): each lane takes every fourth column, the row maximum and the
+        // row sum are combined over the four lanes with two butterfly steps (one thread per row was a chain of 3 d dependent LDS round trips)
+        const int i = tid >> 2, q = tid & 3;
+        const bool row = i < d;
         float mx = -3.0e38f;
-        for (int j = 0; j < d; ++j) mx = fmaxf(mx, A[tid][j]);
+        if (row) for (int j = q; j < d; j += 4) mx = fmaxf(mx, A[i][j]);
+        mx = fmaxf(mx, __shfl_xor(mx, 1)); mx = fmaxf(mx, __shfl_xor(mx, 2));
         float sum = 0.f;
-        for (int j = 0; j < d; ++j) { const float e = expf(A[tid][j] - mx); A[tid][j] = e; sum += e; }
+        if (row) for (int j = q; j < d; j += 4) { const float e = expf(A[i][j] - mx); A[i][j] = e; sum += e; }
+        sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2);
         const float inv = 1.0f / sum;
-        for (int j = 0; j < d; ++j) A[tid][j] *= inv;
+        if (row) for (int j = q; j < d; j += 4) A[i][j] *= inv;
     }
     __syncthreads();
     if (p.attn && blockIdx.y == 0) for (int e = tid; e < npair; e += 256) p.attn[long(bh) * npair + e] = A[e / d][e % d];
@@ -232,17 +238,26 @@ __global__ __launch_bounds__(256) void xca_finalize_kernel(const XcaFinalParams 
         __syncthreads();
         for (int e = tid; e < rows * d; e += 256) { const int r = e / d, i = e - r * d; wps[r][i] = p.Wproj[long(c0 + r) * p.C + h * d + i]; }
         __syncthreads();
-        for (int e = tid; e < rows * d; e += 256) {
-            const int r = e / d, j = e - r * d;
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;          // 4 independent chains: LDS reads of a group are all in flight
-            int i = 0;
-            for (; i + 4 <= d; i += 4) {
-                s0 += A[i][j] * wps[r][i]; s1 += A[i + 1][j] * wps[r][i + 1]; s2 += A[i + 2][j] * wps[r][i + 2]; s3 += A[i + 3][j] * wps[r][i + 3];
+        // 2 x 4 register tiles (two output channels x four head columns): per i two broadcast reads of wps and ONE 16-byte read of A feed
+        // eight FMAs — with one output per thread the fold was LDS-bandwidth bound (two 4-byte reads per FMA, 10 us of the stage-3 launch)
+        const int jq = (d + 3) >> 2, ntile = ((rows + 1) >> 1) * jq;
+        for (int e = tid; e < ntile; e += 256) {
+            const int rp = e / jq, r0 = rp * 2, j0 = (e - rp * jq) * 4;
+            const int r1 = r0 + 1 < rows ? r0 + 1 : r0;
+            float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < d; ++i) {
+                const float4 av = *reinterpret_cast<const float4*>(&A[i][j0]);
+                const float w0 = wps[r0][i], w1 = wps[r1][i];
+                a0[0] += av.x * w0; a0[1] += av.y * w0; a0[2] += av.z * w0; a0[3] += av.w * w0;
+                a1[0] += av.x * w1; a1[1] += av.y * w1; a1[2] += av.z * w1; a1[3] += av.w * w1;
             }
-            for (; i < d; ++i) s0 += A[i][j] * wps[r][i];
-            const float s = (s0 + s1) + (s2 + s3);
-            const int co = c0 + r;
-            Store<T>::st(W + wfrag_offset(co, h * d + j, p.NT, p.ksteps, Store<T>::VEC), s * p.gamma[co]);
+            ACH_UNROLL
+            for (int q = 0; q < 4; ++q) {
+                const int j = j0 + q;
+                if (j >= d) continue;
+                Store<T>::st(W + wfrag_offset(c0 + r0, h * d + j, p.NT, p.ksteps, Store<T>::VEC), a0[q] * p.gamma[c0 + r0]);
+                if (r1 != r0) Store<T>::st(W + wfrag_offset(c0 + r1, h * d + j, p.NT, p.ksteps, Store<T>::VEC), a1[q] * p.gamma[c0 + r1]);
+            }
         }
     }
 }
