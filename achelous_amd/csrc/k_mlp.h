@@ -216,12 +216,15 @@ __device__ __forceinline__ void mlp_inputs(const MlpParams& p, long m, bool vali
 #ifndef ACH_MLP_OCC_12
 #define ACH_MLP_OCC_12 3
 #endif
-template <int DT, bool SPLIT> struct MlpOcc {
-    static constexpr int blocks = (SPLIT && DT > 6) ? 2 : (SPLIT && DT > ACH_MLP_PIPE_SPLIT_DT) ? ACH_MLP_OCC_SPLIT_PIPE : (DT <= 6 ? ACH_MLP_OCC_SMALL : (DT <= 10 ? ACH_MLP_OCC_10 : (DT <= 12 ? ACH_MLP_OCC_12 : 2)));
+// fp32 storage (the parity engine): a hidden chunk is two k-steps of the second GEMM, the prefetched fragments of the narrow SPLIT widths do
+// not fit four workgroups per CU (332 bytes of spills at DT 6) — those keep the plain chunk loop and the small budget.
+template <int DT, bool SPLIT, int VEC> struct MlpOcc {
+    static constexpr int pipe_split_dt = VEC == 8 ? ACH_MLP_PIPE_SPLIT_DT : 6;
+    static constexpr int blocks = (SPLIT && DT > 6) ? 2 : (SPLIT && DT > pipe_split_dt) ? ACH_MLP_OCC_SPLIT_PIPE : (DT <= 6 ? ACH_MLP_OCC_SMALL : (DT <= 10 ? ACH_MLP_OCC_10 : (DT <= 12 ? ACH_MLP_OCC_12 : 2)));
 };
 
 template <class T, int DT, bool SPLIT, bool EVEN = false>
-__global__ __launch_bounds__(256, (MlpOcc<DT, SPLIT>::blocks)) void mlp_kernel(const MlpParams p) {
+__global__ __launch_bounds__(256, (MlpOcc<DT, SPLIT, Store<T>::VEC>::blocks)) void mlp_kernel(const MlpParams p) {
     constexpr int VEC = Store<T>::VEC;
     constexpr int KC = 4 * VEC;
     constexpr int K1MAX = (16 * DT + KC - 1) / KC;
@@ -292,7 +295,7 @@ __global__ __launch_bounds__(256, (MlpOcc<DT, SPLIT>::blocks)) void mlp_kernel(c
     // with a branch per k-step every pair of MFMAs waited for its own L2 round trip).
     // DT <= 6 keeps the small register budget (more workgroups per CU next to the side streams: measured better end to end);
     // DT > 12: branch-free, but the next chunk's fragments are not requested ahead (they would spill).
-    constexpr bool PIPE = SPLIT ? DT > ACH_MLP_PIPE_SPLIT_DT : DT <= ACH_MLP_PIPE_FLAT_DT;
+    constexpr bool PIPE = SPLIT ? DT > MlpOcc<DT, SPLIT, VEC>::pipe_split_dt : DT <= ACH_MLP_PIPE_FLAT_DT;
     constexpr bool AHEAD = PIPE && DT <= 12;
     constexpr int JS = SPLIT ? 4 : 1;
     const int j0 = SPLIT ? wave : 0;
