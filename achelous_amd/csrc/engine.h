@@ -74,6 +74,7 @@ public:
     // (1.36 ms vs 1.66 ms): HIP's graph executor serialises more of the three-branch DAG than the streams do.
     bool use_graph = false;
     bool multi_stream = true;         // option "streams": run the independent radar / point branches on side streams
+    int gemm_rows = 1;                // option "gemm_rows": 16-row sub-tiles per wave (1 / 2 / 4) for GEMMs with K >= 1024 (the dense 3x3 convs of MobileViT)
     bool xca_mfma = true;             // option "xca_mfma": XCA Gram matrices on the matrix cores (xca_gram_mfma_kernel, k_xca.h); 0 = the VALU kernel
     bool dw_even = true;              // option "dw_even": SPLIT mlp_kernel deals depthwise tap ROWS, not whole k-steps, to its four waves (k_mlp.h)
     int radar_rows4 = 2;              // option "radar_rows4": a workgroup of rc_front owns four rows, one per wave (1: block 0 when radar_skip is on; 2: every

@@ -17,6 +17,11 @@
 
 namespace ach {
 
+#ifndef ACH_MV2_DEBUG
+#define ACH_MV2_DEBUG 0                   // timing builds only: 1 = ReLU instead of SiLU on the hidden map (wrong results)
+#endif
+__device__ __forceinline__ float mv2_silu(float x) { return (ACH_MV2_DEBUG & 1) ? fmaxf(x, 0.f) : x * sigmoidf_(x); }
+
 struct Mv2Params {
     const void* X; long ldx;                  // NHWC [B,H,W,Cin], ldx >= k1 * 4 * VEC (channel padding zero)
     void* Y; long ldy;                        // NHWC [B,Ho,Wo,Cout]
@@ -84,7 +89,7 @@ __global__ __launch_bounds__(256, STRIDE == 2 ? 3 : 4) void mv2_kernel(const Mv2
                     const float4 bb = *reinterpret_cast<const float4*>(p.b1 + ch);
                     float v[4] = {acc[t][0] + bb.x, acc[t][1] + bb.y, acc[t][2] + bb.z, acc[t][3] + bb.w};
                     ACH_UNROLL
-                    for (int r = 0; r < 4; ++r) v[r] = in_map ? v[r] * sigmoidf_(v[r]) : 0.f;
+                    for (int r = 0; r < 4; ++r) v[r] = in_map ? mv2_silu(v[r]) : 0.f;
                     Store<T>::st4(reinterpret_cast<T*>(dst) + ch, v);
                 }
             }
@@ -150,7 +155,7 @@ __global__ __launch_bounds__(256, STRIDE == 2 ? 3 : 4) void mv2_kernel(const Mv2
             if (tile0 + 4 * q >= PT) continue;
             float h[8];
             ACH_UNROLL
-            for (int j = 0; j < VEC; ++j) h[j] = a[q][j] * sigmoidf_(a[q][j]);
+            for (int j = 0; j < VEC; ++j) h[j] = mv2_silu(a[q][j]);
             const uint4 bf = frag_pack<T>(h);
             ACH_UNROLL
             for (int t = 0; t < NT2; ++t) mfma16<T>(wf[t], bf, acc[q][t]);

@@ -539,3 +539,25 @@ def test_mobilevit_other_widths_match_oracle(phi):
         det, se, lane, pc = m(x.cuda().bfloat16(), xr.cuda().bfloat16(), xp.cuda().bfloat16())
         for k, a, b, c in zip(OUTPUTS, (*det, se, lane, pc), (*ref[0], ref[1], ref[2], ref[3]), (*amp[0], amp[1], amp[2], amp[3])):
             assert _rel(a.float(), b.float()) <= max(2e-2, 2.0 * _rel(c.float(), b.float())), k
+
+
+@pytest.mark.parametrize('rows', [2, 4])
+def test_gemm_rows_per_wave_is_bit_identical(rows):
+    """Option gemm_rows: the dense 3x3 convs of the MobileViT blocks (K = 9 x 2C >= 1024) with two / four 16-row sub-tiles per wave, so a
+    weight fragment fetched from L2 feeds several MFMAs.  A row's k-loop is unchanged, so the plans agree BIT FOR BIT with one sub-tile."""
+    g = Golden('mv_s2')
+    m, kw = _model(g)
+    x, xr, xp = make_inputs(8, 31, resolution=kw['resolution'], pc_channels=kw['pc_channels'])
+    xs, rs, ps = x.cuda().bfloat16(), xr.cuda().bfloat16(), xp.cuda().bfloat16()
+    with torch.no_grad():
+        e = _engine_of(m, torch.bfloat16) if False else None
+        base = m(xs, rs, ps)
+        e = _engine_of(m, torch.bfloat16)
+        default_rows = 1
+        e.set_option('gemm_rows', 1); e.plan(8)
+        one = m(xs, rs, ps)
+        e.set_option('gemm_rows', rows); e.plan(8)
+        many = m(xs, rs, ps)
+        torch.cuda.synchronize()
+    for a, b, c in zip((*one[0], one[1], one[2]), (*many[0], many[1], many[2]), (*base[0], base[1], base[2])):
+        assert torch.equal(a, b) and torch.equal(a, c)
