@@ -100,7 +100,13 @@ int ach_load_weights(ach_handle* h, const ach_tensor_desc* tensors, size_t n);
  * "head_stream" (1: radar + point branches share low-priority stream 1, fusion + head + NMS run on stream 2 at the caller's priority; default 0: they queue behind the radar branch on stream 1),
  * "side_priority" (with head_stream = 0: bit mask of the side streams created at the lowest stream priority),
  * "point_stream2" (-1 auto / 0 / 1: the point branch opens stream 2 ahead of fusion + head; auto = PointNet++ only),
- * "stem_mfma" (the 4x4/s4 stem conv as an MFMA GEMM gathered from the NCHW image; 0: scalar-FMA kernel). */
+ * "stem_mfma" (the 4x4/s4 stem conv as an MFMA GEMM gathered from the NCHW image; 0: scalar-FMA kernel),
+ * "radar_skip" (closed-form shortcut for empty 16-pixel segments of the first RCBlock, bit-identical), "radar_rows4" (0 / 1 / 2: a
+ * workgroup owns four rows in the first / in all fused RCBlocks and the row-walking conv), "radar_start" (the radar branch is released
+ * after backbone stage 1), "dw_even" (even deal of depthwise tap rows over the four SPLIT waves, d = 144), "xca_mfma" (XCA Gram
+ * matrices on the matrix cores; 0: VALU kernel), "head_mfma" (default 0: bilinear phase of the fused segmentation head on MFMA —
+ * measured slower), "gemm_rows" (default 1: 16-row sub-tiles per wave for GEMMs with K >= 1024 — 2 / 4 measured slower),
+ * "pipeline" (see ach_join).  DESIGN.md §4 has the measurement behind every default. */
 int ach_set_option(ach_handle* h, const char* key, int32_t value);
 
 /* Builds the launch plan and the activation arena for batch size B (re-plan to change B). */
