@@ -79,9 +79,16 @@ void* EngineBase::aalloc(size_t bytes) {
     aarena_used += bytes;
     return p;
 }
+// Every fp32 vector is followed by 64 zeros: the GEMM epilogues fetch the bias of a whole 16 NT-channel chunk with unconditional 16-byte
+// loads (channels >= N of the last chunk read the zeros; their results are never stored).
 float* EngineBase::up_f32(const std::vector<float>& v) {
-    float* d = static_cast<float*>(walloc(v.size() * sizeof(float)));
-    if (!measuring) ACH_HIP_CHECK(hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+    constexpr size_t kTail = 64;
+    float* d = static_cast<float*>(walloc((v.size() + kTail) * sizeof(float)));
+    if (!measuring) {
+        std::vector<float> padded(v.size() + kTail, 0.f);
+        std::copy(v.begin(), v.end(), padded.begin());
+        ACH_HIP_CHECK(hipMemcpy(d, padded.data(), padded.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     return d;
 }
 void EngineBase::reset_plan() {

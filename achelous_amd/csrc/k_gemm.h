@@ -153,6 +153,15 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, unsigned bx, unsi
             ACH_UNROLL
             for (int t = 0; t < NT; ++t) { acc[q][t][0] = 0.f; acc[q][t][1] = 0.f; acc[q][t][2] = 0.f; acc[q][t][3] = 0.f; }
 
+        // the chunk's bias, requested before the k-loop (it used to be 4 NT predicated dword loads AFTER it, their latency exposed): channel
+        // chunk_channel(NT, t, g, r) = one 16-byte piece per tile; the vector is followed by zeros (EngineBase::up_f32)
+        const int cbase = c * (16 * NT);
+        float bv[4 * NT];
+        ACH_UNROLL
+        for (int t = 0; t < NT; ++t) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + cbase + chunk_channel(NT, t, g, 0));
+            bv[t * 4] = b4[0]; bv[t * 4 + 1] = b4[1]; bv[t * 4 + 2] = b4[2]; bv[t * 4 + 3] = b4[3];
+        }
         // k-loop with the operands of step s+1 requested before the MFMAs of step s are issued: on the small maps a wave's
         // lifetime is a chain of dependent L2 round trips, and this halves the chain
         uint4 xn[P], wn[NT];
@@ -193,12 +202,6 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, unsigned bx, unsi
         }
 
         // ---- epilogue: lane holds, for pixel px of every sub-tile, the channels chunk_channel(NT, t, g, r) of this chunk
-        const int cbase = c * (16 * NT);
-        float bv[4 * NT];
-        ACH_UNROLL
-        for (int t = 0; t < NT; ++t)
-            ACH_UNROLL
-            for (int r = 0; r < 4; ++r) { const int n = cbase + chunk_channel(NT, t, g, r); bv[t * 4 + r] = n < p.N ? bias[n] : 0.f; }
 
         ACH_UNROLL
         for (int q = 0; q < P; ++q) {
