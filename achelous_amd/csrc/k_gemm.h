@@ -67,7 +67,16 @@ __device__ __forceinline__ float order_decode(unsigned e) {
     return __uint_as_float((e & 0x80000000u) ? (e & 0x7fffffffu) : ~e);
 }
 
-template <class T, int NT, int P>
+#ifndef ACH_GEMM_DEPTH
+#define ACH_GEMM_DEPTH 3
+#endif
+constexpr int GEMM_DEPTH = ACH_GEMM_DEPTH;      // operand slots in flight in gemm_body's k-loop (DEEP instantiations)
+#ifndef ACH_GEMM_DEEP_KSTEPS
+#define ACH_GEMM_DEEP_KSTEPS 7
+#endif
+constexpr int GEMM_DEEP_KSTEPS = ACH_GEMM_DEEP_KSTEPS;   // k-steps from which launch_gemm picks them
+
+template <class T, int NT, int P, bool DEEP = false>
 __device__ __forceinline__ void gemm_body(const GemmParams& p, unsigned bx, unsigned nbx, unsigned by, unsigned bz) {
     constexpr int VEC = Store<T>::VEC;
     constexpr int KC = 4 * VEC;
@@ -162,43 +171,88 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, unsigned bx, unsi
             const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + cbase + chunk_channel(NT, t, g, 0));
             bv[t * 4] = b4[0]; bv[t * 4 + 1] = b4[1]; bv[t * 4 + 2] = b4[2]; bv[t * 4 + 3] = b4[3];
         }
-        // k-loop with the operands of step s+1 requested before the MFMAs of step s are issued: on the small maps a wave's
-        // lifetime is a chain of dependent L2 round trips, and this halves the chain
-        uint4 xn[P], wn[NT];
-        ACH_UNROLL
-        for (int q = 0; q < P; ++q) xn[q] = load_x(q, 0);
-        {
-            const uint4* wrow = Wf + (long(c) * p.ksteps) * NT * 64 + lane;
-            ACH_UNROLL
-            for (int t = 0; t < NT; ++t) wn[t] = wrow[t * 64];
-        }
-        for (int s = 0; s < p.ksteps; ++s) {
-            uint4 xf[P], wf[NT];
-            ACH_UNROLL
-            for (int q = 0; q < P; ++q) xf[q] = xn[q];
-            ACH_UNROLL
-            for (int t = 0; t < NT; ++t) wf[t] = wn[t];
-            if (s + 1 < p.ksteps) {
+        if constexpr (DEEP) {
+            // k-loop over a ring of GEMM_DEPTH operand slots: the operands of steps s+1 .. s+DEPTH-1 are in flight while step s runs, and a
+            // slot is refilled with step s+DEPTH right after its MFMAs are issued.  On these shapes a wave's lifetime is a chain of L2 round
+            // trips (4 NT MFMAs = 64 cycles of work per 500+ cycle fetch); one step ahead — with the compiler copying "next" into "current"
+            // registers, i.e. waiting for the fetch right behind the MFMAs — hid a tenth of it.  The loop is unrolled over the ring so that the
+            // slots are plain registers.  DEEP is chosen per launch for K >= GEMM_DEEP_KSTEPS k-steps (launch_gemm): on the short k-loops of the
+            // headline config the ring only costs registers and branches (-2 % frames/s when applied everywhere), on EN-S2 / MV-S2 it pays.
+            constexpr int DEPTH = GEMM_DEPTH;
+            uint4 xb[DEPTH][P], wb[DEPTH][NT];
+            const uint4* wchunk = Wf + (long(c) * p.ksteps) * NT * 64 + lane;
+            auto fill = [&](int d, int s) {
                 ACH_UNROLL
-                for (int q = 0; q < P; ++q) xn[q] = load_x(q, s + 1);
-                const uint4* wrow = Wf + (long(c) * p.ksteps + s + 1) * NT * 64 + lane;
+                for (int q = 0; q < P; ++q) xb[d][q] = load_x(q, s);
+                ACH_UNROLL
+                for (int t = 0; t < NT; ++t) wb[d][t] = wchunk[(long(s) * NT + t) * 64];
+            };
+            ACH_UNROLL
+            for (int d = 0; d < DEPTH; ++d)
+                if (d < p.ksteps) fill(d, d);
+            for (int s0 = 0; s0 < p.ksteps; s0 += DEPTH) {
+                ACH_UNROLL
+                for (int d = 0; d < DEPTH; ++d) {
+                    const int s = s0 + d;
+                    if (s >= p.ksteps) break;
+                    uint4 xf[P];
+                    ACH_UNROLL
+                    for (int q = 0; q < P; ++q) xf[q] = xb[d][q];
+                    if (p.ln) {
+                        ACH_UNROLL
+                        for (int q = 0; q < P; ++q) {
+                            float v[8];
+                            frag_unpack<T>(xf[q], v);
+                            ACH_UNROLL
+                            for (int j = 0; j < VEC; ++j) v[j] = (v[j] - mean[q]) * rstd[q];
+                            xf[q] = frag_pack<T>(v);
+                        }
+                    }
+                    ACH_UNROLL
+                    for (int t = 0; t < NT; ++t)
+                        ACH_UNROLL
+                        for (int q = 0; q < P; ++q) mfma16<T>(wb[d][t], xf[q], acc[q][t]);
+                    if (s + DEPTH < p.ksteps) fill(d, s + DEPTH);
+                }
+            }
+        } else {
+            // the operands of step s+1 requested before the MFMAs of step s are issued
+            uint4 xn[P], wn[NT];
+            ACH_UNROLL
+            for (int q = 0; q < P; ++q) xn[q] = load_x(q, 0);
+            {
+                const uint4* wrow = Wf + (long(c) * p.ksteps) * NT * 64 + lane;
                 ACH_UNROLL
                 for (int t = 0; t < NT; ++t) wn[t] = wrow[t * 64];
             }
-            if (p.ln) {
+            for (int s = 0; s < p.ksteps; ++s) {
+                uint4 xf[P], wf[NT];
                 ACH_UNROLL
-                for (int q = 0; q < P; ++q) {
-                    float v[8];
-                    frag_unpack<T>(xf[q], v);
+                for (int q = 0; q < P; ++q) xf[q] = xn[q];
+                ACH_UNROLL
+                for (int t = 0; t < NT; ++t) wf[t] = wn[t];
+                if (s + 1 < p.ksteps) {
                     ACH_UNROLL
-                    for (int j = 0; j < VEC; ++j) v[j] = (v[j] - mean[q]) * rstd[q];
-                    xf[q] = frag_pack<T>(v);
+                    for (int q = 0; q < P; ++q) xn[q] = load_x(q, s + 1);
+                    const uint4* wrow = Wf + (long(c) * p.ksteps + s + 1) * NT * 64 + lane;
+                    ACH_UNROLL
+                    for (int t = 0; t < NT; ++t) wn[t] = wrow[t * 64];
                 }
-            }
-            ACH_UNROLL
-            for (int t = 0; t < NT; ++t)
+                if (p.ln) {
+                    ACH_UNROLL
+                    for (int q = 0; q < P; ++q) {
+                        float v[8];
+                        frag_unpack<T>(xf[q], v);
+                        ACH_UNROLL
+                        for (int j = 0; j < VEC; ++j) v[j] = (v[j] - mean[q]) * rstd[q];
+                        xf[q] = frag_pack<T>(v);
+                    }
+                }
                 ACH_UNROLL
-                for (int q = 0; q < P; ++q) mfma16<T>(wf[t], xf[q], acc[q][t]);
+                for (int t = 0; t < NT; ++t)
+                    ACH_UNROLL
+                    for (int q = 0; q < P; ++q) mfma16<T>(wf[t], xf[q], acc[q][t]);
+            }
         }
 
         // ---- epilogue: lane holds, for pixel px of every sub-tile, the channels chunk_channel(NT, t, g, r) of this chunk
@@ -268,8 +322,8 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, unsigned bx, unsi
     }
 }
 
-template <class T, int NT, int P>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) { gemm_body<T, NT, P>(p, blockIdx.x, gridDim.x, blockIdx.y, blockIdx.z); }
+template <class T, int NT, int P, bool DEEP = false>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) { gemm_body<T, NT, P, DEEP>(p, blockIdx.x, gridDim.x, blockIdx.y, blockIdx.z); }
 
 // Up to three independent GEMMs of the same tile shape in one launch (blockIdx.y = job): the three pyramid levels of the
 // detection head run the same layer on maps of 1600 / 400 / 100 pixels — the small levels ride in the big level's launch
@@ -380,6 +434,11 @@ __global__ __launch_bounds__(256) void gemm_colmax_kernel(const GemmMaxParams p)
 template <class T>
 inline void launch_gemm(const GemmParams& p, int NT, int P, hipStream_t stream) {
     const dim3 grid(unsigned(cdivl(p.M_per_group, 64L * P)), unsigned(p.groups), unsigned(cdiv(p.nchunks, p.chunks_per_block))), block(256);
+    if (P == 1 && p.ksteps >= GEMM_DEEP_KSTEPS) {
+        if (NT == 1) { ACH_LAUNCH((gemm_kernel<T, 1, 1, true>), grid, block, stream, p); return; }
+        if (NT == 2) { ACH_LAUNCH((gemm_kernel<T, 2, 1, true>), grid, block, stream, p); return; }
+        if (NT == 4) { ACH_LAUNCH((gemm_kernel<T, 4, 1, true>), grid, block, stream, p); return; }
+    }
 #define ACH_GEMM_CASE(nt, pp) if (NT == nt && P == pp) { ACH_LAUNCH((gemm_kernel<T, nt, pp>), grid, block, stream, p); return; }
     ACH_GEMM_CASE(1, 1) ACH_GEMM_CASE(1, 2) ACH_GEMM_CASE(1, 4)
     ACH_GEMM_CASE(2, 1) ACH_GEMM_CASE(2, 2) ACH_GEMM_CASE(2, 4)
