@@ -145,9 +145,14 @@ __global__ __launch_bounds__(256) void mvit_attn_mfma_kernel(const MvitAttnParam
     const float sc = p.scale * 1.44269504088896341f;
     const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
     // the lane's share of a K fragment (A operand: row = key, k = d): bf16: g == 0 holds d 0..7 ; fp32: g < 2 hold d 4g .. 4g+3
+    // Every lane reads LDS unconditionally and the lanes that hold no part of the fragment are masked to zero afterwards: written as
+    // `g == 0 ? *lds_ptr : zero` the compiler selected between the LDS POINTER and the address of `zero` in scratch and fetched the fragment
+    // with four generic flat_load_dword — each waited for with vmcnt(0) lgkmcnt(0) right before its MFMA (16 of them in the chunk loop).
+    const unsigned kmask = (VEC == 8 ? g == 0 : g < 2) ? 0xffffffffu : 0u;
     auto kfrag = [&](int t) -> uint4 {
-        if (VEC == 8) return g == 0 ? *reinterpret_cast<const uint4*>(ks + (t * 16 + col) * MVIT_DH) : zero;
-        return g < 2 ? *reinterpret_cast<const uint4*>(ks + (t * 16 + col) * MVIT_DH + 4 * g) : zero;
+        uint4 v = *reinterpret_cast<const uint4*>(ks + (t * 16 + col) * MVIT_DH + (VEC == 8 ? 0 : 4 * (g & 1)));
+        v.x &= kmask; v.y &= kmask; v.z &= kmask; v.w &= kmask;
+        return v;
     };
     // TWO query tiles per wave and pass (QT): every score MFMA feeds its exponentials at once, so a single tile is one dependent chain
     // (MFMA -> exp2 -> pack -> MFMA into the running output); a second, independent tile fills its bubbles (119 -> see DESIGN, 40x40 maps)
@@ -203,8 +208,14 @@ __global__ __launch_bounds__(256) void mvit_attn_mfma_kernel(const MvitAttnParam
             const bool partial = c >= full_chunks;                                    // the last chunk may hold keys past N
             uint4 kf[VEC / 4];
             ACH_UNROLL
-            for (int w = 0; w < VEC / 4; ++w) { const int t = c * (VEC / 4) + w; kf[w] = t < ntiles ? kfrag(t) : zero; }
-            const uint4 vf = col < MVIT_DH ? *reinterpret_cast<const uint4*>(vt + ((c * MVIT_DH + col) * 4 + g) * VEC) : zero;      // A: row = d, k = slot
+            for (int w = 0; w < VEC / 4; ++w) {
+                const int t = c * (VEC / 4) + w;
+                kf[w] = kfrag(t < ntiles ? t : ntiles - 1);                           // same reason: clamp the tile, mask the value
+                const unsigned tm = t < ntiles ? 0xffffffffu : 0u;
+                kf[w].x &= tm; kf[w].y &= tm; kf[w].z &= tm; kf[w].w &= tm;
+            }
+            uint4 vf = *reinterpret_cast<const uint4*>(vt + ((c * MVIT_DH + (col & (MVIT_DH - 1))) * 4 + g) * VEC);                // A: row = d, k = slot
+            { const unsigned vm = col < MVIT_DH ? 0xffffffffu : 0u; vf.x &= vm; vf.y &= vm; vf.z &= vm; vf.w &= vm; }
             ACH_UNROLL
             for (int u = 0; u < QT; ++u) {
                 float pj[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
