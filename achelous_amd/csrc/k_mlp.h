@@ -207,6 +207,9 @@ __device__ __forceinline__ void mlp_inputs(const MlpParams& p, long m, bool vali
 #ifndef ACH_MLP_OCC_SPLIT_PIPE
 #define ACH_MLP_OCC_SPLIT_PIPE 4
 #endif
+#ifndef ACH_MLP_OCC_4
+#define ACH_MLP_OCC_4 ACH_MLP_OCC_SMALL
+#endif
 #ifndef ACH_MLP_OCC_SMALL
 #define ACH_MLP_OCC_SMALL 6
 #endif
@@ -220,7 +223,7 @@ __device__ __forceinline__ void mlp_inputs(const MlpParams& p, long m, bool vali
 // not fit four workgroups per CU (332 bytes of spills at DT 6) — those keep the plain chunk loop and the small budget.
 template <int DT, bool SPLIT, int VEC> struct MlpOcc {
     static constexpr int pipe_split_dt = VEC == 8 ? ACH_MLP_PIPE_SPLIT_DT : 6;
-    static constexpr int blocks = (SPLIT && DT > 6) ? 2 : (SPLIT && DT > pipe_split_dt) ? ACH_MLP_OCC_SPLIT_PIPE : (DT <= 6 ? ACH_MLP_OCC_SMALL : (DT <= 10 ? ACH_MLP_OCC_10 : (DT <= 12 ? ACH_MLP_OCC_12 : 2)));
+    static constexpr int blocks = (SPLIT && DT > 6) ? 2 : (SPLIT && DT > pipe_split_dt) ? ACH_MLP_OCC_SPLIT_PIPE : (DT == 4 ? ACH_MLP_OCC_4 : DT <= 6 ? ACH_MLP_OCC_SMALL : (DT <= 10 ? ACH_MLP_OCC_10 : (DT <= 12 ? ACH_MLP_OCC_12 : 2)));
 };
 
 template <class T, int DT, bool SPLIT, bool EVEN = false>
