@@ -1,15 +1,16 @@
 #!/usr/bin/env python3
 """Per-launch VALU / texture / MFMA busy fractions from the counter passes of pmc_counters.sh.
-usage: python profiles/scripts/pmc_summary.py gpurun_out/ctr_en_s0 profiles/r02_ops_en_s0.json > profiles/r02_pmc_summary_en_s0.txt
+usage: python profiles/scripts/pmc_summary.py profiles/r02_pmc profiles/r02_ops_en_s0.json > profiles/r02_pmc_summary_en_s0.txt
 A launch's row is the LAST forward's dispatch of that launch (dispatch order = plan order: single-stream forward)."""
 import csv, glob, gzip, json, sys, collections
 root = sys.argv[1]
-ops = json.load(open(f'{root}/ops.json'))['ops']
+import os
+ops = json.load(open(f'{root}/ops.json' if os.path.exists(f'{root}/ops.json') else glob.glob(f'{root}/*_ops.json')[0]))['ops']
 iso = {o['op']: o['ms'] for o in json.load(open(sys.argv[2]))['ops']} if len(sys.argv) > 2 else {}     # isolated times: profiles/r02_ops_<cfg>.json
 for o in ops: o['ms'] = iso.get(o['op'], 0.0)
 n = len(ops)
 cnt = collections.defaultdict(dict)                      # dispatch index -> counter -> value
-for f in glob.glob(f'{root}/g*/**/*counter_collection.csv.gz', recursive=True):
+for f in glob.glob(f'{root}/g*/**/*counter_collection.csv.gz', recursive=True) + glob.glob(f'{root}/*_group*.csv.gz'):     # ONE file per group
     rows = list(csv.DictReader(gzip.open(f, 'rt')))
     ach = [r for r in rows if r['Kernel_Name'].startswith(('void ach::', 'ach::'))]
     ids = sorted({int(r['Dispatch_Id']) for r in ach})
