@@ -2,7 +2,7 @@
 
 `Achelous` mirrors the reference `nets.Achelous.Achelous` (constructor, forward signature, outputs, state_dict
 keys); the arithmetic runs in hand-written HIP kernels behind the C ABI of include/achelous.h."""
-from .nets import Achelous
+from .nets import Achelous, Achelous3T
 from .postprocess import decode_outputs, non_max_suppression
 
-__all__ = ['Achelous', 'decode_outputs', 'non_max_suppression']
+__all__ = ['Achelous', 'Achelous3T', 'decode_outputs', 'non_max_suppression']

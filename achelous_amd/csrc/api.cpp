@@ -47,9 +47,9 @@ int ach_create(const ach_config* cfg, ach_handle** out) {
             throw ach::AchError{ACH_ERR_UNSUPPORTED, "backbone must be 'en' or 'mv'"};
         if (cfg->phi < ACH_PHI_S0 || cfg->phi > ACH_PHI_S2) throw ach::AchError{ACH_ERR_UNSUPPORTED, "phi must be S0, S1 or S2"};
         if (cfg->neck != ACH_NECK_GDF && cfg->neck != ACH_NECK_CDF) throw ach::AchError{ACH_ERR_UNSUPPORTED, "neck must be 'gdf' or 'cdf'"};
-        if (cfg->pc_seg != ACH_PCSEG_PN && cfg->pc_seg != ACH_PCSEG_PN2) throw ach::AchError{ACH_ERR_UNSUPPORTED, "pc_seg must be 'pn' or 'pn2'"};
-        if (!cfg->nano_head) throw ach::AchError{ACH_ERR_UNSUPPORTED, "only nano_head=True is built"};
-        if (cfg->num_det < 1 || cfg->num_det > 59 || cfg->num_seg < 1 || cfg->pc_classes < 1 || cfg->pc_channels < 3)
+        if (cfg->pc_seg != ACH_PCSEG_PN && cfg->pc_seg != ACH_PCSEG_PN2 && cfg->pc_seg != ACH_PCSEG_NONE)
+            throw ach::AchError{ACH_ERR_UNSUPPORTED, "pc_seg must be 'pn', 'pn2' or none (Achelous3T)"};
+        if (cfg->num_det < 1 || cfg->num_det > 59 || cfg->num_seg < 1 || (cfg->pc_seg != ACH_PCSEG_NONE && (cfg->pc_classes < 1 || cfg->pc_channels < 3)))
             throw ach::AchError{ACH_ERR_INVALID, "bad class / channel counts"};
         ach_handle* h = new ach_handle();
         h->eng = ach::make_engine(*cfg);
@@ -120,7 +120,7 @@ int ach_forward(ach_handle* h, const void* image, const void* radar, const void*
                 void* se_seg, void* lane_seg, void* pc_seg, void* stream) {
     return guarded(h, [&] {
         if (h->eng->ops.empty()) throw ach::AchError{ACH_ERR_INVALID, "ach_plan must precede ach_forward"};
-        if (!image || !radar || !points || !det3 || !det4 || !det5 || !se_seg || !lane_seg || !pc_seg)
+        if (!image || !radar || !det3 || !det4 || !det5 || !se_seg || !lane_seg || (h->eng->cfg.pc_seg != ACH_PCSEG_NONE && (!points || !pc_seg)))
             throw ach::AchError{ACH_ERR_INVALID, "null input/output pointer"};
         ach::IoPtrs& io = h->eng->io;
         io.image = image; io.radar = radar; io.points = points;
@@ -136,7 +136,7 @@ int ach_forward_detect(ach_handle* h, const void* image, const void* radar, cons
                        float* out_rows, int32_t* out_idx, int32_t* out_count, void* workspace, void* stream) {
     return guarded(h, [&] {
         if (h->eng->ops.empty()) throw ach::AchError{ACH_ERR_INVALID, "ach_plan must precede ach_forward_detect"};
-        if (!image || !radar || !points || !det3 || !det4 || !det5 || !se_seg || !lane_seg || !pc_seg)
+        if (!image || !radar || !det3 || !det4 || !det5 || !se_seg || !lane_seg || (h->eng->cfg.pc_seg != ACH_PCSEG_NONE && (!points || !pc_seg)))
             throw ach::AchError{ACH_ERR_INVALID, "null input/output pointer"};
         if (max_det <= 0 || !decoded || !out_rows || !out_idx || !out_count || !workspace)
             throw ach::AchError{ACH_ERR_INVALID, "bad detect arguments"};
@@ -553,7 +553,7 @@ int ach_forward_profiled(ach_handle* h, const void* image, const void* radar, co
                          void* det5, void* se_seg, void* lane_seg, void* pc_seg, void* stream, float* op_ms, size_t capacity) {
     return guarded(h, [&] {
         if (h->eng->ops.empty()) throw ach::AchError{ACH_ERR_INVALID, "ach_plan must precede ach_forward"};
-        if (!image || !radar || !points || !det3 || !det4 || !det5 || !se_seg || !lane_seg || !pc_seg || !op_ms)
+        if (!image || !radar || !det3 || !det4 || !det5 || !se_seg || !lane_seg || !op_ms || (h->eng->cfg.pc_seg != ACH_PCSEG_NONE && (!points || !pc_seg)))
             throw ach::AchError{ACH_ERR_INVALID, "null pointer"};
         ach::IoPtrs& io = h->eng->io;
         io.image = image; io.radar = radar; io.points = points;

@@ -16,7 +16,7 @@ DTYPE_F32, DTYPE_BF16 = 0, 1
 BACKBONES = {'en': 0, 'mv': 1}
 PHIS = {'S0': 0, 'S1': 1, 'S2': 2}
 NECKS = {'gdf': 0, 'cdf': 1}
-PC_SEGS = {'pn': 0, 'pn2': 1}
+PC_SEGS = {'pn': 0, 'pn2': 1, 'none': 2}     # 'none': Achelous3T (nets/Achelous.py:56-76), no point stream
 
 _ERRORS = {-1: ValueError, -2: NotImplementedError, -3: KeyError, -4: RuntimeError, -5: MemoryError}
 
@@ -173,7 +173,7 @@ def hip_library():
 
 
 def _ptr(t):
-    return ctypes.c_void_p(t.data_ptr())
+    return ctypes.c_void_p(None if t is None else t.data_ptr())
 
 
 class NativeEngine:
@@ -196,11 +196,16 @@ class NativeEngine:
         self.num_det, self.num_seg, self.resolution = num_det, num_seg, resolution
         self.pc_classes, self.num_points, self.pc_channels = pc_classes, num_points, pc_channels
 
+    def destroy(self):
+        """ach_destroy: frees the weight and activation arenas now (the handle is unusable afterwards)."""
+        if getattr(self, 'h', None) and self.h.value:
+            self.L.ach_destroy(self.h)
+            self.h = ctypes.c_void_p()
+            self.batch = 0
+
     def __del__(self):
         try:
-            if getattr(self, 'h', None) and self.h.value:
-                self.L.ach_destroy(self.h)
-                self.h = ctypes.c_void_p()
+            self.destroy()
         except Exception:
             pass
 

@@ -11,6 +11,9 @@ Eval mode runs the fused inference engine (BatchNorm running statistics folded i
 (`.train()`, fp32) runs the unfused network on native forward / backward kernels through autograd (train_graph.py, SURVEY.md §8(f)
 row 4) for every family with reference code (EdgeNeXt / MobileViT, Ghost- / CSP-Dual-FPN, PointNet); PointNet++ raises in training mode.
 """
+import operator
+import weakref
+
 import torch
 import torch.nn as nn
 
@@ -18,14 +21,39 @@ from . import engine as _eng
 from .spec import state_dict_spec
 
 
+_VERSION_OF = operator.attrgetter('_version')
+_DATA_PTR_OF = torch.Tensor.data_ptr
+
+
+class _Node(nn.Module):
+    """A node of the parameter tree.  Replacing a Parameter / buffer / child on it (setattr, load_state_dict(assign=True), prune,
+    parametrize) drops the root's cached tensor list, so the engine refolds the weights on the next forward."""
+
+    def __setattr__(self, name, value):
+        if isinstance(value, (torch.Tensor, nn.Module)):
+            root = self.__dict__.get('_ach_root')
+            root = root() if root is not None else None
+            if root is not None:
+                root.__dict__['_wt_list'] = None
+        super().__setattr__(name, value)
+
+    def __getstate__(self):               # pickle / deepcopy (utils_fit.py:378, ModelEMA): the back-reference is re-made by the new root
+        st = self.__dict__.copy()
+        st.pop('_ach_root', None)
+        return st
+
+
 def _build_tree(root, spec):
     """Register parameters / buffers under the reference's dotted names on a tree of plain nn.Modules."""
+    ref = weakref.ref(root)
     for key, shape, kind in spec:
         parts = key.split('.')
         mod = root
         for p in parts[:-1]:
             if p not in mod._modules:
-                mod.add_module(p, nn.Module())
+                node = _Node()
+                node.__dict__['_ach_root'] = ref
+                mod.add_module(p, node)
             mod = mod._modules[p]
         leaf = parts[-1]
         if kind == 'param':
@@ -68,33 +96,48 @@ class PendingForward:
             pass
 
 
+def _check_supported(backbone, neck, pc_seg, phi, num_seg, image_channels, radar_channels):
+    """ONE error that lists every constructor argument outside the built path — the reference's own defaults
+    (`backbone='ef'`, nets/Achelous.py:27) are among them."""
+    bad = []
+    if backbone not in ('en', 'mv'):
+        bad.append(f"backbone={backbone!r} (built: 'en' EdgeNeXt, 'mv' MobileViT; the reference default 'ef' and the other six backbones are out of scope)")
+    if neck not in ('gdf', 'cdf'):
+        bad.append(f"neck={neck!r} (built: 'gdf' Ghost-Dual-FPN, 'cdf' CSP-Dual-FPN)")
+    if pc_seg not in ('pn', 'pn2', 'none'):
+        bad.append(f"pc_seg={pc_seg!r} (built: 'pn' PointNet, 'pn2' PointNet++ per our own specification)")
+    if phi not in ('S0', 'S1', 'S2'):
+        bad.append(f"phi={phi!r} (built: 'S0', 'S1', 'S2')")
+    if neck == 'gdf' and not 1 <= num_seg <= 16:
+        bad.append(f"num_seg={num_seg} (the fused segmentation-head kernel writes 1..16 classes)")
+    if image_channels != 3 or radar_channels != 3:
+        bad.append(f"image_channels={image_channels}, radar_channels={radar_channels} (built: 3 and 3)")
+    if bad:
+        raise NotImplementedError("achelous_amd.Achelous: unsupported constructor arguments: " + "; ".join(bad)
+                                  + ".  A call that works: Achelous(num_det, num_seg, phi='S0', resolution=320, backbone='en', neck='gdf', pc_seg='pn', nano_head=True)")
+
+
 class Achelous(nn.Module):
+    _point_stream = True
+
     def __init__(self, num_det, num_seg, phi='S0', image_channels=3, radar_channels=3, resolution=416,
                  backbone='ef', neck='gdf', pc_seg='pn', pc_channels=6, pc_classes=9, nano_head=False, spp=True):
         super().__init__()
-        if neck not in ('gdf', 'cdf'):
-            raise NotImplementedError(f"neck={neck!r}: the Ghost-Dual-FPN ('gdf') and CSP-Dual-FPN ('cdf') are built (SURVEY.md §2.1 rows 18-19)")
-        if backbone not in ('en', 'mv'):
-            raise NotImplementedError(f"backbone={backbone!r}: only EdgeNeXt ('en') and MobileViT ('mv') are in scope")
-        if pc_seg not in ('pn', 'pn2'):
-            raise NotImplementedError(f"pc_seg={pc_seg!r}: 'pn' and 'pn2' are built")
+        if not self._point_stream:
+            pc_seg = 'none'
+        elif pc_seg == 'none':
+            raise NotImplementedError("pc_seg='none' is Achelous3T")
         # 'pn2': the reference snapshot contains no PointNet++ implementation (nets/Achelous.py:31-32 only builds 'pn'; its own
         # forward raises for anything else).  Ours follows our own specification of that branch: achelous_amd/spec.py::PN2.
-        if phi not in ('S0', 'S1', 'S2'):
-            raise NotImplementedError(f"phi={phi!r}: only S0, S1, S2 exist for the en/mv backbones")
-        if neck == 'gdf' and not 1 <= num_seg <= 16:
-            raise NotImplementedError(f"num_seg={num_seg}: the fused segmentation-head kernel writes up to 16 classes")
-        if not nano_head:
-            raise NotImplementedError("nano_head=False (256-channel head) is not built")
-        if image_channels != 3 or radar_channels != 3:
-            raise NotImplementedError("image_channels / radar_channels other than 3")
+        _check_supported(backbone, neck, pc_seg, phi, num_seg, image_channels, radar_channels)
         self.num_det, self.num_seg, self.resolution = num_det, num_seg, resolution
         self.phi, self.image_channels, self.radar_channels = phi, image_channels, radar_channels
         self.backbone, self.neck, self.pc_seg_kind = backbone, neck, pc_seg
         self.pc_channels, self.pc_classes, self.nano_head, self.spp = pc_channels, pc_classes, nano_head, spp
         _build_tree(self, state_dict_spec(num_det, num_seg, phi, backbone, pc_channels, pc_classes, nano_head, radar_channels, neck, pc_seg))
         self._init_like_reference()
-        self._engines = {}          # (device index, dtype, padded num_points) -> [NativeEngine, weight version]
+        self._engines = {}          # (device index, dtype, padded num_points, pipelined) -> [NativeEngine, weight version]; LRU, see _engine_for
+        self.max_engines = 4        # per (device, dtype): every engine owns a weight arena and an activation arena (GBs at batch 64)
         self.debug_taps = False     # True: the engine also materialises every SURVEY §8(a) boundary (parity tests)
         self.static_weights = False  # True: skip the per-call check for in-place weight changes (serving loops)
         self.engine_options = {}    # ach_set_option(key, value) pairs applied when an engine is created (include/achelous.h)
@@ -136,10 +179,18 @@ class Achelous(nn.Module):
         if ts is None:
             ts = self.__dict__['_wt_list'] = tuple(self.parameters()) + tuple(self.buffers())
             self.__dict__['_wt_epoch'] = self.__dict__.get('_wt_epoch', 0) + 1
-        v = 0
-        for t in ts:
-            v += t._version
-        return (self.__dict__['_wt_epoch'], v)
+            ref = weakref.ref(self)
+            for m in self.modules():
+                if isinstance(m, _Node):
+                    m.__dict__['_ach_root'] = ref          # (a copy / unpickled module re-links its own nodes here)
+        # `p.data = new` / set_() keep the Parameter object and its version counter but move the storage: the pointers are part of the version
+        return (self.__dict__['_wt_epoch'], sum(map(_VERSION_OF, ts)), sum(map(_DATA_PTR_OF, ts)))
+
+    def __setattr__(self, name, value):
+        # a replaced Parameter / buffer / submodule (setattr, parametrize, prune) must not leave the cached tensor list behind
+        if isinstance(value, (torch.Tensor, nn.Module)):
+            self.__dict__['_wt_list'] = None
+        super().__setattr__(name, value)
 
     def _apply(self, fn, *a, **k):
         self.__dict__['_wt_list'] = None
@@ -180,6 +231,17 @@ class Achelous(nn.Module):
             if pipelined:
                 eng.set_option('pipeline', 1)
             ent = [eng, None]
+            # LRU per (device, dtype): a serving loop over frames with varying point counts (the reference takes any N) would
+            # otherwise grow one full engine per 16-point bucket until hipMalloc fails.  Evicted engines are destroyed (ach_destroy
+            # frees both arenas); one with a pipelined forward still un-joined is never the victim.
+            mine = [k for k in self._engines if k[:2] == key[:2]]
+            while len(mine) >= max(1, int(self.max_engines)):
+                idle = [k for k in mine if self._engines[k][0].forwards_in_flight() == 0]
+                if not idle:
+                    break
+                victim = min(idle, key=lambda k: getattr(self._engines[k][0], '_last_use', 0))
+                self._engines.pop(victim)[0].destroy()
+                mine.remove(victim)
             self._engines[key] = ent
         if ent[1] != ver:
             ent[0].load_state_dict(self.state_dict())
@@ -206,15 +268,20 @@ class Achelous(nn.Module):
         backward kernels (train_graph.py) — BatchNorm with batch statistics and running-estimate updates, gradients for every parameter
         through autograd.  Same output structure as the inference path; the outputs carry `grad_fn`."""
         from . import train_graph, train_ops
-        if not (x.is_cuda and x_radar.is_cuda and x_point_clouds.is_cuda) and not getattr(train_ops._lib, 'test_library', None):
+        has_pts = self.pc_seg_kind != 'none'
+        if not (x.is_cuda and x_radar.is_cuda and (not has_pts or x_point_clouds.is_cuda)) and not getattr(train_ops._lib, 'test_library', None):
             raise RuntimeError("achelous_amd.Achelous.forward needs GPU tensors (HIP training kernels; there is no CPU path)")
+        B = self._check_inputs(x, x_radar, x_point_clouds)
+        det, se, lane, pc = train_graph.TrainGraph(self).forward(x, x_radar, x_point_clouds if has_pts else None)
+        return (list(det), se, lane, pc) if has_pts else (list(det), se, lane)
+
+    def _check_inputs(self, x, x_radar, x_point_clouds):
         B, R = x.shape[0], self.resolution
         if tuple(x.shape) != (B, 3, R, R) or tuple(x_radar.shape) != (B, 3, R, R):
             raise ValueError(f"expected image and radar map of shape [B,3,{R},{R}], got {tuple(x.shape)} / {tuple(x_radar.shape)}")
-        if x_point_clouds.dim() != 3 or x_point_clouds.shape[0] != B or x_point_clouds.shape[1] != self.pc_channels:
+        if self.pc_seg_kind != 'none' and (x_point_clouds.dim() != 3 or x_point_clouds.shape[0] != B or x_point_clouds.shape[1] != self.pc_channels):
             raise ValueError(f"expected points of shape [B,{self.pc_channels},N], got {tuple(x_point_clouds.shape)}")
-        det, se, lane, pc = train_graph.TrainGraph(self).forward(x, x_radar, x_point_clouds)
-        return list(det), se, lane, pc
+        return B
 
     def forward_detect(self, x, x_radar, x_point_clouds, conf_thres=0.5, nms_thres=0.4, max_det=None):
         """forward + decode_outputs + class-aware NMS as one engine call (what achelous.py:246-262 chains per frame).
@@ -246,14 +313,15 @@ class Achelous(nn.Module):
 
         def padded(t):
             return torch.cat([t, t[-1:].expand(pad, *t.shape[1:])], 0) if pad else t
-        xs, rs, ps = padded(x), padded(x_radar), padded(x_point_clouds)
-        parts = [self._run(xs[i:i + size], rs[i:i + size], ps[i:i + size], detect) for i in range(0, n * size, size)]
+        has_pts = self.pc_seg_kind != 'none'
+        xs, rs, ps = padded(x), padded(x_radar), (padded(x_point_clouds) if has_pts else None)
+        parts = [self._run(xs[i:i + size], rs[i:i + size], ps[i:i + size] if has_pts else None, detect) for i in range(0, n * size, size)]
         if detect is None:
             outs, recs = parts, None
         else:
             outs, recs = [p[0] for p in parts], [p[1] for p in parts]
         det = [torch.cat([o[0][k] for o in outs], 0)[:B] for k in range(3)]
-        res = (det, torch.cat([o[1] for o in outs], 0)[:B], torch.cat([o[2] for o in outs], 0)[:B], torch.cat([o[3] for o in outs], 0)[:B])
+        res = (det,) + tuple(torch.cat([o[j] for o in outs], 0)[:B] for j in range(1, 4 if has_pts else 3))
         if recs is None:
             return res
         return res, tuple(torch.cat([r[k] for r in recs], 0)[:B] for k in range(3))
@@ -261,14 +329,11 @@ class Achelous(nn.Module):
     def _run(self, x, x_radar, x_point_clouds, detect, pipelined=False):
         if self.training:
             raise NotImplementedError("achelous_amd.Achelous runs eval-mode inference only; call .eval() first")
-        if not (x.is_cuda and x_radar.is_cuda and x_point_clouds.is_cuda):
+        has_pts = self.pc_seg_kind != 'none'
+        if not (x.is_cuda and x_radar.is_cuda and (not has_pts or x_point_clouds.is_cuda)):
             raise RuntimeError("achelous_amd.Achelous.forward needs GPU tensors (MI355X HIP engine; there is no CPU path)")
-        B, R = x.shape[0], self.resolution
-        if tuple(x.shape) != (B, 3, R, R) or tuple(x_radar.shape) != (B, 3, R, R):
-            raise ValueError(f"expected image and radar map of shape [B,3,{R},{R}], got {tuple(x.shape)} / {tuple(x_radar.shape)}")
-        if x_point_clouds.dim() != 3 or x_point_clouds.shape[0] != B or x_point_clouds.shape[1] != self.pc_channels:
-            raise ValueError(f"expected points of shape [B,{self.pc_channels},N], got {tuple(x_point_clouds.shape)}")
-        dt, dev, n_in = x.dtype, x.device, x_point_clouds.shape[2]
+        B, R = self._check_inputs(x, x_radar, x_point_clouds), self.resolution
+        dt, dev, n_in = x.dtype, x.device, (x_point_clouds.shape[2] if has_pts else 16)
         if B > self.max_plan_batch and not pipelined:
             return self._run_chunked(x, x_radar, x_point_clouds, detect)
         # The reference takes any point count (achelous.py:240-243 feeds whatever the frame holds); the point kernels work on 16-row
@@ -278,21 +343,29 @@ class Achelous(nn.Module):
         N = n_in if self.pc_seg_kind == 'pn2' else -(-n_in // 16) * 16
         with torch.cuda.device(dev):
             eng = self._engine_for(dev, dt, B, N, pipelined)
-            x, x_radar, pts = x.contiguous(), x_radar.to(dt).contiguous(), x_point_clouds.to(dt)
-            if N != n_in:
-                pts = torch.cat([pts, pts[:, :, -1:].expand(-1, -1, N - n_in)], dim=2)
-            pts = pts.contiguous()
+            x, x_radar = x.contiguous(), x_radar.to(dt).contiguous()
+            pts = pc = None
+            if has_pts:
+                pts = x_point_clouds.to(dt)
+                if N != n_in:
+                    pts = torch.cat([pts, pts[:, :, -1:].expand(-1, -1, N - n_in)], dim=2)
+                pts = pts.contiguous()
+                pc = torch.empty(B, N, self.pc_classes, dtype=dt, device=dev)
             nc5 = 5 + self.num_det
             det = [torch.empty(B, nc5, R // s, R // s, dtype=dt, device=dev) for s in (8, 16, 32)]
             se = torch.empty(B, self.num_seg, R, R, dtype=dt, device=dev)
             lane = torch.empty(B, 2, R, R, dtype=dt, device=dev)
-            pc = torch.empty(B, N, self.pc_classes, dtype=dt, device=dev)
             stream = torch.cuda.current_stream(dev).cuda_stream
+
+            def outputs():              # Achelous: (det, se, lane, pc) — Achelous3T: (det, se, lane)   (nets/Achelous.py:53,76)
+                if not has_pts:
+                    return det, se, lane
+                return det, se, lane, (pc if N == n_in else pc[:, :n_in].contiguous())
             if detect is None:
                 eng.forward(x, x_radar, pts, (det[0], det[1], det[2], se, lane, pc), stream)
                 if pipelined:
-                    return PendingForward(eng, dev, (x, x_radar, pts), lambda: (det, se, lane, pc if N == n_in else pc[:, :n_in].contiguous()))
-                return det, se, lane, (pc if N == n_in else pc[:, :n_in].contiguous())
+                    return PendingForward(eng, dev, (x, x_radar, pts), outputs)
+                return outputs()
             conf, iou, max_det = detect
             A = sum((R // s) ** 2 for s in (8, 16, 32))
             if A > 4096:
@@ -310,6 +383,34 @@ class Achelous(nn.Module):
             eng.forward_detect(x, x_radar, pts, (det[0], det[1], det[2], se, lane, pc), decoded, conf, iou, max_det, rows, idx, cnt, ws, stream)
             # scratch is released to the caching allocator in stream order: the join at the end of the call orders it after the side stream
         if pipelined:
-            return PendingForward(eng, dev, (x, x_radar, pts, decoded, ws),
-                                  lambda: ((det, se, lane, pc if N == n_in else pc[:, :n_in].contiguous()), (rows, idx, cnt)))
-        return (det, se, lane, pc if N == n_in else pc[:, :n_in].contiguous()), (rows, idx, cnt)
+            return PendingForward(eng, dev, (x, x_radar, pts, decoded, ws), lambda: (outputs(), (rows, idx, cnt)))
+        return outputs(), (rows, idx, cnt)
+
+
+class Achelous3T(Achelous):
+    """Drop-in for the reference's `nets.Achelous.Achelous3T` (nets/Achelous.py:56-76): the three image-radar tasks without the
+    point-cloud stream — `det_list[3], se_seg, lane_seg = model(image, radar)`.  Same engine with the point branch off
+    (ACH_PCSEG_NONE); the state dict is Achelous' minus `pc_seg_model.*`.  `pc_seg` / `pc_channels` / `pc_classes` are accepted and
+    unused, as in the reference.  (The reference's default `phi='SO'` — letter O — is a KeyError in its own width table; ours is 'S0'.)"""
+    _point_stream = False
+
+    def __init__(self, num_det, num_seg, phi='S0', image_channels=3, radar_channels=3, resolution=320,
+                 backbone='en', neck='gdf', pc_seg='pn', pc_channels=6, pc_classes=9, nano_head=True, spp=True):
+        super().__init__(num_det, num_seg, phi, image_channels, radar_channels, resolution, backbone, neck, 'none', pc_channels,
+                         pc_classes, nano_head, spp)
+
+    def forward(self, x, x_radar):
+        if torch.jit.is_tracing() or torch.compiler.is_compiling():
+            raise NotImplementedError("Achelous3T: the single-node torch op is registered for the four-output model only")
+        if self.training:
+            return self._train_forward(x, x_radar, None)
+        return self._run(x, x_radar, None, None)
+
+    def forward_detect(self, x, x_radar, conf_thres=0.5, nms_thres=0.4, max_det=None):
+        return self._run(x, x_radar, None, (float(conf_thres), float(nms_thres), max_det))
+
+    def submit(self, x, x_radar):
+        return self._run(x, x_radar, None, None, pipelined=True)
+
+    def submit_detect(self, x, x_radar, conf_thres=0.5, nms_thres=0.4, max_det=None):
+        return self._run(x, x_radar, None, (float(conf_thres), float(nms_thres), max_det), pipelined=True)

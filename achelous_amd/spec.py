@@ -337,12 +337,13 @@ def state_dict_spec(num_det, num_seg, phi='S0', backbone='en', pc_channels=6, pc
                     radar_channels=3, neck='gdf', pc_seg='pn'):
     """Ordered [(key, shape, kind)] of the reference state_dict for neck in {'gdf', 'cdf'}, pc_seg='pn'; with pc_seg='pn2' the
     `pc_seg_model.*` keys are those of our own PointNet++ specification (PN2 above)."""
-    if pc_seg not in ('pn', 'pn2'):
-        raise NotImplementedError(f"pc_seg={pc_seg!r}: 'pn' (reference) and 'pn2' (own specification) are built")
+    if pc_seg not in ('pn', 'pn2', 'none'):
+        raise NotImplementedError(f"pc_seg={pc_seg!r}: 'pn' (reference), 'pn2' (own specification) and 'none' (Achelous3T, nets/Achelous.py:56-76) are built")
     if phi not in WIDTHS or backbone not in ('en', 'mv') or neck not in ('gdf', 'cdf'):
         raise NotImplementedError(f"backbone={backbone!r}, phi={phi!r}, neck={neck!r}: only 'en'/'mv' with S0/S1/S2 and gdf/cdf are built")
     s = _Spec()
-    (_pointnet if pc_seg == 'pn' else _pointnet2)(s, pc_channels, pc_classes)
+    if pc_seg != 'none':
+        (_pointnet if pc_seg == 'pn' else _pointnet2)(s, pc_channels, pc_classes)
     (_neck if neck == 'gdf' else _neck_csp)(s, phi, backbone, num_seg)
     _radar(s, phi, radar_channels)
     _fusion(s, phi)

@@ -37,8 +37,8 @@ MOBILEVIT = {  # backbone/vision/mobilevit_modules/mobilevit.py:225-240: channel
 
 class TrainGraph:
     def __init__(self, model):
-        if model.pc_seg_kind != 'pn' or not model.nano_head:
-            raise NotImplementedError("training mode is built for pc_seg='pn' and nano_head=True (PointNet++ has no backward kernels)")
+        if model.pc_seg_kind not in ('pn', 'none'):
+            raise NotImplementedError("training mode is built for pc_seg='pn' and for Achelous3T (PointNet++, our own specification, has no backward kernels)")
         self.m = model
         self.p = dict(model.named_parameters())
         self.b = dict(model.named_buffers())
@@ -335,7 +335,7 @@ class TrainGraph:
         return self.bn(z, f'{e}.norm_stage{stage}', 1e-5, relu=True)
 
     def head(self, feats):
-        """DecoupleHead.forward (head/decouplehead.py:58-103), nano head."""
+        """DecoupleHead.forward (head/decouplehead.py:58-103); the width (64 nano / 256) is the weights'."""
         outs = []
         for k, x in enumerate(feats):
             x = self.base_conv(x, f'det_head.stems.{k}')
@@ -384,9 +384,9 @@ class TrainGraph:
     # ---------------------------------------------------------------------------------------------- Achelous.forward (nets/Achelous.py:49-53)
     def forward(self, x, x_radar, x_pc):
         for t in (x, x_radar, x_pc):
-            if t.dtype != torch.float32:
+            if t is not None and t.dtype != torch.float32:
                 raise TypeError("training mode runs in float32")
-        pc = self.pointnet(x_pc.contiguous())
+        pc = self.pointnet(x_pc.contiguous()) if x_pc is not None else None          # Achelous3T: no point stream
         se, lane, (q5, q4, q3) = self.ghost_dual_fpn(x.contiguous())
         r3, r4, r5 = self.rcnet(x_radar.contiguous())
         det = self.head((self.fuse(q3, r3, 3), self.fuse(q4, r4, 4), self.fuse(q5, r5, 5)))

@@ -52,7 +52,8 @@ enum { ACH_NECK_GDF = 0, ACH_NECK_CDF = 1 };     /* Ghost-Dual-FPN (neck/ghostdu
  * PointNet++ code (nets/Achelous.py:31-32 builds only 'pn'): ACH_PCSEG_PN2 runs OUR OWN specification of that branch
  * (state-dict keys pc_seg_model.sa{1-4} / fp{4-1} / conv1 / bn1 / conv2); num_points must be a multiple
  * of 128 and at most 1024. */
-enum { ACH_PCSEG_PN = 0, ACH_PCSEG_PN2 = 1 };
+enum { ACH_PCSEG_PN = 0, ACH_PCSEG_PN2 = 1,
+       ACH_PCSEG_NONE = 2   /* nets/Achelous.py:56-76 (Achelous3T): no point-cloud stream; `points` / `pc_seg` arguments are ignored (may be NULL) */ };
 
 typedef struct ach_config {
     int32_t num_det;        /* detection classes           (Achelous.__init__ num_det)      */
@@ -67,7 +68,7 @@ typedef struct ach_config {
     int32_t spp;            /* 1: SPP, 0: SPPF             (spp)                            */
     int32_t dtype;          /* ACH_DTYPE_*: storage type of activations, inputs and outputs */
     int32_t neck;           /* ACH_NECK_*                  (neck in {'gdf','cdf'})           */
-    int32_t pc_seg;         /* ACH_PCSEG_*                 (pc_seg in {'pn','pn2'})          */
+    int32_t pc_seg;         /* ACH_PCSEG_*                 (pc_seg in {'pn','pn2'}; NONE = Achelous3T) */
 } ach_config;
 
 /* one entry of a reference-keyed state_dict; `data` is HOST memory, fp32, contiguous, reference shape */

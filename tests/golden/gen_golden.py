@@ -246,8 +246,47 @@ def run_config(name):
           f'{len(keys)} keys')
 
 
+def check_variants():
+    """No fixture, assertions only (`gen_golden.py variants`): the two API variants of nets/Achelous.py that share the fixtures' arithmetic.
+      * Achelous3T (:56-76): its state-dict key list is Achelous' minus `pc_seg_model.*`, its three outputs are bit-identical to the first
+        three of Achelous on the same weights, and achelous_amd.Achelous3T has the same keys / shapes;
+      * nano_head=False (head/decouplehead.py:30-33, the constructor default): key list / shapes equal, oracle == reference on the det maps."""
+    from nets.Achelous import Achelous, Achelous3T
+    import achelous_amd
+    kw = dict(COMMON, backbone='en', phi='S0')
+    three_kw = {k: v for k, v in kw.items() if k != 'pc_seg'}
+    a, t = Achelous(**kw).state_dict(), Achelous3T(**three_kw).state_dict()
+    assert list(t) == [k for k in a if not k.startswith('pc_seg_model.')]
+    ours = achelous_amd.Achelous3T(**three_kw).state_dict()
+    assert list(ours) == list(t) and all(ours[k].shape == t[k].shape for k in t)
+    sd = condition_state_dict(a, seed=WEIGHT_SEED)
+    m4, m3 = Achelous(**kw).eval(), Achelous3T(**three_kw).eval()
+    m4.load_state_dict(sd)
+    m3.load_state_dict({k: v for k, v in sd.items() if k in t})
+    x, xr, xp = make_inputs(1, 5, resolution=COMMON['resolution'], pc_channels=COMMON['pc_channels'])
+    with torch.no_grad():
+        o4, o3 = m4(x, xr, xp), m3(x, xr)
+    assert all(torch.equal(p, q) for p, q in zip(o4[0], o3[0])) and torch.equal(o4[1], o3[1]) and torch.equal(o4[2], o3[2])
+    print('[variants] Achelous3T: keys, shapes and outputs as stated')
+    kw2 = dict(kw, nano_head=False)
+    a2, o2 = Achelous(**kw2).state_dict(), achelous_amd.Achelous(**kw2).state_dict()
+    assert list(a2) == list(o2) and all(a2[k].shape == o2[k].shape for k in a2)
+    sd2 = condition_state_dict(a2, seed=WEIGHT_SEED)
+    mw = Achelous(**kw2).eval()
+    mw.load_state_dict(sd2)
+    with torch.no_grad():
+        dw = mw(x, xr, xp)[0]
+    od = AchelousOracle(sd2, **kw2).forward(x, xr, xp)[0]
+    worst = max(rel_err(p, q) for p, q in zip(od, dw))
+    assert worst < 3e-4, worst
+    print(f'[variants] nano_head=False: keys / shapes equal, oracle == reference on the detection maps (worst {worst:.1e})')
+
+
 if __name__ == '__main__':
     assert os.path.isdir(REF), 'the reference is only available in the build container'
     torch.set_num_threads(os.cpu_count() or 1)
     for cfg in (sys.argv[1:] or list(CONFIGS)):
-        run_config(cfg)
+        if cfg == 'variants':
+            check_variants()
+        else:
+            run_config(cfg)

@@ -36,8 +36,11 @@ def test_hip_library_exports_every_declared_symbol():
     # ach_create argument validation is host-only: exercise the error path (no device touched)
     L = eng_mod.NativeLibrary(eng_mod.HIP_LIBRARY)
     with pytest.raises(NotImplementedError):
-        eng_mod.NativeEngine(L, num_det=7, num_seg=9, phi='S0', backbone='en', resolution=320, pc_channels=5, pc_classes=8,
-                             num_points=512, nano_head=False, spp=True, dtype=0)
+        cfg = eng_mod.AchConfig(7, 9, 0, 5, 320, 5, 8, 512, 1, 1, 0, 0, 0)          # backbone id 5: not 'en' / 'mv'
+        h = ctypes.c_void_p()
+        rc = L.lib.ach_create(ctypes.byref(cfg), ctypes.byref(h))
+        assert rc != 0 and b'backbone' in L.lib.ach_last_error(None)
+        raise eng_mod._ERRORS[rc](L.lib.ach_last_error(None).decode())
 
 
 @pytest.mark.parametrize('name', ['en_s0', 'en_s2', 'mv_s2', 'en_s0_cdf', 'en_s1'])
@@ -65,7 +68,7 @@ def test_drop_in_module_protocols():
         child.deploy = True
     with pytest.raises(RuntimeError):           # no CPU path
         m(torch.zeros(1, 3, 320, 320), torch.zeros(1, 3, 320, 320), torch.zeros(1, 5, 512))
-    for bad in (dict(neck='rdf'), dict(backbone='ef'), dict(pc_seg='pn3'), dict(phi='L'), dict(nano_head=False)):
+    for bad in (dict(neck='rdf'), dict(backbone='ef'), dict(pc_seg='pn3'), dict(phi='L'), dict(pc_seg='none')):
         kw = dict(num_det=7, num_seg=9, phi='S0', resolution=320, backbone='en', neck='gdf', pc_seg='pn', pc_channels=5,
                   pc_classes=8, nano_head=True)
         kw.update(bad)
@@ -85,3 +88,73 @@ def test_forward_is_registered_as_a_torch_library_op():
         outs = torch.ops.achelous_amd.forward(torch.empty(4, 3, 320, 320), torch.empty(4, 3, 320, 320), torch.empty(4, 5, 512), tok)
     assert [tuple(o.shape) for o in outs] == [(4, 12, 40, 40), (4, 12, 20, 20), (4, 12, 10, 10), (4, 9, 320, 320), (4, 2, 320, 320), (4, 512, 8)]
     assert 'achelous_amd::forward' in str(torch.ops.achelous_amd.forward.default._schema)
+
+
+def test_reference_defaults_fail_with_one_message_listing_every_unsupported_argument():
+    """`Achelous(7, 9)` with the reference's own defaults (nets/Achelous.py:27-28: backbone='ef', resolution=416, nano_head=False):
+    only the backbone is outside the built path, and the error says so once, with a working call."""
+    with pytest.raises(NotImplementedError) as e:
+        achelous_amd.Achelous(7, 9)
+    msg = str(e.value)
+    assert "backbone='ef'" in msg and 'nano_head' not in msg.split('A call that works')[0]
+    with pytest.raises(NotImplementedError) as e:
+        achelous_amd.Achelous(7, 99, phi='L', backbone='xx', neck='rdf', image_channels=1)
+    msg = str(e.value)
+    assert all(t in msg for t in ("backbone='xx'", "neck='rdf'", "phi='L'", 'image_channels=1'))
+    achelous_amd.Achelous(7, 9, backbone='en')          # every other reference default is built (416 x 416, 256-wide head, PointNet)
+
+
+def test_achelous3t_state_dict_is_the_four_task_model_without_the_point_branch():
+    """nets/Achelous.py:56-76.  (Checked once against the imported reference in the build container by tests/golden/gen_golden.py:
+    the reference Achelous3T's key list equals its Achelous' minus `pc_seg_model.*`.)"""
+    kw = dict(num_det=7, num_seg=9, phi='S0', resolution=320, backbone='en', neck='gdf', pc_channels=5, pc_classes=8, nano_head=True)
+    full, three = achelous_amd.Achelous(**kw).state_dict(), achelous_amd.Achelous3T(**kw).state_dict()
+    assert list(three.keys()) == [k for k in full if not k.startswith('pc_seg_model.')]
+    assert all(three[k].shape == full[k].shape for k in three)
+    with pytest.raises(RuntimeError):           # no CPU path
+        achelous_amd.Achelous3T(**kw).eval()(torch.zeros(1, 3, 320, 320), torch.zeros(1, 3, 320, 320))
+
+
+def test_weight_changes_of_every_kind_are_seen():
+    """replaced Parameter objects on a submodule, `p.data = new`, child.load_state_dict(assign=True) and in-place writes
+    must all change the weights version (the engine then refolds)."""
+    m = achelous_amd.Achelous(7, 9, phi='S0', resolution=320, backbone='en', pc_channels=5, pc_classes=8, nano_head=True).eval()
+    v = [m._weights_version()]
+
+    def changed():
+        v.append(m._weights_version())
+        return v[-1] != v[-2]
+    assert not changed()
+    stem = m.det_head.stems[0].conv if hasattr(m.det_head.stems, '__getitem__') else getattr(m.det_head.stems, '0').conv
+    with torch.no_grad():
+        stem.weight.mul_(2.0)
+    assert changed()
+    stem.weight = torch.nn.Parameter(torch.ones_like(stem.weight))             # object replaced on a submodule
+    assert changed()
+    stem.weight.data = torch.zeros_like(stem.weight)                           # storage swapped under the same Parameter
+    assert changed()
+    stem.load_state_dict({'weight': torch.full_like(stem.weight, 3.0)}, assign=True)
+    assert changed()
+    import copy
+    m2 = copy.deepcopy(m)
+    m2._weights_version()
+    getattr(m2.det_head.stems, '0').conv.weight = torch.nn.Parameter(torch.ones_like(stem.weight))
+    assert m2.__dict__['_wt_list'] is None and m.__dict__['_wt_list'] is not None      # the copy's nodes point at the copy
+
+
+def test_engine_cache_is_bounded(monkeypatch):
+    """one engine per point-count bucket must not grow without bound; the least recently used engine of a
+    (device, dtype) is destroyed.  Driven on the CPU emulation library through the module's own cache code."""
+    from emu_util import emu_library
+    from achelous_amd import nets
+    monkeypatch.setattr(nets._eng, 'hip_library', emu_library)
+    m = achelous_amd.Achelous(7, 9, phi='S0', resolution=64, backbone='en', pc_channels=5, pc_classes=8, nano_head=True).eval()
+    m.max_engines = 2
+    dev = torch.device('cpu')
+    seen = []
+    for n in (16, 32, 48, 16):
+        seen.append(m._engine_for(dev, torch.float32, 1, n))
+        assert len(m._engines) <= 2
+    assert seen[0].h.value is None and seen[1].h.value is None       # evicted engines were destroyed (arenas freed)
+    assert seen[2].h.value and seen[3].h.value and seen[3] is not seen[0]
+    assert set(k[2] for k in m._engines) == {48, 16}

@@ -421,3 +421,45 @@ def test_emulated_even_depthwise_row_split_bf16(name):
         outs.append([t.float() for t in o] + [eng.read_tap('map3'), eng.read_tap('map4'), eng.read_tap('map5')])
     for a, b in zip(*outs):
         assert rel_err(a, b) < 3e-2
+
+
+def test_emulated_wide_head_matches_oracle():
+    """nano_head=False: the reference constructor's default, base 256 (head/decouplehead.py:30-33) — same kernels, 512-wide merged branch."""
+    from achelous_amd.nets import Achelous
+    kw = dict(num_det=7, num_seg=9, phi='S0', backbone='en', neck='gdf', pc_seg='pn', pc_channels=5, pc_classes=8, nano_head=False, spp=True, resolution=64)
+    sd = condition_state_dict({k: torch.zeros_like(v) for k, v in Achelous(**kw).state_dict().items()}, seed=0)
+    assert sd['det_head.stems.0.conv.weight'].shape[0] == 256
+    x, xr, xp = make_inputs(1, 7, resolution=64, num_points=48, pc_channels=5, radar_cells=40)
+    det, se, lane, pc = AchelousOracle(sd, **{k: kw[k] for k in ORACLE_KEYS}).forward(x, xr, xp)
+    for dtype, td, tol in ((DTYPE_F32, torch.float32, 2e-5), (DTYPE_BF16, torch.bfloat16, 3e-2)):
+        eng = make_engine(emu_library(), kw, 1, sd, 48, dtype, full_taps=False)
+        outs = alloc_outputs(kw, 1, 48, td, 'cpu')
+        eng.forward(x.to(td), xr.to(td), xp.to(td), outs)
+        for a, b in zip(outs[:3], det):
+            assert rel_err(a.float(), b) < tol
+
+
+def test_emulated_three_task_engine_equals_the_four_task_engine():
+    """Achelous3T (nets/Achelous.py:56-76) = Achelous.forward without the point stream: ACH_PCSEG_NONE with NULL point arguments gives,
+    bit for bit, the first five outputs of the full engine on the same weights; it loads a state dict without `pc_seg_model.*`."""
+    kw, sd, (x, xr, xp) = _setup('en_s0', 64, 2, 16)
+    full = make_engine(emu_library(), kw, 2, sd, 16, full_taps=False)
+    o4 = alloc_outputs(kw, 2, 16, torch.float32, 'cpu')
+    full.forward(x, xr, xp, o4)
+    sd3 = {k: v for k, v in sd.items() if not k.startswith('pc_seg_model.')}
+    three = make_engine(emu_library(), dict(kw, pc_seg='none'), 2, sd3, 16, full_taps=False)
+    assert three.launches() < full.launches()
+    o3 = alloc_outputs(kw, 2, 16, torch.float32, 'cpu')
+    three.forward(x, xr, None, (*o3[:5], None))
+    for a, b in zip(o3[:5], o4[:5]):
+        assert torch.equal(a, b)
+    # forward_detect on the three-task engine
+    A, nc5 = sum((64 // s) ** 2 for s in (8, 16, 32)), 5 + kw['num_det']
+    dec = torch.zeros(2, A, nc5)
+    ws = torch.zeros(three.nms_workspace_bytes(2), dtype=torch.uint8)
+    rows, idx, cnt = torch.zeros(2, 20, 7), torch.full((2, 20), -1, dtype=torch.int32), torch.zeros(2, dtype=torch.int32)
+    three.forward_detect(x, xr, None, (*o3[:5], None), dec, 0.05, 0.5, 20, rows, idx, cnt, ws)
+    assert torch.isfinite(dec).all()
+    # a four-task engine still refuses NULL point arguments
+    with pytest.raises(ValueError):
+        full.forward(x, xr, None, (*o4[:5], None))
