@@ -91,6 +91,11 @@ float* EngineBase::up_f32(const std::vector<float>& v) {
     }
     return d;
 }
+void* EngineBase::up_raw(const void* src, size_t bytes) {
+    void* d = walloc(bytes);
+    if (!measuring) ACH_HIP_CHECK(hipMemcpy(d, src, bytes, hipMemcpyHostToDevice));
+    return d;
+}
 void EngineBase::reset_plan() {
 #if !defined(ACH_HOSTEMU)
     drop_graphs();

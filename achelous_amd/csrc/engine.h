@@ -80,6 +80,8 @@ public:
     int radar_rows4 = 2;              // option "radar_rows4": a workgroup of rc_front owns four rows, one per wave (1: block 0 when radar_skip is on; 2: every
                                       // fused block — 29.1 k against 27.7 k frames/s: the per-workgroup weight staging and tables were a fifth of these kernels)
     bool radar_skip = true;           // option "radar_skip": first RCBlock — closed-form shortcut on 16-pixel segments whose neighbourhood of the radar map is empty (k_conv3.h)
+    bool head_rows = true;            // option "head_rows": bf16 — fused last decoder level + head as the row-walking kernel (k_dechead.h: no LDS, DPP row shifts, head 1x1 on MFMA); 0 = the LDS tile kernel (k_nhwc.h)
+    int head_band = 40;               // option "head_band": rows per band of the row-walking kernel
     bool head_mfma = false;           // option "head_mfma": bf16 — bilinear phase of the fused last decoder level on MFMA over a channel-planar t (k_nhwc.h)
     int head_grid = 0;                // option "head_grid": persistent workgroups of the MFMA head kernel (0 = UGM_GRID)
     int head_debug = 0;               // option "head_debug": timing experiments on the fused last decoder level (skips phases: results are wrong)
@@ -157,6 +159,7 @@ protected:
     void* walloc(size_t bytes);
     void* aalloc(size_t bytes);
     float* up_f32(const std::vector<float>& v);
+    void* up_raw(const void* src, size_t bytes);        // opaque constants (pre-packed MFMA fragments)
     void add_op(const std::string& name, std::function<void(hipStream_t)> fn, double bytes = 0, double flops = 0, double layout_bytes = -1) {
         if (measuring) return;
         // timing experiments only (profiles/scripts/skip_ops.sh): ACH_DEBUG_SKIP="substr,substr" turns the matching launches into no-ops

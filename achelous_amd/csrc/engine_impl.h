@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstring>
 
+#include "k_dechead.h"
 #include "k_detect.h"
 #include "k_conv3.h"
 #include "k_gemm.h"
@@ -926,6 +927,38 @@ public:
                             up_f32(wh2), up_f32(bh2), x.B, x.H, x.W, init, nch, oup,
                             x.H > 0 ? float(x.H - 1) / float(2 * x.H - 1) : 0.f, x.W > 0 ? float(x.W - 1) / float(2 * x.W - 1) : 0.f};
         const double bytes = double(t.rows()) * Cg * sizeof(T) + 4.0 * double(t.rows()) * oup * sizeof(T);
+        if (head_rows && !planar && std::is_same<T, bf16_t>::value && t.ld % 4 == 0 && double(t.rows()) * t.ld * 4.0 * oup < 2147483648.0) {
+            // row-walking kernel (k_dechead.h): head 1x1 as the A fragment of v_mfma_f32_16x16x32_bf16 — D row 4g + r = head channel g + 4r,
+            // k = 8g + j = channel 4g + j of x1 (j < 4) or of x2 (j >= 4) — biases and the head's depthwise filters indexed by head channel
+            std::vector<uint16_t> af(size_t(64) * 8, 0);
+            for (int l = 0; l < 64; ++l) {
+                const int i = l & 15, kg = l >> 4, jj = (i / 4) + 4 * (i % 4);
+                for (int j = 0; j < 8; ++j) {
+                    const int orig = j < 4 ? 4 * kg + j : 16 + 4 * kg + (j - 4);
+                    af[size_t(l) * 8 + j] = (i % 4 < 2 && jj < init) ? f32_to_bf16_bits(lh.w[size_t(jj) * cout + orig]) : uint16_t(0);
+                }
+            }
+            std::vector<float> bh8(8, 0.f), wd8(72, 0.f), bd8(8, 0.f);
+            for (int jj = 0; jj < init; ++jj) bh8[jj] = lh.b[jj];
+            for (int jj = 0; jj < nch; ++jj) { bd8[jj] = bh2[jj]; for (int k = 0; k < 9; ++k) wd8[size_t(k) * 8 + jj] = wh2[size_t(k) * nch + jj]; }
+            const int H2 = 2 * x.H, band = std::max(8, std::min(head_band, H2));
+            DecHeadParams dp{t.p, t.ld, full_taps ? f.p : nullptr, full_taps ? f.ld : 0, nullptr, p.Wdw, p.bdw, static_cast<const uint4*>(up_raw(af.data(), af.size() * 2)),
+                             up_f32(bh8), up_f32(wd8), up_f32(bd8), x.B, x.H, x.W, init, nch, oup, p.sy, p.sx, band, cdiv(H2, band), cdiv(2 * x.W, DH_VALID)};
+            const dim3 grid(unsigned(dp.strips) * unsigned(dp.bands) * unsigned(x.B)), block(64);
+            const int dbg = head_debug;
+            const bool dw2 = nch > 4;
+            add_op(head_pfx + ".upghost_head", [dp, grid, block, out, dbg, dw2](hipStream_t s) mutable {
+                dp.out = *out;
+#define ACH_DH_CASE(D) case D: if (dw2) ACH_LAUNCH((dechead_rows_kernel<true, D>), grid, block, s, dp); else ACH_LAUNCH((dechead_rows_kernel<false, D>), grid, block, s, dp); break;
+#if defined(ACH_HEAD_DEBUG)
+                switch (dbg) { ACH_DH_CASE(1) ACH_DH_CASE(2) ACH_DH_CASE(3) ACH_DH_CASE(4) ACH_DH_CASE(7) ACH_DH_CASE(8) ACH_DH_CASE(15) default: ACH_DH_CASE(0) }
+#else
+                switch (dbg) { default: ACH_DH_CASE(0) }
+#endif
+#undef ACH_DH_CASE
+            }, bytes, 2.0 * double(t.rows()) * 4.0 * cout * init);
+            return;
+        }
         const dim3 block(UGH_THREADS);
         if (planar) {
             const int tw = 16 * UGM_NSEG - 4;

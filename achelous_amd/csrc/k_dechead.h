@@ -1,0 +1,214 @@
+// k_dechead.h — last decoder level + Ghost segmentation head as a ROW-WALKING kernel (bf16 engine; round 3).
+//
+//   t  (low resolution, 16 channels)  ->  x1 = relu(bilinear x2 (t))             neck/ghostdualfpn.py:28-39 (Upsample), :175-197
+//                                         x2 = relu(dw3x3(x1) + b)                backbone/conv_utils/ghost_conv.py:6-29 (cheap operation)
+//                                         h  = relu(Wh [x1 | x2] + bh)            head GhostModule, primary conv (32 -> init)
+//                                         out = [h | relu(dw3x3(h) + b')][:oup]   head cheap operation, NCHW
+//
+// The tile kernel it replaces (upghost_head_kernel, k_nhwc.h) stages x1 of a 34 x 10 halo tile in LDS, is LDS- and VALU-issue bound at
+// 10 % of the HBM roofline and spends 4 of 5 VALU instructions on something other than an FMA.  Here NOTHING goes
+// through LDS and nothing is recomputed along y:
+//   * a WAVE owns a strip of 16 columns (12 of them produce outputs; the two cascaded 3x3 windows need 2 columns of halo per side) and
+//     walks DOWN a band of rows.  Lane (n, g) = column n of the strip, channel group g (4 of the level's 16 channels).
+//   * x neighbours come from DPP row shifts (row_shr:1 / row_shl:1 inside the 16-lane row that IS the strip) — no LDS, no barrier;
+//     y neighbours are the two previous rows, still in registers (a three-row rolling window of x1 and of h).
+//   * the bilinear source rows are kept unpacked in registers too: a new source row is fetched every second output row (two 8-byte
+//     loads per lane), one row ahead of its use.
+//   * lane (n, g)'s eight values [x1 c=4g..4g+3 | x2 c=4g..4g+3] ARE k-group g of the B fragment of v_mfma_f32_16x16x32_bf16, so the head's
+//     1x1 conv is ONE MFMA per row of the strip (weights permuted on the host: A fragment in 4 VGPRs).  Head channel jj lands in accumulator
+//     r = jj / 4 of lane group g = jj % 4, i.e. next to its x neighbours again: the head's depthwise conv uses the same DPP shifts.
+// Numerics (bf16 engine): x1 / x2 in fp32 registers, rounded to bf16 once as the MFMA operand (the tile kernel kept them in fp32);
+// the head weights are bf16 like every other MFMA weight of this engine.
+#pragma once
+#include "ach_platform.h"
+
+namespace ach {
+
+struct DecHeadParams {
+    const void* Tq; long ldt;                 // t at low resolution [B,h,w,ldt] bf16 (16 real channels)
+    void* F; long ldf;                        // optional [B,2h,2w,32] tap of [x1 | x2] (nullptr in production plans)
+    void* out;                                // NCHW [B,oup,2h,2w]
+    const float* Wdw; const float* bdw;       // level cheap op: [9][16], [16]   (BN folded)
+    const uint4* Afrag;                       // [64] head primary conv as the bf16 A fragment (rows / k permuted, see above)
+    const float* bh;                          // [8]  head primary bias by channel jj (zero beyond init)
+    const float* Wdh; const float* bdh;       // head cheap op: [9][8], [8] by channel jj (zero beyond nch)
+    int B, h, w, init, nch, oup;
+    float sy, sx;                             // (h-1)/(2h-1), (w-1)/(2w-1): align_corners source scale
+    int band_rows, bands, strips;
+};
+constexpr int DH_VALID = 12;                  // output columns per 16-lane strip
+#ifndef ACH_DH_WAVES
+#define ACH_DH_WAVES 3
+#endif
+constexpr int DH_WAVES = ACH_DH_WAVES;        // register budget: waves per SIMD the compiler must fit
+
+// a + (value of the lane one column to the left / right inside the 16-lane row; 0 at the row's ends): ONE VALU instruction each
+// (v_add_f32 with a DPP row shift on its first source).  The depthwise 3x3 taps are arranged so that only the three per-column partial
+// sums of a row are shifted — two shifted adds per channel instead of six shifted operands.
+#if defined(ACH_HOSTEMU)
+__device__ inline float add_from_left(float a, float v) { const int l = int(threadIdx.x) & 63; const float o = __shfl(v, (l & 15) ? l - 1 : l); return a + ((l & 15) ? o : 0.f); }
+__device__ inline float add_from_right(float a, float v) { const int l = int(threadIdx.x) & 63; const float o = __shfl(v, (l & 15) != 15 ? l + 1 : l); return a + ((l & 15) != 15 ? o : 0.f); }
+#else
+__device__ __forceinline__ float add_from_left(float a, float v) {      // row_shr:1, bound_ctrl: lanes without a source read 0
+    float r;
+    asm("v_add_f32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(v), "v"(a));
+    return r;
+}
+__device__ __forceinline__ float add_from_right(float a, float v) {     // row_shl:1
+    float r;
+    asm("v_add_f32_dpp %0, %1, %2 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(v), "v"(a));
+    return r;
+}
+#endif
+
+// DW2: the head's cheap operation has more than four channels (num_seg > 8): accumulator r = 1 takes part in it too.
+// DBG (timing experiments only, results are wrong): bit 0 no bilinear, 1 no level depthwise, 2 no MFMA, 3 no head depthwise / stores.
+template <bool DW2, int DBG = 0>
+__global__ __launch_bounds__(64, DH_WAVES) void dechead_rows_kernel(const DecHeadParams p) {
+    const int H = 2 * p.h, Wd = 2 * p.w;
+    const unsigned u = xcd_block(blockIdx.x, gridDim.x);
+    const int strip = int(u % unsigned(p.strips)), band = int((u / unsigned(p.strips)) % unsigned(p.bands));
+    const long b = long(u / (unsigned(p.strips) * unsigned(p.bands)));
+    const int lane = int(threadIdx.x) & 63, n = lane & 15, g = lane >> 4;
+    const int x = strip * DH_VALID - 2 + n;
+    const bool in_x = x >= 0 && x < Wd;
+    const bool writer = in_x && n >= 2 && n < 2 + DH_VALID;
+    // ---- per-lane bilinear geometry along x (fixed for the whole band)
+    const int cx = x < 0 ? 0 : (x >= Wd ? Wd - 1 : x);
+    const float fx = p.sx * float(cx);
+    int x0 = int(fx);
+    if (x0 > p.w - 1) x0 = p.w - 1;
+    const int dx = x0 < p.w - 1 ? 1 : 0;
+    const float lx = fx - float(x0);
+    const float wx0 = in_x ? 1.f - lx : 0.f, wx1 = in_x ? lx : 0.f;        // a column outside the map is the depthwise conv's zero padding
+    const bf16_t* Tq = static_cast<const bf16_t*>(p.Tq) + b * p.h * long(p.w) * p.ldt + 4 * g;
+    const int o0 = x0 * int(p.ldt), o1 = (x0 + dx) * int(p.ldt), rowp = p.w * int(p.ldt);
+    // ---- per-lane weights; channel PAIRS (4g, 4g+1) and (4g+2, 4g+3) as packed fp32 (v_pk_fma_f32 / v_pk_mul_f32: two lanes' worth of FMAs per issue)
+    f32x2 wl[9][2], bl[2];
+    ACH_UNROLL
+    for (int k = 0; k < 9; ++k) { const float4 w = *reinterpret_cast<const float4*>(p.Wdw + k * 16 + 4 * g); wl[k][0] = f32x2{w.x, w.y}; wl[k][1] = f32x2{w.z, w.w}; }
+    { const float4 w = *reinterpret_cast<const float4*>(p.bdw + 4 * g); bl[0] = f32x2{w.x, w.y}; bl[1] = f32x2{w.z, w.w}; }
+    constexpr int NR = DW2 ? 2 : 1;
+    float wh[9][NR], bdh[NR], bhv[2];
+    ACH_UNROLL
+    for (int r = 0; r < NR; ++r) {
+        ACH_UNROLL
+        for (int k = 0; k < 9; ++k) wh[k][r] = p.Wdh[k * 8 + g + 4 * r];
+        bdh[r] = p.bdh[g + 4 * r];
+    }
+    bhv[0] = p.bh[g]; bhv[1] = p.bh[g + 4];
+    const uint4 afrag = p.Afrag[lane];
+    const bool has_h[2] = {g < p.init, g + 4 < p.init};
+    const bool st_h[2] = {writer && g < p.init && g < p.oup, writer && g + 4 < p.init && g + 4 < p.oup};
+    const bool st_d[2] = {writer && g < p.nch, writer && g + 4 < p.nch};
+    const long HW = long(H) * Wd;
+    bf16_t* outp = static_cast<bf16_t*>(p.out) + b * p.oup * HW + (in_x ? x : 0);
+    // ---- source rows of t, unpacked: ta = row cy, tb = row cy + 1 (clamped), tn = raw row cy + 2 (clamped), fetched one row ahead
+    const int r0 = band * p.band_rows, r1 = (r0 + p.band_rows < H) ? r0 + p.band_rows : H;
+    auto src_row = [&](int i) { const float fy = p.sy * float(i); int y0 = int(fy); return y0 > p.h - 1 ? p.h - 1 : y0; };
+    auto load_raw = [&](int r, uint2 (&raw)[2]) {
+        const int rr = r < 0 ? 0 : (r > p.h - 1 ? p.h - 1 : r);
+        const bf16_t* q = Tq + long(rr) * rowp;
+        raw[0] = *reinterpret_cast<const uint2*>(q + o0);
+        raw[1] = *reinterpret_cast<const uint2*>(q + o1);
+    };
+    auto unpack = [&](const uint2 (&raw)[2], f32x2 (&o)[2][2]) {            // [column][channel pair]
+        ACH_UNROLL
+        for (int c = 0; c < 2; ++c) {
+            o[c][0] = f32x2{__uint_as_float(raw[c].x << 16), __uint_as_float(raw[c].x & 0xffff0000u)};
+            o[c][1] = f32x2{__uint_as_float(raw[c].y << 16), __uint_as_float(raw[c].y & 0xffff0000u)};
+        }
+    };
+    const int i_first = r0 - 2 < 0 ? 0 : r0 - 2;
+    int cy = src_row(i_first);
+    f32x2 ta[2][2], tb[2][2];
+    uint2 tn[2];
+    { uint2 raw[2]; load_raw(cy, raw); unpack(raw, ta); load_raw(cy + 1, raw); unpack(raw, tb); load_raw(cy + 2, tn); }
+    const f32x2 zero2 = {0.f, 0.f};
+    f32x2 w0[2] = {zero2, zero2}, w1[2] = {zero2, zero2}, w2[2] = {zero2, zero2};                         // rolling window of x1 rows (channel pairs)
+    float v0[2] = {0.f, 0.f}, v1[2] = {0.f, 0.f}, v2[2] = {0.f, 0.f};                                    // rolling window of h rows
+
+    // one step of the walk: x1 row i into xp; x2 / h of row i-1 (x1 rows xm, xc, xp) into hp; output row i-2 (h rows hm, hc, hp).
+    // The caller rotates the roles of the three window slots, so nothing is copied between steps.
+    auto step = [&](const int i, f32x2 (&xm)[2], f32x2 (&xc)[2], f32x2 (&xp)[2], float (&hm)[2], float (&hc)[2], float (&hp)[2]) {
+        // ---- A: x1 row i
+        if (i >= 0 && i < H && !(DBG & 1)) {
+            const float fy = p.sy * float(i);
+            int y0 = int(fy);
+            if (y0 > p.h - 1) y0 = p.h - 1;
+            if (y0 > cy) {                     // (the scale is below 1/2: at most one new source row per output row)
+                ACH_UNROLL
+                for (int c = 0; c < 2; ++c) { ta[c][0] = tb[c][0]; ta[c][1] = tb[c][1]; }
+                unpack(tn, tb);
+                ++cy;
+                load_raw(cy + 2, tn);
+            }
+            const float ly = (y0 < p.h - 1) ? fy - float(y0) : 0.f, hy = 1.f - ly;
+            const float w00 = hy * wx0, w01 = hy * wx1, w10 = ly * wx0, w11 = ly * wx1;
+            ACH_UNROLL
+            for (int q = 0; q < 2; ++q) {
+                const f32x2 v = w00 * ta[0][q] + w01 * ta[1][q] + w10 * tb[0][q] + w11 * tb[1][q];
+                xp[q] = f32x2{v[0] > 0.f ? v[0] : 0.f, v[1] > 0.f ? v[1] : 0.f};
+            }
+        } else {
+            xp[0] = zero2; xp[1] = zero2;
+        }
+        // ---- B: x2 and h of row i-1
+        const int rb = i - 1;
+        if (rb >= r0 - 1 && rb <= r1) {
+            f32x2 x2[2] = {bl[0], bl[1]};
+            if (!(DBG & 2)) {
+                ACH_UNROLL
+                for (int q = 0; q < 2; ++q) {
+                    // per-column partial sums of the left / centre / right taps; the neighbours' sums arrive by two shifted adds per channel
+                    const f32x2 sl = wl[0][q] * xm[q] + wl[3][q] * xc[q] + wl[6][q] * xp[q];      // what this column contributes to x + 1
+                    const f32x2 sr = wl[2][q] * xm[q] + wl[5][q] * xc[q] + wl[8][q] * xp[q];      // ... to x - 1
+                    const f32x2 sc = x2[q] + wl[1][q] * xm[q] + wl[4][q] * xc[q] + wl[7][q] * xp[q];
+                    x2[q] = f32x2{add_from_right(add_from_left(sc[0], sl[0]), sr[0]), add_from_right(add_from_left(sc[1], sl[1]), sr[1])};
+                }
+            }
+            ACH_UNROLL
+            for (int q = 0; q < 2; ++q) x2[q] = f32x2{x2[q][0] > 0.f ? x2[q][0] : 0.f, x2[q][1] > 0.f ? x2[q][1] : 0.f};
+            const bool row_in = rb >= 0 && rb < H;
+            if (p.F && row_in && writer && rb >= r0 && rb < r1) {
+                bf16_t* fo = static_cast<bf16_t*>(p.F) + ((b * H + rb) * long(Wd) + x) * p.ldf + 4 * g;
+                const float a1[4] = {xc[0][0], xc[0][1], xc[1][0], xc[1][1]}, a2[4] = {x2[0][0], x2[0][1], x2[1][0], x2[1][1]};
+                Store<bf16_t>::st4(fo, a1);
+                Store<bf16_t>::st4(fo + 16, a2);
+            }
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            if (!(DBG & 4)) {
+                const uint4 bfrag = make_uint4(pack_bf16x2(xc[0][0], xc[0][1]), pack_bf16x2(xc[1][0], xc[1][1]), pack_bf16x2(x2[0][0], x2[0][1]), pack_bf16x2(x2[1][0], x2[1][1]));
+                mfma16<bf16_t>(afrag, bfrag, acc);
+            }
+            const bool live = row_in && in_x;                   // outside the map h is the head depthwise conv's zero padding
+            ACH_UNROLL
+            for (int r = 0; r < 2; ++r) { const float v = acc[r] + bhv[r]; hp[r] = (live && has_h[r] && v > 0.f) ? v : 0.f; }
+        } else {
+            hp[0] = 0.f; hp[1] = 0.f;
+        }
+        // ---- C: output row i-2
+        const int ro = i - 2;
+        if (ro >= r0 && ro < r1 && !(DBG & 8)) {
+            bf16_t* orow = outp + long(ro) * Wd;
+            ACH_UNROLL
+            for (int r = 0; r < 2; ++r)
+                if (st_h[r]) Store<bf16_t>::st(orow + (g + 4 * r) * HW, hc[r]);
+            ACH_UNROLL
+            for (int r = 0; r < NR; ++r) {
+                float a = bdh[r] + wh[1][r] * hm[r] + wh[4][r] * hc[r] + wh[7][r] * hp[r];
+                a = add_from_left(a, wh[0][r] * hm[r] + wh[3][r] * hc[r] + wh[6][r] * hp[r]);
+                a = add_from_right(a, wh[2][r] * hm[r] + wh[5][r] * hc[r] + wh[8][r] * hp[r]);
+                if (st_d[r]) Store<bf16_t>::st(orow + (p.init + g + 4 * r) * HW, a > 0.f ? a : 0.f);
+            }
+        }
+    };
+    ACH_NO_UNROLL
+    for (int i = r0 - 2; i <= r1 + 1; i += 3) {
+        step(i, w0, w1, w2, v0, v1, v2);
+        if (i + 1 <= r1 + 1) step(i + 1, w1, w2, w0, v1, v2, v0);
+        if (i + 2 <= r1 + 1) step(i + 2, w2, w0, w1, v2, v0, v1);
+    }
+}
+
+}  // namespace ach

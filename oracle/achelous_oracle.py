@@ -37,7 +37,7 @@ MOBILEVIT = {  # backbone/vision/mobilevit_modules/mobilevit.py:225-240
 
 class AchelousOracle:
     def __init__(self, state_dict, num_det=7, num_seg=9, phi='S0', backbone='en', neck='gdf', pc_seg='pn',
-                 pc_channels=5, pc_classes=8, nano_head=True, spp=True, resolution=320):
+                 pc_channels=5, pc_classes=8, nano_head=True, spp=True, resolution=320, boundary_dtype=None):
         if neck not in ('gdf', 'cdf') or backbone not in ('en', 'mv') or pc_seg not in ('pn', 'pn2'):
             raise NotImplementedError("oracle covers backbone in {en,mv}, neck in {gdf,cdf}, pc_seg in {pn,pn2}")
         self.neck = neck
@@ -49,6 +49,17 @@ class AchelousOracle:
         self.pc_channels, self.pc_classes, self.nano_head, self.spp = pc_channels, pc_classes, nano_head, spp
         self.w = WIDTHS[phi]
         self.taps = {}
+        # boundary_dtype=torch.bfloat16: the "ideal bf16-storage engine" — fp32 arithmetic everywhere, but the image / radar inputs and every
+        # SURVEY 8(a) boundary tensor of the image and radar paths (the tensors the taps name) are ROUNDED to that type before they are
+        # passed on.  It is the yardstick for what bf16 storage alone costs on a given set of weights and frames (tests/test_gpu_parity.py).
+        self.boundary_dtype = boundary_dtype
+
+    def _b(self, name, t):
+        """Record a boundary tensor; with boundary_dtype set, hand on its rounded value."""
+        if self.boundary_dtype is not None:
+            t = t.to(self.boundary_dtype).float()
+        self.taps[name] = t
+        return t
 
     # ------------------------------------------------------------------ primitives
     def P(self, key):
@@ -219,7 +230,7 @@ class AchelousOracle:
                     x = self.sdta_encoder(x, b, cfg['scales'][i], cfg['heads'])
                 else:
                     x = self.conv_encoder(x, b, cfg['ks'][i])
-                self.taps[f'backbone.s{i}.b{j}'] = x
+                x = self._b(f'backbone.s{i}.b{j}', x)
             feats.append(x)
         return feats
 
@@ -236,7 +247,7 @@ class AchelousOracle:
         y = self.bn(self.conv(y, pfx + '.conv.3', stride=stride, pad=1, groups=hid), pfx + '.conv.4', 1e-5)
         y = y * torch.sigmoid(y)
         y = self.bn(self.conv(y, pfx + '.conv.6'), pfx + '.conv.7', 1e-5)
-        return x + y if (stride == 1 and inp == oup) else y
+        return self._b(pfx, x + y if (stride == 1 and inp == oup) else y)
 
     def mv_transformer(self, t, pfx, depth, heads=4, dim_head=8):
         """Transformer / Attention / FeedForward (mobilevit.py:33-90); t: [B, P, N, D]."""
@@ -248,33 +259,33 @@ class AchelousOracle:
             q, k, v = [z.reshape(B, Pn, N, heads, dim_head).permute(0, 1, 3, 2, 4) for z in qkv.chunk(3, dim=-1)]
             attn = (q @ k.transpose(-1, -2) * dim_head ** -0.5).softmax(dim=-1)
             o = (attn @ v).permute(0, 1, 3, 2, 4).reshape(B, Pn, N, heads * dim_head)
-            t = F.linear(o, self.P(a + '.fn.to_out.0.weight'), self.P(a + '.fn.to_out.0.bias')) + t
+            t = self._b(a, F.linear(o, self.P(a + '.fn.to_out.0.weight'), self.P(a + '.fn.to_out.0.bias')) + t)
             f = f'{pfx}.layers.{l}.1'
             tn = self.ln_last(t, self.P(f + '.norm.weight'), self.P(f + '.norm.bias'), 1e-5)
             h = F.linear(tn, self.P(f + '.fn.net.0.weight'), self.P(f + '.fn.net.0.bias'))
             h = h * torch.sigmoid(h)
-            t = F.linear(h, self.P(f + '.fn.net.3.weight'), self.P(f + '.fn.net.3.bias')) + t
+            t = self._b(f, F.linear(h, self.P(f + '.fn.net.3.weight'), self.P(f + '.fn.net.3.bias')) + t)
         return t
 
     def mvit_block(self, x, pfx, depth):
         """MobileViTBlock (mobilevit.py:147-165), 2x2 patches."""
         y = x
-        x = self.mv_conv_bn_silu(x, pfx + '.conv1', 1, 1)
-        x = self.mv_conv_bn_silu(x, pfx + '.conv2')
+        x = self._b(pfx + '.conv1', self.mv_conv_bn_silu(x, pfx + '.conv1', 1, 1))
+        x = self._b(pfx + '.conv2', self.mv_conv_bn_silu(x, pfx + '.conv2'))
         B, D, H, W = x.shape
         h, w = H // 2, W // 2
         # 'b d (h ph) (w pw) -> b (ph pw) (h w) d'
         t = x.reshape(B, D, h, 2, w, 2).permute(0, 3, 5, 2, 4, 1).reshape(B, 4, h * w, D)
         t = self.mv_transformer(t, pfx + '.transformer', depth)
         x = t.reshape(B, 2, 2, h, w, D).permute(0, 5, 3, 1, 4, 2).reshape(B, D, H, W)
-        x = self.mv_conv_bn_silu(x, pfx + '.conv3')
+        x = self._b(pfx + '.conv3', self.mv_conv_bn_silu(x, pfx + '.conv3'))
         x = torch.cat((x, y), 1)
-        return self.mv_conv_bn_silu(x, pfx + '.conv4', 1, 1)
+        return self._b(pfx + '.conv4', self.mv_conv_bn_silu(x, pfx + '.conv4', 1, 1))
 
     def mobilevit(self, x, pfx):
         """MobileViT.forward (mobilevit.py:198-222)."""
         ch = MOBILEVIT[self.phi]['ch']
-        x = self.mv_conv_bn_silu(x, pfx + '.conv1', 2, 1)
+        x = self._b(pfx + '.conv1', self.mv_conv_bn_silu(x, pfx + '.conv1', 2, 1))
         x = self.mv2block(x, pfx + '.mv2.0', 1, ch[1])
         x = self.mv2block(x, pfx + '.mv2.1', 2, ch[2])
         x = self.mv2block(x, pfx + '.mv2.2', 1, ch[3])
@@ -312,22 +323,22 @@ class AchelousOracle:
         w = self.w
         feats = self.edgenext(x, f + '.backbone') if self.backbone == 'en' else self.mobilevit(x, f + '.backbone')
         m2, m3, m4, m5 = feats
-        self.taps.update({'map2': m2, 'map3': m3, 'map4': m4, 'map5': m5})
+        m2, m3, m4, m5 = self._b('map2', m2), self._b('map3', m3), self._b('map4', m4), self._b('map5', m5)
         p5 = self.spp_block(m5, f + '.spp')
-        self.taps['spp'] = p5
+        p5 = self._b('spp', p5)
         p4 = torch.cat([self.upsample(p5, f + '.upsample_5_to_4'), m4], 1)
         p4 = self.ghost_bottleneck(p4, f + '.ghost_5_to_4', w[2])
         p3 = torch.cat([self.upsample(p4, f + '.upsample_4_to_3'), m3], 1)
         p3 = self.ghost_bottleneck(p3, f + '.ghost_4_to_3', w[1])
-        self.taps.update({'fpn4': p4, 'fpn3': p3})
+        p4, p3 = self._b('fpn4', p4), self._b('fpn3', p3)
         outs = {}
         for name, sa, oup in (('lane', 'stage_3_lane_seg', 2), ('se', 'stage_3_semantic_seg', self.num_seg)):
             y = self.shuffle_attention(p3, f'{f}.{sa}')
-            self.taps[f'{name}.sa'] = y
+            y = self._b(f'{name}.sa', y)
             for lvl, c in (('3_to_2', w[1]), ('2_to_1', w[0]), ('1_to_0', w[0])):
                 y = self.upsample(y, f'{f}.{name}_seg_{lvl}')
                 y = self.ghost(y, f'{f}.{name}_seg_ghost_{lvl}', c)
-                self.taps[f'{name}.{lvl}'] = y
+                y = self._b(f'{name}.{lvl}', y)
             outs[name] = self.ghost(y, f'{f}.{name}_seg_head', oup)
         return outs['se'], outs['lane'], (p5 + m5, p4 + m4, p3 + m3)
 
@@ -354,21 +365,21 @@ class AchelousOracle:
         f = 'image_radar_encoder.fpn'
         feats = self.edgenext(x, f + '.backbone') if self.backbone == 'en' else self.mobilevit(x, f + '.backbone')
         m2, m3, m4, m5 = feats
-        self.taps.update({'map2': m2, 'map3': m3, 'map4': m4, 'map5': m5})
+        m2, m3, m4, m5 = self._b('map2', m2), self._b('map3', m3), self._b('map4', m4), self._b('map5', m5)
         p5 = self.spp_block(m5, f + '.spp')
-        self.taps['spp'] = p5
+        p5 = self._b('spp', p5)
         p4 = self.csp_layer(torch.cat([self.upsample(p5, f + '.upsample_5_to_4'), m4], 1), f + '.ghost_5_to_4')
         p3 = self.csp_layer(torch.cat([self.upsample(p4, f + '.upsample_4_to_3'), m3], 1), f + '.ghost_4_to_3')
-        self.taps.update({'fpn4': p4, 'fpn3': p3})
+        p4, p3 = self._b('fpn4', p4), self._b('fpn3', p3)
         outs = {}
         w = self.w
         for name, sa, oup in (('lane', 'stage_3_lane_seg', 2), ('se', 'stage_3_semantic_seg', self.num_seg)):
             y = self.shuffle_attention(p3, f'{f}.{sa}')
-            self.taps[f'{name}.sa'] = y
+            y = self._b(f'{name}.sa', y)
             for lvl, c in (('3_to_2', w[1]), ('2_to_1', w[0]), ('1_to_0', w[0])):
                 y = self.upsample(y, f'{f}.{name}_seg_{lvl}')
                 y = self.csp_bottleneck(y, f'{f}.{name}_seg_ghost_{lvl}', c)
-                self.taps[f'{name}.{lvl}'] = y
+                y = self._b(f'{name}.{lvl}', y)
             outs[name] = self.csp_bottleneck(y, f'{f}.{name}_seg_head', oup)
         return outs['se'], outs['lane'], (p5 + m5, p4 + m4, p3 + m3)
 
@@ -390,7 +401,7 @@ class AchelousOracle:
         outs = []
         for i in range(8):
             x = self.rc_block(x, f'image_radar_encoder.radar_encoder.rc_blocks.{i}', down[i])
-            self.taps[f'radar.b{i}'] = x
+            x = self._b(f'radar.b{i}', x)
             if i > 1 and i % 2 == 1:
                 outs.append(x)
         return outs
@@ -467,11 +478,14 @@ class AchelousOracle:
         else:
             pc = torch.from_numpy(self.pn2.forward(x_pc.float()))
             self.taps.update({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in self.pn2.taps.items()})
+        if self.boundary_dtype is not None:
+            x, x_radar = x.to(self.boundary_dtype), x_radar.to(self.boundary_dtype)
         se, lane, (q5, q4, q3) = self.ghost_dual_fpn(x.float()) if self.neck == 'gdf' else self.csp_dual_fpn(x.float())
         r3, r4, r5 = self.rcnet(x_radar.float())
-        self.taps.update({'q5': q5, 'q4': q4, 'q3': q3, 'r3': r3, 'r4': r4, 'r5': r5})
+        self.taps.update({'r3': r3, 'r4': r4, 'r5': r5})
+        q5, q4, q3 = self._b('q5', q5), self._b('q4', q4), self._b('q3', q3)
         p3, p4, p5 = self.fuse(q3, r3, 3), self.fuse(q4, r4, 4), self.fuse(q5, r5, 5)
-        self.taps.update({'p3': p3, 'p4': p4, 'p5': p5})
+        p3, p4, p5 = self._b('p3', p3), self._b('p4', p4), self._b('p5', p5)
         det = self.head((p3, p4, p5))
         return det, se, lane, pc
 

@@ -22,6 +22,98 @@ F32_TOL = 1e-3
 OUTPUTS = ('det0', 'det1', 'det2', 'se_seg', 'lane_seg', 'pc_seg')
 
 
+# ---- The bf16 engine's bound (round 3).  SURVEY 8c's 2e-2 holds for the detection maps and the point output.  The two segmentation
+# maps end 60-layer chains of conv + BN + ReLU on mean-dominated activations, and what bf16 STORAGE alone costs there is a property of the
+# weights and the frames: the oracle has a mode that computes everything in fp32 but rounds the inputs and every SURVEY 8(a) boundary
+# tensor to bf16 (AchelousOracle(boundary_dtype=torch.bfloat16): the "ideal bf16-storage engine", ~50 roundings per forward).  On the
+# fixtures that ideal engine deviates from the fp32 truth by 3-7e-2 on se_seg / lane_seg (1.1e-1 on MV-S2's lane map) and agrees with
+# its arg-max decisions on 96.5-99 % of the pixels — no engine that stores activations in bf16 can do better than that order, and the
+# CPU-autocast evaluation of the reference (round 2's yardstick) is 2-3x noisier still.  So every output must be within
+#     max(2e-2, BF16_VS_IDEAL x the ideal engine's deviation on the same frames),   and never above BF16_HARD_CEILING,
+# and the decisions taken from the outputs (per-pixel arg-max, NMS kept set) must agree with the fp32 truth at least as often as the
+# ideal engine's do, minus a small allowance.  Measured on MI355X (EN-S0 fixture frames): se_seg 2.8e-2 (ideal 3.9e-2), lane_seg 4.7e-2
+# (ideal 6.7e-2), det 1.0-1.3e-2 (ideal 0.6-1.1e-2), pc 0.9e-2.
+BF16_VS_IDEAL = 2.0
+BF16_HARD_CEILING = 0.25
+BF16_ARGMAX_ALLOWANCE = 0.025    # arg-max agreement >= the ideal bf16-storage engine's agreement minus this (and >= 0.9)
+BF16_NMS_JACCARD = 0.95          # kept-set |A & B| / |A | B| against the fp32 truth, per frame: >= this, or >= the ideal engine's minus the allowance
+BF16_NMS_ALLOWANCE = 0.08
+
+
+def ideal_bf16_outputs(sd, kw, x, xr, xp):
+    """fp32 truth and the ideal bf16-storage engine (see above) on the same frames: two oracle evaluations -> dicts over OUTPUTS."""
+    okw = {k: kw[k] for k in ('num_det', 'num_seg', 'phi', 'backbone', 'neck', 'pc_seg', 'pc_channels', 'pc_classes', 'nano_head', 'spp', 'resolution')}
+    sd = {k: v.cpu() for k, v in sd.items()}
+    t = AchelousOracle(sd, **okw).forward(x, xr, xp)
+    i = AchelousOracle(sd, **okw, boundary_dtype=torch.bfloat16).forward(x, xr, xp.bfloat16().float())
+    truth = dict(zip(OUTPUTS, (*t[0], t[1], t[2], t[3])))
+    ideal = dict(zip(OUTPUTS, (*i[0], i[1], i[2], i[3])))
+    return truth, ideal
+
+
+def bf16_output_bound(truth, ideal, k):
+    return min(BF16_HARD_CEILING, max(2e-2, BF16_VS_IDEAL * _rel(ideal[k], truth[k])))
+
+
+def check_bf16_decisions(tag, truth, ideal, got_se, got_lane, kept, resolution, num_det, nms_settings):
+    """Decision level: arg-max class maps of the two segmentation outputs and the NMS kept sets against the fp32 truth, each next to what
+    the ideal bf16-storage engine achieves on the same frames.  `kept`: {(conf, iou): (idx [F, max_det], cnt [F])} from the bf16 engine's
+    forward_detect on the same frames."""
+    w_se, w_lane = decisions(truth['se_seg'], truth['lane_seg'])
+    i_se, i_lane = decisions(ideal['se_seg'], ideal['lane_seg'])
+    a_se, a_lane = decisions(got_se.cpu(), got_lane.cpu())
+    agree = {'se': float((a_se == w_se).float().mean()), 'lane': float((a_lane == w_lane).float().mean())}
+    ideal_agree = {'se': float((i_se == w_se).float().mean()), 'lane': float((i_lane == w_lane).float().mean())}
+    # decisive pixels: top-1 / top-2 gap of the truth above twice the sup-norm bound (and at least 10 % of the map's range) -> no flip is possible
+    m_se = max(0.1, 2.0 * bf16_output_bound(truth, ideal, 'se_seg')), max(0.1, 2.0 * bf16_output_bound(truth, ideal, 'lane_seg'))
+    d_se, d_lane = decisive(truth['se_seg'], m_se[0]), decisive(truth['lane_seg'], m_se[1])
+    dec = {'se': float((a_se == w_se)[d_se].float().mean()) if d_se.any() else 1.0, 'lane': float((a_lane == w_lane)[d_lane].float().mean()) if d_lane.any() else 1.0}
+    det, idet = [truth['det0'], truth['det1'], truth['det2']], [ideal['det0'], ideal['det1'], ideal['det2']]
+    jac, ijac = {}, {}
+    for (conf, iou) in nms_settings:
+        exp = o_nms(o_decode(det, [resolution] * 2), num_det, conf, iou)
+        iexp = o_nms(o_decode(idet, [resolution] * 2), num_det, conf, iou)
+        idx, cnt = kept[(conf, iou)]
+        cap = idx.shape[1]
+        sets = [set(int(i) for i in exp[b][1][:cap]) for b in range(idx.shape[0])]
+        jac[(conf, iou)] = [round(len(set(idx[b, :int(cnt[b])].tolist()) & sets[b]) / max(1, len(set(idx[b, :int(cnt[b])].tolist()) | sets[b])), 4) for b in range(idx.shape[0])]
+        ijac[(conf, iou)] = [round(len(set(int(i) for i in iexp[b][1][:cap]) & sets[b]) / max(1, len(set(int(i) for i in iexp[b][1][:cap]) | sets[b])), 4) for b in range(idx.shape[0])]
+    print(f'{tag}: bf16 decisions vs fp32 truth: arg-max agreement {agree} (ideal bf16-storage engine: {ideal_agree}); on decisive pixels {dec}; '
+          f'NMS kept-set Jaccard {jac} (ideal: {ijac})')
+    problems = []
+    for k in ('se', 'lane'):
+        if dec[k] != 1.0:
+            problems.append(('decisive', k, dec[k]))
+        if agree[k] < max(0.9, ideal_agree[k] - BF16_ARGMAX_ALLOWANCE):
+            problems.append(('argmax', k, agree[k], ideal_agree[k]))
+    for key in jac:
+        for b, (j, ij) in enumerate(zip(jac[key], ijac[key])):
+            if j < min(BF16_NMS_JACCARD, ij - BF16_NMS_ALLOWANCE):
+                problems.append(('nms', key, b, j, ij))
+    assert not problems, (tag, problems)
+
+
+def decisions(se, lane):
+    """The decisions the outputs are used for (achelous.py:283-318: per-pixel argmax of the two segmentation maps)."""
+    return se.float().argmax(1), lane.float().argmax(1)
+
+
+def decisive(t, margin):
+    """Pixels whose top-1 / top-2 gap in the fp32 truth exceeds `margin` x max|t|: there an engine within margin / 2 cannot flip the argmax."""
+    top = t.float().topk(2, dim=1).values
+    return (top[:, 0] - top[:, 1]) > margin * t.abs().max()
+
+
+def kept_set_jaccard(idx_a, cnt_a, idx_b, cnt_b):
+    """Per frame |A & B| / |A | B| over the kept anchor indices of two NMS runs."""
+    out = []
+    for b in range(idx_a.shape[0]):
+        a_ = set(idx_a[b, :int(cnt_a[b])].tolist())
+        b_ = set(idx_b[b, :int(cnt_b[b])].tolist())
+        out.append(len(a_ & b_) / max(1, len(a_ | b_)))
+    return out
+
+
 def bf16_bound(g, tap):
     """Per-tensor bound for the bf16 engine against the reference's fp32 fixture, same metric as fp32.
 
@@ -34,7 +126,9 @@ def bf16_bound(g, tap):
     rounding patterns differs by such factors from run to run).  Internal boundaries (debug taps) get max(4e-2, 3 x): the fused
     kernels round at different places than the layers whose outputs these taps are."""
     ref = g.meta['bf16_autocast_reference_err'].get(tap, 0.0)
-    return max(2e-2, 2.0 * ref) if tap in OUTPUTS else max(4e-2, 3.0 * ref)
+    if tap in OUTPUTS:                     # (round 3: the six outputs are bounded by bf16_output_bound() instead; kept for the option tests)
+        return max(2e-2, 2.0 * ref)
+    return max(4e-2, 3.0 * ref)
 
 
 def _model(g, device='cuda', debug_taps=False):
@@ -121,10 +215,18 @@ def test_forward_bf16_matches_reference_fixtures(name):
             continue
         t = outs[tap].float() if tap in outs else e.read_tap(tap)
         errs[tap] = g.rel_err(tap, t, check_sums=False)
-    print(f'{name}: bf16 rel err per tensor (bound):',
-          {k: f'{v:.1e} ({bf16_bound(g, k):.1e})' for k, v in sorted(errs.items(), key=lambda kv: -kv[1] / bf16_bound(g, kv[0]))})
-    bad = {k: (v, bf16_bound(g, k)) for k, v in errs.items() if not v < bf16_bound(g, k)}
+    truth, ideal = ideal_bf16_outputs(m.state_dict(), kw, x, xr, xp)
+    bound = {k: (bf16_output_bound(truth, ideal, k) if k in OUTPUTS else bf16_bound(g, k)) for k in errs}
+    print(f'{name}: bf16 rel err per tensor (bound):', {k: f'{v:.1e} ({bound[k]:.1e})' for k, v in sorted(errs.items(), key=lambda kv: -kv[1] / bound[kv[0]])})
+    print(f'{name}: outputs: engine / ideal bf16-storage engine:', {k: f'{errs[k]:.1e} / {_rel(ideal[k], truth[k]):.1e}' for k in OUTPUTS})
+    bad = {k: (v, bound[k]) for k, v in errs.items() if not v < bound[k]}
     assert not bad, bad
+    kept = {}
+    for conf, iou in g.meta['nms_settings']:
+        with torch.no_grad():
+            _, (rows, idx, cnt) = m.forward_detect(x.cuda().bfloat16(), xr.cuda().bfloat16(), xp.cuda().bfloat16(), conf, iou, None)
+        kept[(conf, iou)] = (idx.cpu(), cnt.cpu())
+    check_bf16_decisions(name, truth, ideal, se, lane, kept, kw['resolution'], kw['num_det'], [tuple(s_) for s_ in g.meta['nms_settings']])
 
 
 def test_nms_bit_exact_on_reference_decoded():
@@ -197,31 +299,45 @@ def test_deformable_sampling_far_and_boundary_offsets(mode):
         assert max(errs.values()) < tol, (mode, dt, errs)
 
 
-def test_full_batch_64_properties():
-    """BASELINE.json size (B=64).  (1) Frames 0, 21, 42, 63 of a 64-batch of DISTINCT frames against the oracle run on those four
-    frames (fp32 <= 1e-3; bf16 within max(2e-2, 2 x the deviation of the oracle's own bf16-autocast evaluation of these frames)).  (2) Size-independent
-    properties over the whole batch: a frame's outputs do not depend on its batch position or neighbours, outputs finite,
-    segmentation outputs non-negative (post-ReLU), point log-probabilities normalised."""
-    g = Golden('en_s0')
+@pytest.mark.parametrize('name', ['en_s0', 'en_s2', 'mv_s2'])
+def test_full_batch_64_frames_match_oracle(name):
+    """BASELINE.json size (B=64) for every model config (EN-S0 = configs[1], MV-S2 = configs[2], EN-S2 = the per-GPU shard of
+    configs[4]; PointNet++: tests/test_pointnet2.py).  Plans are batch-dependent (N-chunk split over blockIdx.z, SPLIT / one-tile choices,
+    2-GiB chunking), so frames 0, 21, 42, 63 of a 64-batch of DISTINCT frames are compared with the oracle run on those four frames:
+    fp32 <= 1e-3 with identical decisions (arg-max maps, NMS kept indices in order); bf16 under bf16_output_bound() with the decision-level checks."""
+    g = Golden(name)
     m, kw = _model(g)
     x64, r64, p64 = make_inputs(64, 6464, resolution=kw['resolution'], pc_channels=kw['pc_channels'])
     pick = [0, 21, 42, 63]
-    orc = AchelousOracle({k: v.cpu() for k, v in m.state_dict().items()}, **kw)
-    odet, ose, olane, opc = orc.forward(x64[pick], r64[pick], p64[pick])
-    want = dict(zip(OUTPUTS, (*odet, ose, olane, opc)))
-    # the bf16 yardstick of bf16_bound(), re-measured on THESE frames and on whole tensors (the fixture's figures are for its own two
-    # frames and its stored samples): the oracle evaluated under bf16 autocast against its fp32 self
-    with torch.autocast('cpu', dtype=torch.bfloat16):
-        adet, ase, alane, apc = AchelousOracle({k: v.cpu() for k, v in m.state_dict().items()}, **kw).forward(x64[pick], r64[pick], p64[pick])
-    amp = {k: _rel(a.float(), want[k]) for k, a in zip(OUTPUTS, (*adet, ase, alane, apc))}
+    want, ideal = ideal_bf16_outputs(m.state_dict(), kw, x64[pick], r64[pick], p64[pick])
     for dt in (torch.float32, torch.bfloat16):
         with torch.no_grad():
-            det, se, lane, pc = m(x64.cuda().to(dt), r64.cuda().to(dt), p64.cuda().to(dt))
+            (det, se, lane, pc), (rows, idx, cnt) = m.forward_detect(x64.cuda().to(dt), r64.cuda().to(dt), p64.cuda().to(dt), 0.35, 0.35, 100)
         got = dict(zip(OUTPUTS, (*det, se, lane, pc)))
         errs = {k: _rel(got[k][pick].float(), want[k]) for k in OUTPUTS}
-        print(f'B=64 frames {pick} vs oracle, {dt}:', {k: f'{v:.1e}' for k, v in errs.items()}, '| oracle under bf16 autocast:', {k: f'{v:.1e}' for k, v in amp.items()})
+        bound = {k: (F32_TOL if dt == torch.float32 else bf16_output_bound(want, ideal, k)) for k in OUTPUTS}
+        print(f'{name} B=64 frames {pick} vs oracle, {dt}:', {k: f'{v:.1e} ({bound[k]:.1e})' for k, v in errs.items()})
         for k, v in errs.items():
-            assert v < (F32_TOL if dt == torch.float32 else max(2e-2, 2.0 * amp[k])), (dt, k, v, amp[k])
+            assert v < bound[k], (name, dt, k, v, bound[k])
+        kept = {(0.35, 0.35): (idx[pick].cpu(), cnt[pick].cpu())}
+        if dt == torch.float32:
+            a_se, a_lane = decisions(got['se_seg'][pick].cpu(), got['lane_seg'][pick].cpu())
+            w_se, w_lane = decisions(want['se_seg'], want['lane_seg'])
+            assert float((a_se == w_se).float().mean()) > 0.9995 and float((a_lane == w_lane).float().mean()) > 0.9995
+            exp = o_nms(o_decode([want['det0'], want['det1'], want['det2']], [kw['resolution']] * 2), kw['num_det'], 0.35, 0.35)
+            for j in range(4):
+                n = int(kept[(0.35, 0.35)][1][j])
+                assert np.array_equal(kept[(0.35, 0.35)][0][j, :n].numpy().astype(np.int64), exp[j][1][:100]), j
+        else:
+            check_bf16_decisions(f'{name} B=64', want, ideal, got['se_seg'][pick], got['lane_seg'][pick], kept, kw['resolution'], kw['num_det'], [(0.35, 0.35)])
+
+
+def test_full_batch_64_properties():
+    """BASELINE.json size (B=64), size-independent properties over the whole batch: a frame's outputs do not depend on its batch
+    position or neighbours, outputs finite, segmentation outputs non-negative (post-ReLU), point log-probabilities normalised."""
+    g = Golden('en_s0')
+    m, kw = _model(g)
+    x64, r64, p64 = make_inputs(64, 6464, resolution=kw['resolution'], pc_channels=kw['pc_channels'])
     x, xr, xp = x64[:4], r64[:4], p64[:4]
     rep = torch.arange(64) % 4
     perm = torch.randperm(64, generator=torch.Generator().manual_seed(1))
@@ -561,3 +677,45 @@ def test_gemm_rows_per_wave_is_bit_identical(rows):
         torch.cuda.synchronize()
     for a, b, c in zip((*one[0], one[1], one[2]), (*many[0], many[1], many[2]), (*base[0], base[1], base[2])):
         assert torch.equal(a, b) and torch.equal(a, c)
+
+
+def test_three_task_module_and_wide_head():
+    """API variants of nets/Achelous.py on the MI355X.  Achelous3T (:56-76): same weights minus `pc_seg_model.*` -> the first three outputs
+    of Achelous bit for bit, forward_detect too (checked against the imported reference's own Achelous3T by tests/golden/gen_golden.py
+    `variants`).  nano_head=False (head/decouplehead.py:30-33, base 256): fp32 against the oracle, bf16 detection maps under the ceiling."""
+    from achelous_amd import Achelous3T
+    g = Golden('en_s0')
+    m, kw = _model(g)
+    kw3 = {k: v for k, v in kw.items() if k != 'pc_seg'}
+    m3 = Achelous3T(**kw3).eval()
+    m3.load_state_dict({k: v for k, v in m.state_dict().items() if not k.startswith('pc_seg_model.')}, strict=True)
+    m3 = m3.cuda()
+    x, xr, xp = make_inputs(3, 41, resolution=kw['resolution'], pc_channels=kw['pc_channels'])
+    for dt in (torch.float32, torch.bfloat16):
+        xs, rs, ps = x.cuda().to(dt), xr.cuda().to(dt), xp.cuda().to(dt)
+        with torch.no_grad():
+            full, dfull = m.forward_detect(xs, rs, ps, 0.05, 0.5, 100)
+            out3 = m3(xs, rs)
+            three, dthree = m3.forward_detect(xs, rs, 0.05, 0.5, 100)
+            p = m3.submit(xs, rs)
+            sub = p.wait()
+        torch.cuda.synchronize()
+        assert len(out3) == 3 and len(three) == 3
+        for o in (out3, three, sub):
+            for a, b in zip((*o[0], o[1], o[2]), (*full[0], full[1], full[2])):
+                assert torch.equal(a, b)
+        for a, b in zip(dthree, dfull):
+            assert torch.equal(a, b)
+    assert m3.native_engine(torch.float32).launches() < m.native_engine(torch.float32).launches()
+    kww = dict(kw, nano_head=False)
+    mw = Achelous(**kww).eval()
+    sd = condition_state_dict(mw.state_dict(), seed=g.meta['weight_seed'])
+    mw.load_state_dict(sd, strict=True)
+    mw = mw.cuda()
+    okw = {k: kww[k] for k in ('num_det', 'num_seg', 'phi', 'backbone', 'neck', 'pc_seg', 'pc_channels', 'pc_classes', 'nano_head', 'spp', 'resolution')}
+    ref = AchelousOracle({k: v.cpu() for k, v in sd.items()}, **okw).forward(x, xr, xp)
+    with torch.no_grad():
+        det = mw(x.cuda(), xr.cuda(), xp.cuda())[0]
+        det16 = mw(x.cuda().bfloat16(), xr.cuda().bfloat16(), xp.cuda().bfloat16())[0]
+    for k in range(3):
+        assert _rel(det[k], ref[0][k]) <= F32_TOL and _rel(det16[k].float(), ref[0][k]) <= 2e-2, (k, _rel(det[k], ref[0][k]), _rel(det16[k].float(), ref[0][k]))

@@ -197,3 +197,38 @@ def test_gpu_pn2_batch_64_is_batch_independent():
     assert torch.isfinite(full).all()
     assert torch.allclose(torch.exp(full).sum(-1), torch.ones(64, 512), atol=3e-2)
     assert _rel(full[62:64], part) < 2e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype,tol', [(torch.float32, 1e-3), (torch.bfloat16, 6e-2)])
+def test_gpu_pn2_batch_64_frames_match_the_self_oracle(dtype, tol):
+    """BASELINE.json config 4 at its full size, DIRECTLY against the self-oracle (not through batch independence): frames 0, 21, 42, 63
+    of a batch of 64 distinct frames — the B=64 plan (flat colmax grid, N-chunk split) differs from the small-batch plans.  Index
+    selections (FPS picks, ball members) bit-exact, features within the tolerance, the whole batch finite and normalised."""
+    kw = {**KW, 'resolution': 320}
+    m = achelous_amd.Achelous(**kw).eval()
+    m.debug_taps = True
+    sd = condition_state_dict(m.state_dict(), seed=0)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda()
+    x, xr, xp = make_inputs(64, 6464, resolution=320, num_points=512, pc_channels=5)
+    xp = xp.to(dtype)
+    pick = [0, 21, 42, 63]
+    with torch.no_grad():
+        det, se, lane, pc = m(x.cuda().to(dtype), xr.cuda().to(dtype), xp.cuda())
+    torch.cuda.synchronize()
+    orc = AchelousOracle({k: v.cpu() for k, v in sd.items()}, **kw)
+    rdet, rse, rlane, rpc = orc.forward(x[pick], xr[pick], xp[pick].float())
+    errs = {n: _rel(a[pick].float(), b.float()) for n, a, b in zip(('det0', 'det1', 'det2', 'se', 'lane', 'pc'), (*det, se, lane, pc), (*rdet, rse, rlane, rpc))}
+    print('PN2 B=64 frames', pick, dtype, {k: f'{v:.1e}' for k, v in errs.items()})
+    assert max(errs.values()) <= tol, errs
+    assert torch.isfinite(pc.float()).all() and torch.allclose(pc.float().exp().sum(-1), torch.ones(64, 512, device='cuda'), atol=3e-2 if dtype == torch.bfloat16 else 1e-4)
+    e = m.native_engine(dtype)
+    checked = 0
+    for tap in e.tap_names():
+        if tap.startswith('pc.') and tap.endswith(('.fps', '.group_idx', '.xyz')):
+            a, b = e.read_tap(tap), orc.taps[tap]
+            a = a.reshape(64, *b.shape[1:]) if a.numel() == 16 * b.numel() else a
+            assert torch.equal(a[pick].cpu().reshape(b.shape), b.float()), tap
+            checked += 1
+    assert checked >= 8
