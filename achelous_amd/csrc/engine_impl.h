@@ -945,11 +945,24 @@ public:
             DecHeadParams dp{t.p, t.ld, full_taps ? f.p : nullptr, full_taps ? f.ld : 0, nullptr, p.Wdw, p.bdw, static_cast<const uint4*>(up_raw(af.data(), af.size() * 2)),
                              up_f32(bh8), up_f32(wd8), up_f32(bd8), x.B, x.H, x.W, init, nch, oup, p.sy, p.sx, band, cdiv(H2, band), cdiv(2 * x.W, DH_VALID)};
             const dim3 grid(unsigned(dp.strips) * unsigned(dp.bands) * unsigned(x.B)), block(64);
+            // per-output-row interpolation geometry, in the float arithmetic of the tile kernel / torch (k_dechead.h)
+            std::vector<DecHeadRow> rg(static_cast<size_t>(H2) + 4);
+            for (int i = 0; i < H2 + 4; ++i) {
+                const float fy = p.sy * float(i < H2 ? i : H2 - 1);
+                int y0 = int(fy);
+                if (y0 > x.H - 1) y0 = x.H - 1;
+                rg[size_t(i)] = DecHeadRow{y0, y0 < x.H - 1 ? fy - float(y0) : 0.f};
+            }
+            const DecHeadRow* rows = static_cast<const DecHeadRow*>(up_raw(rg.data(), rg.size() * sizeof(DecHeadRow)));
             const int dbg = head_debug;
-            const bool dw2 = nch > 4;
-            add_op(head_pfx + ".upghost_head", [dp, grid, block, out, dbg, dw2](hipStream_t s) mutable {
+            const bool dw2 = nch > 4, tapf = full_taps;
+            add_op(head_pfx + ".upghost_head", [dp, grid, block, out, dbg, dw2, tapf, rows](hipStream_t s) mutable {
                 dp.out = *out;
-#define ACH_DH_CASE(D) case D: if (dw2) ACH_LAUNCH((dechead_rows_kernel<true, D>), grid, block, s, dp); else ACH_LAUNCH((dechead_rows_kernel<false, D>), grid, block, s, dp); break;
+                if (tapf) {                      // parity-test plans: the variant that also writes [x1 | x2]
+                    if (dw2) ACH_LAUNCH((dechead_rows_kernel<true, true, 0>), grid, block, s, dp, rows); else ACH_LAUNCH((dechead_rows_kernel<false, true, 0>), grid, block, s, dp, rows);
+                    return;
+                }
+#define ACH_DH_CASE(D) case D: if (dw2) ACH_LAUNCH((dechead_rows_kernel<true, false, D>), grid, block, s, dp, rows); else ACH_LAUNCH((dechead_rows_kernel<false, false, D>), grid, block, s, dp, rows); break;
 #if defined(ACH_HEAD_DEBUG)
                 switch (dbg) { ACH_DH_CASE(1) ACH_DH_CASE(2) ACH_DH_CASE(3) ACH_DH_CASE(4) ACH_DH_CASE(7) ACH_DH_CASE(8) ACH_DH_CASE(15) default: ACH_DH_CASE(0) }
 #else

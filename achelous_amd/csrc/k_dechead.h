@@ -61,10 +61,23 @@ __device__ __forceinline__ float add_from_right(float a, float v) {     // row_s
 }
 #endif
 
+// Row geometry of the x2 bilinear interpolation, one entry per OUTPUT row (written by the host with the float arithmetic the tile kernel
+// and torch use: fy = sy * float(i); y0 = min(int(fy), h-1); ly = y0 < h-1 ? fy - y0 : 0): the walk reads it with scalar loads instead of
+// recomputing it on the VALU for every row of every strip.
+struct DecHeadRow { int y0; float ly; };
+
+// max(v, 0) of a value that comes out of inline assembly: one v_max_f32 (the compiler would first canonicalise a value it cannot see into)
+#if defined(ACH_HOSTEMU)
+__device__ inline float relu_raw(float v) { return v > 0.f ? v : 0.f; }
+#else
+__device__ __forceinline__ float relu_raw(float v) { float r; asm("v_max_f32_e32 %0, 0, %1" : "=v"(r) : "v"(v)); return r; }
+#endif
+
 // DW2: the head's cheap operation has more than four channels (num_seg > 8): accumulator r = 1 takes part in it too.
 // DBG (timing experiments only, results are wrong): bit 0 no bilinear, 1 no level depthwise, 2 no MFMA, 3 no head depthwise / stores.
-template <bool DW2, int DBG = 0>
-__global__ __launch_bounds__(64, DH_WAVES) void dechead_rows_kernel(const DecHeadParams p) {
+// TAP: also write [x1 | x2] to p.F (parity tests, option full_taps).
+template <bool DW2, bool TAP, int DBG = 0>
+__global__ __launch_bounds__(64, DH_WAVES) void dechead_rows_kernel(const DecHeadParams p, const DecHeadRow* __restrict__ rows) {
     const int H = 2 * p.h, Wd = 2 * p.w;
     const unsigned u = xcd_block(blockIdx.x, gridDim.x);
     const int strip = int(u % unsigned(p.strips)), band = int((u / unsigned(p.strips)) % unsigned(p.bands));
@@ -81,8 +94,9 @@ __global__ __launch_bounds__(64, DH_WAVES) void dechead_rows_kernel(const DecHea
     const int dx = x0 < p.w - 1 ? 1 : 0;
     const float lx = fx - float(x0);
     const float wx0 = in_x ? 1.f - lx : 0.f, wx1 = in_x ? lx : 0.f;        // a column outside the map is the depthwise conv's zero padding
-    const bf16_t* Tq = static_cast<const bf16_t*>(p.Tq) + b * p.h * long(p.w) * p.ldt + 4 * g;
-    const int o0 = x0 * int(p.ldt), o1 = (x0 + dx) * int(p.ldt), rowp = p.w * int(p.ldt);
+    const bf16_t* Tq = static_cast<const bf16_t*>(p.Tq) + b * p.h * long(p.w) * p.ldt;          // (uniform)
+    const unsigned o0 = unsigned(x0 * int(p.ldt) + 4 * g), o1 = unsigned((x0 + dx) * int(p.ldt) + 4 * g);
+    const int rowp = p.w * int(p.ldt);
     // ---- per-lane weights; channel PAIRS (4g, 4g+1) and (4g+2, 4g+3) as packed fp32 (v_pk_fma_f32 / v_pk_mul_f32: two lanes' worth of FMAs per issue)
     f32x2 wl[9][2], bl[2];
     ACH_UNROLL
@@ -98,17 +112,20 @@ __global__ __launch_bounds__(64, DH_WAVES) void dechead_rows_kernel(const DecHea
     }
     bhv[0] = p.bh[g]; bhv[1] = p.bh[g + 4];
     const uint4 afrag = p.Afrag[lane];
-    const bool has_h[2] = {g < p.init, g + 4 < p.init};
+    // a lane whose column lies outside the map, or whose accumulator holds no head channel, keeps h = 0 (the head depthwise conv's zero padding)
+    const bool has_h[2] = {in_x && g < p.init, in_x && g + 4 < p.init};
     const bool st_h[2] = {writer && g < p.init && g < p.oup, writer && g + 4 < p.init && g + 4 < p.oup};
     const bool st_d[2] = {writer && g < p.nch, writer && g + 4 < p.nch};
     const long HW = long(H) * Wd;
-    bf16_t* outp = static_cast<bf16_t*>(p.out) + b * p.oup * HW + (in_x ? x : 0);
+    bf16_t* out_b = static_cast<bf16_t*>(p.out) + b * p.oup * HW;                               // (uniform)
+    const unsigned xo = unsigned(in_x ? x : 0);
+    const unsigned off_h[2] = {unsigned(g * HW) + xo, unsigned((g + 4) * HW) + xo};
+    const unsigned off_d[2] = {unsigned((p.init + g) * HW) + xo, unsigned((p.init + g + 4) * HW) + xo};
     // ---- source rows of t, unpacked: ta = row cy, tb = row cy + 1 (clamped), tn = raw row cy + 2 (clamped), fetched one row ahead
     const int r0 = band * p.band_rows, r1 = (r0 + p.band_rows < H) ? r0 + p.band_rows : H;
-    auto src_row = [&](int i) { const float fy = p.sy * float(i); int y0 = int(fy); return y0 > p.h - 1 ? p.h - 1 : y0; };
     auto load_raw = [&](int r, uint2 (&raw)[2]) {
         const int rr = r < 0 ? 0 : (r > p.h - 1 ? p.h - 1 : r);
-        const bf16_t* q = Tq + long(rr) * rowp;
+        const bf16_t* q = Tq + long(rr) * rowp;                              // uniform base + per-lane 32-bit offsets
         raw[0] = *reinterpret_cast<const uint2*>(q + o0);
         raw[1] = *reinterpret_cast<const uint2*>(q + o1);
     };
@@ -120,7 +137,7 @@ __global__ __launch_bounds__(64, DH_WAVES) void dechead_rows_kernel(const DecHea
         }
     };
     const int i_first = r0 - 2 < 0 ? 0 : r0 - 2;
-    int cy = src_row(i_first);
+    int cy = rows[i_first].y0;
     f32x2 ta[2][2], tb[2][2];
     uint2 tn[2];
     { uint2 raw[2]; load_raw(cy, raw); unpack(raw, ta); load_raw(cy + 1, raw); unpack(raw, tb); load_raw(cy + 2, tn); }
@@ -128,34 +145,33 @@ __global__ __launch_bounds__(64, DH_WAVES) void dechead_rows_kernel(const DecHea
     f32x2 w0[2] = {zero2, zero2}, w1[2] = {zero2, zero2}, w2[2] = {zero2, zero2};                         // rolling window of x1 rows (channel pairs)
     float v0[2] = {0.f, 0.f}, v1[2] = {0.f, 0.f}, v2[2] = {0.f, 0.f};                                    // rolling window of h rows
 
-    // one step of the walk: x1 row i into xp; x2 / h of row i-1 (x1 rows xm, xc, xp) into hp; output row i-2 (h rows hm, hc, hp).
-    // The caller rotates the roles of the three window slots, so nothing is copied between steps.
+    // One step of the walk: x1 row i into xp; x2 / h of row i-1 (x1 rows xm, xc, xp) into hp; output row i-2 (h rows hm, hc, hp).  The caller
+    // rotates the roles of the three window slots, so nothing is copied between steps.  Every stage runs on every step — rows outside the
+    // map get zero interpolation weights / a zeroed h, rows outside the band only lose their stores — so the steady state has no branches.
     auto step = [&](const int i, f32x2 (&xm)[2], f32x2 (&xc)[2], f32x2 (&xp)[2], float (&hm)[2], float (&hc)[2], float (&hp)[2]) {
         // ---- A: x1 row i
-        if (i >= 0 && i < H && !(DBG & 1)) {
-            const float fy = p.sy * float(i);
-            int y0 = int(fy);
-            if (y0 > p.h - 1) y0 = p.h - 1;
-            if (y0 > cy) {                     // (the scale is below 1/2: at most one new source row per output row)
+        {
+            const bool row_ok = i >= 0 && i < H;
+            const DecHeadRow rg = rows[row_ok ? i : 0];                    // scalar load: uniform address
+            if (row_ok && rg.y0 > cy) {                                    // (the scale is below 1/2: at most one new source row per output row)
+                // (a two-slot ping-pong instead of this copy was compiled into ~30 selects per step: slower than the four 64-bit moves)
                 ACH_UNROLL
                 for (int c = 0; c < 2; ++c) { ta[c][0] = tb[c][0]; ta[c][1] = tb[c][1]; }
                 unpack(tn, tb);
                 ++cy;
                 load_raw(cy + 2, tn);
             }
-            const float ly = (y0 < p.h - 1) ? fy - float(y0) : 0.f, hy = 1.f - ly;
+            const float ly = row_ok ? rg.ly : 0.f, hy = row_ok ? 1.f - rg.ly : 0.f;
             const float w00 = hy * wx0, w01 = hy * wx1, w10 = ly * wx0, w11 = ly * wx1;
             ACH_UNROLL
             for (int q = 0; q < 2; ++q) {
-                const f32x2 v = w00 * ta[0][q] + w01 * ta[1][q] + w10 * tb[0][q] + w11 * tb[1][q];
+                const f32x2 v = (DBG & 1) ? ta[0][q] : w00 * ta[0][q] + w01 * ta[1][q] + w10 * tb[0][q] + w11 * tb[1][q];
                 xp[q] = f32x2{v[0] > 0.f ? v[0] : 0.f, v[1] > 0.f ? v[1] : 0.f};
             }
-        } else {
-            xp[0] = zero2; xp[1] = zero2;
         }
         // ---- B: x2 and h of row i-1
-        const int rb = i - 1;
-        if (rb >= r0 - 1 && rb <= r1) {
+        {
+            const int rb = i - 1;
             f32x2 x2[2] = {bl[0], bl[1]};
             if (!(DBG & 2)) {
                 ACH_UNROLL
@@ -168,9 +184,9 @@ __global__ __launch_bounds__(64, DH_WAVES) void dechead_rows_kernel(const DecHea
                 }
             }
             ACH_UNROLL
-            for (int q = 0; q < 2; ++q) x2[q] = f32x2{x2[q][0] > 0.f ? x2[q][0] : 0.f, x2[q][1] > 0.f ? x2[q][1] : 0.f};
+            for (int q = 0; q < 2; ++q) x2[q] = f32x2{relu_raw(x2[q][0]), relu_raw(x2[q][1])};
             const bool row_in = rb >= 0 && rb < H;
-            if (p.F && row_in && writer && rb >= r0 && rb < r1) {
+            if (TAP && row_in && writer && rb >= r0 && rb < r1) {
                 bf16_t* fo = static_cast<bf16_t*>(p.F) + ((b * H + rb) * long(Wd) + x) * p.ldf + 4 * g;
                 const float a1[4] = {xc[0][0], xc[0][1], xc[1][0], xc[1][1]}, a2[4] = {x2[0][0], x2[0][1], x2[1][0], x2[1][1]};
                 Store<bf16_t>::st4(fo, a1);
@@ -181,33 +197,31 @@ __global__ __launch_bounds__(64, DH_WAVES) void dechead_rows_kernel(const DecHea
                 const uint4 bfrag = make_uint4(pack_bf16x2(xc[0][0], xc[0][1]), pack_bf16x2(xc[1][0], xc[1][1]), pack_bf16x2(x2[0][0], x2[0][1]), pack_bf16x2(x2[1][0], x2[1][1]));
                 mfma16<bf16_t>(afrag, bfrag, acc);
             }
-            const bool live = row_in && in_x;                   // outside the map h is the head depthwise conv's zero padding
             ACH_UNROLL
-            for (int r = 0; r < 2; ++r) { const float v = acc[r] + bhv[r]; hp[r] = (live && has_h[r] && v > 0.f) ? v : 0.f; }
-        } else {
-            hp[0] = 0.f; hp[1] = 0.f;
+            for (int r = 0; r < 2; ++r) { const float v = acc[r] + bhv[r]; hp[r] = (row_in && has_h[r] && v > 0.f) ? v : 0.f; }
         }
         // ---- C: output row i-2
-        const int ro = i - 2;
-        if (ro >= r0 && ro < r1 && !(DBG & 8)) {
-            bf16_t* orow = outp + long(ro) * Wd;
+        if (!(DBG & 8)) {
+            const int ro = i - 2;
+            const bool row_st = ro >= r0 && ro < r1;
+            bf16_t* orow = out_b + long(row_st ? ro : r0) * Wd;            // uniform base; per-lane 32-bit offsets
             ACH_UNROLL
             for (int r = 0; r < 2; ++r)
-                if (st_h[r]) Store<bf16_t>::st(orow + (g + 4 * r) * HW, hc[r]);
+                if (row_st && st_h[r]) Store<bf16_t>::st(orow + off_h[r], hc[r]);
             ACH_UNROLL
             for (int r = 0; r < NR; ++r) {
                 float a = bdh[r] + wh[1][r] * hm[r] + wh[4][r] * hc[r] + wh[7][r] * hp[r];
                 a = add_from_left(a, wh[0][r] * hm[r] + wh[3][r] * hc[r] + wh[6][r] * hp[r]);
                 a = add_from_right(a, wh[2][r] * hm[r] + wh[5][r] * hc[r] + wh[8][r] * hp[r]);
-                if (st_d[r]) Store<bf16_t>::st(orow + (p.init + g + 4 * r) * HW, a > 0.f ? a : 0.f);
+                if (row_st && st_d[r]) Store<bf16_t>::st(orow + off_d[r], relu_raw(a));
             }
         }
     };
     ACH_NO_UNROLL
     for (int i = r0 - 2; i <= r1 + 1; i += 3) {
         step(i, w0, w1, w2, v0, v1, v2);
-        if (i + 1 <= r1 + 1) step(i + 1, w1, w2, w0, v1, v2, v0);
-        if (i + 2 <= r1 + 1) step(i + 2, w2, w0, w1, v2, v0, v1);
+        step(i + 1, w1, w2, w0, v1, v2, v0);          // (up to two steps beyond the band: their stores are masked)
+        step(i + 2, w2, w0, w1, v2, v0, v1);
     }
 }
 
