@@ -49,14 +49,17 @@ constexpr int DH_WAVES = ACH_DH_WAVES;        // register budget: waves per SIMD
 __device__ inline float add_from_left(float a, float v) { const int l = int(threadIdx.x) & 63; const float o = __shfl(v, (l & 15) ? l - 1 : l); return a + ((l & 15) ? o : 0.f); }
 __device__ inline float add_from_right(float a, float v) { const int l = int(threadIdx.x) & 63; const float o = __shfl(v, (l & 15) != 15 ? l + 1 : l); return a + ((l & 15) != 15 ? o : 0.f); }
 #else
+// Inline assembly, because the compiler's vectoriser otherwise pairs the adds into v_pk_add_f32 behind two v_mov_b32_dpp.  The hazard
+// recogniser cannot see into an asm statement: a DPP read of a VGPR needs two wait states after the VALU write of that VGPR (measured the
+// hard way: without the s_nop the head read stale partial sums on the MI355X while the CPU emulation was right), hence the s_nop 1.
 __device__ __forceinline__ float add_from_left(float a, float v) {      // row_shr:1, bound_ctrl: lanes without a source read 0
     float r;
-    asm("v_add_f32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(v), "v"(a));
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(v), "v"(a));
     return r;
 }
 __device__ __forceinline__ float add_from_right(float a, float v) {     // row_shl:1
     float r;
-    asm("v_add_f32_dpp %0, %1, %2 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(v), "v"(a));
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(v), "v"(a));
     return r;
 }
 #endif
@@ -65,6 +68,28 @@ __device__ __forceinline__ float add_from_right(float a, float v) {     // row_s
 // and torch use: fy = sy * float(i); y0 = min(int(fy), h-1); ly = y0 < h-1 ? fy - y0 : 0): the walk reads it with scalar loads instead of
 // recomputing it on the VALU for every row of every strip.
 struct DecHeadRow { int y0; float ly; };
+
+// four channels at once: o[q] = (c[q] + left neighbour's l[q]) + right neighbour's r[q] — ONE leading s_nop covers all eight DPP reads
+// (every l / r is written before the statement starts; the chained second add reads the first one's result as a plain operand)
+#if defined(ACH_HOSTEMU)
+__device__ inline void combine4(const float (&c)[4], const float (&l)[4], const float (&r)[4], float (&o)[4]) {
+    for (int q = 0; q < 4; ++q) o[q] = add_from_right(add_from_left(c[q], l[q]), r[q]);
+}
+#else
+__device__ __forceinline__ void combine4(const float (&c)[4], const float (&l)[4], const float (&r)[4], float (&o)[4]) {
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %8, %4 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %9, %5 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %2, %10, %6 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %3, %11, %7 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %0, %12, %0 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %13, %1 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %2, %14, %2 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %3, %15, %3 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+        : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3])
+        : "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(l[0]), "v"(l[1]), "v"(l[2]), "v"(l[3]), "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]));
+}
+#endif
 
 // max(v, 0) of a value that comes out of inline assembly: one v_max_f32 (the compiler would first canonicalise a value it cannot see into)
 #if defined(ACH_HOSTEMU)
@@ -174,14 +199,18 @@ __global__ __launch_bounds__(64, DH_WAVES) void dechead_rows_kernel(const DecHea
             const int rb = i - 1;
             f32x2 x2[2] = {bl[0], bl[1]};
             if (!(DBG & 2)) {
+                // per-column partial sums of the left / centre / right taps; the neighbours' sums arrive by two shifted adds per channel
+                f32x2 sl[2], sr[2], sc[2];
                 ACH_UNROLL
                 for (int q = 0; q < 2; ++q) {
-                    // per-column partial sums of the left / centre / right taps; the neighbours' sums arrive by two shifted adds per channel
-                    const f32x2 sl = wl[0][q] * xm[q] + wl[3][q] * xc[q] + wl[6][q] * xp[q];      // what this column contributes to x + 1
-                    const f32x2 sr = wl[2][q] * xm[q] + wl[5][q] * xc[q] + wl[8][q] * xp[q];      // ... to x - 1
-                    const f32x2 sc = x2[q] + wl[1][q] * xm[q] + wl[4][q] * xc[q] + wl[7][q] * xp[q];
-                    x2[q] = f32x2{add_from_right(add_from_left(sc[0], sl[0]), sr[0]), add_from_right(add_from_left(sc[1], sl[1]), sr[1])};
+                    sl[q] = wl[0][q] * xm[q] + wl[3][q] * xc[q] + wl[6][q] * xp[q];               // what this column contributes to x + 1
+                    sr[q] = wl[2][q] * xm[q] + wl[5][q] * xc[q] + wl[8][q] * xp[q];               // ... to x - 1
+                    sc[q] = x2[q] + wl[1][q] * xm[q] + wl[4][q] * xc[q] + wl[7][q] * xp[q];
                 }
+                const float c4[4] = {sc[0][0], sc[0][1], sc[1][0], sc[1][1]}, l4[4] = {sl[0][0], sl[0][1], sl[1][0], sl[1][1]}, r4[4] = {sr[0][0], sr[0][1], sr[1][0], sr[1][1]};
+                float o4[4];
+                combine4(c4, l4, r4, o4);
+                x2[0] = f32x2{o4[0], o4[1]}; x2[1] = f32x2{o4[2], o4[3]};
             }
             ACH_UNROLL
             for (int q = 0; q < 2; ++q) x2[q] = f32x2{relu_raw(x2[q][0]), relu_raw(x2[q][1])};
