@@ -12,6 +12,7 @@
 #include "k_conv3.h"
 #include "k_gemm.h"
 #include "k_mlp.h"
+#include "k_mlpband.h"
 #include "k_mv2.h"
 #include "k_mvit.h"
 #include "k_nhwc.h"
@@ -445,6 +446,14 @@ public:
         }
         const double bytes = double(mp.M) * C * sizeof(T) * (xin.p == resid.p ? 2.0 : 3.0);
         const double flops = 4.0 * double(mp.M) * C * hidden + (dw_ks ? 2.0 * double(mp.M) * C * dw_ks * dw_ks : 0.0);
+        // small maps, bf16: a band of rows per workgroup — taps from an LDS halo tile, MLP weights fetched once per band (k_mlpband.h)
+        if (mlp_band && split && dw_ks && act == ACT_GELU && xin.p == resid.p && std::is_same<T, bf16_t>::value && mlp_band_supported(k1, DT, dw_ks, xin.H, xin.W)) {
+            MlpBandParams bp;
+            bp.m = mp; bp.rb = mlp_band_rows(xin.H); bp.bands = cdiv(xin.H, bp.rb);
+            const int nb = xin.B;
+            add_op(name, [bp, nb](hipStream_t s) { launch_mlp_band(bp, nb, s); }, bytes, flops);
+            return true;
+        }
         add_op(name, [mp, DT, split](hipStream_t s) { launch_mlp<T>(mp, DT, split, s); }, bytes, flops);
         return true;
     }

@@ -1,0 +1,261 @@
+// k_mlpband.h — a whole ConvEncoder block on the SMALL maps (EdgeNeXt stages 2 / 3: 20x20 and 10x10 at 320x320) as a BAND kernel
+// (bf16 engine; round 3).
+//
+//     y = x + W2 · gelu( W1 · LN( dw_kxk(x) + b_dw ) + b1 ) + b2          edgenext_modules/conv_encoder.py:19-32
+//
+// mlp_kernel (k_mlp.h, SPLIT mode) gives every 16-pixel tile its own workgroup: 1 600 workgroups per 20x20 block, each of which fetches
+// 49 taps x 12 channel groups through the texture path, unpacks every tap it fetches (2 280 VALU instructions per wave, waves busy 26 %
+// of their lifetime) and streams the block's 147 KB of MLP weights from L2 for its one tile — 45 us per block at 2.7 % of HBM / 3.5 % of MFMA.
+// Here a workgroup owns a BAND of rows of one frame (5 rows x 20 columns = 100 pixels = 7 tiles at 320x320: 4 bands x 64 frames = 256
+// workgroups, one per CU, one round):
+//   0. the band's halo (rows + k - 1, columns + k - 1, zero outside the map) is staged into LDS ONCE, unpacked to fp32;
+//   1. the depthwise conv reads its taps from LDS: thread = 5-pixel strip x 4 channels, a tap row is 11 LDS reads for 5 x 7 x 4 FMAs
+//      (the texture path is out of the loop, nothing is unpacked per tap);
+//   2. LayerNorm per pixel on the fp32 sums, rows written to LDS as MFMA B fragments;
+//   3. the MLP: wave w takes hidden chunks w, w + 4, ... for ALL tiles of the band — a chunk's W1 / W2 fragments are fetched once per
+//      workgroup (7x less weight traffic) and feed 7 independent MFMA chains; GEMM1 -> bias -> GELU -> GEMM2 chained through registers
+//      exactly as in mlp_kernel (same weight packing);
+//   4. the four waves' partial outputs are summed through LDS, + bias + residual, stored.
+#pragma once
+#include "ach_platform.h"
+#include "k_gemm.h"
+#include "k_mlp.h"
+
+namespace ach {
+
+struct MlpBandParams {
+    MlpParams m;
+    int rb, bands;               // rows per band, bands per frame
+};
+
+constexpr int MLPB_SP = 5;       // strip of output pixels per thread in the depthwise phase
+constexpr int MLPB_NTB = 3;      // tiles per reduction round
+constexpr int MLPB_THREADS = 512; // 8 waves: 2 per SIMD (the 150 KB of LDS allow one workgroup per CU)
+
+template <int K1, int DT, int KS, int RB, int MAXW>
+struct MlpBandGeom {
+    static constexpr int CP = K1 * 32;
+    static constexpr int HR = RB + KS - 1, WC = MAXW + KS - 1;
+    static constexpr int NT = (RB * MAXW + 15) / 16;
+    static constexpr int XIN_FLOATS = HR * WC * CP;
+    static constexpr int DWV_FLOATS = NT * 16 * CP;
+    static constexpr int XS_BYTES = NT * K1 * 64 * 16;
+    static constexpr int RED_OFF_FLOATS = (XS_BYTES + 1023) / 1024 * 256;           // red starts behind xs, both alias xin
+    static constexpr int RED_FLOATS = 4 * MLPB_NTB * DT * 4 * 64;
+    static_assert(RED_OFF_FLOATS + RED_FLOATS <= XIN_FLOATS, "reduction buffer must fit the dead halo tile");
+    static_assert((XIN_FLOATS + DWV_FLOATS) * 4 <= 160 * 1024, "LDS budget");
+};
+
+template <int K1, int DT, int KS, int RB, int MAXW>
+__global__ __launch_bounds__(MLPB_THREADS, 1) void mlp_band_kernel(const MlpBandParams bp) {
+    using G = MlpBandGeom<K1, DT, KS, RB, MAXW>;
+    typedef bf16_t T;
+    constexpr int CP = G::CP, NT = G::NT, SP = MLPB_SP, NTB = MLPB_NTB;
+    const MlpParams& p = bp.m;
+    __shared__ float xin[G::XIN_FLOATS];
+    __shared__ float dwv[G::DWV_FLOATS];
+    uint4* xs = reinterpret_cast<uint4*>(xin);                    // (phases 2-3; the halo tile is dead by then)
+    float* red = xin + G::RED_OFF_FLOATS;                         // (phase 4)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int px = lane & 15, g = lane >> 4;
+    const unsigned wg = xcd_block(blockIdx.x, gridDim.x);
+    const int band = int(wg % unsigned(bp.bands)), b = int(wg / unsigned(bp.bands));
+    const int H = p.H, W = p.W, C = p.C;
+    const int y0 = band * bp.rb, rows = (y0 + bp.rb <= H) ? bp.rb : H - y0;
+    const int npx = rows * W, nt = (npx + 15) / 16;
+    const int WCr = W + KS - 1, HRr = rows + KS - 1;
+    const T* X = static_cast<const T*>(p.X) + long(b) * H * W * p.ldx;
+
+    // ---- 0. halo tile -> LDS (fp32), zero outside the map and beyond the real channels
+    {
+        constexpr int C8 = CP / 8;
+        const int total = HRr * WCr * C8;
+        constexpr int UN = 4;                                              // loads in flight per thread
+        for (int it0 = tid; it0 < total; it0 += UN * MLPB_THREADS) {
+            uint4 raw[UN];
+            ACH_UNROLL
+            for (int u = 0; u < UN; ++u) {
+                const int it = it0 + u * MLPB_THREADS;
+                raw[u] = make_uint4(0u, 0u, 0u, 0u);
+                if (it < total) {
+                    const int c8 = it % C8, pos = it / C8, wc = pos % WCr, hr = pos / WCr;
+                    const int iy = y0 - KS / 2 + hr, ix = wc - KS / 2;
+                    if (iy >= 0 && iy < H && ix >= 0 && ix < W && c8 * 8 < C) raw[u] = *reinterpret_cast<const uint4*>(X + (long(iy) * W + ix) * p.ldx + c8 * 8);
+                }
+            }
+            ACH_UNROLL
+            for (int u = 0; u < UN; ++u) {
+                const int it = it0 + u * MLPB_THREADS;
+                if (it >= total) continue;
+                const int c8 = it % C8, pos = it / C8;
+                float v[8];
+                frag_unpack<T>(raw[u], v);
+                float* d = xin + pos * CP + c8 * 8;
+                *reinterpret_cast<float4*>(d) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(d + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- 1. depthwise k x k from LDS: thread = strip of SP pixels x 4 channels
+    {
+        constexpr int C4 = CP / 4;
+        const int nstrip = (W + SP - 1) / SP, total = rows * nstrip * C4;
+        for (int it = tid; it < total; it += MLPB_THREADS) {
+            const int cg = it % C4, rest = it / C4, q = rest % nstrip, r = rest / nstrip;
+            const int x0 = q * SP;
+            const float4 bias = *reinterpret_cast<const float4*>(p.bdw + cg * 4);
+            f32x2 acc[SP][2];
+            ACH_UNROLL
+            for (int i = 0; i < SP; ++i) { acc[i][0] = f32x2{bias.x, bias.y}; acc[i][1] = f32x2{bias.z, bias.w}; }
+            ACH_NO_UNROLL
+            for (int ty = 0; ty < KS; ++ty) {
+                const float* row = xin + ((r + ty) * WCr) * CP + cg * 4;
+                f32x2 v[SP + KS - 1][2];
+                ACH_UNROLL
+                for (int j = 0; j < SP + KS - 1; ++j) {
+                    const int col = x0 + j < WCr ? x0 + j : WCr - 1;      // (a partial last strip stays inside the halo row; its outputs are dropped)
+                    const float4 t = *reinterpret_cast<const float4*>(row + col * CP);
+                    v[j][0] = f32x2{t.x, t.y}; v[j][1] = f32x2{t.z, t.w};
+                }
+                ACH_UNROLL
+                for (int tx = 0; tx < KS; ++tx) {
+                    const float4 w = *reinterpret_cast<const float4*>(p.Wdw + long(ty * KS + tx) * CP + cg * 4);
+                    const f32x2 w0 = {w.x, w.y}, w1 = {w.z, w.w};
+                    ACH_UNROLL
+                    for (int i = 0; i < SP; ++i) { acc[i][0] += w0 * v[i + tx][0]; acc[i][1] += w1 * v[i + tx][1]; }
+                }
+            }
+            ACH_UNROLL
+            for (int i = 0; i < SP; ++i)
+                if (x0 + i < W) *reinterpret_cast<float4*>(dwv + (r * W + x0 + i) * CP + cg * 4) = make_float4(acc[i][0][0], acc[i][0][1], acc[i][1][0], acc[i][1][1]);
+        }
+    }
+    __syncthreads();
+    // ---- 2. LayerNorm per pixel (affine folded into W1 / b1), rows -> MFMA B fragments in LDS
+    for (int t = wave; t < nt; t += MLPB_THREADS / 64) {
+        const int pix = t * 16 + px;
+        const bool valid = pix < npx;
+        float v[K1][8];
+        float s1 = 0.f, s2 = 0.f;
+        ACH_UNROLL
+        for (int s = 0; s < K1; ++s) {
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a;
+            if (valid) { const float* src = dwv + pix * CP + s * 32 + g * 8; a = *reinterpret_cast<const float4*>(src); c = *reinterpret_cast<const float4*>(src + 4); }
+            v[s][0] = a.x; v[s][1] = a.y; v[s][2] = a.z; v[s][3] = a.w; v[s][4] = c.x; v[s][5] = c.y; v[s][6] = c.z; v[s][7] = c.w;
+            ACH_UNROLL
+            for (int i = 0; i < 8; ++i) { s1 += v[s][i]; s2 += v[s][i] * v[s][i]; }
+        }
+        s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+        s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+        const float mu = s1 / float(C);
+        float var = s2 / float(C) - mu * mu;
+        var = var > 0.f ? var : 0.f;
+        const float rstd = 1.0f / sqrtf(var + p.ln_eps);
+        ACH_UNROLL
+        for (int s = 0; s < K1; ++s) {
+            const int k0 = s * 32 + g * 8;
+            float o[8];
+            ACH_UNROLL
+            for (int i = 0; i < 8; ++i) o[i] = (valid && k0 + i < C) ? (v[s][i] - mu) * rstd : 0.f;
+            xs[(t * K1 + s) * 64 + lane] = frag_pack<T>(o);
+        }
+    }
+    __syncthreads();
+    // ---- 3. hidden chunks: wave (cw, th) takes chunks cw, cw + 4, ... for the tiles of half th (tiles th, th + 2, ...): the next chunk's
+    //         weight fragments are requested before the current chunk's tiles are computed
+    constexpr int NTH = (NT + 1) / 2;
+    const int cw = wave & 3, th = wave >> 2;
+    f32x4 acc2[NTH][DT];
+    ACH_UNROLL
+    for (int t = 0; t < NTH; ++t) { ACH_UNROLL for (int d = 0; d < DT; ++d) { acc2[t][d][0] = 0.f; acc2[t][d][1] = 0.f; acc2[t][d][2] = 0.f; acc2[t][d][3] = 0.f; } }
+    {
+        const uint4* W1f = static_cast<const uint4*>(p.W1) + lane;
+        const uint4* W2f = static_cast<const uint4*>(p.W2) + lane;
+        uint4 w1[K1][2], w2[DT], n1[K1][2], n2[DT];
+        auto fetch = [&](int j, uint4 (&a)[K1][2], uint4 (&c)[DT]) {
+            const uint4* w1p = W1f + long(j) * K1 * 2 * 64;
+            ACH_UNROLL
+            for (int s = 0; s < K1; ++s) { a[s][0] = w1p[(s * 2) * 64]; a[s][1] = w1p[(s * 2 + 1) * 64]; }
+            ACH_UNROLL
+            for (int d = 0; d < DT; ++d) c[d] = W2f[(long(j) * DT + d) * 64];
+        };
+        if (cw < p.J) fetch(cw, n1, n2);
+        for (int j = cw; j < p.J; j += 4) {
+            ACH_UNROLL
+            for (int s = 0; s < K1; ++s) { w1[s][0] = n1[s][0]; w1[s][1] = n1[s][1]; }
+            ACH_UNROLL
+            for (int d = 0; d < DT; ++d) w2[d] = n2[d];
+            if (j + 4 < p.J) fetch(j + 4, n1, n2);
+            const f32x4 bA = *reinterpret_cast<const f32x4*>(p.b1 + j * 32 + g * 8), bB = *reinterpret_cast<const f32x4*>(p.b1 + j * 32 + g * 8 + 4);
+            ACH_UNROLL
+            for (int tt = 0; tt < NTH; ++tt) {
+                const int t = 2 * tt + th;
+                if (t >= nt) continue;
+                f32x4 a0, a1;
+                a0[0] = a0[1] = a0[2] = a0[3] = 0.f;
+                a1[0] = a1[1] = a1[2] = a1[3] = 0.f;
+                ACH_UNROLL
+                for (int s = 0; s < K1; ++s) { const uint4 xf = xs[(t * K1 + s) * 64 + lane]; mfma16<T>(w1[s][0], xf, a0); mfma16<T>(w1[s][1], xf, a1); }
+                float h[8];
+                ACH_UNROLL
+                for (int r = 0; r < 4; ++r) { h[r] = a0[r] + bA[r]; h[4 + r] = a1[r] + bB[r]; }
+                apply_act_n<T, 8, ACT_GELU>(h, ACT_GELU);
+                const uint4 hf = frag_pack<T>(h);
+                ACH_UNROLL
+                for (int d = 0; d < DT; ++d) mfma16<T>(w2[d], hf, acc2[tt][d]);
+            }
+        }
+    }
+    // ---- 4. sum the four waves' partial outputs through LDS, + bias + residual
+    T* Y = static_cast<T*>(p.Y) + long(b) * H * W * p.ldy;
+    const T* R = static_cast<const T*>(p.R) + long(b) * H * W * p.ldr;
+    // a round covers NTB consecutive tiles t = tb .. tb + NTB - 1; tile t lives in acc2[t / 2] of the waves of half t % 2
+    ACH_UNROLL
+    for (int tb = 0; tb < NT; tb += NTB) {
+        if (tb >= nt) continue;                                            // (uniform)
+        __syncthreads();                                                   // xs (round 0) / the previous round's sums are dead
+        ACH_UNROLL
+        for (int k = 0; k < NTB; ++k) {
+            const int t = tb + k;                                          // compile-time
+            if (t >= NT || (t & 1) != th) continue;
+            ACH_UNROLL
+            for (int d = 0; d < DT; ++d) {
+                ACH_UNROLL
+                for (int r = 0; r < 4; ++r) red[(((cw * NTB + k) * DT + d) * 4 + r) * 64 + lane] = acc2[t / 2][d][r];
+            }
+        }
+        __syncthreads();
+        for (int q = wave; q < NTB * (DT / 2); q += MLPB_THREADS / 64) {   // (tile, channel pair) items of this round, dealt to the waves
+            const int k = q / (DT / 2), pair = q % (DT / 2), t = tb + k;
+            const int pix = t * 16 + px, nb = pair * 32 + g * 8;
+            if (t >= nt || pix >= npx || nb >= p.Cout) continue;
+            float v8[8];
+            ACH_UNROLL
+            for (int i = 0; i < 8; ++i) {
+                const int d = 2 * pair + (i >> 2), r = i & 3;
+                float a = 0.f;
+                ACH_UNROLL
+                for (int w = 0; w < 4; ++w) a += red[(((w * NTB + k) * DT + d) * 4 + r) * 64 + lane];
+                v8[i] = a;
+            }
+            const long m = long(y0) * W + pix;
+            float r8[8], o[8];
+            Store<T>::ld8(R + m * p.ldr + nb, r8);
+            ACH_UNROLL
+            for (int i = 0; i < 8; ++i) o[i] = v8[i] + p.b2[nb + i] + r8[i];
+            Store<T>::st8(Y + m * p.ldy + nb, o);
+        }
+    }
+}
+
+// the instantiated shapes: (k-steps of the input, output tiles, kernel size): EdgeNeXt-S0 stage 2 (d = 96, 7x7) at maps up to 20 wide
+inline bool mlp_band_supported(int k1, int DT, int ks, int H, int W) { return k1 == 3 && DT == 6 && ks == 7 && W <= 20 && H >= 1; }
+inline int mlp_band_rows(int H) { return H >= 5 ? 5 : H; }
+inline void launch_mlp_band(const MlpBandParams& bp, int B, hipStream_t stream) {
+    const dim3 grid(unsigned(bp.bands) * unsigned(B)), block(MLPB_THREADS);
+    ACH_LAUNCH((mlp_band_kernel<3, 6, 7, 5, 20>), grid, block, stream, bp);
+}
+
+}  // namespace ach

@@ -495,3 +495,29 @@ def test_emulated_row_walking_head_matches_the_tile_kernel(res, band, num_seg):
     for k, (a, b) in enumerate(zip(outs[1], outs[0])):
         assert rel_err(a, b) < (5e-3 if k >= 2 else 2e-2), (k, rel_err(a, b))          # the [x1 | x2] taps: the same values up to fp32 summation order, rounded once (isolated one-ulp flips)
     assert rel_err(outs[1][0], se) < 6e-2 and rel_err(outs[1][1], lane) < 6e-2
+
+
+@pytest.mark.parametrize('res,batch', [(96, 2), (160, 1), (320, 1)])
+def test_emulated_band_kernel_matches_the_tile_kernel(res, batch):
+    """bf16 engine: ConvEncoder blocks of the small maps through the band kernel (k_mlpband.h, option mlp_band = 1, default) against
+    mlp_kernel's SPLIT mode (mlp_band = 0) and the oracle, at every stage-2 block boundary.  96 -> 6x6 maps (two bands: 5 + 1 rows, a
+    partial strip), 160 -> 10x10 (two full bands, 4 tiles each), 320 -> 20x20 (the production shape: 4 bands of 7 tiles)."""
+    kw, sd, (x, xr, xp) = _setup('en_s0', res, batch, 16)
+    orc = AchelousOracle(sd, **{k: kw[k] for k in ORACLE_KEYS})
+    orc.forward(x, xr, xp)
+    taps = {}
+    for band in (1, 0):
+        from achelous_amd.engine import NativeEngine
+        eng = NativeEngine(emu_library(), num_det=kw['num_det'], num_seg=kw['num_seg'], phi=kw['phi'], backbone=kw['backbone'], resolution=res,
+                           pc_channels=kw['pc_channels'], pc_classes=kw['pc_classes'], num_points=16, nano_head=True, spp=True, dtype=DTYPE_BF16)
+        eng.set_option('full_taps', 1)
+        eng.set_option('mlp_band', band)
+        eng.load_state_dict(sd)
+        eng.plan(batch)
+        o = alloc_outputs(kw, batch, 16, torch.bfloat16, 'cpu')
+        eng.forward(x.bfloat16(), xr.bfloat16(), xp.bfloat16(), o)
+        taps[band] = {t: eng.read_tap(t) for t in eng.tap_names() if t.startswith('backbone.s2.') or t in ('map4', 'map5')}
+    assert len(taps[1]) >= 7
+    for t in taps[1]:
+        assert rel_err(taps[1][t], taps[0][t]) < 1.5e-2, (t, rel_err(taps[1][t], taps[0][t]))     # same arithmetic, different summation order, bf16 storage
+        assert rel_err(taps[1][t], orc.taps[t]) < 4e-2, (t, rel_err(taps[1][t], orc.taps[t]))
