@@ -449,9 +449,9 @@ public:
         // small maps, bf16: a band of rows per workgroup — taps from an LDS halo tile, MLP weights fetched once per band (k_mlpband.h)
         if (mlp_band && split && dw_ks && act == ACT_GELU && xin.p == resid.p && std::is_same<T, bf16_t>::value && mlp_band_supported(k1, DT, dw_ks, xin.H, xin.W)) {
             MlpBandParams bp;
-            bp.m = mp; bp.rb = mlp_band_rows(xin.H); bp.bands = cdiv(xin.H, bp.rb);
-            const int nb = xin.B;
-            add_op(name, [bp, nb](hipStream_t s) { launch_mlp_band(bp, nb, s); }, bytes, flops);
+            bp.m = mp; bp.rb = mlp_band_rows(k1, DT, dw_ks, xin.H, xin.W); bp.bands = cdiv(xin.H, bp.rb);
+            const int nb = xin.B, shape = mlp_band_shape(k1, DT, dw_ks, xin.W);
+            add_op(name, [bp, nb, shape](hipStream_t s) { launch_mlp_band(bp, shape, nb, s); }, bytes, flops);
             return true;
         }
         add_op(name, [mp, DT, split](hipStream_t s) { launch_mlp<T>(mp, DT, split, s); }, bytes, flops);

@@ -29,28 +29,31 @@ struct MlpBandParams {
 };
 
 constexpr int MLPB_SP = 5;       // strip of output pixels per thread in the depthwise phase
-constexpr int MLPB_NTB = 3;      // tiles per reduction round
+constexpr int mlpb_ntb(int DT) { return DT <= 6 ? 3 : 1; }      // tiles per reduction round (the wide blocks' partial sums are 10-12 KB per tile and wave)
 constexpr int MLPB_THREADS = 512; // 8 waves: 2 per SIMD (the 150 KB of LDS allow one workgroup per CU)
 
-template <int K1, int DT, int KS, int RB, int MAXW>
+// XF32: the halo tile is staged as fp32 (taps need no unpacking; 110 KB for d = 96 at 20x20) — or as bf16 (half the LDS: the wider
+// blocks only fit that way; a tap then costs two more VALU operations per four channels).
+template <int K1, int DT, int KS, int RB, int MAXW, bool XF32>
 struct MlpBandGeom {
     static constexpr int CP = K1 * 32;
     static constexpr int HR = RB + KS - 1, WC = MAXW + KS - 1;
     static constexpr int NT = (RB * MAXW + 15) / 16;
-    static constexpr int XIN_FLOATS = HR * WC * CP;
+    static constexpr int XIN_FLOATS = XF32 ? HR * WC * CP : (HR * WC * CP + 1) / 2;
     static constexpr int DWV_FLOATS = NT * 16 * CP;
     static constexpr int XS_BYTES = NT * K1 * 64 * 16;
     static constexpr int RED_OFF_FLOATS = (XS_BYTES + 1023) / 1024 * 256;           // red starts behind xs, both alias xin
-    static constexpr int RED_FLOATS = 4 * MLPB_NTB * DT * 4 * 64;
+    static constexpr int RED_FLOATS = 4 * mlpb_ntb(DT) * DT * 4 * 64;
     static_assert(RED_OFF_FLOATS + RED_FLOATS <= XIN_FLOATS, "reduction buffer must fit the dead halo tile");
     static_assert((XIN_FLOATS + DWV_FLOATS) * 4 <= 160 * 1024, "LDS budget");
 };
 
-template <int K1, int DT, int KS, int RB, int MAXW>
+// PREF: the next hidden chunk's weight fragments are requested one chunk ahead (a second register set).
+template <int K1, int DT, int KS, int RB, int MAXW, bool XF32, bool PREF>
 __global__ __launch_bounds__(MLPB_THREADS, 1) void mlp_band_kernel(const MlpBandParams bp) {
-    using G = MlpBandGeom<K1, DT, KS, RB, MAXW>;
+    using G = MlpBandGeom<K1, DT, KS, RB, MAXW, XF32>;
     typedef bf16_t T;
-    constexpr int CP = G::CP, NT = G::NT, SP = MLPB_SP, NTB = MLPB_NTB;
+    constexpr int CP = G::CP, NT = G::NT, SP = MLPB_SP, NTB = mlpb_ntb(DT);
     const MlpParams& p = bp.m;
     __shared__ float xin[G::XIN_FLOATS];
     __shared__ float dwv[G::DWV_FLOATS];
@@ -89,11 +92,15 @@ __global__ __launch_bounds__(MLPB_THREADS, 1) void mlp_band_kernel(const MlpBand
                 const int it = it0 + u * MLPB_THREADS;
                 if (it >= total) continue;
                 const int c8 = it % C8, pos = it / C8;
-                float v[8];
-                frag_unpack<T>(raw[u], v);
-                float* d = xin + pos * CP + c8 * 8;
-                *reinterpret_cast<float4*>(d) = make_float4(v[0], v[1], v[2], v[3]);
-                *reinterpret_cast<float4*>(d + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                if (XF32) {
+                    float v[8];
+                    frag_unpack<T>(raw[u], v);
+                    float* d = xin + pos * CP + c8 * 8;
+                    *reinterpret_cast<float4*>(d) = make_float4(v[0], v[1], v[2], v[3]);
+                    *reinterpret_cast<float4*>(d + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                } else {
+                    reinterpret_cast<uint4*>(xin)[pos * C8 + c8] = raw[u];
+                }
             }
         }
     }
@@ -111,13 +118,18 @@ __global__ __launch_bounds__(MLPB_THREADS, 1) void mlp_band_kernel(const MlpBand
             for (int i = 0; i < SP; ++i) { acc[i][0] = f32x2{bias.x, bias.y}; acc[i][1] = f32x2{bias.z, bias.w}; }
             ACH_NO_UNROLL
             for (int ty = 0; ty < KS; ++ty) {
-                const float* row = xin + ((r + ty) * WCr) * CP + cg * 4;
                 f32x2 v[SP + KS - 1][2];
                 ACH_UNROLL
                 for (int j = 0; j < SP + KS - 1; ++j) {
                     const int col = x0 + j < WCr ? x0 + j : WCr - 1;      // (a partial last strip stays inside the halo row; its outputs are dropped)
-                    const float4 t = *reinterpret_cast<const float4*>(row + col * CP);
-                    v[j][0] = f32x2{t.x, t.y}; v[j][1] = f32x2{t.z, t.w};
+                    if (XF32) {
+                        const float4 t = *reinterpret_cast<const float4*>(xin + ((r + ty) * WCr + col) * CP + cg * 4);
+                        v[j][0] = f32x2{t.x, t.y}; v[j][1] = f32x2{t.z, t.w};
+                    } else {
+                        const uint2 t = reinterpret_cast<const uint2*>(xin)[((r + ty) * WCr + col) * (CP / 4) + cg];
+                        v[j][0] = f32x2{__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u)};
+                        v[j][1] = f32x2{__uint_as_float(t.y << 16), __uint_as_float(t.y & 0xffff0000u)};
+                    }
                 }
                 ACH_UNROLL
                 for (int tx = 0; tx < KS; ++tx) {
@@ -181,13 +193,17 @@ __global__ __launch_bounds__(MLPB_THREADS, 1) void mlp_band_kernel(const MlpBand
             ACH_UNROLL
             for (int d = 0; d < DT; ++d) c[d] = W2f[(long(j) * DT + d) * 64];
         };
-        if (cw < p.J) fetch(cw, n1, n2);
+        if (PREF && cw < p.J) fetch(cw, n1, n2);
         for (int j = cw; j < p.J; j += 4) {
-            ACH_UNROLL
-            for (int s = 0; s < K1; ++s) { w1[s][0] = n1[s][0]; w1[s][1] = n1[s][1]; }
-            ACH_UNROLL
-            for (int d = 0; d < DT; ++d) w2[d] = n2[d];
-            if (j + 4 < p.J) fetch(j + 4, n1, n2);
+            if (PREF) {
+                ACH_UNROLL
+                for (int s = 0; s < K1; ++s) { w1[s][0] = n1[s][0]; w1[s][1] = n1[s][1]; }
+                ACH_UNROLL
+                for (int d = 0; d < DT; ++d) w2[d] = n2[d];
+                if (j + 4 < p.J) fetch(j + 4, n1, n2);
+            } else {
+                fetch(j, w1, w2);
+            }
             const f32x4 bA = *reinterpret_cast<const f32x4*>(p.b1 + j * 32 + g * 8), bB = *reinterpret_cast<const f32x4*>(p.b1 + j * 32 + g * 8 + 4);
             ACH_UNROLL
             for (int tt = 0; tt < NTH; ++tt) {
@@ -250,12 +266,23 @@ __global__ __launch_bounds__(MLPB_THREADS, 1) void mlp_band_kernel(const MlpBand
     }
 }
 
-// the instantiated shapes: (k-steps of the input, output tiles, kernel size): EdgeNeXt-S0 stage 2 (d = 96, 7x7) at maps up to 20 wide
-inline bool mlp_band_supported(int k1, int DT, int ks, int H, int W) { return k1 == 3 && DT == 6 && ks == 7 && W <= 20 && H >= 1; }
-inline int mlp_band_rows(int H) { return H >= 5 ? 5 : H; }
-inline void launch_mlp_band(const MlpBandParams& bp, int B, hipStream_t stream) {
+// the instantiated shapes (k-steps of the input, output tiles, kernel size, rows per band, widest map):
+//   d =  96, 7x7, maps up to 20 wide (EdgeNeXt-S0 stage 2): fp32 halo tile, 5 rows, weights prefetched
+//   d = 176, 9x9, maps up to 10 wide (EdgeNeXt-S0 stage 3): bf16 halo tile, 5 rows
+//   d = 144, 7x7, maps up to 20 wide (EdgeNeXt-S2 stage 2): bf16 halo tile, 4 rows
+inline int mlp_band_shape(int k1, int DT, int ks, int W) {
+    if (k1 == 3 && DT == 6 && ks == 7 && W <= 20) return 1;
+    if (k1 == 6 && DT == 12 && ks == 9 && W <= 10) return 2;
+    if (k1 == 5 && DT == 10 && ks == 7 && W <= 20) return 3;
+    return 0;
+}
+inline bool mlp_band_supported(int k1, int DT, int ks, int H, int W) { return H >= 1 && mlp_band_shape(k1, DT, ks, W) != 0; }
+inline int mlp_band_rows(int k1, int DT, int ks, int H, int W) { const int rb = mlp_band_shape(k1, DT, ks, W) == 3 ? 4 : 5; return H >= rb ? rb : H; }
+inline void launch_mlp_band(const MlpBandParams& bp, int shape, int B, hipStream_t stream) {
     const dim3 grid(unsigned(bp.bands) * unsigned(B)), block(MLPB_THREADS);
-    ACH_LAUNCH((mlp_band_kernel<3, 6, 7, 5, 20>), grid, block, stream, bp);
+    if (shape == 1) ACH_LAUNCH((mlp_band_kernel<3, 6, 7, 5, 20, true, true>), grid, block, stream, bp);
+    else if (shape == 2) ACH_LAUNCH((mlp_band_kernel<6, 12, 9, 5, 10, false, false>), grid, block, stream, bp);
+    else ACH_LAUNCH((mlp_band_kernel<5, 10, 7, 4, 20, false, false>), grid, block, stream, bp);
 }
 
 }  // namespace ach

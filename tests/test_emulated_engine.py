@@ -497,12 +497,13 @@ def test_emulated_row_walking_head_matches_the_tile_kernel(res, band, num_seg):
     assert rel_err(outs[1][0], se) < 6e-2 and rel_err(outs[1][1], lane) < 6e-2
 
 
-@pytest.mark.parametrize('res,batch', [(96, 2), (160, 1), (320, 1)])
-def test_emulated_band_kernel_matches_the_tile_kernel(res, batch):
+@pytest.mark.parametrize('name,res,batch', [('en_s0', 96, 2), ('en_s0', 160, 1), ('en_s0', 320, 1), ('en_s2', 320, 1), ('en_s2', 128, 2)])
+def test_emulated_band_kernel_matches_the_tile_kernel(name, res, batch):
     """bf16 engine: ConvEncoder blocks of the small maps through the band kernel (k_mlpband.h, option mlp_band = 1, default) against
     mlp_kernel's SPLIT mode (mlp_band = 0) and the oracle, at every stage-2 block boundary.  96 -> 6x6 maps (two bands: 5 + 1 rows, a
-    partial strip), 160 -> 10x10 (two full bands, 4 tiles each), 320 -> 20x20 (the production shape: 4 bands of 7 tiles)."""
-    kw, sd, (x, xr, xp) = _setup('en_s0', res, batch, 16)
+    partial strip), 160 -> 10x10 (two full bands, 4 tiles each), 320 -> 20x20 (the production shape: 4 bands of 7 tiles).  The three instantiated
+    shapes: EN-S0 stage 2 (d = 96, fp32 halo tile), EN-S0 stage 3 (d = 176, 9x9, bf16 halo tile), EN-S2 stage 2 (d = 144, 4-row bands)."""
+    kw, sd, (x, xr, xp) = _setup(name, res, batch, 16)
     orc = AchelousOracle(sd, **{k: kw[k] for k in ORACLE_KEYS})
     orc.forward(x, xr, xp)
     taps = {}
@@ -516,7 +517,7 @@ def test_emulated_band_kernel_matches_the_tile_kernel(res, batch):
         eng.plan(batch)
         o = alloc_outputs(kw, batch, 16, torch.bfloat16, 'cpu')
         eng.forward(x.bfloat16(), xr.bfloat16(), xp.bfloat16(), o)
-        taps[band] = {t: eng.read_tap(t) for t in eng.tap_names() if t.startswith('backbone.s2.') or t in ('map4', 'map5')}
+        taps[band] = {t: eng.read_tap(t) for t in eng.tap_names() if t.startswith('backbone.s2.') or t.startswith('backbone.s3.') or t in ('map4', 'map5')}
     assert len(taps[1]) >= 7
     for t in taps[1]:
         assert rel_err(taps[1][t], taps[0][t]) < 1.5e-2, (t, rel_err(taps[1][t], taps[0][t]))     # same arithmetic, different summation order, bf16 storage
