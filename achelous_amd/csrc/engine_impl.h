@@ -447,9 +447,9 @@ public:
         const double bytes = double(mp.M) * C * sizeof(T) * (xin.p == resid.p ? 2.0 : 3.0);
         const double flops = 4.0 * double(mp.M) * C * hidden + (dw_ks ? 2.0 * double(mp.M) * C * dw_ks * dw_ks : 0.0);
         // small maps, bf16: a band of rows per workgroup — taps from an LDS halo tile, MLP weights fetched once per band (k_mlpband.h)
-        if (mlp_band && split && dw_ks && act == ACT_GELU && xin.p == resid.p && std::is_same<T, bf16_t>::value && mlp_band_supported(k1, DT, dw_ks, xin.H, xin.W)) {
+        if (mlp_band && (split || mlp_band > 1) && dw_ks && act == ACT_GELU && xin.p == resid.p && std::is_same<T, bf16_t>::value && mlp_band_supported(k1, DT, dw_ks, xin.H, xin.W)) {
             MlpBandParams bp;
-            bp.m = mp; bp.rb = mlp_band_rows(k1, DT, dw_ks, xin.H, xin.W); bp.bands = cdiv(xin.H, bp.rb);
+            bp.m = mp; bp.rb = mlp_band_rows(k1, DT, dw_ks, xin.H, xin.W); bp.bands = cdiv(xin.H, bp.rb); bp.dbg = mlp_band_dbg;
             const int nb = xin.B, shape = mlp_band_shape(k1, DT, dw_ks, xin.W);
             add_op(name, [bp, nb, shape](hipStream_t s) { launch_mlp_band(bp, shape, nb, s); }, bytes, flops);
             return true;

@@ -26,6 +26,7 @@ namespace ach {
 struct MlpBandParams {
     MlpParams m;
     int rb, bands;               // rows per band, bands per frame
+    int dbg;                     // timing experiments only (option mlp_band_dbg; results are wrong): bit 0 no staging, 1 no depthwise, 2 no LayerNorm, 3 no MLP, 4 no reduction
 };
 
 constexpr int MLPB_SP = 5;       // strip of output pixels per thread in the depthwise phase
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(MLPB_THREADS, 1) void mlp_band_kernel(const MlpBand
     const T* X = static_cast<const T*>(p.X) + long(b) * H * W * p.ldx;
 
     // ---- 0. halo tile -> LDS (fp32), zero outside the map and beyond the real channels
-    {
+    if (!(bp.dbg & 1)) {
         constexpr int C8 = CP / 8;
         const int total = HRr * WCr * C8;
         constexpr int UN = 4;                                              // loads in flight per thread
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(MLPB_THREADS, 1) void mlp_band_kernel(const MlpBand
     }
     __syncthreads();
     // ---- 1. depthwise k x k from LDS: thread = strip of SP pixels x 4 channels
-    {
+    if (!(bp.dbg & 2)) {
         constexpr int C4 = CP / 4;
         const int nstrip = (W + SP - 1) / SP, total = rows * nstrip * C4;
         for (int it = tid; it < total; it += MLPB_THREADS) {
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(MLPB_THREADS, 1) void mlp_band_kernel(const MlpBand
     }
     __syncthreads();
     // ---- 2. LayerNorm per pixel (affine folded into W1 / b1), rows -> MFMA B fragments in LDS
-    for (int t = wave; t < nt; t += MLPB_THREADS / 64) {
+    for (int t = wave; t < ((bp.dbg & 4) ? 0 : nt); t += MLPB_THREADS / 64) {
         const int pix = t * 16 + px;
         const bool valid = pix < npx;
         float v[K1][8];
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(MLPB_THREADS, 1) void mlp_band_kernel(const MlpBand
             for (int d = 0; d < DT; ++d) c[d] = W2f[(long(j) * DT + d) * 64];
         };
         if (PREF && cw < p.J) fetch(cw, n1, n2);
-        for (int j = cw; j < p.J; j += 4) {
+        for (int j = cw; j < ((bp.dbg & 8) ? 0 : p.J); j += 4) {
             if (PREF) {
                 ACH_UNROLL
                 for (int s = 0; s < K1; ++s) { w1[s][0] = n1[s][0]; w1[s][1] = n1[s][1]; }
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(MLPB_THREADS, 1) void mlp_band_kernel(const MlpBand
     // a round covers NTB consecutive tiles t = tb .. tb + NTB - 1; tile t lives in acc2[t / 2] of the waves of half t % 2
     ACH_UNROLL
     for (int tb = 0; tb < NT; tb += NTB) {
-        if (tb >= nt) continue;                                            // (uniform)
+        if (tb >= nt || (bp.dbg & 16)) continue;                           // (uniform)
         __syncthreads();                                                   // xs (round 0) / the previous round's sums are dead
         ACH_UNROLL
         for (int k = 0; k < NTB; ++k) {
@@ -274,15 +275,20 @@ inline int mlp_band_shape(int k1, int DT, int ks, int W) {
     if (k1 == 3 && DT == 6 && ks == 7 && W <= 20) return 1;
     if (k1 == 6 && DT == 12 && ks == 9 && W <= 10) return 2;
     if (k1 == 5 && DT == 10 && ks == 7 && W <= 20) return 3;
+    // (option mlp_band = 2 only; measured on EN-S0: stage 1 58 -> 55 us, stage 0 58 -> 75 us, 32.6 k -> 31.0 k frames/s: the large maps keep mlp_kernel)
+    if (k1 == 2 && DT == 4 && ks == 5 && W <= 40 && W > 20) return 4;      // stage 1 (d = 48 / 64): 2-row bands
+    if (k1 == 1 && DT == 2 && ks == 3 && W <= 80 && W > 40) return 5;      // stage 0 (d = 32): 1-row bands
     return 0;
 }
 inline bool mlp_band_supported(int k1, int DT, int ks, int H, int W) { return H >= 1 && mlp_band_shape(k1, DT, ks, W) != 0; }
-inline int mlp_band_rows(int k1, int DT, int ks, int H, int W) { const int rb = mlp_band_shape(k1, DT, ks, W) == 3 ? 4 : 5; return H >= rb ? rb : H; }
+inline int mlp_band_rows(int k1, int DT, int ks, int H, int W) { const int sh = mlp_band_shape(k1, DT, ks, W), rb = sh == 3 ? 4 : (sh == 4 ? 2 : (sh == 5 ? 1 : 5)); return H >= rb ? rb : H; }
 inline void launch_mlp_band(const MlpBandParams& bp, int shape, int B, hipStream_t stream) {
     const dim3 grid(unsigned(bp.bands) * unsigned(B)), block(MLPB_THREADS);
     if (shape == 1) ACH_LAUNCH((mlp_band_kernel<3, 6, 7, 5, 20, true, true>), grid, block, stream, bp);
     else if (shape == 2) ACH_LAUNCH((mlp_band_kernel<6, 12, 9, 5, 10, false, false>), grid, block, stream, bp);
-    else ACH_LAUNCH((mlp_band_kernel<5, 10, 7, 4, 20, false, false>), grid, block, stream, bp);
+    else if (shape == 3) ACH_LAUNCH((mlp_band_kernel<5, 10, 7, 4, 20, false, false>), grid, block, stream, bp);
+    else if (shape == 4) ACH_LAUNCH((mlp_band_kernel<2, 4, 5, 2, 40, true, true>), grid, block, stream, bp);
+    else ACH_LAUNCH((mlp_band_kernel<1, 2, 3, 1, 80, true, true>), grid, block, stream, bp);
 }
 
 }  // namespace ach
