@@ -3,6 +3,7 @@
 // emulation used by the unit tests).  See include/achelous.h for the C ABI and DESIGN.md for the data layout.
 #pragma once
 #include <cstdlib>
+#include <cstdio>
 #include <functional>
 #include <map>
 #include <string>
@@ -162,6 +163,7 @@ protected:
     void* aalloc(size_t bytes);
     float* up_f32(const std::vector<float>& v);
     void* up_raw(const void* src, size_t bytes);        // opaque constants (pre-packed MFMA fragments)
+    bool skip_warned = false;
     void add_op(const std::string& name, std::function<void(hipStream_t)> fn, double bytes = 0, double flops = 0, double layout_bytes = -1) {
         if (measuring) return;
         // timing experiments only (profiles/scripts/skip_ops.sh): ACH_DEBUG_SKIP="substr,substr" turns the matching launches into no-ops
@@ -170,7 +172,11 @@ protected:
             std::string all(skip);
             for (size_t a = 0; a < all.size();) {
                 size_t b = all.find(',', a); if (b == std::string::npos) b = all.size();
-                if (b > a && name.find(all.substr(a, b - a)) != std::string::npos) { fn = [](hipStream_t) {}; break; }
+                if (b > a && name.find(all.substr(a, b - a)) != std::string::npos) {
+                    fn = [](hipStream_t) {};
+                    if (!skip_warned) { skip_warned = true; std::fprintf(stderr, "achelous: ACH_DEBUG_SKIP is set: matching launches are no-ops, outputs are GARBAGE (timing experiments only)\n"); }
+                    break;
+                }
                 a = b + 1;
             }
         }

@@ -1735,11 +1735,11 @@ public:
         ACH_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&Y), size_t(M) * ldy * sizeof(T)));
         ACH_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&R), size_t(M) * ldy * sizeof(T)));
         ACH_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&Wp), size_t(pk.group_elems) * sizeof(T)));
-        ACH_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&bias), size_t(N) * sizeof(float)));
+        ACH_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&bias), (size_t(N) + 64) * sizeof(float)));      // GemmParams.bias: 64 zero floats behind the last channel (gemm_body's 16-byte loads)
         ACH_HIP_CHECK(hipMemset(X, 0x3c, size_t(M) * ldx * sizeof(T)));     // small finite values
         ACH_HIP_CHECK(hipMemset(R, 0x3c, size_t(M) * ldy * sizeof(T)));
         ACH_HIP_CHECK(hipMemset(Wp, 0x3c, size_t(pk.group_elems) * sizeof(T)));
-        ACH_HIP_CHECK(hipMemset(bias, 0, size_t(N) * sizeof(float)));
+        ACH_HIP_CHECK(hipMemset(bias, 0, (size_t(N) + 64) * sizeof(float)));
         GemmParams g;
         std::memset(&g, 0, sizeof(g));
         g.X = X; g.ldx = ldx; g.W = Wp; g.bias = bias; g.Y = Y; g.ldy = ldy; g.R = residual ? R : nullptr; g.ldr = ldy;

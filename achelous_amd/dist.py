@@ -40,8 +40,12 @@ def pack_records(rows, idx, cnt, frames=None):
     if frames < S:
         raise ValueError(f"record capacity {frames} is smaller than the shard ({S} frames)")
     rec = getattr(rows, '_ach_record', None)
-    if frames == S and rec is not None and rec.numel() == record_words(S, max_det):
-        return rec
+    if (frames == S and rec is not None and rec.numel() == record_words(S, max_det) and rec.dtype == torch.int32
+            and idx.dtype == torch.int32 and cnt.dtype == torch.int32 and idx.is_contiguous() and cnt.is_contiguous()
+            and rows.data_ptr() == rec.data_ptr()
+            and idx.data_ptr() == rec.data_ptr() + 4 * S * max_det * 7 and idx.numel() == S * max_det
+            and cnt.data_ptr() == rec.data_ptr() + 4 * S * max_det * 8 and cnt.numel() == S):
+        return rec                  # all three ARE the views forward_detect handed out (a filtered idx / cnt takes the copying path)
     pad = frames - S
     parts = [rows.contiguous().view(-1).view(torch.int32)]
     if pad:

@@ -107,3 +107,20 @@ def test_record_roundtrip_and_shards():
         assert shard_capacity(gb, w) == max(hi - lo for lo, hi in b)
     g = flatten_gathered(*unpack_records(torch.arange(2 * record_words(2, 4), dtype=torch.int32), 2, 4), global_batch=3)
     assert g[0].shape == (3, 4, 7) and g[2].shape == (3,)
+
+
+def test_zero_copy_record_requires_the_original_views():
+    """pack_records may hand back the NMS kernel's record buffer only when rows, idx AND cnt are the views of it; a caller
+    that passes re-ranked indices or filtered counts with the original rows gets them packed, not the stale buffer."""
+    S, md = 3, 8
+    flat = torch.arange(record_words(S, md), dtype=torch.int32)
+    rows = flat[:S * md * 7].view(torch.float32).view(S, md, 7)
+    idx, cnt = flat[S * md * 7:S * md * 8].view(S, md), flat[S * md * 8:]
+    rows._ach_record = flat
+    assert pack_records(rows, idx, cnt).data_ptr() == flat.data_ptr()
+    cnt2 = torch.zeros(S, dtype=torch.int32)
+    out = pack_records(rows, idx, cnt2)
+    assert out.data_ptr() != flat.data_ptr() and int(out[S * md * 8:].sum()) == 0
+    idx2 = idx.clone().flip(1)
+    out = pack_records(rows, idx2, cnt)
+    assert out.data_ptr() != flat.data_ptr() and torch.equal(out[S * md * 7:S * md * 8].view(S, md), idx2)
