@@ -356,6 +356,7 @@ def test_emulated_mfma_bilinear_head_agrees_with_the_per_position_kernel(res, ba
                            resolution=kw['resolution'], pc_channels=kw['pc_channels'], pc_classes=kw['pc_classes'],
                            num_points=16, nano_head=kw['nano_head'], spp=kw['spp'], dtype=DTYPE_BF16)
         eng.set_option('head_mfma', v)
+        eng.set_option('head_rows', 0)                                # both kernels of this test keep [x1 | x2] in fp32 through the head's 1x1 (the row-walking default rounds it to bf16)
         eng.set_option('head_grid', 8 if res == 128 else 5)          # persistent workgroups walk several tiles each (XCD split / plain stride)
         eng.set_option('full_taps', 1)
         eng.load_state_dict(sd)
