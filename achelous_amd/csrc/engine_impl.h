@@ -896,6 +896,30 @@ public:
         UpGhostParams p{t.p, t.ld, y.p, y.ld, up_f32(wt), up_f32(sh), x.B, x.H, x.W, Cg};
         const dim3 grid(unsigned(cdiv(2 * x.W, UPG_TS)) * unsigned(cdiv(2 * x.H, UPG_TS)) * unsigned(x.B)), block(unsigned(16 * Cg));
         const double bytes = double(t.rows()) * Cg * sizeof(T) + double(y.rows()) * cout * sizeof(T);
+        if (level_rows && std::is_same<T, bf16_t>::value && (Cg == 16 || Cg == 24 || Cg == 32) && t.ld % 2 == 0 && y.ld % 2 == 0 &&
+            double(y.rows()) * y.ld * sizeof(T) < 2147483648.0) {
+            // row-walking form (k_dechead.h; option level_rows, OFF: measured slower than the LDS tile on these write-bound levels — 34 / 60 us against 25 / 48)
+            const int H2 = 2 * x.H, band = std::max(8, std::min(head_band, H2));
+            UpGhostRowsParams rp{t.p, t.ld, y.p, y.ld, p.Wdw, p.bdw, x.B, x.H, x.W, Cg, x.W > 0 ? float(x.W - 1) / float(2 * x.W - 1) : 0.f,
+                                 band, cdiv(H2, band), cdiv(2 * x.W, UGR_VALID)};
+            const float sy = x.H > 0 ? float(x.H - 1) / float(2 * x.H - 1) : 0.f;
+            std::vector<DecHeadRow> rg(static_cast<size_t>(H2) + 4);
+            for (int i = 0; i < H2 + 4; ++i) {
+                const float fy = sy * float(i < H2 ? i : H2 - 1);
+                int y0 = int(fy);
+                if (y0 > x.H - 1) y0 = x.H - 1;
+                rg[size_t(i)] = DecHeadRow{y0, y0 < x.H - 1 ? fy - float(y0) : 0.f};
+            }
+            const DecHeadRow* rows = static_cast<const DecHeadRow*>(up_raw(rg.data(), rg.size() * sizeof(DecHeadRow)));
+            const dim3 rgrid(unsigned(rp.strips) * unsigned(rp.bands) * unsigned(x.B)), rblock(64);
+            const int np = Cg / 8;
+            add_op(ghost_pfx + ".upghost", [rp, rgrid, rblock, rows, np](hipStream_t s) {
+                if (np == 2) ACH_LAUNCH((upghost_rows_kernel<2>), rgrid, rblock, s, rp, rows);
+                else if (np == 3) ACH_LAUNCH((upghost_rows_kernel<3>), rgrid, rblock, s, rp, rows);
+                else ACH_LAUNCH((upghost_rows_kernel<4>), rgrid, rblock, s, rp, rows);
+            }, bytes);
+            return y;
+        }
         if (Cg == 16) add_op(ghost_pfx + ".upghost", [p, grid, block](hipStream_t s) { ACH_LAUNCH((upghost_kernel<T, 16>), grid, block, s, p); }, bytes);
         else if (Cg == 24) add_op(ghost_pfx + ".upghost", [p, grid, block](hipStream_t s) { ACH_LAUNCH((upghost_kernel<T, 24>), grid, block, s, p); }, bytes);
         else if (Cg == 32) add_op(ghost_pfx + ".upghost", [p, grid, block](hipStream_t s) { ACH_LAUNCH((upghost_kernel<T, 32>), grid, block, s, p); }, bytes);

@@ -254,4 +254,123 @@ __global__ __launch_bounds__(64, DH_WAVES) void dechead_rows_kernel(const DecHea
     }
 }
 
+// ------------------------------------------------------------------------------------------ the other decoder levels, same walk
+// One decoder level at full resolution — x1 = relu(bilinear x2 (t)), x2 = relu(dw3x3(x1) + b), y = [x1 | x2] (NHWC) — as the row-walking
+// kernel above without the head: one 3x3 window, so 14 of a strip's 16 columns produce outputs.  NP = channel pairs per lane:
+// the level's Cg = 8 NP channels are dealt to the four lane groups (Cg = 16 / 24 / 32).  Replaces upghost_kernel's LDS tile (bf16 engine).
+struct UpGhostRowsParams {
+    const void* Tq; long ldt;                 // t at low resolution [B,h,w,ldt] bf16
+    void* Y; long ldy;                        // [B,2h,2w,2Cg]
+    const float* Wdw; const float* bdw;       // [9][Cg], [Cg]
+    int B, h, w, Cg;
+    float sx;
+    int band_rows, bands, strips;
+};
+constexpr int UGR_VALID = 14;
+
+template <int NP>
+__global__ __launch_bounds__(64, (NP <= 2 ? 4 : (NP == 3 ? 3 : 2))) void upghost_rows_kernel(const UpGhostRowsParams p, const DecHeadRow* __restrict__ rows) {
+    constexpr int CL = 2 * NP;                                   // channels per lane
+    const int H = 2 * p.h, Wd = 2 * p.w;
+    const unsigned u = xcd_block(blockIdx.x, gridDim.x);
+    const int strip = int(u % unsigned(p.strips)), band = int((u / unsigned(p.strips)) % unsigned(p.bands));
+    const long b = long(u / (unsigned(p.strips) * unsigned(p.bands)));
+    const int lane = int(threadIdx.x) & 63, n = lane & 15, g = lane >> 4;
+    const int x = strip * UGR_VALID - 1 + n;
+    const bool in_x = x >= 0 && x < Wd;
+    const bool writer = in_x && n >= 1 && n < 1 + UGR_VALID;
+    const int cx = x < 0 ? 0 : (x >= Wd ? Wd - 1 : x);
+    const float fx = p.sx * float(cx);
+    int x0 = int(fx);
+    if (x0 > p.w - 1) x0 = p.w - 1;
+    const int dx = x0 < p.w - 1 ? 1 : 0;
+    const float lx = fx - float(x0);
+    const float wx0 = in_x ? 1.f - lx : 0.f, wx1 = in_x ? lx : 0.f;
+    const bf16_t* Tq = static_cast<const bf16_t*>(p.Tq) + b * p.h * long(p.w) * p.ldt;
+    const unsigned o0 = unsigned(x0 * int(p.ldt) + CL * g), o1 = unsigned((x0 + dx) * int(p.ldt) + CL * g);
+    const int rowp = p.w * int(p.ldt);
+    f32x2 wl[9][NP], bl[NP];
+    ACH_UNROLL
+    for (int k = 0; k < 9; ++k) { ACH_UNROLL for (int q = 0; q < NP; ++q) wl[k][q] = f32x2{p.Wdw[k * p.Cg + CL * g + 2 * q], p.Wdw[k * p.Cg + CL * g + 2 * q + 1]}; }
+    ACH_UNROLL
+    for (int q = 0; q < NP; ++q) bl[q] = f32x2{p.bdw[CL * g + 2 * q], p.bdw[CL * g + 2 * q + 1]};
+    bf16_t* Yb = static_cast<bf16_t*>(p.Y) + b * long(H) * Wd * p.ldy;                       // (uniform)
+    const unsigned yo = unsigned(in_x ? x : 0) * unsigned(p.ldy) + unsigned(CL * g);
+    const int r0 = band * p.band_rows, r1 = (r0 + p.band_rows < H) ? r0 + p.band_rows : H;
+    auto load_raw = [&](int r, uint32_t (&raw)[2][NP]) {
+        const int rr = r < 0 ? 0 : (r > p.h - 1 ? p.h - 1 : r);
+        const bf16_t* q = Tq + long(rr) * rowp;
+        ACH_UNROLL
+        for (int i = 0; i < NP; ++i) { raw[0][i] = reinterpret_cast<const uint32_t*>(q + o0)[i]; raw[1][i] = reinterpret_cast<const uint32_t*>(q + o1)[i]; }
+    };
+    auto unpack = [&](const uint32_t (&raw)[2][NP], f32x2 (&o)[2][NP]) {
+        ACH_UNROLL
+        for (int c = 0; c < 2; ++c) { ACH_UNROLL for (int i = 0; i < NP; ++i) o[c][i] = f32x2{__uint_as_float(raw[c][i] << 16), __uint_as_float(raw[c][i] & 0xffff0000u)}; }
+    };
+    const int i_first = r0 - 1 < 0 ? 0 : r0 - 1;
+    int cy = rows[i_first].y0;
+    f32x2 ta[2][NP], tb[2][NP];
+    uint32_t tn[2][NP];
+    { uint32_t raw[2][NP]; load_raw(cy, raw); unpack(raw, ta); load_raw(cy + 1, raw); unpack(raw, tb); load_raw(cy + 2, tn); }
+    const f32x2 zero2 = {0.f, 0.f};
+    f32x2 w0[NP], w1[NP], w2[NP];
+    ACH_UNROLL
+    for (int q = 0; q < NP; ++q) { w0[q] = zero2; w1[q] = zero2; w2[q] = zero2; }
+
+    // one step: x1 row i into xp; output row i-1 from x1 rows xm, xc, xp (the caller rotates the window slots)
+    auto step = [&](const int i, f32x2 (&xm)[NP], f32x2 (&xc)[NP], f32x2 (&xp)[NP]) {
+        {
+            const bool row_ok = i >= 0 && i < H;
+            const DecHeadRow rg = rows[row_ok ? i : 0];
+            if (row_ok && rg.y0 > cy) {
+                ACH_UNROLL
+                for (int c = 0; c < 2; ++c) { ACH_UNROLL for (int q = 0; q < NP; ++q) ta[c][q] = tb[c][q]; }
+                unpack(tn, tb);
+                ++cy;
+                load_raw(cy + 2, tn);
+            }
+            const float ly = row_ok ? rg.ly : 0.f, hy = row_ok ? 1.f - rg.ly : 0.f;
+            const float w00 = hy * wx0, w01 = hy * wx1, w10 = ly * wx0, w11 = ly * wx1;
+            ACH_UNROLL
+            for (int q = 0; q < NP; ++q) {
+                const f32x2 v = w00 * ta[0][q] + w01 * ta[1][q] + w10 * tb[0][q] + w11 * tb[1][q];
+                xp[q] = f32x2{v[0] > 0.f ? v[0] : 0.f, v[1] > 0.f ? v[1] : 0.f};
+            }
+        }
+        const int ro = i - 1;
+        float x2[CL];
+        {
+            float c4[4], l4[4], r4[4], o4[4];
+            ACH_UNROLL
+            for (int q0 = 0; q0 < NP; q0 += 2) {                   // two channel pairs per group of shifted adds (the last group of NP = 3 is half used)
+                ACH_UNROLL
+                for (int qq = 0; qq < 2; ++qq) {
+                    const int q = q0 + qq < NP ? q0 + qq : NP - 1;
+                    const f32x2 sl = wl[0][q] * xm[q] + wl[3][q] * xc[q] + wl[6][q] * xp[q];
+                    const f32x2 sr = wl[2][q] * xm[q] + wl[5][q] * xc[q] + wl[8][q] * xp[q];
+                    const f32x2 sc = bl[q] + wl[1][q] * xm[q] + wl[4][q] * xc[q] + wl[7][q] * xp[q];
+                    c4[2 * qq] = sc[0]; c4[2 * qq + 1] = sc[1]; l4[2 * qq] = sl[0]; l4[2 * qq + 1] = sl[1]; r4[2 * qq] = sr[0]; r4[2 * qq + 1] = sr[1];
+                }
+                combine4(c4, l4, r4, o4);
+                ACH_UNROLL
+                for (int e = 0; e < 4; ++e) if (2 * q0 + e < CL) x2[2 * q0 + e] = relu_raw(o4[e]);
+            }
+        }
+        if (ro >= r0 && ro < r1 && writer) {
+            bf16_t* yrow = Yb + long(ro) * Wd * p.ldy + yo;
+            uint32_t a[NP], c[NP];
+            ACH_UNROLL
+            for (int q = 0; q < NP; ++q) { a[q] = pack_bf16x2(xc[q][0], xc[q][1]); c[q] = pack_bf16x2(x2[2 * q], x2[2 * q + 1]); }
+            ACH_UNROLL
+            for (int q = 0; q < NP; ++q) { reinterpret_cast<uint32_t*>(yrow)[q] = a[q]; reinterpret_cast<uint32_t*>(yrow + p.Cg)[q] = c[q]; }
+        }
+    };
+    ACH_NO_UNROLL
+    for (int i = r0 - 1; i <= r1; i += 3) {
+        step(i, w0, w1, w2);
+        step(i + 1, w1, w2, w0);
+        step(i + 2, w2, w0, w1);
+    }
+}
+
 }  // namespace ach

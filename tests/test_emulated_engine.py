@@ -466,13 +466,14 @@ def test_emulated_three_task_engine_equals_the_four_task_engine():
         full.forward(x, xr, None, (*o4[:5], None))
 
 
-@pytest.mark.parametrize('res,band,num_seg', [(96, 8, 9), (64, 40, 9), (128, 24, 13)])
-def test_emulated_row_walking_head_matches_the_tile_kernel(res, band, num_seg):
+@pytest.mark.parametrize('name,res,band,num_seg', [('en_s0', 96, 8, 9), ('en_s0', 64, 40, 9), ('en_s0', 128, 24, 13), ('en_s2', 96, 16, 9)])
+def test_emulated_row_walking_head_matches_the_tile_kernel(name, res, band, num_seg):
     """bf16 engine: the row-walking fused last decoder level (k_dechead.h, option head_rows = 1, default) against the LDS tile kernel
     (head_rows = 0) and the oracle.  Bands of 8 rows put a band boundary inside every window phase; 96 / 64 / 128 columns end in partial
     strips (96 = 8 x 12, 64 = 5 x 12 + 4, 128 = 10 x 12 + 8); num_seg = 13 (init 7, 6 cheap channels) uses both accumulators of a lane
-    group.  The two kernels differ only in where [x1 | x2] is rounded to bf16."""
-    kw, sd, (x, xr, xp) = _setup('en_s0', res, 2, 16)
+    group.  The two kernels differ only in where [x1 | x2] is rounded to bf16.  Option level_rows moves the other two decoder levels to their
+    row-walking kernel (upghost_rows_kernel: 24 + 24 and 16 + 16 channels on EN-S0, 32 + 32 and 16 + 16 on EN-S2); their taps are compared too."""
+    kw, sd, (x, xr, xp) = _setup(name, res, 2, 16)
     if num_seg != kw['num_seg']:
         from achelous_amd.nets import Achelous
         kw = dict(kw, num_seg=num_seg)
@@ -487,14 +488,16 @@ def test_emulated_row_walking_head_matches_the_tile_kernel(res, band, num_seg):
                            pc_channels=kw['pc_channels'], pc_classes=kw['pc_classes'], num_points=16, nano_head=True, spp=True, dtype=DTYPE_BF16)
         eng.set_option('full_taps', 1)
         eng.set_option('head_rows', rows)
+        eng.set_option('level_rows', rows)          # (off by default: measured slower on the MI355X; kept correct)
         eng.set_option('head_band', band)
         eng.load_state_dict(sd)
         eng.plan(2)
         o = alloc_outputs(kw, 2, 16, torch.bfloat16, 'cpu')
         eng.forward(x.bfloat16(), xr.bfloat16(), xp.bfloat16(), o)
-        outs[rows] = (o[3].float(), o[4].float(), eng.read_tap('se.1_to_0'), eng.read_tap('lane.1_to_0'))
+        outs[rows] = (o[3].float(), o[4].float(), eng.read_tap('se.1_to_0'), eng.read_tap('lane.1_to_0'), eng.read_tap('se.3_to_2'), eng.read_tap('lane.3_to_2'),
+                      eng.read_tap('se.2_to_1'), eng.read_tap('lane.2_to_1'))
     for k, (a, b) in enumerate(zip(outs[1], outs[0])):
-        assert rel_err(a, b) < (5e-3 if k >= 2 else 2e-2), (k, rel_err(a, b))          # the [x1 | x2] taps: the same values up to fp32 summation order, rounded once (isolated one-ulp flips)
+        assert rel_err(a, b) < (1.5e-2 if k >= 2 else 2e-2), (k, rel_err(a, b))        # the level taps: the same values up to fp32 summation order, rounded to bf16 level by level (one-ulp flips that propagate)
     assert rel_err(outs[1][0], se) < 6e-2 and rel_err(outs[1][1], lane) < 6e-2
 
 
