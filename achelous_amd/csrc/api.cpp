@@ -90,6 +90,7 @@ int ach_set_option(ach_handle* h, const char* key, int32_t value) {
         else if (std::string(key) == "stem_mfma") h->eng->stem_mfma = value != 0;
         else if (std::string(key) == "point_stream2") h->eng->point_on_head_stream = value;
         else if (std::string(key) == "head_batch") h->eng->head_batch = value != 0;
+        else if (std::string(key) == "head_fuse") h->eng->head_fuse = value != 0;
         else if (std::string(key) == "side_priority") h->eng->side_low_priority = value;
         else if (std::string(key) == "head_stream") h->eng->head_stream = value != 0;
         else if (std::string(key) == "split_decoders") h->eng->split_decoders = value;

@@ -111,6 +111,7 @@ public:
                                       // (event 0), with the point branch ahead of it on the same stream — the first RCBlocks are
                                       // throughput-bound like backbone stages 0 / 1 and halve each other's speed when they overlap
     int pool_strip = 2;               // option "pool_strip": which RCBlock average pools use the 4-pixel strip kernel (engine_impl.h, rcnet)
+    bool head_fuse = true;            // option "head_fuse": bf16, 64-wide towers — a head layer's depthwise 5x5 + pointwise conv as one launch (k_headdw.h); needs head_batch
     bool head_batch = true;           // option "head_batch": each detection-head layer as one launch for the three pyramid levels
     int point_on_head_stream = -1;    // option "point_stream2" (-1 auto / 0 / 1): the point branch opens stream 2 (ahead of fusion + head) instead of queueing behind the radar branch
     bool stem_mfma = true;            // option "stem_mfma": the 4x4/s4 stem conv as an MFMA GEMM gathered from the NCHW image

@@ -11,6 +11,7 @@
 #include "k_detect.h"
 #include "k_conv3.h"
 #include "k_gemm.h"
+#include "k_headdw.h"
 #include "k_mlp.h"
 #include "k_mlpband.h"
 #include "k_mv2.h"
@@ -203,7 +204,7 @@ public:
         }, bytes, 2.0 * double(M) * (o.conv_k > 0 && o.Creal ? double(o.conv_k * o.conv_k * o.Creal) : double(pk.K)) * pk.N, lbytes);
     }
     // ---- batching of the same layer over the detection head's pyramid levels
-    struct BatchJob { int kind = 0; std::string name; GemmParams g; int NT = 1; void** ydyn = nullptr; DwParams d; int ks = 0; double bytes = 0, flops = 0; };
+    struct BatchJob { int kind = 0; std::string name; GemmParams g; int NT = 1; void** ydyn = nullptr; DwParams d; int ks = 0; double bytes = 0, flops = 0; HeadDwJob hj; int shared_in = 0; };
     bool batching = false;
     std::vector<BatchJob> batch_jobs;
     // `levels` chains of `per_level` jobs each were recorded level by level; emit stage s of all levels as one launch
@@ -240,6 +241,21 @@ public:
                     else if (NT == 2) ACH_LAUNCH((gemm_multi_kernel<T, 2>), grid, block, s, m);
                     else ACH_LAUNCH((gemm_multi_kernel<T, 4>), grid, block, s, m);
                 }, bytes, flops);
+            } else if (j0.kind == 2) {              // fused depthwise 5x5 + pointwise layer of the head towers (k_headdw.h), one job per level
+                HeadDwParams hp;
+                std::memset(&hp, 0, sizeof(hp));
+                hp.njobs = levels; hp.shared_in = j0.shared_in;
+                int wg = 0;
+                for (int l = 0; l < levels; ++l) {
+                    const BatchJob& j = batch_jobs[size_t(l * per_level + st)];
+                    if (j.kind != 2 || j.shared_in != j0.shared_in) throw AchError{ACH_ERR_INVALID, "head batching: fused layers differ across levels"};
+                    hp.job[l] = j.hj; hp.job[l].wg0 = wg;
+                    hp.B = j.d.B;
+                    wg += 2 * j.hj.bands * j.d.B;
+                    bytes += j.bytes; flops += j.flops;
+                }
+                const dim3 grid(static_cast<unsigned>(wg)), block(HDW_THREADS);
+                add_op(name, [hp, grid, block](hipStream_t s) { ACH_LAUNCH((headdw_kernel<bf16_t>), grid, block, s, hp); }, bytes, flops);
             } else {
                 DwJobs m;
                 std::memset(&m, 0, sizeof(m));
@@ -1401,6 +1417,36 @@ public:
                 std::vector<float> wt(size_t(25) * 2 * base), bias(size_t(2) * base, 0.f);
                 for (int ch = 0; ch < base; ++ch)
                     for (int t = 0; t < 25; ++t) { wt[size_t(t) * 2 * base + ch] = wc.data[size_t(ch) * 25 + t]; wt[size_t(t) * 2 * base + base + ch] = wr.data[size_t(ch) * 25 + t]; }
+                // fused layer (k_headdw.h): bf16, 64-wide towers, one launch for the three levels
+                const int rbh = headdw_band_rows(x.H, x.W);
+                if (head_fuse && batching && std::is_same<T, bf16_t>::value && base == HDW_C && rbh > 0 && cur.ld % 8 == 0) {
+                    Lin lc = conv_bn(c + ".conv.pconv", c + ".bn", 1e-3), lr = conv_bn(r + ".conv.pconv", r + ".bn", 1e-3);
+                    std::vector<uint16_t> wp(size_t(2) * 2 * 4 * 64 * 8, 0);
+                    std::vector<float> pb(size_t(2) * base, 0.f);
+                    for (int br = 0; br < 2; ++br) {
+                        const Lin& l = br == 0 ? lc : lr;
+                        for (int n = 0; n < base; ++n) pb[size_t(br) * base + n] = l.b[n];
+                        for (int s2 = 0; s2 < 2; ++s2)
+                            for (int t = 0; t < 4; ++t)
+                                for (int ln = 0; ln < 64; ++ln) {
+                                    const int i = ln & 15, kg = ln >> 4, n = (t / 2) * 32 + (i / 4) * 8 + (t % 2) * 4 + (i % 4);
+                                    for (int e = 0; e < 8; ++e)
+                                        wp[(((size_t(br) * 2 + s2) * 4 + t) * 64 + ln) * 8 + e] = f32_to_bf16_bits(l.w[size_t(n) * base + s2 * 32 + kg * 8 + e]);
+                                }
+                    }
+                    A y = alloc(x.B, x.H, x.W, 2 * base);
+                    BatchJob bj; bj.kind = 2; bj.name = "det_head.convs." + ks + "." + js + ".dwpw"; bj.shared_in = (j == 0) ? 1 : 0;
+                    std::memset(&bj.hj, 0, sizeof(bj.hj));
+                    bj.hj.X = cur.p; bj.hj.Y = y.p; bj.hj.ldx = cur.ld; bj.hj.ldy = y.ld; bj.hj.Wdw = up_f32(wt);
+                    bj.hj.Wp = static_cast<const uint4*>(up_raw(wp.data(), wp.size() * 2)); bj.hj.bias = up_f32(pb);
+                    bj.hj.H = x.H; bj.hj.W = x.W; bj.hj.rb = rbh; bj.hj.bands = cdiv(x.H, rbh);
+                    std::memset(&bj.d, 0, sizeof(bj.d)); bj.d.B = x.B;
+                    bj.bytes = double(cur.rows()) * cur.C * sizeof(T) + double(y.rows()) * y.C * sizeof(T);
+                    bj.flops = 2.0 * double(y.rows()) * 2 * base * base;
+                    batch_jobs.push_back(bj);
+                    cur = y;
+                    continue;
+                }
                 A d = alloc(x.B, x.H, x.W, 2 * base);
                 DwParams dp;
                 std::memset(&dp, 0, sizeof(dp));
@@ -1437,7 +1483,7 @@ public:
             GemmOpt o1; o1.ydyn = &io.det[k]; o1.out_nchw = 1; o1.HW = HW; o1.Ctot = NC5; o1.coff = 0;
             gemm("det_head.preds." + ks, cur.p, cur.ld, cur.rows(), pack(lp), nullptr, 0, o1);
         }
-        if (batching) flush_batch(3, 6);
+        if (batching) flush_batch(3, int(batch_jobs.size()) / 3);
     }
 
     // ------------------------------------------------------------------------------------------ PointNet (a18)

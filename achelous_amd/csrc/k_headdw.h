@@ -1,0 +1,163 @@
+// k_headdw.h — one layer of the detection head's two towers, fused (bf16 engine, nano head; round 3):
+//
+//     y[:, br*64 : br*64+64] = relu( Wp_br · dw5x5(x_br) + b_br )        br = cls / reg       head/decouplehead.py:38-52, 70-92
+//                                                                        (BaseConv with ds_conv: dw 5x5 -> pw 1x1 -> BN -> ReLU,
+//                                                                         backbone/conv_utils/normal_conv.py:23-52)
+// It was two launches per layer for the three pyramid levels: `dwconv_strip_multi<5>` — every input element fetched 25 times through the
+// texture path (TA 49 % busy, 58-64 us, and the reason the decoders' tail stretches beside it) — writing a 128-channel tensor that the
+// block-diagonal 128 x 128 GEMM (31 us) read straight back.  Here a 512-thread workgroup owns (frame, band of rows, tower):
+//   0. the band's halo (rows + 4, columns + 4, the tower's 64 input channels) is staged in LDS once, unpacked to fp32;
+//   1. depthwise 5 x 5 from LDS: thread = 5-pixel strip x 4 channels (a tap row: 9 LDS reads for 5 x 5 x 4 FMAs); the sums are written
+//      back to LDS as the bf16 B fragments of the pointwise GEMM — the depthwise output never exists in HBM;
+//   2. the tower's 64 x 64 pointwise conv on MFMA (weights: 8 fragments, register-resident), + bias, ReLU, 16-byte stores.
+// The three levels are one launch (a job per level: 40 x 40 in 4-row bands, 20 x 20 in 5-row bands, 10 x 10 whole).
+#pragma once
+#include "ach_platform.h"
+
+namespace ach {
+
+constexpr int HDW_THREADS = 512, HDW_SP = 5, HDW_C = 64, HDW_MAXPOS = 8 * 44, HDW_MAXT = 10;
+struct HeadDwJob {
+    const void* X; void* Y; long ldx, ldy;
+    const float* Wdw;                 // [25][128] fp32 (both towers side by side)
+    const uint4* Wp;                  // [2 towers][2 k-steps][4 tiles][64 lanes] bf16 A fragments
+    const float* bias;                // [128]
+    int H, W, rb, bands, wg0;         // wg0: first workgroup of the job
+};
+struct HeadDwParams {
+    HeadDwJob job[3];
+    int njobs, B;
+    int shared_in;                    // 1: both towers read the SAME 64 input channels (first layer, fed by the stem); 0: tower br reads channels br*64 ..
+};
+
+template <class T>          // (bf16_t; a template so that the two engine translation units can both include the header)
+__global__ __launch_bounds__(HDW_THREADS, 1) void headdw_kernel(const HeadDwParams p) {
+    constexpr int C = HDW_C, SP = HDW_SP, KS = 5;
+    __shared__ float xin[HDW_MAXPOS * C];                       // 90 KB
+    __shared__ uint4 xs[HDW_MAXT * 2 * 64];                     // 20 KB: B fragments of the band's tiles
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int px = lane & 15, g = lane >> 4;
+    int ji = 0;
+    ACH_UNROLL
+    for (int k = 1; k < 3; ++k) if (k < p.njobs && int(blockIdx.x) >= p.job[k].wg0) ji = k;
+    const HeadDwJob& J = p.job[ji];
+    const int idx = int(blockIdx.x) - J.wg0;
+    const int br = idx & 1, band = (idx >> 1) % J.bands, b = (idx >> 1) / J.bands;
+    const int H = J.H, W = J.W;
+    const int y0 = band * J.rb, rows = (y0 + J.rb <= H) ? J.rb : H - y0;
+    const int npx = rows * W, nt = (npx + 15) / 16;
+    const int WCr = W + KS - 1, HRr = rows + KS - 1;
+    const T* X = static_cast<const T*>(J.X) + long(b) * H * W * J.ldx + (p.shared_in ? 0 : br * C);
+    // ---- 0. halo tile -> LDS (fp32)
+    {
+        constexpr int C8 = C / 8, UN = 2;
+        const int total = HRr * WCr * C8;
+        for (int it0 = tid; it0 < total; it0 += UN * HDW_THREADS) {
+            uint4 raw[UN];
+            ACH_UNROLL
+            for (int u = 0; u < UN; ++u) {
+                const int it = it0 + u * HDW_THREADS;
+                raw[u] = make_uint4(0u, 0u, 0u, 0u);
+                if (it < total) {
+                    const int c8 = it % C8, pos = it / C8, wc = pos % WCr, hr = pos / WCr;
+                    const int iy = y0 - KS / 2 + hr, ix = wc - KS / 2;
+                    if (iy >= 0 && iy < H && ix >= 0 && ix < W) raw[u] = *reinterpret_cast<const uint4*>(X + (long(iy) * W + ix) * J.ldx + c8 * 8);
+                }
+            }
+            ACH_UNROLL
+            for (int u = 0; u < UN; ++u) {
+                const int it = it0 + u * HDW_THREADS;
+                if (it >= total) continue;
+                const int c8 = it % C8, pos = it / C8;
+                float v[8];
+                frag_unpack<T>(raw[u], v);
+                float* d = xin + pos * C + c8 * 8;
+                *reinterpret_cast<float4*>(d) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(d + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            }
+        }
+    }
+    // the pointwise weights of this tower: 2 k-steps x 4 output tiles
+    uint4 wp[2][4];
+    ACH_UNROLL
+    for (int s = 0; s < 2; ++s) { ACH_UNROLL for (int t = 0; t < 4; ++t) wp[s][t] = J.Wp[((br * 2 + s) * 4 + t) * 64 + lane]; }
+    // fragments of the (ragged) last tile must not hold garbage
+    for (int i = tid; i < nt * 2 * 64; i += HDW_THREADS) xs[i] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+    // ---- 1. depthwise 5 x 5 from LDS: thread = strip of SP pixels x 4 channels -> bf16 B fragments
+    {
+        constexpr int C4 = C / 4;
+        const int nstrip = (W + SP - 1) / SP, total = rows * nstrip * C4;
+        const float* wdw = J.Wdw + br * C;
+        for (int it = tid; it < total; it += HDW_THREADS) {
+            const int cg = it % C4, rest = it / C4, q = rest % nstrip, r = rest / nstrip;
+            const int x0 = q * SP;
+            f32x2 acc[SP][2];
+            ACH_UNROLL
+            for (int i = 0; i < SP; ++i) { acc[i][0] = f32x2{0.f, 0.f}; acc[i][1] = f32x2{0.f, 0.f}; }
+            ACH_NO_UNROLL
+            for (int ty = 0; ty < KS; ++ty) {
+                f32x2 v[SP + KS - 1][2];
+                ACH_UNROLL
+                for (int j = 0; j < SP + KS - 1; ++j) {
+                    const int col = x0 + j < WCr ? x0 + j : WCr - 1;
+                    const float4 t = *reinterpret_cast<const float4*>(xin + ((r + ty) * WCr + col) * C + cg * 4);
+                    v[j][0] = f32x2{t.x, t.y}; v[j][1] = f32x2{t.z, t.w};
+                }
+                ACH_UNROLL
+                for (int tx = 0; tx < KS; ++tx) {
+                    const float4 w = *reinterpret_cast<const float4*>(wdw + long(ty * KS + tx) * (2 * C) + cg * 4);
+                    const f32x2 w0 = {w.x, w.y}, w1 = {w.z, w.w};
+                    ACH_UNROLL
+                    for (int i = 0; i < SP; ++i) { acc[i][0] += w0 * v[i + tx][0]; acc[i][1] += w1 * v[i + tx][1]; }
+                }
+            }
+            const int c0 = cg * 4, s = c0 >> 5, gg = (c0 & 31) >> 3, e = c0 & 7;          // k-step, lane group and element of these 4 channels
+            ACH_UNROLL
+            for (int i = 0; i < SP; ++i) {
+                if (x0 + i >= W) continue;
+                const int pix = r * W + x0 + i, t = pix >> 4, pp = pix & 15;
+                uint2 o;
+                o.x = pack_bf16x2(acc[i][0][0], acc[i][0][1]);
+                o.y = pack_bf16x2(acc[i][1][0], acc[i][1][1]);
+                *reinterpret_cast<uint2*>(reinterpret_cast<char*>(xs + (t * 2 + s) * 64 + gg * 16 + pp) + e * 2) = o;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- 2. pointwise 64 x 64 on MFMA, + bias, ReLU; lane (px, g) of tile pair q holds output channels q*32 + g*8 .. +7
+    T* Y = static_cast<T*>(J.Y) + long(b) * H * W * J.ldy + br * C;
+    const float* bias = J.bias + br * C;
+    for (int t = wave; t < nt; t += HDW_THREADS / 64) {
+        f32x4 acc[4];
+        ACH_UNROLL
+        for (int k = 0; k < 4; ++k) { acc[k][0] = 0.f; acc[k][1] = 0.f; acc[k][2] = 0.f; acc[k][3] = 0.f; }
+        ACH_UNROLL
+        for (int s = 0; s < 2; ++s) {
+            const uint4 xf = xs[(t * 2 + s) * 64 + lane];
+            ACH_UNROLL
+            for (int k = 0; k < 4; ++k) mfma16<T>(wp[s][k], xf, acc[k]);
+        }
+        const int pix = t * 16 + px;
+        if (pix >= npx) continue;
+        const long m = long(y0) * W + pix;
+        ACH_UNROLL
+        for (int q = 0; q < 2; ++q) {
+            const int nb = q * 32 + g * 8;
+            float o[8];
+            ACH_UNROLL
+            for (int r = 0; r < 4; ++r) { o[r] = acc[2 * q][r] + bias[nb + r]; o[4 + r] = acc[2 * q + 1][r] + bias[nb + 4 + r]; }
+            ACH_UNROLL
+            for (int i = 0; i < 8; ++i) o[i] = o[i] > 0.f ? o[i] : 0.f;
+            Store<T>::st8(Y + m * J.ldy + nb, o);
+        }
+    }
+}
+
+inline int headdw_band_rows(int H, int W) {            // the band's halo must fit HDW_MAXPOS positions and its pixels HDW_MAXT tiles
+    for (int rb = H; rb >= 1; --rb)
+        if ((rb + 4) * (W + 4) <= HDW_MAXPOS && (rb * W + 15) / 16 <= HDW_MAXT) return rb;
+    return 0;
+}
+
+}  // namespace ach

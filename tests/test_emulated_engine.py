@@ -526,3 +526,30 @@ def test_emulated_band_kernel_matches_the_tile_kernel(name, res, batch):
     for t in taps[1]:
         assert rel_err(taps[1][t], taps[0][t]) < 1.5e-2, (t, rel_err(taps[1][t], taps[0][t]))     # same arithmetic, different summation order, bf16 storage
         assert rel_err(taps[1][t], orc.taps[t]) < 4e-2, (t, rel_err(taps[1][t], orc.taps[t]))
+
+
+@pytest.mark.parametrize('res,batch', [(96, 2), (320, 1), (416, 1)])
+def test_emulated_fused_head_layer_matches_the_two_launches(res, batch):
+    """bf16 engine: a head layer's depthwise 5x5 + pointwise conv of both towers as one launch for the three levels (k_headdw.h, option
+    head_fuse = 1, default) against the dwconv_strip_multi + block-diagonal GEMM pair (head_fuse = 0) and the oracle.  320: 40x40 in 4-row
+    bands of 10 tiles, 20x20 in 8 / 8 / 4-row bands, 10x10 whole; 96: 12x12 / 6x6 / 3x3 (ragged tiles and strips); 416: 52-wide rows (2-row bands)."""
+    kw, sd, (x, xr, xp) = _setup('en_s0', res, batch, 16)
+    det = AchelousOracle(sd, **{k: kw[k] for k in ORACLE_KEYS}).forward(x, xr, xp)[0]
+    outs = {}
+    for fuse in (1, 0):
+        from achelous_amd.engine import NativeEngine
+        eng = NativeEngine(emu_library(), num_det=kw['num_det'], num_seg=kw['num_seg'], phi=kw['phi'], backbone=kw['backbone'], resolution=res,
+                           pc_channels=kw['pc_channels'], pc_classes=kw['pc_classes'], num_points=16, nano_head=True, spp=True, dtype=DTYPE_BF16)
+        eng.set_option('head_fuse', fuse)
+        eng.load_state_dict(sd)
+        eng.plan(batch)
+        o = alloc_outputs(kw, batch, 16, torch.bfloat16, 'cpu')
+        eng.forward(x.bfloat16(), xr.bfloat16(), xp.bfloat16(), o)
+        outs[fuse] = [t.float() for t in o[:3]]
+        if fuse:
+            launches = eng.launches()
+        else:
+            assert eng.launches() == launches + 2          # two layers x (dconv + pconv) -> two fused launches
+    for k in range(3):
+        assert rel_err(outs[1][k], outs[0][k]) < 1.5e-2, (k, rel_err(outs[1][k], outs[0][k]))
+        assert rel_err(outs[1][k], det[k]) < 3e-2, (k, rel_err(outs[1][k], det[k]))
