@@ -91,6 +91,7 @@ int ach_set_option(ach_handle* h, const char* key, int32_t value) {
         else if (std::string(key) == "point_stream2") h->eng->point_on_head_stream = value;
         else if (std::string(key) == "head_batch") h->eng->head_batch = value != 0;
         else if (std::string(key) == "head_fuse") h->eng->head_fuse = value != 0;
+        else if (std::string(key) == "head_fuse_dbg") h->eng->head_fuse_dbg = value;
         else if (std::string(key) == "side_priority") h->eng->side_low_priority = value;
         else if (std::string(key) == "head_stream") h->eng->head_stream = value != 0;
         else if (std::string(key) == "split_decoders") h->eng->split_decoders = value;
@@ -104,7 +105,7 @@ int ach_set_option(ach_handle* h, const char* key, int32_t value) {
         else if (std::string(key) == "radar_rows4") h->eng->radar_rows4 = value;
         else if (std::string(key) == "radar_skip") h->eng->radar_skip = value != 0;
         else if (std::string(key) == "head_mfma") h->eng->head_mfma = value != 0;
-        else if (std::string(key) == "head_rows") h->eng->head_rows = value != 0;
+        else if (std::string(key) == "head_rows") h->eng->head_rows = value;
         else if (std::string(key) == "level_rows") h->eng->level_rows = value != 0;
         else if (std::string(key) == "mlp_band") h->eng->mlp_band = value;
         else if (std::string(key) == "mlp_band_dbg") h->eng->mlp_band_dbg = value;

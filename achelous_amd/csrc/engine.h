@@ -81,7 +81,7 @@ public:
     int radar_rows4 = 2;              // option "radar_rows4": a workgroup of rc_front owns four rows, one per wave (1: block 0 when radar_skip is on; 2: every
                                       // fused block — 29.1 k against 27.7 k frames/s: the per-workgroup weight staging and tables were a fifth of these kernels)
     bool radar_skip = true;           // option "radar_skip": first RCBlock — closed-form shortcut on 16-pixel segments whose neighbourhood of the radar map is empty (k_conv3.h)
-    bool head_rows = true;            // option "head_rows": bf16 — fused last decoder level + head as the row-walking kernel (k_dechead.h: no LDS, DPP row shifts, head 1x1 on MFMA); 0 = the LDS tile kernel (k_nhwc.h)
+    int head_rows = 2;            // option "head_rows": bf16 — fused last decoder level + head as the row-walking kernel (k_dechead.h: no LDS, DPP row shifts, head 1x1 on MFMA); 0 = the LDS tile kernel (k_nhwc.h)
     bool level_rows = false;          // option "level_rows": the other two decoder levels through upghost_rows_kernel too (k_dechead.h).  OFF: their 32- / 48-channel NHWC rows are
                                       // write-bound, and the 16-column strips write them in 64-byte pieces: 3_to_2 25 -> 34 us, 2_to_1 48 -> 60 us, 32.6 k -> 31.6 k frames/s
     int head_band = 40;               // option "head_band": rows per band of the row-walking kernel
@@ -111,6 +111,7 @@ public:
                                       // (event 0), with the point branch ahead of it on the same stream — the first RCBlocks are
                                       // throughput-bound like backbone stages 0 / 1 and halve each other's speed when they overlap
     int pool_strip = 2;               // option "pool_strip": which RCBlock average pools use the 4-pixel strip kernel (engine_impl.h, rcnet)
+    int head_fuse_dbg = 0;            // option "head_fuse_dbg": phase-kill timing experiments on the fused head layer (results are wrong)
     bool head_fuse = true;            // option "head_fuse": bf16, 64-wide towers — a head layer's depthwise 5x5 + pointwise conv as one launch (k_headdw.h); needs head_batch
     bool head_batch = true;           // option "head_batch": each detection-head layer as one launch for the three pyramid levels
     int point_on_head_stream = -1;    // option "point_stream2" (-1 auto / 0 / 1): the point branch opens stream 2 (ahead of fusion + head) instead of queueing behind the radar branch

@@ -244,7 +244,7 @@ public:
             } else if (j0.kind == 2) {              // fused depthwise 5x5 + pointwise layer of the head towers (k_headdw.h), one job per level
                 HeadDwParams hp;
                 std::memset(&hp, 0, sizeof(hp));
-                hp.njobs = levels; hp.shared_in = j0.shared_in;
+                hp.njobs = levels; hp.shared_in = j0.shared_in; hp.dbg = head_fuse_dbg;
                 int wg = 0;
                 for (int l = 0; l < levels; ++l) {
                     const BatchJob& j = batch_jobs[size_t(l * per_level + st)];
@@ -993,6 +993,8 @@ public:
             const int H2 = 2 * x.H, band = std::max(8, std::min(head_band, H2));
             DecHeadParams dp{t.p, t.ld, full_taps ? f.p : nullptr, full_taps ? f.ld : 0, nullptr, p.Wdw, p.bdw, static_cast<const uint4*>(up_raw(af.data(), af.size() * 2)),
                              up_f32(bh8), up_f32(wd8), up_f32(bd8), x.B, x.H, x.W, init, nch, oup, p.sy, p.sx, band, cdiv(H2, band), cdiv(2 * x.W, DH_VALID)};
+            const bool two = head_rows >= 2;              // two columns per lane: strips of 28 valid columns
+            if (two) dp.strips = cdiv(2 * x.W, DH2_VALID);
             const dim3 grid(unsigned(dp.strips) * unsigned(dp.bands) * unsigned(x.B)), block(64);
             // per-output-row interpolation geometry, in the float arithmetic of the tile kernel / torch (k_dechead.h)
             std::vector<DecHeadRow> rg(static_cast<size_t>(H2) + 4);
@@ -1005,8 +1007,13 @@ public:
             const DecHeadRow* rows = static_cast<const DecHeadRow*>(up_raw(rg.data(), rg.size() * sizeof(DecHeadRow)));
             const int dbg = head_debug;
             const bool dw2 = nch > 4, tapf = full_taps;
-            add_op(head_pfx + ".upghost_head", [dp, grid, block, out, dbg, dw2, tapf, rows](hipStream_t s) mutable {
+            add_op(head_pfx + ".upghost_head", [dp, grid, block, out, dbg, dw2, tapf, rows, two](hipStream_t s) mutable {
                 dp.out = *out;
+                if (two) {
+                    if (tapf) { if (dw2) ACH_LAUNCH((dechead_rows2_kernel<true, true>), grid, block, s, dp, rows); else ACH_LAUNCH((dechead_rows2_kernel<false, true>), grid, block, s, dp, rows); }
+                    else { if (dw2) ACH_LAUNCH((dechead_rows2_kernel<true, false>), grid, block, s, dp, rows); else ACH_LAUNCH((dechead_rows2_kernel<false, false>), grid, block, s, dp, rows); }
+                    return;
+                }
                 if (tapf) {                      // parity-test plans: the variant that also writes [x1 | x2]
                     if (dw2) ACH_LAUNCH((dechead_rows_kernel<true, true, 0>), grid, block, s, dp, rows); else ACH_LAUNCH((dechead_rows_kernel<false, true, 0>), grid, block, s, dp, rows);
                     return;

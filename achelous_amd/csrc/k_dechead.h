@@ -254,6 +254,221 @@ __global__ __launch_bounds__(64, DH_WAVES) void dechead_rows_kernel(const DecHea
     }
 }
 
+// ------------------------------------------------------------------------------------------ two columns per lane
+// The same walk with TWO adjacent columns per lane: a strip is 32 columns wide (lane n holds columns 2n and 2n + 1), 28 of them produce
+// outputs instead of 12 of 16, and the per-lane channel count stays at four — the depthwise weights are still 36 registers.  Half of the
+// x neighbours are now in the lane itself: out[2n] = centre + (lane n-1's right column, one DPP add) + (own right column, a plain add),
+// out[2n+1] = centre + (own left column) + (lane n+1's left column, one DPP add).  The head's 1x1 conv is one MFMA per column set; its
+// depthwise conv packs the two columns of a channel into one v_pk_fma_f32; the two columns' outputs are adjacent in memory and leave as ONE
+// dword store per channel.  ~145 VALU instructions per 28 columns (5.2 per pixel against 8.9).
+constexpr int DH2_VALID = 28;
+#ifndef ACH_DH2_WAVES
+#define ACH_DH2_WAVES 2
+#endif
+
+// four values: o[q] = c[q] + (left neighbour lane's l[q]);  and  o[q] = c[q] + (right neighbour lane's r[q]) — one s_nop per group
+#if defined(ACH_HOSTEMU)
+__device__ inline void add4_from_left(const float (&c)[4], const float (&l)[4], float (&o)[4]) { for (int q = 0; q < 4; ++q) o[q] = add_from_left(c[q], l[q]); }
+__device__ inline void add4_from_right(const float (&c)[4], const float (&r)[4], float (&o)[4]) { for (int q = 0; q < 4; ++q) o[q] = add_from_right(c[q], r[q]); }
+#else
+__device__ __forceinline__ void add4_from_left(const float (&c)[4], const float (&l)[4], float (&o)[4]) {
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %8, %4 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %9, %5 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %2, %10, %6 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %3, %11, %7 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+        : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3])
+        : "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(l[0]), "v"(l[1]), "v"(l[2]), "v"(l[3]));
+}
+__device__ __forceinline__ void add4_from_right(const float (&c)[4], const float (&r)[4], float (&o)[4]) {
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %8, %4 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %9, %5 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %2, %10, %6 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %3, %11, %7 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+        : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3])
+        : "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]));
+}
+#endif
+
+template <bool DW2, bool TAP>
+__global__ __launch_bounds__(64, ACH_DH2_WAVES) void dechead_rows2_kernel(const DecHeadParams p, const DecHeadRow* __restrict__ rows) {
+    const int H = 2 * p.h, Wd = 2 * p.w;
+    const unsigned u = xcd_block(blockIdx.x, gridDim.x);
+    const int strip = int(u % unsigned(p.strips)), band = int((u / unsigned(p.strips)) % unsigned(p.bands));
+    const long b = long(u / (unsigned(p.strips) * unsigned(p.bands)));
+    const int lane = int(threadIdx.x) & 63, n = lane & 15, g = lane >> 4;
+    const int xa = strip * DH2_VALID - 2 + 2 * n;                 // column A; column B = xa + 1 (xa is even, the map width is even)
+    const bool in_x = xa >= 0 && xa < Wd;
+    const bool writer = in_x && n >= 1 && n < 15;
+    const bf16_t* Tq = static_cast<const bf16_t*>(p.Tq) + b * p.h * long(p.w) * p.ldt;
+    const int rowp = p.w * int(p.ldt);
+    // ---- per-lane bilinear geometry along x, per column
+    unsigned o0[2], o1[2];
+    float wx0[2], wx1[2];
+    ACH_UNROLL
+    for (int c = 0; c < 2; ++c) {
+        const int x = xa + c;
+        const int cx = x < 0 ? 0 : (x >= Wd ? Wd - 1 : x);
+        const float fx = p.sx * float(cx);
+        int x0 = int(fx);
+        if (x0 > p.w - 1) x0 = p.w - 1;
+        const int dx = x0 < p.w - 1 ? 1 : 0;
+        const float lx = fx - float(x0);
+        wx0[c] = in_x ? 1.f - lx : 0.f; wx1[c] = in_x ? lx : 0.f;
+        o0[c] = unsigned(x0 * int(p.ldt) + 4 * g); o1[c] = unsigned((x0 + dx) * int(p.ldt) + 4 * g);
+    }
+    f32x2 wl[9][2], bl[2];
+    ACH_UNROLL
+    for (int k = 0; k < 9; ++k) { const float4 w = *reinterpret_cast<const float4*>(p.Wdw + k * 16 + 4 * g); wl[k][0] = f32x2{w.x, w.y}; wl[k][1] = f32x2{w.z, w.w}; }
+    { const float4 w = *reinterpret_cast<const float4*>(p.bdw + 4 * g); bl[0] = f32x2{w.x, w.y}; bl[1] = f32x2{w.z, w.w}; }
+    constexpr int NR = DW2 ? 2 : 1;
+    float wh[9][NR], bdh[NR], bhv[2];
+    ACH_UNROLL
+    for (int r = 0; r < NR; ++r) {
+        ACH_UNROLL
+        for (int k = 0; k < 9; ++k) wh[k][r] = p.Wdh[k * 8 + g + 4 * r];
+        bdh[r] = p.bdh[g + 4 * r];
+    }
+    bhv[0] = p.bh[g]; bhv[1] = p.bh[g + 4];
+    const uint4 afrag = p.Afrag[lane];
+    const bool has_h[2] = {in_x && g < p.init, in_x && g + 4 < p.init};
+    const bool st_h[2] = {writer && g < p.init && g < p.oup, writer && g + 4 < p.init && g + 4 < p.oup};
+    const bool st_d[2] = {writer && g < p.nch, writer && g + 4 < p.nch};
+    const long HW = long(H) * Wd;
+    bf16_t* out_b = static_cast<bf16_t*>(p.out) + b * p.oup * HW;
+    const unsigned xo = unsigned(in_x ? xa : 0);
+    const unsigned off_h[2] = {unsigned(g * HW) + xo, unsigned((g + 4) * HW) + xo};
+    const unsigned off_d[2] = {unsigned((p.init + g) * HW) + xo, unsigned((p.init + g + 4) * HW) + xo};
+    const int r0 = band * p.band_rows, r1 = (r0 + p.band_rows < H) ? r0 + p.band_rows : H;
+    // source rows: [column][left / right source column] raw and unpacked (channel pairs)
+    auto load_raw = [&](int r, uint2 (&raw)[2][2]) {
+        const int rr = r < 0 ? 0 : (r > p.h - 1 ? p.h - 1 : r);
+        const bf16_t* q = Tq + long(rr) * rowp;
+        ACH_UNROLL
+        for (int c = 0; c < 2; ++c) { raw[c][0] = *reinterpret_cast<const uint2*>(q + o0[c]); raw[c][1] = *reinterpret_cast<const uint2*>(q + o1[c]); }
+    };
+    auto unpack = [&](const uint2 (&raw)[2][2], f32x2 (&o)[2][2][2]) {       // [column][source column][channel pair]
+        ACH_UNROLL
+        for (int c = 0; c < 2; ++c) {
+            ACH_UNROLL
+            for (int k = 0; k < 2; ++k) {
+                o[c][k][0] = f32x2{__uint_as_float(raw[c][k].x << 16), __uint_as_float(raw[c][k].x & 0xffff0000u)};
+                o[c][k][1] = f32x2{__uint_as_float(raw[c][k].y << 16), __uint_as_float(raw[c][k].y & 0xffff0000u)};
+            }
+        }
+    };
+    const int i_first = r0 - 2 < 0 ? 0 : r0 - 2;
+    int cy = rows[i_first].y0;
+    f32x2 ta[2][2][2], tb[2][2][2];
+    uint2 tn[2][2];
+    { uint2 raw[2][2]; load_raw(cy, raw); unpack(raw, ta); load_raw(cy + 1, raw); unpack(raw, tb); load_raw(cy + 2, tn); }
+    const f32x2 zero2 = {0.f, 0.f};
+    // rolling windows: x1 [column][channel pair] and h as COLUMN pairs per accumulator r
+    f32x2 w0[2][2], w1[2][2], w2[2][2];
+    f32x2 v0[2] = {zero2, zero2}, v1[2] = {zero2, zero2}, v2[2] = {zero2, zero2};
+    ACH_UNROLL
+    for (int c = 0; c < 2; ++c) { ACH_UNROLL for (int q = 0; q < 2; ++q) { w0[c][q] = zero2; w1[c][q] = zero2; w2[c][q] = zero2; } }
+
+    auto step = [&](const int i, f32x2 (&xm)[2][2], f32x2 (&xc)[2][2], f32x2 (&xp)[2][2], f32x2 (&hm)[2], f32x2 (&hc)[2], f32x2 (&hp)[2]) {
+        // ---- A: x1 row i, both columns
+        {
+            const bool row_ok = i >= 0 && i < H;
+            const DecHeadRow rg = rows[row_ok ? i : 0];
+            if (row_ok && rg.y0 > cy) {
+                ACH_UNROLL
+                for (int c = 0; c < 2; ++c) { ACH_UNROLL for (int k = 0; k < 2; ++k) { ta[c][k][0] = tb[c][k][0]; ta[c][k][1] = tb[c][k][1]; } }
+                unpack(tn, tb);
+                ++cy;
+                load_raw(cy + 2, tn);
+            }
+            const float ly = row_ok ? rg.ly : 0.f, hy = row_ok ? 1.f - rg.ly : 0.f;
+            ACH_UNROLL
+            for (int c = 0; c < 2; ++c) {
+                const float w00 = hy * wx0[c], w01 = hy * wx1[c], w10 = ly * wx0[c], w11 = ly * wx1[c];
+                ACH_UNROLL
+                for (int q = 0; q < 2; ++q) {
+                    const f32x2 v = w00 * ta[c][0][q] + w01 * ta[c][1][q] + w10 * tb[c][0][q] + w11 * tb[c][1][q];
+                    xp[c][q] = f32x2{v[0] > 0.f ? v[0] : 0.f, v[1] > 0.f ? v[1] : 0.f};
+                }
+            }
+        }
+        // ---- B: x2 and h of row i-1
+        {
+            const int rb = i - 1;
+            f32x2 sl[2][2], sr[2][2], sc[2][2];
+            ACH_UNROLL
+            for (int c = 0; c < 2; ++c) {
+                ACH_UNROLL
+                for (int q = 0; q < 2; ++q) {
+                    sl[c][q] = wl[0][q] * xm[c][q] + wl[3][q] * xc[c][q] + wl[6][q] * xp[c][q];       // what this column contributes to column + 1
+                    sr[c][q] = wl[2][q] * xm[c][q] + wl[5][q] * xc[c][q] + wl[8][q] * xp[c][q];       // ... to column - 1
+                    sc[c][q] = bl[q] + wl[1][q] * xm[c][q] + wl[4][q] * xc[c][q] + wl[7][q] * xp[c][q];
+                }
+            }
+            // column A: + own B's right-tap sums, + lane n-1's B left-tap sums;   column B: + own A's left-tap sums, + lane n+1's A right-tap sums
+            float ca[4], cb[4], la[4], rb4[4], oa[4], ob[4];
+            ACH_UNROLL
+            for (int q = 0; q < 2; ++q) {
+                const f32x2 a = sc[0][q] + sr[1][q], bq = sc[1][q] + sl[0][q];
+                ca[2 * q] = a[0]; ca[2 * q + 1] = a[1]; cb[2 * q] = bq[0]; cb[2 * q + 1] = bq[1];
+                la[2 * q] = sl[1][q][0]; la[2 * q + 1] = sl[1][q][1]; rb4[2 * q] = sr[0][q][0]; rb4[2 * q + 1] = sr[0][q][1];
+            }
+            add4_from_left(ca, la, oa);
+            add4_from_right(cb, rb4, ob);
+            float x2a[4], x2b[4];
+            ACH_UNROLL
+            for (int e = 0; e < 4; ++e) { x2a[e] = relu_raw(oa[e]); x2b[e] = relu_raw(ob[e]); }
+            const bool row_in = rb >= 0 && rb < H;
+            if (TAP && row_in && writer && rb >= r0 && rb < r1) {
+                bf16_t* fo = static_cast<bf16_t*>(p.F) + ((b * H + rb) * long(Wd) + xa) * p.ldf + 4 * g;
+                const float a1[4] = {xc[0][0][0], xc[0][0][1], xc[0][1][0], xc[0][1][1]}, b1[4] = {xc[1][0][0], xc[1][0][1], xc[1][1][0], xc[1][1][1]};
+                Store<bf16_t>::st4(fo, a1); Store<bf16_t>::st4(fo + 16, x2a);
+                Store<bf16_t>::st4(fo + p.ldf, b1); Store<bf16_t>::st4(fo + p.ldf + 16, x2b);
+            }
+            f32x4 acca = {0.f, 0.f, 0.f, 0.f}, accb = {0.f, 0.f, 0.f, 0.f};
+            {
+                const uint4 fa = make_uint4(pack_bf16x2(xc[0][0][0], xc[0][0][1]), pack_bf16x2(xc[0][1][0], xc[0][1][1]), pack_bf16x2(x2a[0], x2a[1]), pack_bf16x2(x2a[2], x2a[3]));
+                const uint4 fb = make_uint4(pack_bf16x2(xc[1][0][0], xc[1][0][1]), pack_bf16x2(xc[1][1][0], xc[1][1][1]), pack_bf16x2(x2b[0], x2b[1]), pack_bf16x2(x2b[2], x2b[3]));
+                mfma16<bf16_t>(afrag, fa, acca);
+                mfma16<bf16_t>(afrag, fb, accb);
+            }
+            ACH_UNROLL
+            for (int r = 0; r < 2; ++r) {
+                const float va = acca[r] + bhv[r], vb = accb[r] + bhv[r];
+                const bool ok = row_in && has_h[r];
+                hp[r] = f32x2{(ok && va > 0.f) ? va : 0.f, (ok && vb > 0.f) ? vb : 0.f};
+            }
+        }
+        // ---- C: output row i-2: the two columns of a channel leave as one dword
+        {
+            const int ro = i - 2;
+            const bool row_st = ro >= r0 && ro < r1;
+            bf16_t* orow = out_b + long(row_st ? ro : r0) * Wd;
+            ACH_UNROLL
+            for (int r = 0; r < 2; ++r)
+                if (row_st && st_h[r]) *reinterpret_cast<uint32_t*>(orow + off_h[r]) = pack_bf16x2(hc[r][0], hc[r][1]);
+            ACH_UNROLL
+            for (int r = 0; r < NR; ++r) {
+                const f32x2 wv0 = {wh[0][r], wh[0][r]}, wv1 = {wh[1][r], wh[1][r]}, wv2 = {wh[2][r], wh[2][r]}, wv3 = {wh[3][r], wh[3][r]}, wv4 = {wh[4][r], wh[4][r]},
+                            wv5 = {wh[5][r], wh[5][r]}, wv6 = {wh[6][r], wh[6][r]}, wv7 = {wh[7][r], wh[7][r]}, wv8 = {wh[8][r], wh[8][r]};
+                const f32x2 slh = wv0 * hm[r] + wv3 * hc[r] + wv6 * hp[r];               // per column: its contribution to column + 1
+                const f32x2 srh = wv2 * hm[r] + wv5 * hc[r] + wv8 * hp[r];               // ... to column - 1
+                const f32x2 sch = f32x2{bdh[r], bdh[r]} + wv1 * hm[r] + wv4 * hc[r] + wv7 * hp[r];
+                const float oa = add_from_left(sch[0] + srh[1], slh[1]);                 // column A: own B's right taps + lane n-1's B left taps
+                const float ob = add_from_right(sch[1] + slh[0], srh[0]);                // column B: own A's left taps + lane n+1's A right taps
+                if (row_st && st_d[r]) *reinterpret_cast<uint32_t*>(orow + off_d[r]) = pack_bf16x2(relu_raw(oa), relu_raw(ob));
+            }
+        }
+    };
+    ACH_NO_UNROLL
+    for (int i = r0 - 2; i <= r1 + 1; i += 3) {
+        step(i, w0, w1, w2, v0, v1, v2);
+        step(i + 1, w1, w2, w0, v1, v2, v0);
+        step(i + 2, w2, w0, w1, v2, v0, v1);
+    }
+}
+
 // ------------------------------------------------------------------------------------------ the other decoder levels, same walk
 // One decoder level at full resolution — x1 = relu(bilinear x2 (t)), x2 = relu(dw3x3(x1) + b), y = [x1 | x2] (NHWC) — as the row-walking
 // kernel above without the head: one 3x3 window, so 14 of a strip's 16 columns produce outputs.  NP = channel pairs per lane:

@@ -357,7 +357,11 @@ __global__ __launch_bounds__(256) void gemm_colmax_kernel(const GemmMaxParams p)
     __shared__ float red[4][16 * NT];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int px = lane & 15, g = lane >> 4;
-    const int c = int(blockIdx.x % unsigned(p.nchunks)), grp = int(blockIdx.x / unsigned(p.nchunks));      // flat grid: groups can exceed 65535
+    // flat grid (groups can exceed 65535), XCD-aware: the nchunks workgroups of a group all read the group's rows, so a group's chunks stay
+    // in ONE XCD's L2 (round 3: in plain dispatch order a sample's 16 chunks went to all eight XCDs and the 128 -> 1024 convs of PointNet
+    // fetched their activations 7.7x: profiles/r02_traffic_en_s0.json)
+    const unsigned wgid = xcd_block(blockIdx.x, gridDim.x);
+    const int c = int(wgid % unsigned(p.nchunks)), grp = int(wgid / unsigned(p.nchunks));
     const T* X = static_cast<const T*>(p.X) + long(grp) * p.M_per_group * p.ldx;
     const uint4* Wf = reinterpret_cast<const uint4*>(p.W) + long(c) * p.ksteps * NT * 64 + lane;
     float bv[4 * NT], cm[4 * NT];

@@ -27,6 +27,7 @@ struct HeadDwJob {
 struct HeadDwParams {
     HeadDwJob job[3];
     int njobs, B;
+    int dbg;                          // timing experiments only (option head_fuse_dbg; wrong results): bit 0 no staging, 1 no depthwise, 2 no GEMM / stores
     int shared_in;                    // 1: both towers read the SAME 64 input channels (first layer, fed by the stem); 0: tower br reads channels br*64 ..
 };
 
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(HDW_THREADS, 1) void headdw_kernel(const HeadDwPara
     const int WCr = W + KS - 1, HRr = rows + KS - 1;
     const T* X = static_cast<const T*>(J.X) + long(b) * H * W * J.ldx + (p.shared_in ? 0 : br * C);
     // ---- 0. halo tile -> LDS (fp32)
-    {
+    if (!(p.dbg & 1)) {
         constexpr int C8 = C / 8, UN = 2;
         const int total = HRr * WCr * C8;
         for (int it0 = tid; it0 < total; it0 += UN * HDW_THREADS) {
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(HDW_THREADS, 1) void headdw_kernel(const HeadDwPara
     for (int i = tid; i < nt * 2 * 64; i += HDW_THREADS) xs[i] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
     // ---- 1. depthwise 5 x 5 from LDS: thread = strip of SP pixels x 4 channels -> bf16 B fragments
-    {
+    if (!(p.dbg & 2)) {
         constexpr int C4 = C / 4;
         const int nstrip = (W + SP - 1) / SP, total = rows * nstrip * C4;
         const float* wdw = J.Wdw + br * C;
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(HDW_THREADS, 1) void headdw_kernel(const HeadDwPara
     // ---- 2. pointwise 64 x 64 on MFMA, + bias, ReLU; lane (px, g) of tile pair q holds output channels q*32 + g*8 .. +7
     T* Y = static_cast<T*>(J.Y) + long(b) * H * W * J.ldy + br * C;
     const float* bias = J.bias + br * C;
-    for (int t = wave; t < nt; t += HDW_THREADS / 64) {
+    for (int t = wave; t < ((p.dbg & 4) ? 0 : nt); t += HDW_THREADS / 64) {
         f32x4 acc[4];
         ACH_UNROLL
         for (int k = 0; k < 4; ++k) { acc[k][0] = 0.f; acc[k][1] = 0.f; acc[k][2] = 0.f; acc[k][3] = 0.f; }
