@@ -17,6 +17,11 @@
 namespace ach {
 
 constexpr int HDW_THREADS = 512, HDW_SP = 5, HDW_C = 64, HDW_MAXPOS = 8 * 44, HDW_MAXT = 10;
+#ifndef ACH_HDW_F32
+#define ACH_HDW_F32 0             // 1: the halo tile is staged as fp32 (90 KB: one workgroup per CU); 0: as bf16 (45 KB: two per CU, taps unpacked in the loop)
+#endif
+constexpr bool HDW_F32 = ACH_HDW_F32 != 0;
+constexpr int HDW_WGS = HDW_F32 ? 1 : 2;
 struct HeadDwJob {
     const void* X; void* Y; long ldx, ldy;
     const float* Wdw;                 // [25][128] fp32 (both towers side by side)
@@ -32,9 +37,9 @@ struct HeadDwParams {
 };
 
 template <class T>          // (bf16_t; a template so that the two engine translation units can both include the header)
-__global__ __launch_bounds__(HDW_THREADS, 1) void headdw_kernel(const HeadDwParams p) {
+__global__ __launch_bounds__(HDW_THREADS, HDW_WGS) void headdw_kernel(const HeadDwParams p) {
     constexpr int C = HDW_C, SP = HDW_SP, KS = 5;
-    __shared__ float xin[HDW_MAXPOS * C];                       // 90 KB
+    __shared__ float xin[HDW_F32 ? HDW_MAXPOS * C : HDW_MAXPOS * C / 2];       // 90 KB (fp32) / 45 KB (bf16)
     __shared__ uint4 xs[HDW_MAXT * 2 * 64];                     // 20 KB: B fragments of the band's tiles
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int px = lane & 15, g = lane >> 4;
@@ -70,11 +75,15 @@ __global__ __launch_bounds__(HDW_THREADS, 1) void headdw_kernel(const HeadDwPara
                 const int it = it0 + u * HDW_THREADS;
                 if (it >= total) continue;
                 const int c8 = it % C8, pos = it / C8;
-                float v[8];
-                frag_unpack<T>(raw[u], v);
-                float* d = xin + pos * C + c8 * 8;
-                *reinterpret_cast<float4*>(d) = make_float4(v[0], v[1], v[2], v[3]);
-                *reinterpret_cast<float4*>(d + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                if (HDW_F32) {
+                    float v[8];
+                    frag_unpack<T>(raw[u], v);
+                    float* d = xin + pos * C + c8 * 8;
+                    *reinterpret_cast<float4*>(d) = make_float4(v[0], v[1], v[2], v[3]);
+                    *reinterpret_cast<float4*>(d + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                } else {
+                    reinterpret_cast<uint4*>(xin)[pos * C8 + c8] = raw[u];
+                }
             }
         }
     }
@@ -102,8 +111,14 @@ __global__ __launch_bounds__(HDW_THREADS, 1) void headdw_kernel(const HeadDwPara
                 ACH_UNROLL
                 for (int j = 0; j < SP + KS - 1; ++j) {
                     const int col = x0 + j < WCr ? x0 + j : WCr - 1;
-                    const float4 t = *reinterpret_cast<const float4*>(xin + ((r + ty) * WCr + col) * C + cg * 4);
-                    v[j][0] = f32x2{t.x, t.y}; v[j][1] = f32x2{t.z, t.w};
+                    if (HDW_F32) {
+                        const float4 t = *reinterpret_cast<const float4*>(xin + ((r + ty) * WCr + col) * C + cg * 4);
+                        v[j][0] = f32x2{t.x, t.y}; v[j][1] = f32x2{t.z, t.w};
+                    } else {
+                        const uint2 t = reinterpret_cast<const uint2*>(xin)[((r + ty) * WCr + col) * (C / 4) + cg];
+                        v[j][0] = f32x2{__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u)};
+                        v[j][1] = f32x2{__uint_as_float(t.y << 16), __uint_as_float(t.y & 0xffff0000u)};
+                    }
                 }
                 ACH_UNROLL
                 for (int tx = 0; tx < KS; ++tx) {

@@ -50,7 +50,9 @@ struct MlpBandGeom {
 };
 
 // PREF: the next hidden chunk's weight fragments are requested one chunk ahead (a second register set).
-template <int K1, int DT, int KS, int RB, int MAXW, bool XF32, bool PREF>
+// TILEPAR (the narrow blocks of the large maps: few hidden chunks, many tiles): a wave takes whole TILES (t = wave, wave + 8, ...) through
+// every hidden chunk instead of a share of the chunks for every tile — no partial sums, no reduction phase.
+template <int K1, int DT, int KS, int RB, int MAXW, bool XF32, bool PREF, bool TILEPAR = false>
 __global__ __launch_bounds__(MLPB_THREADS, 1) void mlp_band_kernel(const MlpBandParams bp) {
     using G = MlpBandGeom<K1, DT, KS, RB, MAXW, XF32>;
     typedef bf16_t T;
@@ -176,6 +178,62 @@ __global__ __launch_bounds__(MLPB_THREADS, 1) void mlp_band_kernel(const MlpBand
         }
     }
     __syncthreads();
+    if constexpr (TILEPAR) {
+        // ---- 3'. a wave's own tiles through all hidden chunks; + bias + residual straight from the accumulators
+        constexpr int NTW = (NT + MLPB_THREADS / 64 - 1) / (MLPB_THREADS / 64);
+        f32x4 acc[NTW][DT];
+        ACH_UNROLL
+        for (int k = 0; k < NTW; ++k) { ACH_UNROLL for (int d = 0; d < DT; ++d) { acc[k][d][0] = 0.f; acc[k][d][1] = 0.f; acc[k][d][2] = 0.f; acc[k][d][3] = 0.f; } }
+        uint4 xf[NTW][K1];
+        ACH_UNROLL
+        for (int k = 0; k < NTW; ++k) { const int t = wave + k * (MLPB_THREADS / 64); ACH_UNROLL for (int s = 0; s < K1; ++s) xf[k][s] = xs[((t < nt ? t : 0) * K1 + s) * 64 + lane]; }
+        const uint4* W1f = static_cast<const uint4*>(p.W1) + lane;
+        const uint4* W2f = static_cast<const uint4*>(p.W2) + lane;
+        if (wave < nt && !(bp.dbg & 8))
+        for (int j = 0; j < p.J; ++j) {
+            uint4 w1[K1][2], w2[DT];
+            const uint4* w1p = W1f + long(j) * K1 * 2 * 64;
+            ACH_UNROLL
+            for (int s = 0; s < K1; ++s) { w1[s][0] = w1p[(s * 2) * 64]; w1[s][1] = w1p[(s * 2 + 1) * 64]; }
+            ACH_UNROLL
+            for (int d = 0; d < DT; ++d) w2[d] = W2f[(long(j) * DT + d) * 64];
+            const f32x4 bA = *reinterpret_cast<const f32x4*>(p.b1 + j * 32 + g * 8), bB = *reinterpret_cast<const f32x4*>(p.b1 + j * 32 + g * 8 + 4);
+            ACH_UNROLL
+            for (int k = 0; k < NTW; ++k) {
+                f32x4 a0, a1;
+                a0[0] = a0[1] = a0[2] = a0[3] = 0.f;
+                a1[0] = a1[1] = a1[2] = a1[3] = 0.f;
+                ACH_UNROLL
+                for (int s = 0; s < K1; ++s) { mfma16<T>(w1[s][0], xf[k][s], a0); mfma16<T>(w1[s][1], xf[k][s], a1); }
+                float h[8];
+                ACH_UNROLL
+                for (int r = 0; r < 4; ++r) { h[r] = a0[r] + bA[r]; h[4 + r] = a1[r] + bB[r]; }
+                apply_act_n<T, 8, ACT_GELU>(h, ACT_GELU);
+                const uint4 hf = frag_pack<T>(h);
+                ACH_UNROLL
+                for (int d = 0; d < DT; ++d) mfma16<T>(w2[d], hf, acc[k][d]);
+            }
+        }
+        T* Yt = static_cast<T*>(p.Y) + long(b) * H * W * p.ldy;
+        const T* Rt = static_cast<const T*>(p.R) + long(b) * H * W * p.ldr;
+        ACH_UNROLL
+        for (int k = 0; k < NTW; ++k) {
+            const int t = wave + k * (MLPB_THREADS / 64), pix = t * 16 + px;
+            if (t >= nt || pix >= npx || (bp.dbg & 16)) continue;
+            const long m = long(y0) * W + pix;
+            ACH_UNROLL
+            for (int pair = 0; pair < DT / 2; ++pair) {
+                const int nb = pair * 32 + g * 8;
+                if (nb >= p.Cout) continue;
+                float r8[8], o[8];
+                Store<T>::ld8(Rt + m * p.ldr + nb, r8);
+                ACH_UNROLL
+                for (int r = 0; r < 4; ++r) { o[r] = acc[k][2 * pair][r] + p.b2[nb + r] + r8[r]; o[4 + r] = acc[k][2 * pair + 1][r] + p.b2[nb + 4 + r] + r8[4 + r]; }
+                Store<T>::st8(Yt + m * p.ldy + nb, o);
+            }
+        }
+        return;
+    }
     // ---- 3. hidden chunks: wave (cw, th) takes chunks cw, cw + 4, ... for the tiles of half th (tiles th, th + 2, ...): the next chunk's
     //         weight fragments are requested before the current chunk's tiles are computed
     constexpr int NTH = (NT + 1) / 2;
@@ -281,14 +339,14 @@ inline int mlp_band_shape(int k1, int DT, int ks, int W) {
     return 0;
 }
 inline bool mlp_band_supported(int k1, int DT, int ks, int H, int W) { return H >= 1 && mlp_band_shape(k1, DT, ks, W) != 0; }
-inline int mlp_band_rows(int k1, int DT, int ks, int H, int W) { const int sh = mlp_band_shape(k1, DT, ks, W), rb = sh == 3 ? 4 : (sh == 4 ? 2 : (sh == 5 ? 1 : 5)); return H >= rb ? rb : H; }
+inline int mlp_band_rows(int k1, int DT, int ks, int H, int W) { const int sh = mlp_band_shape(k1, DT, ks, W), rb = sh == 3 ? 4 : (sh == 4 ? 4 : (sh == 5 ? 4 : 5)); return H >= rb ? rb : H; }
 inline void launch_mlp_band(const MlpBandParams& bp, int shape, int B, hipStream_t stream) {
     const dim3 grid(unsigned(bp.bands) * unsigned(B)), block(MLPB_THREADS);
     if (shape == 1) ACH_LAUNCH((mlp_band_kernel<3, 6, 7, 5, 20, true, true>), grid, block, stream, bp);
     else if (shape == 2) ACH_LAUNCH((mlp_band_kernel<6, 12, 9, 5, 10, false, false>), grid, block, stream, bp);
     else if (shape == 3) ACH_LAUNCH((mlp_band_kernel<5, 10, 7, 4, 20, false, false>), grid, block, stream, bp);
-    else if (shape == 4) ACH_LAUNCH((mlp_band_kernel<2, 4, 5, 2, 40, true, true>), grid, block, stream, bp);
-    else ACH_LAUNCH((mlp_band_kernel<1, 2, 3, 1, 80, true, true>), grid, block, stream, bp);
+    else if (shape == 4) ACH_LAUNCH((mlp_band_kernel<2, 4, 5, 4, 40, true, false, true>), grid, block, stream, bp);
+    else ACH_LAUNCH((mlp_band_kernel<1, 2, 3, 4, 80, true, false, true>), grid, block, stream, bp);
 }
 
 }  // namespace ach

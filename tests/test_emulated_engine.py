@@ -513,7 +513,7 @@ def test_emulated_band_kernel_matches_the_tile_kernel(name, res, batch):
     orc = AchelousOracle(sd, **{k: kw[k] for k in ORACLE_KEYS})
     orc.forward(x, xr, xp)
     taps = {}
-    for band in (1, 0):
+    for band in (2, 1, 0):                  # 2: also the large maps of stages 0 / 1 (tile-parallel mode; off by default)
         from achelous_amd.engine import NativeEngine
         eng = NativeEngine(emu_library(), num_det=kw['num_det'], num_seg=kw['num_seg'], phi=kw['phi'], backbone=kw['backbone'], resolution=res,
                            pc_channels=kw['pc_channels'], pc_classes=kw['pc_classes'], num_points=16, nano_head=True, spp=True, dtype=DTYPE_BF16)
@@ -523,11 +523,12 @@ def test_emulated_band_kernel_matches_the_tile_kernel(name, res, batch):
         eng.plan(batch)
         o = alloc_outputs(kw, batch, 16, torch.bfloat16, 'cpu')
         eng.forward(x.bfloat16(), xr.bfloat16(), xp.bfloat16(), o)
-        taps[band] = {t: eng.read_tap(t) for t in eng.tap_names() if t.startswith('backbone.s2.') or t.startswith('backbone.s3.') or t in ('map4', 'map5')}
+        taps[band] = {t: eng.read_tap(t) for t in eng.tap_names() if t.startswith('backbone.s') or t in ('map2', 'map3', 'map4', 'map5')}
     assert len(taps[1]) >= 7
-    for t in taps[1]:
-        assert rel_err(taps[1][t], taps[0][t]) < 1.5e-2, (t, rel_err(taps[1][t], taps[0][t]))     # same arithmetic, different summation order, bf16 storage
-        assert rel_err(taps[1][t], orc.taps[t]) < 4e-2, (t, rel_err(taps[1][t], orc.taps[t]))
+    for band in (2, 1):
+        for t in taps[band]:
+            assert rel_err(taps[band][t], taps[0][t]) < 2.5e-2, (band, t, rel_err(taps[band][t], taps[0][t]))     # same arithmetic, different summation order, bf16 storage (two bf16 plans, up to 20 blocks deep)
+            assert rel_err(taps[band][t], orc.taps[t]) < 4e-2, (band, t, rel_err(taps[band][t], orc.taps[t]))
 
 
 @pytest.mark.parametrize('res,batch', [(96, 2), (320, 1), (416, 1)])
