@@ -80,6 +80,7 @@ public:
     bool dw_even = true;              // option "dw_even": SPLIT mlp_kernel deals depthwise tap ROWS, not whole k-steps, to its four waves (k_mlp.h)
     int radar_rows4 = 2;              // option "radar_rows4": a workgroup of rc_front owns four rows, one per wave (1: block 0 when radar_skip is on; 2: every
                                       // fused block — 29.1 k against 27.7 k frames/s: the per-workgroup weight staging and tables were a fifth of these kernels)
+    bool radar_compact = true;        // option "radar_compact": first RCBlock — the active PIXELS of a row are compacted into dense tiles (k_conv3.h; needs radar_skip and four-row workgroups)
     bool radar_skip = true;           // option "radar_skip": first RCBlock — closed-form shortcut on 16-pixel segments whose neighbourhood of the radar map is empty (k_conv3.h)
     int head_rows = 2;            // option "head_rows": bf16 — fused last decoder level + head as the row-walking kernel (k_dechead.h: no LDS, DPP row shifts, head 1x1 on MFMA); 0 = the LDS tile kernel (k_nhwc.h)
     bool level_rows = false;          // option "level_rows": the other two decoder levels through upghost_rows_kernel too (k_dechead.h).  OFF: their 32- / 48-channel NHWC rows are

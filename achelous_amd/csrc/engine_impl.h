@@ -1304,7 +1304,7 @@ public:
                 const long yld = y_bordered ? yb.ld : y.ld;
                 RcFrontParams rp{pooled.p0, pooled.ld, pooled.row, pooled.img, pkom.w, up_f32(b32), pkf.w, up_f32(b16), x.p, x.ld,
                                  y_bordered ? yb.p0 : y.p, yld, y_bordered ? yb.row : long(x.W) * y.ld, y_bordered ? yb.img : long(x.H) * x.W * y.ld,
-                                 B, x.H, x.W, cvp, C, occ, occ_r, (((occ && radar_rows4 == 1) || radar_rows4 == 2) && x.H % 4 == 0) ? 1 : 0};
+                                 B, x.H, x.W, cvp, C, occ, occ_r, radar_compact ? 1 : 0, (((occ && radar_rows4 == 1) || radar_rows4 == 2) && x.H % 4 == 0) ? 1 : 0};
                 // algorithmic bytes: pooled map + residual read once, output written once, REAL channels; the layout figure
                 // counts the pixel pitches the kernel actually moves
                 const double bytes = double(x.rows()) * 3.0 * C * sizeof(T), lbytes = double(x.rows()) * (pooled.ld + x.ld + yld) * sizeof(T);

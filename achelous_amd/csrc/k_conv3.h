@@ -156,6 +156,7 @@ struct RcFrontParams {
     void* Y; long ldy, ypr, ypi;              // output: pixel (0,0) of sample 0 and row / image pitches (dense or zero-bordered)
     int B, H, Wd, cv, C;
     const unsigned short* occ; int occ_r;     // optional occupancy of P per 16-pixel row segment [B][H][Wd/16], one bit per column (avgpool3x3), and the reach of a pixel, see below
+    int compact;                              // 1 (with occ, rows4, <= 4 output channels): the row's ACTIVE PIXELS are compacted into dense 16-pixel tiles (round 3)
     int rows4;                                // 1: a workgroup owns FOUR consecutive rows, one per wave (H % 4 == 0): the weight staging and the tables are paid once per four rows
 };
 
@@ -225,9 +226,11 @@ __global__ __launch_bounds__(256, KS == 3 ? 4 : 1) void rc_front_kernel(const Rc
     const int ntiles = (p.Wd + 15) / 16;
     // the conv inputs of the NEXT tile are fetched while the current tile is being sampled (one memory round trip hidden)
     uint4 xf[KS];
+    const unsigned short* plist_w = nullptr;                        // compact mode (below): x of the tile's pixels comes from the wave's list
+    int plist_n = 0;
     auto fetch = [&](int tile) {
         const int xr = tile * 16 + px;
-        const int x = xr < p.Wd ? xr : p.Wd - 1;
+        const int x = plist_w ? int(plist_w[xr < plist_n ? xr : plist_n - 1]) : (xr < p.Wd ? xr : p.Wd - 1);
         const T* xp = xrow + long(x) * ldp;
         ACH_UNROLL
         for (int s = 0; s < KS; ++s) {
@@ -251,6 +254,40 @@ __global__ __launch_bounds__(256, KS == 3 ? 4 : 1) void rc_front_kernel(const Rc
         const unsigned to_left = unsigned(wave_ballot64((cols & ((1u << p.occ_r) - 1u)) != 0));     // its first occ_r columns reach segment t - 1
         active = own | (to_right << 1) | (to_left >> 1);
     }
+    // Round 3: per-PIXEL activity.  Segment flags leave 36 % of the segments of the bench's maps (256 cells per frame) active, but only ~20 % of the
+    // pixels have an occupied column within occ_r of them: the row's active pixels are compacted into dense tiles (their x positions in a per-wave LDS
+    // list: every lane of the full path already addresses its own pixel), everything else takes the closed form, 64 pixels per wave pass.
+    __shared__ unsigned short plist[4][NARROW ? 512 + 16 : 1];
+    __shared__ unsigned short amask[4][NARROW ? 32 : 1];
+    const bool compact = NARROW && p.compact && p.occ && p.rows4 && p.ldy <= 4 && p.Wd <= 512;
+    int ntot = 0;
+    if (compact) {
+        if constexpr (NARROW) {
+        // this lane's segment: columns occupied within occ_r rows (cols), dilated by occ_r columns with the neighbours' masks
+        unsigned cols = 0;
+        if (lane < ntiles) {
+            const unsigned short* f = p.occ + long(b) * p.H * ntiles + lane;
+#pragma unroll 8
+            for (int dy = -p.occ_r; dy <= p.occ_r; ++dy) {
+                const int y = oy + dy < 0 ? 0 : (oy + dy > p.H - 1 ? p.H - 1 : oy + dy);
+                cols |= f[y * ntiles];
+            }
+        }
+        const unsigned lc = unsigned(__shfl(int(cols), lane > 0 ? lane - 1 : 0)), rc = unsigned(__shfl(int(cols), lane < 63 ? lane + 1 : 63));
+        const unsigned long long wide = (unsigned long long)(lane > 0 ? lc : 0u) | ((unsigned long long)cols << 16) | ((unsigned long long)(lane + 1 < ntiles ? rc : 0u) << 32);
+        unsigned long long dil = wide;
+        for (int d = 1; d <= p.occ_r; ++d) dil |= (wide << d) | (wide >> d);
+        unsigned act16 = lane < ntiles ? unsigned(dil >> 16) & 0xffffu : 0u;
+        const int lim = p.Wd - lane * 16;                                  // columns of this segment inside the map
+        if (lim < 16) act16 &= lim > 0 ? ((1u << lim) - 1u) : 0u;
+        const int cnt = __popcll(static_cast<unsigned long long>(act16));
+        int base = 0;
+        for (int l = 0; l < ntiles; ++l) { const int c = __shfl(cnt, l); if (l < lane) base += c; ntot += c; }
+        if (lane < 32) amask[wave][lane] = static_cast<unsigned short>(act16);
+        for (unsigned m = act16; m; m &= m - 1u) plist[wave][base++] = static_cast<unsigned short>(lane * 16 + (__ffsll(static_cast<long long>(m)) - 1));
+        wave_sync();
+        }
+    }
     const int ch = g * 4;
     auto finish = [&](int x, bool valid, const f32x4& acc) {        // bias, ReLU, residual, one store
         if (valid && ch < int(p.ldy)) {
@@ -261,10 +298,33 @@ __global__ __launch_bounds__(256, KS == 3 ? 4 : 1) void rc_front_kernel(const Rc
             Store<T>::st4(static_cast<T*>(p.Y) + long(b) * p.ypi + long(oy) * p.ypr + long(x) * p.ldy + ch, ov);
         }
     };
+    if (compact) {
+        if constexpr (NARROW) {
+        // empty pixels: relu(bias) + residual, one pixel per lane and pass (all four output channels are lane group 0's: ldy <= 4)
+        float b0[4];
+        ACH_UNROLL
+        for (int i = 0; i < 4; ++i) b0[i] = p.bf[i];
+        for (int xx = lane; xx < p.Wd; xx += 64) {
+            if ((amask[wave][xx >> 4] >> (xx & 15)) & 1) continue;
+            float rr[4], ov[4];
+            Store<T>::ld4(static_cast<const T*>(p.R) + (rowpix + xx) * p.ldr, rr);
+            ACH_UNROLL
+            for (int i = 0; i < 4; ++i) { const float r = 0.f + b0[i]; ov[i] = (r > 0.f ? r : 0.f) + rr[i]; }
+            Store<T>::st4(static_cast<T*>(p.Y) + long(b) * p.ypi + long(oy) * p.ypr + long(xx) * p.ldy, ov);
+        }
+        }
+    }
     // Segments are dealt to the four waves by RANK among the active (and among the empty) ones, not by position: occupied cells come
     // in clusters, and position-strided waves would leave one wave with a row's whole cluster.
     const unsigned tmask = ntiles >= 32 ? 0xffffffffu : ((1u << ntiles) - 1u);
     unsigned rem = active & tmask;
+    if (compact) {
+        if constexpr (NARROW) {
+        const int ctiles = (ntot + 15) / 16;                       // <= 32 (Wd <= 512)
+        rem = ctiles >= 32 ? 0xffffffffu : ((1u << ctiles) - 1u);
+        plist_w = &plist[wave][0]; plist_n = ntot;
+        }
+    }
     int rank = 0;
     auto take = [&]() -> int {                                      // this wave's next segment of `rem` (consumed), or -1
         while (rem) {
@@ -276,7 +336,7 @@ __global__ __launch_bounds__(256, KS == 3 ? 4 : 1) void rc_front_kernel(const Rc
     };
     int tile = take();
     if (tile >= 0) fetch(tile);
-    if (p.occ) {                                                    // empty neighbourhoods: the full path would accumulate +0
+    if (p.occ && !compact) {                                        // empty neighbourhoods: the full path would accumulate +0
         unsigned rem_e = ~active & tmask;
         int rank_e = 0;
         while (rem_e) {
@@ -292,8 +352,8 @@ __global__ __launch_bounds__(256, KS == 3 ? 4 : 1) void rc_front_kernel(const Rc
     while (tile >= 0) {
         const int next = take();
         const int xr = tile * 16 + px;
-        const bool valid = xr < p.Wd;
-        const int x = valid ? xr : p.Wd - 1;
+        const bool valid = plist_w ? xr < plist_n : xr < p.Wd;
+        const int x = plist_w ? int(plist_w[valid ? xr : plist_n - 1]) : (valid ? xr : p.Wd - 1);
         {   // 1. offsets + modulator logits of the tile
             f32x4 a0, a1;
             a0[0] = a0[1] = a0[2] = a0[3] = 0.f;

@@ -375,7 +375,8 @@ def test_emulated_mfma_bilinear_head_agrees_with_the_per_position_kernel(res, ba
 @pytest.mark.parametrize('cells', [0, 2, 40, -1])
 def test_emulated_radar_skip_is_bit_identical(dtype, cells):
     """First RCBlock: segments of 16 pixels whose neighbourhood of the pooled radar map is empty take the closed-form shortcut
-    relu(bias) + residual (k_conv3.h, option radar_skip).  The full path on such a segment accumulates +0, so both plans must agree BIT FOR
+    relu(bias) + residual (k_conv3.h, option radar_skip; with radar_compact the decision is taken per PIXEL and the active pixels of a row are
+    compacted into dense tiles).  The full path on such a segment / pixel accumulates +0, so all plans must agree BIT FOR
     BIT — on an empty map (every segment skipped), a sparse one, the fixtures' density and a dense map (cells = -1: nothing skipped)."""
     from achelous_amd.engine import NativeEngine
     kw, sd, _ = _setup('en_s0', 96, 2, 16)
@@ -384,12 +385,13 @@ def test_emulated_radar_skip_is_bit_identical(dtype, cells):
         xr = torch.zeros_like(xr)
     td = torch.float32 if dtype == DTYPE_F32 else torch.bfloat16
     outs = []
-    for v in (1, 0, 2):
+    for v in (1, 0, 2, 3):
         eng = NativeEngine(emu_library(), num_det=kw['num_det'], num_seg=kw['num_seg'], phi=kw['phi'], backbone=kw['backbone'],
                            resolution=kw['resolution'], pc_channels=kw['pc_channels'], pc_classes=kw['pc_classes'],
                            num_points=16, nano_head=kw['nano_head'], spp=kw['spp'], dtype=dtype)
         eng.set_option('radar_skip', 1 if v else 0)
-        eng.set_option('radar_rows4', 2 if v == 2 else 0)              # v = 2: four rows per workgroup as well
+        eng.set_option('radar_rows4', 2 if v >= 2 else 0)              # v >= 2: four rows per workgroup as well
+        eng.set_option('radar_compact', 0 if v == 3 else 1)           # v = 2: the row's active PIXELS compacted into dense tiles (bf16, round 3); v = 3: whole active segments
         eng.set_option('full_taps', 1)
         eng.load_state_dict(sd)
         eng.plan(2)
