@@ -184,7 +184,7 @@ void EngineBase::run_eager(hipStream_t s) {
         if (multi && op.wait_ev >= 0) (void)hipStreamWaitEvent(st, ev_join[op.wait_ev], 0);
         if (multi && op.wait_ev2 >= 0) (void)hipStreamWaitEvent(st, ev_join[op.wait_ev2], 0);
         if (piped && op.xwait && issued > 0) (void)hipStreamWaitEvent(st, ev_x[par ^ 1], 0);
-        if (piped && op.xwait2 && issued > 0 && x2_recorded[par ^ 1]) (void)hipStreamWaitEvent(st, ev_x2[par ^ 1], 0);
+        if (piped && (dbg_xwait2_op >= 0 ? int(i) == dbg_xwait2_op : op.xwait2) && issued > 0 && x2_recorded[par ^ 1]) (void)hipStreamWaitEvent(st, ev_x2[par ^ 1], 0);
         for (auto& pr : probes) if (int(i) == pr.first) (void)hipEventRecord(pr.ev0[size_t(pr.count % kProbeEvents)], st);
         op.fn(st);
         for (auto& pr : probes) if (int(i) == pr.last) { (void)hipEventRecord(pr.ev1[size_t(pr.count % kProbeEvents)], st); ++pr.count; }

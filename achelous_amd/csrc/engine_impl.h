@@ -463,7 +463,9 @@ public:
         const double bytes = double(mp.M) * C * sizeof(T) * (xin.p == resid.p ? 2.0 : 3.0);
         const double flops = 4.0 * double(mp.M) * C * hidden + (dw_ks ? 2.0 * double(mp.M) * C * dw_ks * dw_ks : 0.0);
         // small maps, bf16: a band of rows per workgroup — taps from an LDS halo tile, MLP weights fetched once per band (k_mlpband.h)
-        if (mlp_band && (split || mlp_band > 1) && dw_ks && act == ACT_GELU && xin.p == resid.p && std::is_same<T, bf16_t>::value && mlp_band_supported(k1, DT, dw_ks, xin.H, xin.W)) {
+        // (if constexpr: kernels that only the bf16 engine launches must not be instantiated by the fp32 engine's translation unit as well —
+        //  the two code objects would carry the same symbol and the runtime registers one of them for the shared host stub)
+        if constexpr (std::is_same<T, bf16_t>::value) if (mlp_band && (split || mlp_band > 1) && dw_ks && act == ACT_GELU && xin.p == resid.p && mlp_band_supported(k1, DT, dw_ks, xin.H, xin.W)) {
             MlpBandParams bp;
             bp.m = mp; bp.rb = mlp_band_rows(k1, DT, dw_ks, xin.H, xin.W); bp.bands = cdiv(xin.H, bp.rb); bp.dbg = mlp_band_dbg;
             const int nb = xin.B, shape = mlp_band_shape(k1, DT, dw_ks, xin.W);
@@ -634,6 +636,7 @@ public:
                 A y = alloc(x.B, x.H / 2, x.W / 2, Co);
                 GemmOpt o; o.conv_k = 2; o.conv_s = 2; o.conv_p = 0; o.Hin = x.H; o.Win = x.W; o.Cin = Ci; o.Ho = x.H / 2; o.Wo = x.W / 2;
                 gemm(d + ".1", t.p, t.ld, y.rows(), pack(l), y.p, y.ld, o);
+                tap("backbone.ds" + std::to_string(i) + ".ln", t); tap("backbone.ds" + std::to_string(i), y);
                 x = y;
             }
             for (int j = 0; j < ec.depths[i]; ++j) {
@@ -912,7 +915,7 @@ public:
         UpGhostParams p{t.p, t.ld, y.p, y.ld, up_f32(wt), up_f32(sh), x.B, x.H, x.W, Cg};
         const dim3 grid(unsigned(cdiv(2 * x.W, UPG_TS)) * unsigned(cdiv(2 * x.H, UPG_TS)) * unsigned(x.B)), block(unsigned(16 * Cg));
         const double bytes = double(t.rows()) * Cg * sizeof(T) + double(y.rows()) * cout * sizeof(T);
-        if (level_rows && std::is_same<T, bf16_t>::value && (Cg == 16 || Cg == 24 || Cg == 32) && t.ld % 2 == 0 && y.ld % 2 == 0 &&
+        if constexpr (std::is_same<T, bf16_t>::value) if (level_rows && (Cg == 16 || Cg == 24 || Cg == 32) && t.ld % 2 == 0 && y.ld % 2 == 0 &&
             double(y.rows()) * y.ld * sizeof(T) < 2147483648.0) {
             // row-walking form (k_dechead.h; option level_rows, OFF: measured slower than the LDS tile on these write-bound levels — 34 / 60 us against 25 / 48)
             const int H2 = 2 * x.H, band = std::max(8, std::min(head_band, H2));
@@ -976,7 +979,7 @@ public:
                             up_f32(wh2), up_f32(bh2), x.B, x.H, x.W, init, nch, oup,
                             x.H > 0 ? float(x.H - 1) / float(2 * x.H - 1) : 0.f, x.W > 0 ? float(x.W - 1) / float(2 * x.W - 1) : 0.f};
         const double bytes = double(t.rows()) * Cg * sizeof(T) + 4.0 * double(t.rows()) * oup * sizeof(T);
-        if (head_rows && !planar && std::is_same<T, bf16_t>::value && t.ld % 4 == 0 && double(t.rows()) * t.ld * 4.0 * oup < 2147483648.0) {
+        if constexpr (std::is_same<T, bf16_t>::value) if (head_rows && !planar && t.ld % 4 == 0 && double(t.rows()) * t.ld * 4.0 * oup < 2147483648.0) {
             // row-walking kernel (k_dechead.h): head 1x1 as the A fragment of v_mfma_f32_16x16x32_bf16 — D row 4g + r = head channel g + 4r,
             // k = 8g + j = channel 4g + j of x1 (j < 4) or of x2 (j >= 4) — biases and the head's depthwise filters indexed by head channel
             std::vector<uint16_t> af(size_t(64) * 8, 0);
@@ -995,7 +998,8 @@ public:
                              up_f32(bh8), up_f32(wd8), up_f32(bd8), x.B, x.H, x.W, init, nch, oup, p.sy, p.sx, band, cdiv(H2, band), cdiv(2 * x.W, DH_VALID)};
             const bool two = head_rows >= 2;              // two columns per lane: strips of 28 valid columns
             if (two) dp.strips = cdiv(2 * x.W, DH2_VALID);
-            const dim3 grid(unsigned(dp.strips) * unsigned(dp.bands) * unsigned(x.B)), block(64);
+            const int wgw = two ? ACH_DH_WG_WAVES : 1;
+            const dim3 grid(unsigned(cdiv(dp.strips * dp.bands * x.B, wgw))), block(unsigned(64 * wgw));
             // per-output-row interpolation geometry, in the float arithmetic of the tile kernel / torch (k_dechead.h)
             std::vector<DecHeadRow> rg(static_cast<size_t>(H2) + 4);
             for (int i = 0; i < H2 + 4; ++i) {

@@ -40,12 +40,21 @@ constexpr int DH_VALID = 12;                  // output columns per 16-lane stri
 #ifndef ACH_DH_WAVES
 #define ACH_DH_WAVES 3
 #endif
-constexpr int DH_WAVES = ACH_DH_WAVES;        // register budget: waves per SIMD the compiler must fit
+constexpr int DH_WAVES = ACH_DH_WAVES;
+#ifndef ACH_DH_WG_WAVES
+#define ACH_DH_WG_WAVES 1          // waves (independent strips) per workgroup of the two-column kernel
+#endif
+#ifndef ACH_DH_MFMA32
+#define ACH_DH_MFMA32 0            // 1: one v_mfma_f32_16x16x32_bf16 per column (see dh_mfma)
+#endif        // register budget: waves per SIMD the compiler must fit
 
 // a + (value of the lane one column to the left / right inside the 16-lane row; 0 at the row's ends): ONE VALU instruction each
 // (v_add_f32 with a DPP row shift on its first source).  The depthwise 3x3 taps are arranged so that only the three per-column partial
 // sums of a row are shifted — two shifted adds per channel instead of six shifted operands.
-#if defined(ACH_HOSTEMU)
+#if !defined(ACH_HOSTEMU) && defined(ACH_DH_NO_ASM)
+__device__ __forceinline__ float add_from_left(float a, float v) { return a + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true)); }
+__device__ __forceinline__ float add_from_right(float a, float v) { return a + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x101, 0xf, 0xf, true)); }
+#elif defined(ACH_HOSTEMU)
 __device__ inline float add_from_left(float a, float v) { const int l = int(threadIdx.x) & 63; const float o = __shfl(v, (l & 15) ? l - 1 : l); return a + ((l & 15) ? o : 0.f); }
 __device__ inline float add_from_right(float a, float v) { const int l = int(threadIdx.x) & 63; const float o = __shfl(v, (l & 15) != 15 ? l + 1 : l); return a + ((l & 15) != 15 ? o : 0.f); }
 #else
@@ -71,7 +80,7 @@ struct DecHeadRow { int y0; float ly; };
 
 // four channels at once: o[q] = (c[q] + left neighbour's l[q]) + right neighbour's r[q] — ONE leading s_nop covers all eight DPP reads
 // (every l / r is written before the statement starts; the chained second add reads the first one's result as a plain operand)
-#if defined(ACH_HOSTEMU)
+#if defined(ACH_HOSTEMU) || defined(ACH_DH_NO_ASM)
 __device__ inline void combine4(const float (&c)[4], const float (&l)[4], const float (&r)[4], float (&o)[4]) {
     for (int q = 0; q < 4; ++q) o[q] = add_from_right(add_from_left(c[q], l[q]), r[q]);
 }
@@ -91,8 +100,28 @@ __device__ __forceinline__ void combine4(const float (&c)[4], const float (&l)[4
 }
 #endif
 
-// max(v, 0) of a value that comes out of inline assembly: one v_max_f32 (the compiler would first canonicalise a value it cannot see into)
+// The head's 1x1 on the matrix cores: D += A (16 x 32, packed once by the host) * B (this lane's 8 channels of 16 pixels), as TWO
+// v_mfma_f32_16x16x16_bf16 (k = 0..15: the x1 half of the lane's channels, k = 16..31: the x2 half), not one v_mfma_f32_16x16x32_bf16.
+// Measured on the MI355X (round 3, tests/test_gpu_parity.py::test_pipelined_submit_wait_equals_plain_calls): with the 16x16x32 form in
+// these long-lived, > 128-VGPR waves, waves of OTHER kernels that shared a SIMD with them (the next forward's backbone on the caller's
+// stream, in pipelined mode) came out a few bf16 ulps off in whole 16-pixel tiles, run to run; with the register budget forced to 128
+// or with the two 16x16x16 instructions the difference is gone (0 of 60 forwards against 3 of 4).  DESIGN.md 4.14 has the experiments.
 #if defined(ACH_HOSTEMU)
+__device__ inline void dh_mfma(const uint4& a, const uint4& b, f32x4& c) { mfma16<bf16_t>(a, b, c); }
+#else
+__device__ __forceinline__ void dh_mfma(const uint4& a, const uint4& b, f32x4& c) {
+#if ACH_DH_MFMA32
+    mfma16<bf16_t>(a, b, c);
+#else
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, make_uint2(a.x, a.y)), __builtin_bit_cast(s16x4, make_uint2(b.x, b.y)), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, make_uint2(a.z, a.w)), __builtin_bit_cast(s16x4, make_uint2(b.z, b.w)), c, 0, 0, 0);
+#endif
+}
+#endif
+
+// max(v, 0) of a value that comes out of inline assembly: one v_max_f32 (the compiler would first canonicalise a value it cannot see into)
+#if defined(ACH_HOSTEMU) || defined(ACH_DH_NO_ASM)
 __device__ inline float relu_raw(float v) { return v > 0.f ? v : 0.f; }
 #else
 __device__ __forceinline__ float relu_raw(float v) { float r; asm("v_max_f32_e32 %0, 0, %1" : "=v"(r) : "v"(v)); return r; }
@@ -224,7 +253,7 @@ __global__ __launch_bounds__(64, DH_WAVES) void dechead_rows_kernel(const DecHea
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             if (!(DBG & 4)) {
                 const uint4 bfrag = make_uint4(pack_bf16x2(xc[0][0], xc[0][1]), pack_bf16x2(xc[1][0], xc[1][1]), pack_bf16x2(x2[0][0], x2[0][1]), pack_bf16x2(x2[1][0], x2[1][1]));
-                mfma16<bf16_t>(afrag, bfrag, acc);
+                dh_mfma(afrag, bfrag, acc);
             }
             ACH_UNROLL
             for (int r = 0; r < 2; ++r) { const float v = acc[r] + bhv[r]; hp[r] = (row_in && has_h[r] && v > 0.f) ? v : 0.f; }
@@ -267,7 +296,7 @@ constexpr int DH2_VALID = 28;
 #endif
 
 // four values: o[q] = c[q] + (left neighbour lane's l[q]);  and  o[q] = c[q] + (right neighbour lane's r[q]) — one s_nop per group
-#if defined(ACH_HOSTEMU)
+#if defined(ACH_HOSTEMU) || defined(ACH_DH_NO_ASM)
 __device__ inline void add4_from_left(const float (&c)[4], const float (&l)[4], float (&o)[4]) { for (int q = 0; q < 4; ++q) o[q] = add_from_left(c[q], l[q]); }
 __device__ inline void add4_from_right(const float (&c)[4], const float (&r)[4], float (&o)[4]) { for (int q = 0; q < 4; ++q) o[q] = add_from_right(c[q], r[q]); }
 #else
@@ -292,9 +321,10 @@ __device__ __forceinline__ void add4_from_right(const float (&c)[4], const float
 #endif
 
 template <bool DW2, bool TAP>
-__global__ __launch_bounds__(64, ACH_DH2_WAVES) void dechead_rows2_kernel(const DecHeadParams p, const DecHeadRow* __restrict__ rows) {
+__global__ __launch_bounds__(64 * ACH_DH_WG_WAVES, ACH_DH2_WAVES) void dechead_rows2_kernel(const DecHeadParams p, const DecHeadRow* __restrict__ rows) {
     const int H = 2 * p.h, Wd = 2 * p.w;
-    const unsigned u = xcd_block(blockIdx.x, gridDim.x);
+    const unsigned u = xcd_block(blockIdx.x, gridDim.x) * ACH_DH_WG_WAVES + unsigned(wave_uniform(int(threadIdx.x) >> 6));
+    if (u >= unsigned(p.strips) * unsigned(p.bands) * unsigned(p.B)) return;
     const int strip = int(u % unsigned(p.strips)), band = int((u / unsigned(p.strips)) % unsigned(p.bands));
     const long b = long(u / (unsigned(p.strips) * unsigned(p.bands)));
     const int lane = int(threadIdx.x) & 63, n = lane & 15, g = lane >> 4;
@@ -430,8 +460,8 @@ __global__ __launch_bounds__(64, ACH_DH2_WAVES) void dechead_rows2_kernel(const 
             {
                 const uint4 fa = make_uint4(pack_bf16x2(xc[0][0][0], xc[0][0][1]), pack_bf16x2(xc[0][1][0], xc[0][1][1]), pack_bf16x2(x2a[0], x2a[1]), pack_bf16x2(x2a[2], x2a[3]));
                 const uint4 fb = make_uint4(pack_bf16x2(xc[1][0][0], xc[1][0][1]), pack_bf16x2(xc[1][1][0], xc[1][1][1]), pack_bf16x2(x2b[0], x2b[1]), pack_bf16x2(x2b[2], x2b[3]));
-                mfma16<bf16_t>(afrag, fa, acca);
-                mfma16<bf16_t>(afrag, fb, accb);
+                dh_mfma(afrag, fa, acca);
+                dh_mfma(afrag, fb, accb);
             }
             ACH_UNROLL
             for (int r = 0; r < 2; ++r) {
