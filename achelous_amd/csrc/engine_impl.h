@@ -8,6 +8,7 @@
 #include <cstring>
 
 #include "k_dechead.h"
+#include "k_upchain.h"
 #include "k_detect.h"
 #include "k_conv3.h"
 #include "k_gemm.h"
@@ -475,16 +476,10 @@ public:
         add_op(name, [mp, DT, split](hipStream_t s) { launch_mlp<T>(mp, DT, split, s); }, bytes, flops);
         return true;
     }
-    // y = l2(act(l1(x))) as one launch (k_mlp.h without LayerNorm / residual); false when the widths are not instantiated
-    bool chain2(const std::string& name, const A& x, const Lin& l1, int act, const Lin& l2, A& y, bool* planar = nullptr) {
-        if (!fuse_mlp) return false;
-        const int Cin = x.C, hidden = l1.N, Cout = l2.N;
+    // packed weights of a two-layer 1x1 chain (mlp_kernel's layouts with DT output tiles) into `mp`
+    void chain_weights(MlpParams& mp, int Cin, int DT, const Lin& l1, int act, const Lin& l2) {
+        const int hidden = l1.N, Cout = l2.N;
         const int k1 = cdiv(Cin, KC), J = cdiv(hidden, 32), hstep = 8 / VEC, ks2 = J * hstep;
-        const bool split = mlp_split < 0 ? x.H * x.W <= 1024 : mlp_split != 0;
-        // narrow layers on maps that are not latency-bound: every weight fragment in registers, several tiles per wave (chain_kernel)
-        const bool small = Cout <= 32 && k1 <= 3 && J <= 2 && !split;
-        const int DT = small ? 2 : mlp_pick_dt(std::max(Cin, Cout));
-        if (DT == 0 || l1.K != Cin || l2.K != hidden) return false;
         std::vector<float> w1(size_t(J) * k1 * 2 * 64 * VEC, 0.f), b1(size_t(J) * 32, 0.f);
         std::vector<float> w2(size_t(ks2) * DT * 64 * VEC, 0.f), b2(size_t(DT) * 16, 0.f);
         if (!measuring) {
@@ -500,12 +495,25 @@ public:
                 }
             }
         }
+        mp.W1 = up_T(w1); mp.b1 = up_f32(b1); mp.W2 = up_T(w2); mp.b2 = up_f32(b2);
+        mp.C = Cin; mp.k1 = k1; mp.J = J; mp.act = act; mp.ln = 0; mp.Cout = Cout;
+    }
+    // y = l2(act(l1(x))) as one launch (k_mlp.h without LayerNorm / residual); false when the widths are not instantiated
+    bool chain2(const std::string& name, const A& x, const Lin& l1, int act, const Lin& l2, A& y, bool* planar = nullptr) {
+        if (!fuse_mlp) return false;
+        const int Cin = x.C, hidden = l1.N, Cout = l2.N;
+        const int k1 = cdiv(Cin, KC), J = cdiv(hidden, 32);
+        const bool split = mlp_split < 0 ? x.H * x.W <= 1024 : mlp_split != 0;
+        // narrow layers on maps that are not latency-bound: every weight fragment in registers, several tiles per wave (chain_kernel)
+        const bool small = Cout <= 32 && k1 <= 3 && J <= 2 && !split;
+        const int DT = small ? 2 : mlp_pick_dt(std::max(Cin, Cout));
+        if (DT == 0 || l1.K != Cin || l2.K != hidden) return false;
         y = alloc(x.B, x.H, x.W, Cout);
         MlpParams mp;
         std::memset(&mp, 0, sizeof(mp));
         mp.X = x.p; mp.ldx = x.ld; mp.Y = y.p; mp.ldy = y.ld;
-        mp.W1 = up_T(w1); mp.b1 = up_f32(b1); mp.W2 = up_T(w2); mp.b2 = up_f32(b2);
-        mp.M = x.rows(); mp.C = Cin; mp.k1 = k1; mp.J = J; mp.act = act; mp.ln = 0; mp.Cout = Cout;
+        chain_weights(mp, Cin, DT, l1, act, l2);
+        mp.M = x.rows();
         if (planar) {                            // channel-planar rows for the MFMA bilinear phase of the fused last decoder level
             *planar = *planar && small && Cout == 16;
             if (*planar) mp.planar_w = x.W;
@@ -895,7 +903,8 @@ public:
     }
     // one decoder level: Upsample (1x1+BN+ReLU, bilinear x2) + GhostModule, restructured (see upghost_kernel):
     // both 1x1 convs at low resolution on MFMA, then one fused full-resolution kernel.
-    A decoder_level(const std::string& up_pfx, const std::string& ghost_pfx, const A& x, int cout) {
+    // the level's two 1x1 convs at LOW resolution (they commute with the bilinear interpolation): t = Wp relu(Wu x + bu) + bp
+    A decoder_pair(const std::string& up_pfx, const std::string& ghost_pfx, const A& x, int cout) {
         Lin lu = conv_bn(up_pfx + ".upsample.0.conv", up_pfx + ".upsample.0.bn", 1e-3);
         Lin lp = conv_bn(ghost_pfx + ".primary_conv.0", ghost_pfx + ".primary_conv.1", 1e-5);
         const int Cg = lp.N;
@@ -907,6 +916,44 @@ public:
             t = alloc(x.B, x.H, x.W, Cg);
             gemm(ghost_pfx + ".primary_lowres", u, pack(lp), t);
         }
+        return t;
+    }
+    // can this level's full-resolution kernel also apply the NEXT level's conv pair (k_upchain.h)?  bf16 production plans only: the level's
+    // output y is a tap of the parity plans
+    bool level_chains(const std::string& ghost_pfx, const std::string& next_up, const std::string& next_ghost) const {
+        if (!level_chain || full_taps || !fuse_mlp || !std::is_same<T, bf16_t>::value) return false;
+        const int Cg = int(W(ghost_pfx + ".primary_conv.0.weight").shape[0]);
+        const HostTensor& wu = W(next_up + ".upsample.0.conv.weight");
+        const HostTensor& wp = W(next_ghost + ".primary_conv.0.weight");
+        return (Cg == 16 || Cg == 24 || Cg == 32) && wu.shape[0] == 32 && wu.shape[1] == 2 * Cg && wp.shape[0] == 16 && wp.shape[1] == 32;
+    }
+    // full-resolution part of a level on t (low resolution, Cg channels) + the next level's pair: returns the next level's t
+    A decoder_level_chained(const std::string& ghost_pfx, const A& t, const std::string& next_up, const std::string& next_ghost) {
+        const int Cg = t.C;
+        Lin lu = conv_bn(next_up + ".upsample.0.conv", next_up + ".upsample.0.bn", 1e-3);
+        Lin lp = conv_bn(next_ghost + ".primary_conv.0", next_ghost + ".primary_conv.1", 1e-5);
+        const HostTensor& w = W(ghost_pfx + ".cheap_operation.0.weight");
+        std::vector<float> sc, sh; bn_coeffs(ghost_pfx + ".cheap_operation.1", 1e-5, sc, sh);
+        std::vector<float> wt(size_t(9) * Cg);
+        for (int c = 0; c < Cg; ++c) for (int k = 0; k < 9; ++k) wt[size_t(k) * Cg + c] = w.data[size_t(c) * 9 + k] * sc[c];
+        A tn = alloc(t.B, 2 * t.H, 2 * t.W, lp.N);
+        MlpParams mp;
+        std::memset(&mp, 0, sizeof(mp));
+        chain_weights(mp, 2 * Cg, 2, lu, ACT_RELU, lp);
+        UpGhostChainParams cp{UpGhostParams{t.p, t.ld, nullptr, 0, up_f32(wt), up_f32(sh), t.B, t.H, t.W, Cg}, tn.p, tn.ld, mp.W1, mp.b1, mp.W2, mp.b2, lp.N};
+        const dim3 grid(unsigned(cdiv(2 * t.W, UPG_TS)) * unsigned(cdiv(2 * t.H, UPG_TS)) * unsigned(t.B)), block(unsigned(16 * Cg));
+        const double bytes = double(t.rows()) * Cg * sizeof(T) + double(tn.rows()) * lp.N * sizeof(T);
+        if constexpr (std::is_same<T, bf16_t>::value)
+            add_op(ghost_pfx + ".upghost+pair", [cp, grid, block, Cg](hipStream_t s) {
+                if (Cg == 16) ACH_LAUNCH((upghost_chain_kernel<16>), grid, block, s, cp);
+                else if (Cg == 24) ACH_LAUNCH((upghost_chain_kernel<24>), grid, block, s, cp);
+                else ACH_LAUNCH((upghost_chain_kernel<32>), grid, block, s, cp);
+            }, bytes, 2.0 * double(tn.rows()) * (2.0 * Cg * 32 + 32.0 * lp.N));
+        return tn;
+    }
+    A decoder_level(const std::string& up_pfx, const std::string& ghost_pfx, const A& x, int cout, const A* t_in = nullptr) {
+        const A t = t_in ? *t_in : decoder_pair(up_pfx, ghost_pfx, x, cout);
+        const int Cg = t.C;
         const HostTensor& w = W(ghost_pfx + ".cheap_operation.0.weight");
         std::vector<float> sc, sh; bn_coeffs(ghost_pfx + ".cheap_operation.1", 1e-5, sc, sh);
         std::vector<float> wt(size_t(9) * Cg);
@@ -946,8 +993,9 @@ public:
         return y;
     }
     // last decoder level (1_to_0) + segmentation head in one full-resolution kernel (upghost_head_kernel)
+    // (`t_in`: the level's low-resolution t, already produced by the previous level's kernel — decoder_level_chained; x is then only a shape)
     void decoder_last_level(const std::string& up_pfx, const std::string& ghost_pfx, const std::string& head_pfx, const std::string& tap_name,
-                            const A& x, int cout, int oup, void** out) {
+                            const A& x, int cout, int oup, void** out, const A* t_in = nullptr) {
         Lin lu = conv_bn(up_pfx + ".upsample.0.conv", up_pfx + ".upsample.0.bn", 1e-3);
         Lin lp = conv_bn(ghost_pfx + ".primary_conv.0", ghost_pfx + ".primary_conv.1", 1e-5);
         const int Cg = lp.N, init = (oup + 1) / 2, nch = oup - init;
@@ -955,8 +1003,9 @@ public:
         if (Cg != UGH_CG || 2 * Cg != cout || lh.K != cout || lh.N != init || init > UGH_IMAX) throw AchError{ACH_ERR_UNSUPPORTED, head_pfx + ": fused last level expects 16+16 channels"};
         A t;
         // bf16: bilinear phase on the matrix cores, t channel-planar (upghost_head_mfma_kernel)
-        bool planar = head_mfma && std::is_same<T, bf16_t>::value && x.W % 4 == 0 && size_t(x.B) * x.H * x.W * Cg * sizeof(T) < (size_t(1) << 31);
-        if (!chain2(ghost_pfx + ".lowres_pair", x, lu, ACT_RELU, lp, t, &planar)) {
+        bool planar = !t_in && head_mfma && std::is_same<T, bf16_t>::value && x.W % 4 == 0 && size_t(x.B) * x.H * x.W * Cg * sizeof(T) < (size_t(1) << 31);
+        if (t_in) t = *t_in;
+        else if (!chain2(ghost_pfx + ".lowres_pair", x, lu, ACT_RELU, lp, t, &planar)) {
             planar = false;
             A u = alloc(x.B, x.H, x.W, lu.N);
             { GemmOpt o; o.act = ACT_RELU; gemm(up_pfx + ".conv", x, pack(lu), u, o); }
@@ -1141,11 +1190,20 @@ public:
                 csp_bottleneck(f + "." + n + "_seg_head", y, oups[d], nullptr, outs[d]);
                 continue;
             }
+            // level l's full-resolution kernel also applies level l+1's low-resolution conv pair where it can (k_upchain.h): the level's
+            // output then never exists in HBM and the pair's launch disappears
+            auto up_of = [&](int l) { return f + "." + n + "_seg_" + lv[l]; };
+            auto gh_of = [&](int l) { return f + "." + n + "_seg_ghost_" + lv[l]; };
+            A t = decoder_pair(up_of(0), gh_of(0), y, cw[0]);
+            bool have_t = true;
             for (int l = 0; l < 2; ++l) {
-                y = decoder_level(f + "." + n + "_seg_" + lv[l], f + "." + n + "_seg_ghost_" + lv[l], y, cw[l]);
+                if (level_chains(gh_of(l), up_of(l + 1), gh_of(l + 1))) { t = decoder_level_chained(gh_of(l), t, up_of(l + 1), gh_of(l + 1)); have_t = true; continue; }
+                y = decoder_level(up_of(l), gh_of(l), t, cw[l], &t);
                 tap(n + "." + lv[l], y);
+                have_t = l < 1;
+                if (have_t) t = decoder_pair(up_of(l + 1), gh_of(l + 1), y, cw[l + 1]);
             }
-            decoder_last_level(f + "." + n + "_seg_" + lv[2], f + "." + n + "_seg_ghost_" + lv[2], f + "." + n + "_seg_head", n + "." + lv[2], y, cw[2], oups[d], outs[d]);
+            decoder_last_level(up_of(2), gh_of(2), f + "." + n + "_seg_head", n + "." + lv[2], have_t ? t : y, cw[2], oups[d], outs[d], have_t ? &t : nullptr);
         }
         if (piped) mark_xsignal2_last();    // the decoders' last launch: the next forward's neck may rewrite the attention maps after it
         cur_stream = 0;

@@ -558,3 +558,32 @@ def test_emulated_fused_head_layer_matches_the_two_launches(res, batch):
     for k in range(3):
         assert rel_err(outs[1][k], outs[0][k]) < 1.5e-2, (k, rel_err(outs[1][k], outs[0][k]))
         assert rel_err(outs[1][k], det[k]) < 3e-2, (k, rel_err(outs[1][k], det[k]))
+
+
+@pytest.mark.parametrize('name,res,batch', [('en_s0', 96, 2), ('en_s0', 160, 1), ('en_s2', 96, 1)])
+def test_emulated_chained_decoder_levels_are_bit_identical_to_the_separate_launches(name, res, batch):
+    """bf16 engine: a decoder level's full-resolution kernel that also applies the NEXT level's low-resolution conv pair (k_upchain.h,
+    option level_chain = 1, default in production plans) against upghost_kernel + chain_kernel (level_chain = 0).  The fused kernel rounds
+    [x1 | x2] to bf16 exactly where the stored level output was rounded and issues chain_kernel's MFMAs in chain_kernel's order on the same
+    packed weights, so the two plans must agree BIT FOR BIT on the segmentation outputs (Cg = 24 and 16 in EN-S0, 32 and 16 in EN-S2;
+    96: 24 / 48-pixel maps = ragged 16 x 16 tiles)."""
+    from achelous_amd.engine import NativeEngine
+    kw, sd, (x, xr, xp) = _setup(name, res, batch, 16)
+    outs = {}
+    for chain in (1, 0):
+        eng = NativeEngine(emu_library(), num_det=kw['num_det'], num_seg=kw['num_seg'], phi=kw['phi'], backbone=kw['backbone'], resolution=res,
+                           pc_channels=kw['pc_channels'], pc_classes=kw['pc_classes'], num_points=16, nano_head=True, spp=True, dtype=DTYPE_BF16)
+        eng.set_option('level_chain', chain)
+        eng.load_state_dict(sd)
+        eng.plan(batch)
+        o = alloc_outputs(kw, batch, 16, torch.bfloat16, 'cpu')
+        eng.forward(x.bfloat16(), xr.bfloat16(), xp.bfloat16(), o)
+        outs[chain] = (o[3].clone(), o[4].clone())
+        names = [t[0] for t in eng.op_table()]
+        if chain:
+            assert sum('upghost+pair' in n for n in names) == 4 and not any('2_to_1.lowres_pair' in n or '1_to_0.lowres_pair' in n for n in names)
+            launches = eng.launches()
+        else:
+            assert eng.launches() == launches + 4          # per decoder: two levels, each a pair launch more
+    assert torch.equal(outs[1][0], outs[0][0]) and torch.equal(outs[1][1], outs[0][1])
+    assert float(outs[1][0].float().abs().max()) > 0
