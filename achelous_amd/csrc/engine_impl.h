@@ -22,6 +22,7 @@
 #include "k_pn2.h"
 #include "k_prepost.h"
 #include "k_radar.h"
+#include "k_sdta.h"
 #include "k_xca.h"
 
 namespace ach {
@@ -536,15 +537,32 @@ public:
         if ((C / heads) > 64) throw AchError{ACH_ERR_UNSUPPORTED, "XCA head dimension > 64"};
         if (width % 4) throw AchError{ACH_ERR_UNSUPPORTED, "SDTA split width must be a multiple of 4"};
         A y = alloc(x.B, x.H, x.W, C);
-        for (int i = 0; i < nums; ++i) {
-            A xi = x.slice(i * width, width), yi = y.slice(i * width, width);
-            A prev = i > 0 ? y.slice((i - 1) * width, width) : A();
-            const std::string c = pfx + ".convs." + std::to_string(i);
-            dwconv(c, xi, i > 0 ? &prev : nullptr, c + ".weight", c + ".bias", "", 0, 3, 1, ACT_NONE, yi);
+        const int HW = x.H * x.W, tailc = C - nums * width, Q = sdta_pre_quads(x.H, x.W, width / 4);
+        const bool has_pos = hasW(pfx + ".pos_embd.token_projection.weight");
+        if (sdta_fuse && (sdta_fuse > 1 || HW <= 400) && Q > 0 && nums >= 1 && tailc >= 0 && tailc % 4 == 0) {
+            // cascade of depthwise 3x3 convs + tail copy + positional encoding as one launch (k_sdta.h)
+            std::vector<float> wt(size_t(nums) * 9 * width), bs(size_t(nums) * width);
+            for (int i = 0; i < nums; ++i) {
+                const HostTensor& w = W(pfx + ".convs." + std::to_string(i) + ".weight");
+                const HostTensor& bi = W(pfx + ".convs." + std::to_string(i) + ".bias");
+                if (w.numel() != long(width) * 9 || bi.numel() != width) throw AchError{ACH_ERR_MISSING_KEY, "SDTA conv shapes at " + pfx};
+                for (int c = 0; c < width; ++c) { bs[size_t(i) * width + c] = bi.data[c]; for (int t = 0; t < 9; ++t) wt[(size_t(i) * 9 + t) * width + c] = w.data[size_t(c) * 9 + t]; }
+            }
+            SdtaPreParams sp{x.p, x.ld, y.p, y.ld, up_f32(wt), up_f32(bs), has_pos ? posenc_table(pfx + ".pos_embd", x.H, x.W, C) : nullptr,
+                             x.B, x.H, x.W, C, width, nums, Q, cdiv(width / 4, Q), cdiv(tailc / 4, Q)};
+            const dim3 grid(unsigned(x.B) * unsigned(sp.conv_wgs + sp.tail_wgs)), block(SDTA_THREADS);
+            add_op(pfx + ".sdta_pre", [sp, grid, block](hipStream_t s) { ACH_LAUNCH(sdta_pre_kernel<T>, grid, block, s, sp); },
+                   2.0 * double(x.rows()) * C * sizeof(T));
+        } else {
+            for (int i = 0; i < nums; ++i) {
+                A xi = x.slice(i * width, width), yi = y.slice(i * width, width);
+                A prev = i > 0 ? y.slice((i - 1) * width, width) : A();
+                const std::string c = pfx + ".convs." + std::to_string(i);
+                dwconv(c, xi, i > 0 ? &prev : nullptr, c + ".weight", c + ".bias", "", 0, 3, 1, ACT_NONE, yi);
+            }
+            copy(pfx + ".split_tail", x.slice(nums * width, C - nums * width), y.slice(nums * width, C - nums * width));
+            if (has_pos) copy(pfx + ".pos_embd", y, y, posenc_table(pfx + ".pos_embd", x.H, x.W, C));
         }
-        copy(pfx + ".split_tail", x.slice(nums * width, C - nums * width), y.slice(nums * width, C - nums * width));
-        if (hasW(pfx + ".pos_embd.token_projection.weight"))
-            copy(pfx + ".pos_embd", y, y, posenc_table(pfx + ".pos_embd", x.H, x.W, C));
         // XCA
         Lin lq = lin(pfx + ".xca.qkv.weight", pfx + ".xca.qkv.bias");
         fold_ln_in(lq, pfx + ".norm_xca");

@@ -587,3 +587,33 @@ def test_emulated_chained_decoder_levels_are_bit_identical_to_the_separate_launc
             assert eng.launches() == launches + 4          # per decoder: two levels, each a pair launch more
     assert torch.equal(outs[1][0], outs[0][0]) and torch.equal(outs[1][1], outs[0][1])
     assert float(outs[1][0].float().abs().max()) > 0
+
+
+@pytest.mark.parametrize('name,res,dtype', [('en_s0', 96, 'bf16'), ('en_s0', 160, 'f32'), ('en_s2', 96, 'bf16'), ('en_s1', 64, 'bf16')])
+def test_emulated_fused_sdta_front_is_bit_identical_to_the_separate_launches(name, res, dtype):
+    """An SDTA encoder's cascade of depthwise 3x3 convs, tail copy and positional encoding as one launch (k_sdta.h, option sdta_fuse = 2;
+    the default 1 does it on maps up to 20 x 20) against the 3-5 separate launches (sdta_fuse = 0): the same rounding points, so every output must agree bit for bit — both
+    storage types, 1 / 2 / 3 convs per encoder (stages 1-3), quad counts that do not fill the last workgroup (width 44 -> 11 quads)."""
+    from achelous_amd.engine import NativeEngine
+    from achelous_amd.engine import DTYPE_F32
+    kw, sd, (x, xr, xp) = _setup(name, res, 2, 16)
+    tdt = torch.bfloat16 if dtype == 'bf16' else torch.float32
+    outs = {}
+    for fuse in (2, 0):          # 2: every map that fits (the default, 1, leaves the 40 x 40 stage to the separate launches: measured)
+        eng = NativeEngine(emu_library(), num_det=kw['num_det'], num_seg=kw['num_seg'], phi=kw['phi'], backbone=kw['backbone'], resolution=res,
+                           pc_channels=kw['pc_channels'], pc_classes=kw['pc_classes'], num_points=16, nano_head=True, spp=True,
+                           dtype=DTYPE_BF16 if dtype == 'bf16' else DTYPE_F32)
+        eng.set_option('sdta_fuse', fuse)
+        eng.load_state_dict(sd)
+        eng.plan(2)
+        o = alloc_outputs(kw, 2, 16, tdt, 'cpu')
+        eng.forward(x.to(tdt), xr.to(tdt), xp.to(tdt), o)
+        outs[fuse] = [t.clone() for t in o]
+        names = [t[0] for t in eng.op_table()]
+        if fuse:
+            assert sum(n.endswith('.sdta_pre') for n in names) == 3 and not any('.split_tail' in n for n in names)
+            launches = eng.launches()
+        else:
+            assert eng.launches() > launches + 5
+    for a, b in zip(outs[2], outs[0]):
+        assert torch.equal(a, b)
