@@ -18,7 +18,12 @@ b en_s0_separate_calls --separate-calls
 b en_s0_force_collective --force-collective
 b en_s0_head_tile --opt head_rows=0
 b en_s0_mlp_tile --opt mlp_band=0
-b en_s0_r02_kernels --opt head_rows=0 --opt mlp_band=0
+b en_s0_r02_kernels --opt head_rows=0 --opt mlp_band=0 --opt head_fuse=0 --opt radar_compact=0 --opt level_chain=0 --opt sdta_fuse=0
+b en_s0_levels_separate --opt level_chain=0
+b en_s0_sdta_separate --opt sdta_fuse=0
+b en_s0_sdta_all --opt sdta_fuse=2
+b en_s0_head_layers_separate --opt head_fuse=0
+b en_s0_radar_segments --opt radar_compact=0
 b en_s0_b256 --batch 256
 b en_s2_b256 --config en_s2 --batch 256
 b en_s2_b512_one_gpu --config en_s2 --batch 512 --plain
