@@ -515,29 +515,39 @@ __global__ __launch_bounds__(256) void copy_kernel(const CopyParams p) {
 struct StatParams { const void* X; long ldx; float* partial; int HW, C, S; };
 template <class T>
 __device__ __forceinline__ void chan_stats_body(const StatParams& p, int b, int s) {
-    __shared__ float red[2][256];
+    __shared__ float4 red[2][256];
     const int tid = threadIdx.x;
     const T* X = static_cast<const T*>(p.X) + long(b) * p.HW * p.ldx;
     float* out = p.partial + (long(b) * p.S + s) * 2 * p.C;
-    // threads = (channel c) x (row lane rl); every thread strides over positions
-    const int tc = p.C < 256 ? p.C : 256;       // channels handled per pass
-    const int rl_n = 256 / tc;                  // row lanes per channel (>= 1)
-    for (int c0 = 0; c0 < p.C; c0 += tc) {
-        const int c = c0 + (tid % tc);
+    // threads = (channel QUAD q) x (row lane rl): one 8 / 16-byte load per position and thread (round 3: was one element per thread —
+    // 2-byte loads, 4x the iterations); every thread strides over positions.  A last quad past C reads the row's zero padding (ld is a
+    // multiple of 8 elements) and is not written.
+    const int cq = (p.C + 3) >> 2;
+    const int tc = cq < 256 ? cq : 256;         // quads handled per pass
+    const int rl_n = 256 / tc;                  // row lanes per quad (>= 1)
+    for (int q0 = 0; q0 < cq; q0 += tc) {
+        const int q = q0 + (tid % tc);
         const int rl = tid / tc;
-        float s1 = 0.f, s2 = 0.f;
-        if (rl < rl_n && c < p.C)
+        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+        if (rl < rl_n && q < cq)
             for (int i = s * rl_n + rl; i < p.HW; i += p.S * rl_n) {
-                const float v = Store<T>::ld(X + long(i) * p.ldx + c);
-                s1 += v; s2 += v * v;
+                float v[4];
+                Store<T>::ld4(X + long(i) * p.ldx + 4 * q, v);
+                ACH_UNROLL
+                for (int e = 0; e < 4; ++e) { s1[e] += v[e]; s2[e] += v[e] * v[e]; }
             }
-        red[0][tid] = s1; red[1][tid] = s2;
+        red[0][tid] = make_float4(s1[0], s1[1], s1[2], s1[3]); red[1][tid] = make_float4(s2[0], s2[1], s2[2], s2[3]);
         __syncthreads();
-        if (tid < tc && c0 + tid < p.C) {
-            float a = 0.f, q = 0.f;
-            for (int r = 0; r < rl_n; ++r) { a += red[0][r * tc + tid]; q += red[1][r * tc + tid]; }
-            out[c0 + tid] = a;
-            out[p.C + c0 + tid] = q;
+        if (tid < tc && q0 + tid < cq) {
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), w = a;
+            for (int r = 0; r < rl_n; ++r) {
+                const float4 u = red[0][r * tc + tid], z = red[1][r * tc + tid];
+                a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w; w.x += z.x; w.y += z.y; w.z += z.z; w.w += z.w;
+            }
+            const int c = 4 * (q0 + tid);
+            const float av[4] = {a.x, a.y, a.z, a.w}, wv[4] = {w.x, w.y, w.z, w.w};
+            ACH_UNROLL
+            for (int e = 0; e < 4; ++e) if (c + e < p.C) { out[c + e] = av[e]; out[p.C + c + e] = wv[e]; }
         }
         __syncthreads();
     }
