@@ -6,7 +6,8 @@
 // `upghost_kernel` wrote y — 2 Cg channels at the level's full resolution, 105 MB per decoder at 160 x 160, batch 64 — and `chain_kernel`
 // (the `.lowres_pair` launch of the next level) read it straight back to produce 16 channels.  Here y only exists as the bf16 B fragments of
 // the pair's first GEMM, in LDS: the level writes t' (16 channels) and the `.lowres_pair` launch disappears.
-//   1. the tile's x1 with a one-pixel halo -> LDS (fp32), as upghost_kernel;
+//   0. the tile's source pixels of t and the interpolation geometry of its 18 rows / columns -> LDS;
+//   1. the tile's x1 with a one-pixel halo -> LDS (fp32), upghost_kernel's arithmetic on the staged values;
 //   2. thread = (pixel, 4-channel group): depthwise 3 x 3, ReLU; [x1 | x2] of the pixel rounded to bf16 (the rounding the stored y had) and,
 //      once every thread is done with x1, written OVER it as B fragments: 16-pixel tile row t, k-step s = channel / 32, lane group (channel % 32) / 8;
 //   3. wave per tile row: chain_kernel's register chain (same packed weights, same MFMA order: bit-identical to the two launches) and
@@ -35,6 +36,10 @@ __global__ __launch_bounds__(16 * CG) void upghost_chain_kernel(const UpGhostCha
     __shared__ __attribute__((aligned(16))) float smem[X1_FLOATS > XS_FLOATS ? X1_FLOATS : XS_FLOATS];
     float* const x1 = smem;
     uint4* const xs = reinterpret_cast<uint4*>(smem);
+    constexpr int SRC = TS / 2 + 4;                          // source rows / columns a halo tile can touch
+    __shared__ __attribute__((aligned(16))) float src[SRC * SRC * CG];
+    struct GeoTab { int i0, i1; float l; int ok; };
+    __shared__ GeoTab ytab[HS], xtab[HS];
     const UpGhostParams& p = q.u;
     const int H = 2 * p.h, Wd = 2 * p.w;
     const int tiles_x = (Wd + TS - 1) / TS, tiles_y = (H + TS - 1) / TS;
@@ -56,28 +61,51 @@ __global__ __launch_bounds__(16 * CG) void upghost_chain_kernel(const UpGhostCha
     float b1[8], b2[8];
     ACH_UNROLL
     for (int i = 0; i < 8; ++i) { b1[i] = q.b1[g * 8 + i]; b2[i] = q.b2[g * 8 + i]; }
-    // ---- 1. relu(bilinear(t)) on the tile + halo (upghost_kernel's arithmetic)
+    // ---- 0. the tile's SOURCE pixels of t (at most 12 x 12 for the 18 x 18 halo tile at scale ~ 1/2) -> LDS as fp32, and the interpolation
+    // geometry of the tile's 18 rows and 18 columns (upghost_kernel's float arithmetic, once per row / column instead of once per
+    // (position, channel quad): the bilinear phase was half of the kernel's ~1 000 VALU instructions per wave, 30 of every 80 of them this)
+    const int oy_first = by > 0 ? by - 1 : 0, ox_first = bx > 0 ? bx - 1 : 0;
+    int ys0 = int(sy * float(oy_first)), xs0 = int(sx * float(ox_first));
+    if (ys0 > p.h - 1) ys0 = p.h - 1;
+    if (xs0 > p.w - 1) xs0 = p.w - 1;
+    for (int i = slot; i < SRC * SRC; i += 64) {
+        const int r = i / SRC, cc = i % SRC;
+        const int yy = ys0 + r < p.h ? ys0 + r : p.h - 1, xx = xs0 + cc < p.w ? xs0 + cc : p.w - 1;
+        float a[4];
+        Store<T>::ld4(Tq + (long(yy) * p.w + xx) * p.ldt, a);
+        *reinterpret_cast<float4*>(src + i * CG + c) = make_float4(a[0], a[1], a[2], a[3]);
+    }
+    if (threadIdx.x < 2 * HS) {
+        const bool isx = threadIdx.x >= HS;
+        const int k = isx ? int(threadIdx.x) - HS : int(threadIdx.x);
+        const int o = (isx ? bx : by) + k - 1, lim = isx ? Wd : H, n = isx ? p.w : p.h;
+        const int cl = o < 0 ? 0 : (o >= lim ? lim - 1 : o);
+        const float f = (isx ? sx : sy) * float(cl);
+        int i0 = int(f);
+        if (i0 > n - 1) i0 = n - 1;
+        const int i1 = i0 + (i0 < n - 1 ? 1 : 0);
+        GeoTab g;
+        g.i0 = i0 - (isx ? xs0 : ys0); g.i1 = i1 - (isx ? xs0 : ys0); g.l = f - float(i0); g.ok = (o >= 0 && o < lim) ? 1 : 0;
+        (isx ? xtab : ytab)[k] = g;
+    }
+    __syncthreads();
+    // ---- 1. relu(bilinear(t)) on the tile + halo, from LDS
     constexpr int ROUNDS = (HS * HS + 63) / 64;
     ACH_UNROLL
     for (int r = 0; r < ROUNDS; ++r) {
         const int pos_raw = slot + r * 64;
         const int pos = pos_raw < HS * HS ? pos_raw : HS * HS - 1;
-        const int oy = by + pos / HS - 1, ox = bx + pos % HS - 1;
-        const bool ok = oy >= 0 && oy < H && ox >= 0 && ox < Wd;
-        const int cy = oy < 0 ? 0 : (oy >= H ? H - 1 : oy), cx = ox < 0 ? 0 : (ox >= Wd ? Wd - 1 : ox);
-        const float fy = sy * float(cy), fx = sx * float(cx);
-        int y0 = int(fy), x0 = int(fx);
-        if (y0 > p.h - 1) y0 = p.h - 1;
-        if (x0 > p.w - 1) x0 = p.w - 1;
-        const int y1 = y0 + (y0 < p.h - 1 ? 1 : 0), x1i = x0 + (x0 < p.w - 1 ? 1 : 0);
-        const float ly = fy - float(y0), lx = fx - float(x0), hy = 1.f - ly, hx = 1.f - lx;
-        float a[4], bq[4], cc[4], d[4], v[4];
-        Store<T>::ld4(Tq + (long(y0) * p.w + x0) * p.ldt, a);
-        Store<T>::ld4(Tq + (long(y0) * p.w + x1i) * p.ldt, bq);
-        Store<T>::ld4(Tq + (long(y1) * p.w + x0) * p.ldt, cc);
-        Store<T>::ld4(Tq + (long(y1) * p.w + x1i) * p.ldt, d);
+        const GeoTab gy = ytab[pos / HS], gx = xtab[pos % HS];
+        const bool ok = gy.ok && gx.ok;                           // outside the map: the dw conv's zero padding
+        const float ly = gy.l, lx = gx.l, hy = 1.f - ly, hx = 1.f - lx;
+        const float4 a = *reinterpret_cast<const float4*>(src + (gy.i0 * SRC + gx.i0) * CG + c);
+        const float4 bq = *reinterpret_cast<const float4*>(src + (gy.i0 * SRC + gx.i1) * CG + c);
+        const float4 cc = *reinterpret_cast<const float4*>(src + (gy.i1 * SRC + gx.i0) * CG + c);
+        const float4 d = *reinterpret_cast<const float4*>(src + (gy.i1 * SRC + gx.i1) * CG + c);
+        const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {bq.x, bq.y, bq.z, bq.w}, cv[4] = {cc.x, cc.y, cc.z, cc.w}, dv[4] = {d.x, d.y, d.z, d.w};
+        float v[4];
         ACH_UNROLL
-        for (int i = 0; i < 4; ++i) { const float t = hy * (hx * a[i] + lx * bq[i]) + ly * (hx * cc[i] + lx * d[i]); v[i] = (ok && t > 0.f) ? t : 0.f; }
+        for (int i = 0; i < 4; ++i) { const float t = hy * (hx * av[i] + lx * bv[i]) + ly * (hx * cv[i] + lx * dv[i]); v[i] = (ok && t > 0.f) ? t : 0.f; }
         if (pos_raw < HS * HS) *reinterpret_cast<float4*>(x1 + pos * CG + c) = make_float4(v[0], v[1], v[2], v[3]);
     }
     float wk[9][4];
