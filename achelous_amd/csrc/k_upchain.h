@@ -26,8 +26,14 @@ struct UpGhostChainParams {
     int Cout;
 };
 
+#ifndef ACH_UPC_WAVES
+#define ACH_UPC_WAVES 0            // > 0: register budget for this many waves per SIMD at every width (experiments)
+#endif
+// register budget: four waves per SIMD at Cg = 16 (four workgroups per CU; measured 59 -> 49 us on the 160 x 160 level against the
+// compiler's free choice of 132), three at Cg = 24 / 32 (two workgroups of 6 / 8 waves per CU)
+#define ACH_UPC_BOUNDS(CG) __launch_bounds__(16 * CG, (ACH_UPC_WAVES > 0 ? ACH_UPC_WAVES : (CG <= 16 ? 4 : 3)))
 template <int CG>
-__global__ __launch_bounds__(16 * CG) void upghost_chain_kernel(const UpGhostChainParams q) {
+__global__ ACH_UPC_BOUNDS(CG) void upghost_chain_kernel(const UpGhostChainParams q) {
     typedef bf16_t T;
     constexpr int TS = UPG_TS, HS = TS + 2, CQ = CG / 4, K1 = (2 * CG + 31) / 32, NW = 16 * CG / 64;
     // one buffer: x1 (fp32, tile + halo) in phases 1-2, then the B fragments of the tile's 16 rows (the depthwise results wait in registers
@@ -49,18 +55,22 @@ __global__ __launch_bounds__(16 * CG) void upghost_chain_kernel(const UpGhostCha
     const int c = (threadIdx.x % CQ) * 4, slot = threadIdx.x / CQ;
     const float sy = H > 1 ? float(p.h - 1) / float(H - 1) : 0.f, sx = Wd > 1 ? float(p.w - 1) / float(Wd - 1) : 0.f;
     const T* Tq = static_cast<const T*>(p.Tq) + b * p.h * long(p.w) * p.ldt + c;
-    // the pair's weights (per wave: 6 fragments + 16 biases) are requested first: their latency hides behind phases 1-2
+    // the pair's weights (per wave: up to 6 fragments + 16 biases): at Cg = 16 requested first, their latency hides behind phases 0-2; at the wider
+    // levels the 40 registers are what keeps the kernel from two workgroups per CU, so they are fetched in front of phase 3
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int px = lane & 15, g = lane >> 4;
     const uint4* W1f = static_cast<const uint4*>(q.W1) + lane;
     const uint4* W2f = static_cast<const uint4*>(q.W2) + lane;
     uint4 w1[K1][2], w2[2];
-    ACH_UNROLL
-    for (int s = 0; s < K1; ++s) { w1[s][0] = W1f[(s * 2) * 64]; w1[s][1] = W1f[(s * 2 + 1) * 64]; }
-    w2[0] = W2f[0]; w2[1] = W2f[64];
     float b1[8], b2[8];
-    ACH_UNROLL
-    for (int i = 0; i < 8; ++i) { b1[i] = q.b1[g * 8 + i]; b2[i] = q.b2[g * 8 + i]; }
+    auto fetch_weights = [&]() {
+        ACH_UNROLL
+        for (int s = 0; s < K1; ++s) { w1[s][0] = W1f[(s * 2) * 64]; w1[s][1] = W1f[(s * 2 + 1) * 64]; }
+        w2[0] = W2f[0]; w2[1] = W2f[64];
+        ACH_UNROLL
+        for (int i = 0; i < 8; ++i) { b1[i] = q.b1[g * 8 + i]; b2[i] = q.b2[g * 8 + i]; }
+    };
+    if (CG <= 16) fetch_weights();
     // ---- 0. the tile's SOURCE pixels of t (at most 12 x 12 for the 18 x 18 halo tile at scale ~ 1/2) -> LDS as fp32, and the interpolation
     // geometry of the tile's 18 rows and 18 columns (upghost_kernel's float arithmetic, once per row / column instead of once per
     // (position, channel quad): the bilinear phase was half of the kernel's ~1 000 VALU instructions per wave, 30 of every 80 of them this)
@@ -89,9 +99,10 @@ __global__ __launch_bounds__(16 * CG) void upghost_chain_kernel(const UpGhostCha
         (isx ? xtab : ytab)[k] = g;
     }
     __syncthreads();
-    // ---- 1. relu(bilinear(t)) on the tile + halo, from LDS
+    // ---- 1. relu(bilinear(t)) on the tile + halo, from LDS (two rounds in flight: fully unrolled the six rounds' 24 float4 loads were
+    // hoisted together and the Cg = 24 kernel took 242 registers)
     constexpr int ROUNDS = (HS * HS + 63) / 64;
-    ACH_UNROLL
+    _Pragma("unroll 2")
     for (int r = 0; r < ROUNDS; ++r) {
         const int pos_raw = slot + r * 64;
         const int pos = pos_raw < HS * HS ? pos_raw : HS * HS - 1;
@@ -132,6 +143,11 @@ __global__ __launch_bounds__(16 * CG) void upghost_chain_kernel(const UpGhostCha
         for (int i = 0; i < 4; ++i) acc[i] = acc[i] > 0.f ? acc[i] : 0.f;
         fr[it][0] = make_uint2(pack_bf16x2(o1[0], o1[1]), pack_bf16x2(o1[2], o1[3]));
         fr[it][1] = make_uint2(pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3]));
+#if !defined(ACH_HOSTEMU)
+        // the packed results must EXIST before the barrier: left alone, the compiler (Cg = 24) read all 36 taps, sank the arithmetic below the
+        // barrier and carried 144 registers across it (242 VGPRs, or 81 spilled at a 168 budget)
+        asm volatile("" : "+v"(fr[it][0].x), "+v"(fr[it][0].y), "+v"(fr[it][1].x), "+v"(fr[it][1].y));
+#endif
     }
     __syncthreads();
     // B fragments: 16-pixel tile row ty, k-step s = channel / 32, lane group (channel % 32) / 8; channels past 2 Cg of the last k-step are zero
@@ -156,6 +172,7 @@ __global__ __launch_bounds__(16 * CG) void upghost_chain_kernel(const UpGhostCha
     }
     __syncthreads();
     // ---- 3. the next level's conv pair on the tile rows (chain_kernel<bf16, K1, 1>'s chain)
+    if (CG > 16) fetch_weights();
     T* Tn = static_cast<T*>(q.Tn);
     for (int ty = wave; ty < TS; ty += NW) {
         f32x4 h0 = {0.f, 0.f, 0.f, 0.f}, h1 = {0.f, 0.f, 0.f, 0.f};
