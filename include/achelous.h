@@ -107,6 +107,15 @@ int ach_load_weights(ach_handle* h, const ach_tensor_desc* tensors, size_t n);
  * after backbone stage 1), "dw_even" (even deal of depthwise tap rows over the four SPLIT waves, d = 144), "xca_mfma" (XCA Gram
  * matrices on the matrix cores; 0: VALU kernel), "head_mfma" (default 0: bilinear phase of the fused segmentation head on MFMA —
  * measured slower), "gemm_rows" (default 1: 16-row sub-tiles per wave for GEMMs with K >= 1024 — 2 / 4 measured slower),
+ * round 3 (bf16 engine): "head_rows" (2: last decoder level + segmentation head as the row-walking two-columns-per-lane kernel, 1: one
+ * column, 0: the LDS tile kernel), "head_band" (rows per workgroup band of that kernel, default 40), "mlp_band" (1: EdgeNeXt blocks on
+ * maps up to 32 x 32 as the band kernel, 2: on every map, 0: never), "head_fuse" (a detection-head layer's depthwise + pointwise convs of both
+ * towers and all levels as one launch), "radar_compact" (first RCBlock: per-pixel activity, active pixels compacted into dense tiles;
+ * bit-identical), "level_chain" (a decoder level's kernel also applies the next level's low-resolution conv pair; bit-identical),
+ * "sdta_fuse" (1: an SDTA encoder's conv cascade + tail copy + positional encoding as one launch on maps up to 20 x 20, 2: every map,
+ * 0: never; bit-identical), "level_rows" (default 0: decoder levels as row-walking kernels — measured slower);  debugging only:
+ * "xwait2_op" (pipelined mode: the launch index that waits for the previous forward's decoders), "head_debug" / "mlp_band_dbg" /
+ * "head_fuse_dbg" (phase-kill timing variants, WRONG results);
  * "pipeline" (see ach_join).  DESIGN.md §4 has the measurement behind every default. */
 int ach_set_option(ach_handle* h, const char* key, int32_t value);
 
