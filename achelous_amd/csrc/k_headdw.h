@@ -5,7 +5,7 @@
 //                                                                         backbone/conv_utils/normal_conv.py:23-52)
 // It was two launches per layer for the three pyramid levels: `dwconv_strip_multi<5>` — every input element fetched 25 times through the
 // texture path (TA 49 % busy, 58-64 us, and the reason the decoders' tail stretches beside it) — writing a 128-channel tensor that the
-// block-diagonal 128 x 128 GEMM (31 us) read straight back.  Here a 512-thread workgroup owns (frame, band of rows, tower):
+// block-diagonal 128 x 128 GEMM (31 us) read straight back.  Here a workgroup (128 threads, see ACH_HDW_THREADS) owns (frame, band of rows, tower):
 //   0. the band's halo (rows + 4, columns + 4, the tower's 64 input channels) is staged in LDS once, unpacked to fp32;
 //   1. depthwise 5 x 5 from LDS: thread = 5-pixel strip x 4 channels (a tap row: 9 LDS reads for 5 x 5 x 4 FMAs); the sums are written
 //      back to LDS as the bf16 B fragments of the pointwise GEMM — the depthwise output never exists in HBM;
@@ -16,12 +16,20 @@
 
 namespace ach {
 
-constexpr int HDW_THREADS = 512, HDW_SP = 5, HDW_C = 64, HDW_MAXPOS = 8 * 44, HDW_MAXT = 10;
+#ifndef ACH_HDW_THREADS
+#define ACH_HDW_THREADS 128           // measured (one box, alternating): 512 threads 36.3 k frames/s, 256: 36.8 k, 128: 37.4 k — the workgroup holds 64 KB of LDS whatever
+                                      // its size, and the fewer wave slots it takes the more of the CU is left to the other streams (isolated 62 / 53 / 51 us).
+                                      // Tried on top: the fragments written over the halo tile (45 KB, sums in registers across the barrier): 51 -> 60 us, -2 %.
+#endif
+#ifndef ACH_HDW_WGS
+#define ACH_HDW_WGS 4
+#endif
+constexpr int HDW_THREADS = ACH_HDW_THREADS, HDW_SP = 5, HDW_C = 64, HDW_MAXPOS = 8 * 44, HDW_MAXT = 10;
 #ifndef ACH_HDW_F32
 #define ACH_HDW_F32 0             // 1: the halo tile is staged as fp32 (90 KB: one workgroup per CU); 0: as bf16 (45 KB: two per CU, taps unpacked in the loop)
 #endif
 constexpr bool HDW_F32 = ACH_HDW_F32 != 0;
-constexpr int HDW_WGS = HDW_F32 ? 1 : 2;
+constexpr int HDW_WGS = ACH_HDW_WGS > 0 ? ACH_HDW_WGS : (HDW_F32 ? 1 : 2);
 struct HeadDwJob {
     const void* X; void* Y; long ldx, ldy;
     const float* Wdw;                 // [25][128] fp32 (both towers side by side)
