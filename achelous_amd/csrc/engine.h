@@ -111,7 +111,10 @@ public:
                                       // to side stream 2 (ahead of fusion + head), the caller's stream is done after the neck, and NOTHING is
                                       // joined at the end of ach_forward: the caller enqueues the next forward first and then calls ach_join
                                       // (at most two forwards in flight; see run_eager).  Results are identical; only the schedule differs.
-    int radar_start = 1;              // option "radar_start" (default 1, measured +1 %, the block-0 front kernel 0.58 -> 0.38 ms in-step): -1 = the radar branch starts with the forward; k = 0..2: only once backbone stage k is done
+    int radar_start = -2;             // option "radar_start": -1 = the radar branch starts with the forward; k = 0..3: only once backbone stage k is done (round 2: 1 measured
+                                      // +1 %, the block-0 front kernel 0.58 -> 0.38 ms in-step); -2 (default) = 2 in the pipelined plan — with round 3's kernels, one box, alternating,
+                                      // three runs: stage 1: 36.31 k frames/s, stage 2: 37.33 k, stage 3: 36.62 k — and 1 in the plain plan (35.77 k / 35.59 k / 33.57 k)
+    int radar_start_eff() const { return radar_start == -2 ? ((pipeline && multi_stream) ? 2 : 1) : radar_start; }
                                       // (event 0), with the point branch ahead of it on the same stream — the first RCBlocks are
                                       // throughput-bound like backbone stages 0 / 1 and halve each other's speed when they overlap
     int pool_strip = 2;               // option "pool_strip": which RCBlock average pools use the 4-pixel strip kernel (engine_impl.h, rcnet)

@@ -674,7 +674,7 @@ public:
             }
             if (has_preset) throw AchError{ACH_ERR_INVALID, "stage output destination was not consumed"};
             feats[i] = x;
-            if (i == radar_start) signal_after_last(0);
+            if (i == radar_start_eff()) signal_after_last(0);
         }
     }
 
@@ -800,15 +800,15 @@ public:
         x = mv2block(pfx + ".mv2.2", x, 1, mc.ch[3]);
         x = mv2block(pfx + ".mv2.3", x, 1, mc.ch[3]);
         feats[0] = x;
-        if (radar_start == 0) signal_after_last(0);
+        if (radar_start_eff() == 0) signal_after_last(0);
         x = mv2block(pfx + ".mv2.4", x, 2, mc.ch[4]);
         x = mvit_block(pfx + ".mvit.0", x, 2);
         feats[1] = x;
-        if (radar_start == 1) signal_after_last(0);
+        if (radar_start_eff() == 1) signal_after_last(0);
         x = mv2block(pfx + ".mv2.5", x, 2, mc.ch[6]);
         x = mvit_block(pfx + ".mvit.1", x, 4);
         feats[2] = x;
-        if (radar_start >= 2) signal_after_last(0);
+        if (radar_start_eff() >= 2) signal_after_last(0);
         x = mv2block(pfx + ".mv2.6", x, 2, mc.ch[8]);
         x = mvit_block(pfx + ".mvit.2", x, 3);
         feats[3] = mv_conv(pfx + ".conv2", x, 1, 1);
@@ -1750,7 +1750,7 @@ public:
         // (auto: stream 2 for PointNet++, and in the pipelined plan, where it shares the stream with the decoders: 27.7 k against 26.4 k
         //  frames/s; the plain plan keeps PointNet on stream 1 ahead of the radar branch — two streams in all: 26.35 k against 25.95 k)
         const bool point2 = point_on_head_stream < 0 ? (cfg.pc_seg == ACH_PCSEG_PN2 || (!head_stream && pipeline)) : point_on_head_stream != 0;
-        const bool radar_late = radar_start >= 0 && multi_stream;
+        const bool radar_late = radar_start_eff() >= 0 && multi_stream;
         auto points = [&] { cur_stream = point2 ? 2 : 1; if (cfg.pc_seg == ACH_PCSEG_PN2) pointnet2(); else if (cfg.pc_seg == ACH_PCSEG_PN) pointnet(); };   // ACH_PCSEG_NONE: Achelous3T
         if (radar_late) points();         // the point branch (small launches) fills the window before the radar branch is released
         cur_stream = 1;

@@ -27,9 +27,14 @@ struct SdtaPreParams {
     int Q;                   // quads per workgroup (1, 2, 4 or 8): SDTA_THREADS / Q pixel slots
     int conv_wgs, tail_wgs;  // workgroups per frame: conv quads / Q, tail quads / Q (rounded up)
 };
-constexpr int SDTA_THREADS = 1024;
-constexpr int SDTA_MAXPPT = 4;            // pixels per thread (H * W <= 4 * 1024 / Q): the cascade's previous outputs stay in registers
-constexpr int SDTA_LDS_FLOATS = 14336;    // 56 KB: H * W * Q float4
+#ifndef ACH_SDTA_THREADS
+#define ACH_SDTA_THREADS 1024
+#define ACH_SDTA_MAXPPT 4
+#define ACH_SDTA_LDS 14336
+#endif
+constexpr int SDTA_THREADS = ACH_SDTA_THREADS;
+constexpr int SDTA_MAXPPT = ACH_SDTA_MAXPPT;            // pixels per thread (H * W <= 4 * 1024 / Q): the cascade's previous outputs stay in registers
+constexpr int SDTA_LDS_FLOATS = ACH_SDTA_LDS;    // 56 KB: H * W * Q float4
 
 template <class T>
 __global__ __launch_bounds__(SDTA_THREADS) void sdta_pre_kernel(const SdtaPreParams p) {
