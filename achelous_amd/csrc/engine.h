@@ -88,7 +88,7 @@ public:
     int head_rows = 2;            // option "head_rows": bf16 — fused last decoder level + head as the row-walking kernel (k_dechead.h: no LDS, DPP row shifts, head 1x1 on MFMA); 0 = the LDS tile kernel (k_nhwc.h)
     bool level_rows = false;          // option "level_rows": the other two decoder levels through upghost_rows_kernel too (k_dechead.h).  OFF: their 32- / 48-channel NHWC rows are
                                       // write-bound, and the 16-column strips write them in 64-byte pieces: 3_to_2 25 -> 34 us, 2_to_1 48 -> 60 us, 32.6 k -> 31.6 k frames/s
-    int head_band = 40;               // option "head_band": rows per band of the row-walking kernel
+    int head_band = 80;               // option "head_band": rows per band of the row-walking kernel (round 3, after the other kernels had settled: 40 rows 37.2 k frames/s, 80: 37.4 k, 160: 36.7 k, 320: 34.4 k)
     bool head_mfma = false;           // option "head_mfma": bf16 — bilinear phase of the fused last decoder level on MFMA over a channel-planar t (k_nhwc.h)
     int head_grid = 0;                // option "head_grid": persistent workgroups of the MFMA head kernel (0 = UGM_GRID)
     int head_debug = 0;               // option "head_debug": timing experiments on the fused last decoder level (skips phases: results are wrong)
@@ -105,7 +105,7 @@ public:
                                       // first RCBlock's shortcut shortened the radar branch: with the head queued BEHIND the radar branch on
                                       // stream 1 the plan is now +1.2 % faster (26.1 k vs 25.8 k frames/s), and — caller + ONE side stream —
                                       // it leaves room for RCCL's stream: all-gather overhead at world size 1 9 % -> 1.5-4.5 %
-    int side_low_priority = 3;        // option "side_priority" (with head_stream = 0): bit k set = side stream k+1 is created at the
+    int side_low_priority = 2;        // option "side_priority" (with head_stream = 0): bit k set = side stream k+1 is created at the
                                       // lowest stream priority
     bool pipeline = false;            // option "pipeline": consecutive forwards overlap.  The segmentation decoders move from the caller's stream
                                       // to side stream 2 (ahead of fusion + head), the caller's stream is done after the neck, and NOTHING is
