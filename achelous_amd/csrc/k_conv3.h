@@ -170,8 +170,11 @@ struct RcFrontParams {
 
 // NARROW (bf16 storage, the first RCBlock: 3 channels): the maps are carried as 4-channel = 8-BYTE pixels (ldp = ldr = ldy = 4, cv = 1).
 // A corner of the sampling and a tap of the conv are one 8-byte load each; a k-slot is one tap x [4 channels | 4 zeros].
+#ifndef ACH_RCF_WIDE_WAVES
+#define ACH_RCF_WIDE_WAVES 1
+#endif
 template <class T, int KS, bool NARROW>
-__global__ __launch_bounds__(256, KS == 3 ? 4 : 1) void rc_front_kernel(const RcFrontParams p) {
+__global__ __launch_bounds__(256, KS == 3 ? 4 : ACH_RCF_WIDE_WAVES) void rc_front_kernel(const RcFrontParams p) {
     constexpr int VEC = Store<T>::VEC;
     __shared__ float oml[4][16][36];                               // per wave: [pixel][27 values], row padded against bank conflicts
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -322,8 +322,16 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, unsigned bx, unsi
     }
 }
 
+#ifndef ACH_GEMM_WAVES
+#define ACH_GEMM_WAVES 0
+#endif
+#if ACH_GEMM_WAVES > 0
+#define ACH_GEMM_BOUNDS __launch_bounds__(256, ACH_GEMM_WAVES)
+#else
+#define ACH_GEMM_BOUNDS __launch_bounds__(256)
+#endif
 template <class T, int NT, int P, bool DEEP = false>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) { gemm_body<T, NT, P, DEEP>(p, blockIdx.x, gridDim.x, blockIdx.y, blockIdx.z); }
+__global__ ACH_GEMM_BOUNDS void gemm_kernel(const GemmParams p) { gemm_body<T, NT, P, DEEP>(p, blockIdx.x, gridDim.x, blockIdx.y, blockIdx.z); }
 
 // Up to three independent GEMMs of the same tile shape in one launch (blockIdx.y = job): the three pyramid levels of the
 // detection head run the same layer on maps of 1600 / 400 / 100 pixels — the small levels ride in the big level's launch
@@ -350,8 +358,16 @@ struct GemmMaxParams {
 // KH > 0: the chunk's KH x NT weight fragments are loaded once and stay in registers for all the row tiles a wave walks
 // (K <= 128: the 128 -> 1024 convs of the PointNet transforms, where re-reading 16 fragments per 16 rows made the kernel
 // L1-bound at 190 TFLOP/s).
+#ifndef ACH_COLMAX_WAVES
+#define ACH_COLMAX_WAVES 0
+#endif
+#if ACH_COLMAX_WAVES > 0
+#define ACH_COLMAX_BOUNDS __launch_bounds__(256, ACH_COLMAX_WAVES)
+#else
+#define ACH_COLMAX_BOUNDS __launch_bounds__(256)
+#endif
 template <class T, int NT, int KH>
-__global__ __launch_bounds__(256) void gemm_colmax_kernel(const GemmMaxParams p) {
+__global__ ACH_COLMAX_BOUNDS void gemm_colmax_kernel(const GemmMaxParams p) {
     constexpr int VEC = Store<T>::VEC;
     constexpr int KC = 4 * VEC;
     __shared__ float red[4][16 * NT];

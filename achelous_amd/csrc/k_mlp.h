@@ -441,8 +441,16 @@ namespace ach {
 #define ACH_CHAIN_TILES 4
 #endif
 constexpr int CHAIN_TILES_PER_WAVE = ACH_CHAIN_TILES;
+#ifndef ACH_CHAIN_WAVES
+#define ACH_CHAIN_WAVES 0
+#endif
+#if ACH_CHAIN_WAVES > 0
+#define ACH_CHAIN_BOUNDS __launch_bounds__(256, ACH_CHAIN_WAVES)
+#else
+#define ACH_CHAIN_BOUNDS __launch_bounds__(256)
+#endif
 template <class T, int K1, int J>
-__global__ __launch_bounds__(256) void chain_kernel(const MlpParams p) {
+__global__ ACH_CHAIN_BOUNDS void chain_kernel(const MlpParams p) {
     constexpr int VEC = Store<T>::VEC;
     constexpr int KC = 4 * VEC;
     constexpr int HSTEP = 8 / VEC;

@@ -104,8 +104,16 @@ __global__ __launch_bounds__(256) void dwconv_strip_multi_kernel(const DwJobs m)
 }
 
 // general kernel (any stride): one thread = 4 channels of one output pixel
+#ifndef ACH_DWK_WAVES
+#define ACH_DWK_WAVES 0
+#endif
+#if ACH_DWK_WAVES > 0
+#define ACH_DWK_BOUNDS __launch_bounds__(256, ACH_DWK_WAVES)
+#else
+#define ACH_DWK_BOUNDS __launch_bounds__(256)
+#endif
 template <class T, int KS>
-__global__ __launch_bounds__(256) void dwconv_kernel(const DwParams p) {
+__global__ ACH_DWK_BOUNDS void dwconv_kernel(const DwParams p) {
     const int cq = p.C >> 2;
     const long total = long(p.B) * p.Ho * p.Wo * cq;
     const long idx = long(xcd_block(blockIdx.x, gridDim.x)) * blockDim.x + threadIdx.x;

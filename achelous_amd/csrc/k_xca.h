@@ -85,8 +85,18 @@ __global__ __launch_bounds__(256) void xca_gram_kernel(const XcaGramParams p) {
 // their diagonals are stored).  A head's tiles start at its first channel, not at a multiple of 16; rows that belong to the next head
 // produce entries that are simply not stored.  Same output layout as xca_gram_kernel; the sums differ from it only in the order of the
 // fp32 additions.  (One head per workgroup was slower than the VALU kernel for d <= 18: 16- / 24-byte pieces of every token row.)
+// register budget of the MFMA Gram kernel: left to itself the compiler takes 188 VGPRs (two workgroups per CU) for a kernel that fits 97 without a
+// spill; at four waves per SIMD the three Gram launches go 20 / 16 / 20 -> 16 / 13 / 19 us and the step gains 1.6 % (round 3, occupancy table of DESIGN 7)
+#ifndef ACH_XCA_WAVES
+#define ACH_XCA_WAVES 4
+#endif
+#if ACH_XCA_WAVES > 0
+#define ACH_XCA_BOUNDS __launch_bounds__(256, ACH_XCA_WAVES)
+#else
+#define ACH_XCA_BOUNDS __launch_bounds__(256)
+#endif
 template <class T, int XCA_DMAX>
-__global__ __launch_bounds__(256) void xca_gram_mfma_kernel(const XcaGramParams p) {
+__global__ ACH_XCA_BOUNDS void xca_gram_mfma_kernel(const XcaGramParams p) {
     constexpr int VEC = Store<T>::VEC, KC = 4 * VEC;        // tokens per MFMA k-step
     constexpr int CH = 4 * KC;                              // tokens staged per round
     constexpr int PITCH = CH + VEC;                         // + 16 bytes: rows land on different banks
