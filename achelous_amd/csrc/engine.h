@@ -105,8 +105,9 @@ public:
                                       // first RCBlock's shortcut shortened the radar branch: with the head queued BEHIND the radar branch on
                                       // stream 1 the plan is now +1.2 % faster (26.1 k vs 25.8 k frames/s), and — caller + ONE side stream —
                                       // it leaves room for RCCL's stream: all-gather overhead at world size 1 9 % -> 1.5-4.5 %
-    int side_low_priority = 2;        // option "side_priority" (with head_stream = 0): bit k set = side stream k+1 is created at the
-                                      // lowest stream priority
+    int side_low_priority = 3;        // option "side_priority" (with head_stream = 0): bit k set = side stream k+1 is created at the
+                                      // lowest stream priority.  (2 = only the decoders' stream low is +0.8 % without a collective and -19 % WITH RCCL's stream
+                                      // beside the engine's: 30.9 k against 37.7 k frames/s with the all-gather forced at world size 1 — both streams stay low.)
     bool pipeline = false;            // option "pipeline": consecutive forwards overlap.  The segmentation decoders move from the caller's stream
                                       // to side stream 2 (ahead of fusion + head), the caller's stream is done after the neck, and NOTHING is
                                       // joined at the end of ach_forward: the caller enqueues the next forward first and then calls ach_join
