@@ -257,7 +257,9 @@ public:
                     bytes += j.bytes; flops += j.flops;
                 }
                 const dim3 grid(static_cast<unsigned>(wg)), block(HDW_THREADS);
-                add_op(name, [hp, grid, block](hipStream_t s) { ACH_LAUNCH((headdw_kernel<bf16_t>), grid, block, s, hp); }, bytes, flops);
+                // (if constexpr: instantiated by the bf16 engine's translation unit ONLY — see fused_mlp_lin)
+                if constexpr (std::is_same<T, bf16_t>::value)
+                    add_op(name, [hp, grid, block](hipStream_t s) { ACH_LAUNCH((headdw_kernel<bf16_t>), grid, block, s, hp); }, bytes, flops);
             } else {
                 DwJobs m;
                 std::memset(&m, 0, sizeof(m));

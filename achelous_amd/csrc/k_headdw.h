@@ -5,7 +5,7 @@
 //                                                                         backbone/conv_utils/normal_conv.py:23-52)
 // It was two launches per layer for the three pyramid levels: `dwconv_strip_multi<5>` — every input element fetched 25 times through the
 // texture path (TA 49 % busy, 58-64 us, and the reason the decoders' tail stretches beside it) — writing a 128-channel tensor that the
-// block-diagonal 128 x 128 GEMM (31 us) read straight back.  Here a workgroup (128 threads, see ACH_HDW_THREADS) owns (frame, band of rows, tower):
+// block-diagonal 128 x 128 GEMM (31 us) read straight back.  Here a workgroup (256 threads, see ACH_HDW_THREADS) owns (frame, band of rows, tower):
 //   0. the band's halo (rows + 4, columns + 4, the tower's 64 input channels) is staged in LDS once, unpacked to fp32;
 //   1. depthwise 5 x 5 from LDS: thread = 5-pixel strip x 4 channels (a tap row: 9 LDS reads for 5 x 5 x 4 FMAs); the sums are written
 //      back to LDS as the bf16 B fragments of the pointwise GEMM — the depthwise output never exists in HBM;
@@ -17,9 +17,10 @@
 namespace ach {
 
 #ifndef ACH_HDW_THREADS
-#define ACH_HDW_THREADS 128           // measured (one box, alternating): 512 threads 36.3 k frames/s, 256: 36.8 k, 128: 37.4 k — the workgroup holds 64 KB of LDS whatever
-                                      // its size, and the fewer wave slots it takes the more of the CU is left to the other streams (isolated 62 / 53 / 51 us).
-                                      // Tried on top: the fragments written over the halo tile (45 KB, sums in registers across the barrier): 51 -> 60 us, -2 %.
+#define ACH_HDW_THREADS 256           // measured (one box, alternating, three runs): 512 threads 37.57 k frames/s (60 us isolated), 256: 38.55 k (47 us), 128: 38.10 k (70 us).
+                                      // (The first comparison of this knob measured a kernel that the fp32 engine's translation unit had ALSO instantiated: the runtime ran
+                                      // that copy — compiled for 512 threads — under a 128-thread launch, i.e. a quarter of the work.  The launch is behind `if constexpr` now.)
+                                      // Tried on top: the fragments written over the halo tile (45 KB, sums in registers across the barrier): slower.
 #endif
 #ifndef ACH_HDW_WGS
 #define ACH_HDW_WGS 4
