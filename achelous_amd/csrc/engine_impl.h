@@ -1102,7 +1102,7 @@ public:
             return;
         }
         const dim3 block(UGH_THREADS);
-        if (planar) {
+        if constexpr (std::is_same<T, bf16_t>::value) if (planar) {
             const int tw = 16 * UGM_NSEG - 4;
             const unsigned tiles = unsigned(cdiv(2 * x.W, tw)) * unsigned(cdiv(2 * x.H, UGM_TH)) * unsigned(x.B);
             const unsigned cap = head_grid > 0 ? unsigned(head_grid) : (UGM_GRID > 0 ? unsigned(UGM_GRID) : tiles);
