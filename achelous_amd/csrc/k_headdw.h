@@ -20,11 +20,14 @@ namespace ach {
 #define ACH_HDW_THREADS 256           // measured (one box, alternating, three runs): 512 threads 37.57 k frames/s (60 us isolated), 256: 38.55 k (47 us), 128: 38.10 k (70 us).
                                       // (The first comparison of this knob measured a kernel that the fp32 engine's translation unit had ALSO instantiated: the runtime ran
                                       // that copy — compiled for 512 threads — under a 128-thread launch, i.e. a quarter of the work.  The launch is behind `if constexpr` now.)
-                                      // Tried on top: the fragments written over the halo tile (45 KB, sums in registers across the barrier): slower.
 #endif
 #ifndef ACH_HDW_WGS
 #define ACH_HDW_WGS 4
 #endif
+#ifndef ACH_HDW_ALIAS
+#define ACH_HDW_ALIAS 1               // the B fragments are written over the halo tile (the depthwise sums wait in registers across a barrier): 45 KB of LDS, three workgroups per CU; 49 -> 43 us, +0.7 % end to end
+#endif
+constexpr int HDW_MAXIT = 1024 / ACH_HDW_THREADS;        // strips x channel quads per thread in the aliased form (engine: rows * strips * 16 <= 1024)
 constexpr int HDW_THREADS = ACH_HDW_THREADS, HDW_SP = 5, HDW_C = 64, HDW_MAXPOS = 8 * 44, HDW_MAXT = 10;
 #ifndef ACH_HDW_F32
 #define ACH_HDW_F32 0             // 1: the halo tile is staged as fp32 (90 KB: one workgroup per CU, 78 us); 0: as bf16 (45 KB: two per CU, taps unpacked in the loop, 48 us)
@@ -48,8 +51,12 @@ struct HeadDwParams {
 template <class T>          // (bf16_t; a template so that the two engine translation units can both include the header)
 __global__ __launch_bounds__(HDW_THREADS, HDW_WGS) void headdw_kernel(const HeadDwParams p) {
     constexpr int C = HDW_C, SP = HDW_SP, KS = 5;
-    __shared__ float xin[HDW_F32 ? HDW_MAXPOS * C : HDW_MAXPOS * C / 2];       // 90 KB (fp32) / 45 KB (bf16)
+    __shared__ __attribute__((aligned(16))) float xin[HDW_F32 ? HDW_MAXPOS * C : HDW_MAXPOS * C / 2];       // 90 KB (fp32) / 45 KB (bf16)
+#if ACH_HDW_ALIAS
+    uint4* const xs = reinterpret_cast<uint4*>(xin);            // the B fragments go OVER the halo tile
+#else
     __shared__ uint4 xs[HDW_MAXT * 2 * 64];                     // 20 KB: B fragments of the band's tiles
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int px = lane & 15, g = lane >> 4;
     int ji = 0;
@@ -96,6 +103,83 @@ __global__ __launch_bounds__(HDW_THREADS, HDW_WGS) void headdw_kernel(const Head
             }
         }
     }
+#if ACH_HDW_ALIAS
+    // ---- 1. depthwise 5 x 5 from LDS: thread = strip of SP pixels x 4 channels.  The bf16 sums wait in registers until every thread is done
+    // with the halo tile, then go OVER it as the B fragments of the pointwise GEMM (one LDS buffer: 45 KB, three workgroups per CU instead of two)
+    __syncthreads();
+    constexpr int C4 = C / 4;
+    const int nstrip = (W + SP - 1) / SP, total = rows * nstrip * C4;
+    uint2 res[HDW_MAXIT][SP];
+    if (!(p.dbg & 2)) {
+        const float* wdw = J.Wdw + br * C;
+        ACH_UNROLL
+        for (int k = 0; k < HDW_MAXIT; ++k) {
+            const int it = tid + k * HDW_THREADS;
+            if (it >= total) break;
+            const int cg = it % C4, rest = it / C4, q = rest % nstrip, r = rest / nstrip;
+            const int x0 = q * SP;
+            f32x2 acc[SP][2];
+            ACH_UNROLL
+            for (int i = 0; i < SP; ++i) { acc[i][0] = f32x2{0.f, 0.f}; acc[i][1] = f32x2{0.f, 0.f}; }
+            ACH_NO_UNROLL
+            for (int ty = 0; ty < KS; ++ty) {
+                f32x2 v[SP + KS - 1][2];
+                ACH_UNROLL
+                for (int j = 0; j < SP + KS - 1; ++j) {
+                    const int col = x0 + j < WCr ? x0 + j : WCr - 1;
+                    if (HDW_F32) {
+                        const float4 t = *reinterpret_cast<const float4*>(xin + ((r + ty) * WCr + col) * C + cg * 4);
+                        v[j][0] = f32x2{t.x, t.y}; v[j][1] = f32x2{t.z, t.w};
+                    } else {
+                        const uint2 t = reinterpret_cast<const uint2*>(xin)[((r + ty) * WCr + col) * (C / 4) + cg];
+                        v[j][0] = f32x2{__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u)};
+                        v[j][1] = f32x2{__uint_as_float(t.y << 16), __uint_as_float(t.y & 0xffff0000u)};
+                    }
+                }
+                ACH_UNROLL
+                for (int tx = 0; tx < KS; ++tx) {
+                    const float4 w = *reinterpret_cast<const float4*>(wdw + long(ty * KS + tx) * (2 * C) + cg * 4);
+                    const f32x2 w0 = {w.x, w.y}, w1 = {w.z, w.w};
+                    ACH_UNROLL
+                    for (int i = 0; i < SP; ++i) { acc[i][0] += w0 * v[i + tx][0]; acc[i][1] += w1 * v[i + tx][1]; }
+                }
+            }
+            ACH_UNROLL
+            for (int i = 0; i < SP; ++i) {
+                res[k][i].x = pack_bf16x2(acc[i][0][0], acc[i][0][1]);
+                res[k][i].y = pack_bf16x2(acc[i][1][0], acc[i][1][1]);
+#if !defined(ACH_HOSTEMU)
+                asm volatile("" : "+v"(res[k][i].x), "+v"(res[k][i].y));          // the sums exist BEFORE the barrier (k_upchain.h: the compiler sinks them otherwise)
+#endif
+            }
+        }
+    }
+    __syncthreads();
+    // the pointwise weights of this tower: 2 k-steps x 4 output tiles
+    uint4 wp[2][4];
+    ACH_UNROLL
+    for (int s = 0; s < 2; ++s) { ACH_UNROLL for (int t = 0; t < 4; ++t) wp[s][t] = J.Wp[((br * 2 + s) * 4 + t) * 64 + lane]; }
+    // fragments of the (ragged) last tile must not hold garbage
+    for (int i = tid; i < nt * 2 * 64; i += HDW_THREADS) xs[i] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+    if (!(p.dbg & 2)) {
+        ACH_UNROLL
+        for (int k = 0; k < HDW_MAXIT; ++k) {
+            const int it = tid + k * HDW_THREADS;
+            if (it >= total) break;
+            const int cg = it % C4, rest = it / C4, q = rest % nstrip, r = rest / nstrip;
+            const int x0 = q * SP;
+            const int c0 = cg * 4, s = c0 >> 5, gg = (c0 & 31) >> 3, e = c0 & 7;          // k-step, lane group and element of these 4 channels
+            ACH_UNROLL
+            for (int i = 0; i < SP; ++i) {
+                if (x0 + i >= W) continue;
+                const int pix = r * W + x0 + i, t = pix >> 4, pp = pix & 15;
+                *reinterpret_cast<uint2*>(reinterpret_cast<char*>(xs + (t * 2 + s) * 64 + gg * 16 + pp) + e * 2) = res[k][i];
+            }
+        }
+    }
+    __syncthreads();
+#else
     // the pointwise weights of this tower: 2 k-steps x 4 output tiles
     uint4 wp[2][4];
     ACH_UNROLL
@@ -150,6 +234,7 @@ __global__ __launch_bounds__(HDW_THREADS, HDW_WGS) void headdw_kernel(const Head
         }
     }
     __syncthreads();
+#endif
     // ---- 2. pointwise 64 x 64 on MFMA, + bias, ReLU; lane (px, g) of tile pair q holds output channels q*32 + g*8 .. +7
     T* Y = static_cast<T*>(J.Y) + long(b) * H * W * J.ldy + br * C;
     const float* bias = J.bias + br * C;
@@ -181,7 +266,7 @@ __global__ __launch_bounds__(HDW_THREADS, HDW_WGS) void headdw_kernel(const Head
 
 inline int headdw_band_rows(int H, int W) {            // the band's halo must fit HDW_MAXPOS positions and its pixels HDW_MAXT tiles
     for (int rb = H; rb >= 1; --rb)
-        if ((rb + 4) * (W + 4) <= HDW_MAXPOS && (rb * W + 15) / 16 <= HDW_MAXT) return rb;
+        if ((rb + 4) * (W + 4) <= HDW_MAXPOS && (rb * W + 15) / 16 <= HDW_MAXT && (!ACH_HDW_ALIAS || rb * ((W + HDW_SP - 1) / HDW_SP) * (HDW_C / 4) <= 1024)) return rb;
     return 0;
 }
 
