@@ -108,6 +108,7 @@ int ach_set_option(ach_handle* h, const char* key, int32_t value) {
         else if (std::string(key) == "head_mfma") h->eng->head_mfma = value != 0;
         else if (std::string(key) == "head_rows") h->eng->head_rows = value;
         else if (std::string(key) == "xwait2_op") h->eng->dbg_xwait2_op = value;
+        else if (std::string(key) == "gemm_blocks") h->eng->gemm_blocks = value;
         else if (std::string(key) == "sdta_fuse") h->eng->sdta_fuse = value;
         else if (std::string(key) == "level_chain") h->eng->level_chain = value != 0;
         else if (std::string(key) == "level_rows") h->eng->level_rows = value != 0;

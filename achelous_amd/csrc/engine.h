@@ -82,6 +82,7 @@ public:
                                       // fused block — 29.1 k against 27.7 k frames/s: the per-workgroup weight staging and tables were a fifth of these kernels)
     bool radar_compact = true;        // option "radar_compact": first RCBlock — the active PIXELS of a row are compacted into dense tiles (k_conv3.h; needs radar_skip and four-row workgroups)
     bool radar_skip = true;           // option "radar_skip": first RCBlock — closed-form shortcut on 16-pixel segments whose neighbourhood of the radar map is empty (k_conv3.h)
+    int gemm_blocks = 0;          // option "gemm_blocks": workgroups a GEMM launch aims for when the rows alone do not fill the chip (0 = 1024: four per CU)
     int sdta_fuse = 1;            // option "sdta_fuse": an SDTA encoder's conv cascade + tail copy + positional encoding as one launch (k_sdta.h): 1 = on maps of at most 20 x 20, 2 = every map that fits, 0 = never
     bool level_chain = true;      // option "level_chain": bf16 production plans — a decoder level's kernel also applies the next level's low-resolution conv pair (k_upchain.h)
     int dbg_xwait2_op = -1;       // option "xwait2_op" (debugging a pipelined race): the launch index that waits for the previous forward's decoders instead of the planned one

@@ -177,7 +177,7 @@ public:
         // N-chunks over blockIdx.z when the row count alone cannot fill 256 CUs (10x10 / 20x20 maps, FC layers).
         // (measured on MI355X, tests/gpu_gemm_bench.py: one 16-row sub-tile per wave beats 2 or 4 at every shape of this
         //  network — the kernel is latency/bandwidth bound and lives on occupancy, not on weight-fragment reuse)
-        const long kTargetBlocks = 1024;
+        const long kTargetBlocks = gemm_blocks > 0 ? gemm_blocks : 1024;
         // ... except the dense 3x3 convs of the MobileViT blocks (K = 9 x 2C = 2592 .. 4320): every 16-row tile re-reads the whole packed
         // weight (0.5-0.9 MB) from L2, so two / four sub-tiles per wave halve / quarter that stream (option `gemm_rows`: sub-tiles per wave for K >= 1024)
         int P = (!batching && pk.K >= 1024 && o.groups == 1 && gemm_rows > 1) ? gemm_rows : 1;
