@@ -1173,9 +1173,21 @@ public:
         const bool split_dec = split_decoders != 0;
         // residual FPN outputs (ghostdualfpn.py:200) — computed BEFORE the decoders so that the detection branch (fusion + head,
         // on the radar stream) can start while the two heavy decoders still run on this stream
-        q[0] = alloc(p3.B, p3.H, p3.W, p3.C); add(f + ".q3", p3, m3, q[0]);
-        q[1] = alloc(p4.B, p4.H, p4.W, p4.C); add(f + ".q4", p4, m4, q[1]);
-        q[2] = alloc(p5.B, p5.H, p5.W, p5.C); add(f + ".q5", p5, m5, q[2]);
+        q[0] = alloc(p3.B, p3.H, p3.W, p3.C);
+        q[1] = alloc(p4.B, p4.H, p4.W, p4.C);
+        q[2] = alloc(p5.B, p5.H, p5.W, p5.C);
+        {   // the three adds as one launch (they were 6-10 us launch floors on the caller's stream)
+            const A* pa[3] = {&p3, &p4, &p5}; const A* pb[3] = {&m3, &m4, &m5};
+            AddJobs aj; aj.n = 3;
+            long mx = 0; double bytes = 0;
+            for (int k = 0; k < 3; ++k) {
+                aj.j[k] = AddParams{pa[k]->p, pa[k]->ld, pb[k]->p, pb[k]->ld, q[k].p, q[k].ld, pa[k]->rows(), pa[k]->C};
+                mx = std::max(mx, pa[k]->rows() * (pa[k]->C / 4));
+                bytes += 3.0 * pa[k]->rows() * pa[k]->C * sizeof(T);
+            }
+            const dim3 grid(unsigned(cdivl(mx, 256)), 3), block(256);
+            add_op(f + ".q3+q4+q5", [aj, grid, block](hipStream_t s) { ACH_LAUNCH(add_multi_kernel<T>, grid, block, s, aj); }, bytes);
+        }
         signal_after_last(1);
         // two segmentation decoders
         const char* names[2] = {"lane", "se"};

@@ -498,6 +498,23 @@ __global__ __launch_bounds__(256) void add_kernel(const AddParams p) {
     for (int i = 0; i < 4; ++i) a[i] += b[i];
     Store<T>::st4(static_cast<T*>(p.Y) + r * p.ldy + c, a);
 }
+// up to three independent adds in one launch (the neck's three residual outputs q3 / q4 / q5: blockIdx.y = job)
+struct AddJobs { AddParams j[3]; int n; };
+template <class T>
+__global__ __launch_bounds__(256) void add_multi_kernel(const AddJobs m) {
+    const AddParams& p = m.j[blockIdx.y];
+    const int cq = p.C >> 2;
+    const long idx = long(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (idx >= p.rows * cq) return;
+    const int c = int(idx % cq) * 4;
+    const long r = idx / cq;
+    float a[4], b[4];
+    Store<T>::ld4(static_cast<const T*>(p.A) + r * p.lda + c, a);
+    Store<T>::ld4(static_cast<const T*>(p.Bp) + r * p.ldb + c, b);
+    ACH_UNROLL
+    for (int i = 0; i < 4; ++i) a[i] += b[i];
+    Store<T>::st4(static_cast<T*>(p.Y) + r * p.ldy + c, a);
+}
 // copy a [rows, C] view (optionally adding a per-position constant [HW][C] fp32: the folded Fourier pos-enc)
 struct CopyParams { const void* X; long ldx; void* Y; long ldy; long rows; int C; const float* posenc; int HW; };
 template <class T>
