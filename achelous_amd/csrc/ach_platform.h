@@ -4,6 +4,7 @@
 #pragma once
 #include <cstdint>
 #include <cstddef>
+#include <type_traits>
 
 #if defined(ACH_HOSTEMU)
 #include "hostemu.h"
@@ -67,6 +68,91 @@ __host__ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 __host__ __device__ __forceinline__ uint16_t f32_to_bf16(float f) { return f32_to_bf16_bits(f); }
 #endif
 
+
+// fp16 storage (round 4): same bytes and the same MFMA rate as bf16 with an 8x finer mantissa (11 bits against 8); it is also the type the
+// reference's own mixed-precision mode computes in (torch.cuda.amp.autocast, utils/utils_fit.py:120-121; train.py:37 --fp16).  Round to
+// nearest even; the host form below is what the weight packers and the CPU emulation use, the device uses v_cvt_pk_f16_f32 / v_cvt_f32_f16.
+struct f16_t { uint16_t bits; };
+
+__host__ __device__ __forceinline__ uint16_t f32_to_f16_bits(float f) {
+    union { uint32_t u; float f; } c;
+    c.f = f;
+    const uint32_t sign = (c.u >> 16) & 0x8000u;
+    const uint32_t x = c.u & 0x7fffffffu;
+    if (x >= 0x7f800000u) return uint16_t(sign | (x > 0x7f800000u ? 0x7e00u : 0x7c00u));
+    const uint32_t e = x >> 23;
+    if (e >= 143u) return uint16_t(sign | 0x7c00u);                        // >= 65536: infinity
+    if (e <= 112u) {                                                       // below 2^-14: subnormal or zero, unit 2^-24
+        if (x < 0x33000000u) return uint16_t(sign);                        // < 2^-25 (a tie at 2^-25 rounds to even = 0)
+        const uint32_t m = (x & 0x7fffffu) | 0x800000u, s = 126u - e;      // value = m * 2^(e - 126) units
+        uint32_t r = m >> s;
+        const uint32_t rem = m & ((1u << s) - 1u), half = 1u << (s - 1u);
+        if (rem > half || (rem == half && (r & 1u))) ++r;
+        return uint16_t(sign | r);
+    }
+    uint32_t r = ((e - 112u) << 10) | ((x & 0x7fffffu) >> 13);
+    const uint32_t rem = x & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (r & 1u))) ++r;                // a carry into the exponent is the right answer (up to infinity)
+    return uint16_t(sign | r);
+}
+__host__ __device__ __forceinline__ float f16_bits_to_f32(uint16_t h) {
+    union { uint32_t u; float f; } c;
+    const uint32_t sign = uint32_t(h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
+    if (e == 0x1fu) c.u = sign | 0x7f800000u | (m << 13);
+    else if (e != 0u) c.u = sign | ((e + 112u) << 23) | (m << 13);
+    else if (m == 0u) c.u = sign;
+    else {                                                                 // subnormal: m * 2^-24, exactly representable
+        c.f = float(m) * 5.9604644775390625e-08f;
+        c.u |= sign;
+    }
+    return c.f;
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef _Float16 f16x2_hw __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {
+    const f32x2_hw v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_hw));              // v_cvt_pk_f16_f32
+}
+__device__ __forceinline__ uint16_t f32_to_f16(float f) { return __builtin_bit_cast(uint16_t, static_cast<_Float16>(f)); }
+__device__ __forceinline__ float f16_to_f32(uint16_t h) { return float(__builtin_bit_cast(_Float16, h)); }
+__device__ __forceinline__ float f16lo_to_f32(uint32_t w) { return float(__builtin_bit_cast(f16x2_hw, w).x); }     // v_cvt_f32_f16
+__device__ __forceinline__ float f16hi_to_f32(uint32_t w) { return float(__builtin_bit_cast(f16x2_hw, w).y); }     // v_cvt_f32_f16_sdwa WORD_1
+#else
+__host__ __device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {
+    return uint32_t(f32_to_f16_bits(lo)) | (uint32_t(f32_to_f16_bits(hi)) << 16);
+}
+__host__ __device__ __forceinline__ uint16_t f32_to_f16(float f) { return f32_to_f16_bits(f); }
+__host__ __device__ __forceinline__ float f16_to_f32(uint16_t h) { return f16_bits_to_f32(h); }
+__host__ __device__ __forceinline__ float f16lo_to_f32(uint32_t w) { return f16_bits_to_f32(uint16_t(w & 0xffffu)); }
+__host__ __device__ __forceinline__ float f16hi_to_f32(uint32_t w) { return f16_bits_to_f32(uint16_t(w >> 16)); }
+#endif
+
+// the two 16-bit storage types behind one interface: a dword holds two consecutive elements (low half first)
+template <class T> struct is_h16 { static constexpr bool value = false; };
+template <> struct is_h16<bf16_t> { static constexpr bool value = true; };
+template <> struct is_h16<f16_t> { static constexpr bool value = true; };
+template <class T> struct H16;
+template <> struct H16<bf16_t> {
+    __host__ __device__ static __forceinline__ uint16_t bits(float v) { return f32_to_bf16_bits(v); }         // host packers (RNE, identical to the device's)
+    __host__ __device__ static __forceinline__ float lo(uint32_t w) { union { uint32_t u; float f; } c; c.u = w << 16; return c.f; }
+    __host__ __device__ static __forceinline__ float hi(uint32_t w) { union { uint32_t u; float f; } c; c.u = w & 0xffff0000u; return c.f; }
+    __host__ __device__ static __forceinline__ uint32_t pack(float a, float b) { return pack_bf16x2(a, b); }
+    __host__ __device__ static __forceinline__ float round(float v) { return bf16_to_f32(f32_to_bf16(v)); }
+};
+template <> struct H16<f16_t> {
+    __host__ __device__ static __forceinline__ uint16_t bits(float v) { return f32_to_f16_bits(v); }
+    __host__ __device__ static __forceinline__ float lo(uint32_t w) { return f16lo_to_f32(w); }
+    __host__ __device__ static __forceinline__ float hi(uint32_t w) { return f16hi_to_f32(w); }
+    __host__ __device__ static __forceinline__ uint32_t pack(float a, float b) { return pack_f16x2(a, b); }
+    __host__ __device__ static __forceinline__ float round(float v) { return f16_to_f32(f32_to_f16(v)); }
+};
+
+// a dword of two IO elements as a dword of two T elements (identity when the types agree)
+template <class IO, class T> __host__ __device__ __forceinline__ uint32_t h16_recast(uint32_t w) {
+    if constexpr (std::is_same<IO, T>::value || !is_h16<IO>::value || !is_h16<T>::value) return w;
+    else return H16<T>::pack(H16<IO>::lo(w), H16<IO>::hi(w));
+}
+
 template <class T> struct Store;
 template <> struct Store<float> {
     static constexpr int VEC = 4;          // elements per 16 bytes
@@ -119,6 +205,42 @@ template <> struct Store<bf16_t> {
     }
 };
 
+template <> struct Store<f16_t> {
+    static constexpr int VEC = 8;
+    __host__ __device__ static __forceinline__ float ld(const f16_t* p) { return f16_to_f32(p->bits); }
+    __host__ __device__ static __forceinline__ void st(f16_t* p, float v) { p->bits = f32_to_f16(v); }
+    __device__ static __forceinline__ void ld4(const f16_t* p, float (&o)[4]) {
+        const uint2 v = *reinterpret_cast<const uint2*>(p);
+        o[0] = f16lo_to_f32(v.x); o[1] = f16hi_to_f32(v.x); o[2] = f16lo_to_f32(v.y); o[3] = f16hi_to_f32(v.y);
+    }
+    __device__ static __forceinline__ void st4(f16_t* p, const float (&i)[4]) {
+        uint2 v;
+        v.x = pack_f16x2(i[0], i[1]);
+        v.y = pack_f16x2(i[2], i[3]);
+        *reinterpret_cast<uint2*>(p) = v;
+    }
+    __device__ static __forceinline__ void ld8(const f16_t* p, float (&o)[8]) {
+        const uint4 v = *reinterpret_cast<const uint4*>(p);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        for (int k = 0; k < 4; ++k) { o[2 * k] = f16lo_to_f32(w[k]); o[2 * k + 1] = f16hi_to_f32(w[k]); }
+    }
+    __device__ static __forceinline__ void st8(f16_t* p, const float (&i)[8]) {
+        uint32_t w[4];
+        for (int k = 0; k < 4; ++k) w[k] = pack_f16x2(i[2 * k], i[2 * k + 1]);
+        *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+};
+
+// element i of a tensor the CALLER owns (network outputs): the storage type, or — fp16-storage engine with bf16 inputs / outputs — bf16
+template <class T> __device__ __forceinline__ void st_user(void* Y, long i, float v, bool alt_bf16) {
+    if constexpr (std::is_same<T, f16_t>::value) { if (alt_bf16) { Store<bf16_t>::st(static_cast<bf16_t*>(Y) + i, v); return; } }
+    Store<T>::st(static_cast<T*>(Y) + i, v);
+}
+template <class T> __device__ __forceinline__ float ld_user(const void* X, long i, bool alt_bf16) {
+    if constexpr (std::is_same<T, f16_t>::value) { if (alt_bf16) return Store<bf16_t>::ld(static_cast<const bf16_t*>(X) + i); }
+    return Store<T>::ld(static_cast<const T*>(X) + i);
+}
+
 // unpack one 16-byte fragment (4 f32 or 8 bf16) to floats / pack it back
 template <class T> __device__ __forceinline__ void frag_unpack(const uint4& f, float* o);
 template <> __device__ __forceinline__ void frag_unpack<float>(const uint4& f, float* o) {
@@ -129,6 +251,11 @@ template <> __device__ __forceinline__ void frag_unpack<bf16_t>(const uint4& f, 
     ACH_UNROLL
     for (int i = 0; i < 4; ++i) { o[2 * i] = bf16_to_f32(uint16_t(w[i] & 0xffffu)); o[2 * i + 1] = bf16_to_f32(uint16_t(w[i] >> 16)); }
 }
+template <> __device__ __forceinline__ void frag_unpack<f16_t>(const uint4& f, float* o) {
+    const uint32_t w[4] = {f.x, f.y, f.z, f.w};
+    ACH_UNROLL
+    for (int i = 0; i < 4; ++i) { o[2 * i] = f16lo_to_f32(w[i]); o[2 * i + 1] = f16hi_to_f32(w[i]); }
+}
 template <class T> __device__ __forceinline__ uint4 frag_pack(const float* i);
 template <> __device__ __forceinline__ uint4 frag_pack<float>(const float* i) {
     return make_uint4(__float_as_uint(i[0]), __float_as_uint(i[1]), __float_as_uint(i[2]), __float_as_uint(i[3]));
@@ -137,6 +264,13 @@ template <> __device__ __forceinline__ uint4 frag_pack<bf16_t>(const float* i) {
     uint32_t w[4];
     ACH_UNROLL
     for (int k = 0; k < 4; ++k) w[k] = pack_bf16x2(i[2 * k], i[2 * k + 1]);
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+template <> __device__ __forceinline__ uint4 frag_pack<f16_t>(const float* i) {
+    uint32_t w[4];
+    ACH_UNROLL
+    for (int k = 0; k < 4; ++k) w[k] = pack_f16x2(i[2 * k], i[2 * k + 1]);
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
@@ -177,6 +311,10 @@ template <class T> __device__ inline void mfma16(const uint4& a, const uint4& b,
 typedef __bf16 bf16x8_hw __attribute__((ext_vector_type(8)));
 template <> __device__ __forceinline__ void mfma16<bf16_t>(const uint4& a, const uint4& b, f32x4& c) {
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_hw, a), __builtin_bit_cast(bf16x8_hw, b), c, 0, 0, 0);
+}
+typedef _Float16 f16x8_hw __attribute__((ext_vector_type(8)));
+template <> __device__ __forceinline__ void mfma16<f16_t>(const uint4& a, const uint4& b, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_hw, a), __builtin_bit_cast(f16x8_hw, b), c, 0, 0, 0);
 }
 template <> __device__ __forceinline__ void mfma16<float>(const uint4& a, const uint4& b, f32x4& c) {
     c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
@@ -278,6 +416,10 @@ template <> inline void buf_ld4<bf16_t>(const BufRsrc& r, unsigned off, float (&
     uint16_t h[4]; buf_load_raw(r, off, h, 8);
     for (int i = 0; i < 4; ++i) o[i] = bf16_to_f32(h[i]);
 }
+template <> inline void buf_ld4<f16_t>(const BufRsrc& r, unsigned off, float (&o)[4]) {
+    uint16_t h[4]; buf_load_raw(r, off, h, 8);
+    for (int i = 0; i < 4; ++i) o[i] = f16_bits_to_f32(h[i]);
+}
 #else
 typedef unsigned int buf_u32x2 __attribute__((ext_vector_type(2)));
 template <class T> __device__ __forceinline__ void buf_ld4(BufRsrc r, unsigned off, float (&o)[4]);
@@ -289,6 +431,10 @@ template <> __device__ __forceinline__ void buf_ld4<bf16_t>(BufRsrc r, unsigned 
     const buf_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, int(off), 0, 0);
     o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
     o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+}
+template <> __device__ __forceinline__ void buf_ld4<f16_t>(BufRsrc r, unsigned off, float (&o)[4]) {
+    const buf_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, int(off), 0, 0);
+    o[0] = f16lo_to_f32(v.x); o[1] = f16hi_to_f32(v.x); o[2] = f16lo_to_f32(v.y); o[3] = f16hi_to_f32(v.y);
 }
 #endif
 
@@ -367,6 +513,7 @@ __device__ __forceinline__ float gelu_sigmoid(float x) {
 }
 template <class T> __device__ __forceinline__ float apply_act_t(float x, int act) { return apply_act(x, act); }
 template <> __device__ __forceinline__ float apply_act_t<bf16_t>(float x, int act) { return act == ACT_GELU ? gelu_sigmoid(x) : apply_act(x, act); }
+template <> __device__ __forceinline__ float apply_act_t<f16_t>(float x, int act) { return act == ACT_GELU ? gelu_sigmoid(x) : apply_act(x, act); }
 // N values at once with the switch on the (launch-uniform) activation OUTSIDE the element loop.  Per element, the compiler kept a
 // scalar branch ladder around every value: eight serialised (bias load -> wait -> ladder -> exp -> rcp) chains per hidden chunk of
 // mlp_kernel, no two transcendentals ever in flight together.  Same formulas as apply_act_t, so results are bit-identical.

@@ -317,14 +317,15 @@ void EngineBase::read_tap(const std::string& name, float* out, size_t cap) {
     auto it = taps.find(name);
     if (it == taps.end()) throw AchError{ACH_ERR_INVALID, "unknown tap: " + name};
     const TapInfo& t = it->second;
-    const bool bf = cfg.dtype == ACH_DTYPE_BF16 && !t.is_f32 && !t.is_i32;
-    const size_t esz = bf ? 2 : 4;
+    const bool bf = cfg.dtype == ACH_DTYPE_BF16 && !t.is_f32 && !t.is_i32, hf = cfg.dtype == ACH_DTYPE_F16 && !t.is_f32 && !t.is_i32;
+    const size_t esz = (bf || hf) ? 2 : 4;
     ACH_HIP_CHECK(hipDeviceSynchronize());
     auto fetch = [&](size_t elems) {
         std::vector<unsigned char> raw(elems * esz);
         ACH_HIP_CHECK(hipMemcpy(raw.data(), t.ptr, raw.size(), hipMemcpyDeviceToHost));
         std::vector<float> f(elems);
         if (bf) for (size_t i = 0; i < elems; ++i) { uint16_t b; std::memcpy(&b, &raw[i * 2], 2); f[i] = bf16_to_f32(b); }
+        else if (hf) for (size_t i = 0; i < elems; ++i) { uint16_t b; std::memcpy(&b, &raw[i * 2], 2); f[i] = f16_bits_to_f32(b); }
         else if (t.is_i32) for (size_t i = 0; i < elems; ++i) { int32_t v; std::memcpy(&v, &raw[i * 4], 4); f[i] = float(v); }
         else std::memcpy(f.data(), raw.data(), elems * 4);
         return f;
@@ -357,9 +358,11 @@ void EngineBase::read_tap(const std::string& name, float* out, size_t cap) {
 
 EngineBase* make_engine_f32(const ach_config& cfg);       // engine_f32.cpp
 EngineBase* make_engine_bf16(const ach_config& cfg);      // engine_bf16.cpp
+EngineBase* make_engine_f16(const ach_config& cfg);       // engine_f16.cpp
 EngineBase* make_engine(const ach_config& cfg) {
     if (cfg.dtype == ACH_DTYPE_F32) return make_engine_f32(cfg);
     if (cfg.dtype == ACH_DTYPE_BF16) return make_engine_bf16(cfg);
+    if (cfg.dtype == ACH_DTYPE_F16) return make_engine_f16(cfg);
     throw AchError{ACH_ERR_INVALID, "unknown dtype"};
 }
 

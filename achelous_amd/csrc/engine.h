@@ -74,6 +74,7 @@ public:
     // MI355X the interleaved eager launches on three streams are as fast at batch 64 (4.3 ms both) and faster at batch 1
     // (1.36 ms vs 1.66 ms): HIP's graph executor serialises more of the three-branch DAG than the streams do.
     bool use_graph = false;
+    bool io_bf16 = false;             // option "io_bf16" (fp16-storage engine only): the caller's input / output tensors are bf16; converted in the first / last kernels
     bool multi_stream = true;         // option "streams": run the independent radar / point branches on side streams
     int gemm_rows = 1;                // option "gemm_rows": 16-row sub-tiles per wave (1 / 2 / 4) for GEMMs with K >= 1024 (the dense 3x3 convs of MobileViT)
     bool xca_mfma = true;             // option "xca_mfma": XCA Gram matrices on the matrix cores (xca_gram_mfma_kernel, k_xca.h); 0 = the VALU kernel

@@ -41,6 +41,10 @@ class Engine final : public EngineBase {
     using S = Store<T>;
     static constexpr int VEC = S::VEC;
     static constexpr int KC = 4 * VEC;
+    static constexpr bool H16E = is_h16<T>::value;                  // bf16 or fp16 storage: the production kernels (k_dechead.h, k_mlpband.h, k_headdw.h, k_upchain.h)
+    // the alternative type of the CALLER's tensors: the fp16-storage engine also takes / returns bf16 (option "io_bf16"); for the other two it is T itself
+    using IOB = typename std::conditional<std::is_same<T, f16_t>::value, bf16_t, T>::type;
+    bool io_alt() const { return std::is_same<T, f16_t>::value && io_bf16; }
 
 public:
     explicit Engine(const ach_config& c) : EngineBase(c) {}
@@ -169,7 +173,7 @@ public:
         g.groups = o.groups; g.M_per_group = int(M / o.groups);
         g.K = pk.K; g.N = pk.N; g.nchunks = pk.nchunks; g.ksteps = pk.ksteps;
         g.act = o.act; g.ln = o.ln ? 1 : 0; g.ln_eps = o.ln_eps;
-        g.out_nchw = o.out_nchw; g.HW = o.HW; g.Ctot = o.Ctot; g.coff = o.coff;
+        g.out_nchw = (o.out_nchw && io_alt()) ? 2 : o.out_nchw; g.HW = o.HW; g.Ctot = o.Ctot; g.coff = o.coff;
         g.vec_store = (ldy % 8 == 0 && (!o.residual || o.residual->ld % 8 == 0)) ? 1 : 0;
         if (ldx % VEC != 0) throw AchError{ACH_ERR_INVALID, name + ": activation row stride not 16-byte aligned"};
         if (o.conv_k > 0 && (o.Cin % VEC != 0 || pk.K != o.conv_k * o.conv_k * o.Cin)) throw AchError{ACH_ERR_UNSUPPORTED, name + ": conv channel count not 16-byte aligned"};
@@ -258,8 +262,8 @@ public:
                 }
                 const dim3 grid(static_cast<unsigned>(wg)), block(HDW_THREADS);
                 // (if constexpr: instantiated by the bf16 engine's translation unit ONLY — see fused_mlp_lin)
-                if constexpr (std::is_same<T, bf16_t>::value)
-                    add_op(name, [hp, grid, block](hipStream_t s) { ACH_LAUNCH((headdw_kernel<bf16_t>), grid, block, s, hp); }, bytes, flops);
+                if constexpr (H16E)
+                    add_op(name, [hp, grid, block](hipStream_t s) { ACH_LAUNCH((headdw_kernel<T>), grid, block, s, hp); }, bytes, flops);
             } else {
                 DwJobs m;
                 std::memset(&m, 0, sizeof(m));
@@ -469,11 +473,11 @@ public:
         // small maps, bf16: a band of rows per workgroup — taps from an LDS halo tile, MLP weights fetched once per band (k_mlpband.h)
         // (if constexpr: kernels that only the bf16 engine launches must not be instantiated by the fp32 engine's translation unit as well —
         //  the two code objects would carry the same symbol and the runtime registers one of them for the shared host stub)
-        if constexpr (std::is_same<T, bf16_t>::value) if (mlp_band && (split || mlp_band > 1) && dw_ks && act == ACT_GELU && xin.p == resid.p && mlp_band_supported(k1, DT, dw_ks, xin.H, xin.W)) {
+        if constexpr (H16E) if (mlp_band && (split || mlp_band > 1) && dw_ks && act == ACT_GELU && xin.p == resid.p && mlp_band_supported(k1, DT, dw_ks, xin.H, xin.W)) {
             MlpBandParams bp;
             bp.m = mp; bp.rb = mlp_band_rows(k1, DT, dw_ks, xin.H, xin.W); bp.bands = cdiv(xin.H, bp.rb); bp.dbg = mlp_band_dbg;
             const int nb = xin.B, shape = mlp_band_shape(k1, DT, dw_ks, xin.W);
-            add_op(name, [bp, nb, shape](hipStream_t s) { launch_mlp_band(bp, shape, nb, s); }, bytes, flops);
+            add_op(name, [bp, nb, shape](hipStream_t s) { launch_mlp_band<T>(bp, shape, nb, s); }, bytes, flops);
             return true;
         }
         add_op(name, [mp, DT, split](hipStream_t s) { launch_mlp<T>(mp, DT, split, s); }, bytes, flops);
@@ -636,13 +640,15 @@ public:
                 if (stem_mfma && pk.NT == 2 && pk.nchunks == 1 && x.ld == 32) {
                     StemMfmaParams sp{nullptr, x.p, pk.w, pk.b, up_f32(W(d + ".1.weight").data), up_f32(W(d + ".1.bias").data), B, R, R, pk.ksteps, 1e-6f};
                     const dim3 grid(unsigned(cdivl(x.rows(), 64))), block(256);
-                    add_op(d, [sp, grid, block, img](hipStream_t s) mutable { sp.X = *img; ACH_LAUNCH(stem_mfma_kernel<T>, grid, block, s, sp); },
+                    const bool alt = io_alt();
+                    add_op(d, [sp, grid, block, img, alt](hipStream_t s) mutable { sp.X = *img; if (alt) ACH_LAUNCH((stem_mfma_kernel<T, IOB>), grid, block, s, sp); else ACH_LAUNCH((stem_mfma_kernel<T, T>), grid, block, s, sp); },
                            double(B) * 3 * R * R * sizeof(T) + double(x.rows()) * 32 * sizeof(T), 2.0 * double(x.rows()) * 48 * 32);
                 } else {
                     StemParams sp{nullptr, x.p, up_f32(wt), up_f32(W(d + ".0.bias").data), up_f32(W(d + ".1.weight").data),
                                   up_f32(W(d + ".1.bias").data), B, R, R, 1e-6f};
                     const dim3 grid(unsigned(cdivl(x.rows(), 256))), block(256);
-                    add_op(d, [sp, grid, block, img](hipStream_t s) mutable { sp.X = *img; ACH_LAUNCH(stem_kernel<T>, grid, block, s, sp); });
+                    const bool alt = io_alt();
+                    add_op(d, [sp, grid, block, img, alt](hipStream_t s) mutable { sp.X = *img; if (alt) ACH_LAUNCH((stem_kernel<T, IOB>), grid, block, s, sp); else ACH_LAUNCH((stem_kernel<T, T>), grid, block, s, sp); });
                 }
             } else {
                 A t = alloc(x.B, x.H, x.W, x.C);
@@ -793,7 +799,8 @@ public:
             ToNhwcParams tp{nullptr, img.p, B, 3, R, R, img.ld};
             const dim3 grid(unsigned(cdivl(img.rows(), 256))), block(256);
             const void** in = &io.image;
-            add_op(pfx + ".to_nhwc", [tp, grid, block, in](hipStream_t s) mutable { tp.X = *in; ACH_LAUNCH(nchw_to_nhwc_kernel<T>, grid, block, s, tp); },
+            const bool alt = io_alt();
+            add_op(pfx + ".to_nhwc", [tp, grid, block, in, alt](hipStream_t s) mutable { tp.X = *in; if (alt) ACH_LAUNCH((nchw_to_nhwc_kernel<T, IOB>), grid, block, s, tp); else ACH_LAUNCH((nchw_to_nhwc_kernel<T, T>), grid, block, s, tp); },
                    double(img.rows()) * (3 + 3) * sizeof(T), 0, double(img.rows()) * (3 + img.ld) * sizeof(T));
         }
         A x = mv_conv(pfx + ".conv1", img, 3, 2);
@@ -941,7 +948,7 @@ public:
     // can this level's full-resolution kernel also apply the NEXT level's conv pair (k_upchain.h)?  bf16 production plans only: the level's
     // output y is a tap of the parity plans
     bool level_chains(const std::string& ghost_pfx, const std::string& next_up, const std::string& next_ghost) const {
-        if (!level_chain || full_taps || !fuse_mlp || !std::is_same<T, bf16_t>::value) return false;
+        if (!level_chain || full_taps || !fuse_mlp || !H16E) return false;
         const int Cg = int(W(ghost_pfx + ".primary_conv.0.weight").shape[0]);
         const HostTensor& wu = W(next_up + ".upsample.0.conv.weight");
         const HostTensor& wp = W(next_ghost + ".primary_conv.0.weight");
@@ -963,11 +970,11 @@ public:
         UpGhostChainParams cp{UpGhostParams{t.p, t.ld, nullptr, 0, up_f32(wt), up_f32(sh), t.B, t.H, t.W, Cg}, tn.p, tn.ld, mp.W1, mp.b1, mp.W2, mp.b2, lp.N};
         const dim3 grid(unsigned(cdiv(2 * t.W, UPG_TS)) * unsigned(cdiv(2 * t.H, UPG_TS)) * unsigned(t.B)), block(unsigned(16 * Cg));
         const double bytes = double(t.rows()) * Cg * sizeof(T) + double(tn.rows()) * lp.N * sizeof(T);
-        if constexpr (std::is_same<T, bf16_t>::value)
+        if constexpr (H16E)
             add_op(ghost_pfx + ".upghost+pair", [cp, grid, block, Cg](hipStream_t s) {
-                if (Cg == 16) ACH_LAUNCH((upghost_chain_kernel<16>), grid, block, s, cp);
-                else if (Cg == 24) ACH_LAUNCH((upghost_chain_kernel<24>), grid, block, s, cp);
-                else ACH_LAUNCH((upghost_chain_kernel<32>), grid, block, s, cp);
+                if (Cg == 16) ACH_LAUNCH((upghost_chain_kernel<T, 16>), grid, block, s, cp);
+                else if (Cg == 24) ACH_LAUNCH((upghost_chain_kernel<T, 24>), grid, block, s, cp);
+                else ACH_LAUNCH((upghost_chain_kernel<T, 32>), grid, block, s, cp);
             }, bytes, 2.0 * double(tn.rows()) * (2.0 * Cg * 32 + 32.0 * lp.N));
         return tn;
     }
@@ -982,7 +989,7 @@ public:
         UpGhostParams p{t.p, t.ld, y.p, y.ld, up_f32(wt), up_f32(sh), x.B, x.H, x.W, Cg};
         const dim3 grid(unsigned(cdiv(2 * x.W, UPG_TS)) * unsigned(cdiv(2 * x.H, UPG_TS)) * unsigned(x.B)), block(unsigned(16 * Cg));
         const double bytes = double(t.rows()) * Cg * sizeof(T) + double(y.rows()) * cout * sizeof(T);
-        if constexpr (std::is_same<T, bf16_t>::value) if (level_rows && (Cg == 16 || Cg == 24 || Cg == 32) && t.ld % 2 == 0 && y.ld % 2 == 0 &&
+        if constexpr (H16E) if (level_rows && (Cg == 16 || Cg == 24 || Cg == 32) && t.ld % 2 == 0 && y.ld % 2 == 0 &&
             double(y.rows()) * y.ld * sizeof(T) < 2147483648.0) {
             // row-walking form (k_dechead.h; option level_rows, OFF: measured slower than the LDS tile on these write-bound levels — 34 / 60 us against 25 / 48)
             const int H2 = 2 * x.H, band = std::max(8, std::min(head_band, H2));
@@ -1000,9 +1007,9 @@ public:
             const dim3 rgrid(unsigned(rp.strips) * unsigned(rp.bands) * unsigned(x.B)), rblock(64);
             const int np = Cg / 8;
             add_op(ghost_pfx + ".upghost", [rp, rgrid, rblock, rows, np](hipStream_t s) {
-                if (np == 2) ACH_LAUNCH((upghost_rows_kernel<2>), rgrid, rblock, s, rp, rows);
-                else if (np == 3) ACH_LAUNCH((upghost_rows_kernel<3>), rgrid, rblock, s, rp, rows);
-                else ACH_LAUNCH((upghost_rows_kernel<4>), rgrid, rblock, s, rp, rows);
+                if (np == 2) ACH_LAUNCH((upghost_rows_kernel<T, 2>), rgrid, rblock, s, rp, rows);
+                else if (np == 3) ACH_LAUNCH((upghost_rows_kernel<T, 3>), rgrid, rblock, s, rp, rows);
+                else ACH_LAUNCH((upghost_rows_kernel<T, 4>), rgrid, rblock, s, rp, rows);
             }, bytes);
             return y;
         }
@@ -1047,8 +1054,9 @@ public:
         UpGhostHeadParams p{t.p, t.ld, full_taps ? f.p : nullptr, full_taps ? f.ld : 0, nullptr, up_f32(wl), up_f32(bl), up_f32(lh.w), up_f32(lh.b),
                             up_f32(wh2), up_f32(bh2), x.B, x.H, x.W, init, nch, oup,
                             x.H > 0 ? float(x.H - 1) / float(2 * x.H - 1) : 0.f, x.W > 0 ? float(x.W - 1) / float(2 * x.W - 1) : 0.f};
+        p.out_bf16 = io_alt() ? 1 : 0;
         const double bytes = double(t.rows()) * Cg * sizeof(T) + 4.0 * double(t.rows()) * oup * sizeof(T);
-        if constexpr (std::is_same<T, bf16_t>::value) if (head_rows && !planar && t.ld % 4 == 0 && double(t.rows()) * t.ld * 4.0 * oup < 2147483648.0) {
+        if constexpr (H16E) if (head_rows && !planar && t.ld % 4 == 0 && double(t.rows()) * t.ld * 4.0 * oup < 2147483648.0) {
             // row-walking kernel (k_dechead.h): head 1x1 as the A fragment of v_mfma_f32_16x16x32_bf16 — D row 4g + r = head channel g + 4r,
             // k = 8g + j = channel 4g + j of x1 (j < 4) or of x2 (j >= 4) — biases and the head's depthwise filters indexed by head channel
             std::vector<uint16_t> af(size_t(64) * 8, 0);
@@ -1056,7 +1064,7 @@ public:
                 const int i = l & 15, kg = l >> 4, jj = (i / 4) + 4 * (i % 4);
                 for (int j = 0; j < 8; ++j) {
                     const int orig = j < 4 ? 4 * kg + j : 16 + 4 * kg + (j - 4);
-                    af[size_t(l) * 8 + j] = (i % 4 < 2 && jj < init) ? f32_to_bf16_bits(lh.w[size_t(jj) * cout + orig]) : uint16_t(0);
+                    af[size_t(l) * 8 + j] = (i % 4 < 2 && jj < init) ? H16<T>::bits(lh.w[size_t(jj) * cout + orig]) : uint16_t(0);
                 }
             }
             std::vector<float> bh8(8, 0.f), wd8(72, 0.f), bd8(8, 0.f);
@@ -1080,24 +1088,29 @@ public:
             const DecHeadRow* rows = static_cast<const DecHeadRow*>(up_raw(rg.data(), rg.size() * sizeof(DecHeadRow)));
             const int dbg = head_debug;
             const bool dw2 = nch > 4, tapf = full_taps;
-            add_op(head_pfx + ".upghost_head", [dp, grid, block, out, dbg, dw2, tapf, rows, two](hipStream_t s) mutable {
+            const bool alt = io_alt();
+            add_op(head_pfx + ".upghost_head", [dp, grid, block, out, dbg, dw2, tapf, rows, two, alt](hipStream_t s) mutable {
                 dp.out = *out;
-                if (two) {
-                    if (tapf) { if (dw2) ACH_LAUNCH((dechead_rows2_kernel<true, true>), grid, block, s, dp, rows); else ACH_LAUNCH((dechead_rows2_kernel<false, true>), grid, block, s, dp, rows); }
-                    else { if (dw2) ACH_LAUNCH((dechead_rows2_kernel<true, false>), grid, block, s, dp, rows); else ACH_LAUNCH((dechead_rows2_kernel<false, false>), grid, block, s, dp, rows); }
-                    return;
-                }
-                if (tapf) {                      // parity-test plans: the variant that also writes [x1 | x2]
-                    if (dw2) ACH_LAUNCH((dechead_rows_kernel<true, true, 0>), grid, block, s, dp, rows); else ACH_LAUNCH((dechead_rows_kernel<false, true, 0>), grid, block, s, dp, rows);
-                    return;
-                }
-#define ACH_DH_CASE(D) case D: if (dw2) ACH_LAUNCH((dechead_rows_kernel<true, false, D>), grid, block, s, dp, rows); else ACH_LAUNCH((dechead_rows_kernel<false, false, D>), grid, block, s, dp, rows); break;
+                auto go = [&](auto io_tag) {             // IO: the type of the caller's output tensor
+                    using IO = decltype(io_tag);
+                    if (two) {
+                        if (tapf) { if (dw2) ACH_LAUNCH((dechead_rows2_kernel<T, IO, true, true>), grid, block, s, dp, rows); else ACH_LAUNCH((dechead_rows2_kernel<T, IO, false, true>), grid, block, s, dp, rows); }
+                        else { if (dw2) ACH_LAUNCH((dechead_rows2_kernel<T, IO, true, false>), grid, block, s, dp, rows); else ACH_LAUNCH((dechead_rows2_kernel<T, IO, false, false>), grid, block, s, dp, rows); }
+                        return;
+                    }
+                    if (tapf) {                      // parity-test plans: the variant that also writes [x1 | x2]
+                        if (dw2) ACH_LAUNCH((dechead_rows_kernel<T, IO, true, true, 0>), grid, block, s, dp, rows); else ACH_LAUNCH((dechead_rows_kernel<T, IO, false, true, 0>), grid, block, s, dp, rows);
+                        return;
+                    }
+#define ACH_DH_CASE(D) case D: if (dw2) ACH_LAUNCH((dechead_rows_kernel<T, IO, true, false, D>), grid, block, s, dp, rows); else ACH_LAUNCH((dechead_rows_kernel<T, IO, false, false, D>), grid, block, s, dp, rows); break;
 #if defined(ACH_HEAD_DEBUG)
-                switch (dbg) { ACH_DH_CASE(1) ACH_DH_CASE(2) ACH_DH_CASE(3) ACH_DH_CASE(4) ACH_DH_CASE(7) ACH_DH_CASE(8) ACH_DH_CASE(15) default: ACH_DH_CASE(0) }
+                    switch (dbg) { ACH_DH_CASE(1) ACH_DH_CASE(2) ACH_DH_CASE(3) ACH_DH_CASE(4) ACH_DH_CASE(7) ACH_DH_CASE(8) ACH_DH_CASE(15) default: ACH_DH_CASE(0) }
 #else
-                switch (dbg) { default: ACH_DH_CASE(0) }
+                    switch (dbg) { default: ACH_DH_CASE(0) }
 #endif
 #undef ACH_DH_CASE
+                };
+                if (alt) go(IOB{}); else go(T{});
             }, bytes, 2.0 * double(t.rows()) * 4.0 * cout * init);
             return;
         }
@@ -1318,12 +1331,13 @@ public:
             const void** rin = &io.radar;
             mark_xwait_next();           // pipelined forwards: this branch rewrites the radar pyramid the previous forward's fusion reads
             const double bytes = double(x.rows()) * (3 + 3) * sizeof(T), lbytes = double(x.rows()) * (3 + x.ld) * sizeof(T);
+            const bool alt = io_alt();
             if (narrow0) {
                 const dim3 grid(unsigned(cdivl(x.rows() / 4, 256))), block(256);
-                add_op("image_radar_encoder.radar_encoder.to_nhwc", [tp, grid, block, rin](hipStream_t s) mutable { tp.X = *rin; ACH_LAUNCH(nchw3_to_nhwc4_kernel<T>, grid, block, s, tp); }, bytes, 0, lbytes);
+                add_op("image_radar_encoder.radar_encoder.to_nhwc", [tp, grid, block, rin, alt](hipStream_t s) mutable { tp.X = *rin; if (alt) ACH_LAUNCH((nchw3_to_nhwc4_kernel<T, IOB>), grid, block, s, tp); else ACH_LAUNCH((nchw3_to_nhwc4_kernel<T, T>), grid, block, s, tp); }, bytes, 0, lbytes);
             } else {
                 const dim3 grid(unsigned(cdivl(x.rows(), 256))), block(256);
-                add_op("image_radar_encoder.radar_encoder.to_nhwc", [tp, grid, block, rin](hipStream_t s) mutable { tp.X = *rin; ACH_LAUNCH(nchw_to_nhwc_kernel<T>, grid, block, s, tp); }, bytes, 0, lbytes);
+                add_op("image_radar_encoder.radar_encoder.to_nhwc", [tp, grid, block, rin, alt](hipStream_t s) mutable { tp.X = *rin; if (alt) ACH_LAUNCH((nchw_to_nhwc_kernel<T, IOB>), grid, block, s, tp); else ACH_LAUNCH((nchw_to_nhwc_kernel<T, T>), grid, block, s, tp); }, bytes, 0, lbytes);
             }
         }
         for (int i = 0; i < 8; ++i) {
@@ -1520,7 +1534,7 @@ public:
                     for (int t = 0; t < 25; ++t) { wt[size_t(t) * 2 * base + ch] = wc.data[size_t(ch) * 25 + t]; wt[size_t(t) * 2 * base + base + ch] = wr.data[size_t(ch) * 25 + t]; }
                 // fused layer (k_headdw.h): bf16, 64-wide towers, one launch for the three levels
                 const int rbh = headdw_band_rows(x.H, x.W);
-                if (head_fuse && batching && std::is_same<T, bf16_t>::value && base == HDW_C && rbh > 0 && cur.ld % 8 == 0) {
+                if constexpr (H16E) if (head_fuse && batching && base == HDW_C && rbh > 0 && cur.ld % 8 == 0) {
                     Lin lc = conv_bn(c + ".conv.pconv", c + ".bn", 1e-3), lr = conv_bn(r + ".conv.pconv", r + ".bn", 1e-3);
                     std::vector<uint16_t> wp(size_t(2) * 2 * 4 * 64 * 8, 0);
                     std::vector<float> pb(size_t(2) * base, 0.f);
@@ -1532,7 +1546,7 @@ public:
                                 for (int ln = 0; ln < 64; ++ln) {
                                     const int i = ln & 15, kg = ln >> 4, n = (t / 2) * 32 + (i / 4) * 8 + (t % 2) * 4 + (i % 4);
                                     for (int e = 0; e < 8; ++e)
-                                        wp[(((size_t(br) * 2 + s2) * 4 + t) * 64 + ln) * 8 + e] = f32_to_bf16_bits(l.w[size_t(n) * base + s2 * 32 + kg * 8 + e]);
+                                        wp[(((size_t(br) * 2 + s2) * 4 + t) * 64 + ln) * 8 + e] = H16<T>::bits(l.w[size_t(n) * base + s2 * 32 + kg * 8 + e]);
                                 }
                     }
                     A y = alloc(x.B, x.H, x.W, 2 * base);
@@ -1633,7 +1647,8 @@ public:
             PcPrepParams pp{nullptr, x0.p, B, D, N, x0.ld};
             const dim3 grid(unsigned(cdivl(long(B) * N * x0.ld, 256))), block(256);
             const void** pin = &io.points;
-            add_op(p + ".prep", [pp, grid, block, pin](hipStream_t s) mutable { pp.X = *pin; ACH_LAUNCH(pc_prep_kernel<T>, grid, block, s, pp); });
+            const bool alt = io_alt();
+            add_op(p + ".prep", [pp, grid, block, pin, alt](hipStream_t s) mutable { pp.X = *pin; if (alt) ACH_LAUNCH((pc_prep_kernel<T, IOB>), grid, block, s, pp); else ACH_LAUNCH((pc_prep_kernel<T, T>), grid, block, s, pp); });
         }
         Rows t9 = stn(p + ".feat.stn", x0, B);
         { TapInfo t; t.ptr = t9.p; t.kind = 2; t.B = B; t.H = 1; t.W = 1; t.C = 9; t.ld = t9.ld; t.add_eye = 3; add_tap("pc.trans", t); }
@@ -1663,7 +1678,8 @@ public:
             LsmParams q{y.p, y.ld, nullptr, long(B) * N, cfg.pc_classes};
             const dim3 grid(unsigned(cdivl(long(B) * N, 256))), block(256);
             void** out = &io.pc;
-            add_op(p + ".log_softmax", [q, grid, block, out](hipStream_t s) mutable { q.Y = *out; ACH_LAUNCH(log_softmax_kernel<T>, grid, block, s, q); });
+            const bool alt = io_alt();
+            add_op(p + ".log_softmax", [q, grid, block, out, alt](hipStream_t s) mutable { q.Y = *out; if (alt) ACH_LAUNCH((log_softmax_kernel<T, IOB>), grid, block, s, q); else ACH_LAUNCH((log_softmax_kernel<T, T>), grid, block, s, q); });
         }
     }
 
@@ -1687,7 +1703,8 @@ public:
             PcPrepParams pp{nullptr, lv[0].f.p, B, D, N, lv[0].f.ld};
             const dim3 grid(unsigned(cdivl(long(B) * N * lv[0].f.ld, 256))), block(256);
             const void** pin = &io.points;
-            add_op(p + ".prep", [pp, grid, block, pin](hipStream_t s) mutable { pp.X = *pin; ACH_LAUNCH(pc_prep_kernel<T>, grid, block, s, pp); });
+            const bool alt = io_alt();
+            add_op(p + ".prep", [pp, grid, block, pin, alt](hipStream_t s) mutable { pp.X = *pin; if (alt) ACH_LAUNCH((pc_prep_kernel<T, IOB>), grid, block, s, pp); else ACH_LAUNCH((pc_prep_kernel<T, T>), grid, block, s, pp); });
         }
         lv[0].xyz = static_cast<float*>(aalloc(size_t(B) * N * 3 * sizeof(float)));
         { Pn2XyzParams q{lv[0].f.p, lv[0].f.ld, lv[0].xyz, long(B) * N}; ew(p + ".xyz", pn2_xyz_kernel<T>, q, long(B) * N * 3); }
@@ -1749,7 +1766,8 @@ public:
             LsmParams q{y.p, y.ld, nullptr, long(B) * N, cfg.pc_classes};
             const dim3 grid(unsigned(cdivl(long(B) * N, 256))), block(256);
             void** out = &io.pc;
-            add_op(p + ".log_softmax", [q, grid, block, out](hipStream_t s) mutable { q.Y = *out; ACH_LAUNCH(log_softmax_kernel<T>, grid, block, s, q); });
+            const bool alt = io_alt();
+            add_op(p + ".log_softmax", [q, grid, block, out, alt](hipStream_t s) mutable { q.Y = *out; if (alt) ACH_LAUNCH((log_softmax_kernel<T, IOB>), grid, block, s, q); else ACH_LAUNCH((log_softmax_kernel<T, T>), grid, block, s, q); });
         }
     }
 
@@ -1870,19 +1888,23 @@ public:
         MinMaxParams pm{in, prepost_scratch, per, S};
         ACH_LAUNCH(frame_minmax_kernel, dim3(unsigned(B), unsigned(S)), dim3(256), s, pm);
         RadarScaleParams ps{in, prepost_scratch, out, per, S, B};
-        ACH_LAUNCH(radar_scale_kernel<T>, dim3(unsigned(cdivl(per * B, 256))), dim3(256), s, ps);
+        if (io_alt()) ACH_LAUNCH(radar_scale_kernel<IOB>, dim3(unsigned(cdivl(per * B, 256))), dim3(256), s, ps);
+        else ACH_LAUNCH(radar_scale_kernel<T>, dim3(unsigned(cdivl(per * B, 256))), dim3(256), s, ps);
     }
     void normalize_points(int B, int N, int D, const float* in, void* out, hipStream_t s) override {
         PointNormParams pp{in, out, B, N, D};
-        ACH_LAUNCH(point_norm_kernel<T>, dim3(unsigned(B * D)), dim3(256), s, pp);
+        if (io_alt()) ACH_LAUNCH(point_norm_kernel<IOB>, dim3(unsigned(B * D)), dim3(256), s, pp);
+        else ACH_LAUNCH(point_norm_kernel<T>, dim3(unsigned(B * D)), dim3(256), s, pp);
     }
     void preprocess_image(int B, const unsigned char* in, void* out, hipStream_t s) override {
         ImagePrepParams pp{in, out, B, cfg.resolution, cfg.resolution};
-        ACH_LAUNCH(image_prep_kernel<T>, dim3(unsigned(cdivl(long(B) * cfg.resolution * cfg.resolution, 256))), dim3(256), s, pp);
+        if (io_alt()) ACH_LAUNCH(image_prep_kernel<IOB>, dim3(unsigned(cdivl(long(B) * cfg.resolution * cfg.resolution, 256))), dim3(256), s, pp);
+        else ACH_LAUNCH(image_prep_kernel<T>, dim3(unsigned(cdivl(long(B) * cfg.resolution * cfg.resolution, 256))), dim3(256), s, pp);
     }
     void seg_argmax(int B, int C, const void* seg, unsigned char* out, hipStream_t s) override {
         SegArgmaxParams pp{seg, out, B, C, long(cfg.resolution) * cfg.resolution};
-        ACH_LAUNCH(seg_argmax_kernel<T>, dim3(unsigned(cdivl(pp.HW * B, 256))), dim3(256), s, pp);
+        if (io_alt()) ACH_LAUNCH(seg_argmax_kernel<IOB>, dim3(unsigned(cdivl(pp.HW * B, 256))), dim3(256), s, pp);
+        else ACH_LAUNCH(seg_argmax_kernel<T>, dim3(unsigned(cdivl(pp.HW * B, 256))), dim3(256), s, pp);
     }
 
     // achelous.py:283-318: softmax -> crop the letterbox bars -> INTER_LINEAR resize to the original size -> argmax (k_prepost.h)
@@ -1890,7 +1912,8 @@ public:
         const int R = cfg.resolution;
         const long HW = long(R) * R;
         SegSoftmaxParams sp{seg, prob_ws, B, C, HW};
-        ACH_LAUNCH(seg_softmax_kernel<T>, dim3(unsigned(cdivl(HW * B, 256))), dim3(256), s, sp);
+        if (io_alt()) ACH_LAUNCH(seg_softmax_kernel<IOB>, dim3(unsigned(cdivl(HW * B, 256))), dim3(256), s, sp);
+        else ACH_LAUNCH(seg_softmax_kernel<T>, dim3(unsigned(cdivl(HW * B, 256))), dim3(256), s, sp);
         // utils_seg/utils.py:19-31 (resize_image): scale = min(w / iw, h / ih), nw = int(iw * scale), nh = int(ih * scale), centred
         const double scale = std::min(double(R) / double(out_w), double(R) / double(out_h));
         const int nw = std::max(1, int(double(out_w) * scale)), nh = std::max(1, int(double(out_h) * scale));
@@ -1941,7 +1964,8 @@ public:
         p.det[0] = d3; p.det[1] = d4; p.det[2] = d5;
         p.h[0] = p.w[0] = r / 8; p.h[1] = p.w[1] = r / 16; p.h[2] = p.w[2] = r / 32;
         p.out = out; p.B = B; p.NC5 = 5 + cfg.num_det; p.A = num_anchors(); p.in_h = float(r); p.in_w = float(r);
-        ACH_LAUNCH(decode_kernel<T>, dim3(unsigned(cdivl(long(B) * p.A, 256))), dim3(256), s, p);
+        if (io_alt()) ACH_LAUNCH(decode_kernel<IOB>, dim3(unsigned(cdivl(long(B) * p.A, 256))), dim3(256), s, p);
+        else ACH_LAUNCH(decode_kernel<T>, dim3(unsigned(cdivl(long(B) * p.A, 256))), dim3(256), s, p);
     }
 };
 

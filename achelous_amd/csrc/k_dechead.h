@@ -107,15 +107,25 @@ __device__ __forceinline__ void combine4(const float (&c)[4], const float (&l)[4
 // stream, in pipelined mode) came out a few bf16 ulps off in whole 16-pixel tiles, run to run; with the register budget forced to 128
 // or with the two 16x16x16 instructions the difference is gone (0 of 60 forwards against 3 of 4).  DESIGN.md 4.14 has the experiments.
 #if defined(ACH_HOSTEMU)
-__device__ inline void dh_mfma(const uint4& a, const uint4& b, f32x4& c) { mfma16<bf16_t>(a, b, c); }
+template <class T> __device__ inline void dh_mfma(const uint4& a, const uint4& b, f32x4& c) { mfma16<T>(a, b, c); }
 #else
-__device__ __forceinline__ void dh_mfma(const uint4& a, const uint4& b, f32x4& c) {
+template <class T> __device__ __forceinline__ void dh_mfma(const uint4& a, const uint4& b, f32x4& c);
+template <> __device__ __forceinline__ void dh_mfma<bf16_t>(const uint4& a, const uint4& b, f32x4& c) {
 #if ACH_DH_MFMA32
     mfma16<bf16_t>(a, b, c);
 #else
     typedef short s16x4 __attribute__((ext_vector_type(4)));
     c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, make_uint2(a.x, a.y)), __builtin_bit_cast(s16x4, make_uint2(b.x, b.y)), c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, make_uint2(a.z, a.w)), __builtin_bit_cast(s16x4, make_uint2(b.z, b.w)), c, 0, 0, 0);
+#endif
+}
+template <> __device__ __forceinline__ void dh_mfma<f16_t>(const uint4& a, const uint4& b, f32x4& c) {
+#if ACH_DH_MFMA32
+    mfma16<f16_t>(a, b, c);
+#else
+    typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+    c = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h16x4, make_uint2(a.x, a.y)), __builtin_bit_cast(h16x4, make_uint2(b.x, b.y)), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h16x4, make_uint2(a.z, a.w)), __builtin_bit_cast(h16x4, make_uint2(b.z, b.w)), c, 0, 0, 0);
 #endif
 }
 #endif
@@ -130,7 +140,7 @@ __device__ __forceinline__ float relu_raw(float v) { float r; asm("v_max_f32_e32
 // DW2: the head's cheap operation has more than four channels (num_seg > 8): accumulator r = 1 takes part in it too.
 // DBG (timing experiments only, results are wrong): bit 0 no bilinear, 1 no level depthwise, 2 no MFMA, 3 no head depthwise / stores.
 // TAP: also write [x1 | x2] to p.F (parity tests, option full_taps).
-template <bool DW2, bool TAP, int DBG = 0>
+template <class T, class IO, bool DW2, bool TAP, int DBG = 0>
 __global__ __launch_bounds__(64, DH_WAVES) void dechead_rows_kernel(const DecHeadParams p, const DecHeadRow* __restrict__ rows) {
     const int H = 2 * p.h, Wd = 2 * p.w;
     const unsigned u = xcd_block(blockIdx.x, gridDim.x);
@@ -148,7 +158,7 @@ __global__ __launch_bounds__(64, DH_WAVES) void dechead_rows_kernel(const DecHea
     const int dx = x0 < p.w - 1 ? 1 : 0;
     const float lx = fx - float(x0);
     const float wx0 = in_x ? 1.f - lx : 0.f, wx1 = in_x ? lx : 0.f;        // a column outside the map is the depthwise conv's zero padding
-    const bf16_t* Tq = static_cast<const bf16_t*>(p.Tq) + b * p.h * long(p.w) * p.ldt;          // (uniform)
+    const T* Tq = static_cast<const T*>(p.Tq) + b * p.h * long(p.w) * p.ldt;          // (uniform)
     const unsigned o0 = unsigned(x0 * int(p.ldt) + 4 * g), o1 = unsigned((x0 + dx) * int(p.ldt) + 4 * g);
     const int rowp = p.w * int(p.ldt);
     // ---- per-lane weights; channel PAIRS (4g, 4g+1) and (4g+2, 4g+3) as packed fp32 (v_pk_fma_f32 / v_pk_mul_f32: two lanes' worth of FMAs per issue)
@@ -171,7 +181,7 @@ __global__ __launch_bounds__(64, DH_WAVES) void dechead_rows_kernel(const DecHea
     const bool st_h[2] = {writer && g < p.init && g < p.oup, writer && g + 4 < p.init && g + 4 < p.oup};
     const bool st_d[2] = {writer && g < p.nch, writer && g + 4 < p.nch};
     const long HW = long(H) * Wd;
-    bf16_t* out_b = static_cast<bf16_t*>(p.out) + b * p.oup * HW;                               // (uniform)
+    IO* out_b = static_cast<IO*>(p.out) + b * p.oup * HW;                               // (uniform)
     const unsigned xo = unsigned(in_x ? x : 0);
     const unsigned off_h[2] = {unsigned(g * HW) + xo, unsigned((g + 4) * HW) + xo};
     const unsigned off_d[2] = {unsigned((p.init + g) * HW) + xo, unsigned((p.init + g + 4) * HW) + xo};
@@ -179,15 +189,15 @@ __global__ __launch_bounds__(64, DH_WAVES) void dechead_rows_kernel(const DecHea
     const int r0 = band * p.band_rows, r1 = (r0 + p.band_rows < H) ? r0 + p.band_rows : H;
     auto load_raw = [&](int r, uint2 (&raw)[2]) {
         const int rr = r < 0 ? 0 : (r > p.h - 1 ? p.h - 1 : r);
-        const bf16_t* q = Tq + long(rr) * rowp;                              // uniform base + per-lane 32-bit offsets
+        const T* q = Tq + long(rr) * rowp;                              // uniform base + per-lane 32-bit offsets
         raw[0] = *reinterpret_cast<const uint2*>(q + o0);
         raw[1] = *reinterpret_cast<const uint2*>(q + o1);
     };
     auto unpack = [&](const uint2 (&raw)[2], f32x2 (&o)[2][2]) {            // [column][channel pair]
         ACH_UNROLL
         for (int c = 0; c < 2; ++c) {
-            o[c][0] = f32x2{__uint_as_float(raw[c].x << 16), __uint_as_float(raw[c].x & 0xffff0000u)};
-            o[c][1] = f32x2{__uint_as_float(raw[c].y << 16), __uint_as_float(raw[c].y & 0xffff0000u)};
+            o[c][0] = f32x2{H16<T>::lo(raw[c].x), H16<T>::hi(raw[c].x)};
+            o[c][1] = f32x2{H16<T>::lo(raw[c].y), H16<T>::hi(raw[c].y)};
         }
     };
     const int i_first = r0 - 2 < 0 ? 0 : r0 - 2;
@@ -245,15 +255,15 @@ __global__ __launch_bounds__(64, DH_WAVES) void dechead_rows_kernel(const DecHea
             for (int q = 0; q < 2; ++q) x2[q] = f32x2{relu_raw(x2[q][0]), relu_raw(x2[q][1])};
             const bool row_in = rb >= 0 && rb < H;
             if (TAP && row_in && writer && rb >= r0 && rb < r1) {
-                bf16_t* fo = static_cast<bf16_t*>(p.F) + ((b * H + rb) * long(Wd) + x) * p.ldf + 4 * g;
+                T* fo = static_cast<T*>(p.F) + ((b * H + rb) * long(Wd) + x) * p.ldf + 4 * g;
                 const float a1[4] = {xc[0][0], xc[0][1], xc[1][0], xc[1][1]}, a2[4] = {x2[0][0], x2[0][1], x2[1][0], x2[1][1]};
-                Store<bf16_t>::st4(fo, a1);
-                Store<bf16_t>::st4(fo + 16, a2);
+                Store<T>::st4(fo, a1);
+                Store<T>::st4(fo + 16, a2);
             }
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             if (!(DBG & 4)) {
-                const uint4 bfrag = make_uint4(pack_bf16x2(xc[0][0], xc[0][1]), pack_bf16x2(xc[1][0], xc[1][1]), pack_bf16x2(x2[0][0], x2[0][1]), pack_bf16x2(x2[1][0], x2[1][1]));
-                dh_mfma(afrag, bfrag, acc);
+                const uint4 bfrag = make_uint4(H16<T>::pack(xc[0][0], xc[0][1]), H16<T>::pack(xc[1][0], xc[1][1]), H16<T>::pack(x2[0][0], x2[0][1]), H16<T>::pack(x2[1][0], x2[1][1]));
+                dh_mfma<T>(afrag, bfrag, acc);
             }
             ACH_UNROLL
             for (int r = 0; r < 2; ++r) { const float v = acc[r] + bhv[r]; hp[r] = (row_in && has_h[r] && v > 0.f) ? v : 0.f; }
@@ -262,16 +272,16 @@ __global__ __launch_bounds__(64, DH_WAVES) void dechead_rows_kernel(const DecHea
         if (!(DBG & 8)) {
             const int ro = i - 2;
             const bool row_st = ro >= r0 && ro < r1;
-            bf16_t* orow = out_b + long(row_st ? ro : r0) * Wd;            // uniform base; per-lane 32-bit offsets
+            IO* orow = out_b + long(row_st ? ro : r0) * Wd;            // uniform base; per-lane 32-bit offsets
             ACH_UNROLL
             for (int r = 0; r < 2; ++r)
-                if (row_st && st_h[r]) Store<bf16_t>::st(orow + off_h[r], hc[r]);
+                if (row_st && st_h[r]) Store<IO>::st(orow + off_h[r], hc[r]);
             ACH_UNROLL
             for (int r = 0; r < NR; ++r) {
                 float a = bdh[r] + wh[1][r] * hm[r] + wh[4][r] * hc[r] + wh[7][r] * hp[r];
                 a = add_from_left(a, wh[0][r] * hm[r] + wh[3][r] * hc[r] + wh[6][r] * hp[r]);
                 a = add_from_right(a, wh[2][r] * hm[r] + wh[5][r] * hc[r] + wh[8][r] * hp[r]);
-                if (row_st && st_d[r]) Store<bf16_t>::st(orow + off_d[r], relu_raw(a));
+                if (row_st && st_d[r]) Store<IO>::st(orow + off_d[r], relu_raw(a));
             }
         }
     };
@@ -320,7 +330,7 @@ __device__ __forceinline__ void add4_from_right(const float (&c)[4], const float
 }
 #endif
 
-template <bool DW2, bool TAP>
+template <class T, class IO, bool DW2, bool TAP>
 __global__ __launch_bounds__(64 * ACH_DH_WG_WAVES, ACH_DH2_WAVES) void dechead_rows2_kernel(const DecHeadParams p, const DecHeadRow* __restrict__ rows) {
     const int H = 2 * p.h, Wd = 2 * p.w;
     const unsigned u = xcd_block(blockIdx.x, gridDim.x) * ACH_DH_WG_WAVES + unsigned(wave_uniform(int(threadIdx.x) >> 6));
@@ -331,7 +341,7 @@ __global__ __launch_bounds__(64 * ACH_DH_WG_WAVES, ACH_DH2_WAVES) void dechead_r
     const int xa = strip * DH2_VALID - 2 + 2 * n;                 // column A; column B = xa + 1 (xa is even, the map width is even)
     const bool in_x = xa >= 0 && xa < Wd;
     const bool writer = in_x && n >= 1 && n < 15;
-    const bf16_t* Tq = static_cast<const bf16_t*>(p.Tq) + b * p.h * long(p.w) * p.ldt;
+    const T* Tq = static_cast<const T*>(p.Tq) + b * p.h * long(p.w) * p.ldt;
     const int rowp = p.w * int(p.ldt);
     // ---- per-lane bilinear geometry along x, per column
     unsigned o0[2], o1[2];
@@ -366,7 +376,7 @@ __global__ __launch_bounds__(64 * ACH_DH_WG_WAVES, ACH_DH2_WAVES) void dechead_r
     const bool st_h[2] = {writer && g < p.init && g < p.oup, writer && g + 4 < p.init && g + 4 < p.oup};
     const bool st_d[2] = {writer && g < p.nch, writer && g + 4 < p.nch};
     const long HW = long(H) * Wd;
-    bf16_t* out_b = static_cast<bf16_t*>(p.out) + b * p.oup * HW;
+    IO* out_b = static_cast<IO*>(p.out) + b * p.oup * HW;
     const unsigned xo = unsigned(in_x ? xa : 0);
     const unsigned off_h[2] = {unsigned(g * HW) + xo, unsigned((g + 4) * HW) + xo};
     const unsigned off_d[2] = {unsigned((p.init + g) * HW) + xo, unsigned((p.init + g + 4) * HW) + xo};
@@ -374,7 +384,7 @@ __global__ __launch_bounds__(64 * ACH_DH_WG_WAVES, ACH_DH2_WAVES) void dechead_r
     // source rows: [column][left / right source column] raw and unpacked (channel pairs)
     auto load_raw = [&](int r, uint2 (&raw)[2][2]) {
         const int rr = r < 0 ? 0 : (r > p.h - 1 ? p.h - 1 : r);
-        const bf16_t* q = Tq + long(rr) * rowp;
+        const T* q = Tq + long(rr) * rowp;
         ACH_UNROLL
         for (int c = 0; c < 2; ++c) { raw[c][0] = *reinterpret_cast<const uint2*>(q + o0[c]); raw[c][1] = *reinterpret_cast<const uint2*>(q + o1[c]); }
     };
@@ -383,8 +393,8 @@ __global__ __launch_bounds__(64 * ACH_DH_WG_WAVES, ACH_DH2_WAVES) void dechead_r
         for (int c = 0; c < 2; ++c) {
             ACH_UNROLL
             for (int k = 0; k < 2; ++k) {
-                o[c][k][0] = f32x2{__uint_as_float(raw[c][k].x << 16), __uint_as_float(raw[c][k].x & 0xffff0000u)};
-                o[c][k][1] = f32x2{__uint_as_float(raw[c][k].y << 16), __uint_as_float(raw[c][k].y & 0xffff0000u)};
+                o[c][k][0] = f32x2{H16<T>::lo(raw[c][k].x), H16<T>::hi(raw[c][k].x)};
+                o[c][k][1] = f32x2{H16<T>::lo(raw[c][k].y), H16<T>::hi(raw[c][k].y)};
             }
         }
     };
@@ -451,17 +461,17 @@ __global__ __launch_bounds__(64 * ACH_DH_WG_WAVES, ACH_DH2_WAVES) void dechead_r
             for (int e = 0; e < 4; ++e) { x2a[e] = relu_raw(oa[e]); x2b[e] = relu_raw(ob[e]); }
             const bool row_in = rb >= 0 && rb < H;
             if (TAP && row_in && writer && rb >= r0 && rb < r1) {
-                bf16_t* fo = static_cast<bf16_t*>(p.F) + ((b * H + rb) * long(Wd) + xa) * p.ldf + 4 * g;
+                T* fo = static_cast<T*>(p.F) + ((b * H + rb) * long(Wd) + xa) * p.ldf + 4 * g;
                 const float a1[4] = {xc[0][0][0], xc[0][0][1], xc[0][1][0], xc[0][1][1]}, b1[4] = {xc[1][0][0], xc[1][0][1], xc[1][1][0], xc[1][1][1]};
-                Store<bf16_t>::st4(fo, a1); Store<bf16_t>::st4(fo + 16, x2a);
-                Store<bf16_t>::st4(fo + p.ldf, b1); Store<bf16_t>::st4(fo + p.ldf + 16, x2b);
+                Store<T>::st4(fo, a1); Store<T>::st4(fo + 16, x2a);
+                Store<T>::st4(fo + p.ldf, b1); Store<T>::st4(fo + p.ldf + 16, x2b);
             }
             f32x4 acca = {0.f, 0.f, 0.f, 0.f}, accb = {0.f, 0.f, 0.f, 0.f};
             {
-                const uint4 fa = make_uint4(pack_bf16x2(xc[0][0][0], xc[0][0][1]), pack_bf16x2(xc[0][1][0], xc[0][1][1]), pack_bf16x2(x2a[0], x2a[1]), pack_bf16x2(x2a[2], x2a[3]));
-                const uint4 fb = make_uint4(pack_bf16x2(xc[1][0][0], xc[1][0][1]), pack_bf16x2(xc[1][1][0], xc[1][1][1]), pack_bf16x2(x2b[0], x2b[1]), pack_bf16x2(x2b[2], x2b[3]));
-                dh_mfma(afrag, fa, acca);
-                dh_mfma(afrag, fb, accb);
+                const uint4 fa = make_uint4(H16<T>::pack(xc[0][0][0], xc[0][0][1]), H16<T>::pack(xc[0][1][0], xc[0][1][1]), H16<T>::pack(x2a[0], x2a[1]), H16<T>::pack(x2a[2], x2a[3]));
+                const uint4 fb = make_uint4(H16<T>::pack(xc[1][0][0], xc[1][0][1]), H16<T>::pack(xc[1][1][0], xc[1][1][1]), H16<T>::pack(x2b[0], x2b[1]), H16<T>::pack(x2b[2], x2b[3]));
+                dh_mfma<T>(afrag, fa, acca);
+                dh_mfma<T>(afrag, fb, accb);
             }
             ACH_UNROLL
             for (int r = 0; r < 2; ++r) {
@@ -474,10 +484,10 @@ __global__ __launch_bounds__(64 * ACH_DH_WG_WAVES, ACH_DH2_WAVES) void dechead_r
         {
             const int ro = i - 2;
             const bool row_st = ro >= r0 && ro < r1;
-            bf16_t* orow = out_b + long(row_st ? ro : r0) * Wd;
+            IO* orow = out_b + long(row_st ? ro : r0) * Wd;
             ACH_UNROLL
             for (int r = 0; r < 2; ++r)
-                if (row_st && st_h[r]) *reinterpret_cast<uint32_t*>(orow + off_h[r]) = pack_bf16x2(hc[r][0], hc[r][1]);
+                if (row_st && st_h[r]) *reinterpret_cast<uint32_t*>(orow + off_h[r]) = H16<IO>::pack(hc[r][0], hc[r][1]);
             ACH_UNROLL
             for (int r = 0; r < NR; ++r) {
                 const f32x2 wv0 = {wh[0][r], wh[0][r]}, wv1 = {wh[1][r], wh[1][r]}, wv2 = {wh[2][r], wh[2][r]}, wv3 = {wh[3][r], wh[3][r]}, wv4 = {wh[4][r], wh[4][r]},
@@ -487,7 +497,7 @@ __global__ __launch_bounds__(64 * ACH_DH_WG_WAVES, ACH_DH2_WAVES) void dechead_r
                 const f32x2 sch = f32x2{bdh[r], bdh[r]} + wv1 * hm[r] + wv4 * hc[r] + wv7 * hp[r];
                 const float oa = add_from_left(sch[0] + srh[1], slh[1]);                 // column A: own B's right taps + lane n-1's B left taps
                 const float ob = add_from_right(sch[1] + slh[0], srh[0]);                // column B: own A's left taps + lane n+1's A right taps
-                if (row_st && st_d[r]) *reinterpret_cast<uint32_t*>(orow + off_d[r]) = pack_bf16x2(relu_raw(oa), relu_raw(ob));
+                if (row_st && st_d[r]) *reinterpret_cast<uint32_t*>(orow + off_d[r]) = H16<IO>::pack(relu_raw(oa), relu_raw(ob));
             }
         }
     };
@@ -513,7 +523,7 @@ struct UpGhostRowsParams {
 };
 constexpr int UGR_VALID = 14;
 
-template <int NP>
+template <class T, int NP>
 __global__ __launch_bounds__(64, (NP <= 2 ? 4 : (NP == 3 ? 3 : 2))) void upghost_rows_kernel(const UpGhostRowsParams p, const DecHeadRow* __restrict__ rows) {
     constexpr int CL = 2 * NP;                                   // channels per lane
     const int H = 2 * p.h, Wd = 2 * p.w;
@@ -531,7 +541,7 @@ __global__ __launch_bounds__(64, (NP <= 2 ? 4 : (NP == 3 ? 3 : 2))) void upghost
     const int dx = x0 < p.w - 1 ? 1 : 0;
     const float lx = fx - float(x0);
     const float wx0 = in_x ? 1.f - lx : 0.f, wx1 = in_x ? lx : 0.f;
-    const bf16_t* Tq = static_cast<const bf16_t*>(p.Tq) + b * p.h * long(p.w) * p.ldt;
+    const T* Tq = static_cast<const T*>(p.Tq) + b * p.h * long(p.w) * p.ldt;
     const unsigned o0 = unsigned(x0 * int(p.ldt) + CL * g), o1 = unsigned((x0 + dx) * int(p.ldt) + CL * g);
     const int rowp = p.w * int(p.ldt);
     f32x2 wl[9][NP], bl[NP];
@@ -539,18 +549,18 @@ __global__ __launch_bounds__(64, (NP <= 2 ? 4 : (NP == 3 ? 3 : 2))) void upghost
     for (int k = 0; k < 9; ++k) { ACH_UNROLL for (int q = 0; q < NP; ++q) wl[k][q] = f32x2{p.Wdw[k * p.Cg + CL * g + 2 * q], p.Wdw[k * p.Cg + CL * g + 2 * q + 1]}; }
     ACH_UNROLL
     for (int q = 0; q < NP; ++q) bl[q] = f32x2{p.bdw[CL * g + 2 * q], p.bdw[CL * g + 2 * q + 1]};
-    bf16_t* Yb = static_cast<bf16_t*>(p.Y) + b * long(H) * Wd * p.ldy;                       // (uniform)
+    T* Yb = static_cast<T*>(p.Y) + b * long(H) * Wd * p.ldy;                       // (uniform)
     const unsigned yo = unsigned(in_x ? x : 0) * unsigned(p.ldy) + unsigned(CL * g);
     const int r0 = band * p.band_rows, r1 = (r0 + p.band_rows < H) ? r0 + p.band_rows : H;
     auto load_raw = [&](int r, uint32_t (&raw)[2][NP]) {
         const int rr = r < 0 ? 0 : (r > p.h - 1 ? p.h - 1 : r);
-        const bf16_t* q = Tq + long(rr) * rowp;
+        const T* q = Tq + long(rr) * rowp;
         ACH_UNROLL
         for (int i = 0; i < NP; ++i) { raw[0][i] = reinterpret_cast<const uint32_t*>(q + o0)[i]; raw[1][i] = reinterpret_cast<const uint32_t*>(q + o1)[i]; }
     };
     auto unpack = [&](const uint32_t (&raw)[2][NP], f32x2 (&o)[2][NP]) {
         ACH_UNROLL
-        for (int c = 0; c < 2; ++c) { ACH_UNROLL for (int i = 0; i < NP; ++i) o[c][i] = f32x2{__uint_as_float(raw[c][i] << 16), __uint_as_float(raw[c][i] & 0xffff0000u)}; }
+        for (int c = 0; c < 2; ++c) { ACH_UNROLL for (int i = 0; i < NP; ++i) o[c][i] = f32x2{H16<T>::lo(raw[c][i]), H16<T>::hi(raw[c][i])}; }
     };
     const int i_first = r0 - 1 < 0 ? 0 : r0 - 1;
     int cy = rows[i_first].y0;
@@ -602,10 +612,10 @@ __global__ __launch_bounds__(64, (NP <= 2 ? 4 : (NP == 3 ? 3 : 2))) void upghost
             }
         }
         if (ro >= r0 && ro < r1 && writer) {
-            bf16_t* yrow = Yb + long(ro) * Wd * p.ldy + yo;
+            T* yrow = Yb + long(ro) * Wd * p.ldy + yo;
             uint32_t a[NP], c[NP];
             ACH_UNROLL
-            for (int q = 0; q < NP; ++q) { a[q] = pack_bf16x2(xc[q][0], xc[q][1]); c[q] = pack_bf16x2(x2[2 * q], x2[2 * q + 1]); }
+            for (int q = 0; q < NP; ++q) { a[q] = H16<T>::pack(xc[q][0], xc[q][1]); c[q] = H16<T>::pack(x2[2 * q], x2[2 * q + 1]); }
             ACH_UNROLL
             for (int q = 0; q < NP; ++q) { reinterpret_cast<uint32_t*>(yrow)[q] = a[q]; reinterpret_cast<uint32_t*>(yrow + p.Cg)[q] = c[q]; }
         }

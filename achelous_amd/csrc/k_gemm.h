@@ -55,7 +55,7 @@ struct GemmParams {
     int nchunks, ksteps;
     int chunks_per_block;               // blockIdx.z selects a contiguous range of N-chunks (fills the chip when M is small)
     int act, ln; float ln_eps;
-    int out_nchw, HW, Ctot, coff;       // NCHW scatter: Y[((b*Ctot + coff + n)*HW + p)], m = b*HW + p
+    int out_nchw, HW, Ctot, coff;       // NCHW scatter: Y[((b*Ctot + coff + n)*HW + p)], m = b*HW + p (2: the caller's tensor is bf16 while the engine stores fp16)
     int vec_store;                      // Y/R rows and channel offsets are 16-byte compatible
 };
 
@@ -275,7 +275,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, unsigned bx, unsi
                     ACH_UNROLL
                     for (int r = 0; r < 4; ++r) {
                         const int n = cbase + chunk_channel(NT, t, g, r);
-                        if (n < p.N) Store<T>::st(Y + ((b * p.Ctot + p.coff + n) * p.HW + pix), o[t * 4 + r]);
+                        if (n < p.N) st_user<T>(Y, (b * p.Ctot + p.coff + n) * p.HW + pix, o[t * 4 + r], p.out_nchw == 2);
                     }
                 continue;
             }

@@ -48,7 +48,7 @@ struct HeadDwParams {
     int shared_in;                    // 1: both towers read the SAME 64 input channels (first layer, fed by the stem); 0: tower br reads channels br*64 ..
 };
 
-template <class T>          // (bf16_t; a template so that the two engine translation units can both include the header)
+template <class T>          // (bf16_t / f16_t: the 16-bit storage types)
 __global__ __launch_bounds__(HDW_THREADS, HDW_WGS) void headdw_kernel(const HeadDwParams p) {
     constexpr int C = HDW_C, SP = HDW_SP, KS = 5;
     __shared__ __attribute__((aligned(16))) float xin[HDW_F32 ? HDW_MAXPOS * C : HDW_MAXPOS * C / 2];       // 90 KB (fp32) / 45 KB (bf16)
@@ -132,8 +132,8 @@ __global__ __launch_bounds__(HDW_THREADS, HDW_WGS) void headdw_kernel(const Head
                         v[j][0] = f32x2{t.x, t.y}; v[j][1] = f32x2{t.z, t.w};
                     } else {
                         const uint2 t = reinterpret_cast<const uint2*>(xin)[((r + ty) * WCr + col) * (C / 4) + cg];
-                        v[j][0] = f32x2{__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u)};
-                        v[j][1] = f32x2{__uint_as_float(t.y << 16), __uint_as_float(t.y & 0xffff0000u)};
+                        v[j][0] = f32x2{H16<T>::lo(t.x), H16<T>::hi(t.x)};
+                        v[j][1] = f32x2{H16<T>::lo(t.y), H16<T>::hi(t.y)};
                     }
                 }
                 ACH_UNROLL
@@ -146,8 +146,8 @@ __global__ __launch_bounds__(HDW_THREADS, HDW_WGS) void headdw_kernel(const Head
             }
             ACH_UNROLL
             for (int i = 0; i < SP; ++i) {
-                res[k][i].x = pack_bf16x2(acc[i][0][0], acc[i][0][1]);
-                res[k][i].y = pack_bf16x2(acc[i][1][0], acc[i][1][1]);
+                res[k][i].x = H16<T>::pack(acc[i][0][0], acc[i][0][1]);
+                res[k][i].y = H16<T>::pack(acc[i][1][0], acc[i][1][1]);
 #if !defined(ACH_HOSTEMU)
                 asm volatile("" : "+v"(res[k][i].x), "+v"(res[k][i].y));          // the sums exist BEFORE the barrier (k_upchain.h: the compiler sinks them otherwise)
 #endif
@@ -209,8 +209,8 @@ __global__ __launch_bounds__(HDW_THREADS, HDW_WGS) void headdw_kernel(const Head
                         v[j][0] = f32x2{t.x, t.y}; v[j][1] = f32x2{t.z, t.w};
                     } else {
                         const uint2 t = reinterpret_cast<const uint2*>(xin)[((r + ty) * WCr + col) * (C / 4) + cg];
-                        v[j][0] = f32x2{__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u)};
-                        v[j][1] = f32x2{__uint_as_float(t.y << 16), __uint_as_float(t.y & 0xffff0000u)};
+                        v[j][0] = f32x2{H16<T>::lo(t.x), H16<T>::hi(t.x)};
+                        v[j][1] = f32x2{H16<T>::lo(t.y), H16<T>::hi(t.y)};
                     }
                 }
                 ACH_UNROLL
@@ -227,8 +227,8 @@ __global__ __launch_bounds__(HDW_THREADS, HDW_WGS) void headdw_kernel(const Head
                 if (x0 + i >= W) continue;
                 const int pix = r * W + x0 + i, t = pix >> 4, pp = pix & 15;
                 uint2 o;
-                o.x = pack_bf16x2(acc[i][0][0], acc[i][0][1]);
-                o.y = pack_bf16x2(acc[i][1][0], acc[i][1][1]);
+                o.x = H16<T>::pack(acc[i][0][0], acc[i][0][1]);
+                o.y = H16<T>::pack(acc[i][1][0], acc[i][1][1]);
                 *reinterpret_cast<uint2*>(reinterpret_cast<char*>(xs + (t * 2 + s) * 64 + gg * 16 + pp) + e * 2) = o;
             }
         }

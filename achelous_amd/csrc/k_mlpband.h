@@ -52,10 +52,9 @@ struct MlpBandGeom {
 // PREF: the next hidden chunk's weight fragments are requested one chunk ahead (a second register set).
 // TILEPAR (the narrow blocks of the large maps: few hidden chunks, many tiles): a wave takes whole TILES (t = wave, wave + 8, ...) through
 // every hidden chunk instead of a share of the chunks for every tile — no partial sums, no reduction phase.
-template <int K1, int DT, int KS, int RB, int MAXW, bool XF32, bool PREF, bool TILEPAR = false>
+template <class T, int K1, int DT, int KS, int RB, int MAXW, bool XF32, bool PREF, bool TILEPAR = false>
 __global__ __launch_bounds__(MLPB_THREADS, 1) void mlp_band_kernel(const MlpBandParams bp) {
     using G = MlpBandGeom<K1, DT, KS, RB, MAXW, XF32>;
-    typedef bf16_t T;
     constexpr int CP = G::CP, NT = G::NT, SP = MLPB_SP, NTB = mlpb_ntb(DT);
     const MlpParams& p = bp.m;
     __shared__ float xin[G::XIN_FLOATS];
@@ -130,8 +129,8 @@ __global__ __launch_bounds__(MLPB_THREADS, 1) void mlp_band_kernel(const MlpBand
                         v[j][0] = f32x2{t.x, t.y}; v[j][1] = f32x2{t.z, t.w};
                     } else {
                         const uint2 t = reinterpret_cast<const uint2*>(xin)[((r + ty) * WCr + col) * (CP / 4) + cg];
-                        v[j][0] = f32x2{__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u)};
-                        v[j][1] = f32x2{__uint_as_float(t.y << 16), __uint_as_float(t.y & 0xffff0000u)};
+                        v[j][0] = f32x2{H16<T>::lo(t.x), H16<T>::hi(t.x)};
+                        v[j][1] = f32x2{H16<T>::lo(t.y), H16<T>::hi(t.y)};
                     }
                 }
                 ACH_UNROLL
@@ -340,13 +339,14 @@ inline int mlp_band_shape(int k1, int DT, int ks, int W) {
 }
 inline bool mlp_band_supported(int k1, int DT, int ks, int H, int W) { return H >= 1 && mlp_band_shape(k1, DT, ks, W) != 0; }
 inline int mlp_band_rows(int k1, int DT, int ks, int H, int W) { const int sh = mlp_band_shape(k1, DT, ks, W), rb = sh == 3 ? 4 : (sh == 4 ? 4 : (sh == 5 ? 4 : 5)); return H >= rb ? rb : H; }
+template <class T>
 inline void launch_mlp_band(const MlpBandParams& bp, int shape, int B, hipStream_t stream) {
     const dim3 grid(unsigned(bp.bands) * unsigned(B)), block(MLPB_THREADS);
-    if (shape == 1) ACH_LAUNCH((mlp_band_kernel<3, 6, 7, 5, 20, true, true>), grid, block, stream, bp);
-    else if (shape == 2) ACH_LAUNCH((mlp_band_kernel<6, 12, 9, 5, 10, false, false>), grid, block, stream, bp);
-    else if (shape == 3) ACH_LAUNCH((mlp_band_kernel<5, 10, 7, 4, 20, false, false>), grid, block, stream, bp);
-    else if (shape == 4) ACH_LAUNCH((mlp_band_kernel<2, 4, 5, 4, 40, true, false, true>), grid, block, stream, bp);
-    else ACH_LAUNCH((mlp_band_kernel<1, 2, 3, 4, 80, true, false, true>), grid, block, stream, bp);
+    if (shape == 1) ACH_LAUNCH((mlp_band_kernel<T, 3, 6, 7, 5, 20, true, true>), grid, block, stream, bp);
+    else if (shape == 2) ACH_LAUNCH((mlp_band_kernel<T, 6, 12, 9, 5, 10, false, false>), grid, block, stream, bp);
+    else if (shape == 3) ACH_LAUNCH((mlp_band_kernel<T, 5, 10, 7, 4, 20, false, false>), grid, block, stream, bp);
+    else if (shape == 4) ACH_LAUNCH((mlp_band_kernel<T, 2, 4, 5, 4, 40, true, false, true>), grid, block, stream, bp);
+    else ACH_LAUNCH((mlp_band_kernel<T, 1, 2, 3, 4, 80, true, false, true>), grid, block, stream, bp);
 }
 
 }  // namespace ach

@@ -253,7 +253,7 @@ struct StemParams {
     const float* bias; const float* lnw; const float* lnb;
     int B, H, Wd; float eps;
 };
-template <class T>
+template <class T, class IO = T>       // IO: the type of the caller's image
 __global__ __launch_bounds__(256) void stem_kernel(const StemParams p) {
     constexpr int CO = 32;
     const int Ho = p.H / 4, Wo = p.Wd / 4;
@@ -263,15 +263,15 @@ __global__ __launch_bounds__(256) void stem_kernel(const StemParams p) {
     const int ox = int(idx % Wo);
     const int oy = int((idx / Wo) % Ho);
     const long b = idx / (long(Wo) * Ho);
-    const T* X = static_cast<const T*>(p.X);
+    const IO* X = static_cast<const IO*>(p.X);
     float acc[CO];
     ACH_UNROLL
     for (int o = 0; o < CO; ++o) acc[o] = p.bias[o];
     for (int c = 0; c < 3; ++c)
         for (int dy = 0; dy < 4; ++dy) {
-            const T* row = X + ((b * 3 + c) * p.H + (oy * 4 + dy)) * long(p.Wd) + ox * 4;
+            const IO* row = X + ((b * 3 + c) * p.H + (oy * 4 + dy)) * long(p.Wd) + ox * 4;
             float v4[4];
-            Store<T>::ld4(row, v4);                               // the patch row: one 8 / 16-byte load (W is a multiple of 4)
+            Store<IO>::ld4(row, v4);                               // the patch row: one 8 / 16-byte load (W is a multiple of 4)
             ACH_UNROLL
             for (int dx = 0; dx < 4; ++dx) {
                 const float v = v4[dx];
@@ -309,7 +309,7 @@ struct StemMfmaParams {
     const void* W; const float* bias; const float* lnw; const float* lnb;   // W: packed NT = 2, ksteps = ceil(48 / KC)
     int B, H, Wd, ksteps; float eps;
 };
-template <class T>
+template <class T, class IO = T>
 __global__ __launch_bounds__(256) void stem_mfma_kernel(const StemMfmaParams p) {
     constexpr int VEC = Store<T>::VEC, KC = 4 * VEC, SEG = VEC / 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const StemMfmaParams p) 
     const int ox = int(m % Wo);
     const int oy = int((m / Wo) % Ho);
     const long b = m / (long(Wo) * Ho);
-    const T* X = static_cast<const T*>(p.X) + (b * 3 * p.H + oy * 4) * long(p.Wd) + ox * 4;     // channel 0, patch row 0
+    const IO* X = static_cast<const IO*>(p.X) + (b * 3 * p.H + oy * 4) * long(p.Wd) + ox * 4;     // channel 0, patch row 0
     const long cstride = long(p.H) * p.Wd;
     f32x4 acc[2];
     acc[0][0] = acc[0][1] = acc[0][2] = acc[0][3] = 0.f;
@@ -335,8 +335,8 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const StemMfmaParams p) 
         for (int h = 0; h < SEG; ++h) {
             const int kk = s * KC + g * VEC + 4 * h;                 // first k of this 4-pixel patch row
             if (valid && kk < 48) {
-                const T* row = X + (kk >> 4) * cstride + ((kk >> 2) & 3) * long(p.Wd);
-                if (sizeof(T) == 2) { const uint2 v = *reinterpret_cast<const uint2*>(row); raw[2 * h] = v.x; raw[2 * h + 1] = v.y; }
+                const IO* row = X + (kk >> 4) * cstride + ((kk >> 2) & 3) * long(p.Wd);
+                if (sizeof(T) == 2) { const uint2 v = *reinterpret_cast<const uint2*>(row); raw[2 * h] = h16_recast<IO, T>(v.x); raw[2 * h + 1] = h16_recast<IO, T>(v.y); }
                 else { const uint4 v = *reinterpret_cast<const uint4*>(row); raw[0] = v.x; raw[1] = v.y; raw[2] = v.z; raw[3] = v.w; }
             }
         }
@@ -801,6 +801,7 @@ struct UpGhostHeadParams {
     const float* Wdh; const float* bdh;       // head cheap op: [9][nch], [nch]
     int B, h, w, init, nch, oup;
     float sy, sx;                             // (h-1)/(2h-1), (w-1)/(2w-1): align_corners source scale (computed on the host, same float division)
+    int out_bf16 = 0;                         // fp16-storage engine: the caller's output tensor is bf16 (st_user)
 };
 constexpr int UGH_TW = 30, UGH_TH = 6, UGH_CG = 16, UGH_IMAX = 8, UGH_THREADS = 256;
 
@@ -870,13 +871,13 @@ __device__ __forceinline__ void upghost_head_tail(const UpGhostHeadParams& p, co
     // ---- outputs: the interior positions
     if (inside && ly_ >= 1 && ly_ <= TH && lx_ >= 1 && lx_ <= TW && !(DBG & 8)) {
         const long HW = long(H) * Wd;
-        T* out = static_cast<T*>(p.out) + b * p.oup * HW + long(oy) * Wd + ox;
-        for (int j = 0; j < p.init && j < p.oup; ++j) Store<T>::st(out + j * HW, hs[j][tid]);
+        const long o0 = b * p.oup * HW + long(oy) * Wd + ox;
+        for (int j = 0; j < p.init && j < p.oup; ++j) st_user<T>(p.out, o0 + j * HW, hs[j][tid], p.out_bf16 != 0);
         for (int j = 0; j < p.nch; ++j) {
             float a = bdh[j];
             ACH_UNROLL
             for (int k = 0; k < 9; ++k) a += hs[j][(ly_ - 1 + k / 3) * W1P + lx_ - 1 + k % 3] * Wdh[k * p.nch + j];
-            Store<T>::st(out + (p.init + j) * HW, a > 0.f ? a : 0.f);
+            st_user<T>(p.out, o0 + (p.init + j) * HW, a > 0.f ? a : 0.f, p.out_bf16 != 0);
         }
     }
 }

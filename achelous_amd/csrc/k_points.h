@@ -11,14 +11,14 @@ namespace ach {
 
 // [B, D, N] (reference layout, utils/dataloader.py:546-547) -> rows [B*N, ld] with channels D..ld-1 zero
 struct PcPrepParams { const void* X; void* Y; int B, D, N; long ld; };
-template <class T>
+template <class T, class IO = T>
 __global__ void pc_prep_kernel(const PcPrepParams p) {
     const long idx = long(blockIdx.x) * blockDim.x + threadIdx.x;
     if (idx >= long(p.B) * p.N * p.ld) return;
     const int c = int(idx % p.ld);
     const long row = idx / p.ld;
     const long b = row / p.N, n = row - b * p.N;
-    const float v = c < p.D ? Store<T>::ld(static_cast<const T*>(p.X) + (b * p.D + c) * p.N + n) : 0.f;
+    const float v = c < p.D ? Store<IO>::ld(static_cast<const IO*>(p.X) + (b * p.D + c) * p.N + n) : 0.f;
     Store<T>::st(static_cast<T*>(p.Y) + idx, v);
 }
 
@@ -74,7 +74,7 @@ __global__ void pc_concat_kernel(const PcConcatParams p) {
 
 // log_softmax over the class axis; output dense [rows, K]
 struct LsmParams { const void* X; long ldx; void* Y; long rows; int K; };
-template <class T>
+template <class T, class IO = T>
 __global__ void log_softmax_kernel(const LsmParams p) {
     const long row = long(blockIdx.x) * blockDim.x + threadIdx.x;
     if (row >= p.rows) return;
@@ -84,7 +84,7 @@ __global__ void log_softmax_kernel(const LsmParams p) {
     float s = 0.f;
     for (int k = 0; k < p.K; ++k) s += expf(Store<T>::ld(x + k) - mx);
     const float lse = mx + logf(s);
-    for (int k = 0; k < p.K; ++k) Store<T>::st(static_cast<T*>(p.Y) + row * p.K + k, Store<T>::ld(x + k) - lse);
+    for (int k = 0; k < p.K; ++k) Store<IO>::st(static_cast<IO*>(p.Y) + row * p.K + k, Store<T>::ld(x + k) - lse);
 }
 
 }  // namespace ach

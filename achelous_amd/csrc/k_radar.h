@@ -18,29 +18,29 @@ namespace ach {
 
 // NCHW [B,C,H,W] -> NHWC [B,H,W,ld] (channels C..ld-1 are left untouched = 0)
 struct ToNhwcParams { const void* X; void* Y; int B, C, H, Wd; long ld; };
-template <class T>
+template <class T, class IO = T>      // IO: the type of the caller's tensor (a 16-bit engine may take bf16 inputs into fp16 storage)
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const ToNhwcParams p) {
     const long total = long(p.B) * p.H * p.Wd;
     const long idx = long(blockIdx.x) * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const long HW = long(p.H) * p.Wd;
     const long b = idx / HW, pix = idx - b * HW;
-    const T* x = static_cast<const T*>(p.X) + b * p.C * HW + pix;
+    const IO* x = static_cast<const IO*>(p.X) + b * p.C * HW + pix;
     T* y = static_cast<T*>(p.Y) + idx * p.ld;
-    for (int c = 0; c < p.C; ++c) y[c] = x[c * HW];
+    for (int c = 0; c < p.C; ++c) Store<T>::st(y + c, Store<IO>::ld(x + c * HW));
 }
 
 // 3-channel NCHW -> 4-channel NHWC pixels (8 B in bf16, 16 B in fp32; channel 3 = 0): the layout of the first RCBlock's maps.
 // One thread = 4 consecutive pixels of a row: one vector load per plane, four pixels written as one contiguous 32 / 64 bytes.
-template <class T>
+template <class T, class IO = T>
 __global__ __launch_bounds__(256) void nchw3_to_nhwc4_kernel(const ToNhwcParams p) {
     const long HW = long(p.H) * p.Wd, quads = HW / 4;
     const long idx = long(blockIdx.x) * blockDim.x + threadIdx.x;
     if (idx >= long(p.B) * quads) return;
     const long b = idx / quads, pix = (idx - b * quads) * 4;
-    const T* x = static_cast<const T*>(p.X) + b * 3 * HW + pix;
+    const IO* x = static_cast<const IO*>(p.X) + b * 3 * HW + pix;
     float c0[4], c1[4], c2[4];
-    Store<T>::ld4(x, c0); Store<T>::ld4(x + HW, c1); Store<T>::ld4(x + 2 * HW, c2);
+    Store<IO>::ld4(x, c0); Store<IO>::ld4(x + HW, c1); Store<IO>::ld4(x + 2 * HW, c2);
     T* y = static_cast<T*>(p.Y) + (b * HW + pix) * 4;
     ACH_UNROLL
     for (int i = 0; i < 4; ++i) { const float v[4] = {c0[i], c1[i], c2[i], 0.f}; Store<T>::st4(y + 4 * i, v); }

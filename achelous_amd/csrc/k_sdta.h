@@ -16,6 +16,7 @@ namespace ach {
 template <class T> __device__ __forceinline__ float round_to(float v);                  // the value a store of v to the storage type reads back as
 template <> __device__ __forceinline__ float round_to<float>(float v) { return v; }
 template <> __device__ __forceinline__ float round_to<bf16_t>(float v) { return bf16_to_f32(f32_to_bf16(v)); }
+template <> __device__ __forceinline__ float round_to<f16_t>(float v) { return f16_to_f32(f32_to_f16(v)); }
 
 struct SdtaPreParams {
     const void* X; long ldx;

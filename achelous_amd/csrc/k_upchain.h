@@ -32,9 +32,8 @@ struct UpGhostChainParams {
 // register budget: four waves per SIMD at Cg = 16 (four workgroups per CU; measured 59 -> 49 us on the 160 x 160 level against the
 // compiler's free choice of 132), three at Cg = 24 / 32 (two workgroups of 6 / 8 waves per CU)
 #define ACH_UPC_BOUNDS(CG) __launch_bounds__(16 * CG, (ACH_UPC_WAVES > 0 ? ACH_UPC_WAVES : (CG <= 16 ? 4 : 3)))
-template <int CG>
+template <class T, int CG>
 __global__ ACH_UPC_BOUNDS(CG) void upghost_chain_kernel(const UpGhostChainParams q) {
-    typedef bf16_t T;
     constexpr int TS = UPG_TS, HS = TS + 2, CQ = CG / 4, K1 = (2 * CG + 31) / 32, NW = 16 * CG / 64;
     // one buffer: x1 (fp32, tile + halo) in phases 1-2, then the B fragments of the tile's 16 rows (the depthwise results wait in registers
     // across the barrier): 21 / 33 / 42 KB for Cg = 16 / 24 / 32 instead of 37 / 64 / 74 — the kernel is latency-bound, workgroups per CU matter
@@ -141,8 +140,8 @@ __global__ ACH_UPC_BOUNDS(CG) void upghost_chain_kernel(const UpGhostChainParams
         }
         ACH_UNROLL
         for (int i = 0; i < 4; ++i) acc[i] = acc[i] > 0.f ? acc[i] : 0.f;
-        fr[it][0] = make_uint2(pack_bf16x2(o1[0], o1[1]), pack_bf16x2(o1[2], o1[3]));
-        fr[it][1] = make_uint2(pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3]));
+        fr[it][0] = make_uint2(H16<T>::pack(o1[0], o1[1]), H16<T>::pack(o1[2], o1[3]));
+        fr[it][1] = make_uint2(H16<T>::pack(acc[0], acc[1]), H16<T>::pack(acc[2], acc[3]));
 #if !defined(ACH_HOSTEMU)
         // the packed results must EXIST before the barrier: left alone, the compiler (Cg = 24) read all 36 taps, sank the arithmetic below the
         // barrier and carried 144 registers across it (242 VGPRs, or 81 spilled at a 168 budget)

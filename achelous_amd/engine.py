@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_LIBRARY = os.path.join(_HERE, 'libachelous_hip.so')
 
-DTYPE_F32, DTYPE_BF16 = 0, 1
+DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2      # include/achelous.h ACH_DTYPE_*: storage type of the activations (F16: inputs / outputs fp16, or bf16 with option io_bf16)
 BACKBONES = {'en': 0, 'mv': 1}
 PHIS = {'S0': 0, 'S1': 1, 'S2': 2}
 NECKS = {'gdf': 0, 'cdf': 1}
@@ -186,7 +186,7 @@ class NativeEngine:
         self.cfg = AchConfig(num_det, num_seg, PHIS[phi], BACKBONES[backbone], resolution, pc_channels, pc_classes,
                              num_points, int(bool(nano_head)), int(bool(spp)), dtype, NECKS[neck], PC_SEGS[pc_seg])
         self.dtype = dtype
-        self.torch_dtype = torch.float32 if dtype == DTYPE_F32 else torch.bfloat16
+        self.torch_dtype = {DTYPE_F32: torch.float32, DTYPE_BF16: torch.bfloat16, DTYPE_F16: torch.float16}[dtype]     # of the caller's tensors (bf16 after set_option('io_bf16', 1))
         self.h = ctypes.c_void_p()
         rc = self.L.ach_create(ctypes.byref(self.cfg), ctypes.byref(self.h))
         if rc != 0:
@@ -238,6 +238,8 @@ class NativeEngine:
     def set_option(self, key, value):
         self._check(self.L.ach_set_option(self.h, key.encode(), int(value)))
         self.batch = 0
+        if key == 'io_bf16' and self.dtype == DTYPE_F16:
+            self.torch_dtype = torch.bfloat16 if int(value) else torch.float16
 
     def plan(self, batch):
         self._check(self.L.ach_plan(self.h, int(batch)))

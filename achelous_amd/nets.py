@@ -142,6 +142,10 @@ class Achelous(nn.Module):
         self.static_weights = False  # True: skip the per-call check for in-place weight changes (serving loops)
         self.engine_options = {}    # ach_set_option(key, value) pairs applied when an engine is created (include/achelous.h)
         self.max_plan_batch = 256   # larger batches run as near-equal chunks through one plan (_run_chunked)
+        # bf16 inputs: 'f16' (default, round 4) = activations and MFMA operands in fp16 — same bytes and matrix rate as bf16 with 11 mantissa bits
+        # instead of 8, the type the reference's own mixed-precision mode computes in (utils/utils_fit.py:120-121) — converted from / to bf16 in
+        # the first / last kernels; 'bf16' = bf16 end to end (round 3's engine).  fp16 inputs always run the fp16 engine.
+        self.bf16_storage = 'f16'
 
     # engines hold ctypes handles: never pickle / deepcopy them (utils_fit.py:378 pickles the module, ModelEMA deep-copies it)
     def __getstate__(self):
@@ -202,7 +206,7 @@ class Achelous(nn.Module):
 
     def native_engine(self, dtype=torch.float32, device=None):
         """The engine that served the last forward of this dtype on `device` (tests, bench: taps, launch table, options)."""
-        code = _eng.DTYPE_BF16 if dtype == torch.bfloat16 else _eng.DTYPE_F32
+        code = self._engine_code(dtype)
         dev = torch.cuda.current_device() if device is None else torch.device(device).index
         hits = [v[0] for k, v in self._engines.items() if k[:2] == (dev, code)]
         hits.sort(key=lambda e: getattr(e, '_last_use', 0))
@@ -210,13 +214,20 @@ class Achelous(nn.Module):
             raise KeyError(f"no forward has run yet for dtype {dtype} on device {dev}")
         return hits[-1]
 
-    def _engine_for(self, device, dtype, batch, num_points, pipelined=False):
+    def _engine_code(self, dtype):
+        """(ACH_DTYPE_* storage type, io_bf16) for inputs of `dtype`."""
         if dtype == torch.float32:
-            code = _eng.DTYPE_F32
-        elif dtype == torch.bfloat16:
-            code = _eng.DTYPE_BF16
-        else:
-            raise TypeError(f"Achelous forward supports float32 and bfloat16 inputs, got {dtype}")
+            return (_eng.DTYPE_F32, 0)
+        if dtype == torch.float16:
+            return (_eng.DTYPE_F16, 0)
+        if dtype == torch.bfloat16:
+            if self.__dict__.get('bf16_storage', 'f16') not in ('f16', 'bf16'):
+                raise ValueError(f"bf16_storage must be 'f16' or 'bf16', got {self.bf16_storage!r}")
+            return (_eng.DTYPE_F16, 1) if self.__dict__.get('bf16_storage', 'f16') == 'f16' else (_eng.DTYPE_BF16, 0)
+        raise TypeError(f"Achelous forward supports float32, float16 and bfloat16 inputs, got {dtype}")
+
+    def _engine_for(self, device, dtype, batch, num_points, pipelined=False):
+        code = self._engine_code(dtype)
         key = (device.index, code, num_points, bool(pipelined))   # one engine per point-count bucket (and schedule): a new N never evicts another's plan
         ent = self._engines.get(key)
         ver = ent[1] if (self.static_weights and ent is not None and ent[1] is not None) else self._weights_version()
@@ -224,7 +235,9 @@ class Achelous(nn.Module):
             eng = _eng.NativeEngine(_eng.hip_library(), num_det=self.num_det, num_seg=self.num_seg, phi=self.phi,
                                     backbone=self.backbone, resolution=self.resolution, pc_channels=self.pc_channels,
                                     pc_classes=self.pc_classes, num_points=num_points, nano_head=self.nano_head,
-                                    spp=self.spp, dtype=code, neck=self.neck, pc_seg=self.pc_seg_kind)
+                                    spp=self.spp, dtype=code[0], neck=self.neck, pc_seg=self.pc_seg_kind)
+            if code[1]:
+                eng.set_option('io_bf16', 1)
             eng.set_option('full_taps', 1 if self.debug_taps else 0)
             for k, v in self.engine_options.items():
                 eng.set_option(k, int(v))

@@ -15,10 +15,10 @@ _handles = {}
 
 
 def _handle(num_det, resolution, dtype):
-    if dtype not in (torch.float32, torch.bfloat16):
-        # the kernels exist for fp32 and bf16 storage only; any other element size would be read / written with the wrong stride
-        raise TypeError(f"achelous_amd kernels take float32 or bfloat16 tensors, got {dtype}")
-    code = _eng.DTYPE_BF16 if dtype == torch.bfloat16 else _eng.DTYPE_F32
+    if dtype not in (torch.float32, torch.bfloat16, torch.float16):
+        # the kernels exist for fp32, bf16 and fp16 tensors only; any other element size would be read / written with the wrong stride
+        raise TypeError(f"achelous_amd kernels take float32, bfloat16 or float16 tensors, got {dtype}")
+    code = {torch.bfloat16: _eng.DTYPE_BF16, torch.float16: _eng.DTYPE_F16, torch.float32: _eng.DTYPE_F32}[dtype]
     key = (torch.cuda.current_device(), num_det, resolution, code)
     if key not in _handles:
         _handles[key] = _eng.NativeEngine(_eng.hip_library(), num_det=num_det, num_seg=1, phi='S0', backbone='en',

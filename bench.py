@@ -59,7 +59,7 @@ WORKLOAD_NAMES = {'en_s0': 'EN-GDF-PN-S0', 'en_s2': 'EN-GDF-PN-S2', 'mv_s2': 'MV
                   'en_s0_pn2': 'EN-GDF-PN2-S0 (PointNet++ per our own specification)'}
 COMMON = dict(num_det=7, num_seg=9, resolution=320, neck='gdf', pc_seg='pn', pc_channels=5, pc_classes=8, nano_head=True, spp=True)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}
+MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'f16': 2500.0, 'f32': 157.3}
 
 
 def cpu_baseline(model, ctor, x, xr, xp, sample, procs=0):
@@ -269,7 +269,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=64, help='frames per GPU per step')
     ap.add_argument('--config', default='en_s0', choices=sorted(CONFIGS))
-    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f16', 'f32'], help='type of the input / output tensors (BASELINE configs[1]: bf16)')
+    ap.add_argument('--storage', default='f16', choices=['f16', 'bf16'], help='with --dtype bf16: activation storage / MFMA operand type inside the engine (f16: round 4 default — same bytes and matrix rate, 11 mantissa bits, the type of the reference\'s own AMP mode; bf16: round 3\'s engine)')
     ap.add_argument('--max-det', type=int, default=100)
     ap.add_argument('--conf', type=float, default=0.35)
     ap.add_argument('--iou', type=float, default=0.35)
@@ -322,11 +323,12 @@ def main():
     from achelous_amd.synth import condition_state_dict, make_inputs, config_seed
 
     cid, kw = CONFIGS[args.config]
-    tdt = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+    tdt = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32}[args.dtype]
     model = Achelous(**dict(COMMON, **kw)).eval()
     model.load_state_dict(condition_state_dict(model.state_dict(), seed=0))
     model = model.to(dev)
     model.static_weights = True          # serving loop: weights do not change between steps
+    model.bf16_storage = args.storage
     model.engine_options = {kv.split('=')[0]: int(kv.split('=')[1]) for kv in args.opt}
     B = args.batch
     x, xr, xp = make_inputs(B, config_seed(cid) + 1000 * rank, resolution=COMMON['resolution'], pc_channels=COMMON['pc_channels'], dense_radar=args.dense_radar)
@@ -465,7 +467,7 @@ def main():
     result = None
     if rank == 0:
         name, dom_bytes, dom_flops = table[dom]
-        esz = 2 if args.dtype == 'bf16' else 4
+        esz = 4 if args.dtype == 'f32' else 2
         achieved = dom_bytes / (probe_ms * 1e-3) / 1e9 if probe_ms > 0 else 0.0
         roofline = {'bound': 'hbm', 'kernel': name, 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                     'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': None,
@@ -474,7 +476,7 @@ def main():
                     'frac_isolated': round(dom_bytes / (prof[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if prof[dom] > 0 else None,
                     'share_of_forward': round(prof[dom] / max(sum(prof), 1e-9), 4)}
         traffic_file = next((f for f in (os.path.join(ROOT, 'profiles', f'r{r:02d}_traffic_{args.config}.json') for r in (3, 2)) if os.path.exists(f)), '')
-        if traffic_file and args.dtype == 'bf16' and B == 64:          # PMC passes are separate rocprofv3 runs (profiles/scripts/profile_config.sh)
+        if traffic_file and args.dtype != 'f32' and B == 64:          # PMC passes are separate rocprofv3 runs (profiles/scripts/profile_config.sh)
             try:
                 roofline['traffic'] = json.load(open(traffic_file))['ops'].get(name, {}).get('traffic_bytes')
             except Exception:

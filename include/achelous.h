@@ -34,7 +34,9 @@ extern "C" {
 
 typedef struct ach_handle ach_handle;
 
-enum { ACH_DTYPE_F32 = 0, ACH_DTYPE_BF16 = 1 };
+enum { ACH_DTYPE_F32 = 0, ACH_DTYPE_BF16 = 1,
+       ACH_DTYPE_F16 = 2    /* fp16 activations and MFMA operands, fp32 accumulation: the type the reference's mixed-precision mode computes in
+                             * (utils/utils_fit.py:120-121, train.py:37 --fp16).  Inputs / outputs are fp16, or bf16 with option "io_bf16" */ };
 enum { ACH_BACKBONE_EDGENEXT = 0, ACH_BACKBONE_MOBILEVIT = 1 };
 enum { ACH_PHI_S0 = 0, ACH_PHI_S1 = 1, ACH_PHI_S2 = 2 };
 
