@@ -309,12 +309,27 @@ template <class T> __device__ inline void mfma16(const uint4& a, const uint4& b,
 }
 #else
 typedef __bf16 bf16x8_hw __attribute__((ext_vector_type(8)));
+#ifndef ACH_MFMA16_SPLIT
+#define ACH_MFMA16_SPLIT 0         // experiments (tests/gpu_coresidency_repro.py): 1 = every 16-bit k-chunk as two 16x16x16 instructions instead of one 16x16x32
+#endif
 template <> __device__ __forceinline__ void mfma16<bf16_t>(const uint4& a, const uint4& b, f32x4& c) {
+#if ACH_MFMA16_SPLIT
+    typedef short s16x4_hw __attribute__((ext_vector_type(4)));
+    c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4_hw, make_uint2(a.x, a.y)), __builtin_bit_cast(s16x4_hw, make_uint2(b.x, b.y)), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4_hw, make_uint2(a.z, a.w)), __builtin_bit_cast(s16x4_hw, make_uint2(b.z, b.w)), c, 0, 0, 0);
+#else
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_hw, a), __builtin_bit_cast(bf16x8_hw, b), c, 0, 0, 0);
+#endif
 }
 typedef _Float16 f16x8_hw __attribute__((ext_vector_type(8)));
 template <> __device__ __forceinline__ void mfma16<f16_t>(const uint4& a, const uint4& b, f32x4& c) {
+#if ACH_MFMA16_SPLIT
+    typedef _Float16 f16x4_hw __attribute__((ext_vector_type(4)));
+    c = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4_hw, make_uint2(a.x, a.y)), __builtin_bit_cast(f16x4_hw, make_uint2(b.x, b.y)), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4_hw, make_uint2(a.z, a.w)), __builtin_bit_cast(f16x4_hw, make_uint2(b.z, b.w)), c, 0, 0, 0);
+#else
     c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_hw, a), __builtin_bit_cast(f16x8_hw, b), c, 0, 0, 0);
+#endif
 }
 template <> __device__ __forceinline__ void mfma16<float>(const uint4& a, const uint4& b, f32x4& c) {
     c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);

@@ -75,6 +75,8 @@ public:
     // (1.36 ms vs 1.66 ms): HIP's graph executor serialises more of the three-branch DAG than the streams do.
     bool use_graph = false;
     bool io_bf16 = false;             // option "io_bf16" (fp16-storage engine only): the caller's input / output tensors are bf16; converted in the first / last kernels
+    bool ds_fuse = true;              // option "ds_fuse": the LayerNorm in front of EdgeNeXt's three 2x2 / stride-2 convs inside the conv's k-loop (k_gemm.h LNTAP; bit-level: same arithmetic, the
+                                      // normalised pixel is rounded to the storage type once, as the separate launch's output was)
     bool multi_stream = true;         // option "streams": run the independent radar / point branches on side streams
     int gemm_rows = 1;                // option "gemm_rows": 16-row sub-tiles per wave (1 / 2 / 4) for GEMMs with K >= 1024 (the dense 3x3 convs of MobileViT)
     bool xca_mfma = true;             // option "xca_mfma": XCA Gram matrices on the matrix cores (xca_gram_mfma_kernel, k_xca.h); 0 = the VALU kernel
@@ -117,9 +119,9 @@ public:
     int radar_start = -2;             // option "radar_start": -1 = the radar branch starts with the forward; k = 0..3: only once backbone stage k is done (round 2: 1 measured
                                       // +1 %, the block-0 front kernel 0.58 -> 0.38 ms in-step); -2 (default) = 2 in the pipelined plan — with round 3's kernels, one box, alternating,
                                       // three runs: stage 1: 36.31 k frames/s, stage 2: 37.33 k, stage 3: 36.62 k — and 1 in the plain plan (35.77 k / 35.59 k / 33.57 k)
+                                      // (released by event 0, with the point branch ahead of it on the same stream — the first RCBlocks are
+                                      //  throughput-bound like backbone stages 0 / 1 and halve each other's speed when they overlap)
     int radar_start_eff() const { return radar_start == -2 ? ((pipeline && multi_stream) ? 2 : 1) : radar_start; }
-                                      // (event 0), with the point branch ahead of it on the same stream — the first RCBlocks are
-                                      // throughput-bound like backbone stages 0 / 1 and halve each other's speed when they overlap
     int pool_strip = 2;               // option "pool_strip": which RCBlock average pools use the 4-pixel strip kernel (engine_impl.h, rcnet)
     int head_fuse_dbg = 0;            // option "head_fuse_dbg": phase-kill timing experiments on the fused head layer (results are wrong)
     bool head_fuse = true;            // option "head_fuse": bf16, 64-wide towers — a head layer's depthwise 5x5 + pointwise conv as one launch (k_headdw.h); needs head_batch
@@ -181,7 +183,9 @@ protected:
     void add_op(const std::string& name, std::function<void(hipStream_t)> fn, double bytes = 0, double flops = 0, double layout_bytes = -1) {
         if (measuring) return;
         // timing experiments only (profiles/scripts/skip_ops.sh): ACH_DEBUG_SKIP="substr,substr" turns the matching launches into no-ops
-        // (events and stream order stay) to read off what a kernel group costs END TO END; the outputs are garbage then.
+        // (events and stream order stay) to read off what a kernel group costs END TO END; the outputs are garbage then.  Compiled ONLY into
+        // the variant libraries that profiles/scripts/build_variant.sh builds with -DACH_TIMING_HOOKS: the shipped library never reads the variable.
+#if defined(ACH_TIMING_HOOKS)
         if (const char* skip = std::getenv("ACH_DEBUG_SKIP")) {
             std::string all(skip);
             for (size_t a = 0; a < all.size();) {
@@ -194,6 +198,7 @@ protected:
                 a = b + 1;
             }
         }
+#endif
         Op op{name, std::move(fn), bytes, layout_bytes < 0 ? bytes : layout_bytes, flops};
         op.stream = cur_stream;
         op.wait_ev = pending_wait; op.wait_ev2 = pending_wait2;

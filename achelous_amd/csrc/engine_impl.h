@@ -154,6 +154,7 @@ public:
 
     struct GemmOpt {
         int act = ACT_NONE; bool ln = false; float ln_eps = 0.f;
+        bool ln_tap = false;                                                      // conv mode, 2x2: LayerNorm of every tap's input pixel fused in (k_gemm.h LNTAP)
         const A* residual = nullptr;
         int conv_k = 0, conv_s = 1, conv_p = 0, Hin = 0, Win = 0, Cin = 0, Ho = 0, Wo = 0;   // implicit-GEMM conv over NHWC
         int Creal = 0;                                                            // conv mode: real channels per pixel (Cin is the stored pitch) for the byte accounting
@@ -172,7 +173,8 @@ public:
         g.R = o.residual ? o.residual->p : nullptr; g.ldr = o.residual ? o.residual->ld : 0;
         g.groups = o.groups; g.M_per_group = int(M / o.groups);
         g.K = pk.K; g.N = pk.N; g.nchunks = pk.nchunks; g.ksteps = pk.ksteps;
-        g.act = o.act; g.ln = o.ln ? 1 : 0; g.ln_eps = o.ln_eps;
+        g.act = o.act; g.ln = o.ln_tap ? 2 : (o.ln ? 1 : 0); g.ln_eps = o.ln_eps;
+        if (o.ln_tap && (o.conv_k != 2 || pk.NT != 4 || o.groups != 1 || batching || o.Cin % VEC != 0)) throw AchError{ACH_ERR_INVALID, name + ": per-tap LayerNorm needs a 2x2 conv with more than 32 outputs"};
         g.out_nchw = (o.out_nchw && io_alt()) ? 2 : o.out_nchw; g.HW = o.HW; g.Ctot = o.Ctot; g.coff = o.coff;
         g.vec_store = (ldy % 8 == 0 && (!o.residual || o.residual->ld % 8 == 0)) ? 1 : 0;
         if (ldx % VEC != 0) throw AchError{ACH_ERR_INVALID, name + ": activation row stride not 16-byte aligned"};
@@ -264,6 +266,7 @@ public:
                 // (if constexpr: instantiated by the bf16 engine's translation unit ONLY — see fused_mlp_lin)
                 if constexpr (H16E)
                     add_op(name, [hp, grid, block](hipStream_t s) { ACH_LAUNCH((headdw_kernel<T>), grid, block, s, hp); }, bytes, flops);
+                else throw AchError{ACH_ERR_INVALID, "head batching: the fused layer exists for 16-bit storage only"};
             } else {
                 DwJobs m;
                 std::memset(&m, 0, sizeof(m));
@@ -651,16 +654,10 @@ public:
                     add_op(d, [sp, grid, block, img, alt](hipStream_t s) mutable { sp.X = *img; if (alt) ACH_LAUNCH((stem_kernel<T, IOB>), grid, block, s, sp); else ACH_LAUNCH((stem_kernel<T, T>), grid, block, s, sp); });
                 }
             } else {
-                A t = alloc(x.B, x.H, x.W, x.C);
-                int G = 1;
-                while (G < x.C / 4 && G < 64) G <<= 1;
-                LnParams lp{x.p, x.ld, t.p, t.ld, up_f32(W(d + ".0.weight").data), up_f32(W(d + ".0.bias").data), x.rows(), x.C, 1e-6f, G};
-                const dim3 grid(unsigned(cdivl(x.rows(), 256 / G))), block(256);
-                add_op(d + ".0", [lp, grid, block](hipStream_t s) { ACH_LAUNCH(layernorm_kernel<T>, grid, block, s, lp); });
                 // conv 2x2 stride 2: k = (dy, dx, c) over two contiguous NHWC segments
                 const HostTensor& w = W(d + ".1.weight");
                 const int Co = int(w.shape[0]), Ci = int(w.shape[1]);
-                if (Ci != x.C || t.ld != t.C) throw AchError{ACH_ERR_UNSUPPORTED, "downsample conv shape"};
+                if (Ci != x.C || Ci % 8 != 0) throw AchError{ACH_ERR_UNSUPPORTED, "downsample conv shape"};
                 Lin l; l.N = Co; l.K = 4 * Ci; l.w.resize(size_t(Co) * 4 * Ci); l.b = W(d + ".1.bias").data;
                 for (int o = 0; o < Co; ++o)
                     for (int c = 0; c < Ci; ++c)
@@ -669,8 +666,30 @@ public:
                                 l.w[size_t(o) * 4 * Ci + (dy * 2 + dx) * Ci + c] = w.data[((size_t(o) * Ci + c) * 2 + dy) * 2 + dx];
                 A y = alloc(x.B, x.H / 2, x.W / 2, Co);
                 GemmOpt o; o.conv_k = 2; o.conv_s = 2; o.conv_p = 0; o.Hin = x.H; o.Win = x.W; o.Cin = Ci; o.Ho = x.H / 2; o.Wo = x.W / 2;
-                gemm(d + ".1", t.p, t.ld, y.rows(), pack(l), y.p, y.ld, o);
-                tap("backbone.ds" + std::to_string(i) + ".ln", t); tap("backbone.ds" + std::to_string(i), y);
+                if (ds_fuse && !full_taps && pick_nt(Co) == 4) {
+                    // the channels-first LayerNorm in front of the conv (edgenext.py:29-34) inside the conv's k-loop: statistics per input pixel = per tap,
+                    // the affine part folded into the weights (k_gemm.h LNTAP) — one launch and one tensor less per down-sampling layer
+                    const auto& lw = W(d + ".0.weight").data; const auto& lb = W(d + ".0.bias").data;
+                    if (int(lw.size()) != Ci) throw AchError{ACH_ERR_MISSING_KEY, "LayerNorm width mismatch at " + d};
+                    for (int n = 0; n < Co; ++n) {
+                        double acc = l.b[n];
+                        for (int k = 0; k < 4 * Ci; ++k) { acc += double(l.w[size_t(n) * 4 * Ci + k]) * lb[k % Ci]; l.w[size_t(n) * 4 * Ci + k] *= lw[k % Ci]; }
+                        l.b[n] = float(acc);
+                    }
+                    o.ln_tap = true; o.ln_eps = 1e-6f;
+                    gemm(d + ".ln+conv", x.p, x.ld, y.rows(), pack(l), y.p, y.ld, o);
+                } else {
+                    A t = alloc(x.B, x.H, x.W, x.C);
+                    if (t.ld != t.C) throw AchError{ACH_ERR_UNSUPPORTED, "downsample conv shape"};
+                    int G = 1;
+                    while (G < x.C / 4 && G < 64) G <<= 1;
+                    LnParams lp{x.p, x.ld, t.p, t.ld, up_f32(W(d + ".0.weight").data), up_f32(W(d + ".0.bias").data), x.rows(), x.C, 1e-6f, G};
+                    const dim3 grid(unsigned(cdivl(x.rows(), 256 / G))), block(256);
+                    add_op(d + ".0", [lp, grid, block](hipStream_t s) { ACH_LAUNCH(layernorm_kernel<T>, grid, block, s, lp); });
+                    gemm(d + ".1", t.p, t.ld, y.rows(), pack(l), y.p, y.ld, o);
+                    tap("backbone.ds" + std::to_string(i) + ".ln", t);
+                }
+                tap("backbone.ds" + std::to_string(i), y);
                 x = y;
             }
             for (int j = 0; j < ec.depths[i]; ++j) {
@@ -970,6 +989,8 @@ public:
         UpGhostChainParams cp{UpGhostParams{t.p, t.ld, nullptr, 0, up_f32(wt), up_f32(sh), t.B, t.H, t.W, Cg}, tn.p, tn.ld, mp.W1, mp.b1, mp.W2, mp.b2, lp.N};
         const dim3 grid(unsigned(cdiv(2 * t.W, UPG_TS)) * unsigned(cdiv(2 * t.H, UPG_TS)) * unsigned(t.B)), block(unsigned(16 * Cg));
         const double bytes = double(t.rows()) * Cg * sizeof(T) + double(tn.rows()) * lp.N * sizeof(T);
+        if (lu.N != 32 || lp.N != 16 || lu.K != 2 * Cg || lp.K != 32) throw AchError{ACH_ERR_INVALID, ghost_pfx + ": chained level expects a 2Cg -> 32 -> 16 pair"};
+        if constexpr (!H16E) throw AchError{ACH_ERR_INVALID, ghost_pfx + ": chained decoder levels exist for 16-bit storage only"};
         if constexpr (H16E)
             add_op(ghost_pfx + ".upghost+pair", [cp, grid, block, Cg](hipStream_t s) {
                 if (Cg == 16) ACH_LAUNCH((upghost_chain_kernel<T, 16>), grid, block, s, cp);
@@ -1515,6 +1536,11 @@ public:
         const int NC5 = 5 + cfg.num_det;
         batching = head_batch;          // the same six layers on three maps: one launch per layer for all levels (flush_batch)
         batch_jobs.clear();
+        // the fused depthwise + pointwise layer (k_headdw.h) is chosen for ALL three levels or for none: flush_batch needs the same number of
+        // jobs on every level (a level-0 map wider than 66 columns — resolution >= 544 — has no band that fits the kernel's LDS tile)
+        bool fuse_layers = head_fuse && batching && H16E;
+        for (int k = 0; k < 3 && fuse_layers; ++k)
+            fuse_layers = int(W("det_head.stems." + std::to_string(k) + ".conv.weight").shape[0]) == HDW_C && headdw_band_rows(p[k].H, p[k].W) > 0;
         for (int k = 0; k < 3; ++k) {
             const std::string ks = std::to_string(k);
             const A& x = p[k];
@@ -1534,7 +1560,8 @@ public:
                     for (int t = 0; t < 25; ++t) { wt[size_t(t) * 2 * base + ch] = wc.data[size_t(ch) * 25 + t]; wt[size_t(t) * 2 * base + base + ch] = wr.data[size_t(ch) * 25 + t]; }
                 // fused layer (k_headdw.h): bf16, 64-wide towers, one launch for the three levels
                 const int rbh = headdw_band_rows(x.H, x.W);
-                if constexpr (H16E) if (head_fuse && batching && base == HDW_C && rbh > 0 && cur.ld % 8 == 0) {
+                if constexpr (H16E) if (fuse_layers) {
+                    if (cur.ld % 8 != 0 || rbh <= 0) throw AchError{ACH_ERR_INVALID, "head: fused layer chosen for a level it does not fit"};
                     Lin lc = conv_bn(c + ".conv.pconv", c + ".bn", 1e-3), lr = conv_bn(r + ".conv.pconv", r + ".bn", 1e-3);
                     std::vector<uint16_t> wp(size_t(2) * 2 * 4 * 64 * 8, 0);
                     std::vector<float> pb(size_t(2) * base, 0.f);

@@ -111,8 +111,10 @@ template <class T> __device__ inline void dh_mfma(const uint4& a, const uint4& b
 #else
 template <class T> __device__ __forceinline__ void dh_mfma(const uint4& a, const uint4& b, f32x4& c);
 template <> __device__ __forceinline__ void dh_mfma<bf16_t>(const uint4& a, const uint4& b, f32x4& c) {
-#if ACH_DH_MFMA32
-    mfma16<bf16_t>(a, b, c);
+#if ACH_DH_MFMA32 == 2       // experiment: the 16x16x32 form with an EARLY-CLOBBER destination (no register shared with A / B) and C = 0
+    { const buf_u32x4 av = {a.x, a.y, a.z, a.w}, bv = {b.x, b.y, b.z, b.w}; asm volatile("s_nop 4\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, 0\n\ts_nop 15\n\ts_nop 3" : "=&v"(c) : "v"(av), "v"(bv)); }
+#elif ACH_DH_MFMA32
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_hw, a), __builtin_bit_cast(bf16x8_hw, b), c, 0, 0, 0);
 #else
     typedef short s16x4 __attribute__((ext_vector_type(4)));
     c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, make_uint2(a.x, a.y)), __builtin_bit_cast(s16x4, make_uint2(b.x, b.y)), c, 0, 0, 0);
@@ -120,8 +122,10 @@ template <> __device__ __forceinline__ void dh_mfma<bf16_t>(const uint4& a, cons
 #endif
 }
 template <> __device__ __forceinline__ void dh_mfma<f16_t>(const uint4& a, const uint4& b, f32x4& c) {
-#if ACH_DH_MFMA32
-    mfma16<f16_t>(a, b, c);
+#if ACH_DH_MFMA32 == 2
+    { const buf_u32x4 av = {a.x, a.y, a.z, a.w}, bv = {b.x, b.y, b.z, b.w}; asm volatile("s_nop 4\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, 0\n\ts_nop 15\n\ts_nop 3" : "=&v"(c) : "v"(av), "v"(bv)); }
+#elif ACH_DH_MFMA32
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_hw, a), __builtin_bit_cast(f16x8_hw, b), c, 0, 0, 0);
 #else
     typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
     c = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h16x4, make_uint2(a.x, a.y)), __builtin_bit_cast(h16x4, make_uint2(b.x, b.y)), c, 0, 0, 0);

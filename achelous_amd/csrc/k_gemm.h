@@ -76,7 +76,10 @@ constexpr int GEMM_DEPTH = ACH_GEMM_DEPTH;      // operand slots in flight in ge
 #endif
 constexpr int GEMM_DEEP_KSTEPS = ACH_GEMM_DEEP_KSTEPS;   // k-steps from which launch_gemm picks them
 
-template <class T, int NT, int P, bool DEEP = false>
+// LNTAP (round 4): conv mode with a channels-first LayerNorm of the INPUT pixels fused in — every tap of the 2x2 / stride-2 patchify convs of
+// EdgeNeXt is a different input pixel with its own mean / variance over its Cin channels (edgenext.py:29-34: LayerNorm then Conv2d); the affine
+// part is folded into the conv weights on the host.  Saves the LayerNorm launch and its tensor in front of each of the three convs.
+template <class T, int NT, int P, bool DEEP = false, bool LNTAP = false>
 __device__ __forceinline__ void gemm_body(const GemmParams& p, unsigned bx, unsigned nbx, unsigned by, unsigned bz) {
     constexpr int VEC = Store<T>::VEC;
     constexpr int KC = 4 * VEC;
@@ -133,7 +136,45 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, unsigned bx, unsi
     // ---- optional LayerNorm prologue: mean / variance over the K channels of each row (one sweep: sum and sum of squares
     //      in fp32; the rows are O(1) activations, so E[x^2] - mean^2 loses nothing that matters at eps = 1e-6)
     float mean[P], rstd[P];
-    if (p.ln) {
+    float tmean[P][4], trstd[P][4];                // LNTAP: per (row, tap)
+    auto tap_of = [&](int s) { return (s * KC + g * VEC) / p.Cin; };
+    if constexpr (LNTAP) {
+        ACH_UNROLL
+        for (int q = 0; q < P; ++q) {
+            float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int s = 0; s < p.ksteps; ++s) {
+                float v[8];
+                frag_unpack<T>(load_x(q, s), v);                   // a lane's VEC channels belong to ONE tap (Cin is a multiple of VEC)
+                float a1 = 0.f, a2 = 0.f;
+                ACH_UNROLL
+                for (int j = 0; j < VEC; ++j) { a1 += v[j]; a2 += v[j] * v[j]; }
+                const int tp = tap_of(s);
+                ACH_UNROLL
+                for (int t = 0; t < 4; ++t) { s1[t] += tp == t ? a1 : 0.f; s2[t] += tp == t ? a2 : 0.f; }
+            }
+            ACH_UNROLL
+            for (int t = 0; t < 4; ++t) {
+                s1[t] += __shfl_xor(s1[t], 16); s2[t] += __shfl_xor(s2[t], 16);
+                s1[t] += __shfl_xor(s1[t], 32); s2[t] += __shfl_xor(s2[t], 32);
+                const float mu = s1[t] / float(p.Cin);
+                float var = s2[t] / float(p.Cin) - mu * mu;
+                var = var > 0.f ? var : 0.f;
+                tmean[q][t] = mu;
+                trstd[q][t] = 1.0f / sqrtf(var + p.ln_eps);
+            }
+        }
+    }
+    auto ln_tap = [&](int q, int s, uint4& xf) {       // x -> (x - mean[tap]) * rstd[tap]
+        const int tp = tap_of(s);
+        const float mu = tp == 0 ? tmean[q][0] : (tp == 1 ? tmean[q][1] : (tp == 2 ? tmean[q][2] : tmean[q][3]));
+        const float rs = tp == 0 ? trstd[q][0] : (tp == 1 ? trstd[q][1] : (tp == 2 ? trstd[q][2] : trstd[q][3]));
+        float v[8];
+        frag_unpack<T>(xf, v);
+        ACH_UNROLL
+        for (int j = 0; j < VEC; ++j) v[j] = (v[j] - mu) * rs;
+        xf = frag_pack<T>(v);
+    };
+    if (!LNTAP && p.ln) {
         ACH_UNROLL
         for (int q = 0; q < P; ++q) {
             float s1 = 0.f, s2 = 0.f;
@@ -198,6 +239,10 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, unsigned bx, unsi
                     uint4 xf[P];
                     ACH_UNROLL
                     for (int q = 0; q < P; ++q) xf[q] = xb[d][q];
+                    if constexpr (LNTAP) {
+                        ACH_UNROLL
+                        for (int q = 0; q < P; ++q) ln_tap(q, s, xf[q]);
+                    } else
                     if (p.ln) {
                         ACH_UNROLL
                         for (int q = 0; q < P; ++q) {
@@ -238,6 +283,10 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, unsigned bx, unsi
                     ACH_UNROLL
                     for (int t = 0; t < NT; ++t) wn[t] = wrow[t * 64];
                 }
+                if constexpr (LNTAP) {
+                    ACH_UNROLL
+                    for (int q = 0; q < P; ++q) ln_tap(q, s, xf[q]);
+                } else
                 if (p.ln) {
                     ACH_UNROLL
                     for (int q = 0; q < P; ++q) {
@@ -330,8 +379,8 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, unsigned bx, unsi
 #else
 #define ACH_GEMM_BOUNDS __launch_bounds__(256)
 #endif
-template <class T, int NT, int P, bool DEEP = false>
-__global__ ACH_GEMM_BOUNDS void gemm_kernel(const GemmParams p) { gemm_body<T, NT, P, DEEP>(p, blockIdx.x, gridDim.x, blockIdx.y, blockIdx.z); }
+template <class T, int NT, int P, bool DEEP = false, bool LNTAP = false>
+__global__ ACH_GEMM_BOUNDS void gemm_kernel(const GemmParams p) { gemm_body<T, NT, P, DEEP, LNTAP>(p, blockIdx.x, gridDim.x, blockIdx.y, blockIdx.z); }
 
 // Up to three independent GEMMs of the same tile shape in one launch (blockIdx.y = job): the three pyramid levels of the
 // detection head run the same layer on maps of 1600 / 400 / 100 pixels — the small levels ride in the big level's launch
@@ -454,6 +503,11 @@ __global__ ACH_COLMAX_BOUNDS void gemm_colmax_kernel(const GemmMaxParams p) {
 template <class T>
 inline void launch_gemm(const GemmParams& p, int NT, int P, hipStream_t stream) {
     const dim3 grid(unsigned(cdivl(p.M_per_group, 64L * P)), unsigned(p.groups), unsigned(cdiv(p.nchunks, p.chunks_per_block))), block(256);
+    if (p.ln == 2) {           // per-tap LayerNorm of a 2x2 patchify conv (the engine only asks for it with NT = 4, P = 1)
+        if (p.ksteps >= GEMM_DEEP_KSTEPS) ACH_LAUNCH((gemm_kernel<T, 4, 1, true, true>), grid, block, stream, p);
+        else ACH_LAUNCH((gemm_kernel<T, 4, 1, false, true>), grid, block, stream, p);
+        return;
+    }
     if (P == 1 && p.ksteps >= GEMM_DEEP_KSTEPS) {
         if (NT == 1) { ACH_LAUNCH((gemm_kernel<T, 1, 1, true>), grid, block, stream, p); return; }
         if (NT == 2) { ACH_LAUNCH((gemm_kernel<T, 2, 1, true>), grid, block, stream, p); return; }

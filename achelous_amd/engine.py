@@ -196,12 +196,13 @@ class NativeEngine:
         self.num_det, self.num_seg, self.resolution = num_det, num_seg, resolution
         self.pc_classes, self.num_points, self.pc_channels = pc_classes, num_points, pc_channels
 
-    def destroy(self):
-        """ach_destroy: frees the weight and activation arenas now (the handle is unusable afterwards)."""
+    def destroy(self, reason='destroyed'):
+        """ach_destroy: frees the weight and activation arenas now (the handle is unusable afterwards: every call raises, naming `reason`)."""
         if getattr(self, 'h', None) and self.h.value:
             self.L.ach_destroy(self.h)
             self.h = ctypes.c_void_p()
             self.batch = 0
+            self._dead = reason
 
     def __del__(self):
         try:
@@ -210,6 +211,8 @@ class NativeEngine:
             pass
 
     def _check(self, rc):
+        if rc != 0 and getattr(self, '_dead', None):
+            raise RuntimeError(f'achelous_amd: this engine was {self._dead}')
         if rc != 0:
             msg = (self.L.ach_last_error(self.h) or b'').decode()
             raise _ERRORS.get(rc, RuntimeError)(msg)

@@ -106,12 +106,14 @@ int ach_load_weights(ach_handle* h, const ach_tensor_desc* tensors, size_t n);
  * "stem_mfma" (the 4x4/s4 stem conv as an MFMA GEMM gathered from the NCHW image; 0: scalar-FMA kernel),
  * "radar_skip" (closed-form shortcut for empty 16-pixel segments of the first RCBlock, bit-identical), "radar_rows4" (0 / 1 / 2: a
  * workgroup owns four rows in the first / in all fused RCBlocks and the row-walking conv), "radar_start" (the radar branch is released
- * after backbone stage 1), "dw_even" (even deal of depthwise tap rows over the four SPLIT waves, d = 144), "xca_mfma" (XCA Gram
+ * after backbone stage k = 0..3, -1 = at once; default -2 = stage 2 in the pipelined plan, stage 1 in the plain plan), "dw_even" (even deal of depthwise tap rows over the four SPLIT waves, d = 144), "xca_mfma" (XCA Gram
  * matrices on the matrix cores; 0: VALU kernel), "head_mfma" (default 0: bilinear phase of the fused segmentation head on MFMA —
- * measured slower), "gemm_rows" (default 1: 16-row sub-tiles per wave for GEMMs with K >= 1024 — 2 / 4 measured slower),
- * round 3 (bf16 engine): "head_rows" (2: last decoder level + segmentation head as the row-walking two-columns-per-lane kernel, 1: one
- * column, 0: the LDS tile kernel), "head_band" (rows per workgroup band of that kernel, default 40), "mlp_band" (1: EdgeNeXt blocks on
- * maps up to 32 x 32 as the band kernel, 2: on every map, 0: never), "head_fuse" (a detection-head layer's depthwise + pointwise convs of both
+ * measured slower), "gemm_rows" (default 1: 16-row sub-tiles per wave for GEMMs with K >= 1024 — 2 / 4 measured slower), "gemm_blocks" (workgroups a GEMM
+ * launch aims for when its rows alone cannot fill the chip; 0 = 1024),
+ * round 4: "io_bf16" (ACH_DTYPE_F16 only: the caller's input / output tensors are bf16, converted in the first / last kernels);
+ * round 3 (16-bit engines): "head_rows" (2: last decoder level + segmentation head as the row-walking two-columns-per-lane kernel, 1: one
+ * column, 0: the LDS tile kernel), "head_band" (rows per workgroup band of that kernel, default 80), "mlp_band" (1: EdgeNeXt blocks of
+ * the instantiated shapes — d = 96 / 144 on maps up to 20 wide, d = 176 up to 10 wide — as the band kernel, 2: also stages 0 / 1, 0: never), "head_fuse" (a detection-head layer's depthwise + pointwise convs of both
  * towers and all levels as one launch), "radar_compact" (first RCBlock: per-pixel activity, active pixels compacted into dense tiles;
  * bit-identical), "level_chain" (a decoder level's kernel also applies the next level's low-resolution conv pair; bit-identical),
  * "sdta_fuse" (1: an SDTA encoder's conv cascade + tail copy + positional encoding as one launch on maps up to 20 x 20, 2: every map,

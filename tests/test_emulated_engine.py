@@ -139,7 +139,7 @@ def test_emulated_forward_detect_equals_the_three_calls():
     assert int(cnt[0]) > 0
 
 
-@pytest.mark.parametrize('option', ['fused_mlp', 'row_conv', 'fused_rc', 'dw_tile', 'head_batch', 'split_decoders', 'head_stream', 'streams', 'stem_mfma', 'radar_start', 'dw_even', 'radar_rows4', 'xca_mfma'])
+@pytest.mark.parametrize('option', ['fused_mlp', 'row_conv', 'fused_rc', 'dw_tile', 'head_batch', 'split_decoders', 'head_stream', 'streams', 'stem_mfma', 'radar_start', 'dw_even', 'radar_rows4', 'xca_mfma', 'ds_fuse'])
 def test_emulated_kernel_switches_agree(option):
     """Each fused / batched kernel against the layer-wise launches it replaced, through the C ABI on the CPU emulation (fp32)."""
     kw, sd, (x, xr, xp) = _setup('en_s0', 64, 1, 16)
@@ -155,8 +155,12 @@ def test_emulated_kernel_switches_agree(option):
         o = alloc_outputs(kw, 1, 16, torch.float32, 'cpu')
         eng.forward(x, xr, xp, o)
         outs.append(o)
+        if v == 1:
+            launches_on = eng.launches()
     for a, b in zip(*outs):
         assert rel_err(a, b) < 2e-5, option
+    if option == 'ds_fuse':          # the LayerNorm in front of the three patchify convs lives in the conv's k-loop: three launches fewer
+        assert sum('.ln+conv' in n for n, _, _ in eng.op_table()) == 0 and launches_on - 0 == eng.launches() - 3
 
 
 def test_emulated_nms_more_candidates_than_fit_in_lds():
