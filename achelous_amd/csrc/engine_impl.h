@@ -12,6 +12,7 @@
 #include "k_detect.h"
 #include "k_conv3.h"
 #include "k_gemm.h"
+#include "k_ghost.h"
 #include "k_headdw.h"
 #include "k_mlp.h"
 #include "k_mlpband.h"
@@ -846,10 +847,46 @@ public:
     Lin conv_bn(const std::string& conv, const std::string& bn, double eps) const { Lin l = lin(conv + ".weight", conv + ".bias"); fold_bn(l, bn, eps); return l; }
 
     // GhostModule (ghost_conv.py:6-29) on NHWC: primary 1x1 -> channels [0,init), cheap dw3x3 -> [init, 2*init)
+    // NT = 2 fragments of a 1x1 conv for the band kernels of k_ghost.h: [chunk of 32 outputs][k-step][2][64 lanes], bias padded to whole chunks
+    struct BandW { const uint4* w = nullptr; const float* b = nullptr; int k1 = 0, chunks = 0; };
+    BandW pack_band(const Lin& l) {
+        BandW bw; bw.k1 = cdiv(l.K, KC); bw.chunks = cdiv(l.N, 32);
+        std::vector<float> blob(size_t(bw.chunks) * bw.k1 * 2 * 64 * VEC, 0.f), bias(size_t(bw.chunks) * 32, 0.f);
+        if (!measuring)
+            for (int n = 0; n < l.N; ++n) {
+                bias[n] = l.b[n];
+                for (int k = 0; k < l.K; ++k) blob[size_t(wfrag_offset(n, k, 2, bw.k1, VEC))] = l.w[size_t(n) * l.K + k];
+            }
+        bw.w = reinterpret_cast<const uint4*>(up_T(blob)); bw.b = up_f32(bias);
+        return bw;
+    }
+    void dw_fold9(const std::string& wkey, const std::string& bnpfx, int C, std::vector<float>& wt, std::vector<float>& bias) const {
+        const HostTensor& w = W(wkey);
+        if (w.numel() != long(C) * 9) throw AchError{ACH_ERR_MISSING_KEY, "depthwise weight shape: " + wkey};
+        std::vector<float> sc, sh; bn_coeffs(bnpfx, 1e-5, sc, sh);
+        wt.assign(size_t(9) * C, 0.f); bias.assign(size_t(C), 0.f);
+        for (int c = 0; c < C; ++c) { bias[c] = sh[c]; for (int t = 0; t < 9; ++t) wt[size_t(t) * C + c] = w.data[size_t(c) * 9 + t] * sc[c]; }
+    }
     A ghost(const std::string& pfx, const A& x, int oup, bool relu) {
         const int init = (oup + 1) / 2;
         if (init % 4 || oup != 2 * init) throw AchError{ACH_ERR_UNSUPPORTED, pfx + ": NHWC GhostModule needs an even output width divisible by 8"};
         A y = alloc(x.B, x.H, x.W, oup);
+        if constexpr (H16E) {
+            // primary 1x1 + cheap depthwise 3x3 as ONE band kernel (k_ghost.h): the primary output's halo rows are recomputed, nothing is read back
+            const int rb = ghost_band_rows(x.H, x.W, init);
+            if (ghost_fuse && !full_taps && rb > 0 && init % 8 == 0 && x.C % 8 == 0 && x.C <= 320 && x.ld % 8 == 0 && y.ld % 8 == 0) {
+                Lin lp = conv_bn(pfx + ".primary_conv.0", pfx + ".primary_conv.1", 1e-5);
+                if (lp.N != init || lp.K != x.C) throw AchError{ACH_ERR_MISSING_KEY, "GhostModule widths at " + pfx};
+                BandW bw = pack_band(lp);
+                std::vector<float> wt, bs; dw_fold9(pfx + ".cheap_operation.0.weight", pfx + ".cheap_operation.1", init, wt, bs);
+                GhostParams gp{x.p, x.ld, y.p, y.ld, bw.w, bw.b, up_f32(wt), up_f32(bs), x.B, x.H, x.W, x.C, bw.k1, init, bw.chunks,
+                               relu ? int(ACT_RELU) : int(ACT_NONE), rb, cdiv(x.H, rb)};
+                const dim3 grid(unsigned(gp.bands) * unsigned(x.B)), block(GH_THREADS);
+                add_op(pfx + ".ghost", [gp, grid, block](hipStream_t s) { ACH_BAND_LAUNCH(ghost_kernel, gp.k1, grid, block, s, gp); },
+                       double(x.rows()) * (x.C + oup) * sizeof(T), 2.0 * double(x.rows()) * x.C * init);
+                return y;
+            }
+        }
         GemmOpt o; o.act = relu ? ACT_RELU : ACT_NONE;
         gemm(pfx + ".primary", x, pack(conv_bn(pfx + ".primary_conv.0", pfx + ".primary_conv.1", 1e-5)), y.slice(0, init), o);
         dwconv(pfx + ".cheap", y.slice(0, init), nullptr, pfx + ".cheap_operation.0.weight", "", pfx + ".cheap_operation.1", 1e-5, 3, 1,
@@ -859,6 +896,22 @@ public:
     A ghost_bottleneck(const std::string& pfx, const A& x, int out_chs) {       // ghost_conv.py:58-70, stride 1, in != out
         A g1 = ghost(pfx + ".ghost1", x, x.C, true);
         A g2 = ghost(pfx + ".ghost2", g1, out_chs, false);
+        if constexpr (H16E) {
+            // shortcut: depthwise 3x3 + BN -> 1x1 + BN, + ghost2's output, as ONE band kernel (k_ghost.h dwpw_kernel)
+            const int rb = dwpw_band_rows(x.H, x.W, x.C);
+            if (ghost_fuse && !full_taps && rb > 0 && x.C % 8 == 0 && out_chs % 8 == 0 && x.ld % 8 == 0 && g2.ld % 8 == 0) {
+                Lin lp = conv_bn(pfx + ".shortcut.2", pfx + ".shortcut.3", 1e-5);
+                if (lp.N != out_chs || lp.K != x.C) throw AchError{ACH_ERR_MISSING_KEY, "GhostBottleneck shortcut widths at " + pfx};
+                BandW bw = pack_band(lp);
+                std::vector<float> wt, bs; dw_fold9(pfx + ".shortcut.0.weight", pfx + ".shortcut.1", x.C, wt, bs);
+                A y = alloc(x.B, x.H, x.W, out_chs);
+                DwPwParams dp{x.p, x.ld, g2.p, g2.ld, y.p, y.ld, up_f32(wt), up_f32(bs), bw.w, bw.b, x.B, x.H, x.W, x.C, bw.k1, out_chs, bw.chunks, rb, cdiv(x.H, rb)};
+                const dim3 grid(unsigned(dp.bands) * unsigned(x.B)), block(GH_THREADS);
+                add_op(pfx + ".shortcut", [dp, grid, block](hipStream_t s) { ACH_BAND_LAUNCH(dwpw_kernel, dp.k1, grid, block, s, dp); },
+                       double(x.rows()) * (x.C + 2.0 * out_chs) * sizeof(T), 2.0 * double(x.rows()) * x.C * out_chs);
+                return y;
+            }
+        }
         A sd = alloc(x.B, x.H, x.W, x.C);
         dwconv(pfx + ".shortcut.dw", x, nullptr, pfx + ".shortcut.0.weight", "", pfx + ".shortcut.1", 1e-5, 3, 1, ACT_NONE, sd);
         A y = alloc(x.B, x.H, x.W, out_chs);
@@ -923,6 +976,18 @@ public:
     // Upsample = BaseConv 1x1 + BN(1e-3) + ReLU, bilinear x2 align_corners (ghostdualfpn.py:28-39); writes into `dst`
     void upsample(const std::string& pfx, const A& x, const A& dst) {
         Lin l = conv_bn(pfx + ".upsample.0.conv", pfx + ".upsample.0.bn", 1e-3);
+        if constexpr (H16E) {
+            // conv + BN + ReLU + bilinear x2 as ONE band kernel (k_ghost.h upconv_kernel): the low-resolution tensor stays in LDS
+            const int rb = upconv_band_rows(x.H, x.W, l.N);
+            if (ghost_fuse && !full_taps && rb > 0 && l.N % 8 == 0 && x.C % 8 == 0 && x.C <= 320 && x.ld % 8 == 0 && dst.ld % 4 == 0 && l.K == x.C) {
+                BandW bw = pack_band(l);
+                UpConvParams up{x.p, x.ld, dst.p, dst.ld, bw.w, bw.b, x.B, x.H, x.W, x.C, bw.k1, l.N, bw.chunks, rb, cdiv(2 * x.H, rb)};
+                const dim3 grid(unsigned(up.bands) * unsigned(x.B)), block(GH_THREADS);
+                add_op(pfx + ".conv+bilinear", [up, grid, block](hipStream_t s) { ACH_BAND_LAUNCH(upconv_kernel, up.k1, grid, block, s, up); },
+                       double(x.rows()) * (x.C + 4.0 * l.N) * sizeof(T), 2.0 * double(x.rows()) * x.C * l.N);
+                return;
+            }
+        }
         A t = alloc(x.B, x.H, x.W, l.N);
         GemmOpt o; o.act = ACT_RELU;
         gemm(pfx + ".conv", x, pack(l), t, o);

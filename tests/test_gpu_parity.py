@@ -625,7 +625,7 @@ def test_forward_detect_equals_the_three_calls():
                 assert int(cnt.max()) > 0
 
 
-@pytest.mark.parametrize('option', ['fused_mlp', 'row_conv', 'fused_rc', 'dw_tile', 'head_batch', 'split_decoders', 'head_stream', 'stem_mfma', 'radar_start', 'head_mfma', 'radar_skip', 'dw_even', 'radar_rows4', 'xca_mfma', 'head_rows', 'head_fuse', 'mlp_band'])
+@pytest.mark.parametrize('option', ['fused_mlp', 'row_conv', 'fused_rc', 'dw_tile', 'head_batch', 'split_decoders', 'head_stream', 'stem_mfma', 'radar_start', 'head_mfma', 'radar_skip', 'dw_even', 'radar_rows4', 'xca_mfma', 'head_rows', 'head_fuse', 'mlp_band', 'ghost_fuse', 'ds_fuse'])
 def test_fused_kernels_agree_with_the_layerwise_path(option):
     """Every fused / batched kernel has a switch back to the layer-wise launches it replaced (include/achelous.h): the two plans
     must agree — to fp32 rounding in the fp32 engine (different summation order), and within the bf16 tolerance in the bf16
