@@ -119,6 +119,9 @@ int ach_set_option(ach_handle* h, const char* key, int32_t value) {
         else if (std::string(key) == "head_debug") h->eng->head_debug = value;
         else if (std::string(key) == "attn_mfma") h->eng->attn_mfma = value != 0;
         else if (std::string(key) == "ds_fuse") h->eng->ds_fuse = value != 0;
+        else if (std::string(key) == "sa_fuse") h->eng->sa_fuse = value != 0;
+        else if (std::string(key) == "pn2_fps_all") h->eng->pn2_fps_all = value != 0;
+        else if (std::string(key) == "ghost_rb") h->eng->ghost_rb = value > 0 ? value : 5;
         else if (std::string(key) == "ghost_fuse") h->eng->ghost_fuse = value != 0;
         else if (std::string(key) == "io_bf16") {
             if (value != 0 && h->eng->cfg.dtype != ACH_DTYPE_F16) throw ach::AchError{ACH_ERR_INVALID, "io_bf16 applies to the fp16-storage engine (ACH_DTYPE_F16) only"};

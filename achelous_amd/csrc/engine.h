@@ -76,6 +76,9 @@ public:
     bool use_graph = false;
     bool io_bf16 = false;             // option "io_bf16" (fp16-storage engine only): the caller's input / output tensors are bf16; converted in the first / last kernels
     bool ghost_fuse = true;           // option "ghost_fuse": 16-bit engines — the neck's GhostModules (primary 1x1 + cheap depthwise 3x3) and the bottlenecks' shortcuts (depthwise 3x3 + 1x1 + residual) as band kernels (k_ghost.h): 3 launches per bottleneck instead of 6
+    int ghost_rb = 5;                 // option "ghost_rb": rows per band of the neck's band kernels (upper bound; the LDS tiles may force fewer)
+    bool pn2_fps_all = true;          // option "pn2_fps_all": PointNet++ — the four levels' farthest-point sampling as one launch (k_pn2.h pn2_fps_all_kernel; identical selections)
+    bool sa_fuse = false;             // option "sa_fuse": ShuffleAttention's coefficient launch inside the apply launch (k_nhwc.h sa_apply_fused_kernel; bit-identical).  OFF: measured 38.3 k against 38.9 k frames/s
     bool ds_fuse = true;              // option "ds_fuse": the LayerNorm in front of EdgeNeXt's three 2x2 / stride-2 convs inside the conv's k-loop (k_gemm.h LNTAP; bit-level: same arithmetic, the
                                       // normalised pixel is rounded to the storage type once, as the separate launch's output was)
     bool multi_stream = true;         // option "streams": run the independent radar / point branches on side streams

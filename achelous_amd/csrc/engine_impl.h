@@ -873,7 +873,7 @@ public:
         A y = alloc(x.B, x.H, x.W, oup);
         if constexpr (H16E) {
             // primary 1x1 + cheap depthwise 3x3 as ONE band kernel (k_ghost.h): the primary output's halo rows are recomputed, nothing is read back
-            const int rb = ghost_band_rows(x.H, x.W, init);
+            const int rb = ghost_band_rows(x.H, x.W, init, ghost_rb);
             if (ghost_fuse && !full_taps && rb > 0 && init % 8 == 0 && x.C % 8 == 0 && x.C <= 320 && x.ld % 8 == 0 && y.ld % 8 == 0) {
                 Lin lp = conv_bn(pfx + ".primary_conv.0", pfx + ".primary_conv.1", 1e-5);
                 if (lp.N != init || lp.K != x.C) throw AchError{ACH_ERR_MISSING_KEY, "GhostModule widths at " + pfx};
@@ -898,7 +898,7 @@ public:
         A g2 = ghost(pfx + ".ghost2", g1, out_chs, false);
         if constexpr (H16E) {
             // shortcut: depthwise 3x3 + BN -> 1x1 + BN, + ghost2's output, as ONE band kernel (k_ghost.h dwpw_kernel)
-            const int rb = dwpw_band_rows(x.H, x.W, x.C);
+            const int rb = dwpw_band_rows(x.H, x.W, x.C, ghost_rb);
             if (ghost_fuse && !full_taps && rb > 0 && x.C % 8 == 0 && out_chs % 8 == 0 && x.ld % 8 == 0 && g2.ld % 8 == 0) {
                 Lin lp = conv_bn(pfx + ".shortcut.2", pfx + ".shortcut.3", 1e-5);
                 if (lp.N != out_chs || lp.K != x.C) throw AchError{ACH_ERR_MISSING_KEY, "GhostBottleneck shortcut widths at " + pfx};
@@ -978,7 +978,7 @@ public:
         Lin l = conv_bn(pfx + ".upsample.0.conv", pfx + ".upsample.0.bn", 1e-3);
         if constexpr (H16E) {
             // conv + BN + ReLU + bilinear x2 as ONE band kernel (k_ghost.h upconv_kernel): the low-resolution tensor stays in LDS
-            const int rb = upconv_band_rows(x.H, x.W, l.N);
+            const int rb = upconv_band_rows(x.H, x.W, l.N, 2 * ghost_rb - 2);
             if (ghost_fuse && !full_taps && rb > 0 && l.N % 8 == 0 && x.C % 8 == 0 && x.C <= 320 && x.ld % 8 == 0 && dst.ld % 4 == 0 && l.K == x.C) {
                 BandW bw = pack_band(l);
                 UpConvParams up{x.p, x.ld, dst.p, dst.ld, bw.w, bw.b, x.B, x.H, x.W, x.C, bw.k1, l.N, bw.chunks, rb, cdiv(2 * x.H, rb)};
@@ -1006,11 +1006,17 @@ public:
         for (int m = 0; m < 2; ++m)
             pc.w[m] = SaWeights{up_f32(W(*pf[m] + ".cweight").data), up_f32(W(*pf[m] + ".cbias").data), up_f32(W(*pf[m] + ".sweight").data),
                                 up_f32(W(*pf[m] + ".sbias").data), up_f32(W(*pf[m] + ".gn.weight").data), up_f32(W(*pf[m] + ".gn.bias").data)};
-        ew(pfx0 + ".coef", sa_coef_kernel, pc, long(2) * x.B * x.C);
         y0 = alloc(x.B, x.H, x.W, x.C);
         y1 = alloc(x.B, x.H, x.W, x.C);
         SaApplyParams pa{x.p, x.ld, y0.p, y1.p, y0.ld, coef, x.B, x.H * x.W, x.C};
-        ew(pfx0 + ".apply", sa_apply_kernel<T>, pa, x.rows() * x.C, 3.0 * x.rows() * x.C * sizeof(T));
+        if (sa_fuse && x.C <= 256 && (long(x.H) * x.W * x.C) % 256 == 0) {       // the coefficients in the apply launch (k_nhwc.h): bit-identical, one launch fewer
+            SaFusedParams pf{pc, pa};
+            ew(pfx0 + ".coef+apply", sa_apply_fused_kernel<T>, pf, x.rows() * x.C, 3.0 * x.rows() * x.C * sizeof(T));
+            return;
+        }
+        ew(pfx0 + ".coef", sa_coef_kernel, pc, long(2) * x.B * x.C);
+        if (x.C % 8 == 0 && x.ld % 4 == 0 && y0.ld % 8 == 0) ew(pfx0 + ".apply", sa_apply8_kernel<T>, pa, x.rows() * (x.C / 8), 3.0 * x.rows() * x.C * sizeof(T));
+        else ew(pfx0 + ".apply", sa_apply_kernel<T>, pa, x.rows() * x.C, 3.0 * x.rows() * x.C * sizeof(T));
     }
     // one decoder level: Upsample (1x1+BN+ReLU, bilinear x2) + GhostModule, restructured (see upghost_kernel):
     // both 1x1 convs at low resolution on MFMA, then one fused full-resolution kernel.
@@ -1790,6 +1796,7 @@ public:
         if (N % 128 || N > 64 * PN2_FPS_MAX_PPT) throw AchError{ACH_ERR_UNSUPPORTED, "pn2: num_points must be a multiple of 128, at most 1024"};
         if (D < 3) throw AchError{ACH_ERR_UNSUPPORTED, "pn2: pc_channels must be at least 3 (xyz first)"};
         Pn2Level lv[5];
+        int* fidx_all[4] = {nullptr, nullptr, nullptr, nullptr};
         lv[0].n = N; lv[0].f = alloc_rows(long(B) * N, D);
         {
             PcPrepParams pp{nullptr, lv[0].f.p, B, D, N, lv[0].f.ld};
@@ -1800,15 +1807,32 @@ public:
         }
         lv[0].xyz = static_cast<float*>(aalloc(size_t(B) * N * 3 * sizeof(float)));
         { Pn2XyzParams q{lv[0].f.p, lv[0].f.ld, lv[0].xyz, long(B) * N}; ew(p + ".xyz", pn2_xyz_kernel<T>, q, long(B) * N * 3); }
+        if (pn2_fps_all) {               // the four levels' farthest-point sampling as ONE launch (k_pn2.h): it depends on the input cloud only
+            FpsAllParams fa;
+            std::memset(&fa, 0, sizeof(fa));
+            fa.levels = 4;
+            double bytes = 0;
+            for (int k = 0; k < 4; ++k) {
+                const int S = N / kDiv[k];
+                lv[k + 1].n = S;
+                lv[k + 1].xyz = static_cast<float*>(aalloc(size_t(B) * S * 3 * sizeof(float)));
+                fidx_all[k] = static_cast<int*>(aalloc(size_t(B) * S * sizeof(int)));
+                fa.lv[k] = FpsParams{lv[k].xyz, lv[k].n, S, fidx_all[k], lv[k + 1].xyz};
+                bytes += double(B) * (lv[k].n + S) * 12.0;
+            }
+            const dim3 grid{unsigned(B)}, block(64);
+            add_op(p + ".fps_all", [fa, grid, block](hipStream_t s) { ACH_LAUNCH(pn2_fps_all_kernel, grid, block, s, fa); }, bytes);
+        }
         for (int k = 0; k < 4; ++k) {
             const std::string sa = p + ".sa" + std::to_string(k + 1);
             const Pn2Level& src = lv[k];
             Pn2Level& dst = lv[k + 1];
             const int S = N / kDiv[k];
             dst.n = S;
-            dst.xyz = static_cast<float*>(aalloc(size_t(B) * S * 3 * sizeof(float)));
-            int* fidx = static_cast<int*>(aalloc(size_t(B) * S * sizeof(int)));
-            {
+            int* fidx = fidx_all[k];
+            if (!pn2_fps_all) {
+                dst.xyz = static_cast<float*>(aalloc(size_t(B) * S * 3 * sizeof(float)));
+                fidx = static_cast<int*>(aalloc(size_t(B) * S * sizeof(int)));
                 FpsParams q{src.xyz, src.n, S, fidx, dst.xyz};
                 add_op(sa + ".fps", [q, B](hipStream_t s) { launch_pn2_fps(q, B, s); },
                        double(B) * (src.n + S) * 12.0);

@@ -643,6 +643,78 @@ __global__ __launch_bounds__(256) void sa_apply_kernel(const SaApplyParams p) {
     Store<T>::st(static_cast<T*>(p.Y1) + pix * p.ldy + co, x * sigmoidf_(k1[0] * x + k1[1]));
 }
 
+// Eight output channels per thread (round 4): outputs co .. co + 7 are inputs c0 .. c0 + 3 of the first half interleaved with the same four of
+// the second half — two 8-byte loads, two 16-byte stores instead of eight 2-byte loads and sixteen 2-byte stores (19 -> 8 us at 40 x 40).  C % 8 == 0.
+template <class T>
+__global__ __launch_bounds__(256) void sa_apply8_kernel(const SaApplyParams p) {
+    const int c8n = p.C / 8;
+    const long total = long(p.B) * p.HW * c8n;
+    const long idx = long(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int q = int(idx % c8n);
+    const long pix = idx / c8n;
+    const long b = pix / p.HW;
+    const int co = q * 8, c0 = co >> 1, half = p.C / 2;
+    float xa[4], xb[4];
+    Store<T>::ld4(static_cast<const T*>(p.X) + pix * p.ldx + c0, xa);
+    Store<T>::ld4(static_cast<const T*>(p.X) + pix * p.ldx + half + c0, xb);
+    const float* k0 = p.coef + (b * p.C) * 2;
+    const float* k1 = k0 + long(p.B) * p.C * 2;
+    float o0[8], o1[8];
+    ACH_UNROLL
+    for (int i = 0; i < 4; ++i) {
+        const int ca = c0 + i, cb = half + c0 + i;
+        o0[2 * i] = xa[i] * sigmoidf_(k0[2 * ca] * xa[i] + k0[2 * ca + 1]);
+        o0[2 * i + 1] = xb[i] * sigmoidf_(k0[2 * cb] * xb[i] + k0[2 * cb + 1]);
+        o1[2 * i] = xa[i] * sigmoidf_(k1[2 * ca] * xa[i] + k1[2 * ca + 1]);
+        o1[2 * i + 1] = xb[i] * sigmoidf_(k1[2 * cb] * xb[i] + k1[2 * cb + 1]);
+    }
+    Store<T>::st8(static_cast<T*>(p.Y0) + pix * p.ldy + co, o0);
+    Store<T>::st8(static_cast<T*>(p.Y1) + pix * p.ldy + co, o1);
+}
+
+// The same with the coefficients computed by the workgroup itself (round 4: one launch fewer on the caller's stream; measured SLOWER end to end —
+// 38.3 k against 38.9 k frames/s: 19 200 workgroups each re-derive 96 coefficients behind a barrier — option sa_fuse, off): a block of 256 consecutive
+// elements lies inside ONE sample when HW * C is a multiple of 256 (the engine checks), so its first 2 C threads evaluate sa_coef_kernel's formulas
+// for that sample into LDS — same operations in the same order, bit-identical results.
+struct SaFusedParams { SaCoefParams c; SaApplyParams a; };
+template <class T>
+__global__ __launch_bounds__(256) void sa_apply_fused_kernel(const SaFusedParams q) {
+    __shared__ float coef[2][256][2];
+    const SaCoefParams& p = q.c;
+    const SaApplyParams& ap = q.a;
+    const long idx = long(blockIdx.x) * blockDim.x + threadIdx.x;
+    const long b = (long(blockIdx.x) * blockDim.x) / (long(ap.HW) * ap.C);
+    for (int i = threadIdx.x; i < 2 * p.C; i += 256) {
+        const int m = i / p.C, c = i - m * p.C;
+        const SaWeights& w = p.w[m];
+        float s1 = 0.f, s2 = 0.f;
+        for (int s = 0; s < p.S; ++s) { const float* qq = p.partial + (b * p.S + s) * 2 * p.C; s1 += qq[c]; s2 += qq[p.C + c]; }
+        const float mean = s1 / float(p.HW);
+        const int cg = p.C / p.G, half = cg / 2;
+        const int j = c % cg;
+        float a, d;
+        if (j < half) { a = 0.f; d = w.cw[j] * mean + w.cb[j]; }
+        else {
+            const int jj = j - half;
+            float var = s2 / float(p.HW) - mean * mean;
+            if (var < 0.f) var = 0.f;
+            const float rstd = 1.0f / sqrtf(var + p.eps);
+            a = w.sw[jj] * w.gnw[jj] * rstd;
+            d = w.sw[jj] * (w.gnb[jj] - w.gnw[jj] * mean * rstd) + w.sb[jj];
+        }
+        coef[m][c][0] = a; coef[m][c][1] = d;
+    }
+    __syncthreads();
+    if (idx >= long(ap.B) * ap.HW * ap.C) return;
+    const int co = int(idx % ap.C);
+    const long pix = idx / ap.C;
+    const int c = (co & 1) * (ap.C / 2) + (co >> 1);          // inverse of the shuffle
+    const float x = Store<T>::ld(static_cast<const T*>(ap.X) + pix * ap.ldx + c);
+    Store<T>::st(static_cast<T*>(ap.Y0) + pix * ap.ldy + co, x * sigmoidf_(coef[0][c][0] * x + coef[0][c][1]));
+    Store<T>::st(static_cast<T*>(ap.Y1) + pix * ap.ldy + co, x * sigmoidf_(coef[1][c][0] * x + coef[1][c][1]));
+}
+
 // ------------------------------------------------------------------------------------------ ECA + fusion
 // scale[b][c] = sigmoid(conv1d_k(mean over HW)) * bn_scale[c] ; shift = bn_shift[c]
 struct EcaParams { const float* partial; int S; const float* w; int k; const float* bn_scale; float* scale; int B, C, HW; };

@@ -42,8 +42,9 @@ __global__ void pn2_xyz_kernel(const Pn2XyzParams p) {
 // Start at point 0; ties to the lowest index.
 constexpr int PN2_FPS_MAX_PPT = 16;             // n <= 1024
 struct FpsParams { const float* xyz; int n, npoint; int* idx; float* new_xyz; };
+// one level for one cloud (blockIdx.x), executed by one wave
 template <int PPT>
-__global__ __launch_bounds__(64) void pn2_fps_kernel(const FpsParams p) {
+__device__ __forceinline__ void pn2_fps_level(const FpsParams& p) {
     const int lane = threadIdx.x;
     const float* xyz = p.xyz + long(blockIdx.x) * p.n * 3;
     float px[PPT], py[PPT], pz[PPT], dist[PPT];
@@ -80,6 +81,32 @@ __global__ __launch_bounds__(64) void pn2_fps_kernel(const FpsParams p) {
             if (nxt < 0 && mask) nxt = 64 * k + __ffsll((long long)mask) - 1;
         }
         far = nxt;
+    }
+}
+template <int PPT>
+__global__ __launch_bounds__(64) void pn2_fps_kernel(const FpsParams p) { pn2_fps_level<PPT>(p); }
+
+// Every level's sampling in ONE launch (round 4): level k + 1 samples the centroids level k picked, so the whole chain depends on the input cloud
+// only.  The wave runs the levels back to back; a level reads the centroids its predecessor wrote (lane 0's stores) after a device-scope fence.
+// Replaces four launches that sat between the levels' shared MLPs (the three small ones are pure latency: 64 / 16 / 4 dependent picks).
+struct FpsAllParams { FpsParams lv[4]; int levels; };
+__device__ __forceinline__ void pn2_fps_dispatch(const FpsParams& q) {
+    const int ppt = (q.n + 63) / 64;
+    if (ppt <= 1) pn2_fps_level<1>(q);
+    else if (ppt <= 4) pn2_fps_level<4>(q);
+    else if (ppt <= 8) pn2_fps_level<8>(q);
+    else pn2_fps_level<PN2_FPS_MAX_PPT>(q);
+}
+static __global__ __launch_bounds__(64) void pn2_fps_all_kernel(const FpsAllParams p) {
+    for (int l = 0; l < p.levels; ++l) {
+        if (l > 0) {
+#if defined(ACH_HOSTEMU)
+            (void)__shfl(0, 0);
+#else
+            __threadfence();                      // lane 0's centroid stores of the previous level are visible to the whole wave's loads
+#endif
+        }
+        pn2_fps_dispatch(p.lv[l]);
     }
 }
 inline void launch_pn2_fps(const FpsParams& p, int B, hipStream_t s) {

@@ -287,6 +287,7 @@ def main():
     ap.add_argument('--ops-json', default=None, help='write the per-launch table (ms, algorithmic bytes) here')
     ap.add_argument('--repeats', type=int, default=5, help='timed blocks of --steps steps each; value / ms_per_step are the median block')
     ap.add_argument('--cpu-procs', type=int, default=0, help='processes of the frames-parallel CPU-baseline leg (0: host cores / 8, at most 32)')
+    ap.add_argument('--no-calibrate', action='store_true', help='with a collective: skip the start-up A/B of the side-stream priority patterns and the gather-on / gather-off overhead leg')
     ap.add_argument('--stub-step-ms', type=float, default=None, help='TEST HOOK: no engine, gloo, a sleep per step (tests/test_bench_launcher.py)')
     args = ap.parse_args()
 
@@ -325,69 +326,110 @@ def main():
 
     cid, kw = CONFIGS[args.config]
     tdt = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32}[args.dtype]
-    model = Achelous(**dict(COMMON, **kw)).eval()
-    model.load_state_dict(condition_state_dict(model.state_dict(), seed=0))
-    model = model.to(dev)
-    model.static_weights = True          # serving loop: weights do not change between steps
-    model.bf16_storage = args.storage
-    model.engine_options = {kv.split('=')[0]: int(kv.split('=')[1]) for kv in args.opt}
     B = args.batch
     x, xr, xp = make_inputs(B, config_seed(cid) + 1000 * rank, resolution=COMMON['resolution'], pc_channels=COMMON['pc_channels'], dense_radar=args.dense_radar)
     x, xr, xp = x.to(dev, tdt), xr.to(dev, tdt), xp.to(dev, tdt)
-    gathered = [torch.empty(world * B * (args.max_det * 8 + 1), dtype=torch.int32, device=dev) for _ in range(2)] if collective else None
-    state = {'k': 0, 'pending': None, 'inflight': None, 'last': None}
     ishape = [COMMON['resolution']] * 2
-
-    extra = torch.cuda.Stream(dev) if args.extra_stream else None
-    scratch = torch.zeros(1024, device=dev) if args.extra_stream else None
-
     # the serving loop is the default schedule; PointNet++'s long point branch shares side stream 2 with the decoders there and is 1 % better plain
     pipelined = not args.plain and not args.separate_calls and (args.pipeline or kw.get('pc_seg') != 'pn2')
+    base_opts = {kv.split('=')[0]: int(kv.split('=')[1]) for kv in args.opt}
 
-    def finish(res):
-        (det, se, lane, pc), (rows, idx, cnt) = res
-        if collective:
-            # pipelined: this step's gather runs on RCCL's stream under the next step's forward; its result is waited for one
-            # step late (alternating receive buffers).  fence() waits for the last one, so all K gathers finish inside the timing.
-            nxt = all_gather_detections_async(rows, idx, cnt, out=gathered[state['k'] & 1], force=args.force_collective)
-            state['k'] += 1
-            if state['pending'] is not None:
-                state['pending'].wait()
-            state['pending'] = nxt
-        state['last'] = (det, se, lane, pc, cnt)
+    def make_runner(extra_opts):
+        """A module + the step / fence closures of the timed loop, with `extra_opts` on top of --opt (engine options are fixed when an engine is built)."""
+        model = Achelous(**dict(COMMON, **kw)).eval()
+        model.load_state_dict(condition_state_dict(model.state_dict(), seed=0))
+        model = model.to(dev)
+        model.static_weights = True          # serving loop: weights do not change between steps
+        model.bf16_storage = args.storage
+        model.engine_options = dict(base_opts, **extra_opts)
+        gathered = [torch.empty(world * B * (args.max_det * 8 + 1), dtype=torch.int32, device=dev) for _ in range(2)] if collective else None
+        state = {'k': 0, 'pending': None, 'inflight': None, 'last': None, 'gather': True}
+        extra = torch.cuda.Stream(dev) if args.extra_stream else None
+        scratch = torch.zeros(1024, device=dev) if args.extra_stream else None
 
-    def step():
-        if extra is not None:
-            extra.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(extra):
-                scratch.add_(1.0)
-            torch.cuda.current_stream(dev).wait_stream(extra)
-        if args.separate_calls:
-            det, se, lane, pc = model(x, xr, xp)
-            dec = decode_outputs(det, ishape)
-            finish(((det, se, lane, pc), nms_device(dec, COMMON['num_det'], args.conf, args.iou, args.max_det)))
-        elif not pipelined:                # the three stages as one engine call (decode + NMS overlap the segmentation decoders)
-            finish(model.forward_detect(x, xr, xp, args.conf, args.iou, args.max_det))
-        else:
-            # serving loop: batch k+1 is enqueued BEFORE batch k is waited for, so the engine overlaps batch k's decoders and
-            # detection branch with batch k+1's backbone (Achelous.submit_detect; fence() drains the last one inside the timing)
-            nxt = model.submit_detect(x, xr, xp, args.conf, args.iou, args.max_det)
+        def finish(res):
+            (det, se, lane, pc), (rows, idx, cnt) = res
+            if collective and state['gather']:
+                # pipelined: this step's gather runs on RCCL's stream under the next step's forward; its result is waited for one
+                # step late (alternating receive buffers).  fence() waits for the last one, so all K gathers finish inside the timing.
+                nxt = all_gather_detections_async(rows, idx, cnt, out=gathered[state['k'] & 1], force=args.force_collective)
+                state['k'] += 1
+                if state['pending'] is not None:
+                    state['pending'].wait()
+                state['pending'] = nxt
+            state['last'] = (det, se, lane, pc, cnt)
+
+        def step():
+            if extra is not None:
+                extra.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(extra):
+                    scratch.add_(1.0)
+                torch.cuda.current_stream(dev).wait_stream(extra)
+            if args.separate_calls:
+                det, se, lane, pc = model(x, xr, xp)
+                dec = decode_outputs(det, ishape)
+                finish(((det, se, lane, pc), nms_device(dec, COMMON['num_det'], args.conf, args.iou, args.max_det)))
+            elif not pipelined:                # the three stages as one engine call (decode + NMS overlap the segmentation decoders)
+                finish(model.forward_detect(x, xr, xp, args.conf, args.iou, args.max_det))
+            else:
+                # serving loop: batch k+1 is enqueued BEFORE batch k is waited for, so the engine overlaps batch k's decoders and
+                # detection branch with batch k+1's backbone (Achelous.submit_detect; fence() drains the last one inside the timing)
+                nxt = model.submit_detect(x, xr, xp, args.conf, args.iou, args.max_det)
+                if state['inflight'] is not None:
+                    finish(state['inflight'].wait())
+                state['inflight'] = nxt
+            return state['last']
+
+        def fence():
             if state['inflight'] is not None:
                 finish(state['inflight'].wait())
-            state['inflight'] = nxt
-        return state['last']
+                state['inflight'] = None
+            if state['pending'] is not None:
+                state['pending'].wait()
+                state['pending'] = None
+            torch.cuda.synchronize(dev)
+            if collective:
+                dist.barrier()
+            torch.cuda.synchronize(dev)
+        return model, step, fence, state
 
-    def fence():
-        if state['inflight'] is not None:
-            finish(state['inflight'].wait())
-            state['inflight'] = None
-        if state['pending'] is not None:
-            state['pending'].wait()
-            state['pending'] = None
-        torch.cuda.synchronize(dev)
-        if collective:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
+    def quick_fps(step, fence, steps=20, reps=3):
+        """MAX-over-ranks median of `reps` fenced blocks of `steps` steps -> frames/s of this rank's shard (calibration legs; not the reported value)."""
+        ts = []
+        for _ in range(reps):
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            fence()
+            ts.append(time.perf_counter() - t0)
+        t = torch.tensor(sorted(ts)[(reps - 1) // 2], dtype=torch.float64, device=dev)
+        if collective and world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return B * steps / float(t)
+
+    # ---- N > 1 (or --force-collective): RCCL's stream is one more active stream beside the engine's three, and which side streams run at the lowest
+    # priority decides what that costs (DESIGN 6: -19 % with the wrong pattern at world size 1).  Measured here, in this process, with the real
+    # collective, instead of taken from a world-1 experiment: every candidate pattern runs the same short loop and the fastest one serves the timed run.
+    calib = None
+    chosen = {}
+    if collective and not args.no_calibrate and 'side_priority' not in base_opts and not args.separate_calls:
+        cands = {}
+        with torch.no_grad():
+            for prio in (3, 2, 1):
+                m_, st_, fe_, _ = make_runner({'side_priority': prio})
+                for _ in range(max(args.warmup, 3)):
+                    st_()
+                cands[prio] = quick_fps(st_, fe_)
+                del m_, st_, fe_
+        best = max(cands, key=lambda k: cands[k])
+        if collective and world > 1:          # every rank must build the same plan
+            tb = torch.tensor([best], dtype=torch.int64, device=dev)
+            dist.broadcast(tb, 0)
+            best = int(tb)
+        chosen = {'side_priority': best}
+        calib = {'side_priority_fps': {str(k): round(v, 1) for k, v in cands.items()}, 'side_priority_chosen': best}
+    model, step, fence, state = make_runner(chosen)
 
     with torch.no_grad():
         for _ in range(max(args.warmup, 1)):
@@ -430,6 +472,15 @@ def main():
             t1 = time.perf_counter()
             blocks.append(t1 - t0)
             enq.append(th - t0)
+        coll = None
+        if collective and not args.no_calibrate:
+            # what the collective costs THIS run: the same loop with the all-gather switched off (the engine's plan and streams unchanged)
+            on = quick_fps(step, fence)
+            state['gather'] = False
+            off = quick_fps(step, fence)
+            state['gather'] = True
+            coll = dict(calib or {}, rccl_stream_overhead_pct=round((off / on - 1.0) * 100.0, 2), fps_gather_on=round(on, 1), fps_gather_off=round(off, 1),
+                        stream_count={'engine': 1 + len({o['stream'] for o in full} - {0}), 'rccl': 1})
         probe_ms, probe_n = eng.read_probe()
         sub_parts = [eng.read_probe_slot(1 + k) for k in range(len(sub_ranges))]
         sub_ms, sub_n = sum(p[0] for p in sub_parts), min([p[1] for p in sub_parts] or [0])
@@ -520,6 +571,7 @@ def main():
             'schedule': 'pipelined submit/wait (batch k+1 enqueued before batch k is joined)' if pipelined else 'plain (every step joined before the next)',
             'plain_forward_detect_fps': round(B * args.steps / plain, 2) if plain else None,
             'compulsory_hbm_frac': round(algo_bytes_frame * (frames / fwd_elapsed) / world / 1e9 / HBM_PEAK_GBS, 5),
+            'collective': coll,          # N > 1 / --force-collective: start-up A/B of the side-stream priority patterns, gather-on vs gather-off in this process
             'roofline': roofline,
             'mfma': {'flops_per_step': flops_step, 'achieved': round(flops_step * (fps / (world * B)) / 1e12, 2), 'peak': mfma_peak, 'unit': 'TFLOP/s',
                      'frac': round(flops_step * (fps / (world * B)) / 1e12 / mfma_peak, 5),
