@@ -239,6 +239,35 @@ int ach_correct_boxes(ach_handle* h, int32_t batch, int32_t max_det, const float
     });
 }
 
+// ---- multi-GPU: the one exchange step of the path — an all-gather of the shards' fixed-size detection records over RCCL.
+// RCCL is resolved at first use (dlopen of librccl.so; ACH_RCCL_LIBRARY overrides the name): the library itself does not link against it, so a
+// single-GPU consumer needs no RCCL at all.  `comm` is an ncclComm_t the caller created with RCCL's own API (one rank per GPU).
+#if !defined(ACH_HOSTEMU)
+#include <dlfcn.h>
+#endif
+size_t ach_record_words(int32_t batch, int32_t max_det) { return (batch > 0 && max_det > 0) ? size_t(batch) * (size_t(max_det) * 8 + 1) : 0; }
+int ach_all_gather_records(ach_handle* h, void* comm, const int32_t* send_record, int32_t* recv_records, int32_t batch, int32_t max_det, void* stream) {
+    return guarded(h, [&] {
+        if (!comm || !send_record || !recv_records || batch <= 0 || max_det <= 0) throw ach::AchError{ACH_ERR_INVALID, "bad all-gather arguments"};
+#if defined(ACH_HOSTEMU)
+        throw ach::AchError{ACH_ERR_UNSUPPORTED, "the CPU emulation has no RCCL"};
+#else
+        typedef int (*allgather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
+        static allgather_fn fn = nullptr;
+        if (!fn) {
+            const char* name = std::getenv("ACH_RCCL_LIBRARY");
+            void* lib = dlopen(name ? name : "librccl.so", RTLD_NOW | RTLD_GLOBAL);
+            if (!lib && !name) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+            if (!lib) throw ach::AchError{ACH_ERR_DEVICE, std::string("RCCL library not found: ") + dlerror()};
+            fn = reinterpret_cast<allgather_fn>(dlsym(lib, "ncclAllGather"));
+            if (!fn) throw ach::AchError{ACH_ERR_DEVICE, "ncclAllGather not found in the RCCL library"};
+        }
+        const int rc = fn(send_record, recv_records, ach_record_words(batch, max_det), /* ncclInt32 */ 2, comm, static_cast<hipStream_t>(stream));
+        if (rc != 0) throw ach::AchError{ACH_ERR_DEVICE, "ncclAllGather failed with code " + std::to_string(rc)};
+#endif
+    });
+}
+
 // ---- one pass of the 8-bit PIL resample (k_prepost.h): stateless
 int ach_resample_pass_u8(const uint8_t* src, uint8_t* dst, const int32_t* bounds, const int32_t* coeffs, int32_t ksize, int32_t h_in, int32_t w_in,
                          int32_t h_out, int32_t w_out, int32_t channels, int32_t vertical, int64_t src_pitch, int64_t dst_pitch, void* stream) {

@@ -39,7 +39,8 @@ class NativeLibrary:
                'ach_forward_profiled', 'ach_set_probe', 'ach_read_probe', 'ach_set_probe_range', 'ach_read_probe_slot', 'ach_bench_gemm', 'ach_set_option', 'ach_preprocess_radar',
                'ach_normalize_points', 'ach_preprocess_image', 'ach_seg_argmax', 'ach_seg_resize_argmax', 'ach_correct_boxes', 'ach_train_gemm', 'ach_train_bn_stats', 'ach_train_bn_relu_fwd', 'ach_train_bn_relu_bwd', 'ach_train_dw3x3', 'ach_train_dw3x3_wgrad', 'ach_train_max_points', 'ach_train_log_softmax', 'ach_resample_pass_u8', 'ach_train_act', 'ach_train_mul', 'ach_train_layernorm', 'ach_train_layernorm_bwd', 'ach_train_dwconv', 'ach_train_dwconv_wgrad',
                'ach_train_im2col', 'ach_train_softmax', 'ach_train_upsample2x', 'ach_train_maxpool', 'ach_train_avgpool3', 'ach_train_row_reduce', 'ach_train_row_scale',
-               'ach_train_col_reduce', 'ach_train_col_scale', 'ach_train_instnorm', 'ach_train_l2norm', 'ach_train_deform_im2col', 'ach_train_deform_bwd')
+               'ach_train_col_reduce', 'ach_train_col_scale', 'ach_train_instnorm', 'ach_train_l2norm', 'ach_train_deform_im2col', 'ach_train_deform_bwd',
+               'ach_record_words', 'ach_all_gather_records')
 
     def __init__(self, path):
         if not os.path.exists(path):
@@ -127,6 +128,10 @@ class NativeLibrary:
                            ('ach_train_deform_bwd', [vp] * 7 + [i32] * 8 + [vp])):
             getattr(L, name).argtypes = args
             getattr(L, name).restype = ctypes.c_int
+        L.ach_record_words.argtypes = [i32, i32]
+        L.ach_record_words.restype = sz
+        L.ach_all_gather_records.argtypes = [vp, vp, vp, vp, i32, i32, vp]
+        L.ach_all_gather_records.restype = ctypes.c_int
         L.ach_tap_count.argtypes = [vp]
         L.ach_tap_count.restype = ctypes.c_int
         L.ach_tap_name.argtypes = [vp, ctypes.c_int]

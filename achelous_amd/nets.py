@@ -253,7 +253,8 @@ class Achelous(nn.Module):
                 if not idle:
                     break
                 victim = min(idle, key=lambda k: getattr(self._engines[k][0], '_last_use', 0))
-                torch.cuda.synchronize(device)          # a plain (joined) forward of the victim may still be running: its arenas are about to be freed
+                if torch.cuda.is_available():
+                    torch.cuda.synchronize(device)      # a plain (joined) forward of the victim may still be running: its arenas are about to be freed
                 self._engines.pop(victim)[0].destroy(reason=f'evicted from the module\'s engine table (more than max_engines = {self.max_engines} plans per device and dtype): raise model.max_engines')
                 mine.remove(victim)
             self._engines[key] = ent

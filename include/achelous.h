@@ -11,6 +11,7 @@
  *   ach_decode                    <- utils/utils_bbox.py:33-85   decode_outputs(outputs, input_shape)
  *   ach_nms                       <- utils/utils_bbox.py:87-132  non_max_suppression(...) up to the host-side un-letterbox
  *   ach_forward_detect            <- achelous.py:196-262         the three calls above as the reference's detect_image chains them
+ *   ach_all_gather_records        <- achelous.py:176             nn.DataParallel's gather of the replicas' outputs (here: RCCL all-gather of detection records)
  *   ach_read_tap / ach_tap_*      <- (test hook) intermediate tensors at the SURVEY.md §8(a) boundaries
  *
  * Conventions: plain pointers and sizes only (no torch / HIP C++ types in the signatures; `stream` is a
@@ -162,6 +163,15 @@ int ach_decode(ach_handle* h, int32_t batch, const void* det3, const void* det4,
 size_t ach_nms_workspace_bytes(const ach_handle* h, int32_t batch);
 int ach_nms(ach_handle* h, int32_t batch, const float* decoded, float conf_thres, float nms_thres, int32_t max_det,
             float* out_rows, int32_t* out_idx, int32_t* out_count, void* workspace, void* stream);
+
+/* Multi-GPU (the reference's nn.DataParallel gather, achelous.py:176): frames shard by contiguous batch slices with NO data-path
+ * collective; the one exchange step is an all-gather of the shards' fixed-size detection records.  A shard's record is ONE flat int32 buffer of
+ * ach_record_words(batch, max_det) words, planar: rows [batch, max_det, 7] (fp32 bits) | kept anchor indices [batch, max_det] | counts [batch] — pass
+ * pointers into it as out_rows / out_idx / out_count of ach_nms / ach_forward_detect (the kernel fills every slot).  ach_all_gather_records enqueues
+ * ncclAllGather(send, recv, words, ncclInt32, comm, stream): `comm` is an ncclComm_t the caller created with RCCL (one rank per GPU), recv_records holds
+ * world x words.  RCCL is dlopen'ed at first use (librccl.so, or $ACH_RCCL_LIBRARY); the library does not link against it. */
+size_t ach_record_words(int32_t batch, int32_t max_det);
+int ach_all_gather_records(ach_handle* h, void* nccl_comm, const int32_t* send_record, int32_t* recv_records, int32_t batch, int32_t max_det, void* stream);
 
 /* Pre / post-processing either side of the forward (the reference does these per frame on the host):
  *   ach_preprocess_radar  <- utils/utils.py:51-54   preprocess_input_radar: (x - min) / (max - min) + 1e-13, min/max per frame;

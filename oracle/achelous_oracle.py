@@ -146,11 +146,12 @@ class AchelousOracle:
     # ------------------------------------------------------------------ EdgeNeXt (a2-a5)
     def pos_fourier(self, pfx, H, W, hidden=32, temperature=10000.0):
         """PositionalEncodingFourier (edgenext_modules/layers.py:38-59); input independent."""
-        y = torch.arange(1, H + 1, dtype=torch.float32).view(H, 1).expand(H, W)
-        x = torch.arange(1, W + 1, dtype=torch.float32).view(1, W).expand(H, W)
+        dev = self.P(pfx + '.token_projection.weight').device           # (CPU everywhere except profiles/scripts/train_step.py --baseline)
+        y = torch.arange(1, H + 1, dtype=torch.float32, device=dev).view(H, 1).expand(H, W)
+        x = torch.arange(1, W + 1, dtype=torch.float32, device=dev).view(1, W).expand(H, W)
         y = y / (float(H) + 1e-6) * (2 * math.pi)
         x = x / (float(W) + 1e-6) * (2 * math.pi)
-        dim_t = torch.arange(hidden, dtype=torch.float32)
+        dim_t = torch.arange(hidden, dtype=torch.float32, device=dev)
         dim_t = temperature ** (2 * torch.div(dim_t, 2, rounding_mode='floor') / hidden)
         px = x[:, :, None] / dim_t
         py = y[:, :, None] / dim_t
@@ -443,7 +444,7 @@ class AchelousOracle:
         y = self._c1(y, pfx + '.fc1', pfx + '.bn4')
         y = self._c1(y, pfx + '.fc2', pfx + '.bn5')
         y = self._c1(y, pfx + '.fc3', None, relu=False)
-        return (y + torch.eye(k).flatten().unsqueeze(0)).view(-1, k, k)
+        return (y + torch.eye(k, device=y.device).flatten().unsqueeze(0)).view(-1, k, k)
 
     def pointnet(self, pts):
         """PointNet_SEG.forward / PointNetEncoder.forward (pointnet_sem_seg.py:26-37, pointnet_utils.py:103-133)."""

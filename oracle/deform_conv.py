@@ -67,10 +67,10 @@ def deform_conv2d(input, offset, weight, bias=None, stride=(1, 1), padding=(0, 0
     Wo = (W + 2 * pw - (dw * (kw - 1) + 1)) // sw + 1
     assert offset.shape == (B, 2 * K, Ho, Wo), offset.shape
     dt = input.dtype
-    ys = (torch.arange(Ho, dtype=dt) * sh - ph).view(1, 1, Ho, 1)
-    xs = (torch.arange(Wo, dtype=dt) * sw - pw).view(1, 1, 1, Wo)
-    ky = (torch.arange(kh, dtype=dt) * dh).repeat_interleave(kw).view(1, K, 1, 1)
-    kx = (torch.arange(kw, dtype=dt) * dw).repeat(kh).view(1, K, 1, 1)
+    ys = (torch.arange(Ho, dtype=dt, device=input.device) * sh - ph).view(1, 1, Ho, 1)
+    xs = (torch.arange(Wo, dtype=dt, device=input.device) * sw - pw).view(1, 1, 1, Wo)
+    ky = (torch.arange(kh, dtype=dt, device=input.device) * dh).repeat_interleave(kw).view(1, K, 1, 1)
+    kx = (torch.arange(kw, dtype=dt, device=input.device) * dw).repeat(kh).view(1, K, 1, 1)
     py = ys + ky + offset[:, 0::2]
     px = xs + kx + offset[:, 1::2]
     cols = _bilinear_zero(input, py, px)              # [B, C, K, Ho, Wo]

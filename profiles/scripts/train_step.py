@@ -14,28 +14,79 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--batch', type=int, default=8)
 ap.add_argument('--steps', type=int, default=5)
 ap.add_argument('--resolution', type=int, default=320)
+ap.add_argument('--baseline', action='store_true', help='also time the SAME step as a torch-op composite on this GPU: the oracle (our restatement of the reference, oracle/achelous_oracle.py) with BatchNorm on batch statistics, fp32, torch autograd + torch SGD')
+ap.add_argument('--device', default='cuda')
 a = ap.parse_args()
 kw = dict(num_det=7, num_seg=9, phi='S0', resolution=a.resolution, backbone='en', neck='gdf', pc_seg='pn', pc_channels=5, pc_classes=8, nano_head=True, spp=True)
 m = Achelous(**kw)
 m.load_state_dict(condition_state_dict(m.state_dict(), seed=0))
-m = m.cuda().train()
+m = m.to(a.device).train()
 opt = torch.optim.SGD(m.parameters(), lr=1e-4, momentum=0.9)
-x, xr, xp = (t.cuda() for t in make_inputs(a.batch, 3, resolution=a.resolution, pc_channels=5))
+x, xr, xp = (t.to(a.device) for t in make_inputs(a.batch, 3, resolution=a.resolution, pc_channels=5))
 g = torch.Generator().manual_seed(4)
+
+
+def sync():
+    if a.device != 'cpu':
+        torch.cuda.synchronize()
+
+
 losses, times = [], []
 targets = None
 for step in range(a.steps + 1):
-    torch.cuda.synchronize(); t0 = time.time()
+    sync(); t0 = time.time()
     det, se, lane, pc = m(x, xr, xp)
     outs = [*det, se, lane, pc]
     if targets is None:
-        targets = [torch.randn(o.shape, generator=g).cuda() * 0.1 + o.detach() for o in outs]
+        targets = [torch.randn(o.shape, generator=g).to(a.device) * 0.1 + o.detach() for o in outs]
     loss = sum(((o - t) ** 2).mean() for o, t in zip(outs, targets))
     opt.zero_grad(set_to_none=True)
     loss.backward()
     opt.step()
-    torch.cuda.synchronize(); times.append(time.time() - t0)
+    sync(); times.append(time.time() - t0)
     losses.append(float(loss.detach()))
-print(json.dumps({'what': 'training step EN-GDF-PN-S0 fp32, native forward/backward kernels + torch SGD', 'batch': a.batch, 'resolution': a.resolution,
+native = {'what': 'training step EN-GDF-PN-S0 fp32, native forward/backward kernels + torch SGD', 'batch': a.batch, 'resolution': a.resolution,
                   'ms_per_step': round(1e3 * sum(times[1:]) / max(len(times) - 1, 1), 2), 'frames_per_s': round(a.batch * (len(times) - 1) / sum(times[1:]), 1),
-                  'loss': [round(v, 5) for v in losses], 'peak_mem_GB': round(torch.cuda.max_memory_allocated() / 2**30, 2)}))
+                  'loss': [round(v, 5) for v in losses], 'peak_mem_GB': round(torch.cuda.max_memory_allocated() / 2**30, 2) if a.device != 'cpu' else None}
+print(json.dumps(native))
+
+
+if a.baseline:
+    # The same step through torch's own ops on the same device: the oracle's graph (test infrastructure, imported here as bench.py's cpu_baseline leg imports
+    # it: a measured yardstick, never a product path) with training-mode BatchNorm, parameters as autograd leaves, torch SGD.  The deformable conv is the
+    # oracle's gather restatement (torchvision's kernel is not installable here), which is what a PyTorch user without torchvision's op would run.
+    import os
+    import sys
+    import torch.nn.functional as F
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
+    from oracle.achelous_oracle import AchelousOracle
+
+    class TrainingOracle(AchelousOracle):
+        def __init__(self, sd, **k):
+            super().__init__(sd, **k)
+            self.sd = {n: (v.detach().float().clone().requires_grad_(True) if v.is_floating_point() and not n.endswith(('running_mean', 'running_var')) else v.detach())
+                       for n, v in sd.items()}
+
+        def bn(self, t, pfx, eps):
+            return F.batch_norm(t, None, None, self.P(pfx + '.weight'), self.P(pfx + '.bias'), True, 0.1, eps)
+
+    okw = {k: kw[k] for k in ('num_det', 'num_seg', 'phi', 'backbone', 'neck', 'pc_seg', 'pc_channels', 'pc_classes', 'nano_head', 'spp', 'resolution')}
+    o = TrainingOracle({k: v.to(a.device) for k, v in condition_state_dict(Achelous(**kw).state_dict(), seed=0).items()}, **okw)
+    leaves = [v for v in o.sd.values() if v.is_floating_point() and v.requires_grad]
+    opt2 = torch.optim.SGD(leaves, lr=1e-4, momentum=0.9)
+    t2 = []
+    for step in range(a.steps + 1):
+        sync(); t0 = time.time()
+        pc = o.pointnet(xp)
+        se, lane, (q5, q4, q3) = o.ghost_dual_fpn(x)
+        r3, r4, r5 = o.rcnet(xr)
+        det = o.head((o.fuse(q3, r3, 3), o.fuse(q4, r4, 4), o.fuse(q5, r5, 5)))
+        outs = [*det, se, lane, pc]
+        loss = sum(((oo - t) ** 2).mean() for oo, t in zip(outs, targets))
+        opt2.zero_grad(set_to_none=True)
+        loss.backward()
+        opt2.step()
+        sync(); t2.append(time.time() - t0)
+    print(json.dumps({'what': 'the same step as a torch-op composite (oracle graph, torch autograd, torch SGD) on the same device', 'batch': a.batch,
+                      'ms_per_step': round(1e3 * sum(t2[1:]) / max(len(t2) - 1, 1), 2), 'frames_per_s': round(a.batch * (len(t2) - 1) / sum(t2[1:]), 1),
+                      'native_over_torch_composite': round((sum(t2[1:]) / max(len(t2) - 1, 1)) / (native['ms_per_step'] * 1e-3), 2)}))

@@ -212,3 +212,33 @@ def test_gpu_train_then_eval_uses_the_updated_weights_and_statistics():
     assert any(not torch.equal(a, b) for a, b in zip((*after[0], after[1]), before))            # the step changed something
     for a, b in zip((*after[0], after[1], after[2], after[3]), (*ref[0], ref[1], ref[2], ref[3])):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_gpu_training_step_under_the_reference_amp_loop():
+    """The reference trains under `torch.cuda.amp.autocast()` + GradScaler by default (utils/utils_fit.py:120-166, train.py:37 --fp16 True): the
+    forward is called with fp32 tensors inside the autocast region and the scaled loss is back-propagated.  The native training graph keeps its
+    own fp32 kernels inside the region (autocast re-types torch ops, not ours), so that loop runs UNCHANGED and its gradients equal the plain
+    loop's — a superset of the precision the reference's AMP mode asks for."""
+    from golden_util import Golden, ctor_kwargs
+    g = Golden('en_s0')
+    kw = dict(ctor_kwargs(g.meta), resolution=96)
+    x, xr, xp = (t.cuda() for t in make_inputs(2, 43, resolution=96, num_points=32, pc_channels=kw['pc_channels'], radar_cells=10))
+    grads = []
+    for amp in (False, True):
+        m = Achelous(**kw)
+        m.load_state_dict(condition_state_dict(m.state_dict(), seed=0))
+        m = m.cuda().train()
+        scaler = torch.amp.GradScaler('cuda', enabled=amp, init_scale=1024.0)
+        with torch.autocast('cuda', dtype=torch.float16, enabled=amp):
+            det, se, lane, pc = m(x, xr, xp)
+            assert se.dtype == torch.float32
+            loss = sum((o.float() ** 2).mean() for o in (*det, se, lane, pc))
+        scaler.scale(loss).backward()
+        inv = 1.0 / float(scaler.get_scale()) if amp else 1.0
+        grads.append({n: p.grad.detach().double() * inv for n, p in m.named_parameters() if p.grad is not None})
+    assert len(grads[0]) > 400 and grads[0].keys() == grads[1].keys()
+    for n in grads[0]:
+        a, b = grads[0][n], grads[1][n]
+        assert torch.isfinite(b).all(), n
+        assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max()) + 1e-12, n
