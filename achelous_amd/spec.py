@@ -77,6 +77,10 @@ def _pointnet(s, pc_channels, pc_classes):      # pointnet_sem_seg.py:13-24, poi
 # segmentation model of the public Pointnet_Pointnet2_pytorch project (sa1-4 / fp4-1 / conv1 / bn1 / conv2, with its channel
 # widths), re-sized to the 512-point clouds of this path: level k keeps N / div points, 32 samples per ball, radii in the units
 # of the column-normalised cloud (achelous.py:240).  Geometry rules (FPS start, distance form, tie-breaks): DESIGN.md section 5b.
+# (Round 4, profiles/scripts/pn2_spec_search.py: the reference's one PointNet++ datum — README.md:81,83: +0.09 M parameters, +0.08 GFLOPs over PointNet,
+#  i.e. ~2.01 M / ~251 M MACs — is fitted by the MULTI-scale model of that project (1.88 M; 190-345 M MACs depending on level sizes), not by this
+#  single-scale one (0.97 M, 207 M MACs).  The single-scale variant stays the specification this round: radii and sample counts of the multi-scale one
+#  would be as much our own choice, and the branch is self-specified either way; DESIGN.md 5b has the table.)
 PN2 = dict(
     sa=[dict(div=2, radius=0.03, nsample=32, mlp=[32, 32, 64]),
         dict(div=8, radius=0.06, nsample=32, mlp=[64, 64, 128]),

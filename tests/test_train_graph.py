@@ -238,7 +238,9 @@ def test_gpu_training_step_under_the_reference_amp_loop():
         inv = 1.0 / float(scaler.get_scale()) if amp else 1.0
         grads.append({n: p.grad.detach().double() * inv for n, p in m.named_parameters() if p.grad is not None})
     assert len(grads[0]) > 400 and grads[0].keys() == grads[1].keys()
+    gmax = max(float(v.abs().max()) for v in grads[0].values())
     for n in grads[0]:
         a, b = grads[0][n], grads[1][n]
         assert torch.isfinite(b).all(), n
-        assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max()) + 1e-12, n
+        # (a bias in front of a training-mode BatchNorm has a TRUE gradient of zero: both loops return rounding noise around it, at the scale of the step's gradients)
+        assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max()) + 2e-6 * gmax, n
