@@ -1249,9 +1249,25 @@ public:
         // SPP (spp.py:41-67)
         const int c_ = w[3] / 2;
         if (c_ % 4) throw AchError{ACH_ERR_UNSUPPORTED, "SPP hidden width must be a multiple of 4"};
-        A cat5 = alloc(m5.B, m5.H, m5.W, 4 * c_);
         mark_xwait_next();               // pipelined forwards: the neck rewrites what the previous forward's stream 2 reads (engine.cpp)
         mark_xwait2_next();              // ... and what its decoders read
+        A p5;
+        bool spp_done = false;
+        if constexpr (H16E) if (ghost_fuse && !full_taps && spp_fused_supported(m5.H, m5.W, w[3], c_) && m5.ld % 8 == 0) {
+            // cv1 -> pools -> cv2 as ONE launch (k_ghost.h spp_fused_kernel): the concat buffer never exists
+            Lin l1 = conv_bn(f + ".spp.cv1.conv", f + ".spp.cv1.bn", 1e-3), l2 = conv_bn(f + ".spp.cv2.conv", f + ".spp.cv2.bn", 1e-3);
+            if (l1.N != c_ || l1.K != w[3] || l2.N != w[3] || l2.K != 4 * c_) throw AchError{ACH_ERR_MISSING_KEY, "SPP widths"};
+            BandW b1 = pack_band(l1), b2 = pack_band(l2);
+            p5 = alloc(m5.B, m5.H, m5.W, w[3]);
+            const int split = b2.chunks >= 4 ? 2 : 1;
+            SppFusedParams sp{m5.p, m5.ld, p5.p, p5.ld, b1.w, b1.b, b2.w, b2.b, m5.B, m5.H, m5.W, w[3], c_, b1.k1, b1.chunks, b2.k1, b2.chunks, split};
+            const dim3 grid(unsigned(m5.B) * unsigned(split)), block(GH_THREADS);
+            add_op(f + ".spp", [sp, grid, block](hipStream_t s) { ACH_LAUNCH((spp_fused_kernel<T>), grid, block, s, sp); },
+                   2.0 * double(m5.rows()) * w[3] * sizeof(T), 2.0 * double(m5.rows()) * (double(w[3]) * c_ + 4.0 * c_ * w[3]));
+            spp_done = true;
+        }
+        if (!spp_done) {
+        A cat5 = alloc(m5.B, m5.H, m5.W, 4 * c_);
         { GemmOpt o; o.act = ACT_SILU; gemm(f + ".spp.cv1", m5, pack(conv_bn(f + ".spp.cv1.conv", f + ".spp.cv1.bn", 1e-3)), cat5.slice(0, c_), o); }
         {
             const int hw = m5.H * m5.W, cq = c_ / 4;
@@ -1261,8 +1277,9 @@ public:
             const dim3 grid(unsigned(m5.B) * unsigned(cdiv(cq, cqb))), block(256);
             add_op(f + ".spp.pool", [sp, grid, block](hipStream_t s) { ACH_LAUNCH(spp_pool_kernel<T>, grid, block, s, sp); }, 5.0 * double(m5.rows()) * c_ * sizeof(T));
         }
-        A p5 = alloc(m5.B, m5.H, m5.W, w[3]);
+        p5 = alloc(m5.B, m5.H, m5.W, w[3]);
         { GemmOpt o; o.act = ACT_SILU; gemm(f + ".spp.cv2", cat5, pack(conv_bn(f + ".spp.cv2.conv", f + ".spp.cv2.bn", 1e-3)), p5, o); }
+        }
         tap("spp", p5);
         // top-down
         A c4 = cat_buf[1].p ? cat_buf[1] : alloc(m4.B, m4.H, m4.W, 2 * w[2]);

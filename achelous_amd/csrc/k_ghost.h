@@ -260,6 +260,125 @@ __global__ __launch_bounds__(GH_THREADS) void upconv_kernel(const UpConvParams p
     }
 }
 
+
+// ------------------------------------------------------------------------------------------ SPP / SPPF (neck/spp.py:41-67) as one launch
+// cv1 (1x1 + BN + SiLU, C -> c_) -> max pools 5 / 9 / 13 (stride 1, -inf padding; SPPF's three chained 5x5 pools are the same windows) -> cat ->
+// cv2 (1x1 + BN + SiLU, 4 c_ -> C) on a map of at most 16 x 16.  A workgroup owns (frame, share of cv2's output chunks) and recomputes cv1 + the
+// pools for its frame (cheap: 100 pixels): cv1's output goes to LDS in the storage type (the rounding the concat buffer had), the pools are
+// computed separably (row maxima, then column maxima) and written straight into the B fragments of cv2 — the concat buffer never exists.
+struct SppFusedParams {
+    const void* X; long ldx;              // [B, H, W, ldx], K1 = C channels
+    void* Y; long ldy;                    // [B, H, W, ldy], N = C channels
+    const uint4* W1; const float* b1;     // cv1: NT = 2 fragments, k1a k-steps, chunks1 chunks
+    const uint4* W2; const float* b2;     // cv2: k1b k-steps (K = 4 c_), chunks2 chunks
+    int B, H, W, C, cmid, k1a, chunks1, k1b, chunks2, split;
+};
+constexpr int SPPF_MAXPIX = 112, SPPF_MAXMID = 96, SPPF_K2MAX = 12;
+template <class T>
+__global__ __launch_bounds__(GH_THREADS) void spp_fused_kernel(const SppFusedParams p) {
+    static_assert(Store<T>::VEC == 8, "16-bit storage");
+    __shared__ __attribute__((aligned(16))) T x1s[SPPF_MAXPIX * SPPF_MAXMID];                  // cv1 output [pix][cmid]
+    __shared__ __attribute__((aligned(16))) T rmax[3][SPPF_MAXPIX * SPPF_MAXMID];              // row maxima of radius 2 / 4 / 6
+    __shared__ __attribute__((aligned(16))) uint4 xs[(SPPF_MAXPIX / 16) * SPPF_K2MAX * 64];    // B fragments of cv2: [tile][k-step][lane]
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
+    const int px = lane & 15, g = lane >> 4;
+    const int b = int(blockIdx.x) / p.split, part = int(blockIdx.x) % p.split;
+    const int HW = p.H * p.W, nt = (HW + 15) / 16, cm = p.cmid;
+    const T* X = static_cast<const T*>(p.X) + long(b) * HW * p.ldx;
+    for (int i = tid; i < nt * p.k1b * 64; i += GH_THREADS) xs[i] = make_uint4(0u, 0u, 0u, 0u);
+    // ---- 1. cv1 -> LDS
+    for (int item = wave; item < nt * p.chunks1; item += GH_WAVES) {
+        const int t = item / p.chunks1, c = item - t * p.chunks1;
+        const int pix = t * 16 + px;
+        const bool valid = pix < HW;
+        const T* xrow = X + long(valid ? pix : 0) * p.ldx + g * 8;
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+        band_gemm_item<T, 6>(p.W1 + long(c) * p.k1a * 2 * 64, p.k1a, lane,
+                             [&](int s) { return (valid && s * 32 + g * 8 < p.C) ? *reinterpret_cast<const uint4*>(xrow + s * 32) : make_uint4(0u, 0u, 0u, 0u); }, a0, a1);
+        const int nb = c * 32 + g * 8;
+        if (!valid || nb >= cm) continue;
+        float o[8];
+        ACH_UNROLL
+        for (int r = 0; r < 4; ++r) { o[r] = a0[r] + p.b1[nb + r]; o[4 + r] = a1[r] + p.b1[nb + 4 + r]; }
+        apply_act_n<T, 8>(o, ACT_SILU);
+        *reinterpret_cast<uint4*>(x1s + pix * cm + nb) = frag_pack<T>(o);
+    }
+    __syncthreads();
+    // ---- 2a. row maxima (radius 2 / 4 / 6) per (pixel, channel quad); x1 itself -> fragments (concat slot 0)
+    const int cq = cm / 4, items = HW * cq;
+    auto to_frag = [&](int pix, int ccat, const float (&v)[4]) {      // 4 consecutive concat channels of a pixel -> its B-fragment slot
+        const int s = ccat >> 5, gg = (ccat & 31) >> 3, e = ccat & 7;
+        uint2 o;
+        o.x = H16<T>::pack(v[0], v[1]); o.y = H16<T>::pack(v[2], v[3]);
+        *reinterpret_cast<uint2*>(reinterpret_cast<char*>(xs + ((pix >> 4) * p.k1b + s) * 64 + gg * 16 + (pix & 15)) + e * 2) = o;
+    };
+    for (int it = tid; it < items; it += GH_THREADS) {
+        const int q = it % cq, pix = it / cq, y = pix / p.W, x = pix - y * p.W;
+        float m[4], m5[4], m9[4];
+        Store<T>::ld4(x1s + pix * cm + q * 4, m);
+        to_frag(pix, q * 4, m);
+        ACH_UNROLL
+        for (int d = 1; d <= 6; ++d) {
+            float v[4];
+            if (x - d >= 0) { Store<T>::ld4(x1s + (pix - d) * cm + q * 4, v); ACH_UNROLL for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], v[e]); }
+            if (x + d < p.W) { Store<T>::ld4(x1s + (pix + d) * cm + q * 4, v); ACH_UNROLL for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], v[e]); }
+            if (d == 2) { ACH_UNROLL for (int e = 0; e < 4; ++e) m5[e] = m[e]; }
+            if (d == 4) { ACH_UNROLL for (int e = 0; e < 4; ++e) m9[e] = m[e]; }
+        }
+        Store<T>::st4(rmax[0] + pix * cm + q * 4, m5);
+        Store<T>::st4(rmax[1] + pix * cm + q * 4, m9);
+        Store<T>::st4(rmax[2] + pix * cm + q * 4, m);
+    }
+    __syncthreads();
+    // ---- 2b. column maxima -> fragments (concat slots 1-3)
+    for (int it = tid; it < items; it += GH_THREADS) {
+        const int q = it % cq, pix = it / cq, y = pix / p.W;
+        float m5[4], m9[4], m13[4];
+        Store<T>::ld4(rmax[0] + pix * cm + q * 4, m5);
+        Store<T>::ld4(rmax[1] + pix * cm + q * 4, m9);
+        Store<T>::ld4(rmax[2] + pix * cm + q * 4, m13);
+        ACH_UNROLL
+        for (int d = 1; d <= 6; ++d) {
+            ACH_UNROLL
+            for (int sgn = -1; sgn <= 1; sgn += 2) {
+                const int yy = y + sgn * d;
+                if (yy < 0 || yy >= p.H) continue;
+                const int j = (pix + sgn * d * p.W) * cm + q * 4;
+                float v[4];
+                if (d <= 2) { Store<T>::ld4(rmax[0] + j, v); ACH_UNROLL for (int e = 0; e < 4; ++e) m5[e] = fmaxf(m5[e], v[e]); }
+                if (d <= 4) { Store<T>::ld4(rmax[1] + j, v); ACH_UNROLL for (int e = 0; e < 4; ++e) m9[e] = fmaxf(m9[e], v[e]); }
+                Store<T>::ld4(rmax[2] + j, v);
+                ACH_UNROLL for (int e = 0; e < 4; ++e) m13[e] = fmaxf(m13[e], v[e]);
+            }
+        }
+        to_frag(pix, cm + q * 4, m5);
+        to_frag(pix, 2 * cm + q * 4, m9);
+        to_frag(pix, 3 * cm + q * 4, m13);
+    }
+    __syncthreads();
+    // ---- 3. cv2 on the fragments: this workgroup's share of the output chunks
+    T* Y = static_cast<T*>(p.Y) + long(b) * HW * p.ldy;
+    const int cper = (p.chunks2 + p.split - 1) / p.split, c_lo = part * cper, c_hi = (c_lo + cper < p.chunks2) ? c_lo + cper : p.chunks2;
+    const int nc = c_hi - c_lo;
+    for (int item = wave; item < nt * nc; item += GH_WAVES) {
+        const int t = item / nc, c = c_lo + (item - t * nc);
+        const int pix = t * 16 + px;
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+        const uint4* xt = xs + (t * p.k1b) * 64 + lane;
+        band_gemm_item<T, SPPF_K2MAX>(p.W2 + long(c) * p.k1b * 2 * 64, p.k1b, lane, [&](int s) { return xt[s * 64]; }, a0, a1);
+        const int nb = c * 32 + g * 8;
+        if (pix >= HW || nb >= p.C) continue;
+        float o[8];
+        ACH_UNROLL
+        for (int r = 0; r < 4; ++r) { o[r] = a0[r] + p.b2[nb + r]; o[4 + r] = a1[r] + p.b2[nb + 4 + r]; }
+        apply_act_n<T, 8>(o, ACT_SILU);
+        Store<T>::st8(Y + long(pix) * p.ldy + nb, o);
+    }
+}
+inline bool spp_fused_supported(int H, int W, int C, int cmid) {
+    return H * W <= SPPF_MAXPIX && cmid <= SPPF_MAXMID && cmid % 8 == 0 && C % 8 == 0 && (C + 31) / 32 <= 6 && (4 * cmid + 31) / 32 <= SPPF_K2MAX;
+}
+
 // KMAX instantiations: 3 / 6 / 10 k-steps (96 / 192 / 320 input channels)
 #define ACH_BAND_LAUNCH(KERN, k1, grid, block, s, prm)                                                          \
     do {                                                                                                            \

@@ -635,18 +635,19 @@ def test_emulated_fused_sdta_front_is_bit_identical_to_the_separate_launches(nam
 
 
 @pytest.mark.parametrize('sdt', H16)
-@pytest.mark.parametrize('name,res,batch', [('en_s0', 160, 2), ('en_s2', 96, 1), ('mv_s2', 128, 1)])
-def test_emulated_neck_band_kernels_are_bit_identical_to_the_separate_launches(name, res, batch, sdt):
-    """16-bit engines: the neck's GhostModules (primary 1x1 + cheap depthwise 3x3), the bottlenecks' shortcuts (depthwise 3x3 + 1x1 + residual) and
-    the Upsample modules (1x1 + BN + ReLU + bilinear x2) as band kernels (k_ghost.h, option ghost_fuse = 1, default) against the GEMM / depthwise /
-    bilinear launches they replace (ghost_fuse = 0): same MFMA order per output, same rounding points, so the outputs must agree BIT FOR BIT;
-    8 launches fewer.  160 -> 10 x 10 and 20 x 20 maps (four 5-row bands), 96 -> 3 x 3 / 6 x 6 / 12 x 12 (ragged tiles), EN-S2 / MV-S2: 288 -> 144 channels."""
+@pytest.mark.parametrize('name,res,batch,spp', [('en_s0', 160, 2, True), ('en_s2', 96, 1, True), ('mv_s2', 128, 1, True), ('en_s0', 320, 1, False)])
+def test_emulated_neck_band_kernels_are_bit_identical_to_the_separate_launches(name, res, batch, spp, sdt):
+    """16-bit engines: the neck's GhostModules (primary 1x1 + cheap depthwise 3x3), the bottlenecks' shortcuts (depthwise 3x3 + 1x1 + residual), the
+    Upsample modules (1x1 + BN + ReLU + bilinear x2) and SPP / SPPF (cv1 -> pools -> cv2) as band kernels (k_ghost.h, option ghost_fuse = 1, default)
+    against the GEMM / depthwise / bilinear / pool launches they replace (ghost_fuse = 0): same MFMA order per output, same rounding points, so the
+    outputs must agree BIT FOR BIT; 8 launches fewer, 10 where the fused SPP applies (176 channels: EN-S0).  160 -> 5 x 5, 10 x 10 and 20 x 20 maps
+    (four 5-row bands), 96 -> 3 x 3 / 6 x 6 / 12 x 12 (ragged tiles), EN-S2 / MV-S2: 288 -> 144 channels, 320 with SPPF: the production shapes."""
     from achelous_amd.engine import NativeEngine
     kw, sd, (x, xr, xp) = _setup(name, res, batch, 16)
     outs = {}
     for fuse in (1, 0):
         eng = NativeEngine(emu_library(), num_det=kw['num_det'], num_seg=kw['num_seg'], phi=kw['phi'], backbone=kw['backbone'], resolution=res,
-                           pc_channels=kw['pc_channels'], pc_classes=kw['pc_classes'], num_points=16, nano_head=True, spp=True, dtype=sdt[0])
+                           pc_channels=kw['pc_channels'], pc_classes=kw['pc_classes'], num_points=16, nano_head=True, spp=spp, dtype=sdt[0])
         eng.set_option('ghost_fuse', fuse)
         eng.load_state_dict(sd)
         eng.plan(batch)
@@ -656,9 +657,11 @@ def test_emulated_neck_band_kernels_are_bit_identical_to_the_separate_launches(n
         names = [t[0] for t in eng.op_table()]
         if fuse:
             assert sum(n.endswith('.ghost') for n in names) == 4 and sum(n.endswith('.shortcut') for n in names) == 2 and sum(n.endswith('.conv+bilinear') for n in names) == 2
+            fused_spp = sum(n.endswith('.fpn.spp') for n in names)
+            assert fused_spp == (1 if name == 'en_s0' else 0)
             launches = eng.launches()
         else:
-            assert eng.launches() == launches + 8
+            assert eng.launches() == launches + 8 + 2 * fused_spp
     for a, b in zip(outs[1], outs[0]):
         assert torch.equal(a, b)
     assert float(outs[1][3].float().abs().max()) > 0
