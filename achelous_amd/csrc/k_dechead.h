@@ -305,6 +305,9 @@ __global__ __launch_bounds__(64, DH_WAVES) void dechead_rows_kernel(const DecHea
 // depthwise conv packs the two columns of a channel into one v_pk_fma_f32; the two columns' outputs are adjacent in memory and leave as ONE
 // dword store per channel.  ~145 VALU instructions per 28 columns (5.2 per pixel against 8.9).
 constexpr int DH2_VALID = 28;
+#ifndef ACH_DH2_HFIRST
+#define ACH_DH2_HFIRST 1           // round 4: interpolate along x ONCE per source row (when it arrives), along y per output row — 2 packed operations per value and row
+#endif                             // instead of 4, no per-row weight products, half the unpacked-source registers.  0 = round 3's four-corner form
 #ifndef ACH_DH2_WAVES
 #define ACH_DH2_WAVES 2
 #endif
@@ -384,13 +387,21 @@ __global__ __launch_bounds__(64 * ACH_DH_WG_WAVES, ACH_DH2_WAVES) void dechead_r
     const unsigned xo = unsigned(in_x ? xa : 0);
     const unsigned off_h[2] = {unsigned(g * HW) + xo, unsigned((g + 4) * HW) + xo};
     const unsigned off_d[2] = {unsigned((p.init + g) * HW) + xo, unsigned((p.init + g + 4) * HW) + xo};
+    const unsigned off_hb[2] = {off_h[0] * unsigned(sizeof(IO)), off_h[1] * unsigned(sizeof(IO))}, off_db[2] = {off_d[0] * unsigned(sizeof(IO)), off_d[1] * unsigned(sizeof(IO))};
     const int r0 = band * p.band_rows, r1 = (r0 + p.band_rows < H) ? r0 + p.band_rows : H;
     // source rows: [column][left / right source column] raw and unpacked (channel pairs)
+    // (byte offsets from a wave-uniform base: the loads / stores then take the base from SGPRs — `global_load v, v_off, s[base]` — instead of a 64-bit
+    //  VALU add per access: 23 v_lshl_add_u64 per three rows in round 3's ISA)
+    const char* Tqb = reinterpret_cast<const char*>(Tq);
+    const unsigned rowpb = unsigned(rowp) * unsigned(sizeof(T));
+    unsigned o0b[2], o1b[2];
+    ACH_UNROLL
+    for (int c = 0; c < 2; ++c) { o0b[c] = o0[c] * unsigned(sizeof(T)); o1b[c] = o1[c] * unsigned(sizeof(T)); }
     auto load_raw = [&](int r, uint2 (&raw)[2][2]) {
         const int rr = r < 0 ? 0 : (r > p.h - 1 ? p.h - 1 : r);
-        const T* q = Tq + long(rr) * rowp;
+        const char* q = Tqb + wave_uniform(int(unsigned(rr) * rowpb));            // (below 2 GiB: plan-time check)
         ACH_UNROLL
-        for (int c = 0; c < 2; ++c) { raw[c][0] = *reinterpret_cast<const uint2*>(q + o0[c]); raw[c][1] = *reinterpret_cast<const uint2*>(q + o1[c]); }
+        for (int c = 0; c < 2; ++c) { raw[c][0] = *reinterpret_cast<const uint2*>(q + o0b[c]); raw[c][1] = *reinterpret_cast<const uint2*>(q + o1b[c]); }
     };
     auto unpack = [&](const uint2 (&raw)[2][2], f32x2 (&o)[2][2][2]) {       // [column][source column][channel pair]
         ACH_UNROLL
@@ -402,11 +413,27 @@ __global__ __launch_bounds__(64 * ACH_DH_WG_WAVES, ACH_DH2_WAVES) void dechead_r
             }
         }
     };
+    // ACH_DH2_HFIRST: a source row blended along x for this lane's two columns: [column][channel pair]
+    auto hblend = [&](const uint2 (&raw)[2][2], f32x2 (&o)[2][2]) {
+        f32x2 u[2][2][2];
+        unpack(raw, u);
+        ACH_UNROLL
+        for (int c = 0; c < 2; ++c) {
+            ACH_UNROLL
+            for (int q = 0; q < 2; ++q) o[c][q] = wx0[c] * u[c][0][q] + wx1[c] * u[c][1][q];
+        }
+    };
     const int i_first = r0 - 2 < 0 ? 0 : r0 - 2;
     int cy = rows[i_first].y0;
+#if ACH_DH2_HFIRST
+    f32x2 ha[2][2], hb[2][2];
+    uint2 tn[2][2];
+    { uint2 raw[2][2]; load_raw(cy, raw); hblend(raw, ha); load_raw(cy + 1, raw); hblend(raw, hb); load_raw(cy + 2, tn); }
+#else
     f32x2 ta[2][2][2], tb[2][2][2];
     uint2 tn[2][2];
     { uint2 raw[2][2]; load_raw(cy, raw); unpack(raw, ta); load_raw(cy + 1, raw); unpack(raw, tb); load_raw(cy + 2, tn); }
+#endif
     const f32x2 zero2 = {0.f, 0.f};
     // rolling windows: x1 [column][channel pair] and h as COLUMN pairs per accumulator r
     f32x2 w0[2][2], w1[2][2], w2[2][2];
@@ -419,6 +446,24 @@ __global__ __launch_bounds__(64 * ACH_DH_WG_WAVES, ACH_DH2_WAVES) void dechead_r
         {
             const bool row_ok = i >= 0 && i < H;
             const DecHeadRow rg = rows[row_ok ? i : 0];
+#if ACH_DH2_HFIRST
+            if (row_ok && rg.y0 > cy) {
+                ACH_UNROLL
+                for (int c = 0; c < 2; ++c) { ha[c][0] = hb[c][0]; ha[c][1] = hb[c][1]; }
+                hblend(tn, hb);
+                ++cy;
+                load_raw(cy + 2, tn);
+            }
+            const float ly = row_ok ? rg.ly : 0.f, hy = row_ok ? 1.f - rg.ly : 0.f;
+            ACH_UNROLL
+            for (int c = 0; c < 2; ++c) {
+                ACH_UNROLL
+                for (int q = 0; q < 2; ++q) {
+                    const f32x2 v = hy * ha[c][q] + ly * hb[c][q];
+                    xp[c][q] = f32x2{v[0] > 0.f ? v[0] : 0.f, v[1] > 0.f ? v[1] : 0.f};
+                }
+            }
+#else
             if (row_ok && rg.y0 > cy) {
                 ACH_UNROLL
                 for (int c = 0; c < 2; ++c) { ACH_UNROLL for (int k = 0; k < 2; ++k) { ta[c][k][0] = tb[c][k][0]; ta[c][k][1] = tb[c][k][1]; } }
@@ -436,6 +481,7 @@ __global__ __launch_bounds__(64 * ACH_DH_WG_WAVES, ACH_DH2_WAVES) void dechead_r
                     xp[c][q] = f32x2{v[0] > 0.f ? v[0] : 0.f, v[1] > 0.f ? v[1] : 0.f};
                 }
             }
+#endif
         }
         // ---- B: x2 and h of row i-1
         {
@@ -488,10 +534,10 @@ __global__ __launch_bounds__(64 * ACH_DH_WG_WAVES, ACH_DH2_WAVES) void dechead_r
         {
             const int ro = i - 2;
             const bool row_st = ro >= r0 && ro < r1;
-            IO* orow = out_b + long(row_st ? ro : r0) * Wd;
+            char* orow = reinterpret_cast<char*>(out_b) + wave_uniform(int(unsigned(row_st ? ro : r0) * unsigned(Wd) * unsigned(sizeof(IO))));        // uniform base; per-lane 32-bit BYTE offsets
             ACH_UNROLL
             for (int r = 0; r < 2; ++r)
-                if (row_st && st_h[r]) *reinterpret_cast<uint32_t*>(orow + off_h[r]) = H16<IO>::pack(hc[r][0], hc[r][1]);
+                if (row_st && st_h[r]) *reinterpret_cast<uint32_t*>(orow + off_hb[r]) = H16<IO>::pack(hc[r][0], hc[r][1]);
             ACH_UNROLL
             for (int r = 0; r < NR; ++r) {
                 const f32x2 wv0 = {wh[0][r], wh[0][r]}, wv1 = {wh[1][r], wh[1][r]}, wv2 = {wh[2][r], wh[2][r]}, wv3 = {wh[3][r], wh[3][r]}, wv4 = {wh[4][r], wh[4][r]},
@@ -501,7 +547,7 @@ __global__ __launch_bounds__(64 * ACH_DH_WG_WAVES, ACH_DH2_WAVES) void dechead_r
                 const f32x2 sch = f32x2{bdh[r], bdh[r]} + wv1 * hm[r] + wv4 * hc[r] + wv7 * hp[r];
                 const float oa = add_from_left(sch[0] + srh[1], slh[1]);                 // column A: own B's right taps + lane n-1's B left taps
                 const float ob = add_from_right(sch[1] + slh[0], srh[0]);                // column B: own A's left taps + lane n+1's A right taps
-                if (row_st && st_d[r]) *reinterpret_cast<uint32_t*>(orow + off_d[r]) = H16<IO>::pack(relu_raw(oa), relu_raw(ob));
+                if (row_st && st_d[r]) *reinterpret_cast<uint32_t*>(orow + off_db[r]) = H16<IO>::pack(relu_raw(oa), relu_raw(ob));
             }
         }
     };

@@ -273,7 +273,7 @@ struct SppFusedParams {
     const uint4* W2; const float* b2;     // cv2: k1b k-steps (K = 4 c_), chunks2 chunks
     int B, H, W, C, cmid, k1a, chunks1, k1b, chunks2, split;
 };
-constexpr int SPPF_MAXPIX = 112, SPPF_MAXMID = 96, SPPF_K2MAX = 12;
+constexpr int SPPF_MAXPIX = 112, SPPF_MAXMID = 88, SPPF_K2MAX = 11;     // LDS: 19.7 + 59.1 + 78.8 KB = 157.7 of 160 KB (EdgeNeXt-S0: 10 x 10 x 176 -> 88)
 template <class T>
 __global__ __launch_bounds__(GH_THREADS) void spp_fused_kernel(const SppFusedParams p) {
     static_assert(Store<T>::VEC == 8, "16-bit storage");
