@@ -419,6 +419,17 @@ __device__ __forceinline__ uint4 buf_load16s(BufRsrc r, unsigned voff, unsigned 
 }
 #endif
 constexpr unsigned BUF_OOB = 0x80000000u;
+// 4-byte store through a buffer resource: a per-lane offset at or beyond the end of the buffer (BUF_OOB) is DROPPED in hardware — a store under a per-lane
+// condition without an exec mask or a skip branch around it.  Straight-line code is what lets the compiler count the memory operations between a load and its
+// use exactly (s_waitcnt vmcnt(N): loads and stores share the counter on gfx9 and retire in order; behind a conditional store it must assume N = 0, i.e.
+// wait for every store issued so far to be acknowledged).  `soff` is the wave-uniform part of the address (MUBUF soffset, an SGPR).
+#if defined(ACH_HOSTEMU)
+inline void buf_store4(const BufRsrc& r, unsigned voff, unsigned soff, uint32_t v) {
+    if (voff < r.bytes && r.bytes >= 4u && size_t(voff) + soff <= size_t(r.bytes) - 4u) std::memcpy(const_cast<char*>(r.base) + voff + soff, &v, 4);
+}
+#else
+__device__ __forceinline__ void buf_store4(BufRsrc r, unsigned voff, unsigned soff, uint32_t v) { __builtin_amdgcn_raw_buffer_store_b32(v, r, int(voff), int(soff), 0); }
+#endif
 // four consecutive elements of the storage type through a buffer resource (8 bytes of bf16 / 16 bytes of fp32), as floats
 #if defined(ACH_HOSTEMU)
 inline void buf_load_raw(const BufRsrc& r, unsigned off, void* dst, unsigned n) {
@@ -459,6 +470,15 @@ template <> __device__ __forceinline__ void buf_ld4<f16_t>(BufRsrc r, unsigned o
 __device__ inline int wave_uniform(int v) { return v; }
 #else
 __device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+#endif
+
+// A 32-bit per-lane byte offset the optimiser must re-materialise where it is used.  Instruction selection works one basic block at a time:
+// `global_load v, v_off, s[base:base+1]` (SGPR base + zero-extended 32-bit VGPR offset) is only matched when the zero-extension sits in the same
+// block as the access.  Hoisted out of a loop, the offset becomes a 64-bit VGPR pair and every access a v_lshl_add_u64 plus a 64-bit address pair.
+#if defined(ACH_HOSTEMU)
+__device__ inline unsigned local_offset(unsigned& v) { return v; }
+#else
+__device__ __forceinline__ unsigned local_offset(unsigned& v) { asm volatile("" : "+v"(v)); return v; }        // in place: no copy, the variable itself is "redefined" here
 #endif
 
 // value of lane `lane` (a compile-time or wave-uniform index) as a scalar

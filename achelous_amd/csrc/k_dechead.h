@@ -137,8 +137,18 @@ template <> __device__ __forceinline__ void dh_mfma<f16_t>(const uint4& a, const
 // max(v, 0) of a value that comes out of inline assembly: one v_max_f32 (the compiler would first canonicalise a value it cannot see into)
 #if defined(ACH_HOSTEMU) || defined(ACH_DH_NO_ASM)
 __device__ inline float relu_raw(float v) { return v > 0.f ? v : 0.f; }
+// relu of two packed 16-bit floats (fp16 and bf16 alike): read as signed 16-bit integers every negative float is below 0 and every non-negative one keeps its
+// order, so max(x, 0) per half IS relu — and rounding is monotonic, so relu-after-rounding = rounding-after-relu
+__device__ inline uint32_t relu_packed16(uint32_t v) { return ((v & 0x8000u) ? 0u : (v & 0xffffu)) | ((v & 0x80000000u) ? 0u : (v & 0xffff0000u)); }
 #else
 __device__ __forceinline__ float relu_raw(float v) { float r; asm("v_max_f32_e32 %0, 0, %1" : "=v"(r) : "v"(v)); return r; }
+// (a builtin, NOT inline asm: the value goes straight into an MFMA operand, and the wait states a VALU write needs before a matrix instruction reads the register
+//  are only inserted for instructions the compiler can see — as inline asm this produced run-to-run differences whenever other kernels shared the CU)
+typedef short dh_s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t relu_packed16(uint32_t v) {
+    const dh_s16x2 r = __builtin_elementwise_max(__builtin_bit_cast(dh_s16x2, v), dh_s16x2{0, 0});      // v_pk_max_i16
+    return __builtin_bit_cast(uint32_t, r);
+}
 #endif
 
 // DW2: the head's cheap operation has more than four channels (num_seg > 8): accumulator r = 1 takes part in it too.
@@ -311,6 +321,15 @@ constexpr int DH2_VALID = 28;
 #ifndef ACH_DH2_WAVES
 #define ACH_DH2_WAVES 2
 #endif
+#ifndef ACH_DH2_BUFST
+#define ACH_DH2_BUFST 1            // round 4: range-checked buffer stores + a fixed number of memory operations per step (0: exec-masked global stores, loads only when a row arrives)
+#endif
+#ifndef ACH_DH2_PK16
+#define ACH_DH2_PK16 1             // round 4: relu on packed 16-bit pairs, non-existent rows / channels through the bias
+#endif
+#ifndef ACH_DH2_RPRE
+#define ACH_DH2_RPRE 1             // round 4: the row record is requested a step ahead
+#endif
 
 // four values: o[q] = c[q] + (left neighbour lane's l[q]);  and  o[q] = c[q] + (right neighbour lane's r[q]) — one s_nop per group
 #if defined(ACH_HOSTEMU) || defined(ACH_DH_NO_ASM)
@@ -387,7 +406,11 @@ __global__ __launch_bounds__(64 * ACH_DH_WG_WAVES, ACH_DH2_WAVES) void dechead_r
     const unsigned xo = unsigned(in_x ? xa : 0);
     const unsigned off_h[2] = {unsigned(g * HW) + xo, unsigned((g + 4) * HW) + xo};
     const unsigned off_d[2] = {unsigned((p.init + g) * HW) + xo, unsigned((p.init + g + 4) * HW) + xo};
-    const unsigned off_hb[2] = {off_h[0] * unsigned(sizeof(IO)), off_h[1] * unsigned(sizeof(IO))}, off_db[2] = {off_d[0] * unsigned(sizeof(IO)), off_d[1] * unsigned(sizeof(IO))};
+    // stores: per-lane byte offsets inside the sample's output, BUF_OOB where the lane has nothing to store (dropped by the buffer range check: no exec masks, no
+    // skip branches — see buf_store4); a row outside the band stores through a zero-length resource
+    const unsigned off_hb[2] = {st_h[0] ? off_h[0] * unsigned(sizeof(IO)) : BUF_OOB, st_h[1] ? off_h[1] * unsigned(sizeof(IO)) : BUF_OOB};
+    const unsigned off_db[2] = {st_d[0] ? off_d[0] * unsigned(sizeof(IO)) : BUF_OOB, st_d[1] ? off_d[1] * unsigned(sizeof(IO)) : BUF_OOB};
+    const unsigned out_bytes = unsigned(p.oup) * unsigned(HW) * unsigned(sizeof(IO));
     const int r0 = band * p.band_rows, r1 = (r0 + p.band_rows < H) ? r0 + p.band_rows : H;
     // source rows: [column][left / right source column] raw and unpacked (channel pairs)
     // (byte offsets from a wave-uniform base: the loads / stores then take the base from SGPRs — `global_load v, v_off, s[base]` — instead of a 64-bit
@@ -401,7 +424,7 @@ __global__ __launch_bounds__(64 * ACH_DH_WG_WAVES, ACH_DH2_WAVES) void dechead_r
         const int rr = r < 0 ? 0 : (r > p.h - 1 ? p.h - 1 : r);
         const char* q = Tqb + wave_uniform(int(unsigned(rr) * rowpb));            // (below 2 GiB: plan-time check)
         ACH_UNROLL
-        for (int c = 0; c < 2; ++c) { raw[c][0] = *reinterpret_cast<const uint2*>(q + o0b[c]); raw[c][1] = *reinterpret_cast<const uint2*>(q + o1b[c]); }
+        for (int c = 0; c < 2; ++c) { raw[c][0] = *reinterpret_cast<const uint2*>(q + local_offset(o0b[c])); raw[c][1] = *reinterpret_cast<const uint2*>(q + local_offset(o1b[c])); }
     };
     auto unpack = [&](const uint2 (&raw)[2][2], f32x2 (&o)[2][2][2]) {       // [column][source column][channel pair]
         ACH_UNROLL
@@ -426,9 +449,22 @@ __global__ __launch_bounds__(64 * ACH_DH_WG_WAVES, ACH_DH2_WAVES) void dechead_r
     const int i_first = r0 - 2 < 0 ? 0 : r0 - 2;
     int cy = rows[i_first].y0;
 #if ACH_DH2_HFIRST
+    // the two live source rows: `par` (wave-uniform) says which array holds the OLDER one — an arriving row overwrites it and the roles swap, instead of
+    // eight register-pair moves per arrival; both orders evaluate hy * older + ly * newer
     f32x2 ha[2][2], hb[2][2];
     uint2 tn[2][2];
+    int par = 0;
     { uint2 raw[2][2]; load_raw(cy, raw); hblend(raw, ha); load_raw(cy + 1, raw); hblend(raw, hb); load_raw(cy + 2, tn); }
+    // as many (dropped) stores behind the first row's loads as every step issues behind its own: the compiler's count of the memory operations between a step's
+    // loads and their use in the next step is then the same on the loop's entry edge and on its back edge — otherwise the first step of every trip takes the
+    // smaller one, i.e. waits for the previous step's stores to be acknowledged
+#if ACH_DH2_BUFST
+    {
+        const BufRsrc none = make_buf(out_b, 0u);
+        ACH_UNROLL
+        for (int r = 0; r < 2 + NR; ++r) buf_store4(none, BUF_OOB, 0u, 0u);
+    }
+#endif
 #else
     f32x2 ta[2][2][2], tb[2][2][2];
     uint2 tn[2][2];
@@ -441,26 +477,53 @@ __global__ __launch_bounds__(64 * ACH_DH_WG_WAVES, ACH_DH2_WAVES) void dechead_r
     ACH_UNROLL
     for (int c = 0; c < 2; ++c) { ACH_UNROLL for (int q = 0; q < 2; ++q) { w0[c][q] = zero2; w1[c][q] = zero2; w2[c][q] = zero2; } }
 
+    DecHeadRow rnext = rows[(r0 - 2 >= 0 && r0 - 2 < H) ? r0 - 2 : 0];
     auto step = [&](const int i, f32x2 (&xm)[2][2], f32x2 (&xc)[2][2], f32x2 (&xp)[2][2], f32x2 (&hm)[2], f32x2 (&hc)[2], f32x2 (&hp)[2]) {
         // ---- A: x1 row i, both columns
         {
             const bool row_ok = i >= 0 && i < H;
-            const DecHeadRow rg = rows[row_ok ? i : 0];
+            // this row's record was requested at the end of the previous step (a scalar load waited for where it is issued costs the wave a scalar-cache
+            // round trip per row, and two or three waves per SIMD do not hide it; scalar loads return out of order, so the request must not sit between
+            // this use and its wait either)
+#if ACH_DH2_RPRE
+            DecHeadRow rg = rnext;
+#else
+            DecHeadRow rg = rows[row_ok ? i : 0];
+#endif
+            // the record is the same in every lane (i is): as scalars, the row-advance test below is a scalar branch and cy, the source-row base and
+            // the blend weights stay in SGPRs (the loads inside the branch then keep their SGPR-base form instead of 64-bit per-lane addresses)
+            rg.y0 = wave_uniform(rg.y0); rg.ly = __int_as_float(wave_uniform(__float_as_int(rg.ly)));
 #if ACH_DH2_HFIRST
             if (row_ok && rg.y0 > cy) {
-                ACH_UNROLL
-                for (int c = 0; c < 2; ++c) { ha[c][0] = hb[c][0]; ha[c][1] = hb[c][1]; }
-                hblend(tn, hb);
+                if (par == 0) hblend(tn, ha); else hblend(tn, hb);
+                par ^= 1;
                 ++cy;
+#if !ACH_DH2_BUFST
                 load_raw(cy + 2, tn);
+#endif
             }
+#if ACH_DH2_BUFST
+            load_raw(cy + 2, tn);          // every step (a repeat of the row already held when nothing arrived): a fixed number of memory operations per step
+#endif
+
             const float ly = row_ok ? rg.ly : 0.f, hy = row_ok ? 1.f - rg.ly : 0.f;
-            ACH_UNROLL
-            for (int c = 0; c < 2; ++c) {
+            if (par == 0) {
                 ACH_UNROLL
-                for (int q = 0; q < 2; ++q) {
-                    const f32x2 v = hy * ha[c][q] + ly * hb[c][q];
-                    xp[c][q] = f32x2{v[0] > 0.f ? v[0] : 0.f, v[1] > 0.f ? v[1] : 0.f};
+                for (int c = 0; c < 2; ++c) {
+                    ACH_UNROLL
+                    for (int q = 0; q < 2; ++q) {
+                        const f32x2 v = hy * ha[c][q] + ly * hb[c][q];
+                        xp[c][q] = f32x2{relu_raw(v[0]), relu_raw(v[1])};
+                    }
+                }
+            } else {
+                ACH_UNROLL
+                for (int c = 0; c < 2; ++c) {
+                    ACH_UNROLL
+                    for (int q = 0; q < 2; ++q) {
+                        const f32x2 v = hy * hb[c][q] + ly * ha[c][q];
+                        xp[c][q] = f32x2{relu_raw(v[0]), relu_raw(v[1])};
+                    }
                 }
             }
 #else
@@ -486,6 +549,9 @@ __global__ __launch_bounds__(64 * ACH_DH_WG_WAVES, ACH_DH2_WAVES) void dechead_r
         // ---- B: x2 and h of row i-1
         {
             const int rb = i - 1;
+#if ACH_DH2_RPRE
+            { const int in = i + 1; rnext = rows[(in >= 0 && in < H) ? in : 0]; }           // next step's record: a whole section B + C ahead of its wait
+#endif
             f32x2 sl[2][2], sr[2][2], sc[2][2];
             ACH_UNROLL
             for (int c = 0; c < 2; ++c) {
@@ -506,11 +572,19 @@ __global__ __launch_bounds__(64 * ACH_DH_WG_WAVES, ACH_DH2_WAVES) void dechead_r
             }
             add4_from_left(ca, la, oa);
             add4_from_right(cb, rb4, ob);
-            float x2a[4], x2b[4];
-            ACH_UNROLL
-            for (int e = 0; e < 4; ++e) { x2a[e] = relu_raw(oa[e]); x2b[e] = relu_raw(ob[e]); }
             const bool row_in = rb >= 0 && rb < H;
+            // x2 = relu(.) only feeds the MFMA (and the debug tap): the relu is applied to the PACKED pairs, four v_pk_max_i16 instead of eight v_max_f32
+#if ACH_DH2_PK16
+            const uint32_t pa0 = relu_packed16(H16<T>::pack(oa[0], oa[1])), pa1 = relu_packed16(H16<T>::pack(oa[2], oa[3]));
+            const uint32_t pb0 = relu_packed16(H16<T>::pack(ob[0], ob[1])), pb1 = relu_packed16(H16<T>::pack(ob[2], ob[3]));
+#else
+            const uint32_t pa0 = H16<T>::pack(relu_raw(oa[0]), relu_raw(oa[1])), pa1 = H16<T>::pack(relu_raw(oa[2]), relu_raw(oa[3]));
+            const uint32_t pb0 = H16<T>::pack(relu_raw(ob[0]), relu_raw(ob[1])), pb1 = H16<T>::pack(relu_raw(ob[2]), relu_raw(ob[3]));
+#endif
             if (TAP && row_in && writer && rb >= r0 && rb < r1) {
+                float x2a[4], x2b[4];
+                ACH_UNROLL
+                for (int e = 0; e < 4; ++e) { x2a[e] = relu_raw(oa[e]); x2b[e] = relu_raw(ob[e]); }
                 T* fo = static_cast<T*>(p.F) + ((b * H + rb) * long(Wd) + xa) * p.ldf + 4 * g;
                 const float a1[4] = {xc[0][0][0], xc[0][0][1], xc[0][1][0], xc[0][1][1]}, b1[4] = {xc[1][0][0], xc[1][0][1], xc[1][1][0], xc[1][1][1]};
                 Store<T>::st4(fo, a1); Store<T>::st4(fo + 16, x2a);
@@ -518,26 +592,39 @@ __global__ __launch_bounds__(64 * ACH_DH_WG_WAVES, ACH_DH2_WAVES) void dechead_r
             }
             f32x4 acca = {0.f, 0.f, 0.f, 0.f}, accb = {0.f, 0.f, 0.f, 0.f};
             {
-                const uint4 fa = make_uint4(H16<T>::pack(xc[0][0][0], xc[0][0][1]), H16<T>::pack(xc[0][1][0], xc[0][1][1]), H16<T>::pack(x2a[0], x2a[1]), H16<T>::pack(x2a[2], x2a[3]));
-                const uint4 fb = make_uint4(H16<T>::pack(xc[1][0][0], xc[1][0][1]), H16<T>::pack(xc[1][1][0], xc[1][1][1]), H16<T>::pack(x2b[0], x2b[1]), H16<T>::pack(x2b[2], x2b[3]));
+                const uint4 fa = make_uint4(H16<T>::pack(xc[0][0][0], xc[0][0][1]), H16<T>::pack(xc[0][1][0], xc[0][1][1]), pa0, pa1);
+                const uint4 fb = make_uint4(H16<T>::pack(xc[1][0][0], xc[1][0][1]), H16<T>::pack(xc[1][1][0], xc[1][1][1]), pb0, pb1);
                 dh_mfma<T>(afrag, fa, acca);
                 dh_mfma<T>(afrag, fb, accb);
             }
             ACH_UNROLL
             for (int r = 0; r < 2; ++r) {
+                // rows / channels that do not exist: a bias no accumulator survives, instead of a compare + select per value
+#if ACH_DH2_PK16
+                const float bsel = (row_in && has_h[r]) ? bhv[r] : -3.0e38f;
+                hp[r] = f32x2{relu_raw(acca[r] + bsel), relu_raw(accb[r] + bsel)};
+#else
                 const float va = acca[r] + bhv[r], vb = accb[r] + bhv[r];
                 const bool ok = row_in && has_h[r];
                 hp[r] = f32x2{(ok && va > 0.f) ? va : 0.f, (ok && vb > 0.f) ? vb : 0.f};
+#endif
             }
         }
         // ---- C: output row i-2: the two columns of a channel leave as one dword
         {
             const int ro = i - 2;
             const bool row_st = ro >= r0 && ro < r1;
-            char* orow = reinterpret_cast<char*>(out_b) + wave_uniform(int(unsigned(row_st ? ro : r0) * unsigned(Wd) * unsigned(sizeof(IO))));        // uniform base; per-lane 32-bit BYTE offsets
+#if ACH_DH2_BUFST
+            const BufRsrc orow = make_buf(out_b, row_st ? out_bytes : 0u);
+            const unsigned orow_off = unsigned(wave_uniform(int(unsigned(row_st ? ro : r0) * unsigned(Wd) * unsigned(sizeof(IO)))));
+            ACH_UNROLL
+            for (int r = 0; r < 2; ++r) buf_store4(orow, off_hb[r], orow_off, H16<IO>::pack(hc[r][0], hc[r][1]));
+#else
+            char* orow = reinterpret_cast<char*>(out_b) + wave_uniform(int(unsigned(row_st ? ro : r0) * unsigned(Wd) * unsigned(sizeof(IO))));
             ACH_UNROLL
             for (int r = 0; r < 2; ++r)
                 if (row_st && st_h[r]) *reinterpret_cast<uint32_t*>(orow + off_hb[r]) = H16<IO>::pack(hc[r][0], hc[r][1]);
+#endif
             ACH_UNROLL
             for (int r = 0; r < NR; ++r) {
                 const f32x2 wv0 = {wh[0][r], wh[0][r]}, wv1 = {wh[1][r], wh[1][r]}, wv2 = {wh[2][r], wh[2][r]}, wv3 = {wh[3][r], wh[3][r]}, wv4 = {wh[4][r], wh[4][r]},
@@ -547,7 +634,11 @@ __global__ __launch_bounds__(64 * ACH_DH_WG_WAVES, ACH_DH2_WAVES) void dechead_r
                 const f32x2 sch = f32x2{bdh[r], bdh[r]} + wv1 * hm[r] + wv4 * hc[r] + wv7 * hp[r];
                 const float oa = add_from_left(sch[0] + srh[1], slh[1]);                 // column A: own B's right taps + lane n-1's B left taps
                 const float ob = add_from_right(sch[1] + slh[0], srh[0]);                // column B: own A's left taps + lane n+1's A right taps
-                if (row_st && st_d[r]) *reinterpret_cast<uint32_t*>(orow + off_db[r]) = H16<IO>::pack(relu_raw(oa), relu_raw(ob));
+#if ACH_DH2_BUFST
+                buf_store4(orow, off_db[r], orow_off, relu_packed16(H16<IO>::pack(oa, ob)));
+#else
+                if (row_st && st_d[r]) *reinterpret_cast<uint32_t*>(orow + off_db[r]) = relu_packed16(H16<IO>::pack(oa, ob));
+#endif
             }
         }
     };
