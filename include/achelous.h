@@ -113,7 +113,7 @@ int ach_load_weights(ach_handle* h, const ach_tensor_desc* tensors, size_t n);
  * launch aims for when its rows alone cannot fill the chip; 0 = 1024),
  * round 4: "io_bf16" (ACH_DTYPE_F16 only: the caller's input / output tensors are bf16, converted in the first / last kernels);
  * round 3 (16-bit engines): "head_rows" (2: last decoder level + segmentation head as the row-walking two-columns-per-lane kernel, 1: one
- * column, 0: the LDS tile kernel), "head_band" (rows per workgroup band of that kernel, default 80), "mlp_band" (1: EdgeNeXt blocks of
+ * column, 0: the LDS tile kernel), "head_band" (rows per workgroup band of that kernel, default 40), "mlp_band" (1: EdgeNeXt blocks of
  * the instantiated shapes — d = 96 / 144 on maps up to 20 wide, d = 176 up to 10 wide — as the band kernel, 2: also stages 0 / 1, 0: never), "head_fuse" (a detection-head layer's depthwise + pointwise convs of both
  * towers and all levels as one launch), "radar_compact" (first RCBlock: per-pixel activity, active pixels compacted into dense tiles;
  * bit-identical), "level_chain" (a decoder level's kernel also applies the next level's low-resolution conv pair; bit-identical),
