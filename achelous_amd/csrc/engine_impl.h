@@ -1726,6 +1726,16 @@ public:
         gemm(name, x.p, x.ld, x.rows, pack(l), y.p, y.ld, o);
         return y;
     }
+    // two consecutive shared-MLP layers as one launch (chain2: the hidden layer never leaves the registers; same rounding points as the two GEMMs);
+    // the points are presented as a one-frame map so that the one-tile-per-wave mode is chosen (32 768 rows)
+    Rows pc_pair(const std::string& n1, const std::string& n2, const Rows& x, const Lin& l1, int act1, const Lin& l2, int act2) {
+        if (pc_chain && act2 == ACT_NONE && x.rows % 16 == 0) {
+            A xa; xa.p = x.p; xa.B = 1; xa.H = int(x.rows / 16); xa.W = 16; xa.C = x.C; xa.ld = x.ld;
+            A ya;
+            if (chain2(n1 + "+" + n2.substr(n2.rfind('.') + 1), xa, l1, act1, l2, ya)) { Rows y; y.p = ya.p; y.rows = x.rows; y.C = ya.C; y.ld = ya.ld; return y; }
+        }
+        return pc_layer(n2, pc_layer(n1, x, l1, act1), l2, act2);
+    }
     // shared MLP + max over the N points of every sample -> [B, C]   (gemm_colmax_kernel: no atomics, nothing materialised)
     Rows pc_layer_max(const std::string& name, const Rows& x, const Lin& l, int act, int B) {
         Packed pk = pack(l);
@@ -1787,8 +1797,7 @@ public:
         { PcConcatParams q{g.p, g.ld, pf.p, pf.ld, cat.p, cat.ld, B, N, g.C, kf}; if ((g.C | kf) & 3) throw AchError{ACH_ERR_UNSUPPORTED, "PointNet feature widths must be multiples of 4"}; ew(p + ".concat", pc_concat_kernel<T>, q, long(B) * N * ((g.C + kf) / 4)); }
         Rows y = pc_layer(p + ".conv1", cat, lin_bn1d(p + ".conv1", p + ".bn1"), ACT_RELU);
         y = pc_layer(p + ".conv2", y, lin_bn1d(p + ".conv2", p + ".bn2"), ACT_RELU);
-        y = pc_layer(p + ".conv3", y, lin_bn1d(p + ".conv3", p + ".bn3"), ACT_RELU);
-        y = pc_layer(p + ".conv4", y, lin_bn1d(p + ".conv4", ""), ACT_NONE);
+        y = pc_pair(p + ".conv3", p + ".conv4", y, lin_bn1d(p + ".conv3", p + ".bn3"), ACT_RELU, lin_bn1d(p + ".conv4", ""), ACT_NONE);
         {
             LsmParams q{y.p, y.ld, nullptr, long(B) * N, cfg.pc_classes};
             const dim3 grid(unsigned(cdivl(long(B) * N, 256))), block(256);
