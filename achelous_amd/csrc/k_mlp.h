@@ -26,6 +26,9 @@
 #include "ach_platform.h"
 #include "k_gemm.h"
 
+#ifndef ACH_MLP_MFMA_PAD
+#define ACH_MLP_MFMA_PAD 0
+#endif
 namespace ach {
 
 // Hidden channel that k index `kappa` of the second GEMM refers to.  bf16 (VEC 8): identity.  fp32 (VEC 4): the 8 values a
@@ -343,6 +346,9 @@ __global__ __launch_bounds__(256, (MlpOcc<DT, SPLIT, Store<T>::VEC>::blocks)) vo
             }
             }
             float h[8];
+#if ACH_MLP_MFMA_PAD
+            asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");      // experiment: 64 extra wait states between the MFMAs and the first read of their results
+#endif
             ACH_UNROLL
             for (int r = 0; r < 4; ++r) { h[r] = a0[r] + bA[r]; h[4 + r] = a1[r] + bB[r]; }
             apply_act_n<T, 8, ((ACH_MLP_DEBUG & 4) ? int(ACT_RELU) : ACT)>(h, p.act);
@@ -370,6 +376,9 @@ __global__ __launch_bounds__(256, (MlpOcc<DT, SPLIT, Store<T>::VEC>::blocks)) vo
         for (int i = 0; i < 8; ++i) o[i] = v8[i] + p.b2[nb + i] + r8[i];
         Store<T>::st8(static_cast<T*>(p.Y) + m * p.ldy + nb, o);
     };
+#if ACH_MLP_MFMA_PAD
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+#endif
     if (!SPLIT) {
         ACH_UNROLL
         for (int pair = 0; pair < DT / 2; ++pair) {
