@@ -814,6 +814,32 @@ public:
     void mobilevit(const std::string& pfx, A feats[4]) {                            // mobilevit.py:198-222
         const MvCfg mc = mv_cfg();
         const int B = batch, R = cfg.resolution;
+        A x;
+        bool stem_done = false;
+        if constexpr (H16E) {
+            // conv1 gathered from the NCHW image (k_nhwc.h, mvstem_kernel): no NHWC copy of the image
+            const HostTensor& w = W(pfx + ".conv1.0.weight");
+            if (mv_stem && R % 2 == 0 && w.shape.size() == 4 && w.shape[0] == 16 && w.shape[1] == 3 && w.shape[2] == 3 && w.shape[3] == 3) {
+                Lin l; l.N = 16; l.K = 64; l.w.assign(size_t(16) * 64, 0.f); l.b.assign(16, 0.f);
+                for (int n = 0; n < 16; ++n)
+                    for (int c = 0; c < 3; ++c)
+                        for (int ky = 0; ky < 3; ++ky)
+                            for (int kx = 0; kx < 3; ++kx) l.w[size_t(n) * 64 + (c * 3 + ky) * 4 + kx] = w.data[((size_t(n) * 3 + c) * 3 + ky) * 3 + kx];
+                fold_bn(l, pfx + ".conv1.1", 1e-5);
+                Packed pk = pack(l);
+                if (pk.NT == 1 && pk.nchunks == 1 && pk.ksteps == 2) {
+                    x = alloc(B, R / 2, R / 2, 16);
+                    MvStemParams sp{nullptr, x.p, pk.w, up_f32(l.b), B, R, R};
+                    const dim3 grid(unsigned(cdivl(x.rows(), 64))), block(256);
+                    const void** in = &io.image;
+                    const bool alt = io_alt();
+                    add_op(pfx + ".conv1", [sp, grid, block, in, alt](hipStream_t s) mutable { sp.X = *in; if (alt) ACH_LAUNCH((mvstem_kernel<T, IOB>), grid, block, s, sp); else ACH_LAUNCH((mvstem_kernel<T, T>), grid, block, s, sp); },
+                           (double(B) * 3 * R * R + double(x.rows()) * 16) * sizeof(T), 2.0 * double(x.rows()) * 27 * 16);
+                    stem_done = true;
+                }
+            }
+        }
+        if (!stem_done) {
         A img = alloc(B, R, R, 3);
         {
             ToNhwcParams tp{nullptr, img.p, B, 3, R, R, img.ld};
@@ -823,7 +849,8 @@ public:
             add_op(pfx + ".to_nhwc", [tp, grid, block, in, alt](hipStream_t s) mutable { tp.X = *in; if (alt) ACH_LAUNCH((nchw_to_nhwc_kernel<T, IOB>), grid, block, s, tp); else ACH_LAUNCH((nchw_to_nhwc_kernel<T, T>), grid, block, s, tp); },
                    double(img.rows()) * (3 + 3) * sizeof(T), 0, double(img.rows()) * (3 + img.ld) * sizeof(T));
         }
-        A x = mv_conv(pfx + ".conv1", img, 3, 2);
+        x = mv_conv(pfx + ".conv1", img, 3, 2);
+        }
         x = mv2block(pfx + ".mv2.0", x, 1, mc.ch[1]);
         x = mv2block(pfx + ".mv2.1", x, 2, mc.ch[2]);
         x = mv2block(pfx + ".mv2.2", x, 1, mc.ch[3]);

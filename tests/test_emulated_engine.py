@@ -163,6 +163,34 @@ def test_emulated_kernel_switches_agree(option):
         assert sum('.ln+conv' in n for n, _, _ in eng.op_table()) == 0 and launches_on - 0 == eng.launches() - 3
 
 
+@pytest.mark.parametrize('sdt', H16)
+@pytest.mark.parametrize('name,res,option,first_tap', [('mv_s2', 128, 'mv_stem', 'map2'), ('mv_s2', 192, 'mv_stem', 'map2'), ('en_s0', 64, 'pc_chain', None)])
+def test_emulated_round4_launch_fusions_agree_with_the_launches_they_replace(name, res, option, first_tap, sdt):
+    """16-bit engines: MobileViT's conv1 gathered straight from the NCHW image (k_nhwc.h mvstem_kernel, option mv_stem: the NHWC copy of the image and
+    its launch are gone; 128 and 192 pixel images) and PointNet's conv3 + conv4 as one chain launch (option pc_chain) against the launches
+    they replace: same arithmetic up to the fp32 summation order, one launch fewer each."""
+    kw, sd, (x, xr, xp) = _setup(name, res, 2, 16)
+    outs, taps, launches = [], [], []
+    for v in (1, 0):
+        from achelous_amd.engine import NativeEngine
+        eng = NativeEngine(emu_library(), num_det=kw['num_det'], num_seg=kw['num_seg'], phi=kw['phi'], backbone=kw['backbone'], resolution=res,
+                           pc_channels=kw['pc_channels'], pc_classes=kw['pc_classes'], num_points=16, nano_head=kw['nano_head'], spp=kw['spp'], dtype=sdt[0])
+        eng.set_option('full_taps', 1)
+        eng.set_option(option, v)
+        eng.load_state_dict(sd)
+        eng.plan(2)
+        o = alloc_outputs(kw, 2, 16, sdt[1], 'cpu')
+        eng.forward(x.to(sdt[1]), xr.to(sdt[1]), xp.to(sdt[1]), o)
+        outs.append([t.float() for t in o])
+        taps.append(eng.read_tap(first_tap) if first_tap else None)
+        launches.append(eng.launches())
+    assert launches[0] == launches[1] - 1, launches
+    for a, b in zip(*outs):
+        assert rel_err(a, b) < sdt[2] * 4e-2, (option, rel_err(a, b))        # two 16-bit plans that differ by one-ulp flips at the stem, the whole network deep (bf16 storage: 2.4e-2 at 192 x 192)
+    if first_tap:
+        assert rel_err(taps[0], taps[1]) < sdt[2] * 5e-3, rel_err(taps[0], taps[1])
+
+
 def test_emulated_nms_more_candidates_than_fit_in_lds():
     """416x416 (3549 anchors, the reference's default resolution): when more than 2112 candidates pass the confidence filter the
     sorted boxes live in global scratch instead of LDS — same kept-index sequence as the oracle, bit for bit."""
