@@ -830,7 +830,7 @@ public:
                 if (pk.NT == 1 && pk.nchunks == 1 && pk.ksteps == 2) {
                     x = alloc(B, R / 2, R / 2, 16);
                     MvStemParams sp{nullptr, x.p, pk.w, up_f32(l.b), B, R, R};
-                    const dim3 grid(unsigned(cdivl(x.rows(), 64))), block(256);
+                    const dim3 grid(unsigned(cdivl(x.rows(), 64 * MVSTEM_TPW))), block(256);
                     const void** in = &io.image;
                     const bool alt = io_alt();
                     add_op(pfx + ".conv1", [sp, grid, block, in, alt](hipStream_t s) mutable { sp.X = *in; if (alt) ACH_LAUNCH((mvstem_kernel<T, IOB>), grid, block, s, sp); else ACH_LAUNCH((mvstem_kernel<T, T>), grid, block, s, sp); },

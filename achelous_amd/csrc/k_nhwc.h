@@ -371,6 +371,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const StemMfmaParams p) 
 // for the pair become 39 MB in + 52 MB out.  The reduction index is k = (c*3 + ky)*4 + kx with kx = 3 a zero weight (K = 36 -> two k-steps of 32): a lane's 8
 // consecutive k values are TWO image rows of [x-1, x, x+1, -], each one aligned dword (x, x+1: x = 2 ox is even) + one 2-byte load (x-1).
 struct MvStemParams { const void* X; void* Y; const void* W; const float* bias; int B, H, Wd; };
+constexpr int MVSTEM_TPW = 4;            // 16-pixel tiles per wave: every load of the four tiles is in flight before the first MFMA (one tile per wave: 51.8 us at batch 64)
 template <class T, class IO>
 __global__ __launch_bounds__(256) void mvstem_kernel(const MvStemParams p) {
     static_assert(Store<T>::VEC == 8, "16-bit storage");
@@ -378,40 +379,55 @@ __global__ __launch_bounds__(256) void mvstem_kernel(const MvStemParams p) {
     const int px = lane & 15, g = lane >> 4;
     const int Ho = p.H / 2, Wo = p.Wd / 2;
     const long total = long(p.B) * Ho * Wo;
-    const long mraw = (long(blockIdx.x) * 4 + wave) * 16 + px;
-    const bool valid = mraw < total;
-    const long m = valid ? mraw : 0;
-    const int ox = int(m % Wo);
-    const int oy = int((m / Wo) % Ho);
-    const long b = m / (long(Wo) * Ho);
     const long cstride = long(p.H) * p.Wd;
-    const IO* X = static_cast<const IO*>(p.X) + b * 3 * cstride + 2 * ox;
-    f32x4 acc;
-    acc[0] = acc[1] = acc[2] = acc[3] = 0.f;
     const uint4* Wf = static_cast<const uint4*>(p.W) + lane;
+    const uint4 w0 = Wf[0], w1 = Wf[64];
+    float bias[4];
     ACH_UNROLL
-    for (int s = 0; s < 2; ++s) {
-        unsigned raw[4] = {0u, 0u, 0u, 0u};
+    for (int r = 0; r < 4; ++r) bias[r] = p.bias[g * 4 + r];
+    unsigned raw[MVSTEM_TPW][2][4];
+    long mm[MVSTEM_TPW];
+    bool ok[MVSTEM_TPW];
+    ACH_UNROLL
+    for (int t = 0; t < MVSTEM_TPW; ++t) {
+        const long mraw = ((long(blockIdx.x) * 4 + wave) * MVSTEM_TPW + t) * 16 + px;
+        ok[t] = mraw < total;
+        const long m = ok[t] ? mraw : 0;
+        mm[t] = m;
+        const int ox = int(m % Wo);
+        const int oy = int((m / Wo) % Ho);
+        const long b = m / (long(Wo) * Ho);
+        const IO* X = static_cast<const IO*>(p.X) + b * 3 * cstride + 2 * ox;
         ACH_UNROLL
-        for (int h = 0; h < 2; ++h) {
-            const int r = (s * 4 + g) * 2 + h;                       // image row (c, ky) of this half of the fragment
-            const int c = r / 3, ky = r - 3 * c;
-            const int y = 2 * oy - 1 + ky;                           // <= H - 1 (H even)
-            if (valid && r < 9 && y >= 0) {
-                const IO* row = X + c * cstride + long(y) * p.Wd;
-                const uint32_t mid = *reinterpret_cast<const uint32_t*>(row);                                  // x, x + 1
-                const uint32_t left = ox > 0 ? uint32_t(reinterpret_cast<const uint16_t*>(row)[-1]) : 0u;      // x - 1 (the conv's zero padding at the left edge)
-                raw[2 * h] = h16_recast<IO, T>(left | (mid << 16));
-                raw[2 * h + 1] = h16_recast<IO, T>(mid >> 16);
+        for (int s = 0; s < 2; ++s) {
+            ACH_UNROLL
+            for (int h = 0; h < 2; ++h) {
+                raw[t][s][2 * h] = 0u; raw[t][s][2 * h + 1] = 0u;
+                const int r = (s * 4 + g) * 2 + h;                       // image row (c, ky) of this half of the fragment
+                const int c = r / 3, ky = r - 3 * c;
+                const int y = 2 * oy - 1 + ky;                           // <= H - 1 (H even)
+                if (ok[t] && r < 9 && y >= 0) {
+                    const IO* row = X + c * cstride + long(y) * p.Wd;
+                    const uint32_t mid = *reinterpret_cast<const uint32_t*>(row);                                  // x, x + 1
+                    const uint32_t left = ox > 0 ? uint32_t(reinterpret_cast<const uint16_t*>(row)[-1]) : 0u;      // x - 1 (the conv's zero padding at the left edge)
+                    raw[t][s][2 * h] = h16_recast<IO, T>(left | (mid << 16));
+                    raw[t][s][2 * h + 1] = h16_recast<IO, T>(mid >> 16);
+                }
             }
         }
-        mfma16<T>(Wf[s * 64], make_uint4(raw[0], raw[1], raw[2], raw[3]), acc);
     }
-    if (!valid) return;
-    float o[4];                                                      // NT = 1: channels 4g .. 4g+3 of pixel px
     ACH_UNROLL
-    for (int r = 0; r < 4; ++r) o[r] = apply_act(acc[r] + p.bias[g * 4 + r], ACT_SILU);
-    Store<T>::st4(static_cast<T*>(p.Y) + m * 16 + g * 4, o);
+    for (int t = 0; t < MVSTEM_TPW; ++t) {
+        f32x4 acc;
+        acc[0] = acc[1] = acc[2] = acc[3] = 0.f;
+        mfma16<T>(w0, make_uint4(raw[t][0][0], raw[t][0][1], raw[t][0][2], raw[t][0][3]), acc);
+        mfma16<T>(w1, make_uint4(raw[t][1][0], raw[t][1][1], raw[t][1][2], raw[t][1][3]), acc);
+        if (!ok[t]) continue;
+        float o[4];                                                      // NT = 1: channels 4g .. 4g+3 of pixel px
+        ACH_UNROLL
+        for (int r = 0; r < 4; ++r) o[r] = apply_act(acc[r] + bias[r], ACT_SILU);
+        Store<T>::st4(static_cast<T*>(p.Y) + mm[t] * 16 + g * 4, o);
+    }
 }
 
 // ------------------------------------------------------------------------------------------ LayerNorm over C
