@@ -77,6 +77,7 @@ public:
     bool io_bf16 = false;             // option "io_bf16" (fp16-storage engine only): the caller's input / output tensors are bf16; converted in the first / last kernels
     bool ghost_fuse = true;           // option "ghost_fuse": 16-bit engines — the neck's GhostModules (primary 1x1 + cheap depthwise 3x3) and the bottlenecks' shortcuts (depthwise 3x3 + 1x1 + residual) as band kernels (k_ghost.h): 3 launches per bottleneck instead of 6
     bool mv_stem = true;              // option "mv_stem": 16-bit engines — MobileViT's conv1 gathered from the NCHW image (no NHWC copy of the image; k_nhwc.h mvstem_kernel)
+    bool radar_direct = true;         // option "radar_direct": 16-bit engines — the first RCBlock reads the caller's NCHW radar map itself (pool + residual): no NHWC copy, one launch fewer
     bool pc_chain = true;             // option "pc_chain": PointNet's conv3 + conv4 (256 -> 128 -> classes) as one two-layer chain launch (k_mlp.h)
     int ghost_rb = 5;                 // option "ghost_rb": rows per band of the neck's band kernels (upper bound; the LDS tiles may force fewer)
     bool pn2_fps_all = true;          // option "pn2_fps_all": PointNet++ — the four levels' farthest-point sampling as one launch (k_pn2.h pn2_fps_all_kernel; identical selections)

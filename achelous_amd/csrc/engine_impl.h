@@ -1461,8 +1461,14 @@ public:
         // as 4-channel pixels — 8 B in bf16, 16 B in fp32 — instead of the 8-channel padding of the generic NHWC layout: they were 2.7x
         // their real bytes in HBM traffic.  Only the fused front + row-walking conv read that layout; the layer-wise fallback keeps 8.
         const bool narrow0 = fuse_rc && row_conv && chans[0] <= 4 && (R * R) % 4 == 0;
-        A x = narrow0 ? alloc_ld(B, R, R, 3, 4) : alloc(B, R, R, 3);
-        {
+        // round 4 (16-bit engines): no NHWC copy of the map at all — the first pool and the first front kernel's residual read the caller's NCHW planes
+        // (option "radar_direct"; needs the strip pool and rows of whole 16-pixel segments)
+        bool direct0 = false;
+        if constexpr (H16E) direct0 = radar_direct && narrow0 && pool_strip > 0 && R % 16 == 0;
+        A x;
+        if (direct0) { x.B = B; x.H = R; x.W = R; x.C = 3; x.ld = 4; x.p = nullptr; }     // shape only
+        else x = narrow0 ? alloc_ld(B, R, R, 3, 4) : alloc(B, R, R, 3);
+        if (!direct0) {
             ToNhwcParams tp{nullptr, x.p, B, 3, R, R, x.ld};
             const void** rin = &io.radar;
             mark_xwait_next();           // pipelined forwards: this branch rewrites the radar pyramid the previous forward's fusion reads
@@ -1496,6 +1502,17 @@ public:
                 for (float v : ob.data) { finite = finite && std::isfinite(v); mx = std::max(mx, std::fabs(v)); }
                 if (finite && mx <= 13.f) { occ_r = 2 + int(std::ceil(mx)); occ = static_cast<unsigned short*>(aalloc(size_t(B) * x.H * (x.W / 16) * sizeof(unsigned short))); }
             }
+            if (i == 0 && direct0) {
+                if constexpr (H16E) {
+                PoolNchwParams pp{nullptr, pooled.p0, pooled.ld, B, x.H, x.W, pooled.row, pooled.img, occ};
+                const dim3 grid(unsigned(cdivl(long(B) * x.H * (x.W / 4), 256))), block(256);
+                const void** rin = &io.radar;
+                const bool alt = io_alt();
+                mark_xwait_next();           // pipelined forwards: this branch rewrites the radar pyramid the previous forward's fusion reads
+                add_op(pfx + ".avgpool", [pp, grid, block, rin, alt](hipStream_t s) mutable { pp.X = *rin; if (alt) ACH_LAUNCH((avgpool3x3_nchw3_kernel<T, IOB>), grid, block, s, pp); else ACH_LAUNCH((avgpool3x3_nchw3_kernel<T, T>), grid, block, s, pp); },
+                       2.0 * x.rows() * C * sizeof(T), 0, double(x.rows()) * (3 + pooled.ld) * sizeof(T));
+                }
+            } else
             { PoolParams pp{x.p, x.ld, pooled.p0, pooled.ld, B, x.H, x.W, C, pooled.row, pooled.img, occ};
               const double bytes = 2.0 * x.rows() * C * sizeof(T), lbytes = double(x.rows()) * (x.ld + pooled.ld) * sizeof(T);
               // strips of 4 output pixels per thread where a strip is contiguous enough for the loads to coalesce: >= 16 channels, or
@@ -1548,11 +1565,14 @@ public:
                 const long yld = y_bordered ? yb.ld : y.ld;
                 RcFrontParams rp{pooled.p0, pooled.ld, pooled.row, pooled.img, pkom.w, up_f32(b32), pkf.w, up_f32(b16), x.p, x.ld,
                                  y_bordered ? yb.p0 : y.p, yld, y_bordered ? yb.row : long(x.W) * y.ld, y_bordered ? yb.img : long(x.H) * x.W * y.ld,
-                                 B, x.H, x.W, cvp, C, occ, occ_r, radar_compact ? 1 : 0, (((occ && radar_rows4 == 1) || radar_rows4 == 2) && x.H % 4 == 0) ? 1 : 0};
+                                 B, x.H, x.W, cvp, C, occ, occ_r, radar_compact ? 1 : 0, (((occ && radar_rows4 == 1) || radar_rows4 == 2) && x.H % 4 == 0) ? 1 : 0, nullptr, 0};
+                const bool rdirect = i == 0 && direct0;
+                const void** rres = &io.radar;
+                const int rbf = io_alt() ? 1 : 0;
                 // algorithmic bytes: pooled map + residual read once, output written once, REAL channels; the layout figure
                 // counts the pixel pitches the kernel actually moves
                 const double bytes = double(x.rows()) * 3.0 * C * sizeof(T), lbytes = double(x.rows()) * (pooled.ld + x.ld + yld) * sizeof(T);
-                add_op(pfx + ".front", [rp, ksp](hipStream_t s) { launch_rc_front<T>(rp, ksp, s); }, bytes,
+                add_op(pfx + ".front", [rp, ksp, rdirect, rres, rbf](hipStream_t s) mutable { if (rdirect) { rp.Rn = *rres; rp.rn_bf16 = rbf; } launch_rc_front<T>(rp, ksp, s); }, bytes,
                        2.0 * double(x.rows()) * 9.0 * C * (27 + C), lbytes);
             } else {
             DeformParams dp;

@@ -158,6 +158,7 @@ struct RcFrontParams {
     const unsigned short* occ; int occ_r;     // optional occupancy of P per 16-pixel row segment [B][H][Wd/16], one bit per column (avgpool3x3), and the reach of a pixel, see below
     int compact;                              // 1 (with occ, rows4, <= 4 output channels): the row's ACTIVE PIXELS are compacted into dense 16-pixel tiles (round 3)
     int rows4;                                // 1: a workgroup owns FOUR consecutive rows, one per wave (H % 4 == 0): the weight staging and the tables are paid once per four rows
+    const void* Rn; int rn_bf16;              // round 4 (NARROW): the residual read straight from the caller's NCHW map [B, 3, H, Wd] (16-bit; rn_bf16: bf16 values behind fp16 storage) instead of R
 };
 
 // Empty segments (first RCBlock only: its input is the raw radar map, > 99 % zeros — radar_feature_map_generate.ipynb).  If P is
@@ -292,10 +293,28 @@ __global__ __launch_bounds__(256, KS == 3 ? 4 : ACH_RCF_WIDE_WAVES) void rc_fron
         }
     }
     const int ch = g * 4;
+    // the block input of pixel x of this row (residual): from the NHWC copy, or (NARROW, round 4) from the three NCHW planes of the caller's map, each value passed
+    // through the storage type exactly as the copy kernel did
+    auto residual4 = [&](int x, int c0, float (&rr)[4]) {
+        if constexpr (NARROW && sizeof(T) == 2) {
+            if (p.Rn) {
+                const uint16_t* q = static_cast<const uint16_t*>(p.Rn) + (long(b) * 3 * p.H + oy) * p.Wd + x;
+                const long cs = long(p.H) * p.Wd;
+                ACH_UNROLL
+                for (int i = 0; i < 3; ++i) {
+                    const uint32_t bits = q[i * cs];
+                    rr[i] = H16<T>::lo(p.rn_bf16 ? h16_recast<bf16_t, T>(bits) : bits);
+                }
+                rr[3] = 0.f;
+                return;
+            }
+        }
+        Store<T>::ld4(static_cast<const T*>(p.R) + (rowpix + x) * p.ldr + c0, rr);
+    };
     auto finish = [&](int x, bool valid, const f32x4& acc) {        // bias, ReLU, residual, one store
         if (valid && ch < int(p.ldy)) {
             float rr[4], ov[4];
-            Store<T>::ld4(static_cast<const T*>(p.R) + (rowpix + x) * p.ldr + ch, rr);
+            residual4(x, ch, rr);
             ACH_UNROLL
             for (int i = 0; i < 4; ++i) { const float r = acc[i] + bo[i]; ov[i] = (r > 0.f ? r : 0.f) + rr[i]; }
             Store<T>::st4(static_cast<T*>(p.Y) + long(b) * p.ypi + long(oy) * p.ypr + long(x) * p.ldy + ch, ov);
@@ -310,7 +329,7 @@ __global__ __launch_bounds__(256, KS == 3 ? 4 : ACH_RCF_WIDE_WAVES) void rc_fron
         for (int xx = lane; xx < p.Wd; xx += 64) {
             if ((amask[wave][xx >> 4] >> (xx & 15)) & 1) continue;
             float rr[4], ov[4];
-            Store<T>::ld4(static_cast<const T*>(p.R) + (rowpix + xx) * p.ldr, rr);
+            residual4(xx, 0, rr);
             ACH_UNROLL
             for (int i = 0; i < 4; ++i) { const float r = 0.f + b0[i]; ov[i] = (r > 0.f ? r : 0.f) + rr[i]; }
             Store<T>::st4(static_cast<T*>(p.Y) + long(b) * p.ypi + long(oy) * p.ypr + long(xx) * p.ldy, ov);

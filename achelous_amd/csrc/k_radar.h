@@ -115,6 +115,61 @@ __global__ __launch_bounds__(256) void avgpool3x3_kernel(const PoolParams p) {
     }
 }
 
+// The first RCBlock's pool straight from the caller's NCHW radar map (round 4): the NHWC copy of the map (52 MB written and read twice at batch 64) and its launch
+// are gone.  One thread = a strip of 4 output pixels x the 3 channels; per (plane, row) one aligned 8-byte load (x0 .. x0+3: x0 % 4 == 0, Wd % 16 == 0) and the two
+// neighbours as 2-byte loads.  Same sums in the same order as avgpool3x3_kernel<T, 4> on the 4-channel copy (values pass through the storage type first, as the copy did):
+// bit-identical pooled map and occupancy masks.
+struct PoolNchwParams { const void* X; void* Y; long ldy; int B, H, Wd; long ypr, ypi; unsigned short* occ; };
+template <class T, class IO>
+__global__ __launch_bounds__(256) void avgpool3x3_nchw3_kernel(const PoolNchwParams p) {
+    static_assert(sizeof(T) == 2 && sizeof(IO) == 2, "16-bit storage");
+    const int strips = p.Wd / 4;
+    const long total = long(p.B) * p.H * strips;
+    const long idx_raw = long(xcd_block(blockIdx.x, gridDim.x)) * blockDim.x + threadIdx.x;
+    const bool live = idx_raw < total;
+    if (!live && !p.occ) return;
+    long r = live ? idx_raw : total - 1;
+    const int x0 = int(r % strips) * 4; r /= strips;
+    const int y = int(r % p.H);
+    const long b = r / p.H;
+    const long cstride = long(p.H) * p.Wd;
+    const uint16_t* X = static_cast<const uint16_t*>(p.X) + b * 3 * cstride + x0;
+    auto val = [](uint32_t bits) { return H16<T>::lo(h16_recast<IO, T>(bits & 0xffffu)); };
+    float col[6][3];
+    ACH_UNROLL
+    for (int j = 0; j < 6; ++j) { col[j][0] = 0.f; col[j][1] = 0.f; col[j][2] = 0.f; }
+    ACH_UNROLL
+    for (int dy = -1; dy <= 1; ++dy) {
+        const int iy = y + dy;
+        const bool rowin = iy >= 0 && iy < p.H;
+        ACH_UNROLL
+        for (int c = 0; c < 3; ++c) {
+            const uint16_t* row = X + c * cstride + long(rowin ? iy : y) * p.Wd;
+            const uint2 mid = *reinterpret_cast<const uint2*>(row);
+            const uint32_t lft = x0 > 0 ? uint32_t(row[-1]) : 0u, rgt = x0 + 4 < p.Wd ? uint32_t(row[4]) : 0u;
+            const float v[6] = {val(lft), val(mid.x), val(mid.x >> 16), val(mid.y), val(mid.y >> 16), val(rgt)};
+            ACH_UNROLL
+            for (int j = 0; j < 6; ++j) col[j][c] += rowin ? v[j] : 0.f;
+        }
+    }
+    T* yrow = static_cast<T*>(p.Y) + b * p.ypi + y * p.ypr;
+    int nz = 0;
+    ACH_UNROLL
+    for (int o = 0; o < 4; ++o) {
+        float acc[4];
+        ACH_UNROLL
+        for (int i = 0; i < 3; ++i) { acc[i] = ((col[o][i] + col[o + 1][i]) + col[o + 2][i]) * (1.0f / 9.0f); nz |= !(acc[i] == 0.f) ? 1 << o : 0; }
+        acc[3] = 0.f;
+        if (live) Store<T>::st4(yrow + long(x0 + o) * p.ldy, acc);
+    }
+    if (p.occ) {
+        int m = live ? nz : 0;
+        m |= __shfl_xor(m, 1) << 4;
+        m |= __shfl_xor(m, 2) << 8;
+        if (live && (threadIdx.x & 3) == 0) p.occ[(b * p.H + y) * long(p.Wd >> 4) + (x0 >> 4)] = static_cast<unsigned short>(m & 0xffff);
+    }
+}
+
 // ---- shared by both deformable kernels: one tap's bilinear footprint (torchvision 0.12.0 deform_conv2d semantics:
 // a sample at or beyond -1 / H (W) is 0, corners outside the map contribute 0).  The sampled tensor carries a one-pixel zero
 // border, so clamping the coordinate to [-1, H] and the top-left corner to [-1, H-1] reproduces exactly that with no

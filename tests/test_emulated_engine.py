@@ -442,6 +442,38 @@ def test_emulated_radar_skip_is_bit_identical(dtype, cells):
             assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize('sdt', H16)
+@pytest.mark.parametrize('cells,io_bf16', [(2, 0), (40, 0), (-1, 0), (40, 1)])
+def test_emulated_radar_direct_is_bit_identical(sdt, cells, io_bf16):
+    """16-bit engines, round 4: the first RCBlock pools and adds its residual straight from the caller's NCHW radar map (k_radar.h avgpool3x3_nchw3_kernel,
+    rc_front's residual4; option radar_direct) instead of from an NHWC copy: one launch fewer, the same sums in the same order — BIT-identical outputs and
+    radar taps on sparse, fixture-density and dense maps, also with bf16 tensors in front of fp16 storage (io_bf16)."""
+    from achelous_amd.engine import NativeEngine
+    if io_bf16 and sdt[0] != DTYPE_F16:
+        pytest.skip('io_bf16 is an option of the fp16-storage engine')
+    kw, sd, _ = _setup('en_s0', 96, 2, 16)
+    x, xr, xp = make_inputs(2, 11, resolution=96, num_points=16, pc_channels=kw['pc_channels'], radar_cells=max(cells, 1), dense_radar=cells < 0)
+    td = torch.bfloat16 if io_bf16 else sdt[1]
+    outs, launches = [], []
+    for v in (1, 0):
+        eng = NativeEngine(emu_library(), num_det=kw['num_det'], num_seg=kw['num_seg'], phi=kw['phi'], backbone=kw['backbone'],
+                           resolution=kw['resolution'], pc_channels=kw['pc_channels'], pc_classes=kw['pc_classes'],
+                           num_points=16, nano_head=kw['nano_head'], spp=kw['spp'], dtype=sdt[0])
+        if io_bf16:
+            eng.set_option('io_bf16', 1)
+        eng.set_option('radar_direct', v)
+        eng.set_option('full_taps', 1)
+        eng.load_state_dict(sd)
+        eng.plan(2)
+        o = alloc_outputs(kw, 2, 16, td, 'cpu')
+        eng.forward(x.to(td), xr.to(td), xp.to(td), o)
+        outs.append([t.float() for t in o[:3]] + [eng.read_tap(t) for t in ('radar.b0', 'radar.b1', 'r3', 'r5')])
+        launches.append(eng.launches())
+    assert launches[0] == launches[1] - 1
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize('name', ['en_s2'])
 def test_emulated_even_depthwise_row_split_bf16(name):
     """bf16 SPLIT blocks of EN-S2's stage 2 (d = 144: 5 k-steps): the k1 * k depthwise tap rows dealt evenly to the four waves (option dw_even)
