@@ -30,6 +30,10 @@ b en_s0_sdta_separate --opt sdta_fuse=0
 b en_s0_sdta_all --opt sdta_fuse=2
 b en_s0_head_layers_separate --opt head_fuse=0
 b en_s0_radar_segments --opt radar_compact=0
+b en_s0_radar_copy --opt radar_direct=0
+b en_s0_head_band80 --opt head_band=80
+b en_s0_spp_launches_separate --opt ghost_fuse=0
+b mv_s2_image_copy --config mv_s2 --opt mv_stem=0
 b en_s0_b256 --batch 256
 b en_s2_b256 --config en_s2 --batch 256
 b en_s2_b512_one_gpu --config en_s2 --batch 512 --plain
