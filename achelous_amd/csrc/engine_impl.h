@@ -1464,7 +1464,7 @@ public:
         // round 4 (16-bit engines): no NHWC copy of the map at all — the first pool and the first front kernel's residual read the caller's NCHW planes
         // (option "radar_direct"; needs the strip pool and rows of whole 16-pixel segments)
         bool direct0 = false;
-        if constexpr (H16E) direct0 = radar_direct && narrow0 && pool_strip > 0 && R % 16 == 0;
+        if constexpr (H16E) direct0 = radar_direct && narrow0 && pool_strip > 0 && R % 16 == 0 && R % POOLN_ROWS == 0;
         A x;
         if (direct0) { x.B = B; x.H = R; x.W = R; x.C = 3; x.ld = 4; x.p = nullptr; }     // shape only
         else x = narrow0 ? alloc_ld(B, R, R, 3, 4) : alloc(B, R, R, 3);
@@ -1505,7 +1505,7 @@ public:
             if (i == 0 && direct0) {
                 if constexpr (H16E) {
                 PoolNchwParams pp{nullptr, pooled.p0, pooled.ld, B, x.H, x.W, pooled.row, pooled.img, occ};
-                const dim3 grid(unsigned(cdivl(long(B) * x.H * (x.W / 4), 256))), block(256);
+                const dim3 grid(unsigned(cdivl(long(B) * (x.H / POOLN_ROWS) * (x.W / 4), 256))), block(256);
                 const void** rin = &io.radar;
                 const bool alt = io_alt();
                 mark_xwait_next();           // pipelined forwards: this branch rewrites the radar pyramid the previous forward's fusion reads

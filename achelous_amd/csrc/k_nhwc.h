@@ -385,34 +385,51 @@ __global__ __launch_bounds__(256) void mvstem_kernel(const MvStemParams p) {
     float bias[4];
     ACH_UNROLL
     for (int r = 0; r < 4; ++r) bias[r] = p.bias[g * 4 + r];
-    unsigned raw[MVSTEM_TPW][2][4];
-    long mm[MVSTEM_TPW];
+    // phase 1: every address and every load of the wave's four tiles (32-bit index arithmetic: B * Ho * Wo < 2^31); phase 2 converts.  All loads are
+    // unconditional, from clamped addresses — padding and idle k-slots are zeroed afterwards (a load under a lane condition is a branch, and behind a branch the
+    // compiler waits for each load by itself)
+    uint32_t mid[MVSTEM_TPW][2][2], lraw[MVSTEM_TPW][2][2];
+    bool use[MVSTEM_TPW][2][2], hasl[MVSTEM_TPW];
+    unsigned mm[MVSTEM_TPW];
     bool ok[MVSTEM_TPW];
+    const unsigned utotal = unsigned(total), uWo = unsigned(Wo), uHo = unsigned(Ho);
     ACH_UNROLL
     for (int t = 0; t < MVSTEM_TPW; ++t) {
-        const long mraw = ((long(blockIdx.x) * 4 + wave) * MVSTEM_TPW + t) * 16 + px;
-        ok[t] = mraw < total;
-        const long m = ok[t] ? mraw : 0;
+        const unsigned mraw = ((blockIdx.x * 4u + unsigned(wave)) * MVSTEM_TPW + unsigned(t)) * 16u + unsigned(px);
+        ok[t] = mraw < utotal;
+        const unsigned m = ok[t] ? mraw : 0u;
         mm[t] = m;
-        const int ox = int(m % Wo);
-        const int oy = int((m / Wo) % Ho);
-        const long b = m / (long(Wo) * Ho);
-        const IO* X = static_cast<const IO*>(p.X) + b * 3 * cstride + 2 * ox;
+        const unsigned q = m / uWo;
+        const int ox = int(m - q * uWo);
+        const unsigned b = q / uHo;
+        const int oy = int(q - b * uHo);
+        hasl[t] = ox > 0;
+        const IO* X = static_cast<const IO*>(p.X) + long(b) * 3 * cstride + 2 * ox;
         ACH_UNROLL
         for (int s = 0; s < 2; ++s) {
             ACH_UNROLL
             for (int h = 0; h < 2; ++h) {
-                raw[t][s][2 * h] = 0u; raw[t][s][2 * h + 1] = 0u;
-                const int r = (s * 4 + g) * 2 + h;                       // image row (c, ky) of this half of the fragment
-                const int c = r / 3, ky = r - 3 * c;
-                const int y = 2 * oy - 1 + ky;                           // <= H - 1 (H even)
-                if (ok[t] && r < 9 && y >= 0) {
-                    const IO* row = X + c * cstride + long(y) * p.Wd;
-                    const uint32_t mid = *reinterpret_cast<const uint32_t*>(row);                                  // x, x + 1
-                    const uint32_t left = ox > 0 ? uint32_t(reinterpret_cast<const uint16_t*>(row)[-1]) : 0u;      // x - 1 (the conv's zero padding at the left edge)
-                    raw[t][s][2 * h] = h16_recast<IO, T>(left | (mid << 16));
-                    raw[t][s][2 * h + 1] = h16_recast<IO, T>(mid >> 16);
-                }
+                const int r = (s * 4 + g) * 2 + h;                       // image row (c, ky) of this half of the fragment (r >= 9: zero weights, nothing to fetch)
+                const int rc = r < 9 ? r : 8;
+                const int c = rc / 3, ky = rc - 3 * c;
+                const int y = 2 * oy - 1 + ky;                           // <= H - 1 (H even); -1 = the conv's zero padding above the image
+                const IO* row = X + c * cstride + long(y < 0 ? 0 : y) * p.Wd;
+                mid[t][s][h] = *reinterpret_cast<const uint32_t*>(row);                                            // x, x + 1
+                lraw[t][s][h] = uint32_t(reinterpret_cast<const uint16_t*>(row)[hasl[t] ? -1 : 0]);                // x - 1
+                use[t][s][h] = ok[t] && r < 9 && y >= 0;
+            }
+        }
+    }
+    unsigned raw[MVSTEM_TPW][2][4];
+    ACH_UNROLL
+    for (int t = 0; t < MVSTEM_TPW; ++t) {
+        ACH_UNROLL
+        for (int s = 0; s < 2; ++s) {
+            ACH_UNROLL
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t left = hasl[t] ? lraw[t][s][h] : 0u;                                                // the conv's zero padding at the left edge
+                raw[t][s][2 * h] = use[t][s][h] ? h16_recast<IO, T>(left | (mid[t][s][h] << 16)) : 0u;
+                raw[t][s][2 * h + 1] = use[t][s][h] ? h16_recast<IO, T>(mid[t][s][h] >> 16) : 0u;
             }
         }
     }
@@ -426,7 +443,7 @@ __global__ __launch_bounds__(256) void mvstem_kernel(const MvStemParams p) {
         float o[4];                                                      // NT = 1: channels 4g .. 4g+3 of pixel px
         ACH_UNROLL
         for (int r = 0; r < 4; ++r) o[r] = apply_act(acc[r] + bias[r], ACT_SILU);
-        Store<T>::st4(static_cast<T*>(p.Y) + mm[t] * 16 + g * 4, o);
+        Store<T>::st4(static_cast<T*>(p.Y) + long(mm[t]) * 16 + g * 4, o);
     }
 }
 
