@@ -380,12 +380,40 @@ __global__ __launch_bounds__(256, (MlpOcc<DT, SPLIT, Store<T>::VEC>::blocks)) vo
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
 #endif
     if (!SPLIT) {
+        if constexpr (sizeof(T) == 2) {
+            // every residual row and bias vector of the tile requested first, unconditionally (clamped addresses), then the arithmetic and the stores: inside
+            // `finish` each pair's loads sit behind a lane condition, i.e. a branch, and the wave paid one memory round trip PER PAIR (five at d = 144) — each of
+            // them also waiting for the previous pair's store (round 4).  Same sums in the same order.
+            constexpr int NP = DT / 2;
+            uint4 rr[NP];
+            float4 ba[NP], bb[NP];
+            const bool hasR = p.R != nullptr;
+            ACH_UNROLL
+            for (int pair = 0; pair < NP; ++pair) {
+                const int nb = pair * 32 + g * 8;
+                ba[pair] = *reinterpret_cast<const float4*>(p.b2 + nb);
+                bb[pair] = *reinterpret_cast<const float4*>(p.b2 + nb + 4);
+                rr[pair] = make_uint4(0u, 0u, 0u, 0u);
+                if (hasR) rr[pair] = *reinterpret_cast<const uint4*>(static_cast<const T*>(p.R) + m * p.ldr + (nb < p.Cout ? nb : 0));
+            }
+            ACH_UNROLL
+            for (int pair = 0; pair < NP; ++pair) {
+                const int nb = pair * 32 + g * 8;
+                float r8[8], o[8];
+                frag_unpack<T>(rr[pair], r8);
+                const float bv[8] = {ba[pair].x, ba[pair].y, ba[pair].z, ba[pair].w, bb[pair].x, bb[pair].y, bb[pair].z, bb[pair].w};
+                ACH_UNROLL
+                for (int r = 0; r < 4; ++r) { o[r] = acc2[2 * pair][r] + bv[r] + r8[r]; o[4 + r] = acc2[2 * pair + 1][r] + bv[4 + r] + r8[4 + r]; }
+                if (valid && nb < p.Cout) Store<T>::st8(static_cast<T*>(p.Y) + m * p.ldy + nb, o);
+            }
+        } else {
         ACH_UNROLL
         for (int pair = 0; pair < DT / 2; ++pair) {
             float v8[8];
             ACH_UNROLL
             for (int r = 0; r < 4; ++r) { v8[r] = acc2[2 * pair][r]; v8[4 + r] = acc2[2 * pair + 1][r]; }
             finish(pair, v8);
+        }
         }
     } else {
         ACH_UNROLL
