@@ -174,6 +174,21 @@ struct RcFrontParams {
 #ifndef ACH_RCF_WIDE_WAVES
 #define ACH_RCF_WIDE_WAVES 1
 #endif
+// fp16 storage (round 4): the four-corner blend of a deformable tap on PACKED halves — the corners are fp16 in memory and the blended value is rounded to fp16 for the
+// MFMA anyway; v_pk_mul_f16 + 3 v_pk_fma_f16 per channel pair replace 2 x (2 conversions + 4 fp32 FMAs) and the final pack: ~68 -> ~20 VALU instructions per tap and lane.
+// Costs 2-3 fp16 ulps on the sampled value instead of 0.5 (fp32 blend, one rounding); every radar tap of the fixtures stays at 1-3e-3 of the reference (bound 2e-2).
+// bf16 storage has no packed FMA on gfx950 and keeps the fp32 blend, as does the CPU emulation.
+#ifndef ACH_RCF_PK16
+#define ACH_RCF_PK16 1
+#endif
+#if !defined(ACH_HOSTEMU)
+typedef _Float16 rcf_h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t rcf_blend_h2(uint32_t a, uint32_t b, uint32_t c, uint32_t d, rcf_h2 w00, rcf_h2 w01, rcf_h2 w10, rcf_h2 w11) {
+    const rcf_h2 r = __builtin_elementwise_fma(w11, __builtin_bit_cast(rcf_h2, d), __builtin_elementwise_fma(w10, __builtin_bit_cast(rcf_h2, c),
+                     __builtin_elementwise_fma(w01, __builtin_bit_cast(rcf_h2, b), w00 * __builtin_bit_cast(rcf_h2, a))));
+    return __builtin_bit_cast(uint32_t, r);
+}
+#endif
 template <class T, int KS, bool NARROW>
 __global__ __launch_bounds__(256, KS == 3 ? 4 : ACH_RCF_WIDE_WAVES) void rc_front_kernel(const RcFrontParams p) {
     constexpr int VEC = Store<T>::VEC;
@@ -407,6 +422,24 @@ __global__ __launch_bounds__(256, KS == 3 ? 4 : ACH_RCF_WIDE_WAVES) void rc_fron
             const unsigned q0b = q0 + unsigned(ldp) * esz, q1b = q1 + unsigned(ldp) * esz;
             const float live = tapi[s] < 0 ? 0.f : 1.f;
             const float w00 = t.w00 * live, w01 = t.w01 * live, w10 = t.w10 * live, w11 = t.w11 * live;
+#if !defined(ACH_HOSTEMU) && ACH_RCF_PK16
+            if constexpr (std::is_same<T, f16_t>::value) {
+                const rcf_h2 h00 = {_Float16(w00), _Float16(w00)}, h01 = {_Float16(w01), _Float16(w01)}, h10 = {_Float16(w10), _Float16(w10)}, h11 = {_Float16(w11), _Float16(w11)};
+                uint4 fr;
+                if constexpr (NARROW) {
+                    const uint2 A = *reinterpret_cast<const uint2*>(Pb + q0), Bq = *reinterpret_cast<const uint2*>(Pb + q0b);
+                    const uint2 Cq = *reinterpret_cast<const uint2*>(Pb + q1), D = *reinterpret_cast<const uint2*>(Pb + q1b);
+                    fr = make_uint4(rcf_blend_h2(A.x, Bq.x, Cq.x, D.x, h00, h01, h10, h11), rcf_blend_h2(A.y, Bq.y, Cq.y, D.y, h00, h01, h10, h11), 0u, 0u);
+                } else {
+                    const uint4 A = *reinterpret_cast<const uint4*>(Pb + q0), Bq = *reinterpret_cast<const uint4*>(Pb + q0b);
+                    const uint4 Cq = *reinterpret_cast<const uint4*>(Pb + q1), D = *reinterpret_cast<const uint4*>(Pb + q1b);
+                    fr = make_uint4(rcf_blend_h2(A.x, Bq.x, Cq.x, D.x, h00, h01, h10, h11), rcf_blend_h2(A.y, Bq.y, Cq.y, D.y, h00, h01, h10, h11),
+                                    rcf_blend_h2(A.z, Bq.z, Cq.z, D.z, h00, h01, h10, h11), rcf_blend_h2(A.w, Bq.w, Cq.w, D.w, h00, h01, h10, h11));
+                }
+                mfma16<T>(WLDS ? wsh[(2 * KS + s) * 64 + lane] : wfd[WLDS ? 0 : s], fr, acc);
+                continue;
+            }
+#endif
             float v[8];
             if constexpr (NARROW && VEC == 8) {
                 float a[4], bq[4], cc[4], d[4];

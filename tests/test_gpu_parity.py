@@ -97,13 +97,20 @@ def check_h16_decisions(tag, truth, got_se, got_lane, kept, resolution, num_det,
         cap = idx.shape[1]
         jac, unexpl = [], []
         for b in range(idx.shape[0]):
-            want = [int(i) for i in exp[b][1][:cap]]
+            want_full = [int(i) for i in exp[b][1]]
+            want = want_full[:cap]
             got = [int(i) for i in idx[b, :int(cnt[b])].tolist()]
             j = len(set(want) & set(got)) / max(1, len(set(want) | set(got)))
             # below H16_NMS_JACCARD every differing anchor must be a marginal decision of the truth (and the set must not fall under the floor)
             u = nms_unexplained(tdec[b], want, got, num_det, conf, iou) if j < H16_NMS_JACCARD else []
+            if u and len(want_full) >= cap:
+                # a frame whose kept list is cut at `cap` (max_det, score order) has a third kind of marginal decision, the rank at the cut: an anchor the truth keeps
+                # BEYOND the cut appears in the engine's list when k flips ahead of it drop out, and the last k of the truth's first `cap` leave when k flips enter
+                k_in = len(set(got) - set(want))
+                tail = set(want[max(0, cap - k_in):])
+                u = [a for a in u if not ((a in got and a in want_full) or a in tail)]
             jac.append(round(j, 4)); unexpl.append(len(u))
-            if j < H16_NMS_JACCARD and (u or j < H16_NMS_FLOOR or len(want) >= cap):
+            if j < H16_NMS_JACCARD and (u or j < H16_NMS_FLOOR):
                 problems.append(('nms', (conf, iou), b, j, u[:8]))
         report[(conf, iou)] = (jac, unexpl)
     print(f'{tag}: 16-bit decisions vs fp32 truth: arg-max agreement {agree}; on decisive pixels {dec}; NMS kept-set (Jaccard, anchors not explained by a marginal decision of the truth) {report}')
