@@ -15,7 +15,10 @@
 
 namespace ach {
 
-constexpr int XCA_CT = 32;       // output-channel tile of xca_finalize: one workgroup per (sample, head, tile) — the softmax is recomputed
+#ifndef ACH_XCA_CT
+#define ACH_XCA_CT 32
+#endif
+constexpr int XCA_CT = ACH_XCA_CT;       // output-channel tile of xca_finalize: one workgroup per (sample, head, tile) — the softmax is recomputed
                                  // per tile (d x d, cheap) so that the fold runs on 4-6x more workgroups instead of a serial loop
 
 struct XcaGramParams { const void* qkv; long ld; float* partial; int B, N, C, heads, S; int hg; };   // hg: heads per workgroup (xca_gram_mfma_kernel)
