@@ -123,6 +123,7 @@ int ach_set_option(ach_handle* h, const char* key, int32_t value) {
         else if (std::string(key) == "pn2_fps_all") h->eng->pn2_fps_all = value != 0;
         else if (std::string(key) == "ghost_rb") h->eng->ghost_rb = value > 0 ? value : 5;
         else if (std::string(key) == "pc_chain") h->eng->pc_chain = value != 0;
+        else if (std::string(key) == "mlp_split_hw") h->eng->mlp_split_hw = value;
         else if (std::string(key) == "radar_direct") h->eng->radar_direct = value != 0;
         else if (std::string(key) == "mv_stem") h->eng->mv_stem = value != 0;
         else if (std::string(key) == "ghost_fuse") h->eng->ghost_fuse = value != 0;

@@ -139,6 +139,7 @@ public:
     bool dw_tile = true;              // option "dw_tile": LDS-tiled depthwise kernel on the 10x10 maps
     bool fuse_rc = true;              // option "fused_rc": RCBlock conv + deformable sampling + contraction as one launch (k_conv3.h)
     bool row_conv = true;             // option "row_conv": narrow 3x3 convs through k_conv3.h instead of the generic implicit GEMM
+    int mlp_split_hw = 1024;          // option "mlp_split_hw": with mlp_split = -1, maps of at most this many pixels run four waves per tile
     int mlp_split = -1;               // option "mlp_split": -1 auto (by tile count), 0 one tile per wave, 1 four waves per tile
     bool full_taps = false;           // option "full_taps": also materialise boundaries that production plans keep on-chip
     int batch = 0;

@@ -460,7 +460,7 @@ public:
         mp.W1 = up_T(w1); mp.b1 = up_f32(b1); mp.W2 = up_T(w2); mp.b2 = up_f32(b2);
         mp.M = xin.rows(); mp.C = C; mp.k1 = k1; mp.J = J; mp.act = act; mp.ln_eps = ln_eps; mp.ln = 1; mp.Cout = C;
         // per-sample map size, not batch, decides the geometry: a frame's result must not depend on the batch it is in
-        const bool split = mlp_split < 0 ? xin.H * xin.W <= 1024 : mlp_split != 0;
+        const bool split = mlp_split < 0 ? xin.H * xin.W <= mlp_split_hw : mlp_split != 0;
         if (split && dw_ks && dw_even && mlp_even_dt(DT)) {               // the instantiated widths (launch_mlp)
             // deal the k1 * k tap rows to the four waves in contiguous shares when that lowers the slowest wave's count and no share spans
             // more than two k-steps (the exchange buffer holds two slots per wave)
@@ -514,7 +514,7 @@ public:
         if (!fuse_mlp) return false;
         const int Cin = x.C, hidden = l1.N, Cout = l2.N;
         const int k1 = cdiv(Cin, KC), J = cdiv(hidden, 32);
-        const bool split = mlp_split < 0 ? x.H * x.W <= 1024 : mlp_split != 0;
+        const bool split = mlp_split < 0 ? x.H * x.W <= mlp_split_hw : mlp_split != 0;
         // narrow layers on maps that are not latency-bound: every weight fragment in registers, several tiles per wave (chain_kernel)
         const bool small = Cout <= 32 && k1 <= 3 && J <= 2 && !split;
         const int DT = small ? 2 : mlp_pick_dt(std::max(Cin, Cout));

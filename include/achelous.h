@@ -117,7 +117,7 @@ int ach_load_weights(ach_handle* h, const ach_tensor_desc* tensors, size_t n);
  * ShuffleAttention's coefficient launch folded into the apply launch — measured slower), "pn2_fps_all" (default 1: PointNet++'s four farthest-point samplings as one
  * launch), "pc_chain" (default 1: PointNet's conv3 + conv4 as one two-layer chain launch), "mv_stem" (default 1, 16-bit engines: MobileViT's conv1 gathered straight
  * from the NCHW image instead of an NHWC copy + implicit GEMM), "radar_direct" (default 1, 16-bit engines: the first RCBlock pools and adds its residual straight
- * from the NCHW radar map; bit-identical);
+ * from the NCHW radar map; bit-identical), "mlp_split_hw" (default 1024: maps of at most this many pixels run the fused blocks with four waves per 16-pixel tile);
  * round 3 (16-bit engines): "head_rows" (2: last decoder level + segmentation head as the row-walking two-columns-per-lane kernel, 1: one
  * column, 0: the LDS tile kernel), "head_band" (rows per workgroup band of that kernel, default 40), "mlp_band" (1: EdgeNeXt blocks of
  * the instantiated shapes — d = 96 / 144 on maps up to 20 wide, d = 176 up to 10 wide — as the band kernel, 2: also stages 0 / 1, 0: never), "head_fuse" (a detection-head layer's depthwise + pointwise convs of both
