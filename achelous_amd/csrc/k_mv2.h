@@ -54,7 +54,12 @@ __global__ __launch_bounds__(256, STRIDE == 2 ? 3 : 4) void mv2_kernel(const Mv2
     constexpr int PITCH = HID * int(sizeof(T)) + 16;               // bytes per region pixel (padding: conflict-free 16-byte reads)
     constexpr int NT1 = HID / 16, KS2 = HID / KC;
     __shared__ __attribute__((aligned(16))) unsigned char hs[RP * PITCH];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the depthwise weights and bias ([9][HID] + [HID] floats, 2.5 / 5 KB) staged once per workgroup (round 4): phase 2 fetched a tap's weights from global memory
+    // inside the tap loop, behind a lane-condition block per pixel tile — nine exposed L1 round trips per k-step (vmcnt(0) in front of every tap's FMAs)
+    __shared__ __attribute__((aligned(16))) float wdl[10 * HID];
+    for (int i = threadIdx.x; i < 10 * HID / 4; i += 256)
+        reinterpret_cast<float4*>(wdl)[i] = i < 9 * HID / 4 ? reinterpret_cast<const float4*>(p.Wdw)[i] : reinterpret_cast<const float4*>(p.bdw)[i - 9 * HID / 4];
+    const int lane = threadIdx.x & 63, wave = wave_uniform(int(threadIdx.x) >> 6);
     const int px = lane & 15, g = lane >> 4;
     const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + TH - 1) / TH;
     const unsigned wg = xcd_block(blockIdx.x, gridDim.x);          // neighbouring tiles share halo lines: keep them in one L2
@@ -77,7 +82,11 @@ __global__ __launch_bounds__(256, STRIDE == 2 ? 3 : 4) void mv2_kernel(const Mv2
             for (int t = 0; t < NT1; ++t) { acc[t][0] = acc[t][1] = acc[t][2] = acc[t][3] = 0.f; }
             for (int s = 0; s < p.k1; ++s) {
                 // (k-slots past the pixel's stored channels meet zero weights; do not read the neighbouring pixel for them)
-                const uint4 xf = (s * KC + g * VEC) < int(p.ldx) ? *reinterpret_cast<const uint4*>(xp + s * KC + g * VEC) : make_uint4(0u, 0u, 0u, 0u);
+                // (an unconditional load from a clamped offset, zeroed afterwards: a load under a lane condition is waited for alone)
+                const int xo = s * KC + g * VEC;
+                const bool xin = xo < int(p.ldx);
+                const uint4 xr = *reinterpret_cast<const uint4*>(xp + (xin ? xo : 0));
+                const uint4 xf = make_uint4(xin ? xr.x : 0u, xin ? xr.y : 0u, xin ? xr.z : 0u, xin ? xr.w : 0u);
                 ACH_UNROLL
                 for (int t = 0; t < NT1; ++t) mfma16<T>(W1[(t * p.k1 + s) * 64], xf, acc[t]);
             }
@@ -122,7 +131,7 @@ __global__ __launch_bounds__(256, STRIDE == 2 ? 3 : 4) void mv2_kernel(const Mv2
         const int ch = s * KC + g * VEC;
         float bd[VEC];
         ACH_UNROLL
-        for (int j = 0; j < VEC; j += 4) { const float4 w = *reinterpret_cast<const float4*>(p.bdw + ch + j); bd[j] = w.x; bd[j + 1] = w.y; bd[j + 2] = w.z; bd[j + 3] = w.w; }
+        for (int j = 0; j < VEC; j += 4) { const float4 w = *reinterpret_cast<const float4*>(wdl + 9 * HID + ch + j); bd[j] = w.x; bd[j + 1] = w.y; bd[j + 2] = w.z; bd[j + 3] = w.w; }
         uint4 wf[NT2];
         ACH_UNROLL
         for (int t = 0; t < NT2; ++t) wf[t] = W2[(t * KS2 + s) * 64];
@@ -138,7 +147,7 @@ __global__ __launch_bounds__(256, STRIDE == 2 ? 3 : 4) void mv2_kernel(const Mv2
             float wd[VEC];
             ACH_UNROLL
             for (int j = 0; j < VEC; j += 4) {
-                const float4 w = *reinterpret_cast<const float4*>(p.Wdw + k * HID + ch + j);
+                const float4 w = *reinterpret_cast<const float4*>(wdl + k * HID + ch + j);
                 wd[j] = w.x; wd[j + 1] = w.y; wd[j + 2] = w.z; wd[j + 3] = w.w;
             }
             ACH_UNROLL
