@@ -81,7 +81,7 @@ __host__ __device__ __forceinline__ uint16_t f32_to_f16_bits(float f) {
     const uint32_t x = c.u & 0x7fffffffu;
     if (x >= 0x7f800000u) return uint16_t(sign | (x > 0x7f800000u ? 0x7e00u : 0x7c00u));
     const uint32_t e = x >> 23;
-    if (e >= 143u) return uint16_t(sign | 0x7c00u);                        // >= 65536: infinity
+    if (e >= 143u) return uint16_t(sign | 0x7bffu);                        // >= 65536: the largest finite half (MODE.FP16_OVFL, see f16_sat_mode below)
     if (e <= 112u) {                                                       // below 2^-14: subnormal or zero, unit 2^-24
         if (x < 0x33000000u) return uint16_t(sign);                        // < 2^-25 (a tie at 2^-25 rounds to even = 0)
         const uint32_t m = (x & 0x7fffffu) | 0x800000u, s = 126u - e;      // value = m * 2^(e - 126) units
@@ -92,7 +92,8 @@ __host__ __device__ __forceinline__ uint16_t f32_to_f16_bits(float f) {
     }
     uint32_t r = ((e - 112u) << 10) | ((x & 0x7fffffu) >> 13);
     const uint32_t rem = x & 0x1fffu;
-    if (rem > 0x1000u || (rem == 0x1000u && (r & 1u))) ++r;                // a carry into the exponent is the right answer (up to infinity)
+    if (rem > 0x1000u || (rem == 0x1000u && (r & 1u))) ++r;                // a carry into the exponent is the right answer ...
+    if (r >= 0x7c00u) r = 0x7bffu;                                         // ... except into infinity: a finite value saturates
     return uint16_t(sign | r);
 }
 __host__ __device__ __forceinline__ float f16_bits_to_f32(uint16_t h) {
@@ -126,6 +127,18 @@ __host__ __device__ __forceinline__ float f16_to_f32(uint16_t h) { return f16_bi
 __host__ __device__ __forceinline__ float f16lo_to_f32(uint32_t w) { return f16_bits_to_f32(uint16_t(w & 0xffffu)); }
 __host__ __device__ __forceinline__ float f16hi_to_f32(uint32_t w) { return f16_bits_to_f32(uint16_t(w >> 16)); }
 #endif
+
+// fp16 storage overflows at 65504 where bf16 does not.  Every kernel of the fp16 engine sets MODE.FP16_OVFL (bit 23 of HW_REG_MODE) as its first instruction:
+// an fp16 result that overflows (v_cvt_pk_f16_f32, v_cvt_f16_f32, the packed-half arithmetic of k_conv3.h) then clamps to +-65504 instead of becoming infinity
+// (measured on the MI355X, profiles/scripts/ubench/f16_ovfl.hip; infinities and NaNs that come IN stay what they are).  A saturated activation is still a wrong
+// one — what the mode buys is that it stays finite and DETECTABLE: ach_count_saturated (api.cpp) counts the +-65504 / non-finite elements of a forward's
+// activation tensors, and achelous_amd.Achelous falls back to bf16 storage when a model's first forward shows any (nets.py, `f16_guard`).  The host converter
+// above saturates the same way, so the CPU emulation and the weight packers agree with the device.
+template <class T> __device__ __forceinline__ void f16_sat_mode() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (std::is_same<T, f16_t>::value) __builtin_amdgcn_s_setreg((0 << 11) | (23 << 6) | 1, 1);      // hwreg(HW_REG_MODE, 23, 1) = 1
+#endif
+}
 
 // the two 16-bit storage types behind one interface: a dword holds two consecutive elements (low half first)
 template <class T> struct is_h16 { static constexpr bool value = false; };

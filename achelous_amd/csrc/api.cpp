@@ -114,7 +114,7 @@ int ach_set_option(ach_handle* h, const char* key, int32_t value) {
         else if (std::string(key) == "level_rows") h->eng->level_rows = value != 0;
         else if (std::string(key) == "mlp_band") h->eng->mlp_band = value;
         else if (std::string(key) == "mlp_band_dbg") h->eng->mlp_band_dbg = value;
-        else if (std::string(key) == "head_band") h->eng->head_band = value > 0 ? value : 80;
+        else if (std::string(key) == "head_band") h->eng->head_band = value > 0 ? value : 40;
         else if (std::string(key) == "head_grid") h->eng->head_grid = value;
         else if (std::string(key) == "head_debug") h->eng->head_debug = value;
         else if (std::string(key) == "attn_mfma") h->eng->attn_mfma = value != 0;
@@ -580,6 +580,12 @@ int ach_read_tap(ach_handle* h, const char* name, float* host_out, size_t capaci
     return guarded(h, [&] {
         if (!name || !host_out) throw ach::AchError{ACH_ERR_INVALID, "bad tap arguments"};
         h->eng->read_tap(name, host_out, capacity_elems);
+    });
+}
+int ach_count_saturated(ach_handle* h, void* stream, uint64_t* count) {
+    return guarded(h, [&] {
+        if (!count) throw ach::AchError{ACH_ERR_INVALID, "null count"};
+        *count = uint64_t(h->eng->count_saturated(static_cast<hipStream_t>(stream)));
     });
 }
 int ach_plan_launches(const ach_handle* h) { return (h && h->eng) ? int(h->eng->ops.size()) : 0; }

@@ -32,6 +32,7 @@ EngineBase::~EngineBase() {
     if (warena) (void)hipFree(warena);
     if (aarena) (void)hipFree(aarena);
     if (prepost_scratch) (void)hipFree(prepost_scratch);
+    if (sat_dev) (void)hipFree(sat_dev);
 #if !defined(ACH_HOSTEMU)
     drop_graphs();
     if (capture_stream) (void)hipStreamDestroy(capture_stream);
@@ -102,7 +103,7 @@ void EngineBase::reset_plan() {
 #endif
     for (auto& pr : probes) pr.first = pr.last = -1;
     cur_stream = 0; pending_wait = -1; pending_wait2 = -1;
-    ops.clear(); taps.clear(); tap_order.clear();
+    ops.clear(); taps.clear(); tap_order.clear(); t_regions.clear(); sat_dev_regions = 0;
     warena_used = 0; aarena_used = 0;
 }
 // Side streams are shared by every engine of the process on a device (one set per priority pattern) and live as long as the process:

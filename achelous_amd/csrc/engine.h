@@ -164,6 +164,12 @@ public:
     void set_probe_range(int slot, int first, int last);
     void read_probe_slot(int slot, float* avg_ms, int* samples);
     virtual void decode(int B, const void* d3, const void* d4, const void* d5, float* out, hipStream_t s) = 0;
+    // fp16 storage: how many elements of the plan's activation tensors are saturated (+-65504: every kernel of the fp16 engine runs with MODE.FP16_OVFL, so an
+    // overflowing conversion clamps instead of becoming infinity) or non-finite after the forward(s) enqueued on `s` so far; synchronises `s`.  0 for the other engines.
+    virtual unsigned long long count_saturated(hipStream_t s) = 0;
+    std::vector<std::pair<const void*, size_t>> t_regions;       // activation tensors held in the storage type: (device pointer, bytes), filled by plan()
+    void* sat_dev = nullptr; size_t sat_dev_regions = 0;         // device copy of t_regions + the counter (count_saturated)
+    void note_region(const void* p, size_t bytes) { if (!measuring) t_regions.emplace_back(p, bytes); }
     void nms(int B, const float* decoded, float conf, float iou, int max_det, float* rows, int* idx, int* count,
              void* workspace, hipStream_t s);
     size_t nms_workspace_bytes(int B) const;

@@ -64,16 +64,19 @@ public:
     A alloc(int B, int H, int W, int C) {
         A a; a.B = B; a.H = H; a.W = W; a.C = C; a.ld = round_up(C, 8);
         a.p = static_cast<T*>(aalloc(size_t(a.rows()) * a.ld * sizeof(T)));
+        note_region(a.p, size_t(a.rows()) * a.ld * sizeof(T));
         return a;
     }
     A alloc_ld(int B, int H, int W, int C, long ld) {          // explicit pixel pitch (the 4-channel maps of the first RCBlock)
         A a; a.B = B; a.H = H; a.W = W; a.C = C; a.ld = ld;
         a.p = static_cast<T*>(aalloc(size_t(a.rows()) * a.ld * sizeof(T)));
+        note_region(a.p, size_t(a.rows()) * a.ld * sizeof(T));
         return a;
     }
     Pl alloc_pl(int B, int C, int H, int W) {
         Pl a; a.B = B; a.C = C; a.H = H; a.W = W;
         a.p = static_cast<T*>(aalloc(size_t(B) * C * H * W * sizeof(T)));
+        note_region(a.p, size_t(B) * C * H * W * sizeof(T));
         return a;
     }
     float* alloc_f32(size_t n) { return static_cast<float*>(aalloc(n * sizeof(float))); }
@@ -510,11 +513,13 @@ public:
         mp.C = Cin; mp.k1 = k1; mp.J = J; mp.act = act; mp.ln = 0; mp.Cout = Cout;
     }
     // y = l2(act(l1(x))) as one launch (k_mlp.h without LayerNorm / residual); false when the widths are not instantiated
-    bool chain2(const std::string& name, const A& x, const Lin& l1, int act, const Lin& l2, A& y, bool* planar = nullptr) {
+    // (`allow_split` = false: the caller's "map" is not a frame — pc_pair presents B*N points as one map, whose size depends on the BATCH; the four-waves-per-tile
+    //  mode sums in another fp32 order than the one-wave mode, and a frame's result must not depend on the batch it is in)
+    bool chain2(const std::string& name, const A& x, const Lin& l1, int act, const Lin& l2, A& y, bool* planar = nullptr, bool allow_split = true) {
         if (!fuse_mlp) return false;
         const int Cin = x.C, hidden = l1.N, Cout = l2.N;
         const int k1 = cdiv(Cin, KC), J = cdiv(hidden, 32);
-        const bool split = mlp_split < 0 ? x.H * x.W <= mlp_split_hw : mlp_split != 0;
+        const bool split = allow_split && (mlp_split < 0 ? x.H * x.W <= mlp_split_hw : mlp_split != 0);
         // narrow layers on maps that are not latency-bound: every weight fragment in registers, several tiles per wave (chain_kernel)
         const bool small = Cout <= 32 && k1 <= 3 && J <= 2 && !split;
         const int DT = small ? 2 : mlp_pick_dt(std::max(Cin, Cout));
@@ -926,7 +931,7 @@ public:
         if constexpr (H16E) {
             // shortcut: depthwise 3x3 + BN -> 1x1 + BN, + ghost2's output, as ONE band kernel (k_ghost.h dwpw_kernel)
             const int rb = dwpw_band_rows(x.H, x.W, x.C, ghost_rb);
-            if (ghost_fuse && !full_taps && rb > 0 && x.C % 8 == 0 && out_chs % 8 == 0 && x.ld % 8 == 0 && g2.ld % 8 == 0) {
+            if (ghost_fuse && !full_taps && rb > 0 && x.C % 8 == 0 && x.C <= 320 && out_chs % 8 == 0 && x.ld % 8 == 0 && g2.ld % 8 == 0) {   // (ACH_BAND_LAUNCH: k1 <= 10)
                 Lin lp = conv_bn(pfx + ".shortcut.2", pfx + ".shortcut.3", 1e-5);
                 if (lp.N != out_chs || lp.K != x.C) throw AchError{ACH_ERR_MISSING_KEY, "GhostBottleneck shortcut widths at " + pfx};
                 BandW bw = pack_band(lp);
@@ -1175,7 +1180,10 @@ public:
                             x.H > 0 ? float(x.H - 1) / float(2 * x.H - 1) : 0.f, x.W > 0 ? float(x.W - 1) / float(2 * x.W - 1) : 0.f};
         p.out_bf16 = io_alt() ? 1 : 0;
         const double bytes = double(t.rows()) * Cg * sizeof(T) + 4.0 * double(t.rows()) * oup * sizeof(T);
-        if constexpr (H16E) if (head_rows && !planar && t.ld % 4 == 0 && double(t.rows()) * t.ld * 4.0 * oup < 2147483648.0) {
+        // (the row walk addresses one SAMPLE at a time — a 64-bit base per frame, 32-bit byte offsets inside it — so only a frame's own tensors must stay below
+        //  2 GiB, whatever the batch: round 4's test was on the whole batch and dropped plans above ~145 frames back to the LDS-tile head)
+        if constexpr (H16E) if (head_rows && !planar && t.ld % 4 == 0 && double(x.H) * x.W * t.ld * sizeof(T) < 2147483648.0 &&
+                                4.0 * double(x.H) * x.W * oup * sizeof(T) < 2147483648.0 && double(x.B) * cdiv(2 * x.H, 8) * cdiv(2 * x.W, DH_VALID) < 4294967296.0) {
             // row-walking kernel (k_dechead.h): head 1x1 as the A fragment of v_mfma_f32_16x16x32_bf16 — D row 4g + r = head channel g + 4r,
             // k = 8g + j = channel 4g + j of x1 (j < 4) or of x2 (j >= 4) — biases and the head's depthwise filters indexed by head channel
             std::vector<uint16_t> af(size_t(64) * 8, 0);
@@ -1765,7 +1773,7 @@ public:
 
     // ------------------------------------------------------------------------------------------ PointNet (a18)
     struct Rows { T* p = nullptr; long rows = 0; int C = 0; long ld = 0; };
-    Rows alloc_rows(long rows, int C) { Rows r; r.rows = rows; r.C = C; r.ld = round_up(C, 8); r.p = static_cast<T*>(aalloc(size_t(rows) * r.ld * sizeof(T))); return r; }
+    Rows alloc_rows(long rows, int C) { Rows r; r.rows = rows; r.C = C; r.ld = round_up(C, 8); r.p = static_cast<T*>(aalloc(size_t(rows) * r.ld * sizeof(T))); note_region(r.p, size_t(rows) * r.ld * sizeof(T)); return r; }
     Lin lin_bn1d(const std::string& conv, const std::string& bn) const { Lin l = lin(conv + ".weight", conv + ".bias"); if (!bn.empty()) fold_bn(l, bn, 1e-5); return l; }
     Rows pc_layer(const std::string& name, const Rows& x, const Lin& l, int act) {
         Rows y = alloc_rows(x.rows, l.N);
@@ -1779,7 +1787,7 @@ public:
         if (pc_chain && act2 == ACT_NONE && x.rows % 16 == 0) {
             A xa; xa.p = x.p; xa.B = 1; xa.H = int(x.rows / 16); xa.W = 16; xa.C = x.C; xa.ld = x.ld;
             A ya;
-            if (chain2(n1 + "+" + n2.substr(n2.rfind('.') + 1), xa, l1, act1, l2, ya)) { Rows y; y.p = ya.p; y.rows = x.rows; y.C = ya.C; y.ld = ya.ld; return y; }
+            if (chain2(n1 + "+" + n2.substr(n2.rfind('.') + 1), xa, l1, act1, l2, ya, nullptr, false)) { Rows y; y.p = ya.p; y.rows = x.rows; y.C = ya.C; y.ld = ya.ld; return y; }
         }
         return pc_layer(n2, pc_layer(n1, x, l1, act1), l2, act2);
     }
@@ -2145,6 +2153,31 @@ public:
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         (void)hipFree(X); (void)hipFree(Y); (void)hipFree(R); (void)hipFree(Wp); (void)hipFree(bias);
         return ms / float(iters);
+    }
+
+    unsigned long long count_saturated(hipStream_t s) override {
+        if constexpr (!std::is_same<T, f16_t>::value) { (void)s; return 0ull; }
+        else {
+            if (ops.empty()) throw AchError{ACH_ERR_INVALID, "ach_plan must precede ach_count_saturated"};
+            const size_t n = t_regions.size();
+            if (n == 0) return 0ull;
+            if (!sat_dev || sat_dev_regions != n) {
+                if (sat_dev) (void)hipFree(sat_dev);
+                sat_dev = nullptr;
+                ACH_HIP_CHECK(hipMalloc(&sat_dev, 256 + n * sizeof(SatRegion)));
+                std::vector<SatRegion> tab(n);
+                for (size_t i = 0; i < n; ++i) tab[i] = SatRegion{static_cast<const uint32_t*>(t_regions[i].first), static_cast<unsigned long long>((t_regions[i].second + 3) / 4)};
+                ACH_HIP_CHECK(hipMemcpy(static_cast<char*>(sat_dev) + 256, tab.data(), n * sizeof(SatRegion), hipMemcpyHostToDevice));
+                sat_dev_regions = n;
+            }
+            ACH_HIP_CHECK(hipMemsetAsync(sat_dev, 0, 8, s));
+            ACH_LAUNCH(sat_count_kernel, dim3(64, unsigned(n)), dim3(256), s, reinterpret_cast<const SatRegion*>(static_cast<char*>(sat_dev) + 256),
+                       static_cast<unsigned long long*>(sat_dev));
+            unsigned long long out = 0;
+            ACH_HIP_CHECK(hipMemcpyAsync(&out, sat_dev, 8, hipMemcpyDeviceToHost, s));
+            ACH_HIP_CHECK(hipStreamSynchronize(s));
+            return out;
+        }
     }
 
     void decode(int B, const void* d3, const void* d4, const void* d5, float* out, hipStream_t s) override {

@@ -33,7 +33,7 @@ struct Conv3Params {
 // HALF: the input pixel is HALF a 16-byte vector (4 bf16 channels = 8 B: the 3-channel maps of the first RCBlock, ldx = 4, cv = 1):
 // a k-slot is still one tap x 8 k-elements, its upper four elements are zero (zero weights there), and a tap is one 8-byte load.
 template <class T, int KS, int NT, int STRIDE, bool HALF = false>
-__global__ __launch_bounds__(256) void conv3x3_rows_kernel(const Conv3Params p) {
+__global__ __launch_bounds__(256) void conv3x3_rows_kernel(const Conv3Params p) { f16_sat_mode<T>();
     constexpr int VEC = Store<T>::VEC;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int px = lane & 15, g = lane >> 4;
@@ -190,7 +190,7 @@ __device__ __forceinline__ uint32_t rcf_blend_h2(uint32_t a, uint32_t b, uint32_
 }
 #endif
 template <class T, int KS, bool NARROW>
-__global__ __launch_bounds__(256, KS == 3 ? 4 : ACH_RCF_WIDE_WAVES) void rc_front_kernel(const RcFrontParams p) {
+__global__ __launch_bounds__(256, KS == 3 ? 4 : ACH_RCF_WIDE_WAVES) void rc_front_kernel(const RcFrontParams p) { f16_sat_mode<T>();
     constexpr int VEC = Store<T>::VEC;
     __shared__ float oml[4][16][36];                               // per wave: [pixel][27 values], row padded against bank conflicts
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -155,7 +155,7 @@ __device__ __forceinline__ uint32_t relu_packed16(uint32_t v) {
 // DBG (timing experiments only, results are wrong): bit 0 no bilinear, 1 no level depthwise, 2 no MFMA, 3 no head depthwise / stores.
 // TAP: also write [x1 | x2] to p.F (parity tests, option full_taps).
 template <class T, class IO, bool DW2, bool TAP, int DBG = 0>
-__global__ __launch_bounds__(64, DH_WAVES) void dechead_rows_kernel(const DecHeadParams p, const DecHeadRow* __restrict__ rows) {
+__global__ __launch_bounds__(64, DH_WAVES) void dechead_rows_kernel(const DecHeadParams p, const DecHeadRow* __restrict__ rows) { f16_sat_mode<T>();
     const int H = 2 * p.h, Wd = 2 * p.w;
     const unsigned u = xcd_block(blockIdx.x, gridDim.x);
     const int strip = int(u % unsigned(p.strips)), band = int((u / unsigned(p.strips)) % unsigned(p.bands));
@@ -357,7 +357,7 @@ __device__ __forceinline__ void add4_from_right(const float (&c)[4], const float
 #endif
 
 template <class T, class IO, bool DW2, bool TAP>
-__global__ __launch_bounds__(64 * ACH_DH_WG_WAVES, ACH_DH2_WAVES) void dechead_rows2_kernel(const DecHeadParams p, const DecHeadRow* __restrict__ rows) {
+__global__ __launch_bounds__(64 * ACH_DH_WG_WAVES, ACH_DH2_WAVES) void dechead_rows2_kernel(const DecHeadParams p, const DecHeadRow* __restrict__ rows) { f16_sat_mode<T>();
     const int H = 2 * p.h, Wd = 2 * p.w;
     const unsigned u = xcd_block(blockIdx.x, gridDim.x) * ACH_DH_WG_WAVES + unsigned(wave_uniform(int(threadIdx.x) >> 6));
     if (u >= unsigned(p.strips) * unsigned(p.bands) * unsigned(p.B)) return;
@@ -665,7 +665,7 @@ struct UpGhostRowsParams {
 constexpr int UGR_VALID = 14;
 
 template <class T, int NP>
-__global__ __launch_bounds__(64, (NP <= 2 ? 4 : (NP == 3 ? 3 : 2))) void upghost_rows_kernel(const UpGhostRowsParams p, const DecHeadRow* __restrict__ rows) {
+__global__ __launch_bounds__(64, (NP <= 2 ? 4 : (NP == 3 ? 3 : 2))) void upghost_rows_kernel(const UpGhostRowsParams p, const DecHeadRow* __restrict__ rows) { f16_sat_mode<T>();
     constexpr int CL = 2 * NP;                                   // channels per lane
     const int H = 2 * p.h, Wd = 2 * p.w;
     const unsigned u = xcd_block(blockIdx.x, gridDim.x);

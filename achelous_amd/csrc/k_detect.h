@@ -26,7 +26,7 @@ struct DecodeParams {
     int B, NC5, A; float in_h, in_w;
 };
 template <class T>
-__global__ __launch_bounds__(256) void decode_kernel(const DecodeParams p) {
+__global__ __launch_bounds__(256) void decode_kernel(const DecodeParams p) { f16_sat_mode<T>();
     const long idx = long(blockIdx.x) * blockDim.x + threadIdx.x;
     if (idx >= long(p.B) * p.A) return;
     const long b = idx / p.A;

@@ -380,14 +380,14 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, unsigned bx, unsi
 #define ACH_GEMM_BOUNDS __launch_bounds__(256)
 #endif
 template <class T, int NT, int P, bool DEEP = false, bool LNTAP = false>
-__global__ ACH_GEMM_BOUNDS void gemm_kernel(const GemmParams p) { gemm_body<T, NT, P, DEEP, LNTAP>(p, blockIdx.x, gridDim.x, blockIdx.y, blockIdx.z); }
+__global__ ACH_GEMM_BOUNDS void gemm_kernel(const GemmParams p) { f16_sat_mode<T>(); gemm_body<T, NT, P, DEEP, LNTAP>(p, blockIdx.x, gridDim.x, blockIdx.y, blockIdx.z); }
 
 // Up to three independent GEMMs of the same tile shape in one launch (blockIdx.y = job): the three pyramid levels of the
 // detection head run the same layer on maps of 1600 / 400 / 100 pixels — the small levels ride in the big level's launch
 // instead of costing a latency-bound launch each.  Jobs have groups == 1.
 struct GemmJobs { GemmParams p[3]; unsigned nbx[3], nbz[3]; int n; };
 template <class T, int NT>
-__global__ __launch_bounds__(256) void gemm_multi_kernel(const GemmJobs m) {
+__global__ __launch_bounds__(256) void gemm_multi_kernel(const GemmJobs m) { f16_sat_mode<T>();
     const unsigned j = blockIdx.y;
     if (blockIdx.x >= m.nbx[j] || blockIdx.z >= m.nbz[j]) return;
     gemm_body<T, NT, 1>(m.p[j], blockIdx.x, m.nbx[j], 0u, blockIdx.z);
@@ -416,7 +416,7 @@ struct GemmMaxParams {
 #define ACH_COLMAX_BOUNDS __launch_bounds__(256)
 #endif
 template <class T, int NT, int KH>
-__global__ ACH_COLMAX_BOUNDS void gemm_colmax_kernel(const GemmMaxParams p) {
+__global__ ACH_COLMAX_BOUNDS void gemm_colmax_kernel(const GemmMaxParams p) { f16_sat_mode<T>();
     constexpr int VEC = Store<T>::VEC;
     constexpr int KC = 4 * VEC;
     __shared__ float red[4][16 * NT];

@@ -49,7 +49,7 @@ struct GhostParams {
 };
 
 template <class T, int KMAX>
-__global__ __launch_bounds__(GH_THREADS) void ghost_kernel(const GhostParams p) {
+__global__ __launch_bounds__(GH_THREADS) void ghost_kernel(const GhostParams p) { f16_sat_mode<T>();
     static_assert(Store<T>::VEC == 8, "16-bit storage");
     __shared__ __attribute__((aligned(16))) unsigned char smem[GH_LDS_BYTES];
     T* const x1s = reinterpret_cast<T*>(smem);                       // [(rows + 2) x (W + 2)][init]
@@ -117,7 +117,7 @@ struct DwPwParams {
 };
 
 template <class T, int KMAX>
-__global__ __launch_bounds__(GH_THREADS) void dwpw_kernel(const DwPwParams p) {
+__global__ __launch_bounds__(GH_THREADS) void dwpw_kernel(const DwPwParams p) { f16_sat_mode<T>();
     static_assert(Store<T>::VEC == 8, "16-bit storage");
     __shared__ __attribute__((aligned(16))) unsigned char halo[DP_HALO_BYTES];
     __shared__ __attribute__((aligned(16))) unsigned char frag[DP_FRAG_BYTES];
@@ -198,7 +198,7 @@ struct UpConvParams {
 };
 
 template <class T, int KMAX>
-__global__ __launch_bounds__(GH_THREADS) void upconv_kernel(const UpConvParams p) {
+__global__ __launch_bounds__(GH_THREADS) void upconv_kernel(const UpConvParams p) { f16_sat_mode<T>();
     static_assert(Store<T>::VEC == 8, "16-bit storage");
     __shared__ __attribute__((aligned(16))) unsigned char smem[UC_LDS_BYTES];
     T* const ts = reinterpret_cast<T*>(smem);                        // [source rows][w][N]
@@ -275,7 +275,7 @@ struct SppFusedParams {
 };
 constexpr int SPPF_MAXPIX = 112, SPPF_MAXMID = 88, SPPF_K2MAX = 11;     // LDS: 19.7 + 59.1 + 78.8 KB = 157.7 of 160 KB (EdgeNeXt-S0: 10 x 10 x 176 -> 88)
 template <class T>
-__global__ __launch_bounds__(GH_THREADS) void spp_fused_kernel(const SppFusedParams p) {
+__global__ __launch_bounds__(GH_THREADS) void spp_fused_kernel(const SppFusedParams p) { f16_sat_mode<T>();
     static_assert(Store<T>::VEC == 8, "16-bit storage");
     __shared__ __attribute__((aligned(16))) T x1s[SPPF_MAXPIX * SPPF_MAXMID];                  // cv1 output [pix][cmid]
     __shared__ __attribute__((aligned(16))) T rmax[3][SPPF_MAXPIX * SPPF_MAXMID];              // row maxima of radius 2 / 4 / 6

@@ -49,7 +49,7 @@ struct HeadDwParams {
 };
 
 template <class T>          // (bf16_t / f16_t: the 16-bit storage types)
-__global__ __launch_bounds__(HDW_THREADS, HDW_WGS) void headdw_kernel(const HeadDwParams p) {
+__global__ __launch_bounds__(HDW_THREADS, HDW_WGS) void headdw_kernel(const HeadDwParams p) { f16_sat_mode<T>();
     constexpr int C = HDW_C, SP = HDW_SP, KS = 5;
     __shared__ __attribute__((aligned(16))) float xin[HDW_F32 ? HDW_MAXPOS * C : HDW_MAXPOS * C / 2];       // 90 KB (fp32) / 45 KB (bf16)
 #if ACH_HDW_ALIAS

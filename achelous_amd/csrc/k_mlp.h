@@ -231,7 +231,7 @@ template <int DT, bool SPLIT, int VEC> struct MlpOcc {
 };
 
 template <class T, int DT, bool SPLIT, bool EVEN = false>
-__global__ __launch_bounds__(256, (MlpOcc<DT, SPLIT, Store<T>::VEC>::blocks)) void mlp_kernel(const MlpParams p) {
+__global__ __launch_bounds__(256, (MlpOcc<DT, SPLIT, Store<T>::VEC>::blocks)) void mlp_kernel(const MlpParams p) { f16_sat_mode<T>();
     constexpr int VEC = Store<T>::VEC;
     constexpr int KC = 4 * VEC;
     constexpr int K1MAX = (16 * DT + KC - 1) / KC;
@@ -487,7 +487,7 @@ constexpr int CHAIN_TILES_PER_WAVE = ACH_CHAIN_TILES;
 #define ACH_CHAIN_BOUNDS __launch_bounds__(256)
 #endif
 template <class T, int K1, int J>
-__global__ ACH_CHAIN_BOUNDS void chain_kernel(const MlpParams p) {
+__global__ ACH_CHAIN_BOUNDS void chain_kernel(const MlpParams p) { f16_sat_mode<T>();
     constexpr int VEC = Store<T>::VEC;
     constexpr int KC = 4 * VEC;
     constexpr int HSTEP = 8 / VEC;

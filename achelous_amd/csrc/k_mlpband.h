@@ -53,7 +53,7 @@ struct MlpBandGeom {
 // TILEPAR (the narrow blocks of the large maps: few hidden chunks, many tiles): a wave takes whole TILES (t = wave, wave + 8, ...) through
 // every hidden chunk instead of a share of the chunks for every tile — no partial sums, no reduction phase.
 template <class T, int K1, int DT, int KS, int RB, int MAXW, bool XF32, bool PREF, bool TILEPAR = false>
-__global__ __launch_bounds__(MLPB_THREADS, 1) void mlp_band_kernel(const MlpBandParams bp) {
+__global__ __launch_bounds__(MLPB_THREADS, 1) void mlp_band_kernel(const MlpBandParams bp) { f16_sat_mode<T>();
     using G = MlpBandGeom<K1, DT, KS, RB, MAXW, XF32>;
     constexpr int CP = G::CP, NT = G::NT, SP = MLPB_SP, NTB = mlpb_ntb(DT);
     const MlpParams& p = bp.m;

@@ -47,7 +47,7 @@ template <> struct Mv2Tile<2, 4> { static constexpr int TW = 8, TH = 2; };      
 
 // HID: hidden width (64 | 128); NT2 = Cout / 16 (1 | 2 | 4).  Static LDS: region pixels x (HID elements + 16 B of padding).
 template <class T, int STRIDE, int HID, int NT2>
-__global__ __launch_bounds__(256, STRIDE == 2 ? 3 : 4) void mv2_kernel(const Mv2Params p) {
+__global__ __launch_bounds__(256, STRIDE == 2 ? 3 : 4) void mv2_kernel(const Mv2Params p) { f16_sat_mode<T>();
     constexpr int VEC = Store<T>::VEC, KC = 4 * VEC;
     constexpr int TW = Mv2Tile<STRIDE, int(sizeof(T))>::TW, TH = Mv2Tile<STRIDE, int(sizeof(T))>::TH;
     constexpr int RW = TW * STRIDE + (STRIDE == 1 ? 2 : 1), RH = TH * STRIDE + (STRIDE == 1 ? 2 : 1), RP = RW * RH;

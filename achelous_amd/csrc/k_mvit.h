@@ -19,7 +19,7 @@ constexpr int MVIT_NMAX = 1600;
 // NMAX sizes the LDS staging: 400 tokens (a 40x40 map: 25 KB, six workgroups per CU) or 1600 (100 KB, one workgroup per CU —
 // with the large instantiation on a 40x40 map the kernel ran at one wave per SIMD and 2.5x slower)
 template <class T, int NMAX>
-__global__ __launch_bounds__(256) void mvit_attn_kernel(const MvitAttnParams p) {
+__global__ __launch_bounds__(256) void mvit_attn_kernel(const MvitAttnParams p) { f16_sat_mode<T>();
     __shared__ float ks[NMAX * MVIT_DH];
     __shared__ float vs[NMAX * MVIT_DH];
     const int h2 = p.H / 2, w2 = p.Wd / 2, N = h2 * w2;
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void mvit_attn_kernel(const MvitAttnParams p) 
 // k-range; the kernel is bound by the exponentials, not by the matrix cores.  Replaces one-query-per-thread VALU dot products:
 // 165 us -> see DESIGN (MV-GDF-PN-S2, 40x40 map, batch 64).
 template <class T, int NMAX>
-__global__ __launch_bounds__(256) void mvit_attn_mfma_kernel(const MvitAttnParams p) {
+__global__ __launch_bounds__(256) void mvit_attn_mfma_kernel(const MvitAttnParams p) { f16_sat_mode<T>();
     constexpr int VEC = Store<T>::VEC, CH = 4 * VEC;              // keys per P.V chunk: 32 (bf16) / 16 (fp32)
     constexpr int NT = (NMAX + 15) / 16, NC = (NMAX + CH - 1) / CH;
     __shared__ __attribute__((aligned(16))) T ks[NT * 16 * MVIT_DH];                 // [key][d]

@@ -93,11 +93,11 @@ __device__ __forceinline__ void dwconv_strip_body(const DwParams& p, unsigned bx
 }
 
 template <class T, int KS, int OW>
-__global__ __launch_bounds__(256) void dwconv_strip_kernel(const DwParams p) { dwconv_strip_body<T, KS, OW>(p, blockIdx.x, gridDim.x); }
+__global__ __launch_bounds__(256) void dwconv_strip_kernel(const DwParams p) { f16_sat_mode<T>(); dwconv_strip_body<T, KS, OW>(p, blockIdx.x, gridDim.x); }
 // up to three independent maps in one launch (blockIdx.y = job; the detection head's three pyramid levels)
 struct DwJobs { DwParams p[3]; unsigned nbx[3]; int n; };
 template <class T, int KS, int OW>
-__global__ __launch_bounds__(256) void dwconv_strip_multi_kernel(const DwJobs m) {
+__global__ __launch_bounds__(256) void dwconv_strip_multi_kernel(const DwJobs m) { f16_sat_mode<T>();
     const unsigned j = blockIdx.y;
     if (blockIdx.x >= m.nbx[j]) return;
     dwconv_strip_body<T, KS, OW>(m.p[j], blockIdx.x, m.nbx[j]);
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void dwconv_strip_multi_kernel(const DwJobs m)
 #define ACH_DWK_BOUNDS __launch_bounds__(256)
 #endif
 template <class T, int KS>
-__global__ ACH_DWK_BOUNDS void dwconv_kernel(const DwParams p) {
+__global__ ACH_DWK_BOUNDS void dwconv_kernel(const DwParams p) { f16_sat_mode<T>();
     const int cq = p.C >> 2;
     const long total = long(p.B) * p.Ho * p.Wo * cq;
     const long idx = long(xcd_block(blockIdx.x, gridDim.x)) * blockDim.x + threadIdx.x;
@@ -159,7 +159,7 @@ __global__ ACH_DWK_BOUNDS void dwconv_kernel(const DwParams p) {
 // two ds_read_b128 + two packed FMAs per tap per thread (thread = 4 channels x 1 output).
 constexpr int DWT_TS = 8;
 template <class T, int KS>
-__global__ __launch_bounds__(256) void dwconv_tile_kernel(const DwParams p) {
+__global__ __launch_bounds__(256) void dwconv_tile_kernel(const DwParams p) { f16_sat_mode<T>();
     constexpr int TS = DWT_TS, HS = TS + KS - 1, PAD = KS / 2;
     __shared__ float4 xs[HS * HS * 4];
     __shared__ float4 ws[KS * KS * 4];
@@ -254,7 +254,7 @@ struct StemParams {
     int B, H, Wd; float eps;
 };
 template <class T, class IO = T>       // IO: the type of the caller's image
-__global__ __launch_bounds__(256) void stem_kernel(const StemParams p) {
+__global__ __launch_bounds__(256) void stem_kernel(const StemParams p) { f16_sat_mode<T>();
     constexpr int CO = 32;
     const int Ho = p.H / 4, Wo = p.Wd / 4;
     const long total = long(p.B) * Ho * Wo;
@@ -310,7 +310,7 @@ struct StemMfmaParams {
     int B, H, Wd, ksteps; float eps;
 };
 template <class T, class IO = T>
-__global__ __launch_bounds__(256) void stem_mfma_kernel(const StemMfmaParams p) {
+__global__ __launch_bounds__(256) void stem_mfma_kernel(const StemMfmaParams p) { f16_sat_mode<T>();
     constexpr int VEC = Store<T>::VEC, KC = 4 * VEC, SEG = VEC / 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int px = lane & 15, g = lane >> 4;
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const StemMfmaParams p) 
 struct MvStemParams { const void* X; void* Y; const void* W; const float* bias; int B, H, Wd; };
 constexpr int MVSTEM_TPW = 4;            // 16-pixel tiles per wave: every load of the four tiles is in flight before the first MFMA (one tile per wave: 51.8 us at batch 64)
 template <class T, class IO>
-__global__ __launch_bounds__(256) void mvstem_kernel(const MvStemParams p) {
+__global__ __launch_bounds__(256) void mvstem_kernel(const MvStemParams p) { f16_sat_mode<T>();
     static_assert(Store<T>::VEC == 8, "16-bit storage");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int px = lane & 15, g = lane >> 4;
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(256) void mvstem_kernel(const MvStemParams p) {
 // (G = power of two >= C/4, <= 64), each lane holding 4 channels per step; reductions are xor-shuffles inside the group.
 struct LnParams { const void* X; long ldx; void* Y; long ldy; const float* w; const float* b; long rows; int C; float eps; int G; };
 template <class T>
-__global__ __launch_bounds__(256) void layernorm_kernel(const LnParams p) {
+__global__ __launch_bounds__(256) void layernorm_kernel(const LnParams p) { f16_sat_mode<T>();
     const int G = p.G, rows_per_block = 256 / G;
     const int gl = threadIdx.x % G;
     const long row = long(blockIdx.x) * rows_per_block + threadIdx.x / G;
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnParams p) {
 // nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True): src = dst * (in-1)/(out-1)
 struct UpParams { const void* X; long ldx; void* Y; long ldy; int B, H, Wd, C; };
 template <class T>
-__global__ __launch_bounds__(256) void upsample2x_kernel(const UpParams p) {
+__global__ __launch_bounds__(256) void upsample2x_kernel(const UpParams p) { f16_sat_mode<T>();
     const int Ho = p.H * 2, Wo = p.Wd * 2, cq = p.C >> 2;
     const long total = long(p.B) * Ho * Wo * cq;
     const long idx = long(xcd_block(blockIdx.x, gridDim.x)) * blockDim.x + threadIdx.x;
@@ -523,7 +523,7 @@ struct SppParams { void* buf; long ld; int B, H, Wd, C, cqb; };
 // global loads.  H * W * cqb <= SPP_TILE.
 constexpr int SPP_TILE = 768;
 template <class T>
-__global__ __launch_bounds__(256) void spp_pool_kernel(const SppParams p) {
+__global__ __launch_bounds__(256) void spp_pool_kernel(const SppParams p) { f16_sat_mode<T>();
     __shared__ float4 src[SPP_TILE], r5[SPP_TILE], r9[SPP_TILE], r13[SPP_TILE];
     const int cq = p.C >> 2, groups = (cq + p.cqb - 1) / p.cqb;
     const int b = blockIdx.x / groups, q0 = (blockIdx.x % groups) * p.cqb;
@@ -567,7 +567,7 @@ __global__ __launch_bounds__(256) void spp_pool_kernel(const SppParams p) {
 // ------------------------------------------------------------------------------------------ element-wise
 struct AddParams { const void* A; long lda; const void* Bp; long ldb; void* Y; long ldy; long rows; int C; };
 template <class T>
-__global__ __launch_bounds__(256) void add_kernel(const AddParams p) {
+__global__ __launch_bounds__(256) void add_kernel(const AddParams p) { f16_sat_mode<T>();
     const int cq = p.C >> 2;
     const long idx = long(blockIdx.x) * blockDim.x + threadIdx.x;
     if (idx >= p.rows * cq) return;
@@ -583,7 +583,7 @@ __global__ __launch_bounds__(256) void add_kernel(const AddParams p) {
 // up to three independent adds in one launch (the neck's three residual outputs q3 / q4 / q5: blockIdx.y = job)
 struct AddJobs { AddParams j[3]; int n; };
 template <class T>
-__global__ __launch_bounds__(256) void add_multi_kernel(const AddJobs m) {
+__global__ __launch_bounds__(256) void add_multi_kernel(const AddJobs m) { f16_sat_mode<T>();
     const AddParams& p = m.j[blockIdx.y];
     const int cq = p.C >> 2;
     const long idx = long(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -600,7 +600,7 @@ __global__ __launch_bounds__(256) void add_multi_kernel(const AddJobs m) {
 // copy a [rows, C] view (optionally adding a per-position constant [HW][C] fp32: the folded Fourier pos-enc)
 struct CopyParams { const void* X; long ldx; void* Y; long ldy; long rows; int C; const float* posenc; int HW; };
 template <class T>
-__global__ __launch_bounds__(256) void copy_kernel(const CopyParams p) {
+__global__ __launch_bounds__(256) void copy_kernel(const CopyParams p) { f16_sat_mode<T>();
     const int cq = p.C >> 2;
     const long idx = long(blockIdx.x) * blockDim.x + threadIdx.x;
     if (idx >= p.rows * cq) return;
@@ -660,11 +660,11 @@ __device__ __forceinline__ void chan_stats_body(const StatParams& p, int b, int 
     }
 }
 template <class T>
-__global__ __launch_bounds__(256) void chan_stats_kernel(const StatParams p) { chan_stats_body<T>(p, blockIdx.x, blockIdx.y); }
+__global__ __launch_bounds__(256) void chan_stats_kernel(const StatParams p) { f16_sat_mode<T>(); chan_stats_body<T>(p, blockIdx.x, blockIdx.y); }
 // up to 6 independent jobs in one launch (the six ECA inputs of the fusion stage): blockIdx.z = job
 template <class P> struct Multi6 { P j[6]; int n; };
 template <class T>
-__global__ __launch_bounds__(256) void chan_stats_multi_kernel(const Multi6<StatParams> m) {
+__global__ __launch_bounds__(256) void chan_stats_multi_kernel(const Multi6<StatParams> m) { f16_sat_mode<T>();
     const StatParams& p = m.j[blockIdx.z];
     if (int(blockIdx.y) >= p.S) return;
     chan_stats_body<T>(p, blockIdx.x, blockIdx.y);
@@ -710,7 +710,7 @@ static __global__ void sa_coef_kernel(const SaCoefParams p) {
 // apply + channel_shuffle(groups=2): input channel c -> output channel (c % (C/2)) * 2 + c / (C/2)
 struct SaApplyParams { const void* X; long ldx; void* Y0; void* Y1; long ldy; const float* coef; int B, HW, C; };
 template <class T>
-__global__ __launch_bounds__(256) void sa_apply_kernel(const SaApplyParams p) {
+__global__ __launch_bounds__(256) void sa_apply_kernel(const SaApplyParams p) { f16_sat_mode<T>();
     const long total = long(p.B) * p.HW * p.C;
     const long idx = long(blockIdx.x) * blockDim.x + threadIdx.x;
     if (idx >= total) return;
@@ -728,7 +728,7 @@ __global__ __launch_bounds__(256) void sa_apply_kernel(const SaApplyParams p) {
 // Eight output channels per thread (round 4): outputs co .. co + 7 are inputs c0 .. c0 + 3 of the first half interleaved with the same four of
 // the second half — two 8-byte loads, two 16-byte stores instead of eight 2-byte loads and sixteen 2-byte stores (19 -> 8 us at 40 x 40).  C % 8 == 0.
 template <class T>
-__global__ __launch_bounds__(256) void sa_apply8_kernel(const SaApplyParams p) {
+__global__ __launch_bounds__(256) void sa_apply8_kernel(const SaApplyParams p) { f16_sat_mode<T>();
     const int c8n = p.C / 8;
     const long total = long(p.B) * p.HW * c8n;
     const long idx = long(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -761,7 +761,7 @@ __global__ __launch_bounds__(256) void sa_apply8_kernel(const SaApplyParams p) {
 // for that sample into LDS — same operations in the same order, bit-identical results.
 struct SaFusedParams { SaCoefParams c; SaApplyParams a; };
 template <class T>
-__global__ __launch_bounds__(256) void sa_apply_fused_kernel(const SaFusedParams q) {
+__global__ __launch_bounds__(256) void sa_apply_fused_kernel(const SaFusedParams q) { f16_sat_mode<T>();
     __shared__ float coef[2][256][2];
     const SaCoefParams& p = q.c;
     const SaApplyParams& ap = q.a;
@@ -847,7 +847,7 @@ __device__ __forceinline__ void fuse_scale_body(const FuseParams& p, long idx) {
     Store<T>::st4(static_cast<T*>(p.Y) + pix * p.ldy + c, o);
 }
 template <class T>
-__global__ __launch_bounds__(256) void fuse_scale_multi_kernel(const Multi6<FuseParams> m) { fuse_scale_body<T>(m.j[blockIdx.y], long(blockIdx.x) * blockDim.x + threadIdx.x); }
+__global__ __launch_bounds__(256) void fuse_scale_multi_kernel(const Multi6<FuseParams> m) { f16_sat_mode<T>(); fuse_scale_body<T>(m.j[blockIdx.y], long(blockIdx.x) * blockDim.x + threadIdx.x); }
 
 }  // namespace ach
 
@@ -872,7 +872,7 @@ constexpr int UPG_CMAX = 32;
 // CG = Ghost half-width (16 / 24 / 32).  64 * CG/4 threads: a thread owns one 4-channel group for the whole tile (its nine
 // depthwise weight vectors live in registers) and walks the tile's pixels 64 at a time.
 template <class T, int CG>
-__global__ __launch_bounds__(16 * CG) void upghost_kernel(const UpGhostParams p) {
+__global__ __launch_bounds__(16 * CG) void upghost_kernel(const UpGhostParams p) { f16_sat_mode<T>();
     constexpr int TS = UPG_TS, HS = TS + 2, CQ = CG / 4;
     __shared__ float x1[HS * HS * CG];
     const int H = 2 * p.h, Wd = 2 * p.w;
@@ -1045,7 +1045,7 @@ __device__ __forceinline__ void upghost_head_tail(const UpGhostHeadParams& p, co
 template <class T, int DBG = 0>
 __global__ __launch_bounds__(UGH_THREADS) void upghost_head_kernel(const UpGhostHeadParams p, const float* __restrict__ Wdw, const float* __restrict__ bdw,
                                                            const float* __restrict__ Wh, const float* __restrict__ bh,
-                                                           const float* __restrict__ Wdh, const float* __restrict__ bdh) {
+                                                           const float* __restrict__ Wdh, const float* __restrict__ bdh) { f16_sat_mode<T>();
     constexpr int TW = UGH_TW, TH = UGH_TH, CG = UGH_CG, CS = CG + 4;
     constexpr int W2 = TW + 4, H2 = TH + 4;
     __shared__ float x1s[H2 * W2 * CS];

@@ -25,7 +25,7 @@ __device__ __forceinline__ float pn2_sqdist(float ax, float ay, float az, float 
 // rows [B*N, ld] (storage type) -> xyz fp32 [B*N, 3]
 struct Pn2XyzParams { const void* X; long ldx; float* xyz; long rows; };
 template <class T>
-__global__ void pn2_xyz_kernel(const Pn2XyzParams p) {
+__global__ void pn2_xyz_kernel(const Pn2XyzParams p) { f16_sat_mode<T>();
     const long idx = long(blockIdx.x) * blockDim.x + threadIdx.x;
     if (idx >= p.rows * 3) return;
     const long row = idx / 3;
@@ -129,7 +129,7 @@ struct GroupParams {
     int B, n, S, nsample; float r2;
 };
 template <class T>
-__global__ __launch_bounds__(256) void pn2_group_kernel(const GroupParams p) {
+__global__ __launch_bounds__(256) void pn2_group_kernel(const GroupParams p) { f16_sat_mode<T>();
     __shared__ int s_idx[4][PN2_MAX_NSAMPLE];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long cent = long(blockIdx.x) * 4 + wave;
@@ -174,7 +174,7 @@ struct InterpParams {
     void* out; long ldo; int B, n, s;
 };
 template <class T>
-__global__ __launch_bounds__(256) void pn2_interp_kernel(const InterpParams p) {
+__global__ __launch_bounds__(256) void pn2_interp_kernel(const InterpParams p) { f16_sat_mode<T>();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long pt = long(blockIdx.x) * 4 + wave;
     if (pt >= long(p.B) * p.n) return;

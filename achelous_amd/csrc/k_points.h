@@ -12,7 +12,7 @@ namespace ach {
 // [B, D, N] (reference layout, utils/dataloader.py:546-547) -> rows [B*N, ld] with channels D..ld-1 zero
 struct PcPrepParams { const void* X; void* Y; int B, D, N; long ld; };
 template <class T, class IO = T>
-__global__ void pc_prep_kernel(const PcPrepParams p) {
+__global__ void pc_prep_kernel(const PcPrepParams p) { f16_sat_mode<T>();
     const long idx = long(blockIdx.x) * blockDim.x + threadIdx.x;
     if (idx >= long(p.B) * p.N * p.ld) return;
     const int c = int(idx % p.ld);
@@ -25,7 +25,7 @@ __global__ void pc_prep_kernel(const PcPrepParams p) {
 // x' = [xyz @ (fc3 + I3), extra features]   (pointnet_utils.py:39-44,106-112)
 struct PcT3Params { const void* X; long ldx; const void* t9; long ldt; void* Y; long ldy; int B, N, D; };
 template <class T>
-__global__ void pc_apply_t3_kernel(const PcT3Params p) {
+__global__ void pc_apply_t3_kernel(const PcT3Params p) { f16_sat_mode<T>();
     const long row = long(blockIdx.x) * blockDim.x + threadIdx.x;
     if (row >= long(p.B) * p.N) return;
     const long b = row / p.N;
@@ -46,7 +46,7 @@ __global__ void pc_apply_t3_kernel(const PcT3Params p) {
 // (bmm(x[N,k], Tf[k,k]), pointnet_utils.py:79-84,116-120)
 struct PcPackParams { const void* t; long ldt; void* Wp; long group_stride; int B, k, NT, ksteps; };
 template <class T>
-__global__ void pc_pack_transform_kernel(const PcPackParams p) {
+__global__ void pc_pack_transform_kernel(const PcPackParams p) { f16_sat_mode<T>();
     const long idx = long(blockIdx.x) * blockDim.x + threadIdx.x;
     if (idx >= long(p.B) * p.k * p.k) return;
     const int j = int(idx % p.k);
@@ -59,7 +59,7 @@ __global__ void pc_pack_transform_kernel(const PcPackParams p) {
 // rows [B*N, ldy]: channels [0,G) = global feature of the sample, [G, G+F) = per-point feature
 struct PcConcatParams { const void* g; long ldg; const void* f; long ldf; void* Y; long ldy; int B, N, G, F; };
 template <class T>
-__global__ void pc_concat_kernel(const PcConcatParams p) {
+__global__ void pc_concat_kernel(const PcConcatParams p) { f16_sat_mode<T>();
     const int C4 = (p.G + p.F) >> 2;                       // one thread = 4 channels (G and F are multiples of 4: 128 + 32)
     const long idx = long(blockIdx.x) * blockDim.x + threadIdx.x;
     if (idx >= long(p.B) * p.N * C4) return;
@@ -75,7 +75,7 @@ __global__ void pc_concat_kernel(const PcConcatParams p) {
 // log_softmax over the class axis; output dense [rows, K]
 struct LsmParams { const void* X; long ldx; void* Y; long rows; int K; };
 template <class T, class IO = T>
-__global__ void log_softmax_kernel(const LsmParams p) {
+__global__ void log_softmax_kernel(const LsmParams p) { f16_sat_mode<T>();
     const long row = long(blockIdx.x) * blockDim.x + threadIdx.x;
     if (row >= p.rows) return;
     const T* x = static_cast<const T*>(p.X) + row * p.ldx;

@@ -26,7 +26,7 @@ static __global__ __launch_bounds__(256) void frame_minmax_kernel(const MinMaxPa
 }
 struct RadarScaleParams { const float* X; const float* partial; void* Y; long per_frame; int S; int B; };
 template <class T>
-__global__ __launch_bounds__(256) void radar_scale_kernel(const RadarScaleParams p) {
+__global__ __launch_bounds__(256) void radar_scale_kernel(const RadarScaleParams p) { f16_sat_mode<T>();
     const long idx = long(blockIdx.x) * blockDim.x + threadIdx.x;
     if (idx >= p.per_frame * p.B) return;
     const long b = idx / p.per_frame;
@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void radar_scale_kernel(const RadarScaleParams
 // ---- points: sklearn.preprocessing.normalize(X[N,D], axis=0) (zero columns are left unchanged) and [N,D] -> [D,N]
 struct PointNormParams { const float* X; void* Y; int B, N, D; };
 template <class T>
-__global__ __launch_bounds__(256) void point_norm_kernel(const PointNormParams p) {
+__global__ __launch_bounds__(256) void point_norm_kernel(const PointNormParams p) { f16_sat_mode<T>();
     __shared__ float red[256];
     const long b = blockIdx.x / p.D;
     const int d = blockIdx.x % p.D;
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void point_norm_kernel(const PointNormParams p
 // ---- image: uint8 HWC (already letterboxed by the host) -> ((v / 255) - mean) / std, CHW
 struct ImagePrepParams { const unsigned char* X; void* Y; int B, H, Wd; };
 template <class T>
-__global__ __launch_bounds__(256) void image_prep_kernel(const ImagePrepParams p) {
+__global__ __launch_bounds__(256) void image_prep_kernel(const ImagePrepParams p) { f16_sat_mode<T>();
     const long idx = long(blockIdx.x) * blockDim.x + threadIdx.x;
     const long HW = long(p.H) * p.Wd;
     if (idx >= HW * p.B) return;
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void image_prep_kernel(const ImagePrepParams p
 // ---- segmentation: class index per pixel (first maximum, as numpy / torch argmax)
 struct SegArgmaxParams { const void* X; unsigned char* Y; int B, C; long HW; };
 template <class T>
-__global__ __launch_bounds__(256) void seg_argmax_kernel(const SegArgmaxParams p) {
+__global__ __launch_bounds__(256) void seg_argmax_kernel(const SegArgmaxParams p) { f16_sat_mode<T>();
     const long idx = long(blockIdx.x) * blockDim.x + threadIdx.x;
     if (idx >= p.HW * p.B) return;
     const long b = idx / p.HW, pix = idx - b * p.HW;
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void seg_argmax_kernel(const SegArgmaxParams p
 // weight 0); rows blended horizontally first, then vertically, in fp32).  OpenCV is not installable in this image: parity unpinned.
 struct SegSoftmaxParams { const void* X; float* P; int B, C; long HW; };
 template <class T>
-__global__ __launch_bounds__(256) void seg_softmax_kernel(const SegSoftmaxParams p) {
+__global__ __launch_bounds__(256) void seg_softmax_kernel(const SegSoftmaxParams p) { f16_sat_mode<T>();
     const long idx = long(blockIdx.x) * blockDim.x + threadIdx.x;
     if (idx >= p.HW * p.B) return;
     const long b = idx / p.HW, pix = idx - b * p.HW;
@@ -200,6 +200,20 @@ static __global__ __launch_bounds__(256) void resample_pass_kernel(const Resampl
     }
     const int v = ss >> 22;                                                   // arithmetic shift, then clip8
     p.dst[long(y) * p.dst_pitch + long(x) * p.C + c] = uint8_t(v < 0 ? 0 : (v > 255 ? 255 : v));
+}
+
+
+// ---- fp16 storage: elements of the plan's activation tensors that are saturated (|x| = 65504, what an overflowing conversion produces under MODE.FP16_OVFL,
+// ach_platform.h f16_sat_mode), infinite or NaN — i.e. halves whose magnitude bits are >= 0x7bff.  blockIdx.y = tensor, grid-stride over its dwords.
+struct SatRegion { const uint32_t* p; unsigned long long dwords; };
+static __global__ __launch_bounds__(256) void sat_count_kernel(const SatRegion* __restrict__ regions, unsigned long long* __restrict__ count) {
+    const SatRegion r = regions[blockIdx.y];
+    unsigned n = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < r.dwords; i += (unsigned long long)gridDim.x * blockDim.x) {
+        const uint32_t w = r.p[i];
+        n += ((w & 0x7fffu) >= 0x7bffu) + (((w >> 16) & 0x7fffu) >= 0x7bffu);
+    }
+    if (n) atomicAdd(count, (unsigned long long)n);
 }
 
 }  // namespace ach

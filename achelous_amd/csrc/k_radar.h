@@ -19,7 +19,7 @@ namespace ach {
 // NCHW [B,C,H,W] -> NHWC [B,H,W,ld] (channels C..ld-1 are left untouched = 0)
 struct ToNhwcParams { const void* X; void* Y; int B, C, H, Wd; long ld; };
 template <class T, class IO = T>      // IO: the type of the caller's tensor (a 16-bit engine may take bf16 inputs into fp16 storage)
-__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const ToNhwcParams p) {
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const ToNhwcParams p) { f16_sat_mode<T>();
     const long total = long(p.B) * p.H * p.Wd;
     const long idx = long(blockIdx.x) * blockDim.x + threadIdx.x;
     if (idx >= total) return;
@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const ToNhwcParams p)
 // 3-channel NCHW -> 4-channel NHWC pixels (8 B in bf16, 16 B in fp32; channel 3 = 0): the layout of the first RCBlock's maps.
 // One thread = 4 consecutive pixels of a row: one vector load per plane, four pixels written as one contiguous 32 / 64 bytes.
 template <class T, class IO = T>
-__global__ __launch_bounds__(256) void nchw3_to_nhwc4_kernel(const ToNhwcParams p) {
+__global__ __launch_bounds__(256) void nchw3_to_nhwc4_kernel(const ToNhwcParams p) { f16_sat_mode<T>();
     const long HW = long(p.H) * p.Wd, quads = HW / 4;
     const long idx = long(blockIdx.x) * blockDim.x + threadIdx.x;
     if (idx >= long(p.B) * quads) return;
@@ -58,7 +58,7 @@ struct PoolParams { const void* X; long ldx; void* Y; long ldy; int B, H, Wd, C;
 // (AVG_OW = 1 for maps with fewer than 16 channels: with one or two channel groups per pixel a strip per lane spreads a wave's
 // loads over 4x more cache lines and the texture path becomes the limit — measured 47 -> 55 us on the 3-channel 320x320 map.)
 template <class T, int AVG_OW>
-__global__ __launch_bounds__(256) void avgpool3x3_kernel(const PoolParams p) {
+__global__ __launch_bounds__(256) void avgpool3x3_kernel(const PoolParams p) { f16_sat_mode<T>();
     const int cq = (p.C + 3) >> 2;
     const int strips = (p.Wd + AVG_OW - 1) / AVG_OW;
     const long total = long(p.B) * p.H * strips * cq;
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void avgpool3x3_kernel(const PoolParams p) {
 struct PoolNchwParams { const void* X; void* Y; long ldy; int B, H, Wd; long ypr, ypi; unsigned short* occ; };
 constexpr int POOLN_ROWS = 4;            // output rows per thread: 6 input rows are fetched and converted for 4 output rows instead of 12 (one row per thread: 50.7 us at batch 64)
 template <class T, class IO>
-__global__ __launch_bounds__(256) void avgpool3x3_nchw3_kernel(const PoolNchwParams p) {
+__global__ __launch_bounds__(256) void avgpool3x3_nchw3_kernel(const PoolNchwParams p) { f16_sat_mode<T>();
     static_assert(sizeof(T) == 2 && sizeof(IO) == 2, "16-bit storage");
     const int strips = p.Wd / 4, rblocks = p.H / POOLN_ROWS;               // H % POOLN_ROWS == 0 (engine)
     const long total = long(p.B) * rblocks * strips;
@@ -240,7 +240,7 @@ struct DeformParams {
 // C <= 8: sampling + contraction + ReLU + residual in one pass, one thread per pixel.  CP = channels fetched per corner (4 or 8).
 // The folded weights are wave-uniform: passed as __restrict__ kernel arguments so they are fetched with scalar loads.
 template <class T, int C, int CP>
-__global__ __launch_bounds__(256) void deform_fused_kernel(const DeformParams p, const float* __restrict__ Wf, const float* __restrict__ bf) {
+__global__ __launch_bounds__(256) void deform_fused_kernel(const DeformParams p, const float* __restrict__ Wf, const float* __restrict__ bf) { f16_sat_mode<T>();
     const long total = long(p.B) * p.H * p.Wd;
     const long idx = long(xcd_block(blockIdx.x, gridDim.x)) * blockDim.x + threadIdx.x;
     if (idx >= total) return;
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void deform_fused_kernel(const DeformParams p,
 
 // generic: one thread per (pixel, tap, 4-channel group) writes the masked bilinear sample into the column buffer
 template <class T>
-__global__ __launch_bounds__(256) void deform_sample_kernel(const DeformParams p) {
+__global__ __launch_bounds__(256) void deform_sample_kernel(const DeformParams p) { f16_sat_mode<T>();
     const int cq = p.Cp >> 2;
     const long total = long(p.B) * p.H * p.Wd * 9 * cq;
     const long idx = long(xcd_block(blockIdx.x, gridDim.x)) * blockDim.x + threadIdx.x;

@@ -38,7 +38,7 @@ constexpr int SDTA_MAXPPT = ACH_SDTA_MAXPPT;            // pixels per thread (H 
 constexpr int SDTA_LDS_FLOATS = ACH_SDTA_LDS;    // 56 KB: H * W * Q float4
 
 template <class T>
-__global__ __launch_bounds__(SDTA_THREADS) void sdta_pre_kernel(const SdtaPreParams p) {
+__global__ __launch_bounds__(SDTA_THREADS) void sdta_pre_kernel(const SdtaPreParams p) { f16_sat_mode<T>();
     __shared__ __attribute__((aligned(16))) float s[SDTA_LDS_FLOATS];
     __shared__ float4 wl[10 * 8];            // [tap 0..8, bias][quad]
     const int HW = p.H * p.Wd, per = p.conv_wgs + p.tail_wgs;

@@ -33,7 +33,7 @@ struct UpGhostChainParams {
 // compiler's free choice of 132), three at Cg = 24 / 32 (two workgroups of 6 / 8 waves per CU)
 #define ACH_UPC_BOUNDS(CG) __launch_bounds__(16 * CG, (ACH_UPC_WAVES > 0 ? ACH_UPC_WAVES : (CG <= 16 ? 4 : 3)))
 template <class T, int CG>
-__global__ ACH_UPC_BOUNDS(CG) void upghost_chain_kernel(const UpGhostChainParams q) {
+__global__ ACH_UPC_BOUNDS(CG) void upghost_chain_kernel(const UpGhostChainParams q) { f16_sat_mode<T>();
     constexpr int TS = UPG_TS, HS = TS + 2, CQ = CG / 4, K1 = (2 * CG + 31) / 32, NW = 16 * CG / 64;
     // one buffer: x1 (fp32, tile + halo) in phases 1-2, then the B fragments of the tile's 16 rows (the depthwise results wait in registers
     // across the barrier): 21 / 33 / 42 KB for Cg = 16 / 24 / 32 instead of 37 / 64 / 74 — the kernel is latency-bound, workgroups per CU matter

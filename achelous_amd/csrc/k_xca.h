@@ -25,7 +25,7 @@ struct XcaGramParams { const void* qkv; long ld; float* partial; int B, N, C, he
 
 // partial layout per (b, h, s): [d*d gram | d sum q^2 | d sum k^2]
 template <class T, int XCA_DMAX>
-__global__ __launch_bounds__(256) void xca_gram_kernel(const XcaGramParams p) {
+__global__ __launch_bounds__(256) void xca_gram_kernel(const XcaGramParams p) { f16_sat_mode<T>();
     constexpr int TOK = 16;
     __shared__ float qs[TOK][XCA_DMAX];
     __shared__ float ks[TOK][XCA_DMAX];
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void xca_gram_kernel(const XcaGramParams p) {
 #define ACH_XCA_BOUNDS __launch_bounds__(256)
 #endif
 template <class T, int XCA_DMAX>
-__global__ ACH_XCA_BOUNDS void xca_gram_mfma_kernel(const XcaGramParams p) {
+__global__ ACH_XCA_BOUNDS void xca_gram_mfma_kernel(const XcaGramParams p) { f16_sat_mode<T>();
     constexpr int VEC = Store<T>::VEC, KC = 4 * VEC;        // tokens per MFMA k-step
     constexpr int CH = 4 * KC;                              // tokens staged per round
     constexpr int PITCH = CH + VEC;                         // + 16 bytes: rows land on different banks
@@ -206,7 +206,7 @@ struct XcaFinalParams {
 };
 
 template <class T, int XCA_DMAX>
-__global__ __launch_bounds__(256) void xca_finalize_kernel(const XcaFinalParams p) {
+__global__ __launch_bounds__(256) void xca_finalize_kernel(const XcaFinalParams p) { f16_sat_mode<T>();
     __shared__ __attribute__((aligned(16))) float A[XCA_DMAX][XCA_DMAX + 4];     // rows 16-byte aligned: the fold reads four columns at once
     __shared__ float nq[XCA_DMAX], nk[XCA_DMAX];
     __shared__ float wps[XCA_CT][XCA_DMAX + 1];

@@ -40,7 +40,7 @@ class NativeLibrary:
                'ach_normalize_points', 'ach_preprocess_image', 'ach_seg_argmax', 'ach_seg_resize_argmax', 'ach_correct_boxes', 'ach_train_gemm', 'ach_train_bn_stats', 'ach_train_bn_relu_fwd', 'ach_train_bn_relu_bwd', 'ach_train_dw3x3', 'ach_train_dw3x3_wgrad', 'ach_train_max_points', 'ach_train_log_softmax', 'ach_resample_pass_u8', 'ach_train_act', 'ach_train_mul', 'ach_train_layernorm', 'ach_train_layernorm_bwd', 'ach_train_dwconv', 'ach_train_dwconv_wgrad',
                'ach_train_im2col', 'ach_train_softmax', 'ach_train_upsample2x', 'ach_train_maxpool', 'ach_train_avgpool3', 'ach_train_row_reduce', 'ach_train_row_scale',
                'ach_train_col_reduce', 'ach_train_col_scale', 'ach_train_instnorm', 'ach_train_l2norm', 'ach_train_deform_im2col', 'ach_train_deform_bwd',
-               'ach_record_words', 'ach_all_gather_records')
+               'ach_record_words', 'ach_all_gather_records', 'ach_count_saturated')
 
     def __init__(self, path):
         if not os.path.exists(path):
@@ -132,6 +132,8 @@ class NativeLibrary:
         L.ach_record_words.restype = sz
         L.ach_all_gather_records.argtypes = [vp, vp, vp, vp, i32, i32, vp]
         L.ach_all_gather_records.restype = ctypes.c_int
+        L.ach_count_saturated.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_uint64)]
+        L.ach_count_saturated.restype = ctypes.c_int
         L.ach_tap_count.argtypes = [vp]
         L.ach_tap_count.restype = ctypes.c_int
         L.ach_tap_name.argtypes = [vp, ctypes.c_int]
@@ -277,6 +279,13 @@ class NativeEngine:
 
     def forwards_in_flight(self):
         return int(self.L.ach_forwards_in_flight(self.h))
+
+    def count_saturated(self, stream=0):
+        """fp16-storage engine: elements of the plan's activation tensors that are saturated (+-65504) or non-finite after the forwards
+        enqueued on `stream` so far (synchronises the stream); always 0 for the fp32 / bf16 engines (include/achelous.h)."""
+        n = ctypes.c_uint64(0)
+        self._check(self.L.ach_count_saturated(self.h, ctypes.c_void_p(stream), ctypes.byref(n)))
+        return int(n.value)
 
     def op_table(self):
         """[(name, algorithmic bytes, flops)] of every launch in the plan."""

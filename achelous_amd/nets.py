@@ -146,6 +146,13 @@ class Achelous(nn.Module):
         # instead of 8, the type the reference's own mixed-precision mode computes in (utils/utils_fit.py:120-121) — converted from / to bf16 in
         # the first / last kernels; 'bf16' = bf16 end to end (round 3's engine).  fp16 inputs always run the fp16 engine.
         self.bf16_storage = 'f16'
+        # fp16 overflows at 65504 where bf16 does not.  The fp16 engine's kernels run with MODE.FP16_OVFL (an overflowing conversion clamps to +-65504 instead of
+        # becoming infinity), and the module checks the activation tensors of the FIRST forward after every weight change for saturated / non-finite elements
+        # (ach_count_saturated, ~1 ms + one stream synchronisation): if there are any and the caller's tensors are bf16, the module warns, switches
+        # `bf16_storage` to 'bf16' and recomputes that forward with bf16 storage; fp16 callers chose the type themselves and only get the warning.
+        # 'first' (default) | 'always' (every forward: a debugging aid, it serialises the stream) | 'off'
+        self.f16_guard = 'first'
+        self.f16_saturated = 0      # what the last check counted
 
     # engines hold ctypes handles: never pickle / deepcopy them (utils_fit.py:378 pickles the module, ModelEMA deep-copies it)
     def __getstate__(self):
@@ -243,7 +250,7 @@ class Achelous(nn.Module):
                 eng.set_option(k, int(v))
             if pipelined:
                 eng.set_option('pipeline', 1)
-            ent = [eng, None]
+            ent = [eng, None, None]          # engine, weights version loaded, weights version the fp16 range guard has checked
             # LRU per (device, dtype): a serving loop over frames with varying point counts (the reference takes any N) would
             # otherwise grow one full engine per 16-point bucket until hipMalloc fails.  Evicted engines are destroyed (ach_destroy
             # frees both arenas); one with a pipelined forward still un-joined is never the victim.
@@ -341,6 +348,31 @@ class Achelous(nn.Module):
             return res
         return res, tuple(torch.cat([r[k] for r in recs], 0)[:B] for k in range(3))
 
+    def _f16_range_check(self, eng, dev, dt, stream, pipelined):
+        """The fp16 range guard (see `f16_guard` in __init__).  True = the forward just enqueued saturated and must be recomputed with bf16 storage."""
+        mode = self.__dict__.get('f16_guard', 'first')
+        if mode == 'off' or eng.dtype != _eng.DTYPE_F16:
+            return False
+        ent = next(v for v in self._engines.values() if v[0] is eng)
+        if mode != 'always' and ent[2] == ent[1]:
+            return False
+        if pipelined:                       # the decoders / detection tail of this forward are still on the side streams: join them first
+            while eng.forwards_in_flight() > 0:
+                eng.join(stream)
+        n = self.f16_saturated = eng.count_saturated(stream)
+        ent[2] = ent[1]
+        if n == 0:
+            return False
+        import warnings
+        if dt == torch.bfloat16 and self.__dict__.get('bf16_storage', 'f16') == 'f16':
+            warnings.warn(f"achelous_amd: {n} activation elements reached the fp16 range limit (65504) with these weights / inputs; "
+                          f"switching this module to bf16 storage (model.bf16_storage = 'bf16') and recomputing the forward", RuntimeWarning, stacklevel=4)
+            self.bf16_storage = 'bf16'
+            return True
+        warnings.warn(f"achelous_amd: {n} activation elements reached the fp16 range limit (65504); they were clamped, the outputs are not "
+                      f"reliable.  Use bfloat16 or float32 inputs for this checkpoint", RuntimeWarning, stacklevel=4)
+        return False
+
     def _run(self, x, x_radar, x_point_clouds, detect, pipelined=False):
         if self.training:
             raise NotImplementedError("achelous_amd.Achelous runs eval-mode inference only; call .eval() first")
@@ -378,6 +410,8 @@ class Achelous(nn.Module):
                 return det, se, lane, (pc if N == n_in else pc[:, :n_in].contiguous())
             if detect is None:
                 eng.forward(x, x_radar, pts, (det[0], det[1], det[2], se, lane, pc), stream)
+                if self._f16_range_check(eng, dev, dt, stream, pipelined):
+                    return self._run(x, x_radar, x_point_clouds, detect, pipelined)
                 if pipelined:
                     return PendingForward(eng, dev, (x, x_radar, pts), outputs)
                 return outputs()
@@ -396,6 +430,8 @@ class Achelous(nn.Module):
             rows._ach_record = rec
             ws = torch.empty(eng.nms_workspace_bytes(B), dtype=torch.uint8, device=dev)
             eng.forward_detect(x, x_radar, pts, (det[0], det[1], det[2], se, lane, pc), decoded, conf, iou, max_det, rows, idx, cnt, ws, stream)
+            if self._f16_range_check(eng, dev, dt, stream, pipelined):
+                return self._run(x, x_radar, x_point_clouds, detect, pipelined)
             # scratch is released to the caching allocator in stream order: the join at the end of the call orders it after the side stream
         if pipelined:
             return PendingForward(eng, dev, (x, x_radar, pts, decoded, ws), lambda: (outputs(), (rows, idx, cnt)))

@@ -201,6 +201,14 @@ int ach_seg_resize_argmax(ach_handle* h, int32_t batch, int32_t channels, const 
 int ach_correct_boxes(ach_handle* h, int32_t batch, int32_t max_det, const float* rows, const int32_t* count, int32_t image_h, int32_t image_w,
                       int32_t letterbox, float* out_rows, void* stream);
 
+/* Range guard of the fp16-storage engine (ACH_DTYPE_F16).  The reference runs fp32 or, under autocast, fp16 WITH torch's GradScaler / inf checks
+ * (utils/utils_fit.py:120-166); bf16 callers (BASELINE configs[1]) are served by fp16 storage inside, which overflows at 65504 where bf16 does not.
+ * Every kernel of that engine therefore runs with MODE.FP16_OVFL (overflowing conversions clamp to +-65504, never infinity), and this entry counts the
+ * elements of the plan's activation tensors that are saturated or non-finite after the forward(s) enqueued on `stream` so far (it synchronises the
+ * stream; ~1 ms at batch 64).  0 = the forward stayed inside the fp16 range.  Always 0 for the fp32 / bf16 engines.  The Python module checks a
+ * model's first forward with it and falls back to bf16 storage when it is not 0 (achelous_amd/nets.py, `f16_guard`). */
+int ach_count_saturated(ach_handle* h, void* stream, uint64_t* count);
+
 /* test hooks: intermediate tensors of the last ach_forward, converted to fp32 NCHW (or [rows, C]) on the host */
 int ach_tap_count(const ach_handle* h);
 const char* ach_tap_name(const ach_handle* h, int i);

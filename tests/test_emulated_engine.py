@@ -725,3 +725,45 @@ def test_emulated_neck_band_kernels_are_bit_identical_to_the_separate_launches(n
     for a, b in zip(outs[1], outs[0]):
         assert torch.equal(a, b)
     assert float(outs[1][3].float().abs().max()) > 0
+
+
+def test_emulated_f16_storage_saturates_and_counts_instead_of_overflowing():
+    """fp16 storage overflows at 65504 where bf16 does not.  Every kernel of the fp16 engine sets MODE.FP16_OVFL — an overflowing conversion
+    clamps to +-65504 (ach_platform.h f16_sat_mode; the host converter the emulation uses saturates the same way) — and ach_count_saturated counts the
+    clamped / non-finite elements of the plan's activation tensors.  A stem LayerNorm gain of 3e5 (residual stream ~1e5 .. 1e6) must: be COUNTED by the
+    fp16 engine, leave every output finite (no inf - inf = NaN downstream), and be no event at all for the bf16 and fp32 engines (count 0, finite); with
+    the conditioned weights the fp16 engine counts 0."""
+    kw, sd, (x, xr, xp) = _setup('en_s0', 64, 2, 16)
+    big = dict(sd)
+    k = 'image_radar_encoder.fpn.backbone.downsample_layers.0.1.weight'
+    big[k] = sd[k] * 3e5
+    counts = {}
+    for tag, state in (('conditioned', sd), ('large', big)):
+        for dt in (DTYPE_F16, DTYPE_BF16, DTYPE_F32):
+            eng = make_engine(emu_library(), kw, 2, state, 16, dt, full_taps=False)
+            td = TORCH_DTYPE[dt]
+            outs = alloc_outputs(kw, 2, 16, td, 'cpu')
+            eng.forward(x.to(td), xr.to(td), xp.to(td), outs)
+            counts[tag, dt] = eng.count_saturated()
+            if dt == DTYPE_F16 or tag == 'conditioned':
+                for o in outs:
+                    assert torch.isfinite(o.float()).all(), (tag, dt)
+    assert counts['conditioned', DTYPE_F16] == 0
+    assert counts['large', DTYPE_F16] > 0
+    assert counts['large', DTYPE_BF16] == 0 and counts['large', DTYPE_F32] == 0 and counts['conditioned', DTYPE_BF16] == 0
+
+
+@pytest.mark.parametrize('sdt', H16)
+def test_emulated_point_branch_does_not_depend_on_the_batch(sdt):
+    """pc_pair presents B x N points to the two-layer chain kernel as ONE map, so the four-waves-per-tile mode (another fp32 summation order)
+    used to be chosen by B * N <= 16 * mlp_split_hw — batches 1-2 at N = 512 took it, batch 3 and above did not.  A frame's point-cloud output must be
+    bit-identical whatever batch it is part of."""
+    npts = 512
+    kw, sd, (x, xr, xp) = _setup('en_s0', 64, 4, npts)
+    res = {}
+    for B in (1, 4):
+        eng = make_engine(emu_library(), kw, B, sd, npts, sdt[0], full_taps=False)
+        outs = alloc_outputs(kw, B, npts, sdt[1], 'cpu')
+        eng.forward(x[:B].to(sdt[1]), xr[:B].to(sdt[1]), xp[:B].to(sdt[1]), outs)
+        res[B] = outs[5][0].clone()
+    assert torch.equal(res[1], res[4])

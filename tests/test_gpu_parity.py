@@ -36,13 +36,17 @@ H16_NMS_SCORE_MARGIN, H16_NMS_IOU_MARGIN = 0.02, 0.06      # decision of the tru
 H16_NMS_FLOOR = 0.85
 
 
-def nms_unexplained(dec, kept_truth, kept_got, num_det, conf, iou):
+def nms_unexplained(dec, kept_truth, kept_got, num_det, conf, iou, rules=None):
     """Greedy NMS is discontinuous: an anchor whose score sits at the confidence threshold, or whose IoU with a better box sits at the NMS
     threshold, flips under ANY perturbation, and a flip changes which later boxes survive.  Returns the anchors in the symmetric difference of
     the two kept sets that are NOT such marginal decisions of the TRUTH `dec` [A, 5 + C] (decoded, one frame): an anchor is explained when
     (a) |obj * cls - conf| <= H16_NMS_SCORE_MARGIN, or (b) some same-class candidate has |IoU - iou| <= H16_NMS_IOU_MARGIN with it, or
     (c) it overlaps (IoU > iou - margin) an anchor of the symmetric difference that is already explained (the cascade).  utils_bbox.py:109-130."""
     diff = sorted(set(kept_truth) ^ set(kept_got))
+    if rules is None:
+        rules = {}
+    for k in ('score', 'iou', 'cascade', 'unexplained'):
+        rules.setdefault(k, 0)
     if not diff:
         return []
     d = dec.double()
@@ -61,8 +65,10 @@ def nms_unexplained(dec, kept_truth, kept_got, num_det, conf, iou):
     for i in diff:
         same = cand[(cls_id[cand] == cls_id[i]) & (cand != i)]
         v = iou_with(i, same) if len(same) else torch.zeros(0, dtype=torch.float64)
-        if abs(float(score[i]) - conf) <= H16_NMS_SCORE_MARGIN or bool(((v - iou).abs() <= H16_NMS_IOU_MARGIN).any()):
-            explained.add(i)
+        if abs(float(score[i]) - conf) <= H16_NMS_SCORE_MARGIN:
+            explained.add(i); rules['score'] += 1
+        elif bool(((v - iou).abs() <= H16_NMS_IOU_MARGIN).any()):
+            explained.add(i); rules['iou'] += 1
         else:
             rest.append(i)
     changed = True
@@ -71,8 +77,14 @@ def nms_unexplained(dec, kept_truth, kept_got, num_det, conf, iou):
         for i in list(rest):
             js = torch.tensor([j for j in explained if int(cls_id[j]) == int(cls_id[i])], dtype=torch.long)
             if len(js) and bool((iou_with(i, js) > iou - H16_NMS_IOU_MARGIN).any()):
-                explained.add(i); rest.remove(i); changed = True
+                explained.add(i); rest.remove(i); changed = True; rules['cascade'] += 1
+    rules['unexplained'] += len(rest)
     return rest
+
+
+# the two rules that excuse an anchor WITHOUT a margin of its own — the cascade (it overlaps an anchor that is itself excused) and the rank
+# at the max_det cut — may excuse at most this many anchors per frame; the counts per rule are printed per frame (profiles/r05_parity_table.txt)
+H16_NMS_MAX_INDIRECT = 2
 
 
 def truth_outputs(sd, kw, x, xr, xp):
@@ -95,24 +107,34 @@ def check_h16_decisions(tag, truth, got_se, got_lane, kept, resolution, num_det,
         exp = o_nms(tdec.clone(), num_det, conf, iou)
         idx, cnt = kept[(conf, iou)]
         cap = idx.shape[1]
-        jac, unexpl = [], []
+        jac, unexpl, excused = [], [], []
         for b in range(idx.shape[0]):
             want_full = [int(i) for i in exp[b][1]]
             want = want_full[:cap]
             got = [int(i) for i in idx[b, :int(cnt[b])].tolist()]
             j = len(set(want) & set(got)) / max(1, len(set(want) | set(got)))
             # below H16_NMS_JACCARD every differing anchor must be a marginal decision of the truth (and the set must not fall under the floor)
-            u = nms_unexplained(tdec[b], want, got, num_det, conf, iou) if j < H16_NMS_JACCARD else []
+            rules = {}
+            u = nms_unexplained(tdec[b], want, got, num_det, conf, iou, rules) if j < H16_NMS_JACCARD else []
+            rules['rank_at_cut'] = 0
             if u and len(want_full) >= cap:
                 # a frame whose kept list is cut at `cap` (max_det, score order) has a third kind of marginal decision, the rank at the cut: an anchor the truth keeps
                 # BEYOND the cut appears in the engine's list when k flips ahead of it drop out, and the last k of the truth's first `cap` leave when k flips enter
                 k_in = len(set(got) - set(want))
                 tail = set(want[max(0, cap - k_in):])
-                u = [a for a in u if not ((a in got and a in want_full) or a in tail)]
+                u2 = [a for a in u if not ((a in got and a in want_full) or a in tail)]
+                rules['rank_at_cut'] = len(u) - len(u2)
+                u = u2
             jac.append(round(j, 4)); unexpl.append(len(u))
+            if j < H16_NMS_JACCARD:
+                excused.append((b, round(j, 3), {k: v for k, v in rules.items() if v and k != 'unexplained'}))
             if j < H16_NMS_JACCARD and (u or j < H16_NMS_FLOOR):
                 problems.append(('nms', (conf, iou), b, j, u[:8]))
+            if rules.get('cascade', 0) > H16_NMS_MAX_INDIRECT or rules['rank_at_cut'] > H16_NMS_MAX_INDIRECT:
+                problems.append(('nms-indirect-excuses', (conf, iou), b, j, dict(rules)))
         report[(conf, iou)] = (jac, unexpl)
+        if excused:
+            print(f'{tag}: NMS conf {conf} iou {iou}: frames below Jaccard {H16_NMS_JACCARD} and what excused their differing anchors (frame, Jaccard, anchors per rule): {excused}')
     print(f'{tag}: 16-bit decisions vs fp32 truth: arg-max agreement {agree}; on decisive pixels {dec}; NMS kept-set (Jaccard, anchors not explained by a marginal decision of the truth) {report}')
     for k in ('se', 'lane'):
         if dec[k] != 1.0:
@@ -461,11 +483,22 @@ def test_full_batch_64_frames_match_oracle(name):
             (det, se, lane, pc), (rows, idx, cnt) = m.forward_detect(x64.cuda().to(dt), r64.cuda().to(dt), p64.cuda().to(dt), 0.35, 0.35, 100)
         got = dict(zip(OUTPUTS, (*det, se, lane, pc)))
         errs = {k: _rel(got[k][pick].float(), want[k]) for k in OUTPUTS}
-        # (MobileViT-S2's water-line map is the one output above 2e-2: 3.5e-2 on these frames, 2.3e-2 on the fixture's — bounded by VERDICT r3's 5e-2)
-        bound = {k: (F32_TOL if dt == torch.float32 else (5e-2 if (kw['backbone'] == 'mv' and k == 'lane_seg') else H16_TOL_SAME_INPUTS)) for k in OUTPUTS}
+        # (MobileViT-S2's water-line map is the one output above 2e-2: 2.7e-2 on these frames, 2.3e-2 on the fixture's — held to H16_TOL's 3e-2; round 4 allowed 5e-2)
+        bound = {k: (F32_TOL if dt == torch.float32 else (H16_TOL['lane_seg'] if (kw['backbone'] == 'mv' and k == 'lane_seg') else H16_TOL_SAME_INPUTS)) for k in OUTPUTS}
         print(f'{name} B=64 frames {pick} vs oracle, {dt}:', {k: f'{v:.1e} ({bound[k]:.1e})' for k, v in errs.items()})
         for k, v in errs.items():
             assert v < bound[k], (name, dt, k, v, bound[k])
+        if dt != torch.float32:
+            # ALSO against the truth on the UN-rounded fp32 inputs, flat H16_TOL.  What the rounding of the inputs alone does to the truth
+            # (the oracle on bf16-rounded inputs against the oracle on fp32 inputs — no engine involved) is printed beside it and ADDED to the bound: an engine
+            # that is handed bf16 tensors cannot undo their rounding (EN-S0: se 1.4e-2, lane 2.0e-2 before any engine arithmetic; MV-S2 lane 0.8e-2).
+            floor = {k: _rel(want[k], want32[k]) for k in OUTPUTS}
+            errs32 = {k: _rel(got[k][pick].float(), want32[k]) for k in OUTPUTS}
+            bound32 = {k: H16_TOL[k] + floor[k] for k in OUTPUTS}
+            print(f'{name} B=64 frames {pick} vs oracle on the UN-rounded inputs, {dt}: err (bound; input-rounding floor):',
+                  {k: f'{errs32[k]:.1e} ({bound32[k]:.1e}; {floor[k]:.1e})' for k in OUTPUTS})
+            for k in OUTPUTS:
+                assert errs32[k] < bound32[k], (name, dt, k, errs32[k], bound32[k], floor[k])
         kept = {(0.35, 0.35): (idx[pick].cpu(), cnt[pick].cpu())}
         if dt == torch.float32:
             a_se, a_lane = decisions(got['se_seg'][pick].cpu(), got['lane_seg'][pick].cpu())
@@ -653,8 +686,9 @@ def test_fused_kernels_agree_with_the_layerwise_path(option):
             e.set_option(option, default)
             e.plan(2)
         for k, a, b in zip(OUTPUTS, (*alt[0], alt[1], alt[2], alt[3]), (*ref[0], ref[1], ref[2], ref[3])):
-            # two bf16 plans that are each within bf16_bound of the fp32 truth may differ from each other by twice that
-            tol = 1e-4 if dt == torch.float32 else 2.0 * bf16_bound(g, k)
+            # two 16-bit plans that are each within H16_TOL of the fp32 truth may differ from each other by twice that
+            # (twice the bound each plan is held to against the truth — H16_TOL — not round 3's 2 x bf16_bound >= 4e-2)
+            tol = 1e-4 if dt == torch.float32 else 2.0 * H16_TOL[k]
             assert _rel(a.float(), b.float()) <= tol, (option, dt, k, _rel(a.float(), b.float()), tol)
 
 
@@ -872,3 +906,87 @@ def test_three_task_module_and_wide_head():
         det16 = mw(x.cuda().bfloat16(), xr.cuda().bfloat16(), xp.cuda().bfloat16())[0]
     for k in range(3):
         assert _rel(det[k], ref[0][k]) <= F32_TOL and _rel(det16[k].float(), ref[0][k]) <= 2e-2, (k, _rel(det[k], ref[0][k]), _rel(det16[k].float(), ref[0][k]))
+
+
+def test_row_walking_head_serves_plans_of_any_batch():
+    """VERDICT r4 item 3.  The row-walking decoder head addresses one SAMPLE at a time (64-bit base per frame, 32-bit offsets inside it); round 4's plan-time test
+    was on the whole batch's element count and silently dropped plans above ~145 frames back to the LDS-tile head (0.092 of the HBM peak instead of 0.23).  The two
+    head kernels round [x1 | x2] at different points, so BIT-identical segmentation maps for the same frames in a 160-frame plan and in a 64-frame plan say that
+    the large plan runs the row-walking kernel; a 16-frame plan with head_rows = 0 must differ (the check has teeth)."""
+    g = Golden('en_s0')
+    m, kw = _model(g)
+    m.max_plan_batch = 512
+    x, xr, xp = make_inputs(64, 777, resolution=kw['resolution'], pc_channels=kw['pc_channels'])
+    dt = torch.bfloat16
+    xs, rs, ps = x.cuda().to(dt), xr.cuda().to(dt), xp.cuda().to(dt)
+    rep = torch.arange(160) % 64
+    with torch.no_grad():
+        _, se64, la64, _ = m(xs, rs, ps)
+        se64, la64 = se64.clone(), la64.clone()
+        _, se160, la160, _ = m(xs[rep].contiguous(), rs[rep].contiguous(), ps[rep].contiguous())
+        torch.cuda.synchronize()
+        assert _engine_of(m, dt).batch == 160
+        for b in (0, 63, 64, 100, 159):
+            assert torch.equal(se160[b], se64[b % 64]) and torch.equal(la160[b], la64[b % 64]), b
+        e = _engine_of(m, dt)
+        e.set_option('head_rows', 0)
+        e.plan(16)
+        _, se_t, la_t, _ = m(xs[:16], rs[:16], ps[:16])
+        torch.cuda.synchronize()
+        assert not torch.equal(se_t, se64[:16])
+        assert _rel(se_t.float(), se64[:16].float()) < 2e-2
+
+
+def test_f16_range_guard_counts_saturation_and_falls_back_to_bf16_storage():
+    """ADVICE r4 (medium).  bf16 callers are served by fp16 storage inside (overflow at 65504 where bf16 has fp32's range).  The fp16 engine's kernels run with
+    MODE.FP16_OVFL — an overflowing conversion clamps, it never becomes infinity — ach_count_saturated counts the clamped elements, and the module checks the first
+    forward after every weight change: on saturation it warns, switches to bf16 storage and recomputes.  Conditioned weights: count 0, fp16 storage stays.
+    Stem LayerNorm gain x 3e5 (residual stream 1e5 .. 1e6, fine in bf16): the guard must fire, the served outputs must be the bf16-storage engine's, finite."""
+    import warnings
+    g = Golden('en_s0')
+    m, kw = _model(g)
+    x, xr, xp = make_inputs(2, 5, resolution=kw['resolution'], pc_channels=kw['pc_channels'])
+    xs, rs, ps = x.cuda().bfloat16(), xr.cuda().bfloat16(), xp.cuda().bfloat16()
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter('error')
+        m(xs, rs, ps)
+    assert m.bf16_storage == 'f16' and m.f16_saturated == 0 and _engine_of(m, torch.bfloat16).dtype == eng_mod.DTYPE_F16
+    with torch.no_grad():
+        m.get_parameter('image_radar_encoder.fpn.backbone.downsample_layers.0.1.weight').mul_(3e5)
+    with torch.no_grad(), pytest.warns(RuntimeWarning, match='fp16 range'):
+        det, se, lane, pc = m(xs, rs, ps)
+    torch.cuda.synchronize()
+    assert m.f16_saturated > 0 and m.bf16_storage == 'bf16'
+    assert _engine_of(m, torch.bfloat16).dtype == eng_mod.DTYPE_BF16
+    for t in (*det, se, lane, pc):
+        assert torch.isfinite(t.float()).all()
+    # the served result IS the bf16-storage engine's
+    m2, _ = _model(g)
+    m2.bf16_storage = 'bf16'
+    with torch.no_grad():
+        m2.get_parameter('image_radar_encoder.fpn.backbone.downsample_layers.0.1.weight').mul_(3e5)
+        det2, se2, lane2, pc2 = m2(xs, rs, ps)
+    assert torch.equal(se, se2) and torch.equal(det[0], det2[0])
+    # the raw fp16 engine on the same weights: saturated, but FINITE (no inf - inf = NaN downstream)
+    m3, _ = _model(g)
+    m3.f16_guard = 'off'
+    with torch.no_grad():
+        m3.get_parameter('image_radar_encoder.fpn.backbone.downsample_layers.0.1.weight').mul_(3e5)
+        det3, se3, lane3, pc3 = m3(xs, rs, ps)
+    torch.cuda.synchronize()
+    assert _engine_of(m3, torch.bfloat16).count_saturated(torch.cuda.current_stream().cuda_stream) > 0
+    for t in (*det3, se3, lane3, pc3):
+        assert torch.isfinite(t.float()).all()
+
+
+def test_point_branch_does_not_depend_on_the_batch():
+    """the two-layer chain of PointNet's conv3 + conv4 must not pick its four-waves-per-tile mode from B x N (engine_impl.h pc_pair)."""
+    g = Golden('en_s0')
+    m, kw = _model(g)
+    x, xr, xp = make_inputs(4, 41, resolution=kw['resolution'], pc_channels=kw['pc_channels'])
+    for dt in (torch.float32, torch.bfloat16):
+        xs, rs, ps = x.cuda().to(dt), xr.cuda().to(dt), xp.cuda().to(dt)
+        with torch.no_grad():
+            pc4 = m(xs, rs, ps)[3].clone()
+            pc1 = m(xs[:1], rs[:1], ps[:1])[3]
+        assert torch.equal(pc4[:1], pc1), dt
