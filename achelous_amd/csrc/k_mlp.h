@@ -26,6 +26,9 @@
 #include "ach_platform.h"
 #include "k_gemm.h"
 
+#ifndef ACH_MLP_DW_LDS
+#define ACH_MLP_DW_LDS 1                  // one-tile-per-wave kernels: depthwise weights staged in LDS once per workgroup (0 = fetched per tap from global memory, round 4)
+#endif
 #ifndef ACH_MLP_MFMA_PAD
 #define ACH_MLP_MFMA_PAD 0
 #endif
@@ -65,13 +68,16 @@ constexpr int MLP_RED_TILES = 4;          // output tiles reduced per LDS round 
 // the map gets an out-of-range offset and comes back as zeros, so a tap costs one add and one load — no clamps, no 64-bit
 // address arithmetic, no masking of the packed data (this loop is VALU-issue bound: 25 -> 15 instructions per tap).  Rows outside
 // the map are skipped.  The weights are kept in fp32 so that only the activations need unpacking.
-template <class T, int KS>
-__device__ __forceinline__ void mlp_dw(const MlpParams& p, const BufRsrc& xb, long pix0, int oy, int ox, int k0, float* acc, int ty0 = 0, int ty1 = KS) {
+// WL (round 5): the weights come from the workgroup's LDS copy `wl` (same [tap][ldc] layout; mlp_kernel stages it once) instead of global memory: per tap a
+// lane fetched its 8 fp32 weights with two 16-byte VECTOR loads — the address depends on the lane group — i.e. 100 of the 150 texture-path operations of a
+// 5 x 5 / 48-channel tile were weights, on a path the counters put at 62 % busy (profiles/r04_pmc_summary_en_s0.txt, stages.1.0.block).
+template <class T, int KS, bool WL = false>
+__device__ __forceinline__ void mlp_dw(const MlpParams& p, const BufRsrc& xb, long pix0, int oy, int ox, int k0, float* acc, int ty0 = 0, int ty1 = KS, const float* wl = nullptr) {
     constexpr int VEC = Store<T>::VEC;
     constexpr int TG = KS <= 5 ? KS : (KS + 1) / 2;
     constexpr unsigned ESZ = sizeof(T);
     const int ldc = p.k1 * 4 * VEC;
-    const float* wdw = p.Wdw + k0;
+    const float* wdw = (WL ? wl : p.Wdw) + k0;
     const unsigned pitch = unsigned(p.ldx) * ESZ, rowpitch = unsigned(p.W) * pitch;
     const unsigned base = unsigned(pix0) * pitch + unsigned(k0) * ESZ;
     unsigned coff[KS];
@@ -117,8 +123,8 @@ __device__ __forceinline__ void mlp_dw(const MlpParams& p, const BufRsrc& xb, lo
 // k-steps per wave, 5 k-steps (d = 144) are 2 / 1 / 1 / 1 and 3 k-steps (d = 96) 1 / 1 / 1 / 0 — the depthwise phase waits for its slowest wave.
 // Dealing the k1 * KS tap ROWS in four contiguous shares makes that 9 / 9 / 9 / 8 rows instead of 14 / 7 / 7 / 7; the owner of a k-step
 // (as before: wave s % 4) then sums the shares in wave order (deterministic), adds the bias and forms the fragment.
-template <class T, int K1MAX, bool SPLIT, int KS, bool EVEN>
-__device__ __forceinline__ void mlp_inputs(const MlpParams& p, long m, bool valid, int g, int wave, int lane, uint4* xs, uint4* xf, float& s1, float& s2, float* part) {
+template <class T, int K1MAX, bool SPLIT, int KS, bool EVEN, bool WL = false>
+__device__ __forceinline__ void mlp_inputs(const MlpParams& p, long m, bool valid, int g, int wave, int lane, uint4* xs, uint4* xf, float& s1, float& s2, float* part, const float* wl = nullptr) {
     constexpr int VEC = Store<T>::VEC;
     constexpr int KC = 4 * VEC;
     const T* X = static_cast<const T*>(p.X);
@@ -186,9 +192,15 @@ __device__ __forceinline__ void mlp_inputs(const MlpParams& p, long m, bool vali
                 for (int i = 0; i < VEC; ++i) { s1 += v[i]; s2 += v[i] * v[i]; }
             } else {
                 float acc[8];
-                ACH_UNROLL
-                for (int i = 0; i < VEC; ++i) acc[i] = p.bdw[k0 + i];
-                mlp_dw<T, (KS > 0 ? KS : 3)>(p, xb, pix0, oy, ox, k0, acc);
+                if constexpr (WL) {             // bias behind the taps in the LDS copy
+                    const float* bl = wl + KS * KS * (p.k1 * 4 * VEC) + k0;
+                    ACH_UNROLL
+                    for (int q = 0; q < VEC / 4; ++q) { const f32x4 b4 = *reinterpret_cast<const f32x4*>(bl + 4 * q); acc[4 * q] = b4[0]; acc[4 * q + 1] = b4[1]; acc[4 * q + 2] = b4[2]; acc[4 * q + 3] = b4[3]; }
+                } else {
+                    ACH_UNROLL
+                    for (int i = 0; i < VEC; ++i) acc[i] = p.bdw[k0 + i];
+                }
+                mlp_dw<T, (KS > 0 ? KS : 3), WL>(p, xb, pix0, oy, ox, k0, acc, 0, (KS > 0 ? KS : 3), wl);
                 ACH_UNROLL
                 for (int i = 0; i < VEC; ++i) { s1 += acc[i]; s2 += acc[i] * acc[i]; }     // channels >= C: zero weights, zero bias
                 frag = frag_pack<T>(acc);
@@ -240,6 +252,9 @@ __global__ __launch_bounds__(256, (MlpOcc<DT, SPLIT, Store<T>::VEC>::blocks)) vo
     __shared__ uint4 xs[SPLIT ? K1MAX * 64 : 1];         // SPLIT: exchanged input fragments
     __shared__ float st[SPLIT ? 4 * 16 * 2 : 1];         //        per-wave partial LayerNorm sums
     __shared__ float red[SPLIT ? 4 * RT * 4 * 64 : 1];   //        partial outputs, RT tiles per round
+    // one-tile-per-wave kernels of up to 96 channels (stages 0 / 1), depthwise 3 x 3 / 5 x 5: [taps][ldc] weights + [ldc] bias, staged once per workgroup (mlp_dw WL)
+    constexpr bool DWL = ACH_MLP_DW_LDS && !SPLIT && DT <= 6;
+    __shared__ __attribute__((aligned(16))) float wl[DWL ? 26 * K1MAX * KC : 4];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int px = lane & 15, g = lane >> 4;
@@ -255,6 +270,22 @@ __global__ __launch_bounds__(256, (MlpOcc<DT, SPLIT, Store<T>::VEC>::blocks)) vo
     ACH_UNROLL
     for (int s = 0; s < K1MAX; ++s) xf[s] = make_uint4(0u, 0u, 0u, 0u);
     float s1 = 0.f, s2 = 0.f;
+    bool staged = false;
+    if constexpr (DWL) {
+        if (p.dw_k == 3 || p.dw_k == 5) {           // (launch-uniform)
+            const int ldc = p.k1 * KC, nw = p.dw_k * p.dw_k * ldc;
+            for (int i = int(threadIdx.x) * 4; i < nw + ldc; i += 1024)
+                *reinterpret_cast<f32x4*>(wl + i) = *reinterpret_cast<const f32x4*>(i < nw ? p.Wdw + i : p.bdw + (i - nw));
+            __syncthreads();
+            staged = true;
+        }
+    }
+    if (staged) {
+        if constexpr (DWL) {
+            if (p.dw_k == 3) mlp_inputs<T, K1MAX, SPLIT, 3, EVEN, true>(p, m, valid, g, wave, lane, xs, xf, s1, s2, red, wl);
+            else mlp_inputs<T, K1MAX, SPLIT, 5, EVEN, true>(p, m, valid, g, wave, lane, xs, xf, s1, s2, red, wl);
+        }
+    } else
     switch (p.dw_k) {
         case 0: mlp_inputs<T, K1MAX, SPLIT, 0, EVEN>(p, m, valid, g, wave, lane, xs, xf, s1, s2, red); break;
         case 3: mlp_inputs<T, K1MAX, SPLIT, 3, EVEN>(p, m, valid, g, wave, lane, xs, xf, s1, s2, red); break;
