@@ -122,14 +122,93 @@ def all_gather_detections(rows, idx, cnt, group=None, global_batch=None):
 class ShardedDetector:
     """forward + decode + NMS on the local shard (one engine call, Achelous.forward_detect), then the all-gather.  `model` is an
     achelous_amd.Achelous on this rank's GPU.  `__call__` returns the gathered detections; `submit` returns a PendingDetections so
-    that a serving loop can wait for batch k's detections after it has enqueued batch k+1."""
+    that a serving loop can wait for batch k's detections after it has enqueued batch k+1.
 
-    def __init__(self, model, conf_thres=0.35, nms_thres=0.35, max_det=100, group=None, global_batch=None, force_collective=False):
+    Stream-priority calibration.  RCCL's stream is one more ACTIVE stream beside the engine's three, and which of the engine's
+    side streams run at the lowest priority then decides the throughput: measured at world size 1 with the real collective, the patterns
+    3 / 2 / 1 (engine option `side_priority`, a bit mask) gave 38.9 k / 27.4 k / 14.7 k frames/s, and which one wins depends on the number of
+    channels RCCL opens, i.e. on the world size.  So the pattern is MEASURED, in the serving process, with the live collective: the first
+    `submit` / `__call__` (or an explicit `calibrate(...)`) runs the same short pipelined loop under every candidate pattern, takes the
+    MAX over ranks of each time, picks the fastest on rank 0, broadcasts the choice (every rank must build the same plan) and rebuilds the
+    model's engine with it.  `calibrate=False`, or a `side_priority` already present in `model.engine_options`, opts out; without a
+    collective (one rank, not forced) there is nothing to calibrate."""
+
+    PATTERNS = (3, 2, 1)
+
+    def __init__(self, model, conf_thres=0.35, nms_thres=0.35, max_det=100, group=None, global_batch=None, force_collective=False,
+                 calibrate=True, calibrate_steps=20, calibrate_warmup=3):
         self.model, self.conf, self.iou, self.max_det, self.group, self.global_batch = model, conf_thres, nms_thres, max_det, group, global_batch
         self.force_collective = force_collective          # diagnostic: run the collective even at world size 1
+        self.auto_calibrate, self.calibrate_steps, self.calibrate_warmup = bool(calibrate), int(calibrate_steps), int(calibrate_warmup)
+        self.calibration = None                           # {'side_priority_fps': {pattern: frames/s of this rank's shard}, 'side_priority_chosen': p} once measured
+
+    def _collective_active(self):
+        if not dist.is_initialized():
+            return False
+        return dist.get_world_size(self.group) > 1 or self.force_collective
+
+    def _sync(self):
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        if self._collective_active():
+            dist.barrier(self.group)
+
+    @torch.no_grad()
+    def calibrate(self, x, x_radar, x_points, patterns=None, steps=None, warmup=None):
+        """Measure the candidate `side_priority` patterns with the real collective on these (representative) inputs and keep the fastest.
+        Collective call: every rank of the group must make it.  Returns the record also left in `self.calibration`."""
+        import time
+        patterns = tuple(self.PATTERNS if patterns is None else patterns)
+        steps = self.calibrate_steps if steps is None else int(steps)
+        warmup = self.calibrate_warmup if warmup is None else int(warmup)
+        self.auto_calibrate = False                       # (also keeps the loops below from recursing into the automatic form)
+        fps = {}
+        for p in patterns:
+            self.model.reset_engines()
+            self.model.engine_options = dict(self.model.engine_options, side_priority=int(p))
+            times = []
+            for rep in range(2):                          # first block: plan build + warm-up, second block: the measurement
+                self._sync()
+                t0 = time.perf_counter()
+                inflight, pending = None, None
+                for _ in range(warmup if rep == 0 else steps):
+                    nxt = self.model.submit_detect(x, x_radar, x_points, self.conf, self.iou, self.max_det)
+                    if inflight is not None:
+                        (_, (rows, idx, cnt)) = inflight.wait()
+                        g = all_gather_detections_async(rows, idx, cnt, self.group, None, self.force_collective, self.global_batch)
+                        if pending is not None:
+                            pending.wait()
+                        pending = g
+                    inflight = nxt
+                (_, (rows, idx, cnt)) = inflight.wait()
+                all_gather_detections_async(rows, idx, cnt, self.group, None, self.force_collective, self.global_batch).wait()
+                if pending is not None:
+                    pending.wait()
+                self._sync()
+                times.append(time.perf_counter() - t0)
+            t = torch.tensor([times[1]], dtype=torch.float64, device=rows.device)
+            if self._collective_active():
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            fps[int(p)] = x.shape[0] * steps / float(t)
+        best = max(fps, key=lambda k: fps[k])
+        if self._collective_active():                     # every rank must build the same plan: rank 0's choice
+            tb = torch.tensor([best], dtype=torch.int64, device=rows.device)
+            dist.broadcast(tb, dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+            best = int(tb)
+        self.model.reset_engines()
+        self.model.engine_options = dict(self.model.engine_options, side_priority=best)
+        self.calibration = {'side_priority_fps': {str(k): round(v, 1) for k, v in fps.items()}, 'side_priority_chosen': best}
+        return self.calibration
+
+    def _maybe_calibrate(self, x, x_radar, x_points):
+        if self.auto_calibrate:
+            self.auto_calibrate = False
+            if self._collective_active() and 'side_priority' not in getattr(self.model, 'engine_options', {}) and hasattr(self.model, 'reset_engines'):
+                self.calibrate(x, x_radar, x_points)
 
     @torch.no_grad()
     def submit(self, x, x_radar, x_points, out=None):
+        self._maybe_calibrate(x, x_radar, x_points)
         (det, se, lane, pc), (rows, idx, cnt) = self.model.forward_detect(x, x_radar, x_points, self.conf, self.iou, self.max_det)
         return all_gather_detections_async(rows, idx, cnt, self.group, out, self.force_collective, self.global_batch), (se, lane, pc)
 

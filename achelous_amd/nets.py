@@ -221,6 +221,18 @@ class Achelous(nn.Module):
             raise KeyError(f"no forward has run yet for dtype {dtype} on device {dev}")
         return hits[-1]
 
+    def reset_engines(self, device=None):
+        """Destroy every cached engine (of `device`, or of all devices): the next forward builds a fresh one with the current `engine_options`
+        (options are fixed when an engine is created).  Engines with a pipelined forward still un-joined must be waited for first."""
+        dev = None if device is None else torch.device(device).index
+        for k in [k for k in self._engines if dev is None or k[0] == dev]:
+            eng = self._engines[k][0]
+            if eng.forwards_in_flight():
+                raise RuntimeError("reset_engines: a pipelined forward is still un-joined (wait() for it first)")
+            if torch.cuda.is_available():
+                torch.cuda.synchronize(k[0])
+            self._engines.pop(k)[0].destroy(reason='reset_engines() was called (engine options changed)')
+
     def _engine_code(self, dtype):
         """(ACH_DTYPE_* storage type, io_bf16) for inputs of `dtype`."""
         if dtype == torch.float32:

@@ -124,3 +124,91 @@ def test_zero_copy_record_requires_the_original_views():
     idx2 = idx.clone().flip(1)
     out = pack_records(rows, idx2, cnt)
     assert out.data_ptr() != flat.data_ptr() and torch.equal(out[S * md * 7:S * md * 8].view(S, md), idx2)
+
+
+# ---- ShardedDetector's stream-priority calibration (dist.py): the choice is a MAX-over-ranks measurement with the live collective and every rank ends up with
+# rank 0's choice.  The engine itself needs a GPU; here a stand-in with the module's protocol (engine_options / reset_engines / submit_detect / forward_detect)
+# whose step time depends on the pattern AND on the rank: rank 1 alone would pick pattern 1, the slowest rank decides, so both must pick 2.
+class _FakeModel:
+    STEP_MS = {0: {3: 4.0, 2: 1.0, 1: 3.0}, 1: {3: 4.0, 2: 2.0, 1: 0.5}}
+
+    def __init__(self, rank, B, max_det):
+        self.rank, self.B, self.max_det = rank, B, max_det
+        self.engine_options, self.resets, self.built_with = {}, 0, []
+        self._built = False
+
+    def reset_engines(self, device=None):
+        self.resets += 1
+        self._built = False
+
+    def _step(self):
+        import time
+        if not self._built:
+            self._built = True
+            self.built_with.append(self.engine_options.get('side_priority'))
+        time.sleep(self.STEP_MS[self.rank][self.engine_options.get('side_priority', 3)] * 1e-3)
+        return (None, None, None, None), _fake_shard(self.rank, self.B, self.max_det)
+
+    def forward_detect(self, x, xr, xp, conf, iou, max_det):
+        return self._step()
+
+    def submit_detect(self, x, xr, xp, conf, iou, max_det):
+        res = self._step()
+
+        class P:
+            def wait(self_inner):
+                return res
+        return P()
+
+
+def _calib_worker(rank, world, port, q):
+    from achelous_amd.dist import ShardedDetector
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    B, md = 4, 8
+    x = torch.zeros(B, 3, 8, 8)
+    m = _FakeModel(rank, B, md)
+    det = ShardedDetector(m, max_det=md, calibrate_steps=8, calibrate_warmup=2)
+    (rows, idx, cnt), _ = det(x, x, x)                          # first call calibrates, then serves
+    ok = rows.shape[0] == world * B and det.calibration is not None
+    chosen = det.calibration['side_priority_chosen']
+    ok &= m.engine_options.get('side_priority') == chosen and m.built_with[-1] == chosen and m.built_with[:3] == [3, 2, 1]
+    n_resets = m.resets
+    det(x, x, x)                                                # no second calibration
+    ok &= m.resets == n_resets
+    # opt-outs: calibrate=False, and a caller-chosen pattern
+    m2 = _FakeModel(rank, B, md)
+    ShardedDetector(m2, max_det=md, calibrate=False)(x, x, x)
+    m3 = _FakeModel(rank, B, md); m3.engine_options = {'side_priority': 1}
+    ShardedDetector(m3, max_det=md)(x, x, x)
+    ok &= m2.resets == 0 and m3.resets == 0 and m3.engine_options == {'side_priority': 1}
+    q.put((rank, bool(ok), chosen, det.calibration['side_priority_fps']))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_detector_calibrates_side_priority_consistently_world2():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_calib_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _, _ in res), res
+    assert res[0][2] == res[1][2] == 2, res                      # max over ranks: {3: 4 ms, 2: 2 ms, 1: 3 ms} per step
+    assert res[0][3] == res[1][3], res                           # both ranks hold the same (max-reduced) table
+
+
+def test_sharded_detector_without_a_collective_does_not_calibrate():
+    from achelous_amd.dist import ShardedDetector
+    m = _FakeModel(0, 2, 4)
+    det = ShardedDetector(m, max_det=4)
+    (rows, idx, cnt), _ = det(torch.zeros(2, 3, 8, 8), None, None)
+    assert m.resets == 0 and det.calibration is None and rows.shape[0] == 2
