@@ -213,6 +213,19 @@ protected:
                 a = b + 1;
             }
         }
+        // ACH_DEBUG_ONLY="substr,substr": the complement — every launch that matches NONE of the substrings becomes a no-op.  tests/test_gpu_coresidency.py builds
+        // its AGGRESSOR engines this way (a plan reduced to the row-walking heads, or the radar front kernels, or the band kernels, looping on its own stream
+        // beside a victim forward of the SHIPPED library); an aggressor's outputs are never looked at.
+        if (const char* only = std::getenv("ACH_DEBUG_ONLY")) {
+            std::string all(only);
+            bool keep = false;
+            for (size_t a = 0; a < all.size() && !keep;) {
+                size_t b = all.find(',', a); if (b == std::string::npos) b = all.size();
+                if (b > a && name.find(all.substr(a, b - a)) != std::string::npos) keep = true;
+                a = b + 1;
+            }
+            if (!keep && !all.empty()) fn = [](hipStream_t) {};
+        }
 #endif
         Op op{name, std::move(fn), bytes, layout_bytes < 0 ? bytes : layout_bytes, flops};
         op.stream = cur_stream;

@@ -137,6 +137,7 @@ class Achelous(nn.Module):
         _build_tree(self, state_dict_spec(num_det, num_seg, phi, backbone, pc_channels, pc_classes, nano_head, radar_channels, neck, pc_seg))
         self._init_like_reference()
         self._engines = {}          # (device index, dtype, padded num_points, pipelined) -> [NativeEngine, weight version]; LRU, see _engine_for
+        self.native_library = None  # an engine.NativeLibrary other than the product library (differently COMPILED A/B builds, the co-residency test's aggressor): None = libachelous_hip.so
         self.max_engines = 4        # per (device, dtype): every engine owns a weight arena and an activation arena (GBs at batch 64)
         self.debug_taps = False     # True: the engine also materialises every SURVEY §8(a) boundary (parity tests)
         self.static_weights = False  # True: skip the per-call check for in-place weight changes (serving loops)
@@ -158,6 +159,7 @@ class Achelous(nn.Module):
     def __getstate__(self):
         st = self.__dict__.copy()
         st['_engines'] = {}
+        st['native_library'] = None
         st['_wt_list'] = None
         st['_op_token'] = None
         return st
@@ -251,7 +253,7 @@ class Achelous(nn.Module):
         ent = self._engines.get(key)
         ver = ent[1] if (self.static_weights and ent is not None and ent[1] is not None) else self._weights_version()
         if ent is None:
-            eng = _eng.NativeEngine(_eng.hip_library(), num_det=self.num_det, num_seg=self.num_seg, phi=self.phi,
+            eng = _eng.NativeEngine(self.__dict__.get('native_library') or _eng.hip_library(), num_det=self.num_det, num_seg=self.num_seg, phi=self.phi,
                                     backbone=self.backbone, resolution=self.resolution, pc_channels=self.pc_channels,
                                     pc_classes=self.pc_classes, num_points=num_points, nano_head=self.nano_head,
                                     spp=self.spp, dtype=code[0], neck=self.neck, pc_seg=self.pc_seg_kind)
