@@ -178,3 +178,58 @@ def test_no_kernel_is_instantiated_by_both_engine_translation_units():
     common = {k for k in kernels[0] & kernels[1] if 'pn2_fps_kernel' not in k}      # storage-independent, one definition, identical in both
     assert not common, sorted(common)
     assert any('bf16_t' in k for k in kernels[1]) and not any('bf16_t' in k for k in kernels[0])
+
+
+# ---- ISA rule of DESIGN 4.17: no inline-asm result may be a matrix-instruction operand (the hazard recogniser cannot see into an asm statement)
+def _scan_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('isa_asm_mfma_scan', os.path.join(REPO, 'profiles', 'scripts', 'isa_asm_mfma_scan.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_isa_scan_flags_an_asm_result_that_feeds_an_mfma(tmp_path):
+    bad = '''_Zkernel_bad:
+	v_mov_b32_e32 v5, v1
+	;;#ASMSTART
+	v_pk_max_i16 v10, v5, 0
+	;;#ASMEND
+	v_add_f32_e32 v7, v1, v2
+	v_mfma_f32_16x16x32_f16 v[0:3], v[20:23], v[8:11], v[0:3]
+.Lfunc_end0:
+'''
+    good = '''_Zkernel_good:
+	;;#ASMSTART
+	s_nop 1
+	v_add_f32_dpp v10, v5, v6 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1
+	;;#ASMEND
+	v_cvt_pk_f16_f32 v10, v10, v11
+	v_mfma_f32_16x16x32_f16 v[0:3], v[20:23], v[8:11], v[0:3]
+	;;#ASMSTART
+	v_max_f32_e32 v30, 0, v31
+	;;#ASMEND
+	v_mfma_f32_16x16x32_f16 v[0:3], v[20:23], v[8:11], v[0:3]
+.Lfunc_end1:
+'''
+    m = _scan_module()
+    pb, pg = tmp_path / 'bad.s', tmp_path / 'good.s'
+    pb.write_text(bad); pg.write_text(good)
+    blocks, findings = m.scan(str(pb))
+    assert blocks == 1 and len(findings) == 1 and findings[0][1] == '_Zkernel_bad' and ('v', 10) in findings[0][4]
+    blocks, findings = m.scan(str(pg))
+    assert blocks == 2 and findings == []
+
+
+def test_no_inline_asm_result_feeds_a_matrix_instruction_in_the_shipped_kernels():
+    """The gfx950 assembly of both 16-bit engines (every kernel with inline assembly lives there) passes the scan."""
+    import subprocess
+    csrc = os.path.join(REPO, 'achelous_amd', 'csrc')
+    if not os.path.exists('/opt/rocm/bin/hipcc'):
+        pytest.skip('no hipcc')
+    subprocess.run(['make', '-s', '-C', csrc, '-j2', 'isa'], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    m = _scan_module()
+    for tu in ('engine_f16.s', 'engine_bf16.s'):
+        blocks, findings = m.scan(os.path.join(csrc, 'build', tu))
+        assert blocks > 100, (tu, blocks)               # the DPP adds / v_max of the row-walking kernels are there
+        assert findings == [], findings[:5]
