@@ -10,6 +10,7 @@
 #include "hostemu.h"
 #define ACH_LAUNCH(kern, grid, block, stream, ...) \
     do { (void)(stream); hostemu::launch((grid), (block), [=]() { kern(__VA_ARGS__); }); } while (0)
+#define ACH_LAUNCH_LDS(kern, grid, block, lds_bytes, stream, ...) ACH_LAUNCH(kern, grid, block, stream, __VA_ARGS__)
 #define ACH_UNROLL
 #define ACH_NO_UNROLL
 namespace ach {
@@ -22,6 +23,10 @@ struct f32x4 {
 #else
 #include <hip/hip_runtime.h>
 #define ACH_LAUNCH(kern, grid, block, stream, ...) hipLaunchKernelGGL(kern, (grid), (block), 0, (stream), __VA_ARGS__)
+// the same launch with `lds_bytes` of (unused) dynamic LDS per workgroup: an OCCUPANCY CAP — a compute unit holds at most 160 KB / lds_bytes workgroups of the
+// kernel, whatever its registers would allow.  For long-lived, register-heavy kernels on the side streams: with 3 x 152 VGPRs per SIMD the row-walking
+// head leaves the caller's stream no room on ANY compute unit for as long as it runs.
+#define ACH_LAUNCH_LDS(kern, grid, block, lds_bytes, stream, ...) hipLaunchKernelGGL(kern, (grid), (block), (lds_bytes), (stream), __VA_ARGS__)
 #define ACH_UNROLL _Pragma("unroll")
 #define ACH_NO_UNROLL _Pragma("unroll 1")
 namespace ach {

@@ -75,6 +75,7 @@ public:
     // (1.36 ms vs 1.66 ms): HIP's graph executor serialises more of the three-branch DAG than the streams do.
     bool use_graph = false;
     bool io_bf16 = false;             // option "io_bf16" (fp16-storage engine only): the caller's input / output tensors are bf16; converted in the first / last kernels
+    bool csp_fuse = true;             // option "csp_fuse": 16-bit engines, CSP-Dual-FPN — the full-resolution decoder level and the segmentation head as one row-walking launch (k_csphead.h) instead of five layer-wise ones
     bool ghost_fuse = true;           // option "ghost_fuse": 16-bit engines — the neck's GhostModules (primary 1x1 + cheap depthwise 3x3) and the bottlenecks' shortcuts (depthwise 3x3 + 1x1 + residual) as band kernels (k_ghost.h): 3 launches per bottleneck instead of 6
     bool mv_stem = true;              // option "mv_stem": 16-bit engines — MobileViT's conv1 gathered from the NCHW image (no NHWC copy of the image; k_nhwc.h mvstem_kernel)
     bool radar_direct = true;         // option "radar_direct": 16-bit engines — the first RCBlock reads the caller's NCHW radar map itself (pool + residual): no NHWC copy, one launch fewer
@@ -117,6 +118,7 @@ public:
                                       // first RCBlock's shortcut shortened the radar branch: with the head queued BEHIND the radar branch on
                                       // stream 1 the plan is now +1.2 % faster (26.1 k vs 25.8 k frames/s), and — caller + ONE side stream —
                                       // it leaves room for RCCL's stream: all-gather overhead at world size 1 9 % -> 1.5-4.5 %
+    int head_lds_pad = 0;             // option "head_lds_pad": bytes of unused dynamic LDS per workgroup of the row-walking decoder head = an occupancy cap (160 KB / pad workgroups per CU)
     int side_low_priority = 3;        // option "side_priority" (with head_stream = 0): bit k set = side stream k+1 is created at the
                                       // lowest stream priority.  (2 = only the decoders' stream low is +0.8 % without a collective and -19 % WITH RCCL's stream
                                       // beside the engine's: 30.9 k against 37.7 k frames/s with the all-gather forced at world size 1 — both streams stay low.)

@@ -8,6 +8,7 @@
 #include <cstring>
 
 #include "k_dechead.h"
+#include "k_csphead.h"
 #include "k_upchain.h"
 #include "k_detect.h"
 #include "k_conv3.h"
@@ -1005,6 +1006,72 @@ public:
         { GemmOpt o; o.act = ACT_SILU; gemm(pfx + ".conv3", cat, pack(conv_bn(pfx + ".conv3.conv", pfx + ".conv3.bn", 1e-3)), y, o); }
         return y;
     }
+    // CSP-Dual-FPN, the last decoder level (Upsample + Bottleneck at full resolution) and the segmentation head (a Bottleneck, num_class outputs) as ONE row-walking
+    // launch (k_csphead.h) behind two low-resolution 1x1 GEMMs: u = relu(BN(conv_up(y))), v = BN(conv1(u)) (conv1's SiLU moves behind the interpolation it commutes with).
+    // false = the widths are not the fused kernel's (32 -> 16 -> 32 channels, head hidden <= 4, <= 16 classes) or the plan wants the level's taps: layer-wise launches.
+    bool csp_last_level(const std::string& up_pfx, const std::string& bn_pfx, const std::string& head_pfx, const A& y, int oup, void** out) {
+        if constexpr (!H16E) return false;
+        else {
+        if (!csp_fuse || full_taps) return false;
+        Lin lu = conv_bn(up_pfx + ".upsample.0.conv", up_pfx + ".upsample.0.bn", 1e-3);
+        Lin l1 = conv_bn(bn_pfx + ".conv1.conv", bn_pfx + ".conv1.bn", 1e-3);
+        Lin lh1 = conv_bn(head_pfx + ".conv1.conv", head_pfx + ".conv1.bn", 1e-3);
+        const int hid = lh1.N;
+        if (lu.N != 32 || lu.K != y.C || l1.N != 16 || l1.K != 32 || lh1.K != 32 || hid < 1 || hid > 4 || oup < 1 || oup > 16) return false;
+        Lin l2 = base_conv3(bn_pfx + ".conv2", 16, 16), lh2 = base_conv3(head_pfx + ".conv2", hid, 4);
+        if (l2.N != 32 || lh2.N != oup) return false;
+        const int H2 = 2 * y.H, W2 = 2 * y.W;
+        if (double(y.H) * y.W * 48 * sizeof(T) >= 2147483648.0 || double(H2) * W2 * oup * sizeof(T) >= 2147483648.0) return false;
+        A uv = alloc(y.B, y.H, y.W, 48);
+        const A u = uv.slice(0, 32), v = uv.slice(32, 16);
+        { GemmOpt o; o.act = ACT_RELU; gemm(up_pfx + ".conv", y, pack(lu), u, o); }
+        gemm(bn_pfx + ".conv1_lowres", u, pack(l1), v);
+        // A fragments (lane l: row i = l & 15, k group kg = l >> 4, elements j < 8), see k_csphead.h
+        std::vector<uint16_t> f2(size_t(10) * 64 * 8, 0), f1(size_t(64) * 8, 0), f3(size_t(2) * 64 * 8, 0);
+        for (int l = 0; l < 64; ++l) {
+            const int i = l & 15, kg = l >> 4;
+            for (int j = 0; j < 8; ++j) {
+                for (int s = 0; s < 5; ++s)
+                    for (int t = 0; t < 2; ++t) {
+                        const int tp = 2 * s + (kg >> 1), ch = 8 * (kg & 1) + j;
+                        if (tp < 9) f2[((size_t(s) * 2 + t) * 64 + l) * 8 + j] = H16<T>::bits(l2.w[size_t(16 * t + i) * l2.K + size_t(tp) * 16 + ch]);
+                    }
+                const int r = i & 3, c = j < 4 ? 4 * kg + j : 16 + 4 * kg + (j - 4);
+                if (r < hid) f1[size_t(l) * 8 + j] = H16<T>::bits(lh1.w[size_t(r) * 32 + c]);
+                for (int s = 0; s < 2; ++s) {
+                    const int tp = 8 * s + 2 * kg + (j >> 2), ch = j & 3;
+                    if (tp < 9 && ch < hid && i < oup) f3[(size_t(s) * 64 + l) * 8 + j] = H16<T>::bits(lh2.w[size_t(i) * lh2.K + size_t(tp) * 4 + ch]);
+                }
+            }
+        }
+        std::vector<float> b2(32, 0.f), bh1(4, 0.f), bh2(16, 0.f);
+        for (int n = 0; n < 32; ++n) b2[size_t(n)] = l2.b[size_t(n)];
+        for (int n = 0; n < hid; ++n) bh1[size_t(n)] = lh1.b[size_t(n)];
+        for (int n = 0; n < oup; ++n) bh2[size_t(n)] = lh2.b[size_t(n)];
+        const int band = std::max(8, std::min(head_band, H2));
+        CspHeadParams cp{uv.p, uv.ld, nullptr, static_cast<const uint4*>(up_raw(f2.data(), f2.size() * 2)), up_f32(b2), static_cast<const uint4*>(up_raw(f1.data(), f1.size() * 2)), up_f32(bh1),
+                         static_cast<const uint4*>(up_raw(f3.data(), f3.size() * 2)), up_f32(bh2), y.B, y.H, y.W, hid, oup,
+                         y.H > 0 ? float(y.H - 1) / float(H2 - 1) : 0.f, y.W > 0 ? float(y.W - 1) / float(W2 - 1) : 0.f, band, cdiv(H2, band), cdiv(W2, CSPH_VALID)};
+        if (double(cp.strips) * cp.bands * y.B >= 4294967296.0) return false;
+        std::vector<DecHeadRow> rg(static_cast<size_t>(H2) + 4);
+        for (int i = 0; i < H2 + 4; ++i) {                       // the float arithmetic of upsample2x_kernel / torch (align_corners)
+            const float fy = cp.sy * float(i < H2 ? i : H2 - 1);
+            int y0 = int(fy);
+            if (y0 > y.H - 1) y0 = y.H - 1;
+            rg[size_t(i)] = DecHeadRow{y0, y0 < y.H - 1 ? fy - float(y0) : 0.f};
+        }
+        const DecHeadRow* rows = static_cast<const DecHeadRow*>(up_raw(rg.data(), rg.size() * sizeof(DecHeadRow)));
+        const dim3 grid(unsigned(cp.strips) * unsigned(cp.bands) * unsigned(y.B)), block(64);
+        const bool alt = io_alt();
+        const double px = double(y.B) * H2 * W2;
+        add_op(head_pfx + ".csp_level+head", [cp, grid, block, out, rows, alt](hipStream_t s) mutable {
+            cp.out = *out;
+            if (alt) { if constexpr (std::is_same<T, f16_t>::value) ACH_LAUNCH((csp_head_rows_kernel<T, bf16_t>), grid, block, s, cp, rows); }
+            else ACH_LAUNCH((csp_head_rows_kernel<T, T>), grid, block, s, cp, rows);
+        }, double(uv.rows()) * 48 * sizeof(T) + px * oup * sizeof(T), 2.0 * px * (144.0 * 32 + 32.0 * hid + 36.0 * oup));
+        return true;
+        }
+    }
     // Upsample = BaseConv 1x1 + BN(1e-3) + ReLU, bilinear x2 align_corners (ghostdualfpn.py:28-39); writes into `dst`
     void upsample(const std::string& pfx, const A& x, const A& dst) {
         Lin l = conv_bn(pfx + ".upsample.0.conv", pfx + ".upsample.0.bn", 1e-3);
@@ -1216,13 +1283,14 @@ public:
             const int dbg = head_debug;
             const bool dw2 = nch > 4, tapf = full_taps;
             const bool alt = io_alt();
-            add_op(head_pfx + ".upghost_head", [dp, grid, block, out, dbg, dw2, tapf, rows, two, alt](hipStream_t s) mutable {
+            const unsigned pad = unsigned(head_lds_pad);          // occupancy cap of the row-walking head (option "head_lds_pad", bytes of unused dynamic LDS per single-wave workgroup)
+            add_op(head_pfx + ".upghost_head", [dp, grid, block, out, dbg, dw2, tapf, rows, two, alt, pad](hipStream_t s) mutable {
                 dp.out = *out;
                 auto go = [&](auto io_tag) {             // IO: the type of the caller's output tensor
                     using IO = decltype(io_tag);
                     if (two) {
                         if (tapf) { if (dw2) ACH_LAUNCH((dechead_rows2_kernel<T, IO, true, true>), grid, block, s, dp, rows); else ACH_LAUNCH((dechead_rows2_kernel<T, IO, false, true>), grid, block, s, dp, rows); }
-                        else { if (dw2) ACH_LAUNCH((dechead_rows2_kernel<T, IO, true, false>), grid, block, s, dp, rows); else ACH_LAUNCH((dechead_rows2_kernel<T, IO, false, false>), grid, block, s, dp, rows); }
+                        else { if (dw2) ACH_LAUNCH_LDS((dechead_rows2_kernel<T, IO, true, false>), grid, block, pad, s, dp, rows); else ACH_LAUNCH_LDS((dechead_rows2_kernel<T, IO, false, false>), grid, block, pad, s, dp, rows); }
                         return;
                     }
                     if (tapf) {                      // parity-test plans: the variant that also writes [x1 | x2]
@@ -1367,8 +1435,9 @@ public:
             tap(n + ".sa", y);
             const char* lv[3] = {"3_to_2", "2_to_1", "1_to_0"};
             const int cw[3] = {w[1], w[0], w[0]};
-            if (csp) {          // Upsample + Bottleneck per level, Bottleneck head (layer-wise on the generic kernels)
+            if (csp) {          // Upsample + Bottleneck per level, Bottleneck head: layer-wise on the generic kernels, the full-resolution level + head fused (k_csphead.h)
                 for (int l = 0; l < 3; ++l) {
+                    if (l == 2 && csp_last_level(f + "." + n + "_seg_" + lv[l], f + "." + n + "_seg_ghost_" + lv[l], f + "." + n + "_seg_head", y, oups[d], outs[d])) { y = A(); break; }
                     A u = alloc(y.B, 2 * y.H, 2 * y.W, cw[l]);
                     upsample(f + "." + n + "_seg_" + lv[l], y, u);
                     A v = alloc(u.B, u.H, u.W, cw[l]);
@@ -1376,7 +1445,7 @@ public:
                     tap(n + "." + lv[l], v);
                     y = v;
                 }
-                csp_bottleneck(f + "." + n + "_seg_head", y, oups[d], nullptr, outs[d]);
+                if (y.p) csp_bottleneck(f + "." + n + "_seg_head", y, oups[d], nullptr, outs[d]);
                 continue;
             }
             // level l's full-resolution kernel also applies level l+1's low-resolution conv pair where it can (k_upchain.h): the level's

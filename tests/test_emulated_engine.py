@@ -767,3 +767,40 @@ def test_emulated_point_branch_does_not_depend_on_the_batch(sdt):
         eng.forward(x[:B].to(sdt[1]), xr[:B].to(sdt[1]), xp[:B].to(sdt[1]), outs)
         res[B] = outs[5][0].clone()
     assert torch.equal(res[1], res[4])
+
+
+@pytest.mark.parametrize('sdt', H16)
+@pytest.mark.parametrize('res,band,num_seg', [(96, 8, 9), (64, 40, 9), (128, 24, 5)])
+def test_emulated_csp_fused_last_level_matches_the_layerwise_launches(res, band, num_seg, sdt):
+    """CSP-Dual-FPN, 16-bit engines: the full-resolution decoder level + segmentation head as one row-walking launch (k_csphead.h, option csp_fuse = 1, the
+    default of production plans) against the five layer-wise launches it replaces (csp_fuse = 0) and the oracle.  Bands of 8 rows put a band boundary inside every
+    phase of the two rolling windows; 96 / 64 / 128 columns end in full / partial strips of 12; num_seg = 5 has two hidden channels in the head (9: four; the
+    water-line head: one).  The two plans differ in where x, a, y, h are rounded to the storage type (HBM tensors layer-wise, MFMA operands here)."""
+    from achelous_amd.engine import NativeEngine
+    from achelous_amd.nets import Achelous
+    kw, sd, (x, xr, xp) = _setup('en_s0_cdf', res, 2, 16)
+    if num_seg != kw['num_seg']:
+        kw = dict(kw, num_seg=num_seg)
+        okw = {k: kw[k] for k in ('num_det', 'num_seg', 'phi', 'resolution', 'backbone', 'neck', 'pc_seg', 'pc_channels', 'pc_classes', 'nano_head', 'spp')}
+        sd = condition_state_dict({k: torch.zeros_like(v) for k, v in Achelous(**okw).state_dict().items()}, seed=0)
+    orc = AchelousOracle(sd, **{k: kw[k] for k in ORACLE_KEYS})
+    _, se, lane, _ = orc.forward(x, xr, xp)
+    outs, launches = {}, {}
+    for fuse in (1, 0):
+        eng = NativeEngine(emu_library(), num_det=kw['num_det'], num_seg=kw['num_seg'], phi=kw['phi'], backbone=kw['backbone'], resolution=res,
+                           pc_channels=kw['pc_channels'], pc_classes=kw['pc_classes'], num_points=16, nano_head=True, spp=True, dtype=sdt[0], neck='cdf')
+        eng.set_option('full_taps', 0)
+        eng.set_option('csp_fuse', fuse)
+        eng.set_option('head_band', band)
+        eng.load_state_dict(sd)
+        eng.plan(2)
+        launches[fuse] = [n for n, _, _ in eng.op_table()]
+        o = alloc_outputs(kw, 2, 16, sdt[1], 'cpu')
+        eng.forward(x.to(sdt[1]), xr.to(sdt[1]), xp.to(sdt[1]), o)
+        outs[fuse] = (o[3].float(), o[4].float())
+    assert sum('csp_level+head' in n for n in launches[1]) == 2 and not any('csp_level+head' in n for n in launches[0])
+    assert len(launches[0]) - len(launches[1]) == 2 * (5 - 3)         # per decoder: conv+bilinear, conv1, conv2, head.conv1, head.conv2 -> conv, conv1_lowres, fused
+    for k in range(2):
+        assert rel_err(outs[1][k], outs[0][k]) < sdt[2] * 3e-2, (k, rel_err(outs[1][k], outs[0][k]))
+    assert rel_err(outs[1][0], se) < sdt[2] * 6e-2 and rel_err(outs[1][1], lane) < sdt[2] * 6e-2
+    assert rel_err(outs[0][0], se) < sdt[2] * 6e-2 and rel_err(outs[0][1], lane) < sdt[2] * 6e-2
