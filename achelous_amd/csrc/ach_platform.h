@@ -448,6 +448,21 @@ inline void buf_store4(const BufRsrc& r, unsigned voff, unsigned soff, uint32_t 
 #else
 __device__ __forceinline__ void buf_store4(BufRsrc r, unsigned voff, unsigned soff, uint32_t v) { __builtin_amdgcn_raw_buffer_store_b32(v, r, int(voff), int(soff), 0); }
 #endif
+// the same for 2 bytes (the low half of `v`) and for 8 bytes
+#if defined(ACH_HOSTEMU)
+inline void buf_store2(const BufRsrc& r, unsigned voff, unsigned soff, uint32_t v) {
+    const uint16_t h = uint16_t(v);
+    if (voff < r.bytes && r.bytes >= 2u && size_t(voff) + soff <= size_t(r.bytes) - 2u) std::memcpy(const_cast<char*>(r.base) + voff + soff, &h, 2);
+}
+inline void buf_store8(const BufRsrc& r, unsigned voff, unsigned soff, uint32_t a, uint32_t b) {
+    const uint32_t q[2] = {a, b};
+    if (voff < r.bytes && r.bytes >= 8u && size_t(voff) + soff <= size_t(r.bytes) - 8u) std::memcpy(const_cast<char*>(r.base) + voff + soff, q, 8);
+}
+#else
+__device__ __forceinline__ void buf_store2(BufRsrc r, unsigned voff, unsigned soff, uint32_t v) { __builtin_amdgcn_raw_buffer_store_b16(short(v), r, int(voff), int(soff), 0); }
+typedef unsigned int buf_st_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void buf_store8(BufRsrc r, unsigned voff, unsigned soff, uint32_t a, uint32_t b) { __builtin_amdgcn_raw_buffer_store_b64(buf_st_u32x2{a, b}, r, int(voff), int(soff), 0); }
+#endif
 // four consecutive elements of the storage type through a buffer resource (8 bytes of bf16 / 16 bytes of fp32), as floats
 #if defined(ACH_HOSTEMU)
 inline void buf_load_raw(const BufRsrc& r, unsigned off, void* dst, unsigned n) {

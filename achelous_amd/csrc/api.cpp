@@ -127,7 +127,8 @@ int ach_set_option(ach_handle* h, const char* key, int32_t value) {
         else if (std::string(key) == "mlp_split_hw") h->eng->mlp_split_hw = value;
         else if (std::string(key) == "radar_direct") h->eng->radar_direct = value != 0;
         else if (std::string(key) == "mv_stem") h->eng->mv_stem = value != 0;
-        else if (std::string(key) == "csp_fuse") h->eng->csp_fuse = value != 0;
+        else if (std::string(key) == "csp_fuse") h->eng->csp_fuse = value < 0 ? 0 : (value > 2 ? 2 : value);
+        else if (std::string(key) == "csp_band") h->eng->csp_band = value > 0 ? value : 40;
         else if (std::string(key) == "ghost_fuse") h->eng->ghost_fuse = value != 0;
         else if (std::string(key) == "io_bf16") {
             if (value != 0 && h->eng->cfg.dtype != ACH_DTYPE_F16) throw ach::AchError{ACH_ERR_INVALID, "io_bf16 applies to the fp16-storage engine (ACH_DTYPE_F16) only"};

@@ -1006,22 +1006,31 @@ public:
         { GemmOpt o; o.act = ACT_SILU; gemm(pfx + ".conv3", cat, pack(conv_bn(pfx + ".conv3.conv", pfx + ".conv3.bn", 1e-3)), y, o); }
         return y;
     }
-    // CSP-Dual-FPN, the last decoder level (Upsample + Bottleneck at full resolution) and the segmentation head (a Bottleneck, num_class outputs) as ONE row-walking
-    // launch (k_csphead.h) behind two low-resolution 1x1 GEMMs: u = relu(BN(conv_up(y))), v = BN(conv1(u)) (conv1's SiLU moves behind the interpolation it commutes with).
+    // CSP-Dual-FPN, a decoder level (Upsample + Bottleneck) as ONE row-walking launch (k_csphead.h) behind two low-resolution 1x1 GEMMs: u = relu(BN(conv_up(y))),
+    // v = BN(conv1(u)) (conv1's SiLU moves behind the interpolation it commutes with) — with `head_pfx` the level is the last one and the segmentation head (a
+    // Bottleneck, num_class outputs, NCHW into the caller's tensor) rides in the same launch; otherwise the level's output y (NHWC, 32 channels) is written to `dst`.
     // false = the widths are not the fused kernel's (32 -> 16 -> 32 channels, head hidden <= 4, <= 16 classes) or the plan wants the level's taps: layer-wise launches.
-    bool csp_last_level(const std::string& up_pfx, const std::string& bn_pfx, const std::string& head_pfx, const A& y, int oup, void** out) {
+    bool csp_level_fused(const std::string& up_pfx, const std::string& bn_pfx, const std::string& head_pfx, const A& y, int oup, void** out, const A* dst) {
         if constexpr (!H16E) return false;
         else {
-        if (!csp_fuse || full_taps) return false;
+        const bool head = !head_pfx.empty();
+        if (!csp_fuse || full_taps || (!head && csp_fuse < 2)) return false;
         Lin lu = conv_bn(up_pfx + ".upsample.0.conv", up_pfx + ".upsample.0.bn", 1e-3);
         Lin l1 = conv_bn(bn_pfx + ".conv1.conv", bn_pfx + ".conv1.bn", 1e-3);
-        Lin lh1 = conv_bn(head_pfx + ".conv1.conv", head_pfx + ".conv1.bn", 1e-3);
-        const int hid = lh1.N;
-        if (lu.N != 32 || lu.K != y.C || l1.N != 16 || l1.K != 32 || lh1.K != 32 || hid < 1 || hid > 4 || oup < 1 || oup > 16) return false;
-        Lin l2 = base_conv3(bn_pfx + ".conv2", 16, 16), lh2 = base_conv3(head_pfx + ".conv2", hid, 4);
-        if (l2.N != 32 || lh2.N != oup) return false;
+        if (lu.N != 32 || lu.K != y.C || l1.N != 16 || l1.K != 32) return false;
+        Lin lh1, lh2;
+        int hid = 0;
+        if (head) {
+            lh1 = conv_bn(head_pfx + ".conv1.conv", head_pfx + ".conv1.bn", 1e-3);
+            hid = lh1.N;
+            if (lh1.K != 32 || hid < 1 || hid > 4 || oup < 1 || oup > 16) return false;
+            lh2 = base_conv3(head_pfx + ".conv2", hid, 4);
+            if (lh2.N != oup) return false;
+        } else if (!dst || dst->C != 32 || dst->ld % 4) return false;
+        Lin l2 = base_conv3(bn_pfx + ".conv2", 16, 16);
+        if (l2.N != 32) return false;
         const int H2 = 2 * y.H, W2 = 2 * y.W;
-        if (double(y.H) * y.W * 48 * sizeof(T) >= 2147483648.0 || double(H2) * W2 * oup * sizeof(T) >= 2147483648.0) return false;
+        if (double(y.H) * y.W * 48 * sizeof(T) >= 2147483648.0 || double(H2) * W2 * (head ? oup : int(dst->ld)) * sizeof(T) >= 2147483648.0) return false;
         A uv = alloc(y.B, y.H, y.W, 48);
         const A u = uv.slice(0, 32), v = uv.slice(32, 16);
         { GemmOpt o; o.act = ACT_RELU; gemm(up_pfx + ".conv", y, pack(lu), u, o); }
@@ -1036,6 +1045,7 @@ public:
                         const int tp = 2 * s + (kg >> 1), ch = 8 * (kg & 1) + j;
                         if (tp < 9) f2[((size_t(s) * 2 + t) * 64 + l) * 8 + j] = H16<T>::bits(l2.w[size_t(16 * t + i) * l2.K + size_t(tp) * 16 + ch]);
                     }
+                if (!head) continue;
                 const int r = i & 3, c = j < 4 ? 4 * kg + j : 16 + 4 * kg + (j - 4);
                 if (r < hid) f1[size_t(l) * 8 + j] = H16<T>::bits(lh1.w[size_t(r) * 32 + c]);
                 for (int s = 0; s < 2; ++s) {
@@ -1047,11 +1057,12 @@ public:
         std::vector<float> b2(32, 0.f), bh1(4, 0.f), bh2(16, 0.f);
         for (int n = 0; n < 32; ++n) b2[size_t(n)] = l2.b[size_t(n)];
         for (int n = 0; n < hid; ++n) bh1[size_t(n)] = lh1.b[size_t(n)];
-        for (int n = 0; n < oup; ++n) bh2[size_t(n)] = lh2.b[size_t(n)];
-        const int band = std::max(8, std::min(head_band, H2));
-        CspHeadParams cp{uv.p, uv.ld, nullptr, static_cast<const uint4*>(up_raw(f2.data(), f2.size() * 2)), up_f32(b2), static_cast<const uint4*>(up_raw(f1.data(), f1.size() * 2)), up_f32(bh1),
+        for (int n = 0; n < (head ? oup : 0); ++n) bh2[size_t(n)] = lh2.b[size_t(n)];
+        const int band = std::max(8, std::min(csp_band, H2));
+        CspHeadParams cp{uv.p, uv.ld, head ? nullptr : static_cast<void*>(dst->p), head ? 0 : dst->ld,
+                         static_cast<const uint4*>(up_raw(f2.data(), f2.size() * 2)), up_f32(b2), static_cast<const uint4*>(up_raw(f1.data(), f1.size() * 2)), up_f32(bh1),
                          static_cast<const uint4*>(up_raw(f3.data(), f3.size() * 2)), up_f32(bh2), y.B, y.H, y.W, hid, oup,
-                         y.H > 0 ? float(y.H - 1) / float(H2 - 1) : 0.f, y.W > 0 ? float(y.W - 1) / float(W2 - 1) : 0.f, band, cdiv(H2, band), cdiv(W2, CSPH_VALID)};
+                         y.H > 0 ? float(y.H - 1) / float(H2 - 1) : 0.f, y.W > 0 ? float(y.W - 1) / float(W2 - 1) : 0.f, band, cdiv(H2, band), cdiv(W2, head ? CSPH_VALID : CSPL_VALID)};
         if (double(cp.strips) * cp.bands * y.B >= 4294967296.0) return false;
         std::vector<DecHeadRow> rg(static_cast<size_t>(H2) + 4);
         for (int i = 0; i < H2 + 4; ++i) {                       // the float arithmetic of upsample2x_kernel / torch (align_corners)
@@ -1064,11 +1075,15 @@ public:
         const dim3 grid(unsigned(cp.strips) * unsigned(cp.bands) * unsigned(y.B)), block(64);
         const bool alt = io_alt();
         const double px = double(y.B) * H2 * W2;
-        add_op(head_pfx + ".csp_level+head", [cp, grid, block, out, rows, alt](hipStream_t s) mutable {
-            cp.out = *out;
-            if (alt) { if constexpr (std::is_same<T, f16_t>::value) ACH_LAUNCH((csp_head_rows_kernel<T, bf16_t>), grid, block, s, cp, rows); }
-            else ACH_LAUNCH((csp_head_rows_kernel<T, T>), grid, block, s, cp, rows);
-        }, double(uv.rows()) * 48 * sizeof(T) + px * oup * sizeof(T), 2.0 * px * (144.0 * 32 + 32.0 * hid + 36.0 * oup));
+        if (head)
+            add_op(head_pfx + ".csp_level+head", [cp, grid, block, out, rows, alt](hipStream_t s) mutable {
+                cp.out = *out;
+                if (alt) { if constexpr (std::is_same<T, f16_t>::value) ACH_LAUNCH((csp_head_rows_kernel<T, bf16_t, true>), grid, block, s, cp, rows); }
+                else ACH_LAUNCH((csp_head_rows_kernel<T, T, true>), grid, block, s, cp, rows);
+            }, double(uv.rows()) * 48 * sizeof(T) + px * oup * sizeof(T), 2.0 * px * (144.0 * 32 + 32.0 * hid + 36.0 * oup));
+        else
+            add_op(bn_pfx + ".csp_level", [cp, grid, block, rows](hipStream_t s) { ACH_LAUNCH((csp_head_rows_kernel<T, T, false>), grid, block, s, cp, rows); },
+                   double(uv.rows()) * 48 * sizeof(T) + px * 32 * sizeof(T), 2.0 * px * 144.0 * 32);
         return true;
         }
     }
@@ -1437,7 +1452,11 @@ public:
             const int cw[3] = {w[1], w[0], w[0]};
             if (csp) {          // Upsample + Bottleneck per level, Bottleneck head: layer-wise on the generic kernels, the full-resolution level + head fused (k_csphead.h)
                 for (int l = 0; l < 3; ++l) {
-                    if (l == 2 && csp_last_level(f + "." + n + "_seg_" + lv[l], f + "." + n + "_seg_ghost_" + lv[l], f + "." + n + "_seg_head", y, oups[d], outs[d])) { y = A(); break; }
+                    if (l == 2 && csp_level_fused(f + "." + n + "_seg_" + lv[l], f + "." + n + "_seg_ghost_" + lv[l], f + "." + n + "_seg_head", y, oups[d], outs[d], nullptr)) { y = A(); break; }
+                    if (l < 2 && cw[l] == 32 && csp_fuse >= 2 && !full_taps && H16E) {
+                        A v = alloc(y.B, 2 * y.H, 2 * y.W, cw[l]);
+                        if (csp_level_fused(f + "." + n + "_seg_" + lv[l], f + "." + n + "_seg_ghost_" + lv[l], "", y, 0, nullptr, &v)) { y = v; continue; }
+                    }
                     A u = alloc(y.B, 2 * y.H, 2 * y.W, cw[l]);
                     upsample(f + "." + n + "_seg_" + lv[l], y, u);
                     A v = alloc(u.B, u.H, u.W, cw[l]);

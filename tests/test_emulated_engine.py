@@ -786,7 +786,7 @@ def test_emulated_csp_fused_last_level_matches_the_layerwise_launches(res, band,
     orc = AchelousOracle(sd, **{k: kw[k] for k in ORACLE_KEYS})
     _, se, lane, _ = orc.forward(x, xr, xp)
     outs, launches = {}, {}
-    for fuse in (1, 0):
+    for fuse in (2, 1, 0):                       # 2 (default): the 32-channel level below the last one as a row-walking launch too
         eng = NativeEngine(emu_library(), num_det=kw['num_det'], num_seg=kw['num_seg'], phi=kw['phi'], backbone=kw['backbone'], resolution=res,
                            pc_channels=kw['pc_channels'], pc_classes=kw['pc_classes'], num_points=16, nano_head=True, spp=True, dtype=sdt[0], neck='cdf')
         eng.set_option('full_taps', 0)
@@ -799,8 +799,11 @@ def test_emulated_csp_fused_last_level_matches_the_layerwise_launches(res, band,
         eng.forward(x.to(sdt[1]), xr.to(sdt[1]), xp.to(sdt[1]), o)
         outs[fuse] = (o[3].float(), o[4].float())
     assert sum('csp_level+head' in n for n in launches[1]) == 2 and not any('csp_level+head' in n for n in launches[0])
+    assert sum(n.endswith('.csp_level') for n in launches[2]) == 2 and not any(n.endswith('.csp_level') for n in launches[1])
     assert len(launches[0]) - len(launches[1]) == 2 * (5 - 3)         # per decoder: conv+bilinear, conv1, conv2, head.conv1, head.conv2 -> conv, conv1_lowres, fused
-    for k in range(2):
-        assert rel_err(outs[1][k], outs[0][k]) < sdt[2] * 3e-2, (k, rel_err(outs[1][k], outs[0][k]))
-    assert rel_err(outs[1][0], se) < sdt[2] * 6e-2 and rel_err(outs[1][1], lane) < sdt[2] * 6e-2
+    assert len(launches[2]) == len(launches[1])                       # conv+bilinear, conv1, conv2 -> conv, conv1_lowres, fused
+    for fuse in (2, 1):
+        for k in range(2):
+            assert rel_err(outs[fuse][k], outs[0][k]) < sdt[2] * 3e-2, (fuse, k, rel_err(outs[fuse][k], outs[0][k]))
+        assert rel_err(outs[fuse][0], se) < sdt[2] * 6e-2 and rel_err(outs[fuse][1], lane) < sdt[2] * 6e-2
     assert rel_err(outs[0][0], se) < sdt[2] * 6e-2 and rel_err(outs[0][1], lane) < sdt[2] * 6e-2

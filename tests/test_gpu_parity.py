@@ -990,3 +990,34 @@ def test_point_branch_does_not_depend_on_the_batch():
             pc4 = m(xs, rs, ps)[3].clone()
             pc1 = m(xs[:1], rs[:1], ps[:1])[3]
         assert torch.equal(pc4[:1], pc1), dt
+
+
+@pytest.mark.parametrize('storage', ['f16', 'bf16'])
+def test_csp_fused_last_level_on_the_production_plan(storage):
+    """CSP-Dual-FPN: the PRODUCTION plan (no debug taps) runs the full-resolution decoder level + head as one row-walking launch per decoder (k_csphead.h).  Its
+    segmentation outputs against the reference's fp32 fixture at the bounds every 16-bit output is held to, and against the layer-wise plan (csp_fuse = 0) at twice
+    those bounds (the two round x, a, y, h at different places); every other output is untouched by the option: bit-identical."""
+    g = Golden('en_s0_cdf')
+    x, xr, xp = make_inputs(g.meta['batch'], g.meta['input_seed'], resolution=g.meta['ctor']['resolution'], pc_channels=g.meta['ctor']['pc_channels'])
+    xs = tuple(t.cuda().bfloat16() for t in (x, xr, xp))
+    res = {}
+    for fuse in (2, 1, 0):
+        m, kw = _model(g)
+        m.bf16_storage = storage
+        m.engine_options = {'csp_fuse': fuse}
+        with torch.no_grad():
+            det, se, lane, pc = m(*xs)
+        torch.cuda.synchronize()
+        names = [o['op'] for o in _engine_of(m, torch.bfloat16).op_table_full()]
+        assert sum('csp_level+head' in n for n in names) == (2 if fuse else 0) and sum(n.endswith('.csp_level') for n in names) == (2 if fuse == 2 else 0)
+        res[fuse] = (det, se, lane, pc)
+        if fuse:
+            tol = {k: (H16_TOL[k] if storage == 'f16' else 4.0 * H16_TOL[k]) for k in ('se_seg', 'lane_seg')}      # bf16 storage: 8x coarser rounding
+            e_se, e_lane = g.rel_err('se_seg', se.float(), check_sums=False), g.rel_err('lane_seg', lane.float(), check_sums=False)
+            print(f'en_s0_cdf fused levels (csp_fuse = {fuse}) [{storage} storage]: se {e_se:.2e} lane {e_lane:.2e}')
+            assert e_se < tol['se_seg'] and e_lane < tol['lane_seg'], (e_se, e_lane)
+    scale = 2.0 if storage == 'f16' else 8.0
+    for fuse in (2, 1):
+        assert _rel(res[fuse][1].float(), res[0][1].float()) < scale * H16_TOL['se_seg'] and _rel(res[fuse][2].float(), res[0][2].float()) < scale * H16_TOL['lane_seg']
+        for a, b in zip((*res[fuse][0], res[fuse][3]), (*res[0][0], res[0][3])):
+            assert torch.equal(a, b)
