@@ -528,7 +528,7 @@ def main():
                     'launch_ms': round(probe_ms, 5), 'launches_timed': probe_n, 'launch_ms_isolated': round(prof[dom], 5), 'launch_ms_isolated_best_of_3': round(prof_min[dom], 5),
                     'frac_isolated': round(dom_bytes / (prof[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if prof[dom] > 0 else None,
                     'share_of_forward': round(prof[dom] / max(sum(prof), 1e-9), 4)}
-        traffic_file = next((f for f in (os.path.join(ROOT, 'profiles', f'r{r:02d}_traffic_{args.config}.json') for r in (4, 3, 2)) if os.path.exists(f)), '')
+        traffic_file = next((f for f in (os.path.join(ROOT, 'profiles', f'r{r:02d}_traffic_{args.config}.json') for r in (5, 4, 3, 2)) if os.path.exists(f)), '')
         if traffic_file and args.dtype != 'f32' and B == 64:          # PMC passes are separate rocprofv3 runs (profiles/scripts/profile_config.sh)
             try:
                 roofline['traffic'] = json.load(open(traffic_file))['ops'].get(name, {}).get('traffic_bytes')

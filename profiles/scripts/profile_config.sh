@@ -1,11 +1,11 @@
 #!/bin/bash
-# Everything a reader needs to recompute the bench line's fractions for one config, into profiles/ (round tag $TAG, default r04):
+# Everything a reader needs to recompute the bench line's fractions for one config, into profiles/ (round tag $TAG, default r05):
 #   ${TAG}_kernel_stats_<cfg>.csv  rocprofv3 --kernel-trace --stats of the bench command (per-kernel calls / average duration)
 #   ${TAG}_traffic_<cfg>.json      per-launch HBM traffic from two separate PMC passes (FETCH_SIZE, WRITE_SIZE)
 #   ${TAG}_bench_<cfg>.json        the bench line itself (+ ${TAG}_ops_<cfg>.json: per-launch isolated times, bytes, flops)
 # usage (GPU box, repo root): bash profiles/scripts/profile_config.sh <cfg>      -> files under gpurun_out/prof_<cfg>/ (copy to profiles/)
 cfg=${1:-en_s0}
-TAG=${TAG:-r04}
+TAG=${TAG:-r05}
 root="${GRAFT_REPO_ROOT:-/root/repo}"
 cd /tmp && export TMPDIR=/tmp
 cd "$root"

@@ -2,9 +2,9 @@
 # Everything under profiles/ for one round, on one box: per-config kernel stats + PMC traffic + bench lines (profile_config.sh), the
 # bench variants of the headline config, the training-step record.  usage: bash profiles/scripts/round_artifacts.sh   -> gpurun_out/
 root="${GRAFT_REPO_ROOT:-/root/repo}"
-export TAG=${TAG:-r04}
+export TAG=${TAG:-r05}
 cd "$root"; mkdir -p gpurun_out/variants
-for cfg in en_s0 mv_s2 en_s2 en_s0_pn2; do bash profiles/scripts/profile_config.sh $cfg > gpurun_out/profile_$cfg.log 2>&1; done
+for cfg in en_s0 mv_s2 en_s2 en_s0_pn2 en_s0_cdf; do bash profiles/scripts/profile_config.sh $cfg > gpurun_out/profile_$cfg.log 2>&1; done
 b() { name=$1; shift; python bench.py --steps 20 --warmup 5 --no-cpu-baseline "$@" 2>/dev/null | grep '^{"metric' | tail -1 > gpurun_out/variants/${TAG}_bench_$name.json; }
 b en_s0_dense_radar --dense-radar
 b en_s0_storage_bf16 --storage bf16
@@ -15,7 +15,8 @@ b en_s0_pn2_pipelined --config en_s0_pn2 --pipeline
 b en_s1 --config en_s1
 b en_s0_dense_radar_noskip --dense-radar --opt radar_skip=0
 b en_s0_noskip --opt radar_skip=0
-b en_s0_cdf --config en_s0_cdf
+b en_s0_cdf_layerwise --config en_s0_cdf --opt csp_fuse=0
+b en_s0_cdf_last_level_only --config en_s0_cdf --opt csp_fuse=1
 b en_s0_f32 --dtype f32
 b en_s0_b1 --batch 1
 b en_s0_b8 --batch 8
