@@ -488,6 +488,12 @@ public:
             add_op(name, [bp, nb, shape](hipStream_t s) { launch_mlp_band<T>(bp, shape, nb, s); }, bytes, flops);
             return true;
         }
+        // plain rows, wide blocks (MobileViT's feed-forward layers, d = 144 / 192): two tiles per wave — half the weight traffic (k_mlp.h ffn2_kernel); bit-identical
+        // (large maps only — the per-sample size decides, as for `split`: on the 20 x 20 maps 800 two-tile waves are too few, 54 -> 118 us measured)
+        if constexpr (H16E) if (ffn_rows2 && !split && !dw_ks && (DT == 10 || DT == 12) && mp.M >= long(ffn_rows2_min)) {
+            add_op(name, [mp, DT](hipStream_t s) { launch_ffn2<T>(mp, DT, s); }, bytes, flops);
+            return true;
+        }
         add_op(name, [mp, DT, split](hipStream_t s) { launch_mlp<T>(mp, DT, split, s); }, bytes, flops);
         return true;
     }

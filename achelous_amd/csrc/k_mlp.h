@@ -488,6 +488,146 @@ inline bool launch_mlp(const MlpParams& p, int DT, bool split, hipStream_t strea
 #undef ACH_MLP_CASE
     return false;
 }
+// ------------------------------------------------------------------------------------------ two tiles per wave (round 5)
+// The feed-forward blocks of MobileViT's transformers (LN -> fc1 -> SiLU -> fc2 -> + input; d = 144 / 192, hidden 2d) are plain-row launches of mlp_kernel with one
+// 16-row tile per wave: every wave streams the layer's 2 d * 2d weights (166 / 295 KB) through L1 for its 16 rows — ~1 GB of L2 reads per layer at batch 64, and the
+// measured time (99 - 105 us at d = 144) IS that volume at the L2's rate.  Here a wave owns TWO tiles: a weight fragment is loaded once and feeds
+// two MFMAs, half the L2 traffic; same weight packing, the same sums in the same order per row (bit-identical to mlp_kernel).
+template <class T, int DT>
+__global__ __launch_bounds__(256, 2) void ffn2_kernel(const MlpParams p) { f16_sat_mode<T>();
+    constexpr int VEC = Store<T>::VEC;
+    constexpr int KC = 4 * VEC;
+    constexpr int K1MAX = (16 * DT + KC - 1) / KC;
+    constexpr int HSTEP = 8 / VEC;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int px = lane & 15, g = lane >> 4;
+    const long pair = long(blockIdx.x) * 4 + wave;
+    const T* X = static_cast<const T*>(p.X);
+    long m[2]; bool valid[2];
+    uint4 xf[2][K1MAX];
+    ACH_UNROLL
+    for (int q = 0; q < 2; ++q) {
+        const long mraw = (pair * 2 + q) * 16 + px;
+        valid[q] = mraw < p.M;
+        m[q] = valid[q] ? mraw : 0;
+        float s1 = 0.f, s2 = 0.f;
+        ACH_UNROLL
+        for (int s = 0; s < K1MAX; ++s) {
+            xf[q][s] = make_uint4(0u, 0u, 0u, 0u);
+            const int k0 = s * KC + g * VEC;
+            if (s < p.k1 && valid[q] && k0 < p.C) {
+                xf[q][s] = *reinterpret_cast<const uint4*>(X + m[q] * p.ldx + k0);
+                float v[8];
+                frag_unpack<T>(xf[q][s], v);
+                ACH_UNROLL
+                for (int i = 0; i < VEC; ++i) { s1 += v[i]; s2 += v[i] * v[i]; }
+            }
+        }
+        s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+        s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+        if (p.ln) {
+            const float mu = s1 / float(p.C);
+            float var = s2 / float(p.C) - mu * mu;
+            var = var > 0.f ? var : 0.f;
+            const float rstd = 1.0f / sqrtf(var + p.ln_eps);
+            ACH_UNROLL
+            for (int s = 0; s < K1MAX; ++s) {
+                if (s >= p.k1) continue;
+                const int k0 = s * KC + g * VEC;
+                float v[8];
+                frag_unpack<T>(xf[q][s], v);
+                ACH_UNROLL
+                for (int i = 0; i < VEC; ++i) v[i] = (k0 + i < p.C) ? (v[i] - mu) * rstd : 0.f;
+                xf[q][s] = frag_pack<T>(v);
+            }
+        }
+    }
+    f32x4 acc2[2][DT];
+    ACH_UNROLL
+    for (int q = 0; q < 2; ++q)
+        ACH_UNROLL
+        for (int t = 0; t < DT; ++t) { acc2[q][t][0] = 0.f; acc2[q][t][1] = 0.f; acc2[q][t][2] = 0.f; acc2[q][t][3] = 0.f; }
+    const uint4* W1f = static_cast<const uint4*>(p.W1) + lane;
+    const uint4* W2f = static_cast<const uint4*>(p.W2) + lane;
+    auto hidden = [&](auto actc) {
+        constexpr int ACT = decltype(actc)::value;
+        for (int j = 0; j < p.J; ++j) {
+            f32x4 a0[2], a1[2];
+            ACH_UNROLL
+            for (int q = 0; q < 2; ++q) { a0[q][0] = a0[q][1] = a0[q][2] = a0[q][3] = 0.f; a1[q][0] = a1[q][1] = a1[q][2] = a1[q][3] = 0.f; }
+            const f32x4 bA = *reinterpret_cast<const f32x4*>(p.b1 + j * 32 + g * 8), bB = *reinterpret_cast<const f32x4*>(p.b1 + j * 32 + g * 8 + 4);
+            const uint4* w1 = W1f + long(j) * p.k1 * 2 * 64;
+            // (k-steps beyond k1 re-read the last fragment against a zero input: branch-free, every load of the chunk can be in flight at once)
+            uint4 wa[K1MAX], wb[K1MAX];
+            ACH_UNROLL
+            for (int s = 0; s < K1MAX; ++s) { const int sc = s < p.k1 ? s : p.k1 - 1; wa[s] = w1[(sc * 2) * 64]; wb[s] = w1[(sc * 2 + 1) * 64]; }
+            ACH_UNROLL
+            for (int s = 0; s < K1MAX; ++s) {
+                mfma16<T>(wa[s], xf[0][s], a0[0]); mfma16<T>(wb[s], xf[0][s], a1[0]);
+                mfma16<T>(wa[s], xf[1][s], a0[1]); mfma16<T>(wb[s], xf[1][s], a1[1]);
+            }
+            uint4 hf[2][HSTEP];
+            ACH_UNROLL
+            for (int q = 0; q < 2; ++q) {
+                float h[8];
+                ACH_UNROLL
+                for (int r = 0; r < 4; ++r) { h[r] = a0[q][r] + bA[r]; h[4 + r] = a1[q][r] + bB[r]; }
+                apply_act_n<T, 8, ACT>(h, p.act);
+                ACH_UNROLL
+                for (int hh = 0; hh < HSTEP; ++hh) hf[q][hh] = frag_pack<T>(h + hh * VEC);
+            }
+            ACH_UNROLL
+            for (int hh = 0; hh < HSTEP; ++hh) {
+                const uint4* w2 = W2f + long(j * HSTEP + hh) * DT * 64;
+                ACH_UNROLL
+                for (int t = 0; t < DT; ++t) { const uint4 w = w2[t * 64]; mfma16<T>(w, hf[0][hh], acc2[0][t]); mfma16<T>(w, hf[1][hh], acc2[1][t]); }
+            }
+        }
+    };
+    switch (p.act) {
+        case ACT_GELU: hidden(std::integral_constant<int, ACT_GELU>{}); break;
+        case ACT_SILU: hidden(std::integral_constant<int, ACT_SILU>{}); break;
+        default: hidden(std::integral_constant<int, -1>{}); break;
+    }
+    // + bias + residual, 8 consecutive channels per lane per tile pair (mlp_kernel's 16-bit epilogue)
+    constexpr int NP = DT / 2;
+    const bool hasR = p.R != nullptr;
+    ACH_UNROLL
+    for (int q = 0; q < 2; ++q) {
+        uint4 rr[NP];
+        float4 ba[NP], bb[NP];
+        ACH_UNROLL
+        for (int pr_ = 0; pr_ < NP; ++pr_) {
+            const int nb = pr_ * 32 + g * 8;
+            ba[pr_] = *reinterpret_cast<const float4*>(p.b2 + nb);
+            bb[pr_] = *reinterpret_cast<const float4*>(p.b2 + nb + 4);
+            rr[pr_] = make_uint4(0u, 0u, 0u, 0u);
+            if (hasR) rr[pr_] = *reinterpret_cast<const uint4*>(static_cast<const T*>(p.R) + m[q] * p.ldr + (nb < p.Cout ? nb : 0));
+        }
+        ACH_UNROLL
+        for (int pr_ = 0; pr_ < NP; ++pr_) {
+            const int nb = pr_ * 32 + g * 8;
+            float r8[8], o[8];
+            frag_unpack<T>(rr[pr_], r8);
+            const float bv[8] = {ba[pr_].x, ba[pr_].y, ba[pr_].z, ba[pr_].w, bb[pr_].x, bb[pr_].y, bb[pr_].z, bb[pr_].w};
+            ACH_UNROLL
+            for (int r = 0; r < 4; ++r) { o[r] = acc2[q][2 * pr_][r] + bv[r] + r8[r]; o[4 + r] = acc2[q][2 * pr_ + 1][r] + bv[4 + r] + r8[4 + r]; }
+            if (valid[q] && nb < p.Cout) Store<T>::st8(static_cast<T*>(p.Y) + m[q] * p.ldy + nb, o);
+        }
+    }
+}
+// plain-row launches (no depthwise conv) of the 16-bit engines whose width is instantiated: two tiles per wave
+template <class T>
+inline bool launch_ffn2(const MlpParams& p, int DT, hipStream_t stream) {
+    if constexpr (sizeof(T) != 2) return false;
+    else {
+        if (p.dw_k != 0 || (DT != 10 && DT != 12)) return false;
+        const long tiles = (p.M + 15) / 16;
+        const dim3 grid(unsigned((tiles + 7) / 8)), block(256);
+        if (DT == 10) ACH_LAUNCH((ffn2_kernel<T, 10>), grid, block, stream, p); else ACH_LAUNCH((ffn2_kernel<T, 12>), grid, block, stream, p);
+        return true;
+    }
+}
 inline bool mlp_even_dt(int DT) { return DT == 10; }      // d = 96 (DT 6) re-measured at the 128-register budget: 45 -> 49 us per block, still not instantiated
 inline int mlp_pick_dt(int C) {
     const int need = 2 * ((C + 31) / 32);

@@ -807,3 +807,33 @@ def test_emulated_csp_fused_last_level_matches_the_layerwise_launches(res, band,
             assert rel_err(outs[fuse][k], outs[0][k]) < sdt[2] * 3e-2, (fuse, k, rel_err(outs[fuse][k], outs[0][k]))
         assert rel_err(outs[fuse][0], se) < sdt[2] * 6e-2 and rel_err(outs[fuse][1], lane) < sdt[2] * 6e-2
     assert rel_err(outs[0][0], se) < sdt[2] * 6e-2 and rel_err(outs[0][1], lane) < sdt[2] * 6e-2
+
+
+@pytest.mark.parametrize('sdt', H16)
+def test_emulated_two_tiles_per_wave_ffn_is_bit_identical_to_the_one_tile_kernel(sdt):
+    """MobileViT's transformer feed-forward layers (d = 144 / 192 on MV-S2) through ffn2_kernel (k_mlp.h: two 16-row tiles per wave, every weight fragment feeds two
+    MFMAs; option ffn_rows2 = 1, default) against the one-tile-per-wave launches of mlp_kernel (ffn_rows2 = 0, mlp_split = 0): the same sums in the same order,
+    bit-identical backbone taps and outputs.  Against the default small-map mode of the old path (four waves per tile, partial sums through LDS): rounding only."""
+    from achelous_amd.engine import NativeEngine
+    kw, sd, (x, xr, xp) = _setup('mv_s2', 128, 2, 16)
+    res = {}
+    # (mlp_split = 0: at 128 x 128 every map is below the four-waves-per-tile threshold, and ffn2 takes the one-tile-per-wave launches only)
+    for tag, opts in (('rows2', {'ffn_rows2': 1, 'mlp_split': 0}), ('one_tile', {'ffn_rows2': 0, 'mlp_split': 0}), ('split', {'ffn_rows2': 0})):     # (mlp_split = 0 also for the blocks ffn2 does not take: d = 240)
+        eng = NativeEngine(emu_library(), num_det=kw['num_det'], num_seg=kw['num_seg'], phi=kw['phi'], backbone=kw['backbone'], resolution=128,
+                           pc_channels=kw['pc_channels'], pc_classes=kw['pc_classes'], num_points=16, nano_head=True, spp=True, dtype=sdt[0])
+        eng.set_option('full_taps', 1)
+        for k, v in opts.items():
+            eng.set_option(k, v)
+        eng.load_state_dict(sd)
+        eng.plan(2)
+        o = alloc_outputs(kw, 2, 16, sdt[1], 'cpu')
+        eng.forward(x.to(sdt[1]), xr.to(sdt[1]), xp.to(sdt[1]), o)
+        taps = {t: eng.read_tap(t) for t in eng.tap_names() if t.startswith('backbone.') or t.startswith('map')}
+        res[tag] = ([t.float() for t in o], taps)
+    assert len(res['rows2'][1]) >= 4
+    for t in res['rows2'][1]:
+        assert torch.equal(res['rows2'][1][t], res['one_tile'][1][t]), t
+    for a, b in zip(res['rows2'][0], res['one_tile'][0]):
+        assert torch.equal(a, b)
+    for a, b in zip(res['rows2'][0], res['split'][0]):
+        assert rel_err(a, b) < sdt[2] * 4e-2
