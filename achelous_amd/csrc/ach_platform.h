@@ -420,6 +420,7 @@ inline uint4 buf_load16(const BufRsrc& r, unsigned off) {
     return v;
 }
 inline uint4 buf_load16s(const BufRsrc& r, unsigned voff, unsigned soff) { return buf_load16(r, voff + soff); }
+inline uint4 buf_load16_agent(const BufRsrc& r, unsigned off) { return buf_load16(r, off); }
 #else
 typedef __amdgpu_buffer_rsrc_t BufRsrc;
 typedef unsigned int buf_u32x4 __attribute__((ext_vector_type(4)));
@@ -428,6 +429,11 @@ __device__ __forceinline__ BufRsrc make_buf(const void* p, unsigned bytes) {
 }
 __device__ __forceinline__ uint4 buf_load16(BufRsrc r, unsigned off) {
     const buf_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, int(off), 0, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+// the same load at AGENT scope (sc1: it must not be served from this compute unit's L1): data another workgroup of the running kernel wrote (k_mlpband.h run kernel)
+__device__ __forceinline__ uint4 buf_load16_agent(BufRsrc r, unsigned off) {
+    const buf_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, int(off), 0, 0x10);
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 // per-lane offset + wave-uniform offset (the MUBUF soffset operand: no VALU add); the range check applies to their sum

@@ -114,6 +114,7 @@ int ach_set_option(ach_handle* h, const char* key, int32_t value) {
         else if (std::string(key) == "level_chain") h->eng->level_chain = value != 0;
         else if (std::string(key) == "level_rows") h->eng->level_rows = value != 0;
         else if (std::string(key) == "mlp_band") h->eng->mlp_band = value;
+        else if (std::string(key) == "mlp_band_run") h->eng->mlp_band_run = value != 0;
         else if (std::string(key) == "mlp_band_dbg") h->eng->mlp_band_dbg = value;
         else if (std::string(key) == "head_band") h->eng->head_band = value > 0 ? value : 40;
         else if (std::string(key) == "head_grid") h->eng->head_grid = value;

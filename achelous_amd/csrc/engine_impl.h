@@ -398,6 +398,46 @@ public:
     }
     // One launch for [depthwise kxk ->] LN -> Linear -> act -> Linear -> scale -> + resid (k_mlp.h).  Returns false when the
     // width is outside the kernel's instantiations (the caller then runs the layer-wise path).
+    // ConvEncoder blocks that took the band kernel, in plan order (index of their launch): merge_band_runs turns each run of consecutive ones — block i + 1 reads what
+    // block i wrote, same geometry, nothing else of the plan in between — into ONE persistent launch (k_mlpband.h mlp_band_run_kernel; option "mlp_band_run")
+    struct BandOp { size_t op; MlpBandParams bp; int nb, shape; };
+    std::vector<BandOp> band_ops;
+    void merge_band_runs() {
+#if !defined(ACH_HOSTEMU)
+        if constexpr (H16E) {
+            if (measuring || !mlp_band_run || use_graph) { band_ops.clear(); return; }
+            for (size_t a = 0; a < band_ops.size();) {
+                size_t e = a + 1;
+                while (e < band_ops.size() && e - a < size_t(MLPB_RUN_MAX) && band_ops[e].op == band_ops[e - 1].op + 1 && band_ops[e].shape == band_ops[a].shape && band_ops[e].nb == band_ops[a].nb &&
+                       band_ops[e].bp.m.X == band_ops[e - 1].bp.m.Y && band_ops[e].bp.bands == band_ops[a].bp.bands && band_ops[e].bp.rb == band_ops[a].bp.rb &&
+                       ops[band_ops[e].op].stream == ops[band_ops[a].op].stream && ops[band_ops[e].op].wait_ev < 0 && ops[band_ops[e].op].wait_ev2 < 0 && !ops[band_ops[e].op].xwait &&
+                       !ops[band_ops[e].op].xwait2 && ops[band_ops[e - 1].op].signal_ev < 0 && !ops[band_ops[e - 1].op].xsignal && !ops[band_ops[e - 1].op].xsignal2) ++e;
+                const size_t n = e - a;
+                // (the bands of a frame must share an XCD — xcd_block: the launch's workgroups in eight equal chunks of whole frames — because the blocks hand their rows over through that L2)
+                const long nwg = long(band_ops[a].bp.bands) * band_ops[a].nb;
+                if (n >= 2 && mlp_band_run_shape(band_ops[a].shape) && nwg % 8 == 0 && (nwg / 8) % band_ops[a].bp.bands == 0) {
+                    MlpBandRunParams rp;
+                    std::memset(&rp, 0, sizeof(rp));
+                    for (size_t k = 0; k < n; ++k) rp.blk[k] = band_ops[a + k].bp;
+                    rp.n = int(n);
+                    std::vector<unsigned> zeros(size_t(band_ops[a].nb), 0u);
+                    rp.sync = static_cast<unsigned*>(up_raw(zeros.data(), zeros.size() * sizeof(unsigned)));
+                    const int nb = band_ops[a].nb, shape = band_ops[a].shape;
+                    const size_t first = band_ops[a].op, last = band_ops[e - 1].op;
+                    Op& op = ops[first];
+                    for (size_t k = first + 1; k <= last; ++k) { op.bytes += ops[k].bytes; op.layout_bytes += ops[k].layout_bytes; op.flops += ops[k].flops; }
+                    op.signal_ev = ops[last].signal_ev; op.xsignal = ops[last].xsignal; op.xsignal2 = ops[last].xsignal2;
+                    op.name += "..+" + std::to_string(n - 1);
+                    op.fn = [rp, nb, shape](hipStream_t s) mutable { launch_mlp_band_run<T>(rp, shape, nb, s); ++rp.epoch; };
+                    ops.erase(ops.begin() + long(first) + 1, ops.begin() + long(last) + 1);
+                    for (size_t k = e; k < band_ops.size(); ++k) band_ops[k].op -= n - 1;
+                }
+                a = e;
+            }
+        }
+#endif
+        band_ops.clear();
+    }
     bool fused_mlp(const std::string& pfx, const A& xin, const A& resid, int dw_ks, A& y) {
         if (!fuse_mlp || mlp_pick_dt(xin.C) == 0) return false;
         Lin l1 = lin(pfx + ".pwconv1.weight", pfx + ".pwconv1.bias");
@@ -485,6 +525,7 @@ public:
             MlpBandParams bp;
             bp.m = mp; bp.rb = mlp_band_rows(k1, DT, dw_ks, xin.H, xin.W); bp.bands = cdiv(xin.H, bp.rb); bp.dbg = mlp_band_dbg;
             const int nb = xin.B, shape = mlp_band_shape(k1, DT, dw_ks, xin.W);
+            if (!measuring) band_ops.push_back(BandOp{ops.size(), bp, nb, shape});          // (merge_band_runs: consecutive blocks of a stage as one launch)
             add_op(name, [bp, nb, shape](hipStream_t s) { launch_mlp_band<T>(bp, shape, nb, s); }, bytes, flops);
             return true;
         }
@@ -714,6 +755,7 @@ public:
             }
             if (has_preset) throw AchError{ACH_ERR_INVALID, "stage output destination was not consumed"};
             feats[i] = x;
+            merge_band_runs();
             if (i == radar_start_eff()) signal_after_last(0);
         }
     }

@@ -52,25 +52,24 @@ struct MlpBandGeom {
 // PREF: the next hidden chunk's weight fragments are requested one chunk ahead (a second register set).
 // TILEPAR (the narrow blocks of the large maps: few hidden chunks, many tiles): a wave takes whole TILES (t = wave, wave + 8, ...) through
 // every hidden chunk instead of a share of the chunks for every tile — no partial sums, no reduction phase.
-template <class T, int K1, int DT, int KS, int RB, int MAXW, bool XF32, bool PREF, bool TILEPAR = false>
-__global__ __launch_bounds__(MLPB_THREADS, 1) void mlp_band_kernel(const MlpBandParams bp) { f16_sat_mode<T>();
+// the block for (frame b, band) of `bp`, on the workgroup's two LDS arrays (the kernel below; mlp_band_run_kernel calls it once per block of a run)
+// COH: the input rows may have been written by OTHER workgroups of the running launch (the run kernel): the halo loads go to L2 (agent scope), not to this unit's L1
+template <class T, int K1, int DT, int KS, int RB, int MAXW, bool XF32, bool PREF, bool TILEPAR, bool COH = false>
+__device__ __forceinline__ void mlp_band_body(const MlpBandParams& bp, const int band, const int b, float* xin, float* dwv) {
     using G = MlpBandGeom<K1, DT, KS, RB, MAXW, XF32>;
     constexpr int CP = G::CP, NT = G::NT, SP = MLPB_SP, NTB = mlpb_ntb(DT);
     const MlpParams& p = bp.m;
-    __shared__ float xin[G::XIN_FLOATS];
-    __shared__ float dwv[G::DWV_FLOATS];
     uint4* xs = reinterpret_cast<uint4*>(xin);                    // (phases 2-3; the halo tile is dead by then)
     float* red = xin + G::RED_OFF_FLOATS;                         // (phase 4)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int px = lane & 15, g = lane >> 4;
-    const unsigned wg = xcd_block(blockIdx.x, gridDim.x);
-    const int band = int(wg % unsigned(bp.bands)), b = int(wg / unsigned(bp.bands));
     const int H = p.H, W = p.W, C = p.C;
     const int y0 = band * bp.rb, rows = (y0 + bp.rb <= H) ? bp.rb : H - y0;
     const int npx = rows * W, nt = (npx + 15) / 16;
     const int WCr = W + KS - 1, HRr = rows + KS - 1;
     const T* X = static_cast<const T*>(p.X) + long(b) * H * W * p.ldx;
+    const BufRsrc xcoh = make_buf(X, COH ? unsigned(long(H) * W * p.ldx * long(sizeof(T))) : 0u);       // (one frame: far below 2 GiB)
 
     // ---- 0. halo tile -> LDS (fp32), zero outside the map and beyond the real channels
     if (!(bp.dbg & 1)) {
@@ -86,7 +85,10 @@ __global__ __launch_bounds__(MLPB_THREADS, 1) void mlp_band_kernel(const MlpBand
                 if (it < total) {
                     const int c8 = it % C8, pos = it / C8, wc = pos % WCr, hr = pos / WCr;
                     const int iy = y0 - KS / 2 + hr, ix = wc - KS / 2;
-                    if (iy >= 0 && iy < H && ix >= 0 && ix < W && c8 * 8 < C) raw[u] = *reinterpret_cast<const uint4*>(X + (long(iy) * W + ix) * p.ldx + c8 * 8);
+                    if (iy >= 0 && iy < H && ix >= 0 && ix < W && c8 * 8 < C) {
+                        if (COH && !(bp.dbg & 64)) raw[u] = buf_load16_agent(xcoh, unsigned(((long(iy) * W + ix) * p.ldx + c8 * 8) * long(sizeof(T))));
+                        else raw[u] = *reinterpret_cast<const uint4*>(X + (long(iy) * W + ix) * p.ldx + c8 * 8);
+                    }
                 }
             }
             ACH_UNROLL
@@ -323,6 +325,71 @@ __global__ __launch_bounds__(MLPB_THREADS, 1) void mlp_band_kernel(const MlpBand
         }
     }
 }
+
+template <class T, int K1, int DT, int KS, int RB, int MAXW, bool XF32, bool PREF, bool TILEPAR = false>
+__global__ __launch_bounds__(MLPB_THREADS, 1) void mlp_band_kernel(const MlpBandParams bp) { f16_sat_mode<T>();
+    using G = MlpBandGeom<K1, DT, KS, RB, MAXW, XF32>;
+    __shared__ float xin[G::XIN_FLOATS];
+    __shared__ float dwv[G::DWV_FLOATS];
+    const unsigned wg = xcd_block(blockIdx.x, gridDim.x);
+    mlp_band_body<T, K1, DT, KS, RB, MAXW, XF32, PREF, TILEPAR>(bp, int(wg % unsigned(bp.bands)), int(wg / unsigned(bp.bands)), xin, dwv);
+}
+
+// ------------------------------------------------------------------------------------------ a RUN of blocks as one launch (round 5)
+// A stage's ConvEncoder blocks are the same kernel on the same geometry, each reading what the previous one wrote — five launches at 20 x 20 (EdgeNeXt-S0 stage 2; nine
+// on S2), each of which needs an EMPTY compute unit per workgroup (2 x 238 VGPRs per SIMD, 153 KB of LDS).  In the pipelined step the side streams' workgroups take every
+// unit a finished block frees, and each of the five launches waits again: 58 / 53 / 72 / 49 / 30 us in-step against 26 - 27 alone.  Here ONE launch runs the
+// whole run: a workgroup keeps its compute unit and its (frame, band) for all blocks; between two blocks the bands of a FRAME (the only workgroups whose halo rows it reads)
+// meet at a counter in global memory — release fence, one atomic add per workgroup, a bounded spin, acquire fence (which also drops the stale L1 lines of the
+// neighbours' rows).  The frame's workgroups sit on one XCD (xcd_block), so the traffic stays in that L2.  Deadlock-free: a workgroup that is not resident yet holds nothing,
+// and the resident ones wait only for workgroups of their own launch, which the dispatcher places as other kernels' workgroups retire; the spin is BOUNDED all the same
+// (a wrong result is a failed test, a hung GPU is a lost box).  `epoch` (the launch's sequence number, from the host) makes the counters monotonic: no reset launch.
+constexpr int MLPB_RUN_MAX = 9;
+struct MlpBandRunParams {
+    MlpBandParams blk[MLPB_RUN_MAX];
+    int n;
+    unsigned* sync;              // [frames], zero when the plan is built
+    unsigned epoch;
+};
+#if !defined(ACH_HOSTEMU)
+template <class T, int K1, int DT, int KS, int RB, int MAXW, bool XF32, bool PREF>
+__global__ __launch_bounds__(MLPB_THREADS, 1) void mlp_band_run_kernel(const MlpBandRunParams rp) { f16_sat_mode<T>();
+    using G = MlpBandGeom<K1, DT, KS, RB, MAXW, XF32>;
+    __shared__ float xin[G::XIN_FLOATS];
+    __shared__ float dwv[G::DWV_FLOATS];
+    const unsigned wg = xcd_block(blockIdx.x, gridDim.x);
+    const int bands = rp.blk[0].bands;
+    const int band = int(wg % unsigned(bands)), b = int(wg / unsigned(bands));
+    ACH_NO_UNROLL
+    for (int i = 0; i < rp.n; ++i) {
+        mlp_band_body<T, K1, DT, KS, RB, MAXW, XF32, PREF, false, true>(rp.blk[i], band, b, xin, dwv);        // (one instantiation: the first block's agent-scope loads are merely unnecessary)
+        if (i + 1 == rp.n) break;
+        // this wave's rows of Y have reached L2 (the L1 is write-through; the frame's workgroups share an XCD, i.e. that L2: an AGENT-scope release would write the whole
+        // L2 back and the matching acquire would drop it — measured: 41.5 k -> 37.8 k frames/s) before the workgroup arrives
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        if (threadIdx.x == 0 && !(rp.blk[0].dbg & 32)) {          // (dbg 32 / 64: timing experiments — no barrier / plain halo loads; wrong results)
+            const unsigned target = (rp.epoch * unsigned(rp.n - 1) + unsigned(i + 1)) * unsigned(bands);
+            __hip_atomic_fetch_add(rp.sync + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int spin = 0; spin < (1 << 22); ++spin) {
+                if (int(__hip_atomic_load(rp.sync + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0) break;
+                __builtin_amdgcn_s_sleep(8);
+            }
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");       // (ordering only: the next block's halo loads are agent-scope loads, see COH)
+    }
+}
+template <class T>
+inline bool launch_mlp_band_run(const MlpBandRunParams& rp, int shape, int B, hipStream_t stream) {
+    const dim3 grid(unsigned(rp.blk[0].bands) * unsigned(B)), block(MLPB_THREADS);
+    if (shape == 1) ACH_LAUNCH((mlp_band_run_kernel<T, 3, 6, 7, 5, 20, true, true>), grid, block, stream, rp);
+    else if (shape == 3) ACH_LAUNCH((mlp_band_run_kernel<T, 5, 10, 7, 4, 20, false, false>), grid, block, stream, rp);
+    else return false;
+    return true;
+}
+#endif
+inline bool mlp_band_run_shape(int shape) { return shape == 1 || shape == 3; }
 
 // the instantiated shapes (k-steps of the input, output tiles, kernel size, rows per band, widest map):
 //   d =  96, 7x7, maps up to 20 wide (EdgeNeXt-S0 stage 2): fp32 halo tile, 5 rows, weights prefetched

@@ -1021,3 +1021,52 @@ def test_csp_fused_last_level_on_the_production_plan(storage):
         assert _rel(res[fuse][1].float(), res[0][1].float()) < scale * H16_TOL['se_seg'] and _rel(res[fuse][2].float(), res[0][2].float()) < scale * H16_TOL['lane_seg']
         for a, b in zip((*res[fuse][0], res[fuse][3]), (*res[0][0], res[0][3])):
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('name,blocks', [('en_s0', 5), ('en_s2', 8)])
+def test_persistent_band_run_is_bit_identical_to_the_separate_launches(name, blocks):
+    """Stage 2's ConvEncoder blocks as ONE persistent launch with per-frame barriers between the blocks (k_mlpband.h mlp_band_run_kernel, option mlp_band_run = 1; off by
+    default: measured no faster) against one launch per block (mlp_band_run = 0): the same kernel body on the same data — every output and every backbone tap bit-identical, over repeated
+    forwards (the barrier counters are monotonic across launches), plain and pipelined, both 16-bit storages, with the side streams busy beside it."""
+    g = Golden(name)
+    kw = ctor_kwargs(g.meta)
+    for storage in ('f16', 'bf16'):
+        batches = []
+        for i in range(3):
+            x, xr, xp = make_inputs(16, 800 + i, resolution=kw['resolution'], pc_channels=kw['pc_channels'], dense_radar=(i == 1))
+            batches.append(tuple(t.cuda().bfloat16() for t in (x, xr, xp)))
+        res = {}
+        for run in (1, 0):
+            m, _ = _model(g)
+            m.bf16_storage = storage
+            m.engine_options = {'mlp_band_run': run}
+            outs = []
+            with torch.no_grad():
+                for rep in range(4):
+                    for b in batches:
+                        outs.append([t.clone() for t in (lambda r: (*r[0][0], r[0][1], r[0][2], r[0][3], *r[1]))(m.forward_detect(*b, 0.05, 0.5, 100))])
+                torch.cuda.synchronize()
+                names = [o['op'] for o in _engine_of(m, torch.bfloat16).op_table_full()]
+                taps = {t: _engine_of(m, torch.bfloat16).read_tap(t) for t in _engine_of(m, torch.bfloat16).tap_names() if t.startswith('backbone.s2')}
+                prev, pip = None, []
+                for rep in range(3):
+                    for b in batches:
+                        nxt = m.submit_detect(*b, 0.05, 0.5, 100)
+                        if prev is not None:
+                            r = prev.wait()
+                            pip.append([t.clone() for t in (*r[0][0], r[0][1], r[0][2], r[0][3], *r[1])])
+                        prev = nxt
+                r = prev.wait()
+                pip.append([t.clone() for t in (*r[0][0], r[0][1], r[0][2], r[0][3], *r[1])])
+                torch.cuda.synchronize()
+            res[run] = (outs, taps, pip, names)
+        merged = [n for n in res[1][3] if '..+' in n]
+        assert len(merged) == 1 and merged[0].endswith(f'..+{blocks - 1}') and len(res[0][3]) - len(res[1][3]) == blocks - 1, (merged, len(res[0][3]), len(res[1][3]))
+        for a, b_ in zip(res[1][0], res[0][0]):
+            for p, q in zip(a, b_):
+                assert torch.equal(p, q), storage
+        for t in res[1][1]:
+            assert torch.equal(res[1][1][t], res[0][1][t]), (storage, t)
+        for k, a in enumerate(res[1][2]):
+            for p, q in zip(a, res[1][0][k % 3]):
+                assert torch.equal(p, q), (storage, 'pipelined', k)
