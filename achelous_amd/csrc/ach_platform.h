@@ -357,6 +357,26 @@ template <> __device__ __forceinline__ void mfma16<float>(const uint4& a, const 
 }
 #endif
 
+// The same k-chunk as TWO v_mfma_f32_16x16x16 instructions (k = 0..15, then 16..31: the same products, the same accumulation order per half) — the form every kernel
+// with LONG-LIVED matrix-instruction waves must use (row-walking kernels, multi-tile MLP waves): a co-resident wave that issues v_mfma_f32_16x16x32 changes the results of other
+// waves' MFMA chunk loops on the MI355X, two 16x16x16 do not (tests/test_gpu_coresidency.py).  Same matrix-pipe passes (2 x 4 instead of 8).
+#if defined(ACH_HOSTEMU)
+template <class T> __device__ inline void mfma16_pair(const uint4& a, const uint4& b, f32x4& c) { mfma16<T>(a, b, c); }
+#else
+template <class T> __device__ __forceinline__ void mfma16_pair(const uint4& a, const uint4& b, f32x4& c);
+template <> __device__ __forceinline__ void mfma16_pair<bf16_t>(const uint4& a, const uint4& b, f32x4& c) {
+    typedef short s16x4_p __attribute__((ext_vector_type(4)));
+    c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4_p, make_uint2(a.x, a.y)), __builtin_bit_cast(s16x4_p, make_uint2(b.x, b.y)), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4_p, make_uint2(a.z, a.w)), __builtin_bit_cast(s16x4_p, make_uint2(b.z, b.w)), c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ void mfma16_pair<f16_t>(const uint4& a, const uint4& b, f32x4& c) {
+    typedef _Float16 f16x4_p __attribute__((ext_vector_type(4)));
+    c = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4_p, make_uint2(a.x, a.y)), __builtin_bit_cast(f16x4_p, make_uint2(b.x, b.y)), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4_p, make_uint2(a.z, a.w)), __builtin_bit_cast(f16x4_p, make_uint2(b.z, b.w)), c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ void mfma16_pair<float>(const uint4& a, const uint4& b, f32x4& c) { mfma16<float>(a, b, c); }
+#endif
+
 // wave-level helpers for 64-bit masks (the CPU emulation goes through its shuffle)
 #if defined(ACH_HOSTEMU)
 __device__ inline unsigned long long wave_read64(unsigned long long v, int lane) { return __shfl(v, lane); }

@@ -586,6 +586,20 @@ public:
                double(mp.M) * (Cin + Cout) * sizeof(T), 2.0 * double(mp.M) * hidden * (Cin + Cout));
         return true;
     }
+    // the same pair with BOTH outputs kept, into existing (slices of) tensors: hdst = act(l1 x), ydst = l2 hdst — chain_kernel only (narrow layers, hidden a multiple of 32)
+    bool chain2_into(const std::string& name, const A& x, const Lin& l1, int act, const Lin& l2, const A& ydst, const A& hdst) {
+        if (!fuse_mlp || VEC != 8) return false;
+        const int Cin = x.C, hidden = l1.N, Cout = l2.N;
+        const int k1 = cdiv(Cin, KC), J = cdiv(hidden, 32);
+        if (!(Cout <= 32 && k1 <= 3 && J <= 2) || hidden % 32 || l1.K != Cin || l2.K != hidden || hdst.C != hidden || ydst.C != Cout || hdst.ld % 8 || ydst.ld % 8) return false;
+        MlpParams mp;
+        std::memset(&mp, 0, sizeof(mp));
+        mp.X = x.p; mp.ldx = x.ld; mp.Y = ydst.p; mp.ldy = ydst.ld; mp.Hout = hdst.p; mp.ldh = hdst.ld;
+        chain_weights(mp, Cin, 2, l1, act, l2);
+        mp.M = x.rows();
+        add_op(name, [mp](hipStream_t s) { launch_chain<T>(mp, s); }, double(mp.M) * (Cin + hidden + Cout) * sizeof(T), 2.0 * double(mp.M) * hidden * (Cin + Cout));
+        return true;
+    }
     A conv_encoder(const std::string& pfx, const A& x, int ks) {          // conv_encoder.py:19-32
         A fy;
         if (fused_mlp(pfx, x, x, ks, fy)) return fy;
@@ -1081,8 +1095,10 @@ public:
         if (double(y.H) * y.W * 48 * sizeof(T) >= 2147483648.0 || double(H2) * W2 * (head ? oup : int(dst->ld)) * sizeof(T) >= 2147483648.0) return false;
         A uv = alloc(y.B, y.H, y.W, 48);
         const A u = uv.slice(0, 32), v = uv.slice(32, 16);
-        { GemmOpt o; o.act = ACT_RELU; gemm(up_pfx + ".conv", y, pack(lu), u, o); }
-        gemm(bn_pfx + ".conv1_lowres", u, pack(l1), v);
+        if (!chain2_into(up_pfx + ".conv+conv1_lowres", y, lu, ACT_RELU, l1, v, u)) {            // one launch for both (u is the chain's hidden layer), or two GEMMs
+            { GemmOpt o; o.act = ACT_RELU; gemm(up_pfx + ".conv", y, pack(lu), u, o); }
+            gemm(bn_pfx + ".conv1_lowres", u, pack(l1), v);
+        }
         // A fragments (lane l: row i = l & 15, k group kg = l >> 4, elements j < 8), see k_csphead.h
         std::vector<uint16_t> f2(size_t(10) * 64 * 8, 0), f1(size_t(64) * 8, 0), f3(size_t(2) * 64 * 8, 0);
         for (int l = 0; l < 64; ++l) {

@@ -24,6 +24,7 @@
 // Round 5, second version (399 / 417 -> see DESIGN 4.20): a lane interpolates and activates only FOUR of its eight `a` channels — lanes (n, g) and (n, g ^ 2) need the
 // same eight — and the halves are exchanged with one cross-half shuffle per dword; x stays in fp32 registers until it is added; every store is a range-checked buffer
 // store at a per-lane offset computed once (no per-row branch); rows beyond the head's hidden width need no test (their A rows and biases are zero: silu(0) = 0).
+// Every matrix instruction of the walk is the 16x16x16 PAIR form (mfma16_pair): these are long-lived MFMA waves.
 // Numerics: u, v are stored in the engine's 16-bit type (as the layer-wise plan stores them); x, a, y, h are fp32 in registers and rounded once, where an MFMA
 // consumes them (the layer-wise plan rounds each to the storage type in HBM).
 #pragma once
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(64, 2) void csp_head_rows_kernel(const CspHeadParam
                     f.x = csph_tap<TB, 0xC>(f.x, am.d[0], ac.d[0], ap.d[0]); f.y = csph_tap<TB, 0xC>(f.y, am.d[1], ac.d[1], ap.d[1]);     \
                     f.z = csph_tap<TB, 0xC>(f.z, am.d[2], ac.d[2], ap.d[2]); f.w = csph_tap<TB, 0xC>(f.w, am.d[3], ac.d[3], ap.d[3]);     \
                 }                                                                                                                          \
-                mfma16<T>(w2[S][0], f, ca); mfma16<T>(w2[S][1], f, cb);                                                                    \
+                mfma16_pair<T>(w2[S][0], f, ca); mfma16_pair<T>(w2[S][1], f, cb);                                                                    \
             }
             CSPH_KSTEP(0) CSPH_KSTEP(1) CSPH_KSTEP(2) CSPH_KSTEP(3) CSPH_KSTEP(4)
 #undef CSPH_KSTEP
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(64, 2) void csp_head_rows_kernel(const CspHeadParam
             const uint4 yf = make_uint4(H16<T>::pack(y[0], y[1]), H16<T>::pack(y[2], y[3]), H16<T>::pack(y[4], y[5]), H16<T>::pack(y[6], y[7]));
             if (HEAD) {
                 f32x4 hh = {0.f, 0.f, 0.f, 0.f};
-                mfma16<T>(wh1, yf, hh);
+                mfma16_pair<T>(wh1, yf, hh);
                 const bool live = rb >= 0 && rb < H && in_x;                 // outside the map h is the last conv's zero padding
                 float hv[4];
                 ACH_UNROLL
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(64, 2) void csp_head_rows_kernel(const CspHeadParam
             f1.x = csph_tap<8, 0x1>(0u, hm.d[0], hc.d[0], hp.d[0]); f1.y = csph_tap<8, 0x1>(0u, hm.d[1], hc.d[1], hp.d[1]);
             f1.z = 0u; f1.w = 0u;
             f32x4 oc = {0.f, 0.f, 0.f, 0.f};
-            mfma16<T>(wh2a, f0, oc); mfma16<T>(wh2b, f1, oc);
+            mfma16_pair<T>(wh2a, f0, oc); mfma16_pair<T>(wh2b, f1, oc);
             const bool row_st = ro >= r0 && ro < r1;
             const BufRsrc orow = make_buf(out_b, row_st ? out_bytes : 0u);
             const unsigned soff = unsigned(wave_uniform(int(unsigned(row_st ? ro : r0) * unsigned(Wd) * unsigned(sizeof(IO)))));

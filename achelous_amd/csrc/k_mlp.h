@@ -56,6 +56,7 @@ struct MlpParams {
     int ln, Cout;                         // ln = 0: no normalisation (plain two-layer chain); Cout: output width (R may be null)
     int planar_w;                         // chain_kernel only, > 0: Y is written channel-planar per map row, [M / planar_w][Cout][planar_w]
     int dw_even;                          // SPLIT + depthwise: the k1 * dw_k tap ROWS are dealt evenly to the four waves (mlp_inputs), not whole k-steps
+    void* Hout; long ldh;                 // chain_kernel only, optional: the hidden activations act(W1 x + b1) are stored too (rows of ldh elements) — a layer pair whose FIRST output is needed as well (k_csphead.h's [u | v])
 };
 
 constexpr int MLP_RED_TILES = 4;          // output tiles reduced per LDS round in SPLIT mode
@@ -493,6 +494,8 @@ inline bool launch_mlp(const MlpParams& p, int DT, bool split, hipStream_t strea
 // 16-row tile per wave: every wave streams the layer's 2 d * 2d weights (166 / 295 KB) through L1 for its 16 rows — ~1 GB of L2 reads per layer at batch 64, and the
 // measured time (99 - 105 us at d = 144) IS that volume at the L2's rate.  Here a wave owns TWO tiles: a weight fragment is loaded once and feeds
 // two MFMAs, half the L2 traffic; same weight packing, the same sums in the same order per row (bit-identical to mlp_kernel).
+// Its waves live for 9 - 12 hidden chunks of ~40 matrix instructions: they use the 16x16x16 PAIR form (mfma16_pair, ach_platform.h) — with v_mfma_f32_16x16x32 the co-residency
+// guard saw MV-S2's outputs change beside every aggressor, poison waves included (5 - 12 of 20 passes; first tap map3), i.e. the kernel's waves disturbed each other.
 template <class T, int DT>
 __global__ __launch_bounds__(256, 2) void ffn2_kernel(const MlpParams p) { f16_sat_mode<T>();
     constexpr int VEC = Store<T>::VEC;
@@ -563,8 +566,8 @@ __global__ __launch_bounds__(256, 2) void ffn2_kernel(const MlpParams p) { f16_s
             for (int s = 0; s < K1MAX; ++s) { const int sc = s < p.k1 ? s : p.k1 - 1; wa[s] = w1[(sc * 2) * 64]; wb[s] = w1[(sc * 2 + 1) * 64]; }
             ACH_UNROLL
             for (int s = 0; s < K1MAX; ++s) {
-                mfma16<T>(wa[s], xf[0][s], a0[0]); mfma16<T>(wb[s], xf[0][s], a1[0]);
-                mfma16<T>(wa[s], xf[1][s], a0[1]); mfma16<T>(wb[s], xf[1][s], a1[1]);
+                mfma16_pair<T>(wa[s], xf[0][s], a0[0]); mfma16_pair<T>(wb[s], xf[0][s], a1[0]);
+                mfma16_pair<T>(wa[s], xf[1][s], a0[1]); mfma16_pair<T>(wb[s], xf[1][s], a1[1]);
             }
             uint4 hf[2][HSTEP];
             ACH_UNROLL
@@ -580,7 +583,7 @@ __global__ __launch_bounds__(256, 2) void ffn2_kernel(const MlpParams p) { f16_s
             for (int hh = 0; hh < HSTEP; ++hh) {
                 const uint4* w2 = W2f + long(j * HSTEP + hh) * DT * 64;
                 ACH_UNROLL
-                for (int t = 0; t < DT; ++t) { const uint4 w = w2[t * 64]; mfma16<T>(w, hf[0][hh], acc2[0][t]); mfma16<T>(w, hf[1][hh], acc2[1][t]); }
+                for (int t = 0; t < DT; ++t) { const uint4 w = w2[t * 64]; mfma16_pair<T>(w, hf[0][hh], acc2[0][t]); mfma16_pair<T>(w, hf[1][hh], acc2[1][t]); }
             }
         }
     };
@@ -718,6 +721,7 @@ __global__ ACH_CHAIN_BOUNDS void chain_kernel(const MlpParams p) { f16_sat_mode<
             ACH_UNROLL
             for (int r = 0; r < 4; ++r) { h[r] = h0[j][r] + b1[j][r]; h[4 + r] = h1[j][r] + b1[j][4 + r]; }
             apply_act_n<T, 8>(h, p.act);
+            if (p.Hout && mr < p.M) Store<T>::st8(static_cast<T*>(p.Hout) + mr * p.ldh + j * 32 + g * 8, h);      // hidden channels j * 32 + 8 g .. + 7 are this lane's (see the header)
             ACH_UNROLL
             for (int hh = 0; hh < HSTEP; ++hh) {
                 const uint4 hf = frag_pack<T>(h + hh * VEC);

@@ -800,8 +800,8 @@ def test_emulated_csp_fused_last_level_matches_the_layerwise_launches(res, band,
         outs[fuse] = (o[3].float(), o[4].float())
     assert sum('csp_level+head' in n for n in launches[1]) == 2 and not any('csp_level+head' in n for n in launches[0])
     assert sum(n.endswith('.csp_level') for n in launches[2]) == 2 and not any(n.endswith('.csp_level') for n in launches[1])
-    assert len(launches[0]) - len(launches[1]) == 2 * (5 - 3)         # per decoder: conv+bilinear, conv1, conv2, head.conv1, head.conv2 -> conv, conv1_lowres, fused
-    assert len(launches[2]) == len(launches[1])                       # conv+bilinear, conv1, conv2 -> conv, conv1_lowres, fused
+    assert len(launches[0]) - len(launches[1]) == 2 * (5 - 2)         # per decoder: conv+bilinear, conv1, conv2, head.conv1, head.conv2 -> conv+conv1_lowres (one chain launch, both outputs kept), fused
+    assert len(launches[1]) - len(launches[2]) == 2 * (3 - 2)         # conv+bilinear, conv1, conv2 -> conv+conv1_lowres, fused
     for fuse in (2, 1):
         for k in range(2):
             assert rel_err(outs[fuse][k], outs[0][k]) < sdt[2] * 3e-2, (fuse, k, rel_err(outs[fuse][k], outs[0][k]))
