@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""The round's results table of DESIGN.md section 5 from the committed bench lines: python profiles/scripts/results_table.py [TAG]  (default r04)."""
+"""The round's results table of DESIGN.md section 5 from the committed bench lines: python profiles/scripts/results_table.py [TAG]  (default r05)."""
 import json
 import sys
 
-TAG = sys.argv[1] if len(sys.argv) > 1 else 'r04'
+TAG = sys.argv[1] if len(sys.argv) > 1 else 'r05'
 
 
 def L(name):
@@ -37,7 +37,8 @@ print(row('EN-S2 batch 512 on one GPU / batch 256', ['en_s2_b512_one_gpu', 'en_s
 m = L('mv_s2')
 print(f"| MV-S2 batch 64; plain leg; mv_stem=0 | **{k(m['value'])}**; {k(m['plain_forward_detect_fps'])}; {k(L('mv_s2_image_copy')['value'])} | {m['ms_per_step']:.3f} |")
 print(row('PN2 plain / pipelined', ['en_s0_pn2', 'en_s0_pn2_pipelined']))
-print(row('EN-S1 / EN-CDF-S0', ['en_s1', 'en_s0_cdf']))
+print(row('EN-S1', ['en_s1']))
+print(row('EN-CDF-S0: both 32-channel levels fused (default) / last level + head only / layer-wise', ['en_s0_cdf', 'en_s0_cdf_last_level_only', 'en_s0_cdf_layerwise']))
 c = h['cpu_baseline']
 print(f"| CPU baseline: frames-parallel / one process / batch 1 | {c['value']:.1f} / {c.get('single_process', {}).get('value', 0):.1f} / {c.get('batch1_fps', 0):.1f} | — |")
 r = h['roofline']
