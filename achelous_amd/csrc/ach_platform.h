@@ -566,18 +566,54 @@ __device__ __forceinline__ float wave_max_f32(float v) {
 // in the epilogue of bandwidth-bound kernels (measured: +28 us on a 47 us GEMM for GELU with the exact forms)
 #if defined(ACH_HOSTEMU)
 __device__ inline float fast_rcp(float x) { return 1.0f / x; }
+__device__ inline float ln_rstd(float v) { return 1.0f / sqrtf(v); }
 __device__ inline float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 __device__ inline float fast_exp(float x) { return expf(x); }
 __device__ inline float fast_exp2(float x) { return exp2f(x); }
 #else
-__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+// ACH_TRANS_PAD (experiments): 8 wait states behind every transcendental instruction issued through these wrappers — the stand-alone reproducer
+// (profiles/scripts/ubench/ffn2_coresidency.hip) stops differing with them, i.e. what a co-resident 8-pass matrix instruction disturbs is the hand-over of a
+// transcendental result to the instruction that uses it (the compiler inserts ONE wait state there on gfx940 / gfx950: "trans forwarding hazard")
+#ifndef ACH_TRANS_PAD
+#define ACH_TRANS_PAD 0
+#endif
+__device__ __forceinline__ float trans_pad(float r) {
+#if ACH_TRANS_PAD
+    asm volatile("s_nop 7" : "+v"(r));
+#endif
+    return r;
+}
+__device__ __forceinline__ float fast_rcp(float x) { return trans_pad(__builtin_amdgcn_rcpf(x)); }
+// 1 / sqrt(v) of a LayerNorm / norm statistic: the IEEE form by default; with ACH_TRANS_PAD the hardware reciprocal square root behind the padding
+__device__ __forceinline__ float ln_rstd(float v) {
+#if ACH_TRANS_PAD
+    return trans_pad(__builtin_amdgcn_rsqf(v));
+#else
+    return 1.0f / sqrtf(v);
+#endif
+}
 __device__ __forceinline__ float clampf(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }      // v_med3_f32
-__device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
-__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float fast_exp(float x) { return trans_pad(__expf(x)); }
+__device__ __forceinline__ float fast_exp2(float x) { return trans_pad(__builtin_amdgcn_exp2f(x)); }
 #endif
 enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2, ACT_GELU = 3, ACT_SIGMOID = 4 };
 
+#ifndef ACH_SIGMOID_POLY
+#define ACH_SIGMOID_POLY 0           // experiments only (profiles/scripts/ubench/ffn2_coresidency.hip): 1 = a polynomial WITHOUT transcendental instructions (wrong values), 2 = the
+#endif                               // real form with 8 wait states behind each transcendental instruction
+#if ACH_SIGMOID_POLY == 1
+__device__ __forceinline__ float sigmoidf_(float x) { const float c = clampf(x, -3.f, 3.f); return 0.5f + c * (0.25f - c * c * 0.0138f); }
+#elif ACH_SIGMOID_POLY == 2
+__device__ __forceinline__ float sigmoidf_(float x) {
+    float e = fast_exp(-x);
+    asm volatile("s_nop 7" : "+v"(e));
+    float r = fast_rcp(1.0f + e);
+    asm volatile("s_nop 7" : "+v"(r));
+    return r;
+}
+#else
 __device__ __forceinline__ float sigmoidf_(float x) { return fast_rcp(1.0f + fast_exp(-x)); }
+#endif
 // erf by Abramowitz & Stegun 7.1.26: |error| <= 1.5e-7 (fp32 epsilon level), one exp + one reciprocal + 6 FMA
 // (the library erff is ~3x the VALU work; GELU runs on every hidden unit of every EdgeNeXt MLP)
 __device__ __forceinline__ float erf_as(float x) {

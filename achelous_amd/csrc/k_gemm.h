@@ -160,7 +160,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, unsigned bx, unsi
                 float var = s2[t] / float(p.Cin) - mu * mu;
                 var = var > 0.f ? var : 0.f;
                 tmean[q][t] = mu;
-                trstd[q][t] = 1.0f / sqrtf(var + p.ln_eps);
+                trstd[q][t] = ln_rstd(var + p.ln_eps);
             }
         }
     }
@@ -190,7 +190,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, unsigned bx, unsi
             float var = s2 / float(p.K) - mu * mu;
             var = var > 0.f ? var : 0.f;
             mean[q] = mu;
-            rstd[q] = 1.0f / sqrtf(var + p.ln_eps);
+            rstd[q] = ln_rstd(var + p.ln_eps);
         }
     }
 

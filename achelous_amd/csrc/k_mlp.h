@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256, (MlpOcc<DT, SPLIT, Store<T>::VEC>::blocks)) vo
         const float mu = s1 / float(p.C);
         float var = s2 / float(p.C) - mu * mu;
         var = var > 0.f ? var : 0.f;
-        const float rstd = 1.0f / sqrtf(var + p.ln_eps);
+        const float rstd = ln_rstd(var + p.ln_eps);
         ACH_UNROLL
         for (int s = 0; s < K1MAX; ++s) {
             if (s >= p.k1) continue;
@@ -496,6 +496,16 @@ inline bool launch_mlp(const MlpParams& p, int DT, bool split, hipStream_t strea
 // two MFMAs, half the L2 traffic; same weight packing, the same sums in the same order per row (bit-identical to mlp_kernel).
 // Its waves live for 9 - 12 hidden chunks of ~40 matrix instructions: they use the 16x16x16 PAIR form (mfma16_pair, ach_platform.h) — with v_mfma_f32_16x16x32 the co-residency
 // guard saw MV-S2's outputs change beside every aggressor, poison waves included (5 - 12 of 20 passes; first tap map3), i.e. the kernel's waves disturbed each other.
+#ifndef ACH_FFN2_MFMA32
+#define ACH_FFN2_MFMA32 0          // 1 (profiles/scripts/ubench/ffn2_coresidency.hip only): the v_mfma_f32_16x16x32 form that the co-residency guard rejected
+#endif
+template <class T> __device__ __forceinline__ void ffn2_mfma(const uint4& a, const uint4& b, f32x4& c) {
+#if ACH_FFN2_MFMA32
+    mfma16<T>(a, b, c);
+#else
+    mfma16_pair<T>(a, b, c);
+#endif
+}
 template <class T, int DT>
 __global__ __launch_bounds__(256, 2) void ffn2_kernel(const MlpParams p) { f16_sat_mode<T>();
     constexpr int VEC = Store<T>::VEC;
@@ -532,7 +542,7 @@ __global__ __launch_bounds__(256, 2) void ffn2_kernel(const MlpParams p) { f16_s
             const float mu = s1 / float(p.C);
             float var = s2 / float(p.C) - mu * mu;
             var = var > 0.f ? var : 0.f;
-            const float rstd = 1.0f / sqrtf(var + p.ln_eps);
+            const float rstd = ln_rstd(var + p.ln_eps);
             ACH_UNROLL
             for (int s = 0; s < K1MAX; ++s) {
                 if (s >= p.k1) continue;
@@ -566,8 +576,8 @@ __global__ __launch_bounds__(256, 2) void ffn2_kernel(const MlpParams p) { f16_s
             for (int s = 0; s < K1MAX; ++s) { const int sc = s < p.k1 ? s : p.k1 - 1; wa[s] = w1[(sc * 2) * 64]; wb[s] = w1[(sc * 2 + 1) * 64]; }
             ACH_UNROLL
             for (int s = 0; s < K1MAX; ++s) {
-                mfma16_pair<T>(wa[s], xf[0][s], a0[0]); mfma16_pair<T>(wb[s], xf[0][s], a1[0]);
-                mfma16_pair<T>(wa[s], xf[1][s], a0[1]); mfma16_pair<T>(wb[s], xf[1][s], a1[1]);
+                ffn2_mfma<T>(wa[s], xf[0][s], a0[0]); ffn2_mfma<T>(wb[s], xf[0][s], a1[0]);
+                ffn2_mfma<T>(wa[s], xf[1][s], a0[1]); ffn2_mfma<T>(wb[s], xf[1][s], a1[1]);
             }
             uint4 hf[2][HSTEP];
             ACH_UNROLL
@@ -583,7 +593,7 @@ __global__ __launch_bounds__(256, 2) void ffn2_kernel(const MlpParams p) { f16_s
             for (int hh = 0; hh < HSTEP; ++hh) {
                 const uint4* w2 = W2f + long(j * HSTEP + hh) * DT * 64;
                 ACH_UNROLL
-                for (int t = 0; t < DT; ++t) { const uint4 w = w2[t * 64]; mfma16_pair<T>(w, hf[0][hh], acc2[0][t]); mfma16_pair<T>(w, hf[1][hh], acc2[1][t]); }
+                for (int t = 0; t < DT; ++t) { const uint4 w = w2[t * 64]; ffn2_mfma<T>(w, hf[0][hh], acc2[0][t]); ffn2_mfma<T>(w, hf[1][hh], acc2[1][t]); }
             }
         }
     };

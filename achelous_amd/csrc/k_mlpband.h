@@ -168,7 +168,7 @@ __device__ __forceinline__ void mlp_band_body(const MlpBandParams& bp, const int
         const float mu = s1 / float(C);
         float var = s2 / float(C) - mu * mu;
         var = var > 0.f ? var : 0.f;
-        const float rstd = 1.0f / sqrtf(var + p.ln_eps);
+        const float rstd = ln_rstd(var + p.ln_eps);
         ACH_UNROLL
         for (int s = 0; s < K1; ++s) {
             const int k0 = s * 32 + g * 8;

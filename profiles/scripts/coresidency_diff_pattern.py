@@ -30,6 +30,9 @@ def main():
     opts = {'streams': 0}
     opts.update({kv.split('=')[0]: int(kv.split('=')[1]) for kv in a.opt})
     vm, kw = T._module(g, None, opts, a.storage)
+    if os.environ.get('ACH_VICTIM_LIB'):                      # a differently compiled victim (profiles/scripts/build_variant.sh)
+        from achelous_amd.engine import NativeLibrary
+        vm.native_library = NativeLibrary(os.path.join(ROOT, os.environ['ACH_VICTIM_LIB']))
     vm.debug_taps = a.full_taps
     x, xr, xp = T.make_inputs(16, 701, resolution=kw['resolution'], pc_channels=kw['pc_channels'])
     b = tuple(t.cuda().to(torch.bfloat16) for t in (x, xr, xp))
@@ -44,7 +47,7 @@ def main():
     eng = vm.native_engine(torch.bfloat16)
     names = eng.tap_names()
     alone = {t: eng.read_tap(t) for t in names}
-    ag = T.Aggressor(Golden('en_s0'), T._variant(a.aggressor), a.only, False, a.storage)
+    ag = T.Spin(0, 0, 8192, 1500, 20) if a.only == 'spin' else T.Aggressor(Golden('en_s0'), T._variant(a.aggressor), a.only, False, a.storage)
     out = {'config': a.config, 'storage': a.storage, 'options': opts, 'full_taps': a.full_taps, 'taps': len(names), 'passes': []}
     for rep in range(a.passes):
         ag.enqueue(4.0 * ms, vs)
