@@ -129,6 +129,8 @@ int ach_set_option(ach_handle* h, const char* key, int32_t value) {
         else if (std::string(key) == "radar_direct") h->eng->radar_direct = value != 0;
         else if (std::string(key) == "mv_stem") h->eng->mv_stem = value != 0;
         else if (std::string(key) == "csp_fuse") h->eng->csp_fuse = value < 0 ? 0 : (value > 2 ? 2 : value);
+        else if (std::string(key) == "band_rows_s3") h->eng->band_rows_s3 = value;
+        else if (std::string(key) == "spp_split") h->eng->spp_split = value;
         else if (std::string(key) == "ffn_rows2") h->eng->ffn_rows2 = value != 0;
         else if (std::string(key) == "csp_band") h->eng->csp_band = value > 0 ? value : 40;
         else if (std::string(key) == "ghost_fuse") h->eng->ghost_fuse = value != 0;

@@ -76,6 +76,8 @@ public:
     bool use_graph = false;
     bool io_bf16 = false;             // option "io_bf16" (fp16-storage engine only): the caller's input / output tensors are bf16; converted in the first / last kernels
     int csp_fuse = 2;                 // option "csp_fuse": 16-bit engines, CSP-Dual-FPN — 1: the full-resolution decoder level and the segmentation head as one row-walking launch (k_csphead.h) instead of five layer-wise ones; 2 (default): the 32-channel level below it as well; 0: layer-wise
+    int band_rows_s3 = 0;             // option "band_rows_s3": rows per band of the stage-3 band kernel (0 = 5)
+    int spp_split = 0;                // option "spp_split": workgroups per frame of the fused SPP launch (0 = auto: 2)
     bool ffn_rows2 = true;            // option "ffn_rows2": 16-bit engines — plain-row fused MLPs of 144..192 channels (MobileViT's feed-forward layers) with two 16-row tiles per wave (k_mlp.h ffn2_kernel); bit-identical
     int ffn_rows2_min = 0;            // ... for launches of at least this many rows (0: always — a frame must not depend on the batch it is in, and the four-waves-per-tile kernel sums in another order)
     int csp_band = 40;                // option "csp_band": rows per band of those launches (a band pays 2-4 rows of run-in)

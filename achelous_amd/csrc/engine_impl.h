@@ -523,7 +523,9 @@ public:
         //  the two code objects would carry the same symbol and the runtime registers one of them for the shared host stub)
         if constexpr (H16E) if (mlp_band && (split || mlp_band > 1) && dw_ks && act == ACT_GELU && xin.p == resid.p && mlp_band_supported(k1, DT, dw_ks, xin.H, xin.W)) {
             MlpBandParams bp;
-            bp.m = mp; bp.rb = mlp_band_rows(k1, DT, dw_ks, xin.H, xin.W); bp.bands = cdiv(xin.H, bp.rb); bp.dbg = mlp_band_dbg;
+            bp.m = mp; bp.rb = mlp_band_rows(k1, DT, dw_ks, xin.H, xin.W);
+            if (band_rows_s3 > 0 && mlp_band_shape(k1, DT, dw_ks, xin.W) == 2) bp.rb = std::min(std::min(band_rows_s3, 5), xin.H);     // (the 10 x 10 maps: 5-row bands are 128 workgroups at batch 64)
+            bp.bands = cdiv(xin.H, bp.rb); bp.dbg = mlp_band_dbg;
             const int nb = xin.B, shape = mlp_band_shape(k1, DT, dw_ks, xin.W);
             if (!measuring) band_ops.push_back(BandOp{ops.size(), bp, nb, shape});          // (merge_band_runs: consecutive blocks of a stage as one launch)
             add_op(name, [bp, nb, shape](hipStream_t s) { launch_mlp_band<T>(bp, shape, nb, s); }, bytes, flops);
@@ -1441,7 +1443,7 @@ public:
             if (l1.N != c_ || l1.K != w[3] || l2.N != w[3] || l2.K != 4 * c_) throw AchError{ACH_ERR_MISSING_KEY, "SPP widths"};
             BandW b1 = pack_band(l1), b2 = pack_band(l2);
             p5 = alloc(m5.B, m5.H, m5.W, w[3]);
-            const int split = b2.chunks >= 4 ? 2 : 1;
+            const int split = spp_split > 0 ? std::min(spp_split, b2.chunks) : (b2.chunks >= 4 ? 2 : 1);       // workgroups per frame: each recomputes cv1 + the pools and takes a share of cv2's output chunks
             SppFusedParams sp{m5.p, m5.ld, p5.p, p5.ld, b1.w, b1.b, b2.w, b2.b, m5.B, m5.H, m5.W, w[3], c_, b1.k1, b1.chunks, b2.k1, b2.chunks, split};
             const dim3 grid(unsigned(m5.B) * unsigned(split)), block(GH_THREADS);
             add_op(f + ".spp", [sp, grid, block](hipStream_t s) { ACH_LAUNCH((spp_fused_kernel<T>), grid, block, s, sp); },
