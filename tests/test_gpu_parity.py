@@ -5,6 +5,8 @@ would call `Achelous.forward` / `decode_outputs` / `non_max_suppression`, agains
 Tolerances (SURVEY.md §8c): fp32 path  max|a-b| / (max|b| + 1e-6) <= 1e-3 per tensor (measured 1e-6 .. 1e-4);
 NMS kept indices bit-exact; bf16 path: PER-TENSOR bounds, see bf16_bound().
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -1070,3 +1072,37 @@ def test_persistent_band_run_is_bit_identical_to_the_separate_launches(name, blo
         for k, a in enumerate(res[1][2]):
             for p, q in zip(a, res[1][0][k % 3]):
                 assert torch.equal(p, q), (storage, 'pipelined', k)
+
+
+def test_packed_fp16_deformable_blend_stays_within_a_few_fp16_ulps_of_the_fp32_blend():
+    """the fp16 engine blends the four corners of a deformable tap on packed halves (v_pk_fma_f16, k_conv3.h ACH_RCF_PK16 = 1) — arithmetic that neither the
+    CPU emulation nor the bf16 engine has.  Against the SAME engine compiled with the fp32 blend (tests/variants/libachelous_blend32.so, `make variants`), on dense radar
+    maps with far / boundary offsets: every radar tap within 4 fp16 ulps of the tap's largest magnitude (measured 1 - 3: a sampled value carries 2 - 3 ulps instead of
+    0.5, and the later blocks see each other's roundings), the six outputs within half the 16-bit bounds."""
+    import subprocess
+    from achelous_amd.engine import NativeLibrary
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'variants', 'libachelous_blend32.so')
+    if not os.path.exists(path):
+        subprocess.run(['make', '-s', '-C', os.path.join(os.path.dirname(path), '..', '..', 'achelous_amd', 'csrc'), 'variants', '-j8'], check=True)
+    g = Golden('en_s0')
+    x, xr, xp = make_inputs(4, 31, resolution=320, pc_channels=5, dense_radar=True)
+    xs = tuple(t.cuda().half() for t in (x, xr, xp))
+    res = {}
+    for tag, lib in (('pk16', None), ('blend32', NativeLibrary(path))):
+        m, kw = _model(g, debug_taps=True)
+        m.native_library = lib
+        with torch.no_grad():
+            det, se, lane, pc = m(*xs)
+        torch.cuda.synchronize()
+        e = _engine_of(m, torch.float16)
+        res[tag] = ({t: e.read_tap(t) for t in e.tap_names() if t.startswith('radar.') or t in ('r3', 'r4', 'r5')}, (*det, se, lane, pc))
+    assert len(res['pk16'][0]) >= 8
+    worst = {}
+    for t, a in res['pk16'][0].items():
+        b = res['blend32'][0][t]
+        worst[t] = float((a - b).abs().max() / (b.abs().max() + 1e-6)) / 2.0 ** -11          # in fp16 ulps of the tap's largest magnitude
+    print('packed fp16 blend vs fp32 blend, fp16 ulps of the largest magnitude per radar tap:', {k: round(v, 2) for k, v in worst.items()})
+    assert max(worst.values()) < 4.0, worst
+    assert any(v > 0 for v in worst.values())                       # (the two libraries really differ)
+    for k, (a, b) in zip(('det0', 'det1', 'det2', 'se_seg', 'lane_seg', 'pc_seg'), zip(res['pk16'][1], res['blend32'][1])):
+        assert _rel(a.float(), b.float()) < 0.5 * H16_TOL[k], (k, _rel(a.float(), b.float()))
