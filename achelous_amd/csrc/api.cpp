@@ -1,5 +1,6 @@
 // api.cpp — the extern "C" boundary of libachelous_hip.so (declared in include/achelous.h).
 // No exception crosses it: every failure becomes a negative code + a message retrievable with ach_last_error().
+#include <atomic>
 #include <cstring>
 #include <functional>
 #include <string>
@@ -96,6 +97,7 @@ int ach_set_option(ach_handle* h, const char* key, int32_t value) {
         else if (std::string(key) == "head_lds_pad") h->eng->head_lds_pad = value < 0 ? 0 : (value > 65536 ? 65536 : value);
         else if (std::string(key) == "head_stream") h->eng->head_stream = value != 0;
         else if (std::string(key) == "split_decoders") h->eng->split_decoders = value;
+        else if (std::string(key) == "dec_fork") h->eng->dec_fork = value < 0 ? 0 : (value > 3 ? 3 : value);
         else if (std::string(key) == "radar_start") h->eng->radar_start = value;
         else if (std::string(key) == "pipeline") h->eng->pipeline = value != 0;
         else if (std::string(key) == "pool_strip") h->eng->pool_strip = value;
@@ -321,23 +323,40 @@ static int train_slices(long total, int C) {
     const long want = (total + 16383) / 16384, cap = std::max<long>(1, 2048 / std::max(C, 1));
     return int(std::max<long>(1, std::min<long>(std::min<long>(want, cap), 64)));
 }
+// element type of the training GEMMs' matrix-instruction operands, process-wide: 0 = fp32 (default), 1 = bf16 operands with fp32 accumulation (k_train.h)
+static std::atomic<int> g_train_gemm_precision{0};
+int ach_train_set_gemm_precision(int32_t precision) {
+    if (precision != 0 && precision != 1) return ACH_ERR_INVALID;
+    g_train_gemm_precision.store(precision, std::memory_order_relaxed);
+    return ACH_OK;
+}
+int ach_train_get_gemm_precision(void) { return g_train_gemm_precision.load(std::memory_order_relaxed); }
 int ach_train_gemm(const float* A, const float* B, float* C, const float* bias, int32_t M, int32_t N, int32_t K, int64_t lda, int64_t ldb, int64_t ldc,
                    int64_t stride_a, int64_t stride_b, int64_t stride_c, int32_t trans_a, int32_t trans_b, int32_t batch, int32_t reduce_batch,
                    int32_t accumulate, void* stream) {
     return train_guard([&] {
         if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0) throw ach::AchError{ACH_ERR_INVALID, "bad train_gemm arguments"};
         ach::TrainGemmParams p{A, B, C, bias, M, N, K, long(lda), long(ldb), long(ldc), long(stride_a), long(stride_b), long(stride_c), trans_a, trans_b, batch, reduce_batch, accumulate, 1, nullptr};
-        dim3 grid(unsigned((N + 63) / 64), unsigned((M + 63) / 64), unsigned(reduce_batch ? 1 : batch));
+        // block tile: 32 rows / columns where the output has no more (k_train.h: the streaming shapes)
+        const int tm = M <= 32 ? 32 : 64, tn = N <= 32 ? 32 : 64;
+        dim3 grid(unsigned((N + tn - 1) / tn), unsigned((M + tm - 1) / tm), unsigned(reduce_batch ? 1 : batch));
         if (reduce_batch) {           // few output tiles, long reduction (weight gradients): split it over ~1024 workgroups, partial sums in a workspace
-            const long T = long(batch) * ((K + 15) / 16), tiles = long(grid.x) * grid.y;
-            long split = std::min<long>(std::min<long>(1024 / tiles, T / 8), 512);
+            const long T = long(batch) * ((K + ach::TRAIN_GEMM_TK - 1) / ach::TRAIN_GEMM_TK), tiles = long(grid.x) * grid.y;
+            long split = std::min<long>(std::min<long>(2048 / tiles, T / 4), 2048);
             if (split > 1) {
                 p.ksplit = int(split);
                 p.ws = train_workspace(size_t(split) * M * N * sizeof(float));
                 grid.z = unsigned(split);
             }
         }
-        ACH_LAUNCH(ach::train_gemm_kernel, grid, dim3(256), static_cast<hipStream_t>(stream), p);
+        const hipStream_t st = static_cast<hipStream_t>(stream);
+        const bool h16 = g_train_gemm_precision.load(std::memory_order_relaxed) == 1;
+#define ACH_TG_LAUNCH(TM, TN) { if (h16) ACH_LAUNCH((ach::train_gemm_kernel<ach::bf16_t, TM, TN>), grid, dim3(256), st, p); else ACH_LAUNCH((ach::train_gemm_kernel<float, TM, TN>), grid, dim3(256), st, p); }
+        if (tm == 32 && tn == 32) ACH_TG_LAUNCH(32, 32)
+        else if (tm == 32) ACH_TG_LAUNCH(32, 64)
+        else if (tn == 32) ACH_TG_LAUNCH(64, 32)
+        else ACH_TG_LAUNCH(64, 64)
+#undef ACH_TG_LAUNCH
         if (p.ksplit > 1) ACH_LAUNCH(ach::train_gemm_reduce_kernel, dim3(unsigned(ach::cdivl(long(M) * N, 16))), dim3(256), static_cast<hipStream_t>(stream), p);
     });
 }

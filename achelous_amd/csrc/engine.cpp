@@ -41,7 +41,7 @@ EngineBase::~EngineBase() {
         for (int k = 0; k < kSideStreams; ++k) (void)hipEventDestroy(ev_end[k]);          // (the streams belong to the process-wide pool)
         (void)hipEventDestroy(ev_fork);
         for (int k = 0; k < kJoinEvents; ++k) (void)hipEventDestroy(ev_join[k]);
-        for (int q = 0; q < 2; ++q) { (void)hipEventDestroy(ev_x[q]); (void)hipEventDestroy(ev_x2[q]); for (int k = 0; k < kSideStreams; ++k) (void)hipEventDestroy(ev_done[k][q]); }
+        for (int q = 0; q < 2; ++q) { (void)hipEventDestroy(ev_x[q]); (void)hipEventDestroy(ev_x2[q]); (void)hipEventDestroy(ev_x3[q]); for (int k = 0; k < kSideStreams; ++k) (void)hipEventDestroy(ev_done[k][q]); }
     }
     for (auto& pr : probes) { for (auto e : pr.ev0) (void)hipEventDestroy(e); for (auto e : pr.ev1) (void)hipEventDestroy(e); }
 }
@@ -140,6 +140,7 @@ void EngineBase::ensure_streams() {
     for (int q = 0; q < 2; ++q) {
         ACH_HIP_CHECK(hipEventCreate(&ev_x[q]));
         ACH_HIP_CHECK(hipEventCreate(&ev_x2[q]));
+        ACH_HIP_CHECK(hipEventCreate(&ev_x3[q]));
         for (int k = 0; k < kSideStreams; ++k) ACH_HIP_CHECK(hipEventCreate(&ev_done[k][q]));
     }
     streams_ready = true;
@@ -186,12 +187,14 @@ void EngineBase::run_eager(hipStream_t s) {
         if (multi && op.wait_ev2 >= 0) (void)hipStreamWaitEvent(st, ev_join[op.wait_ev2], 0);
         if (piped && op.xwait && issued > 0) (void)hipStreamWaitEvent(st, ev_x[par ^ 1], 0);
         if (piped && (dbg_xwait2_op >= 0 ? int(i) == dbg_xwait2_op : op.xwait2) && issued > 0 && x2_recorded[par ^ 1]) (void)hipStreamWaitEvent(st, ev_x2[par ^ 1], 0);
+        if (piped && op.xwait3 && issued > 0 && x3_recorded[par ^ 1]) (void)hipStreamWaitEvent(st, ev_x3[par ^ 1], 0);
         for (auto& pr : probes) if (int(i) == pr.first) (void)hipEventRecord(pr.ev0[size_t(pr.count % kProbeEvents)], st);
         op.fn(st);
         for (auto& pr : probes) if (int(i) == pr.last) { (void)hipEventRecord(pr.ev1[size_t(pr.count % kProbeEvents)], st); ++pr.count; }
         if (multi && op.signal_ev >= 0) (void)hipEventRecord(ev_join[op.signal_ev], st);
         if (piped && op.xsignal) (void)hipEventRecord(ev_x[par], st);
         if (piped && op.xsignal2) { (void)hipEventRecord(ev_x2[par], st); x2_recorded[par] = true; }
+        if (piped && op.xsignal3) { (void)hipEventRecord(ev_x3[par], st); x3_recorded[par] = true; }
     }
     if (detect_tail) detect_tail((multi && detect_stream > 0 && used[detect_stream - 1]) ? side_stream[detect_stream - 1] : s);   // det maps are final on that stream
     if (piped) {

@@ -50,6 +50,8 @@ struct Op {
     bool xwait2 = false;          // the same pair for the DECODERS' reads of the attention maps: since fusion + head moved to the radar stream
     bool xsignal2 = false;        //   (head_stream = 0) the fusion launch no longer follows the decoders in stream order, so `xsignal` alone would
                                   //   let the next forward's neck overwrite what this forward's decoders still read
+    bool xwait3 = false;          // option dec_fork = 3 (the NECK on stream 2): the backbone launch that first writes a feature map the previous forward's neck
+    bool xsignal3 = false;        //   reads (stage 1's output, a slice of the neck's concat buffer) waits for that neck's last reader of the backbone's maps
 };
 
 struct IoPtrs {
@@ -116,6 +118,8 @@ public:
     int mlp_band_dbg = 0;             // option "mlp_band_dbg": phase-kill timing experiments on the band kernel (results are wrong)
     int mlp_band = 1;                 // option "mlp_band" (2: also the large maps of stages 0 / 1): bf16 — ConvEncoder blocks on the small maps as the band kernel (k_mlpband.h: LDS halo tile, weights once per band); 0 = mlp_kernel's SPLIT mode
     bool fuse_mlp = true;             // option "fused_mlp": EdgeNeXt blocks as one kernel (k_mlp.h) instead of dw / pw1 / pw2 launches
+    int dec_fork = 1;                 // option "dec_fork" (pipelined plan): 0 = the decoders leave the caller's stream behind the shared ShuffleAttention stage (round 3), 1 = in front of it
+                                      // (default, round 5: +0.9 %), 2 = as soon as p3 exists, 3 = the whole NECK on stream 2 (EdgeNeXt plans; the caller's stream carries the backbone only) — engine_impl.h neck()
     int split_decoders = 0;           // option "split_decoders": semantic decoder on side stream 3.  OFF: with the other branches at low
                                       // priority it no longer pays (23.8 k vs 22.9 k frames/s), and the process must stay at <= 4 ACTIVE
                                       // streams — caller + 2 here leaves one for a collective (RCCL) stream; a fifth costs 28 %
@@ -241,6 +245,7 @@ protected:
         pending_wait = -1; pending_wait2 = -1;
         op.xwait = pending_xwait; pending_xwait = false;
         op.xwait2 = pending_xwait2; pending_xwait2 = false;
+        op.xwait3 = pending_xwait3; pending_xwait3 = false;
         ops.push_back(std::move(op));
     }
     // branch bookkeeping while the plan is built
@@ -265,6 +270,11 @@ protected:
     bool pending_xwait = false, pending_xwait2 = false;
     void mark_xwait2_next() { pending_xwait2 = true; }
     void mark_xsignal2_last() { if (!measuring && !ops.empty()) ops.back().xsignal2 = true; }
+    bool pending_xwait3 = false;
+    void mark_xwait3_next() { pending_xwait3 = true; }
+    void mark_xsignal3_last() { if (!measuring && !ops.empty()) ops.back().xsignal3 = true; }
+    hipEvent_t ev_x3[2] = {nullptr, nullptr};
+    bool x3_recorded[2] = {false, false};
 #if !defined(ACH_HOSTEMU)
     struct GraphEntry { IoPtrs io; hipGraphExec_t exec; unsigned long stamp; };
     std::vector<GraphEntry> graphs;

@@ -411,7 +411,7 @@ public:
                 while (e < band_ops.size() && e - a < size_t(MLPB_RUN_MAX) && band_ops[e].op == band_ops[e - 1].op + 1 && band_ops[e].shape == band_ops[a].shape && band_ops[e].nb == band_ops[a].nb &&
                        band_ops[e].bp.m.X == band_ops[e - 1].bp.m.Y && band_ops[e].bp.bands == band_ops[a].bp.bands && band_ops[e].bp.rb == band_ops[a].bp.rb &&
                        ops[band_ops[e].op].stream == ops[band_ops[a].op].stream && ops[band_ops[e].op].wait_ev < 0 && ops[band_ops[e].op].wait_ev2 < 0 && !ops[band_ops[e].op].xwait &&
-                       !ops[band_ops[e].op].xwait2 && ops[band_ops[e - 1].op].signal_ev < 0 && !ops[band_ops[e - 1].op].xsignal && !ops[band_ops[e - 1].op].xsignal2) ++e;
+                       !ops[band_ops[e].op].xwait2 && !ops[band_ops[e].op].xwait3 && !ops[band_ops[e - 1].op].xsignal3 && ops[band_ops[e - 1].op].signal_ev < 0 && !ops[band_ops[e - 1].op].xsignal && !ops[band_ops[e - 1].op].xsignal2) ++e;
                 const size_t n = e - a;
                 // (the bands of a frame must share an XCD — xcd_block: the launch's workgroups in eight equal chunks of whole frames — because the blocks hand their rows over through that L2)
                 const long nwg = long(band_ops[a].bp.bands) * band_ops[a].nb;
@@ -450,9 +450,11 @@ public:
     // When set, the next block output is written there instead of a fresh allocation (a channel slice of a concat buffer of the
     // neck: torch.cat((upsampled, backbone feature), 1) then needs no copy).  Consumed by the first block that produces an output.
     A preset_out; bool has_preset = false;
+    bool neck_on_side = false;        // this plan runs the neck on stream 2 (option dec_fork = 3; decided in build())
     A block_out(const A& like) {
         if (has_preset) {
             has_preset = false;
+            if (neck_on_side) mark_xwait3_next();      // (the launch that writes this slice of the neck's concat buffer: the previous forward's neck, on stream 2, may still read it)
             if (preset_out.B != like.B || preset_out.H != like.H || preset_out.W != like.W || preset_out.C != like.C)
                 throw AchError{ACH_ERR_INVALID, "preset block output does not match the block"};
             return preset_out;
@@ -1433,6 +1435,12 @@ public:
         // SPP (spp.py:41-67)
         const int c_ = w[3] / 2;
         if (c_ % 4) throw AchError{ACH_ERR_UNSUPPORTED, "SPP hidden width must be a multiple of 4"};
+        if (neck_on_side) {              // dec_fork = 3: everything from here on runs on stream 2, behind the backbone's last launch
+            if (measuring || ops.empty() || ops.back().signal_ev >= 0) { if (!measuring) throw AchError{ACH_ERR_INVALID, "dec_fork = 3: the backbone's last launch already signals an event"}; }
+            else ops.back().signal_ev = 2;
+            cur_stream = 2;
+            wait_before_next(2);
+        }
         mark_xwait_next();               // pipelined forwards: the neck rewrites what the previous forward's stream 2 reads (engine.cpp)
         mark_xwait2_next();              // ... and what its decoders read
         A p5;
@@ -1477,6 +1485,12 @@ public:
         A p3 = csp ? csp_layer(f + ".ghost_4_to_3", c3, w[1]) : ghost_bottleneck(f + ".ghost_4_to_3", c3, w[1]);
         tap("fpn4", p4); tap("fpn3", p3);
         const bool split_dec = split_decoders != 0;
+        const bool piped = pipeline && multi_stream && !split_dec;
+        // option "dec_fork": where the pipelined plan's decoders leave the caller's stream — 0: behind the shared ShuffleAttention stage (round 3), 1: in front of it
+        // (the stage's three launches move to stream 2: the caller's stream is the pipelined loop's bottleneck), 2: as soon as p3 exists (the residual
+        // adds stay on the caller's stream and run beside the attention stage)
+        const int fork = neck_on_side ? 3 : (piped ? std::min(dec_fork, 2) : 0);
+        if (fork == 2) signal_after_last(2);
         // residual FPN outputs (ghostdualfpn.py:200) — computed BEFORE the decoders so that the detection branch (fusion + head,
         // on the radar stream) can start while the two heavy decoders still run on this stream
         q[0] = alloc(p3.B, p3.H, p3.W, p3.C);
@@ -1495,15 +1509,17 @@ public:
             add_op(f + ".q3+q4+q5", [aj, grid, block](hipStream_t s) { ACH_LAUNCH(add_multi_kernel<T>, grid, block, s, aj); }, bytes);
         }
         signal_after_last(1);
+        if (fork == 3) mark_xsignal3_last();        // the residual adds are the neck's last reader of the backbone's feature maps
         // two segmentation decoders
         const char* names[2] = {"lane", "se"};
         const char* sa[2] = {"stage_3_lane_seg", "stage_3_semantic_seg"};
         const int oups[2] = {2, cfg.num_seg};
         void** outs[2] = {&io.lane, &io.se};
         A ysa[2];
+        if (fork == 1) { cur_stream = 2; wait_before_next(1); }                        // (event 1 = the residual adds, the caller's last launch of this forward)
+        if (fork == 2) { cur_stream = 2; wait_before_next(2); }
         shuffle_attention_pair(f + "." + sa[0], f + "." + sa[1], p3, ysa[0], ysa[1]);
-        const bool piped = pipeline && multi_stream && !split_dec;
-        if (piped) { signal_after_last(2); cur_stream = 2; wait_before_next(2); }     // both decoders leave the caller's stream
+        if (piped && fork == 0) { signal_after_last(2); cur_stream = 2; wait_before_next(2); }     // both decoders leave the caller's stream
         if (split_dec) signal_after_last(2);   // the semantic decoder may start on its own stream
         for (int d = 0; d < 2; ++d) {
             // past the shared attention stage the two decoders are independent: water-line decoder on the caller's stream, semantic
@@ -2144,6 +2160,8 @@ public:
         cur_stream = 0;
         A m[4];
         cat_buf[0] = A(); cat_buf[1] = A();
+        // the neck on stream 2 needs the stage outputs' launches to be identifiable (the preset concat slices of the EdgeNeXt plans) and the radar branch released before stage 3
+        neck_on_side = pipeline && multi_stream && split_decoders == 0 && dec_fork == 3 && cfg.backbone == ACH_BACKBONE_EDGENEXT && radar_start_eff() < 3;
         if (cfg.backbone == ACH_BACKBONE_EDGENEXT) {
             // stage 1 / stage 2 outputs go straight into the second half of the neck's concat buffers (no cat copy)
             const int* wd = widths();

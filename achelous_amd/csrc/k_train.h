@@ -2,7 +2,8 @@
 //     y = relu(BatchNorm1d(Conv1d_k1(x)))        x [B, Cin, N] -> y [B, Cout, N]      (pointnet_utils.py:29-31, 69-71, 124-127;
 // pointnet_sem_seg.py:31-33) in TRAINING mode — batch statistics over (B, N), running statistics updated — forward and backward.
 // The reference trains it through ATen autograd (utils/utils_fit.py:37-166); here the same arithmetic is four kernels in fp32:
-//   train_gemm      C[b] (+)= op(A[b]) op(B[b]) on fp32 MFMA (v_mfma_f32_16x16x4_f32), LDS-staged 64 x 64 x 16 tiles, any transposition,
+//   train_gemm      C[b] (+)= op(A[b]) op(B[b]) on fp32 MFMA (v_mfma_f32_16x16x4_f32) or with operands rounded to bf16 (ach_train_set_gemm_precision),
+//                   LDS-staged 64 x 64 x 32 tiles, any transposition,
 //                   optional reduction over the batch (the weight gradient sums over samples) and row bias
 //   bn_stats        per channel mean / biased variance over (B, N), two passes (mean, then centred squares)
 //   bn_relu_fwd     y = [relu](gamma * (z - mean) * rstd + beta)
@@ -28,72 +29,138 @@ struct TrainGemmParams {
 };
 
 // 256 threads = 4 waves; wave w owns the 32 x 32 quadrant (w >> 1, w & 1) of the 64 x 64 block tile: 2 x 2 MFMA tiles.
+// Round 5: the operands' element type on the matrix cores is a template parameter —
+//   T = float : v_mfma_f32_16x16x4_f32 on the fp32 values (the exact-arithmetic mode, the one the float64 reference-step test holds to 5e-3)
+//   T = bf16_t: the fp32 values are rounded to bf16 WHILE THEY ARE STAGED into LDS (no 16-bit copy of anything exists in memory), products on
+//               v_mfma_f32_16x16x16_bf16 pairs, accumulation, bias and output in fp32 — what the reference's default loop asks for with
+//               torch.cuda.amp.autocast (utils/utils_fit.py:120-166), minus its 16-bit activations.  bf16, not fp16: GradScaler multiplies the gradients
+//               by 2^16, which an fp16 operand would turn into infinities; bf16 keeps fp32's exponent range.
+// and the staging is 16-byte loads along whichever index the stored matrix is contiguous in (scalar loads only where leading dimension, batch
+// stride or base address are not multiples of four floats, or a tile crosses the matrix edge), a k-tile of 32, two LDS buffers (ONE barrier per
+// k-tile, the next tile's global loads in flight while the matrix cores work on this one).  LDS tiles are [row][k] for both operands, so every
+// fragment is one 16-byte LDS read (k = 4 lk + j for fp32 — any bijection is legal as long as A and B agree — and k = 8 lk + j for bf16).
+constexpr int TRAIN_GEMM_TK = 32;
+
+static __device__ __forceinline__ f32x4 tg_load4(const float* ptr, int nvalid, bool vec) {        // four consecutive floats, zeros beyond `nvalid`
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (nvalid >= 4 && vec) v = *reinterpret_cast<const f32x4*>(ptr);
+    else {
+        if (nvalid > 0) v[0] = ptr[0];
+        if (nvalid > 1) v[1] = ptr[1];
+        if (nvalid > 2) v[2] = ptr[2];
+        if (nvalid > 3) v[3] = ptr[3];
+    }
+    return v;
+}
+template <class T> static __device__ __forceinline__ void tg_store_pair(T* dst, float a, float b) {  // elements k, k + 1 of one row (k even)
+    if constexpr (is_h16<T>::value) *reinterpret_cast<uint32_t*>(dst) = H16<T>::pack(a, b);
+    else { dst[0] = a; dst[1] = b; }
+}
+
+// one operand's ROWS x 32 tile (ROWS = 64 or 32): registers <- global (`fetch`), LDS <- registers (`stash`).  `kcontig`: the stored matrix is contiguous
+// along k (A as stored M x K, B as stored N x K); otherwise along the row index (A stored K x M, B stored K x N).
+//   kcontig            : thread = (row tid >> 3 [+ 32 when ROWS = 64], k quad tid & 7)  -> one 8- / 16-byte LDS store per vector
+//   else, ROWS = 64    : thread = (k pair tid >> 4, row quad tid & 15), rows k and k + 1 -> four (k, k + 1) pair stores
+//   else, ROWS = 32    : thread = (k tid >> 3, row quad tid & 7)                         -> four single-element stores
+struct TgOperand { const float* base; long ld; int rows, r0; bool kcontig, vec; };
+template <int ROWS> static __device__ __forceinline__ void tg_fetch(const TgOperand& o, const float* mat, int K, int k0, int tid, f32x4& v0, f32x4& v1) {
+    if (o.kcontig) {
+        const int kq = tid & 7, k = k0 + 4 * kq, r = o.r0 + (tid >> 3);
+        v0 = tg_load4(mat + long(r) * o.ld + k, r < o.rows ? K - k : 0, o.vec);
+        if constexpr (ROWS == 64) v1 = tg_load4(mat + long(r + 32) * o.ld + k, r + 32 < o.rows ? K - k : 0, o.vec);
+    } else if constexpr (ROWS == 64) {
+        const int k = k0 + 2 * (tid >> 4), r = o.r0 + 4 * (tid & 15);
+        v0 = tg_load4(mat + long(k) * o.ld + r, k < K ? o.rows - r : 0, o.vec);
+        v1 = tg_load4(mat + long(k + 1) * o.ld + r, k + 1 < K ? o.rows - r : 0, o.vec);
+    } else {
+        const int k = k0 + (tid >> 3), r = o.r0 + 4 * (tid & 7);
+        v0 = tg_load4(mat + long(k) * o.ld + r, k < K ? o.rows - r : 0, o.vec);
+    }
+}
+template <class T, int ROWS, int PITCH> static __device__ __forceinline__ void tg_stash(const TgOperand& o, int tid, const f32x4 v0, const f32x4 v1, T (*S)[PITCH]) {
+    if (o.kcontig) {
+        const float f0[4] = {v0[0], v0[1], v0[2], v0[3]};
+        Store<T>::st4(&S[tid >> 3][4 * (tid & 7)], f0);
+        if constexpr (ROWS == 64) { const float f1[4] = {v1[0], v1[1], v1[2], v1[3]}; Store<T>::st4(&S[(tid >> 3) + 32][4 * (tid & 7)], f1); }
+    } else if constexpr (ROWS == 64) {
+        const int kp = tid >> 4, r = 4 * (tid & 15);
+        tg_store_pair<T>(&S[r][2 * kp], v0[0], v1[0]);
+        tg_store_pair<T>(&S[r + 1][2 * kp], v0[1], v1[1]);
+        tg_store_pair<T>(&S[r + 2][2 * kp], v0[2], v1[2]);
+        tg_store_pair<T>(&S[r + 3][2 * kp], v0[3], v1[3]);
+    } else {
+        const int k = tid >> 3, r = 4 * (tid & 7);
+        Store<T>::st(&S[r][k], v0[0]); Store<T>::st(&S[r + 1][k], v0[1]); Store<T>::st(&S[r + 2][k], v0[2]); Store<T>::st(&S[r + 3][k], v0[3]);
+    }
+}
+
+// TM x TN block tile (each 64 or 32; 2 x 2 waves, a wave owns TM/2 x TN/2).  The 32-row forms are for the STREAMING shapes of a training step — a weight
+// gradient is a 16 x 32 output reduced over 32 x 102 400 positions, a decoder's 1x1 convolution a 16 x 102 400 output with K = 32 — where what matters is
+// bytes in flight per compute unit: a 64-row tile leaves most of the staging threads without a row to load and its LDS allows four workgroups per compute unit.
+template <class T, int TM, int TN>
 static __global__ __launch_bounds__(256) void train_gemm_kernel(const TrainGemmParams p) {
-    constexpr int TM = 64, TN = 64, TK = 16, PAD = 4;
-    __shared__ float As[TK][TM + PAD];
-    __shared__ float Bs[TK][TN + PAD];
+    constexpr int TK = TRAIN_GEMM_TK, VEC = Store<T>::VEC, PITCH = TK + VEC, KCH = TK / (4 * VEC), MI = TM / 32, NJ = TN / 32;
+    __shared__ __attribute__((aligned(16))) T As[2][TM][PITCH];
+    __shared__ __attribute__((aligned(16))) T Bs[2][TN][PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
-    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    const int wm = (wave >> 1) * (TM / 2), wn = (wave & 1) * (TN / 2);
     const int li = lane & 15, lk = lane >> 4;
-    f32x4 acc[2][2];
+    f32x4 acc[MI][NJ];
     ACH_UNROLL
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
         ACH_UNROLL
-        for (int j = 0; j < 2; ++j) { acc[i][j][0] = acc[i][j][1] = acc[i][j][2] = acc[i][j][3] = 0.f; }
+        for (int j = 0; j < NJ; ++j) { acc[i][j][0] = acc[i][j][1] = acc[i][j][2] = acc[i][j][3] = 0.f; }
     // the reduction range as (batch, k-tile) pairs, linearised: everything for one output of a batched product, the whole batch for a
     // batch-reduced one, or this workgroup's share of it when split
     const long ktiles = (p.K + TK - 1) / TK;
     long t_lo, t_hi;
     if (!p.reduce_batch) { t_lo = long(blockIdx.z) * ktiles; t_hi = t_lo + ktiles; }
-    else if (p.ksplit > 1) { const long T = long(p.batch) * ktiles, per = (T + p.ksplit - 1) / p.ksplit; t_lo = long(blockIdx.z) * per; t_hi = t_lo + per < T ? t_lo + per : T; }
+    else if (p.ksplit > 1) { const long T2 = long(p.batch) * ktiles, per = (T2 + p.ksplit - 1) / p.ksplit; t_lo = long(blockIdx.z) * per; t_hi = t_lo + per < T2 ? t_lo + per : T2; }
     else { t_lo = 0; t_hi = long(p.batch) * ktiles; }
-    {
-        for (long t = t_lo; t < t_hi; ++t) {
-            const int b = int(t / ktiles), k0 = int(t - long(b) * ktiles) * TK;
-            const float* A = p.A + long(b) * p.sA;
-            const float* B = p.B + long(b) * p.sB;
-            // stage the two tiles k-major; each thread moves 4 elements of A and 4 of B (64 x 16 = 1024 each)
+    const auto aligned4 = [](const float* q, long ld, long stride) { return ((reinterpret_cast<uintptr_t>(q) & 15u) == 0) && (ld % 4 == 0) && (stride % 4 == 0); };
+    const TgOperand oa{p.A, p.lda, p.M, m0, !p.transA, aligned4(p.A, p.lda, p.sA)};
+    const TgOperand ob{p.B, p.ldb, p.N, n0, p.transB != 0, aligned4(p.B, p.ldb, p.sB)};
+    f32x4 ra0, ra1, rb0, rb1;
+    ra1 = rb1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#define ACH_TG_FETCH(t)  { const long t_ = (t); const int b_ = int(t_ / ktiles), k0_ = int(t_ - long(b_) * ktiles) * TK; \
+                           tg_fetch<TM>(oa, p.A + long(b_) * p.sA, p.K, k0_, tid, ra0, ra1); tg_fetch<TN>(ob, p.B + long(b_) * p.sB, p.K, k0_, tid, rb0, rb1); }
+    if (t_lo < t_hi) {
+        ACH_TG_FETCH(t_lo);
+        tg_stash<T, TM, PITCH>(oa, tid, ra0, ra1, As[0]);
+        tg_stash<T, TN, PITCH>(ob, tid, rb0, rb1, Bs[0]);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (long t = t_lo; t < t_hi; ++t) {
+        const bool more = t + 1 < t_hi;
+        if (more) ACH_TG_FETCH(t + 1);
+        ACH_UNROLL
+        for (int kc = 0; kc < KCH; ++kc) {
+            uint4 a[MI], bb[NJ];
             ACH_UNROLL
-            for (int e = 0; e < 4; ++e) {
-                const int idx = tid + e * 256;
-                {   // A: element (m, k)
-                    const int m = p.transA ? idx % TM : idx / TK, k = p.transA ? idx / TM : idx % TK;      // walk the contiguous index of the stored matrix fastest
-                    const int gm = m0 + m, gk = k0 + k;
-                    float v = 0.f;
-                    if (gm < p.M && gk < p.K) v = p.transA ? A[long(gk) * p.lda + gm] : A[long(gm) * p.lda + gk];
-                    As[k][m] = v;
-                }
-                {   // B: element (k, n)
-                    const int n = p.transB ? idx / TK : idx % TN, k = p.transB ? idx % TK : idx / TN;
-                    const int gn = n0 + n, gk = k0 + k;
-                    float v = 0.f;
-                    if (gn < p.N && gk < p.K) v = p.transB ? B[long(gn) * p.ldb + gk] : B[long(gk) * p.ldb + gn];
-                    Bs[k][n] = v;
-                }
-            }
-            __syncthreads();
+            for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const uint4*>(&As[cur][wm + 16 * i + li][kc * 4 * VEC + lk * VEC]);
             ACH_UNROLL
-            for (int i = 0; i < 2; ++i) {
-                const uint4 a = make_uint4(__float_as_uint(As[lk][wm + 16 * i + li]), __float_as_uint(As[4 + lk][wm + 16 * i + li]),
-                                           __float_as_uint(As[8 + lk][wm + 16 * i + li]), __float_as_uint(As[12 + lk][wm + 16 * i + li]));
+            for (int j = 0; j < NJ; ++j) bb[j] = *reinterpret_cast<const uint4*>(&Bs[cur][wn + 16 * j + li][kc * 4 * VEC + lk * VEC]);
+            ACH_UNROLL
+            for (int i = 0; i < MI; ++i)
                 ACH_UNROLL
-                for (int j = 0; j < 2; ++j) {
-                    const uint4 bb = make_uint4(__float_as_uint(Bs[lk][wn + 16 * j + li]), __float_as_uint(Bs[4 + lk][wn + 16 * j + li]),
-                                                __float_as_uint(Bs[8 + lk][wn + 16 * j + li]), __float_as_uint(Bs[12 + lk][wn + 16 * j + li]));
-                    mfma16<float>(a, bb, acc[i][j]);
-                }
-            }
-            __syncthreads();
+                for (int j = 0; j < NJ; ++j) mfma16_pair<T>(a[i], bb[j], acc[i][j]);        // (long-lived matrix-instruction waves: the pair form)
         }
+        if (more) {
+            tg_stash<T, TM, PITCH>(oa, tid, ra0, ra1, As[cur ^ 1]);
+            tg_stash<T, TN, PITCH>(ob, tid, rb0, rb1, Bs[cur ^ 1]);
+        }
+        __syncthreads();
+        cur ^= 1;
     }
     const bool partial = p.reduce_batch && p.ksplit > 1;
     float* C = partial ? p.ws + long(blockIdx.z) * p.M * p.N : p.C + (p.reduce_batch ? 0L : long(blockIdx.z) * p.sC);
     const long ldc = partial ? long(p.N) : p.ldc;
     ACH_UNROLL
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
         ACH_UNROLL
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
             ACH_UNROLL
             for (int r = 0; r < 4; ++r) {
                 const int gm = m0 + wm + 16 * i + lk * 4 + r, gn = n0 + wn + 16 * j + li;
@@ -104,6 +171,7 @@ static __global__ __launch_bounds__(256) void train_gemm_kernel(const TrainGemmP
                     *c = p.accumulate ? *c + v : v;
                 }
             }
+#undef ACH_TG_FETCH
 }
 // C = [C +] bias + sum_z ws[z].  One 16-lane group per output element: lane j sums z = j, j + 16, ... (ascending), then the group
 // folds 16 -> 1 in a fixed butterfly: a deterministic order, and 16 partial loads in flight per element instead of one thread walking

@@ -153,6 +153,14 @@ class Achelous(nn.Module):
         # `bf16_storage` to 'bf16' and recomputes that forward with bf16 storage; fp16 callers chose the type themselves and only get the warning.
         # 'first' (default) | 'always' (every forward: a debugging aid, it serialises the stream) | 'off'
         self.f16_guard = 'first'
+        # training mode: element type of the GEMMs' matrix-instruction operands (every dense / 1x1 convolution and Linear, forward and backward; csrc/k_train.h).
+        # 'fp32' (default) | 'bf16' = the fp32 operands are rounded to bf16 while they are staged into LDS, fp32 accumulation; activations, statistics, gradients
+        # and every other kernel stay fp32 either way.  Measured: 'bf16' is NOT faster — this network's training GEMMs are streams of fp32
+        # activations through 16 - 48-channel layers, bound by HBM at either operand width — and costs what 16-bit operands cost (outputs 1 - 4e-2 of the float64
+        # step where fp32 is 1e-5; torch's own autocast(bfloat16) of the same graph: 5e-2), so the reference's AMP loop (utils/utils_fit.py:120-166) keeps running
+        # on fp32 kernels unless the caller asks.  The switch is process-wide in the library (ach_train_set_gemm_precision) and is set by every training forward,
+        # so the backward that follows a forward runs with that forward's choice.
+        self.train_precision = 'fp32'
         self.f16_saturated = 0      # what the last check counted
 
     # engines hold ctypes handles: never pickle / deepcopy them (utils_fit.py:378 pickles the module, ModelEMA deep-copies it)
@@ -308,6 +316,9 @@ class Achelous(nn.Module):
         if not (x.is_cuda and x_radar.is_cuda and (not has_pts or x_point_clouds.is_cuda)) and not getattr(train_ops._lib, 'test_library', None):
             raise RuntimeError("achelous_amd.Achelous.forward needs GPU tensors (HIP training kernels; there is no CPU path)")
         B = self._check_inputs(x, x_radar, x_point_clouds)
+        if self.train_precision not in ('fp32', 'bf16'):
+            raise ValueError(f"train_precision must be 'fp32' or 'bf16', got {self.train_precision!r}")
+        train_ops.set_gemm_precision(x, 1 if self.train_precision == 'bf16' else 0)
         det, se, lane, pc = train_graph.TrainGraph(self).forward(x, x_radar, x_point_clouds if has_pts else None)
         return (list(det), se, lane, pc) if has_pts else (list(det), se, lane)
 

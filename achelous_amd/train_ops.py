@@ -34,6 +34,16 @@ def _lib(t):
     return getattr(_lib, 'test_library', None) or _eng.hip_library()
 
 
+def set_gemm_precision(t, precision):
+    """Operand type of every `ach_train_gemm` from now on, process-wide: 0 = fp32 MFMA, 1 = operands rounded to bf16 while staged, fp32
+    accumulation (include/achelous.h).  `t`: any tensor of the device the step runs on (selects the library as `_lib` does).  Returns the previous value."""
+    L = _lib(t).lib
+    prev = L.ach_train_get_gemm_precision()
+    if L.ach_train_set_gemm_precision(int(precision)) != 0:
+        raise ValueError(f"gemm precision must be 0 (fp32) or 1 (bf16 operands), got {precision!r}")
+    return prev
+
+
 def _check(lib, rc):
     if rc != 0:
         raise RuntimeError((lib.lib.ach_last_error(None) or b'train kernel failed').decode())

@@ -251,6 +251,14 @@ int ach_read_probe_slot(ach_handle* h, int slot, float* avg_ms, int* samples);
 int ach_train_gemm(const float* A, const float* B, float* C, const float* bias, int32_t M, int32_t N, int32_t K, int64_t lda, int64_t ldb, int64_t ldc,
                    int64_t stride_a, int64_t stride_b, int64_t stride_c, int32_t trans_a, int32_t trans_b, int32_t batch, int32_t reduce_batch,
                    int32_t accumulate, void* stream);
+/*   ach_train_set_gemm_precision   element type of ach_train_gemm's matrix-instruction operands, process-wide: 0 = fp32 (default; the arithmetic the
+ *                          float64 reference-step test holds to 5e-3), 1 = the fp32 operands are rounded to bf16 while they are staged into LDS, products
+ *                          accumulated in fp32, fp32 output (the reference's default loop runs under torch.cuda.amp.autocast, utils/utils_fit.py:120-166,
+ *                          train.py:37 `fp16 = True`; achelous_amd.Achelous.train_precision = 'bf16' selects it).  Every other training kernel stays fp32.
+ *                          Measured no faster on this network (its training GEMMs are HBM-bound streams of fp32 activations): opt-in.
+ *                          Returns ACH_ERR_INVALID for another value; ach_train_get_gemm_precision returns the current one. */
+int ach_train_set_gemm_precision(int32_t precision);
+int ach_train_get_gemm_precision(void);
 int ach_train_bn_stats(const float* z, float* mean, float* var, int32_t B, int32_t C, int32_t N, void* stream);
 int ach_train_bn_relu_fwd(const float* z, const float* mean, const float* var, const float* gamma, const float* beta, float* y, int32_t B, int32_t C,
                           int32_t N, float eps, int32_t relu, void* stream);

@@ -655,6 +655,37 @@ def test_pipelined_submit_wait_equals_plain_calls(name, reps):
             assert torch.equal(o0[1], want[0][0][1]) and torch.equal(o[1], want[1][0][1])
 
 
+@pytest.mark.parametrize('fork', [0, 2, 3])
+def test_pipelined_decoder_fork_points_are_bit_identical(fork):
+    """Option "dec_fork" (round 5): the pipelined plan's decoders leave the caller's stream in front of the shared ShuffleAttention stage (1) or as soon as p3
+    exists (2) instead of behind the stage — same launches, same buffers, another stream for three of them: bit-identical to the plain calls, several passes
+    with two forwards in flight (the stage's inputs are rewritten by the NEXT forward's neck, which waits for this forward's decoders)."""
+    g = Golden('en_s0')
+    m, kw = _model(g)
+    m.engine_options = dict(m.engine_options, dec_fork=fork)
+    m.reset_engines()
+    for dt in (torch.float32, torch.bfloat16):
+        batches = []
+        for i in range(6):
+            x, xr, xp = make_inputs(16, 900 + i, resolution=kw['resolution'], pc_channels=kw['pc_channels'], dense_radar=(i % 2 == 1))
+            batches.append((x.cuda().to(dt), xr.cuda().to(dt), xp.cuda().to(dt)))
+        with torch.no_grad():
+            want = [m.forward_detect(*b, 0.05, 0.5, 100) for b in batches]
+            torch.cuda.synchronize()
+            for rep in range(2 if dt == torch.float32 else 6):
+                got, prev = [], None
+                for b in batches:
+                    nxt = m.submit_detect(*b, 0.05, 0.5, 100)
+                    if prev is not None:
+                        got.append(prev.wait())
+                    prev = nxt
+                got.append(prev.wait())
+                torch.cuda.synchronize()
+                for (o1, d1), (o2, d2) in zip(got, want):
+                    for a, b_ in zip((*o1[0], o1[1], o1[2], o1[3], *d1), (*o2[0], o2[1], o2[2], o2[3], *d2)):
+                        assert torch.equal(a, b_), (dt, fork, rep)
+
+
 def test_forward_detect_equals_the_three_calls():
     """ach_forward_detect (decode + NMS behind the detection head on its stream) == forward -> decode_outputs -> NMS, bit for bit."""
     g = Golden('en_s0')
