@@ -13,6 +13,7 @@
 #include "k_prepost.h"
 #include "k_train.h"
 #include "k_train2.h"
+#include "k_train3.h"
 
 struct ach_handle {
     ach::EngineBase* eng = nullptr;
@@ -481,8 +482,16 @@ int ach_train_dwconv_wgrad(const float* x, const float* dz, float* dw, int32_t B
     return train_guard([&] {
         train_need(x && dz && dw && B > 0 && C > 0 && H > 0 && W > 0 && k > 0 && (k & 1), "ach_train_dwconv_wgrad");
         ach::TrainDwWgradParams p{x, dz, dw, B, C, H, W, k, 1, nullptr};
-        p.S = train_slices(long(B) * H * W, C * k * k);
+        const bool taps = (k == 3 || k == 5 || k == 7 || k == 9) && long(B) * H * W < (1L << 31);      // all taps of a channel in one pass (k_train2.h)
+        p.S = train_slices(long(B) * H * W, taps ? C : C * k * k);
         if (p.S > 1) p.ws = train_workspace(size_t(C) * k * k * p.S * sizeof(float));
+        const hipStream_t st = static_cast<hipStream_t>(stream);
+        const dim3 gt(unsigned(C), unsigned(p.S));
+        if (taps && k == 3) ACH_LAUNCH(ach::train_dwconv_wgrad_taps_kernel<3>, gt, dim3(256), st, p);
+        else if (taps && k == 5) ACH_LAUNCH(ach::train_dwconv_wgrad_taps_kernel<5>, gt, dim3(256), st, p);
+        else if (taps && k == 7) ACH_LAUNCH(ach::train_dwconv_wgrad_taps_kernel<7>, gt, dim3(256), st, p);
+        else if (taps) ACH_LAUNCH(ach::train_dwconv_wgrad_taps_kernel<9>, gt, dim3(256), st, p);
+        else
         ACH_LAUNCH(ach::train_dwconv_wgrad_kernel, dim3(unsigned(C * k * k), unsigned(p.S)), dim3(256), static_cast<hipStream_t>(stream), p);
         if (p.S > 1) ACH_LAUNCH(ach::train_dwconv_wgrad_finalize_kernel, dim3(unsigned((C * k * k + 255) / 256)), dim3(256), static_cast<hipStream_t>(stream), p);
     });
@@ -579,10 +588,51 @@ int ach_train_deform_im2col(const float* x, const float* offset, const float* ma
 int ach_train_deform_bwd(const float* x, const float* offset, const float* mask, const float* dcol, float* dx_zeroed, float* doffset, float* dmask, int32_t B,
                          int32_t C, int32_t H, int32_t W, int32_t Ho, int32_t Wo, int32_t stride, int32_t pad, void* stream) {
     return train_guard([&] {
-        train_need(x && offset && mask && dcol && dx_zeroed && doffset && dmask && B > 0 && C > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && stride > 0, "ach_train_deform_bwd");
+        train_need(x && offset && mask && dcol && doffset && dmask && B > 0 && C > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && stride > 0, "ach_train_deform_bwd");
         ach::TrainDeformParams p{x, offset, mask, nullptr, dcol, dx_zeroed, doffset, dmask, B, C, H, W, Ho, Wo, stride, pad};
         ACH_TRAIN_1D(ach::train_deform_bwd_coord_kernel, p, long(B) * 9 * Ho * Wo);
-        ACH_TRAIN_1D(ach::train_deform_bwd_input_kernel, p, long(B) * C * 9 * Ho * Wo);
+        if (dx_zeroed && stride == 1) {          // adds combined in LDS per 16 x 16 tile of positions (k_train2.h); NULL: the input needs no gradient (the first RCBlock reads the pooled radar map)
+            const long tiles = long((Wo + ach::DBI_T - 1) / ach::DBI_T) * ((Ho + ach::DBI_T - 1) / ach::DBI_T);
+            ACH_LAUNCH(ach::train_deform_bwd_input_tile_kernel, dim3(unsigned(tiles * B)), dim3(256), static_cast<hipStream_t>(stream), p);
+        } else if (dx_zeroed) ACH_TRAIN_1D(ach::train_deform_bwd_input_kernel, p, long(B) * C * 9 * Ho * Wo);
+    });
+}
+// ---- PointNet++ in training mode (k_train3.h): the inference engine's geometry kernels at fp32 + the two scatter-form adjoints
+int ach_train_pn2_fps(const float* xyz, int32_t B, int32_t n, int32_t npoint, int32_t* idx, float* new_xyz, void* stream) {
+    return train_guard([&] {
+        train_need(xyz && idx && new_xyz && B > 0 && n > 0 && npoint > 0 && npoint <= n && n <= 64 * ach::PN2_FPS_MAX_PPT, "ach_train_pn2_fps");
+        ach::launch_pn2_fps(ach::FpsParams{xyz, n, npoint, idx, new_xyz}, B, static_cast<hipStream_t>(stream));
+    });
+}
+int ach_train_pn2_group(const float* xyz, const float* new_xyz, const float* feats, int32_t C, int32_t B, int32_t n, int32_t S, int32_t nsample, float radius2,
+                        float* grouped, int32_t* group_idx, void* stream) {
+    return train_guard([&] {
+        train_need(xyz && new_xyz && (feats || C == 0) && grouped && group_idx && C >= 0 && B > 0 && n > 0 && S > 0 && nsample > 0 && nsample <= ach::PN2_MAX_NSAMPLE, "ach_train_pn2_group");
+        ach::GroupParams q{xyz, new_xyz, feats, long(C), C, grouped, long(3 + C), group_idx, B, n, S, nsample, radius2};
+        ACH_LAUNCH(ach::pn2_group_kernel<float>, dim3(unsigned(ach::cdivl(long(B) * S, 4))), dim3(256), static_cast<hipStream_t>(stream), q);
+    });
+}
+int ach_train_pn2_group_bwd(const int32_t* group_idx, const float* dgrouped, float* dfeats_zeroed, int32_t C, int32_t B, int32_t n, int32_t S, int32_t nsample, void* stream) {
+    return train_guard([&] {
+        train_need(group_idx && dgrouped && dfeats_zeroed && C > 0 && B > 0 && n > 0 && S > 0 && nsample > 0, "ach_train_pn2_group_bwd");
+        ach::Pn2GroupBwdParams q{group_idx, dgrouped, long(3 + C), dfeats_zeroed, C, B, n, S, nsample};
+        ACH_TRAIN_1D(ach::train_pn2_group_bwd_kernel, q, long(B) * S * nsample * C);
+    });
+}
+int ach_train_pn2_interp(const float* xyz1, const float* xyz2, const float* skip, int32_t C1, const float* sparse, int32_t C2, float* out, float* dskip, float* dsparse_zeroed,
+                         const float* dout, int32_t B, int32_t n, int32_t s, void* stream) {
+    return train_guard([&] {
+        train_need(xyz1 && xyz2 && C1 >= 0 && C2 > 0 && B > 0 && n > 0 && s >= 3 && s <= 64 * ach::PN2_INTERP_SPL, "ach_train_pn2_interp");
+        const dim3 grid(unsigned(ach::cdivl(long(B) * n, 4))), block(256);
+        if (!dout) {
+            train_need((skip || C1 == 0) && sparse && out, "ach_train_pn2_interp (forward)");
+            ach::InterpParams q{xyz1, xyz2, skip, long(C1), C1, sparse, long(C2), C2, out, long(C1 + C2), B, n, s};
+            ACH_LAUNCH(ach::pn2_interp_kernel<float>, grid, block, static_cast<hipStream_t>(stream), q);
+        } else {
+            train_need((dskip || C1 == 0) && dsparse_zeroed, "ach_train_pn2_interp (backward)");
+            ach::InterpParams q{xyz1, xyz2, nullptr, long(C1), C1, nullptr, long(C2), C2, nullptr, long(C1 + C2), B, n, s};
+            ACH_LAUNCH(ach::train_pn2_interp_bwd_kernel, grid, block, static_cast<hipStream_t>(stream), q, dout, dskip, dsparse_zeroed);
+        }
     });
 }
 #undef ACH_TRAIN_1D

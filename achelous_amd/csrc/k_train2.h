@@ -23,6 +23,10 @@ __device__ __forceinline__ float block_sum_256(float v, float* sh) {       // sh
     return r;
 }
 
+// i / d for index arithmetic: 32-bit division where both fit (this target has no integer divider: a 64-bit division is ~200 instructions, a 32-bit one ~30;
+// the one-thread-per-element kernels below split their linear index three to five times per element)
+__device__ __forceinline__ long tdiv(long i, long d) { return ((static_cast<unsigned long>(i) | static_cast<unsigned long>(d)) >> 32) == 0 ? long(unsigned(i) / unsigned(d)) : i / d; }
+
 // ------------------------------------------------------------------------------------------ activations
 // kind 0 ReLU, 1 SiLU, 2 GELU (erf form, nn.GELU default), 3 sigmoid.  dy == nullptr: out = f(x); else out = dy * f'(x).
 struct TrainActParams { const float* x; const float* dy; float* out; long n; int kind; };
@@ -108,7 +112,8 @@ static __global__ __launch_bounds__(256) void train_dwconv_kernel(const TrainDwP
     const long i = long(blockIdx.x) * 256 + threadIdx.x;
     const long total = long(p.B) * p.C * p.H * p.W;
     if (i >= total) return;
-    const int ox = int(i % p.W), oy = int((i / p.W) % p.H), c = int((i / (long(p.W) * p.H)) % p.C);
+    const long row = tdiv(i, p.W), pl = tdiv(row, p.H);
+    const int ox = int(i - row * p.W), oy = int(row - pl * p.H), c = int(pl - tdiv(pl, p.C) * p.C);
     const float* xp = p.x + (i - long(oy) * p.W - ox);
     const float* w = p.w + long(c) * p.k * p.k;
     const int r = p.k / 2;
@@ -147,6 +152,52 @@ static __global__ __launch_bounds__(256) void train_dwconv_wgrad_kernel(const Tr
     a = block_sum_256(a, sh);
     if (threadIdx.x == 0) { if (p.S > 1) p.ws[long(blockIdx.x) * p.S + blockIdx.y] = a; else p.dw[blockIdx.x] = a; }
 }
+// Round 5: ALL k x k taps of a channel in one pass.  The kernel above walks the (B, H, W) range once per TAP — 9 to 81 passes over dz and x per layer, two 64-bit divisions per
+// element — and was 9 % of a batch-32 training step (6.7 ms; 1.2 ms for one 16-channel 3x3 layer at 320 x 320).  Here a workgroup owns (channel, slice), a thread keeps k x k
+// accumulators in registers, reads dz once per position and the k x k neighbours of x through L1; 32-bit index arithmetic (B H W < 2^31 is checked by the caller); one block
+// reduction per tap at the end.  Same partial layout (ws[(c k k + t) S + s]) and finalize kernel; the sums differ from the per-tap kernel's only in the order of the fp32 additions.
+template <int K>
+static __global__ __launch_bounds__(256) void train_dwconv_wgrad_taps_kernel(const TrainDwWgradParams p) {
+    constexpr int R = K / 2, KK = K * K;
+    __shared__ float part[4][KK];
+    const int c = blockIdx.x;
+    const unsigned hw = unsigned(p.H) * unsigned(p.W), total = unsigned(p.B) * hw;
+    const unsigned per = p.S > 1 ? (total + unsigned(p.S) - 1) / unsigned(p.S) : total, lo = p.S > 1 ? blockIdx.y * per : 0u, hi = (lo + per < total) ? lo + per : total;
+    float acc[KK];
+    ACH_UNROLL
+    for (int t = 0; t < KK; ++t) acc[t] = 0.f;
+    for (unsigned e = lo + threadIdx.x; e < hi; e += 256) {
+        const unsigned b = e / hw, pix = e - b * hw;
+        const int oy = int(pix / unsigned(p.W)), ox = int(pix - unsigned(oy) * unsigned(p.W));
+        const float* xc = p.x + (long(b) * p.C + c) * long(hw);
+        const float g = p.dz[(long(b) * p.C + c) * long(hw) + pix];
+        ACH_UNROLL
+        for (int ky = 0; ky < K; ++ky) {
+            const int iy = oy + ky - R;
+            const bool row = iy >= 0 && iy < p.H;
+            const float* xr = xc + long(row ? iy : 0) * p.W;
+            ACH_UNROLL
+            for (int kx = 0; kx < K; ++kx) {
+                const int ix = ox + kx - R;
+                const bool in = row && ix >= 0 && ix < p.W;
+                acc[ky * K + kx] += g * (in ? xr[ix] : 0.f);
+            }
+        }
+    }
+    // per tap: butterfly inside the wave (no barrier), the four waves' sums through LDS, ONE barrier for all taps
+    const int lane = int(threadIdx.x) & 63, wave = int(threadIdx.x) >> 6;
+    ACH_UNROLL
+    for (int t = 0; t < KK; ++t) {
+        float v = acc[t];
+        v += __shfl_xor(v, 32); v += __shfl_xor(v, 16); v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+        if (lane == 0) part[wave][t] = v;
+    }
+    __syncthreads();
+    for (int t = int(threadIdx.x); t < KK; t += 256) {
+        const float a = ((part[0][t] + part[1][t]) + part[2][t]) + part[3][t];
+        if (p.S > 1) p.ws[(long(c) * KK + t) * p.S + blockIdx.y] = a; else p.dw[c * KK + t] = a;
+    }
+}
 static __global__ __launch_bounds__(256) void train_dwconv_wgrad_finalize_kernel(const TrainDwWgradParams p) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= p.C * p.k * p.k) return;
@@ -162,17 +213,17 @@ static __global__ __launch_bounds__(256) void train_im2col_kernel(const TrainCol
     const long i = long(blockIdx.x) * 256 + threadIdx.x;
     const long K = long(p.C) * p.kh * p.kw, O = long(p.Ho) * p.Wo;
     if (i >= long(p.B) * K * O) return;
-    const long o = i % O, kk = (i / O) % K, b = i / (O * K);
-    const int ox = int(o % p.Wo), oy = int(o / p.Wo);
-    const int kx = int(kk % p.kw), ky = int((kk / p.kw) % p.kh), ci = int(kk / (long(p.kw) * p.kh));
+    const long io = tdiv(i, O), o = i - io * O, b = tdiv(io, K), kk = io - b * K;
+    const int oy = int(tdiv(o, p.Wo)), ox = int(o - long(oy) * p.Wo);
+    const int kq = int(kk) / p.kw, kx = int(kk) - kq * p.kw, ci = kq / p.kh, ky = kq - ci * p.kh;
     const int iy = oy * p.sh - p.ph + ky, ix = ox * p.sw - p.pw + kx;
     p.dst[i] = (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? p.src[((b * p.C + ci) * p.H + iy) * long(p.W) + ix] : 0.f;
 }
 static __global__ __launch_bounds__(256) void train_col2im_kernel(const TrainColParams p) {      // dx[b][ci][iy][ix] = sum of the col entries that read it
     const long i = long(blockIdx.x) * 256 + threadIdx.x;
     if (i >= long(p.B) * p.C * p.H * p.W) return;
-    const int ix = int(i % p.W), iy = int((i / p.W) % p.H), ci = int((i / (long(p.W) * p.H)) % p.C);
-    const long b = i / (long(p.W) * p.H * p.C);
+    const long row = tdiv(i, p.W), pl = tdiv(row, p.H), b = tdiv(pl, p.C);
+    const int ix = int(i - row * p.W), iy = int(row - pl * p.H), ci = int(pl - b * p.C);
     const long K = long(p.C) * p.kh * p.kw, O = long(p.Ho) * p.Wo;
     float a = 0.f;
     for (int ky = 0; ky < p.kh; ++ky) {
@@ -224,8 +275,8 @@ static __global__ __launch_bounds__(256) void train_up2_fwd_kernel(const TrainUp
     const int H = 2 * p.h, W = 2 * p.w;
     const long i = long(blockIdx.x) * 256 + threadIdx.x;
     if (i >= p.planes * H * W) return;
-    const int ox = int(i % W), oy = int((i / W) % H);
-    const long pl = i / (long(W) * H);
+    const long row = tdiv(i, W), pl = tdiv(row, H);
+    const int ox = int(i - row * W), oy = int(row - pl * H);
     int y0, y1, x0, x1; float ly, lx;
     up2_src(oy, p.h, p.sy, y0, y1, ly); up2_src(ox, p.w, p.sx, x0, x1, lx);
     const float* s = p.src + pl * p.h * p.w;
@@ -236,8 +287,8 @@ static __global__ __launch_bounds__(256) void train_up2_bwd_kernel(const TrainUp
     const int H = 2 * p.h, W = 2 * p.w;
     const long i = long(blockIdx.x) * 256 + threadIdx.x;
     if (i >= p.planes * p.h * p.w) return;
-    const int ix = int(i % p.w), iy = int((i / p.w) % p.h);
-    const long pl = i / (long(p.w) * p.h);
+    const long row = tdiv(i, p.w), pl = tdiv(row, p.h);
+    const int ix = int(i - row * p.w), iy = int(row - pl * p.h);
     const float* dy = p.src + pl * H * W;
     float a = 0.f;
     for (int oy = 2 * iy - 2 < 0 ? 0 : 2 * iy - 2; oy <= 2 * iy + 2 && oy < H; ++oy) {
@@ -396,8 +447,9 @@ static __global__ __launch_bounds__(256) void train_deform_im2col_kernel(const T
     const long O = long(p.Ho) * p.Wo;
     const long i = long(blockIdx.x) * 256 + threadIdx.x;
     if (i >= long(p.B) * p.C * 9 * O) return;
-    const long o = i % O; const int k = int((i / O) % 9), ci = int((i / (O * 9)) % p.C); const long b = i / (O * 9 * p.C);
-    const int ox = int(o % p.Wo), oy = int(o / p.Wo);
+    const long io = tdiv(i, O), o = i - io * O, ic = tdiv(io, 9), b = tdiv(ic, p.C);
+    const int k = int(io - ic * 9), ci = int(ic - b * p.C);
+    const int oy = int(tdiv(o, p.Wo)), ox = int(o - long(oy) * p.Wo);
     const float py = float(oy * p.stride - p.pad + k / 3) + p.offset[(b * 18 + 2 * k) * O + o];
     const float px = float(ox * p.stride - p.pad + k % 3) + p.offset[(b * 18 + 2 * k + 1) * O + o];
     float v = 0.f;
@@ -414,8 +466,9 @@ static __global__ __launch_bounds__(256) void train_deform_bwd_coord_kernel(cons
     const long O = long(p.Ho) * p.Wo;
     const long i = long(blockIdx.x) * 256 + threadIdx.x;
     if (i >= long(p.B) * 9 * O) return;
-    const long o = i % O; const int k = int((i / O) % 9); const long b = i / (O * 9);
-    const int ox = int(o % p.Wo), oy = int(o / p.Wo);
+    const long io = tdiv(i, O), o = i - io * O, b = tdiv(io, 9);
+    const int k = int(io - b * 9);
+    const int oy = int(tdiv(o, p.Wo)), ox = int(o - long(oy) * p.Wo);
     const float py = float(oy * p.stride - p.pad + k / 3) + p.offset[(b * 18 + 2 * k) * O + o];
     const float px = float(ox * p.stride - p.pad + k % 3) + p.offset[(b * 18 + 2 * k + 1) * O + o];
     const float m = p.mask[(b * 9 + k) * O + o];
@@ -437,12 +490,21 @@ static __global__ __launch_bounds__(256) void train_deform_bwd_coord_kernel(cons
     p.doffset[(b * 18 + 2 * k) * O + o] = gy;
     p.doffset[(b * 18 + 2 * k + 1) * O + o] = gx;
 }
+// fp32 add at the L2 (global_atomic_add_f32, no return value): without -munsafe-fp-atomics the plain atomicAdd(float*) is a compare-and-swap LOOP per element —
+// the 354 M adds of the first radar block's input gradient at batch 32 took 2.6 ms that way.  The buffers are hipMalloc'd (coarse-grained) device memory, where the
+// hardware instruction is valid; the result is the same sum in another (equally unspecified) order.
+#if defined(ACH_HOSTEMU)
+static inline void train_atomic_add(float* p, float v) { atomicAdd(p, v); }
+#else
+static __device__ __forceinline__ void train_atomic_add(float* p, float v) { unsafeAtomicAdd(p, v); }
+#endif
 static __global__ __launch_bounds__(256) void train_deform_bwd_input_kernel(const TrainDeformParams p) {     // one thread per col element: 4 atomic adds
     const long O = long(p.Ho) * p.Wo;
     const long i = long(blockIdx.x) * 256 + threadIdx.x;
     if (i >= long(p.B) * p.C * 9 * O) return;
-    const long o = i % O; const int k = int((i / O) % 9), ci = int((i / (O * 9)) % p.C); const long b = i / (O * 9 * p.C);
-    const int ox = int(o % p.Wo), oy = int(o / p.Wo);
+    const long io = tdiv(i, O), o = i - io * O, ic = tdiv(io, 9), b = tdiv(ic, p.C);
+    const int k = int(io - ic * 9), ci = int(ic - b * p.C);
+    const int oy = int(tdiv(o, p.Wo)), ox = int(o - long(oy) * p.Wo);
     const float py = float(oy * p.stride - p.pad + k / 3) + p.offset[(b * 18 + 2 * k) * O + o];
     const float px = float(ox * p.stride - p.pad + k % 3) + p.offset[(b * 18 + 2 * k + 1) * O + o];
     if (!(py > -1.f && px > -1.f && py < float(p.H) && px < float(p.W))) return;
@@ -454,7 +516,66 @@ static __global__ __launch_bounds__(256) void train_deform_bwd_input_kernel(cons
     ACH_UNROLL
     for (int q = 0; q < 4; ++q) {
         const int y = y0 + (q >> 1), x = x0 + (q & 1);
-        if (y >= 0 && y < p.H && x >= 0 && x < p.W) atomicAdd(dimg + long(y) * p.W + x, g * wts[q]);
+        if (y >= 0 && y < p.H && x >= 0 && x < p.W) train_atomic_add(dimg + long(y) * p.W + x, g * wts[q]);
+    }
+}
+
+// Round 5: the same scatter with the adds COMBINED IN LDS first (stride 1, every RCBlock).  A workgroup owns a 16 x 16 tile of output positions of one sample; per channel it
+// accumulates the 9 x 4 corner contributions of its positions into an LDS tile of the input plane (the output tile + a halo of DBI_R pixels: offsets are a few pixels; LDS atomics),
+// then adds the tile's non-zero cells to dx — one L2 atomic per touched input pixel instead of 36 per output position (the kernel above: 354 M L2 atomics for the 160 x 160 block
+// at batch 32, 2.6 ms).  A corner outside the LDS tile (a far offset) goes to dx directly, so any offset is handled.  The tap geometry (corner, four modulated weights) is computed
+// once per position and kept in registers across the channel loop.  Same sums in another order.
+constexpr int DBI_T = 16, DBI_R = 8, DBI_W = DBI_T + 2 * DBI_R + 2;
+static __global__ __launch_bounds__(256) void train_deform_bwd_input_tile_kernel(const TrainDeformParams p) {
+    __shared__ float tile[DBI_W][DBI_W + 1];
+    const int tid = threadIdx.x;
+    const int tiles_x = (p.Wo + DBI_T - 1) / DBI_T, tiles_y = (p.Ho + DBI_T - 1) / DBI_T;
+    const int tx = int(blockIdx.x % unsigned(tiles_x)), ty = int((blockIdx.x / unsigned(tiles_x)) % unsigned(tiles_y));
+    const long b = long(blockIdx.x / (unsigned(tiles_x) * unsigned(tiles_y)));
+    const int ox = tx * DBI_T + (tid & 15), oy = ty * DBI_T + (tid >> 4);
+    const bool live = ox < p.Wo && oy < p.Ho;
+    const long O = long(p.Ho) * p.Wo, o = long(oy) * p.Wo + ox;
+    const int iy0 = ty * DBI_T - p.pad - DBI_R, ix0 = tx * DBI_T - p.pad - DBI_R;          // input pixel of tile[0][0]  (stride 1)
+    int cy[9], cx[9]; float w[9][4]; bool on[9];
+    ACH_UNROLL
+    for (int k = 0; k < 9; ++k) {
+        on[k] = false; cy[k] = cx[k] = 0; w[k][0] = w[k][1] = w[k][2] = w[k][3] = 0.f;
+        if (!live) continue;
+        const float py = float(oy - p.pad + k / 3) + p.offset[(b * 18 + 2 * k) * O + o];
+        const float px = float(ox - p.pad + k % 3) + p.offset[(b * 18 + 2 * k + 1) * O + o];
+        if (!(py > -1.f && px > -1.f && py < float(p.H) && px < float(p.W))) continue;
+        const float m = p.mask[(b * 9 + k) * O + o];
+        const int y0 = int(floorf(py)), x0 = int(floorf(px));
+        const float ly = py - float(y0), lx = px - float(x0), hy = 1.f - ly, hx = 1.f - lx;
+        on[k] = true; cy[k] = y0; cx[k] = x0;
+        w[k][0] = hy * hx * m; w[k][1] = hy * lx * m; w[k][2] = ly * hx * m; w[k][3] = ly * lx * m;
+    }
+    for (int ci = 0; ci < p.C; ++ci) {
+        for (int e = tid; e < DBI_W * DBI_W; e += 256) tile[e / DBI_W][e % DBI_W] = 0.f;
+        __syncthreads();
+        float* dimg = p.dx + (b * p.C + ci) * long(p.H) * p.W;
+        ACH_UNROLL
+        for (int k = 0; k < 9; ++k) {
+            if (!on[k]) continue;
+            const float g = p.dcol[((b * p.C + ci) * 9 + k) * O + o];
+            ACH_UNROLL
+            for (int q = 0; q < 4; ++q) {
+                const int y = cy[k] + (q >> 1), x = cx[k] + (q & 1);
+                if (y < 0 || y >= p.H || x < 0 || x >= p.W) continue;
+                // (the modulation is folded into w: g * mask * corner weight, the product the per-element kernel forms as (dcol * mask) * weight — one rounding apart)
+                const int ty_ = y - iy0, tx_ = x - ix0;
+                if (ty_ >= 0 && ty_ < DBI_W && tx_ >= 0 && tx_ < DBI_W) atomicAdd(&tile[ty_][tx_], g * w[k][q]);
+                else train_atomic_add(dimg + long(y) * p.W + x, g * w[k][q]);
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < DBI_W * DBI_W; e += 256) {
+            const int r = e / DBI_W, c = e % DBI_W;
+            const float v = tile[r][c];
+            const int y = iy0 + r, x = ix0 + c;
+            if (v != 0.f && y >= 0 && y < p.H && x >= 0 && x < p.W) train_atomic_add(dimg + long(y) * p.W + x, v);
+        }
+        __syncthreads();
     }
 }
 

@@ -9,7 +9,7 @@ libachelous_hip.so).  There is no PyTorch-op or CPU fallback: without the HIP li
 
 Eval mode runs the fused inference engine (BatchNorm running statistics folded into the convolutions).  Training mode
 (`.train()`, fp32) runs the unfused network on native forward / backward kernels through autograd (train_graph.py, SURVEY.md §8(f)
-row 4) for every family with reference code (EdgeNeXt / MobileViT, Ghost- / CSP-Dual-FPN, PointNet); PointNet++ raises in training mode.
+row 4) for every family with reference code (EdgeNeXt / MobileViT, Ghost- / CSP-Dual-FPN, PointNet) and, since round 5, for PointNet++ (our own specification: k_train3.h).
 """
 import operator
 import weakref

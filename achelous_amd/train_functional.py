@@ -581,11 +581,87 @@ class _DeformConvFn(torch.autograd.Function):
         _gemm(lib, s, dy, col, dw, Co, K, O, O, O, K, Co * O, K * O, 0, 0, 1, B, reduce=1)
         dcol = col                                                                # reuse the buffer
         _gemm(lib, s, w2, dy, dcol, K, O, Co, K, O, O, 0, Co * O, K * O, 1, 0, B)
-        dx = torch.zeros_like(x)
+        dx = torch.zeros_like(x) if ctx.needs_input_grad[0] else None             # (the first RCBlock samples the pooled radar map: an input, no gradient — 354 M atomic adds at batch 32)
         doff, dmask = torch.empty_like(offset), torch.empty_like(mask)
-        _check(lib, L.ach_train_deform_bwd(_p(x), _p(offset), _p(mask), _p(dcol), _p(dx), _p(doff), _p(dmask), B, C, H, W, Ho, Wo, stride, pad, s))
+        _check(lib, L.ach_train_deform_bwd(_p(x), _p(offset), _p(mask), _p(dcol), _p(dx) if dx is not None else _NULL, _p(doff), _p(dmask), B, C, H, W, Ho, Wo, stride, pad, s))
         return dx, doff, dmask, dw.view(wshape), None, None
 
 
 def deform_conv3x3(x, offset, mask, weight, stride=1, pad=1):
     return _DeformConvFn.apply(x, offset, mask, weight, stride, pad)
+
+
+# ------------------------------------------------------------------------------------------------------------------ PointNet++ (our own specification)
+def pn2_fps(xyz, npoint):
+    """Farthest-point sampling of xyz [B, n, 3] (no gradient: coordinates of the input cloud) -> idx int32 [B, npoint], new_xyz [B, npoint, 3]."""
+    xyz = _f32(xyz.detach(), 'pn2_fps')
+    B, n, _ = xyz.shape
+    lib = _lib(xyz)
+    idx = torch.empty(B, npoint, dtype=torch.int32, device=xyz.device)
+    new_xyz = _empty(xyz, B, npoint, 3)
+    _check(lib, lib.lib.ach_train_pn2_fps(_p(xyz), B, n, npoint, _p(idx), _p(new_xyz), _stream(xyz)))
+    return idx, new_xyz
+
+
+class _Pn2GroupFn(torch.autograd.Function):
+    """Ball query + grouping: rows [(b, s, k), 3 + C] = [xyz[group] - centroid | feats[group]]; the adjoint scatters the feature columns back."""
+
+    @staticmethod
+    def forward(ctx, xyz, new_xyz, feats, nsample, radius2):
+        xyz, new_xyz, feats = _f32(xyz, 'pn2_group'), _f32(new_xyz, 'pn2_group'), _f32(feats, 'pn2_group')
+        B, n, C = feats.shape
+        S = new_xyz.shape[1]
+        lib = _lib(xyz)
+        g = _empty(xyz, B * S * nsample, 3 + C)
+        gidx = torch.empty(B, S, nsample, dtype=torch.int32, device=xyz.device)
+        _check(lib, lib.lib.ach_train_pn2_group(_p(xyz), _p(new_xyz), _p(feats), C, B, n, S, nsample, float(radius2), _p(g), _p(gidx), _stream(xyz)))
+        ctx.save_for_backward(gidx)
+        ctx.dims = (B, n, C, S, nsample)
+        return g
+
+    @staticmethod
+    def backward(ctx, dg):
+        (gidx,) = ctx.saved_tensors
+        B, n, C, S, nsample = ctx.dims
+        lib = _lib(dg)
+        dg = dg.contiguous()
+        df = torch.zeros(B, n, C, dtype=torch.float32, device=dg.device)
+        _check(lib, lib.lib.ach_train_pn2_group_bwd(_p(gidx), _p(dg), _p(df), C, B, n, S, nsample, _stream(dg)))
+        return None, None, df, None, None
+
+
+def pn2_group(xyz, new_xyz, feats, nsample, radius2):
+    return _Pn2GroupFn.apply(xyz, new_xyz, feats, nsample, radius2)
+
+
+class _Pn2InterpFn(torch.autograd.Function):
+    """Feature propagation input: rows [(b, point), C1 + C2] = [skip | inverse-distance 3-NN interpolation of the sparse level's features]."""
+
+    @staticmethod
+    def forward(ctx, xyz1, xyz2, skip, sparse):
+        xyz1, xyz2, sparse = _f32(xyz1, 'pn2_interp'), _f32(xyz2, 'pn2_interp'), _f32(sparse, 'pn2_interp')
+        B, n, _ = xyz1.shape
+        s, C2 = sparse.shape[1], sparse.shape[2]
+        sk = _f32(skip, 'pn2_interp') if skip is not None else None
+        C1 = sk.shape[2] if sk is not None else 0
+        lib = _lib(xyz1)
+        out = _empty(xyz1, B * n, C1 + C2)
+        _check(lib, lib.lib.ach_train_pn2_interp(_p(xyz1), _p(xyz2), _p(sk) if sk is not None else _NULL, C1, _p(sparse), C2, _p(out), _NULL, _NULL, _NULL, B, n, s, _stream(xyz1)))
+        ctx.save_for_backward(xyz1, xyz2)
+        ctx.dims = (B, n, s, C1, C2)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        xyz1, xyz2 = ctx.saved_tensors
+        B, n, s, C1, C2 = ctx.dims
+        lib = _lib(dout)
+        dout = dout.contiguous()
+        dskip = _empty(dout, B, n, C1) if C1 else None
+        dsparse = torch.zeros(B, s, C2, dtype=torch.float32, device=dout.device)
+        _check(lib, lib.lib.ach_train_pn2_interp(_p(xyz1), _p(xyz2), _NULL, C1, _NULL, C2, _NULL, _p(dskip) if dskip is not None else _NULL, _p(dsparse), _p(dout), B, n, s, _stream(dout)))
+        return None, None, dskip, dsparse
+
+
+def pn2_interp(xyz1, xyz2, skip, sparse):
+    return _Pn2InterpFn.apply(xyz1, xyz2, skip, sparse)

@@ -37,8 +37,6 @@ MOBILEVIT = {  # backbone/vision/mobilevit_modules/mobilevit.py:225-240: channel
 
 class TrainGraph:
     def __init__(self, model):
-        if model.pc_seg_kind not in ('pn', 'none'):
-            raise NotImplementedError("training mode is built for pc_seg='pn' and for Achelous3T (PointNet++, our own specification, has no backward kernels)")
         self.m = model
         self.p = dict(model.named_parameters())
         self.b = dict(model.named_buffers())
@@ -381,12 +379,55 @@ class TrainGraph:
             x = self.shared_mlp(x, f'{p}.conv{i}', f'{p}.bn{i}')
         return _LogSoftmaxPointsFn.apply(_LinearFn.apply(x, self.P(p + '.conv4.weight'), self.P(p + '.conv4.bias')))
 
+    # ---------------------------------------------------------------------------------------------- PointNet++ (OUR OWN specification, DESIGN 5b / spec.py::PN2)
+    def rows_mlp(self, rows, conv, bn):
+        """Conv (k = 1) + BatchNorm + ReLU over ROWS [R, C]: the statistics run over all rows — BatchNorm2d over (B, centroids, samples) of a set-abstraction level,
+        BatchNorm1d over (B, points) of a propagation level — i.e. the shared MLP on [1, C, R]."""
+        return self.shared_mlp(rows.t().contiguous().unsqueeze(0), conv, bn).squeeze(0).t().contiguous()
+
+    def pointnet2(self, pts):
+        """Set abstraction x 4 (farthest-point sampling, ball query, shared MLP, max over the ball), feature propagation x 4 (3-NN interpolation + skip + shared MLP), head.
+        The reference snapshot has no PointNet++ code (nets/Achelous.py:31-32): structure, widths, radii and tie rules are spec.py::PN2's, the same ones the inference
+        engine and oracle/pointnet2_oracle.py follow; the geometry kernels ARE the inference engine's (k_pn2.h at fp32), so a training forward selects exactly the
+        points an inference forward selects."""
+        import numpy as np
+        from .spec import PN2
+        p = 'pc_seg_model'
+        B, D, N = pts.shape
+        rows = pts.transpose(1, 2).contiguous()                                   # [B, N, D]
+        levels = [(rows[:, :, :3].contiguous(), rows)]
+        for k, cfg in enumerate(PN2['sa']):
+            xyz, feats = levels[-1]
+            S, K = N // cfg['div'], cfg['nsample']
+            _, new_xyz = TF.pn2_fps(xyz, S)
+            h = TF.pn2_group(xyz, new_xyz, feats, K, float(np.float32(cfg['radius'] * cfg['radius'])))          # [B*S*K, 3 + C]
+            x = h.t().contiguous().unsqueeze(0)
+            for i in range(len(cfg['mlp'])):
+                x = self.shared_mlp(x, f'{p}.sa{k + 1}.mlp_convs.{i}', f'{p}.sa{k + 1}.mlp_bns.{i}')
+            cout = x.shape[1]
+            f = _MaxPointsFn.apply(x.view(cout, B * S, K))                       # max over the ball: [cout, B*S]
+            levels.append((new_xyz, f.t().contiguous().view(B, S, cout)))
+        cur = levels[-1][1]
+        L = len(PN2['sa'])
+        for j, widths in enumerate(PN2['fp']):                                   # fp4 .. fp1
+            lvl = L - 1 - j
+            xyz1, f1 = levels[lvl]
+            h = TF.pn2_interp(xyz1, levels[lvl + 1][0], f1 if lvl > 0 else None, cur)                           # [B*n, C1 + C2]
+            for i in range(len(widths)):
+                h = self.rows_mlp(h, f'{p}.fp{lvl + 1}.mlp_convs.{i}', f'{p}.fp{lvl + 1}.mlp_bns.{i}')
+            cur = h.view(B, xyz1.shape[1], widths[-1])
+        h = self.rows_mlp(cur.reshape(B * N, -1), p + '.conv1', p + '.bn1')
+        z = _LinearFn.apply(h.view(B, N, -1).transpose(1, 2).contiguous(), self.P(p + '.conv2.weight'), self.P(p + '.conv2.bias'))       # [B, classes, N]
+        return _LogSoftmaxPointsFn.apply(z)
+
     # ---------------------------------------------------------------------------------------------- Achelous.forward (nets/Achelous.py:49-53)
     def forward(self, x, x_radar, x_pc):
         for t in (x, x_radar, x_pc):
             if t is not None and t.dtype != torch.float32:
                 raise TypeError("training mode runs in float32")
-        pc = self.pointnet(x_pc.contiguous()) if x_pc is not None else None          # Achelous3T: no point stream
+        pc = None                                                                    # Achelous3T: no point stream
+        if x_pc is not None:
+            pc = self.pointnet2(x_pc.contiguous()) if self.m.pc_seg_kind == 'pn2' else self.pointnet(x_pc.contiguous())
         se, lane, (q5, q4, q3) = self.ghost_dual_fpn(x.contiguous())
         r3, r4, r5 = self.rcnet(x_radar.contiguous())
         det = self.head((self.fuse(q3, r3, 3), self.fuse(q4, r4, 4), self.fuse(q5, r5, 5)))

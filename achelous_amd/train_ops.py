@@ -17,8 +17,7 @@ autograd routes.  All of it as `torch.autograd.Function`s over the kernels of cs
 batch statistics; normalise + ReLU; their backward).  In training mode it normalises with the batch statistics and updates
 `running_mean` / `running_var` exactly as `nn.BatchNorm1d` does (momentum 0.1, unbiased variance into the running estimate); in eval
 mode it uses the running statistics.  Parameter names (`conv.weight [cout,cin,1]`, `conv.bias`, `bn.weight`, ...) are those of the
-torch layers it replaces.  fp32 on GPU tensors only; no PyTorch-op or CPU fallback.  `Achelous.forward` in `.train()` still raises:
-the other blocks (EdgeNeXt, GDF, RCNet, head) have no backward kernels yet.
+torch layers it replaces.  fp32 on GPU tensors only; no PyTorch-op or CPU fallback.  (`Achelous.forward` in `.train()` composes these with train_functional.py's primitives for the whole model: train_graph.py.)
 """
 import ctypes
 

@@ -295,7 +295,7 @@ int ach_resample_pass_u8(const uint8_t* src, uint8_t* dst, const int32_t* bounds
  *   ach_train_instnorm       per-row statistics (GroupNorm with one channel per group), gamma / beta index r % C; backward also returns per-row dgamma / dbeta
  *   ach_train_l2norm         y = x / max(||x||, eps) per row (F.normalize)
  *   ach_train_deform_im2col  modulated deformable 3x3 sampling (torchvision 0.12 deform_conv2d semantics): col [B][C*9][Ho*Wo]
- *   ach_train_deform_bwd     from dcol: doffset, dmask, and dx (scattered with fp32 atomics into a buffer the caller zeroed) */
+ *   ach_train_deform_bwd     from dcol: doffset, dmask, and dx (scattered with fp32 atomics into a buffer the caller zeroed; dx_zeroed = NULL skips it: an input without a gradient) */
 int ach_train_act(const float* x, const float* dy, float* out, int64_t n, int32_t kind, void* stream);
 int ach_train_mul(const float* a, const float* b, float* out, int64_t n, void* stream);      /* out = a * b element-wise */
 int ach_train_layernorm(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, int64_t rows, int32_t C, int64_t inner,
@@ -321,6 +321,21 @@ int ach_train_deform_im2col(const float* x, const float* offset, const float* ma
                             int32_t stride, int32_t pad, void* stream);
 int ach_train_deform_bwd(const float* x, const float* offset, const float* mask, const float* dcol, float* dx_zeroed, float* doffset, float* dmask, int32_t B,
                          int32_t C, int32_t H, int32_t W, int32_t Ho, int32_t Wo, int32_t stride, int32_t pad, void* stream);
+
+/* PointNet++ in training mode (achelous_amd/csrc/k_train3.h; OUR OWN specification of `pc_seg='pn2'`, DESIGN.md 5b — the reference snapshot builds only 'pn',
+ * nets/Achelous.py:31-32, and trains whatever it builds through ATen autograd, utils/utils_fit.py:37-166).  Point tensors are ROWS: xyz [B, n, 3], features [B, n, C].
+ *   ach_train_pn2_fps        farthest-point sampling (start at point 0, ties to the lowest index): idx [B, npoint], new_xyz [B, npoint, 3]
+ *   ach_train_pn2_group      ball query + grouping: grouped [B*S*nsample, 3 + C] = [xyz - centroid | features], group_idx [B, S, nsample] (first nsample in-ball
+ *                            points in index order, padded with the first)
+ *   ach_train_pn2_group_bwd  dfeats[b, group_idx, c] += dgrouped[.., 3 + c] into a buffer the caller zeroed (fp32 atomics; the xyz columns carry no gradient)
+ *   ach_train_pn2_interp     dout == NULL: out [B*n, C1 + C2] = [skip | sum_j w_j sparse[nn_j]] (3-NN, w = 1 / (d + 1e-8) normalised);
+ *                            else the adjoint: dskip [B*n, C1] and dsparse [B, s, C2] (zeroed by the caller, fp32 atomics) from dout */
+int ach_train_pn2_fps(const float* xyz, int32_t B, int32_t n, int32_t npoint, int32_t* idx, float* new_xyz, void* stream);
+int ach_train_pn2_group(const float* xyz, const float* new_xyz, const float* feats, int32_t C, int32_t B, int32_t n, int32_t S, int32_t nsample, float radius2,
+                        float* grouped, int32_t* group_idx, void* stream);
+int ach_train_pn2_group_bwd(const int32_t* group_idx, const float* dgrouped, float* dfeats_zeroed, int32_t C, int32_t B, int32_t n, int32_t S, int32_t nsample, void* stream);
+int ach_train_pn2_interp(const float* xyz1, const float* xyz2, const float* skip, int32_t C1, const float* sparse, int32_t C2, float* out, float* dskip, float* dsparse_zeroed,
+                         const float* dout, int32_t B, int32_t n, int32_t s, void* stream);
 
 #ifdef __cplusplus
 }

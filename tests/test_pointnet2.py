@@ -232,3 +232,130 @@ def test_gpu_pn2_batch_64_frames_match_the_self_oracle(dtype, tol):
             assert torch.equal(a[pick].cpu().reshape(b.shape), b.float()), tap
             checked += 1
     assert checked >= 8
+
+
+# ------------------------------------------------------------------------------------------------ training mode (round 5)
+def _pn2_autograd_reference(sd, pts, cot, dtype):
+    """The specification's graph in TRAINING mode through torch autograd: index selection by the numpy oracle's own functions (fp32, the rules of DESIGN 5b), every
+    differentiable operation a torch op in `dtype`, BatchNorm on batch statistics.  -> (log-probabilities [B, N, classes], {parameter: gradient})."""
+    import torch.nn.functional as F
+    P = {k: v.detach().to(dtype).requires_grad_(True) for k, v in sd.items() if k.startswith('pc_seg_model.') and v.is_floating_point() and 'running' not in k}
+
+    def mlp(rows, conv, bn):
+        w = P[conv + '.weight']
+        y = rows @ w.reshape(w.shape[0], -1).t() + P[conv + '.bias']
+        return torch.relu(F.batch_norm(y, None, None, P[bn + '.weight'], P[bn + '.bias'], True, 0.1, 1e-5))
+
+    B, D, N = pts.shape
+    rows = pts.transpose(1, 2).to(dtype)                                       # [B, N, D]
+    xyz = [[np.ascontiguousarray(rows[b, :, :3].float().numpy()) for b in range(B)]]
+    feats = [rows]
+    p = 'pc_seg_model'
+    for k, cfg in enumerate(po.PN2['sa']):
+        S, K = N // cfg['div'], cfg['nsample']
+        new_xyz, groups = [], []
+        for b in range(B):
+            fps = po.farthest_point_sample(xyz[-1][b], S)
+            nx = xyz[-1][b][fps]
+            idx = torch.from_numpy(po.ball_query(cfg['radius'], K, xyz[-1][b], nx).astype(np.int64))
+            rel = torch.from_numpy(xyz[-1][b][idx.numpy()] - nx[:, None, :]).to(dtype)      # fp32 differences, as the kernel forms them
+            groups.append(torch.cat([rel, feats[-1][b][idx]], -1))                       # [S, K, 3 + C]
+            new_xyz.append(nx)
+        h = torch.stack(groups).reshape(B * S * K, -1)
+        for i in range(len(cfg['mlp'])):
+            h = mlp(h, f'{p}.sa{k + 1}.mlp_convs.{i}', f'{p}.sa{k + 1}.mlp_bns.{i}')
+        feats.append(h.reshape(B, S, K, -1).max(2).values)
+        xyz.append(new_xyz)
+    cur = feats[-1]
+    L = len(po.PN2['sa'])
+    for j, widths in enumerate(po.PN2['fp']):
+        lvl = L - 1 - j
+        outs = []
+        for b in range(B):
+            idx, w = po.three_nn_weights(xyz[lvl][b], xyz[lvl + 1][b])
+            idx, w = torch.from_numpy(idx.astype(np.int64)), torch.from_numpy(w).to(dtype)
+            interp = (w[:, 0:1] * cur[b][idx[:, 0]] + w[:, 1:2] * cur[b][idx[:, 1]]) + w[:, 2:3] * cur[b][idx[:, 2]]
+            outs.append(interp if lvl == 0 else torch.cat([feats[lvl][b], interp], -1))
+        h = torch.stack(outs).reshape(B * len(xyz[lvl][0]), -1)
+        for i in range(len(widths)):
+            h = mlp(h, f'{p}.fp{lvl + 1}.mlp_convs.{i}', f'{p}.fp{lvl + 1}.mlp_bns.{i}')
+        cur = h.reshape(B, len(xyz[lvl][0]), -1)
+    h = mlp(cur.reshape(B * N, -1), p + '.conv1', p + '.bn1')
+    w = P[p + '.conv2.weight']
+    y = torch.log_softmax(h @ w.reshape(w.shape[0], -1).t() + P[p + '.conv2.bias'], -1).reshape(B, N, -1)
+    (y * cot.to(dtype)).sum().backward()
+    return y.detach().double(), {k: v.grad.double() for k, v in P.items() if v.grad is not None}
+
+
+def _check_pn2_training(dev, B=2, npts=384):
+    from achelous_amd.train_graph import TrainGraph
+    sd = _state_dict()
+    m = achelous_amd.Achelous(**{**KW, 'resolution': 64})
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dev).train()
+    _, _, xp = make_inputs(B, 7, resolution=64, num_points=npts, pc_channels=5, radar_cells=40)
+    pc = TrainGraph(m).pointnet2(xp.to(dev))
+    g = torch.Generator().manual_seed(2)
+    cot = torch.randn(pc.shape, generator=g)
+    (pc * cot.to(dev)).sum().backward()
+    ref, rg = _pn2_autograd_reference(sd, xp, cot, torch.float64)
+    _, yg = _pn2_autograd_reference(sd, xp, cot, torch.float32)                 # torch's own float32 evaluation: the yardstick
+    assert pc.shape == (B, npts, 8) and _rel(pc.detach().cpu().float(), ref.float()) < 2e-4
+    gscale = max(float(v.abs().max()) for v in rg.values())
+    seen = 0
+    for k, p_ in m.named_parameters():
+        if not k.startswith('pc_seg_model.'):
+            continue
+        assert p_.grad is not None and k in rg, k
+        got, want = p_.grad.detach().cpu().double(), rg[k].reshape(p_.shape)
+        err = float((got - want).norm() / (want.norm() + 1e-300))
+        yard = float((yg[k].reshape(p_.shape) - want).norm() / (want.norm() + 1e-300))
+        # (a bias in front of a training-mode BatchNorm has a TRUE gradient of zero: rounding noise on both sides)
+        assert err < max(2e-3, 8 * yard) or float((got - want).abs().max()) <= 2e-6 * gscale, (k, err, yard)
+        seen += 1
+    assert seen == sum(1 for k, _ in m.named_parameters() if k.startswith('pc_seg_model.')) and seen >= 80
+    for k, v in m.named_buffers():
+        if k.startswith('pc_seg_model.') and k.endswith('num_batches_tracked'):
+            assert int(v) == 1, k
+
+
+def test_emulated_pn2_training_branch_matches_autograd():
+    """`pc_seg='pn2'` in `.train()` (round 5: it used to raise): log-probabilities and the gradient of every parameter of the branch against torch autograd (float64)
+    on the specification's graph with the oracle's index selection — SELF-ORACLE, parity unpinned, like the branch's forward."""
+    from achelous_amd import train_ops
+    from emu_util import emu_library
+    train_ops._lib.test_library = emu_library()
+    try:
+        _check_pn2_training('cpu')
+    finally:
+        train_ops._lib.test_library = None
+
+
+@pytest.mark.gpu
+def test_gpu_pn2_training_branch_matches_autograd():
+    _check_pn2_training('cuda', B=4, npts=512)
+
+
+@pytest.mark.gpu
+def test_gpu_pn2_model_trains_end_to_end():
+    """The whole EN-GDF-PN2-S0 model steps in training mode: finite loss, gradients for the branch, BatchNorm statistics updated, and `.eval()` afterwards runs the
+    inference engine on the updated weights."""
+    m = achelous_amd.Achelous(**{**KW, 'resolution': 96})
+    m.load_state_dict(_state_dict(), strict=True)
+    m = m.cuda().train()
+    x, xr, xp = (t.cuda() for t in make_inputs(2, 5, resolution=96, num_points=384, pc_channels=5, radar_cells=12))
+    opt = torch.optim.SGD(m.parameters(), lr=1e-3)
+    before = m.state_dict()['pc_seg_model.sa1.mlp_bns.0.running_mean'].clone()
+    for _ in range(2):
+        det, se, lane, pc = m(x, xr, xp)
+        loss = sum((o ** 2).mean() for o in (*det, se, lane, pc))
+        assert torch.isfinite(loss)
+        opt.zero_grad()
+        loss.backward()
+        assert m.get_parameter('pc_seg_model.fp1.mlp_convs.0.weight').grad.abs().max() > 0
+        opt.step()
+    assert not torch.equal(before, m.state_dict()['pc_seg_model.sa1.mlp_bns.0.running_mean'])
+    m.eval()
+    with torch.no_grad():
+        pc_eval = m(x, xr, xp)[3]
+    assert pc_eval.shape == (2, 384, 8) and torch.isfinite(pc_eval.float()).all()
