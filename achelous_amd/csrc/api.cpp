@@ -475,7 +475,11 @@ int ach_train_dwconv(const float* x, const float* w, const float* bias, float* y
     return train_guard([&] {
         train_need(x && w && y && B > 0 && C > 0 && H > 0 && W > 0 && k > 0 && (k & 1), "ach_train_dwconv");
         ach::TrainDwParams p{x, w, bias, y, B, C, H, W, k, flip};
-        ACH_TRAIN_1D(ach::train_dwconv_kernel, p, long(B) * C * H * W);
+        if (k == 3) ACH_TRAIN_1D(ach::train_dwconv_kernel<3>, p, long(B) * C * H * W);
+        else if (k == 5) ACH_TRAIN_1D(ach::train_dwconv_kernel<5>, p, long(B) * C * H * W);
+        else if (k == 7) ACH_TRAIN_1D(ach::train_dwconv_kernel<7>, p, long(B) * C * H * W);
+        else if (k == 9) ACH_TRAIN_1D(ach::train_dwconv_kernel<9>, p, long(B) * C * H * W);
+        else ACH_TRAIN_1D(ach::train_dwconv_kernel<0>, p, long(B) * C * H * W);
     });
 }
 int ach_train_dwconv_wgrad(const float* x, const float* dz, float* dw, int32_t B, int32_t C, int32_t H, int32_t W, int32_t k, void* stream) {
@@ -591,10 +595,9 @@ int ach_train_deform_bwd(const float* x, const float* offset, const float* mask,
         train_need(x && offset && mask && dcol && doffset && dmask && B > 0 && C > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && stride > 0, "ach_train_deform_bwd");
         ach::TrainDeformParams p{x, offset, mask, nullptr, dcol, dx_zeroed, doffset, dmask, B, C, H, W, Ho, Wo, stride, pad};
         ACH_TRAIN_1D(ach::train_deform_bwd_coord_kernel, p, long(B) * 9 * Ho * Wo);
-        if (dx_zeroed && stride == 1) {          // adds combined in LDS per 16 x 16 tile of positions (k_train2.h); NULL: the input needs no gradient (the first RCBlock reads the pooled radar map)
-            const long tiles = long((Wo + ach::DBI_T - 1) / ach::DBI_T) * ((Ho + ach::DBI_T - 1) / ach::DBI_T);
-            ACH_LAUNCH(ach::train_deform_bwd_input_tile_kernel, dim3(unsigned(tiles * B)), dim3(256), static_cast<hipStream_t>(stream), p);
-        } else if (dx_zeroed) ACH_TRAIN_1D(ach::train_deform_bwd_input_kernel, p, long(B) * C * 9 * Ho * Wo);
+        // (dx_zeroed = NULL: the input needs no gradient — the first RCBlock reads the pooled radar map.  An LDS-combining form of this scatter — a workgroup per 16 x 16 tile of
+        //  positions, LDS atomics, one L2 atomic per touched input pixel instead of 36 per position — was measured 4x SLOWER end to end (batch-32 step 64.5 -> 86.7 ms) and is not kept.)
+        if (dx_zeroed) ACH_TRAIN_1D(ach::train_deform_bwd_input_kernel, p, long(B) * C * 9 * Ho * Wo);
     });
 }
 // ---- PointNet++ in training mode (k_train3.h): the inference engine's geometry kernels at fp32 + the two scatter-form adjoints

@@ -146,7 +146,8 @@ public:
     int head_fuse_dbg = 0;            // option "head_fuse_dbg": phase-kill timing experiments on the fused head layer (results are wrong)
     bool head_fuse = true;            // option "head_fuse": bf16, 64-wide towers — a head layer's depthwise 5x5 + pointwise conv as one launch (k_headdw.h); needs head_batch
     bool head_batch = true;           // option "head_batch": each detection-head layer as one launch for the three pyramid levels
-    int point_on_head_stream = -1;    // option "point_stream2" (-1 auto / 0 / 1): the point branch opens stream 2 (ahead of fusion + head) instead of queueing behind the radar branch
+    int point_on_head_stream = -1;    // option "point_stream2" (-1 auto / 0 / 1 / 3): the point branch opens stream 2 (ahead of fusion + head) instead of queueing behind the radar branch;
+                                      // 3 (round 5): a stream of its own — the process's FOURTH active stream, i.e. none left for a collective's (section 4.10): single-GPU serving only
     bool stem_mfma = true;            // option "stem_mfma": the 4x4/s4 stem conv as an MFMA GEMM gathered from the NCHW image
     bool dw_tile = true;              // option "dw_tile": LDS-tiled depthwise kernel on the 10x10 maps
     bool fuse_rc = true;              // option "fused_rc": RCBlock conv + deformable sampling + contraction as one launch (k_conv3.h)

@@ -2150,7 +2150,7 @@ public:
         //  frames/s; the plain plan keeps PointNet on stream 1 ahead of the radar branch — two streams in all: 26.35 k against 25.95 k)
         const bool point2 = point_on_head_stream < 0 ? (cfg.pc_seg == ACH_PCSEG_PN2 || (!head_stream && pipeline)) : point_on_head_stream != 0;
         const bool radar_late = radar_start_eff() >= 0 && multi_stream;
-        auto points = [&] { cur_stream = point2 ? 2 : 1; if (cfg.pc_seg == ACH_PCSEG_PN2) pointnet2(); else if (cfg.pc_seg == ACH_PCSEG_PN) pointnet(); };   // ACH_PCSEG_NONE: Achelous3T
+        auto points = [&] { cur_stream = point_on_head_stream == 3 ? 3 : (point2 ? 2 : 1); if (cfg.pc_seg == ACH_PCSEG_PN2) pointnet2(); else if (cfg.pc_seg == ACH_PCSEG_PN) pointnet(); };   // ACH_PCSEG_NONE: Achelous3T
         if (radar_late) points();         // the point branch (small launches) fills the window before the radar branch is released
         cur_stream = 1;
         if (radar_late) wait_before_next(0);

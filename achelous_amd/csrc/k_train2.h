@@ -108,6 +108,9 @@ static __global__ __launch_bounds__(256) void train_ln_bwd_param_kernel(const Tr
 // ------------------------------------------------------------------------------------------ depthwise k x k, stride 1, pad k/2
 // x [B,C,H,W], w [C,k*k]; flip mirrors the taps (the input gradient of the same layer); bias optional
 struct TrainDwParams { const float* x; const float* w; const float* bias; float* y; int B, C, H, W, k, flip; };
+// KT > 0: the kernel size as a compile-time constant (3 / 5 / 7 / 9: every depthwise layer of the model) — the tap loops unroll, a row's bounds test is hoisted, the taps' addresses
+// are constant offsets; KT = 0: any odd k at run time.  (The run-time form was 6 % of a batch-32 training step.)
+template <int KT>
 static __global__ __launch_bounds__(256) void train_dwconv_kernel(const TrainDwParams p) {
     const long i = long(blockIdx.x) * 256 + threadIdx.x;
     const long total = long(p.B) * p.C * p.H * p.W;
@@ -115,16 +118,32 @@ static __global__ __launch_bounds__(256) void train_dwconv_kernel(const TrainDwP
     const long row = tdiv(i, p.W), pl = tdiv(row, p.H);
     const int ox = int(i - row * p.W), oy = int(row - pl * p.H), c = int(pl - tdiv(pl, p.C) * p.C);
     const float* xp = p.x + (i - long(oy) * p.W - ox);
-    const float* w = p.w + long(c) * p.k * p.k;
-    const int r = p.k / 2;
+    const int k = KT > 0 ? KT : p.k;
+    const float* w = p.w + long(c) * k * k;
+    const int r = k / 2;
     float acc = p.bias ? p.bias[c] : 0.f;
-    for (int ky = 0; ky < p.k; ++ky) {
+    if constexpr (KT > 0) {
+        ACH_UNROLL
+        for (int ky = 0; ky < KT; ++ky) {
+            const int iy = oy + ky - r;
+            if (iy < 0 || iy >= p.H) continue;
+            const float* xr = xp + long(iy) * p.W;
+            ACH_UNROLL
+            for (int kx = 0; kx < KT; ++kx) {
+                const int ix = ox + kx - r;
+                const float wv = w[p.flip ? (KT - 1 - ky) * KT + (KT - 1 - kx) : ky * KT + kx];
+                const float xv = xr[ix < 0 ? 0 : (ix >= p.W ? p.W - 1 : ix)];             // unconditional load from a clamped address, then a select (no divergence at the map's edges)
+                acc += ((ix >= 0 && ix < p.W) ? xv : 0.f) * wv;
+            }
+        }
+    } else
+    for (int ky = 0; ky < k; ++ky) {
         const int iy = oy + ky - r;
         if (iy < 0 || iy >= p.H) continue;
-        for (int kx = 0; kx < p.k; ++kx) {
+        for (int kx = 0; kx < k; ++kx) {
             const int ix = ox + kx - r;
             if (ix < 0 || ix >= p.W) continue;
-            const int t = p.flip ? (p.k - 1 - ky) * p.k + (p.k - 1 - kx) : ky * p.k + kx;
+            const int t = p.flip ? (k - 1 - ky) * k + (k - 1 - kx) : ky * k + kx;
             acc += xp[long(iy) * p.W + ix] * w[t];
         }
     }
@@ -517,65 +536,6 @@ static __global__ __launch_bounds__(256) void train_deform_bwd_input_kernel(cons
     for (int q = 0; q < 4; ++q) {
         const int y = y0 + (q >> 1), x = x0 + (q & 1);
         if (y >= 0 && y < p.H && x >= 0 && x < p.W) train_atomic_add(dimg + long(y) * p.W + x, g * wts[q]);
-    }
-}
-
-// Round 5: the same scatter with the adds COMBINED IN LDS first (stride 1, every RCBlock).  A workgroup owns a 16 x 16 tile of output positions of one sample; per channel it
-// accumulates the 9 x 4 corner contributions of its positions into an LDS tile of the input plane (the output tile + a halo of DBI_R pixels: offsets are a few pixels; LDS atomics),
-// then adds the tile's non-zero cells to dx — one L2 atomic per touched input pixel instead of 36 per output position (the kernel above: 354 M L2 atomics for the 160 x 160 block
-// at batch 32, 2.6 ms).  A corner outside the LDS tile (a far offset) goes to dx directly, so any offset is handled.  The tap geometry (corner, four modulated weights) is computed
-// once per position and kept in registers across the channel loop.  Same sums in another order.
-constexpr int DBI_T = 16, DBI_R = 8, DBI_W = DBI_T + 2 * DBI_R + 2;
-static __global__ __launch_bounds__(256) void train_deform_bwd_input_tile_kernel(const TrainDeformParams p) {
-    __shared__ float tile[DBI_W][DBI_W + 1];
-    const int tid = threadIdx.x;
-    const int tiles_x = (p.Wo + DBI_T - 1) / DBI_T, tiles_y = (p.Ho + DBI_T - 1) / DBI_T;
-    const int tx = int(blockIdx.x % unsigned(tiles_x)), ty = int((blockIdx.x / unsigned(tiles_x)) % unsigned(tiles_y));
-    const long b = long(blockIdx.x / (unsigned(tiles_x) * unsigned(tiles_y)));
-    const int ox = tx * DBI_T + (tid & 15), oy = ty * DBI_T + (tid >> 4);
-    const bool live = ox < p.Wo && oy < p.Ho;
-    const long O = long(p.Ho) * p.Wo, o = long(oy) * p.Wo + ox;
-    const int iy0 = ty * DBI_T - p.pad - DBI_R, ix0 = tx * DBI_T - p.pad - DBI_R;          // input pixel of tile[0][0]  (stride 1)
-    int cy[9], cx[9]; float w[9][4]; bool on[9];
-    ACH_UNROLL
-    for (int k = 0; k < 9; ++k) {
-        on[k] = false; cy[k] = cx[k] = 0; w[k][0] = w[k][1] = w[k][2] = w[k][3] = 0.f;
-        if (!live) continue;
-        const float py = float(oy - p.pad + k / 3) + p.offset[(b * 18 + 2 * k) * O + o];
-        const float px = float(ox - p.pad + k % 3) + p.offset[(b * 18 + 2 * k + 1) * O + o];
-        if (!(py > -1.f && px > -1.f && py < float(p.H) && px < float(p.W))) continue;
-        const float m = p.mask[(b * 9 + k) * O + o];
-        const int y0 = int(floorf(py)), x0 = int(floorf(px));
-        const float ly = py - float(y0), lx = px - float(x0), hy = 1.f - ly, hx = 1.f - lx;
-        on[k] = true; cy[k] = y0; cx[k] = x0;
-        w[k][0] = hy * hx * m; w[k][1] = hy * lx * m; w[k][2] = ly * hx * m; w[k][3] = ly * lx * m;
-    }
-    for (int ci = 0; ci < p.C; ++ci) {
-        for (int e = tid; e < DBI_W * DBI_W; e += 256) tile[e / DBI_W][e % DBI_W] = 0.f;
-        __syncthreads();
-        float* dimg = p.dx + (b * p.C + ci) * long(p.H) * p.W;
-        ACH_UNROLL
-        for (int k = 0; k < 9; ++k) {
-            if (!on[k]) continue;
-            const float g = p.dcol[((b * p.C + ci) * 9 + k) * O + o];
-            ACH_UNROLL
-            for (int q = 0; q < 4; ++q) {
-                const int y = cy[k] + (q >> 1), x = cx[k] + (q & 1);
-                if (y < 0 || y >= p.H || x < 0 || x >= p.W) continue;
-                // (the modulation is folded into w: g * mask * corner weight, the product the per-element kernel forms as (dcol * mask) * weight — one rounding apart)
-                const int ty_ = y - iy0, tx_ = x - ix0;
-                if (ty_ >= 0 && ty_ < DBI_W && tx_ >= 0 && tx_ < DBI_W) atomicAdd(&tile[ty_][tx_], g * w[k][q]);
-                else train_atomic_add(dimg + long(y) * p.W + x, g * w[k][q]);
-            }
-        }
-        __syncthreads();
-        for (int e = tid; e < DBI_W * DBI_W; e += 256) {
-            const int r = e / DBI_W, c = e % DBI_W;
-            const float v = tile[r][c];
-            const int y = iy0 + r, x = ix0 + c;
-            if (v != 0.f && y >= 0 && y < p.H && x >= 0 && x < p.W) train_atomic_add(dimg + long(y) * p.W + x, v);
-        }
-        __syncthreads();
     }
 }
 

@@ -131,7 +131,10 @@ int ach_load_weights(ach_handle* h, const ach_tensor_desc* tensors, size_t n);
  * (k_csphead.h), the last one with the segmentation head in it; 1: the last level + head only; 0: layer-wise), "csp_band" (rows per band of those launches, default
  * 40), "head_lds_pad" (default 0: bytes of unused dynamic LDS per workgroup of the Ghost-FPN row-walking head = an occupancy cap; every cap measured slower);
  * "ffn_rows2" (default 1: MobileViT's feed-forward layers on the large maps with two 16-row tiles per wave; bit-identical), "mlp_band_run" (default 0: a stage's
- * band-kernel ConvEncoder blocks as one persistent launch with per-frame barriers; bit-identical, measured no faster);
+ * band-kernel ConvEncoder blocks as one persistent launch with per-frame barriers; bit-identical, measured no faster), "dec_fork" (pipelined plan: where the
+ * segmentation decoders leave the caller's stream — 1, default: in front of the shared ShuffleAttention stage (+0.9 %), 0: behind it (round 3), 2: as soon as the
+ * neck's p3 exists, 3: the whole neck on stream 2, ordered against the next forward's backbone by a third cross-forward event (EdgeNeXt plans; level with 1);
+ * bit-identical);
  * "pipeline" (see ach_join).  DESIGN.md §4 has the measurement behind every default. */
 int ach_set_option(ach_handle* h, const char* key, int32_t value);
 

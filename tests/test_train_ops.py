@@ -17,40 +17,39 @@ def _reference(cin, cout, relu, seed):
 
 
 def _run(dev, B, cin, cout, N, relu, seed=0):
-    """Truth = the torch layers in float64.  The native layer (fp32 kernels) is held to 2e-4 of each tensor's scale OR to four times the error torch's own float32 evaluation of the
-    same layers makes against that truth: where a BatchNorm output lies within rounding of zero the ReLU mask — and with it one whole term of dbeta / dgamma / dW / dx — depends on the
-    summation ORDER of the convolution (33 M outputs at the largest GPU case: a few dozen such elements), for torch's float32 kernels exactly as for ours."""
+    """Truth = the torch layers in float64, with ONE concession that makes the comparison well-posed: where a BatchNorm output lies within rounding of zero, on which side of it a
+    float32 evaluation lands — and with that one whole term of dbeta / dgamma / dW / dx — depends on the summation order of the convolution (33 M outputs in the largest GPU case:
+    a handful of such elements, in torch's own float32 kernels as much as in ours).  The truth's backward therefore uses the native layer's ReLU mask, after checking that the two
+    masks differ only at elements whose true pre-activation is at rounding distance from zero."""
     layer = train_ops.SharedMLP1d(cin, cout, relu=relu)
     g = torch.Generator().manual_seed(seed + 1)
     x = torch.randn(B, cin, N, generator=g)
     dy = torch.randn(B, cout, N, generator=g)
-
-    def torch_run(dtype):
-        conv, bn = _reference(cin, cout, relu, seed)
-        conv, bn = conv.to(dtype).train(), bn.to(dtype).train()
-        xr = x.clone().to(dtype).requires_grad_(True)
-        yr = bn(conv(xr))
-        yr = torch.relu(yr) if relu else yr
-        yr.backward(dy.to(dtype))
-        return conv, bn, {'y': yr.detach(), 'dx': xr.grad, 'dW': conv.weight.grad, 'dgamma': bn.weight.grad, 'dbeta': bn.bias.grad, 'running_mean': bn.running_mean, 'running_var': bn.running_var}
-
-    conv, bn, truth = torch_run(torch.float64)
-    conv32, _, yard = torch_run(torch.float32)
     layer.conv.load_state_dict(_reference(cin, cout, relu, seed)[0].state_dict()); layer.bn.load_state_dict(_reference(cin, cout, relu, seed)[1].state_dict())
     layer = layer.to(dev).train()
     xn = x.clone().to(dev).requires_grad_(True)
     yn = layer(xn)
     yn.backward(dy.to(dev))
+    conv, bn = _reference(cin, cout, relu, seed)
+    conv, bn = conv.double().train(), bn.double().train()
+    xr = x.clone().double().requires_grad_(True)
+    pre = bn(conv(xr))
+    if relu:
+        mask = yn.detach().cpu() > 0
+        diff = mask != (pre.detach() > 0)
+        assert int(diff.sum()) <= max(2, int(2e-6 * diff.numel())) and (not diff.any() or float(pre.detach()[diff].abs().max()) < 2e-5), (int(diff.sum()), diff.numel())
+        yr = pre * mask.double()
+    else:
+        yr = pre
+    yr.backward(dy.double())
+    truth = {'y': yr.detach(), 'dx': xr.grad, 'dW': conv.weight.grad, 'dgamma': bn.weight.grad, 'dbeta': bn.bias.grad, 'running_mean': bn.running_mean, 'running_var': bn.running_var}
     ours = {'y': yn, 'dx': xn.grad, 'dW': layer.conv.weight.grad, 'dgamma': layer.bn.weight.grad, 'dbeta': layer.bn.bias.grad,
             'running_mean': layer.bn.running_mean, 'running_var': layer.bn.running_var}
     rel = lambda a, b: ((a.detach().cpu().double() - b.detach().double()).abs().max() / (b.detach().double().abs().max() + 1e-12)).item()
     errs = {k: rel(ours[k], truth[k]) for k in truth}
-    yerr = {k: rel(yard[k], truth[k]) for k in truth}
-    for k in errs:
-        assert errs[k] < max(2e-4, 4 * yerr[k]), (k, errs, yerr)
-    assert errs['y'] < 2e-5 and errs['running_mean'] < 2e-5 and errs['running_var'] < 2e-5, errs          # (no mask in these)
+    assert max(errs.values()) < 2e-4, errs
     # the conv bias feeds a training-mode BatchNorm: its true gradient is rounding noise around zero
-    assert layer.conv.bias.grad.abs().max().item() == 0.0 and conv32.bias.grad.abs().max().item() < 1e-3 * dy.abs().sum().item()
+    assert layer.conv.bias.grad.abs().max().item() == 0.0 and conv.bias.grad.abs().max().item() < 1e-6 * dy.abs().sum().item()
     assert int(layer.bn.num_batches_tracked) == 1
     return errs
 
