@@ -98,6 +98,7 @@ int ach_set_option(ach_handle* h, const char* key, int32_t value) {
         else if (std::string(key) == "head_lds_pad") h->eng->head_lds_pad = value < 0 ? 0 : (value > 65536 ? 65536 : value);
         else if (std::string(key) == "head_stream") h->eng->head_stream = value != 0;
         else if (std::string(key) == "split_decoders") h->eng->split_decoders = value;
+        else if (std::string(key) == "group_max") h->eng->group_max = value < 0 ? 0 : value;
         else if (std::string(key) == "dec_fork") h->eng->dec_fork = value < 0 ? 0 : (value > 3 ? 3 : value);
         else if (std::string(key) == "radar_start") h->eng->radar_start = value;
         else if (std::string(key) == "pipeline") h->eng->pipeline = value != 0;

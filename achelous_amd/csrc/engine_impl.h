@@ -1969,6 +1969,17 @@ public:
         const dim3 grid(unsigned(pk.nchunks) * unsigned(B)), block(256);
         const int NT = pk.NT;
         const double bytes = double(x.rows) * pk.K * sizeof(T) + double(pk.group_elems) * sizeof(T) + double(B) * pk.N * sizeof(T);
+        // many small groups (PointNet++'s balls): a wave per group instead of a workgroup per group (k_gemm.h gemm_groupmax_kernel; option "group_max", bit-identical)
+        if (group_max > 0 && NT == 4 && g.M_per_group <= 64 && B >= group_max) {
+            const dim3 gridg(unsigned(pk.nchunks) * unsigned(cdiv(B, 4 * GMAX_PER_WAVE)));
+            add_op(name, [g, gridg, block](hipStream_t s) {
+                if (g.ksteps == 1) ACH_LAUNCH((gemm_groupmax_kernel<T, 4, 1>), gridg, block, s, g);
+                else if (g.ksteps == 2) ACH_LAUNCH((gemm_groupmax_kernel<T, 4, 2>), gridg, block, s, g);
+                else if (g.ksteps == 4) ACH_LAUNCH((gemm_groupmax_kernel<T, 4, 4>), gridg, block, s, g);
+                else ACH_LAUNCH((gemm_groupmax_kernel<T, 4, 0>), gridg, block, s, g);
+            }, bytes, 2.0 * double(x.rows) * pk.K * pk.N);
+            return y;
+        }
         add_op(name, [g, grid, block, NT](hipStream_t s) {
             if (NT == 1) ACH_LAUNCH((gemm_colmax_kernel<T, 1, 0>), grid, block, s, g);
             else if (NT == 2) ACH_LAUNCH((gemm_colmax_kernel<T, 2, 0>), grid, block, s, g);

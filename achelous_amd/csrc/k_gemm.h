@@ -500,6 +500,90 @@ __global__ ACH_COLMAX_BOUNDS void gemm_colmax_kernel(const GemmMaxParams p) { f1
     }
 }
 
+// The same layer for MANY SMALL groups (PointNet++: the max over the 32 samples of a ball, 16 384 balls at the first level of a batch of 64).  gemm_colmax_kernel gives every
+// (group, chunk) a four-wave workgroup — two of the four waves have no rows, every workgroup fetches the chunk's weights and meets at a barrier for 32 rows of work: 56 us for a
+// 2 GFLOP layer (round 5: profiles/r05_ops_en_s0_pn2.json), launch-rate bound.  Here a WAVE owns whole groups — GMAX_PER_WAVE consecutive groups of one chunk, the chunk's
+// weight fragments fetched once per wave (registers for KH k-steps, L1 otherwise), a group's row tiles walked in order, the 16 rows of a tile reduced by DPP row operations,
+// nothing through LDS, no barrier.  Per row the same MFMA sequence, bias and activation as gemm_colmax_kernel and a maximum is order-independent: bit-identical outputs.
+constexpr int GMAX_PER_WAVE = 4;
+template <class T, int NT, int KH>
+__global__ __launch_bounds__(256) void gemm_groupmax_kernel(const GemmMaxParams p) { f16_sat_mode<T>();
+    constexpr int VEC = Store<T>::VEC;
+    constexpr int KC = 4 * VEC;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int px = lane & 15, g = lane >> 4;
+    const unsigned wgid = blockIdx.x;
+    const int c = int(wgid % unsigned(p.nchunks));
+    const long grp0 = (long(wgid / unsigned(p.nchunks)) * 4 + wave) * GMAX_PER_WAVE;
+    if (grp0 >= p.groups) return;                                     // whole waves leave; no barrier below
+    const uint4* Wf = reinterpret_cast<const uint4*>(p.W) + long(c) * p.ksteps * NT * 64 + lane;
+    float bv[4 * NT];
+    ACH_UNROLL
+    for (int t = 0; t < NT; ++t)
+        ACH_UNROLL
+        for (int r = 0; r < 4; ++r) { const int n = c * (16 * NT) + chunk_channel(NT, t, g, r); bv[t * 4 + r] = n < p.N ? p.bias[n] : 0.f; }
+    uint4 wh[KH > 0 ? KH : 1][NT];
+    if (KH > 0) {
+        ACH_UNROLL
+        for (int s = 0; s < KH; ++s)
+            ACH_UNROLL
+            for (int t = 0; t < NT; ++t) wh[s][t] = Wf[(s * NT + t) * 64];
+    }
+    for (int gi = 0; gi < GMAX_PER_WAVE; ++gi) {
+        const long grp = grp0 + gi;
+        if (grp >= p.groups) break;
+        const T* X = static_cast<const T*>(p.X) + grp * p.M_per_group * p.ldx;
+        float cm[4 * NT];
+        ACH_UNROLL
+        for (int e = 0; e < 4 * NT; ++e) cm[e] = -3.0e38f;
+        for (int r0 = 0; r0 < p.M_per_group; r0 += 16) {
+            const int row = r0 + px;
+            const bool valid = row < p.M_per_group;
+            f32x4 acc[NT];
+            ACH_UNROLL
+            for (int t = 0; t < NT; ++t) { acc[t][0] = 0.f; acc[t][1] = 0.f; acc[t][2] = 0.f; acc[t][3] = 0.f; }
+            if (KH > 0) {
+                uint4 xf[KH > 0 ? KH : 1];
+                ACH_UNROLL
+                for (int s = 0; s < KH; ++s) {
+                    const int k0 = s * KC + g * VEC;
+                    xf[s] = (valid && k0 < p.K) ? *reinterpret_cast<const uint4*>(X + long(row) * p.ldx + k0) : make_uint4(0u, 0u, 0u, 0u);
+                }
+                ACH_UNROLL
+                for (int s = 0; s < KH; ++s)
+                    ACH_UNROLL
+                    for (int t = 0; t < NT; ++t) mfma16<T>(wh[s][t], xf[s], acc[t]);
+            } else
+            for (int s = 0; s < p.ksteps; ++s) {
+                const int k0 = s * KC + g * VEC;
+                uint4 xf = make_uint4(0u, 0u, 0u, 0u);
+                if (valid && k0 < p.K) xf = *reinterpret_cast<const uint4*>(X + long(row) * p.ldx + k0);
+                ACH_UNROLL
+                for (int t = 0; t < NT; ++t) mfma16<T>(Wf[(s * NT + t) * 64], xf, acc[t]);
+            }
+            if (valid) {
+                float av[4 * NT];
+                ACH_UNROLL
+                for (int t = 0; t < NT; ++t)
+                    ACH_UNROLL
+                    for (int r = 0; r < 4; ++r) av[t * 4 + r] = acc[t][r] + bv[t * 4 + r];
+                apply_act_n<float, 4 * NT>(av, p.act);
+                ACH_UNROLL
+                for (int e = 0; e < 4 * NT; ++e) cm[e] = fmaxf(cm[e], av[e]);
+            }
+        }
+        T* Y = static_cast<T*>(p.Y) + grp * p.ldy + c * (16 * NT);
+        ACH_UNROLL
+        for (int t = 0; t < NT; ++t)
+            ACH_UNROLL
+            for (int r = 0; r < 4; ++r) {
+                const float m = row16_max(cm[t * 4 + r]);
+                const int n = chunk_channel(NT, t, g, r);
+                if (px == 0 && c * (16 * NT) + n < p.N) Store<T>::st(Y + n, m);
+            }
+    }
+}
+
 template <class T>
 inline void launch_gemm(const GemmParams& p, int NT, int P, hipStream_t stream) {
     const dim3 grid(unsigned(cdivl(p.M_per_group, 64L * P)), unsigned(p.groups), unsigned(cdiv(p.nchunks, p.chunks_per_block))), block(256);

@@ -155,6 +155,27 @@ __global__ __launch_bounds__(256) void pn2_group_kernel(const GroupParams p) { f
     const T* feats = static_cast<const T*>(p.feats) + b * p.n * p.ldf;
     T* out = static_cast<T*>(p.out) + cent * p.nsample * p.ldo;
     const int ldo = int(p.ldo), total = p.nsample * ldo;         // the group's rows are contiguous: (sample, channel) flattened over the lanes
+    if (ldo >= 64 && (p.nsample & 3) == 0) {
+        // wide rows (the deeper levels: 67 - 259 columns): FOUR rows at a time with the column index on the lanes — four independent loads in flight per lane and no division;
+        // the flattened walk below is a chain of LDS read -> load -> store per element (132 dependent rounds for a 32 x 264 group: 41 us for the last level's 8.5 MB)
+        for (int j0 = 0; j0 < p.nsample; j0 += 4) {
+            int src[4];
+            ACH_UNROLL
+            for (int q = 0; q < 4; ++q) src[q] = s_idx[wave][(j0 + q) < cnt ? j0 + q : 0];
+            for (int col = lane; col < ldo; col += 64) {
+                float v[4];
+                ACH_UNROLL
+                for (int q = 0; q < 4; ++q) {
+                    v[q] = 0.f;
+                    if (col < 3) v[q] = xyz[src[q] * 3 + col] - (col == 0 ? cx : col == 1 ? cy : cz);
+                    else if (col < 3 + p.C) v[q] = Store<T>::ld(feats + long(src[q]) * p.ldf + (col - 3));
+                }
+                ACH_UNROLL
+                for (int q = 0; q < 4; ++q) Store<T>::st(out + (j0 + q) * ldo + col, v[q]);
+            }
+        }
+        return;
+    }
     for (int e = lane; e < total; e += 64) {
         const int j = e / ldo, col = e - j * ldo;
         const int src = s_idx[wave][j < cnt ? j : 0];

@@ -140,6 +140,33 @@ def test_emulated_pn2_matches_the_self_oracle(dtype, tol):
     assert seen == 4 * 4 + 4
 
 
+@pytest.mark.parametrize('dtype', [DTYPE_F32, DTYPE_BF16])
+def test_emulated_pn2_wave_per_ball_max_is_bit_identical(dtype):
+    """Option "group_max" (round 5, k_gemm.h gemm_groupmax_kernel): the shared-MLP + max-over-the-ball layers with a wave per ball instead of a workgroup per ball — same MFMA
+    sequence per row, and a maximum is order-independent: every tap and the output bit for bit (the first set-abstraction level of this batch has 512 balls: the new kernel;
+    the deeper ones keep the workgroup form)."""
+    from achelous_amd.engine import NativeEngine
+    from emu_util import alloc_outputs, emu_library
+    sd = _state_dict()
+    B, npts = 2, 512
+    td = torch.float32 if dtype == DTYPE_F32 else torch.bfloat16
+    x, xr, xp = make_inputs(B, 9, resolution=64, num_points=npts, pc_channels=5, radar_cells=40)
+    res = []
+    for opt in (0, 1):
+        eng = NativeEngine(emu_library(), num_det=KW['num_det'], num_seg=KW['num_seg'], phi=KW['phi'], backbone=KW['backbone'], resolution=KW['resolution'],
+                           pc_channels=KW['pc_channels'], pc_classes=KW['pc_classes'], num_points=npts, nano_head=KW['nano_head'], spp=KW['spp'], dtype=dtype, neck='gdf', pc_seg='pn2')
+        eng.set_option('full_taps', 1)
+        eng.set_option('group_max', 256 * opt)            # (threshold in balls; the default, 1024, would leave this small batch on the workgroup form)
+        eng.load_state_dict(sd)
+        eng.plan(B)
+        outs = alloc_outputs(KW, B, npts, td, 'cpu')
+        eng.forward(x.to(td), xr.to(td), xp.to(td), outs)
+        res.append((outs[5].clone(), {t: eng.read_tap(t).clone() for t in eng.tap_names() if t.startswith('pc.')}))
+    assert torch.equal(res[0][0], res[1][0])
+    for t in res[0][1]:
+        assert torch.equal(res[0][1][t], res[1][1][t]), t
+
+
 def test_emulated_pn2_rejects_unsupported_point_counts():
     from emu_util import emu_library, make_engine
     with pytest.raises(NotImplementedError):
