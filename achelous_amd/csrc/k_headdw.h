@@ -28,7 +28,13 @@ namespace ach {
 #define ACH_HDW_ALIAS 1               // the B fragments are written over the halo tile (the depthwise sums wait in registers across a barrier): 45 KB of LDS, three workgroups per CU; 49 -> 43 us, +0.7 % end to end
 #endif
 constexpr int HDW_MAXIT = 1024 / ACH_HDW_THREADS;        // strips x channel quads per thread in the aliased form (engine: rows * strips * 16 <= 1024)
-constexpr int HDW_THREADS = ACH_HDW_THREADS, HDW_SP = 5, HDW_C = 64, HDW_MAXPOS = 8 * 44, HDW_MAXT = 10;
+#ifndef ACH_HDW_HALO_ROWS
+#define ACH_HDW_HALO_ROWS 8           // rows of the staged halo tile (44 columns): 8 = 4-row bands on the 40 x 40 level (every input row staged twice: the launch's PMC traffic is 1.85x its
+#endif                                // algorithmic bytes); 12 with ACH_HDW_MAXT 20 = 8-row bands (1.5x), 67 KB of LDS — A/B in profiles/r05_sweep_headdw_bands.txt
+#ifndef ACH_HDW_MAXT
+#define ACH_HDW_MAXT 10
+#endif
+constexpr int HDW_THREADS = ACH_HDW_THREADS, HDW_SP = 5, HDW_C = 64, HDW_MAXPOS = ACH_HDW_HALO_ROWS * 44, HDW_MAXT = ACH_HDW_MAXT;
 #ifndef ACH_HDW_F32
 #define ACH_HDW_F32 0             // 1: the halo tile is staged as fp32 (90 KB: one workgroup per CU, 78 us); 0: as bf16 (45 KB: two per CU, taps unpacked in the loop, 48 us)
 #endif
