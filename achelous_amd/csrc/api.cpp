@@ -467,9 +467,12 @@ int ach_train_layernorm_bwd(const float* x, const float* dy, const float* gamma,
                             int64_t rows, int32_t C, int64_t inner, void* stream) {
     return train_guard([&] {
         train_need(x && dy && gamma && mean && rstd && dx && dgamma && dbeta && rows > 0 && C > 0 && inner > 0, "ach_train_layernorm_bwd");
-        ach::TrainLnBwdParams p{x, dy, gamma, mean, rstd, dx, dgamma, dbeta, long(rows), C, long(inner)};
+        ach::TrainLnBwdParams p{x, dy, gamma, mean, rstd, dx, dgamma, dbeta, long(rows), C, long(inner), 1, nullptr};
         ACH_TRAIN_1D(ach::train_ln_bwd_dx_kernel, p, long(rows) * inner);
-        ACH_TRAIN_ROWS(ach::train_ln_bwd_param_kernel, p, C);
+        p.S = train_slices(long(rows) * inner, C);
+        if (p.S > 1) p.ws = train_workspace(size_t(2) * C * p.S * sizeof(float));
+        ACH_LAUNCH(ach::train_ln_bwd_param_kernel, dim3(unsigned(C), unsigned(p.S)), dim3(256), static_cast<hipStream_t>(stream), p);
+        if (p.S > 1) ACH_LAUNCH(ach::train_ln_bwd_param_finalize_kernel, dim3(unsigned((C + 255) / 256)), dim3(256), static_cast<hipStream_t>(stream), p);
     });
 }
 int ach_train_dwconv(const float* x, const float* w, const float* bias, float* y, int32_t B, int32_t C, int32_t H, int32_t W, int32_t k, int32_t flip, void* stream) {

@@ -301,6 +301,12 @@ def _pair(v):
     return (v, v) if isinstance(v, int) else tuple(v)
 
 
+# A dense / deformable convolution's column buffer (im2col: k*k times the input) is kept from the forward to the backward when it is at most this many bytes — the
+# backward then skips its own im2col pass and writes the column gradient over it (round 5: the recomputation was 2.9 ms of a 65 ms batch-32 step; the kept buffers add
+# ~2 GB to its 9.6 GB peak).  Larger buffers are recomputed, as every buffer was before; 0 = always recompute.
+KEEP_COLUMN_BYTES = 1 << 30
+
+
 class _Conv2dFn(torch.autograd.Function):
     """Dense Conv2d (groups = 1): im2col + fp32 MFMA GEMM; 1x1 / stride 1 convolutions skip the column buffer."""
 
@@ -328,6 +334,7 @@ class _Conv2dFn(torch.autograd.Function):
         _gemm(lib, s, w2, col, y, Co, O, K, K, O, O, 0, K * O, Co * O, 0, 0, B, bias=bias.detach().contiguous() if bias is not None else None)
         ctx.save_for_backward(x, w2)
         ctx.cfg = (cfg, direct, bias is not None, tuple(weight.shape))
+        ctx.col = col if (not direct and col.numel() * 4 <= KEEP_COLUMN_BYTES) else None
         return y
 
     @staticmethod
@@ -339,16 +346,19 @@ class _Conv2dFn(torch.autograd.Function):
         lib = _lib(x)
         L, s = lib.lib, _stream(x)
         dy = dy.contiguous()
+        kept = ctx.col is not None
         if direct:
             col = x
-        else:                                        # the column buffer is recomputed rather than kept alive between forward and backward
+        elif kept:                                   # the forward's column buffer (KEEP_COLUMN_BYTES)
+            col, ctx.col = ctx.col, None
+        else:                                        # ... or recomputed
             col = _empty(x, B, K, O)
             _check(lib, L.ach_train_im2col(_p(x), _p(col), *cfg, 0, s))
         dw = _empty(x, Co, K)                        # dW = sum_b dy[b] col[b]^T
         _gemm(lib, s, dy, col, dw, Co, K, O, O, O, K, Co * O, K * O, 0, 0, 1, B, reduce=1)
         dx = None
         if ctx.needs_input_grad[0]:
-            dcol = torch.empty_like(x) if direct else _empty(x, B, K, O)      # dcol[b] = W^T dy[b]
+            dcol = torch.empty_like(x) if direct else col                     # dcol[b] = W^T dy[b]  (over the column buffer: the weight gradient above was its last reader, in stream order)
             _gemm(lib, s, w2, dy, dcol, K, O, Co, K, O, O, 0, Co * O, K * O, 1, 0, B)
             if direct:
                 dx = dcol
@@ -564,6 +574,7 @@ class _DeformConvFn(torch.autograd.Function):
         _gemm(lib, s, w2, col, y, Co, O, K, K, O, O, 0, K * O, Co * O, 0, 0, B)
         ctx.save_for_backward(x, offset, mask, w2)
         ctx.cfg = (Ho, Wo, stride, pad, tuple(weight.shape))
+        ctx.col = col if col.numel() * 4 <= KEEP_COLUMN_BYTES else None
         return y
 
     @staticmethod
@@ -575,8 +586,11 @@ class _DeformConvFn(torch.autograd.Function):
         lib = _lib(x)
         L, s = lib.lib, _stream(x)
         dy = dy.contiguous()
-        col = _empty(x, B, K, O)
-        _check(lib, L.ach_train_deform_im2col(_p(x), _p(offset), _p(mask), _p(col), B, C, H, W, Ho, Wo, stride, pad, s))
+        if ctx.col is not None:                                                    # the forward's sampled columns (KEEP_COLUMN_BYTES)
+            col, ctx.col = ctx.col, None
+        else:
+            col = _empty(x, B, K, O)
+            _check(lib, L.ach_train_deform_im2col(_p(x), _p(offset), _p(mask), _p(col), B, C, H, W, Ho, Wo, stride, pad, s))
         dw = _empty(x, Co, K)
         _gemm(lib, s, dy, col, dw, Co, K, O, O, O, K, Co * O, K * O, 0, 0, 1, B, reduce=1)
         dcol = col                                                                # reuse the buffer

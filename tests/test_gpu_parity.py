@@ -1144,5 +1144,6 @@ def test_packed_fp16_deformable_blend_stays_within_a_few_fp16_ulps_of_the_fp32_b
     print('packed fp16 blend vs fp32 blend, fp16 ulps of the largest magnitude per radar tap:', {k: round(v, 2) for k, v in worst.items()})
     assert all(v < (8.0 if t in ('radar.b6', 'radar.b7', 'r5') else 4.0) for t, v in worst.items()), worst
     assert any(v > 0 for v in worst.values())                       # (the two libraries really differ)
-    for k, (a, b) in zip(('det0', 'det1', 'det2', 'se_seg', 'lane_seg', 'pc_seg'), zip(res['pk16'][1], res['blend32'][1])):
-        assert _rel(a.float(), b.float()) < 0.75 * H16_TOL[k], (k, _rel(a.float(), b.float()))
+    ratios = {k: _rel(a.float(), b.float()) / H16_TOL[k] for k, (a, b) in zip(('det0', 'det1', 'det2', 'se_seg', 'lane_seg', 'pc_seg'), zip(res['pk16'][1], res['blend32'][1]))}
+    print('packed fp16 blend vs fp32 blend, outputs as fractions of the 16-bit bounds:', {k: round(v, 3) for k, v in ratios.items()})
+    assert all(v < 0.75 for v in ratios.values()), ratios
