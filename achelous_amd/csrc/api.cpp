@@ -98,6 +98,7 @@ int ach_set_option(ach_handle* h, const char* key, int32_t value) {
         else if (std::string(key) == "head_lds_pad") h->eng->head_lds_pad = value < 0 ? 0 : (value > 65536 ? 65536 : value);
         else if (std::string(key) == "head_stream") h->eng->head_stream = value != 0;
         else if (std::string(key) == "split_decoders") h->eng->split_decoders = value;
+        else if (std::string(key) == "group_wpc") h->eng->group_wpc = value < 0 ? 0 : value;
         else if (std::string(key) == "group_max") h->eng->group_max = value < 0 ? 0 : value;
         else if (std::string(key) == "dec_fork") h->eng->dec_fork = value < 0 ? 0 : (value > 3 ? 3 : value);
         else if (std::string(key) == "radar_start") h->eng->radar_start = value;
@@ -615,7 +616,7 @@ int ach_train_pn2_group(const float* xyz, const float* new_xyz, const float* fea
                         float* grouped, int32_t* group_idx, void* stream) {
     return train_guard([&] {
         train_need(xyz && new_xyz && (feats || C == 0) && grouped && group_idx && C >= 0 && B > 0 && n > 0 && S > 0 && nsample > 0 && nsample <= ach::PN2_MAX_NSAMPLE, "ach_train_pn2_group");
-        ach::GroupParams q{xyz, new_xyz, feats, long(C), C, grouped, long(3 + C), group_idx, B, n, S, nsample, radius2};
+        ach::GroupParams q{xyz, new_xyz, feats, long(C), C, grouped, long(3 + C), group_idx, B, n, S, nsample, radius2, 1};
         ACH_LAUNCH(ach::pn2_group_kernel<float>, dim3(unsigned(ach::cdivl(long(B) * S, 4))), dim3(256), static_cast<hipStream_t>(stream), q);
     });
 }

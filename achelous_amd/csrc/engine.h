@@ -118,6 +118,7 @@ public:
     int mlp_band_dbg = 0;             // option "mlp_band_dbg": phase-kill timing experiments on the band kernel (results are wrong)
     int mlp_band = 1;                 // option "mlp_band" (2: also the large maps of stages 0 / 1): bf16 — ConvEncoder blocks on the small maps as the band kernel (k_mlpband.h: LDS halo tile, weights once per band); 0 = mlp_kernel's SPLIT mode
     bool fuse_mlp = true;             // option "fused_mlp": EdgeNeXt blocks as one kernel (k_mlp.h) instead of dw / pw1 / pw2 launches
+    int group_wpc = 4096;             // option "group_wpc" (round 5; 0 = never): PointNet++ grouping with a WORKGROUP per centroid (four waves share a group's rows) on levels with at most this many centroids; bit-identical
     int group_max = 1024;             // option "group_max" (round 5; 0 = never): PointNet++'s shared-MLP + max-over-the-ball layers with a WAVE per ball (k_gemm.h gemm_groupmax_kernel) instead of a workgroup
                                       // per ball, for layers with at least this many balls (batch 64: 56 / 35 / 30 us -> 27 / 18 / 18 us for 16 384 / 4 096 / 1 024 balls; the last level's 256 balls: 36 -> 43 us, kept on the workgroup form); bit-identical
     int dec_fork = 1;                 // option "dec_fork" (pipelined plan): 0 = the decoders leave the caller's stream behind the shared ShuffleAttention stage (round 3), 1 = in front of it

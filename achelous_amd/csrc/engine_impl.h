@@ -2108,8 +2108,9 @@ public:
                 TapInfo t; t.ptr = gidx; t.kind = 2; t.is_i32 = 1; t.B = B * S; t.H = 1; t.W = 1; t.C = kNs; t.ld = kNs; add_tap("pc.sa" + std::to_string(k + 1) + ".group_idx", t);
             }
             {
-                GroupParams q{src.xyz, dst.xyz, src.f.p, src.f.ld, src.f.C, g.p, g.ld, gidx, B, src.n, S, kNs, float(kRadius[k] * kRadius[k])};
-                const dim3 grid(unsigned(cdivl(long(B) * S, 4))), block(256);
+                const int wpc = (group_wpc > 0 && long(B) * S <= group_wpc) ? 4 : 1;          // few centroids: a workgroup per centroid (k_pn2.h)
+                GroupParams q{src.xyz, dst.xyz, src.f.p, src.f.ld, src.f.C, g.p, g.ld, gidx, B, src.n, S, kNs, float(kRadius[k] * kRadius[k]), wpc};
+                const dim3 grid(unsigned(wpc == 4 ? long(B) * S : cdivl(long(B) * S, 4))), block(256);
                 add_op(sa + ".group", [q, grid, block](hipStream_t s) { ACH_LAUNCH(pn2_group_kernel<T>, grid, block, s, q); },
                        double(g.rows) * g.C * sizeof(T) * 2.0);
             }

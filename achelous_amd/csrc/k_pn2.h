@@ -127,13 +127,16 @@ struct GroupParams {
     const float* xyz; const float* new_xyz; const void* feats; long ldf; int C;
     void* out; long ldo; int* group_idx;
     int B, n, S, nsample; float r2;
-};
+    int wpc;                          // waves per centroid: 1 (a workgroup = four centroids) or 4 (round 5: a workgroup = ONE centroid, every wave repeats the (cheap) ball query and copies a
+};                                    // quarter of the group's rows — the deeper levels have 256 - 4 096 centroids per batch of 64 and were a latency chain on as many waves: 32 - 42 us for 8 - 35 MB)
 template <class T>
 __global__ __launch_bounds__(256) void pn2_group_kernel(const GroupParams p) { f16_sat_mode<T>();
     __shared__ int s_idx[4][PN2_MAX_NSAMPLE];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long cent = long(blockIdx.x) * 4 + wave;
+    const bool shared = p.wpc == 4;
+    const long cent = shared ? long(blockIdx.x) : long(blockIdx.x) * 4 + wave;
     if (cent >= long(p.B) * p.S) return;                      // whole waves leave; no workgroup barrier below
+    const int jlo = shared ? wave * ((p.nsample + 3) / 4) : 0, jhi_ = shared ? jlo + (p.nsample + 3) / 4 : p.nsample, jhi = jhi_ < p.nsample ? jhi_ : p.nsample;      // this wave's rows of the group
     const long b = cent / p.S;
     const float cx = p.new_xyz[cent * 3], cy = p.new_xyz[cent * 3 + 1], cz = p.new_xyz[cent * 3 + 2];
     const float* xyz = p.xyz + b * p.n * 3;
@@ -148,17 +151,17 @@ __global__ __launch_bounds__(256) void pn2_group_kernel(const GroupParams p) { f
     }
     if (cnt > p.nsample) cnt = p.nsample;
     wave_sync();
-    if (lane < p.nsample) {
+    if (lane < p.nsample && (!shared || wave == 0)) {
         const int src = s_idx[wave][lane < cnt ? lane : 0];
         if (p.group_idx) p.group_idx[cent * p.nsample + lane] = src;
     }
     const T* feats = static_cast<const T*>(p.feats) + b * p.n * p.ldf;
     T* out = static_cast<T*>(p.out) + cent * p.nsample * p.ldo;
     const int ldo = int(p.ldo), total = p.nsample * ldo;         // the group's rows are contiguous: (sample, channel) flattened over the lanes
-    if (ldo >= 64 && (p.nsample & 3) == 0) {
+    if (ldo >= 64 && ((jhi - jlo) & 3) == 0) {
         // wide rows (the deeper levels: 67 - 259 columns): FOUR rows at a time with the column index on the lanes — four independent loads in flight per lane and no division;
         // the flattened walk below is a chain of LDS read -> load -> store per element (132 dependent rounds for a 32 x 264 group: 41 us for the last level's 8.5 MB)
-        for (int j0 = 0; j0 < p.nsample; j0 += 4) {
+        for (int j0 = jlo; j0 < jhi; j0 += 4) {
             int src[4];
             ACH_UNROLL
             for (int q = 0; q < 4; ++q) src[q] = s_idx[wave][(j0 + q) < cnt ? j0 + q : 0];
@@ -176,7 +179,7 @@ __global__ __launch_bounds__(256) void pn2_group_kernel(const GroupParams p) { f
         }
         return;
     }
-    for (int e = lane; e < total; e += 64) {
+    for (int e = jlo * ldo + lane; e < jhi * ldo; e += 64) {
         const int j = e / ldo, col = e - j * ldo;
         const int src = s_idx[wave][j < cnt ? j : 0];
         float v = 0.f;

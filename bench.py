@@ -330,8 +330,9 @@ def main():
     x, xr, xp = make_inputs(B, config_seed(cid) + 1000 * rank, resolution=COMMON['resolution'], pc_channels=COMMON['pc_channels'], dense_radar=args.dense_radar)
     x, xr, xp = x.to(dev, tdt), xr.to(dev, tdt), xp.to(dev, tdt)
     ishape = [COMMON['resolution']] * 2
-    # the serving loop is the default schedule; PointNet++'s long point branch shares side stream 2 with the decoders there and is 1 % better plain
-    pipelined = not args.plain and not args.separate_calls and (args.pipeline or kw.get('pc_seg') != 'pn2')
+    # the serving loop is the default schedule for every config (PointNet++ too since round 5: 36.0 k frames/s against 35.0 k plain, profiles/r05_sweep_pn2_group.txt;
+    # until the wave-per-ball max layers and the workgroup-per-centroid grouping its long point branch made the plain loop 1 % better)
+    pipelined = not args.plain and not args.separate_calls
     base_opts = {kv.split('=')[0]: int(kv.split('=')[1]) for kv in args.opt}
 
     def make_runner(extra_opts):

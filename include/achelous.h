@@ -135,7 +135,7 @@ int ach_load_weights(ach_handle* h, const ach_tensor_desc* tensors, size_t n);
  * segmentation decoders leave the caller's stream — 1, default: in front of the shared ShuffleAttention stage (+0.9 %), 0: behind it (round 3), 2: as soon as the
  * neck's p3 exists, 3: the whole neck on stream 2, ordered against the next forward's backbone by a third cross-forward event (EdgeNeXt plans; level with 1);
  * bit-identical), "group_max" (default 1024; 0 = never: PointNet++'s shared-MLP + max-over-the-ball layers with a wave per ball for layers of at least this many balls;
- * bit-identical), "point_stream2" = 3 (the point branch on a stream of its own — the process's fourth: measured -1 %, and it leaves no stream for a collective);
+ * bit-identical), "group_wpc" (default 4096; 0 = never: PointNet++ grouping with a workgroup per centroid on levels with at most this many centroids; bit-identical), "point_stream2" = 3 (the point branch on a stream of its own — the process's fourth: measured -1 %, and it leaves no stream for a collective);
  * "pipeline" (see ach_join).  DESIGN.md §4 has the measurement behind every default. */
 int ach_set_option(ach_handle* h, const char* key, int32_t value);
 

@@ -36,7 +36,7 @@ print(f"| EN-S2 batch 64; plain leg | **{k(e['value'])}**; {k(e['plain_forward_d
 print(row('EN-S2 batch 512 on one GPU / batch 256', ['en_s2_b512_one_gpu', 'en_s2_b256']))
 m = L('mv_s2')
 print(f"| MV-S2 batch 64; plain leg; mv_stem=0; ffn_rows2=0 | **{k(m['value'])}**; {k(m['plain_forward_detect_fps'])}; {k(L('mv_s2_image_copy')['value'])}; {k(L('mv_s2_ffn_one_tile')['value'])} | {m['ms_per_step']:.3f} |")
-print(row('PN2 plain / pipelined', ['en_s0_pn2', 'en_s0_pn2_pipelined']))
+print(row('PN2 pipelined (default since round 5) / plain', ['en_s0_pn2', 'en_s0_pn2_plain']))
 print(row('EN-S1', ['en_s1']))
 print(row('EN-CDF-S0: both 32-channel levels fused (default) / last level + head only / layer-wise', ['en_s0_cdf', 'en_s0_cdf_last_level_only', 'en_s0_cdf_layerwise']))
 c = h['cpu_baseline']

@@ -11,7 +11,7 @@ b en_s0_storage_bf16 --storage bf16
 b en_s0_io_f16 --dtype f16
 b en_s0_neck_launches_separate --opt ghost_fuse=0 --opt ds_fuse=0
 b en_s0_r03_kernels --storage bf16 --opt ghost_fuse=0 --opt ds_fuse=0
-b en_s0_pn2_pipelined --config en_s0_pn2 --pipeline
+b en_s0_pn2_plain --config en_s0_pn2 --plain
 b en_s1 --config en_s1
 b en_s0_dense_radar_noskip --dense-radar --opt radar_skip=0
 b en_s0_noskip --opt radar_skip=0
