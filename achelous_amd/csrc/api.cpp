@@ -369,9 +369,8 @@ int ach_train_bn_stats(const float* z, float* mean, float* var, int32_t B, int32
         const int S = train_slices(long(B) * N, C);
         if (S > 1) {
             ach::BnSliceParams q{z, train_workspace(size_t(2) * C * S * sizeof(float)), mean, var, B, C, N, S};
-            ACH_LAUNCH(ach::train_bn_slice_kernel<0>, dim3(unsigned(C), unsigned(S)), dim3(256), static_cast<hipStream_t>(stream), q);
-            ACH_LAUNCH(ach::train_bn_slice_kernel<1>, dim3(unsigned(C), unsigned(S)), dim3(256), static_cast<hipStream_t>(stream), q);
-            ACH_LAUNCH(ach::train_bn_slice_finalize_kernel, dim3(unsigned((C + 255) / 256)), dim3(256), static_cast<hipStream_t>(stream), q);
+            ACH_LAUNCH(ach::train_bn_slice2_kernel, dim3(unsigned(C), unsigned(S)), dim3(256), static_cast<hipStream_t>(stream), q);          // both passes of a slice, the second out of the L2
+            ACH_LAUNCH(ach::train_bn_slice2_finalize_kernel, dim3(unsigned((C + 255) / 256)), dim3(256), static_cast<hipStream_t>(stream), q);
             return;
         }
         ach::BnStatsParams p{z, mean, var, B, C, N};

@@ -316,9 +316,10 @@ class Achelous(nn.Module):
         if not (x.is_cuda and x_radar.is_cuda and (not has_pts or x_point_clouds.is_cuda)) and not getattr(train_ops._lib, 'test_library', None):
             raise RuntimeError("achelous_amd.Achelous.forward needs GPU tensors (HIP training kernels; there is no CPU path)")
         B = self._check_inputs(x, x_radar, x_point_clouds)
-        if self.train_precision not in ('fp32', 'bf16'):
-            raise ValueError(f"train_precision must be 'fp32' or 'bf16', got {self.train_precision!r}")
-        train_ops.set_gemm_precision(x, 1 if self.train_precision == 'bf16' else 0)
+        precision = getattr(self, 'train_precision', 'fp32')          # (modules pickled before round 5 have no such attribute: utils_fit.py:378 pickles the module)
+        if precision not in ('fp32', 'bf16'):
+            raise ValueError(f"train_precision must be 'fp32' or 'bf16', got {precision!r}")
+        train_ops.set_gemm_precision(x, 1 if precision == 'bf16' else 0)
         det, se, lane, pc = train_graph.TrainGraph(self).forward(x, x_radar, x_point_clouds if has_pts else None)
         return (list(det), se, lane, pc) if has_pts else (list(det), se, lane)
 

@@ -242,8 +242,10 @@ def test_gpu_training_step_under_the_reference_amp_loop():
     for n in grads[0]:
         a, b = grads[0][n], grads[1][n]
         assert torch.isfinite(b).all(), n
-        # (a bias in front of a training-mode BatchNorm has a TRUE gradient of zero: both loops return rounding noise around it, at the scale of the step's gradients)
-        assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max()) + 2e-6 * gmax, n
+        # (a bias in front of a training-mode BatchNorm has a TRUE gradient of zero: both loops return rounding noise around it, at the scale of the step's gradients — and not the
+        #  same noise twice: the deformable conv's input gradient is summed with atomics, in an order that differs from run to run.  Measured over repeated runs: up to 2.5e-6 of the
+        #  step's largest gradient on `rc_blocks.0.weight_conv1.bias`; the floor is 5e-6)
+        assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max()) + 5e-6 * gmax, n
 
 
 def _bf16_step_errors(batch=8, resolution=160, points=128):
