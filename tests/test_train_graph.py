@@ -16,6 +16,11 @@ import torch
 from achelous_amd import Achelous, train_ops
 from achelous_amd.synth import condition_state_dict, make_inputs
 
+# A bias in front of a training-mode BatchNorm has a TRUE gradient of zero: every float32 evaluation returns rounding noise around it, at the scale of the step's gradients — and on
+# the GPU not the same noise twice (the deformable conv's input gradient is summed with atomics in an order that differs from run to run).  Such tensors are held to this fraction of
+# the step's largest gradient instead of a relative bound (measured over repeated runs on the MI355X: up to 2.5e-6).
+ZERO_GRAD_FLOOR = 5e-6
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 FIX = os.path.join(HERE, 'golden', 'train_en_s0')
 
@@ -63,11 +68,11 @@ def _check(dev):
             continue
         assert p.grad is not None, k
         err, ref, inf, amax = _compare(fx, 'grad::' + k, p.grad)
-        if amax > 2e-6 * gscale:
+        if amax > ZERO_GRAD_FLOOR * gscale:
             report.append((err, ref, k))
         # a bias in front of a training-mode BatchNorm has a TRUE gradient of zero: both sides return rounding noise around it, so
         # such tensors are held to an absolute floor relative to the largest gradient of the step instead
-        assert err <= max(5e-3, 8 * ref) or amax <= 2e-6 * gscale, (k, err, ref, amax, inf, gscale)
+        assert err <= max(5e-3, 8 * ref) or amax <= ZERO_GRAD_FLOOR * gscale, (k, err, ref, amax, inf, gscale)
         n += 1
     assert n == 527
     for k, v in m.named_buffers():
@@ -156,7 +161,7 @@ def _check_against_oracle_autograd(dev, phi, spp, res, fixture):
         yard = float((f32_grads[k] - ref).norm() / (ref.norm() + 1e-300))
         # a wiring check (a wrong graph is off by O(1)): BatchNorm over 2 frames of 2x2 maps and PointNet's max over 32 points make a
         # float32 step deviate from the float64 truth by several per cent on some tensors — torch's own float32 does the same
-        assert err < max(6e-2, 6 * yard) or float((got - ref).abs().max()) <= 2e-6 * gscale, (k, err, yard)
+        assert err < max(6e-2, 6 * yard) or float((got - ref).abs().max()) <= ZERO_GRAD_FLOOR * gscale, (k, err, yard)
         checked += 1
     assert checked > 500
 
@@ -245,7 +250,7 @@ def test_gpu_training_step_under_the_reference_amp_loop():
         # (a bias in front of a training-mode BatchNorm has a TRUE gradient of zero: both loops return rounding noise around it, at the scale of the step's gradients — and not the
         #  same noise twice: the deformable conv's input gradient is summed with atomics, in an order that differs from run to run.  Measured over repeated runs: up to 2.5e-6 of the
         #  step's largest gradient on `rc_blocks.0.weight_conv1.bias`; the floor is 5e-6)
-        assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max()) + 5e-6 * gmax, n
+        assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max()) + ZERO_GRAD_FLOOR * gmax, n
 
 
 def _bf16_step_errors(batch=8, resolution=160, points=128):
