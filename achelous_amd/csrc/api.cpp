@@ -377,11 +377,21 @@ int ach_train_bn_stats(const float* z, float* mean, float* var, int32_t B, int32
         ACH_LAUNCH(ach::train_bn_stats_kernel, dim3(unsigned(C)), dim3(256), static_cast<hipStream_t>(stream), p);
     });
 }
+int ach_train_bn_running(const float* mean, const float* var, float* running_mean, float* running_var, int32_t C, float momentum, float unbias, void* stream) {
+    return train_guard([&] {
+        if (!mean || !var || !running_mean || !running_var || C <= 0) throw ach::AchError{ACH_ERR_INVALID, "bad train_bn_running arguments"};
+        ach::BnRunningParams p{mean, var, running_mean, running_var, C, momentum, unbias};
+        ACH_LAUNCH(ach::train_bn_running_kernel, dim3(unsigned((C + 255) / 256)), dim3(256), static_cast<hipStream_t>(stream), p);
+    });
+}
 int ach_train_bn_relu_fwd(const float* z, const float* mean, const float* var, const float* gamma, const float* beta, float* y, int32_t B, int32_t C,
                           int32_t N, float eps, int32_t relu, void* stream) {
     return train_guard([&] {
         if (!z || !mean || !var || !gamma || !beta || !y || B <= 0 || C <= 0 || N <= 0) throw ach::AchError{ACH_ERR_INVALID, "bad train_bn_relu_fwd arguments"};
         ach::BnReluFwdParams p{z, mean, var, gamma, beta, y, B, C, N, eps, relu};
+        const bool quad = (N & 3) == 0 && long(B) * C <= 65535 && ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(y)) & 15u) == 0;      // a plane per blockIdx.y, four positions per thread
+        if (quad) ACH_LAUNCH(ach::train_bn_relu_fwd4_kernel, dim3(unsigned(ach::cdivl(long(N) / 4, 256)), unsigned(long(B) * C)), dim3(256), static_cast<hipStream_t>(stream), p);
+        else
         ACH_LAUNCH(ach::train_bn_relu_fwd_kernel, dim3(unsigned(ach::cdivl(long(B) * C * N, 256))), dim3(256), static_cast<hipStream_t>(stream), p);
     });
 }
@@ -394,6 +404,10 @@ int ach_train_bn_relu_bwd(const float* z, const float* y, const float* dy, const
         if (p.S > 1) p.ws = train_workspace(size_t(2) * C * p.S * sizeof(float));
         ACH_LAUNCH(ach::train_bn_relu_bwd_reduce_kernel, dim3(unsigned(C), unsigned(p.S)), dim3(256), static_cast<hipStream_t>(stream), p);
         if (p.S > 1) ACH_LAUNCH(ach::train_bn_relu_bwd_finalize_kernel, dim3(unsigned((C + 255) / 256)), dim3(256), static_cast<hipStream_t>(stream), p);
+        const bool quad = (N & 3) == 0 && long(B) * C <= 65535 &&
+                          ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dz)) & 15u) == 0;
+        if (quad) ACH_LAUNCH(ach::train_bn_relu_bwd_apply4_kernel, dim3(unsigned(ach::cdivl(long(N) / 4, 256)), unsigned(long(B) * C)), dim3(256), static_cast<hipStream_t>(stream), p);
+        else
         ACH_LAUNCH(ach::train_bn_relu_bwd_apply_kernel, dim3(unsigned(ach::cdivl(long(B) * C * N, 256))), dim3(256), static_cast<hipStream_t>(stream), p);
     });
 }
@@ -479,6 +493,14 @@ int ach_train_dwconv(const float* x, const float* w, const float* bias, float* y
     return train_guard([&] {
         train_need(x && w && y && B > 0 && C > 0 && H > 0 && W > 0 && k > 0 && (k & 1), "ach_train_dwconv");
         ach::TrainDwParams p{x, w, bias, y, B, C, H, W, k, flip};
+        const bool quad = (W & 3) == 0 && long(B) * C <= 65535 && (reinterpret_cast<uintptr_t>(y) & 15u) == 0;      // four outputs of a row per thread (k_train2.h)
+        const dim3 gq(unsigned(ach::cdivl(long(H) * (W / 4), 256)), unsigned(long(B) * C)), bq(256);
+        const hipStream_t st = static_cast<hipStream_t>(stream);
+        if (quad && k == 3) ACH_LAUNCH(ach::train_dwconv4_kernel<3>, gq, bq, st, p);
+        else if (quad && k == 5) ACH_LAUNCH(ach::train_dwconv4_kernel<5>, gq, bq, st, p);
+        else if (quad && k == 7) ACH_LAUNCH(ach::train_dwconv4_kernel<7>, gq, bq, st, p);
+        else if (quad && k == 9) ACH_LAUNCH(ach::train_dwconv4_kernel<9>, gq, bq, st, p);
+        else
         if (k == 3) ACH_TRAIN_1D(ach::train_dwconv_kernel<3>, p, long(B) * C * H * W);
         else if (k == 5) ACH_TRAIN_1D(ach::train_dwconv_kernel<5>, p, long(B) * C * H * W);
         else if (k == 7) ACH_TRAIN_1D(ach::train_dwconv_kernel<7>, p, long(B) * C * H * W);

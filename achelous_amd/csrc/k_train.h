@@ -304,6 +304,16 @@ static __global__ __launch_bounds__(256) void train_bn_slice_finalize_kernel(con
     p.mean[c] = m / total; p.var[c] = q / total;
 }
 
+// nn.BatchNorm's running estimates after a training forward: running <- (1 - m) running + m batch (the variance unbiased: `unbias` = M / (M - 1)).  One launch in place of the four
+// element-wise torch launches per layer (mul_, add_, mul_, add_: 320 launches of a training step's ~2 000, which at batch 32 is bound by the HOST's launch rate since round 5).
+struct BnRunningParams { const float* mean; const float* var; float* running_mean; float* running_var; int C; float momentum, unbias; };
+static __global__ __launch_bounds__(256) void train_bn_running_kernel(const BnRunningParams p) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= p.C) return;
+    p.running_mean[c] = (1.0f - p.momentum) * p.running_mean[c] + p.momentum * p.mean[c];
+    p.running_var[c] = (1.0f - p.momentum) * p.running_var[c] + (p.momentum * p.unbias) * p.var[c];
+}
+
 struct BnReluFwdParams { const float* Z; const float* mean; const float* var; const float* gamma; const float* beta; float* Y; int B, C, N; float eps; int relu; };
 static __global__ __launch_bounds__(256) void train_bn_relu_fwd_kernel(const BnReluFwdParams p) {
     const long idx = long(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -311,6 +321,23 @@ static __global__ __launch_bounds__(256) void train_bn_relu_fwd_kernel(const BnR
     const int c = long(p.B) * p.C * p.N < (1L << 31) ? int((unsigned(idx) / unsigned(p.N)) % unsigned(p.C)) : int((idx / p.N) % p.C);      // (64-bit divisions only where they are needed)
     const float v = p.gamma[c] * ((p.Z[idx] - p.mean[c]) * (1.0f / sqrtf(p.var[c] + p.eps))) + p.beta[c];
     p.Y[idx] = (p.relu && v < 0.f) ? 0.f : v;
+}
+
+// the same with one (sample, channel) plane per blockIdx.y and four positions per thread (N a multiple of four): no index division, the channel's constants formed once per thread
+// from uniform loads, 16-byte loads and stores
+static __global__ __launch_bounds__(256) void train_bn_relu_fwd4_kernel(const BnReluFwdParams p) {
+    const unsigned q = blockIdx.x * 256u + threadIdx.x;
+    if (q >= unsigned(p.N >> 2)) return;
+    const long plane = blockIdx.y;
+    const int c = int(plane % p.C);
+    const float mean = p.mean[c], beta = p.beta[c], g = p.gamma[c], rstd = 1.0f / sqrtf(p.var[c] + p.eps);
+    const long off = plane * long(p.N) + 4L * q;
+    const float4 z = *reinterpret_cast<const float4*>(p.Z + off);
+    const float zi[4] = {z.x, z.y, z.z, z.w};
+    float o[4];
+    ACH_UNROLL
+    for (int i = 0; i < 4; ++i) { const float v = g * ((zi[i] - mean) * rstd) + beta; o[i] = (p.relu && v < 0.f) ? 0.f : v; }          // (the per-element kernel's expression, term for term)
+    *reinterpret_cast<float4*>(p.Y + off) = make_float4(o[0], o[1], o[2], o[3]);
 }
 
 // backward, step 1: per channel  dbeta = sum g,  dgamma = sum g * xhat   with g = dy * (y > 0 | no relu)
@@ -356,6 +383,26 @@ static __global__ __launch_bounds__(256) void train_bn_relu_bwd_apply_kernel(con
     const float g = (p.relu && !(p.Y[idx] > 0.f)) ? 0.f : p.dY[idx];
     const float invM = 1.0f / float(long(p.B) * p.N);
     p.dZ[idx] = p.gamma[c] * rstd * (g - p.dbeta[c] * invM - xhat * p.dgamma[c] * invM);
+}
+
+static __global__ __launch_bounds__(256) void train_bn_relu_bwd_apply4_kernel(const BnReluBwdParams p) {      // (plane per blockIdx.y, four positions per thread: see train_bn_relu_fwd4_kernel)
+    const unsigned q = blockIdx.x * 256u + threadIdx.x;
+    if (q >= unsigned(p.N >> 2)) return;
+    const long plane = blockIdx.y;
+    const int c = int(plane % p.C);
+    const float rstd = 1.0f / sqrtf(p.var[c] + p.eps), mean = p.mean[c], gamma = p.gamma[c], db = p.dbeta[c], dg = p.dgamma[c];
+    const float invM = 1.0f / float(long(p.B) * p.N);
+    const long off = plane * long(p.N) + 4L * q;
+    const float4 z = *reinterpret_cast<const float4*>(p.Z + off), y = *reinterpret_cast<const float4*>(p.Y + off), dy = *reinterpret_cast<const float4*>(p.dY + off);
+    const float zi[4] = {z.x, z.y, z.z, z.w}, yi[4] = {y.x, y.y, y.z, y.w}, di[4] = {dy.x, dy.y, dy.z, dy.w};
+    float o[4];
+    ACH_UNROLL
+    for (int i = 0; i < 4; ++i) {
+        const float xhat = (zi[i] - mean) * rstd;
+        const float g = (p.relu && !(yi[i] > 0.f)) ? 0.f : di[i];
+        o[i] = gamma * rstd * (g - db * invM - xhat * dg * invM);
+    }
+    *reinterpret_cast<float4*>(p.dZ + off) = make_float4(o[0], o[1], o[2], o[3]);
 }
 
 // ---- depthwise 3x3, stride 1, pad 1 on [B, C, H, W] (GhostModule's cheap operation, the GhostBottleneck shortcut: ghost_conv.py:19-23,47-56)

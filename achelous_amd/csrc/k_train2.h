@@ -173,6 +173,43 @@ static __global__ __launch_bounds__(256) void train_dwconv_kernel(const TrainDwP
     }
     p.y[i] = acc;
 }
+// The same convolution with FOUR consecutive outputs of a row per thread (W a multiple of four; one plane per blockIdx.y): the index split — three divisions per output above, ~100 of
+// the thread's ~150 instructions — is one division per four outputs, a tap row is K + 3 loads for 4 K products instead of 4 K loads, the store is 16 bytes.  (The per-output form ran at
+// 0.9 TB/s on the 320 x 320 layers — VALU-bound by its own index arithmetic — and was 3.1 ms of a batch-32 training step.)
+template <int KT>
+static __global__ __launch_bounds__(256) void train_dwconv4_kernel(const TrainDwParams p) {
+    constexpr int R = KT / 2;
+    const int wq = p.W >> 2;
+    const unsigned q = blockIdx.x * 256u + threadIdx.x;
+    if (q >= unsigned(p.H) * unsigned(wq)) return;
+    const int oy = int(q / unsigned(wq)), ox = int(q - unsigned(oy) * unsigned(wq)) * 4;
+    const long plane = blockIdx.y;                                   // b * C + c
+    const int c = int(plane % p.C);
+    const float* xp = p.x + plane * long(p.H) * p.W;
+    const float* w = p.w + long(c) * KT * KT;
+    const float b0 = p.bias ? p.bias[c] : 0.f;
+    float acc[4] = {b0, b0, b0, b0};
+    ACH_UNROLL
+    for (int ky = 0; ky < KT; ++ky) {
+        const int iy = oy + ky - R;
+        if (iy < 0 || iy >= p.H) continue;
+        const float* xr = xp + long(iy) * p.W;
+        float v[KT + 3];
+        ACH_UNROLL
+        for (int j = 0; j < KT + 3; ++j) {
+            const int ix = ox + j - R;
+            const float t = xr[ix < 0 ? 0 : (ix >= p.W ? p.W - 1 : ix)];             // unconditional load from a clamped address, then a select
+            v[j] = (ix >= 0 && ix < p.W) ? t : 0.f;
+        }
+        ACH_UNROLL
+        for (int kx = 0; kx < KT; ++kx) {
+            const float wv = w[p.flip ? (KT - 1 - ky) * KT + (KT - 1 - kx) : ky * KT + kx];
+            ACH_UNROLL
+            for (int i = 0; i < 4; ++i) acc[i] += v[kx + i] * wv;
+        }
+    }
+    *reinterpret_cast<float4*>(p.y + plane * long(p.H) * p.W + long(oy) * p.W + ox) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+}
 // one workgroup per (channel, tap) and SLICE of the (B, H, W) range: a 16-channel 3x3 layer at 320 x 320 is 144 (channel, tap) pairs of
 // 819 200 terms each at batch 8 — 144 workgroups walking 3 200 iterations on a 256-CU chip took 2 ms; S > 1: partials into ws [C*k*k][S],
 // summed in slice order by train_dwconv_wgrad_finalize_kernel
@@ -205,10 +242,41 @@ static __global__ __launch_bounds__(256) void train_dwconv_wgrad_taps_kernel(con
     __shared__ float part[4][KK];
     const int c = blockIdx.x;
     const unsigned hw = unsigned(p.H) * unsigned(p.W), total = unsigned(p.B) * hw;
-    const unsigned per = p.S > 1 ? (total + unsigned(p.S) - 1) / unsigned(p.S) : total, lo = p.S > 1 ? blockIdx.y * per : 0u, hi = (lo + per < total) ? lo + per : total;
+    const unsigned per0 = p.S > 1 ? (total + unsigned(p.S) - 1) / unsigned(p.S) : total;
+    const unsigned per = (p.W & 3) == 0 ? ((per0 + 3u) & ~3u) : per0;          // (slices of whole quads when W is a multiple of four: see the quad walk below; trailing slices may be empty)
+    const unsigned lo = p.S > 1 ? blockIdx.y * per : 0u, hi = lo >= total ? lo : ((lo + per < total) ? lo + per : total);
     float acc[KK];
     ACH_UNROLL
     for (int t = 0; t < KK; ++t) acc[t] = 0.f;
+    if ((p.W & 3) == 0 && (per & 3) == 0) {
+        // four consecutive positions of a row per step (W and the slice length are multiples of four, so a quad never straddles a row or a slice): two index divisions and
+        // K (K + 3) loads of x per four positions instead of eight and 4 K K
+        const unsigned wq = unsigned(p.W) >> 2, hwq = hw >> 2;
+        for (unsigned e4 = (lo >> 2) + threadIdx.x; e4 < (hi >> 2); e4 += 256) {
+            const unsigned b = e4 / hwq, q = e4 - b * hwq;
+            const int oy = int(q / wq), ox = int(q - unsigned(oy) * wq) * 4;
+            const float* xc = p.x + (long(b) * p.C + c) * long(hw);
+            const float4 g4 = *reinterpret_cast<const float4*>(p.dz + (long(b) * p.C + c) * long(hw) + long(oy) * p.W + ox);
+            const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+            ACH_UNROLL
+            for (int ky = 0; ky < K; ++ky) {
+                const int iy = oy + ky - R;
+                if (iy < 0 || iy >= p.H) continue;
+                const float* xr = xc + long(iy) * p.W;
+                float v[K + 3];
+                ACH_UNROLL
+                for (int j = 0; j < K + 3; ++j) {
+                    const int ix = ox + j - R;
+                    const float t = xr[ix < 0 ? 0 : (ix >= p.W ? p.W - 1 : ix)];
+                    v[j] = (ix >= 0 && ix < p.W) ? t : 0.f;
+                }
+                ACH_UNROLL
+                for (int kx = 0; kx < K; ++kx)
+                    ACH_UNROLL
+                    for (int i = 0; i < 4; ++i) acc[ky * K + kx] += g[i] * v[kx + i];
+            }
+        }
+    } else
     for (unsigned e = lo + threadIdx.x; e < hi; e += 256) {
         const unsigned b = e / hw, pix = e - b * hw;
         const int oy = int(pix / unsigned(p.W)), ox = int(pix - unsigned(oy) * unsigned(p.W));

@@ -354,7 +354,7 @@ class _Conv2dFn(torch.autograd.Function):
         else:                                        # ... or recomputed
             col = _empty(x, B, K, O)
             _check(lib, L.ach_train_im2col(_p(x), _p(col), *cfg, 0, s))
-        dw = _empty(x, Co, K)                        # dW = sum_b dy[b] col[b]^T
+        dw = _empty(x, *wshape)                      # dW = sum_b dy[b] col[b]^T  ([Co, K] in memory; allocated in the parameter's shape: a view would make AccumulateGrad clone it)
         _gemm(lib, s, dy, col, dw, Co, K, O, O, O, K, Co * O, K * O, 0, 0, 1, B, reduce=1)
         dx = None
         if ctx.needs_input_grad[0]:
@@ -370,7 +370,7 @@ class _Conv2dFn(torch.autograd.Function):
             per = _empty(x, B * Co)
             _check(lib, L.ach_train_row_reduce(_p(dy), _NULL, _p(per), B * Co, O, 1.0, s))
             db = per.view(B, Co).sum(0)
-        return dx, dw.view(wshape), db, None, None
+        return dx, dw, db, None, None
 
 
 def conv2d(x, weight, bias=None, stride=1, padding=0):
@@ -413,14 +413,14 @@ class _DWConvFn(torch.autograd.Function):
         dy = dy.contiguous()
         dx = torch.empty_like(x)
         _check(lib, L.ach_train_dwconv(_p(dy), _p(w2), _NULL, _p(dx), B, C, H, W, k, 1, s))
-        dw = _empty(x, C, k * k)
+        dw = _empty(x, C, 1, k, k)
         _check(lib, L.ach_train_dwconv_wgrad(_p(x), _p(dy), _p(dw), B, C, H, W, k, s))
         db = None
         if has_bias:
             per = _empty(x, B * C)
             _check(lib, L.ach_train_row_reduce(_p(dy), _NULL, _p(per), B * C, H * W, 1.0, s))
             db = per.view(B, C).sum(0)
-        return dx, dw.view(C, 1, k, k), db
+        return dx, dw, db
 
 
 def dwconv(x, weight, bias=None):
@@ -591,14 +591,14 @@ class _DeformConvFn(torch.autograd.Function):
         else:
             col = _empty(x, B, K, O)
             _check(lib, L.ach_train_deform_im2col(_p(x), _p(offset), _p(mask), _p(col), B, C, H, W, Ho, Wo, stride, pad, s))
-        dw = _empty(x, Co, K)
+        dw = _empty(x, *wshape)
         _gemm(lib, s, dy, col, dw, Co, K, O, O, O, K, Co * O, K * O, 0, 0, 1, B, reduce=1)
         dcol = col                                                                # reuse the buffer
         _gemm(lib, s, w2, dy, dcol, K, O, Co, K, O, O, 0, Co * O, K * O, 1, 0, B)
         dx = torch.zeros_like(x) if ctx.needs_input_grad[0] else None             # (the first RCBlock samples the pooled radar map: an input, no gradient — 354 M atomic adds at batch 32)
         doff, dmask = torch.empty_like(offset), torch.empty_like(mask)
         _check(lib, L.ach_train_deform_bwd(_p(x), _p(offset), _p(mask), _p(dcol), _p(dx) if dx is not None else _NULL, _p(doff), _p(dmask), B, C, H, W, Ho, Wo, stride, pad, s))
-        return dx, doff, dmask, dw.view(wshape), None, None
+        return dx, doff, dmask, dw, None, None
 
 
 def deform_conv3x3(x, offset, mask, weight, stride=1, pad=1):

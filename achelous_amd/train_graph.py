@@ -42,6 +42,7 @@ class TrainGraph:
         self.b = dict(model.named_buffers())
         self.cfg = EDGENEXT[model.phi]
         self.w = WIDTHS[model.phi]
+        self._nbt = []                    # the num_batches_tracked buffers of the BatchNorm layers this forward went through: incremented together at its end (one multi-tensor launch, not 80)
 
     # ---------------------------------------------------------------------------------------------- parameter access, layers
     def P(self, key):
@@ -53,7 +54,7 @@ class TrainGraph:
     def bn(self, x, pfx, eps, relu=False):
         """nn.BatchNorm in training mode: batch statistics, running estimates and num_batches_tracked updated.  The BaseConv / SPP Conv
         layers are built with eps 1e-3 AND momentum 0.03 (normal_conv.py:45, spp.py:31); every other BatchNorm has torch's defaults."""
-        self.b[pfx + '.num_batches_tracked'] += 1
+        self._nbt.append(self.b[pfx + '.num_batches_tracked'])
         return TF.batchnorm(x, self.P(pfx + '.weight'), self.P(pfx + '.bias'), self.b[pfx + '.running_mean'], self.b[pfx + '.running_var'],
                             True, 0.03 if eps == 1e-3 else BN_MOMENTUM, eps, relu)
 
@@ -345,7 +346,7 @@ class TrainGraph:
     # ---------------------------------------------------------------------------------------------- PointNet
     def shared_mlp(self, x, conv, bn, relu=True):
         """Conv1d(k=1) / Linear + BatchNorm1d [+ ReLU] on [B, C, N] (pointnet_utils.py:29-31, 69-71, 124-127)."""
-        self.b[bn + '.num_batches_tracked'] += 1
+        self._nbt.append(self.b[bn + '.num_batches_tracked'])
         return _SharedMLP1dFn.apply(x, self.P(conv + '.weight'), self.P(conv + '.bias'), self.P(bn + '.weight'), self.P(bn + '.bias'),
                                     self.b[bn + '.running_mean'], self.b[bn + '.running_var'], True, BN_MOMENTUM, 1e-5, relu)
 
@@ -431,4 +432,12 @@ class TrainGraph:
         se, lane, (q5, q4, q3) = self.ghost_dual_fpn(x.contiguous())
         r3, r4, r5 = self.rcnet(x_radar.contiguous())
         det = self.head((self.fuse(q3, r3, 3), self.fuse(q4, r4, 4), self.fuse(q5, r5, 5)))
+        self.flush_counters()
         return det, se, lane, pc
+
+    def flush_counters(self):
+        """num_batches_tracked += 1 for every BatchNorm layer evaluated since the last flush (callers that evaluate a branch on its own — the tests — call this themselves)."""
+        if self._nbt:
+            with torch.no_grad():
+                torch._foreach_add_(self._nbt, 1)
+            self._nbt = []

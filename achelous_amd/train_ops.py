@@ -56,6 +56,13 @@ def _stream(t):
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream if t.is_cuda else 0)
 
 
+def _update_running(lib, L, s, mean, var, running_mean, running_var, momentum, m):
+    """nn.BatchNorm's running-estimate update as ONE native launch (it was four element-wise torch launches per layer)."""
+    if running_mean.dtype != torch.float32 or running_var.dtype != torch.float32 or not running_mean.is_contiguous() or not running_var.is_contiguous():
+        raise TypeError("BatchNorm running statistics must be contiguous float32 tensors")
+    _check(lib, L.ach_train_bn_running(_p(mean), _p(var), _p(running_mean), _p(running_var), mean.numel(), float(momentum), float(m) / float(max(m - 1, 1)), s))
+
+
 class _SharedMLP1dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, training, momentum, eps, relu):
@@ -77,10 +84,7 @@ class _SharedMLP1dFn(torch.autograd.Function):
         if training:
             _check(lib, L.ach_train_bn_stats(_p(z), _p(mean), _p(var), B, cout, N, s))
             if running_mean is not None:
-                with torch.no_grad():                     # nn.BatchNorm1d: running <- (1 - m) running + m batch, unbiased variance
-                    m = B * N
-                    running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
-                    running_var.mul_(1 - momentum).add_(var, alpha=momentum * m / max(m - 1, 1))
+                _update_running(lib, L, s, mean, var, running_mean, running_var, momentum, B * N)      # nn.BatchNorm1d: running <- (1 - m) running + m batch, unbiased variance
         else:
             mean.copy_(running_mean)
             var.copy_(running_var)
@@ -109,11 +113,11 @@ class _SharedMLP1dFn(torch.autograd.Function):
         _check(lib, L.ach_train_bn_relu_bwd(_p(z), _p(y), _p(dy), _p(mean), _p(var), _p(gamma), _p(dgamma), _p(dbeta), _p(dz), B, cout, N, eps, relu, s))
         dx = torch.empty_like(x)            # dx[b] = W^T dz[b]: A = W stored [cout, cin] = K x M
         _check(lib, L.ach_train_gemm(_p(w2), _p(dz), _p(dx), ctypes.c_void_p(), cin, N, cout, cin, N, N, 0, cout * N, cin * N, 1, 0, B, 0, 0, s))
-        dw = torch.empty(cout, cin, dtype=torch.float32, device=x.device)        # dW = sum_b dz[b] x[b]^T: B = x[b] stored [cin, N] = N x K
+        dw = torch.empty(wshape, dtype=torch.float32, device=x.device)          # dW = sum_b dz[b] x[b]^T: B = x[b] stored [cin, N] = N x K; in the parameter's own shape (a VIEW of a 2-D buffer would make AccumulateGrad clone it: one copy per parameter and step)
         _check(lib, L.ach_train_gemm(_p(dz), _p(x), _p(dw), ctypes.c_void_p(), cout, cin, N, N, N, cin, cout * N, cin * N, 0, 0, 1, B, 1, 0, s))
         # a bias in front of a training-mode BatchNorm has zero gradient: the batch mean it shifts is subtracted again (sum dz = 0)
         dbias = torch.zeros(cout, dtype=torch.float32, device=x.device) if has_bias else None
-        return dx, dw.reshape(wshape), dbias, dgamma, dbeta, None, None, None, None, None, None
+        return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None, None
 
 
 class SharedMLP1d(nn.Module):
@@ -141,10 +145,7 @@ def _bn_train_fwd(lib, L, s, z3, gamma, beta, running_mean, running_var, trainin
     if training:
         _check(lib, L.ach_train_bn_stats(_p(z3), _p(mean), _p(var), B, C, N, s))
         if running_mean is not None:
-            with torch.no_grad():
-                m = B * N
-                running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
-                running_var.mul_(1 - momentum).add_(var, alpha=momentum * m / max(m - 1, 1))
+            _update_running(lib, L, s, mean, var, running_mean, running_var, momentum, B * N)
     else:
         mean.copy_(running_mean)
         var.copy_(running_var)
@@ -191,9 +192,9 @@ class _DWConvBNFn(torch.autograd.Function):
         _check(lib, L.ach_train_bn_relu_bwd(_p(z), _p(y), _p(dy), _p(mean), _p(var), _p(gamma), _p(dgamma), _p(dbeta), _p(dz), B, C, H * W, eps, relu, s))
         dx = torch.empty_like(x)
         _check(lib, L.ach_train_dw3x3(_p(dz), _p(w2), _p(dx), B, C, H, W, 1, s))                    # mirrored taps
-        dw = torch.empty(C, 9, dtype=torch.float32, device=x.device)
+        dw = torch.empty(C, 1, 3, 3, dtype=torch.float32, device=x.device)
         _check(lib, L.ach_train_dw3x3_wgrad(_p(x), _p(dz), _p(dw), B, C, H, W, s))
-        return dx, dw.view(C, 1, 3, 3), dgamma, dbeta, None, None, None, None, None, None
+        return dx, dw, dgamma, dbeta, None, None, None, None, None, None
 
 
 def _conv1x1_bn(x, conv, bn, relu, training):
@@ -281,7 +282,7 @@ class _LinearFn(torch.autograd.Function):
         dz = dz.contiguous()
         dx = torch.empty_like(x)
         _check(lib, L.ach_train_gemm(_p(w2), _p(dz), _p(dx), ctypes.c_void_p(), cin, N, cout, cin, N, N, 0, cout * N, cin * N, 1, 0, B, 0, 0, s))
-        dw = torch.empty(cout, cin, dtype=torch.float32, device=x.device)
+        dw = torch.empty(wshape, dtype=torch.float32, device=x.device)          # (in the parameter's own shape: a VIEW of a 2-D buffer would make autograd's AccumulateGrad clone it — one copy per parameter and step)
         _check(lib, L.ach_train_gemm(_p(dz), _p(x), _p(dw), ctypes.c_void_p(), cout, cin, N, N, N, cin, cout * N, cin * N, 0, 0, 1, B, 1, 0, s))
         db = None
         if has_bias:                      # db[c] = sum over (B, N) of dz = B N x the per-channel mean the statistics kernel returns
@@ -289,7 +290,7 @@ class _LinearFn(torch.autograd.Function):
             scratch = torch.empty(cout, dtype=torch.float32, device=x.device)
             _check(lib, L.ach_train_bn_stats(_p(dz), _p(db), _p(scratch), B, cout, N, s))
             db = db * float(B * N)
-        return dx, dw.reshape(wshape), db
+        return dx, dw, db
 
 
 class _BmmPointsFn(torch.autograd.Function):

@@ -264,6 +264,8 @@ int ach_train_gemm(const float* A, const float* B, float* C, const float* bias, 
 int ach_train_set_gemm_precision(int32_t precision);
 int ach_train_get_gemm_precision(void);
 int ach_train_bn_stats(const float* z, float* mean, float* var, int32_t B, int32_t C, int32_t N, void* stream);
+/*   ach_train_bn_running    nn.BatchNorm's running estimates after a training forward: running <- (1 - momentum) running + momentum batch; `unbias` = M / (M - 1) on the variance */
+int ach_train_bn_running(const float* mean, const float* var, float* running_mean, float* running_var, int32_t C, float momentum, float unbias, void* stream);
 int ach_train_bn_relu_fwd(const float* z, const float* mean, const float* var, const float* gamma, const float* beta, float* y, int32_t B, int32_t C,
                           int32_t N, float eps, int32_t relu, void* stream);
 int ach_train_bn_relu_bwd(const float* z, const float* y, const float* dy, const float* mean, const float* var, const float* gamma, float* dgamma,

@@ -321,7 +321,9 @@ def _check_pn2_training(dev, B=2, npts=384):
     m.load_state_dict(sd, strict=True)
     m = m.to(dev).train()
     _, _, xp = make_inputs(B, 7, resolution=64, num_points=npts, pc_channels=5, radar_cells=40)
-    pc = TrainGraph(m).pointnet2(xp.to(dev))
+    tg = TrainGraph(m)
+    pc = tg.pointnet2(xp.to(dev))
+    tg.flush_counters()
     g = torch.Generator().manual_seed(2)
     cot = torch.randn(pc.shape, generator=g)
     (pc * cot.to(dev)).sum().backward()

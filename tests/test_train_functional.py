@@ -95,6 +95,9 @@ def _cases(dev):
     for k in (3, 5, 7, 9):
         yield f'dwconv k{k}', (lambda k=k: _check(TF.dwconv, lambda x, w, b: F.conv2d(x, w, b, 1, k // 2, groups=x.shape[1]),
                                                    [(_r(2, 6, 10, 9), True), (_r(6, 1, k, k, seed=1, scale=0.3), True), (_r(6, seed=2), True)], dev))
+    for k in (3, 5, 7, 9):            # W a multiple of four: the four-outputs-per-thread kernel (forward and, with mirrored taps, the input gradient); W = 4 is narrower than the 9-tap window
+        yield f'dwconv k{k} quad', (lambda k=k: _check(TF.dwconv, lambda x, w, b: F.conv2d(x, w, b, 1, k // 2, groups=x.shape[1]),
+                                                        [(_r(2, 5, 7, 12 if k < 9 else 4), True), (_r(5, 1, k, k, seed=1, scale=0.3), True), (_r(5, seed=2), True)], dev))
     yield 'dwconv k3 sliced', lambda: _check(TF.dwconv, lambda x, w, b: F.conv2d(x, w, b, 1, 1, groups=x.shape[1]),                  # weight gradient in 2 slices
                                             [(_r(2, 4, 100, 100), True), (_r(4, 1, 3, 3, seed=1, scale=0.3), True), (_r(4, seed=2), True)], dev)
     yield 'bmm_nt', lambda: _check(TF.bmm_nt, lambda a, b: a @ b.transpose(1, 2), [(_r(5, 12, 70), True), (_r(5, 9, 70, seed=1), True)], dev)
