@@ -46,7 +46,8 @@ for step in range(a.steps + 1):
     sync(); times.append(time.time() - t0)
     losses.append(float(loss.detach()))
 native = {'what': 'training step EN-GDF-PN-S0 fp32, native forward/backward kernels + torch SGD', 'batch': a.batch, 'resolution': a.resolution,
-                  'ms_per_step': round(1e3 * sorted(times[1:])[(len(times) - 1) // 2], 2), 'frames_per_s': round(a.batch / sorted(times[1:])[(len(times) - 1) // 2], 1),
+                  'ms_per_step': round(1e3 * sorted(times[1:])[(len(times) - 2) // 2], 2), 'frames_per_s': round(a.batch / sorted(times[1:])[(len(times) - 2) // 2], 1),
+                  'ms_best_step': round(1e3 * min(times[1:]), 2),
                   'ms_steps': [round(1e3 * t, 1) for t in times],          # step 0 = first call (allocations, plan); ms_per_step = the MEDIAN of the others (a step that hits an allocator stall is an outlier of 2x)
                   'loss': [round(v, 5) for v in losses], 'peak_mem_GB': round(torch.cuda.max_memory_allocated() / 2**30, 2) if a.device != 'cpu' else None}
 print(json.dumps(native))
@@ -89,6 +90,6 @@ if a.baseline:
         opt2.step()
         sync(); t2.append(time.time() - t0)
     print(json.dumps({'what': 'the same step as a torch-op composite (oracle graph, torch autograd, torch SGD) on the same device', 'batch': a.batch,
-                      'ms_per_step': round(1e3 * sorted(t2[1:])[(len(t2) - 1) // 2], 2), 'frames_per_s': round(a.batch / sorted(t2[1:])[(len(t2) - 1) // 2], 1),
+                      'ms_per_step': round(1e3 * sorted(t2[1:])[(len(t2) - 2) // 2], 2), 'frames_per_s': round(a.batch / sorted(t2[1:])[(len(t2) - 2) // 2], 1),
                       'ms_steps': [round(1e3 * t, 1) for t in t2],
-                      'native_over_torch_composite': round(sorted(t2[1:])[(len(t2) - 1) // 2] / (native['ms_per_step'] * 1e-3), 2)}))
+                      'native_over_torch_composite': round(sorted(t2[1:])[(len(t2) - 2) // 2] / (native['ms_per_step'] * 1e-3), 2)}))
