@@ -194,6 +194,8 @@ static __global__ __launch_bounds__(256) void train_gemm_reduce_kernel(const Tra
 // Walking the (B, N) positions of ONE channel of a [B, C, N] tensor with a stride of 256: position i = b N + n.  The kernels below used to form
 // ((i / N) * C + c) * N + i % N per element — two 64-bit divisions (~200 instructions on this target, which has no integer divider) for one to three loads;
 // the reductions were 16 % of a batch-32 training step.  One division at the start, then n += 256 with a carry into b.
+// positions per slice of a channel's (B, N) range cut into S slices: whole quads when N is a multiple of four (the quad walks below); trailing slices may then be empty
+__host__ __device__ __forceinline__ long bn_slice_len(long total, int S, int N) { const long per = (total + S - 1) / S; return (N & 3) == 0 ? ((per + 3) & ~3L) : per; }
 struct BnWalk {
     long b; int n, N;
     __device__ __forceinline__ BnWalk(long i, int N_) : b(i / N_), n(int(i - (i / N_) * N_)), N(N_) {}
@@ -261,10 +263,14 @@ static __global__ __launch_bounds__(256) void train_bn_slice2_kernel(const BnSli
     __shared__ float red[256];
     __shared__ float s_mean;
     const int c = blockIdx.x, sl = blockIdx.y;
-    const long total = long(p.B) * p.N, per = (total + p.S - 1) / p.S;
-    const long lo = long(sl) * per, hi = lo + per < total ? lo + per : total;
+    const long total = long(p.B) * p.N, per = bn_slice_len(total, p.S, p.N);
+    const long lo = long(sl) * per < total ? long(sl) * per : total, hi = lo + per < total ? lo + per : total;
     float a = 0.f;
-    { BnWalk w(lo + threadIdx.x, p.N); for (long i = lo + threadIdx.x; i < hi; i += 256, w.step()) a += p.Z[w.offset(p.C, c)]; }
+    const bool quad = (p.N & 3) == 0 && (lo & 3) == 0 && (hi & 3) == 0;          // four positions per step, 16-byte loads (see train_bn_relu_bwd_reduce_kernel)
+    if (quad) {
+        BnWalk w((lo >> 2) + threadIdx.x, p.N >> 2);
+        for (long i = (lo >> 2) + threadIdx.x; i < (hi >> 2); i += 256, w.step()) { const float4 z = *reinterpret_cast<const float4*>(p.Z + (w.b * p.C + c) * long(p.N) + 4L * w.n); a += (z.x + z.y) + (z.z + z.w); }
+    } else { BnWalk w(lo + threadIdx.x, p.N); for (long i = lo + threadIdx.x; i < hi; i += 256, w.step()) a += p.Z[w.offset(p.C, c)]; }
     red[threadIdx.x] = a;
     __syncthreads();
     for (int st = 128; st >= 1; st >>= 1) { if (int(threadIdx.x) < st) red[threadIdx.x] += red[threadIdx.x + st]; __syncthreads(); }
@@ -272,7 +278,14 @@ static __global__ __launch_bounds__(256) void train_bn_slice2_kernel(const BnSli
     __syncthreads();
     const float m = s_mean;
     float q = 0.f;
-    { BnWalk w(lo + threadIdx.x, p.N); for (long i = lo + threadIdx.x; i < hi; i += 256, w.step()) { const float d = p.Z[w.offset(p.C, c)] - m; q += d * d; } }
+    if (quad) {
+        BnWalk w((lo >> 2) + threadIdx.x, p.N >> 2);
+        for (long i = (lo >> 2) + threadIdx.x; i < (hi >> 2); i += 256, w.step()) {
+            const float4 z = *reinterpret_cast<const float4*>(p.Z + (w.b * p.C + c) * long(p.N) + 4L * w.n);
+            const float d0 = z.x - m, d1 = z.y - m, d2 = z.z - m, d3 = z.w - m;
+            q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        }
+    } else { BnWalk w(lo + threadIdx.x, p.N); for (long i = lo + threadIdx.x; i < hi; i += 256, w.step()) { const float d = p.Z[w.offset(p.C, c)] - m; q += d * d; } }
     __syncthreads();
     red[threadIdx.x] = q;
     __syncthreads();
@@ -282,13 +295,13 @@ static __global__ __launch_bounds__(256) void train_bn_slice2_kernel(const BnSli
 static __global__ __launch_bounds__(256) void train_bn_slice2_finalize_kernel(const BnSliceParams p) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= p.C) return;
-    const long total = long(p.B) * p.N, per = (total + p.S - 1) / p.S;
+    const long total = long(p.B) * p.N, per = bn_slice_len(total, p.S, p.N);
     float sum = 0.f;
     for (int j = 0; j < p.S; ++j) sum += p.ws[long(c) * p.S + j];
     const float mean = sum / float(total);
     float m2 = 0.f;
     for (int j = 0; j < p.S; ++j) {
-        const long lo = long(j) * per, hi = lo + per < total ? lo + per : total;
+        const long lo = long(j) * per < total ? long(j) * per : total, hi = lo + per < total ? lo + per : total;
         if (hi <= lo) continue;
         const float nj = float(hi - lo), dm = p.ws[long(c) * p.S + j] / nj - mean;
         m2 += p.ws[(long(p.C) + c) * p.S + j] + nj * dm * dm;
@@ -350,14 +363,27 @@ static __global__ __launch_bounds__(256) void train_bn_relu_bwd_reduce_kernel(co
     __shared__ float r0[256], r1[256];
     const int c = blockIdx.x;
     const long total = long(p.B) * p.N;
-    const long per = p.S > 1 ? (total + p.S - 1) / p.S : total, lo = p.S > 1 ? long(blockIdx.y) * per : 0, hi = lo + per < total ? lo + per : total;
+    const long per = p.S > 1 ? bn_slice_len(total, p.S, p.N) : total, lo0 = p.S > 1 ? long(blockIdx.y) * per : 0, lo = lo0 < total ? lo0 : total, hi = lo + per < total ? lo + per : total;
     const float mean = p.mean[c], rstd = 1.0f / sqrtf(p.var[c] + p.eps);
     float sb = 0.f, sg = 0.f;
+    if ((p.N & 3) == 0 && (lo & 3) == 0 && (hi & 3) == 0) {
+        // four positions per step with 16-byte loads (N and the slice bounds are multiples of four: a quad never straddles a sample): a quarter of the load instructions, four
+        // times the bytes in flight per thread — this reduction reads three tensors and was at 2.6 TB/s with scalar loads
+        BnWalk w((lo >> 2) + threadIdx.x, p.N >> 2);
+        for (long i = (lo >> 2) + threadIdx.x; i < (hi >> 2); i += 256, w.step()) {
+            const long o = (w.b * p.C + c) * long(p.N) + 4L * w.n;
+            const float4 z = *reinterpret_cast<const float4*>(p.Z + o), y = *reinterpret_cast<const float4*>(p.Y + o), d = *reinterpret_cast<const float4*>(p.dY + o);
+            const float zi[4] = {z.x, z.y, z.z, z.w}, yi[4] = {y.x, y.y, y.z, y.w}, di[4] = {d.x, d.y, d.z, d.w};
+            ACH_UNROLL
+            for (int q = 0; q < 4; ++q) { const float g = (p.relu && !(yi[q] > 0.f)) ? 0.f : di[q]; sb += g; sg += g * ((zi[q] - mean) * rstd); }
+        }
+    } else {
     BnWalk w(lo + threadIdx.x, p.N);
     for (long i = lo + threadIdx.x; i < hi; i += 256, w.step()) {
         const long o = w.offset(p.C, c);
         const float g = (p.relu && !(p.Y[o] > 0.f)) ? 0.f : p.dY[o];
         sb += g; sg += g * ((p.Z[o] - mean) * rstd);
+    }
     }
     r0[threadIdx.x] = sb; r1[threadIdx.x] = sg;
     __syncthreads();

@@ -242,41 +242,11 @@ static __global__ __launch_bounds__(256) void train_dwconv_wgrad_taps_kernel(con
     __shared__ float part[4][KK];
     const int c = blockIdx.x;
     const unsigned hw = unsigned(p.H) * unsigned(p.W), total = unsigned(p.B) * hw;
-    const unsigned per0 = p.S > 1 ? (total + unsigned(p.S) - 1) / unsigned(p.S) : total;
-    const unsigned per = (p.W & 3) == 0 ? ((per0 + 3u) & ~3u) : per0;          // (slices of whole quads when W is a multiple of four: see the quad walk below; trailing slices may be empty)
-    const unsigned lo = p.S > 1 ? blockIdx.y * per : 0u, hi = lo >= total ? lo : ((lo + per < total) ? lo + per : total);
+    const unsigned per = p.S > 1 ? (total + unsigned(p.S) - 1) / unsigned(p.S) : total, lo = p.S > 1 ? blockIdx.y * per : 0u, hi = (lo + per < total) ? lo + per : total;
     float acc[KK];
     ACH_UNROLL
     for (int t = 0; t < KK; ++t) acc[t] = 0.f;
-    if ((p.W & 3) == 0 && (per & 3) == 0) {
-        // four consecutive positions of a row per step (W and the slice length are multiples of four, so a quad never straddles a row or a slice): two index divisions and
-        // K (K + 3) loads of x per four positions instead of eight and 4 K K
-        const unsigned wq = unsigned(p.W) >> 2, hwq = hw >> 2;
-        for (unsigned e4 = (lo >> 2) + threadIdx.x; e4 < (hi >> 2); e4 += 256) {
-            const unsigned b = e4 / hwq, q = e4 - b * hwq;
-            const int oy = int(q / wq), ox = int(q - unsigned(oy) * wq) * 4;
-            const float* xc = p.x + (long(b) * p.C + c) * long(hw);
-            const float4 g4 = *reinterpret_cast<const float4*>(p.dz + (long(b) * p.C + c) * long(hw) + long(oy) * p.W + ox);
-            const float g[4] = {g4.x, g4.y, g4.z, g4.w};
-            ACH_UNROLL
-            for (int ky = 0; ky < K; ++ky) {
-                const int iy = oy + ky - R;
-                if (iy < 0 || iy >= p.H) continue;
-                const float* xr = xc + long(iy) * p.W;
-                float v[K + 3];
-                ACH_UNROLL
-                for (int j = 0; j < K + 3; ++j) {
-                    const int ix = ox + j - R;
-                    const float t = xr[ix < 0 ? 0 : (ix >= p.W ? p.W - 1 : ix)];
-                    v[j] = (ix >= 0 && ix < p.W) ? t : 0.f;
-                }
-                ACH_UNROLL
-                for (int kx = 0; kx < K; ++kx)
-                    ACH_UNROLL
-                    for (int i = 0; i < 4; ++i) acc[ky * K + kx] += g[i] * v[kx + i];
-            }
-        }
-    } else
+    // (a four-positions-per-step walk — K (K + 3) loads of x per four positions instead of 4 K K — was measured SLOWER here: 89 us per call against 70)
     for (unsigned e = lo + threadIdx.x; e < hi; e += 256) {
         const unsigned b = e / hw, pix = e - b * hw;
         const int oy = int(pix / unsigned(p.W)), ox = int(pix - unsigned(oy) * unsigned(p.W));
