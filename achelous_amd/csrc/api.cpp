@@ -459,7 +459,9 @@ int ach_train_act(const float* x, const float* dy, float* out, int64_t n, int32_
     return train_guard([&] {
         train_need(x && out && n > 0 && kind >= 0 && kind <= 3, "ach_train_act");
         ach::TrainActParams p{x, dy, out, long(n), kind};
-        ACH_TRAIN_1D(ach::train_act_kernel, p, long(n));
+        const bool quad = (n & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(out)) & 15u) == 0;
+        if (quad) ACH_TRAIN_1D(ach::train_act4_kernel, p, long(n) / 4);
+        else ACH_TRAIN_1D(ach::train_act_kernel, p, long(n));
     });
 }
 int ach_train_mul(const float* a, const float* b, float* out, int64_t n, void* stream) {

@@ -176,15 +176,23 @@ static __global__ __launch_bounds__(256) void train_gemm_kernel(const TrainGemmP
 // C = [C +] bias + sum_z ws[z].  One 16-lane group per output element: lane j sums z = j, j + 16, ... (ascending), then the group
 // folds 16 -> 1 in a fixed butterfly: a deterministic order, and 16 partial loads in flight per element instead of one thread walking
 // up to 512 strided partials (that version took 35-120 us per weight gradient: 10 % of a training step).
+// (Round 5: the 16 partial-sum walkers of an element used to be the 16 LANES of a group — 16 gathers of 4 bytes a step; now thread (j, e) of the workgroup walks z = j, j + 16, ... for
+//  element i0 + e, so a 16-lane group reads 64 contiguous bytes, and the 16 walkers of an element meet in LDS.  The same sums in the same order: bit-identical.)
 static __global__ __launch_bounds__(256) void train_gemm_reduce_kernel(const TrainGemmParams p) {
-    const long i = long(blockIdx.x) * 16 + (threadIdx.x >> 4);
-    const int j = threadIdx.x & 15;
+    __shared__ float red[16][17];
+    const int e = threadIdx.x & 15, j = threadIdx.x >> 4;
+    const long i = long(blockIdx.x) * 16 + e;
     const long MN = long(p.M) * p.N;
     float v = 0.f;
     if (i < MN)
         for (int z = j; z < p.ksplit; z += 16) v += p.ws[long(z) * MN + i];
-    v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
-    if (i >= MN || j != 0) return;
+    red[j][e] = v;
+    __syncthreads();
+    if (j != 0 || i >= MN) return;
+    float a[8];
+    ACH_UNROLL
+    for (int q = 0; q < 8; ++q) a[q] = red[q][e] + red[q + 8][e];                     // the butterfly's xor-8 step ...
+    v = ((a[0] + a[4]) + (a[2] + a[6])) + ((a[1] + a[5]) + (a[3] + a[7]));            // ... and its xor-4, xor-2, xor-1 steps as lane 0 saw them
     const int gm = int(i / p.N), gn = int(i - long(gm) * p.N);
     v += p.bias ? p.bias[gm] : 0.f;
     float* c = p.C + long(gm) * p.ldc + gn;

@@ -31,18 +31,30 @@ __device__ __forceinline__ long tdiv(long i, long d) { return ((static_cast<unsi
 // ------------------------------------------------------------------------------------------ activations
 // kind 0 ReLU, 1 SiLU, 2 GELU (erf form, nn.GELU default), 3 sigmoid.  dy == nullptr: out = f(x); else out = dy * f'(x).
 struct TrainActParams { const float* x; const float* dy; float* out; long n; int kind; };
-static __global__ __launch_bounds__(256) void train_act_kernel(const TrainActParams p) {
-    const long i = long(blockIdx.x) * 256 + threadIdx.x;
-    if (i >= p.n) return;
-    const float x = p.x[i];
+__device__ __forceinline__ float train_act_value(float x, float dy, bool bwd, int kind) {
     float f, d;
-    if (p.kind == 0) { f = x > 0.f ? x : 0.f; d = x > 0.f ? 1.f : 0.f; }
-    else if (p.kind == 1) { const float s = 1.f / (1.f + expf(-x)); f = x * s; d = s * (1.f + x * (1.f - s)); }
-    else if (p.kind == 2) {
+    if (kind == 0) { f = x > 0.f ? x : 0.f; d = x > 0.f ? 1.f : 0.f; }
+    else if (kind == 1) { const float s = 1.f / (1.f + expf(-x)); f = x * s; d = s * (1.f + x * (1.f - s)); }
+    else if (kind == 2) {
         const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
         f = x * cdf; d = cdf + x * 0.3989422804014327f * expf(-0.5f * x * x);
     } else { const float s = 1.f / (1.f + expf(-x)); f = s; d = s * (1.f - s); }
-    p.out[i] = p.dy ? p.dy[i] * d : f;
+    return bwd ? dy * d : f;
+}
+static __global__ __launch_bounds__(256) void train_act_kernel(const TrainActParams p) {
+    const long i = long(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= p.n) return;
+    p.out[i] = train_act_value(p.x[i], p.dy ? p.dy[i] : 0.f, p.dy != nullptr, p.kind);
+}
+// four elements per thread with 16-byte accesses (n a multiple of four, 16-byte aligned tensors: every activation map of the model)
+static __global__ __launch_bounds__(256) void train_act4_kernel(const TrainActParams p) {
+    const long i = (long(blockIdx.x) * 256 + threadIdx.x) * 4;
+    if (i >= p.n) return;
+    const float4 x = *reinterpret_cast<const float4*>(p.x + i);
+    const float4 g = p.dy ? *reinterpret_cast<const float4*>(p.dy + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool bwd = p.dy != nullptr;
+    *reinterpret_cast<float4*>(p.out + i) = make_float4(train_act_value(x.x, g.x, bwd, p.kind), train_act_value(x.y, g.y, bwd, p.kind),
+                                                        train_act_value(x.z, g.z, bwd, p.kind), train_act_value(x.w, g.w, bwd, p.kind));
 }
 
 // element-wise product (gates that are full tensors: shuffle_attention.py:66); its backward is the same kernel with the other factor
