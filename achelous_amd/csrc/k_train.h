@@ -200,7 +200,7 @@ static __global__ __launch_bounds__(256) void train_gemm_reduce_kernel(const Tra
 }
 
 // Walking the (B, N) positions of ONE channel of a [B, C, N] tensor with a stride of 256: position i = b N + n.  The kernels below used to form
-// ((i / N) * C + c) * N + i % N per element — two 64-bit divisions (~200 instructions on this target, which has no integer divider) for one to three loads;
+// ((i / N) * C + c) * N + i % N per element — two 64-bit divisions (dozens of instructions each on this target, which has no integer divider, even through the compiler's 32-bit bypass) for one to three loads;
 // the reductions were 16 % of a batch-32 training step.  One division at the start, then n += 256 with a carry into b.
 // positions per slice of a channel's (B, N) range cut into S slices: whole quads when N is a multiple of four (the quad walks below); trailing slices may then be empty
 __host__ __device__ __forceinline__ long bn_slice_len(long total, int S, int N) { const long per = (total + S - 1) / S; return (N & 3) == 0 ? ((per + 3) & ~3L) : per; }

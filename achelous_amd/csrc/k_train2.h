@@ -24,7 +24,7 @@ __device__ __forceinline__ float block_sum_256(float v, float* sh) {       // sh
     return r;
 }
 
-// i / d for index arithmetic: 32-bit division where both fit (this target has no integer divider: a 64-bit division is ~200 instructions, a 32-bit one ~30;
+// i / d for index arithmetic: 32-bit division where both fit (this target has no integer divider: a 64-bit division is a long sequence even through the compiler's run-time 32-bit bypass, a 32-bit one ~30 instructions;
 // the one-thread-per-element kernels below split their linear index three to five times per element)
 __device__ __forceinline__ long tdiv(long i, long d) { return ((static_cast<unsigned long>(i) | static_cast<unsigned long>(d)) >> 32) == 0 ? long(unsigned(i) / unsigned(d)) : i / d; }
 
