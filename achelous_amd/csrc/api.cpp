@@ -476,7 +476,9 @@ int ach_train_layernorm(const float* x, const float* gamma, const float* beta, f
     return train_guard([&] {
         train_need(x && gamma && beta && y && mean && rstd && rows > 0 && C > 0 && inner > 0, "ach_train_layernorm");
         ach::TrainLnParams p{x, gamma, beta, y, mean, rstd, long(rows), C, long(inner), eps};
-        ACH_TRAIN_1D(ach::train_ln_fwd_kernel, p, long(rows) * inner);
+        const bool quad = (inner & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(mean) | reinterpret_cast<uintptr_t>(rstd)) & 15u) == 0;
+        if (quad) ACH_TRAIN_1D(ach::train_ln_fwd4_kernel, p, long(rows) * (inner / 4));
+        else ACH_TRAIN_1D(ach::train_ln_fwd_kernel, p, long(rows) * inner);
     });
 }
 int ach_train_layernorm_bwd(const float* x, const float* dy, const float* gamma, const float* mean, const float* rstd, float* dx, float* dgamma, float* dbeta,
@@ -484,7 +486,9 @@ int ach_train_layernorm_bwd(const float* x, const float* dy, const float* gamma,
     return train_guard([&] {
         train_need(x && dy && gamma && mean && rstd && dx && dgamma && dbeta && rows > 0 && C > 0 && inner > 0, "ach_train_layernorm_bwd");
         ach::TrainLnBwdParams p{x, dy, gamma, mean, rstd, dx, dgamma, dbeta, long(rows), C, long(inner), 1, nullptr};
-        ACH_TRAIN_1D(ach::train_ln_bwd_dx_kernel, p, long(rows) * inner);
+        const bool quad = (inner & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(mean) | reinterpret_cast<uintptr_t>(rstd)) & 15u) == 0;
+        if (quad) ACH_TRAIN_1D(ach::train_ln_bwd_dx4_kernel, p, long(rows) * (inner / 4));
+        else ACH_TRAIN_1D(ach::train_ln_bwd_dx_kernel, p, long(rows) * inner);
         p.S = train_slices(long(rows) * inner, C);
         if (p.S > 1) p.ws = train_workspace(size_t(2) * C * p.S * sizeof(float));
         ACH_LAUNCH(ach::train_ln_bwd_param_kernel, dim3(unsigned(C), unsigned(p.S)), dim3(256), static_cast<hipStream_t>(stream), p);

@@ -223,7 +223,9 @@ static __global__ __launch_bounds__(256) void train_bn_stats_kernel(const BnStat
     const int c = blockIdx.x;
     const long total = long(p.B) * p.N;
     float s = 0.f;
-    { BnWalk w(threadIdx.x, p.N); for (long i = threadIdx.x; i < total; i += 256, w.step()) s += p.Z[w.offset(p.C, c)]; }
+    const bool quad = (p.N & 3) == 0;                 // four positions per step, 16-byte loads (see train_bn_relu_bwd_reduce_kernel)
+    if (quad) { BnWalk w(threadIdx.x, p.N >> 2); for (long i = threadIdx.x; i < (total >> 2); i += 256, w.step()) { const float4 z = *reinterpret_cast<const float4*>(p.Z + (w.b * p.C + c) * long(p.N) + 4L * w.n); s += (z.x + z.y) + (z.z + z.w); } }
+    else { BnWalk w(threadIdx.x, p.N); for (long i = threadIdx.x; i < total; i += 256, w.step()) s += p.Z[w.offset(p.C, c)]; }
     red[threadIdx.x] = s;
     __syncthreads();
     for (int st = 128; st >= 1; st >>= 1) { if (int(threadIdx.x) < st) red[threadIdx.x] += red[threadIdx.x + st]; __syncthreads(); }
@@ -231,7 +233,14 @@ static __global__ __launch_bounds__(256) void train_bn_stats_kernel(const BnStat
     __syncthreads();
     const float mean = s_mean;
     float q = 0.f;
-    { BnWalk w(threadIdx.x, p.N); for (long i = threadIdx.x; i < total; i += 256, w.step()) { const float d = p.Z[w.offset(p.C, c)] - mean; q += d * d; } }
+    if (quad) {
+        BnWalk w(threadIdx.x, p.N >> 2);
+        for (long i = threadIdx.x; i < (total >> 2); i += 256, w.step()) {
+            const float4 z = *reinterpret_cast<const float4*>(p.Z + (w.b * p.C + c) * long(p.N) + 4L * w.n);
+            const float d0 = z.x - mean, d1 = z.y - mean, d2 = z.z - mean, d3 = z.w - mean;
+            q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        }
+    } else { BnWalk w(threadIdx.x, p.N); for (long i = threadIdx.x; i < total; i += 256, w.step()) { const float d = p.Z[w.offset(p.C, c)] - mean; q += d * d; } }
     __syncthreads();
     red[threadIdx.x] = q;
     __syncthreads();

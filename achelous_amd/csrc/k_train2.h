@@ -83,6 +83,36 @@ static __global__ __launch_bounds__(256) void train_ln_fwd_kernel(const TrainLnP
     for (int c = 0; c < p.C; ++c) y[c * p.inner] = (x[c * p.inner] - m) * rs * p.gamma[c] + p.beta[c];
     p.mean[gidx] = m; p.rstd[gidx] = rs;
 }
+// the same with four consecutive `inner` positions per thread and 16-byte accesses (inner a multiple of four: every channels-first map of the model)
+static __global__ __launch_bounds__(256) void train_ln_fwd4_kernel(const TrainLnParams p) {
+    const long q = long(blockIdx.x) * 256 + threadIdx.x, iq = p.inner >> 2;
+    if (q >= p.rows * iq) return;
+    const long r = tdiv(q, iq), i = (q - r * iq) * 4;
+    const float* x = p.x + r * p.C * p.inner + i;
+    float m[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < p.C; ++c) { const float4 t = *reinterpret_cast<const float4*>(x + c * p.inner); m[0] += t.x; m[1] += t.y; m[2] += t.z; m[3] += t.w; }
+    ACH_UNROLL
+    for (int k = 0; k < 4; ++k) m[k] /= float(p.C);
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < p.C; ++c) {
+        const float4 t = *reinterpret_cast<const float4*>(x + c * p.inner);
+        const float d0 = t.x - m[0], d1 = t.y - m[1], d2 = t.z - m[2], d3 = t.w - m[3];
+        v[0] += d0 * d0; v[1] += d1 * d1; v[2] += d2 * d2; v[3] += d3 * d3;
+    }
+    float rs[4];
+    ACH_UNROLL
+    for (int k = 0; k < 4; ++k) rs[k] = 1.f / sqrtf(v[k] / float(p.C) + p.eps);
+    float* y = p.y + r * p.C * p.inner + i;
+    for (int c = 0; c < p.C; ++c) {
+        const float4 t = *reinterpret_cast<const float4*>(x + c * p.inner);
+        const float g = p.gamma[c], b = p.beta[c];
+        *reinterpret_cast<float4*>(y + c * p.inner) = make_float4((t.x - m[0]) * rs[0] * g + b, (t.y - m[1]) * rs[1] * g + b, (t.z - m[2]) * rs[2] * g + b, (t.w - m[3]) * rs[3] * g + b);
+    }
+    const long gidx = r * p.inner + i;
+    *reinterpret_cast<float4*>(p.mean + gidx) = make_float4(m[0], m[1], m[2], m[3]);
+    *reinterpret_cast<float4*>(p.rstd + gidx) = make_float4(rs[0], rs[1], rs[2], rs[3]);
+}
+
 struct TrainLnBwdParams { const float* x; const float* dy; const float* gamma; const float* mean; const float* rstd; float* dx; float* dgamma; float* dbeta;
                           long rows; int C; long inner;
                           int S; float* ws; };     // S > 1: the parameter gradients' (rows, inner) range in S slices (grid C x S), partials in ws [2][C][S], summed in order by the finalize kernel
@@ -101,6 +131,33 @@ static __global__ __launch_bounds__(256) void train_ln_bwd_dx_kernel(const Train
     for (int c = 0; c < p.C; ++c) {
         const float g = p.dy[base + c * p.inner] * p.gamma[c], xh = (p.x[base + c * p.inner] - m) * rs;
         p.dx[base + c * p.inner] = rs * (g - s1 - xh * s2);
+    }
+}
+static __global__ __launch_bounds__(256) void train_ln_bwd_dx4_kernel(const TrainLnBwdParams p) {      // (four `inner` positions per thread: see train_ln_fwd4_kernel)
+    const long q = long(blockIdx.x) * 256 + threadIdx.x, iq = p.inner >> 2;
+    if (q >= p.rows * iq) return;
+    const long r = tdiv(q, iq), i = (q - r * iq) * 4;
+    const long base = r * p.C * p.inner + i, gidx = r * p.inner + i;
+    const float4 m4 = *reinterpret_cast<const float4*>(p.mean + gidx), r4 = *reinterpret_cast<const float4*>(p.rstd + gidx);
+    const float m[4] = {m4.x, m4.y, m4.z, m4.w}, rs[4] = {r4.x, r4.y, r4.z, r4.w};
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < p.C; ++c) {
+        const float4 d = *reinterpret_cast<const float4*>(p.dy + base + c * p.inner), x = *reinterpret_cast<const float4*>(p.x + base + c * p.inner);
+        const float gm = p.gamma[c];
+        const float dv[4] = {d.x, d.y, d.z, d.w}, xv[4] = {x.x, x.y, x.z, x.w};
+        ACH_UNROLL
+        for (int k = 0; k < 4; ++k) { const float g = dv[k] * gm, xh = (xv[k] - m[k]) * rs[k]; s1[k] += g; s2[k] += g * xh; }
+    }
+    ACH_UNROLL
+    for (int k = 0; k < 4; ++k) { s1[k] /= float(p.C); s2[k] /= float(p.C); }
+    for (int c = 0; c < p.C; ++c) {
+        const float4 d = *reinterpret_cast<const float4*>(p.dy + base + c * p.inner), x = *reinterpret_cast<const float4*>(p.x + base + c * p.inner);
+        const float gm = p.gamma[c];
+        const float dv[4] = {d.x, d.y, d.z, d.w}, xv[4] = {x.x, x.y, x.z, x.w};
+        float o[4];
+        ACH_UNROLL
+        for (int k = 0; k < 4; ++k) { const float g = dv[k] * gm, xh = (xv[k] - m[k]) * rs[k]; o[k] = rs[k] * (g - s1[k] - xh * s2[k]); }
+        *reinterpret_cast<float4*>(p.dx + base + c * p.inner) = make_float4(o[0], o[1], o[2], o[3]);
     }
 }
 // dgamma / dbeta: one workgroup per (channel, slice).  (Round 5: it was one workgroup per CHANNEL — 32 to 176 workgroups on a 256-CU chip — with a 64-bit division per element:
@@ -445,6 +502,15 @@ static __global__ __launch_bounds__(256) void train_row_reduce_kernel(const Trai
     __shared__ float sh[256];
     const long r = blockIdx.x;
     float v = 0.f;
+    if ((p.N & 3) == 0 && ((reinterpret_cast<uintptr_t>(p.a) | reinterpret_cast<uintptr_t>(p.b)) & 15u) == 0) {       // 16-byte loads (rows of a multiple of four floats)
+        const float4* a4 = reinterpret_cast<const float4*>(p.a + r * p.N);
+        const float4* b4 = p.b ? reinterpret_cast<const float4*>(p.b + r * p.N) : nullptr;
+        for (long i = threadIdx.x; i < (p.N >> 2); i += 256) {
+            const float4 a = a4[i];
+            if (b4) { const float4 b = b4[i]; v += (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w); }
+            else v += (a.x + a.y) + (a.z + a.w);
+        }
+    } else
     for (long i = threadIdx.x; i < p.N; i += 256) v += p.a[r * p.N + i] * (p.b ? p.b[r * p.N + i] : 1.f);
     v = block_sum_256(v, sh);
     if (threadIdx.x == 0) p.out[r] = v * p.scale;

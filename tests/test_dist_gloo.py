@@ -130,7 +130,7 @@ def test_zero_copy_record_requires_the_original_views():
 # rank 0's choice.  The engine itself needs a GPU; here a stand-in with the module's protocol (engine_options / reset_engines / submit_detect / forward_detect)
 # whose step time depends on the pattern AND on the rank: rank 1 alone would pick pattern 1, the slowest rank decides, so both must pick 2.
 class _FakeModel:
-    STEP_MS = {0: {3: 4.0, 2: 1.0, 1: 3.0}, 1: {3: 4.0, 2: 2.0, 1: 0.5}}
+    STEP_MS = {0: {3: 20.0, 2: 5.0, 1: 15.0}, 1: {3: 20.0, 2: 10.0, 1: 2.5}}          # (tens of milliseconds: on a loaded host — a parallel test run — the collective's own jitter is milliseconds)
 
     def __init__(self, rank, B, max_det):
         self.rank, self.B, self.max_det = rank, B, max_det
@@ -202,7 +202,7 @@ def test_sharded_detector_calibrates_side_priority_consistently_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok, _, _ in res), res
-    assert res[0][2] == res[1][2] == 2, res                      # max over ranks: {3: 4 ms, 2: 2 ms, 1: 3 ms} per step
+    assert res[0][2] == res[1][2] == 2, res                      # max over ranks: {3: 20 ms, 2: 10 ms, 1: 15 ms} per step
     assert res[0][3] == res[1][3], res                           # both ranks hold the same (max-reduced) table
 
 

@@ -75,6 +75,9 @@ def _cases(dev):
     yield 'layernorm_channels', lambda: _check(lambda x, g, b: TF.layernorm_channels(x, g, b, 1e-6),
                                                lambda x, g, b: F.layer_norm(x.permute(0, 2, 3, 1), (x.shape[1],), g, b, 1e-6).permute(0, 3, 1, 2),
                                                [(_r(2, 24, 5, 7), True), (_r(24, seed=1) + 1, True), (_r(24, seed=2), True)], dev)
+    yield 'layernorm_channels quad', lambda: _check(lambda x, g, b: TF.layernorm_channels(x, g, b, 1e-6),              # H * W a multiple of four: the four-positions-per-thread kernels
+                                                    lambda x, g, b: F.layer_norm(x.permute(0, 2, 3, 1), (x.shape[1],), g, b, 1e-6).permute(0, 3, 1, 2),
+                                                    [(_r(3, 20, 6, 10), True), (_r(20, seed=1) + 1, True), (_r(20, seed=2), True)], dev)
     yield 'instance_norm', lambda: _check(lambda x, g, b: TF.instance_norm(x, g, b, 1e-5), lambda x, g, b: F.group_norm(x, x.shape[1], g, b, 1e-5),
                                           [(_r(3, 6, 5, 7), True), (_r(6, seed=1) + 1, True), (_r(6, seed=2), True)], dev)
     yield 'l2_normalize', lambda: _check(TF.l2_normalize_last, lambda x: F.normalize(x, dim=-1), [(_r(2, 4, 6, 50), True)], dev)
