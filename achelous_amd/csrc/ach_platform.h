@@ -141,7 +141,9 @@ __host__ __device__ __forceinline__ float f16hi_to_f32(uint32_t w) { return f16_
 // above saturates the same way, so the CPU emulation and the weight packers agree with the device.
 template <class T> __device__ __forceinline__ void f16_sat_mode() {
 #if defined(__HIP_DEVICE_COMPILE__)
+#if !defined(ACH_NO_F16_OVFL)                                                                                  // (experiments only: the mode left clear)
     if constexpr (std::is_same<T, f16_t>::value) __builtin_amdgcn_s_setreg((0 << 11) | (23 << 6) | 1, 1);      // hwreg(HW_REG_MODE, 23, 1) = 1
+#endif
 #endif
 }
 
@@ -327,9 +329,24 @@ template <class T> __device__ inline void mfma16(const uint4& a, const uint4& b,
 }
 #else
 typedef __bf16 bf16x8_hw __attribute__((ext_vector_type(8)));
+// Round 6: the shipped library contains NO v_mfma_f32_16x16x32_{f16,bf16}: every 16-bit k-chunk is two 16x16x16 instructions (the same products, the same matrix-pipe time).
+// profiles/r06_coresidency/ffn2_*_table.txt: with two waves of one SIMD interleaving matrix instructions, one of them the 16x16x32 form, whole 16-row tiles of EITHER wave come
+// out wrong run to run — also when the victim only issues 16x16x16 pairs, also with 48 wait states behind every matrix instruction of the victim (so it is not a software hazard
+// inside a wave), never with one wave per SIMD, never when no wave issues the 16x16x32 form.  The plans run three streams on the same compute units, so no kernel may issue it
+// (tests/test_abi_and_host.py checks the ISA of both 16-bit engines).  0 = the one-instruction form (variant builds / measurements only; it measured +1.8 % on EN-S0 in round 5).
 #ifndef ACH_MFMA16_SPLIT
-#define ACH_MFMA16_SPLIT 0         // experiments (tests/gpu_coresidency_repro.py): 1 = every 16-bit k-chunk as two 16x16x16 instructions instead of one 16x16x32
+#define ACH_MFMA16_SPLIT 1
 #endif
+// ACH_MFMA_NOP_AFTER (experiments, profiles/scripts/ffn2_bisect.sh): 48 wait states behind every matrix instruction issued through mfma16 / mfma16_pair — a whole
+// 8-pass instruction has left the pipe before the wave issues anything else
+#ifndef ACH_MFMA_NOP_AFTER
+#define ACH_MFMA_NOP_AFTER 0
+#endif
+__device__ __forceinline__ void mfma_nop_after(f32x4& c) {
+#if ACH_MFMA_NOP_AFTER
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(c));
+#endif
+}
 template <> __device__ __forceinline__ void mfma16<bf16_t>(const uint4& a, const uint4& b, f32x4& c) {
 #if ACH_MFMA16_SPLIT
     typedef short s16x4_hw __attribute__((ext_vector_type(4)));
@@ -338,6 +355,7 @@ template <> __device__ __forceinline__ void mfma16<bf16_t>(const uint4& a, const
 #else
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_hw, a), __builtin_bit_cast(bf16x8_hw, b), c, 0, 0, 0);
 #endif
+    mfma_nop_after(c);
 }
 typedef _Float16 f16x8_hw __attribute__((ext_vector_type(8)));
 template <> __device__ __forceinline__ void mfma16<f16_t>(const uint4& a, const uint4& b, f32x4& c) {
@@ -348,6 +366,7 @@ template <> __device__ __forceinline__ void mfma16<f16_t>(const uint4& a, const 
 #else
     c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_hw, a), __builtin_bit_cast(f16x8_hw, b), c, 0, 0, 0);
 #endif
+    mfma_nop_after(c);
 }
 template <> __device__ __forceinline__ void mfma16<float>(const uint4& a, const uint4& b, f32x4& c) {
     c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
@@ -368,11 +387,13 @@ template <> __device__ __forceinline__ void mfma16_pair<bf16_t>(const uint4& a, 
     typedef short s16x4_p __attribute__((ext_vector_type(4)));
     c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4_p, make_uint2(a.x, a.y)), __builtin_bit_cast(s16x4_p, make_uint2(b.x, b.y)), c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4_p, make_uint2(a.z, a.w)), __builtin_bit_cast(s16x4_p, make_uint2(b.z, b.w)), c, 0, 0, 0);
+    mfma_nop_after(c);
 }
 template <> __device__ __forceinline__ void mfma16_pair<f16_t>(const uint4& a, const uint4& b, f32x4& c) {
     typedef _Float16 f16x4_p __attribute__((ext_vector_type(4)));
     c = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4_p, make_uint2(a.x, a.y)), __builtin_bit_cast(f16x4_p, make_uint2(b.x, b.y)), c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4_p, make_uint2(a.z, a.w)), __builtin_bit_cast(f16x4_p, make_uint2(b.z, b.w)), c, 0, 0, 0);
+    mfma_nop_after(c);
 }
 template <> __device__ __forceinline__ void mfma16_pair<float>(const uint4& a, const uint4& b, f32x4& c) { mfma16<float>(a, b, c); }
 #endif

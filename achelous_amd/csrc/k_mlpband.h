@@ -364,9 +364,12 @@ __global__ __launch_bounds__(MLPB_THREADS, 1) void mlp_band_run_kernel(const Mlp
     for (int i = 0; i < rp.n; ++i) {
         mlp_band_body<T, K1, DT, KS, RB, MAXW, XF32, PREF, false, true>(rp.blk[i], band, b, xin, dwv);        // (one instantiation: the first block's agent-scope loads are merely unnecessary)
         if (i + 1 == rp.n) break;
-        // this wave's rows of Y have reached L2 (the L1 is write-through; the frame's workgroups share an XCD, i.e. that L2: an AGENT-scope release would write the whole
-        // L2 back and the matching acquire would drop it — measured: 41.5 k -> 37.8 k frames/s) before the workgroup arrives
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        // AGENT-scope release / acquire (round 6): the rows must be visible to workgroups on OTHER compute units.  Round 5 used workgroup-scope fences on the argument
+        // that a frame's workgroups share an XCD's L2 (xcd_block) — but a workgroup-scope fence is not an acquire for another unit's data and workgroup -> XCD placement
+        // is not architecturally defined; it passed the bit-identity test and was a placement-dependent protocol all the same.  The agent-scope
+        // form costs the L2 write-back / invalidate (measured in round 5: 41.5 k -> 37.8 k frames/s), which is why the option stays OFF: kept as the correct statement
+        // of the experiment, not as a plan anyone should select.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __syncthreads();
         if (threadIdx.x == 0 && !(rp.blk[0].dbg & 32)) {          // (dbg 32 / 64: timing experiments — no barrier / plain halo loads; wrong results)
             const unsigned target = (rp.epoch * unsigned(rp.n - 1) + unsigned(i + 1)) * unsigned(bands);
@@ -377,7 +380,7 @@ __global__ __launch_bounds__(MLPB_THREADS, 1) void mlp_band_run_kernel(const Mlp
             }
         }
         __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");       // (ordering only: the next block's halo loads are agent-scope loads, see COH)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
 }
 template <class T>

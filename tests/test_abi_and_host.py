@@ -233,3 +233,17 @@ def test_no_inline_asm_result_feeds_a_matrix_instruction_in_the_shipped_kernels(
         blocks, findings = m.scan(os.path.join(csrc, 'build', tu))
         assert blocks > 100, (tu, blocks)               # the DPP adds / v_max of the row-walking kernels are there
         assert findings == [], findings[:5]
+
+
+def test_the_shipped_kernels_contain_no_16x16x32_matrix_instruction():
+    """DESIGN 4 (pair-form rule, round 6): a wave that issues v_mfma_f32_16x16x32_{f16,bf16} changes the results of OTHER waves' matrix instructions on the same SIMD
+    (profiles/r06_coresidency/); the plans overlap three streams, so the shipped 16-bit engines must not contain the instruction at all."""
+    import subprocess
+    csrc = os.path.join(REPO, 'achelous_amd', 'csrc')
+    if not os.path.exists('/opt/rocm/bin/hipcc'):
+        pytest.skip('no hipcc')
+    subprocess.run(['make', '-s', '-C', csrc, '-j2', 'isa'], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    for tu in ('engine_f16.s', 'engine_bf16.s'):
+        text = open(os.path.join(csrc, 'build', tu)).read()
+        assert text.count('v_mfma_f32_16x16x16') > 100, tu
+        assert 'v_mfma_f32_16x16x32' not in text, tu
