@@ -94,6 +94,7 @@ public:
                                       // normalised pixel is rounded to the storage type once, as the separate launch's output was)
     bool multi_stream = true;         // option "streams": run the independent radar / point branches on side streams
     int gemm_rows = 1;                // option "gemm_rows": 16-row sub-tiles per wave (1 / 2 / 4) for GEMMs with K >= 1024 (the dense 3x3 convs of MobileViT)
+    int xca_frame = 16;               // option "xca_frame": a whole XCA (qkv, Gram, softmax + fold, projection) as ONE launch with one workgroup of this many waves (8 / 16) per frame (k_xcaframe.h, 16-bit engines); 0 = four launches
     bool xca_mfma = true;             // option "xca_mfma": XCA Gram matrices on the matrix cores (xca_gram_mfma_kernel, k_xca.h); 0 = the VALU kernel
     bool dw_even = true;              // option "dw_even": SPLIT mlp_kernel deals depthwise tap ROWS, not whole k-steps, to its four waves (k_mlp.h)
     int radar_rows4 = 2;              // option "radar_rows4": a workgroup of rc_front owns four rows, one per wave (1: block 0 when radar_skip is on; 2: every

@@ -26,6 +26,7 @@
 #include "k_radar.h"
 #include "k_sdta.h"
 #include "k_xca.h"
+#include "k_xcaframe.h"
 
 namespace ach {
 
@@ -648,17 +649,70 @@ public:
         Lin lq = lin(pfx + ".xca.qkv.weight", pfx + ".xca.qkv.bias");
         fold_ln_in(lq, pfx + ".norm_xca");
         A qkv = alloc(x.B, x.H, x.W, 3 * C);
-        GemmOpt oq; oq.ln = true; oq.ln_eps = 1e-6f;
-        gemm(pfx + ".xca.qkv", y, pack(lq), qkv, oq);
+        const Packed pq = pack(lq);
         const int d = C / heads, N = x.H * x.W;
-        // Gram matrices over token slices, then softmax + fold into per-sample projection weights (see k_xca.h)
-        const int S = N >= 1024 ? 8 : (N >= 256 ? 4 : 1);
-        float* partial = alloc_f32(size_t(x.B) * heads * S * (d * d + 2 * d));
         // heads per workgroup of the MFMA Gram kernel: the largest divisor of `heads` whose channels fit the 64-channel staging tile and
         // whose tiles are at most six per wave (k_xca.h)
         const int tmx = cdiv(d, 16), per_head = tmx * tmx + 2 * tmx;
         int hg = 0;
         for (int c = 1; c <= heads; ++c) if (heads % c == 0 && c * d <= 64 && c * per_head <= 24) hg = c;
+        Packed pe = pack_shape(C, C);
+        T* weff = static_cast<T*>(aalloc(size_t(x.B) * pe.group_elems * sizeof(T)));
+        Lin lp = lin(pfx + ".xca.proj.weight", pfx + ".xca.proj.bias");
+        const std::vector<float>& gx = W(pfx + ".gamma_xca").data;
+        std::vector<float> bproj(static_cast<size_t>(C), 0.f);
+        for (int c = 0; c < C; ++c) bproj[c] = lp.b[c] * gx[c];
+        pe.b = up_f32(bproj);
+        A t2 = alloc(x.B, x.H, x.W, C);
+        // ---- the whole attention as one launch, one workgroup per frame (k_xcaframe.h; 16-bit engines, option `xca_frame` = waves per workgroup, 0 = four launches)
+        bool framed = false;
+        if constexpr (H16E) {
+            const int KSf = cdiv(d, KC), CT = cdiv(C, 16), DR = tmx * 16, KP = KSf * KC + VEC;
+            const bool small = d <= 48 && C * (d + 1) <= XCAF_SMALL_AFL && heads * DR * KP <= XCAF_SMALL_PEL;
+            const bool big = d <= 64 && C * (d + 1) <= XCAF_BIG_AFL && heads * DR * KP <= XCAF_BIG_PEL;
+            if ((xca_frame == 8 || xca_frame == 16) && !full_taps && xca_mfma && d % 2 == 0 && hg > 0 && (small || big) && pq.NT == 4 && pe.NT == 4 &&
+                qkv.ld % 8 == 0 && y.ld % 8 == 0 && t2.ld % 8 == 0) {
+                XcaFrameParams fp;
+                std::memset(&fp, 0, sizeof(fp));
+                GemmParams& g1 = fp.qkv;
+                g1.X = y.p; g1.ldx = y.ld; g1.W = pq.w; g1.bias = pq.b; g1.Y = qkv.p; g1.ldy = qkv.ld;
+                g1.groups = x.B; g1.M_per_group = N; g1.K = pq.K; g1.N = pq.N; g1.nchunks = pq.nchunks; g1.ksteps = pq.ksteps; g1.chunks_per_block = 1;
+                g1.act = ACT_NONE; g1.ln = 1; g1.ln_eps = 1e-6f; g1.vec_store = 1;
+                GemmParams& g2 = fp.proj;
+                g2.X = qkv.p + 2 * C; g2.ldx = qkv.ld; g2.W = weff; g2.w_group_stride = pe.group_elems; g2.bias = pe.b; g2.Y = t2.p; g2.ldy = t2.ld;
+                g2.R = y.p; g2.ldr = y.ld; g2.groups = x.B; g2.M_per_group = N; g2.K = C; g2.N = C; g2.nchunks = pe.nchunks; g2.ksteps = pe.ksteps; g2.chunks_per_block = 1;
+                g2.act = ACT_NONE; g2.vec_store = 1;
+                fp.gram = XcaGramParams{qkv.p, qkv.ld, alloc_f32(size_t(x.B) * heads * (d * d + 2 * d)), x.B, N, C, heads, 1, hg};
+                fp.temperature = up_f32(W(pfx + ".xca.temperature").data);
+                std::vector<float> wpg(size_t(heads) * CT * KSf * 64 * VEC, 0.f);
+                for (int h = 0; h < heads; ++h)
+                    for (int ct = 0; ct < CT; ++ct)
+                        for (int s2 = 0; s2 < KSf; ++s2)
+                            for (int l = 0; l < 64; ++l)
+                                for (int jj = 0; jj < VEC; ++jj) {
+                                    const int n = ct * 16 + (l & 15), k = s2 * KC + (l >> 4) * VEC + jj;
+                                    if (n < C && k < d) wpg[((size_t(h) * CT + ct) * KSf + s2) * 64 * VEC + size_t(l) * VEC + jj] = gx[n] * lp.w[size_t(n) * C + h * d + k];
+                                }
+                fp.Wpg = up_T(wpg);
+                fp.B = x.B; fp.N = N; fp.C = C; fp.heads = heads; fp.d = d; fp.KS = KSf; fp.CT = CT;
+                const int nw = xca_frame;
+                const dim3 grid(static_cast<unsigned>(x.B));
+                add_op(pfx + ".xca.frame", [fp, grid, small, nw](hipStream_t s) {
+                           if (small) { if (nw == 16) ACH_LAUNCH((xca_frame_kernel<T, 48, XCAF_SMALL_AFL, XCAF_SMALL_PEL, 16>), grid, dim3(1024), s, fp);
+                                        else ACH_LAUNCH((xca_frame_kernel<T, 48, XCAF_SMALL_AFL, XCAF_SMALL_PEL, 8>), grid, dim3(512), s, fp); }
+                           else { if (nw == 16) ACH_LAUNCH((xca_frame_kernel<T, 64, XCAF_BIG_AFL, XCAF_BIG_PEL, 16>), grid, dim3(1024), s, fp);
+                                  else ACH_LAUNCH((xca_frame_kernel<T, 64, XCAF_BIG_AFL, XCAF_BIG_PEL, 8>), grid, dim3(512), s, fp); } },
+                       2.0 * double(x.rows()) * C * sizeof(T) + double(pq.group_elems + heads * CT * KSf * 64 * VEC) * sizeof(T),
+                       2.0 * double(x.rows()) * C * (4.0 * C + 2.0 * d) + 2.0 * double(x.B) * C * d * d);
+                framed = true;
+            }
+        }
+        if (!framed) {
+        GemmOpt oq; oq.ln = true; oq.ln_eps = 1e-6f;
+        gemm(pfx + ".xca.qkv", y, pq, qkv, oq);
+        // Gram matrices over token slices, then softmax + fold into per-sample projection weights (see k_xca.h)
+        const int S = N >= 1024 ? 8 : (N >= 256 ? 4 : 1);
+        float* partial = alloc_f32(size_t(x.B) * heads * S * (d * d + 2 * d));
         XcaGramParams pg{qkv.p, qkv.ld, partial, x.B, N, C, heads, S, hg};
         {
             const dim3 grid(unsigned(x.B * heads), unsigned(S)), block(256);
@@ -672,13 +726,6 @@ public:
                        else if (d <= 48) ACH_LAUNCH((xca_gram_kernel<T, 48>), grid, block, s, pg); else ACH_LAUNCH((xca_gram_kernel<T, 64>), grid, block, s, pg); },
                    2.0 * x.rows() * C * sizeof(T));
         }
-        Packed pe = pack_shape(C, C);
-        T* weff = static_cast<T*>(aalloc(size_t(x.B) * pe.group_elems * sizeof(T)));
-        Lin lp = lin(pfx + ".xca.proj.weight", pfx + ".xca.proj.bias");
-        const std::vector<float>& gx = W(pfx + ".gamma_xca").data;
-        std::vector<float> bproj(static_cast<size_t>(C), 0.f);
-        for (int c = 0; c < C; ++c) bproj[c] = lp.b[c] * gx[c];
-        pe.b = up_f32(bproj);
         XcaFinalParams pf{partial, S, up_f32(W(pfx + ".xca.temperature").data), up_f32(lp.w), up_f32(gx), nullptr, weff, pe.group_elems,
                           x.B, C, heads, pe.NT, pe.ksteps};
         {
@@ -686,10 +733,10 @@ public:
             add_op(pfx + ".xca.finalize", [pf, grid, block, d](hipStream_t s) { if (d <= 48) ACH_LAUNCH((xca_finalize_kernel<T, 48>), grid, block, s, pf); else ACH_LAUNCH((xca_finalize_kernel<T, 64>), grid, block, s, pf); });
         }
         // t2 = y + gamma_xca * proj(attn @ v): one GEMM over v (channel slice [2C,3C) of qkv) with per-sample weights
-        A t2 = alloc(x.B, x.H, x.W, C);
         {
             GemmOpt op; op.residual = &y; op.groups = x.B; op.w_group_stride = pe.group_elems; op.w_override = weff;
             gemm(pfx + ".xca.proj", qkv.p + 2 * C, qkv.ld, qkv.rows(), pe, t2.p, t2.ld, op);
+        }
         }
         A fy;
         if (fused_mlp(pfx, t2, x, 0, fy)) return fy;

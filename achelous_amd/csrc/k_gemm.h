@@ -80,10 +80,11 @@ constexpr int GEMM_DEEP_KSTEPS = ACH_GEMM_DEEP_KSTEPS;   // k-steps from which l
 // EdgeNeXt is a different input pixel with its own mean / variance over its Cin channels (edgenext.py:29-34: LayerNorm then Conv2d); the affine
 // part is folded into the conv weights on the host.  Saves the LayerNorm launch and its tensor in front of each of the three convs.
 template <class T, int NT, int P, bool DEEP = false, bool LNTAP = false>
-__device__ __forceinline__ void gemm_body(const GemmParams& p, unsigned bx, unsigned nbx, unsigned by, unsigned bz) {
+__device__ __forceinline__ void gemm_body(const GemmParams& p, unsigned bx, unsigned nbx, unsigned by, unsigned bz, int wave_in = -1) {
     constexpr int VEC = Store<T>::VEC;
     constexpr int KC = 4 * VEC;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // wave_in >= 0: the caller deals (row tile, chunk range) units to its waves itself (xca_frame_kernel, k_xcaframe.h); the body has no barrier
+    const int lane = threadIdx.x & 63, wave = wave_in >= 0 ? wave_in : int(threadIdx.x >> 6);
     const int px = lane & 15, g = lane >> 4;
     const int grp = by;
     // implicit-GEMM convs re-read halo rows across row tiles: XCD-aware tile order keeps those re-reads inside one L2

@@ -98,16 +98,22 @@ __global__ __launch_bounds__(256) void xca_gram_kernel(const XcaGramParams p) { 
 #else
 #define ACH_XCA_BOUNDS __launch_bounds__(256)
 #endif
-template <class T, int XCA_DMAX>
-__global__ ACH_XCA_BOUNDS void xca_gram_mfma_kernel(const XcaGramParams p) { f16_sat_mode<T>();
-    constexpr int VEC = Store<T>::VEC, KC = 4 * VEC;        // tokens per MFMA k-step
-    constexpr int CH = 4 * KC;                              // tokens staged per round
-    constexpr int PITCH = CH + VEC;                         // + 16 bytes: rows land on different banks
-    constexpr int ROWS = XCA_DMAX + 16;                     // a head's last tile may reach 15 rows past the group's channels (zeros)
-    constexpr int MAXIT = 6;                                // items per wave: 8 heads x 3, 3 heads x 8, one head of 4 x 4 + 8 -> 24 in all
-    __shared__ __attribute__((aligned(16))) T ts[2][ROWS][PITCH];
-    const int ngroups = (p.heads + p.hg - 1) / p.hg;
-    const int b = blockIdx.x / ngroups, grp = blockIdx.x - b * ngroups, sp = blockIdx.y;
+// The body for one (sample b, head group grp, token slice sp) on a workgroup of NWV waves; `tsf` = the workgroup's LDS staging tile [2][ROWS][PITCH] of T.
+// (xca_gram_mfma_kernel: NWV = 4, one call per workgroup; xca_frame_kernel, k_xcaframe.h: NWV = 16, one call per head group of the frame.)
+template <class T, int XCA_DMAX> struct XcaGramTile {
+    static constexpr int VEC = Store<T>::VEC, KC = 4 * VEC;       // tokens per MFMA k-step
+    static constexpr int CH = 4 * KC;                             // tokens staged per round
+    static constexpr int PITCH = CH + VEC;                        // + 16 bytes: rows land on different banks
+    static constexpr int ROWS = XCA_DMAX + 16;                    // a head's last tile may reach 15 rows past the group's channels (zeros)
+    static constexpr int ELEMS = 2 * ROWS * PITCH;
+};
+template <class T, int XCA_DMAX, int NWV>
+__device__ __forceinline__ void xca_gram_mfma_body(const XcaGramParams& p, T* tsf, int b, int grp, int sp) {
+    using G = XcaGramTile<T, XCA_DMAX>;
+    constexpr int VEC = G::VEC, KC = G::KC, CH = G::CH, PITCH = G::PITCH, ROWS = G::ROWS;
+    constexpr int MAXIT = (24 + NWV - 1) / NWV;            // items per wave: 8 heads x 3, 3 heads x 8, one head of 4 x 4 + 8 -> 24 in all
+    constexpr int NTH = 64 * NWV;
+    auto ts = [&](int which, int row, int t) -> T& { return tsf[(which * ROWS + row) * PITCH + t]; };
     const int h0 = grp * p.hg, nh = (h0 + p.hg <= p.heads) ? p.hg : p.heads - h0;
     const int d = p.C / p.heads, gc2 = (nh * d) >> 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -118,9 +124,9 @@ __global__ ACH_XCA_BOUNDS void xca_gram_mfma_kernel(const XcaGramParams p) { f16
     const int tm = (d + 15) >> 4, ngram = tm * tm, per_head = ngram + 2 * tm, nitems = nh * per_head;
     {   // rows past the group's channels stay zero (16-byte stores; the staged rows are rewritten every round)
         const int r0 = nh * d, nv = (ROWS - r0) * (PITCH / VEC);
-        for (int e = tid; e < 2 * nv; e += 256) {
+        for (int e = tid; e < 2 * nv; e += NTH) {
             const int which = e >= nv, k = e - which * nv;
-            reinterpret_cast<uint4*>(&ts[which][r0][0])[k] = make_uint4(0u, 0u, 0u, 0u);
+            reinterpret_cast<uint4*>(&ts(which, r0, 0))[k] = make_uint4(0u, 0u, 0u, 0u);
         }
     }
     // a token row's q (or k) channels of this group as 16-byte pieces when everything is 16-byte aligned (12 x 4, 24 x 2, 8 x 8 channels),
@@ -134,18 +140,17 @@ __global__ ACH_XCA_BOUNDS void xca_gram_mfma_kernel(const XcaGramParams p) { f16
     int rowa[MAXIT], rowb[MAXIT];                           // row index + which * ROWS
     ACH_UNROLL
     for (int it = 0; it < MAXIT; ++it) {
-        const int item = wave + 4 * it;
+        const int item = wave + NWV * it;
         rowa[it] = rowb[it] = 0;
         if (item >= nitems) continue;
         const int hh = item / per_head, k = item - hh * per_head;
         if (k < ngram) { const int ti = k / tm, tj = k - ti * tm; rowa[it] = hh * d + ti * 16; rowb[it] = ROWS + hh * d + tj * 16; }
         else { const int w = (k - ngram) / tm, t = (k - ngram) - w * tm; rowa[it] = rowb[it] = w * ROWS + hh * d + t * 16; }
     }
-    const T* tsf = &ts[0][0][0];
     for (int n0 = n_lo; n0 < n_hi; n0 += CH) {
         __syncthreads();
         if (wide) {
-            for (int e = tid; e < 2 * CH * gv; e += 256) {
+            for (int e = tid; e < 2 * CH * gv; e += NTH) {
                 const int which = e / (CH * gv), r = e - which * CH * gv;
                 const int t = r / gv, cv = r - t * gv, n = n0 + t;
                 uint4 v = make_uint4(0u, 0u, 0u, 0u);
@@ -153,15 +158,15 @@ __global__ ACH_XCA_BOUNDS void xca_gram_mfma_kernel(const XcaGramParams p) { f16
                 T el[VEC];
                 __builtin_memcpy(el, &v, sizeof(v));
                 ACH_UNROLL
-                for (int i = 0; i < VEC; ++i) ts[which][cv * VEC + i][t] = el[i];
+                for (int i = 0; i < VEC; ++i) ts(which, cv * VEC + i, t) = el[i];
             }
         } else
-        for (int e = tid; e < 2 * CH * gc2; e += 256) {
+        for (int e = tid; e < 2 * CH * gc2; e += NTH) {
             const int which = e / (CH * gc2), r = e - which * CH * gc2;
             const int t = r / gc2, cp = r - t * gc2, n = n0 + t;
             T v0 = T{}, v1 = v0;
             if (n < n_hi) { const T* src = base + long(n) * p.ld + which * p.C + 2 * cp; v0 = src[0]; v1 = src[1]; }
-            ts[which][2 * cp][t] = v0; ts[which][2 * cp + 1][t] = v1;
+            ts(which, 2 * cp, t) = v0; ts(which, 2 * cp + 1, t) = v1;
         }
         __syncthreads();
         ACH_UNROLL
@@ -169,7 +174,7 @@ __global__ ACH_XCA_BOUNDS void xca_gram_mfma_kernel(const XcaGramParams p) { f16
             if (n0 + ks * KC >= n_hi) continue;
             ACH_UNROLL
             for (int it = 0; it < MAXIT; ++it) {
-                if (wave + 4 * it >= nitems) continue;
+                if (wave + NWV * it >= nitems) continue;
                 const uint4 fa = *reinterpret_cast<const uint4*>(tsf + (rowa[it] + col) * PITCH + ks * KC + g * VEC);
                 const uint4 fb = *reinterpret_cast<const uint4*>(tsf + (rowb[it] + col) * PITCH + ks * KC + g * VEC);
                 mfma16<T>(fa, fb, acc[it]);
@@ -178,7 +183,7 @@ __global__ ACH_XCA_BOUNDS void xca_gram_mfma_kernel(const XcaGramParams p) { f16
     }
     ACH_UNROLL
     for (int it = 0; it < MAXIT; ++it) {
-        const int item = wave + 4 * it;
+        const int item = wave + NWV * it;
         if (item >= nitems) continue;
         const int hh = item / per_head, k = item - hh * per_head;
         float* out = p.partial + ((long(b) * p.heads + h0 + hh) * p.S + sp) * (d * d + 2 * d);
@@ -193,6 +198,13 @@ __global__ ACH_XCA_BOUNDS void xca_gram_mfma_kernel(const XcaGramParams p) { f16
             if ((col >> 2) == g && i < d) out[d * d + w * d + i] = dv;
         }
     }
+}
+template <class T, int XCA_DMAX>
+__global__ ACH_XCA_BOUNDS void xca_gram_mfma_kernel(const XcaGramParams p) { f16_sat_mode<T>();
+    __shared__ __attribute__((aligned(16))) T ts[XcaGramTile<T, XCA_DMAX>::ELEMS];
+    const int ngroups = (p.heads + p.hg - 1) / p.hg;
+    const int b = blockIdx.x / ngroups, grp = blockIdx.x - b * ngroups;
+    xca_gram_mfma_body<T, XCA_DMAX, 4>(p, ts, b, grp, int(blockIdx.y));
 }
 
 struct XcaFinalParams {
