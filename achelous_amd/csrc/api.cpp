@@ -108,6 +108,10 @@ int ach_set_option(ach_handle* h, const char* key, int32_t value) {
         else if (std::string(key) == "dw_even") h->eng->dw_even = value != 0;
         else if (std::string(key) == "xca_mfma") h->eng->xca_mfma = value != 0;
         else if (std::string(key) == "xca_frame") h->eng->xca_frame = value;
+        else if (std::string(key) == "xca_fold_mfma") h->eng->xca_fold_mfma = value != 0;
+        else if (std::string(key) == "xca_slice") h->eng->xca_slice = value;
+        else if (std::string(key) == "xca_front_waves") h->eng->xca_front_waves = value;
+        else if (std::string(key) == "xca_back_waves") h->eng->xca_back_waves = value;
         else if (std::string(key) == "gemm_rows") h->eng->gemm_rows = (value == 2 || value == 4) ? value : 1;
         else if (std::string(key) == "radar_rows4") h->eng->radar_rows4 = value;
         else if (std::string(key) == "radar_skip") h->eng->radar_skip = value != 0;

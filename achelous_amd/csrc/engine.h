@@ -94,7 +94,10 @@ public:
                                       // normalised pixel is rounded to the storage type once, as the separate launch's output was)
     bool multi_stream = true;         // option "streams": run the independent radar / point branches on side streams
     int gemm_rows = 1;                // option "gemm_rows": 16-row sub-tiles per wave (1 / 2 / 4) for GEMMs with K >= 1024 (the dense 3x3 convs of MobileViT)
-    int xca_frame = 16;               // option "xca_frame": a whole XCA (qkv, Gram, softmax + fold, projection) as ONE launch with one workgroup of this many waves (8 / 16) per frame (k_xcaframe.h, 16-bit engines); 0 = four launches
+    int xca_frame = 0;                // option "xca_frame" (16-bit engines, k_xcaframe.h): 2 = an XCA as TWO launches (qkv + Gram partials per token slice; softmax + fold + projection per 64 tokens), 1 = ONE launch with a workgroup per frame (measured slower), 0 = the four launches of rounds 1-5
+    bool xca_fold_mfma = true;        // option "xca_fold_mfma" (16-bit engines): the finalize launch of the four-launch XCA folds softmax(attn) into the projection weights on the matrix cores, one workgroup per (frame, head) (k_xcaframe.h); 0 = round 5's fp32 VALU fold per (frame, head, 32 output channels)
+    int xca_slice = 0;                // option "xca_slice": tokens per workgroup of the front kernel (0: 64, 128 on maps of 1024 tokens or more)
+    int xca_front_waves = 0, xca_back_waves = 0;   // options: waves per workgroup of the two kernels (4 / 8 / 16; 0: by the number of work units)
     bool xca_mfma = true;             // option "xca_mfma": XCA Gram matrices on the matrix cores (xca_gram_mfma_kernel, k_xca.h); 0 = the VALU kernel
     bool dw_even = true;              // option "dw_even": SPLIT mlp_kernel deals depthwise tap ROWS, not whole k-steps, to its four waves (k_mlp.h)
     int radar_rows4 = 2;              // option "radar_rows4": a workgroup of rc_front owns four rows, one per wave (1: block 0 when radar_skip is on; 2: every

@@ -664,26 +664,32 @@ public:
         for (int c = 0; c < C; ++c) bproj[c] = lp.b[c] * gx[c];
         pe.b = up_f32(bproj);
         A t2 = alloc(x.B, x.H, x.W, C);
-        // ---- the whole attention as one launch, one workgroup per frame (k_xcaframe.h; 16-bit engines, option `xca_frame` = waves per workgroup, 0 = four launches)
+        // ---- the attention in two launches (k_xcaframe.h; 16-bit engines; option `xca_frame`: 2 = front + back kernels, 1 = ONE launch with a workgroup per frame
+        //      (measured slower), 0 = the four launches of rounds 1-5)
         bool framed = false;
         if constexpr (H16E) {
             const int KSf = cdiv(d, KC), CT = cdiv(C, 16), DR = tmx * 16, KP = KSf * KC + VEC;
-            const bool small = d <= 48 && C * (d + 1) <= XCAF_SMALL_AFL && heads * DR * KP <= XCAF_SMALL_PEL;
-            const bool big = d <= 64 && C * (d + 1) <= XCAF_BIG_AFL && heads * DR * KP <= XCAF_BIG_PEL;
-            if ((xca_frame == 8 || xca_frame == 16) && !full_taps && xca_mfma && d % 2 == 0 && hg > 0 && (small || big) && pq.NT == 4 && pe.NT == 4 &&
+            const bool tiny = C * (d + 3) <= XCAF_TINY_AFL && heads * DR * KP <= XCAF_TINY_PEL;
+            const bool small = d <= 48 && C * (d + 3) <= XCAF_SMALL_AFL && heads * DR * KP <= XCAF_SMALL_PEL;
+            const bool big = d <= 64 && C * (d + 3) <= XCAF_BIG_AFL && heads * DR * KP <= XCAF_BIG_PEL;
+            if ((xca_frame == 1 || xca_frame == 2) && !full_taps && xca_mfma && d % 2 == 0 && hg > 0 && (small || big) && pq.NT == 4 && pe.NT == 4 &&
                 qkv.ld % 8 == 0 && y.ld % 8 == 0 && t2.ld % 8 == 0) {
-                XcaFrameParams fp;
-                std::memset(&fp, 0, sizeof(fp));
-                GemmParams& g1 = fp.qkv;
+                const bool two = xca_frame == 2;
+                // token slices of the front kernel: 64 tokens (128 on the 40 x 40 maps: 13 partials per frame to sum instead of 25); one slice in the one-launch form
+                const int per = !two ? ((N + 15) / 16) * 16 : (xca_slice > 0 ? ((xca_slice + 15) / 16) * 16 : (N >= 1024 ? 128 : 64));
+                const int S = cdiv(N, per);
+                GemmParams g1;
+                std::memset(&g1, 0, sizeof(g1));
                 g1.X = y.p; g1.ldx = y.ld; g1.W = pq.w; g1.bias = pq.b; g1.Y = qkv.p; g1.ldy = qkv.ld;
                 g1.groups = x.B; g1.M_per_group = N; g1.K = pq.K; g1.N = pq.N; g1.nchunks = pq.nchunks; g1.ksteps = pq.ksteps; g1.chunks_per_block = 1;
                 g1.act = ACT_NONE; g1.ln = 1; g1.ln_eps = 1e-6f; g1.vec_store = 1;
-                GemmParams& g2 = fp.proj;
+                GemmParams g2;
+                std::memset(&g2, 0, sizeof(g2));
                 g2.X = qkv.p + 2 * C; g2.ldx = qkv.ld; g2.W = weff; g2.w_group_stride = pe.group_elems; g2.bias = pe.b; g2.Y = t2.p; g2.ldy = t2.ld;
                 g2.R = y.p; g2.ldr = y.ld; g2.groups = x.B; g2.M_per_group = N; g2.K = C; g2.N = C; g2.nchunks = pe.nchunks; g2.ksteps = pe.ksteps; g2.chunks_per_block = 1;
                 g2.act = ACT_NONE; g2.vec_store = 1;
-                fp.gram = XcaGramParams{qkv.p, qkv.ld, alloc_f32(size_t(x.B) * heads * (d * d + 2 * d)), x.B, N, C, heads, 1, hg};
-                fp.temperature = up_f32(W(pfx + ".xca.temperature").data);
+                XcaGramParams gp{qkv.p, qkv.ld, alloc_f32(size_t(x.B) * heads * S * (d * d + 2 * d)), x.B, N, C, heads, S, hg};
+                gp.per = per;
                 std::vector<float> wpg(size_t(heads) * CT * KSf * 64 * VEC, 0.f);
                 for (int h = 0; h < heads; ++h)
                     for (int ct = 0; ct < CT; ++ct)
@@ -693,17 +699,46 @@ public:
                                     const int n = ct * 16 + (l & 15), k = s2 * KC + (l >> 4) * VEC + jj;
                                     if (n < C && k < d) wpg[((size_t(h) * CT + ct) * KSf + s2) * 64 * VEC + size_t(l) * VEC + jj] = gx[n] * lp.w[size_t(n) * C + h * d + k];
                                 }
-                fp.Wpg = up_T(wpg);
-                fp.B = x.B; fp.N = N; fp.C = C; fp.heads = heads; fp.d = d; fp.KS = KSf; fp.CT = CT;
-                const int nw = xca_frame;
-                const dim3 grid(static_cast<unsigned>(x.B));
-                add_op(pfx + ".xca.frame", [fp, grid, small, nw](hipStream_t s) {
-                           if (small) { if (nw == 16) ACH_LAUNCH((xca_frame_kernel<T, 48, XCAF_SMALL_AFL, XCAF_SMALL_PEL, 16>), grid, dim3(1024), s, fp);
-                                        else ACH_LAUNCH((xca_frame_kernel<T, 48, XCAF_SMALL_AFL, XCAF_SMALL_PEL, 8>), grid, dim3(512), s, fp); }
-                           else { if (nw == 16) ACH_LAUNCH((xca_frame_kernel<T, 64, XCAF_BIG_AFL, XCAF_BIG_PEL, 16>), grid, dim3(1024), s, fp);
-                                  else ACH_LAUNCH((xca_frame_kernel<T, 64, XCAF_BIG_AFL, XCAF_BIG_PEL, 8>), grid, dim3(512), s, fp); } },
-                       2.0 * double(x.rows()) * C * sizeof(T) + double(pq.group_elems + heads * CT * KSf * 64 * VEC) * sizeof(T),
-                       2.0 * double(x.rows()) * C * (4.0 * C + 2.0 * d) + 2.0 * double(x.B) * C * d * d);
+                XcaFoldParams fo{gp.partial, S, up_f32(W(pfx + ".xca.temperature").data), up_T(wpg), nullptr, C, heads, d, KSf, CT};
+                const double wbytes = double(pq.group_elems + heads * CT * KSf * 64 * VEC) * sizeof(T);
+                const double flops = 2.0 * double(x.rows()) * C * (4.0 * C + 2.0 * d) + 2.0 * double(x.B) * C * d * d;
+                if (!two) {
+                    XcaFrameParams fp;
+                    std::memset(&fp, 0, sizeof(fp));
+                    fp.qkv = g1; fp.proj = g2; fp.gram = gp; fp.fold = fo; fp.N = N; fp.heads = heads;
+                    const dim3 grid(static_cast<unsigned>(x.B));
+                    add_op(pfx + ".xca.frame", [fp, grid, small](hipStream_t s) {
+                               if (small) ACH_LAUNCH((xca_frame_kernel<T, 48, XCAF_SMALL_AFL, XCAF_SMALL_PEL, 16>), grid, dim3(1024), s, fp);
+                               else ACH_LAUNCH((xca_frame_kernel<T, 64, XCAF_BIG_AFL, XCAF_BIG_PEL, 16>), grid, dim3(1024), s, fp); },
+                           2.0 * double(x.rows()) * C * sizeof(T) + wbytes, flops);
+                } else {
+                    XcaFrontParams fr;
+                    std::memset(&fr, 0, sizeof(fr));
+                    fr.qkv = g1; fr.gram = gp; fr.N = N; fr.S = S;
+                    // waves per workgroup: enough for a slice's (tile, chunk) units in about two rounds
+                    const int funits = (per / 16) * pq.nchunks;
+                    const int fw = xca_front_waves > 0 ? xca_front_waves : (funits >= 24 ? 16 : (funits >= 12 ? 8 : 4));
+                    const dim3 gridf(static_cast<unsigned>(x.B * S));
+                    const bool gsmall = hg * d <= 48;
+                    add_op(pfx + ".xca.qkv+gram", [fr, gridf, gsmall, fw](hipStream_t s) {
+#define ACH_XCAF_FRONT(dm, nw) ACH_LAUNCH((xca_front_kernel<T, dm, nw>), gridf, dim3(64 * nw), s, fr)
+                               if (gsmall) { if (fw == 16) ACH_XCAF_FRONT(48, 16); else if (fw == 8) ACH_XCAF_FRONT(48, 8); else ACH_XCAF_FRONT(48, 4); }
+                               else { if (fw == 16) ACH_XCAF_FRONT(64, 16); else if (fw == 8) ACH_XCAF_FRONT(64, 8); else ACH_XCAF_FRONT(64, 4); }
+#undef ACH_XCAF_FRONT
+                           }, double(x.rows()) * C * sizeof(T) + double(pq.group_elems) * sizeof(T), 2.0 * double(x.rows()) * C * (3.0 * C + 2.0 * d));
+                    XcaBackParams bk;
+                    std::memset(&bk, 0, sizeof(bk));
+                    bk.proj = g2; bk.fold = fo; bk.N = N; bk.RB = cdiv(N, 64);
+                    const int bw = xca_back_waves > 0 ? xca_back_waves : (heads * tmx * CT >= 64 ? 16 : (heads * tmx * CT >= 24 ? 8 : 4));
+                    const dim3 gridb(static_cast<unsigned>(x.B * bk.RB));
+                    add_op(pfx + ".xca.fold+proj", [bk, gridb, tiny, small, bw](hipStream_t s) {
+#define ACH_XCAF_BACK(af, pl, nw) ACH_LAUNCH((xca_back_kernel<T, af, pl, nw>), gridb, dim3(64 * nw), s, bk)
+                               if (tiny) { if (bw == 16) ACH_XCAF_BACK(XCAF_TINY_AFL, XCAF_TINY_PEL, 16); else if (bw == 8) ACH_XCAF_BACK(XCAF_TINY_AFL, XCAF_TINY_PEL, 8); else ACH_XCAF_BACK(XCAF_TINY_AFL, XCAF_TINY_PEL, 4); }
+                               else if (small) { if (bw == 16) ACH_XCAF_BACK(XCAF_SMALL_AFL, XCAF_SMALL_PEL, 16); else if (bw == 8) ACH_XCAF_BACK(XCAF_SMALL_AFL, XCAF_SMALL_PEL, 8); else ACH_XCAF_BACK(XCAF_SMALL_AFL, XCAF_SMALL_PEL, 4); }
+                               else { if (bw == 16) ACH_XCAF_BACK(XCAF_BIG_AFL, XCAF_BIG_PEL, 16); else if (bw == 8) ACH_XCAF_BACK(XCAF_BIG_AFL, XCAF_BIG_PEL, 8); else ACH_XCAF_BACK(XCAF_BIG_AFL, XCAF_BIG_PEL, 4); }
+#undef ACH_XCAF_BACK
+                           }, double(x.rows()) * C * sizeof(T) + double(heads * CT * KSf * 64 * VEC) * sizeof(T), 2.0 * double(x.rows()) * C * C + 2.0 * double(x.B) * C * d * d);
+                }
                 framed = true;
             }
         }
@@ -728,7 +763,36 @@ public:
         }
         XcaFinalParams pf{partial, S, up_f32(W(pfx + ".xca.temperature").data), up_f32(lp.w), up_f32(gx), nullptr, weff, pe.group_elems,
                           x.B, C, heads, pe.NT, pe.ksteps};
-        {
+        bool fold_done = false;
+        if constexpr (H16E) {
+            // the same launch with the fold on the matrix cores, one workgroup per (frame, head) (k_xcaframe.h xca_fold_body; option xca_fold_mfma)
+            const int KSf = cdiv(d, KC), CT = cdiv(C, 16), DR = tmx * 16, KP = KSf * KC + VEC;
+            const bool tiny = C * (d + 3) <= XCAF_TINY_AFL && heads * DR * KP <= XCAF_TINY_PEL;
+            const bool small = d <= 48 && C * (d + 3) <= XCAF_SMALL_AFL && heads * DR * KP <= XCAF_SMALL_PEL;
+            const bool big = d <= 64 && C * (d + 3) <= XCAF_BIG_AFL && heads * DR * KP <= XCAF_BIG_PEL;
+            if (xca_fold_mfma && !full_taps && (tiny || small || big) && pe.NT == 4) {
+                std::vector<float> wpg(size_t(heads) * CT * KSf * 64 * VEC, 0.f);
+                for (int h = 0; h < heads; ++h)
+                    for (int ct = 0; ct < CT; ++ct)
+                        for (int s2 = 0; s2 < KSf; ++s2)
+                            for (int l = 0; l < 64; ++l)
+                                for (int jj = 0; jj < VEC; ++jj) {
+                                    const int n = ct * 16 + (l & 15), k = s2 * KC + (l >> 4) * VEC + jj;
+                                    if (n < C && k < d) wpg[((size_t(h) * CT + ct) * KSf + s2) * 64 * VEC + size_t(l) * VEC + jj] = gx[n] * lp.w[size_t(n) * C + h * d + k];
+                                }
+                XcaFinalMfmaParams fm;
+                std::memset(&fm, 0, sizeof(fm));
+                fm.proj.W = weff; fm.proj.w_group_stride = pe.group_elems; fm.proj.ksteps = pe.ksteps;
+                fm.fold = XcaFoldParams{partial, S, pf.temperature, up_T(wpg), nullptr, C, heads, d, KSf, CT};
+                const dim3 grid(unsigned(x.B * heads)), block(256);
+                add_op(pfx + ".xca.finalize", [fm, grid, block, tiny, small](hipStream_t s) {
+                           if (tiny) ACH_LAUNCH((xca_finalize_mfma_kernel<T, XCAF_TINY_AFL, XCAF_TINY_PEL>), grid, block, s, fm);
+                           else if (small) ACH_LAUNCH((xca_finalize_mfma_kernel<T, XCAF_SMALL_AFL, XCAF_SMALL_PEL>), grid, block, s, fm);
+                           else ACH_LAUNCH((xca_finalize_mfma_kernel<T, XCAF_BIG_AFL, XCAF_BIG_PEL>), grid, block, s, fm); });
+                fold_done = true;
+            }
+        }
+        if (!fold_done) {
             const dim3 grid(unsigned(x.B * heads), unsigned(cdiv(C, XCA_CT))), block(256);
             add_op(pfx + ".xca.finalize", [pf, grid, block, d](hipStream_t s) { if (d <= 48) ACH_LAUNCH((xca_finalize_kernel<T, 48>), grid, block, s, pf); else ACH_LAUNCH((xca_finalize_kernel<T, 64>), grid, block, s, pf); });
         }

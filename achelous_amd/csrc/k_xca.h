@@ -21,7 +21,7 @@ namespace ach {
 constexpr int XCA_CT = ACH_XCA_CT;       // output-channel tile of xca_finalize: one workgroup per (sample, head, tile) — the softmax is recomputed
                                  // per tile (d x d, cheap) so that the fold runs on 4-6x more workgroups instead of a serial loop
 
-struct XcaGramParams { const void* qkv; long ld; float* partial; int B, N, C, heads, S; int hg; };   // hg: heads per workgroup (xca_gram_mfma_kernel)
+struct XcaGramParams { const void* qkv; long ld; float* partial; int B, N, C, heads, S; int hg; int per = 0; };   // hg: heads per workgroup (xca_gram_mfma_kernel); per > 0: tokens per slice (else ceil(N / S))
 
 // partial layout per (b, h, s): [d*d gram | d sum q^2 | d sum k^2]
 template <class T, int XCA_DMAX>
@@ -118,7 +118,7 @@ __device__ __forceinline__ void xca_gram_mfma_body(const XcaGramParams& p, T* ts
     const int d = p.C / p.heads, gc2 = (nh * d) >> 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 15, g = lane >> 4;
-    const int per = (p.N + p.S - 1) / p.S;
+    const int per = p.per > 0 ? p.per : (p.N + p.S - 1) / p.S;
     const int n_lo = sp * per, n_hi = (n_lo + per < p.N) ? n_lo + per : p.N;
     const T* base = static_cast<const T*>(p.qkv) + long(b) * p.N * p.ld + h0 * d;
     const int tm = (d + 15) >> 4, ngram = tm * tm, per_head = ngram + 2 * tm, nitems = nh * per_head;

@@ -837,3 +837,38 @@ def test_emulated_two_tiles_per_wave_ffn_is_bit_identical_to_the_one_tile_kernel
         assert torch.equal(a, b)
     for a, b in zip(res['rows2'][0], res['split'][0]):
         assert rel_err(a, b) < sdt[2] * 4e-2
+
+
+@pytest.mark.parametrize('name,res,dtype,tol', [('en_s0', 160, 'f16', 6e-3), ('en_s2', 96, 'f16', 6e-3), ('en_s1', 96, 'bf16', 4e-2), ('en_s0', 96, 'bf16', 4e-2)])
+def test_emulated_xca_launch_forms_agree(name, res, dtype, tol):
+    """Round 6 (k_xcaframe.h): the cross-covariance attention of an SDTA block as TWO launches (option xca_frame = 2: qkv + Gram partials per token slice, then softmax +
+    fold + projection per 64 tokens), as ONE launch with a workgroup per frame (xca_frame = 1) and — the default — as the four launches of rounds 1-5 with the fold of
+    the finalize launch on the matrix cores (xca_fold_mfma = 1), each against the four launches with round 5's fp32 VALU fold.  The GEMMs run the same per-row sums; the
+    Gram partials are summed over other slice boundaries and the fold rounds softmax(attn) and gamma * Wproj to the storage type, so the outputs agree to a few ulps
+    of the storage type, not bit for bit; the point branch does not depend on any of it."""
+    from achelous_amd.engine import NativeEngine
+    kw, sd, (x, xr, xp) = _setup(name, res, 2, 16)
+    tdt = {'bf16': torch.bfloat16, 'f16': torch.float16}[dtype]
+    outs, launches = {}, {}
+    for key, opts in (('four', {'xca_frame': 0, 'xca_fold_mfma': 0}), ('four+mfma', {'xca_frame': 0, 'xca_fold_mfma': 1}), ('two', {'xca_frame': 2}), ('one', {'xca_frame': 1})):
+        eng = NativeEngine(emu_library(), num_det=kw['num_det'], num_seg=kw['num_seg'], phi=kw['phi'], backbone=kw['backbone'], resolution=res,
+                           pc_channels=kw['pc_channels'], pc_classes=kw['pc_classes'], num_points=16, nano_head=True, spp=True,
+                           dtype={'bf16': DTYPE_BF16, 'f16': DTYPE_F16}[dtype])
+        for k, v in opts.items():
+            eng.set_option(k, v)
+        eng.load_state_dict(sd)
+        eng.plan(2)
+        o = alloc_outputs(kw, 2, 16, tdt, 'cpu')
+        eng.forward(x.to(tdt), xr.to(tdt), xp.to(tdt), o)
+        outs[key] = [t.clone() for t in o]
+        launches[key] = eng.launches()
+        names = [t[0] for t in eng.op_table()]
+        if key == 'two':
+            assert sum(n.endswith('.xca.qkv+gram') for n in names) == 3 and sum(n.endswith('.xca.fold+proj') for n in names) == 3
+        if key == 'one':
+            assert sum(n.endswith('.xca.frame') for n in names) == 3
+    assert launches['four'] == launches['four+mfma'] == launches['two'] + 6 == launches['one'] + 9
+    for key in ('four+mfma', 'two', 'one'):
+        for a, b in zip(outs[key][:5], outs['four'][:5]):
+            assert rel_err(a, b) < tol, (key, rel_err(a, b))
+        assert torch.equal(outs[key][5], outs['four'][5])
