@@ -131,13 +131,19 @@ class ShardedDetector:
     `submit` / `__call__` (or an explicit `calibrate(...)`) runs the same short pipelined loop under every candidate pattern, takes the
     MAX over ranks of each time, picks the fastest on rank 0, broadcasts the choice (every rank must build the same plan) and rebuilds the
     model's engine with it.  `calibrate=False`, or a `side_priority` already present in `model.engine_options`, opts out; without a
-    collective (one rank, not forced) there is nothing to calibrate."""
+    collective (one rank, not forced) there is nothing to calibrate.
+
+    The calibration times THE LOOP THAT IS SERVED (the pattern's sign flips between schedules, and the plain and the pipelined plan are different engines):
+    `pipelined=False` (default) — `submit` = `model.forward_detect` + the asynchronous gather, the caller waits for batch k's detections after submitting batch k+1;
+    `pipelined=True` — `submit` = `model.submit_detect` (the engine's submit / wait plan: the decoders of batch k overlap the backbone of batch k+1); the returned
+    object's `wait()` joins the forward, runs the gather and returns the gathered detections."""
 
     PATTERNS = (3, 2, 1)
 
     def __init__(self, model, conf_thres=0.35, nms_thres=0.35, max_det=100, group=None, global_batch=None, force_collective=False,
-                 calibrate=True, calibrate_steps=20, calibrate_warmup=3):
+                 calibrate=True, calibrate_steps=20, calibrate_warmup=3, pipelined=False):
         self.model, self.conf, self.iou, self.max_det, self.group, self.global_batch = model, conf_thres, nms_thres, max_det, group, global_batch
+        self.pipelined = bool(pipelined)
         self.force_collective = force_collective          # diagnostic: run the collective even at world size 1
         self.auto_calibrate, self.calibrate_steps, self.calibrate_warmup = bool(calibrate), int(calibrate_steps), int(calibrate_warmup)
         self.calibration = None                           # {'side_priority_fps': {pattern: frames/s of this rank's shard}, 'side_priority_chosen': p} once measured
@@ -159,8 +165,8 @@ class ShardedDetector:
         Collective call: every rank of the group must make it.  Returns the record also left in `self.calibration`."""
         import time
         patterns = tuple(self.PATTERNS if patterns is None else patterns)
-        steps = self.calibrate_steps if steps is None else int(steps)
-        warmup = self.calibrate_warmup if warmup is None else int(warmup)
+        steps = max(1, self.calibrate_steps if steps is None else int(steps))
+        warmup = max(1, self.calibrate_warmup if warmup is None else int(warmup))       # (the first block also builds the plan: never empty)
         self.auto_calibrate = False                       # (also keeps the loops below from recursing into the automatic form)
         fps = {}
         for p in patterns:
@@ -171,17 +177,25 @@ class ShardedDetector:
                 self._sync()
                 t0 = time.perf_counter()
                 inflight, pending = None, None
-                for _ in range(warmup if rep == 0 else steps):
-                    nxt = self.model.submit_detect(x, x_radar, x_points, self.conf, self.iou, self.max_det)
-                    if inflight is not None:
-                        (_, (rows, idx, cnt)) = inflight.wait()
+                if self.pipelined:
+                    for _ in range(warmup if rep == 0 else steps):
+                        nxt = self.model.submit_detect(x, x_radar, x_points, self.conf, self.iou, self.max_det)
+                        if inflight is not None:
+                            (_, (rows, idx, cnt)) = inflight.wait()
+                            g = all_gather_detections_async(rows, idx, cnt, self.group, None, self.force_collective, self.global_batch)
+                            if pending is not None:
+                                pending.wait()
+                            pending = g
+                        inflight = nxt
+                    (_, (rows, idx, cnt)) = inflight.wait()
+                    all_gather_detections_async(rows, idx, cnt, self.group, None, self.force_collective, self.global_batch).wait()
+                else:                                     # the plain plan: what `submit` serves by default
+                    for _ in range(warmup if rep == 0 else steps):
+                        (_, (rows, idx, cnt)) = self.model.forward_detect(x, x_radar, x_points, self.conf, self.iou, self.max_det)
                         g = all_gather_detections_async(rows, idx, cnt, self.group, None, self.force_collective, self.global_batch)
                         if pending is not None:
                             pending.wait()
                         pending = g
-                    inflight = nxt
-                (_, (rows, idx, cnt)) = inflight.wait()
-                all_gather_detections_async(rows, idx, cnt, self.group, None, self.force_collective, self.global_batch).wait()
                 if pending is not None:
                     pending.wait()
                 self._sync()
@@ -208,11 +222,32 @@ class ShardedDetector:
 
     @torch.no_grad()
     def submit(self, x, x_radar, x_points, out=None):
+        """Plain plan: (PendingDetections, (se, lane, pc)).  Pipelined plan (`pipelined=True`): (PendingShard, None) — the segmentation outputs exist once the
+        forward has been joined: `PendingShard.wait()` returns ((rows, idx, cnt) gathered, (se, lane, pc))."""
         self._maybe_calibrate(x, x_radar, x_points)
+        if self.pipelined:
+            return PendingShard(self, self.model.submit_detect(x, x_radar, x_points, self.conf, self.iou, self.max_det), out), None
         (det, se, lane, pc), (rows, idx, cnt) = self.model.forward_detect(x, x_radar, x_points, self.conf, self.iou, self.max_det)
         return all_gather_detections_async(rows, idx, cnt, self.group, out, self.force_collective, self.global_batch), (se, lane, pc)
 
     def __call__(self, x, x_radar, x_points):
         pending, seg = self.submit(x, x_radar, x_points)
-        r, i, c = pending.wait()
+        if self.pipelined:
+            (r, i, c), seg = pending.wait()
+        else:
+            r, i, c = pending.wait()
         return flatten_gathered(r, i, c, self.global_batch), seg       # segmentation outputs stay sharded on their rank
+
+
+class PendingShard:
+    """A batch submitted through the engine's pipelined plan by ShardedDetector(pipelined=True): `wait()` joins the forward, gathers the detection records
+    and returns ((rows, idx, cnt) of all ranks, (se, lane, pc) of this rank's shard)."""
+
+    def __init__(self, owner, inflight, out):
+        self._owner, self._inflight, self._out = owner, inflight, out
+
+    def wait(self):
+        o = self._owner
+        (det, se, lane, pc), (rows, idx, cnt) = self._inflight.wait()
+        g = all_gather_detections_async(rows, idx, cnt, o.group, self._out, o.force_collective, o.global_batch)
+        return g.wait(), (se, lane, pc)

@@ -151,8 +151,11 @@ class Achelous(nn.Module):
         # becoming infinity), and the module checks the activation tensors of the FIRST forward after every weight change for saturated / non-finite elements
         # (ach_count_saturated, ~1 ms + one stream synchronisation): if there are any and the caller's tensors are bf16, the module warns, switches
         # `bf16_storage` to 'bf16' and recomputes that forward with bf16 storage; fp16 callers chose the type themselves and only get the warning.
-        # 'first' (default) | 'always' (every forward: a debugging aid, it serialises the stream) | 'off'
-        self.f16_guard = 'first'
+        # 'periodic' (default, round 6) = that check on the first forward after a weight change AND on every `f16_guard_every`-th forward after it: a LATER input that
+        # overflows the fp16 storage is clamped, finite and wrong, and with 'first' alone nothing would ever say so; between two checks it still is —
+        # INTEGRATION.md states the window.  'first' = round 5's behaviour | 'always' (every forward: a debugging aid, it serialises the stream) | 'off'
+        self.f16_guard = 'periodic'
+        self.f16_guard_every = 256  # forwards between two periodic checks (~1 ms + one stream synchronisation each: 0.3 % of a 1.5 ms step)
         # training mode: element type of the GEMMs' matrix-instruction operands (every dense / 1x1 convolution and Linear, forward and backward; csrc/k_train.h).
         # 'fp32' (default) | 'bf16' = the fp32 operands are rounded to bf16 while they are staged into LDS, fp32 accumulation; activations, statistics, gradients
         # and every other kernel stay fp32 either way.  Measured: 'bf16' is NOT faster — this network's training GEMMs are streams of fp32
@@ -376,12 +379,18 @@ class Achelous(nn.Module):
 
     def _f16_range_check(self, eng, dev, dt, stream, pipelined):
         """The fp16 range guard (see `f16_guard` in __init__).  True = the forward just enqueued saturated and must be recomputed with bf16 storage."""
-        mode = self.__dict__.get('f16_guard', 'first')
+        mode = self.__dict__.get('f16_guard', 'periodic')
         if mode == 'off' or eng.dtype != _eng.DTYPE_F16:
             return False
         ent = next(v for v in self._engines.values() if v[0] is eng)
         if mode != 'always' and ent[2] == ent[1]:
-            return False
+            if mode != 'periodic':
+                return False
+            since = self.__dict__.setdefault('_f16_since_check', {})
+            since[id(eng)] = since.get(id(eng), 0) + 1
+            if since[id(eng)] < max(1, int(self.__dict__.get('f16_guard_every', 256))):
+                return False
+        self.__dict__.setdefault('_f16_since_check', {})[id(eng)] = 0
         if pipelined:                       # the decoders / detection tail of this forward are still on the side streams: join them first
             while eng.forwards_in_flight() > 0:
                 eng.join(stream)

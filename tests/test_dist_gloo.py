@@ -136,6 +136,7 @@ class _FakeModel:
         self.rank, self.B, self.max_det = rank, B, max_det
         self.engine_options, self.resets, self.built_with = {}, 0, []
         self._built = False
+        self.calls = {'forward_detect': 0, 'submit_detect': 0}
 
     def reset_engines(self, device=None):
         self.resets += 1
@@ -150,9 +151,11 @@ class _FakeModel:
         return (None, None, None, None), _fake_shard(self.rank, self.B, self.max_det)
 
     def forward_detect(self, x, xr, xp, conf, iou, max_det):
+        self.calls['forward_detect'] += 1
         return self._step()
 
     def submit_detect(self, x, xr, xp, conf, iou, max_det):
+        self.calls['submit_detect'] += 1
         res = self._step()
 
         class P:
@@ -183,6 +186,19 @@ def _calib_worker(rank, world, port, q):
     m3 = _FakeModel(rank, B, md); m3.engine_options = {'side_priority': 1}
     ShardedDetector(m3, max_det=md)(x, x, x)
     ok &= m2.resets == 0 and m3.resets == 0 and m3.engine_options == {'side_priority': 1}
+    # the calibration times the loop that is served — the plain detector never touched the pipelined plan ...
+    ok &= m.calls['submit_detect'] == 0 and m.calls['forward_detect'] > 0
+    # ... and a pipelined detector calibrates AND serves through submit_detect only (warm-up 0 is clamped to one step: the first block builds the plan)
+    m4 = _FakeModel(rank, B, md)
+    det4 = ShardedDetector(m4, max_det=md, calibrate_steps=4, calibrate_warmup=0, pipelined=True)
+    p1, seg1 = det4.submit(x, x, x)
+    p2, _ = det4.submit(x, x, x)
+    (r1, i1, c1), _ = p1.wait()
+    (r2, i2, c2), _ = p2.wait()
+    ok &= seg1 is None and r1.shape[0] == world and r1.shape[1] == B and r2.shape == r1.shape
+    ok &= m4.calls['forward_detect'] == 0 and m4.calls['submit_detect'] > 2 and det4.calibration['side_priority_chosen'] == chosen
+    (rows4, _, _), _ = det4(x, x, x)
+    ok &= rows4.shape[0] == world * B
     q.put((rank, bool(ok), chosen, det.calibration['side_priority_fps']))
     dist.barrier()
     dist.destroy_process_group()

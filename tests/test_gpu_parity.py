@@ -1020,6 +1020,39 @@ def test_f16_range_guard_counts_saturation_and_falls_back_to_bf16_storage():
         assert torch.isfinite(t.float()).all()
 
 
+def test_f16_range_guard_catches_a_later_input_that_overflows():
+    """with the check on the FIRST forward only, a later INPUT that overflows the fp16 storage is clamped — finite, wrong, silent.  The default
+    guard is periodic: every `f16_guard_every`-th forward is checked too.  Conditioned weights, ordinary frames: nothing fires over several periods; then an image scaled
+    by 1e5 (fine in bf16, the caller's type): the next periodic check warns, switches to bf16 storage and recomputes that forward."""
+    import warnings
+    g = Golden('en_s0')
+    m, kw = _model(g)
+    m.f16_guard_every = 3
+    x, xr, xp = make_inputs(2, 5, resolution=kw['resolution'], pc_channels=kw['pc_channels'])
+    xs, rs, ps = x.cuda().bfloat16(), xr.cuda().bfloat16(), xp.cuda().bfloat16()
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter('error')
+        for _ in range(8):
+            m(xs, rs, ps)
+    assert m.bf16_storage == 'f16' and m.f16_saturated == 0
+    big = (xs.float() * 1e5).bfloat16()
+    fired = 0
+    with torch.no_grad(), warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        for i in range(3):
+            det, se, lane, pc = m(big, rs, ps)
+            fired = i + 1
+            if m.bf16_storage == 'bf16':
+                break
+    torch.cuda.synchronize()
+    assert m.bf16_storage == 'bf16' and fired <= 3 and any('fp16 range' in str(x_.message) for x_ in w)
+    m2, _ = _model(g)
+    m2.bf16_storage = 'bf16'
+    with torch.no_grad():
+        det2, se2, lane2, pc2 = m2(big, rs, ps)
+    assert torch.equal(se, se2) and torch.equal(det[0], det2[0])          # the forward that tripped the check was recomputed with bf16 storage
+
+
 def test_point_branch_does_not_depend_on_the_batch():
     """the two-layer chain of PointNet's conv3 + conv4 must not pick its four-waves-per-tile mode from B x N (engine_impl.h pc_pair)."""
     g = Golden('en_s0')
