@@ -342,7 +342,13 @@ int ach_train_get_gemm_precision(void) { return g_train_gemm_precision.load(std:
 int ach_train_gemm(const float* A, const float* B, float* C, const float* bias, int32_t M, int32_t N, int32_t K, int64_t lda, int64_t ldb, int64_t ldc,
                    int64_t stride_a, int64_t stride_b, int64_t stride_c, int32_t trans_a, int32_t trans_b, int32_t batch, int32_t reduce_batch,
                    int32_t accumulate, void* stream) {
+    return ach_train_gemm_p(A, B, C, bias, M, N, K, lda, ldb, ldc, stride_a, stride_b, stride_c, trans_a, trans_b, batch, reduce_batch, accumulate, -1, stream);
+}
+int ach_train_gemm_p(const float* A, const float* B, float* C, const float* bias, int32_t M, int32_t N, int32_t K, int64_t lda, int64_t ldb, int64_t ldc,
+                     int64_t stride_a, int64_t stride_b, int64_t stride_c, int32_t trans_a, int32_t trans_b, int32_t batch, int32_t reduce_batch,
+                     int32_t accumulate, int32_t precision, void* stream) {
     return train_guard([&] {
+        if (precision < -1 || precision > 1) throw ach::AchError{ACH_ERR_INVALID, "train_gemm precision must be -1 (the process-wide setting), 0 (fp32) or 1 (bf16 operands)"};
         if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0) throw ach::AchError{ACH_ERR_INVALID, "bad train_gemm arguments"};
         ach::TrainGemmParams p{A, B, C, bias, M, N, K, long(lda), long(ldb), long(ldc), long(stride_a), long(stride_b), long(stride_c), trans_a, trans_b, batch, reduce_batch, accumulate, 1, nullptr};
         // block tile: 32 rows / columns where the output has no more (k_train.h: the streaming shapes)
@@ -358,7 +364,7 @@ int ach_train_gemm(const float* A, const float* B, float* C, const float* bias, 
             }
         }
         const hipStream_t st = static_cast<hipStream_t>(stream);
-        const bool h16 = g_train_gemm_precision.load(std::memory_order_relaxed) == 1;
+        const bool h16 = (precision >= 0 ? precision : g_train_gemm_precision.load(std::memory_order_relaxed)) == 1;
 #define ACH_TG_LAUNCH(TM, TN) { if (h16) ACH_LAUNCH((ach::train_gemm_kernel<ach::bf16_t, TM, TN>), grid, dim3(256), st, p); else ACH_LAUNCH((ach::train_gemm_kernel<float, TM, TN>), grid, dim3(256), st, p); }
         if (tm == 32 && tn == 32) ACH_TG_LAUNCH(32, 32)
         else if (tm == 32) ACH_TG_LAUNCH(32, 64)

@@ -223,7 +223,7 @@ static __global__ __launch_bounds__(256) void train_bn_stats_kernel(const BnStat
     const int c = blockIdx.x;
     const long total = long(p.B) * p.N;
     float s = 0.f;
-    const bool quad = (p.N & 3) == 0;                 // four positions per step, 16-byte loads (see train_bn_relu_bwd_reduce_kernel)
+    const bool quad = (p.N & 3) == 0 && (reinterpret_cast<uintptr_t>(p.Z) & 15u) == 0;      // four positions per step, 16-byte loads from a 16-byte aligned tensor (see train_bn_relu_bwd_reduce_kernel)
     if (quad) { BnWalk w(threadIdx.x, p.N >> 2); for (long i = threadIdx.x; i < (total >> 2); i += 256, w.step()) { const float4 z = *reinterpret_cast<const float4*>(p.Z + (w.b * p.C + c) * long(p.N) + 4L * w.n); s += (z.x + z.y) + (z.z + z.w); } }
     else { BnWalk w(threadIdx.x, p.N); for (long i = threadIdx.x; i < total; i += 256, w.step()) s += p.Z[w.offset(p.C, c)]; }
     red[threadIdx.x] = s;
@@ -283,7 +283,7 @@ static __global__ __launch_bounds__(256) void train_bn_slice2_kernel(const BnSli
     const long total = long(p.B) * p.N, per = bn_slice_len(total, p.S, p.N);
     const long lo = long(sl) * per < total ? long(sl) * per : total, hi = lo + per < total ? lo + per : total;
     float a = 0.f;
-    const bool quad = (p.N & 3) == 0 && (lo & 3) == 0 && (hi & 3) == 0;          // four positions per step, 16-byte loads (see train_bn_relu_bwd_reduce_kernel)
+    const bool quad = (p.N & 3) == 0 && (lo & 3) == 0 && (hi & 3) == 0 && (reinterpret_cast<uintptr_t>(p.Z) & 15u) == 0;          // four positions per step, 16-byte loads (see train_bn_relu_bwd_reduce_kernel)
     if (quad) {
         BnWalk w((lo >> 2) + threadIdx.x, p.N >> 2);
         for (long i = (lo >> 2) + threadIdx.x; i < (hi >> 2); i += 256, w.step()) { const float4 z = *reinterpret_cast<const float4*>(p.Z + (w.b * p.C + c) * long(p.N) + 4L * w.n); a += (z.x + z.y) + (z.z + z.w); }
@@ -383,7 +383,7 @@ static __global__ __launch_bounds__(256) void train_bn_relu_bwd_reduce_kernel(co
     const long per = p.S > 1 ? bn_slice_len(total, p.S, p.N) : total, lo0 = p.S > 1 ? long(blockIdx.y) * per : 0, lo = lo0 < total ? lo0 : total, hi = lo + per < total ? lo + per : total;
     const float mean = p.mean[c], rstd = 1.0f / sqrtf(p.var[c] + p.eps);
     float sb = 0.f, sg = 0.f;
-    if ((p.N & 3) == 0 && (lo & 3) == 0 && (hi & 3) == 0) {
+    if ((p.N & 3) == 0 && (lo & 3) == 0 && (hi & 3) == 0 && ((reinterpret_cast<uintptr_t>(p.Z) | reinterpret_cast<uintptr_t>(p.Y) | reinterpret_cast<uintptr_t>(p.dY)) & 15u) == 0) {      // (a view at an odd element offset takes the scalar walk)
         // four positions per step with 16-byte loads (N and the slice bounds are multiples of four: a quad never straddles a sample): a quarter of the load instructions, four
         // times the bytes in flight per thread — this reduction reads three tensors and was at 2.6 TB/s with scalar loads
         BnWalk w((lo >> 2) + threadIdx.x, p.N >> 2);

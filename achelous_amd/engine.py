@@ -37,7 +37,7 @@ class NativeLibrary:
                'ach_forward', 'ach_forward_detect', 'ach_join', 'ach_forwards_in_flight', 'ach_decode', 'ach_nms_workspace_bytes', 'ach_nms', 'ach_tap_count', 'ach_tap_name',
                'ach_tap_shape', 'ach_read_tap', 'ach_plan_launches', 'ach_op_name', 'ach_op_bytes', 'ach_op_layout_bytes', 'ach_op_flops', 'ach_op_stream',
                'ach_forward_profiled', 'ach_set_probe', 'ach_read_probe', 'ach_set_probe_range', 'ach_read_probe_slot', 'ach_bench_gemm', 'ach_set_option', 'ach_preprocess_radar',
-               'ach_normalize_points', 'ach_preprocess_image', 'ach_seg_argmax', 'ach_seg_resize_argmax', 'ach_correct_boxes', 'ach_train_pn2_fps', 'ach_train_pn2_group', 'ach_train_pn2_group_bwd', 'ach_train_pn2_interp', 'ach_train_gemm', 'ach_train_set_gemm_precision', 'ach_train_get_gemm_precision', 'ach_train_bn_stats', 'ach_train_bn_running', 'ach_train_bn_relu_fwd', 'ach_train_bn_relu_bwd', 'ach_train_dw3x3', 'ach_train_dw3x3_wgrad', 'ach_train_max_points', 'ach_train_log_softmax', 'ach_resample_pass_u8', 'ach_train_act', 'ach_train_mul', 'ach_train_layernorm', 'ach_train_layernorm_bwd', 'ach_train_dwconv', 'ach_train_dwconv_wgrad',
+               'ach_normalize_points', 'ach_preprocess_image', 'ach_seg_argmax', 'ach_seg_resize_argmax', 'ach_correct_boxes', 'ach_train_pn2_fps', 'ach_train_pn2_group', 'ach_train_pn2_group_bwd', 'ach_train_pn2_interp', 'ach_train_gemm', 'ach_train_gemm_p', 'ach_train_set_gemm_precision', 'ach_train_get_gemm_precision', 'ach_train_bn_stats', 'ach_train_bn_running', 'ach_train_bn_relu_fwd', 'ach_train_bn_relu_bwd', 'ach_train_dw3x3', 'ach_train_dw3x3_wgrad', 'ach_train_max_points', 'ach_train_log_softmax', 'ach_resample_pass_u8', 'ach_train_act', 'ach_train_mul', 'ach_train_layernorm', 'ach_train_layernorm_bwd', 'ach_train_dwconv', 'ach_train_dwconv_wgrad',
                'ach_train_im2col', 'ach_train_softmax', 'ach_train_upsample2x', 'ach_train_maxpool', 'ach_train_avgpool3', 'ach_train_row_reduce', 'ach_train_row_scale',
                'ach_train_col_reduce', 'ach_train_col_scale', 'ach_train_instnorm', 'ach_train_l2norm', 'ach_train_deform_im2col', 'ach_train_deform_bwd',
                'ach_record_words', 'ach_all_gather_records', 'ach_count_saturated')
@@ -92,6 +92,8 @@ class NativeLibrary:
         i64 = ctypes.c_int64
         L.ach_train_gemm.argtypes = [vp, vp, vp, vp, i32, i32, i32, i64, i64, i64, i64, i64, i64, i32, i32, i32, i32, i32, vp]
         L.ach_train_gemm.restype = ctypes.c_int
+        L.ach_train_gemm_p.argtypes = [vp, vp, vp, vp, i32, i32, i32, i64, i64, i64, i64, i64, i64, i32, i32, i32, i32, i32, i32, vp]
+        L.ach_train_gemm_p.restype = ctypes.c_int
         L.ach_train_pn2_fps.argtypes = [vp, i32, i32, i32, vp, vp, vp]
         L.ach_train_pn2_group.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, ctypes.c_float, vp, vp, vp]
         L.ach_train_pn2_group_bwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp]

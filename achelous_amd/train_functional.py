@@ -25,8 +25,14 @@ def _empty(like, *shape):
     return torch.empty(*shape, dtype=torch.float32, device=like.device)
 
 
-def _gemm(lib, s, A, B, C, M, N, K, lda, ldb, ldc, sA, sB, sC, tA, tB, batch, reduce=0, acc=0, bias=None):
-    _check(lib, lib.lib.ach_train_gemm(_p(A), _p(B), _p(C), _p(bias) if bias is not None else _NULL, M, N, K, lda, ldb, ldc, sA, sB, sC, tA, tB, batch, reduce, acc, s))
+def _prec(lib):
+    """The operand type a training forward runs its GEMMs with (ach_train_set_gemm_precision, set by the module's forward): recorded on the autograd ctx so that the
+    node's backward launches use the same one whatever another module or thread has set meanwhile (ach_train_gemm_p)."""
+    return int(lib.lib.ach_train_get_gemm_precision())
+
+
+def _gemm(lib, s, A, B, C, M, N, K, lda, ldb, ldc, sA, sB, sC, tA, tB, batch, reduce=0, acc=0, bias=None, prec=-1):
+    _check(lib, lib.lib.ach_train_gemm_p(_p(A), _p(B), _p(C), _p(bias) if bias is not None else _NULL, M, N, K, lda, ldb, ldc, sA, sB, sC, tA, tB, batch, reduce, acc, int(prec), s))
 
 
 # ------------------------------------------------------------------------------------------------------------------ element-wise
@@ -304,7 +310,11 @@ def _pair(v):
 # A dense / deformable convolution's column buffer (im2col: k*k times the input) is kept from the forward to the backward when it is at most this many bytes — the
 # backward then skips its own im2col pass and writes the column gradient over it (round 5: the recomputation was 2.9 ms of a 65 ms batch-32 step; the kept buffers add
 # ~2 GB to its 9.6 GB peak).  Larger buffers are recomputed, as every buffer was before; 0 = always recompute.
-KEEP_COLUMN_BYTES = 1 << 30
+# The switch: environment variable ACHELOUS_KEEP_COLUMN_BYTES (read at import) or `achelous_amd.train_functional.KEEP_COLUMN_BYTES = n` at run time.
+# The kept buffer is a plain ctx attribute, not save_for_backward: it is OVERWRITTEN by the column gradient in the backward, which saved-tensor hooks (checkpointing,
+# CPU offload) must not see as a saved activation; with such hooks installed set the limit to 0.
+import os as _os
+KEEP_COLUMN_BYTES = int(_os.environ.get('ACHELOUS_KEEP_COLUMN_BYTES', 1 << 30))
 
 
 class _Conv2dFn(torch.autograd.Function):
@@ -331,7 +341,8 @@ class _Conv2dFn(torch.autograd.Function):
             _check(lib, L.ach_train_im2col(_p(x), _p(col), *cfg, 0, s))
         w2 = weight.detach().reshape(Co, K).contiguous()
         y = _empty(x, B, Co, Ho, Wo)
-        _gemm(lib, s, w2, col, y, Co, O, K, K, O, O, 0, K * O, Co * O, 0, 0, B, bias=bias.detach().contiguous() if bias is not None else None)
+        ctx.prec = _prec(lib)
+        _gemm(lib, s, w2, col, y, Co, O, K, K, O, O, 0, K * O, Co * O, 0, 0, B, bias=bias.detach().contiguous() if bias is not None else None, prec=ctx.prec)
         ctx.save_for_backward(x, w2)
         ctx.cfg = (cfg, direct, bias is not None, tuple(weight.shape))
         ctx.col = col if (not direct and col.numel() * 4 <= KEEP_COLUMN_BYTES) else None
@@ -355,11 +366,11 @@ class _Conv2dFn(torch.autograd.Function):
             col = _empty(x, B, K, O)
             _check(lib, L.ach_train_im2col(_p(x), _p(col), *cfg, 0, s))
         dw = _empty(x, *wshape)                      # dW = sum_b dy[b] col[b]^T  ([Co, K] in memory; allocated in the parameter's shape: a view would make AccumulateGrad clone it)
-        _gemm(lib, s, dy, col, dw, Co, K, O, O, O, K, Co * O, K * O, 0, 0, 1, B, reduce=1)
+        _gemm(lib, s, dy, col, dw, Co, K, O, O, O, K, Co * O, K * O, 0, 0, 1, B, reduce=1, prec=ctx.prec)
         dx = None
         if ctx.needs_input_grad[0]:
             dcol = torch.empty_like(x) if direct else col                     # dcol[b] = W^T dy[b]  (over the column buffer: the weight gradient above was its last reader, in stream order)
-            _gemm(lib, s, w2, dy, dcol, K, O, Co, K, O, O, 0, Co * O, K * O, 1, 0, B)
+            _gemm(lib, s, w2, dy, dcol, K, O, Co, K, O, O, 0, Co * O, K * O, 1, 0, B, prec=ctx.prec)
             if direct:
                 dx = dcol
             else:
@@ -437,7 +448,8 @@ class _BmmFn(torch.autograd.Function):
         N = b.shape[1] if nt else b.shape[2]
         lib = _lib(a)
         c = _empty(a, T, M, N)
-        _gemm(lib, _stream(a), a, b, c, M, N, K, K, K if nt else N, N, M * K, b.shape[1] * b.shape[2], M * N, 0, 1 if nt else 0, T)
+        ctx.prec = _prec(lib)
+        _gemm(lib, _stream(a), a, b, c, M, N, K, K, K if nt else N, N, M * K, b.shape[1] * b.shape[2], M * N, 0, 1 if nt else 0, T, prec=ctx.prec)
         ctx.save_for_backward(a, b)
         ctx.nt = nt
         return c
@@ -453,11 +465,11 @@ class _BmmFn(torch.autograd.Function):
         dc = dc.contiguous()
         da, db = torch.empty_like(a), torch.empty_like(b)
         if nt:       # C = A B^T: dA = dC B ; dB = dC^T A
-            _gemm(lib, s, dc, b, da, M, K, N, N, K, K, M * N, N * K, M * K, 0, 0, T)
-            _gemm(lib, s, dc, a, db, N, K, M, N, K, K, M * N, M * K, N * K, 1, 0, T)
+            _gemm(lib, s, dc, b, da, M, K, N, N, K, K, M * N, N * K, M * K, 0, 0, T, prec=ctx.prec)
+            _gemm(lib, s, dc, a, db, N, K, M, N, K, K, M * N, M * K, N * K, 1, 0, T, prec=ctx.prec)
         else:        # C = A B: dA = dC B^T ; dB = A^T dC
-            _gemm(lib, s, dc, b, da, M, K, N, N, N, K, M * N, K * N, M * K, 0, 1, T)
-            _gemm(lib, s, a, dc, db, K, N, M, K, N, N, M * K, M * N, K * N, 1, 0, T)
+            _gemm(lib, s, dc, b, da, M, K, N, N, N, K, M * N, K * N, M * K, 0, 1, T, prec=ctx.prec)
+            _gemm(lib, s, a, dc, db, K, N, M, K, N, N, M * K, M * N, K * N, 1, 0, T, prec=ctx.prec)
         return da, db, None
 
 
@@ -571,7 +583,8 @@ class _DeformConvFn(torch.autograd.Function):
         _check(lib, L.ach_train_deform_im2col(_p(x), _p(offset), _p(mask), _p(col), B, C, H, W, Ho, Wo, stride, pad, s))
         w2 = weight.detach().reshape(Co, K).contiguous()
         y = _empty(x, B, Co, Ho, Wo)
-        _gemm(lib, s, w2, col, y, Co, O, K, K, O, O, 0, K * O, Co * O, 0, 0, B)
+        ctx.prec = _prec(lib)
+        _gemm(lib, s, w2, col, y, Co, O, K, K, O, O, 0, K * O, Co * O, 0, 0, B, prec=ctx.prec)
         ctx.save_for_backward(x, offset, mask, w2)
         ctx.cfg = (Ho, Wo, stride, pad, tuple(weight.shape))
         ctx.col = col if col.numel() * 4 <= KEEP_COLUMN_BYTES else None
@@ -592,9 +605,9 @@ class _DeformConvFn(torch.autograd.Function):
             col = _empty(x, B, K, O)
             _check(lib, L.ach_train_deform_im2col(_p(x), _p(offset), _p(mask), _p(col), B, C, H, W, Ho, Wo, stride, pad, s))
         dw = _empty(x, *wshape)
-        _gemm(lib, s, dy, col, dw, Co, K, O, O, O, K, Co * O, K * O, 0, 0, 1, B, reduce=1)
+        _gemm(lib, s, dy, col, dw, Co, K, O, O, O, K, Co * O, K * O, 0, 0, 1, B, reduce=1, prec=ctx.prec)
         dcol = col                                                                # reuse the buffer
-        _gemm(lib, s, w2, dy, dcol, K, O, Co, K, O, O, 0, Co * O, K * O, 1, 0, B)
+        _gemm(lib, s, w2, dy, dcol, K, O, Co, K, O, O, 0, Co * O, K * O, 1, 0, B, prec=ctx.prec)
         dx = torch.zeros_like(x) if ctx.needs_input_grad[0] else None             # (the first RCBlock samples the pooled radar map: an input, no gradient — 354 M atomic adds at batch 32)
         doff, dmask = torch.empty_like(offset), torch.empty_like(mask)
         _check(lib, L.ach_train_deform_bwd(_p(x), _p(offset), _p(mask), _p(dcol), _p(dx) if dx is not None else _NULL, _p(doff), _p(dmask), B, C, H, W, Ho, Wo, stride, pad, s))

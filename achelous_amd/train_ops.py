@@ -77,8 +77,9 @@ class _SharedMLP1dFn(torch.autograd.Function):
         L, s = lib.lib, _stream(x)
         z = torch.empty(B, cout, N, dtype=torch.float32, device=x.device)
         bs = bias.detach().contiguous() if bias is not None else None           # bound to a name: a temporary would be freed before the kernel reads it
-        _check(lib, L.ach_train_gemm(_p(w2), _p(x), _p(z), _p(bs) if bs is not None else ctypes.c_void_p(), cout, N, cin,
-                                     cin, N, N, 0, cin * N, cout * N, 0, 0, B, 0, 0, s))
+        ctx.prec = int(L.ach_train_get_gemm_precision())      # recorded for this node's backward launches (ach_train_gemm_p)
+        _check(lib, L.ach_train_gemm_p(_p(w2), _p(x), _p(z), _p(bs) if bs is not None else ctypes.c_void_p(), cout, N, cin,
+                                     cin, N, N, 0, cin * N, cout * N, 0, 0, B, 0, 0, ctx.prec, s))
         mean = torch.empty(cout, dtype=torch.float32, device=x.device)
         var = torch.empty(cout, dtype=torch.float32, device=x.device)
         if training:
@@ -112,9 +113,9 @@ class _SharedMLP1dFn(torch.autograd.Function):
         dz = torch.empty_like(z)
         _check(lib, L.ach_train_bn_relu_bwd(_p(z), _p(y), _p(dy), _p(mean), _p(var), _p(gamma), _p(dgamma), _p(dbeta), _p(dz), B, cout, N, eps, relu, s))
         dx = torch.empty_like(x)            # dx[b] = W^T dz[b]: A = W stored [cout, cin] = K x M
-        _check(lib, L.ach_train_gemm(_p(w2), _p(dz), _p(dx), ctypes.c_void_p(), cin, N, cout, cin, N, N, 0, cout * N, cin * N, 1, 0, B, 0, 0, s))
+        _check(lib, L.ach_train_gemm_p(_p(w2), _p(dz), _p(dx), ctypes.c_void_p(), cin, N, cout, cin, N, N, 0, cout * N, cin * N, 1, 0, B, 0, 0, ctx.prec, s))
         dw = torch.empty(wshape, dtype=torch.float32, device=x.device)          # dW = sum_b dz[b] x[b]^T: B = x[b] stored [cin, N] = N x K; in the parameter's own shape (a VIEW of a 2-D buffer would make AccumulateGrad clone it: one copy per parameter and step)
-        _check(lib, L.ach_train_gemm(_p(dz), _p(x), _p(dw), ctypes.c_void_p(), cout, cin, N, N, N, cin, cout * N, cin * N, 0, 0, 1, B, 1, 0, s))
+        _check(lib, L.ach_train_gemm_p(_p(dz), _p(x), _p(dw), ctypes.c_void_p(), cout, cin, N, N, N, cin, cout * N, cin * N, 0, 0, 1, B, 1, 0, ctx.prec, s))
         # a bias in front of a training-mode BatchNorm has zero gradient: the batch mean it shifts is subtracted again (sum dz = 0)
         dbias = torch.zeros(cout, dtype=torch.float32, device=x.device) if has_bias else None
         return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None, None
@@ -265,8 +266,9 @@ class _LinearFn(torch.autograd.Function):
         L, s = lib.lib, _stream(x)
         z = torch.empty(B, cout, N, dtype=torch.float32, device=x.device)
         bs = bias.detach().contiguous() if bias is not None else None           # bound to a name: a temporary would be freed before the kernel reads it
-        _check(lib, L.ach_train_gemm(_p(w2), _p(x), _p(z), _p(bs) if bs is not None else ctypes.c_void_p(), cout, N, cin,
-                                     cin, N, N, 0, cin * N, cout * N, 0, 0, B, 0, 0, s))
+        ctx.prec = int(L.ach_train_get_gemm_precision())      # recorded for this node's backward launches (ach_train_gemm_p)
+        _check(lib, L.ach_train_gemm_p(_p(w2), _p(x), _p(z), _p(bs) if bs is not None else ctypes.c_void_p(), cout, N, cin,
+                                     cin, N, N, 0, cin * N, cout * N, 0, 0, B, 0, 0, ctx.prec, s))
         ctx.save_for_backward(x, w2)
         ctx.cfg = (bias is not None, tuple(weight.shape))
         return z
@@ -281,9 +283,9 @@ class _LinearFn(torch.autograd.Function):
         L, s = lib.lib, _stream(x)
         dz = dz.contiguous()
         dx = torch.empty_like(x)
-        _check(lib, L.ach_train_gemm(_p(w2), _p(dz), _p(dx), ctypes.c_void_p(), cin, N, cout, cin, N, N, 0, cout * N, cin * N, 1, 0, B, 0, 0, s))
+        _check(lib, L.ach_train_gemm_p(_p(w2), _p(dz), _p(dx), ctypes.c_void_p(), cin, N, cout, cin, N, N, 0, cout * N, cin * N, 1, 0, B, 0, 0, ctx.prec, s))
         dw = torch.empty(wshape, dtype=torch.float32, device=x.device)          # (in the parameter's own shape: a VIEW of a 2-D buffer would make autograd's AccumulateGrad clone it — one copy per parameter and step)
-        _check(lib, L.ach_train_gemm(_p(dz), _p(x), _p(dw), ctypes.c_void_p(), cout, cin, N, N, N, cin, cout * N, cin * N, 0, 0, 1, B, 1, 0, s))
+        _check(lib, L.ach_train_gemm_p(_p(dz), _p(x), _p(dw), ctypes.c_void_p(), cout, cin, N, N, N, cin, cout * N, cin * N, 0, 0, 1, B, 1, 0, ctx.prec, s))
         db = None
         if has_bias:                      # db[c] = sum over (B, N) of dz = B N x the per-channel mean the statistics kernel returns
             db = torch.empty(cout, dtype=torch.float32, device=x.device)
@@ -303,7 +305,8 @@ class _BmmPointsFn(torch.autograd.Function):
         lib = _lib(x)
         L, s = lib.lib, _stream(x)
         y = torch.empty_like(x)
-        _check(lib, L.ach_train_gemm(_p(T), _p(x), _p(y), ctypes.c_void_p(), K, N, K, K, N, N, K * K, K * N, K * N, 1, 0, B, 0, 0, s))
+        ctx.prec = int(L.ach_train_get_gemm_precision())      # recorded for this node's backward launches (ach_train_gemm_p)
+        _check(lib, L.ach_train_gemm_p(_p(T), _p(x), _p(y), ctypes.c_void_p(), K, N, K, K, N, N, K * K, K * N, K * N, 1, 0, B, 0, 0, ctx.prec, s))
         ctx.save_for_backward(x, T)
         return y
 
@@ -315,9 +318,9 @@ class _BmmPointsFn(torch.autograd.Function):
         L, s = lib.lib, _stream(x)
         dy = dy.contiguous()
         dx = torch.empty_like(x)                                   # dx[b] = T[b] dy[b]
-        _check(lib, L.ach_train_gemm(_p(T), _p(dy), _p(dx), ctypes.c_void_p(), K, N, K, K, N, N, K * K, K * N, K * N, 0, 0, B, 0, 0, s))
+        _check(lib, L.ach_train_gemm_p(_p(T), _p(dy), _p(dx), ctypes.c_void_p(), K, N, K, K, N, N, K * K, K * N, K * N, 0, 0, B, 0, 0, ctx.prec, s))
         dT = torch.empty_like(T)                                   # dT[b] = x[b] dy[b]^T
-        _check(lib, L.ach_train_gemm(_p(x), _p(dy), _p(dT), ctypes.c_void_p(), K, K, N, N, N, K, K * N, K * N, K * K, 0, 1, B, 0, 0, s))
+        _check(lib, L.ach_train_gemm_p(_p(x), _p(dy), _p(dT), ctypes.c_void_p(), K, K, N, N, N, K, K * N, K * N, K * K, 0, 1, B, 0, 0, ctx.prec, s))
         return dx, dT
 
 

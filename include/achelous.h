@@ -263,6 +263,12 @@ int ach_train_gemm(const float* A, const float* B, float* C, const float* bias, 
  *                          Returns ACH_ERR_INVALID for another value; ach_train_get_gemm_precision returns the current one. */
 int ach_train_set_gemm_precision(int32_t precision);
 int ach_train_get_gemm_precision(void);
+/*   ach_train_gemm_p       ach_train_gemm with the operand type of THIS call (0 / 1 as above; -1 = the process-wide setting): an autograd node records the type its
+ *                          forward ran with and passes it to its backward launches, so two modules (or threads) with different `train_precision` never run a backward
+ *                          with the other's choice */
+int ach_train_gemm_p(const float* A, const float* B, float* C, const float* bias, int32_t M, int32_t N, int32_t K, int64_t lda, int64_t ldb, int64_t ldc,
+                     int64_t stride_a, int64_t stride_b, int64_t stride_c, int32_t trans_a, int32_t trans_b, int32_t batch, int32_t reduce_batch,
+                     int32_t accumulate, int32_t precision, void* stream);
 int ach_train_bn_stats(const float* z, float* mean, float* var, int32_t B, int32_t C, int32_t N, void* stream);
 /*   ach_train_bn_running    nn.BatchNorm's running estimates after a training forward: running <- (1 - momentum) running + momentum batch; `unbias` = M / (M - 1) on the variance */
 int ach_train_bn_running(const float* mean, const float* var, float* running_mean, float* running_var, int32_t C, float momentum, float unbias, void* stream);

@@ -18,7 +18,7 @@ can see.  This file makes the pairing systematic:
 
 Sensitivity check (`test_the_guard_sees_the_mfma32_head`): the same harness with the aggressor's head compiled as ONE 16x16x32 MFMA
 (tests/variants/libachelous_hooks_mfma32.so) — the form DESIGN 4.15 measured to disturb its neighbours — must see differences; the outcome per
-box is written to gpurun_out/coresidency_r05.jsonl either way."""
+box is written to gpurun_out/coresidency_r06.jsonl either way."""
 import json
 import os
 
@@ -39,6 +39,9 @@ AGGRESSORS = {
     'valu': ('rc_blocks.0.front,rc_blocks.1.front,rc_blocks.2.front,rc_blocks.3.front', True),
     'lds': ('stages.2.,stages.3.0.block,.ghost,.shortcut,det_head.convs', False),
 }
+# round 6: the plain GEMM launches — short-lived matrix-instruction waves, the issuers of the 16x16x32 form in every plan until round 6 (now the 16x16x16
+# pair like everything else: tests/test_abi_and_host.py) — as an aggressor of their own
+GEMM_AGGRESSOR = ('.xca.qkv,.xca.proj,downsample_layers,fpn.q3,det_head.stems,det_head.preds,upsample_5_to_4,upsample_4_to_3,lowres_pair,pc_seg_model.conv', False)
 _libs = {}
 
 
@@ -52,8 +55,8 @@ def _variant(name):
     return _libs[name]
 
 
-def _module(g, library=None, options=None, storage='f16'):
-    kw = ctor_kwargs(g.meta)
+def _module(g, library=None, options=None, storage='f16', **override):
+    kw = dict(ctor_kwargs(g.meta), **override)
     m = Achelous(**kw).eval()
     m.load_state_dict(g.calibrate(condition_state_dict(m.state_dict(), seed=g.meta['weight_seed'])), strict=True)
     m = m.cuda()
@@ -192,12 +195,12 @@ def _spin_cycles_per_ms():
     return _spin[0]
 
 
-def _victim_runs(g, storage, aggressor_of, passes):
+def _victim_runs(g, storage, aggressor_of, passes, batch=16, **override):
     """-> list of {'aggressor', 'passes', 'passes_that_differ', 'first': {...}} for one victim configuration."""
-    vm, kw = _module(g, None, {'streams': 0}, storage)
+    vm, kw = _module(g, None, {'streams': 0}, storage, **override)
     batches = []
     for i in range(2):
-        x, xr, xp = make_inputs(16, 700 + i, resolution=kw['resolution'], pc_channels=kw['pc_channels'], dense_radar=(i == 1))
+        x, xr, xp = make_inputs(batch, 700 + i, resolution=kw['resolution'], pc_channels=kw['pc_channels'], dense_radar=(i == 1))
         batches.append(tuple(t.cuda().to(torch.bfloat16) for t in (x, xr, xp)))
     vstream = torch.cuda.Stream()
     with torch.no_grad(), torch.cuda.stream(vstream):
@@ -256,7 +259,7 @@ def _victim_runs(g, storage, aggressor_of, passes):
 def _log(rec):
     out = os.path.join(REPO, 'gpurun_out')
     os.makedirs(out, exist_ok=True)
-    with open(os.path.join(out, 'coresidency_r05.jsonl'), 'a') as f:
+    with open(os.path.join(out, 'coresidency_r06.jsonl'), 'a') as f:
         f.write(json.dumps(rec) + '\n')
 
 
@@ -280,6 +283,21 @@ def test_no_kernel_consumes_registers_or_lds_it_did_not_write(config, storage):
     res = _victim_runs(g, storage, {'poison_nan': lambda st: Poison(0x7fc07fc0), 'poison_f16nan': lambda st: Poison(0x7e007e00)}, 10)
     for r in res:
         _log(dict(r, victim=config, storage=storage, aggressor_library='tests/variants/poison.hip'))
+    assert all(r['passes_that_differ'] == 0 for r in res), res
+
+
+@pytest.mark.parametrize('config,batch,override', [('en_s0', 1, {}), ('en_s0', 8, {}), ('en_s0', 64, {}), ('en_s0', 8, {'resolution': 416}), ('en_s2', 16, {}),
+                                                   ('en_s0', 16, {'pc_seg': 'pn2'})])
+def test_guard_matrix_other_batches_resolutions_and_a_gemm_aggressor(config, batch, override):
+    """the guard beyond batch 16 / 320 x 320 / four configurations — batch 1, 8 and 64, 416 x 416, EN-S2, the PointNet++ branch — beside the row-walking heads
+    and beside the plain GEMM launches (dense radar maps are the second of the two victim batches in every cell)."""
+    g = Golden(config)
+    ga = Golden('en_s0')
+    lib = _variant('libachelous_hooks.so')
+    aggressors = {'gemm': lambda st: Aggressor(ga, lib, GEMM_AGGRESSOR[0], GEMM_AGGRESSOR[1], st), 'rows': lambda st: Aggressor(ga, lib, AGGRESSORS['rows'][0], False, st)}
+    res = _victim_runs(g, 'f16', aggressors, 10, batch=batch, **override)
+    for r in res:
+        _log(dict(r, victim=config, storage='f16', batch=batch, override=override, aggressor_library='hooks (shipped kernels)'))
     assert all(r['passes_that_differ'] == 0 for r in res), res
 
 
