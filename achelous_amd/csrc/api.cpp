@@ -49,8 +49,8 @@ int ach_create(const ach_config* cfg, ach_handle** out) {
             throw ach::AchError{ACH_ERR_UNSUPPORTED, "backbone must be 'en' or 'mv'"};
         if (cfg->phi < ACH_PHI_S0 || cfg->phi > ACH_PHI_S2) throw ach::AchError{ACH_ERR_UNSUPPORTED, "phi must be S0, S1 or S2"};
         if (cfg->neck != ACH_NECK_GDF && cfg->neck != ACH_NECK_CDF) throw ach::AchError{ACH_ERR_UNSUPPORTED, "neck must be 'gdf' or 'cdf'"};
-        if (cfg->pc_seg != ACH_PCSEG_PN && cfg->pc_seg != ACH_PCSEG_PN2 && cfg->pc_seg != ACH_PCSEG_NONE)
-            throw ach::AchError{ACH_ERR_UNSUPPORTED, "pc_seg must be 'pn', 'pn2' or none (Achelous3T)"};
+        if (cfg->pc_seg != ACH_PCSEG_PN && cfg->pc_seg != ACH_PCSEG_PN2 && cfg->pc_seg != ACH_PCSEG_NONE && cfg->pc_seg != ACH_PCSEG_PN2_MSG)
+            throw ach::AchError{ACH_ERR_UNSUPPORTED, "pc_seg must be 'pn', 'pn2', 'pn2_msg' or none (Achelous3T)"};
         if (cfg->num_det < 1 || cfg->num_det > 59 || cfg->num_seg < 1 || (cfg->pc_seg != ACH_PCSEG_NONE && (cfg->pc_classes < 1 || cfg->pc_channels < 3)))
             throw ach::AchError{ACH_ERR_INVALID, "bad class / channel counts"};
         ach_handle* h = new ach_handle();

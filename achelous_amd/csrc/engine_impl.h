@@ -2073,9 +2073,11 @@ public:
         return pc_layer(n2, pc_layer(n1, x, l1, act1), l2, act2);
     }
     // shared MLP + max over the N points of every sample -> [B, C]   (gemm_colmax_kernel: no atomics, nothing materialised)
-    Rows pc_layer_max(const std::string& name, const Rows& x, const Lin& l, int act, int B) {
+    Rows pc_layer_max(const std::string& name, const Rows& x, const Lin& l, int act, int B, const Rows* dst = nullptr, int coff = 0) {
         Packed pk = pack(l);
-        Rows y = alloc_rows(B, l.N);
+        Rows y;
+        if (dst) { y = *dst; y.p += coff; y.C = l.N; }         // channels [coff, coff + N) of a wider [B, .] tensor (PointNet++ multi-scale: the scales' maxima side by side)
+        else y = alloc_rows(B, l.N);
         GemmMaxParams g{x.p, x.ld, pk.w, pk.b, y.p, y.ld, int(x.rows / B), B, pk.K, pk.N, pk.nchunks, pk.ksteps, act};
         const dim3 grid(unsigned(pk.nchunks) * unsigned(B)), block(256);
         const int NT = pk.NT;
@@ -2164,8 +2166,12 @@ public:
         const int B = batch, N = cfg.num_points, D = cfg.pc_channels;
         static const int kDiv[4] = {2, 8, 32, 128};
         static const double kRadius[4] = {0.03, 0.06, 0.12, 0.24};
-        static const int kNs = 32;
         static const int kFpLayers[4] = {2, 2, 2, 3};                             // fp4, fp3, fp2, fp1
+        // spec.py::PN2 — one (radius, 32 samples) stack per level, keys sa{k}.mlp_convs.<i> — or PN2_MSG (round 6) — two stacks per level on the same centroids, radii [r, 2r],
+        // 16 / 32 samples, keys sa{k}.conv_blocks.<scale>.<i>, their maxima concatenated
+        const bool msg = cfg.pc_seg == ACH_PCSEG_PN2_MSG;
+        const int nscales = msg ? 2 : 1;
+        const int kNsS[2] = {msg ? 16 : 32, 32};
         if (N % 128 || N > 64 * PN2_FPS_MAX_PPT) throw AchError{ACH_ERR_UNSUPPORTED, "pn2: num_points must be a multiple of 128, at most 1024"};
         if (D < 3) throw AchError{ACH_ERR_UNSUPPORTED, "pn2: pc_channels must be at least 3 (xyz first)"};
         Pn2Level lv[5];
@@ -2212,22 +2218,39 @@ public:
             }
             { TapInfo t; t.ptr = dst.xyz; t.kind = 2; t.is_f32 = 1; t.B = B * S; t.H = 1; t.W = 1; t.C = 3; t.ld = 3; add_tap("pc.sa" + std::to_string(k + 1) + ".xyz", t); }
             { TapInfo t; t.ptr = fidx; t.kind = 2; t.is_i32 = 1; t.B = B; t.H = 1; t.W = 1; t.C = S; t.ld = S; add_tap("pc.sa" + std::to_string(k + 1) + ".fps", t); }
-            Rows g = alloc_rows(long(B) * S * kNs, 3 + src.f.C);
-            int* gidx = nullptr;
-            if (full_taps) {                                                      // parity hook: the ball-query selections themselves
-                gidx = static_cast<int*>(aalloc(size_t(B) * S * kNs * sizeof(int)));
-                TapInfo t; t.ptr = gidx; t.kind = 2; t.is_i32 = 1; t.B = B * S; t.H = 1; t.W = 1; t.C = kNs; t.ld = kNs; add_tap("pc.sa" + std::to_string(k + 1) + ".group_idx", t);
+            int wtot = 0, wsc[2] = {0, 0};
+            for (int j = 0; j < nscales; ++j) {
+                const std::string last = msg ? sa + ".conv_blocks." + std::to_string(j) + ".2.weight" : sa + ".mlp_convs.2.weight";
+                wsc[j] = int(W(last).shape[0]);
+                wtot += wsc[j];
             }
-            {
-                const int wpc = (group_wpc > 0 && long(B) * S <= group_wpc) ? 4 : 1;          // few centroids: a workgroup per centroid (k_pn2.h)
-                GroupParams q{src.xyz, dst.xyz, src.f.p, src.f.ld, src.f.C, g.p, g.ld, gidx, B, src.n, S, kNs, float(kRadius[k] * kRadius[k]), wpc};
-                const dim3 grid(unsigned(wpc == 4 ? long(B) * S : cdivl(long(B) * S, 4))), block(256);
-                add_op(sa + ".group", [q, grid, block](hipStream_t s) { ACH_LAUNCH(pn2_group_kernel<T>, grid, block, s, q); },
-                       double(g.rows) * g.C * sizeof(T) * 2.0);
+            if (msg) dst.f = alloc_rows(long(B) * S, wtot);
+            int coff = 0;
+            for (int j = 0; j < nscales; ++j) {
+                const int kNs = kNsS[j];
+                const double radius = kRadius[k] * (j == 0 ? 1.0 : 2.0);
+                const std::string sfx = msg ? "." + std::to_string(j) : "";
+                auto cname = [&](int i) { return msg ? sa + ".conv_blocks." + std::to_string(j) + "." + std::to_string(i) : sa + ".mlp_convs." + std::to_string(i); };
+                auto bname = [&](int i) { return msg ? sa + ".bn_blocks." + std::to_string(j) + "." + std::to_string(i) : sa + ".mlp_bns." + std::to_string(i); };
+                Rows g = alloc_rows(long(B) * S * kNs, 3 + src.f.C);
+                int* gidx = nullptr;
+                if (full_taps) {                                                      // parity hook: the ball-query selections themselves
+                    gidx = static_cast<int*>(aalloc(size_t(B) * S * kNs * sizeof(int)));
+                    TapInfo t; t.ptr = gidx; t.kind = 2; t.is_i32 = 1; t.B = B * S; t.H = 1; t.W = 1; t.C = kNs; t.ld = kNs; add_tap("pc.sa" + std::to_string(k + 1) + ".group_idx" + sfx, t);
+                }
+                {
+                    const int wpc = (group_wpc > 0 && long(B) * S <= group_wpc) ? 4 : 1;          // few centroids: a workgroup per centroid (k_pn2.h)
+                    GroupParams q{src.xyz, dst.xyz, src.f.p, src.f.ld, src.f.C, g.p, g.ld, gidx, B, src.n, S, kNs, float(radius * radius), wpc};
+                    const dim3 grid(unsigned(wpc == 4 ? long(B) * S : cdivl(long(B) * S, 4))), block(256);
+                    add_op(sa + ".group" + sfx, [q, grid, block](hipStream_t s) { ACH_LAUNCH(pn2_group_kernel<T>, grid, block, s, q); },
+                           double(g.rows) * g.C * sizeof(T) * 2.0);
+                }
+                Rows h = pc_layer(sa + ".mlp" + sfx + ".0", g, lin_bn1d(cname(0), bname(0)), ACT_RELU);
+                h = pc_layer(sa + ".mlp" + sfx + ".1", h, lin_bn1d(cname(1), bname(1)), ACT_RELU);
+                if (msg) pc_layer_max(sa + ".mlp" + sfx + ".2", h, lin_bn1d(cname(2), bname(2)), ACT_RELU, B * S, &dst.f, coff);
+                else dst.f = pc_layer_max(sa + ".mlp.2", h, lin_bn1d(cname(2), bname(2)), ACT_RELU, B * S);
+                coff += wsc[j];
             }
-            Rows h = pc_layer(sa + ".mlp.0", g, lin_bn1d(sa + ".mlp_convs.0", sa + ".mlp_bns.0"), ACT_RELU);
-            h = pc_layer(sa + ".mlp.1", h, lin_bn1d(sa + ".mlp_convs.1", sa + ".mlp_bns.1"), ACT_RELU);
-            dst.f = pc_layer_max(sa + ".mlp.2", h, lin_bn1d(sa + ".mlp_convs.2", sa + ".mlp_bns.2"), ACT_RELU, B * S);
             { TapInfo t; t.ptr = dst.f.p; t.kind = 2; t.B = B * S; t.H = 1; t.W = 1; t.C = dst.f.C; t.ld = dst.f.ld; add_tap("pc.sa" + std::to_string(k + 1) + ".feat", t); }
         }
         Rows cur = lv[4].f;
@@ -2271,9 +2294,9 @@ public:
         // branch opens stream 2 instead, ahead of fusion + head, which only start once the neck is done (measured +4.8 %; PointNet: neutral)
         // (auto: stream 2 for PointNet++, and in the pipelined plan, where it shares the stream with the decoders: 27.7 k against 26.4 k
         //  frames/s; the plain plan keeps PointNet on stream 1 ahead of the radar branch — two streams in all: 26.35 k against 25.95 k)
-        const bool point2 = point_on_head_stream < 0 ? (cfg.pc_seg == ACH_PCSEG_PN2 || (!head_stream && pipeline)) : point_on_head_stream != 0;
+        const bool point2 = point_on_head_stream < 0 ? (cfg.pc_seg == ACH_PCSEG_PN2 || cfg.pc_seg == ACH_PCSEG_PN2_MSG || (!head_stream && pipeline)) : point_on_head_stream != 0;
         const bool radar_late = radar_start_eff() >= 0 && multi_stream;
-        auto points = [&] { cur_stream = point_on_head_stream == 3 ? 3 : (point2 ? 2 : 1); if (cfg.pc_seg == ACH_PCSEG_PN2) pointnet2(); else if (cfg.pc_seg == ACH_PCSEG_PN) pointnet(); };   // ACH_PCSEG_NONE: Achelous3T
+        auto points = [&] { cur_stream = point_on_head_stream == 3 ? 3 : (point2 ? 2 : 1); if (cfg.pc_seg == ACH_PCSEG_PN2 || cfg.pc_seg == ACH_PCSEG_PN2_MSG) pointnet2(); else if (cfg.pc_seg == ACH_PCSEG_PN) pointnet(); };   // ACH_PCSEG_NONE: Achelous3T
         if (radar_late) points();         // the point branch (small launches) fills the window before the radar branch is released
         cur_stream = 1;
         if (radar_late) wait_before_next(0);

@@ -16,7 +16,7 @@ DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2      # include/achelous.h ACH_DTYPE_*
 BACKBONES = {'en': 0, 'mv': 1}
 PHIS = {'S0': 0, 'S1': 1, 'S2': 2}
 NECKS = {'gdf': 0, 'cdf': 1}
-PC_SEGS = {'pn': 0, 'pn2': 1, 'none': 2}     # 'none': Achelous3T (nets/Achelous.py:56-76), no point stream
+PC_SEGS = {'pn': 0, 'pn2': 1, 'none': 2, 'pn2_msg': 3}     # 'none': Achelous3T (nets/Achelous.py:56-76), no point stream
 
 _ERRORS = {-1: ValueError, -2: NotImplementedError, -3: KeyError, -4: RuntimeError, -5: MemoryError}
 

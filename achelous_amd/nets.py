@@ -104,8 +104,8 @@ def _check_supported(backbone, neck, pc_seg, phi, num_seg, image_channels, radar
         bad.append(f"backbone={backbone!r} (built: 'en' EdgeNeXt, 'mv' MobileViT; the reference default 'ef' and the other six backbones are out of scope)")
     if neck not in ('gdf', 'cdf'):
         bad.append(f"neck={neck!r} (built: 'gdf' Ghost-Dual-FPN, 'cdf' CSP-Dual-FPN)")
-    if pc_seg not in ('pn', 'pn2', 'none'):
-        bad.append(f"pc_seg={pc_seg!r} (built: 'pn' PointNet, 'pn2' PointNet++ per our own specification)")
+    if pc_seg not in ('pn', 'pn2', 'pn2_msg', 'none'):
+        bad.append(f"pc_seg={pc_seg!r} (built: 'pn' PointNet, 'pn2' / 'pn2_msg' PointNet++ per our own single- / multi-scale specification)")
     if phi not in ('S0', 'S1', 'S2'):
         bad.append(f"phi={phi!r} (built: 'S0', 'S1', 'S2')")
     if neck == 'gdf' and not 1 <= num_seg <= 16:
@@ -422,7 +422,7 @@ class Achelous(nn.Module):
         # tiles.  PointNet is per-point MLPs + max over points, so repeating the last point changes nothing: pad to the next
         # multiple of 16 (the engine's bucket) and trim the padded rows of the output.  PointNet++ (our own specification) samples
         # and groups by index and takes multiples of 128 only.
-        N = n_in if self.pc_seg_kind == 'pn2' else -(-n_in // 16) * 16
+        N = n_in if self.pc_seg_kind in ('pn2', 'pn2_msg') else -(-n_in // 16) * 16
         with torch.cuda.device(dev):
             eng = self._engine_for(dev, dt, B, N, pipelined)
             x, x_radar = x.contiguous(), x_radar.to(dt).contiguous()

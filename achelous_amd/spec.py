@@ -91,19 +91,55 @@ PN2 = dict(
 )
 
 
-def _pointnet2(s, pc_channels, pc_classes):
+# The MULTI-scale-grouping variant (`pc_seg='pn2_msg'`, round 6): the reference's only PointNet++ datum — README.md:81,83: +0.09 M parameters and
+# +0.08 GFLOPs over the PointNet model — is fitted by the multi-scale semantic-segmentation model of the same public project (two radii per level, two shared-MLP stacks whose
+# maxima are concatenated), not by the single-scale one above (profiles/scripts/pn2_spec_search.py; DESIGN.md 5b has the parameter / MAC table).  Widths, sample counts and key
+# names (`conv_blocks.<scale>.<layer>`, `bn_blocks...`) are that model's; level sizes and the radius ladder are PN2's (each level: [r, 2r]); every tie / distance rule is
+# PN2's, and a grouped row is [xyz - centroid | features] at BOTH scales (the published multi-scale code concatenates the other way round: a permutation of the first
+# layer's input columns, fixed here so that one grouping kernel serves both variants).  Self-specified and self-checked like PN2: PARITY UNPINNED.
+PN2_MSG = dict(
+    sa=[dict(div=2, scales=[dict(radius=0.03, nsample=16, mlp=[16, 16, 32]), dict(radius=0.06, nsample=32, mlp=[32, 32, 64])]),
+        dict(div=8, scales=[dict(radius=0.06, nsample=16, mlp=[64, 64, 128]), dict(radius=0.12, nsample=32, mlp=[64, 96, 128])]),
+        dict(div=32, scales=[dict(radius=0.12, nsample=16, mlp=[128, 196, 256]), dict(radius=0.24, nsample=32, mlp=[128, 196, 256])]),
+        dict(div=128, scales=[dict(radius=0.24, nsample=16, mlp=[256, 256, 512]), dict(radius=0.48, nsample=32, mlp=[256, 384, 512])])],
+    fp=[[256, 256], [256, 256], [256, 128], [128, 128, 128]],          # fp4, fp3, fp2, fp1
+    head=128,
+)
+PN2_VARIANTS = {'pn2': PN2, 'pn2_msg': PN2_MSG}
+
+
+def pn2_scales(level):
+    """The (radius, nsample, mlp) stacks of a set-abstraction level: one for the single-scale specification, two for the multi-scale one."""
+    return level['scales'] if 'scales' in level else [dict(radius=level['radius'], nsample=level['nsample'], mlp=level['mlp'])]
+
+
+def pn2_level_width(level):
+    return sum(sc['mlp'][-1] for sc in pn2_scales(level))
+
+
+def _pointnet2(s, pc_channels, pc_classes, spec=None):
+    spec = spec or PN2
     p = 'pc_seg_model'
-    feat = [pc_channels] + [lvl['mlp'][-1] for lvl in PN2['sa']]        # feature width at l0 .. l4
-    for k, lvl in enumerate(PN2['sa']):
-        cin = feat[k] + 3
-        for i, c in enumerate(lvl['mlp']):
-            s.wb(f'{p}.sa{k + 1}.mlp_convs.{i}', (c, cin, 1, 1))
-            cin = c
-        for i, c in enumerate(lvl['mlp']):
-            s.bn(f'{p}.sa{k + 1}.mlp_bns.{i}', c)
+    feat = [pc_channels] + [pn2_level_width(lvl) for lvl in spec['sa']]        # feature width at l0 .. l4
+    for k, lvl in enumerate(spec['sa']):
+        if 'scales' not in lvl:
+            cin = feat[k] + 3
+            for i, c in enumerate(lvl['mlp']):
+                s.wb(f'{p}.sa{k + 1}.mlp_convs.{i}', (c, cin, 1, 1))
+                cin = c
+            for i, c in enumerate(lvl['mlp']):
+                s.bn(f'{p}.sa{k + 1}.mlp_bns.{i}', c)
+            continue
+        for j, sc in enumerate(lvl['scales']):
+            cin = feat[k] + 3
+            for i, c in enumerate(sc['mlp']):
+                s.wb(f'{p}.sa{k + 1}.conv_blocks.{j}.{i}', (c, cin, 1, 1))
+                cin = c
+            for i, c in enumerate(sc['mlp']):
+                s.bn(f'{p}.sa{k + 1}.bn_blocks.{j}.{i}', c)
     cur = feat[-1]
-    L = len(PN2['sa'])
-    for j, widths in enumerate(PN2['fp']):
+    L = len(spec['sa'])
+    for j, widths in enumerate(spec['fp']):
         lvl = L - 1 - j                                                  # dense level of this propagation
         cin = cur + (feat[lvl] if lvl > 0 else 0)
         for i, c in enumerate(widths):
@@ -112,9 +148,9 @@ def _pointnet2(s, pc_channels, pc_classes):
         for i, c in enumerate(widths):
             s.bn(f'{p}.fp{lvl + 1}.mlp_bns.{i}', c)
         cur = widths[-1]
-    s.wb(p + '.conv1', (PN2['head'], cur, 1))
-    s.bn(p + '.bn1', PN2['head'])
-    s.wb(p + '.conv2', (pc_classes, PN2['head'], 1))
+    s.wb(p + '.conv1', (spec['head'], cur, 1))
+    s.bn(p + '.bn1', spec['head'])
+    s.wb(p + '.conv2', (pc_classes, spec['head'], 1))
 
 
 def _edgenext(s, pfx, phi):                     # edgenext.py:9-62
@@ -341,13 +377,16 @@ def state_dict_spec(num_det, num_seg, phi='S0', backbone='en', pc_channels=6, pc
                     radar_channels=3, neck='gdf', pc_seg='pn'):
     """Ordered [(key, shape, kind)] of the reference state_dict for neck in {'gdf', 'cdf'}, pc_seg='pn'; with pc_seg='pn2' the
     `pc_seg_model.*` keys are those of our own PointNet++ specification (PN2 above)."""
-    if pc_seg not in ('pn', 'pn2', 'none'):
-        raise NotImplementedError(f"pc_seg={pc_seg!r}: 'pn' (reference), 'pn2' (own specification) and 'none' (Achelous3T, nets/Achelous.py:56-76) are built")
+    if pc_seg not in ('pn', 'pn2', 'pn2_msg', 'none'):
+        raise NotImplementedError(f"pc_seg={pc_seg!r}: 'pn' (reference), 'pn2' / 'pn2_msg' (own specifications) and 'none' (Achelous3T, nets/Achelous.py:56-76) are built")
     if phi not in WIDTHS or backbone not in ('en', 'mv') or neck not in ('gdf', 'cdf'):
         raise NotImplementedError(f"backbone={backbone!r}, phi={phi!r}, neck={neck!r}: only 'en'/'mv' with S0/S1/S2 and gdf/cdf are built")
     s = _Spec()
     if pc_seg != 'none':
-        (_pointnet if pc_seg == 'pn' else _pointnet2)(s, pc_channels, pc_classes)
+        if pc_seg == 'pn':
+            _pointnet(s, pc_channels, pc_classes)
+        else:
+            _pointnet2(s, pc_channels, pc_classes, PN2_VARIANTS[pc_seg])
     (_neck if neck == 'gdf' else _neck_csp)(s, phi, backbone, num_seg)
     _radar(s, phi, radar_channels)
     _fusion(s, phi)

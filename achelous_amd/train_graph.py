@@ -392,22 +392,28 @@ class TrainGraph:
         engine and oracle/pointnet2_oracle.py follow; the geometry kernels ARE the inference engine's (k_pn2.h at fp32), so a training forward selects exactly the
         points an inference forward selects."""
         import numpy as np
-        from .spec import PN2
+        from .spec import PN2_VARIANTS, pn2_scales
+        PN2 = PN2_VARIANTS[self.m.pc_seg_kind]
         p = 'pc_seg_model'
         B, D, N = pts.shape
         rows = pts.transpose(1, 2).contiguous()                                   # [B, N, D]
         levels = [(rows[:, :, :3].contiguous(), rows)]
         for k, cfg in enumerate(PN2['sa']):
             xyz, feats = levels[-1]
-            S, K = N // cfg['div'], cfg['nsample']
+            S = N // cfg['div']
             _, new_xyz = TF.pn2_fps(xyz, S)
-            h = TF.pn2_group(xyz, new_xyz, feats, K, float(np.float32(cfg['radius'] * cfg['radius'])))          # [B*S*K, 3 + C]
-            x = h.t().contiguous().unsqueeze(0)
-            for i in range(len(cfg['mlp'])):
-                x = self.shared_mlp(x, f'{p}.sa{k + 1}.mlp_convs.{i}', f'{p}.sa{k + 1}.mlp_bns.{i}')
-            cout = x.shape[1]
-            f = _MaxPointsFn.apply(x.view(cout, B * S, K))                       # max over the ball: [cout, B*S]
-            levels.append((new_xyz, f.t().contiguous().view(B, S, cout)))
+            outs = []
+            for j, sc in enumerate(pn2_scales(cfg)):                              # one (radius, nsample, MLP) stack — or two, on the same centroids (pn2_msg)
+                K = sc['nsample']
+                h = TF.pn2_group(xyz, new_xyz, feats, K, float(np.float32(sc['radius'] * sc['radius'])))        # [B*S*K, 3 + C]
+                x = h.t().contiguous().unsqueeze(0)
+                for i in range(len(sc['mlp'])):
+                    names = (f'{p}.sa{k + 1}.conv_blocks.{j}.{i}', f'{p}.sa{k + 1}.bn_blocks.{j}.{i}') if 'scales' in cfg else (f'{p}.sa{k + 1}.mlp_convs.{i}', f'{p}.sa{k + 1}.mlp_bns.{i}')
+                    x = self.shared_mlp(x, *names)
+                cout = x.shape[1]
+                f = _MaxPointsFn.apply(x.view(cout, B * S, K))                   # max over the ball: [cout, B*S]
+                outs.append(f.t().contiguous().view(B, S, cout))
+            levels.append((new_xyz, outs[0] if len(outs) == 1 else torch.cat(outs, 2).contiguous()))
         cur = levels[-1][1]
         L = len(PN2['sa'])
         for j, widths in enumerate(PN2['fp']):                                   # fp4 .. fp1
@@ -428,7 +434,7 @@ class TrainGraph:
                 raise TypeError("training mode runs in float32")
         pc = None                                                                    # Achelous3T: no point stream
         if x_pc is not None:
-            pc = self.pointnet2(x_pc.contiguous()) if self.m.pc_seg_kind == 'pn2' else self.pointnet(x_pc.contiguous())
+            pc = self.pointnet2(x_pc.contiguous()) if self.m.pc_seg_kind in ('pn2', 'pn2_msg') else self.pointnet(x_pc.contiguous())
         se, lane, (q5, q4, q3) = self.ghost_dual_fpn(x.contiguous())
         r3, r4, r5 = self.rcnet(x_radar.contiguous())
         det = self.head((self.fuse(q3, r3, 3), self.fuse(q4, r4, 4), self.fuse(q5, r5, 5)))

@@ -53,10 +53,12 @@ CONFIGS = {
     'mv_s2': (3, dict(backbone='mv', phi='S2')),
     'en_s0_cdf': (6, dict(backbone='en', phi='S0', neck='cdf')),      # SURVEY §8(f) rank 3 (not a BASELINE config)
     'en_s0_pn2': (4, dict(backbone='en', phi='S0', pc_seg='pn2')),    # BASELINE config 4: PointNet++ per our own specification
+    'en_s0_pn2_msg': (8, dict(backbone='en', phi='S0', pc_seg='pn2_msg')),   # the multi-scale-grouping PointNet++ (round 6): the variant README.md:81,83's parameter count points at; own specification
     'en_s1': (7, dict(backbone='en', phi='S1')),                      # the middle width (not a BASELINE config)
 }
 WORKLOAD_NAMES = {'en_s0': 'EN-GDF-PN-S0', 'en_s2': 'EN-GDF-PN-S2', 'mv_s2': 'MV-GDF-PN-S2', 'en_s0_cdf': 'EN-CDF-PN-S0', 'en_s1': 'EN-GDF-PN-S1',
-                  'en_s0_pn2': 'EN-GDF-PN2-S0 (PointNet++ per our own specification)'}
+                  'en_s0_pn2': 'EN-GDF-PN2-S0 (PointNet++ per our own specification)',
+                  'en_s0_pn2_msg': 'EN-GDF-PN2-S0 (multi-scale-grouping PointNet++ per our own specification)'}
 COMMON = dict(num_det=7, num_seg=9, resolution=320, neck='gdf', pc_seg='pn', pc_channels=5, pc_classes=8, nano_head=True, spp=True)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'f16': 2500.0, 'f32': 157.3}

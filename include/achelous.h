@@ -56,7 +56,9 @@ enum { ACH_NECK_GDF = 0, ACH_NECK_CDF = 1 };     /* Ghost-Dual-FPN (neck/ghostdu
  * (state-dict keys pc_seg_model.sa{1-4} / fp{4-1} / conv1 / bn1 / conv2); num_points must be a multiple
  * of 128 and at most 1024. */
 enum { ACH_PCSEG_PN = 0, ACH_PCSEG_PN2 = 1,
-       ACH_PCSEG_NONE = 2   /* nets/Achelous.py:56-76 (Achelous3T): no point-cloud stream; `points` / `pc_seg` arguments are ignored (may be NULL) */ };
+       ACH_PCSEG_NONE = 2,  /* nets/Achelous.py:56-76 (Achelous3T): no point-cloud stream; `points` / `pc_seg` arguments are ignored (may be NULL) */
+       ACH_PCSEG_PN2_MSG = 3 /* round 6: the MULTI-scale-grouping PointNet++ (spec.py::PN2_MSG: two radii and two shared-MLP stacks per level, keys sa{k}.conv_blocks.<scale>.<layer>):
+                                the variant the reference's only PointNet++ datum (README.md:81,83: ~2.0 M parameters) points at; own specification, parity unpinned */ };
 
 typedef struct ach_config {
     int32_t num_det;        /* detection classes           (Achelous.__init__ num_det)      */

@@ -19,7 +19,7 @@ import torch.nn.functional as F
 
 from .deform_conv import deform_conv2d
 from .nms import batched_nms_np
-from .pointnet2_oracle import PointNet2Oracle
+from .pointnet2_oracle import PN2, PN2_MSG, PointNet2Oracle
 
 WIDTHS = {'S0': [32, 48, 96, 176], 'S1': [32, 48, 120, 224], 'S2': [32, 64, 144, 288]}  # neck/ghostdualfpn.py:20-25
 
@@ -38,11 +38,11 @@ MOBILEVIT = {  # backbone/vision/mobilevit_modules/mobilevit.py:225-240
 class AchelousOracle:
     def __init__(self, state_dict, num_det=7, num_seg=9, phi='S0', backbone='en', neck='gdf', pc_seg='pn',
                  pc_channels=5, pc_classes=8, nano_head=True, spp=True, resolution=320, boundary_dtype=None):
-        if neck not in ('gdf', 'cdf') or backbone not in ('en', 'mv') or pc_seg not in ('pn', 'pn2'):
-            raise NotImplementedError("oracle covers backbone in {en,mv}, neck in {gdf,cdf}, pc_seg in {pn,pn2}")
+        if neck not in ('gdf', 'cdf') or backbone not in ('en', 'mv') or pc_seg not in ('pn', 'pn2', 'pn2_msg'):
+            raise NotImplementedError("oracle covers backbone in {en,mv}, neck in {gdf,cdf}, pc_seg in {pn,pn2,pn2_msg}")
         self.neck = neck
         # 'pn2' has no reference implementation: own specification, self-oracle, parity unpinned (pointnet2_oracle.py)
-        self.pn2 = PointNet2Oracle(state_dict) if pc_seg == 'pn2' else None
+        self.pn2 = PointNet2Oracle(state_dict, {'pn2': PN2, 'pn2_msg': PN2_MSG}[pc_seg]) if pc_seg in ('pn2', 'pn2_msg') else None
         self.sd = {k: (v.detach().to(device='cpu', dtype=torch.float32) if v.is_floating_point() else v.detach().cpu())
                    for k, v in state_dict.items()}
         self.num_det, self.num_seg, self.phi, self.backbone = num_det, num_seg, phi, backbone

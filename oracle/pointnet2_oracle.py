@@ -38,6 +38,19 @@ PN2 = dict(
 )
 
 
+# the multi-scale-grouping variant (`pc_seg='pn2_msg'`, spec.py::PN2_MSG — equally our own specification, equally PARITY UNPINNED): per level two (radius, nsample,
+# shared-MLP) stacks on the same centroids, their maxima concatenated; widths / sample counts / key names of the public project's multi-scale semantic-segmentation model,
+# level sizes, radius ladder and every geometry rule as above; a grouped row is [xyz - centroid | features] at both scales.
+PN2_MSG = dict(
+    sa=[dict(div=2, scales=[dict(radius=0.03, nsample=16, mlp=[16, 16, 32]), dict(radius=0.06, nsample=32, mlp=[32, 32, 64])]),
+        dict(div=8, scales=[dict(radius=0.06, nsample=16, mlp=[64, 64, 128]), dict(radius=0.12, nsample=32, mlp=[64, 96, 128])]),
+        dict(div=32, scales=[dict(radius=0.12, nsample=16, mlp=[128, 196, 256]), dict(radius=0.24, nsample=32, mlp=[128, 196, 256])]),
+        dict(div=128, scales=[dict(radius=0.24, nsample=16, mlp=[256, 256, 512]), dict(radius=0.48, nsample=32, mlp=[256, 384, 512])])],
+    fp=[[256, 256], [256, 256], [256, 128], [128, 128, 128]],
+    head=128,
+)
+
+
 def sqdist(a, b):
     """[n,3], [m,3] -> [n,m]; ((dx*dx + dy*dy) + dz*dz), fp32, one rounding per operation."""
     d = a[:, None, :].astype(f32) - b[None, :, :].astype(f32)
@@ -105,14 +118,25 @@ class PointNet2Oracle:
         s = n0 // cfg['div']
         fps = farthest_point_sample(xyz, s)
         new_xyz = xyz[fps]
-        idx = ball_query(cfg['radius'], cfg['nsample'], xyz, new_xyz)
-        g = np.concatenate([xyz[idx] - new_xyz[:, None, :], feats[idx]], -1)          # [s, ns, 3 + C]
-        h = g.reshape(s * cfg['nsample'], -1).astype(f32)
-        for i in range(len(cfg['mlp'])):
-            h = self.mlp(h, f'{pfx}.mlp_convs.{i}', f'{pfx}.mlp_bns.{i}')
         self.taps[f'pc.sa{k + 1}.fps'] = fps
-        self.taps[f'pc.sa{k + 1}.group_idx'] = idx
-        return new_xyz, h.reshape(s, cfg['nsample'], -1).max(1)
+        if 'scales' not in cfg:
+            idx = ball_query(cfg['radius'], cfg['nsample'], xyz, new_xyz)
+            g = np.concatenate([xyz[idx] - new_xyz[:, None, :], feats[idx]], -1)          # [s, ns, 3 + C]
+            h = g.reshape(s * cfg['nsample'], -1).astype(f32)
+            for i in range(len(cfg['mlp'])):
+                h = self.mlp(h, f'{pfx}.mlp_convs.{i}', f'{pfx}.mlp_bns.{i}')
+            self.taps[f'pc.sa{k + 1}.group_idx'] = idx
+            return new_xyz, h.reshape(s, cfg['nsample'], -1).max(1)
+        outs = []
+        for j, sc in enumerate(cfg['scales']):                                           # multi-scale: the same centroids, one ball query + MLP stack per radius
+            idx = ball_query(sc['radius'], sc['nsample'], xyz, new_xyz)
+            g = np.concatenate([xyz[idx] - new_xyz[:, None, :], feats[idx]], -1)
+            h = g.reshape(s * sc['nsample'], -1).astype(f32)
+            for i in range(len(sc['mlp'])):
+                h = self.mlp(h, f'{pfx}.conv_blocks.{j}.{i}', f'{pfx}.bn_blocks.{j}.{i}')
+            self.taps[f'pc.sa{k + 1}.group_idx.{j}'] = idx
+            outs.append(h.reshape(s, sc['nsample'], -1).max(1))
+        return new_xyz, np.concatenate(outs, -1)
 
     def feature_propagation(self, name, nlayers, xyz1, xyz2, p1, p2):
         idx, w = three_nn_weights(xyz1, xyz2)

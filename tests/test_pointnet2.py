@@ -18,10 +18,19 @@ KW = dict(num_det=7, num_seg=9, phi='S0', backbone='en', neck='gdf', pc_seg='pn2
           spp=True, resolution=64)
 
 
-def _state_dict(seed=0):
+KWM = {**KW, 'pc_seg': 'pn2_msg'}              # the multi-scale-grouping variant (round 6; spec.py::PN2_MSG): equally our own specification, equally parity unpinned
+KWS = {'pn2': KW, 'pn2_msg': KWM}
+VARIANTS = ['pn2', 'pn2_msg']
+
+
+def _state_dict(seed=0, variant='pn2'):
     blank = {k: torch.zeros(s, dtype=torch.int64 if kind == 'buffer_i64' else torch.float32)
-             for k, s, kind in spec.state_dict_spec(7, 9, 'S0', 'en', 5, 8, True, 3, 'gdf', 'pn2')}
+             for k, s, kind in spec.state_dict_spec(7, 9, 'S0', 'en', 5, 8, True, 3, 'gdf', variant)}
     return condition_state_dict(blank, seed=seed)
+
+
+def _is_index_tap(tap):
+    return tap.endswith(('.fps', '.xyz')) or '.group_idx' in tap
 
 
 def _rel(a, b):
@@ -31,7 +40,23 @@ def _rel(a, b):
 
 # ------------------------------------------------------------------------------------------------ specification / oracle
 def test_oracle_constants_equal_the_specification():
-    assert po.PN2 == spec.PN2
+    assert po.PN2 == spec.PN2 and po.PN2_MSG == spec.PN2_MSG
+
+
+def test_state_dict_keys_of_the_multi_scale_specification():
+    keys = [(k, s) for k, s, _ in spec.state_dict_spec(7, 9, 'S0', 'en', 5, 8, True, 3, 'gdf', 'pn2_msg') if k.startswith('pc_seg_model.')]
+    d = dict(keys)
+    assert len(keys) == 240
+    assert d['pc_seg_model.sa1.conv_blocks.0.0.weight'] == (16, 8, 1, 1) and d['pc_seg_model.sa1.conv_blocks.1.2.weight'] == (64, 32, 1, 1)
+    assert d['pc_seg_model.sa2.conv_blocks.1.0.weight'] == (64, 99, 1, 1)      # 3 relative coordinates + (32 + 64) features of level 1
+    assert d['pc_seg_model.sa3.conv_blocks.0.1.weight'] == (196, 128, 1, 1)
+    assert d['pc_seg_model.fp4.mlp_convs.0.weight'] == (256, 1536, 1)         # skip 512 + interpolated 1024
+    assert d['pc_seg_model.fp2.mlp_convs.0.weight'] == (256, 352, 1)          # skip 96 + interpolated 256
+    n = sum(int(np.prod(s)) for k, s in keys if 'running' not in k and 'num_batches' not in k)
+    assert n == 1882432                                                       # README.md:81,83 point at ~2.0 M for the reference's PN2 row; the single-scale PN2 has 0.97 M
+    ref = [k for k, _, _ in spec.state_dict_spec(7, 9, 'S0', 'en', 5, 8, True, 3, 'gdf', 'pn') if not k.startswith('pc_seg_model.')]
+    own = [k for k, _, _ in spec.state_dict_spec(7, 9, 'S0', 'en', 5, 8, True, 3, 'gdf', 'pn2_msg') if not k.startswith('pc_seg_model.')]
+    assert ref == own
 
 
 def test_state_dict_keys_of_the_specification():
@@ -112,10 +137,12 @@ def test_module_accepts_pn2_and_declares_the_specified_parameters():
 
 
 # ------------------------------------------------------------------------------------------------ engine under emulation
+@pytest.mark.parametrize('variant', VARIANTS)
 @pytest.mark.parametrize('dtype,tol', [(DTYPE_F32, 2e-5), (DTYPE_BF16, 6e-2)])
-def test_emulated_pn2_matches_the_self_oracle(dtype, tol):
+def test_emulated_pn2_matches_the_self_oracle(dtype, tol, variant):
     from emu_util import alloc_outputs, emu_library, make_engine
-    sd = _state_dict()
+    KW = KWS[variant]
+    sd = _state_dict(variant=variant)
     B, npts = 2, 512
     td = torch.float32 if dtype == DTYPE_F32 else torch.bfloat16
     x, xr, xp = make_inputs(B, 7, resolution=64, num_points=npts, pc_channels=5, radar_cells=40)
@@ -132,12 +159,12 @@ def test_emulated_pn2_matches_the_self_oracle(dtype, tol):
             continue
         a, b = eng.read_tap(tap), orc.taps[tap]
         a = a.reshape(b.shape)
-        if tap.endswith(('.fps', '.group_idx', '.xyz')):
+        if _is_index_tap(tap):
             assert torch.equal(a, b.float()), tap      # index selection: bit-exact
         else:
             assert _rel(a, b.float()) < tol, tap
         seen += 1
-    assert seen == 4 * 4 + 4
+    assert seen == (4 * 4 + 4 if variant == 'pn2' else 4 * 5 + 4)
 
 
 @pytest.mark.parametrize('dtype', [DTYPE_F32, DTYPE_BF16])
@@ -175,9 +202,10 @@ def test_emulated_pn2_rejects_unsupported_point_counts():
 
 # ------------------------------------------------------------------------------------------------ HIP build (MI355X)
 @pytest.mark.gpu
+@pytest.mark.parametrize('variant', VARIANTS)
 @pytest.mark.parametrize('dtype,tol', [(torch.float32, 1e-3), (torch.bfloat16, 6e-2)])
-def test_gpu_pn2_matches_the_self_oracle(dtype, tol):
-    kw = {**KW, 'resolution': 320}
+def test_gpu_pn2_matches_the_self_oracle(dtype, tol, variant):
+    kw = {**KWS[variant], 'resolution': 320}
     m = achelous_amd.Achelous(**kw).eval()
     m.debug_taps = True
     sd = condition_state_dict(m.state_dict(), seed=0)
@@ -200,12 +228,12 @@ def test_gpu_pn2_matches_the_self_oracle(dtype, tol):
         if tap.startswith('pc.'):
             a, b = e.read_tap(tap), orc.taps[tap]
             a = a.reshape(b.shape)
-            if tap.endswith(('.fps', '.group_idx', '.xyz')):
+            if _is_index_tap(tap):
                 assert torch.equal(a.cpu(), b.float()), tap
             else:
                 assert _rel(a, b.float()) <= tol, tap
             checked += 1
-    assert checked == 20
+    assert checked == (20 if variant == 'pn2' else 24)
 
 
 @pytest.mark.gpu
@@ -227,12 +255,13 @@ def test_gpu_pn2_batch_64_is_batch_independent():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('variant', VARIANTS)
 @pytest.mark.parametrize('dtype,tol', [(torch.float32, 1e-3), (torch.bfloat16, 6e-2)])
-def test_gpu_pn2_batch_64_frames_match_the_self_oracle(dtype, tol):
+def test_gpu_pn2_batch_64_frames_match_the_self_oracle(dtype, tol, variant):
     """BASELINE.json config 4 at its full size, DIRECTLY against the self-oracle (not through batch independence): frames 0, 21, 42, 63
     of a batch of 64 distinct frames — the B=64 plan (flat colmax grid, N-chunk split) differs from the small-batch plans.  Index
     selections (FPS picks, ball members) bit-exact, features within the tolerance, the whole batch finite and normalised."""
-    kw = {**KW, 'resolution': 320}
+    kw = {**KWS[variant], 'resolution': 320}
     m = achelous_amd.Achelous(**kw).eval()
     m.debug_taps = True
     sd = condition_state_dict(m.state_dict(), seed=0)
@@ -247,13 +276,13 @@ def test_gpu_pn2_batch_64_frames_match_the_self_oracle(dtype, tol):
     orc = AchelousOracle({k: v.cpu() for k, v in sd.items()}, **kw)
     rdet, rse, rlane, rpc = orc.forward(x[pick], xr[pick], xp[pick].float())
     errs = {n: _rel(a[pick].float(), b.float()) for n, a, b in zip(('det0', 'det1', 'det2', 'se', 'lane', 'pc'), (*det, se, lane, pc), (*rdet, rse, rlane, rpc))}
-    print('PN2 B=64 frames', pick, dtype, {k: f'{v:.1e}' for k, v in errs.items()})
+    print(variant, 'B=64 frames', pick, dtype, {k: f'{v:.1e}' for k, v in errs.items()})
     assert max(errs.values()) <= tol, errs
     assert torch.isfinite(pc.float()).all() and torch.allclose(pc.float().exp().sum(-1), torch.ones(64, 512, device='cuda'), atol=3e-2 if dtype == torch.bfloat16 else 1e-4)
     e = m.native_engine(dtype)
     checked = 0
     for tap in e.tap_names():
-        if tap.startswith('pc.') and tap.endswith(('.fps', '.group_idx', '.xyz')):
+        if tap.startswith('pc.') and _is_index_tap(tap):
             a, b = e.read_tap(tap), orc.taps[tap]
             a = a.reshape(64, *b.shape[1:]) if a.numel() == 16 * b.numel() else a
             assert torch.equal(a[pick].cpu().reshape(b.shape), b.float()), tap
@@ -262,7 +291,7 @@ def test_gpu_pn2_batch_64_frames_match_the_self_oracle(dtype, tol):
 
 
 # ------------------------------------------------------------------------------------------------ training mode (round 5)
-def _pn2_autograd_reference(sd, pts, cot, dtype):
+def _pn2_autograd_reference(sd, pts, cot, dtype, variant='pn2'):
     """The specification's graph in TRAINING mode through torch autograd: index selection by the numpy oracle's own functions (fp32, the rules of DESIGN 5b), every
     differentiable operation a torch op in `dtype`, BatchNorm on batch statistics.  -> (log-probabilities [B, N, classes], {parameter: gradient})."""
     import torch.nn.functional as F
@@ -278,24 +307,32 @@ def _pn2_autograd_reference(sd, pts, cot, dtype):
     xyz = [[np.ascontiguousarray(rows[b, :, :3].float().numpy()) for b in range(B)]]
     feats = [rows]
     p = 'pc_seg_model'
-    for k, cfg in enumerate(po.PN2['sa']):
-        S, K = N // cfg['div'], cfg['nsample']
-        new_xyz, groups = [], []
+    SPEC = {'pn2': po.PN2, 'pn2_msg': po.PN2_MSG}[variant]
+    for k, cfg in enumerate(SPEC['sa']):
+        S = N // cfg['div']
+        new_xyz = []
         for b in range(B):
             fps = po.farthest_point_sample(xyz[-1][b], S)
-            nx = xyz[-1][b][fps]
-            idx = torch.from_numpy(po.ball_query(cfg['radius'], K, xyz[-1][b], nx).astype(np.int64))
-            rel = torch.from_numpy(xyz[-1][b][idx.numpy()] - nx[:, None, :]).to(dtype)      # fp32 differences, as the kernel forms them
-            groups.append(torch.cat([rel, feats[-1][b][idx]], -1))                       # [S, K, 3 + C]
-            new_xyz.append(nx)
-        h = torch.stack(groups).reshape(B * S * K, -1)
-        for i in range(len(cfg['mlp'])):
-            h = mlp(h, f'{p}.sa{k + 1}.mlp_convs.{i}', f'{p}.sa{k + 1}.mlp_bns.{i}')
-        feats.append(h.reshape(B, S, K, -1).max(2).values)
+            new_xyz.append(xyz[-1][b][fps])
+        outs = []
+        for j, sc in enumerate(spec.pn2_scales(cfg)):
+            K = sc['nsample']
+            groups = []
+            for b in range(B):
+                nx = new_xyz[b]
+                idx = torch.from_numpy(po.ball_query(sc['radius'], K, xyz[-1][b], nx).astype(np.int64))
+                rel = torch.from_numpy(xyz[-1][b][idx.numpy()] - nx[:, None, :]).to(dtype)      # fp32 differences, as the kernel forms them
+                groups.append(torch.cat([rel, feats[-1][b][idx]], -1))                       # [S, K, 3 + C]
+            h = torch.stack(groups).reshape(B * S * K, -1)
+            for i in range(len(sc['mlp'])):
+                names = (f'{p}.sa{k + 1}.conv_blocks.{j}.{i}', f'{p}.sa{k + 1}.bn_blocks.{j}.{i}') if 'scales' in cfg else (f'{p}.sa{k + 1}.mlp_convs.{i}', f'{p}.sa{k + 1}.mlp_bns.{i}')
+                h = mlp(h, *names)
+            outs.append(h.reshape(B, S, K, -1).max(2).values)
+        feats.append(outs[0] if len(outs) == 1 else torch.cat(outs, -1))
         xyz.append(new_xyz)
     cur = feats[-1]
-    L = len(po.PN2['sa'])
-    for j, widths in enumerate(po.PN2['fp']):
+    L = len(SPEC['sa'])
+    for j, widths in enumerate(SPEC['fp']):
         lvl = L - 1 - j
         outs = []
         for b in range(B):
@@ -314,10 +351,10 @@ def _pn2_autograd_reference(sd, pts, cot, dtype):
     return y.detach().double(), {k: v.grad.double() for k, v in P.items() if v.grad is not None}
 
 
-def _check_pn2_training(dev, B=2, npts=384):
+def _check_pn2_training(dev, B=2, npts=384, variant='pn2'):
     from achelous_amd.train_graph import TrainGraph
-    sd = _state_dict()
-    m = achelous_amd.Achelous(**{**KW, 'resolution': 64})
+    sd = _state_dict(variant=variant)
+    m = achelous_amd.Achelous(**{**KWS[variant], 'resolution': 64})
     m.load_state_dict(sd, strict=True)
     m = m.to(dev).train()
     _, _, xp = make_inputs(B, 7, resolution=64, num_points=npts, pc_channels=5, radar_cells=40)
@@ -327,8 +364,8 @@ def _check_pn2_training(dev, B=2, npts=384):
     g = torch.Generator().manual_seed(2)
     cot = torch.randn(pc.shape, generator=g)
     (pc * cot.to(dev)).sum().backward()
-    ref, rg = _pn2_autograd_reference(sd, xp, cot, torch.float64)
-    _, yg = _pn2_autograd_reference(sd, xp, cot, torch.float32)                 # torch's own float32 evaluation: the yardstick
+    ref, rg = _pn2_autograd_reference(sd, xp, cot, torch.float64, variant)
+    _, yg = _pn2_autograd_reference(sd, xp, cot, torch.float32, variant)        # torch's own float32 evaluation: the yardstick
     assert pc.shape == (B, npts, 8) and _rel(pc.detach().cpu().float(), ref.float()) < 2e-4
     gscale = max(float(v.abs().max()) for v in rg.values())
     seen = 0
@@ -348,21 +385,23 @@ def _check_pn2_training(dev, B=2, npts=384):
             assert int(v) == 1, k
 
 
-def test_emulated_pn2_training_branch_matches_autograd():
+@pytest.mark.parametrize('variant', VARIANTS)
+def test_emulated_pn2_training_branch_matches_autograd(variant):
     """`pc_seg='pn2'` in `.train()` (round 5: it used to raise): log-probabilities and the gradient of every parameter of the branch against torch autograd (float64)
     on the specification's graph with the oracle's index selection — SELF-ORACLE, parity unpinned, like the branch's forward."""
     from achelous_amd import train_ops
     from emu_util import emu_library
     train_ops._lib.test_library = emu_library()
     try:
-        _check_pn2_training('cpu')
+        _check_pn2_training('cpu', variant=variant)
     finally:
         train_ops._lib.test_library = None
 
 
 @pytest.mark.gpu
-def test_gpu_pn2_training_branch_matches_autograd():
-    _check_pn2_training('cuda', B=4, npts=512)
+@pytest.mark.parametrize('variant', VARIANTS)
+def test_gpu_pn2_training_branch_matches_autograd(variant):
+    _check_pn2_training('cuda', B=4, npts=512, variant=variant)
 
 
 @pytest.mark.gpu
