@@ -126,6 +126,7 @@ int ach_set_option(ach_handle* h, const char* key, int32_t value) {
         else if (std::string(key) == "mlp_band") h->eng->mlp_band = value;
         else if (std::string(key) == "mlp_band_run") h->eng->mlp_band_run = value != 0;
         else if (std::string(key) == "mlp_band_dbg") h->eng->mlp_band_dbg = value;
+        else if (std::string(key) == "mlp_band_lean") h->eng->mlp_band_lean = value;
         else if (std::string(key) == "head_band") h->eng->head_band = value > 0 ? value : 40;
         else if (std::string(key) == "head_grid") h->eng->head_grid = value;
         else if (std::string(key) == "head_debug") h->eng->head_debug = value;

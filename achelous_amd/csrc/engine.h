@@ -119,6 +119,7 @@ public:
     bool attn_mfma = true;            // option "attn_mfma": MobileViT attention scores / P.V on MFMA (k_mvit.h) instead of one query per thread
     bool fuse_mv2 = true;             // option "fused_mv2": MobileViT's MV2 blocks (1x1 -> dw3x3 -> 1x1) as one launch (k_mv2.h)
     bool mlp_band_run = false;        // option "mlp_band_run" (default 0: measured level — 41.7 k against 41.9 k frames/s on EN-S0, plain loop of EN-S2 +3 %): consecutive band-kernel ConvEncoder blocks of a stage as ONE persistent launch with per-frame barriers between the blocks (k_mlpband.h mlp_band_run_kernel); bit-identical
+    int mlp_band_lean = 0;            // option "mlp_band_lean" (experiment, round 6): the d = 96 band kernel with a 16-bit halo tile and no weight-prefetch register set (98 KB of LDS instead of 153)
     int mlp_band_dbg = 0;             // option "mlp_band_dbg": phase-kill timing experiments on the band kernel (results are wrong)
     int mlp_band = 1;                 // option "mlp_band" (2: also the large maps of stages 0 / 1): bf16 — ConvEncoder blocks on the small maps as the band kernel (k_mlpband.h: LDS halo tile, weights once per band); 0 = mlp_kernel's SPLIT mode
     bool fuse_mlp = true;             // option "fused_mlp": EdgeNeXt blocks as one kernel (k_mlp.h) instead of dw / pw1 / pw2 launches

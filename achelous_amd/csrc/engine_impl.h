@@ -529,7 +529,9 @@ public:
             bp.m = mp; bp.rb = mlp_band_rows(k1, DT, dw_ks, xin.H, xin.W);
             if (band_rows_s3 > 0 && mlp_band_shape(k1, DT, dw_ks, xin.W) == 2) bp.rb = std::min(std::min(band_rows_s3, 5), xin.H);     // (the 10 x 10 maps: 5-row bands are 128 workgroups at batch 64)
             bp.bands = cdiv(xin.H, bp.rb); bp.dbg = mlp_band_dbg;
-            const int nb = xin.B, shape = mlp_band_shape(k1, DT, dw_ks, xin.W);
+            int shape = mlp_band_shape(k1, DT, dw_ks, xin.W);
+            if (shape == 1 && mlp_band_lean) shape = 11;
+            const int nb = xin.B;
             if (!measuring) band_ops.push_back(BandOp{ops.size(), bp, nb, shape});          // (merge_band_runs: consecutive blocks of a stage as one launch)
             add_op(name, [bp, nb, shape](hipStream_t s) { launch_mlp_band<T>(bp, shape, nb, s); }, bytes, flops);
             return true;

@@ -30,7 +30,7 @@ struct MlpBandParams {
 };
 
 constexpr int MLPB_SP = 5;       // strip of output pixels per thread in the depthwise phase
-constexpr int mlpb_ntb(int DT) { return DT <= 6 ? 3 : 1; }      // tiles per reduction round (the wide blocks' partial sums are 10-12 KB per tile and wave)
+constexpr int mlpb_ntb(int DT, bool XF32 = true) { return (DT <= 6 && XF32) ? 3 : 1; }      // tiles per reduction round (the wide blocks' partial sums are 10-12 KB per tile and wave)
 constexpr int MLPB_THREADS = 512; // 8 waves: 2 per SIMD (the 150 KB of LDS allow one workgroup per CU)
 
 // XF32: the halo tile is staged as fp32 (taps need no unpacking; 110 KB for d = 96 at 20x20) — or as bf16 (half the LDS: the wider
@@ -44,7 +44,7 @@ struct MlpBandGeom {
     static constexpr int DWV_FLOATS = NT * 16 * CP;
     static constexpr int XS_BYTES = NT * K1 * 64 * 16;
     static constexpr int RED_OFF_FLOATS = (XS_BYTES + 1023) / 1024 * 256;           // red starts behind xs, both alias xin
-    static constexpr int RED_FLOATS = 4 * mlpb_ntb(DT) * DT * 4 * 64;
+    static constexpr int RED_FLOATS = 4 * mlpb_ntb(DT, XF32) * DT * 4 * 64;
     static_assert(RED_OFF_FLOATS + RED_FLOATS <= XIN_FLOATS, "reduction buffer must fit the dead halo tile");
     static_assert((XIN_FLOATS + DWV_FLOATS) * 4 <= 160 * 1024, "LDS budget");
 };
@@ -57,7 +57,7 @@ struct MlpBandGeom {
 template <class T, int K1, int DT, int KS, int RB, int MAXW, bool XF32, bool PREF, bool TILEPAR, bool COH = false>
 __device__ __forceinline__ void mlp_band_body(const MlpBandParams& bp, const int band, const int b, float* xin, float* dwv) {
     using G = MlpBandGeom<K1, DT, KS, RB, MAXW, XF32>;
-    constexpr int CP = G::CP, NT = G::NT, SP = MLPB_SP, NTB = mlpb_ntb(DT);
+    constexpr int CP = G::CP, NT = G::NT, SP = MLPB_SP, NTB = mlpb_ntb(DT, XF32);
     const MlpParams& p = bp.m;
     uint4* xs = reinterpret_cast<uint4*>(xin);                    // (phases 2-3; the halo tile is dead by then)
     float* red = xin + G::RED_OFF_FLOATS;                         // (phase 4)
@@ -413,6 +413,7 @@ template <class T>
 inline void launch_mlp_band(const MlpBandParams& bp, int shape, int B, hipStream_t stream) {
     const dim3 grid(unsigned(bp.bands) * unsigned(B)), block(MLPB_THREADS);
     if (shape == 1) ACH_LAUNCH((mlp_band_kernel<T, 3, 6, 7, 5, 20, true, true>), grid, block, stream, bp);
+    else if (shape == 11) ACH_LAUNCH((mlp_band_kernel<T, 3, 6, 7, 5, 20, false, false>), grid, block, stream, bp);      // option mlp_band_lean: 16-bit halo tile, no weight prefetch set
     else if (shape == 2) ACH_LAUNCH((mlp_band_kernel<T, 6, 12, 9, 5, 10, false, false>), grid, block, stream, bp);
     else if (shape == 3) ACH_LAUNCH((mlp_band_kernel<T, 5, 10, 7, 4, 20, false, false>), grid, block, stream, bp);
     else if (shape == 4) ACH_LAUNCH((mlp_band_kernel<T, 2, 4, 5, 4, 40, true, false, true>), grid, block, stream, bp);

@@ -35,6 +35,9 @@ MOBILEVIT = {  # backbone/vision/mobilevit_modules/mobilevit.py:225-240: channel
 }
 
 
+_POS_TABLES = {}        # (H, W, device, hidden, temperature) -> the Fourier position table [1, 64, H, W]
+
+
 class TrainGraph:
     def __init__(self, model):
         self.m = model
@@ -127,6 +130,9 @@ class TrainGraph:
     # ---------------------------------------------------------------------------------------------- EdgeNeXt
     def pos_fourier(self, pfx, H, W, device, hidden=32, temperature=10000.0):
         """PositionalEncodingFourier (edgenext_modules/layers.py:38-59): an input-independent table, then its 1x1 projection (trainable)."""
+        key = (H, W, str(device), hidden, temperature)
+        if key in _POS_TABLES:                                                   # the table depends on (H, W) only: built and uploaded once (it used to be a host -> device copy per
+            return self.conv(_POS_TABLES[key], pfx + '.token_projection')       # step — which also made the step impossible to capture in a graph)
         y = torch.arange(1, H + 1, dtype=torch.float32).view(H, 1).expand(H, W) / (float(H) + 1e-6) * (2 * math.pi)
         x = torch.arange(1, W + 1, dtype=torch.float32).view(1, W).expand(H, W) / (float(W) + 1e-6) * (2 * math.pi)
         dim_t = torch.arange(hidden, dtype=torch.float32)
@@ -135,6 +141,7 @@ class TrainGraph:
         px = torch.stack((px[:, :, 0::2].sin(), px[:, :, 1::2].cos()), dim=3).flatten(2)
         py = torch.stack((py[:, :, 0::2].sin(), py[:, :, 1::2].cos()), dim=3).flatten(2)
         pos = torch.cat((py, px), dim=2).permute(2, 0, 1).unsqueeze(0).contiguous().to(device)      # [1, 64, H, W]
+        _POS_TABLES[key] = pos
         return self.conv(pos, pfx + '.token_projection')
 
     def mlp_tail(self, x, pfx):
@@ -447,3 +454,86 @@ class TrainGraph:
             with torch.no_grad():
                 torch._foreach_add_(self._nbt, 1)
             self._nbt = []
+
+
+class GraphedTrainStep:
+    """One whole training step — `model(x, radar, points)` in `.train()`, `loss_fn`, `loss.backward()`, `optimizer.step()` — captured ONCE into a HIP graph and replayed
+    (round 6).  A step of this network is ~1 300 small launches issued from Python through ctypes; below batch ~16 the host cannot issue them as fast as the
+    GPU retires them (batch 8: 31 ms eager, of which the GPU needs 22).  A replayed graph has no host side: batch 8 21.8 ms (-30 %), batch 16 30.2 ms (-3 %), batch 32 unchanged
+    (47 ms: GPU-bound).  The reference's own loop (utils/utils_fit.py:37-166) is eager and keeps working unchanged; this is the opt-in for small-batch fine-tuning:
+
+        step = GraphedTrainStep(net, opt, loss_fn, (images, radar, points), (targets...))     # captures; the model / optimizer state is left exactly as it was
+        for images, radar, points, *targets in loader:
+            loss = step(images, radar, points, *targets)                                      # copies into the captured buffers, replays; `loss` is a device tensor
+
+    Requirements (those of any whole-step capture): fixed shapes and dtypes (the example tensors'), a `loss_fn(outputs, *targets) -> scalar tensor` made of torch ops without host
+    synchronisation (no `.item()`, no data-dependent Python control flow), an optimizer whose step is capture-safe (SGD; Adam / AdamW with `capturable=True`), and no change of
+    `requires_grad` flags or parameter identity afterwards.  `outputs` = `(det_list, se, lane, pc)` as `forward` returns them; `step.outputs` holds the last replay's.
+    The warm-up steps that precede the capture run on the example batch and are UNDONE: parameters, BatchNorm statistics and optimizer state are restored in place.
+    If the model has already run EAGER training steps, drop every reference to their outputs / losses first: a live autograd graph keeps the parameters' AccumulateGrad nodes
+    bound to the eager steps' stream, and replaying them inside a capture is not legal (measured: hipStreamEndCapture crashes)."""
+
+    def __init__(self, model, optimizer, loss_fn, example_inputs, example_targets=(), warmup=3):
+        if not model.training:
+            raise RuntimeError("GraphedTrainStep captures a TRAINING step: call model.train() first")
+        self.model, self.optimizer, self.loss_fn = model, optimizer, loss_fn
+        self.inputs = tuple(t.detach().clone() if t is not None else None for t in example_inputs)
+        self.targets = tuple(t.detach().clone() for t in example_targets)
+        dev = self.inputs[0].device
+        if dev.type != 'cuda':
+            raise RuntimeError("GraphedTrainStep needs GPU tensors")
+        import gc
+        gc.collect()                                                          # (unreferenced autograd graphs of earlier eager steps release their AccumulateGrad nodes)
+        saved_model = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        had_state = len(optimizer.state) > 0
+        saved_opt = {id(p): {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in st.items()} for p, st in optimizer.state.items()} if had_state else None
+
+        def run():
+            outs = model(*self.inputs)
+            loss = loss_fn(outs, *self.targets)
+            loss.backward()
+            optimizer.step()
+            return outs, loss
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(max(1, int(warmup))):                              # allocator pools, workspaces, lazily built optimizer state: everything a capture may not create
+                optimizer.zero_grad(set_to_none=True)
+                run()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        optimizer.zero_grad(set_to_none=True)
+        with torch.cuda.graph(self.graph):
+            self.outputs, self.loss = run()
+        torch.cuda.synchronize(dev)
+        # undo the warm-up steps (a capture itself executes nothing): parameters and buffers back in place; optimizer state back to what it was — or, if it had none, to zeros,
+        # which is what the first real step of a fresh optimizer computes from (SGD: buf = grad; Adam: moments and step count from zero)
+        with torch.no_grad():
+            for k, v in model.state_dict().items():
+                v.copy_(saved_model[k])
+            for p, st in optimizer.state.items():
+                for k, v in st.items():
+                    if torch.is_tensor(v):
+                        if had_state and id(p) in saved_opt and k in saved_opt[id(p)]:
+                            v.copy_(saved_opt[id(p)][k])
+                        else:
+                            v.zero_()
+        self.steps = 0
+
+    @torch.no_grad()
+    def _load(self, inputs, targets):
+        if len(inputs) != len(self.inputs) or len(targets) != len(self.targets):
+            raise ValueError("GraphedTrainStep: the number of inputs / targets differs from the captured step's")
+        for dst, src in zip(self.inputs + self.targets, tuple(inputs) + tuple(targets)):
+            if dst is None:
+                continue
+            if src.shape != dst.shape or src.dtype != dst.dtype:
+                raise ValueError(f"GraphedTrainStep: captured {tuple(dst.shape)} {dst.dtype}, got {tuple(src.shape)} {src.dtype} (a graph has fixed shapes: build another step)")
+            dst.copy_(src, non_blocking=True)
+
+    def __call__(self, x, x_radar, x_points, *targets):
+        self._load((x, x_radar, x_points), targets)
+        self.graph.replay()
+        self.steps += 1
+        return self.loss.detach()

@@ -16,6 +16,7 @@ ap.add_argument('--steps', type=int, default=5)
 ap.add_argument('--resolution', type=int, default=320)
 ap.add_argument('--baseline', action='store_true', help='also time the SAME step as a torch-op composite on this GPU: the oracle (our restatement of the reference, oracle/achelous_oracle.py) with BatchNorm on batch statistics, fp32, torch autograd + torch SGD')
 ap.add_argument('--device', default='cuda')
+ap.add_argument('--graph', action='store_true', help='also time the step captured into a HIP graph (achelous_amd.train_graph.GraphedTrainStep)')
 a = ap.parse_args()
 kw = dict(num_det=7, num_seg=9, phi='S0', resolution=a.resolution, backbone='en', neck='gdf', pc_seg='pn', pc_channels=5, pc_classes=8, nano_head=True, spp=True)
 m = Achelous(**kw)
@@ -51,6 +52,21 @@ native = {'what': 'training step EN-GDF-PN-S0 fp32, native forward/backward kern
                   'ms_steps': [round(1e3 * t, 1) for t in times],          # step 0 = first call (allocations, plan); ms_per_step = the MEDIAN of the others (a step that hits an allocator stall is an outlier of 2x)
                   'loss': [round(v, 5) for v in losses], 'peak_mem_GB': round(torch.cuda.max_memory_allocated() / 2**30, 2) if a.device != 'cpu' else None}
 print(json.dumps(native))
+if a.graph:
+    from achelous_amd.train_graph import GraphedTrainStep
+
+    def loss_fn(outs, *tg):
+        det, se, lane, pc = outs
+        return sum(((o - t) ** 2).mean() for o, t in zip([*det, se, lane, pc], tg))
+    del det, se, lane, pc, outs, loss          # (no live autograd graph of the eager steps: their AccumulateGrad nodes are bound to the eager steps' stream)
+    gs = GraphedTrainStep(m, opt, loss_fn, (x, xr, xp), tuple(targets))
+    tt = []
+    for step in range(a.steps + 2):
+        sync(); t0 = time.time()
+        l = gs(x, xr, xp, *targets)
+        sync(); tt.append(time.time() - t0)
+    print(json.dumps({'what': 'the same step captured once into a HIP graph and replayed (GraphedTrainStep)', 'batch': a.batch, 'ms_per_step': round(1e3 * sorted(tt[2:])[(len(tt) - 3) // 2], 2),
+                      'ms_steps': [round(1e3 * t, 1) for t in tt], 'loss': round(float(l), 5)}))
 
 
 if a.baseline:

@@ -303,3 +303,51 @@ def test_gpu_bf16_operand_training_step_is_no_worse_than_torch_autocast():
     assert len(go) > 450
     assert np.median(go) <= np.median(gy) and np.percentile(go, 90) <= np.percentile(gy, 90), (np.median(go), np.median(gy))
     assert (go <= 2.0 * gy + 5e-2).mean() >= 0.97, float((go <= 2.0 * gy + 5e-2).mean())                   # tensor by tensor (both are noisy: 97 % of the tensors)
+
+
+@pytest.mark.gpu
+def test_gpu_graphed_training_step_equals_the_eager_step():
+    """`train_graph.GraphedTrainStep` (round 6): forward + loss + backward + SGD step captured once into a HIP graph and replayed.  Three replayed steps on three different batches
+    against three eager steps of a twin model from the same state: the losses and every parameter / BatchNorm statistic agree to the run-to-run noise of the eager step itself
+    (the deformable conv's input gradient is summed with atomics), and building the step leaves the model and the optimizer exactly as they were."""
+    from achelous_amd.train_graph import GraphedTrainStep
+    kw = dict(num_det=7, num_seg=9, phi='S0', resolution=96, backbone='en', neck='gdf', pc_seg='pn', pc_channels=5, pc_classes=8, nano_head=True, spp=True)
+    sd = condition_state_dict(Achelous(**kw).state_dict(), seed=0)
+    batches = [tuple(t.cuda() for t in make_inputs(2, 30 + i, resolution=96, num_points=64, pc_channels=5, radar_cells=12)) for i in range(3)]
+
+    def make():
+        m = Achelous(**kw)
+        m.load_state_dict(sd, strict=True)
+        m = m.cuda().train()
+        return m, torch.optim.SGD(m.parameters(), lr=1e-3, momentum=0.9)
+
+    def loss_fn(outs, tgt):
+        det, se, lane, pc = outs
+        return sum((o ** 2).mean() for o in (*det, se, lane)) + ((pc - tgt) ** 2).mean()
+    tgt = [torch.randn(2, 64, 8, generator=torch.Generator().manual_seed(9 + i)).cuda() for i in range(3)]
+    m1, o1 = make()
+    eager = []
+    for (x, xr, xp), t in zip(batches, tgt):
+        o1.zero_grad(set_to_none=True)
+        loss = loss_fn(m1(x, xr, xp), t)
+        loss.backward()
+        o1.step()
+        eager.append(float(loss.detach()))
+    m2, o2 = make()
+    before = {k: v.clone() for k, v in m2.state_dict().items()}
+    step = GraphedTrainStep(m2, o2, loss_fn, batches[0], (tgt[0],))
+    for k, v in m2.state_dict().items():
+        assert torch.equal(v, before[k]), k                               # the warm-up steps were undone
+    graphed = [float(step(*b, t)) for b, t in zip(batches, tgt)]
+    torch.cuda.synchronize()
+    for a, b in zip(eager, graphed):
+        assert abs(a - b) <= 1e-4 * abs(a) + 1e-7, (eager, graphed)
+    s1, s2 = m1.state_dict(), m2.state_dict()
+    for k in s1:
+        if s1[k].is_floating_point():
+            d = float((s1[k].double() - s2[k].double()).abs().max())
+            assert d <= 1e-4 * float(s1[k].double().abs().max()) + 1e-6, (k, d)
+        else:
+            assert torch.equal(s1[k], s2[k]), k                           # num_batches_tracked: three steps each
+    with pytest.raises(ValueError):
+        step(batches[0][0][:1], batches[0][1][:1], batches[0][2][:1], tgt[0][:1])
