@@ -1791,7 +1791,10 @@ public:
                 float mx = 0.f;
                 bool finite = true;
                 for (float v : ob.data) { finite = finite && std::isfinite(v); mx = std::max(mx, std::fabs(v)); }
-                if (finite && mx <= 13.f) { occ_r = 2 + int(std::ceil(mx)); occ = static_cast<unsigned short*>(aalloc(size_t(B) * x.H * (x.W / 16) * sizeof(unsigned short))); }
+                // reach of a pixel whose 3x3 window of P is zero (offsets = the bias b exactly): tap row ty samples at oy + (ty - 1) + b, |b| <= mx, so the bilinear corners lie in
+                // [oy - 1 - ceil(mx), oy + 2 + floor(mx)]: 2 + floor(mx) rows / columns (round 6; it was 2 + ceil(mx), one more than needed for every non-integer mx — 7 x 7 instead of
+                // 5 x 5 pixels of full path around each occupied cell of the bench's maps).  At an integer mx the outermost corner has weight exactly 0 on a finite value.
+                if (finite && mx <= 13.f) { occ_r = 2 + int(std::floor(mx)); occ = static_cast<unsigned short*>(aalloc(size_t(B) * x.H * (x.W / 16) * sizeof(unsigned short))); }
             }
             if (i == 0 && direct0) {
                 if constexpr (H16E) {
