@@ -1799,6 +1799,7 @@ public:
             if (i == 0 && direct0) {
                 if constexpr (H16E) {
                 PoolNchwParams pp{nullptr, pooled.p0, pooled.ld, B, x.H, x.W, pooled.row, pooled.img, occ};
+                pp.sparse = (radar_pool_sparse && occ) ? 1 : 0;
                 const dim3 grid(unsigned(cdivl(long(B) * (x.H / POOLN_ROWS) * (x.W / 4), 256))), block(256);
                 const void** rin = &io.radar;
                 const bool alt = io_alt();

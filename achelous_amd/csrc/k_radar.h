@@ -119,7 +119,10 @@ __global__ __launch_bounds__(256) void avgpool3x3_kernel(const PoolParams p) { f
 // are gone.  One thread = a strip of 4 output pixels x the 3 channels; per (plane, row) one aligned 8-byte load (x0 .. x0+3: x0 % 4 == 0, Wd % 16 == 0) and the two
 // neighbours as 2-byte loads.  Same sums in the same order as avgpool3x3_kernel<T, 4> on the 4-channel copy (values pass through the storage type first, as the copy did):
 // bit-identical pooled map and occupancy masks.
-struct PoolNchwParams { const void* X; void* Y; long ldy; int B, H, Wd; long ypr, ypi; unsigned short* occ; };
+// sparse (round 6; needs occ): a pixel is STORED only if its pooled value is non-zero or the buffer still holds a non-zero value there from the previous forward — the occupancy word the
+// kernel is about to overwrite says which pixels those are (arena and masks are zero when the plan is built, and nothing else writes either).  The bench's maps are > 99 % zeros: the
+// launch writes ~3 MB instead of 52 MB; the pooled map in memory is bit for bit what the unconditional stores leave.
+struct PoolNchwParams { const void* X; void* Y; long ldy; int B, H, Wd; long ypr, ypi; unsigned short* occ; int sparse = 0; };
 constexpr int POOLN_ROWS = 4;            // output rows per thread: 6 input rows are fetched and converted for 4 output rows instead of 12 (one row per thread: 50.7 us at batch 64)
 template <class T, class IO>
 __global__ __launch_bounds__(256) void avgpool3x3_nchw3_kernel(const PoolNchwParams p) { f16_sat_mode<T>();
@@ -153,6 +156,10 @@ __global__ __launch_bounds__(256) void avgpool3x3_nchw3_kernel(const PoolNchwPar
             for (int j = 0; j < 6; ++j) o[c][j] = rowin ? v[j] : 0.f;
         }
     };
+    const bool sparse = p.sparse && p.occ;
+    int old4[POOLN_ROWS];                                                  // bit o: pixel x0 + o of row y0 + k held a non-zero value after the previous forward
+    ACH_UNROLL
+    for (int k = 0; k < POOLN_ROWS; ++k) old4[k] = sparse ? (int(p.occ[(b * p.H + y0 + k) * long(p.Wd >> 4) + (x0 >> 4)]) >> (x0 & 15)) & 15 : 15;
     fetch(y0 - 1, rows[0]);
     fetch(y0, rows[1]);
     int nzr[POOLN_ROWS];
@@ -171,7 +178,7 @@ __global__ __launch_bounds__(256) void avgpool3x3_nchw3_kernel(const PoolNchwPar
             ACH_UNROLL
             for (int i = 0; i < 3; ++i) { acc[i] = ((col[o][i] + col[o + 1][i]) + col[o + 2][i]) * (1.0f / 9.0f); nz |= !(acc[i] == 0.f) ? 1 << o : 0; }
             acc[3] = 0.f;
-            if (live) Store<T>::st4(yrow + long(x0 + o) * p.ldy, acc);
+            if (live && (((nz | old4[k]) >> o) & 1)) Store<T>::st4(yrow + long(x0 + o) * p.ldy, acc);
         }
         nzr[k] = nz;
     }

@@ -872,3 +872,35 @@ def test_emulated_xca_launch_forms_agree(name, res, dtype, tol):
         for a, b in zip(outs[key][:5], outs['four'][:5]):
             assert rel_err(a, b) < tol, (key, rel_err(a, b))
         assert torch.equal(outs[key][5], outs['four'][5])
+
+
+@pytest.mark.parametrize('sdt', H16)
+def test_emulated_sparse_pool_stores_leave_the_same_map(sdt):
+    """Round 6 (k_radar.h, option radar_pool_sparse): the first RCBlock's pool stores a pixel only where the pooled map is non-zero now or was after the PREVIOUS forward (the
+    occupancy word it is about to overwrite).  Five consecutive forwards of ONE engine on different maps — sparse, other sparse cells, empty, dense, sparse again: every stale
+    value must be cleared, nothing else touched — against an engine that stores every pixel: outputs and radar taps bit for bit."""
+    from achelous_amd.engine import NativeEngine
+    dtype, td, _ = sdt
+    kw, sd, _ = _setup('en_s0', 96, 2, 16)
+    frames = []
+    for i, (cells, dense) in enumerate([(6, False), (9, False), (0, False), (1, True), (4, False)]):
+        x, xr, xp = make_inputs(2, 50 + i, resolution=96, num_points=16, pc_channels=kw['pc_channels'], radar_cells=max(cells, 1), dense_radar=dense)
+        if cells == 0:
+            xr = torch.zeros_like(xr)
+        frames.append((x.to(td), xr.to(td), xp.to(td)))
+    res = {}
+    for sparse in (1, 0):
+        eng = NativeEngine(emu_library(), num_det=kw['num_det'], num_seg=kw['num_seg'], phi=kw['phi'], backbone=kw['backbone'], resolution=kw['resolution'],
+                           pc_channels=kw['pc_channels'], pc_classes=kw['pc_classes'], num_points=16, nano_head=kw['nano_head'], spp=kw['spp'], dtype=dtype)
+        eng.set_option('radar_pool_sparse', sparse)
+        eng.set_option('full_taps', 1)
+        eng.load_state_dict(sd)
+        eng.plan(2)
+        res[sparse] = []
+        for f in frames:
+            o = alloc_outputs(kw, 2, 16, td, 'cpu')
+            eng.forward(*f, o)
+            res[sparse].append([t.clone() for t in o[:3]] + [eng.read_tap(t) for t in ('radar.b0', 'radar.b1', 'r3', 'r5')])
+    for a_list, b_list in zip(res[1], res[0]):
+        for a, b in zip(a_list, b_list):
+            assert torch.equal(a, b)
