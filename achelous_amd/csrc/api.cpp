@@ -115,6 +115,7 @@ int ach_set_option(ach_handle* h, const char* key, int32_t value) {
         else if (std::string(key) == "gemm_rows") h->eng->gemm_rows = (value == 2 || value == 4) ? value : 1;
         else if (std::string(key) == "radar_rows4") h->eng->radar_rows4 = value;
         else if (std::string(key) == "radar_skip") h->eng->radar_skip = value != 0;
+        else if (std::string(key) == "radar_bg") h->eng->radar_bg = value != 0;
         else if (std::string(key) == "radar_pool_sparse") h->eng->radar_pool_sparse = value != 0;
         else if (std::string(key) == "radar_compact") h->eng->radar_compact = value != 0;
         else if (std::string(key) == "head_mfma") h->eng->head_mfma = value != 0;

@@ -103,6 +103,7 @@ public:
     int radar_rows4 = 2;              // option "radar_rows4": a workgroup of rc_front owns four rows, one per wave (1: block 0 when radar_skip is on; 2: every
                                       // fused block — 29.1 k against 27.7 k frames/s: the per-workgroup weight staging and tables were a fifth of these kernels)
     bool radar_compact = true;        // option "radar_compact": first RCBlock — the active PIXELS of a row are compacted into dense tiles (k_conv3.h; needs radar_skip and four-row workgroups)
+    bool radar_bg = true;             // option "radar_bg" (round 6): first RCBlock — its output map keeps the background value relu(bias) at every pixel that is not active, rc_front neither reads nor writes unoccupied pixels (k_conv3.h background mode; needs radar_skip, radar_compact, radar_direct)
     bool radar_pool_sparse = true;    // option "radar_pool_sparse" (round 6): first RCBlock's pool stores a pixel only where the pooled map is, or was after the previous forward, non-zero (k_radar.h; needs radar_skip's occupancy masks and radar_direct)
     bool radar_skip = true;           // option "radar_skip": first RCBlock — closed-form shortcut on 16-pixel segments whose neighbourhood of the radar map is empty (k_conv3.h)
     int gemm_blocks = 0;          // option "gemm_blocks": workgroups a GEMM launch aims for when the rows alone do not fill the chip (0 = 1024: four per CU)

@@ -24,6 +24,7 @@
 #include "k_pn2.h"
 #include "k_prepost.h"
 #include "k_radar.h"
+#include <functional>
 #include "k_sdta.h"
 #include "k_xca.h"
 #include "k_xcaframe.h"
@@ -139,6 +140,7 @@ public:
         for (int n = 0; n < l.N; ++n) { for (int k = 0; k < l.K; ++k) l.w[size_t(n) * l.K + k] *= g[n]; l.b[n] *= g[n]; }
     }
 
+    std::vector<std::function<void()>> post_plan;            // run once when the plan is built, after the arena has been zeroed
     struct Packed { T* w = nullptr; float* b = nullptr; int N = 0, K = 0, NT = 1, nchunks = 0, ksteps = 0; long group_elems = 0; };
     static int pick_nt(int N) { return N <= 16 ? 1 : (N <= 32 ? 2 : 4); }
     Packed pack_shape(int N, int K) const {
@@ -1862,6 +1864,17 @@ public:
                                  y_bordered ? yb.p0 : y.p, yld, y_bordered ? yb.row : long(x.W) * y.ld, y_bordered ? yb.img : long(x.H) * x.W * y.ld,
                                  B, x.H, x.W, cvp, C, occ, occ_r, radar_compact ? 1 : 0, (((occ && radar_rows4 == 1) || radar_rows4 == 2) && x.H % 4 == 0) ? 1 : 0, nullptr, 0};
                 const bool rdirect = i == 0 && direct0;
+                if constexpr (H16E) {
+                    // background mode (k_conv3.h, round 6): the conditions are the kernel's own for its compact path, plus the NCHW pool (its occupancy masks include non-zero raw inputs)
+                    if (radar_bg && rdirect && occ && y_bordered && narrow && rp.compact && rp.rows4 && yld <= 4 && x.W <= 512) {
+                        rp.prev = static_cast<unsigned short*>(aalloc(size_t(B) * x.H * (x.W / 16) * sizeof(unsigned short)));
+                        rp.bg = 1;
+                        uint32_t h[4];
+                        for (int c = 0; c < 4; ++c) { const float r = c < C ? lf.b[c] : 0.f; h[c] = H16<T>::bits(r > 0.f ? r : 0.f); }
+                        FillPx8Params fq{yb.p0, yb.row, yb.img, B, x.H, x.W, make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16))};
+                        if (!measuring) post_plan.push_back([fq]() { ACH_LAUNCH(fill_px8_kernel<T>, dim3(unsigned(cdivl(long(fq.B) * fq.H * fq.Wd, 256))), dim3(256), hipStream_t(nullptr), fq); });
+                    }
+                }
                 const void** rres = &io.radar;
                 const int rbf = io_alt() ? 1 : 0;
                 // algorithmic bytes: pooled map + residual read once, output written once, REAL channels; the layout figure
@@ -2391,8 +2404,10 @@ public:
         if (wneed > warena_cap) { if (warena) (void)hipFree(warena); warena = nullptr; ACH_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&warena), wneed)); warena_cap = wneed; }
         if (aneed > aarena_cap) { if (aarena) (void)hipFree(aarena); aarena = nullptr; ACH_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&aarena), aneed)); aarena_cap = aneed; }
         reset_plan();
+        post_plan.clear();
         build();
         ACH_HIP_CHECK(hipMemset(aarena, 0, aarena_used));      // channel padding lanes stay zero for the lifetime of the plan
+        for (auto& f : post_plan) f();                          // tensors that start from something other than zero (the first RCBlock's background, radar_bg)
         ACH_HIP_CHECK(hipDeviceSynchronize());
     }
 

@@ -159,6 +159,10 @@ struct RcFrontParams {
     int compact;                              // 1 (with occ, rows4, <= 4 output channels): the row's ACTIVE PIXELS are compacted into dense 16-pixel tiles (round 3)
     int rows4;                                // 1: a workgroup owns FOUR consecutive rows, one per wave (H % 4 == 0): the weight staging and the tables are paid once per four rows
     const void* Rn; int rn_bf16;              // round 4 (NARROW): the residual read straight from the caller's NCHW map [B, 3, H, Wd] (16-bit; rn_bf16: bf16 values behind fp16 storage) instead of R
+    // round 6, BACKGROUND mode (compact mode only): the output map holds relu(bias) — what an unoccupied pixel with a zero input evaluates to — at every pixel that was not active
+    // after the previous forward (written once when the plan is built), `prev` [B][H][Wd/16] holds those activity masks.  An inactive pixel is then neither read nor written:
+    // the kernel only restores the background where a pixel was active last time and is not now.  Needs occupancy masks that include non-zero raw inputs (avgpool3x3_nchw3_kernel).
+    unsigned short* prev; int bg;
 };
 
 // Empty segments (first RCBlock only: its input is the raw radar map, > 99 % zeros — radar_feature_map_generate.ipynb).  If P is
@@ -303,6 +307,18 @@ __global__ __launch_bounds__(256, KS == 3 ? 4 : ACH_RCF_WIDE_WAVES) void rc_fron
         int base = 0;
         for (int l = 0; l < ntiles; ++l) { const int c = __shfl(cnt, l); if (l < lane) base += c; ntot += c; }
         if (lane < 32) amask[wave][lane] = static_cast<unsigned short>(act16);
+        if (p.bg && lane < ntiles) {
+            unsigned short* pw = p.prev + (long(b) * p.H + oy) * ntiles + lane;
+            unsigned stale = unsigned(*pw) & ~act16;                         // active after the previous forward, background now
+            *pw = static_cast<unsigned short>(act16);
+            for (; stale; stale &= stale - 1u) {
+                const int xx = lane * 16 + (__ffsll(static_cast<long long>(stale)) - 1);
+                float ov[4];
+                ACH_UNROLL
+                for (int i = 0; i < 4; ++i) { const float r = 0.f + p.bf[i]; ov[i] = (r > 0.f ? r : 0.f) + 0.f; }
+                Store<T>::st4(static_cast<T*>(p.Y) + long(b) * p.ypi + long(oy) * p.ypr + long(xx) * p.ldy, ov);
+            }
+        }
         for (unsigned m = act16; m; m &= m - 1u) plist[wave][base++] = static_cast<unsigned short>(lane * 16 + (__ffsll(static_cast<long long>(m)) - 1));
         wave_sync();
         }
@@ -335,7 +351,7 @@ __global__ __launch_bounds__(256, KS == 3 ? 4 : ACH_RCF_WIDE_WAVES) void rc_fron
             Store<T>::st4(static_cast<T*>(p.Y) + long(b) * p.ypi + long(oy) * p.ypr + long(x) * p.ldy + ch, ov);
         }
     };
-    if (compact) {
+    if (compact && !p.bg) {
         if constexpr (NARROW) {
         // empty pixels: relu(bias) + residual, one pixel per lane and pass (all four output channels are lane group 0's: ldy <= 4)
         float b0[4];

@@ -177,6 +177,10 @@ __global__ __launch_bounds__(256) void avgpool3x3_nchw3_kernel(const PoolNchwPar
             float acc[4];
             ACH_UNROLL
             for (int i = 0; i < 3; ++i) { acc[i] = ((col[o][i] + col[o + 1][i]) + col[o + 2][i]) * (1.0f / 9.0f); nz |= !(acc[i] == 0.f) ? 1 << o : 0; }
+            // a non-zero RAW value under a pooled zero (sums that cancel exactly) counts as occupied too: rc_front's background mode (k_conv3.h, round 6) relies on
+            // "unoccupied => the block's input is zero there"; a superset of the occupied pixels is always exact (the full path is)
+            ACH_UNROLL
+            for (int i = 0; i < 3; ++i) nz |= !(mid[i][o + 1] == 0.f) ? 1 << o : 0;
             acc[3] = 0.f;
             if (live && (((nz | old4[k]) >> o) & 1)) Store<T>::st4(yrow + long(x0 + o) * p.ldy, acc);
         }
@@ -191,6 +195,17 @@ __global__ __launch_bounds__(256) void avgpool3x3_nchw3_kernel(const PoolNchwPar
             if (live && (threadIdx.x & 3) == 0) p.occ[(b * p.H + y0 + k) * long(p.Wd >> 4) + (x0 >> 4)] = static_cast<unsigned short>(m & 0xffff);
         }
     }
+}
+
+// every interior pixel of a bordered map of 8-byte pixels <- one value (plan time: the background of the first RCBlock's output, k_conv3.h)
+struct FillPx8Params { void* Y; long ypr, ypi; int B, H, Wd; uint2 v; };
+template <class T>
+__global__ __launch_bounds__(256) void fill_px8_kernel(const FillPx8Params p) {
+    const long i = long(blockIdx.x) * blockDim.x + threadIdx.x, total = long(p.B) * p.H * p.Wd;
+    if (i >= total) return;
+    const int x = int(i % p.Wd), y = int((i / p.Wd) % p.H);
+    const long b = i / (long(p.Wd) * p.H);
+    *reinterpret_cast<uint2*>(static_cast<char*>(p.Y) + (b * p.ypi + long(y) * p.ypr) * 2 + long(x) * 8) = p.v;
 }
 
 // ---- shared by both deformable kernels: one tap's bilinear footprint (torchvision 0.12.0 deform_conv2d semantics:

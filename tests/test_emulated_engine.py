@@ -877,7 +877,8 @@ def test_emulated_xca_launch_forms_agree(name, res, dtype, tol):
 @pytest.mark.parametrize('sdt', H16)
 def test_emulated_sparse_pool_stores_leave_the_same_map(sdt):
     """Round 6 (k_radar.h, option radar_pool_sparse): the first RCBlock's pool stores a pixel only where the pooled map is non-zero now or was after the PREVIOUS forward (the
-    occupancy word it is about to overwrite).  Five consecutive forwards of ONE engine on different maps — sparse, other sparse cells, empty, dense, sparse again: every stale
+    occupancy word it is about to overwrite); rc_front's BACKGROUND mode (k_conv3.h, option radar_bg) neither reads nor writes an unoccupied pixel: the output map holds
+    relu(bias) there since the plan was built, and only pixels that were active after the previous forward and are not now are restored.  Five consecutive forwards of ONE engine on different maps — sparse, other sparse cells, empty, dense, sparse again: every stale
     value must be cleared, nothing else touched — against an engine that stores every pixel: outputs and radar taps bit for bit."""
     from achelous_amd.engine import NativeEngine
     dtype, td, _ = sdt
@@ -889,10 +890,11 @@ def test_emulated_sparse_pool_stores_leave_the_same_map(sdt):
             xr = torch.zeros_like(xr)
         frames.append((x.to(td), xr.to(td), xp.to(td)))
     res = {}
-    for sparse in (1, 0):
+    for sparse in (1, 0, 2, 3):                                # 1: both sparse forms (the default plan), 0: neither, 2: only the pool's stores, 3: only rc_front's background mode
         eng = NativeEngine(emu_library(), num_det=kw['num_det'], num_seg=kw['num_seg'], phi=kw['phi'], backbone=kw['backbone'], resolution=kw['resolution'],
                            pc_channels=kw['pc_channels'], pc_classes=kw['pc_classes'], num_points=16, nano_head=kw['nano_head'], spp=kw['spp'], dtype=dtype)
-        eng.set_option('radar_pool_sparse', sparse)
+        eng.set_option('radar_pool_sparse', 1 if sparse in (1, 2) else 0)
+        eng.set_option('radar_bg', 1 if sparse in (1, 3) else 0)
         eng.set_option('full_taps', 1)
         eng.load_state_dict(sd)
         eng.plan(2)
@@ -901,6 +903,7 @@ def test_emulated_sparse_pool_stores_leave_the_same_map(sdt):
             o = alloc_outputs(kw, 2, 16, td, 'cpu')
             eng.forward(*f, o)
             res[sparse].append([t.clone() for t in o[:3]] + [eng.read_tap(t) for t in ('radar.b0', 'radar.b1', 'r3', 'r5')])
-    for a_list, b_list in zip(res[1], res[0]):
-        for a, b in zip(a_list, b_list):
-            assert torch.equal(a, b)
+    for other in (1, 2, 3):
+        for a_list, b_list in zip(res[other], res[0]):
+            for a, b in zip(a_list, b_list):
+                assert torch.equal(a, b), other
