@@ -1098,6 +1098,47 @@ def test_csp_fused_last_level_on_the_production_plan(storage):
             assert torch.equal(a, b)
 
 
+def test_first_rcblock_sparse_forms_are_bit_identical_over_consecutive_forwards():
+    """Round 6: the first RCBlock's pool stores only where the pooled map is or was non-zero, and rc_front leaves unoccupied pixels at the background value the plan wrote —
+    both carry state from one forward to the next.  ONE model, six consecutive batches of 16 frames — sparse maps, other cells, empty maps, dense maps, sparse again, the first batch
+    again — plain and pipelined, against a model with both options off: every output and the NMS records bit for bit."""
+    g = Golden('en_s0')
+    kw = ctor_kwargs(g.meta)
+    batches = []
+    for i, (cells, dense) in enumerate([(256, False), (40, False), (0, False), (1, True), (256, False)]):
+        x, xr, xp = make_inputs(16, 900 + i, resolution=kw['resolution'], pc_channels=kw['pc_channels'], radar_cells=max(cells, 1), dense_radar=dense)
+        if cells == 0:
+            xr = torch.zeros_like(xr)
+        batches.append(tuple(t.cuda().bfloat16() for t in (x, xr, xp)))
+    batches.append(batches[0])
+    res = {}
+    for key, opts in (('sparse', {}), ('dense', {'radar_pool_sparse': 0, 'radar_bg': 0})):
+        m, _ = _model(g)
+        m.engine_options = opts
+        outs = []
+        with torch.no_grad():
+            for b in batches:                                           # plain calls
+                (det, se, lane, pc), (rows, idx, cnt) = m.forward_detect(*b, 0.05, 0.5, 100)
+                outs.append([t.clone() for t in (*det, se, lane, pc, rows, idx, cnt)])
+            pend = None
+            for b in batches:                                           # the pipelined plan (another engine of the same module: its own buffers and masks)
+                nxt = m.submit_detect(*b, 0.05, 0.5, 100)
+                if pend is not None:
+                    (det, se, lane, pc), (rows, idx, cnt) = pend.wait()
+                    outs.append([t.clone() for t in (*det, se, lane, pc, rows, idx, cnt)])
+                pend = nxt
+            (det, se, lane, pc), (rows, idx, cnt) = pend.wait()
+            outs.append([t.clone() for t in (*det, se, lane, pc, rows, idx, cnt)])
+        torch.cuda.synchronize()
+        res[key] = outs
+    assert len(res['sparse']) == 12
+    for a_list, b_list in zip(res['sparse'], res['dense']):
+        for a, b in zip(a_list, b_list):
+            assert torch.equal(a, b)
+    for a, b in zip(res['sparse'][0], res['sparse'][5]):                 # the first batch again, after dense and empty maps: the same bits
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize('name', ['en_s0', 'en_s2'])
 def test_xca_launch_forms_against_the_reference_fixture(name):
     """Round 6 (k_xcaframe.h): the default plan folds softmax(attn) into the projection weights on the matrix cores (xca_fold_mfma = 1); the two-launch and one-launch
