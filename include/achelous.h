@@ -138,7 +138,13 @@ int ach_load_weights(ach_handle* h, const ach_tensor_desc* tensors, size_t n);
  * neck's p3 exists, 3: the whole neck on stream 2, ordered against the next forward's backbone by a third cross-forward event (EdgeNeXt plans; level with 1);
  * bit-identical), "group_max" (default 1024; 0 = never: PointNet++'s shared-MLP + max-over-the-ball layers with a wave per ball for layers of at least this many balls;
  * bit-identical), "group_wpc" (default 4096; 0 = never: PointNet++ grouping with a workgroup per centroid on levels with at most this many centroids; bit-identical), "point_stream2" = 3 (the point branch on a stream of its own — the process's fourth: measured -1 %, and it leaves no stream for a collective);
- * "pipeline" (see ach_join).  DESIGN.md §4 has the measurement behind every default. */
+ * round 6 (16-bit engines): "xca_fold_mfma" (default 1: the XCA finalize launch folds softmax(attn) into the projection weights on the matrix cores, one workgroup per (frame, head);
+ * 0: round 5's fp32 VALU fold), "xca_frame" (default 0: four launches per attention; 2: two launches — qkv + Gram partials per token slice, softmax + fold + projection per 64 tokens;
+ * 1: one launch with a workgroup per frame; both measured slower) with "xca_slice", "xca_front_waves", "xca_back_waves"; "radar_pool_sparse" (default 1: the first
+ * RCBlock's pool stores a pixel only where the pooled map is, or was after the previous forward, non-zero) and "radar_bg" (default 1: the block's output map keeps relu(bias) at every
+ * unoccupied pixel; rc_front neither reads nor writes such pixels) — both bit-identical, both carry masks from one forward to the next inside the plan's arena;
+ * "mlp_band_lean" (default 0: the d = 96 band kernel with a 16-bit halo tile, 98 KB of LDS: measured neutral);
+ * "pipeline" (see ach_join).  DESIGN.md §4 and profiles/NOTES_r0*.md have the measurement behind every default. */
 int ach_set_option(ach_handle* h, const char* key, int32_t value);
 
 /* Builds the launch plan and the activation arena for batch size B (re-plan to change B). */
